@@ -1,0 +1,287 @@
+// BatchNorm3d (training and eval), fused activation / residual kernels, HBM-bound.
+//
+// Reference semantics: nn.BatchNorm3d as instantiated by slowfast/models/batchnorm_helper.py:16-37
+// (eps 1e-5, momentum 0.1, per-GPU local statistics), the ResBlock tail
+// relu(shortcut + branch2) of slowfast/models/resnet_helper.py:512-521, and their autograd.
+// The conv kernels (sf_igemm.h) leave per-tile column sums; `finalize` turns them into a
+// per-channel scale/shift; consumers apply scale/shift(+ReLU) on the fly, or `bn_act` materialises.
+//
+// Thread map for an [M][C] fp16 tensor (C % 8 == 0): G = C/8 channel groups, TG = min(G,256) threads
+// across the channels of a row (16 B each, coalesced), 256/TG rows per pass; a thread keeps its
+// channel group for the whole kernel so per-channel constants and partial sums live in registers.
+#pragma once
+#include "sf_common.h"
+
+struct RowTile {
+    int M, C;
+    int rows_per_block;
+    __device__ __forceinline__ bool init(int& gcol, int& r0, int& r1, int& rstep) const {
+        const int G = C >> 3;
+        const int TG = G < SF_THREADS ? G : SF_THREADS;
+        const int rpi = SF_THREADS / TG;
+        const int tx = threadIdx.x % TG, ty = threadIdx.x / TG;
+        gcol = blockIdx.y * SF_THREADS + tx;
+        r0 = blockIdx.x * rows_per_block + ty;
+        r1 = (blockIdx.x + 1) * rows_per_block;
+        if (r1 > M) r1 = M;
+        rstep = rpi;
+        return ty < rpi && gcol < G;
+    }
+};
+
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = p[e];
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward statistics -> scale/shift
+struct BnFinalizeParams {
+    const float* part;   // [nblk][2][C] (sum, sumsq); nblk == 0 -> eval mode (running statistics)
+    int nblk;
+    int C;
+    float count;         // N*T*H*W
+    const float* gamma;
+    const float* beta;
+    float* running_mean; // updated in training mode when non-null
+    float* running_var;
+    float momentum;
+    float eps;
+    float* scale;        // out [C]
+    float* shift;        // out [C]
+    float* save_mean;    // out [C]
+    float* save_rstd;    // out [C]
+};
+
+__global__ __launch_bounds__(SF_THREADS) void sf_bn_finalize_kernel(BnFinalizeParams p) {
+    // 32 channels per block, 8 partial-row segments per channel
+    __shared__ double s_s[8][32];
+    __shared__ double s_q[8][32];
+    const int cx = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double s = 0.0, q = 0.0;
+    if (c < p.C) {
+        for (int b = seg; b < p.nblk; b += 8) {
+            s += (double)p.part[((int64_t)b * 2 + 0) * p.C + c];
+            q += (double)p.part[((int64_t)b * 2 + 1) * p.C + c];
+        }
+    }
+    s_s[seg][cx] = s;
+    s_q[seg][cx] = q;
+    __syncthreads();
+    if (seg == 0 && c < p.C) {
+        float mean, var;
+        if (p.nblk > 0) {
+            for (int k = 1; k < 8; ++k) { s += s_s[k][cx]; q += s_q[k][cx]; }
+            double m = s / (double)p.count;
+            double v = q / (double)p.count - m * m;
+            if (v < 0.0) v = 0.0;
+            mean = (float)m;
+            var = (float)v;
+            if (p.running_mean) {
+                double unb = p.count > 1.f ? v * (double)p.count / ((double)p.count - 1.0) : v;
+                p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+                p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
+            }
+        } else {
+            mean = p.running_mean[c];
+            var = p.running_var[c];
+        }
+        const float rstd = 1.0f / sqrtf(var + p.eps);
+        const float sc = p.gamma[c] * rstd;
+        p.scale[c] = sc;
+        p.shift[c] = p.beta[c] - mean * sc;
+        if (p.save_mean) p.save_mean[c] = mean;
+        if (p.save_rstd) p.save_rstd[c] = rstd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = act( y*scale + shift  [+ r*rscale + rshift | + r] )
+struct BnActParams {
+    RowTile rt;
+    const f16* y; int ldy;
+    const float* scale; const float* shift;     // scale == nullptr: identity
+    const f16* r; int ldr;                      // optional second operand
+    const float* rscale; const float* rshift;   // rscale == nullptr: plain add
+    int relu;
+    f16* out; int ldo;
+};
+
+__global__ __launch_bounds__(SF_THREADS) void sf_bn_act_kernel(BnActParams p) {
+    int gcol, r0, r1, rstep;
+    if (!p.rt.init(gcol, r0, r1, rstep)) return;
+    const int c = gcol * 8;
+    float sc[8], sh[8], rsc[8], rsh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; rsc[e] = 1.f; rsh[e] = 0.f; }
+    if (p.scale) { load8f(p.scale + c, sc); load8f(p.shift + c, sh); }
+    if (p.r && p.rscale) { load8f(p.rscale + c, rsc); load8f(p.rshift + c, rsh); }
+    for (int m = r0; m < r1; m += rstep) {
+        f16x8 v = ld16(p.y + (int64_t)m * p.ldy + c);
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (float)v[e] * sc[e] + sh[e];
+        if (p.r) {
+            f16x8 rv = ld16(p.r + (int64_t)m * p.ldr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += (float)rv[e] * rsc[e] + rsh[e];
+        }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = x[e];
+            if (p.relu) t = t > 0.f ? t : 0.f;
+            o[e] = (f16)t;
+        }
+        st16(p.out + (int64_t)m * p.ldo + c, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: per-channel sums of g and g*y, g = dz masked by the activation
+struct BnBwdReduceParams {
+    RowTile rt;
+    const f16* dz; int lddz;
+    const f16* zmask; int ldm;                  // optional: mask = zmask > 0 (block-output ReLU)
+    const f16* y; int ldy;
+    const float* scale; const float* shift;     // for relu_self: mask = y*scale+shift > 0
+    int relu_self;
+    float* part;                                // [gridDim.x][2][C]
+};
+
+__device__ __forceinline__ void masked_grad8(const f16x8& dz, const f16x8& yv, const f16* zmask_ptr, int relu_self,
+                                             const float (&sc)[8], const float (&sh)[8], float (&g)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = (float)dz[e];
+    if (zmask_ptr) {
+        f16x8 z = ld16(zmask_ptr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((float)z[e] > 0.f) ? g[e] : 0.f;
+    } else if (relu_self) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((float)yv[e] * sc[e] + sh[e] > 0.f) ? g[e] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_reduce_kernel(BnBwdReduceParams p) {
+    __shared__ float s_red[SF_THREADS][17];
+    int gcol, r0, r1, rstep;
+    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const int c = gcol * 8;
+    float sg[8], sgy[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sgy[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
+    if (active) {
+        if (p.relu_self) { load8f(p.scale + c, sc); load8f(p.shift + c, sh); }
+        for (int m = r0; m < r1; m += rstep) {
+            f16x8 dz = ld16(p.dz + (int64_t)m * p.lddz + c);
+            f16x8 yv = ld16(p.y + (int64_t)m * p.ldy + c);
+            float g[8];
+            masked_grad8(dz, yv, p.zmask ? p.zmask + (int64_t)m * p.ldm + c : nullptr, p.relu_self, sc, sh, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sg[e] += g[e]; sgy[e] += g[e] * (float)yv[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s_red[threadIdx.x][e] = sg[e]; s_red[threadIdx.x][8 + e] = sgy[e]; }
+    __syncthreads();
+    const int G = p.rt.C >> 3;
+    const int TG = G < SF_THREADS ? G : SF_THREADS;
+    const int rpi = SF_THREADS / TG;
+    if (active && (int)threadIdx.x < TG) {
+        for (int k = 1; k < rpi; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s_red[threadIdx.x][e] += s_red[threadIdx.x + k * TG][e];
+        float* o = p.part + (int64_t)blockIdx.x * 2 * p.rt.C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[c + e] = s_red[threadIdx.x][e];
+            o[p.rt.C + c + e] = s_red[threadIdx.x][8 + e];
+        }
+    }
+}
+
+struct BnBwdFinalizeParams {
+    const float* part; int nblk; int C;
+    float count;
+    const float* gamma; const float* mean; const float* rstd;
+    float inv_loss_scale;
+    float* dgamma; float* dbeta;   // fp32 parameter gradients (+= when accumulate)
+    int accumulate;
+    float* coef;                   // out [3][C]: dy = k1*g + k2 + k3*y
+};
+
+__global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_finalize_kernel(BnBwdFinalizeParams p) {
+    __shared__ double s_s[8][32];
+    __shared__ double s_q[8][32];
+    const int cx = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double s = 0.0, q = 0.0;
+    if (c < p.C) {
+        for (int b = seg; b < p.nblk; b += 8) {
+            s += (double)p.part[((int64_t)b * 2 + 0) * p.C + c];
+            q += (double)p.part[((int64_t)b * 2 + 1) * p.C + c];
+        }
+    }
+    s_s[seg][cx] = s;
+    s_q[seg][cx] = q;
+    __syncthreads();
+    if (seg == 0 && c < p.C) {
+        for (int k = 1; k < 8; ++k) { s += s_s[k][cx]; q += s_q[k][cx]; }
+        const double mean = p.mean[c], rstd = p.rstd[c], gam = p.gamma[c];
+        const double dbeta = s;                       // sum g
+        const double dgamma = rstd * (q - mean * s);  // sum g*xhat
+        const double n = p.count;
+        const double k1 = gam * rstd;
+        const double k3 = -gam * rstd * rstd * dgamma / n;
+        const double k2 = -gam * rstd * dbeta / n - k3 * mean;
+        p.coef[c] = (float)k1;
+        p.coef[p.C + c] = (float)k2;
+        p.coef[2 * p.C + c] = (float)k3;
+        const float dg = (float)(dgamma * p.inv_loss_scale), db = (float)(dbeta * p.inv_loss_scale);
+        if (p.accumulate) { p.dgamma[c] += dg; p.dbeta[c] += db; }
+        else { p.dgamma[c] = dg; p.dbeta[c] = db; }
+    }
+}
+
+struct BnBwdApplyParams {
+    RowTile rt;
+    const f16* dz; int lddz;
+    const f16* zmask; int ldm;
+    const f16* y; int ldy;
+    const float* scale; const float* shift;
+    int relu_self;
+    const float* coef;       // [3][C]
+    f16* dy; int lddy;
+    f16* gout; int ldg;      // optional: the masked gradient itself (identity-shortcut path)
+};
+
+__global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_apply_kernel(BnBwdApplyParams p) {
+    int gcol, r0, r1, rstep;
+    if (!p.rt.init(gcol, r0, r1, rstep)) return;
+    const int c = gcol * 8, C = p.rt.C;
+    float sc[8], sh[8], k1[8], k2[8], k3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    if (p.relu_self) { load8f(p.scale + c, sc); load8f(p.shift + c, sh); }
+    load8f(p.coef + c, k1);
+    load8f(p.coef + C + c, k2);
+    load8f(p.coef + 2 * C + c, k3);
+    for (int m = r0; m < r1; m += rstep) {
+        f16x8 dz = ld16(p.dz + (int64_t)m * p.lddz + c);
+        f16x8 yv = ld16(p.y + (int64_t)m * p.ldy + c);
+        float g[8];
+        masked_grad8(dz, yv, p.zmask ? p.zmask + (int64_t)m * p.ldm + c : nullptr, p.relu_self, sc, sh, g);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)(k1[e] * g[e] + k2[e] + k3[e] * (float)yv[e]);
+        st16(p.dy + (int64_t)m * p.lddy + c, o);
+        if (p.gout) {
+            f16x8 go;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) go[e] = (f16)g[e];
+            st16(p.gout + (int64_t)m * p.ldg + c, go);
+        }
+    }
+}

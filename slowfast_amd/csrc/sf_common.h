@@ -1,0 +1,169 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) kernels of slowfast_amd.
+//
+// Data model: activations live in HBM as fp16, channels-last -- logical (N,C,T,H,W)
+// tensors whose memory order is N,T,H,W,C ("position rows" of C channels, row pitch `ld` elements so
+// channel-slice views work).  All contractions run on v_mfma_f32_16x16x32_f16 with fp32 accumulation;
+// BatchNorm statistics, affine parameters and weight gradients are fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// LDS transpose read (ds_read_b64_tr_b16).  The host functional simulator (tests/hostsim) pre-defines
+// this hook; on gfx950 it is the builtin.
+#ifndef SF_LDS_TR16
+#define SF_LDS_TR16(p) \
+    __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(p))
+#endif
+
+#define SF_WAVE 64
+#define SF_THREADS 256
+
+// ---------------------------------------------------------------------------------------------
+// Division by a runtime-constant divisor (host computes the magic): q = (umulhi(x, mul) + x) >> shr,
+// exact for 0 <= x < 2^31 and 1 <= d < 2^31.
+struct FastDiv {
+    uint32_t d, mul, shr;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d ? d : 1;
+    uint32_t s = 0;
+    while ((1ull << s) < f.d) ++s;
+    uint64_t m = ((1ull << (32 + s)) + f.d - 1) / f.d - (1ull << 32);
+    f.mul = (uint32_t)m;
+    f.shr = s;
+    return f;
+}
+__device__ __forceinline__ uint32_t fd_div(uint32_t x, const FastDiv& f) {
+    uint32_t hi = (uint32_t)(((uint64_t)x * f.mul) >> 32);
+    return (hi + x) >> f.shr;
+}
+__device__ __forceinline__ void fd_divmod(uint32_t x, const FastDiv& f, uint32_t& q, uint32_t& r) {
+    q = fd_div(x, f);
+    r = x - q * f.d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16-byte global/LDS moves.
+__device__ __forceinline__ f16x8 ld16(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
+__device__ __forceinline__ void st16(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
+__device__ __forceinline__ f16x8 zero8() {
+    f16x8 z = {(f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0, (f16)0};
+    return z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gathered ("im2col on the fly") operand of the implicit GEMMs.  Rows are positions of the ROW
+// space (fwd/wgrad: conv output positions; dgrad: conv input positions), columns are the flattened
+// (tap, channel) index k = tap*C + c with tap = (kt*kH + kh)*kW + kw.  The element at (row, k) is
+// src[position(row, tap)][c] or 0 when the tap falls outside the SOURCE tensor (zero padding) --
+// optionally passed through the producer's BatchNorm(+ReLU) on the fly (per-channel scale/shift).
+struct GatherSide {
+    const f16* src;
+    int ld;                 // row pitch of src in elements
+    int C;                  // channels per tap on the K axis (multiple of 8)
+    int sT, sH, sW;         // SOURCE spatial dims
+    int kT, kH, kW;
+    int strT, strH, strW;
+    int padT, padH, padW;
+    int dilT, dilH, dilW;
+    int mode;               // 0: rows are conv outputs (src pos = out*str - pad + tap*dil)
+                            // 1: rows are conv inputs  (src pos = (in + pad - tap*dil)/str, exact)
+    int Ktot;               // taps*C
+    FastDiv fdC, fdkW, fdkH;      // k -> tap, tap -> (kt, kh, kw)
+    FastDiv fdrW, fdrH, fdrT;     // row -> (n, a, b, c) in the ROW space
+    FastDiv fdsT, fdsH, fdsW;     // dgrad stride divisibility
+    const float* scale;     // optional on-the-fly BN of the source (nullptr = none), length C
+    const float* shift;
+    int relu;
+};
+
+struct RowPos {
+    int n;
+    int bt, bh, bw;   // mode 0: out*str - pad ; mode 1: in + pad
+    bool valid;
+};
+
+__device__ __forceinline__ RowPos decode_row(const GatherSide& g, uint32_t row, bool valid) {
+    RowPos r;
+    uint32_t q, w, h, t, n;
+    fd_divmod(row, g.fdrW, q, w);
+    fd_divmod(q, g.fdrH, q, h);
+    fd_divmod(q, g.fdrT, n, t);
+    r.n = (int)n;
+    if (g.mode == 0) {
+        r.bt = (int)t * g.strT - g.padT;
+        r.bh = (int)h * g.strH - g.padH;
+        r.bw = (int)w * g.strW - g.padW;
+    } else {
+        r.bt = (int)t + g.padT;
+        r.bh = (int)h + g.padH;
+        r.bw = (int)w + g.padW;
+    }
+    r.valid = valid;
+    return r;
+}
+
+// Source offset (in elements) of (row, k-group starting at column k0); returns false when the group
+// is padding (outside the source, beyond Ktot, or an inactive row).
+__device__ __forceinline__ bool gather_offset(const GatherSide& g, const RowPos& r, uint32_t k0, int64_t& off,
+                                              uint32_t& c0) {
+    if (!r.valid || k0 >= (uint32_t)g.Ktot) return false;
+    uint32_t tap, kt, kh, kw, q;
+    fd_divmod(k0, g.fdC, tap, c0);
+    fd_divmod(tap, g.fdkW, q, kw);
+    fd_divmod(q, g.fdkH, kt, kh);
+    int t, h, w;
+    if (g.mode == 0) {
+        t = r.bt + (int)kt * g.dilT;
+        h = r.bh + (int)kh * g.dilH;
+        w = r.bw + (int)kw * g.dilW;
+        if ((unsigned)t >= (unsigned)g.sT || (unsigned)h >= (unsigned)g.sH || (unsigned)w >= (unsigned)g.sW) return false;
+    } else {
+        int ut = r.bt - (int)kt * g.dilT, uh = r.bh - (int)kh * g.dilH, uw = r.bw - (int)kw * g.dilW;
+        if (ut < 0 || uh < 0 || uw < 0) return false;
+        uint32_t qt, rt, qh, rh, qw, rw;
+        fd_divmod((uint32_t)ut, g.fdsT, qt, rt);
+        fd_divmod((uint32_t)uh, g.fdsH, qh, rh);
+        fd_divmod((uint32_t)uw, g.fdsW, qw, rw);
+        if (rt | rh | rw) return false;
+        if (qt >= (uint32_t)g.sT || qh >= (uint32_t)g.sH || qw >= (uint32_t)g.sW) return false;
+        t = (int)qt; h = (int)qh; w = (int)qw;
+    }
+    off = ((((int64_t)r.n * g.sT + t) * g.sH + h) * g.sW + w) * (int64_t)g.ld + c0;
+    return true;
+}
+
+// y = max(0, x*scale + shift) on 8 consecutive channels, fp32 math, tables in LDS.
+__device__ __forceinline__ f16x8 bn_relu8(f16x8 v, const float* sc, const float* sh, int relu) {
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float x = (float)v[e] * sc[e] + sh[e];
+        if (relu) x = x > 0.f ? x : 0.f;
+        o[e] = (f16)x;
+    }
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS operand tile [rows][32] fp16 (64-byte rows = four 16-byte slots).  The slot is rotated by
+// 2*((row>>2)&3) so that each ds_read_b128 lane group of the MFMA fragment read (16 rows x one slot)
+// lands on 16 distinct 16-byte bank slots (MI355X_MICROARCH.md, LDS table).
+__device__ __forceinline__ int lds_tile_off(int row, int slot) {
+    return row * 32 + (((slot + 2 * ((row >> 2) & 3)) & 3) << 3);
+}
+
+__device__ __forceinline__ float wave_sum_over_row_groups(float v) {
+    // sums the 4 lanes {l, l^16, l^32, l^48} (the 4 row groups of a 16x16 MFMA accumulator column)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}

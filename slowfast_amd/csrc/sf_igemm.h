@@ -1,0 +1,386 @@
+// Implicit-GEMM convolution kernels (forward / data-gradient / weight-gradient) for gfx950.
+//
+// One gather-GEMM skeleton serves every Conv3d geometry of the reference's ResNet/SlowFast path
+// (reference call sites: slowfast/models/resnet_helper.py:331-369 BottleneckTransform a/b/c,
+// :485-493 ResBlock.branch1, stem_helper.py:182-189 ResNetBasicStem.conv,
+// video_model_builder.py:147-154 FuseFastToSlow.conv_f2s):
+//   fwd  : Y[m, co]   = sum_k A(m, k) * Wf[co, k]     A = gathered input,   k = (tap, ci)
+//   dgrad: dX[p, ci]  = sum_k A(p, k) * Wd[ci, k]     A = gathered dY,      k = (tap, co)
+//   wgrad: dW[co, k]  = sum_m dY[m, co] * A(m, k)     (reduction over positions, LDS transpose read)
+// Tiles: 128 x BN x 32, 4 waves, v_mfma_f32_16x16x32_f16, fp32 accumulate, register-staged double
+// buffered LDS (global loads of step s+1 are in flight under the MFMAs of step s).
+#pragma once
+#include "sf_common.h"
+
+struct IgemmParams {
+    GatherSide g;
+    int M;              // rows of the output
+    const f16* wmat;    // [Nout][ldw] fp16, K contiguous, zero padded to ldw
+    int ldw;
+    int Nout;
+    int ksteps;         // ceil(Ktot / 32)
+    f16* y;
+    int ldy;
+    const float* bias;  // optional [Nout]
+    const f16* resid;   // optional [M][ldr] added in the epilogue (dgrad accumulation)
+    int ldr;
+    float* stat_part;   // optional [mtiles][2][Nout] per-tile column sum / sum of squares (BatchNorm)
+    int ntiles_n;
+};
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
+    constexpr int BM = 128, BK = 32;
+    constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
+    constexpr int STG_LD = BN + 8;
+    constexpr int SMEM_MAIN = 2 * (A_ELEMS + B_ELEMS), SMEM_STG = BM * STG_LD;
+    constexpr int SMEM = SMEM_MAIN > SMEM_STG ? SMEM_MAIN : SMEM_STG;
+    constexpr int NB = (BN * 4 + SF_THREADS - 1) / SF_THREADS;
+
+    __shared__ __attribute__((aligned(16))) f16 smem[SMEM];
+    __shared__ float s_scale[512];
+    __shared__ float s_shift[512];
+    __shared__ float s_red[WAVES_M][2][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int nt = blockIdx.x % p.ntiles_n, mt = blockIdx.x / p.ntiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const GatherSide& g = p.g;
+    const bool has_tf = g.scale != nullptr;
+
+    if (has_tf) {
+        for (int c = tid; c < g.C; c += SF_THREADS) {
+            s_scale[c] = g.scale[c];
+            s_shift[c] = g.shift[c];
+        }
+    }
+
+    // loader assignment: A rows (tid>>2) and (tid>>2)+64, 16-byte slot tid&3
+    const int kq = tid & 3;
+    RowPos rp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int row = m0 + (tid >> 2) + 64 * j;
+        rp[j] = decode_row(g, (uint32_t)row, row < p.M);
+    }
+
+    f16x8 ra[2], rb[NB];
+    bool ra_ok[2];
+    uint32_t ra_c0[2];
+
+    auto load_tile = [&](int ks) {
+        const uint32_t k0 = (uint32_t)(ks * BK + kq * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int64_t off;
+            uint32_t c0 = 0;
+            bool ok = gather_offset(g, rp[j], k0, off, c0);
+            ra[j] = ok ? ld16(g.src + off) : zero8();
+            ra_ok[j] = ok;
+            ra_c0[j] = c0;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int idx = tid + SF_THREADS * j;
+            int brow = idx >> 2;
+            int co = n0 + brow;
+            bool ok = (idx < BN * 4) && (co < p.Nout);
+            rb[j] = ok ? ld16(p.wmat + (int64_t)co * p.ldw + k0) : zero8();
+        }
+    };
+    auto store_tile = [&](int buf) {
+        f16* As = smem + buf * (A_ELEMS + B_ELEMS);
+        f16* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f16x8 v = ra[j];
+            if (has_tf && ra_ok[j]) v = bn_relu8(v, s_scale + ra_c0[j], s_shift + ra_c0[j], g.relu);
+            st16(As + lds_tile_off((tid >> 2) + 64 * j, kq), v);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int idx = tid + SF_THREADS * j;
+            if (idx < BN * 4) st16(Bs + lds_tile_off(idx >> 2, kq), rb[j]);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const f16* As = smem + buf * (A_ELEMS + B_ELEMS);
+        const f16* Bs = As + A_ELEMS;
+        f16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = ld16(As + lds_tile_off(wm * WM + i * 16 + (lane & 15), lane >> 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = ld16(Bs + lds_tile_off(wn * WN + j * 16 + (lane & 15), lane >> 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+
+    if (has_tf) __syncthreads();  // scale/shift tables visible before the first store_tile
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int ks = 0; ks < p.ksteps; ++ks) {
+        const bool more = ks + 1 < p.ksteps;
+        if (more) load_tile(ks + 1);
+        compute(ks & 1);
+        if (more) store_tile((ks + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: BatchNorm partial statistics (fp32, from the accumulators)
+    if (p.stat_part) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r];
+                    s += v;
+                    q += v * v;
+                }
+            s = wave_sum_over_row_groups(s);
+            q = wave_sum_over_row_groups(q);
+            if (lane < 16) {
+                s_red[wm][0][wn * WN + j * 16 + lane] = s;
+                s_red[wm][1][wn * WN + j * 16 + lane] = q;
+            }
+        }
+    }
+    // ---------------- stage the tile through LDS so that global stores are 16-byte, row-contiguous
+    f16* stg = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * WN + j * 16 + (lane & 15);
+            const float b = (p.bias && (n0 + col) < p.Nout) ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * WM + i * 16 + 4 * (lane >> 4) + r;
+                stg[row * STG_LD + col] = (f16)(acc[i][j][r] + b);
+            }
+        }
+    __syncthreads();
+    if (p.stat_part && tid < BN) {
+        const int col = n0 + tid;
+        if (col < p.Nout) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) {
+                s += s_red[w][0][tid];
+                q += s_red[w][1][tid];
+            }
+            p.stat_part[((int64_t)mt * 2 + 0) * p.Nout + col] = s;
+            p.stat_part[((int64_t)mt * 2 + 1) * p.Nout + col] = q;
+        }
+    }
+    constexpr int CG = BN / 8;
+    for (int idx = tid; idx < BM * CG; idx += SF_THREADS) {
+        const int row = idx / CG, cg = idx % CG;
+        const int m = m0 + row, col = n0 + cg * 8;
+        if (m < p.M && col < p.Nout) {
+            f16x8 v = ld16(stg + row * STG_LD + cg * 8);
+            if (p.resid) {
+                f16x8 r = ld16(p.resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)r[e]);
+            }
+            st16(p.y + (int64_t)m * p.ldy + col, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct WgradParams {
+    GatherSide g;       // gathered forward input (mode 0), columns k = tap*g.C + ci
+    const f16* dy;      // [M][ldy]
+    int ldy;
+    int Co;
+    int M;
+    float* dw;          // fp32 [Co][Cw][taps] (PyTorch Conv3d weight layout), atomically accumulated
+    int Cw;             // channels of the weight tensor (<= g.C; stem input is channel-padded)
+    int taps;
+    float out_scale;    // 1 / loss_scale
+    int nchunks;        // ceil(M / 32)
+    int chunks_per_split;
+};
+
+template <class V>
+__device__ __forceinline__ f16x4 as_f16x4(V v) {
+    f16x4 o;
+    __builtin_memcpy(&o, &v, 8);
+    return o;
+}
+
+// TR = true : MFMA fragments via ds_read_b64_tr_b16 (hardware transpose read)
+// TR = false: eight scalar LDS reads per fragment (reference path, selectable with SF_WGRAD_SCALAR=1)
+template <int BMW, int WM, int WN, bool TR>
+__global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
+    constexpr int BNW = 128, BKM = 32;
+    constexpr int WAVES_N = BNW / WN, WAVES_M = BMW / WM;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int LDA = BMW + 16, LDB = BNW + 16;
+    constexpr int BUF = BKM * (LDA + LDB);
+    constexpr int NA = (4 * BMW + SF_THREADS - 1) / SF_THREADS;
+
+    __shared__ __attribute__((aligned(16))) f16 smem[2 * BUF];
+    __shared__ float s_scale[512];
+    __shared__ float s_shift[512];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int n0 = blockIdx.x * BNW, c0 = blockIdx.y * BMW;
+    const GatherSide& g = p.g;
+    const bool has_tf = g.scale != nullptr;
+    if (has_tf) {
+        for (int c = tid; c < g.C; c += SF_THREADS) {
+            s_scale[c] = g.scale[c];
+            s_shift[c] = g.shift[c];
+        }
+    }
+    const int cb = blockIdx.z * p.chunks_per_split;
+    int ce = cb + p.chunks_per_split;
+    if (ce > p.nchunks) ce = p.nchunks;
+
+    f16x8 ra[NA], rb[2];
+    bool rb_ok[2];
+    uint32_t rb_c0[2];
+    const uint32_t xk0 = (uint32_t)(n0 + (tid & 15) * 8);
+
+    auto load_tile = [&](int chunk) {
+        const int mbase = chunk * BKM;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            int idx = tid + SF_THREADS * j;
+            int ml = idx / (BMW / 8), cg = idx % (BMW / 8);
+            int m = mbase + ml, co = c0 + cg * 8;
+            bool ok = (idx < 4 * BMW) && (m < p.M) && (co < p.Co);
+            ra[j] = ok ? ld16(p.dy + (int64_t)m * p.ldy + co) : zero8();
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int ml = (tid >> 4) + 16 * j;
+            int m = mbase + ml;
+            RowPos rp = decode_row(g, (uint32_t)m, m < p.M);
+            int64_t off;
+            uint32_t cc = 0;
+            bool ok = gather_offset(g, rp, xk0, off, cc);
+            rb[j] = ok ? ld16(g.src + off) : zero8();
+            rb_ok[j] = ok;
+            rb_c0[j] = cc;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        f16* Ys = smem + buf * BUF;
+        f16* Xs = Ys + BKM * LDA;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            int idx = tid + SF_THREADS * j;
+            if (idx < 4 * BMW) st16(Ys + (idx / (BMW / 8)) * LDA + (idx % (BMW / 8)) * 8, ra[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f16x8 v = rb[j];
+            if (has_tf && rb_ok[j]) v = bn_relu8(v, s_scale + rb_c0[j], s_shift + rb_c0[j], g.relu);
+            st16(Xs + ((tid >> 4) + 16 * j) * LDB + (tid & 15) * 8, v);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int pl = lane & 15, g4 = lane >> 4;
+    auto compute = [&](int buf) {
+        const f16* Ys = smem + buf * BUF;
+        const f16* Xs = Ys + BKM * LDA;
+        f16x8 af[TM], bf[TN];
+        if constexpr (TR) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f16* ptr = Ys + (8 * g4 + 4 * h + (pl >> 2)) * LDA + wm * WM + i * 16 + 4 * (pl & 3);
+                    f16x4 t = as_f16x4(SF_LDS_TR16(ptr));
+                    af[i][4 * h + 0] = t[0]; af[i][4 * h + 1] = t[1]; af[i][4 * h + 2] = t[2]; af[i][4 * h + 3] = t[3];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f16* ptr = Xs + (8 * g4 + 4 * h + (pl >> 2)) * LDB + wn * WN + j * 16 + 4 * (pl & 3);
+                    f16x4 t = as_f16x4(SF_LDS_TR16(ptr));
+                    bf[j][4 * h + 0] = t[0]; bf[j][4 * h + 1] = t[1]; bf[j][4 * h + 2] = t[2]; bf[j][4 * h + 3] = t[3];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[i][e] = Ys[(8 * g4 + e) * LDA + wm * WM + i * 16 + pl];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bf[j][e] = Xs[(8 * g4 + e) * LDB + wn * WN + j * 16 + pl];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+
+    if (has_tf) __syncthreads();
+    if (cb < ce) {
+        load_tile(cb);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int ch = cb; ch < ce; ++ch) {
+        const bool more = ch + 1 < ce;
+        if (more) load_tile(ch + 1);
+        compute((ch - cb) & 1);
+        if (more) store_tile((ch - cb + 1) & 1);
+        __syncthreads();
+    }
+    if (cb >= ce) return;
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const uint32_t kcol = (uint32_t)(n0 + wn * WN + j * 16 + pl);
+        if (kcol >= (uint32_t)g.Ktot) continue;
+        uint32_t tap, ci;
+        fd_divmod(kcol, g.fdC, tap, ci);
+        if (ci >= (uint32_t)p.Cw) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = c0 + wm * WM + i * 16 + 4 * g4 + r;
+                if (co < p.Co)
+                    atomicAdd(p.dw + ((int64_t)co * p.Cw + ci) * p.taps + tap, acc[i][j][r] * p.out_scale);
+            }
+    }
+}

@@ -1,0 +1,94 @@
+"""ctypes binding of libsfamd.so (C ABI declared in include/sfamd.h).
+
+The product path is the hipcc-built gfx950 library next to this file.  There is NO fallback: if the
+library is missing, or tensors are not on a GPU, calls raise.  The CPU test-suite points
+``SFAMD_LIBRARY`` at the host functional simulator (tests/hostsim, the same kernel sources compiled
+for the host) to exercise the host logic and the kernels' index math without a GPU; that build
+identifies itself through ``sf_backend() == "hostsim"`` and is never picked up implicitly.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
+ABI_VERSION = 1
+
+
+class ConvDesc(Structure):
+    """Mirror of ``sf_conv_desc``."""
+
+    _fields_ = [(n, c_int32) for n in (
+        "N", "Ci", "Ti", "Hi", "Wi", "Co", "To", "Ho", "Wo", "kT", "kH", "kW", "sT", "sH", "sW",
+        "pT", "pH", "pW", "dT", "dH", "dW", "Cw", "ldx", "ldy")]
+
+
+_P = c_void_p
+_F = c_void_p  # float* passed as raw address
+_SIGNATURES = {
+    "sf_abi_version": (c_int, []),
+    "sf_backend": (c_char_p, []),
+    "sf_last_error": (c_char_p, []),
+    "sf_conv_weight_ld": (c_int, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
+    "sf_prep_weights": (c_int, [POINTER(ConvDesc), _F, _P, _P, _P]),
+    "sf_conv_fwd_mtiles": (c_int, [POINTER(ConvDesc)]),
+    "sf_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _F, _F, c_int, _F, _P, _F, _P]),
+    "sf_conv_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P]),
+    "sf_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _F, _F, c_int, _P, _F, c_float, c_int, _P]),
+    "sf_bn_finalize": (c_int, [_F, c_int32, c_int32, c_float, _F, _F, _F, _F, c_float, c_float, _F, _F, _F, _F, _P]),
+    "sf_bn_act": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, _P, c_int32, _F, _F, c_int, _P, c_int32, _P]),
+    "sf_bn_bwd_blocks": (c_int, [c_int64, c_int32]),
+    "sf_bn_bwd_reduce": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, _F, _F, c_int, _F, _P]),
+    "sf_bn_bwd_finalize": (c_int, [_F, c_int32, c_int32, c_float, _F, _F, _F, c_float, _F, _F, c_int, _F, _P]),
+    "sf_bn_bwd_apply": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, _F, _F, c_int, _F, _P,
+                                c_int32, _P, c_int32, _P]),
+    "sf_pool_fwd": (c_int, [c_int32] * 11 + [_P, c_int32, _F, _F, c_int, _P, c_int32, _P]),
+    "sf_pool_bwd": (c_int, [c_int32] * 11 + [_P, c_int32, _F, _F, c_int, _P, c_int32, _P, c_int32, _P]),
+    "sf_ncthw_to_cl": (c_int, [_F, c_int32, c_int32, c_int64, c_int32, _P, _P]),
+    "sf_cl_to_ncthw": (c_int, [_P, c_int32, c_int32, c_int32, c_int64, _F, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class SfError(RuntimeError):
+    pass
+
+
+class SfLibrary:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise SfError(
+                f"native library not found: {path}. Build it with `python -m slowfast_amd.build_ext` "
+                "(hipcc --offload-arch=gfx950); slowfast_amd has no CPU/PyTorch fallback.")
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        ver = self.cdll.sf_abi_version()
+        if ver != ABI_VERSION:
+            raise SfError(f"{path}: ABI version {ver}, expected {ABI_VERSION}")
+        self.backend = self.cdll.sf_backend().decode()
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc < 0:
+            raise SfError(f"{name}: {self.cdll.sf_last_error().decode()}")
+        return rc
+
+
+_lib = None
+
+
+def get_lib():
+    """The loaded native library (loads on first use; raises SfError if it cannot)."""
+    global _lib
+    if _lib is None:
+        _lib = SfLibrary(os.environ.get("SFAMD_LIBRARY", DEFAULT_LIBRARY))
+    return _lib
+
+
+def reset_lib():
+    global _lib
+    _lib = None

@@ -1,0 +1,284 @@
+"""Tensor-level wrappers over the C ABI (include/sfamd.h).
+
+PyTorch is used here only for device memory and streams.  Activations are fp16 tensors of LOGICAL
+shape (N, C, T, H, W) -- the reference's NCTHW convention (slowfast/models/video_model_builder.py:423)
+-- whose MEMORY order is N,T,H,W,C with a row pitch ``ld`` (``torch.channels_last_3d`` strides, or a
+channel slice of such a tensor).  Nothing in this file computes on the CPU or through ATen kernels.
+"""
+from ctypes import byref, c_int32
+
+import torch
+
+from .lib import ConvDesc, SfError, get_lib
+
+_f16 = torch.float16
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+def _stream(t):
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    if get_lib().backend != "hostsim":
+        raise SfError("slowfast_amd kernels need CUDA/HIP tensors (got a CPU tensor and the gfx950 library)")
+    return None
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# channels-last helpers
+def cl_empty(shape, device, ld=None, zero=False):
+    """fp16 tensor of logical shape (N,C,T,H,W) stored N,T,H,W,C with row pitch ``ld``."""
+    N, C, T, H, W = shape
+    ld = C if ld is None else ld
+    base = (torch.zeros if zero else torch.empty)((N, T, H, W, ld), dtype=_f16, device=device)
+    return base[..., :C].permute(0, 4, 1, 2, 3)
+
+
+def cl_ld(x):
+    """Row pitch of a channels-last activation; raises if ``x`` is not in that layout."""
+    if x.dim() != 5 or x.dtype != _f16:
+        raise SfError(f"expected a 5-D fp16 channels-last activation, got {tuple(x.shape)} {x.dtype}")
+    N, C, T, H, W = x.shape
+    if C > 1 and x.stride(1) != 1:
+        raise SfError("activation is not channels-last (channel stride != 1); use ops.to_cl()")
+    if W > 1:
+        ld = x.stride(4)
+    elif H > 1:
+        ld = x.stride(3)
+    elif T > 1:
+        ld = x.stride(2)
+    elif N > 1:
+        ld = x.stride(0)
+    else:
+        ld = C
+    exp = (T * H * W * ld, 1, H * W * ld, W * ld, ld)
+    for dim, size in enumerate(x.shape):
+        if size > 1 and x.stride(dim) != exp[dim]:
+            raise SfError(f"activation strides {x.stride()} are not channels-last with pitch {ld}")
+    if ld < C or ld % 8 or C % 8 or x.data_ptr() % 16:
+        raise SfError(f"activation needs C % 8 == 0, pitch % 8 == 0, 16-byte base (C={C}, ld={ld})")
+    return ld
+
+
+def is_cl(x):
+    try:
+        cl_ld(x)
+        return True
+    except SfError:
+        return False
+
+
+def rows(x):
+    N, C, T, H, W = x.shape
+    return N * T * H * W
+
+
+def ncthw_to_cl(x, Cp=None):
+    """NCTHW fp32 clip -> channels-last fp16, channels zero-padded to ``Cp`` (sf_ncthw_to_cl)."""
+    assert x.dim() == 5 and x.dtype == torch.float32
+    x = x.contiguous()
+    N, C, T, H, W = x.shape
+    Cp = Cp or (C + 7) // 8 * 8
+    out = cl_empty((N, Cp, T, H, W), x.device)
+    get_lib().call("sf_ncthw_to_cl", x.data_ptr(), N, C, T * H * W, Cp, out.data_ptr(), _stream(x))
+    return out
+
+
+def cl_to_ncthw(x):
+    """channels-last fp16 -> contiguous NCTHW fp32 (sf_cl_to_ncthw)."""
+    ld = cl_ld(x)
+    N, C, T, H, W = x.shape
+    out = torch.empty((N, C, T, H, W), dtype=torch.float32, device=x.device)
+    get_lib().call("sf_cl_to_ncthw", x.data_ptr(), ld, N, C, T * H * W, out.data_ptr(), _stream(x))
+    return out
+
+
+def to_cl(x):
+    """Accept what a caller of the reference modules would pass: NCTHW fp32/fp16 in any layout."""
+    if x.dtype == _f16 and is_cl(x):
+        return x
+    return ncthw_to_cl(x.float())
+
+
+# ------------------------------------------------------------------------------------------------
+class ConvGeom:
+    """Geometry of one nn.Conv3d call (groups == 1) on a given input shape."""
+
+    def __init__(self, in_shape, Co, kernel, stride=1, padding=0, dilation=1, Cw=None):
+        self.N, self.Ci, self.Ti, self.Hi, self.Wi = in_shape
+        self.Co = Co
+        self.k, self.s, self.p, self.d = _triple(kernel), _triple(stride), _triple(padding), _triple(dilation)
+        self.Cw = self.Ci if Cw is None else Cw
+        self.To, self.Ho, self.Wo = [
+            (i + 2 * p - d * (k - 1) - 1) // s + 1
+            for i, k, s, p, d in zip((self.Ti, self.Hi, self.Wi), self.k, self.s, self.p, self.d)]
+        self.taps = self.k[0] * self.k[1] * self.k[2]
+        ldf, ldd = c_int32(), c_int32()
+        get_lib().call("sf_conv_weight_ld", byref(self.desc(self.Ci, self.Co)), byref(ldf), byref(ldd))
+        self.ldf, self.ldd = ldf.value, ldd.value
+
+    @property
+    def in_shape(self):
+        return (self.N, self.Ci, self.Ti, self.Hi, self.Wi)
+
+    @property
+    def out_shape(self):
+        return (self.N, self.Co, self.To, self.Ho, self.Wo)
+
+    @property
+    def out_rows(self):
+        return self.N * self.To * self.Ho * self.Wo
+
+    def desc(self, ldx, ldy):
+        return ConvDesc(self.N, self.Ci, self.Ti, self.Hi, self.Wi, self.Co, self.To, self.Ho, self.Wo,
+                        *self.k, *self.s, *self.p, *self.d, self.Cw, ldx, ldy)
+
+
+def prep_weights(w, geom, need_dgrad=True):
+    """fp32 Conv3d weight -> fp16 GEMM operands (forward [Co][ldf], dgrad [Ci][ldd])."""
+    assert w.dtype == torch.float32 and tuple(w.shape) == (geom.Co, geom.Cw) + geom.k, (w.shape, geom.Co, geom.Cw)
+    w = w.contiguous()
+    wf = torch.empty((geom.Co, geom.ldf), dtype=_f16, device=w.device)
+    wd = torch.empty((geom.Ci, geom.ldd), dtype=_f16, device=w.device) if need_dgrad else None
+    get_lib().call("sf_prep_weights", byref(geom.desc(geom.Ci, geom.Co)), w.data_ptr(), wf.data_ptr(), _ptr(wd),
+                   _stream(w))
+    return wf, wd
+
+
+def _affine(in_affine):
+    if in_affine is None:
+        return None, None, 0
+    scale, shift, relu = in_affine
+    assert scale.dtype == torch.float32 and shift.dtype == torch.float32
+    return scale, shift, int(bool(relu))
+
+
+def conv_fwd(x, wf, geom, in_affine=None, bias=None, stats=True, out=None):
+    """y = conv3d(act(x)); returns (y, stat_part or None).  act = producer BN(+ReLU) applied on the fly."""
+    assert tuple(x.shape) == geom.in_shape, (x.shape, geom.in_shape)
+    ldx = cl_ld(x)
+    y = cl_empty(geom.out_shape, x.device) if out is None else out
+    ldy = cl_ld(y)
+    lib = get_lib()
+    d = geom.desc(ldx, ldy)
+    part = None
+    if stats:
+        mt = lib.call("sf_conv_fwd_mtiles", byref(d))
+        part = torch.empty((mt, 2, geom.Co), dtype=torch.float32, device=x.device)
+    sc, sh, relu = _affine(in_affine)
+    lib.call("sf_conv_fwd", byref(d), x.data_ptr(), wf.data_ptr(), _ptr(sc), _ptr(sh), relu, _ptr(bias),
+             y.data_ptr(), _ptr(part), _stream(x))
+    return y, part
+
+
+def conv_dgrad(dy, wd, geom, resid=None, out=None):
+    """dx = conv_transpose3d(dy, w) [+ resid]."""
+    assert tuple(dy.shape) == geom.out_shape
+    ldy = cl_ld(dy)
+    dx = cl_empty(geom.in_shape, dy.device) if out is None else out
+    ldx = cl_ld(dx)
+    ldr = cl_ld(resid) if resid is not None else 0
+    if resid is not None:
+        assert tuple(resid.shape) == geom.in_shape
+    get_lib().call("sf_conv_dgrad", byref(geom.desc(ldx, ldy)), dy.data_ptr(), wd.data_ptr(), _ptr(resid), ldr,
+                   dx.data_ptr(), _stream(dy))
+    return dx
+
+
+def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True):
+    """dw (+)= out_scale * d(loss)/d(weight); dw is an fp32 tensor shaped like the Conv3d weight."""
+    assert tuple(x.shape) == geom.in_shape and tuple(dy.shape) == geom.out_shape
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == geom.Co * geom.Cw * geom.taps
+    sc, sh, relu = _affine(in_affine)
+    get_lib().call("sf_conv_wgrad", byref(geom.desc(cl_ld(x), cl_ld(dy))), x.data_ptr(), _ptr(sc), _ptr(sh), relu,
+                   dy.data_ptr(), dw.data_ptr(), float(out_scale), int(zero_first), _stream(x))
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------
+def bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum, eps, training=True):
+    """Per-tile sums -> (scale, shift, mean, rstd); updates running statistics in training mode."""
+    C = gamma.numel()
+    dev = gamma.device
+    scale, shift, mean, rstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+    nblk = part.shape[0] if training else 0
+    get_lib().call("sf_bn_finalize", _ptr(part) if training else None, nblk, C, float(count), gamma.data_ptr(),
+                   beta.data_ptr(), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+                   scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream(gamma))
+    return scale, shift, mean, rstd
+
+
+def bn_act(y, scale=None, shift=None, relu=False, resid=None, rscale=None, rshift=None, out=None):
+    """out = relu?(y*scale+shift [+ resid*rscale+rshift | + resid]) materialised in fp16."""
+    ldy = cl_ld(y)
+    N, C, T, H, W = y.shape
+    out = cl_empty(y.shape, y.device) if out is None else out
+    assert tuple(out.shape) == tuple(y.shape)
+    get_lib().call("sf_bn_act", rows(y), C, y.data_ptr(), ldy, _ptr(scale), _ptr(shift), _ptr(resid),
+                   cl_ld(resid) if resid is not None else 0, _ptr(rscale), _ptr(rshift), int(bool(relu)),
+                   out.data_ptr(), cl_ld(out), _stream(y))
+    return out
+
+
+def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None, inv_loss_scale=1.0,
+           accumulate=False, want_g=False, out=None):
+    """BatchNorm3d (training) backward through an optional ReLU.
+
+    dz: gradient w.r.t. act(bn(y)); the ReLU mask is ``zmask > 0`` (block output) or recomputed from
+    ``relu_affine = (scale, shift)``; writes fp32 dgamma/dbeta and returns dy (and the masked g)."""
+    lib = get_lib()
+    N, C, T, H, W = y.shape
+    M = rows(y)
+    s = _stream(y)
+    nblk = lib.call("sf_bn_bwd_blocks", M, C)
+    part = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
+    sc, sh = (relu_affine if relu_affine is not None else (None, None))
+    relu_self = int(relu_affine is not None)
+    lddz, ldy, ldm = cl_ld(dz), cl_ld(y), (cl_ld(zmask) if zmask is not None else 0)
+    lib.call("sf_bn_bwd_reduce", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
+             relu_self, part.data_ptr(), s)
+    coef = torch.empty((3, C), dtype=torch.float32, device=y.device)
+    lib.call("sf_bn_bwd_finalize", part.data_ptr(), nblk, C, float(M), gamma.data_ptr(), mean.data_ptr(),
+             rstd.data_ptr(), float(inv_loss_scale), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
+             coef.data_ptr(), s)
+    dy = cl_empty(y.shape, y.device) if out is None else out
+    g = cl_empty(y.shape, y.device) if want_g else None
+    lib.call("sf_bn_bwd_apply", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
+             relu_self, coef.data_ptr(), dy.data_ptr(), cl_ld(dy), _ptr(g), cl_ld(g) if g is not None else 0, s)
+    return (dy, g) if want_g else dy
+
+
+# ------------------------------------------------------------------------------------------------
+def _pool_args(y, kernel, stride, padding):
+    N, C, T, H, W = y.shape
+    (kH, kW), (sH, sW), (pH, pW) = kernel, stride, padding
+    return (N, T, H, W, C, kH, kW, sH, sW, pH, pW), ((H + 2 * pH - kH) // sH + 1, (W + 2 * pW - kW) // sW + 1)
+
+
+def pool_fwd(y, kernel, stride, padding, affine=None):
+    """MaxPool over (H,W) of act(y), act = producer BN(+ReLU) from ``affine = (scale, shift, relu)``."""
+    args, (Ho, Wo) = _pool_args(y, kernel, stride, padding)
+    N, C, T, H, W = y.shape
+    out = cl_empty((N, C, T, Ho, Wo), y.device)
+    sc, sh, relu = _affine(affine)
+    get_lib().call("sf_pool_fwd", *args, y.data_ptr(), cl_ld(y), _ptr(sc), _ptr(sh), relu, out.data_ptr(),
+                   cl_ld(out), _stream(y))
+    return out
+
+
+def pool_bwd(y, dout, kernel, stride, padding, affine=None):
+    """Gradient w.r.t. the BatchNorm output (max-pool backward + ReLU mask)."""
+    args, (Ho, Wo) = _pool_args(y, kernel, stride, padding)
+    N, C, T, H, W = y.shape
+    assert tuple(dout.shape) == (N, C, T, Ho, Wo)
+    g = cl_empty(y.shape, y.device)
+    sc, sh, relu = _affine(affine)
+    get_lib().call("sf_pool_bwd", *args, y.data_ptr(), cl_ld(y), _ptr(sc), _ptr(sh), relu, dout.data_ptr(),
+                   cl_ld(dout), g.data_ptr(), cl_ld(g), _stream(y))
+    return g

@@ -1,0 +1,203 @@
+"""Kernel parity checks shared by the CPU (host simulator) and GPU (-m gpu) test files.
+
+Reference = the plain torch fp32 op the reference model calls (F.conv3d, F.batch_norm, F.max_pool3d,
+autograd) evaluated on the CPU on the SAME fp16-rounded operands, so the only differences are the
+accumulation order and the fp16 rounding of the stored result (tolerances below are stated in units
+of fp16 epsilon 2^-10 ~ 1e-3).
+"""
+import torch
+import torch.nn.functional as F
+
+from slowfast_amd import ops
+
+F16_EPS = 2.0 ** -10
+
+
+def host_to_cl(x, device):
+    """NCTHW float (cpu) -> channels-last fp16 on `device` (test utility, not the product path)."""
+    x = x.to(torch.float16).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+    return x.to(device)
+
+
+def cl_to_host(x):
+    return x.detach().float().cpu().contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def assert_close(name, got, ref, tol):
+    e = rel_err(got, ref)
+    assert e <= tol, f"{name}: max-abs error / max|ref| = {e:.3e} > {tol:.1e}"
+    return e
+
+
+def make_conv_case(seed, in_shape, Co, k, s, p, d, Cw=None):
+    g = torch.Generator().manual_seed(seed)
+    N, Ci, T, H, W = in_shape
+    Cw = Ci if Cw is None else Cw
+    x = torch.randn(in_shape, generator=g)
+    if Cw < Ci:
+        x[:, Cw:] = 0
+    x = x.half().float()
+    w = (torch.randn((Co, Cw) + tuple(k), generator=g) / (Cw * k[0] * k[1] * k[2]) ** 0.5)
+    return x, w
+
+
+def check_conv_fwd(device, in_shape, Co, k, s, p, d=(1, 1, 1), Cw=None, affine=False, ldx_extra=0, seed=0):
+    x, w = make_conv_case(seed, in_shape, Co, k, s, p, d, Cw)
+    geom = ops.ConvGeom(in_shape, Co, k, s, p, d, Cw=Cw)
+    wf, wd = ops.prep_weights(w.to(device), geom)
+    w16 = w.half().float()
+    xin = x
+    in_affine = None
+    if affine:
+        g = torch.Generator().manual_seed(seed + 1)
+        sc = torch.randn(in_shape[1], generator=g)
+        sh = torch.randn(in_shape[1], generator=g) * 0.5
+        xin = F.relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)).half().float()
+        in_affine = (sc.to(device), sh.to(device), True)
+    if ldx_extra:
+        N, Ci, T, H, W = in_shape
+        big = ops.cl_empty((N, Ci + ldx_extra, T, H, W), device, zero=True)
+        xc = big[:, ldx_extra:]
+        xc.copy_(host_to_cl(x, device))
+    else:
+        xc = host_to_cl(x, device)
+    y, part = ops.conv_fwd(xc, wf, geom, in_affine=in_affine, stats=True)
+    ref = F.conv3d(xin[:, : w.shape[1]], w16, None, s, p, d)
+    assert tuple(y.shape) == tuple(ref.shape)
+    e = assert_close("conv_fwd", cl_to_host(y), ref, 2 * F16_EPS)
+    tot = part.sum(0).cpu()
+    assert_close("conv_fwd stats sum", tot[0], ref.sum((0, 2, 3, 4)), 1e-4 * max(1.0, float(ref.abs().sum((0, 2, 3, 4)).max() / (ref.sum((0, 2, 3, 4)).abs().max() + 1e-9))))
+    assert_close("conv_fwd stats sumsq", tot[1], (ref * ref).sum((0, 2, 3, 4)), 1e-4)
+    return e
+
+
+def check_conv_dgrad(device, in_shape, Co, k, s, p, d=(1, 1, 1), resid=False, seed=0):
+    x, w = make_conv_case(seed, in_shape, Co, k, s, p, d)
+    geom = ops.ConvGeom(in_shape, Co, k, s, p, d)
+    wf, wd = ops.prep_weights(w.to(device), geom)
+    w16 = w.half().float()
+    g = torch.Generator().manual_seed(seed + 2)
+    dy = torch.randn(geom.out_shape, generator=g).half().float()
+    xr = x.clone().requires_grad_(True)
+    F.conv3d(xr, w16, None, s, p, d).backward(dy)
+    ref = xr.grad
+    r = None
+    if resid:
+        rr = torch.randn(in_shape, generator=g).half().float()
+        ref = (ref.half().float() + rr)
+        r = host_to_cl(rr, device)
+    dx = ops.conv_dgrad(host_to_cl(dy, device), wd, geom, resid=r)
+    return assert_close("conv_dgrad", cl_to_host(dx), ref, 2 * F16_EPS)
+
+
+def check_conv_wgrad(device, in_shape, Co, k, s, p, d=(1, 1, 1), Cw=None, affine=False, out_scale=1.0, seed=0):
+    x, w = make_conv_case(seed, in_shape, Co, k, s, p, d, Cw)
+    geom = ops.ConvGeom(in_shape, Co, k, s, p, d, Cw=Cw)
+    g = torch.Generator().manual_seed(seed + 3)
+    dy = torch.randn(geom.out_shape, generator=g).half().float()
+    xin = x
+    in_affine = None
+    if affine:
+        sc = torch.randn(in_shape[1], generator=g)
+        sh = torch.randn(in_shape[1], generator=g) * 0.5
+        xin = F.relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)).half().float()
+        in_affine = (sc.to(device), sh.to(device), True)
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(xin[:, : w.shape[1]], wr, None, s, p, d).backward(dy)
+    ref = wr.grad * out_scale
+    dw = torch.full(w.shape, 7.0, dtype=torch.float32, device=device)  # must be cleared by zero_first
+    ops.conv_wgrad(host_to_cl(x, device), host_to_cl(dy, device), geom, dw, in_affine=in_affine, out_scale=out_scale,
+                   zero_first=True)
+    return assert_close("conv_wgrad", dw.cpu(), ref, 1e-4)
+
+
+def check_bn_chain(device, shape, relu=True, residual=None, seed=0):
+    """conv-stat partials -> finalize -> bn_act, and the backward (reduce/finalize/apply)."""
+    g = torch.Generator().manual_seed(seed)
+    N, C, T, H, W = shape
+    y = (torch.randn(shape, generator=g) * 1.5 + 0.3).half().float()
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    dz = torch.randn(shape, generator=g).half().float()
+    M = N * T * H * W
+    # reference
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    zr = F.batch_norm(yr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    res = None
+    if residual is not None:
+        res = torch.randn(shape, generator=g).half().float()
+        zr = zr + res
+    if relu:
+        zr = F.relu(zr)
+    zr.backward(dz)
+    # ours: partial sums as the conv epilogue would leave them (2 tiles)
+    yf = y.permute(0, 2, 3, 4, 1).reshape(M, C)
+    half = M // 2
+    part = torch.stack([torch.stack([yf[:half].sum(0), (yf[:half] ** 2).sum(0)]),
+                        torch.stack([yf[half:].sum(0), (yf[half:] ** 2).sum(0)])]).to(device)
+    gd, bd, rmd, rvd = gamma.to(device), beta.to(device), rm.clone().to(device), rv.clone().to(device)
+    scale, shift, mean, rstd = ops.bn_finalize(part, M, gd, bd, rmd, rvd, 0.1, 1e-5, training=True)
+    assert_close("running_mean", rmd.cpu(), rm_ref, 1e-5)
+    assert_close("running_var", rvd.cpu(), rv_ref, 1e-5)
+    yc = host_to_cl(y, device)
+    rc = host_to_cl(res, device) if res is not None else None
+    z = ops.bn_act(yc, scale, shift, relu=relu, resid=rc)
+    assert_close("bn_act", cl_to_host(z), zr.detach(), 2 * F16_EPS)
+    dgamma = torch.empty(C, device=device)
+    dbeta = torch.empty(C, device=device)
+    dzc = host_to_cl(dz, device)
+    if residual is not None:
+        dy, gm = ops.bn_bwd(dzc, yc, gd, mean, rstd, dgamma, dbeta, zmask=z if relu else None, want_g=True,
+                            inv_loss_scale=0.5)
+        gref = dz * (zr.detach() > 0) if relu else dz
+        assert_close("bn_bwd g", cl_to_host(gm), gref, 1e-6)
+    else:
+        dy = ops.bn_bwd(dzc, yc, gd, mean, rstd, dgamma, dbeta, relu_affine=(scale, shift) if relu else None,
+                        inv_loss_scale=0.5)
+    assert_close("bn_bwd dy", cl_to_host(dy), yr.grad, 3 * F16_EPS)
+    assert_close("bn_bwd dgamma", dgamma.cpu(), gr.grad * 0.5, 2e-3)
+    assert_close("bn_bwd dbeta", dbeta.cpu(), br.grad * 0.5, 2e-3)
+    # eval mode uses the running statistics
+    sc_e, sh_e, _, _ = ops.bn_finalize(None, M, gd, bd, rmd, rvd, 0.1, 1e-5, training=False)
+    ze = ops.bn_act(yc, sc_e, sh_e, relu=False)
+    zref = F.batch_norm(y, rm_ref, rv_ref, gamma, beta, False, 0.1, 1e-5)
+    assert_close("bn eval", cl_to_host(ze), zref, 2 * F16_EPS)
+
+
+def check_pool(device, shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    N, C, T, H, W = shape
+    y = torch.randn(shape, generator=g).half().float()
+    sc = torch.rand(C, generator=g) + 0.5
+    sh = torch.randn(C, generator=g) * 0.3
+    yr = y.clone()
+    z = F.relu(yr * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)).half().float().requires_grad_(True)
+    pr = F.max_pool3d(z, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    dout = torch.randn(pr.shape, generator=g).half().float()
+    pr.backward(dout)
+    gref = z.grad * (z.detach() > 0)
+    yc = host_to_cl(y, device)
+    aff = (sc.to(device), sh.to(device), True)
+    out = ops.pool_fwd(yc, (3, 3), (2, 2), (1, 1), affine=aff)
+    assert_close("pool_fwd", cl_to_host(out), pr.detach(), 1e-6)
+    gm = ops.pool_bwd(yc, host_to_cl(dout, device), (3, 3), (2, 2), (1, 1), affine=aff)
+    assert_close("pool_bwd", cl_to_host(gm), gref, 2 * F16_EPS)
+
+
+def check_layout(device, shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g)
+    xc = ops.ncthw_to_cl(x.to(device))
+    assert xc.shape[1] == (shape[1] + 7) // 8 * 8
+    assert_close("ncthw_to_cl", cl_to_host(xc)[:, : shape[1]], x.half().float(), 1e-6)
+    assert float(cl_to_host(xc)[:, shape[1]:].abs().max()) == 0.0 if xc.shape[1] > shape[1] else True
+    back = ops.cl_to_ncthw(xc)
+    assert_close("cl_to_ncthw", back.cpu()[:, : shape[1]], x.half().float(), 1e-6)

@@ -1,0 +1,87 @@
+"""GPU (-m gpu): parity of every libsfamd kernel on a real MI355X against the torch fp32 reference op."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests import kernel_checks as kc
+from tests.test_kernels_hostsim import CONV_CASES
+
+pytestmark = pytest.mark.gpu
+
+BIG_CASES = [
+    ((4, 64, 4, 28, 28), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    ((2, 320, 4, 28, 28), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    ((2, 256, 4, 14, 14), 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    ((2, 128, 4, 28, 28), 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),
+    ((2, 640, 8, 14, 14), 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),
+    ((2, 32, 16, 28, 28), 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 1, 1)),
+    ((2, 8, 8, 56, 56), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    ((2, 320, 2, 28, 28), 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),
+    ((1, 512, 4, 7, 7), 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    ((2, 64, 4, 14, 14), 64, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES + BIG_CASES)
+def test_conv_fwd(gpu, case):
+    kc.check_conv_fwd(gpu, *case)
+
+
+@pytest.mark.parametrize("case", CONV_CASES + BIG_CASES)
+def test_conv_dgrad(gpu, case):
+    kc.check_conv_dgrad(gpu, *case)
+
+
+@pytest.mark.parametrize("case", CONV_CASES + BIG_CASES)
+def test_conv_wgrad(gpu, case):
+    kc.check_conv_wgrad(gpu, *case)
+
+
+def test_conv_fused_input_bn(gpu):
+    kc.check_conv_fwd(gpu, (2, 64, 4, 14, 14), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), affine=True)
+    kc.check_conv_wgrad(gpu, (2, 64, 4, 14, 14), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), affine=True, out_scale=0.25)
+    kc.check_conv_fwd(gpu, (1, 16, 1, 6, 6), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), ldx_extra=8)
+    kc.check_conv_dgrad(gpu, (2, 16, 2, 9, 9), 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), resid=True)
+
+
+def test_conv_stem(gpu):
+    kc.check_conv_fwd(gpu, (2, 8, 2, 32, 32), 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), Cw=3)
+    kc.check_conv_fwd(gpu, (1, 8, 8, 32, 32), 8, (5, 7, 7), (1, 2, 2), (2, 3, 3), Cw=3)
+    kc.check_conv_wgrad(gpu, (2, 8, 2, 32, 32), 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), Cw=3)
+    kc.check_conv_wgrad(gpu, (1, 8, 8, 32, 32), 8, (5, 7, 7), (1, 2, 2), (2, 3, 3), Cw=3)
+
+
+def test_wgrad_scalar_fragment_path(gpu):
+    """The transpose-read (ds_read_b64_tr_b16) and the scalar LDS fragment paths must agree with torch."""
+    code = ("import torch; from tests import kernel_checks as kc; d=torch.device('cuda:0');"
+            "kc.check_conv_wgrad(d,(2,64,4,14,14),64,(1,3,3),(1,1,1),(0,1,1));"
+            "kc.check_conv_wgrad(d,(2,16,2,9,9),24,(1,1,1),(1,1,1),(0,0,0)); print('ok')")
+    env = dict(os.environ, SF_WGRAD_SCALAR="1")
+    env.pop("SFAMD_LIBRARY", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("shape,relu,residual", [
+    ((2, 16, 2, 5, 5), True, None),
+    ((4, 256, 4, 14, 14), True, True),
+    ((2, 2048, 2, 7, 7), True, True),
+    ((4, 8, 8, 28, 28), True, None),
+    ((2, 80, 4, 14, 14), False, True),
+    ((2, 64, 4, 28, 28), False, None),
+])
+def test_bn_chain(gpu, shape, relu, residual):
+    kc.check_bn_chain(gpu, shape, relu=relu, residual=residual)
+
+
+def test_pool(gpu):
+    kc.check_pool(gpu, (1, 8, 2, 9, 9))
+    kc.check_pool(gpu, (2, 64, 2, 56, 56))
+
+
+def test_layout(gpu):
+    kc.check_layout(gpu, (2, 3, 4, 32, 32))
+    kc.check_layout(gpu, (1, 16, 1, 4, 4))

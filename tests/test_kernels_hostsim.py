@@ -1,0 +1,78 @@
+"""CPU: every kernel + launcher of libsfamd executed through the host functional simulator."""
+import pytest
+
+from tests import kernel_checks as kc
+
+CONV_CASES = [
+    # in_shape (N,Ci,T,H,W), Co, kernel, stride, pad, dil
+    ((2, 16, 2, 5, 5), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),      # pointwise, M=100 < one tile
+    ((1, 32, 2, 6, 6), 64, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),      # strided shortcut conv
+    ((1, 16, 4, 4, 4), 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),      # temporal conv
+    ((1, 8, 2, 9, 9), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),        # spatial conv, M=162 (2 tiles)
+    ((1, 16, 1, 9, 9), 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),      # stride 2, Co=24 (masked cols)
+    ((1, 8, 1, 8, 8), 16, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),       # dilation 2
+    ((1, 8, 8, 3, 3), 16, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 1, 1)),       # FuseFastToSlow lateral
+    ((1, 80, 1, 4, 4), 136, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),     # Ci=80, two N tiles (136)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(sim, case):
+    kc.check_conv_fwd(sim, *case)
+
+
+def test_conv_fwd_fused_input_bn(sim):
+    kc.check_conv_fwd(sim, (1, 16, 1, 7, 7), 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), affine=True)
+
+
+def test_conv_fwd_channel_slice_input(sim):
+    kc.check_conv_fwd(sim, (1, 16, 1, 6, 6), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), ldx_extra=8)
+
+
+def test_conv_fwd_stem(sim):
+    # 3-channel clip zero-padded to 8 channels, weight has Cw=3
+    kc.check_conv_fwd(sim, (1, 8, 1, 12, 12), 8, (1, 7, 7), (1, 2, 2), (0, 3, 3), Cw=3)
+    kc.check_conv_fwd(sim, (1, 8, 5, 6, 6), 8, (5, 7, 7), (1, 2, 2), (2, 3, 3), Cw=3)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad(sim, case):
+    kc.check_conv_dgrad(sim, *case)
+
+
+def test_conv_dgrad_residual(sim):
+    kc.check_conv_dgrad(sim, (1, 16, 2, 5, 5), 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), resid=True)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad(sim, case):
+    kc.check_conv_wgrad(sim, *case)
+
+
+def test_conv_wgrad_fused_input_bn_and_scale(sim):
+    kc.check_conv_wgrad(sim, (1, 16, 1, 7, 7), 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), affine=True, out_scale=0.25)
+
+
+def test_conv_wgrad_stem(sim):
+    kc.check_conv_wgrad(sim, (1, 8, 1, 12, 12), 8, (1, 7, 7), (1, 2, 2), (0, 3, 3), Cw=3)
+
+
+
+@pytest.mark.parametrize("shape,relu,residual", [
+    ((2, 16, 2, 5, 5), True, None),
+    ((2, 8, 3, 7, 7), False, None),
+    ((1, 80, 2, 4, 4), True, True),
+    ((2, 24, 1, 6, 6), False, True),
+])
+def test_bn_chain(sim, shape, relu, residual):
+    kc.check_bn_chain(sim, shape, relu=relu, residual=residual)
+
+
+def test_pool(sim):
+    kc.check_pool(sim, (1, 8, 2, 9, 9))
+    kc.check_pool(sim, (2, 16, 1, 8, 8))
+
+
+def test_layout(sim):
+    kc.check_layout(sim, (2, 3, 2, 5, 5))
+    kc.check_layout(sim, (1, 16, 1, 4, 4))
