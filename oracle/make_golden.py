@@ -1,0 +1,96 @@
+"""Pin the CPU oracle to the real reference and write tests/golden/*.json (run in the build container).
+
+For each case: build the UNMODIFIED reference model (via oracle/refshim.py) from its own YAML + overrides,
+load deterministic parameters (oracle.video_ref.randomize_state), run forward + cross-entropy + backward
+on a seeded synthetic batch, run the oracle restatement on the same state_dict/batch, REQUIRE agreement
+to fp32 round-off, and store the reference's numbers (logits, loss, grad-norm, per-parameter grad norms,
+updated BN running statistics checksums).  The fixtures let the GPU box (which has no /root/reference)
+check the oracle -- and through it the HIP engine -- against the reference's own outputs.
+
+    python -m oracle.make_golden
+"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import refshim, video_ref  # noqa: E402
+
+TINY = ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 32,
+        "RESNET.WIDTH_PER_GROUP", 16, "RESNET.DEPTH", 18]
+CASES = {
+    # name: (reference yaml, overrides, batch)
+    "slowfast_tiny": ("configs/Kinetics/SLOWFAST_8x8_R50.yaml",
+                      TINY + ["DATA.NUM_FRAMES", 8, "SLOWFAST.BETA_INV", 2,
+                              "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2, 2], [2, 2], [2, 2], [2, 2]]"], 2),
+    "c2d_tiny": ("configs/Kinetics/C2D_8x8_R50.yaml",
+                 TINY + ["DATA.NUM_FRAMES", 4, "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2], [2], [2], [2]]"], 2),
+    "slow_tiny": ("configs/Kinetics/SLOW_8x8_R50.yaml",
+                  TINY + ["DATA.NUM_FRAMES", 4, "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2], [2], [2], [2]]"], 2),
+    # full-width R50 models at reduced clip size, batch chosen so every BatchNorm sees >= 100 samples
+    # (a BN over a handful of samples amplifies fp16 round-off and would test conditioning, not kernels)
+    "slowfast_r50_mid": ("configs/Kinetics/SLOWFAST_8x8_R50.yaml",
+                         ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96,
+                          "DATA.NUM_FRAMES", 16], 4),
+    "c2d_r50_mid": ("configs/Kinetics/C2D_8x8_R50.yaml",
+                    ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
+    "i3d_r50_mid": ("configs/Kinetics/I3D_8x8_R50.yaml",
+                    ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
+}
+
+
+def run_case(name):
+    yaml_rel, opts, batch = CASES[name]
+    cfg = refshim.reference_cfg(yaml_rel, opts)
+    torch.manual_seed(0)
+    model = refshim.reference_model(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = video_ref.randomize_state(shapes, seed=1234)
+    model.load_state_dict(sd)
+    model.train()
+    inputs, labels = video_ref.synthetic_batch(cfg, batch, seed=4321)
+    logits = model([x.clone() for x in inputs])
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    ref_grads = {k: p.grad for k, p in model.named_parameters()}
+    ref_stats = {k: v for k, v in model.state_dict().items() if "running" in k}
+
+    o_logits, o_loss, o_grads, o_stats = video_ref.loss_and_grads(sd, cfg, inputs, labels)
+    err = float((o_logits - logits.detach()).abs().max() / logits.detach().abs().max())
+    assert err < 1e-5, f"{name}: oracle logits differ from the reference ({err:.2e})"
+    assert abs(float(o_loss) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    worst = 0.0
+    for k, g in ref_grads.items():
+        e = float((o_grads[k] - g).abs().max() / (g.abs().max() + 1e-12))
+        worst = max(worst, e)
+    assert worst < 1e-4, f"{name}: oracle gradients differ from the reference ({worst:.2e})"
+    for k, v in ref_stats.items():
+        assert torch.allclose(o_stats[k], v, rtol=1e-5, atol=1e-6), k
+    gn = float(video_ref.grad_norm(ref_grads))
+    print(f"{name}: params {sum(v.numel() for v in ref_grads.values())/1e6:.3f} M  loss {float(loss):.6f}  "
+          f"grad_norm {gn:.6f}  oracle-vs-reference logits {err:.1e} grads {worst:.1e}")
+    return {
+        "reference_yaml": yaml_rel, "opts": opts, "batch": batch, "param_seed": 1234, "data_seed": 4321,
+        "logits": logits.detach().tolist(), "loss": float(loss), "grad_norm": gn,
+        "param_grad_norms": {k: float(g.norm()) for k, g in ref_grads.items()},
+        "running_stat_sums": {k: float(v.double().sum()) for k, v in ref_stats.items()},
+        "num_params": sum(v.numel() for v in ref_grads.values()),
+        "torch_version": torch.__version__,
+    }
+
+
+def main():
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    for name in CASES:
+        rec = run_case(name)
+        with open(os.path.join(out_dir, name + ".json"), "w") as f:
+            json.dump(rec, f)
+    print("wrote", out_dir)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""Import shim for the UNMODIFIED reference (TEST INFRASTRUCTURE; only used in the build container).
+
+`install()` makes ``/root/reference/slowfast/{models,config}`` importable on a machine that lacks the
+reference's un-vendored third-party packages (fvcore, pytorchvideo, detectron2, iopath, ...), by
+registering small stand-ins for exactly the symbols its model code imports (SURVEY.md 8c lists them):
+  fvcore.common.config.CfgNode     -> slowfast_amd.config.CfgNode (yacs-compatible subset)
+  fvcore.common.registry.Registry  -> slowfast_amd.registry.Registry
+  fvcore.nn.weight_init            -> c2_msra_fill = kaiming_normal_(fan_out, relu); c2_xavier_fill = kaiming_uniform_(a=1)
+  pytorchvideo.layers.swish.Swish, pytorchvideo.layers.batch_norm.NaiveSyncBatchNorm{1d,3d} (import-time only)
+  pytorchvideo.losses.soft_target_cross_entropy.SoftTargetCrossEntropyLoss
+  detectron2.layers.ROIAlign (import-time only), slowfast.utils.logging -> stdlib logging
+``slowfast`` and ``slowfast.models`` are pre-seeded as path-only packages so that their __init__.py
+(which drags in cv2 / torchvision through the SSL models) is bypassed.  Nothing here is shipped with
+or imported by the product package; it does not exist on the GPU box and no `-m gpu` test needs it.
+"""
+import logging as _pylogging
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("SLOWFAST_REFERENCE", "/root/reference")
+
+
+def available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "slowfast", "models"))
+
+
+def _module(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _package(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def install():
+    if "slowfast.models.video_model_builder" in sys.modules:
+        return
+    if not available():
+        raise RuntimeError(f"reference tree not found under {REFERENCE_ROOT}")
+    import torch
+    import torch.nn as nn
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    from slowfast_amd.config import CfgNode
+    from slowfast_amd.registry import Registry
+
+    class _RefCfgNode(CfgNode):
+        """yacs semantics the reference relies on: new keys only via merge of known keys."""
+
+    def c2_msra_fill(module):
+        nn.init.kaiming_normal_(module.weight, mode="fan_out", nonlinearity="relu")
+        if module.bias is not None:
+            nn.init.constant_(module.bias, 0)
+
+    def c2_xavier_fill(module):
+        nn.init.kaiming_uniform_(module.weight, a=1)
+        if module.bias is not None:
+            nn.init.constant_(module.bias, 0)
+
+    class Swish(nn.Module):
+        def forward(self, x):
+            return x * torch.sigmoid(x)
+
+    class SoftTargetCrossEntropyLoss(nn.Module):
+        def __init__(self, ignore_index=-100, reduction="mean", normalize_targets=True):
+            super().__init__()
+            self.reduction, self.normalize_targets = reduction, normalize_targets
+
+        def forward(self, x, target):
+            if self.normalize_targets:
+                target = target / (target.sum(-1, keepdim=True) + 1e-6)
+            loss = torch.sum(-target * torch.nn.functional.log_softmax(x, dim=-1), dim=-1)
+            return loss.mean() if self.reduction == "mean" else loss
+
+    class _ImportOnly(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError("stand-in for an un-vendored dependency (import-time only)")
+
+    _module("fvcore")
+    _module("fvcore.common")
+    _module("fvcore.common.config", CfgNode=_RefCfgNode)
+    _module("fvcore.common.registry", Registry=Registry)
+    _module("fvcore.nn")
+    _module("fvcore.nn.weight_init", c2_msra_fill=c2_msra_fill, c2_xavier_fill=c2_xavier_fill)
+    _module("pytorchvideo")
+    _module("pytorchvideo.layers")
+    _module("pytorchvideo.layers.swish", Swish=Swish)
+    _module("pytorchvideo.layers.batch_norm", NaiveSyncBatchNorm1d=_ImportOnly, NaiveSyncBatchNorm3d=_ImportOnly)
+    _module("pytorchvideo.losses")
+    _module("pytorchvideo.losses.soft_target_cross_entropy", SoftTargetCrossEntropyLoss=SoftTargetCrossEntropyLoss)
+    _module("detectron2")
+    _module("detectron2.layers", ROIAlign=_ImportOnly)
+
+    ref = os.path.join(REFERENCE_ROOT, "slowfast")
+    _package("slowfast", ref)
+    _package("slowfast.models", os.path.join(ref, "models"))
+    _package("slowfast.utils", os.path.join(ref, "utils"))
+    _package("slowfast.config", os.path.join(ref, "config"))
+    log = _module("slowfast.utils.logging", get_logger=_pylogging.getLogger)
+    sys.modules["slowfast.utils"].logging = log
+
+    import slowfast.models.video_model_builder  # noqa: F401  (registers SlowFast / ResNet / X3D / MViT)
+
+
+def reference_cfg(yaml_rel, opts=()):
+    """get_cfg() of the reference + one of its YAML files + KEY VALUE overrides."""
+    install()
+    from slowfast.config.defaults import get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REFERENCE_ROOT, yaml_rel))
+    if opts:
+        cfg.merge_from_list(list(opts))
+    return cfg
+
+
+def reference_model(cfg):
+    install()
+    from slowfast.models.build import MODEL_REGISTRY
+    return MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)

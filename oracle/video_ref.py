@@ -1,0 +1,169 @@
+"""CPU restatement (plain torch fp32/fp64) of the reference's ResNet / SlowFast forward graph.
+
+TEST INFRASTRUCTURE: the oracle the HIP engine is checked against.  It is pinned to the real
+reference by oracle/make_golden.py (run in the build container, where /root/reference is importable):
+logits, loss and every parameter gradient agree with the unmodified reference model to fp32 round-off,
+and the values are committed under tests/golden/.  Each function cites the reference lines it follows.
+
+The graph is driven by a flat ``state_dict`` (reference key names) and the cfg; every op is the torch
+functional the reference's nn.Module would dispatch to, so autograd gives the reference backward.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _bn(x, sd, prefix, training, stats_out, momentum=0.1, eps=1e-5):
+    """nn.BatchNorm3d (slowfast/models/batchnorm_helper.py:24-25 -> torch BatchNorm3d; eps/momentum as passed at
+    every construction site, e.g. resnet_helper.py:340-342)."""
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if training:
+        rm, rv = rm.clone(), rv.clone()
+        y = F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"], True, momentum, eps)
+        if stats_out is not None:
+            stats_out[prefix + ".running_mean"], stats_out[prefix + ".running_var"] = rm, rv
+        return y
+    return F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"], False, momentum, eps)
+
+
+def stem(x, sd, prefix, training, stats_out):
+    """ResNetBasicStem.forward: conv -> bn -> relu -> MaxPool3d([1,3,3],[1,2,2],[0,1,1]) (stem_helper.py:182-201)."""
+    w = sd[prefix + ".conv.weight"]
+    kt = w.shape[2]
+    x = F.conv3d(x, w, None, (1, 2, 2), (kt // 2, 3, 3))
+    x = F.relu(_bn(x, sd, prefix + ".bn", training, stats_out))
+    return F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+
+
+def fuse(xs, xf, sd, prefix, alpha, training, stats_out):
+    """FuseFastToSlow.forward (video_model_builder.py:162-169): time-strided conv on Fast, BN, ReLU, concat."""
+    w = sd[prefix + ".conv_f2s.weight"]
+    k = w.shape[2]
+    f = F.conv3d(xf, w, None, (alpha, 1, 1), (k // 2, 0, 0))
+    f = F.relu(_bn(f, sd, prefix + ".bn", training, stats_out))
+    return torch.cat([xs, f], 1)
+
+
+def res_block(x, sd, prefix, stride, dilation, stride_1x1, training, stats_out):
+    """ResBlock.forward (resnet_helper.py:512-521) around BottleneckTransform.forward (:377-392)."""
+    s_a, s_b = (stride, 1) if stride_1x1 else (1, stride)
+    b2 = prefix + ".branch2"
+    wa = sd[b2 + ".a.weight"]
+    kt = wa.shape[2]
+    y = F.conv3d(x, wa, None, (1, s_a, s_a), (kt // 2, 0, 0))
+    y = F.relu(_bn(y, sd, b2 + ".a_bn", training, stats_out))
+    y = F.conv3d(y, sd[b2 + ".b.weight"], None, (1, s_b, s_b), (0, dilation, dilation), (1, dilation, dilation))
+    y = F.relu(_bn(y, sd, b2 + ".b_bn", training, stats_out))
+    y = F.conv3d(y, sd[b2 + ".c.weight"])
+    y = _bn(y, sd, b2 + ".c_bn", training, stats_out)
+    if prefix + ".branch1.weight" in sd:
+        sc = F.conv3d(x, sd[prefix + ".branch1.weight"], None, (1, stride, stride))
+        sc = _bn(sc, sd, prefix + ".branch1_bn", training, stats_out)
+    else:
+        sc = x
+    return F.relu(sc + y)
+
+
+def res_stage(xs, sd, name, strides, dilations, stride_1x1, training, stats_out):
+    """ResStage.forward (resnet_helper.py:697-726) without Nonlocal blocks."""
+    out = []
+    for p, x in enumerate(xs):
+        i = 0
+        while f"{name}.pathway{p}_res{i}.branch2.a.weight" in sd:
+            x = res_block(x, sd, f"{name}.pathway{p}_res{i}", strides[p] if i == 0 else 1, dilations[p], stride_1x1,
+                          training, stats_out)
+            i += 1
+        out.append(x)
+    return out
+
+
+_POOL1_T = {"2d": 1, "c2d": 2, "slow_c2d": 1, "i3d": 2, "slow_i3d": 1, "slow": 1, "slowfast": 1}
+
+
+def video_forward(sd, cfg, inputs, training=True, stats_out=None):
+    """SlowFast.forward (video_model_builder.py:423-441) / ResNet.forward (:645-660) + ResNetBasicHead.forward
+    (head_helper.py:305-350).  Dropout is not applied (the parity harness sets MODEL.DROPOUT_RATE 0)."""
+    P = len(inputs)
+    two = P == 2
+    x = [stem(inputs[p], sd, f"s1.pathway{p}_stem", training, stats_out) for p in range(P)]
+    if two:
+        x[0] = fuse(x[0], x[1], sd, "s1_fuse", cfg.SLOWFAST.ALPHA, training, stats_out)
+    for i in range(4):
+        name = f"s{i + 2}"
+        x = res_stage(x, sd, name, cfg.RESNET.SPATIAL_STRIDES[i], cfg.RESNET.SPATIAL_DILATIONS[i],
+                      cfg.RESNET.STRIDE_1X1, training, stats_out)
+        if i == 0:
+            pt = _POOL1_T[cfg.MODEL.ARCH]
+            if pt != 1:
+                x = [F.max_pool3d(v, (pt, 1, 1), (pt, 1, 1)) for v in x]
+        if two and i < 3:
+            x[0] = fuse(x[0], x[1], sd, f"{name}_fuse", cfg.SLOWFAST.ALPHA, training, stats_out)
+    crop = cfg.DATA.TRAIN_CROP_SIZE // 32
+    frames = [cfg.DATA.NUM_FRAMES // cfg.SLOWFAST.ALPHA, cfg.DATA.NUM_FRAMES] if two else \
+        [cfg.DATA.NUM_FRAMES // _POOL1_T[cfg.MODEL.ARCH]]
+    feats = [F.avg_pool3d(v, (frames[p], crop, crop), 1) for p, v in enumerate(x)]
+    z = torch.cat(feats, 1).permute(0, 2, 3, 4, 1)
+    z = F.linear(z, sd["head.projection.weight"], sd["head.projection.bias"])
+    if not training:
+        if cfg.MODEL.HEAD_ACT == "softmax":
+            z = F.softmax(z, dim=4)
+        elif cfg.MODEL.HEAD_ACT == "sigmoid":
+            z = torch.sigmoid(z)
+        z = z.mean([1, 2, 3])
+    return z.reshape(z.shape[0], -1)
+
+
+# ------------------------------------------------------------------------------------------------
+def randomize_state(shapes, seed, dtype=torch.float32):
+    """Deterministic non-degenerate parameters/buffers for parity runs, keyed by reference state_dict names.
+
+    Fresh reference init would zero every block-final BN gamma (RESNET.ZERO_INIT_FINAL_BN), which
+    makes gradients vanish; this fills BN affine/running statistics with generic values instead."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in shapes.items():
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.zeros((), dtype=torch.long)
+        elif name.endswith("running_mean"):
+            sd[name] = (torch.randn(shape, generator=g) * 0.1).to(dtype)
+        elif name.endswith("running_var"):
+            sd[name] = (torch.rand(shape, generator=g) + 0.5).to(dtype)
+        elif len(shape) == 5:   # Conv3d weight: fan-in scaled so activations stay O(1)
+            fan_in = shape[1] * shape[2] * shape[3] * shape[4]
+            sd[name] = (torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5).to(dtype)
+        elif len(shape) == 2:   # Linear weight
+            sd[name] = (torch.randn(shape, generator=g) * 0.05).to(dtype)
+        elif "bn" in name and name.endswith(".weight"):
+            sd[name] = (torch.rand(shape, generator=g) + 0.5).to(dtype)
+        else:                   # biases
+            sd[name] = (torch.randn(shape, generator=g) * 0.1).to(dtype)
+    return sd
+
+
+def synthetic_batch(cfg, batch, seed, num_classes=None):
+    """Kinetics-shaped synthetic clips: x = randn(B,3,T,S,S); SlowFast slow pathway =
+    index_select(fast, 2, linspace(0, T-1, T//alpha)) (slowfast/datasets/utils.py:96-102); integer labels."""
+    g = torch.Generator().manual_seed(seed)
+    T, S = cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE
+    fast = torch.randn((batch, 3, T, S, S), generator=g)
+    labels = torch.randint(0, num_classes or cfg.MODEL.NUM_CLASSES, (batch,), generator=g)
+    if len(cfg.DATA.INPUT_CHANNEL_NUM) == 2:
+        idx = torch.linspace(0, T - 1, T // cfg.SLOWFAST.ALPHA).long()
+        return [torch.index_select(fast, 2, idx), fast], labels
+    return [fast], labels
+
+
+def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32):
+    """Training-mode forward + mean cross-entropy + backward; returns logits, loss, {name: grad}, new running stats."""
+    params = {k: v.detach().to(dtype).clone().requires_grad_(v.is_floating_point() and "running" not in k)
+              for k, v in sd.items() if v.is_floating_point()}
+    stats = {}
+    logits = video_forward(params, cfg, [x.to(dtype) for x in inputs], training=True, stats_out=stats)
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    grads = {k: v.grad for k, v in params.items() if v.requires_grad}
+    return logits.detach(), loss.detach(), grads, stats
+
+
+def grad_norm(grads):
+    """Global L2 norm of all parameter gradients (slowfast/models/optimizer.py:362-379 get_grad_norm_)."""
+    return torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()))

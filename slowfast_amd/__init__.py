@@ -1,0 +1,10 @@
+"""slowfast_amd -- MI355X-native forward/backward engine for the PySlowFast video backbones.
+
+Hand-written gfx950 HIP kernels behind a C ABI (include/sfamd.h, csrc/), wrapped as torch.nn.Module
+drop-ins with the reference's constructor signatures, cfg keys and state_dict names.
+"""
+from .config import CfgNode, get_cfg, get_preset  # noqa: F401
+from .registry import MODEL_REGISTRY, build_model  # noqa: F401
+
+__version__ = "0.1.0"
+from . import video_models  # noqa: F401,E402  (registers SlowFast / ResNet in MODEL_REGISTRY)

@@ -1,0 +1,170 @@
+"""Configuration node for the hot path.
+
+A small yacs-style attribute tree with the reference's key names and default values for every key the
+video-backbone path reads (slowfast/config/defaults.py: MODEL.* :393-441, RESNET.* :293-327,
+SLOWFAST.* :633-648, NONLOCAL.* :363-385, BN.* :99-126, DATA.* :666-716, SOLVER.* :812-878).
+It loads the reference's own YAML files unchanged (including string-encoded tuples such as
+``PATCH_KERNEL: (3, 7, 7)``); keys outside the hot path are accepted and kept, not interpreted.
+When the reference package is installed, its ``CfgNode`` can be passed to every constructor here
+instead -- only attribute access is used.
+"""
+import ast
+import copy
+
+import yaml
+
+
+class CfgNode(dict):
+    def __init__(self, init=None):
+        super().__init__()
+        for k, v in (init or {}).items():
+            self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    @staticmethod
+    def _coerce(value):
+        if isinstance(value, str):
+            try:
+                return ast.literal_eval(value)
+            except (ValueError, SyntaxError):
+                return value
+        return value
+
+    def merge_from_dict(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict):
+                if k not in self or not isinstance(self[k], CfgNode):
+                    self[k] = CfgNode()
+                self[k].merge_from_dict(v)
+            else:
+                v = self._coerce(v)
+                if isinstance(v, tuple) and isinstance(self.get(k), list):
+                    v = list(v)
+                self[k] = v
+
+    def merge_from_file(self, path):
+        with open(path) as f:
+            self.merge_from_dict(yaml.safe_load(f) or {})
+
+    def merge_from_list(self, opts):
+        assert len(opts) % 2 == 0, "opts must be KEY VALUE pairs"
+        for key, value in zip(opts[0::2], opts[1::2]):
+            node = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                if p not in node:
+                    node[p] = CfgNode()
+                node = node[p]
+            node[parts[-1]] = self._coerce(value)
+
+    def dump(self):
+        def plain(n):
+            return {k: plain(v) if isinstance(v, CfgNode) else v for k, v in n.items()}
+        return yaml.safe_dump(plain(self))
+
+
+_DEFAULTS = {
+    "BN": {"USE_PRECISE_STATS": False, "NUM_BATCHES_PRECISE": 200, "WEIGHT_DECAY": 0.0, "NORM_TYPE": "batchnorm",
+           "NUM_SPLITS": 1, "NUM_SYNC_DEVICES": 1, "GLOBAL_SYNC": False},
+    "TRAIN": {"ENABLE": True, "DATASET": "kinetics", "BATCH_SIZE": 64, "MIXED_PRECISION": False},
+    "TEST": {"ENABLE": True, "DATASET": "kinetics", "BATCH_SIZE": 8},
+    "RESNET": {"TRANS_FUNC": "bottleneck_transform", "NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "INPLACE_RELU": True,
+               "STRIDE_1X1": False, "ZERO_INIT_FINAL_BN": False, "ZERO_INIT_FINAL_CONV": False, "DEPTH": 50,
+               "NUM_BLOCK_TEMP_KERNEL": [[3], [4], [6], [3]], "SPATIAL_STRIDES": [[1], [2], [2], [2]],
+               "SPATIAL_DILATIONS": [[1], [1], [1], [1]]},
+    "NONLOCAL": {"LOCATION": [[[]], [[]], [[]], [[]]], "GROUP": [[1], [1], [1], [1]], "INSTANTIATION": "dot_product",
+                 "POOL": [[[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]],
+                          [[1, 2, 2], [1, 2, 2]]]},
+    "MODEL": {"ARCH": "slowfast", "MODEL_NAME": "SlowFast", "NUM_CLASSES": 400, "LOSS_FUNC": "cross_entropy",
+              "SINGLE_PATHWAY_ARCH": ["2d", "c2d", "i3d", "slow", "x3d", "mvit", "maskmvit"],
+              "MULTI_PATHWAY_ARCH": ["slowfast"], "DROPOUT_RATE": 0.5, "DROPCONNECT_RATE": 0.0, "FC_INIT_STD": 0.01,
+              "HEAD_ACT": "softmax", "ACT_CHECKPOINT": False, "DETACH_FINAL_FC": False, "FROZEN_BN": False,
+              "FP16_ALLREDUCE": False},
+    "SLOWFAST": {"BETA_INV": 8, "ALPHA": 8, "FUSION_CONV_CHANNEL_RATIO": 2, "FUSION_KERNEL_SZ": 5},
+    "DATA": {"NUM_FRAMES": 8, "SAMPLING_RATE": 8, "MEAN": [0.45, 0.45, 0.45], "INPUT_CHANNEL_NUM": [3, 3],
+             "STD": [0.225, 0.225, 0.225], "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256},
+    "SOLVER": {"BASE_LR": 0.1, "MOMENTUM": 0.9, "DAMPENING": 0.0, "NESTEROV": True, "WEIGHT_DECAY": 1e-4,
+               "OPTIMIZING_METHOD": "sgd", "ZERO_WD_1D_PARAM": False, "CLIP_GRAD_VAL": None,
+               "CLIP_GRAD_L2NORM": None, "LAYER_DECAY": 1.0},
+    "DETECTION": {"ENABLE": False, "ALIGNED": True, "SPATIAL_SCALE_FACTOR": 16, "ROI_XFORM_RESOLUTION": 7},
+    "MULTIGRID": {"SHORT_CYCLE": False, "LONG_CYCLE": False},
+    "CONTRASTIVE": {"NUM_MLP_LAYERS": 1, "MLP_DIM": 2048, "BN_MLP": False, "BN_SYNC_MLP": False,
+                    "PREDICTOR_DEPTHS": []},
+    "NUM_GPUS": 1, "NUM_SHARDS": 1, "SHARD_ID": 0, "RNG_SEED": 1, "LOG_MODEL_INFO": True, "DIST_BACKEND": "nccl",
+    "OUTPUT_DIR": ".",
+}
+
+
+def get_cfg():
+    """Defaults of the hot-path keys (values as in slowfast/config/defaults.py)."""
+    return CfgNode(copy.deepcopy(_DEFAULTS))
+
+
+# The two Kinetics configs named by BASELINE.json, as overlays on the defaults
+# (values from configs/Kinetics/SLOWFAST_8x8_R50.yaml and configs/Kinetics/C2D_8x8_R50.yaml).
+PRESETS = {
+    "SLOWFAST_8x8_R50": {
+        "DATA": {"NUM_FRAMES": 32, "SAMPLING_RATE": 2, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256,
+                 "INPUT_CHANNEL_NUM": [3, 3]},
+        "SLOWFAST": {"ALPHA": 4, "BETA_INV": 8, "FUSION_CONV_CHANNEL_RATIO": 2, "FUSION_KERNEL_SZ": 7},
+        "RESNET": {"ZERO_INIT_FINAL_BN": True, "WIDTH_PER_GROUP": 64, "NUM_GROUPS": 1, "DEPTH": 50,
+                   "TRANS_FUNC": "bottleneck_transform", "STRIDE_1X1": False,
+                   "NUM_BLOCK_TEMP_KERNEL": [[3, 3], [4, 4], [6, 6], [3, 3]],
+                   "SPATIAL_STRIDES": [[1, 1], [2, 2], [2, 2], [2, 2]],
+                   "SPATIAL_DILATIONS": [[1, 1], [1, 1], [1, 1], [1, 1]]},
+        "NONLOCAL": {"LOCATION": [[[], []], [[], []], [[], []], [[], []]],
+                     "GROUP": [[1, 1], [1, 1], [1, 1], [1, 1]], "INSTANTIATION": "dot_product"},
+        "MODEL": {"NUM_CLASSES": 400, "ARCH": "slowfast", "MODEL_NAME": "SlowFast", "LOSS_FUNC": "cross_entropy",
+                  "DROPOUT_RATE": 0.5},
+    },
+    "C2D_8x8_R50": {
+        "DATA": {"NUM_FRAMES": 8, "SAMPLING_RATE": 8, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256,
+                 "INPUT_CHANNEL_NUM": [3]},
+        "RESNET": {"ZERO_INIT_FINAL_BN": True, "WIDTH_PER_GROUP": 64, "NUM_GROUPS": 1, "DEPTH": 50,
+                   "TRANS_FUNC": "bottleneck_transform", "STRIDE_1X1": False,
+                   "NUM_BLOCK_TEMP_KERNEL": [[3], [4], [6], [3]]},
+        "NONLOCAL": {"LOCATION": [[[]], [[]], [[]], [[]]], "GROUP": [[1], [1], [1], [1]],
+                     "INSTANTIATION": "softmax"},
+        "MODEL": {"NUM_CLASSES": 400, "ARCH": "c2d", "MODEL_NAME": "ResNet", "LOSS_FUNC": "cross_entropy",
+                  "DROPOUT_RATE": 0.5},
+    },
+}
+
+
+def _variant(base, **model):
+    v = copy.deepcopy(PRESETS[base])
+    v["MODEL"].update(model)
+    return v
+
+
+PRESETS["SLOW_8x8_R50"] = _variant("C2D_8x8_R50", ARCH="slow")      # configs/Kinetics/SLOW_8x8_R50.yaml
+PRESETS["SLOW_8x8_R50"]["NONLOCAL"]["INSTANTIATION"] = "dot_product"
+PRESETS["I3D_8x8_R50"] = _variant("C2D_8x8_R50", ARCH="i3d")        # configs/Kinetics/I3D_8x8_R50.yaml
+
+
+def preset_for_yaml(yaml_rel):
+    """Preset name for a reference YAML path such as 'configs/Kinetics/SLOWFAST_8x8_R50.yaml'."""
+    import os
+    name = os.path.splitext(os.path.basename(yaml_rel))[0]
+    if name not in PRESETS:
+        raise KeyError(f"no built-in preset for {yaml_rel}; load the YAML with CfgNode.merge_from_file")
+    return name
+
+
+def get_preset(name, opts=()):
+    cfg = get_cfg()
+    cfg.merge_from_dict(PRESETS[name])
+    if opts:
+        cfg.merge_from_list(list(opts))
+    return cfg

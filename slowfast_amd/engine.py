@@ -1,0 +1,290 @@
+"""Forward/backward engine: the fused block schedules and their hand-written backward passes.
+
+Granularity: one ``torch.autograd.Function`` per reference block (stem, FuseFastToSlow, ResBlock).
+Inside a block nothing goes through ATen or the autograd tape: the Function runs a fixed schedule of
+libsfamd kernels in forward and the mirrored schedule in backward (recomputing BN+ReLU on the fly
+from the raw conv outputs it saved).  Autograd only chains blocks.
+
+Fusion plan per bottleneck block (reference graph: slowfast/models/resnet_helper.py:377-392, :512-521):
+
+    forward   ya = conv_a(x)            [+ per-channel sum/sumsq in the epilogue]
+              yb = conv_b(relu(bn_a(ya)))    BN+ReLU of `a` applied while loading conv_b's operand
+              yc = conv_c(relu(bn_b(yb)))
+              out = relu(bn_c(yc) + shortcut)      shortcut = x | bn_1(conv_1(x)), one elementwise pass
+    backward  (dyc[, dy1|g]) <- BN backward of dout masked by (out > 0)
+              wgrad_c / dgrad_c with relu(bn_b(yb)) recomputed on the fly, ... down to
+              dx = dgrad_a(dya) + (g | dgrad_1(dy1))      residual add fused in the dgrad epilogue
+
+Parameter gradients are written straight into ``param.grad`` (fp32; accumulated when it already
+exists, which is how GradReducer's flat bucket views receive them) and ``grad_ready`` listeners are
+told which parameters are final, so the gradient all-reduce can overlap the rest of backward.
+"""
+import torch
+
+from . import ops
+
+_f16 = torch.float16
+_listeners = []
+
+
+def add_grad_ready_listener(fn):
+    _listeners.append(fn)
+    return fn
+
+
+def remove_grad_ready_listener(fn):
+    if fn in _listeners:
+        _listeners.remove(fn)
+
+
+def _notify(params):
+    for fn in _listeners:
+        fn(params)
+
+
+def as_cl(t):
+    """Gradients/activations entering a block from torch code may be fp32 or NCTHW-contiguous."""
+    if t.dtype == _f16 and ops.is_cl(t):
+        return t
+    return ops.to_cl(t)
+
+
+def _grad_dest(param):
+    """(tensor to write d(loss)/d(param) into, whether the kernel must clear it first)."""
+    if param.grad is not None:
+        assert param.grad.dtype == torch.float32 and param.grad.is_contiguous()
+        return param.grad, False
+    g = torch.empty_like(param, memory_format=torch.contiguous_format)
+    param.grad = g
+    return g, True
+
+
+class BNState:
+    __slots__ = ("scale", "shift", "mean", "rstd")
+
+    def __init__(self, scale, shift, mean, rstd):
+        self.scale, self.shift, self.mean, self.rstd = scale, shift, mean, rstd
+
+
+class ConvUnit:
+    """Binds an nn.Conv3d (+ its nn.BatchNorm3d) parameter container to the conv/BN kernels.
+
+    The nn modules stay plain parameter holders so state_dict keys, weight init
+    (slowfast/utils/weight_init_helper.py:10-54) and optimizer param grouping
+    (slowfast/models/optimizer.py:41-56) of the reference keep working on the drop-ins."""
+
+    def __init__(self, conv, bn=None):
+        assert conv.groups == 1, "grouped convolutions are handled by the depthwise path, not the implicit GEMM"
+        assert conv.padding_mode == "zeros"
+        assert bn is None or bn.momentum is not None, "cumulative-average BatchNorm is not supported"
+        self.conv, self.bn = conv, bn
+        self._geoms = {}
+        self._wkey, self._w = None, None
+
+    def geom(self, in_shape):
+        key = tuple(in_shape)
+        g = self._geoms.get(key)
+        if g is None:
+            c = self.conv
+            g = ops.ConvGeom(key, c.out_channels, c.kernel_size, c.stride, c.padding, c.dilation, Cw=c.in_channels)
+            self._geoms[key] = g
+        return g
+
+    def weights(self, geom):
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version, geom.Ci, w.device)
+        if self._wkey != key:
+            self._w = ops.prep_weights(w.detach(), geom, need_dgrad=(geom.Cw == geom.Ci))
+            self._wkey = key
+        return self._w
+
+    def forward(self, x, in_affine, training):
+        geom = self.geom(x.shape)
+        wf, _ = self.weights(geom)
+        bn = self.bn
+        if bn is None:
+            y, _ = ops.conv_fwd(x, wf, geom, in_affine=in_affine, bias=self.conv.bias, stats=False)
+            return y, None
+        assert self.conv.bias is None
+        use_batch_stats = training or bn.running_mean is None
+        y, part = ops.conv_fwd(x, wf, geom, in_affine=in_affine, stats=use_batch_stats)
+        track = bn.track_running_stats and training
+        st = ops.bn_finalize(part, geom.out_rows, bn.weight, bn.bias, bn.running_mean if track or not use_batch_stats else None,
+                             bn.running_var if track or not use_batch_stats else None, bn.momentum, bn.eps,
+                             training=use_batch_stats)
+        return y, BNState(*st)
+
+    def backward(self, x, in_affine, dy, need_dx, resid=None):
+        """Weight gradient into conv.weight.grad; returns dx (+ resid) when need_dx."""
+        geom = self.geom(x.shape)
+        w = self.conv.weight
+        if w.requires_grad:
+            dw, zero_first = _grad_dest(w)
+            ops.conv_wgrad(x, dy, geom, dw, in_affine=in_affine, out_scale=1.0, zero_first=zero_first)
+        if not need_dx:
+            return None
+        _, wd = self.weights(geom)
+        return ops.conv_dgrad(dy, wd, geom, resid=resid)
+
+    def bn_backward(self, dz, y, st, zmask=None, relu_self=False, want_g=False):
+        """BatchNorm3d backward (through ReLU) -> dy; writes bn.weight.grad / bn.bias.grad."""
+        bn = self.bn
+        if bn.weight.requires_grad:
+            dgamma, zg = _grad_dest(bn.weight)
+            dbeta, zb = _grad_dest(bn.bias)
+            assert zg == zb
+            accumulate = not zg
+        else:
+            dgamma = torch.empty_like(bn.weight)
+            dbeta = torch.empty_like(bn.bias)
+            accumulate = False
+        return ops.bn_bwd(dz, y, bn.weight, st.mean, st.rstd, dgamma, dbeta, zmask=zmask,
+                          relu_affine=(st.scale, st.shift) if relu_self else None, inv_loss_scale=1.0,
+                          accumulate=accumulate, want_g=want_g)
+
+    def params(self):
+        p = [self.conv.weight]
+        if self.conv.bias is not None:
+            p.append(self.conv.bias)
+        if self.bn is not None:
+            p += [self.bn.weight, self.bn.bias]
+        return p
+
+
+# ------------------------------------------------------------------------------------------------
+class StemFn(torch.autograd.Function):
+    """conv -> BN -> ReLU -> MaxPool3d([1,k,k]) (slowfast/models/stem_helper.py:196-201)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        unit = mod._unit
+        xcl = ops.to_cl(x)
+        y, st = unit.forward(xcl, None, mod.training)
+        k, s, p = mod.pool_layer.kernel_size, mod.pool_layer.stride, mod.pool_layer.padding
+        assert k[0] == 1 and s[0] == 1 and p[0] == 0, "stem pooling is spatial-only in every reference config"
+        out = ops.pool_fwd(y, k[1:], s[1:], p[1:], affine=(st.scale, st.shift, True))
+        ctx.mod, ctx.xcl, ctx.y, ctx.st = mod, xcl, y, st
+        ctx.pool = (tuple(k[1:]), tuple(s[1:]), tuple(p[1:]))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        unit = ctx.mod._unit
+        st = ctx.st
+        g = ops.pool_bwd(ctx.y, as_cl(dout), *ctx.pool, affine=(st.scale, st.shift, True))
+        dy = unit.bn_backward(g, ctx.y, st)
+        unit.backward(ctx.xcl, None, dy, need_dx=False)
+        _notify(unit.params())
+        ctx.xcl = ctx.y = None
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class FuseFn(torch.autograd.Function):
+    """FuseFastToSlow: cat([x_s, relu(bn(conv_f2s(x_f)))], 1) (video_model_builder.py:162-169).
+
+    The lateral branch is written directly into its channel slice of the concatenated buffer."""
+
+    @staticmethod
+    def forward(ctx, x_s, x_f, mod, *params):
+        unit = mod._unit
+        x_s, x_f = as_cl(x_s), as_cl(x_f)
+        yf, st = unit.forward(x_f, None, mod.training)
+        N, Cs, T, H, W = x_s.shape
+        Cf = yf.shape[1]
+        assert tuple(yf.shape) == (N, Cf, T, H, W), "lateral connection does not match the Slow pathway shape"
+        cat = ops.cl_empty((N, Cs + Cf, T, H, W), x_s.device)
+        ops.bn_act(x_s, out=cat[:, :Cs])
+        ops.bn_act(yf, st.scale, st.shift, relu=True, out=cat[:, Cs:])
+        ctx.mod, ctx.yf, ctx.st, ctx.Cs = mod, yf, st, Cs
+        ctx.save_for_backward(x_f)
+        return cat, x_f.view_as(x_f)
+
+    @staticmethod
+    def backward(ctx, dcat, dxf):
+        unit = ctx.mod._unit
+        (x_f,) = ctx.saved_tensors
+        dcat = as_cl(dcat)
+        dyf = unit.bn_backward(dcat[:, ctx.Cs:], ctx.yf, ctx.st, relu_self=True)
+        need_dx = ctx.needs_input_grad[1]
+        dx_f = unit.backward(x_f, None, dyf, need_dx=need_dx, resid=as_cl(dxf) if dxf is not None else None)
+        _notify(unit.params())
+        ctx.yf = None
+        dx_s = dcat[:, :ctx.Cs] if ctx.needs_input_grad[0] else None
+        return (dx_s, dx_f, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class ResBlockFn(torch.autograd.Function):
+    """relu(shortcut(x) + bottleneck(x)) (slowfast/models/resnet_helper.py:377-392, 512-521)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        x = as_cl(x)
+        t = mod.branch2
+        A, B, C, P = t._a, t._b, t._c, mod._proj
+        tr = mod.training
+        ya, sa = A.forward(x, None, tr)
+        yb, sb = B.forward(ya, (sa.scale, sa.shift, True), tr)
+        yc, sc = C.forward(yb, (sb.scale, sb.shift, True), tr)
+        if P is not None:
+            y1, s1 = P.forward(x, None, tr)
+            out = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=y1, rscale=s1.scale, rshift=s1.shift)
+        else:
+            y1, s1 = None, None
+            out = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x)
+        ctx.mod = mod
+        ctx.raw = (ya, yb, yc, y1)
+        ctx.bn = (sa, sb, sc, s1)
+        ctx.save_for_backward(x, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        t = mod.branch2
+        A, B, C, P = t._a, t._b, t._c, mod._proj
+        x, out = ctx.saved_tensors
+        ya, yb, yc, y1 = ctx.raw
+        sa, sb, sc, s1 = ctx.bn
+        dout = as_cl(dout)
+        need_dx = ctx.needs_input_grad[0]
+        if P is not None:
+            dyc = C.bn_backward(dout, yc, sc, zmask=out)
+            dy1 = P.bn_backward(dout, y1, s1, zmask=out)
+            g = None
+        else:
+            dyc, g = C.bn_backward(dout, yc, sc, zmask=out, want_g=True)
+        d_ab = C.backward(yb, (sb.scale, sb.shift, True), dyc, need_dx=True)
+        dyb = B.bn_backward(d_ab, yb, sb, relu_self=True)
+        d_aa = B.backward(ya, (sa.scale, sa.shift, True), dyb, need_dx=True)
+        dya = A.bn_backward(d_aa, ya, sa, relu_self=True)
+        if P is not None:
+            dx1 = P.backward(x, None, dy1, need_dx=need_dx)
+            dx = A.backward(x, None, dya, need_dx=need_dx, resid=dx1)
+        else:
+            dx = A.backward(x, None, dya, need_dx=need_dx, resid=g)
+        _notify(mod._param_list)
+        ctx.raw = ctx.bn = None
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class ConvBNActFn(torch.autograd.Function):
+    """Stand-alone conv -> BN -> (ReLU), materialised (used by BottleneckTransform.forward on its own)."""
+
+    @staticmethod
+    def forward(ctx, x, unit, relu, training, *params):
+        x = as_cl(x)
+        y, st = unit.forward(x, None, training)
+        out = ops.bn_act(y, st.scale, st.shift, relu=relu)
+        ctx.unit, ctx.relu, ctx.y, ctx.st = unit, relu, y, st
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        unit = ctx.unit
+        (x,) = ctx.saved_tensors
+        dy = unit.bn_backward(as_cl(dout), ctx.y, ctx.st, relu_self=ctx.relu)
+        dx = unit.backward(x, None, dy, need_dx=ctx.needs_input_grad[0])
+        _notify(unit.params())
+        ctx.y = None
+        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)

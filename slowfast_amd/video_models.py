@@ -1,0 +1,221 @@
+"""Model builders ``SlowFast`` and ``ResNet`` (C2D / I3D / Slow) on the fused engine.
+
+Same cfg keys, module tree and state_dict names as slowfast/models/video_model_builder.py:172-441
+(SlowFast) and :444-660 (ResNet), so reference checkpoints load unchanged; the graph is assembled
+from per-stage tables instead of the reference's unrolled constructor."""
+import torch
+import torch.nn as nn
+
+from .engine import ConvUnit, FuseFn
+from .heads import ResNetBasicHead
+from .registry import MODEL_REGISTRY
+from .resblocks import ResStage
+from .stems import VideoModelStem
+
+# blocks per stage (res2..res5) by depth
+_STAGE_DEPTH = {18: (2, 2, 2, 2), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+# temporal kernel of [conv1, res2, res3, res4, res5] per pathway
+_TEMPORAL_KERNELS = {
+    "2d": [[[1]]] * 5,
+    "c2d": [[[1]]] * 5,
+    "slow_c2d": [[[1]]] * 5,
+    "i3d": [[[5]], [[3]], [[3, 1]], [[3, 1]], [[1, 3]]],
+    "slow_i3d": [[[5]], [[3]], [[3, 1]], [[3, 1]], [[1, 3]]],
+    "slow": [[[1]], [[1]], [[1]], [[3]], [[3]]],
+    "slowfast": [[[1], [5]], [[1], [3]], [[1], [3]], [[3], [3]], [[3], [3]]],
+}
+# pooling applied after res2, per pathway
+_POOL1 = {"2d": [[1, 1, 1]], "c2d": [[2, 1, 1]], "slow_c2d": [[1, 1, 1]], "i3d": [[2, 1, 1]],
+          "slow_i3d": [[1, 1, 1]], "slow": [[1, 1, 1]], "slowfast": [[1, 1, 1], [1, 1, 1]]}
+
+
+def get_norm(cfg):
+    """BN.NORM_TYPE -> norm layer class (slowfast/models/batchnorm_helper.py:16-37); the hot path uses
+    per-GPU local statistics, i.e. nn.BatchNorm3d as the parameter container."""
+    if cfg.BN.NORM_TYPE == "batchnorm":
+        return nn.BatchNorm3d
+    raise NotImplementedError(f"Norm type {cfg.BN.NORM_TYPE} is outside the hot path (sub/sync BN are multigrid/SSL only)")
+
+
+def init_weights(model, fc_init_std=0.01, zero_init_final_bn=True, zero_init_final_conv=False):
+    """ResNet-style init with the reference's rules (slowfast/utils/weight_init_helper.py:10-54):
+    Conv3d Kaiming-normal(fan_out, relu); BN gamma 1 (0 on the block-final BN when requested), beta 0;
+    Linear N(0, fc_init_std), bias 0."""
+    for m in model.modules():
+        if isinstance(m, nn.Conv3d):
+            if getattr(m, "final_conv", False) and zero_init_final_conv:
+                nn.init.zeros_(m.weight)
+            else:
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, (nn.BatchNorm3d, nn.BatchNorm2d, nn.BatchNorm1d)):
+            zero = getattr(m, "transform_final_bn", False) and zero_init_final_bn
+            if m.weight is not None:
+                nn.init.constant_(m.weight, 0.0 if zero else 1.0)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        if isinstance(m, nn.Linear):
+            nn.init.normal_(m.weight, mean=0.0, std=fc_init_std)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+
+class FuseFastToSlow(nn.Module):
+    """Lateral connection Fast -> Slow (video_model_builder.py:112-169): children conv_f2s, bn, relu."""
+
+    def __init__(self, dim_in, fusion_conv_channel_ratio, fusion_kernel, alpha, eps=1e-5, bn_mmt=0.1,
+                 inplace_relu=True, norm_module=nn.BatchNorm3d):
+        super().__init__()
+        self.conv_f2s = nn.Conv3d(dim_in, dim_in * fusion_conv_channel_ratio, kernel_size=(fusion_kernel, 1, 1),
+                                  stride=(alpha, 1, 1), padding=(fusion_kernel // 2, 0, 0), bias=False)
+        self.bn = norm_module(num_features=dim_in * fusion_conv_channel_ratio, eps=eps, momentum=bn_mmt)
+        self.relu = nn.ReLU(inplace_relu)
+        self._unit = ConvUnit(self.conv_f2s, self.bn)
+
+    def forward(self, x):
+        x_s_fuse, x_f = FuseFn.apply(x[0], x[1], self, self.conv_f2s.weight, self.bn.weight, self.bn.bias)
+        return [x_s_fuse, x_f]
+
+
+def _bump_batches_tracked(model):
+    """nn.BatchNorm3d.num_batches_tracked += 1 for every BN, in one foreach call per training forward."""
+    bufs = model.__dict__.get("_nbt")
+    if bufs is None:
+        bufs = model.__dict__["_nbt"] = [m.num_batches_tracked for m in model.modules()
+                                         if isinstance(m, nn.modules.batchnorm._BatchNorm)
+                                         and m.num_batches_tracked is not None]
+    if bufs:
+        torch._foreach_add_(bufs, 1)
+
+
+class _ResNetBase(nn.Module):
+    def _stage(self, cfg, idx, dim_in, dim_out, dim_inner, depth):
+        """res{idx+2}: idx indexes cfg lists (0 -> res2)."""
+        P = self.num_pathways
+        return ResStage(
+            dim_in=dim_in, dim_out=dim_out, dim_inner=dim_inner,
+            temp_kernel_sizes=_TEMPORAL_KERNELS[cfg.MODEL.ARCH][idx + 1],
+            stride=cfg.RESNET.SPATIAL_STRIDES[idx], num_blocks=[depth] * P, num_groups=[cfg.RESNET.NUM_GROUPS] * P,
+            num_block_temp_kernel=cfg.RESNET.NUM_BLOCK_TEMP_KERNEL[idx], nonlocal_inds=cfg.NONLOCAL.LOCATION[idx],
+            nonlocal_group=cfg.NONLOCAL.GROUP[idx], nonlocal_pool=cfg.NONLOCAL.POOL[idx],
+            instantiation=cfg.NONLOCAL.INSTANTIATION, trans_func_name=cfg.RESNET.TRANS_FUNC,
+            stride_1x1=cfg.RESNET.STRIDE_1X1, inplace_relu=cfg.RESNET.INPLACE_RELU,
+            dilation=cfg.RESNET.SPATIAL_DILATIONS[idx], norm_module=self.norm_module)
+
+    def _head(self, cfg, dim_in, frames):
+        assert not cfg.DETECTION.ENABLE, "ResNetRoIHead (AVA) is a 'next' row of the scope table"
+        pool = _POOL1[cfg.MODEL.ARCH]
+        if cfg.MULTIGRID.SHORT_CYCLE or cfg.MODEL.MODEL_NAME == "ContrastiveModel":
+            pool_size = [None] * len(dim_in)
+        else:
+            s = cfg.DATA.TRAIN_CROP_SIZE // 32
+            pool_size = [[frames[p] // pool[p][0], s // pool[p][1], s // pool[p][2]] for p in range(len(dim_in))]
+        return ResNetBasicHead(dim_in=dim_in, num_classes=cfg.MODEL.NUM_CLASSES, pool_size=pool_size,
+                               dropout_rate=cfg.MODEL.DROPOUT_RATE, act_func=cfg.MODEL.HEAD_ACT,
+                               detach_final_fc=cfg.MODEL.DETACH_FINAL_FC, cfg=cfg)
+
+    def _finish(self, cfg):
+        init_weights(self, cfg.MODEL.FC_INIT_STD, cfg.RESNET.ZERO_INIT_FINAL_BN, cfg.RESNET.ZERO_INIT_FINAL_CONV)
+
+
+@MODEL_REGISTRY.register()
+class SlowFast(_ResNetBase):
+    """Two-pathway SlowFast network; forward(x=[slow NCTHW, fast NCTHW]) -> logits (B, num_classes)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.norm_module = get_norm(cfg)
+        self.cfg = cfg
+        self.enable_detection = cfg.DETECTION.ENABLE
+        self.num_pathways = 2
+        arch = cfg.MODEL.ARCH
+        assert arch in _POOL1 and len(_POOL1[arch]) == 2 and cfg.RESNET.DEPTH in _STAGE_DEPTH
+        depths = _STAGE_DEPTH[cfg.RESNET.DEPTH]
+        w = cfg.RESNET.WIDTH_PER_GROUP
+        inner = cfg.RESNET.NUM_GROUPS * w
+        beta_inv, ratio = cfg.SLOWFAST.BETA_INV, cfg.SLOWFAST.FUSION_CONV_CHANNEL_RATIO
+        lateral = beta_inv // ratio            # slow width / lateral width
+        tk = _TEMPORAL_KERNELS[arch]
+        self.s1 = VideoModelStem(
+            dim_in=cfg.DATA.INPUT_CHANNEL_NUM, dim_out=[w, w // beta_inv],
+            kernel=[tk[0][0] + [7, 7], tk[0][1] + [7, 7]], stride=[[1, 2, 2]] * 2,
+            padding=[[tk[0][0][0] // 2, 3, 3], [tk[0][1][0] // 2, 3, 3]], norm_module=self.norm_module)
+
+        def fuse(width):
+            return FuseFastToSlow(width // beta_inv, ratio, cfg.SLOWFAST.FUSION_KERNEL_SZ, cfg.SLOWFAST.ALPHA,
+                                  norm_module=self.norm_module)
+
+        self.s1_fuse = fuse(w)
+        width_in = w
+        for i, depth in enumerate(depths):      # res2..res5: output width w*4, w*8, w*16, w*32
+            width_out = w * 4 * (2 ** i)
+            stage = self._stage(cfg, i,
+                                dim_in=[width_in + width_in // lateral, width_in // beta_inv],
+                                dim_out=[width_out, width_out // beta_inv],
+                                dim_inner=[inner * 2 ** i, inner * 2 ** i // beta_inv], depth=depth)
+            setattr(self, f"s{i + 2}", stage)
+            if i < 3:
+                setattr(self, f"s{i + 2}_fuse", fuse(width_out))
+            if i == 0:
+                for p in range(2):
+                    ps = _POOL1[arch][p]
+                    self.add_module(f"pathway{p}_pool", nn.MaxPool3d(kernel_size=ps, stride=ps, padding=[0, 0, 0]))
+            width_in = width_out
+        frames = [cfg.DATA.NUM_FRAMES // cfg.SLOWFAST.ALPHA, cfg.DATA.NUM_FRAMES]
+        self.head = self._head(cfg, [w * 32, w * 32 // beta_inv], frames)
+        self._finish(cfg)
+
+    def forward(self, x, bboxes=None):
+        if self.training:
+            _bump_batches_tracked(self)
+        x = self.s1_fuse(self.s1(list(x)))
+        x = self.s2_fuse(self.s2(x))
+        for p in range(self.num_pathways):
+            pool = getattr(self, f"pathway{p}_pool")
+            if tuple(pool.kernel_size) != (1, 1, 1):
+                x[p] = pool(x[p])
+        x = self.s3_fuse(self.s3(x))
+        x = self.s4_fuse(self.s4(x))
+        x = self.s5(x)
+        return self.head(x)
+
+
+@MODEL_REGISTRY.register()
+class ResNet(_ResNetBase):
+    """Single-pathway ResNet video models (C2D, I3D, Slow); forward(x=[NCTHW]) -> logits."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.norm_module = get_norm(cfg)
+        self.cfg = cfg
+        self.enable_detection = cfg.DETECTION.ENABLE
+        self.num_pathways = 1
+        arch = cfg.MODEL.ARCH
+        assert arch in _POOL1 and len(_POOL1[arch]) == 1 and cfg.RESNET.DEPTH in _STAGE_DEPTH
+        depths = _STAGE_DEPTH[cfg.RESNET.DEPTH]
+        w = cfg.RESNET.WIDTH_PER_GROUP
+        inner = cfg.RESNET.NUM_GROUPS * w
+        tk = _TEMPORAL_KERNELS[arch]
+        self.s1 = VideoModelStem(dim_in=cfg.DATA.INPUT_CHANNEL_NUM, dim_out=[w], kernel=[tk[0][0] + [7, 7]],
+                                 stride=[[1, 2, 2]], padding=[[tk[0][0][0] // 2, 3, 3]], norm_module=self.norm_module)
+        width_in = w
+        for i, depth in enumerate(depths):
+            width_out = w * 4 * (2 ** i)
+            setattr(self, f"s{i + 2}", self._stage(cfg, i, [width_in], [width_out], [inner * 2 ** i], depth))
+            if i == 0:
+                ps = _POOL1[arch][0]
+                self.add_module("pathway0_pool", nn.MaxPool3d(kernel_size=ps, stride=ps, padding=[0, 0, 0]))
+            width_in = width_out
+        self.head = self._head(cfg, [w * 32], [cfg.DATA.NUM_FRAMES])
+        self._finish(cfg)
+
+    def forward(self, x, bboxes=None):
+        if self.training:
+            _bump_batches_tracked(self)
+        x = self.s2(self.s1(list(x)))
+        pool = self.pathway0_pool
+        if tuple(pool.kernel_size) != (1, 1, 1):
+            x[0] = pool(x[0])
+        x = self.s5(self.s4(self.s3(x)))
+        return self.head(x)

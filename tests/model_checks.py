@@ -1,0 +1,90 @@
+"""Model-level parity: the HIP engine (drop-in nn.Modules) against the CPU oracle and the golden fixtures.
+
+Tolerance (BASELINE.json north_star): logits, loss and gradient norms within 1e-3 relative of the fp32
+reference when computing in fp16 with fp32 accumulation.  Logits are compared relative to the largest
+|logit|; per-parameter gradients by relative L2 error with a looser bound (they are sums of O(1e5)
+fp16-rounded products and are only constrained through the global grad-norm by the north star).
+"""
+import json
+import os
+
+import torch
+
+import slowfast_amd as sa
+from oracle import video_ref
+from slowfast_amd.config import preset_for_yaml
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN_DIR, name + ".json")) as f:
+        return json.load(f)
+
+
+def cfg_for(gold, extra=()):
+    return sa.get_preset(preset_for_yaml(gold["reference_yaml"]), list(gold["opts"]) + list(extra))
+
+
+def oracle_run(gold, cfg):
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)   # only used for the state_dict shapes
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = video_ref.randomize_state(shapes, gold["param_seed"])
+    inputs, labels = video_ref.synthetic_batch(cfg, gold["batch"], gold["data_seed"])
+    logits, loss, grads, stats = video_ref.loss_and_grads(sd, cfg, inputs, labels)
+    return model, sd, inputs, labels, logits, loss, grads, stats
+
+
+def check_oracle_against_golden(name):
+    """The oracle reproduces the numbers the real reference produced in the build container."""
+    gold = load_golden(name)
+    cfg = cfg_for(gold)
+    _, _, _, _, logits, loss, grads, stats = oracle_run(gold, cfg)
+    ref_logits = torch.tensor(gold["logits"])
+    assert float((logits - ref_logits).abs().max() / ref_logits.abs().max()) < 1e-5
+    assert abs(float(loss) - gold["loss"]) < 1e-5 * max(1.0, abs(gold["loss"]))
+    assert abs(float(video_ref.grad_norm(grads)) - gold["grad_norm"]) < 1e-4 * gold["grad_norm"]
+    assert sum(g.numel() for g in grads.values()) == gold["num_params"]
+    for k, n in gold["param_grad_norms"].items():
+        assert abs(float(grads[k].norm()) - n) <= 2e-4 * max(n, 1e-3 * gold["grad_norm"]), k
+    for k, s in gold["running_stat_sums"].items():
+        assert abs(float(stats[k].double().sum()) - s) <= 1e-4 * max(1.0, abs(s)), k
+
+
+def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=1e-3, tol_param=2e-2,
+                 tol_stats=2e-3, report=None):
+    """Forward + CE + backward of the drop-in model on `device` vs the oracle (and the golden numbers)."""
+    gold = load_golden(name)
+    cfg = cfg_for(gold)
+    model, sd, inputs, labels, o_logits, o_loss, o_grads, o_stats = oracle_run(gold, cfg)
+    model.load_state_dict(sd)
+    model = model.to(device).train()
+    logits = model([x.to(device) for x in inputs])
+    loss = torch.nn.functional.cross_entropy(logits.float(), labels.to(device))
+    (loss * loss_scale).backward()
+    res = {}
+    res["logits"] = float((logits.detach().float().cpu() - o_logits).abs().max() / o_logits.abs().max())
+    res["loss"] = abs(float(loss) - float(o_loss)) / max(1.0, abs(float(o_loss)))
+    grads = {k: p.grad.detach().float().cpu() / loss_scale for k, p in model.named_parameters()}
+    gn, ogn = float(video_ref.grad_norm(grads)), float(video_ref.grad_norm(o_grads))
+    res["grad_norm"] = abs(gn - ogn) / ogn
+    res["golden_loss"] = abs(float(loss) - gold["loss"]) / max(1.0, abs(gold["loss"]))
+    res["golden_grad_norm"] = abs(gn - gold["grad_norm"]) / gold["grad_norm"]
+    worst, worst_k = 0.0, None
+    for k, g in o_grads.items():
+        e = float((grads[k] - g).norm() / (g.norm() + 1e-3 * ogn / len(o_grads) ** 0.5))
+        if e > worst:
+            worst, worst_k = e, k
+    res["param_grad_worst"] = worst
+    res["param_grad_worst_name"] = worst_k
+    msd = model.state_dict()
+    res["running_stats"] = max(
+        float((msd[k].float().cpu() - v).abs().max() / (v.abs().max() + 1e-6)) for k, v in o_stats.items())
+    if report is not None:
+        report[name] = res
+    assert res["logits"] <= tol_logits, res
+    assert res["loss"] <= tol_loss and res["golden_loss"] <= tol_loss, res
+    assert res["grad_norm"] <= tol_gnorm and res["golden_grad_norm"] <= tol_gnorm, res
+    assert res["param_grad_worst"] <= tol_param, res
+    assert res["running_stats"] <= tol_stats, res
+    return res

@@ -1,0 +1,14 @@
+"""CPU: whole-model forward/backward of the drop-in modules through the host simulator vs the oracle.
+
+These tiny models (batch 2, 32x32 crops) put only 4-16 samples under the deepest BatchNorms, which amplifies
+fp16 round-off by 1-2 orders of magnitude; the bounds here are therefore loose and the test is a wiring check
+(every block, lateral connection, pooling and the head in the right order with the right parameters).
+Strict parity: tests/test_blocks_hostsim.py (well-conditioned blocks) and the -m gpu model tests."""
+import pytest
+
+from tests import model_checks as mc
+
+
+@pytest.mark.parametrize("name", ["slowfast_tiny", "c2d_tiny"])
+def test_engine_wiring_matches_oracle(sim, name):
+    mc.check_engine(name, sim, tol_logits=0.15, tol_loss=0.02, tol_gnorm=0.35, tol_param=2.0, tol_stats=0.05)

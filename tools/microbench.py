@@ -1,0 +1,118 @@
+"""Per-kernel timing of libsfamd on the SlowFast-8x8-R50 layer geometries.
+
+Times conv fwd / dgrad / wgrad and the BN/elementwise kernels with HIP events on torch's current
+stream, prints achieved TFLOP/s and algorithmic GB/s per layer.  Usage:
+    python tools/microbench.py [--batch 32] [--iters 5] [--json gpurun_out/microbench.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slowfast_amd import ops  # noqa: E402
+
+# (name, Ci, T, H, W, Co, kernel, stride, pad, count)
+LAYERS = [
+    ("slow.stem 3->64 1x7x7/2", 8, 8, 224, 224, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), 1),
+    ("fast.stem 3->8 5x7x7/2", 8, 32, 224, 224, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3), 1),
+    ("s2.slow a 80->64 1x1", 80, 8, 56, 56, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), 1),
+    ("s2.slow b 64->64 1x3x3", 64, 8, 56, 56, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), 3),
+    ("s2.slow c 64->256 1x1", 64, 8, 56, 56, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), 3),
+    ("s2.slow a 256->64 1x1", 256, 8, 56, 56, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), 2),
+    ("s2.fast a 32->8 3x1x1", 32, 32, 56, 56, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), 2),
+    ("s2.fast b 8->8 1x3x3", 8, 32, 56, 56, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), 3),
+    ("s2.fast c 8->32 1x1", 8, 32, 56, 56, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), 4),
+    ("fuse2 32->64 7x1x1/4", 32, 32, 56, 56, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), 1),
+    ("s3.slow a 320->128 1x1", 320, 8, 56, 56, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), 1),
+    ("s3.slow b 128->128 3x3/2", 128, 8, 56, 56, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), 1),
+    ("s3.slow sc 320->512 1x1/2", 320, 8, 56, 56, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), 1),
+    ("s3.slow b 128->128 3x3", 128, 8, 28, 28, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), 3),
+    ("s3.slow c 128->512 1x1", 128, 8, 28, 28, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), 4),
+    ("s3.slow a 512->128 1x1", 512, 8, 28, 28, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), 3),
+    ("s3.fast a 64->16 3x1x1", 64, 32, 28, 28, 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), 3),
+    ("s3.fast c 16->64 1x1", 16, 32, 28, 28, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), 4),
+    ("s4.slow a 640->256 3x1x1", 640, 8, 28, 28, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), 1),
+    ("s4.slow a 1024->256 3x1x1", 1024, 8, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), 5),
+    ("s4.slow b 256->256 3x3", 256, 8, 14, 14, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), 5),
+    ("s4.slow c 256->1024 1x1", 256, 8, 14, 14, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), 6),
+    ("s4.fast a 128->32 3x1x1", 128, 32, 14, 14, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), 5),
+    ("s5.slow a 1280->512 3x1x1", 1280, 8, 14, 14, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), 1),
+    ("s5.slow a 2048->512 3x1x1", 2048, 8, 7, 7, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), 2),
+    ("s5.slow b 512->512 3x3", 512, 8, 7, 7, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), 2),
+    ("s5.slow c 512->2048 1x1", 512, 8, 7, 7, 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0), 3),
+]
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--json", default="")
+    ap.add_argument("--filter", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rows = []
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "bn": 0.0}
+    for name, Ci, T, H, W, Co, k, s, p, cnt in LAYERS:
+        if a.filter and a.filter not in name:
+            continue
+        Cw = 3 if "stem" in name else Ci
+        geom = ops.ConvGeom((a.batch, Ci, T, H, W), Co, k, s, p, Cw=Cw)
+        x = ops.cl_empty(geom.in_shape, dev)
+        x.normal_()
+        w = torch.randn((Co, Cw) + k, device=dev) * 0.05
+        wf, wd = ops.prep_weights(w, geom)
+        y, part = ops.conv_fwd(x, wf, geom)
+        dy = ops.cl_empty(geom.out_shape, dev)
+        dy.normal_()
+        dw = torch.empty_like(w)
+        sc = torch.ones(Ci, device=dev)
+        sh = torch.zeros(Ci, device=dev)
+        macs = geom.out_rows * Co * Cw * geom.taps
+        t_f = timeit(lambda: ops.conv_fwd(x, wf, geom, out=y), a.iters)
+        t_fa = timeit(lambda: ops.conv_fwd(x, wf, geom, in_affine=(sc, sh, True), out=y), a.iters) if Ci <= 512 else float("nan")
+        dx = ops.cl_empty(geom.in_shape, dev)
+        t_d = timeit(lambda: ops.conv_dgrad(dy, wd, geom, out=dx), a.iters) if "stem" not in name else 0.0
+        t_w = timeit(lambda: ops.conv_wgrad(x, dy, geom, dw), a.iters)
+        gamma = torch.ones(Co, device=dev); beta = torch.zeros(Co, device=dev)
+        rm = torch.zeros(Co, device=dev); rv = torch.ones(Co, device=dev)
+        scale, shift, mean, rstd = ops.bn_finalize(part, geom.out_rows, gamma, beta, rm, rv, 0.1, 1e-5)
+        z = ops.cl_empty(geom.out_shape, dev)
+        t_act = timeit(lambda: ops.bn_act(y, scale, shift, relu=True, out=z), a.iters)
+        dgm = torch.empty(Co, device=dev); dbt = torch.empty(Co, device=dev)
+        t_bb = timeit(lambda: ops.bn_bwd(dy, y, gamma, mean, rstd, dgm, dbt, relu_affine=(scale, shift), out=z), a.iters)
+        bytes_io = 2.0 * (x.numel() * Cw / Ci + y.numel())
+        row = dict(name=name, count=cnt, gmac=macs / 1e9, fwd_ms=t_f, fwd_affine_ms=t_fa, dgrad_ms=t_d, wgrad_ms=t_w,
+                   bn_act_ms=t_act, bn_bwd_ms=t_bb, fwd_tflops=2 * macs / t_f / 1e9,
+                   dgrad_tflops=(2 * macs / t_d / 1e9 if t_d else 0), wgrad_tflops=2 * macs / t_w / 1e9,
+                   fwd_gbs=bytes_io / t_f / 1e6, act_gbs=2.0 * 2 * y.numel() / t_act / 1e6,
+                   bnbwd_gbs=2.0 * 5 * y.numel() / t_bb / 1e6)
+        rows.append(row)
+        tot["fwd"] += cnt * t_f; tot["dgrad"] += cnt * t_d; tot["wgrad"] += cnt * t_w; tot["bn"] += cnt * (t_act + t_bb)
+        print(f"{name:30s} x{cnt} {macs/1e9:7.1f} GMAC | fwd {t_f:7.3f} ms {row['fwd_tflops']:7.1f} TF {row['fwd_gbs']:7.0f} GB/s "
+              f"(+bn {t_fa:7.3f}) | dgrad {t_d:7.3f} ms {row['dgrad_tflops']:7.1f} TF | wgrad {t_w:7.3f} ms {row['wgrad_tflops']:7.1f} TF "
+              f"| act {t_act:6.3f} ms {row['act_gbs']:6.0f} GB/s | bnbwd {t_bb:6.3f} ms {row['bnbwd_gbs']:6.0f} GB/s", flush=True)
+    print("weighted totals (ms):", {k: round(v, 2) for k, v in tot.items()}, "sum", round(sum(tot.values()), 2))
+    if a.json:
+        os.makedirs(os.path.dirname(a.json) or ".", exist_ok=True)
+        with open(a.json, "w") as f:
+            json.dump(dict(batch=a.batch, rows=rows, totals=tot), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
