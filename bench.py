@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SlowFast-8x8-R50 training step (forward + backward + SGD) on synthetic Kinetics clips.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the env), per-GPU batch 32 (weak scaling), gradients
+all-reduced over RCCL by slowfast_amd.data_parallel.GradReducer overlapped with backward.  Rank 0 prints ONE
+JSON line.  `value` = clips/s of the whole job with the clips already resident in HBM.  After the timed
+region one more step is run with HIP events around every libsfamd launch (slowfast_amd.profiler) to report the
+dominant kernel against its roofline, and (N=1 only) the CPU oracle is timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
+# per clip, SlowFast-8x8-R50 32x224^2: MAC_fwd 50.309 G -> 6*MAC train flops; boundary elements
+# E = 216.5 M -> byte floor 5*E*2 B = 2.165 GB
+TRAIN_GFLOP_PER_CLIP = {"SLOWFAST_8x8_R50": 301.9, "C2D_8x8_R50": 117.0}
+BYTE_FLOOR_GB_PER_CLIP = {"SLOWFAST_8x8_R50": 2.165, "C2D_8x8_R50": 1.019}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--preset", default="SLOWFAST_8x8_R50")
+    ap.add_argument("--loss-scale", type=float, default=1024.0)
+    ap.add_argument("--bucket-mb", type=float, default=48.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--cpu-baseline-clips", type=int, default=2)
+    return ap.parse_args()
+
+
+def make_optimizer(model, cfg):
+    """SGD as the reference constructs it (slowfast/models/optimizer.py:15-140): BN parameters get
+    BN.WEIGHT_DECAY, the rest SOLVER.WEIGHT_DECAY; momentum / nesterov from SOLVER."""
+    bn, rest = [], []
+    for m in model.modules():
+        is_bn = isinstance(m, torch.nn.modules.batchnorm._NormBase)
+        for p in m.parameters(recurse=False):
+            (bn if is_bn else rest).append(p)
+    groups = [{"params": bn, "weight_decay": cfg.BN.WEIGHT_DECAY}, {"params": rest, "weight_decay": cfg.SOLVER.WEIGHT_DECAY}]
+    kw = dict(lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, dampening=cfg.SOLVER.DAMPENING,
+              nesterov=cfg.SOLVER.NESTEROV)
+    try:
+        return torch.optim.SGD(groups, fused=True, **kw)
+    except Exception:
+        return torch.optim.SGD(groups, foreach=True, **kw)
+
+
+def cpu_baseline(cfg, clips):
+    """The CPU oracle (plain torch fp32 restatement of the reference graph) on the host cores."""
+    from oracle import video_ref
+    import slowfast_amd as sa
+    torch.set_num_threads(os.cpu_count() or 1)
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k in sd:                         # ZERO_INIT_FINAL_BN gammas -> 1 so backward does full work
+        if k.endswith("c_bn.weight"):
+            sd[k].fill_(1.0)
+    inputs, labels = video_ref.synthetic_batch(cfg, clips, seed=0)
+    video_ref.loss_and_grads(sd, cfg, inputs, labels)            # warm-up
+    best, iters = 1e30, 2
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        video_ref.loss_and_grads(sd, cfg, inputs, labels)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": clips / best, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{clips} clips x (fwd + cross-entropy + bwd), best of {iters} timed iterations after 1 warm-up, "
+                      f"torch {torch.__version__} CPU fp32"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import slowfast_amd as sa
+    from slowfast_amd.data_parallel import GradReducer
+    from slowfast_amd.lib import get_lib
+    from slowfast_amd.profiler import KernelProfiler
+    assert get_lib().backend == "gfx950", "bench.py measures the HIP library only"
+
+    cfg = sa.get_preset(a.preset, ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", a.batch * world])
+    torch.manual_seed(cfg.RNG_SEED)
+    model = sa.build_model(cfg, gpu_id=local).train()
+    if world > 1:                        # replicas start identical (DDP's initial broadcast)
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+    opt = make_optimizer(model, cfg)
+    reducer = GradReducer(model, bucket_mb=a.bucket_mb)
+    reducer.attach_torch_param_hooks(model.head.parameters())
+
+    g = torch.Generator(device=dev).manual_seed(cfg.RNG_SEED + rank)
+    T, S = cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE
+    fast = torch.randn((a.batch, 3, T, S, S), generator=g, device=dev)
+    labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (a.batch,), generator=g, device=dev)
+    if len(cfg.DATA.INPUT_CHANNEL_NUM) == 2:
+        idx = torch.linspace(0, T - 1, T // cfg.SLOWFAST.ALPHA).long().to(dev)
+        inputs = [torch.index_select(fast, 2, idx).contiguous(), fast]
+    else:
+        inputs = [fast]
+
+    def step():
+        reducer.zero_grad()
+        logits = model(inputs)
+        loss = F.cross_entropy(logits.float(), labels)
+        (loss * a.loss_scale).backward()
+        reducer.finish(loss_scale=a.loss_scale)
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+
+    kernels, roof = {}, None
+    if not a.no_kernel_profile:
+        with KernelProfiler() as prof:
+            step()
+        summ = prof.summary()
+        tot = sum(v["ms"] for v in summ.values())
+        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]:
+            kernels[k] = {"calls": v["calls"], "ms": round(v["ms"], 3), "avg_ms": round(v["avg_ms"], 4),
+                          "share": round(v["ms"] / tot, 3), "GB/s": round(v["gbs"], 1), "TFLOP/s": round(v["tflops"], 1)}
+        name, v = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        ai = v["flops"] / max(v["bytes"], 1.0)
+        if ai > MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:
+            roof = {"kernel": name, "bound": "mfma", "achieved": round(v["tflops"], 2), "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(v["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": None}
+        else:
+            roof = {"kernel": name, "bound": "hbm", "achieved": round(v["gbs"], 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(v["gbs"] / HBM_PEAK_GBS, 4), "traffic": None}
+        roof["avg_launch_ms"] = round(v["avg_ms"], 4)
+        roof["launches_per_step"] = v["calls"]
+        roof["kernel_ms_per_step"] = round(tot, 2)
+
+    if rank == 0:
+        clips = a.batch * world * a.steps
+        value = clips / dt
+        ms = dt / a.steps * 1e3
+        out = {
+            "metric": "clips/sec (fwd+bwd), SlowFast-8x8-R50 32x224^2 synthetic clips, per-GPU batch 32",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp16", "data": "synthetic",
+            "config": {"workload": f"{a.preset}: forward + cross-entropy + backward + SGD step, inputs resident in HBM, "
+                                   f"per-GPU batch {a.batch}", "global_batch": a.batch * world,
+                       "parallelism": f"dp{world}", "loss_scale": a.loss_scale, "bucket_mb": a.bucket_mb},
+            "per_gpu_clips_per_s": round(value / world, 2), "final_loss": round(final_loss, 4),
+        }
+        if a.preset in BYTE_FLOOR_GB_PER_CLIP:
+            per_gpu = value / world
+            out["model_roofline"] = {
+                "bound": "hbm", "achieved": round(per_gpu * BYTE_FLOOR_GB_PER_CLIP[a.preset], 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(per_gpu * BYTE_FLOOR_GB_PER_CLIP[a.preset] / HBM_PEAK_GBS, 4),
+                "note": "whole step vs the fused-ideal byte floor 5*E*2B per clip (SURVEY.md 8d)",
+                "mfma_tflops": round(per_gpu * TRAIN_GFLOP_PER_CLIP[a.preset] / 1e3, 1)}
+        if roof is not None:
+            out["roofline"] = roof
+            out["kernels"] = kernels
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_clips)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

