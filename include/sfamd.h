@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 1
+#define SF_ABI_VERSION 2
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -54,9 +54,13 @@ int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf, const floa
 /* dx = conv_transpose(dy, w) (+ resid), dx pitch = d->ldx, dy pitch = d->ldy */
 int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr, void* dx,
                   sf_stream_t stream);
-/* dw[Co][Cw][taps] (+)= out_scale * sum_m dy[m] (x) act(x)[m]; zero_first clears dw on the stream */
+/* dw[Co][Cw][taps] = (zero_first ? 0 : dw) + out_scale * sum_m dy[m] (x) act(x)[m].  The reduction over positions
+ * is split; `workspace` (>= sf_conv_wgrad_workspace(d) bytes, caller-owned) holds the per-split partials, which a
+ * second kernel sums in a fixed order (no atomics: results are run-to-run reproducible). */
+int64_t sf_conv_wgrad_workspace(const sf_conv_desc* d);
 int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, int in_relu,
-                  const void* dy, float* dw, float out_scale, int zero_first, sf_stream_t stream);
+                  const void* dy, float* dw, float out_scale, int zero_first, void* workspace, int64_t workspace_bytes,
+                  sf_stream_t stream);
 
 /* ---- BatchNorm3d -- replaces nn.BatchNorm3d built by batchnorm_helper.py:16-37 (get_norm) at every
  * *_bn call site of resnet_helper.py / stem_helper.py / video_model_builder.py:155-159, plus the

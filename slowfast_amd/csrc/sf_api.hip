@@ -188,43 +188,78 @@ static void launch_wgrad(const WgradParams& p, dim3 grid, bool scalar, hipStream
     else hipLaunchKernelGGL((sf_wgrad_kernel<BMW, WM, WN, true>), grid, dim3(SF_THREADS), 0, s, p);
 }
 
+// Split-K plan of the weight gradient: the reduction over the M = N*To*Ho*Wo positions is cut into `splits`
+// slabs so that ~4 workgroups per CU are in flight; each split stores its [Co_pad][Kpad] fp32 partial tile
+// set with plain stores and sf_wgrad_reduce_kernel sums them (deterministic, no atomics).
+struct WgradPlan {
+    int BMW, tiles_k, tiles_c, Co_pad, Kpad, nchunks, chunks_per_split, splits;
+    size_t ws_bytes;
+};
+static WgradPlan plan_wgrad(const sf_conv_desc* d) {
+    WgradPlan w;
+    const int taps = d->kT * d->kH * d->kW;
+    const int Ktot = taps * d->Ci;
+    const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
+    w.BMW = d->Co >= 128 ? 128 : d->Co >= 64 ? 64 : d->Co >= 32 ? 32 : 16;
+    w.tiles_k = cdiv(Ktot, 128);
+    w.tiles_c = cdiv(d->Co, w.BMW);
+    w.Kpad = w.tiles_k * 128;
+    w.Co_pad = w.tiles_c * w.BMW;
+    w.nchunks = cdiv(M, 32);
+    const int64_t slab = (int64_t)w.Co_pad * w.Kpad * 4;
+    int splits = cdiv(1024, (int64_t)w.tiles_k * w.tiles_c);
+    const int64_t cap = (256ll << 20) / slab;            // keep the workspace <= 256 MiB
+    if (splits > cap) splits = (int)(cap < 1 ? 1 : cap);
+    if (splits > w.nchunks) splits = w.nchunks;
+    if (splits < 1) splits = 1;
+    w.chunks_per_split = cdiv(w.nchunks, splits);
+    w.splits = cdiv(w.nchunks, w.chunks_per_split);
+    w.ws_bytes = (size_t)slab * w.splits;
+    return w;
+}
+
+extern "C" int64_t sf_conv_wgrad_workspace(const sf_conv_desc* d) {
+    if (check_desc(d)) return -1;
+    return (int64_t)plan_wgrad(d).ws_bytes;
+}
+
 extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
                              int in_relu, const void* dy, float* dw, float out_scale, int zero_first,
-                             sf_stream_t stream) {
+                             void* workspace, int64_t workspace_bytes, sf_stream_t stream) {
     if (check_desc(d)) return -1;
-    REQUIRE(x && dy && dw, "sf_conv_wgrad: null pointer");
+    REQUIRE(x && dy && dw && workspace, "sf_conv_wgrad: null pointer");
     REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sf_conv_wgrad: in_scale/in_shift must come together");
     REQUIRE(!in_scale || d->Ci <= 512, "sf_conv_wgrad: fused input BatchNorm supports Ci <= 512 (got %d)", d->Ci);
     static const bool scalar = getenv("SF_WGRAD_SCALAR") && atoi(getenv("SF_WGRAD_SCALAR")) != 0;
     hipStream_t s = (hipStream_t)stream;
+    const WgradPlan w = plan_wgrad(d);
+    REQUIRE(workspace_bytes >= (int64_t)w.ws_bytes, "sf_conv_wgrad: workspace too small (%lld < %lld bytes)",
+            (long long)workspace_bytes, (long long)w.ws_bytes);
+    REQUIRE(w.splits <= 65535, "sf_conv_wgrad: too many splits");
     WgradParams p;
     memset(&p, 0, sizeof(p));
     p.g = gather_fwd(d, x, in_scale, in_shift, in_relu);
     p.dy = (const f16*)dy; p.ldy = d->ldy; p.Co = d->Co;
     p.M = d->N * d->To * d->Ho * d->Wo;
-    p.dw = dw; p.Cw = d->Cw; p.taps = d->kT * d->kH * d->kW;
-    p.out_scale = out_scale;
-    p.nchunks = cdiv(p.M, 32);
-    if (zero_first) {
-        if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Co * d->Cw * p.taps, s) != hipSuccess)
-            return fail("sf_conv_wgrad: memset failed");
-    }
-    const int BMW = d->Co >= 128 ? 128 : d->Co >= 64 ? 64 : d->Co >= 32 ? 32 : 16;
-    const int tiles_k = cdiv(p.g.Ktot, 128), tiles_c = cdiv(d->Co, BMW);
-    int splits = cdiv(2048, (int64_t)tiles_k * tiles_c);
-    if (splits > p.nchunks) splits = p.nchunks;
-    if (splits < 1) splits = 1;
-    p.chunks_per_split = cdiv(p.nchunks, splits);
-    splits = cdiv(p.nchunks, p.chunks_per_split);
-    REQUIRE(splits <= 65535, "sf_conv_wgrad: too many splits");
-    dim3 grid(tiles_k, tiles_c, splits);
-    switch (BMW) {
+    p.ws = (float*)workspace; p.Co_pad = w.Co_pad; p.Kpad = w.Kpad;
+    p.nchunks = w.nchunks; p.chunks_per_split = w.chunks_per_split;
+    dim3 grid(w.tiles_k, w.tiles_c, w.splits);
+    switch (w.BMW) {
         case 128: launch_wgrad<128, 64, 64>(p, grid, scalar, s); break;
         case 64: launch_wgrad<64, 32, 64>(p, grid, scalar, s); break;
         case 32: launch_wgrad<32, 32, 32>(p, grid, scalar, s); break;
         default: launch_wgrad<16, 16, 32>(p, grid, scalar, s); break;
     }
-    return check_launch("wgrad");
+    if (check_launch("wgrad")) return -1;
+    WgradReduceParams r;
+    r.ws = (const float*)workspace; r.splits = w.splits; r.Co = d->Co; r.Co_pad = w.Co_pad; r.Kpad = w.Kpad;
+    r.Ktot = p.g.Ktot; r.fdC = p.g.fdC; r.dw = dw; r.Cw = d->Cw; r.taps = d->kT * d->kH * d->kW;
+    r.out_scale = out_scale; r.accumulate = zero_first ? 0 : 1;
+    int64_t total = (int64_t)d->Co * w.Kpad;
+    int blocks = (int)((total + SF_THREADS - 1) / SF_THREADS);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sf_wgrad_reduce_kernel, dim3(blocks), dim3(SF_THREADS), 0, s, r);
+    return check_launch("wgrad_reduce");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -214,13 +214,41 @@ struct WgradParams {
     int ldy;
     int Co;
     int M;
-    float* dw;          // fp32 [Co][Cw][taps] (PyTorch Conv3d weight layout), atomically accumulated
-    int Cw;             // channels of the weight tensor (<= g.C; stem input is channel-padded)
-    int taps;
-    float out_scale;    // 1 / loss_scale
+    float* ws;          // split partials [splits][Co_pad][Kpad] fp32 (plain stores, reduced by sf_wgrad_reduce_kernel)
+    int Co_pad, Kpad;
     int nchunks;        // ceil(M / 32)
     int chunks_per_split;
 };
+
+// dw[Co][Cw][taps] (PyTorch Conv3d weight layout) (+)= out_scale * sum_splits ws[s][co][tap*C + ci]
+struct WgradReduceParams {
+    const float* ws;
+    int splits, Co, Co_pad, Kpad, Ktot;
+    FastDiv fdC;
+    float* dw;
+    int Cw, taps;
+    float out_scale;
+    int accumulate;
+};
+
+__global__ __launch_bounds__(SF_THREADS) void sf_wgrad_reduce_kernel(WgradReduceParams p) {
+    const int64_t total = (int64_t)p.Co * p.Kpad;
+    const int64_t slab = (int64_t)p.Co_pad * p.Kpad;
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * SF_THREADS) {
+        const int co = (int)(idx / p.Kpad), kcol = (int)(idx % p.Kpad);
+        if (kcol >= p.Ktot) continue;
+        uint32_t tap, ci;
+        fd_divmod((uint32_t)kcol, p.fdC, tap, ci);
+        if (ci >= (uint32_t)p.Cw) continue;
+        float s = 0.f;
+        const float* src = p.ws + (int64_t)co * p.Kpad + kcol;
+        for (int z = 0; z < p.splits; ++z) s += src[z * slab];
+        float* dst = p.dw + ((int64_t)co * p.Cw + ci) * p.taps + tap;
+        s *= p.out_scale;
+        *dst = p.accumulate ? *dst + s : s;
+    }
+}
 
 template <class V>
 __device__ __forceinline__ f16x4 as_f16x4(V v) {
@@ -365,22 +393,17 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
         if (more) store_tile((ch - cb + 1) & 1);
         __syncthreads();
     }
-    if (cb >= ce) return;
-
+    // every split owns its slab: plain (non-atomic) stores, also when it had no rows to reduce (zeros)
+    float* slab = p.ws + (int64_t)blockIdx.z * p.Co_pad * p.Kpad;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const uint32_t kcol = (uint32_t)(n0 + wn * WN + j * 16 + pl);
-        if (kcol >= (uint32_t)g.Ktot) continue;
-        uint32_t tap, ci;
-        fd_divmod(kcol, g.fdC, tap, ci);
-        if (ci >= (uint32_t)p.Cw) continue;
+        const int kcol = n0 + wn * WN + j * 16 + pl;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = c0 + wm * WM + i * 16 + 4 * g4 + r;
-                if (co < p.Co)
-                    atomicAdd(p.dw + ((int64_t)co * p.Cw + ci) * p.taps + tap, acc[i][j][r] * p.out_scale);
+                slab[(int64_t)co * p.Kpad + kcol] = acc[i][j][r];
             }
     }
 }

@@ -122,6 +122,7 @@ class ConvGeom:
         ldf, ldd = c_int32(), c_int32()
         get_lib().call("sf_conv_weight_ld", byref(self.desc(self.Ci, self.Co)), byref(ldf), byref(ldd))
         self.ldf, self.ldd = ldf.value, ldd.value
+        self.ws_bytes = None   # wgrad split-partial workspace (queried lazily)
 
     @property
     def in_shape(self):
@@ -199,13 +200,31 @@ def conv_dgrad(dy, wd, geom, resid=None, out=None):
     return dx
 
 
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """One grow-only scratch buffer per device: every user is enqueued on the same stream, so launches that
+    share it are ordered (the callee allocates nothing, SURVEY.md 8b 'Ownership')."""
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
 def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True):
     """dw (+)= out_scale * d(loss)/d(weight); dw is an fp32 tensor shaped like the Conv3d weight."""
     assert tuple(x.shape) == geom.in_shape and tuple(dy.shape) == geom.out_shape
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == geom.Co * geom.Cw * geom.taps
     sc, sh, relu = _affine(in_affine)
-    get_lib().call("sf_conv_wgrad", byref(geom.desc(cl_ld(x), cl_ld(dy))), x.data_ptr(), _ptr(sc), _ptr(sh), relu,
-                   dy.data_ptr(), dw.data_ptr(), float(out_scale), int(zero_first), _stream(x),
+    lib = get_lib()
+    d = geom.desc(cl_ld(x), cl_ld(dy))
+    if geom.ws_bytes is None:
+        geom.ws_bytes = lib.call("sf_conv_wgrad_workspace", byref(d))
+    ws = _workspace(x.device, geom.ws_bytes)
+    lib.call("sf_conv_wgrad", byref(d), x.data_ptr(), _ptr(sc), _ptr(sh), relu,
+                   dy.data_ptr(), dw.data_ptr(), float(out_scale), int(zero_first), ws.data_ptr(), ws.numel(), _stream(x),
                    work=geom.work(reads_x=1, reads_y=1))
     return dw
 
