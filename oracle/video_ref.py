@@ -12,6 +12,50 @@ import torch
 import torch.nn.functional as F
 
 
+class _RoundFp16(torch.autograd.Function):
+    """y = fp16(x) in forward AND fp16(dy) in backward: emulates an fp16 HBM round trip of an activation and of
+    its gradient.  Used only by the "fp16 storage model" of the oracle (``video_forward(..., store=round_fp16)``),
+    which tells apart rounding noise of ANY fp16-storage implementation from real kernel defects."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.half().to(g.dtype)
+
+
+def round_fp16(x):
+    return _RoundFp16.apply(x)
+
+
+def _ident(x):
+    return x
+
+
+_STORE = _ident   # identity = the reference's fp32 graph; round_fp16 = fp16 storage model
+
+
+class fp16_storage_model:
+    """Context manager: every tensor that an fp16-storage implementation would round (conv operands and outputs,
+    block outputs, their gradients) is rounded to fp16 at that point; arithmetic stays fp32.  This is NOT the
+    oracle's reference mode (default: exact fp32 restatement of the reference); it is the yardstick that says how
+    far from fp32 a correct fp16-storage / fp32-accumulate engine is expected to land."""
+
+    def __enter__(self):
+        global _STORE
+        self._old, _STORE = _STORE, round_fp16
+
+    def __exit__(self, *exc):
+        global _STORE
+        _STORE = self._old
+
+
+def _conv(x, w, *args):
+    return _STORE(F.conv3d(x, _STORE(w), *args))
+
+
 def _bn(x, sd, prefix, training, stats_out, momentum=0.1, eps=1e-5):
     """nn.BatchNorm3d (slowfast/models/batchnorm_helper.py:24-25 -> torch BatchNorm3d; eps/momentum as passed at
     every construction site, e.g. resnet_helper.py:340-342)."""
@@ -29,8 +73,8 @@ def stem(x, sd, prefix, training, stats_out):
     """ResNetBasicStem.forward: conv -> bn -> relu -> MaxPool3d([1,3,3],[1,2,2],[0,1,1]) (stem_helper.py:182-201)."""
     w = sd[prefix + ".conv.weight"]
     kt = w.shape[2]
-    x = F.conv3d(x, w, None, (1, 2, 2), (kt // 2, 3, 3))
-    x = F.relu(_bn(x, sd, prefix + ".bn", training, stats_out))
+    x = _conv(_STORE(x), w, None, (1, 2, 2), (kt // 2, 3, 3))
+    x = _STORE(F.relu(_bn(x, sd, prefix + ".bn", training, stats_out)))
     return F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
 
 
@@ -38,8 +82,8 @@ def fuse(xs, xf, sd, prefix, alpha, training, stats_out):
     """FuseFastToSlow.forward (video_model_builder.py:162-169): time-strided conv on Fast, BN, ReLU, concat."""
     w = sd[prefix + ".conv_f2s.weight"]
     k = w.shape[2]
-    f = F.conv3d(xf, w, None, (alpha, 1, 1), (k // 2, 0, 0))
-    f = F.relu(_bn(f, sd, prefix + ".bn", training, stats_out))
+    f = _conv(xf, w, None, (alpha, 1, 1), (k // 2, 0, 0))
+    f = _STORE(F.relu(_bn(f, sd, prefix + ".bn", training, stats_out)))
     return torch.cat([xs, f], 1)
 
 
@@ -49,18 +93,18 @@ def res_block(x, sd, prefix, stride, dilation, stride_1x1, training, stats_out):
     b2 = prefix + ".branch2"
     wa = sd[b2 + ".a.weight"]
     kt = wa.shape[2]
-    y = F.conv3d(x, wa, None, (1, s_a, s_a), (kt // 2, 0, 0))
-    y = F.relu(_bn(y, sd, b2 + ".a_bn", training, stats_out))
-    y = F.conv3d(y, sd[b2 + ".b.weight"], None, (1, s_b, s_b), (0, dilation, dilation), (1, dilation, dilation))
-    y = F.relu(_bn(y, sd, b2 + ".b_bn", training, stats_out))
-    y = F.conv3d(y, sd[b2 + ".c.weight"])
+    y = _conv(x, wa, None, (1, s_a, s_a), (kt // 2, 0, 0))
+    y = _STORE(F.relu(_bn(y, sd, b2 + ".a_bn", training, stats_out)))
+    y = _conv(y, sd[b2 + ".b.weight"], None, (1, s_b, s_b), (0, dilation, dilation), (1, dilation, dilation))
+    y = _STORE(F.relu(_bn(y, sd, b2 + ".b_bn", training, stats_out)))
+    y = _conv(y, sd[b2 + ".c.weight"])
     y = _bn(y, sd, b2 + ".c_bn", training, stats_out)
     if prefix + ".branch1.weight" in sd:
-        sc = F.conv3d(x, sd[prefix + ".branch1.weight"], None, (1, stride, stride))
+        sc = _conv(x, sd[prefix + ".branch1.weight"], None, (1, stride, stride))
         sc = _bn(sc, sd, prefix + ".branch1_bn", training, stats_out)
     else:
         sc = x
-    return F.relu(sc + y)
+    return _STORE(F.relu(sc + y))
 
 
 def res_stage(xs, sd, name, strides, dilations, stride_1x1, training, stats_out):

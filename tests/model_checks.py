@@ -51,12 +51,56 @@ def check_oracle_against_golden(name):
         assert abs(float(stats[k].double().sum()) - s) <= 1e-4 * max(1.0, abs(s)), k
 
 
+YARD = 2.5
+_yard_cache = {}
+
+
+def _global_rel(grads, ref):
+    num = sum(float((grads[k].double() - g.double()).pow(2).sum()) for k, g in ref.items())
+    den = sum(float(g.double().pow(2).sum()) for g in ref.values())
+    return (num / den) ** 0.5
+
+
+def _param_worst(grads, ref, ogn):
+    worst, worst_k = 0.0, None
+    for k, g in ref.items():
+        e = float((grads[k] - g).norm() / (g.norm() + 1e-3 * ogn / len(ref) ** 0.5))
+        if e > worst:
+            worst, worst_k = e, k
+    return worst, worst_k
+
+
+def storage_model_yardstick(name, sd, cfg, inputs, labels, o_logits, o_loss, o_grads, o_stats):
+    """Deviation of the oracle's fp16 storage model (fp32 arithmetic, fp16-rounded stored tensors) from its fp32
+    mode on this case: what ANY correct fp16-storage engine is expected to show.  The engine's own deviation from
+    the fp32 reference must stay within max(north-star tolerance, YARD x this)."""
+    if name in _yard_cache:
+        return _yard_cache[name]
+    with video_ref.fp16_storage_model():
+        logits, loss, grads, stats = video_ref.loss_and_grads(sd, cfg, inputs, labels)
+    ogn = float(video_ref.grad_norm(o_grads))
+    y = {
+        "logits": float((logits - o_logits).abs().max() / o_logits.abs().max()),
+        "loss": abs(float(loss) - float(o_loss)) / max(1.0, abs(float(o_loss))),
+        "grad_norm": abs(float(video_ref.grad_norm(grads)) - ogn) / ogn,
+        "grad_global": _global_rel(grads, o_grads),
+        "param_grad_worst": _param_worst(grads, o_grads, ogn)[0],
+        "running_stats": max(float((stats[k] - v).abs().max() / (v.abs().max() + 1e-6)) for k, v in o_stats.items()),
+    }
+    _yard_cache[name] = y
+    return y
+
+
 def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=1e-3, tol_param=2e-2,
-                 tol_stats=2e-3, report=None):
-    """Forward + CE + backward of the drop-in model on `device` vs the oracle (and the golden numbers)."""
+                 tol_stats=2e-3, tol_global=1e-2, report=None):
+    """Forward + CE + backward of the drop-in model on `device` vs the oracle (and the golden numbers).
+
+    Each bound is max(tol_*, YARD x the fp16-storage-model deviation of the same quantity), see
+    storage_model_yardstick()."""
     gold = load_golden(name)
     cfg = cfg_for(gold)
     model, sd, inputs, labels, o_logits, o_loss, o_grads, o_stats = oracle_run(gold, cfg)
+    yard = storage_model_yardstick(name, sd, cfg, inputs, labels, o_logits, o_loss, o_grads, o_stats)
     model.load_state_dict(sd)
     model = model.to(device).train()
     logits = model([x.to(device) for x in inputs])
@@ -70,21 +114,23 @@ def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, t
     res["grad_norm"] = abs(gn - ogn) / ogn
     res["golden_loss"] = abs(float(loss) - gold["loss"]) / max(1.0, abs(gold["loss"]))
     res["golden_grad_norm"] = abs(gn - gold["grad_norm"]) / gold["grad_norm"]
-    worst, worst_k = 0.0, None
-    for k, g in o_grads.items():
-        e = float((grads[k] - g).norm() / (g.norm() + 1e-3 * ogn / len(o_grads) ** 0.5))
-        if e > worst:
-            worst, worst_k = e, k
-    res["param_grad_worst"] = worst
-    res["param_grad_worst_name"] = worst_k
+    res["grad_global"] = _global_rel(grads, o_grads)
+    res["param_grad_worst"], res["param_grad_worst_name"] = _param_worst(grads, o_grads, ogn)
     msd = model.state_dict()
     res["running_stats"] = max(
         float((msd[k].float().cpu() - v).abs().max() / (v.abs().max() + 1e-6)) for k, v in o_stats.items())
+    res["yardstick"] = yard
     if report is not None:
         report[name] = res
-    assert res["logits"] <= tol_logits, res
-    assert res["loss"] <= tol_loss and res["golden_loss"] <= tol_loss, res
-    assert res["grad_norm"] <= tol_gnorm and res["golden_grad_norm"] <= tol_gnorm, res
-    assert res["param_grad_worst"] <= tol_param, res
-    assert res["running_stats"] <= tol_stats, res
+
+    def bound(key, tol):
+        return max(tol, YARD * yard[key])
+
+    assert res["logits"] <= bound("logits", tol_logits), res
+    assert res["loss"] <= bound("loss", tol_loss) and res["golden_loss"] <= bound("loss", tol_loss), res
+    assert res["grad_norm"] <= bound("grad_norm", tol_gnorm), res
+    assert res["golden_grad_norm"] <= bound("grad_norm", tol_gnorm) + 1e-4, res
+    assert res["grad_global"] <= bound("grad_global", tol_global), res
+    assert res["param_grad_worst"] <= bound("param_grad_worst", tol_param), res
+    assert res["running_stats"] <= bound("running_stats", tol_stats), res
     return res

@@ -31,7 +31,7 @@ def test_model_matches_reference(gpu, name, loss_scale):
     rep = {}
     try:
         mc.check_engine(name, gpu, loss_scale=loss_scale, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=1e-3,
-                        tol_param=0.1, report=rep)
+                        tol_param=0.1, report=rep)   # bounds widen to YARD x the fp16-storage-model deviation
     finally:
         print(name, loss_scale, rep.get(name))
 
@@ -77,10 +77,15 @@ def test_full_size_batch2_against_oracle(gpu):
     grads = {k: p.grad.float().cpu() / 64.0 for k, p in model.named_parameters()}
     e_logits = float((logits.detach().float().cpu() - o_logits).abs().max() / o_logits.abs().max())
     gn, ogn = float(video_ref.grad_norm(grads)), float(video_ref.grad_norm(o_grads))
-    print("full-size batch2:", e_logits, float(loss), float(o_loss), gn, ogn)
-    assert e_logits < 4e-3
-    assert abs(float(loss) - float(o_loss)) < 1e-3 * max(1.0, float(o_loss))
-    assert abs(gn - ogn) < 2e-3 * ogn
+    with video_ref.fp16_storage_model():     # yardstick: what fp16 storage alone costs on this case
+        q_logits, q_loss, q_grads, _ = video_ref.loss_and_grads(sd, cfg, inputs, labels)
+    y_logits = float((q_logits - o_logits).abs().max() / o_logits.abs().max())
+    y_loss = abs(float(q_loss) - float(o_loss)) / max(1.0, float(o_loss))
+    y_gn = abs(float(video_ref.grad_norm(q_grads)) - ogn) / ogn
+    print("full-size batch2:", e_logits, float(loss), float(o_loss), gn, ogn, "yardstick", y_logits, y_loss, y_gn)
+    assert e_logits < max(4e-3, mc.YARD * y_logits)
+    assert abs(float(loss) - float(o_loss)) < max(1e-3, mc.YARD * y_loss) * max(1.0, float(o_loss))
+    assert abs(gn - ogn) < max(2e-3, mc.YARD * y_gn) * ogn
 
 
 def test_full_size_batch32_properties(gpu):
