@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--cpu-baseline-clips", type=int, default=2)
+    ap.add_argument("--cpu-baseline-threads", type=int, default=0, help="0 = min(64, os.cpu_count())")
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU oracle and exit")
+    ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of a HIP graph")
     return ap.parse_args()
 
 
@@ -64,11 +68,30 @@ def make_optimizer(model, cfg):
         return torch.optim.SGD(groups, foreach=True, **kw)
 
 
-def cpu_baseline(cfg, clips):
+def cpu_baseline_subprocess(a):
+    """Time the CPU oracle in a child process with a hard time limit (the default bench run must finish in minutes
+    whatever the host looks like); returns the cpu_baseline object."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--preset", a.preset,
+           "--cpu-baseline-clips", str(a.cpu_baseline_clips), "--cpu-baseline-threads", str(a.cpu_baseline_threads)]
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=a.cpu_baseline_timeout, env=env)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "clips/s", "cores": None, "kind": "port",
+                "sample": "failed: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "clips/s", "cores": None, "kind": "port",
+                "sample": f"timed out after {a.cpu_baseline_timeout:.0f} s"}
+
+
+def cpu_baseline(cfg, clips, threads=0):
     """The CPU oracle (plain torch fp32 restatement of the reference graph) on the host cores."""
     from oracle import video_ref
     import slowfast_amd as sa
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(threads or min(64, os.cpu_count() or 1))
     model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     for k in sd:                         # ZERO_INIT_FINAL_BN gammas -> 1 so backward does full work
@@ -88,6 +111,11 @@ def cpu_baseline(cfg, clips):
 
 def main():
     a = parse()
+    if a.cpu_baseline_only:
+        import slowfast_amd as sa
+        cfg = sa.get_preset(a.preset, ["NUM_GPUS", 0, "TRAIN.BATCH_SIZE", a.cpu_baseline_clips])
+        print(json.dumps(cpu_baseline(cfg, a.cpu_baseline_clips, a.cpu_baseline_threads)), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,7 +151,14 @@ def main():
     else:
         inputs = [fast]
 
+    from slowfast_amd.step import TrainStep
+    train_step = TrainStep(model, reducer, opt, F.cross_entropy, loss_scale=a.loss_scale,
+                           use_graph=not a.no_graph, warmup=1)
+
     def step():
+        return train_step(inputs, labels)
+
+    def eager_step():
         reducer.zero_grad()
         logits = model(inputs)
         loss = F.cross_entropy(logits.float(), labels)
@@ -138,6 +173,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    a.warmup = max(a.warmup, 0 if a.no_graph else 2)         # graph mode: 1 eager step + the capturing step
     for _ in range(a.warmup):
         loss = step()
     fence()
@@ -150,12 +186,12 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     kernels, roof = {}, None
     if not a.no_kernel_profile:
         with KernelProfiler() as prof:
-            step()
+            eager_step()
         summ = prof.summary()
         tot = sum(v["ms"] for v in summ.values())
         for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]:
@@ -184,7 +220,8 @@ def main():
             "dtype": "fp16", "data": "synthetic",
             "config": {"workload": f"{a.preset}: forward + cross-entropy + backward + SGD step, inputs resident in HBM, "
                                    f"per-GPU batch {a.batch}", "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "loss_scale": a.loss_scale, "bucket_mb": a.bucket_mb},
+                       "parallelism": f"dp{world}", "loss_scale": a.loss_scale, "bucket_mb": a.bucket_mb,
+                       "launch": "eager" if a.no_graph else "hip-graph(fwd+bwd) + eager all-reduce/SGD"},
             "per_gpu_clips_per_s": round(value / world, 2), "final_loss": round(final_loss, 4),
         }
         if a.preset in BYTE_FLOOR_GB_PER_CLIP:
@@ -198,7 +235,7 @@ def main():
             out["roofline"] = roof
             out["kernels"] = kernels
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_clips)
+            out["cpu_baseline"] = cpu_baseline_subprocess(a)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

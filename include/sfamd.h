@@ -18,14 +18,14 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 2
+#define SF_ABI_VERSION 3
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
  * (the stem's 3-channel clip is zero-padded to 8), Cw the channel count of the fp32 weight. */
 typedef struct sf_conv_desc {
     int32_t N, Ci, Ti, Hi, Wi;
-    int32_t Co, To, Ho, Wo;
+    int32_t Co, To, Ho, Wo; /* To/Ho/Wo may be smaller than the conv formula: trailing outputs are dropped */
     int32_t kT, kH, kW;
     int32_t sT, sH, sW;
     int32_t pT, pH, pW;
@@ -65,9 +65,10 @@ int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, c
 /* ---- BatchNorm3d -- replaces nn.BatchNorm3d built by batchnorm_helper.py:16-37 (get_norm) at every
  * *_bn call site of resnet_helper.py / stem_helper.py / video_model_builder.py:155-159, plus the
  * nn.ReLU and the residual add of resnet_helper.py:512-521. */
-/* nblk > 0: training (partials -> batch statistics, running stats updated when non-null);
+/* `part` is scratch: long tables are folded in place before the final reduction (contents are destroyed).
+ * nblk > 0: training (partials -> batch statistics, running stats updated when non-null);
  * nblk == 0: eval (running statistics).  Outputs scale = gamma*rstd, shift = beta - mean*scale. */
-int sf_bn_finalize(const float* part, int32_t nblk, int32_t C, float count, const float* gamma, const float* beta,
+int sf_bn_finalize(float* part, int32_t nblk, int32_t C, float count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                    float* save_mean, float* save_rstd, sf_stream_t stream);
 /* out = relu?( y*scale+shift [+ r*rscale+rshift | + r] ); scale == NULL means identity */
@@ -81,7 +82,7 @@ int sf_bn_bwd_reduce(int64_t M, int32_t C, const void* dz, int32_t lddz, const v
                      int32_t ldy, const float* scale, const float* shift, int relu_self, float* part,
                      sf_stream_t stream);
 /* dgamma/dbeta (fp32, unscaled by inv_loss_scale) and coef[3][C] with dy = k1*g + k2 + k3*y */
-int sf_bn_bwd_finalize(const float* part, int32_t nblk, int32_t C, float count, const float* gamma, const float* mean,
+int sf_bn_bwd_finalize(float* part, int32_t nblk, int32_t C, float count, const float* gamma, const float* mean,
                        const float* rstd, float inv_loss_scale, float* dgamma, float* dbeta, int accumulate,
                        float* coef, sf_stream_t stream);
 int sf_bn_bwd_apply(int64_t M, int32_t C, const void* dz, int32_t lddz, const void* zmask, int32_t ldm, const void* y,
@@ -92,10 +93,12 @@ int sf_bn_bwd_apply(int64_t M, int32_t C, const void* dz, int32_t lddz, const vo
  * stem_helper.py:190-201 (bn -> relu -> pool_layer). */
 int sf_pool_fwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kH, int32_t kW, int32_t sH, int32_t sW,
                 int32_t pH, int32_t pW, const void* y, int32_t ldy, const float* scale, const float* shift, int relu,
-                void* out, int32_t ldo, sf_stream_t stream);
-/* g[N,T,H,W,C] = gradient w.r.t. the BatchNorm output (pool + ReLU backward) */
+                void* out, int32_t ldo, void* argmax, sf_stream_t stream);
+/* g[N,T,H,W,C] = gradient w.r.t. the BatchNorm output (pool + ReLU backward) from the forward's pooled output
+ * (ReLU mask: pooled > 0) and its byte argmax table [N,T,Ho,Wo][C] (window-local index kh*kW+kw of the first
+ * maximum, as recorded by torch's max_pool3d) */
 int sf_pool_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kH, int32_t kW, int32_t sH, int32_t sW,
-                int32_t pH, int32_t pW, const void* y, int32_t ldy, const float* scale, const float* shift, int relu,
+                int32_t pH, int32_t pW, const void* pooled, int32_t ldp, const void* argmax, int relu,
                 const void* dout, int32_t lddo, void* g, int32_t ldg, sf_stream_t stream);
 
 /* ---- layout: clips arrive NCTHW fp32 (tools/train_net.py:79-98) */

@@ -51,8 +51,10 @@ static int check_desc(const sf_conv_desc* d) {
     int To = (d->Ti + 2 * d->pT - d->dT * (d->kT - 1) - 1) / d->sT + 1;
     int Ho = (d->Hi + 2 * d->pH - d->dH * (d->kH - 1) - 1) / d->sH + 1;
     int Wo = (d->Wi + 2 * d->pW - d->dW * (d->kW - 1) - 1) / d->sW + 1;
-    REQUIRE(To == d->To && Ho == d->Ho && Wo == d->Wo, "conv: output dims (%d,%d,%d) do not match geometry (%d,%d,%d)",
-            d->To, d->Ho, d->Wo, To, Ho, Wo);
+    // fewer outputs than the formula gives = trailing output positions dropped (asymmetric end padding; used by
+    // the W-pair-folded stem convolutions); more would read outside the padded input
+    REQUIRE(d->To >= 1 && d->Ho >= 1 && d->Wo >= 1 && d->To <= To && d->Ho <= Ho && d->Wo <= Wo,
+            "conv: output dims (%d,%d,%d) exceed the geometry's (%d,%d,%d)", d->To, d->Ho, d->Wo, To, Ho, Wo);
     int64_t Mo = (int64_t)d->N * d->To * d->Ho * d->Wo, Mi = (int64_t)d->N * d->Ti * d->Hi * d->Wi;
     REQUIRE(Mo < (1ll << 31) && Mi < (1ll << 31), "conv: more than 2^31 positions");
     return 0;
@@ -182,17 +184,17 @@ extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* 
     return run_igemm(p, (hipStream_t)stream);
 }
 
-template <int BMW, int WM, int WN>
+template <int BMW, int WM, int WN, int KS>
 static void launch_wgrad(const WgradParams& p, dim3 grid, bool scalar, hipStream_t s) {
-    if (scalar) hipLaunchKernelGGL((sf_wgrad_kernel<BMW, WM, WN, false>), grid, dim3(SF_THREADS), 0, s, p);
-    else hipLaunchKernelGGL((sf_wgrad_kernel<BMW, WM, WN, true>), grid, dim3(SF_THREADS), 0, s, p);
+    if (scalar) hipLaunchKernelGGL((sf_wgrad_kernel<BMW, WM, WN, KS, false>), grid, dim3(SF_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((sf_wgrad_kernel<BMW, WM, WN, KS, true>), grid, dim3(SF_THREADS), 0, s, p);
 }
 
 // Split-K plan of the weight gradient: the reduction over the M = N*To*Ho*Wo positions is cut into `splits`
 // slabs so that ~4 workgroups per CU are in flight; each split stores its [Co_pad][Kpad] fp32 partial tile
 // set with plain stores and sf_wgrad_reduce_kernel sums them (deterministic, no atomics).
 struct WgradPlan {
-    int BMW, tiles_k, tiles_c, Co_pad, Kpad, nchunks, chunks_per_split, splits;
+    int BMW, KS, tiles_k, tiles_c, Co_pad, Kpad, nchunks, chunks_per_split, splits;
     size_t ws_bytes;
 };
 static WgradPlan plan_wgrad(const sf_conv_desc* d) {
@@ -201,6 +203,7 @@ static WgradPlan plan_wgrad(const sf_conv_desc* d) {
     const int Ktot = taps * d->Ci;
     const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
     w.BMW = d->Co >= 128 ? 128 : d->Co >= 64 ? 64 : d->Co >= 32 ? 32 : 16;
+    w.KS = w.BMW <= 32 ? 4 : 1;                          // 32-position chunks per pipeline stage
     w.tiles_k = cdiv(Ktot, 128);
     w.tiles_c = cdiv(d->Co, w.BMW);
     w.Kpad = w.tiles_k * 128;
@@ -210,9 +213,10 @@ static WgradPlan plan_wgrad(const sf_conv_desc* d) {
     int splits = cdiv(1024, (int64_t)w.tiles_k * w.tiles_c);
     const int64_t cap = (256ll << 20) / slab;            // keep the workspace <= 256 MiB
     if (splits > cap) splits = (int)(cap < 1 ? 1 : cap);
-    if (splits > w.nchunks) splits = w.nchunks;
+    const int nstages = cdiv(w.nchunks, w.KS);
+    if (splits > nstages) splits = nstages;
     if (splits < 1) splits = 1;
-    w.chunks_per_split = cdiv(w.nchunks, splits);
+    w.chunks_per_split = cdiv(nstages, splits) * w.KS;   // whole stages per split
     w.splits = cdiv(w.nchunks, w.chunks_per_split);
     w.ws_bytes = (size_t)slab * w.splits;
     return w;
@@ -245,10 +249,10 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
     p.nchunks = w.nchunks; p.chunks_per_split = w.chunks_per_split;
     dim3 grid(w.tiles_k, w.tiles_c, w.splits);
     switch (w.BMW) {
-        case 128: launch_wgrad<128, 64, 64>(p, grid, scalar, s); break;
-        case 64: launch_wgrad<64, 32, 64>(p, grid, scalar, s); break;
-        case 32: launch_wgrad<32, 32, 32>(p, grid, scalar, s); break;
-        default: launch_wgrad<16, 16, 32>(p, grid, scalar, s); break;
+        case 128: launch_wgrad<128, 64, 64, 1>(p, grid, scalar, s); break;
+        case 64: launch_wgrad<64, 32, 64, 1>(p, grid, scalar, s); break;
+        case 32: launch_wgrad<32, 32, 32, 4>(p, grid, scalar, s); break;
+        default: launch_wgrad<16, 16, 32, 4>(p, grid, scalar, s); break;
     }
     if (check_launch("wgrad")) return -1;
     WgradReduceParams r;
@@ -256,9 +260,11 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
     r.Ktot = p.g.Ktot; r.fdC = p.g.fdC; r.dw = dw; r.Cw = d->Cw; r.taps = d->kT * d->kH * d->kW;
     r.out_scale = out_scale; r.accumulate = zero_first ? 0 : 1;
     int64_t total = (int64_t)d->Co * w.Kpad;
-    int blocks = (int)((total + SF_THREADS - 1) / SF_THREADS);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(sf_wgrad_reduce_kernel, dim3(blocks), dim3(SF_THREADS), 0, s, r);
+    int lanes = 1;
+    while (lanes < 32 && lanes * 4 <= w.splits) lanes *= 2;   // ~>= 4 splits per lane, 8..256 elements per block
+    r.lanes = lanes;
+    const int per_block = SF_THREADS / lanes;
+    hipLaunchKernelGGL(sf_wgrad_reduce_kernel, dim3(cdiv(total, per_block)), dim3(SF_THREADS), 0, s, r);
     return check_launch("wgrad_reduce");
 }
 
@@ -281,12 +287,25 @@ static int check_rows(const char* who, int64_t M, int C) {
     return 0;
 }
 
-extern "C" int sf_bn_finalize(const float* part, int32_t nblk, int32_t C, float count, const float* gamma,
+// Folds a long partial table in place (sf_part_fold_kernel) so that the single-workgroup-per-32-channels
+// finalize kernels never walk more than a few hundred rows; returns the row stride of the surviving rows.
+static int fold_partials(float* part, int& nblk, int C, hipStream_t s) {
+    if (nblk <= 256) return 1;
+    const int group = nblk <= 2048 ? 16 : nblk <= 8192 ? 32 : 64;
+    const int cols = 2 * C;
+    dim3 grid(cdiv(cols, SF_THREADS), cdiv(nblk, group));
+    hipLaunchKernelGGL(sf_part_fold_kernel, grid, dim3(SF_THREADS), 0, s, part, nblk, cols, group);
+    nblk = cdiv(nblk, group);
+    return group;
+}
+
+extern "C" int sf_bn_finalize(float* part, int32_t nblk, int32_t C, float count, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                               float* scale, float* shift, float* save_mean, float* save_rstd, sf_stream_t stream) {
     REQUIRE(gamma && beta && scale && shift, "sf_bn_finalize: null pointer");
     REQUIRE(nblk > 0 ? part != nullptr : (running_mean && running_var), "sf_bn_finalize: missing statistics source");
     BnFinalizeParams p;
+    p.row_stride = nblk > 0 ? fold_partials(part, nblk, C, (hipStream_t)stream) : 1;
     p.part = part; p.nblk = nblk; p.C = C; p.count = count; p.gamma = gamma; p.beta = beta;
     p.running_mean = running_mean; p.running_var = running_var; p.momentum = momentum; p.eps = eps;
     p.scale = scale; p.shift = shift; p.save_mean = save_mean; p.save_rstd = save_rstd;
@@ -332,11 +351,12 @@ extern "C" int sf_bn_bwd_reduce(int64_t M, int32_t C, const void* dz, int32_t ld
     return check_launch("bn_bwd_reduce");
 }
 
-extern "C" int sf_bn_bwd_finalize(const float* part, int32_t nblk, int32_t C, float count, const float* gamma,
+extern "C" int sf_bn_bwd_finalize(float* part, int32_t nblk, int32_t C, float count, const float* gamma,
                                   const float* mean, const float* rstd, float inv_loss_scale, float* dgamma,
                                   float* dbeta, int accumulate, float* coef, sf_stream_t stream) {
     REQUIRE(part && gamma && mean && rstd && dgamma && dbeta && coef, "sf_bn_bwd_finalize: null pointer");
     BnBwdFinalizeParams p;
+    p.row_stride = fold_partials(part, nblk, C, (hipStream_t)stream);
     p.part = part; p.nblk = nblk; p.C = C; p.count = count; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
     p.inv_loss_scale = inv_loss_scale; p.dgamma = dgamma; p.dbeta = dbeta; p.accumulate = accumulate; p.coef = coef;
     hipLaunchKernelGGL(sf_bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
@@ -382,11 +402,12 @@ static int pool_grid(int64_t total) {
 
 extern "C" int sf_pool_fwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kH, int32_t kW, int32_t sH,
                            int32_t sW, int32_t pH, int32_t pW, const void* y, int32_t ldy, const float* scale,
-                           const float* shift, int relu, void* out, int32_t ldo, sf_stream_t stream) {
+                           const float* shift, int relu, void* out, int32_t ldo, void* argmax, sf_stream_t stream) {
     PoolParams p;
     if (fill_pool(p, N, T, H, W, C, kH, kW, sH, sW, pH, pW, y, ldy, scale, shift, relu)) return -1;
     REQUIRE(y && out, "sf_pool_fwd: null pointer");
-    p.out = (f16*)out; p.ldo = ldo;
+    REQUIRE(kH * kW <= 255, "sf_pool_fwd: window too large for the byte argmax");
+    p.out = (f16*)out; p.ldo = ldo; p.argmax = (uint8_t*)argmax;
     p.fdW = make_fastdiv(p.Wo); p.fdH = make_fastdiv(p.Ho);
     p.total = (int64_t)N * T * p.Ho * p.Wo * (C / 8);
     REQUIRE(p.total < (1ll << 31), "sf_pool_fwd: too many elements");
@@ -395,13 +416,13 @@ extern "C" int sf_pool_fwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C
 }
 
 extern "C" int sf_pool_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kH, int32_t kW, int32_t sH,
-                           int32_t sW, int32_t pH, int32_t pW, const void* y, int32_t ldy, const float* scale,
-                           const float* shift, int relu, const void* dout, int32_t lddo, void* g, int32_t ldg,
-                           sf_stream_t stream) {
+                           int32_t sW, int32_t pH, int32_t pW, const void* pooled, int32_t ldp, const void* argmax,
+                           int relu, const void* dout, int32_t lddo, void* g, int32_t ldg, sf_stream_t stream) {
     PoolParams p;
-    if (fill_pool(p, N, T, H, W, C, kH, kW, sH, sW, pH, pW, y, ldy, scale, shift, relu)) return -1;
-    REQUIRE(y && dout && g, "sf_pool_bwd: null pointer");
+    if (fill_pool(p, N, T, H, W, C, kH, kW, sH, sW, pH, pW, nullptr, 0, nullptr, nullptr, relu)) return -1;
+    REQUIRE(pooled && argmax && dout && g, "sf_pool_bwd: null pointer");
     p.out = (f16*)g; p.ldo = ldg; p.dout = (const f16*)dout; p.lddo = lddo;
+    p.pooled = (const f16*)pooled; p.ldp = ldp; p.argmax = (uint8_t*)argmax;
     p.fdW = make_fastdiv(W); p.fdH = make_fastdiv(H);
     p.total = (int64_t)N * T * H * W * (C / 8);
     REQUIRE(p.total < (1ll << 31), "sf_pool_bwd: too many elements");
@@ -411,7 +432,7 @@ extern "C" int sf_pool_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C
 
 extern "C" int sf_ncthw_to_cl(const float* x, int32_t N, int32_t C, int64_t S, int32_t Cp, void* out,
                               sf_stream_t stream) {
-    REQUIRE(x && out && Cp % 8 == 0 && Cp >= C, "sf_ncthw_to_cl: bad arguments");
+    REQUIRE(x && out && (Cp % 8 == 0 || Cp == 4) && Cp >= C, "sf_ncthw_to_cl: bad arguments");
     hipLaunchKernelGGL(sf_ncthw_to_cl_kernel, dim3(pool_grid((int64_t)N * S)), dim3(SF_THREADS), 0,
                        (hipStream_t)stream, x, (f16*)out, N, C, S, Cp);
     return check_launch("ncthw_to_cl");

@@ -35,10 +35,55 @@ __device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stage 1 of the per-channel reductions (forward statistics and backward sums): the producers leave one
+// row of 2*C partial sums per workgroup (up to ~25k rows for the stem); a thread per column folds `group`
+// consecutive rows into the first row of its group, IN PLACE (a thread only ever touches its own column of
+// its own group, so there is no cross-thread hazard), in a fixed order (deterministic).  The finalize
+// kernels then walk the surviving rows with stride `group`.
+__global__ __launch_bounds__(SF_THREADS) void sf_part_fold_kernel(float* part, int nblk, int cols, int group) {
+    const int col = blockIdx.x * SF_THREADS + threadIdx.x;
+    if (col >= cols) return;
+    const int r0 = blockIdx.y * group;
+    int r1 = r0 + group;
+    if (r1 > nblk) r1 = nblk;
+    float* base = part + (int64_t)r0 * cols + col;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        const float v0 = base[(int64_t)(r - r0) * cols], v1 = base[(int64_t)(r - r0 + 1) * cols];
+        const float v2 = base[(int64_t)(r - r0 + 2) * cols], v3 = base[(int64_t)(r - r0 + 3) * cols];
+        a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+    }
+    for (; r < r1; ++r) a0 += (double)base[(int64_t)(r - r0) * cols];
+    base[0] = (float)((a0 + a1) + (a2 + a3));
+}
+
+// sums of rows seg, seg+8, ... (< nrows) of a [nrows][2][C] table whose rows are `stride` table-rows apart
+__device__ __forceinline__ void strided_col_sums(const float* part, int nrows, int stride, int C, int c, int seg,
+                                                 double& s, double& q) {
+    double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
+    const int64_t rs = (int64_t)stride * 2 * C;
+    int b = seg;
+    for (; b + 8 < nrows; b += 16) {
+        const float* p0 = part + (int64_t)b * rs + c;
+        const float* p1 = p0 + 8 * rs;
+        const float u0 = p0[0], w0 = p0[C], u1 = p1[0], w1 = p1[C];
+        s0 += (double)u0; q0 += (double)w0; s1 += (double)u1; q1 += (double)w1;
+    }
+    for (; b < nrows; b += 8) {
+        const float* p0 = part + (int64_t)b * rs + c;
+        s0 += (double)p0[0]; q0 += (double)p0[C];
+    }
+    s = s0 + s1;
+    q = q0 + q1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward statistics -> scale/shift
 struct BnFinalizeParams {
-    const float* part;   // [nblk][2][C] (sum, sumsq); nblk == 0 -> eval mode (running statistics)
+    const float* part;   // [nblk][2][C] (sum, sumsq), rows `row_stride` apart; nblk == 0 -> eval mode
     int nblk;
+    int row_stride;
     int C;
     float count;         // N*T*H*W
     const float* gamma;
@@ -60,12 +105,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_finalize_kernel(BnFinalizePa
     const int cx = threadIdx.x & 31, seg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     double s = 0.0, q = 0.0;
-    if (c < p.C) {
-        for (int b = seg; b < p.nblk; b += 8) {
-            s += (double)p.part[((int64_t)b * 2 + 0) * p.C + c];
-            q += (double)p.part[((int64_t)b * 2 + 1) * p.C + c];
-        }
-    }
+    if (c < p.C && p.nblk > 0) strided_col_sums(p.part, p.nblk, p.row_stride, p.C, c, seg, s, q);
     s_s[seg][cx] = s;
     s_q[seg][cx] = q;
     __syncthreads();
@@ -203,7 +243,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_reduce_kernel(BnBwdReduc
 }
 
 struct BnBwdFinalizeParams {
-    const float* part; int nblk; int C;
+    const float* part; int nblk; int row_stride; int C;
     float count;
     const float* gamma; const float* mean; const float* rstd;
     float inv_loss_scale;
@@ -218,12 +258,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_finalize_kernel(BnBwdFin
     const int cx = threadIdx.x & 31, seg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     double s = 0.0, q = 0.0;
-    if (c < p.C) {
-        for (int b = seg; b < p.nblk; b += 8) {
-            s += (double)p.part[((int64_t)b * 2 + 0) * p.C + c];
-            q += (double)p.part[((int64_t)b * 2 + 1) * p.C + c];
-        }
-    }
+    if (c < p.C) strided_col_sums(p.part, p.nblk, p.row_stride, p.C, c, seg, s, q);
     s_s[seg][cx] = s;
     s_q[seg][cx] = q;
     __syncthreads();

@@ -13,6 +13,7 @@ typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((aligned(8))) u32x2 { uint32_t x, y; };
 typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 // LDS transpose read (ds_read_b64_tr_b16).  The host functional simulator (tests/hostsim) pre-defines

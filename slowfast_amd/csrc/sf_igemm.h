@@ -229,24 +229,47 @@ struct WgradReduceParams {
     int Cw, taps;
     float out_scale;
     int accumulate;
+    int lanes;          // split lanes per output element (power of two, 1..32)
 };
 
+// 256 threads = E output elements x L split lanes (L = p.lanes, a power of two <= 32): lane z of an element sums
+// splits z, z+L, ... with two independent accumulators, an LDS tree folds the L lanes (fixed order: the result
+// does not depend on scheduling).  Consecutive elements are consecutive kcol, i.e. contiguous in every slab.
 __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_reduce_kernel(WgradReduceParams p) {
+    __shared__ float s_acc[SF_THREADS];
+    const int L = p.lanes, E = SF_THREADS / L;
+    const int e = threadIdx.x % E, z0 = threadIdx.x / E;
     const int64_t total = (int64_t)p.Co * p.Kpad;
     const int64_t slab = (int64_t)p.Co_pad * p.Kpad;
-    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * SF_THREADS) {
+    const int64_t idx = (int64_t)blockIdx.x * E + e;
+    float a0 = 0.f, a1 = 0.f;
+    if (idx < total) {
+        const float* src = p.ws + idx;          // element (co, kcol) sits at co*Kpad + kcol = idx in every slab
+        int z = z0;
+        for (; z + L < p.splits; z += 2 * L) {
+            const float v0 = src[(int64_t)z * slab], v1 = src[(int64_t)(z + L) * slab];
+            a0 += v0;
+            a1 += v1;
+        }
+        if (z < p.splits) a0 += src[(int64_t)z * slab];
+    }
+    s_acc[threadIdx.x] = a0 + a1;
+    __syncthreads();
+    for (int half = L >> 1; half >= 1; half >>= 1) {
+        if (z0 < half) s_acc[threadIdx.x] += s_acc[threadIdx.x + half * E];
+        __syncthreads();
+    }
+    if (z0 == 0 && idx < total) {
         const int co = (int)(idx / p.Kpad), kcol = (int)(idx % p.Kpad);
-        if (kcol >= p.Ktot) continue;
-        uint32_t tap, ci;
-        fd_divmod((uint32_t)kcol, p.fdC, tap, ci);
-        if (ci >= (uint32_t)p.Cw) continue;
-        float s = 0.f;
-        const float* src = p.ws + (int64_t)co * p.Kpad + kcol;
-        for (int z = 0; z < p.splits; ++z) s += src[z * slab];
-        float* dst = p.dw + ((int64_t)co * p.Cw + ci) * p.taps + tap;
-        s *= p.out_scale;
-        *dst = p.accumulate ? *dst + s : s;
+        if (kcol < p.Ktot) {
+            uint32_t tap, ci;
+            fd_divmod((uint32_t)kcol, p.fdC, tap, ci);
+            if (ci < (uint32_t)p.Cw) {
+                float* dst = p.dw + ((int64_t)co * p.Cw + ci) * p.taps + tap;
+                const float v = s_acc[threadIdx.x] * p.out_scale;
+                *dst = p.accumulate ? *dst + v : v;
+            }
+        }
     }
 }
 
@@ -257,19 +280,52 @@ __device__ __forceinline__ f16x4 as_f16x4(V v) {
     return o;
 }
 
+// Tap decomposition of one K-column group, hoisted out of the position loop of the weight-gradient kernel
+// (a loader thread keeps its column group for the whole kernel).
+struct TapPos {
+    int dt, dh, dw;     // tap offsets in source coordinates (kt*dilT, kh*dilH, kw*dilW)
+    uint32_t c0;        // first channel of the 8-channel group
+    bool valid;         // column group < Ktot
+};
+__device__ __forceinline__ TapPos decode_tap(const GatherSide& g, uint32_t k0) {
+    TapPos t;
+    t.valid = k0 < (uint32_t)g.Ktot;
+    uint32_t tap, kt, kh, kw, q;
+    fd_divmod(t.valid ? k0 : 0u, g.fdC, tap, t.c0);
+    fd_divmod(tap, g.fdkW, q, kw);
+    fd_divmod(q, g.fdkH, kt, kh);
+    t.dt = (int)kt * g.dilT; t.dh = (int)kh * g.dilH; t.dw = (int)kw * g.dilW;
+    return t;
+}
+// mode-0 gather (rows are conv outputs) of a pre-decoded tap
+__device__ __forceinline__ bool gather_offset_tap(const GatherSide& g, const RowPos& r, const TapPos& tp, int64_t& off) {
+    if (!r.valid || !tp.valid) return false;
+    const int t = r.bt + tp.dt, h = r.bh + tp.dh, w = r.bw + tp.dw;
+    if ((unsigned)t >= (unsigned)g.sT || (unsigned)h >= (unsigned)g.sH || (unsigned)w >= (unsigned)g.sW) return false;
+    off = ((((int64_t)r.n * g.sT + t) * g.sH + h) * g.sW + w) * (int64_t)g.ld + tp.c0;
+    return true;
+}
+
+// Weight gradient: dW[co][k] = sum_m dY[m][co] * A(m, k), one BMW x 128 tile of dW per workgroup, reduction over
+// the positions of one split.  A stage stages KS*32 positions of both operands in LDS.
+//   KS == 1: two LDS buffers, global loads of stage s+1 in flight under the MFMAs of stage s (MFMA-bound tiles);
+//   KS  > 1: small-Co tiles are HBM-bound and latency-limited -- a long stage (128 positions) amortises the
+//            barrier and the load latency, one LDS buffer + register staging keeps 3 workgroups per CU.
 // TR = true : MFMA fragments via ds_read_b64_tr_b16 (hardware transpose read)
 // TR = false: eight scalar LDS reads per fragment (reference path, selectable with SF_WGRAD_SCALAR=1)
-template <int BMW, int WM, int WN, bool TR>
+template <int BMW, int WM, int WN, int KS, bool TR>
 __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
-    constexpr int BNW = 128, BKM = 32;
+    constexpr int BNW = 128, BKM = 32, ROWS = BKM * KS;
     constexpr int WAVES_N = BNW / WN, WAVES_M = BMW / WM;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int LDA = BMW + 16, LDB = BNW + 16;
-    constexpr int BUF = BKM * (LDA + LDB);
-    constexpr int NA = (4 * BMW + SF_THREADS - 1) / SF_THREADS;
+    constexpr int BUF = ROWS * (LDA + LDB);
+    constexpr int NBUF = KS == 1 ? 2 : 1;
+    constexpr int NA = (ROWS * (BMW / 8) + SF_THREADS - 1) / SF_THREADS;
+    constexpr int NX = 2 * KS;
 
-    __shared__ __attribute__((aligned(16))) f16 smem[2 * BUF];
+    __shared__ __attribute__((aligned(16))) f16 smem[NBUF * BUF];
     __shared__ float s_scale[512];
     __shared__ float s_shift[512];
 
@@ -285,50 +341,48 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             s_shift[c] = g.shift[c];
         }
     }
-    const int cb = blockIdx.z * p.chunks_per_split;
-    int ce = cb + p.chunks_per_split;
-    if (ce > p.nchunks) ce = p.nchunks;
+    // this split's stages (chunks_per_split counts 32-position chunks and is a multiple of KS)
+    const int sb = blockIdx.z * (p.chunks_per_split / KS);
+    int se = sb + p.chunks_per_split / KS;
+    const int nstages = (p.nchunks + KS - 1) / KS;
+    if (se > nstages) se = nstages;
 
-    f16x8 ra[NA], rb[2];
-    bool rb_ok[2];
-    uint32_t rb_c0[2];
-    const uint32_t xk0 = (uint32_t)(n0 + (tid & 15) * 8);
+    f16x8 ra[NA], rb[NX];
+    bool rb_ok[NX];
+    const TapPos tp = decode_tap(g, (uint32_t)(n0 + (tid & 15) * 8));
 
-    auto load_tile = [&](int chunk) {
-        const int mbase = chunk * BKM;
+    auto load_tile = [&](int stage) {
+        const int mbase = stage * ROWS;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int idx = tid + SF_THREADS * j;
             int ml = idx / (BMW / 8), cg = idx % (BMW / 8);
             int m = mbase + ml, co = c0 + cg * 8;
-            bool ok = (idx < 4 * BMW) && (m < p.M) && (co < p.Co);
+            bool ok = (idx < ROWS * (BMW / 8)) && (m < p.M) && (co < p.Co);
             ra[j] = ok ? ld16(p.dy + (int64_t)m * p.ldy + co) : zero8();
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int ml = (tid >> 4) + 16 * j;
-            int m = mbase + ml;
+        for (int j = 0; j < NX; ++j) {
+            int m = mbase + (tid >> 4) + 16 * j;
             RowPos rp = decode_row(g, (uint32_t)m, m < p.M);
             int64_t off;
-            uint32_t cc = 0;
-            bool ok = gather_offset(g, rp, xk0, off, cc);
+            bool ok = gather_offset_tap(g, rp, tp, off);
             rb[j] = ok ? ld16(g.src + off) : zero8();
             rb_ok[j] = ok;
-            rb_c0[j] = cc;
         }
     };
     auto store_tile = [&](int buf) {
         f16* Ys = smem + buf * BUF;
-        f16* Xs = Ys + BKM * LDA;
+        f16* Xs = Ys + ROWS * LDA;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int idx = tid + SF_THREADS * j;
-            if (idx < 4 * BMW) st16(Ys + (idx / (BMW / 8)) * LDA + (idx % (BMW / 8)) * 8, ra[j]);
+            if (idx < ROWS * (BMW / 8)) st16(Ys + (idx / (BMW / 8)) * LDA + (idx % (BMW / 8)) * 8, ra[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NX; ++j) {
             f16x8 v = rb[j];
-            if (has_tf && rb_ok[j]) v = bn_relu8(v, s_scale + rb_c0[j], s_shift + rb_c0[j], g.relu);
+            if (has_tf && rb_ok[j]) v = bn_relu8(v, s_scale + tp.c0, s_shift + tp.c0, g.relu);
             st16(Xs + ((tid >> 4) + 16 * j) * LDB + (tid & 15) * 8, v);
         }
     };
@@ -341,57 +395,67 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
 
     const int pl = lane & 15, g4 = lane >> 4;
     auto compute = [&](int buf) {
-        const f16* Ys = smem + buf * BUF;
-        const f16* Xs = Ys + BKM * LDA;
-        f16x8 af[TM], bf[TN];
-        if constexpr (TR) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16* Ys = smem + buf * BUF + ks * BKM * LDA;
+            const f16* Xs = smem + buf * BUF + ROWS * LDA + ks * BKM * LDB;
+            f16x8 af[TM], bf[TN];
+            if constexpr (TR) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f16* ptr = Ys + (8 * g4 + 4 * h + (pl >> 2)) * LDA + wm * WM + i * 16 + 4 * (pl & 3);
-                    f16x4 t = as_f16x4(SF_LDS_TR16(ptr));
-                    af[i][4 * h + 0] = t[0]; af[i][4 * h + 1] = t[1]; af[i][4 * h + 2] = t[2]; af[i][4 * h + 3] = t[3];
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f16* ptr = Ys + (8 * g4 + 4 * h + (pl >> 2)) * LDA + wm * WM + i * 16 + 4 * (pl & 3);
+                        f16x4 t = as_f16x4(SF_LDS_TR16(ptr));
+                        af[i][4 * h + 0] = t[0]; af[i][4 * h + 1] = t[1]; af[i][4 * h + 2] = t[2]; af[i][4 * h + 3] = t[3];
+                    }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+                for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f16* ptr = Xs + (8 * g4 + 4 * h + (pl >> 2)) * LDB + wn * WN + j * 16 + 4 * (pl & 3);
-                    f16x4 t = as_f16x4(SF_LDS_TR16(ptr));
-                    bf[j][4 * h + 0] = t[0]; bf[j][4 * h + 1] = t[1]; bf[j][4 * h + 2] = t[2]; bf[j][4 * h + 3] = t[3];
+                    for (int h = 0; h < 2; ++h) {
+                        const f16* ptr = Xs + (8 * g4 + 4 * h + (pl >> 2)) * LDB + wn * WN + j * 16 + 4 * (pl & 3);
+                        f16x4 t = as_f16x4(SF_LDS_TR16(ptr));
+                        bf[j][4 * h + 0] = t[0]; bf[j][4 * h + 1] = t[1]; bf[j][4 * h + 2] = t[2]; bf[j][4 * h + 3] = t[3];
+                    }
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) af[i][e] = Ys[(8 * g4 + e) * LDA + wm * WM + i * 16 + pl];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bf[j][e] = Xs[(8 * g4 + e) * LDB + wn * WN + j * 16 + pl];
             }
-        } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) af[i][e] = Ys[(8 * g4 + e) * LDA + wm * WM + i * 16 + pl];
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bf[j][e] = Xs[(8 * g4 + e) * LDB + wn * WN + j * 16 + pl];
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
 
     if (has_tf) __syncthreads();
-    if (cb < ce) {
-        load_tile(cb);
+    if (sb < se) {
+        load_tile(sb);
         store_tile(0);
     }
     __syncthreads();
-    for (int ch = cb; ch < ce; ++ch) {
-        const bool more = ch + 1 < ce;
-        if (more) load_tile(ch + 1);
-        compute((ch - cb) & 1);
-        if (more) store_tile((ch - cb + 1) & 1);
-        __syncthreads();
+    for (int st = sb; st < se; ++st) {
+        const bool more = st + 1 < se;
+        if (more) load_tile(st + 1);
+        if constexpr (NBUF == 2) {
+            compute((st - sb) & 1);
+            if (more) store_tile((st - sb + 1) & 1);
+            __syncthreads();
+        } else {
+            compute(0);
+            __syncthreads();            // every wave is done reading the stage
+            if (more) store_tile(0);
+            __syncthreads();
+        }
     }
     // every split owns its slab: plain (non-atomic) stores, also when it had no rows to reduce (zeros)
     float* slab = p.ws + (int64_t)blockIdx.z * p.Co_pad * p.Kpad;

@@ -6,12 +6,15 @@
 #include "sf_common.h"
 
 struct PoolParams {
-    const f16* y; int ldy;          // raw conv output [N,T,H,W][C]
+    const f16* y; int ldy;          // fwd: raw conv output [N,T,H,W][C]
     const float* scale; const float* shift; int relu;   // producer BN (+ReLU); scale may be null
     int N, T, H, W, C;
     int Ho, Wo;
     int kH, kW, sH, sW, pH, pW;
     f16* out; int ldo;              // fwd: pooled [N,T,Ho,Wo][C]; bwd: g [N,T,H,W][C]
+    uint8_t* argmax;                // fwd (optional out) / bwd (in): window-local index kh*kW+kw of the maximum,
+                                    // [N,T,Ho,Wo][C] bytes
+    const f16* pooled; int ldp;     // bwd: the forward's pooled output (ReLU mask: gradient flows iff pooled > 0)
     const f16* dout; int lddo;      // bwd: gradient of the pooled output
     FastDiv fdG, fdW, fdH;          // work index -> (group, w, h, rest); dims of the iterated space
     int64_t total;
@@ -23,12 +26,13 @@ __device__ __forceinline__ void bn_act8(const f16x8& v, const float (&sc)[8], co
     for (int e = 0; e < 8; ++e) {
         float x = (float)v[e] * sc[e] + sh[e];
         if (relu) x = x > 0.f ? x : 0.f;
-        z[e] = (float)(f16)x;  // forward stores fp16: compare what the forward compared
+        z[e] = (float)(f16)x;  // the pooled tensor is stored in fp16: compare what is stored
     }
 }
 
+// One thread per (pooled position, 8 channels).  The FIRST maximum in scan order wins (the element torch's
+// max_pool3d records); its window-local index is kept for the backward pass.
 __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
-    const int G = p.C >> 3;
     for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
          idx += (int64_t)gridDim.x * SF_THREADS) {
         uint32_t q, gcol, wo, ho, nt;
@@ -44,8 +48,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
             for (int e = 0; e < 8; ++e) { sc[e] = p.scale[c + e]; sh[e] = p.shift[c + e]; }
         }
         float best[8];
+        uint32_t arg[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = 0; }
         for (int kh = 0; kh < p.kH; ++kh) {
             const int h = (int)ho * p.sH - p.pH + kh;
             if ((unsigned)h >= (unsigned)p.H) continue;
@@ -55,20 +60,32 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
                 f16x8 v = ld16(p.y + (((int64_t)nt * p.H + h) * p.W + w) * p.ldy + c);
                 float z[8];
                 bn_act8(v, sc, sh, p.relu, z);
+                const uint32_t code = (uint32_t)(kh * p.kW + kw);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) best[e] = z[e] > best[e] ? z[e] : best[e];
+                for (int e = 0; e < 8; ++e) {
+                    const bool gt = z[e] > best[e];
+                    best[e] = gt ? z[e] : best[e];
+                    arg[e] = gt ? code : arg[e];
+                }
             }
         }
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (f16)best[e];
-        st16(p.out + (((int64_t)nt * p.Ho + ho) * p.Wo + wo) * p.ldo + c, o);
+        const int64_t orow = ((int64_t)nt * p.Ho + ho) * p.Wo + wo;
+        st16(p.out + orow * p.ldo + c, o);
+        if (p.argmax) {
+            u32x2 pk;
+            pk.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+            pk.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+            *reinterpret_cast<u32x2*>(p.argmax + orow * p.C + c) = pk;
+        }
     }
 }
 
-// Gather form of the max-pool backward: one thread per (input position, 8 channels) decides, for
-// each window that covers it, whether it is that window's FIRST maximum in scan order (the element
-// torch's max_pool3d records), sums the matching output gradients and applies the ReLU mask.
+// Gather form of the max-pool(+ReLU) backward: one thread per (input position, 8 channels) visits the (at most
+// ceil(kH/sH)*ceil(kW/sW)) windows that cover it and takes a window's gradient iff the recorded argmax is this
+// position and the pooled value is positive (the ReLU in front of the pool passed it).
 __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
     for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
          idx += (int64_t)gridDim.x * SF_THREADS) {
@@ -77,16 +94,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
         fd_divmod(q, p.fdW, q, w);
         fd_divmod(q, p.fdH, nt, h);
         const int c = gcol * 8;
-        float sc[8], sh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
-        if (p.scale) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { sc[e] = p.scale[c + e]; sh[e] = p.shift[c + e]; }
-        }
-        const f16* ybase = p.y + (int64_t)nt * p.H * p.W * p.ldy + c;
-        float zs[8], g[8];
-        bn_act8(ld16(ybase + ((int64_t)h * p.W + w) * p.ldy), sc, sh, p.relu, zs);
+        float g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = 0.f;
         // windows ho with ho*sH - pH <= h <= ho*sH - pH + kH - 1
@@ -98,31 +106,22 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
             const int khs = (int)h - (ho * p.sH - p.pH);
             for (int wo = wo_lo; wo <= wo_hi; ++wo) {
                 const int kws = (int)w - (wo * p.sW - p.pW);
-                bool isarg[8];
+                const uint32_t me = (uint32_t)(khs * p.kW + kws);
+                const int64_t orow = ((int64_t)nt * p.Ho + ho) * p.Wo + wo;
+                const u32x2 pk = *reinterpret_cast<const u32x2*>(p.argmax + orow * p.C + c);
+                const f16x8 d = ld16(p.dout + orow * p.lddo + c);
+                const f16x8 pv = ld16(p.pooled + orow * p.ldp + c);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) isarg[e] = true;
-                for (int kh = 0; kh < p.kH; ++kh) {
-                    const int hh = ho * p.sH - p.pH + kh;
-                    if ((unsigned)hh >= (unsigned)p.H) continue;
-                    for (int kw = 0; kw < p.kW; ++kw) {
-                        const int ww = wo * p.sW - p.pW + kw;
-                        if ((unsigned)ww >= (unsigned)p.W) continue;
-                        if (kh == khs && kw == kws) continue;
-                        float zq[8];
-                        bn_act8(ld16(ybase + ((int64_t)hh * p.W + ww) * p.ldy), sc, sh, p.relu, zq);
-                        const bool before = (kh < khs) || (kh == khs && kw < kws);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) isarg[e] = isarg[e] && (before ? (zs[e] > zq[e]) : (zs[e] >= zq[e]));
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t a = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
+                    const bool take = (a == me) && (!p.relu || (float)pv[e] > 0.f);
+                    g[e] += take ? (float)d[e] : 0.f;
                 }
-                f16x8 d = ld16(p.dout + (((int64_t)nt * p.Ho + ho) * p.Wo + wo) * p.lddo + c);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) g[e] += isarg[e] ? (float)d[e] : 0.f;
             }
         }
         f16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (f16)((p.relu && !(zs[e] > 0.f)) ? 0.f : g[e]);
+        for (int e = 0; e < 8; ++e) o[e] = (f16)g[e];
         st16(p.out + (((int64_t)nt * p.H + h) * p.W + w) * p.ldo + c, o);
     }
 }
@@ -135,6 +134,13 @@ __global__ __launch_bounds__(SF_THREADS) void sf_ncthw_to_cl_kernel(const float*
     for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * SF_THREADS) {
         const int64_t n = idx / S, s = idx - n * S;
+        if (Cp == 4) {   // 3-channel clips for the W-pair-folded stem convolutions: 8 bytes per position
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = e < C ? (f16)x[(n * C + e) * S + s] : (f16)0;
+            *reinterpret_cast<f16x4*>(out + idx * 4) = o;
+            continue;
+        }
         for (int cg = 0; cg < Cp; cg += 8) {
             f16x8 o;
 #pragma unroll

@@ -50,6 +50,7 @@ class GradReducer:
         self._listener = engine.add_grad_ready_listener(self._on_ready)
         # parameters owned by plain torch modules (the head) announce themselves through autograd hooks
         self._hooked = set()
+        self.capturing = False                  # True while TrainStep records the HIP graph: no collectives
         self.zero_grad()
 
     # -- per-iteration protocol -------------------------------------------------------------------------
@@ -59,6 +60,14 @@ class GradReducer:
         for p, v in self._views.items():
             if p.grad is not v:
                 p.grad = v
+        self._pending = [len(ps) for _, _, ps in self.buckets]
+        self._ready = set()
+        self._handles = []
+
+    def begin_replay(self):
+        """Before replaying a captured forward/backward (slowfast_amd.step.TrainStep): the captured work clears
+        the flat buffer and writes every gradient, but none of the Python-side readiness callbacks run, so all
+        buckets are reduced by finish()."""
         self._pending = [len(ps) for _, _, ps in self.buckets]
         self._ready = set()
         self._handles = []
@@ -80,7 +89,7 @@ class GradReducer:
                 self._launch(bi)
 
     def _launch(self, bi):
-        if self.world == 1:
+        if self.world == 1 or self.capturing:
             return
         s, e, _ = self.buckets[bi]
         view = self.flat[s:e]

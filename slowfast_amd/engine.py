@@ -25,6 +25,10 @@ from . import ops
 
 _f16 = torch.float16
 _listeners = []
+# While a training step is being captured into a HIP graph (slowfast_amd.step.TrainStep) the fp32 -> fp16 weight
+# repack must be part of the captured work unconditionally: a replay runs after an optimizer update that the
+# host-side version check below never sees.
+FORCE_WEIGHT_PREP = False
 
 
 def add_grad_ready_listener(fn):
@@ -93,7 +97,7 @@ class ConvUnit:
     def weights(self, geom):
         w = self.conv.weight
         key = (w.data_ptr(), w._version, geom.Ci, w.device)
-        if self._wkey != key:
+        if FORCE_WEIGHT_PREP or self._wkey != key:
             self._w = ops.prep_weights(w.detach(), geom, need_dgrad=(geom.Cw == geom.Ci))
             self._wkey = key
         return self._w
@@ -151,6 +155,78 @@ class ConvUnit:
         return p
 
 
+class StemConvUnit(ConvUnit):
+    """Conv3d with <= 4 input channels (the RGB stems) as a W-pair-folded implicit GEMM.
+
+    A 3-channel clip padded to 8 channels would waste 5/8 of every MFMA K-step.  Instead the clip is stored
+    N,T,H,W,4 and read as N,T,H,W/2,8: one 16-byte operand group = two neighbouring pixels x 4 channels.  The
+    (kT,kH,kW) stride-(.,.,sW) convolution becomes a (kT,kH,kW2) stride-(.,.,sW/2) convolution over that view with
+    the kW axis zero-extended to an even length starting on an even pixel (one leading zero tap when pW is odd),
+    so K = taps2*8 carries 3/4 * kW/(2 kW2) useful elements (66 % for 7 taps) instead of 3/8.  The virtual weight
+    [Co][8][kT][kH][kW2] is gathered from / scattered to the nn.Conv3d parameter with a few tiny tensor ops."""
+
+    def __init__(self, conv, bn=None):
+        super().__init__(conv, bn)
+        kT, kH, kW = conv.kernel_size
+        sT, sH, sW = conv.stride
+        pT, pH, pW = conv.padding
+        assert conv.in_channels <= 4 and sW % 2 == 0 and conv.dilation == (1, 1, 1)
+        self.lead = pW % 2
+        self.kext = kW + self.lead + ((kW + self.lead) % 2)
+        self.k2 = (kT, kH, self.kext // 2)
+        self.s2 = (sT, sH, sW // 2)
+        self.p2 = (pT, pH, (pW + self.lead) // 2)
+
+    def prepare_input(self, x):
+        """NCTHW fp32 clip -> the W-pair view (N, 8, T, H, W/2) fp16."""
+        return ops.ncthw_to_cl_wpairs(x.float())
+
+    def geom(self, in_shape):
+        key = tuple(in_shape)
+        g = self._geoms.get(key)
+        if g is None:
+            c = self.conv
+            N, C2, T, H, W2 = key
+            assert C2 == 8
+            Wo = (2 * W2 + 2 * c.padding[2] - c.kernel_size[2]) // c.stride[2] + 1
+            g = ops.ConvGeom(key, c.out_channels, self.k2, self.s2, self.p2, (1, 1, 1), Cw=8)
+            g = ops.ConvGeom(key, c.out_channels, self.k2, self.s2, self.p2, (1, 1, 1), Cw=8,
+                             out_dims=(g.To, g.Ho, Wo))
+            self._geoms[key] = g
+        return g
+
+    def _virtual_weight(self, w):
+        Co, Cin, kT, kH, kW = w.shape
+        wv = torch.nn.functional.pad(w, (self.lead, self.kext - kW - self.lead, 0, 0, 0, 0, 0, 4 - Cin))
+        wv = wv.view(Co, 4, kT, kH, self.kext // 2, 2).permute(0, 5, 1, 2, 3, 4)
+        return wv.reshape(Co, 8, kT, kH, self.kext // 2).contiguous()
+
+    def weights(self, geom):
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version, geom.Ci, w.device)
+        if FORCE_WEIGHT_PREP or self._wkey != key:
+            self._w = ops.prep_weights(self._virtual_weight(w.detach()), geom, need_dgrad=False)
+            self._wkey = key
+        return self._w
+
+    def backward(self, x, in_affine, dy, need_dx, resid=None):
+        assert not need_dx, "the stems take the input clip: no data gradient"
+        geom = self.geom(x.shape)
+        w = self.conv.weight
+        if w.requires_grad:
+            Co, Cin, kT, kH, kW = w.shape
+            dwv = torch.empty((Co, 8, kT, kH, self.kext // 2), dtype=torch.float32, device=w.device)
+            ops.conv_wgrad(x, dy, geom, dwv, in_affine=in_affine, out_scale=1.0, zero_first=True)
+            dw = dwv.view(Co, 2, 4, kT, kH, self.kext // 2).permute(0, 2, 3, 4, 5, 1).reshape(Co, 4, kT, kH, self.kext)
+            dw = dw[:, :Cin, :, :, self.lead:self.lead + kW]
+            dst, zero_first = _grad_dest(w)
+            if zero_first:
+                dst.copy_(dw)
+            else:
+                dst.add_(dw)
+        return None
+
+
 # ------------------------------------------------------------------------------------------------
 class StemFn(torch.autograd.Function):
     """conv -> BN -> ReLU -> MaxPool3d([1,k,k]) (slowfast/models/stem_helper.py:196-201)."""
@@ -158,24 +234,25 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, *params):
         unit = mod._unit
-        xcl = ops.to_cl(x)
+        xcl = unit.prepare_input(x) if isinstance(unit, StemConvUnit) else ops.to_cl(x)
         y, st = unit.forward(xcl, None, mod.training)
         k, s, p = mod.pool_layer.kernel_size, mod.pool_layer.stride, mod.pool_layer.padding
         assert k[0] == 1 and s[0] == 1 and p[0] == 0, "stem pooling is spatial-only in every reference config"
-        out = ops.pool_fwd(y, k[1:], s[1:], p[1:], affine=(st.scale, st.shift, True))
+        out, arg = ops.pool_fwd(y, k[1:], s[1:], p[1:], affine=(st.scale, st.shift, True))
         ctx.mod, ctx.xcl, ctx.y, ctx.st = mod, xcl, y, st
         ctx.pool = (tuple(k[1:]), tuple(s[1:]), tuple(p[1:]))
+        ctx.pooled, ctx.arg = out, arg
         return out
 
     @staticmethod
     def backward(ctx, dout):
         unit = ctx.mod._unit
         st = ctx.st
-        g = ops.pool_bwd(ctx.y, as_cl(dout), *ctx.pool, affine=(st.scale, st.shift, True))
+        g = ops.pool_bwd(ctx.y.shape, ctx.pooled, ctx.arg, as_cl(dout), *ctx.pool, relu=True)
         dy = unit.bn_backward(g, ctx.y, st)
         unit.backward(ctx.xcl, None, dy, need_dx=False)
         _notify(unit.params())
-        ctx.xcl = ctx.y = None
+        ctx.xcl = ctx.y = ctx.pooled = ctx.arg = None
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 

@@ -86,8 +86,22 @@ def ncthw_to_cl(x, Cp=None):
     N, C, T, H, W = x.shape
     Cp = Cp or (C + 7) // 8 * 8
     out = cl_empty((N, Cp, T, H, W), x.device)
-    get_lib().call("sf_ncthw_to_cl", x.data_ptr(), N, C, T * H * W, Cp, out.data_ptr(), _stream(x))
+    get_lib().call("sf_ncthw_to_cl", x.data_ptr(), N, C, T * H * W, Cp, out.data_ptr(), _stream(x),
+                   work=dict(bytes=4.0 * x.numel() + 2.0 * out.numel()))
     return out
+
+
+def ncthw_to_cl_wpairs(x):
+    """NCTHW fp32 clip with C <= 4 -> fp16 N,T,H,W,4 viewed as a channels-last tensor of logical shape
+    (N, 8, T, H, W/2): channel index = (w & 1) * 4 + c.  Operand layout of the W-pair-folded stem convolution
+    (engine.StemConvUnit)."""
+    assert x.dim() == 5 and x.dtype == torch.float32 and x.shape[1] <= 4 and x.shape[4] % 2 == 0
+    x = x.contiguous()
+    N, C, T, H, W = x.shape
+    base = torch.empty((N, T, H, W // 2, 8), dtype=_f16, device=x.device)
+    get_lib().call("sf_ncthw_to_cl", x.data_ptr(), N, C, T * H * W, 4, base.data_ptr(), _stream(x),
+                   work=dict(bytes=4.0 * x.numel() + 2.0 * base.numel()))
+    return base.permute(0, 4, 1, 2, 3)
 
 
 def cl_to_ncthw(x):
@@ -110,7 +124,7 @@ def to_cl(x):
 class ConvGeom:
     """Geometry of one nn.Conv3d call (groups == 1) on a given input shape."""
 
-    def __init__(self, in_shape, Co, kernel, stride=1, padding=0, dilation=1, Cw=None):
+    def __init__(self, in_shape, Co, kernel, stride=1, padding=0, dilation=1, Cw=None, out_dims=None):
         self.N, self.Ci, self.Ti, self.Hi, self.Wi = in_shape
         self.Co = Co
         self.k, self.s, self.p, self.d = _triple(kernel), _triple(stride), _triple(padding), _triple(dilation)
@@ -118,6 +132,9 @@ class ConvGeom:
         self.To, self.Ho, self.Wo = [
             (i + 2 * p - d * (k - 1) - 1) // s + 1
             for i, k, s, p, d in zip((self.Ti, self.Hi, self.Wi), self.k, self.s, self.p, self.d)]
+        if out_dims is not None:      # drop trailing output positions (asymmetric end padding)
+            assert all(1 <= o <= f for o, f in zip(out_dims, (self.To, self.Ho, self.Wo)))
+            self.To, self.Ho, self.Wo = out_dims
         self.taps = self.k[0] * self.k[1] * self.k[2]
         ldf, ldd = c_int32(), c_int32()
         get_lib().call("sf_conv_weight_ld", byref(self.desc(self.Ci, self.Co)), byref(ldf), byref(ldd))
@@ -291,25 +308,26 @@ def _pool_args(y, kernel, stride, padding):
     return (N, T, H, W, C, kH, kW, sH, sW, pH, pW), ((H + 2 * pH - kH) // sH + 1, (W + 2 * pW - kW) // sW + 1)
 
 
-def pool_fwd(y, kernel, stride, padding, affine=None):
-    """MaxPool over (H,W) of act(y), act = producer BN(+ReLU) from ``affine = (scale, shift, relu)``."""
+def pool_fwd(y, kernel, stride, padding, affine=None, want_argmax=True):
+    """MaxPool over (H,W) of act(y), act = producer BN(+ReLU) from ``affine = (scale, shift, relu)``.
+    Returns (pooled, argmax): argmax = uint8 window-local index of the first maximum (for pool_bwd)."""
     args, (Ho, Wo) = _pool_args(y, kernel, stride, padding)
     N, C, T, H, W = y.shape
     out = cl_empty((N, C, T, Ho, Wo), y.device)
+    arg = torch.empty((N, T, Ho, Wo, C), dtype=torch.uint8, device=y.device) if want_argmax else None
     sc, sh, relu = _affine(affine)
     get_lib().call("sf_pool_fwd", *args, y.data_ptr(), cl_ld(y), _ptr(sc), _ptr(sh), relu, out.data_ptr(),
-                   cl_ld(out), _stream(y), work=dict(bytes=2.0 * (y.numel() + out.numel())))
-    return out
+                   cl_ld(out), _ptr(arg), _stream(y), work=dict(bytes=2.0 * (y.numel() + out.numel())))
+    return out, arg
 
 
-def pool_bwd(y, dout, kernel, stride, padding, affine=None):
-    """Gradient w.r.t. the BatchNorm output (max-pool backward + ReLU mask)."""
-    args, (Ho, Wo) = _pool_args(y, kernel, stride, padding)
-    N, C, T, H, W = y.shape
-    assert tuple(dout.shape) == (N, C, T, Ho, Wo)
-    g = cl_empty(y.shape, y.device)
-    sc, sh, relu = _affine(affine)
-    get_lib().call("sf_pool_bwd", *args, y.data_ptr(), cl_ld(y), _ptr(sc), _ptr(sh), relu, dout.data_ptr(),
-                   cl_ld(dout), g.data_ptr(), cl_ld(g), _stream(y),
-                   work=dict(bytes=2.0 * (2 * y.numel() + dout.numel())))
+def pool_bwd(in_shape, pooled, argmax, dout, kernel, stride, padding, relu=True):
+    """Gradient w.r.t. the BatchNorm output feeding relu -> max-pool (argmax gather + ReLU mask pooled > 0)."""
+    N, C, T, H, W = in_shape
+    (kH, kW), (sH, sW), (pH, pW) = kernel, stride, padding
+    assert tuple(dout.shape) == tuple(pooled.shape)
+    g = cl_empty(in_shape, dout.device)
+    get_lib().call("sf_pool_bwd", N, T, H, W, C, kH, kW, sH, sW, pH, pW, pooled.data_ptr(), cl_ld(pooled),
+                   argmax.data_ptr(), int(bool(relu)), dout.data_ptr(), cl_ld(dout), g.data_ptr(), cl_ld(g),
+                   _stream(dout), work=dict(bytes=2.0 * (g.numel() + 2.5 * dout.numel())))
     return g

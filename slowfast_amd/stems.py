@@ -3,7 +3,7 @@ state_dict keys (slowfast/models/stem_helper.py:20-201), executed by the fused e
 conv -> [BN statistics in the conv epilogue] -> BN+ReLU+MaxPool in one pass (engine.StemFn)."""
 import torch.nn as nn
 
-from .engine import ConvUnit, StemFn
+from .engine import ConvUnit, StemConvUnit, StemFn
 
 
 class ResNetBasicStem(nn.Module):
@@ -17,7 +17,8 @@ class ResNetBasicStem(nn.Module):
         self.bn = norm_module(num_features=dim_out, eps=eps, momentum=bn_mmt)
         self.relu = nn.ReLU(inplace_relu)
         self.pool_layer = nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
-        self._unit = ConvUnit(self.conv, self.bn)
+        foldable = dim_in <= 4 and stride[2] % 2 == 0
+        self._unit = (StemConvUnit if foldable else ConvUnit)(self.conv, self.bn)
 
     def forward(self, x):
         return StemFn.apply(x, self, self.conv.weight, self.bn.weight, self.bn.bias)

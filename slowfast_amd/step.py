@@ -1,0 +1,85 @@
+"""One training iteration of the hot path as a replayable HIP graph.
+
+Mirrors the inner loop of the reference's ``train_epoch`` (tools/train_net.py:104-172): zero_grad ->
+``preds = model(inputs)`` -> ``loss = loss_fun(preds, labels)`` -> ``loss.backward()`` -> gradient all-reduce ->
+``optimizer.step()``.  A SlowFast-R50 step is ~2000 short kernel launches issued from Python; on MI355X the
+kernels of a bs32 step take tens of milliseconds, the same order as the host time needed to issue them one by
+one.  ``TrainStep`` therefore captures [zero_grad, forward, loss, backward] ONCE into a HIP graph
+(``torch.cuda.CUDAGraph`` is hipGraph on ROCm; every libsfamd launch goes to the capturing stream) and replays
+it per iteration; shapes are static (synthetic or fixed-size clips), inputs are copied into static buffers.
+The gradient all-reduce (RCCL, flat fp32 buckets) and the optimizer update run eagerly after the replay, so
+the 1-GPU and N-GPU paths execute the same captured work.
+
+Without a GPU (host-simulator tests) or with ``use_graph=False`` the same sequence runs eagerly.
+"""
+import torch
+
+from . import engine
+
+
+class TrainStep:
+    def __init__(self, model, reducer, optimizer, loss_fn, loss_scale=1.0, use_graph=None, warmup=2):
+        self.model, self.reducer, self.optimizer, self.loss_fn = model, reducer, optimizer, loss_fn
+        self.loss_scale = float(loss_scale)
+        dev = next(model.parameters()).device
+        self.use_graph = (dev.type == "cuda") if use_graph is None else bool(use_graph)
+        self.warmup = warmup
+        self._graph = None
+        self._static_in = None
+        self._static_labels = None
+        self._loss = None
+        self._logits = None
+        self._calls = 0
+
+    # ------------------------------------------------------------------------------------------------
+    def _fwd_bwd(self, inputs, labels):
+        self.reducer.zero_grad()
+        logits = self.model(inputs)
+        loss = self.loss_fn(logits.float(), labels)
+        (loss * self.loss_scale).backward()
+        return logits, loss
+
+    def _finish(self):
+        self.reducer.finish(loss_scale=self.loss_scale)
+        if self.optimizer is not None:
+            self.optimizer.step()
+
+    def _capture(self, inputs, labels):
+        self._static_in = [x.clone() for x in inputs]
+        self._static_labels = labels.clone()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        engine.FORCE_WEIGHT_PREP = True
+        self.reducer.capturing = True
+        try:
+            with torch.cuda.graph(g):
+                logits, loss = self._fwd_bwd(self._static_in, self._static_labels)
+        finally:
+            engine.FORCE_WEIGHT_PREP = False
+            self.reducer.capturing = False
+        self._graph, self._logits, self._loss = g, logits.detach(), loss.detach()
+
+    def __call__(self, inputs, labels):
+        """Runs one iteration; returns the (unscaled) loss tensor of this iteration."""
+        self._calls += 1
+        if not self.use_graph or self._calls <= self.warmup:
+            logits, loss = self._fwd_bwd(inputs, labels)
+            self._logits, self._loss = logits.detach(), loss.detach()
+            self._finish()
+            return self._loss
+        if self._graph is None:
+            self._capture(inputs, labels)
+        else:
+            for dst, src in zip(self._static_in, inputs):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+            if self._static_labels.data_ptr() != labels.data_ptr():
+                self._static_labels.copy_(labels, non_blocking=True)
+        self.reducer.begin_replay()
+        self._graph.replay()
+        self._finish()
+        return self._loss
+
+    @property
+    def logits(self):
+        return self._logits

@@ -186,9 +186,9 @@ def check_pool(device, shape, seed=0):
     gref = z.grad * (z.detach() > 0)
     yc = host_to_cl(y, device)
     aff = (sc.to(device), sh.to(device), True)
-    out = ops.pool_fwd(yc, (3, 3), (2, 2), (1, 1), affine=aff)
+    out, arg = ops.pool_fwd(yc, (3, 3), (2, 2), (1, 1), affine=aff)
     assert_close("pool_fwd", cl_to_host(out), pr.detach(), 2 * F16_EPS)  # fused multiply-add vs mul+add before fp16 rounding
-    gm = ops.pool_bwd(yc, host_to_cl(dout, device), (3, 3), (2, 2), (1, 1), affine=aff)
+    gm = ops.pool_bwd(tuple(yc.shape), out, arg, host_to_cl(dout, device), (3, 3), (2, 2), (1, 1), relu=True)
     assert_close("pool_bwd", cl_to_host(gm), gref, 2 * F16_EPS)
 
 
@@ -201,3 +201,35 @@ def check_layout(device, shape, seed=0):
     assert float(cl_to_host(xc)[:, shape[1]:].abs().max()) == 0.0 if xc.shape[1] > shape[1] else True
     back = ops.cl_to_ncthw(xc)
     assert_close("cl_to_ncthw", back.cpu()[:, : shape[1]], x.half().float(), 1e-6)
+
+
+def check_bn_finalize_long(device, nblk, C, seed=0):
+    """Long partial tables take the in-place fold stage (sf_part_fold_kernel) before the final reduction, in
+    the forward (sf_bn_finalize) and the backward (sf_bn_bwd_finalize) statistics."""
+    from slowfast_amd.lib import get_lib
+    g = torch.Generator().manual_seed(seed)
+    rows = 128
+    s = torch.randn((nblk, C), generator=g) * rows ** 0.5 + 0.3 * rows
+    q = torch.rand((nblk, C), generator=g) * rows + rows
+    part = torch.stack([s, q], 1).contiguous()
+    count = float(nblk * rows)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    mean = s.double().sum(0) / count
+    var = q.double().sum(0) / count - mean * mean
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale, shift, m, r = ops.bn_finalize(part.clone().to(device), count, gamma.to(device), beta.to(device), None, None,
+                                         0.1, 1e-5, training=True)
+    assert_close("finalize mean", m.cpu(), mean.float(), 1e-6)
+    assert_close("finalize rstd", r.cpu(), rstd.float(), 1e-5)
+    assert_close("finalize scale", scale.cpu(), (gamma.double() * rstd).float(), 1e-5)
+    assert_close("finalize shift", shift.cpu(), (beta.double() - mean * gamma.double() * rstd).float(), 1e-5)
+    # backward sums
+    dgamma, dbeta = torch.empty(C, device=device), torch.empty(C, device=device)
+    coef = torch.empty((3, C), device=device)
+    pd = part.clone().to(device)
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None
+    get_lib().call("sf_bn_bwd_finalize", pd.data_ptr(), nblk, C, count, gamma.to(device).data_ptr(), m.data_ptr(),
+                   r.data_ptr(), 1.0, dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr(), stream)
+    sg, sgy = s.double().sum(0), q.double().sum(0)
+    assert_close("bwd dbeta", dbeta.cpu(), sg.float(), 1e-6)
+    assert_close("bwd dgamma", dgamma.cpu(), (rstd * (sgy - mean * sg)).float(), 1e-5)

@@ -85,3 +85,16 @@ def test_pool(gpu):
 def test_layout(gpu):
     kc.check_layout(gpu, (2, 3, 4, 32, 32))
     kc.check_layout(gpu, (1, 16, 1, 4, 4))
+
+
+def test_bn_finalize_long_tables(gpu):
+    kc.check_bn_finalize_long(gpu, 300, 24)
+    kc.check_bn_finalize_long(gpu, 2500, 8)
+    kc.check_bn_finalize_long(gpu, 25088, 64)    # the slow-pathway stem at batch 32
+    kc.check_bn_finalize_long(gpu, 200, 40)
+
+
+def test_wgrad_many_splits(gpu):
+    kc.check_conv_wgrad(gpu, (4, 8, 16, 56, 56), 8, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    kc.check_conv_wgrad(gpu, (4, 32, 16, 56, 56), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+    kc.check_conv_wgrad(gpu, (4, 8, 16, 56, 56), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0))

@@ -76,3 +76,16 @@ def test_pool(sim):
 def test_layout(sim):
     kc.check_layout(sim, (2, 3, 2, 5, 5))
     kc.check_layout(sim, (1, 16, 1, 4, 4))
+
+
+def test_bn_finalize_long_tables(sim):
+    kc.check_bn_finalize_long(sim, 300, 24)      # folded with group 16
+    kc.check_bn_finalize_long(sim, 2500, 8)      # group 32
+    kc.check_bn_finalize_long(sim, 9000, 16)     # group 64, ragged last group
+    kc.check_bn_finalize_long(sim, 200, 40)      # short table: no fold
+
+
+def test_wgrad_many_splits(sim):
+    """Tiny-channel layer with a long position axis: many split partials, multi-lane reduce kernel."""
+    kc.check_conv_wgrad(sim, (2, 8, 8, 24, 24), 8, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    kc.check_conv_wgrad(sim, (1, 8, 4, 32, 32), 32, (3, 1, 1), (1, 1, 1), (1, 0, 0))

@@ -16,8 +16,9 @@ from slowfast_amd import ops  # noqa: E402
 
 # (name, Ci, T, H, W, Co, kernel, stride, pad, count)
 LAYERS = [
-    ("slow.stem 3->64 1x7x7/2", 8, 8, 224, 224, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), 1),
-    ("fast.stem 3->8 5x7x7/2", 8, 32, 224, 224, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3), 1),
+    # RGB stems as W-pair-folded convolutions (engine.StemConvUnit): input (N,8,T,224,112), kernel (kT,7,4)
+    ("slow.stem 3->64 1x7x7/2", 8, 8, 224, 112, 64, (1, 7, 4), (1, 2, 1), (0, 3, 2), 1),
+    ("fast.stem 3->8 5x7x7/2", 8, 32, 224, 112, 8, (5, 7, 4), (1, 2, 1), (2, 3, 2), 1),
     ("s2.slow a 80->64 1x1", 80, 8, 56, 56, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), 1),
     ("s2.slow b 64->64 1x3x3", 64, 8, 56, 56, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), 3),
     ("s2.slow c 64->256 1x1", 64, 8, 56, 56, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), 3),
@@ -71,8 +72,9 @@ def main():
     for name, Ci, T, H, W, Co, k, s, p, cnt in LAYERS:
         if a.filter and a.filter not in name:
             continue
-        Cw = 3 if "stem" in name else Ci
-        geom = ops.ConvGeom((a.batch, Ci, T, H, W), Co, k, s, p, Cw=Cw)
+        Cw = Ci
+        stem = "stem" in name
+        geom = ops.ConvGeom((a.batch, Ci, T, H, W), Co, k, s, p, Cw=Cw, out_dims=(T, 112, 112) if stem else None)
         x = ops.cl_empty(geom.in_shape, dev)
         x.normal_()
         w = torch.randn((Co, Cw) + k, device=dev) * 0.05
@@ -83,7 +85,7 @@ def main():
         dw = torch.empty_like(w)
         sc = torch.ones(Ci, device=dev)
         sh = torch.zeros(Ci, device=dev)
-        macs = geom.out_rows * Co * Cw * geom.taps
+        macs = geom.out_rows * Co * (3 * k[0] * 49 if stem else Cw * geom.taps)   # useful MACs
         t_f = timeit(lambda: ops.conv_fwd(x, wf, geom, out=y), a.iters)
         t_fa = timeit(lambda: ops.conv_fwd(x, wf, geom, in_affine=(sc, sh, True), out=y), a.iters) if Ci <= 512 else float("nan")
         dx = ops.cl_empty(geom.in_shape, dev)
