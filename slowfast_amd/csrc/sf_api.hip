@@ -71,6 +71,12 @@ static void fill_gather_common(GatherSide& g, const sf_conv_desc* d) {
     g.fdsH = make_fastdiv(d->sH);
     g.fdsW = make_fastdiv(d->sW);
     g.scale = nullptr; g.shift = nullptr; g.relu = 0;
+    g.fdHW = make_fastdiv((uint32_t)d->Hi * (uint32_t)d->Wi);
+}
+// 1x1x1 / (kT,1,1) convolutions with unit strides: input and output share (H, W)
+static bool is_pointwise(const sf_conv_desc* d) {
+    return d->kH == 1 && d->kW == 1 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pH == 0 && d->pW == 0 &&
+           d->Ho == d->Hi && d->Wo == d->Wi;
 }
 
 // gathered forward input: rows = output positions
@@ -84,6 +90,7 @@ static GatherSide gather_fwd(const sf_conv_desc* d, const void* x, const float* 
     g.Ktot = d->kT * d->kH * d->kW * d->Ci;
     g.fdC = make_fastdiv(d->Ci);
     g.fdrW = make_fastdiv(d->Wo); g.fdrH = make_fastdiv(d->Ho); g.fdrT = make_fastdiv(d->To);
+    g.rowT = d->To;
     g.scale = sc; g.shift = sh; g.relu = relu;
     return g;
 }
@@ -98,21 +105,23 @@ static GatherSide gather_dgrad(const sf_conv_desc* d, const void* dy) {
     g.Ktot = d->kT * d->kH * d->kW * d->Co;
     g.fdC = make_fastdiv(d->Co);
     g.fdrW = make_fastdiv(d->Wi); g.fdrH = make_fastdiv(d->Hi); g.fdrT = make_fastdiv(d->Ti);
+    g.rowT = d->Ti;
     return g;
 }
 
 template <int BN, int WM, int WN>
-static void launch_igemm(const IgemmParams& p, hipStream_t s) {
+static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s) {
     int mt = cdiv(p.M, 128);
     dim3 grid((unsigned)(mt * p.ntiles_n));
-    hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN>), grid, dim3(SF_THREADS), 0, s, p);
+    if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true>), grid, dim3(SF_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false>), grid, dim3(SF_THREADS), 0, s, p);
 }
 
-static int run_igemm(IgemmParams& p, hipStream_t s) {
-    if (p.Nout > 64) { p.ntiles_n = cdiv(p.Nout, 128); launch_igemm<128, 64, 64>(p, s); }
-    else if (p.Nout > 32) { p.ntiles_n = 1; launch_igemm<64, 32, 64>(p, s); }
-    else if (p.Nout > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, s); }
-    else { p.ntiles_n = 1; launch_igemm<16, 32, 16>(p, s); }
+static int run_igemm(IgemmParams& p, bool pw, hipStream_t s) {
+    if (p.Nout > 64) { p.ntiles_n = cdiv(p.Nout, 128); launch_igemm<128, 64, 64>(p, pw, s); }
+    else if (p.Nout > 32) { p.ntiles_n = 1; launch_igemm<64, 32, 64>(p, pw, s); }
+    else if (p.Nout > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, pw, s); }
+    else { p.ntiles_n = 1; launch_igemm<16, 32, 16>(p, pw, s); }
     return check_launch("igemm");
 }
 
@@ -163,7 +172,7 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf,
     p.y = (f16*)y; p.ldy = d->ldy;
     p.bias = bias; p.resid = nullptr; p.ldr = 0;
     p.stat_part = stat_part;
-    return run_igemm(p, (hipStream_t)stream);
+    return run_igemm(p, is_pointwise(d), (hipStream_t)stream);
 }
 
 extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
@@ -181,7 +190,7 @@ extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* 
     p.ksteps = cdiv(p.g.Ktot, 32);
     p.y = (f16*)dx; p.ldy = d->ldx;
     p.resid = (const f16*)resid; p.ldr = ldr;
-    return run_igemm(p, (hipStream_t)stream);
+    return run_igemm(p, is_pointwise(d), (hipStream_t)stream);
 }
 
 template <int BMW, int WM, int WN, int KS>

@@ -223,17 +223,44 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_reduce_kernel(BnBwdReduc
             for (int e = 0; e < 8; ++e) { sg[e] += g[e]; sgy[e] += g[e] * (float)yv[e]; }
         }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s_red[threadIdx.x][e] = sg[e]; s_red[threadIdx.x][8 + e] = sgy[e]; }
-    __syncthreads();
     const int G = p.rt.C >> 3;
     const int TG = G < SF_THREADS ? G : SF_THREADS;
     const int rpi = SF_THREADS / TG;
+    float* o = p.part + (int64_t)blockIdx.x * 2 * p.rt.C;
+    if (TG < SF_WAVE && (TG & (TG - 1)) == 0) {
+        // lanes l, l+TG, l+2TG, ... of a wave hold the same channel group: butterfly over them, then 4 waves via LDS
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            for (int mask = TG; mask < SF_WAVE; mask <<= 1) {
+                sg[e] += __shfl_xor(sg[e], mask);
+                sgy[e] += __shfl_xor(sgy[e], mask);
+            }
+        }
+        const int lane = threadIdx.x & (SF_WAVE - 1), wave = threadIdx.x >> 6;
+        if (lane < TG) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s_red[wave * TG + lane][e] = sg[e]; s_red[wave * TG + lane][8 + e] = sgy[e]; }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < TG && (int)(blockIdx.y * SF_THREADS + threadIdx.x) < G) {
+            const int cc = (blockIdx.y * SF_THREADS + threadIdx.x) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[cc + e] = (s_red[threadIdx.x][e] + s_red[TG + threadIdx.x][e]) +
+                            (s_red[2 * TG + threadIdx.x][e] + s_red[3 * TG + threadIdx.x][e]);
+                o[p.rt.C + cc + e] = (s_red[threadIdx.x][8 + e] + s_red[TG + threadIdx.x][8 + e]) +
+                                     (s_red[2 * TG + threadIdx.x][8 + e] + s_red[3 * TG + threadIdx.x][8 + e]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s_red[threadIdx.x][e] = sg[e]; s_red[threadIdx.x][8 + e] = sgy[e]; }
+    __syncthreads();
     if (active && (int)threadIdx.x < TG) {
         for (int k = 1; k < rpi; ++k)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s_red[threadIdx.x][e] += s_red[threadIdx.x + k * TG][e];
-        float* o = p.part + (int64_t)blockIdx.x * 2 * p.rt.C;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             o[c + e] = s_red[threadIdx.x][e];

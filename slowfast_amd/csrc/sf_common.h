@@ -81,6 +81,8 @@ struct GatherSide {
     FastDiv fdC, fdkW, fdkH;      // k -> tap, tap -> (kt, kh, kw)
     FastDiv fdrW, fdrH, fdrT;     // row -> (n, a, b, c) in the ROW space
     FastDiv fdsT, fdsH, fdsW;     // dgrad stride divisibility
+    FastDiv fdHW;                 // pointwise fast path: row -> (n*T + t, h*W + w)
+    int rowT;                     // T extent of the ROW space
     const float* scale;     // optional on-the-fly BN of the source (nullptr = none), length C
     const float* shift;
     int relu;
@@ -139,6 +141,32 @@ __device__ __forceinline__ bool gather_offset(const GatherSide& g, const RowPos&
         t = (int)qt; h = (int)qh; w = (int)qw;
     }
     off = ((((int64_t)r.n * g.sT + t) * g.sH + h) * g.sW + w) * (int64_t)g.ld + c0;
+    return true;
+}
+
+// Pointwise fast path (kH = kW = 1, all strides 1, no H/W padding -- the 1x1x1 and (kT,1,1) convolutions, 60 % of
+// the SlowFast MACs): a row and its source positions share (n, h, w), only t moves with the tap, so the gather is
+// one division by C per K-step instead of the full tap decomposition.  RowPos reuse: bt = t -/+ padT, bh = h*W+w.
+__device__ __forceinline__ RowPos decode_row_pw(const GatherSide& g, uint32_t row, bool valid) {
+    RowPos r;
+    uint32_t q, hw, n, t;
+    fd_divmod(row, g.fdHW, q, hw);
+    fd_divmod(q, g.fdrT, n, t);
+    r.n = (int)n;
+    r.bt = g.mode == 0 ? (int)t - g.padT : (int)t + g.padT;
+    r.bh = (int)hw;
+    r.bw = 0;
+    r.valid = valid;
+    return r;
+}
+__device__ __forceinline__ bool gather_offset_pw(const GatherSide& g, const RowPos& r, uint32_t k0, int64_t& off,
+                                                 uint32_t& c0) {
+    if (!r.valid || k0 >= (uint32_t)g.Ktot) return false;
+    uint32_t kt;
+    fd_divmod(k0, g.fdC, kt, c0);
+    const int t = g.mode == 0 ? r.bt + (int)kt * g.dilT : r.bt - (int)kt * g.dilT;
+    if ((unsigned)t >= (unsigned)g.sT) return false;
+    off = (((int64_t)r.n * g.sT + t) * (int64_t)g.fdHW.d + r.bh) * (int64_t)g.ld + c0;
     return true;
 }
 

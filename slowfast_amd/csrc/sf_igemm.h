@@ -28,7 +28,7 @@ struct IgemmParams {
     int ntiles_n;
 };
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, bool PW>
 __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
     constexpr int BM = 128, BK = 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         int row = m0 + (tid >> 2) + 64 * j;
-        rp[j] = decode_row(g, (uint32_t)row, row < p.M);
+        rp[j] = PW ? decode_row_pw(g, (uint32_t)row, row < p.M) : decode_row(g, (uint32_t)row, row < p.M);
     }
 
     f16x8 ra[2], rb[NB];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
         for (int j = 0; j < 2; ++j) {
             int64_t off;
             uint32_t c0 = 0;
-            bool ok = gather_offset(g, rp[j], k0, off, c0);
+            bool ok = PW ? gather_offset_pw(g, rp[j], k0, off, c0) : gather_offset(g, rp[j], k0, off, c0);
             ra[j] = ok ? ld16(g.src + off) : zero8();
             ra_ok[j] = ok;
             ra_c0[j] = c0;

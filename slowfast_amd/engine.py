@@ -94,17 +94,19 @@ class ConvUnit:
             self._geoms[key] = g
         return g
 
-    def weights(self, geom):
+    def weights(self, geom, fresh=False):
+        """fp16 GEMM operands of the current weight.  ``fresh`` (forward pass) forces the repack while a training
+        step is being captured; the backward pass of the same step reuses what its forward packed."""
         w = self.conv.weight
         key = (w.data_ptr(), w._version, geom.Ci, w.device)
-        if FORCE_WEIGHT_PREP or self._wkey != key:
+        if (fresh and FORCE_WEIGHT_PREP) or self._wkey != key:
             self._w = ops.prep_weights(w.detach(), geom, need_dgrad=(geom.Cw == geom.Ci))
             self._wkey = key
         return self._w
 
     def forward(self, x, in_affine, training):
         geom = self.geom(x.shape)
-        wf, _ = self.weights(geom)
+        wf, _ = self.weights(geom, fresh=True)
         bn = self.bn
         if bn is None:
             y, _ = ops.conv_fwd(x, wf, geom, in_affine=in_affine, bias=self.conv.bias, stats=False)
@@ -201,10 +203,10 @@ class StemConvUnit(ConvUnit):
         wv = wv.view(Co, 4, kT, kH, self.kext // 2, 2).permute(0, 5, 1, 2, 3, 4)
         return wv.reshape(Co, 8, kT, kH, self.kext // 2).contiguous()
 
-    def weights(self, geom):
+    def weights(self, geom, fresh=False):
         w = self.conv.weight
         key = (w.data_ptr(), w._version, geom.Ci, w.device)
-        if FORCE_WEIGHT_PREP or self._wkey != key:
+        if (fresh and FORCE_WEIGHT_PREP) or self._wkey != key:
             self._w = ops.prep_weights(self._virtual_weight(w.detach()), geom, need_dgrad=False)
             self._wkey = key
         return self._w

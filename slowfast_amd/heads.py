@@ -36,8 +36,15 @@ class ResNetBasicHead(nn.Module):
         assert len(inputs) == self.num_pathways, f"Input tensor does not contain {self.num_pathways} pathway"
         pooled = []
         for i, x in enumerate(inputs):
-            x = x.float().contiguous()
-            pooled.append(getattr(self, f"pathway{i}_avgpool")(x))
+            pool = getattr(self, f"pathway{i}_avgpool")
+            full = isinstance(pool, nn.AdaptiveAvgPool3d) or tuple(pool.kernel_size) == tuple(x.shape[2:])
+            if full and x.dim() == 5 and x.stride(1) == 1:
+                # the pool window is the whole (T,H,W) extent (training crop): mean over the channels-last rows
+                N, C = x.shape[:2]
+                rows = x.permute(0, 2, 3, 4, 1).reshape(N, -1, C)
+                pooled.append(rows.float().mean(1).view(N, C, 1, 1, 1))
+            else:
+                pooled.append(pool(x.float().contiguous()))
         x = torch.cat(pooled, 1).permute(0, 2, 3, 4, 1)
         if hasattr(self, "dropout"):
             x = self.dropout(x)

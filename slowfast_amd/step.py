@@ -45,7 +45,8 @@ class TrainStep:
             self.optimizer.step()
 
     def _capture(self, inputs, labels):
-        self._static_in = [x.clone() for x in inputs]
+        self._is_list = isinstance(inputs, (list, tuple))
+        self._static_in = [x.clone() for x in inputs] if self._is_list else inputs.clone()
         self._static_labels = labels.clone()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -70,7 +71,8 @@ class TrainStep:
         if self._graph is None:
             self._capture(inputs, labels)
         else:
-            for dst, src in zip(self._static_in, inputs):
+            pairs = zip(self._static_in, inputs) if self._is_list else [(self._static_in, inputs)]
+            for dst, src in pairs:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
             if self._static_labels.data_ptr() != labels.data_ptr():
