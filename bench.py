@@ -28,8 +28,12 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
 # per clip, SlowFast-8x8-R50 32x224^2: MAC_fwd 50.309 G -> 6*MAC train flops; boundary elements
 # E = 216.5 M -> byte floor 5*E*2 B = 2.165 GB
-TRAIN_GFLOP_PER_CLIP = {"SLOWFAST_8x8_R50": 301.9, "C2D_8x8_R50": 117.0}
-BYTE_FLOOR_GB_PER_CLIP = {"SLOWFAST_8x8_R50": 2.165, "C2D_8x8_R50": 1.019}
+TRAIN_GFLOP_PER_CLIP = {"SLOWFAST_8x8_R50": 301.9, "C2D_8x8_R50": 117.0, "MVITv2_S_16x4": 383.6}
+BYTE_FLOOR_GB_PER_CLIP = {"SLOWFAST_8x8_R50": 2.165, "C2D_8x8_R50": 1.019, "MVITv2_S_16x4": 1.845}
+METRIC_NAME = {"SLOWFAST_8x8_R50": "SlowFast-8x8-R50 32x224^2", "C2D_8x8_R50": "C2D-R50 8x224^2",
+               "MVITv2_S_16x4": "MViTv2-S 16x224^2"}
+# synthetic-run overrides: stochastic ops off so that runs are comparable and parity-checkable
+PRESET_OPTS = {"MVITv2_S_16x4": ["MVIT.DROPPATH_RATE", 0.0, "MODEL.DROPOUT_RATE", 0.0]}
 
 
 def parse():
@@ -54,12 +58,21 @@ def parse():
 def make_optimizer(model, cfg):
     """SGD as the reference constructs it (slowfast/models/optimizer.py:15-140): BN parameters get
     BN.WEIGHT_DECAY, the rest SOLVER.WEIGHT_DECAY; momentum / nesterov from SOLVER."""
-    bn, rest = [], []
+    bn, rest, zero = [], [], []
     for m in model.modules():
         is_bn = isinstance(m, torch.nn.modules.batchnorm._NormBase)
         for p in m.parameters(recurse=False):
-            (bn if is_bn else rest).append(p)
-    groups = [{"params": bn, "weight_decay": cfg.BN.WEIGHT_DECAY}, {"params": rest, "weight_decay": cfg.SOLVER.WEIGHT_DECAY}]
+            if is_bn:
+                bn.append(p)
+            elif cfg.SOLVER.ZERO_WD_1D_PARAM and (p.dim() == 1 or p.shape == (1, 1, p.shape[-1])):
+                zero.append(p)                      # optimizer.py:57-66: no decay on 1-D parameters (MViT recipe)
+            else:
+                rest.append(p)
+    groups = [g for g in ({"params": bn, "weight_decay": cfg.BN.WEIGHT_DECAY},
+                          {"params": rest, "weight_decay": cfg.SOLVER.WEIGHT_DECAY},
+                          {"params": zero, "weight_decay": 0.0}) if g["params"]]
+    if cfg.SOLVER.OPTIMIZING_METHOD == "adamw":    # slowfast/models/optimizer.py:118-125
+        return torch.optim.AdamW(groups, lr=cfg.SOLVER.BASE_LR, betas=(0.9, 0.999), eps=1e-08, fused=True)
     kw = dict(lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, dampening=cfg.SOLVER.DAMPENING,
               nesterov=cfg.SOLVER.NESTEROV)
     try:
@@ -89,8 +102,9 @@ def cpu_baseline_subprocess(a):
 
 def cpu_baseline(cfg, clips, threads=0):
     """The CPU oracle (plain torch fp32 restatement of the reference graph) on the host cores."""
-    from oracle import video_ref
+    from oracle import mvit_ref, video_ref
     import slowfast_amd as sa
+    fam = mvit_ref if cfg.MODEL.MODEL_NAME == "MViT" else video_ref
     torch.set_num_threads(threads or min(64, os.cpu_count() or 1))
     model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -98,11 +112,11 @@ def cpu_baseline(cfg, clips, threads=0):
         if k.endswith("c_bn.weight"):
             sd[k].fill_(1.0)
     inputs, labels = video_ref.synthetic_batch(cfg, clips, seed=0)
-    video_ref.loss_and_grads(sd, cfg, inputs, labels)            # warm-up
+    fam.loss_and_grads(sd, cfg, inputs, labels)            # warm-up
     best, iters = 1e30, 2
     for _ in range(iters):
         t0 = time.perf_counter()
-        video_ref.loss_and_grads(sd, cfg, inputs, labels)
+        fam.loss_and_grads(sd, cfg, inputs, labels)
         best = min(best, time.perf_counter() - t0)
     return {"value": clips / best, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{clips} clips x (fwd + cross-entropy + bwd), best of {iters} timed iterations after 1 warm-up, "
@@ -113,7 +127,8 @@ def main():
     a = parse()
     if a.cpu_baseline_only:
         import slowfast_amd as sa
-        cfg = sa.get_preset(a.preset, ["NUM_GPUS", 0, "TRAIN.BATCH_SIZE", a.cpu_baseline_clips])
+        cfg = sa.get_preset(a.preset, ["NUM_GPUS", 0, "TRAIN.BATCH_SIZE", a.cpu_baseline_clips]
+                            + PRESET_OPTS.get(a.preset, []))
         print(json.dumps(cpu_baseline(cfg, a.cpu_baseline_clips, a.cpu_baseline_threads)), flush=True)
         return
     rank = int(os.environ.get("RANK", "0"))
@@ -131,7 +146,7 @@ def main():
     from slowfast_amd.profiler import KernelProfiler
     assert get_lib().backend == "gfx950", "bench.py measures the HIP library only"
 
-    cfg = sa.get_preset(a.preset, ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", a.batch * world])
+    cfg = sa.get_preset(a.preset, ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", a.batch * world] + PRESET_OPTS.get(a.preset, []))
     torch.manual_seed(cfg.RNG_SEED)
     model = sa.build_model(cfg, gpu_id=local).train()
     if world > 1:                        # replicas start identical (DDP's initial broadcast)
@@ -214,11 +229,13 @@ def main():
         value = clips / dt
         ms = dt / a.steps * 1e3
         out = {
-            "metric": "clips/sec (fwd+bwd), SlowFast-8x8-R50 32x224^2 synthetic clips, per-GPU batch 32",
+            "metric": f"clips/sec (fwd+bwd), {METRIC_NAME.get(a.preset, a.preset)} synthetic clips, "
+                      f"per-GPU batch {a.batch}",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": f"{a.preset}: forward + cross-entropy + backward + SGD step, inputs resident in HBM, "
+            "config": {"workload": f"{a.preset}: forward + cross-entropy + backward + {cfg.SOLVER.OPTIMIZING_METHOD} step, "
+                                   f"inputs resident in HBM, "
                                    f"per-GPU batch {a.batch}", "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "loss_scale": a.loss_scale, "bucket_mb": a.bucket_mb,
                        "launch": "eager" if a.no_graph else "hip-graph(fwd+bwd) + eager all-reduce/SGD"},

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 3
+#define SF_ABI_VERSION 4
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -93,17 +93,106 @@ int sf_bn_bwd_apply(int64_t M, int32_t C, const void* dz, int32_t lddz, const vo
  * stem_helper.py:190-201 (bn -> relu -> pool_layer). */
 int sf_pool_fwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kH, int32_t kW, int32_t sH, int32_t sW,
                 int32_t pH, int32_t pW, const void* y, int32_t ldy, const float* scale, const float* shift, int relu,
-                void* out, int32_t ldo, void* argmax, sf_stream_t stream);
+                void* out, int32_t ldo, void* argmax, int32_t cls, sf_stream_t stream);
 /* g[N,T,H,W,C] = gradient w.r.t. the BatchNorm output (pool + ReLU backward) from the forward's pooled output
  * (ReLU mask: pooled > 0) and its byte argmax table [N,T,Ho,Wo][C] (window-local index kh*kW+kw of the first
  * maximum, as recorded by torch's max_pool3d) */
 int sf_pool_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kH, int32_t kW, int32_t sH, int32_t sW,
                 int32_t pH, int32_t pW, const void* pooled, int32_t ldp, const void* argmax, int relu,
-                const void* dout, int32_t lddo, void* g, int32_t ldg, sf_stream_t stream);
+                const void* dout, int32_t lddo, void* g, int32_t ldg, int32_t cls, sf_stream_t stream);
+/* cls != 0 (both calls): TOKEN tensors -- every sample's T*H*W rows are preceded by one cls-token row that passes
+ * through the pool unchanged; replaces attention_pool(x, pool_skip=nn.MaxPool3d) of attention.py:13-45, 485-498. */
 
 /* ---- layout: clips arrive NCTHW fp32 (tools/train_net.py:79-98) */
 int sf_ncthw_to_cl(const float* x, int32_t N, int32_t C, int64_t S, int32_t Cp, void* out, sf_stream_t stream);
 int sf_cl_to_ncthw(const void* x, int32_t ld, int32_t N, int32_t C, int64_t S, float* out, sf_stream_t stream);
+
+/* =====================================================================================================
+ * Token-space entry points (MViT pooled attention, Mlp; also used by Nonlocal and X3D).  Token tensors are fp16
+ * [rows][C] with a row pitch in elements (multiple of 8); parameters, statistics and their gradients are fp32.
+ * ===================================================================================================== */
+
+/* Batched GEMM  Y[z][m][n] = sum_k A[z][m][k] * W[z][n][k] (+ bias[n]) (+ resid[z][m][n]),  z = b*bh + j,
+ * operand z at base + b*s?_b + j*s?_h (elements).  nbatch = 1, bh = 1 is a plain nn.Linear forward
+ * (y = x W^T + b: attention.py:193,195,482; common.py:19-21) or its data gradient (W = weight^T operand).
+ * In attention: scores = q k^T (attention.py:355) and attn @ v (:379) per (batch, head). */
+int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias,
+             const void* resid, int32_t ldr, void* Y, int32_t ldy, int32_t nbatch, int32_t bh, int64_t sa_b, int64_t sa_h,
+             int64_t sw_b, int64_t sw_h, int64_t sy_b, int64_t sy_h, int64_t sr_b, int64_t sr_h, int32_t resid_row0,
+             sf_stream_t stream);
+/* resid_row0: the residual is added to rows m >= resid_row0 only (residual pooling skips the cls row,
+ * attention.py:381-385).  N need not be a multiple of 8 when ldy covers N rounded up to 8 (pad columns <- 0). */
+/* Batched "TN" GEMM  Out[z][r][c] = scale * sum_m P[z][m][r] * X[z][m][c]  (fp16 out): the attention gradients
+ * dV = P^T dO and dK = dS^T q (autograd of attention.py:355,379). */
+int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int32_t ldp, const void* X, int32_t ldx, void* Out,
+                int32_t ldo, float scale, int32_t nbatch, int32_t bh, int64_t sp_b, int64_t sp_h, int64_t sx_b,
+                int64_t sx_h, int64_t so_b, int64_t so_h, sf_stream_t stream);
+
+/* nn.LayerNorm(C, eps) over the last dim (attention.py:240-268, 428, 456; video_model_builder.py:1032) */
+int sf_layernorm_fwd(int64_t M, int32_t C, const void* x, int32_t ldx, const float* gamma, const float* beta, float eps,
+                     void* y, int32_t ldy, float* mean, float* rstd, sf_stream_t stream);
+int sf_layernorm_bwd_blocks(int64_t M, int32_t C);   /* rows of `part` */
+/* dx = LN backward (+ resid); part[blk][0][c] = sum dy*xhat, part[blk][1][c] = sum dy -> sf_colsum_finalize */
+int sf_layernorm_bwd(int64_t M, int32_t C, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* gamma,
+                     const float* mean, const float* rstd, const void* resid, int32_t ldr, void* dx, int32_t lddx,
+                     float* part, sf_stream_t stream);
+/* column sums of an [M][C] tensor (bias gradients): part[blk][0][c] */
+int sf_colsum_blocks(int64_t M, int32_t C);
+int sf_colsum(int64_t M, int32_t C, const void* x, int32_t ldx, float* part, sf_stream_t stream);
+/* out0[c % fold] (+)= scale * sum_blk part[blk][0][c], out1 likewise from part[blk][1][c] (either may be NULL);
+ * `part` is scratch (folded in place) */
+int sf_colsum_finalize(float* part, int32_t nblk, int32_t C, int32_t fold, float* out0, float* out1, float scale,
+                       int accumulate, sf_stream_t stream);
+/* out[i] (+)= scale * sum_b part[b*row_len + offset + i] */
+int sf_rows_sum(const float* part, int32_t nblk, int64_t row_len, int64_t offset, int32_t n, float* out, float scale,
+                int accumulate, sf_stream_t stream);
+/* nn.GELU (exact erf; common.py:20) on contiguous arrays of n elements (n % 8 == 0) */
+int sf_gelu_fwd(int64_t n, const void* h, void* a, sf_stream_t stream);
+int sf_gelu_bwd(int64_t n, const void* h, const void* da, void* dh, sf_stream_t stream);
+
+/* Depthwise Conv3d(C, C, k, stride, padding, groups = C) on channels-last rows; C may be heads*Cw with one weight
+ * [Cw][taps] shared by the heads (MViT pool_q/k/v, attention.py:227-266); cls != 0: token tensors whose cls row is
+ * routed around the convolution (attention.py:24-36).  Also X3DTransform.b (resnet_helper.py:214-224) and the
+ * X3D stem's (5,1,1) temporal conv (stem_helper.py:267-275).  ldx / ldy = pitches of input / output rows. */
+typedef struct sf_dw_desc {
+    int32_t N, C, Cw, cls;
+    int32_t Ti, Hi, Wi, To, Ho, Wo;
+    int32_t kT, kH, kW, sT, sH, sW, pT, pH, pW;
+    int32_t ldx, ldy;
+} sf_dw_desc;
+int sf_dwconv_fwd_blocks(const sf_dw_desc* d);       /* rows of stat_part */
+/* stat_part (optional): [blocks][2][C] per-block sum / sum of squares of the outputs (BatchNorm statistics) */
+int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w, void* y, float* stat_part, sf_stream_t stream);
+int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float* w, void* dx, sf_stream_t stream);
+int64_t sf_dwconv_wgrad_workspace(const sf_dw_desc* d);
+int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* dy, float* dw, float out_scale, int zero_first,
+                    void* workspace, int64_t workspace_bytes, sf_stream_t stream);
+
+/* Pooled attention (attention.py:354-385).  Tokens are [B][N][heads*D]; scores [B][heads][Nq][lds]. */
+typedef struct sf_attn_desc {
+    int32_t B, heads, D, cls;
+    int32_t Nq, qT, qH, qW;        /* Nq = cls + qT*qH*qW */
+    int32_t Nk, kT, kH, kW;        /* Nk = cls + kT*kH*kW */
+    int32_t rows_h, rows_w, rows_t; /* rows of rel_pos_h / rel_pos_w / rel_pos_t */
+} sf_attn_desc;
+/* rq[(b,q,head)][kH+kW+kT] = <q_unscaled, rel_pos_{h,w,t}[idx]> (cal_rel_pos_spatial/temporal, attention.py:64-147);
+ * idx_h [qH][kH], idx_w [qW][kW], idx_t [qT][kT] are the reference's dist_* tables as int32 */
+int sf_relpos_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, const float* rel_h, const float* rel_w,
+                  const float* rel_t, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t, float* rq,
+                  sf_stream_t stream);
+int sf_relpos_bwd_blocks(const sf_attn_desc* d);    /* blocks of dtab_part, each (rows_h+rows_w+rows_t)*D floats */
+/* dq += sum_j drq[j] * table_j; dtab_part = per-block partial gradients of the three tables (-> sf_rows_sum) */
+int sf_relpos_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, const float* rel_h, const float* rel_w,
+                  const float* rel_t, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t, const float* drq,
+                  void* dq, int32_t lddq, float* dtab_part, sf_stream_t stream);
+/* in place: s <- softmax_k(scale*s + bias), bias from rq (NULL = none); pad columns [Nk, lds) <- 0 */
+int sf_softmax_fwd(const sf_attn_desc* d, void* s, int32_t lds, float scale, const float* rq, sf_stream_t stream);
+/* in place: dp <- scale * P*(dp - sum_k P*dp); drq (optional) <- per-(kh|kw|kt) sums of the unscaled dS */
+int sf_softmax_bwd(const sf_attn_desc* d, void* dp, const void* prob, int32_t lds, float scale, float* drq,
+                   sf_stream_t stream);
+/* xt[b][head][c][k] = x[b][k][head*D + c], zero for k in [Nk, ldk): K-contiguous operand for P.V and dS.K */
+int sf_transpose_heads(const void* x, int32_t ldx, void* xt, int32_t ldk, int32_t B, int32_t Nk, int32_t heads, int32_t D,
+                       sf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import refshim, video_ref  # noqa: E402
+from oracle import mvit_ref, refshim, video_ref  # noqa: E402
 
 TINY = ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 32,
         "RESNET.WIDTH_PER_GROUP", 16, "RESNET.DEPTH", 18]
@@ -39,7 +39,22 @@ CASES = {
                     ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
     "i3d_r50_mid": ("configs/Kinetics/I3D_8x8_R50.yaml",
                     ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
+    # MViTv2: a 4-block miniature (every block type: q-pooling, dim change, k/v pooling, rel-pos) and the full
+    # 16-block MViTv2-S at a reduced clip size
+    "mvit_tiny": ("configs/Kinetics/MVITv2_S_16x4.yaml",
+                  ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "MODEL.NUM_CLASSES", 10,
+                   "DATA.TRAIN_CROP_SIZE", 64, "DATA.TEST_CROP_SIZE", 64, "DATA.NUM_FRAMES", 8, "MVIT.DEPTH", 4,
+                   "MVIT.EMBED_DIM", 32, "MVIT.DIM_MUL", "[[1, 2.0], [3, 2.0]]", "MVIT.HEAD_MUL", "[[1, 2.0], [3, 2.0]]",
+                   "MVIT.POOL_Q_STRIDE", "[[0, 1, 1, 1], [1, 1, 2, 2], [2, 1, 1, 1], [3, 1, 2, 2]]",
+                   "MVIT.POOL_KV_STRIDE_ADAPTIVE", "[1, 4, 4]", "MIXUP.ENABLE", False], 2),
+    "mvit_s_mid": ("configs/Kinetics/MVITv2_S_16x4.yaml",
+                   ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96,
+                    "DATA.TEST_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8, "MIXUP.ENABLE", False], 2),
 }
+
+
+def _family(cfg):
+    return mvit_ref if cfg.MODEL.MODEL_NAME == "MViT" else video_ref
 
 
 def run_case(name):
@@ -48,7 +63,8 @@ def run_case(name):
     torch.manual_seed(0)
     model = refshim.reference_model(cfg)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = video_ref.randomize_state(shapes, seed=1234)
+    fam = _family(cfg)
+    sd = fam.randomize_state(shapes, seed=1234)
     model.load_state_dict(sd)
     model.train()
     inputs, labels = video_ref.synthetic_batch(cfg, batch, seed=4321)
@@ -58,13 +74,16 @@ def run_case(name):
     ref_grads = {k: p.grad for k, p in model.named_parameters()}
     ref_stats = {k: v for k, v in model.state_dict().items() if "running" in k}
 
-    o_logits, o_loss, o_grads, o_stats = video_ref.loss_and_grads(sd, cfg, inputs, labels)
+    o_logits, o_loss, o_grads, o_stats = fam.loss_and_grads(sd, cfg, inputs, labels)
     err = float((o_logits - logits.detach()).abs().max() / logits.detach().abs().max())
     assert err < 1e-5, f"{name}: oracle logits differ from the reference ({err:.2e})"
     assert abs(float(o_loss) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
     worst = 0.0
+    gmax = max(float(g.abs().max()) for g in ref_grads.values())
     for k, g in ref_grads.items():
-        e = float((o_grads[k] - g).abs().max() / (g.abs().max() + 1e-12))
+        # parameters whose true gradient vanishes identically (e.g. MViT norm_k.bias: a constant added to every key
+        # shifts all scores of a query equally) carry round-off only: measure against the global gradient scale
+        e = float((o_grads[k] - g).abs().max() / (g.abs().max() + 1e-3 * gmax))
         worst = max(worst, e)
     assert worst < 1e-4, f"{name}: oracle gradients differ from the reference ({worst:.2e})"
     for k, v in ref_stats.items():
@@ -85,7 +104,7 @@ def run_case(name):
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):
         rec = run_case(name)
         with open(os.path.join(out_dir, name + ".json"), "w") as f:
             json.dump(rec, f)

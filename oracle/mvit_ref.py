@@ -1,0 +1,213 @@
+"""CPU restatement (plain torch fp32/fp64) of the reference's MViT forward graph (MViTv2 configuration family:
+conv pooling, cls token, decomposed relative positions, residual pooling, DIM_MUL_IN_ATT).
+
+TEST INFRASTRUCTURE: the oracle the HIP engine's MViT path is checked against.  Pinned to the unmodified reference
+by oracle/make_golden.py (golden fixtures tests/golden/mvit_*.json).  Each function cites the reference lines it
+follows.  Driven by a flat ``state_dict`` with the reference's key names; autograd gives the reference backward.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import video_ref as _vr
+
+
+def _store(x):
+    return _vr._STORE(x)
+
+
+def _linear(x, sd, prefix):
+    return _store(F.linear(x, _store(sd[prefix + ".weight"]), sd.get(prefix + ".bias")))
+
+
+def _ln(x, sd, prefix, eps=1e-6):
+    """nn.LayerNorm(eps=1e-6) (video_model_builder.py:857-858 partial(nn.LayerNorm, eps=1e-6))."""
+    return _store(F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps))
+
+
+def attention_pool(tensor, weight, stride, thw, has_cls, norm=None, sd=None, pool_mode="conv"):
+    """attention_pool (attention.py:13-45) with a depthwise Conv3d (kernel 3x3x3 / padding 1 per cfg POOL_KVQ_KERNEL)
+    or a MaxPool3d for the skip path (weight None).  tensor: (B, heads, L, C) or (B, L, C)."""
+    dim3 = tensor.ndim == 3
+    if dim3:
+        tensor = tensor.unsqueeze(1)
+    if has_cls:
+        cls_tok, tensor = tensor[:, :, :1, :], tensor[:, :, 1:, :]
+    B, N, L, C = tensor.shape
+    T, H, W = thw
+    t = tensor.reshape(B * N, T, H, W, C).permute(0, 4, 1, 2, 3).contiguous()
+    if pool_mode == "conv":
+        k = weight.shape[2:]
+        t = F.conv3d(t, _store(weight), None, tuple(stride), tuple(int(v // 2) for v in k), 1, C)
+        t = _store(t)
+    else:   # max: kernel = stride + 1 where stride > 1 (attention.py:430-432)
+        k = [s + 1 if s > 1 else s for s in stride]
+        t = F.max_pool3d(t, k, tuple(stride), [int(v // 2) for v in k])
+    thw_new = [t.shape[2], t.shape[3], t.shape[4]]
+    t = t.reshape(B, N, C, -1).transpose(2, 3)
+    if has_cls:
+        t = torch.cat((cls_tok, t), dim=2)
+    if norm is not None:
+        t = _ln(t, sd, norm)
+    if dim3:
+        t = t.squeeze(1)
+    return t, thw_new
+
+
+def rel_pos_index(q_size, k_size):
+    """dist tables of cal_rel_pos_spatial / cal_rel_pos_temporal (attention.py:76-88, 123-130) as int64."""
+    q_ratio = max(k_size / q_size, 1.0)
+    k_ratio = max(q_size / k_size, 1.0)
+    dist = torch.arange(q_size)[:, None] * q_ratio - torch.arange(k_size)[None, :] * k_ratio
+    dist += (k_size - 1) * k_ratio
+    return dist.long()
+
+
+def _rel_pos_bias(attn, q, has_cls, q_shape, k_shape, rel_h, rel_w, rel_t):
+    """cal_rel_pos_spatial + cal_rel_pos_temporal (attention.py:64-147); tables are used at their native size
+    (no interpolation: 2*max(q,k)-1 rows, as constructed at attention.py:271-287)."""
+    sp = 1 if has_cls else 0
+    q_t, q_h, q_w = q_shape
+    k_t, k_h, k_w = k_shape
+    B, nh, qN, dim = q.shape
+    r_q = q[:, :, sp:].reshape(B, nh, q_t, q_h, q_w, dim)
+    out = attn[:, :, sp:, sp:].reshape(B, nh, q_t, q_h, q_w, k_t, k_h, k_w)
+    if rel_h is not None:
+        assert rel_h.shape[0] == 2 * max(q_h, k_h) - 1 and rel_w.shape[0] == 2 * max(q_w, k_w) - 1
+        Rh = rel_h[rel_pos_index(q_h, k_h)]
+        Rw = rel_w[rel_pos_index(q_w, k_w)]
+        rel_h_q = torch.einsum("bythwc,hkc->bythwk", r_q, Rh)
+        rel_w_q = torch.einsum("bythwc,wkc->bythwk", r_q, Rw)
+        out = out + rel_h_q[:, :, :, :, :, None, :, None] + rel_w_q[:, :, :, :, :, None, None, :]
+    if rel_t is not None:
+        assert rel_t.shape[0] == 2 * max(q_t, k_t) - 1
+        Rt = rel_t[rel_pos_index(q_t, k_t)]
+        rel_t_q = torch.einsum("bythwc,tkc->bythwk", r_q, Rt)
+        out = out + rel_t_q[:, :, :, :, :, :, None, None]
+    out = out.reshape(B, nh, q_t * q_h * q_w, k_t * k_h * k_w)
+    if sp:
+        top = attn[:, :, :1, :]
+        left = attn[:, :, 1:, :1]
+        out = torch.cat([top, torch.cat([left, out], dim=3)], dim=2)
+    return out
+
+
+def attention(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, residual_pooling=True):
+    """MultiScaleAttention.forward (attention.py:293-392), mode "conv", pool_first False, fused qkv."""
+    B, N, _ = x.shape
+    qkv = _linear(x, sd, prefix + ".qkv").reshape(B, N, 3, heads, -1).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q, q_shape = attention_pool(q, sd[prefix + ".pool_q.weight"], stride_q, thw, has_cls, prefix + ".norm_q", sd)
+    k, k_shape = attention_pool(k, sd[prefix + ".pool_k.weight"], stride_kv, thw, has_cls, prefix + ".norm_k", sd)
+    v, _ = attention_pool(v, sd[prefix + ".pool_v.weight"], stride_kv, thw, has_cls, prefix + ".norm_v", sd)
+    head_dim = q.shape[-1]
+    scale = head_dim ** -0.5
+    attn = (q * scale) @ k.transpose(-2, -1)
+    attn = _store(attn)
+    attn = _rel_pos_bias(attn, q, has_cls, q_shape, k_shape, sd.get(prefix + ".rel_pos_h"), sd.get(prefix + ".rel_pos_w"),
+                         sd.get(prefix + ".rel_pos_t"))
+    attn = _store(attn.softmax(dim=-1))
+    o = attn @ v
+    if residual_pooling:
+        if has_cls:
+            o = torch.cat([o[:, :, :1, :], o[:, :, 1:, :] + q[:, :, 1:, :]], dim=2)
+        else:
+            o = o + q
+    o = _store(o)
+    o = o.transpose(1, 2).reshape(B, -1, heads * head_dim)
+    return _linear(o, sd, prefix + ".proj"), q_shape
+
+
+def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True):
+    """MultiScaleBlock.forward (attention.py:491-514) with DIM_MUL_IN_ATT (proj applied to the normed input)."""
+    x_norm = _ln(x, sd, prefix + ".norm1")
+    x_block, thw_new = attention(x_norm, sd, prefix + ".attn", thw, heads, stride_q, stride_kv, has_cls)
+    if prefix + ".proj.weight" in sd:
+        x = _linear(x_norm, sd, prefix + ".proj")
+    if math.prod(stride_q) > 1:
+        x_res, _ = attention_pool(x, None, stride_q, thw, has_cls, pool_mode="max")
+    else:
+        x_res = x
+    x = _store(x_res + x_block)
+    x_norm = _ln(x, sd, prefix + ".norm2")
+    h = _linear(x_norm, sd, prefix + ".mlp.fc1")
+    h = _store(F.gelu(h))
+    x_mlp = F.linear(h, _store(sd[prefix + ".mlp.fc2.weight"]), sd[prefix + ".mlp.fc2.bias"])
+    return _store(x + x_mlp), thw_new
+
+
+def mvit_plan(cfg):
+    """Per-block (heads, stride_q, stride_kv) from the cfg, as MViT.__init__ derives them
+    (video_model_builder.py:906-1004)."""
+    depth = cfg.MVIT.DEPTH
+    head_mul = [1.0] * (depth + 1)
+    for i, m in cfg.MVIT.HEAD_MUL:
+        head_mul[i] = m
+    stride_q = [[1, 1, 1] for _ in range(depth)]
+    for e in cfg.MVIT.POOL_Q_STRIDE:
+        stride_q[e[0]] = list(e[1:])
+    stride_kv = []
+    _kv = list(cfg.MVIT.POOL_KV_STRIDE_ADAPTIVE)
+    for i in range(depth):
+        if math.prod(stride_q[i]) > 1:
+            _kv = [max(_kv[d] // stride_q[i][d], 1) for d in range(3)]
+        stride_kv.append(list(_kv))
+    heads, plan = cfg.MVIT.NUM_HEADS, []
+    for i in range(depth):
+        heads = int(round(heads * head_mul[i]))
+        plan.append((heads, stride_q[i], stride_kv[i]))
+    return plan
+
+
+def mvit_forward(sd, cfg, inputs, training=True):
+    """MViT.forward (video_model_builder.py:1166-1244) for CLS_EMBED_ON, no abs-pos, no dropout / drop-path
+    (the parity harness sets them to 0), + TransformerBasicHead.forward (head_helper.py:538-563)."""
+    x = inputs[0]
+    w = sd["patch_embed.proj.weight"]
+    stride, pad = tuple(cfg.MVIT.PATCH_STRIDE), tuple(cfg.MVIT.PATCH_PADDING)
+    x = _store(F.conv3d(_store(x), _store(w), sd["patch_embed.proj.bias"], stride, pad))
+    B, C, T, H, W = x.shape
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat((sd["cls_token"].expand(B, -1, -1), x), dim=1)
+    x = _store(x)
+    thw = [T, H, W]
+    for i, (heads, sq, skv) in enumerate(mvit_plan(cfg)):
+        x, thw = block(x, sd, f"blocks.{i}", thw, heads, sq, skv)
+    x = _ln(x[:, 0], sd, "norm")
+    z = F.linear(x, sd["head.projection.weight"], sd["head.projection.bias"])
+    if not training and cfg.MODEL.HEAD_ACT == "softmax":
+        z = F.softmax(z, dim=1)
+    return z
+
+
+def randomize_state(shapes, seed, dtype=torch.float32):
+    """Deterministic generic parameters keyed by the reference's MViT state_dict names."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in shapes.items():
+        if name.endswith("weight") and len(shape) == 1:          # LayerNorm gamma
+            sd[name] = (torch.rand(shape, generator=g) + 0.5).to(dtype)
+        elif name.endswith("bias"):
+            sd[name] = (torch.randn(shape, generator=g) * 0.1).to(dtype)
+        elif "rel_pos" in name:
+            sd[name] = (torch.randn(shape, generator=g) * 0.2).to(dtype)
+        elif name == "cls_token":
+            sd[name] = (torch.randn(shape, generator=g) * 0.5).to(dtype)
+        elif len(shape) == 5:                                     # conv weights: fan-in scaled
+            fan_in = shape[1] * shape[2] * shape[3] * shape[4]
+            sd[name] = (torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5).to(dtype)
+        elif len(shape) == 2:                                     # Linear weights
+            sd[name] = (torch.randn(shape, generator=g) * (1.0 / shape[1]) ** 0.5).to(dtype)
+        else:
+            sd[name] = (torch.randn(shape, generator=g) * 0.1).to(dtype)
+    return sd
+
+
+def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32):
+    params = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    logits = mvit_forward(params, cfg, [x.to(dtype) for x in inputs], training=True)
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    grads = {k: v.grad for k, v in params.items() if v.grad is not None}
+    return logits.detach(), loss.detach(), grads, {}

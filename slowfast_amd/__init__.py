@@ -8,3 +8,4 @@ from .registry import MODEL_REGISTRY, build_model  # noqa: F401
 
 __version__ = "0.1.0"
 from . import video_models  # noqa: F401,E402  (registers SlowFast / ResNet in MODEL_REGISTRY)
+from . import mvit  # noqa: F401,E402  (registers MViT)

@@ -101,6 +101,17 @@ _DEFAULTS = {
     "MULTIGRID": {"SHORT_CYCLE": False, "LONG_CYCLE": False},
     "CONTRASTIVE": {"NUM_MLP_LAYERS": 1, "MLP_DIM": 2048, "BN_MLP": False, "BN_SYNC_MLP": False,
                     "PREDICTOR_DEPTHS": []},
+    # slowfast/config/defaults.py:447-558
+    "MVIT": {"MODE": "conv", "POOL_FIRST": False, "CLS_EMBED_ON": True, "PATCH_KERNEL": [3, 7, 7],
+             "PATCH_STRIDE": [2, 4, 4], "PATCH_PADDING": [2, 4, 4], "PATCH_2D": False, "EMBED_DIM": 96, "NUM_HEADS": 1,
+             "MLP_RATIO": 4.0, "QKV_BIAS": True, "DROPPATH_RATE": 0.1, "LAYER_SCALE_INIT_VALUE": 0.0, "DEPTH": 16,
+             "NORM": "layernorm", "DIM_MUL": [], "HEAD_MUL": [], "POOL_KV_STRIDE": [], "POOL_KV_STRIDE_ADAPTIVE": None,
+             "POOL_Q_STRIDE": [], "POOL_KVQ_KERNEL": None, "ZERO_DECAY_POS_CLS": True, "NORM_STEM": False,
+             "SEP_POS_EMBED": False, "DROPOUT_RATE": 0.0, "USE_ABS_POS": True, "REL_POS_SPATIAL": False,
+             "REL_POS_TEMPORAL": False, "REL_POS_ZERO_INIT": False, "RESIDUAL_POOLING": False, "DIM_MUL_IN_ATT": False,
+             "SEPARATE_QKV": False, "HEAD_INIT_SCALE": 1.0, "USE_MEAN_POOLING": False, "USE_FIXED_SINCOS_POS": False,
+             "REV": {"ENABLE": False}},
+    "MIXUP": {"ENABLE": False},
     "NUM_GPUS": 1, "NUM_SHARDS": 1, "SHARD_ID": 0, "RNG_SEED": 1, "LOG_MODEL_INFO": True, "DIST_BACKEND": "nccl",
     "OUTPUT_DIR": ".",
 }
@@ -139,6 +150,26 @@ PRESETS = {
         "MODEL": {"NUM_CLASSES": 400, "ARCH": "c2d", "MODEL_NAME": "ResNet", "LOSS_FUNC": "cross_entropy",
                   "DROPOUT_RATE": 0.5},
     },
+}
+
+
+# configs/Kinetics/MVITv2_S_16x4.yaml
+PRESETS["MVITv2_S_16x4"] = {
+    "DATA": {"NUM_FRAMES": 16, "SAMPLING_RATE": 4, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 224,
+             "INPUT_CHANNEL_NUM": [3]},
+    "MVIT": {"ZERO_DECAY_POS_CLS": False, "USE_ABS_POS": False, "REL_POS_SPATIAL": True, "REL_POS_TEMPORAL": True,
+             "DEPTH": 16, "NUM_HEADS": 1, "EMBED_DIM": 96, "PATCH_KERNEL": [3, 7, 7], "PATCH_STRIDE": [2, 4, 4],
+             "PATCH_PADDING": [1, 3, 3], "MLP_RATIO": 4.0, "QKV_BIAS": True, "DROPPATH_RATE": 0.2, "NORM": "layernorm",
+             "MODE": "conv", "CLS_EMBED_ON": True, "DIM_MUL": [[1, 2.0], [3, 2.0], [14, 2.0]],
+             "HEAD_MUL": [[1, 2.0], [3, 2.0], [14, 2.0]], "POOL_KVQ_KERNEL": [3, 3, 3],
+             "POOL_KV_STRIDE_ADAPTIVE": [1, 8, 8],
+             "POOL_Q_STRIDE": [[0, 1, 1, 1], [1, 1, 2, 2], [2, 1, 1, 1], [3, 1, 2, 2]] + [[i, 1, 1, 1] for i in range(4, 14)]
+             + [[14, 1, 2, 2], [15, 1, 1, 1]],
+             "DROPOUT_RATE": 0.0, "DIM_MUL_IN_ATT": True, "RESIDUAL_POOLING": True},
+    "SOLVER": {"BASE_LR": 0.0001, "MOMENTUM": 0.9, "WEIGHT_DECAY": 0.05, "OPTIMIZING_METHOD": "adamw",
+               "ZERO_WD_1D_PARAM": True, "CLIP_GRAD_L2NORM": 1.0},
+    "MODEL": {"NUM_CLASSES": 400, "ARCH": "mvit", "MODEL_NAME": "MViT", "LOSS_FUNC": "soft_cross_entropy",
+              "DROPOUT_RATE": 0.5},
 }
 
 

@@ -4,6 +4,8 @@
 #include "sf_common.h"
 #include "sf_igemm.h"
 #include "sf_pool.h"
+#include "sf_dwconv.h"
+#include "sf_tokens.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -411,31 +413,37 @@ static int pool_grid(int64_t total) {
 
 extern "C" int sf_pool_fwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kH, int32_t kW, int32_t sH,
                            int32_t sW, int32_t pH, int32_t pW, const void* y, int32_t ldy, const float* scale,
-                           const float* shift, int relu, void* out, int32_t ldo, void* argmax, sf_stream_t stream) {
+                           const float* shift, int relu, void* out, int32_t ldo, void* argmax, int32_t cls,
+                           sf_stream_t stream) {
     PoolParams p;
     if (fill_pool(p, N, T, H, W, C, kH, kW, sH, sW, pH, pW, y, ldy, scale, shift, relu)) return -1;
     REQUIRE(y && out, "sf_pool_fwd: null pointer");
+    p.cls = cls ? 1 : 0; p.fdT = make_fastdiv(T);
     REQUIRE(kH * kW <= 255, "sf_pool_fwd: window too large for the byte argmax");
     p.out = (f16*)out; p.ldo = ldo; p.argmax = (uint8_t*)argmax;
     p.fdW = make_fastdiv(p.Wo); p.fdH = make_fastdiv(p.Ho);
     p.total = (int64_t)N * T * p.Ho * p.Wo * (C / 8);
     REQUIRE(p.total < (1ll << 31), "sf_pool_fwd: too many elements");
-    hipLaunchKernelGGL(sf_pool_fwd_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sf_pool_fwd_kernel, dim3(pool_grid(p.total + (int64_t)N * (C / 8))), dim3(SF_THREADS), 0,
+                       (hipStream_t)stream, p);
     return check_launch("pool_fwd");
 }
 
 extern "C" int sf_pool_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kH, int32_t kW, int32_t sH,
                            int32_t sW, int32_t pH, int32_t pW, const void* pooled, int32_t ldp, const void* argmax,
-                           int relu, const void* dout, int32_t lddo, void* g, int32_t ldg, sf_stream_t stream) {
+                           int relu, const void* dout, int32_t lddo, void* g, int32_t ldg, int32_t cls,
+                           sf_stream_t stream) {
     PoolParams p;
     if (fill_pool(p, N, T, H, W, C, kH, kW, sH, sW, pH, pW, nullptr, 0, nullptr, nullptr, relu)) return -1;
     REQUIRE(pooled && argmax && dout && g, "sf_pool_bwd: null pointer");
+    p.cls = cls ? 1 : 0; p.fdT = make_fastdiv(T);
     p.out = (f16*)g; p.ldo = ldg; p.dout = (const f16*)dout; p.lddo = lddo;
     p.pooled = (const f16*)pooled; p.ldp = ldp; p.argmax = (uint8_t*)argmax;
     p.fdW = make_fastdiv(W); p.fdH = make_fastdiv(H);
     p.total = (int64_t)N * T * H * W * (C / 8);
     REQUIRE(p.total < (1ll << 31), "sf_pool_bwd: too many elements");
-    hipLaunchKernelGGL(sf_pool_bwd_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sf_pool_bwd_kernel, dim3(pool_grid(p.total + (int64_t)N * (C / 8))), dim3(SF_THREADS), 0,
+                       (hipStream_t)stream, p);
     return check_launch("pool_bwd");
 }
 
@@ -453,4 +461,392 @@ extern "C" int sf_cl_to_ncthw(const void* x, int32_t ld, int32_t N, int32_t C, i
     hipLaunchKernelGGL(sf_cl_to_ncthw_kernel, dim3(pool_grid((int64_t)N * C * S)), dim3(SF_THREADS), 0,
                        (hipStream_t)stream, (const f16*)x, ld, out, N, C, S);
     return check_launch("cl_to_ncthw");
+}
+
+// ================================================================================================
+// Token-space entry points (MViT / Nonlocal / X3D): batched GEMMs, LayerNorm, GELU, column sums, depthwise
+// convolution, pooled-attention softmax with relative-position bias.
+static GatherSide gather_matrix(const void* a, int64_t M, int32_t K, int32_t lda) {
+    // a plain [M][K] matrix as the pointwise gather of a 1x1x1 convolution over N=1, T=1, H=1, W=M
+    GatherSide g;
+    memset(&g, 0, sizeof(g));
+    g.src = (const f16*)a; g.ld = lda; g.C = K;
+    g.sT = 1; g.sH = 1; g.sW = (int)M;
+    g.kT = g.kH = g.kW = 1; g.strT = g.strH = g.strW = 1; g.dilT = g.dilH = g.dilW = 1;
+    g.mode = 0; g.Ktot = K;
+    g.fdC = make_fastdiv(K); g.fdkW = make_fastdiv(1); g.fdkH = make_fastdiv(1);
+    g.fdrW = make_fastdiv((uint32_t)M); g.fdrH = make_fastdiv(1); g.fdrT = make_fastdiv(1);
+    g.fdsT = g.fdsH = g.fdsW = make_fastdiv(1);
+    g.fdHW = make_fastdiv((uint32_t)M); g.rowT = 1;
+    return g;
+}
+
+extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
+                        const float* bias, const void* resid, int32_t ldr, void* Y, int32_t ldy, int32_t nbatch,
+                        int32_t bh, int64_t sa_b, int64_t sa_h, int64_t sw_b, int64_t sw_h, int64_t sy_b, int64_t sy_h,
+                        int64_t sr_b, int64_t sr_h, int32_t resid_row0, sf_stream_t stream) {
+    REQUIRE(A && W && Y, "sf_bgemm: null pointer");
+    REQUIRE(M > 0 && M < (1ll << 31) && N > 0 && K > 0, "sf_bgemm: bad shape");
+    // rows of Y are written in 16-byte groups: the pitch must cover N rounded up to 8 (the pad columns get zeros)
+    REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 && lda >= K && ldw >= K && ldy >= roundup(N, 8),
+            "sf_bgemm: K and the pitches must be multiples of 8 (N=%d K=%d lda=%d ldw=%d ldy=%d)", N, K, lda, ldw, ldy);
+    REQUIRE(!(bias || resid) || N % 8 == 0, "sf_bgemm: bias / residual need N %% 8 == 0");
+    REQUIRE(nbatch >= 1 && bh >= 1 && nbatch % bh == 0 && nbatch <= 65535, "sf_bgemm: bad batch (%d, %d)", nbatch, bh);
+    REQUIRE(!resid || (ldr % 8 == 0 && ldr >= N), "sf_bgemm: bad residual pitch");
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.g = gather_matrix(A, M, K, lda);
+    p.M = (int)M;
+    p.wmat = (const f16*)W; p.ldw = ldw; p.Nout = N;
+    p.ksteps = cdiv(K, 32);
+    p.y = (f16*)Y; p.ldy = ldy; p.bias = bias; p.resid = (const f16*)resid; p.ldr = ldr;
+    p.bh = bh; p.sa_b = sa_b; p.sa_h = sa_h; p.sw_b = sw_b; p.sw_h = sw_h; p.sy_b = sy_b; p.sy_h = sy_h;
+    p.sr_b = sr_b; p.sr_h = sr_h; p.resid_row0 = resid_row0;
+    hipStream_t s = (hipStream_t)stream;
+    const int mt = cdiv(M, 128);
+#define SF_BG(BN_, WM_, WN_)                                                                                   \
+    do {                                                                                                       \
+        p.ntiles_n = cdiv(N, BN_);                                                                             \
+        hipLaunchKernelGGL((sf_igemm_kernel<BN_, WM_, WN_, true>), dim3((unsigned)(mt * p.ntiles_n), nbatch), \
+                           dim3(SF_THREADS), 0, s, p);                                                         \
+    } while (0)
+    if (N > 64) SF_BG(128, 64, 64);
+    else if (N > 32) SF_BG(64, 32, 64);
+    else if (N > 16) SF_BG(32, 32, 32);
+    else SF_BG(16, 32, 16);
+#undef SF_BG
+    return check_launch("bgemm");
+}
+
+extern "C" int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int32_t ldp, const void* X, int32_t ldx,
+                           void* Out, int32_t ldo, float scale, int32_t nbatch, int32_t bh, int64_t sp_b, int64_t sp_h,
+                           int64_t sx_b, int64_t sx_h, int64_t so_b, int64_t so_h, sf_stream_t stream) {
+    REQUIRE(P && X && Out, "sf_bgemm_tn: null pointer");
+    REQUIRE(M > 0 && M < (1ll << 31) && R > 0 && Kc > 0, "sf_bgemm_tn: bad shape");
+    REQUIRE(Kc % 8 == 0 && ldp % 8 == 0 && ldx % 8 == 0 && ldp >= R && ldx >= Kc && ldo >= Kc,
+            "sf_bgemm_tn: Kc and the pitches must be multiples of 8");
+    REQUIRE(nbatch >= 1 && bh >= 1 && nbatch % bh == 0 && nbatch <= 65535, "sf_bgemm_tn: bad batch");
+    static const bool scalar = getenv("SF_WGRAD_SCALAR") && atoi(getenv("SF_WGRAD_SCALAR")) != 0;
+    WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.g = gather_matrix(X, M, Kc, ldx);
+    p.dy = (const f16*)P; p.ldy = ldp; p.Co = R; p.M = (int)M;
+    p.nchunks = cdiv(M, 32);
+    p.bh = bh; p.sp_b = sp_b; p.sp_h = sp_h; p.sx_b = sx_b; p.sx_h = sx_h; p.so_b = so_b; p.so_h = so_h;
+    p.out16 = (f16*)Out; p.ldo = ldo; p.out_scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_k = cdiv(Kc, 128);
+    if (R >= 128) { p.chunks_per_split = p.nchunks; launch_wgrad<128, 64, 64, 1>(p, dim3(tiles_k, cdiv(R, 128), nbatch), scalar, s); }
+    else if (R >= 64) { p.chunks_per_split = p.nchunks; launch_wgrad<64, 32, 64, 1>(p, dim3(tiles_k, cdiv(R, 64), nbatch), scalar, s); }
+    else if (R >= 32) { p.chunks_per_split = roundup(p.nchunks, 4); launch_wgrad<32, 32, 32, 4>(p, dim3(tiles_k, cdiv(R, 32), nbatch), scalar, s); }
+    else { p.chunks_per_split = roundup(p.nchunks, 4); launch_wgrad<16, 16, 32, 4>(p, dim3(tiles_k, cdiv(R, 16), nbatch), scalar, s); }
+    return check_launch("bgemm_tn");
+}
+
+// ---- LayerNorm
+template <int L, int NS>
+static void launch_ln_fwd(const LnParams& p, hipStream_t s) {
+    const int rpb = SF_THREADS / L;
+    int blocks = cdiv(p.M, rpb);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((sf_layernorm_fwd_kernel<L, NS>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
+}
+template <int L, int NS>
+static void launch_ln_bwd(const LnParams& p, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL((sf_layernorm_bwd_kernel<L, NS>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
+}
+static int ln_lanes(int C) { return C <= 128 ? 16 : C <= 256 ? 32 : 64; }
+static int check_ln(const char* who, int64_t M, int C) {
+    REQUIRE(M > 0 && M < (1ll << 31), "%s: bad row count", who);
+    REQUIRE(C > 0 && C % 8 == 0 && C <= 1024, "%s: C must be a multiple of 8, <= 1024 (got %d)", who, C);
+    return 0;
+}
+extern "C" int sf_layernorm_fwd(int64_t M, int32_t C, const void* x, int32_t ldx, const float* gamma, const float* beta,
+                                float eps, void* y, int32_t ldy, float* mean, float* rstd, sf_stream_t stream) {
+    if (check_ln("sf_layernorm_fwd", M, C)) return -1;
+    REQUIRE(x && gamma && beta && y, "sf_layernorm_fwd: null pointer");
+    LnParams p;
+    memset(&p, 0, sizeof(p));
+    p.M = (int)M; p.C = C; p.x = (const f16*)x; p.ldx = ldx; p.gamma = gamma; p.beta = beta; p.eps = eps;
+    p.y = (f16*)y; p.ldy = ldy; p.mean = mean; p.rstd = rstd;
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 128) launch_ln_fwd<16, 1>(p, s);
+    else if (C <= 256) launch_ln_fwd<32, 1>(p, s);
+    else if (C <= 512) launch_ln_fwd<64, 1>(p, s);
+    else launch_ln_fwd<64, 2>(p, s);
+    return check_launch("layernorm_fwd");
+}
+static int ln_bwd_plan(int64_t M, int C, int& rows_per_block) {
+    const int rpb = SF_THREADS / ln_lanes(C);
+    int blocks = cdiv(M, rpb);
+    if (blocks > 1024) blocks = 1024;
+    rows_per_block = roundup(cdiv(M, blocks), rpb);
+    return cdiv(M, rows_per_block);
+}
+extern "C" int sf_layernorm_bwd_blocks(int64_t M, int32_t C) {
+    if (check_ln("sf_layernorm_bwd_blocks", M, C)) return -1;
+    int rpb;
+    return ln_bwd_plan(M, C, rpb);
+}
+extern "C" int sf_layernorm_bwd(int64_t M, int32_t C, const void* dy, int32_t lddy, const void* x, int32_t ldx,
+                                const float* gamma, const float* mean, const float* rstd, const void* resid, int32_t ldr,
+                                void* dx, int32_t lddx, float* part, sf_stream_t stream) {
+    if (check_ln("sf_layernorm_bwd", M, C)) return -1;
+    REQUIRE(dy && x && gamma && mean && rstd && dx && part, "sf_layernorm_bwd: null pointer");
+    LnParams p;
+    memset(&p, 0, sizeof(p));
+    p.M = (int)M; p.C = C; p.x = (const f16*)x; p.ldx = ldx; p.gamma = gamma; p.mean = (float*)mean; p.rstd = (float*)rstd;
+    p.dy = (const f16*)dy; p.lddy = lddy; p.resid = (const f16*)resid; p.ldr = ldr; p.dx = (f16*)dx; p.lddx = lddx;
+    p.part = part;
+    const int blocks = ln_bwd_plan(M, C, p.rows_per_block);
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 128) launch_ln_bwd<16, 1>(p, blocks, s);
+    else if (C <= 256) launch_ln_bwd<32, 1>(p, blocks, s);
+    else if (C <= 512) launch_ln_bwd<64, 1>(p, blocks, s);
+    else launch_ln_bwd<64, 2>(p, blocks, s);
+    return check_launch("layernorm_bwd");
+}
+
+// ---- column sums
+static const int kColBlocks = 1024;
+extern "C" int sf_colsum_blocks(int64_t M, int32_t C) {
+    if (check_rows("sf_colsum_blocks", M, C)) return -1;
+    dim3 grid;
+    make_rowtile(M, C, kColBlocks, grid);
+    return (int)grid.x;
+}
+extern "C" int sf_colsum(int64_t M, int32_t C, const void* x, int32_t ldx, float* part, sf_stream_t stream) {
+    if (check_rows("sf_colsum", M, C)) return -1;
+    REQUIRE(x && part, "sf_colsum: null pointer");
+    ColSumParams p;
+    dim3 grid;
+    p.rt = make_rowtile(M, C, kColBlocks, grid);
+    p.x = (const f16*)x; p.ldx = ldx; p.part = part;
+    hipLaunchKernelGGL(sf_colsum_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("colsum");
+}
+extern "C" int sf_colsum_finalize(float* part, int32_t nblk, int32_t C, int32_t fold, float* out0, float* out1,
+                                  float scale, int accumulate, sf_stream_t stream) {
+    REQUIRE(part && nblk > 0 && C > 0 && fold > 0 && C % fold == 0, "sf_colsum_finalize: bad arguments");
+    ColFinalizeParams p;
+    p.row_stride = fold_partials(part, nblk, C, (hipStream_t)stream);
+    p.part = part; p.nblk = nblk; p.C = C; p.fold = fold; p.out0 = out0; p.out1 = out1; p.scale = scale;
+    p.accumulate = accumulate;
+    hipLaunchKernelGGL(sf_colsum_finalize_kernel, dim3(cdiv(fold, 32)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("colsum_finalize");
+}
+
+// ---- GELU
+extern "C" int sf_gelu_fwd(int64_t n, const void* h, void* a, sf_stream_t stream) {
+    REQUIRE(h && a && n > 0 && n % 8 == 0, "sf_gelu_fwd: bad arguments");
+    hipLaunchKernelGGL(sf_gelu_fwd_kernel, dim3(pool_grid(n / 8)), dim3(SF_THREADS), 0, (hipStream_t)stream,
+                       (const f16*)h, (f16*)a, n / 8);
+    return check_launch("gelu_fwd");
+}
+extern "C" int sf_gelu_bwd(int64_t n, const void* h, const void* da, void* dh, sf_stream_t stream) {
+    REQUIRE(h && da && dh && n > 0 && n % 8 == 0, "sf_gelu_bwd: bad arguments");
+    hipLaunchKernelGGL(sf_gelu_bwd_kernel, dim3(pool_grid(n / 8)), dim3(SF_THREADS), 0, (hipStream_t)stream,
+                       (const f16*)h, (const f16*)da, (f16*)dh, n / 8);
+    return check_launch("gelu_bwd");
+}
+
+// ---- depthwise convolution
+static int fill_dw(DwParams& p, const sf_dw_desc* d, bool rows_are_outputs, int max_blocks, dim3& grid) {
+    REQUIRE(d != nullptr, "dwconv: null descriptor");
+    REQUIRE(d->N > 0 && d->C > 0 && d->C % 8 == 0 && d->Cw > 0 && d->Cw % 8 == 0 && d->C % d->Cw == 0,
+            "dwconv: C and Cw must be multiples of 8 with C %% Cw == 0 (C=%d Cw=%d)", d->C, d->Cw);
+    const int taps = d->kT * d->kH * d->kW;
+    REQUIRE(taps * d->Cw <= SF_DW_MAX_W, "dwconv: taps*Cw = %d exceeds the LDS weight stage (%d)", taps * d->Cw, SF_DW_MAX_W);
+    REQUIRE(d->kH * d->kW <= 9, "dwconv: at most 9 spatial taps");
+    const int To = (d->Ti + 2 * d->pT - d->kT) / d->sT + 1, Ho = (d->Hi + 2 * d->pH - d->kH) / d->sH + 1,
+              Wo = (d->Wi + 2 * d->pW - d->kW) / d->sW + 1;
+    REQUIRE(To == d->To && Ho == d->Ho && Wo == d->Wo, "dwconv: output dims do not match the geometry");
+    memset(&p, 0, sizeof(p));
+    p.N = d->N; p.C = d->C; p.Cw = d->Cw; p.cls = d->cls ? 1 : 0;
+    p.Ti = d->Ti; p.Hi = d->Hi; p.Wi = d->Wi; p.To = d->To; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.kT = d->kT; p.kH = d->kH; p.kW = d->kW; p.sT = d->sT; p.sH = d->sH; p.sW = d->sW;
+    p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
+    const int64_t S = rows_are_outputs ? (int64_t)d->To * d->Ho * d->Wo : (int64_t)d->Ti * d->Hi * d->Wi;
+    const int64_t M = (int64_t)d->N * (S + p.cls);
+    REQUIRE(M < (1ll << 31), "dwconv: too many rows");
+    p.rt = make_rowtile(M, d->C, max_blocks, grid);
+    p.fdRow = make_fastdiv((uint32_t)(S + p.cls));
+    p.fdW = make_fastdiv(rows_are_outputs ? d->Wo : d->Wi);
+    p.fdH = make_fastdiv(rows_are_outputs ? d->Ho : d->Hi);
+    p.fdsT = make_fastdiv(d->sT); p.fdsH = make_fastdiv(d->sH); p.fdsW = make_fastdiv(d->sW);
+    return 0;
+}
+static const int kDwFwdBlocks = 2048, kDwWgradBlocks = 256;
+extern "C" int sf_dwconv_fwd_blocks(const sf_dw_desc* d) {
+    DwParams p;
+    dim3 grid;
+    if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
+    return (int)grid.x;
+}
+extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w, void* y, float* stat_part,
+                             sf_stream_t stream) {
+    DwParams p;
+    dim3 grid;
+    if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
+    REQUIRE(x && w && y, "sf_dwconv_fwd: null pointer");
+    p.x = (const f16*)x; p.ldx = d->ldx; p.w = w; p.y = (f16*)y; p.ldy = d->ldy; p.stat_part = stat_part;
+    hipLaunchKernelGGL(sf_dwconv_fwd_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("dwconv_fwd");
+}
+extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float* w, void* dx, sf_stream_t stream) {
+    DwParams p;
+    dim3 grid;
+    if (fill_dw(p, d, false, 8192, grid)) return -1;
+    REQUIRE(dy && w && dx, "sf_dwconv_dgrad: null pointer");
+    p.dy = (const f16*)dy; p.lddy = d->ldy; p.w = w; p.y = (f16*)dx; p.ldy = d->ldx;
+    hipLaunchKernelGGL(sf_dwconv_dgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("dwconv_dgrad");
+}
+extern "C" int64_t sf_dwconv_wgrad_workspace(const sf_dw_desc* d) {
+    DwParams p;
+    dim3 grid;
+    if (fill_dw(p, d, true, kDwWgradBlocks, grid)) return -1;
+    return (int64_t)grid.x * d->kT * d->kH * d->kW * d->C * 4;
+}
+extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* dy, float* dw, float out_scale,
+                               int zero_first, void* workspace, int64_t workspace_bytes, sf_stream_t stream) {
+    DwParams p;
+    dim3 grid;
+    if (fill_dw(p, d, true, kDwWgradBlocks, grid)) return -1;
+    REQUIRE(x && dy && dw && workspace, "sf_dwconv_wgrad: null pointer");
+    const int taps = d->kT * d->kH * d->kW;
+    REQUIRE(workspace_bytes >= (int64_t)grid.x * taps * d->C * 4, "sf_dwconv_wgrad: workspace too small");
+    REQUIRE(grid.y == 1, "sf_dwconv_wgrad: C > 2048 is not supported");
+    p.x = (const f16*)x; p.ldx = d->ldx; p.dy = (const f16*)dy; p.lddy = d->ldy; p.wpart = (float*)workspace;
+    grid.z = d->kT;
+    hipLaunchKernelGGL(sf_dwconv_wgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    if (check_launch("dwconv_wgrad")) return -1;
+    DwFinalizeParams f;
+    f.wpart = (const float*)workspace; f.nblk = grid.x; f.taps = taps; f.C = d->C; f.Cw = d->Cw;
+    f.dw = dw; f.scale = out_scale; f.accumulate = zero_first ? 0 : 1;
+    hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, SF_THREADS)), dim3(SF_THREADS), 0,
+                       (hipStream_t)stream, f);
+    return check_launch("dwconv_wgrad_finalize");
+}
+
+// ---- relative-position terms + softmax of pooled attention
+static int fill_relpos(RelPosParams& p, const sf_attn_desc* d) {
+    REQUIRE(d != nullptr, "attention: null descriptor");
+    REQUIRE(d->B > 0 && d->heads > 0 && d->D > 0 && d->D <= 128, "attention: bad shape (head dim <= 128)");
+    REQUIRE(d->Nq == d->cls + d->qT * d->qH * d->qW && d->Nk == d->cls + d->kT * d->kH * d->kW,
+            "attention: token counts do not match the (T,H,W) shapes");
+    REQUIRE(d->kH + d->kW + d->kT <= 64, "attention: kH + kW + kT must be <= 64");
+    memset(&p, 0, sizeof(p));
+    p.B = d->B; p.Nq = d->Nq; p.heads = d->heads; p.D = d->D; p.cls = d->cls;
+    p.qT = d->qT; p.qH = d->qH; p.qW = d->qW; p.KH = d->kH; p.KW = d->kW; p.KT = d->kT;
+    p.rows_h = d->rows_h; p.rows_w = d->rows_w; p.rows_t = d->rows_t;
+    p.fdHeads = make_fastdiv(d->heads); p.fdNq = make_fastdiv(d->Nq);
+    p.fdW = make_fastdiv(d->qW); p.fdH = make_fastdiv(d->qH);
+    return 0;
+}
+extern "C" int sf_relpos_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, const float* rel_h, const float* rel_w,
+                             const float* rel_t, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t,
+                             float* rq, sf_stream_t stream) {
+    RelPosParams p;
+    if (fill_relpos(p, d)) return -1;
+    REQUIRE(q && rel_h && rel_w && rel_t && idx_h && idx_w && idx_t && rq, "sf_relpos_fwd: null pointer");
+    p.q = (const f16*)q; p.ldq = ldq; p.rel_h = rel_h; p.rel_w = rel_w; p.rel_t = rel_t;
+    p.idx_h = idx_h; p.idx_w = idx_w; p.idx_t = idx_t; p.rq = rq;
+    const int64_t rows = (int64_t)d->B * d->Nq * d->heads;
+    int blocks = cdiv(rows, 4);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sf_relpos_fwd_kernel, dim3(blocks), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("relpos_fwd");
+}
+static const int kRelposBwdBlocks = 512;
+extern "C" int sf_relpos_bwd_blocks(const sf_attn_desc* d) {
+    REQUIRE(d != nullptr, "sf_relpos_bwd_blocks: null descriptor");
+    const int64_t rows = (int64_t)d->B * d->Nq * d->heads;
+    const int rpb = cdiv(rows, kRelposBwdBlocks);
+    return cdiv(rows, rpb);
+}
+extern "C" int sf_relpos_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, const float* rel_h, const float* rel_w,
+                             const float* rel_t, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t,
+                             const float* drq, void* dq, int32_t lddq, float* dtab_part, sf_stream_t stream) {
+    RelPosParams p;
+    if (fill_relpos(p, d)) return -1;
+    REQUIRE(q && rel_h && rel_w && rel_t && idx_h && idx_w && idx_t && drq && dq && dtab_part, "sf_relpos_bwd: null pointer");
+    REQUIRE((d->rows_h + d->rows_w + d->rows_t) * d->D <= SF_RELPOS_MAX_TAB, "sf_relpos_bwd: tables exceed the LDS stage");
+    p.q = (const f16*)q; p.ldq = ldq; p.rel_h = rel_h; p.rel_w = rel_w; p.rel_t = rel_t;
+    p.idx_h = idx_h; p.idx_w = idx_w; p.idx_t = idx_t; p.drq = drq; p.dq = (f16*)dq; p.lddq = lddq;
+    p.dtab_part = dtab_part;
+    const int64_t rows = (int64_t)d->B * d->Nq * d->heads;
+    p.rows_per_block = cdiv(rows, kRelposBwdBlocks);
+    hipLaunchKernelGGL(sf_relpos_bwd_kernel, dim3(cdiv(rows, p.rows_per_block)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("relpos_bwd");
+}
+// out[i] (+)= scale * sum_b part[b*row_len + offset + i], i < n   (table gradients from per-block partials)
+__global__ __launch_bounds__(SF_THREADS) void sf_rows_sum_kernel(const float* part, int nblk, int64_t row_len, int64_t offset,
+                                                                  int n, float* out, float scale, int accumulate) {
+    const int i = blockIdx.x * SF_THREADS + threadIdx.x;
+    if (i >= n) return;
+    double s0 = 0.0, s1 = 0.0;
+    const float* src = part + offset + i;
+    int b = 0;
+    for (; b + 2 <= nblk; b += 2) { s0 += (double)src[b * row_len]; s1 += (double)src[(b + 1) * row_len]; }
+    if (b < nblk) s0 += (double)src[b * row_len];
+    const float v = (float)((s0 + s1) * scale);
+    out[i] = accumulate ? out[i] + v : v;
+}
+extern "C" int sf_rows_sum(const float* part, int32_t nblk, int64_t row_len, int64_t offset, int32_t n, float* out,
+                           float scale, int accumulate, sf_stream_t stream) {
+    REQUIRE(part && out && nblk > 0 && n > 0, "sf_rows_sum: bad arguments");
+    hipLaunchKernelGGL(sf_rows_sum_kernel, dim3(cdiv(n, SF_THREADS)), dim3(SF_THREADS), 0, (hipStream_t)stream, part, nblk,
+                       row_len, offset, n, out, scale, accumulate);
+    return check_launch("rows_sum");
+}
+
+static int fill_softmax(SoftmaxParams& p, const sf_attn_desc* d, void* s, int32_t lds, float scale) {
+    REQUIRE(d != nullptr && s != nullptr, "softmax: null pointer");
+    REQUIRE(lds % 8 == 0 && lds >= d->Nk && lds <= 64 * 8 * 4, "softmax: score pitch must be a multiple of 8 in [Nk, 2048]");
+    memset(&p, 0, sizeof(p));
+    p.s = (f16*)s; p.lds = lds; p.rows = d->B * d->heads * d->Nq;
+    p.Nq = d->Nq; p.Nk = d->Nk; p.heads = d->heads; p.cls = d->cls; p.kT = d->kT; p.kH = d->kH; p.kW = d->kW;
+    p.scale = scale; p.R = d->kH + d->kW + d->kT; p.KH = d->kH; p.KW = d->kW;
+    p.fdNq = make_fastdiv(d->Nq); p.fdHeads = make_fastdiv(d->heads);
+    p.fdkW = make_fastdiv(d->kW); p.fdkH = make_fastdiv(d->kH);
+    return 0;
+}
+extern "C" int sf_softmax_fwd(const sf_attn_desc* d, void* s, int32_t lds, float scale, const float* rq, sf_stream_t stream) {
+    SoftmaxParams p;
+    if (fill_softmax(p, d, s, lds, scale)) return -1;
+    p.rq = rq;
+    int blocks = cdiv(p.rows, 4);
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t st = (hipStream_t)stream;
+    if (lds <= 512) hipLaunchKernelGGL((sf_softmax_fwd_kernel<1>), dim3(blocks), dim3(SF_THREADS), 0, st, p);
+    else if (lds <= 1024) hipLaunchKernelGGL((sf_softmax_fwd_kernel<2>), dim3(blocks), dim3(SF_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((sf_softmax_fwd_kernel<4>), dim3(blocks), dim3(SF_THREADS), 0, st, p);
+    return check_launch("softmax_fwd");
+}
+extern "C" int sf_softmax_bwd(const sf_attn_desc* d, void* dp, const void* prob, int32_t lds, float scale, float* drq,
+                              sf_stream_t stream) {
+    SoftmaxParams p;
+    if (fill_softmax(p, d, dp, lds, scale)) return -1;
+    REQUIRE(prob != nullptr, "sf_softmax_bwd: null pointer");
+    p.prob = (const f16*)prob; p.drq = drq;
+    int blocks = cdiv(p.rows, 4);
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t st = (hipStream_t)stream;
+    if (lds <= 512) hipLaunchKernelGGL((sf_softmax_bwd_kernel<1>), dim3(blocks), dim3(SF_THREADS), 0, st, p);
+    else if (lds <= 1024) hipLaunchKernelGGL((sf_softmax_bwd_kernel<2>), dim3(blocks), dim3(SF_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((sf_softmax_bwd_kernel<4>), dim3(blocks), dim3(SF_THREADS), 0, st, p);
+    return check_launch("softmax_bwd");
+}
+
+extern "C" int sf_transpose_heads(const void* x, int32_t ldx, void* xt, int32_t ldk, int32_t B, int32_t Nk, int32_t heads,
+                                  int32_t D, sf_stream_t stream) {
+    REQUIRE(x && xt && ldk % 8 == 0 && ldk >= Nk && B > 0 && heads > 0 && D > 0, "sf_transpose_heads: bad arguments");
+    TransposeParams p;
+    p.x = (const f16*)x; p.ldx = ldx; p.xt = (f16*)xt; p.ldk = ldk; p.B = B; p.Nk = Nk; p.heads = heads; p.D = D;
+    p.total = (int64_t)B * heads * D * (ldk / 8);
+    REQUIRE(p.total < (1ll << 31), "sf_transpose_heads: too many elements");
+    p.fdK8 = make_fastdiv(ldk / 8); p.fdD = make_fastdiv(D); p.fdHeads = make_fastdiv(heads);
+    hipLaunchKernelGGL(sf_transpose_heads_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("transpose_heads");
 }

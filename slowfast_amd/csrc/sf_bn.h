@@ -178,6 +178,55 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_act_kernel(BnActParams p) {
     }
 }
 
+// Block-level reduction of two per-thread 8-channel partial sums under the RowTile thread map; writes one row
+// [2][C] of a partial table (fixed order: deterministic).
+__device__ __forceinline__ void rowtile_reduce_store(const RowTile& rt, bool active, int c, float (&sg)[8],
+                                                     float (&sgy)[8], float* o, float (*s_red)[17]) {
+    const int G = rt.C >> 3;
+    const int TG = G < SF_THREADS ? G : SF_THREADS;
+    const int rpi = SF_THREADS / TG;
+    if (TG < SF_WAVE && (TG & (TG - 1)) == 0) {
+        // lanes l, l+TG, l+2TG, ... of a wave hold the same channel group: butterfly over them, then 4 waves via LDS
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            for (int mask = TG; mask < SF_WAVE; mask <<= 1) {
+                sg[e] += __shfl_xor(sg[e], mask);
+                sgy[e] += __shfl_xor(sgy[e], mask);
+            }
+        }
+        const int lane = threadIdx.x & (SF_WAVE - 1), wave = threadIdx.x >> 6;
+        if (lane < TG) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s_red[wave * TG + lane][e] = sg[e]; s_red[wave * TG + lane][8 + e] = sgy[e]; }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < TG && (int)(blockIdx.y * SF_THREADS + threadIdx.x) < G) {
+            const int cc = (blockIdx.y * SF_THREADS + threadIdx.x) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[cc + e] = (s_red[threadIdx.x][e] + s_red[TG + threadIdx.x][e]) +
+                            (s_red[2 * TG + threadIdx.x][e] + s_red[3 * TG + threadIdx.x][e]);
+                o[rt.C + cc + e] = (s_red[threadIdx.x][8 + e] + s_red[TG + threadIdx.x][8 + e]) +
+                                   (s_red[2 * TG + threadIdx.x][8 + e] + s_red[3 * TG + threadIdx.x][8 + e]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s_red[threadIdx.x][e] = sg[e]; s_red[threadIdx.x][8 + e] = sgy[e]; }
+    __syncthreads();
+    if (active && (int)threadIdx.x < TG) {
+        for (int k = 1; k < rpi; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s_red[threadIdx.x][e] += s_red[threadIdx.x + k * TG][e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[c + e] = s_red[threadIdx.x][e];
+            o[rt.C + c + e] = s_red[threadIdx.x][8 + e];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward: per-channel sums of g and g*y, g = dz masked by the activation
 struct BnBwdReduceParams {
@@ -223,50 +272,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_reduce_kernel(BnBwdReduc
             for (int e = 0; e < 8; ++e) { sg[e] += g[e]; sgy[e] += g[e] * (float)yv[e]; }
         }
     }
-    const int G = p.rt.C >> 3;
-    const int TG = G < SF_THREADS ? G : SF_THREADS;
-    const int rpi = SF_THREADS / TG;
-    float* o = p.part + (int64_t)blockIdx.x * 2 * p.rt.C;
-    if (TG < SF_WAVE && (TG & (TG - 1)) == 0) {
-        // lanes l, l+TG, l+2TG, ... of a wave hold the same channel group: butterfly over them, then 4 waves via LDS
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            for (int mask = TG; mask < SF_WAVE; mask <<= 1) {
-                sg[e] += __shfl_xor(sg[e], mask);
-                sgy[e] += __shfl_xor(sgy[e], mask);
-            }
-        }
-        const int lane = threadIdx.x & (SF_WAVE - 1), wave = threadIdx.x >> 6;
-        if (lane < TG) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { s_red[wave * TG + lane][e] = sg[e]; s_red[wave * TG + lane][8 + e] = sgy[e]; }
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < TG && (int)(blockIdx.y * SF_THREADS + threadIdx.x) < G) {
-            const int cc = (blockIdx.y * SF_THREADS + threadIdx.x) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                o[cc + e] = (s_red[threadIdx.x][e] + s_red[TG + threadIdx.x][e]) +
-                            (s_red[2 * TG + threadIdx.x][e] + s_red[3 * TG + threadIdx.x][e]);
-                o[p.rt.C + cc + e] = (s_red[threadIdx.x][8 + e] + s_red[TG + threadIdx.x][8 + e]) +
-                                     (s_red[2 * TG + threadIdx.x][8 + e] + s_red[3 * TG + threadIdx.x][8 + e]);
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s_red[threadIdx.x][e] = sg[e]; s_red[threadIdx.x][8 + e] = sgy[e]; }
-    __syncthreads();
-    if (active && (int)threadIdx.x < TG) {
-        for (int k = 1; k < rpi; ++k)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s_red[threadIdx.x][e] += s_red[threadIdx.x + k * TG][e];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            o[c + e] = s_red[threadIdx.x][e];
-            o[p.rt.C + c + e] = s_red[threadIdx.x][8 + e];
-        }
-    }
+    rowtile_reduce_store(p.rt, active, c, sg, sgy, p.part + (int64_t)blockIdx.x * 2 * p.rt.C, s_red);
 }
 
 struct BnBwdFinalizeParams {

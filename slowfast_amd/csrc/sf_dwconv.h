@@ -1,0 +1,245 @@
+// Depthwise 3-D convolution on channels-last fp16 tensors (HBM-bound stencil, no MFMA).
+//
+// Reference call sites: MViT attention pooling pool_q / pool_k / pool_v = Conv3d(96, 96, 3x3x3, stride (1,s,s),
+// groups=96) applied per head with the cls token routed around it (slowfast/models/attention.py:13-45, 227-266);
+// X3D X3DTransform.b = Conv3d(C, C, 3x3x3, stride (1,s,s), groups=C) (resnet_helper.py:214-224) and the X3D stem's
+// temporal conv Conv3d(24, 24, (5,1,1), groups=24) (stem_helper.py:267-275).
+//
+// Rows of a tensor are (n, [cls], t, h, w) with a row pitch; row(n, pos) = n*(S + cls) + cls + pos.  The weight is
+// the nn.Conv3d parameter itself, fp32 [Cw][taps]; C may be a multiple of Cw (heads side by side share the
+// weight: channel c uses weight channel c % Cw).
+#pragma once
+#include "sf_bn.h"
+#include "sf_common.h"
+
+#define SF_DW_MAX_W 12288   // taps * Cw floats staged in LDS (48 KiB): 27 x 432 for the widest X3D-M stage
+
+struct DwParams {
+    const f16* x; int ldx;          // fwd/wgrad: input;  dgrad: unused
+    const float* w;                 // [Cw][taps]
+    f16* y; int ldy;                // fwd: output;       dgrad: dx (rows of the INPUT space)
+    const f16* dy; int lddy;        // dgrad/wgrad: output gradient
+    int N, C, Cw, cls;
+    int Ti, Hi, Wi, To, Ho, Wo;
+    int kT, kH, kW, sT, sH, sW, pT, pH, pW;
+    RowTile rt;                     // rows iterated: fwd/wgrad N*(So+cls), dgrad N*(Si+cls)
+    float* stat_part;               // fwd, optional: [gridDim.x][2][C] per-block sum / sum of squares (BatchNorm)
+    float* wpart;                   // wgrad: [gridDim.x][taps][C] per-block partial weight gradients
+    FastDiv fdRow, fdW, fdH;        // row -> (n, r); r - cls -> (t, h, w) of the iterated space
+    FastDiv fdsT, fdsH, fdsW;
+};
+
+__device__ __forceinline__ void dw_stage_weights(const DwParams& p, float* s_w) {
+    // LDS layout [tap][Cw] so that a thread's 8 channels are contiguous
+    const int taps = p.kT * p.kH * p.kW;
+    for (int i = threadIdx.x; i < taps * p.Cw; i += SF_THREADS) {
+        const int cw = i / taps, tap = i % taps;
+        s_w[tap * p.Cw + cw] = p.w[i];
+    }
+}
+
+__device__ __forceinline__ bool dw_decode(const DwParams& p, uint32_t row, uint32_t& n, int& t, int& h, int& w) {
+    // returns true for the cls row of a sample
+    uint32_t r, q, ww, hh, tt;
+    fd_divmod(row, p.fdRow, n, r);
+    if (p.cls && r == 0) { t = h = w = 0; return true; }
+    fd_divmod(r - (uint32_t)p.cls, p.fdW, q, ww);
+    fd_divmod(q, p.fdH, tt, hh);
+    t = (int)tt; h = (int)hh; w = (int)ww;
+    return false;
+}
+
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_kernel(DwParams p) {
+    __shared__ float s_w[SF_DW_MAX_W];
+    __shared__ float s_red[SF_THREADS][17];
+    dw_stage_weights(p, s_w);
+    __syncthreads();
+    int gcol, r0, r1, rstep;
+    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const int c = gcol * 8;
+    const int cw = c % p.Cw;
+    const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls;
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    if (active) {
+        for (int m = r0; m < r1; m += rstep) {
+            uint32_t n;
+            int to, ho, wo;
+            const bool is_cls = dw_decode(p, (uint32_t)m, n, to, ho, wo);
+            const f16* xb = p.x + ((int64_t)n * Si) * p.ldx + c;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            if (is_cls) {
+                f16x8 v = ld16(xb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = (float)v[e];
+            } else {
+                int tap = 0;
+                for (int kt = 0; kt < p.kT; ++kt) {
+                    const int t = to * p.sT - p.pT + kt;
+                    for (int kh = 0; kh < p.kH; ++kh) {
+                        const int h = ho * p.sH - p.pH + kh;
+                        for (int kw = 0; kw < p.kW; ++kw, ++tap) {
+                            const int w = wo * p.sW - p.pW + kw;
+                            if ((unsigned)t >= (unsigned)p.Ti || (unsigned)h >= (unsigned)p.Hi ||
+                                (unsigned)w >= (unsigned)p.Wi) continue;
+                            f16x8 v = ld16(xb + (p.cls + ((int64_t)t * p.Hi + h) * p.Wi + w) * p.ldx);
+                            const float* wt = s_w + tap * p.Cw + cw;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e] * wt[e];
+                        }
+                    }
+                }
+            }
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (f16)acc[e];
+                ssum[e] += acc[e];
+                ssq[e] += acc[e] * acc[e];
+            }
+            st16(p.y + (int64_t)m * p.ldy + c, o);
+        }
+    }
+    if (p.stat_part)
+        rowtile_reduce_store(p.rt, active, c, ssum, ssq, p.stat_part + (int64_t)blockIdx.x * 2 * p.rt.C, s_red);
+}
+
+// dx[n, t, h, w, c] = sum_taps w[c][tap] * dy[n, (t + pT - kt)/sT, (h + pH - kh)/sH, (w + pW - kw)/sW, c]
+// (terms with a non-integral or out-of-range quotient vanish); the cls row passes through.
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_kernel(DwParams p) {
+    __shared__ float s_w[SF_DW_MAX_W];
+    dw_stage_weights(p, s_w);
+    __syncthreads();
+    int gcol, r0, r1, rstep;
+    if (!p.rt.init(gcol, r0, r1, rstep)) return;
+    const int c = gcol * 8;
+    const int cw = c % p.Cw;
+    const int64_t So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
+    for (int m = r0; m < r1; m += rstep) {
+        uint32_t n;
+        int t, h, w;
+        const bool is_cls = dw_decode(p, (uint32_t)m, n, t, h, w);
+        const f16* db = p.dy + ((int64_t)n * So) * p.lddy + c;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (is_cls) {
+            f16x8 v = ld16(db);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = (float)v[e];
+        } else {
+            int tap = 0;
+            for (int kt = 0; kt < p.kT; ++kt) {
+                const int ut = t + p.pT - kt;
+                for (int kh = 0; kh < p.kH; ++kh) {
+                    const int uh = h + p.pH - kh;
+                    for (int kw = 0; kw < p.kW; ++kw, ++tap) {
+                        const int uw = w + p.pW - kw;
+                        if (ut < 0 || uh < 0 || uw < 0) continue;
+                        uint32_t qt, rt, qh, rh, qw, rw;
+                        fd_divmod((uint32_t)ut, p.fdsT, qt, rt);
+                        fd_divmod((uint32_t)uh, p.fdsH, qh, rh);
+                        fd_divmod((uint32_t)uw, p.fdsW, qw, rw);
+                        if ((rt | rh | rw) || qt >= (uint32_t)p.To || qh >= (uint32_t)p.Ho || qw >= (uint32_t)p.Wo) continue;
+                        f16x8 v = ld16(db + (p.cls + ((int64_t)qt * p.Ho + qh) * p.Wo + qw) * p.lddy);
+                        const float* wt = s_w + tap * p.Cw + cw;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e] * wt[e];
+                    }
+                }
+            }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)acc[e];
+        st16(p.y + (int64_t)m * p.ldy + c, o);
+    }
+}
+
+// Per-block partial weight gradients: wpart[blk][tap][c] = sum over the block's output rows of dy * x(tap).
+// blockIdx.z selects the temporal tap kt; the kH*kW (<= 9) taps of that plane are accumulated in registers.
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_kernel(DwParams p) {
+    __shared__ float s_red[SF_THREADS][9];
+    int gcol, r0, r1, rstep;
+    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const int c = gcol * 8;
+    const int kt = blockIdx.z;
+    const int nsp = p.kH * p.kW;
+    const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls;
+    float acc[9][8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+    if (active) {
+        for (int m = r0; m < r1; m += rstep) {
+            uint32_t n;
+            int to, ho, wo;
+            if (dw_decode(p, (uint32_t)m, n, to, ho, wo)) continue;
+            const int t = to * p.sT - p.pT + kt;
+            if ((unsigned)t >= (unsigned)p.Ti) continue;
+            f16x8 d = ld16(p.dy + (int64_t)m * p.lddy + c);
+            const f16* xb = p.x + ((int64_t)n * Si + p.cls) * p.ldx + c;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (i < nsp) {
+                    const int kh = i / p.kW, kw = i % p.kW;
+                    const int h = ho * p.sH - p.pH + kh, w = wo * p.sW - p.pW + kw;
+                    if ((unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi) {
+                        f16x8 v = ld16(xb + (((int64_t)t * p.Hi + h) * p.Wi + w) * p.ldx);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[i][e] += (float)d[e] * (float)v[e];
+                    }
+                }
+            }
+        }
+    }
+    // fold the row-lanes of the block, one tap at a time (fixed order)
+    const int G = p.rt.C >> 3;
+    const int TG = G < SF_THREADS ? G : SF_THREADS;
+    const int rpi = SF_THREADS / TG;
+    const int taps = p.kT * nsp;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {       // static register indices: a runtime-indexed acc[] would live in scratch
+        if (i < nsp) {                  // block-uniform
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_red[threadIdx.x][e] = acc[i][e];
+            __syncthreads();
+            if (active && (int)threadIdx.x < TG) {
+                float* o = p.wpart + ((int64_t)blockIdx.x * taps + kt * nsp + i) * p.rt.C + c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a = 0.f;
+                    for (int k = 0; k < rpi; ++k) a += s_red[threadIdx.x + k * TG][e];
+                    o[e] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// dw[cw][tap] (+)= scale * sum over blocks and over the C/Cw channel copies of wpart[blk][tap][c]
+struct DwFinalizeParams {
+    const float* wpart; int nblk, taps, C, Cw;
+    float* dw; float scale; int accumulate;
+};
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_finalize_kernel(DwFinalizeParams p) {
+    const int idx = blockIdx.x * SF_THREADS + threadIdx.x;      // (tap, cw), cw fastest
+    if (idx >= p.taps * p.Cw) return;
+    const int tap = idx / p.Cw, cw = idx % p.Cw;
+    double s0 = 0.0, s1 = 0.0;
+    for (int c = cw; c < p.C; c += p.Cw) {
+        const float* src = p.wpart + (int64_t)tap * p.C + c;
+        const int64_t bs = (int64_t)p.taps * p.C;
+        int b = 0;
+        for (; b + 2 <= p.nblk; b += 2) { s0 += (double)src[b * bs]; s1 += (double)src[(b + 1) * bs]; }
+        if (b < p.nblk) s0 += (double)src[b * bs];
+    }
+    float* dst = p.dw + (int64_t)cw * p.taps + tap;
+    const float v = (float)((s0 + s1) * p.scale);
+    *dst = p.accumulate ? *dst + v : v;
+}

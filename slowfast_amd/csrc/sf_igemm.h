@@ -26,6 +26,10 @@ struct IgemmParams {
     int ldr;
     float* stat_part;   // optional [mtiles][2][Nout] per-tile column sum / sum of squares (BatchNorm)
     int ntiles_n;
+    // batched GEMMs (attention): blockIdx.y = b*bh + j, operands advance by (b, j) strides (elements)
+    int bh;
+    int64_t sa_b, sa_h, sw_b, sw_h, sy_b, sy_h, sr_b, sr_h;
+    int resid_row0;     // the residual is added to rows >= resid_row0 only (pooled attention: not to the cls row)
 };
 
 template <int BN, int WM, int WN, bool PW>
@@ -52,6 +56,17 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
     const int m0 = mt * BM, n0 = nt * BN;
     const GatherSide& g = p.g;
     const bool has_tf = g.scale != nullptr;
+    const f16* a_src = g.src;
+    const f16* wmat = p.wmat;
+    f16* yout = p.y;
+    const f16* resid = p.resid;
+    if (p.bh > 0) {
+        const int zb = blockIdx.y / p.bh, zj = blockIdx.y % p.bh;
+        a_src += zb * p.sa_b + zj * p.sa_h;
+        wmat += zb * p.sw_b + zj * p.sw_h;
+        yout += zb * p.sy_b + zj * p.sy_h;
+        if (resid) resid += zb * p.sr_b + zj * p.sr_h;
+    }
 
     if (has_tf) {
         for (int c = tid; c < g.C; c += SF_THREADS) {
@@ -80,7 +95,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
             int64_t off;
             uint32_t c0 = 0;
             bool ok = PW ? gather_offset_pw(g, rp[j], k0, off, c0) : gather_offset(g, rp[j], k0, off, c0);
-            ra[j] = ok ? ld16(g.src + off) : zero8();
+            ra[j] = ok ? ld16(a_src + off) : zero8();
             ra_ok[j] = ok;
             ra_c0[j] = c0;
         }
@@ -89,8 +104,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
             int idx = tid + SF_THREADS * j;
             int brow = idx >> 2;
             int co = n0 + brow;
-            bool ok = (idx < BN * 4) && (co < p.Nout);
-            rb[j] = ok ? ld16(p.wmat + (int64_t)co * p.ldw + k0) : zero8();
+            bool ok = (idx < BN * 4) && (co < p.Nout) && (k0 < (uint32_t)g.Ktot);
+            rb[j] = ok ? ld16(wmat + (int64_t)co * p.ldw + k0) : zero8();
         }
     };
     auto store_tile = [&](int buf) {
@@ -197,12 +212,12 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
         const int m = m0 + row, col = n0 + cg * 8;
         if (m < p.M && col < p.Nout) {
             f16x8 v = ld16(stg + row * STG_LD + cg * 8);
-            if (p.resid) {
-                f16x8 r = ld16(p.resid + (int64_t)m * p.ldr + col);
+            if (resid && m >= p.resid_row0) {
+                f16x8 r = ld16(resid + (int64_t)m * p.ldr + col);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)r[e]);
             }
-            st16(p.y + (int64_t)m * p.ldy + col, v);
+            st16(yout + (int64_t)m * p.ldy + col, v);
         }
     }
 }
@@ -218,6 +233,11 @@ struct WgradParams {
     int Co_pad, Kpad;
     int nchunks;        // ceil(M / 32)
     int chunks_per_split;
+    // batched "TN" GEMM mode (attention dV / dK): blockIdx.z = b*bh + j selects the operands, one split, and the
+    // tile is written directly as fp16: out[co][k] = out_scale * sum_m dy[m][co] * x[m][k]
+    int bh;
+    int64_t sp_b, sp_h, sx_b, sx_h, so_b, so_h;
+    f16* out16; int ldo; float out_scale;
 };
 
 // dw[Co][Cw][taps] (PyTorch Conv3d weight layout) (+)= out_scale * sum_splits ws[s][co][tap*C + ci]
@@ -341,10 +361,21 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             s_shift[c] = g.shift[c];
         }
     }
-    // this split's stages (chunks_per_split counts 32-position chunks and is a multiple of KS)
-    const int sb = blockIdx.z * (p.chunks_per_split / KS);
-    int se = sb + p.chunks_per_split / KS;
+    const f16* x_src = g.src;
+    const f16* dy_src = p.dy;
+    f16* out16 = p.out16;
     const int nstages = (p.nchunks + KS - 1) / KS;
+    // this split's stages (chunks_per_split counts 32-position chunks and is a multiple of KS)
+    int sb = blockIdx.z * (p.chunks_per_split / KS);
+    int se = sb + p.chunks_per_split / KS;
+    if (p.bh > 0) {
+        const int zb = blockIdx.z / p.bh, zj = blockIdx.z % p.bh;
+        dy_src += zb * p.sp_b + zj * p.sp_h;
+        x_src += zb * p.sx_b + zj * p.sx_h;
+        out16 += zb * p.so_b + zj * p.so_h;
+        sb = 0;
+        se = nstages;
+    }
     if (se > nstages) se = nstages;
 
     f16x8 ra[NA], rb[NX];
@@ -359,7 +390,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             int ml = idx / (BMW / 8), cg = idx % (BMW / 8);
             int m = mbase + ml, co = c0 + cg * 8;
             bool ok = (idx < ROWS * (BMW / 8)) && (m < p.M) && (co < p.Co);
-            ra[j] = ok ? ld16(p.dy + (int64_t)m * p.ldy + co) : zero8();
+            ra[j] = ok ? ld16(dy_src + (int64_t)m * p.ldy + co) : zero8();
         }
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
@@ -367,7 +398,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             RowPos rp = decode_row(g, (uint32_t)m, m < p.M);
             int64_t off;
             bool ok = gather_offset_tap(g, rp, tp, off);
-            rb[j] = ok ? ld16(g.src + off) : zero8();
+            rb[j] = ok ? ld16(x_src + off) : zero8();
             rb_ok[j] = ok;
         }
     };
@@ -456,6 +487,20 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             if (more) store_tile(0);
             __syncthreads();
         }
+    }
+    if (p.bh > 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int kcol = n0 + wn * WN + j * 16 + pl;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = c0 + wm * WM + i * 16 + 4 * g4 + r;
+                    if (co < p.Co && kcol < g.Ktot) out16[(int64_t)co * p.ldo + kcol] = (f16)(acc[i][j][r] * p.out_scale);
+                }
+        }
+        return;
     }
     // every split owns its slab: plain (non-atomic) stores, also when it had no rows to reduce (zeros)
     float* slab = p.ws + (int64_t)blockIdx.z * p.Co_pad * p.Kpad;

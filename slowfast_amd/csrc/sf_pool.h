@@ -18,7 +18,16 @@ struct PoolParams {
     const f16* dout; int lddo;      // bwd: gradient of the pooled output
     FastDiv fdG, fdW, fdH;          // work index -> (group, w, h, rest); dims of the iterated space
     int64_t total;
+    int cls;                        // token tensors: every sample's T*H*W rows are preceded by one cls row, which
+    FastDiv fdT;                    // passes through the pool (attention.py:24-36); row += nt / T + 1
 };
+
+// row of (nt = n*T + t, h, w) in a tensor whose spatial dims are (Hx, Wx)
+__device__ __forceinline__ int64_t pool_row(const PoolParams& p, uint32_t nt, int Hx, int Wx, int h, int w) {
+    int64_t r = ((int64_t)nt * Hx + h) * Wx + w;
+    if (p.cls) r += fd_div(nt, p.fdT) + 1;
+    return r;
+}
 
 __device__ __forceinline__ void bn_act8(const f16x8& v, const float (&sc)[8], const float (&sh)[8], int relu,
                                         float (&z)[8]) {
@@ -33,8 +42,18 @@ __device__ __forceinline__ void bn_act8(const f16x8& v, const float (&sc)[8], co
 // One thread per (pooled position, 8 channels).  The FIRST maximum in scan order wins (the element torch's
 // max_pool3d records); its window-local index is kept for the backward pass.
 __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
-    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
+    const int64_t ncls = p.cls ? (int64_t)p.N * (p.C >> 3) : 0;
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total + ncls;
          idx += (int64_t)gridDim.x * SF_THREADS) {
+        if (idx >= p.total) {     // cls rows: copy
+            const int64_t j = idx - p.total;
+            const int G = p.C >> 3;
+            const int64_t n = j / G;
+            const int c = (int)(j % G) * 8;
+            st16(p.out + n * ((int64_t)p.T * p.Ho * p.Wo + 1) * p.ldo + c,
+                 ld16(p.y + n * ((int64_t)p.T * p.H * p.W + 1) * p.ldy + c));
+            continue;
+        }
         uint32_t q, gcol, wo, ho, nt;
         fd_divmod((uint32_t)idx, p.fdG, q, gcol);
         fd_divmod(q, p.fdW, q, wo);
@@ -57,7 +76,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
             for (int kw = 0; kw < p.kW; ++kw) {
                 const int w = (int)wo * p.sW - p.pW + kw;
                 if ((unsigned)w >= (unsigned)p.W) continue;
-                f16x8 v = ld16(p.y + (((int64_t)nt * p.H + h) * p.W + w) * p.ldy + c);
+                f16x8 v = ld16(p.y + pool_row(p, nt, p.H, p.W, h, w) * p.ldy + c);
                 float z[8];
                 bn_act8(v, sc, sh, p.relu, z);
                 const uint32_t code = (uint32_t)(kh * p.kW + kw);
@@ -72,7 +91,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (f16)best[e];
-        const int64_t orow = ((int64_t)nt * p.Ho + ho) * p.Wo + wo;
+        const int64_t orow = pool_row(p, nt, p.Ho, p.Wo, (int)ho, (int)wo);
         st16(p.out + orow * p.ldo + c, o);
         if (p.argmax) {
             u32x2 pk;
@@ -87,8 +106,18 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
 // ceil(kH/sH)*ceil(kW/sW)) windows that cover it and takes a window's gradient iff the recorded argmax is this
 // position and the pooled value is positive (the ReLU in front of the pool passed it).
 __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
-    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
+    const int64_t ncls = p.cls ? (int64_t)p.N * (p.C >> 3) : 0;
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total + ncls;
          idx += (int64_t)gridDim.x * SF_THREADS) {
+        if (idx >= p.total) {     // cls rows: the gradient passes through
+            const int64_t j = idx - p.total;
+            const int G = p.C >> 3;
+            const int64_t n = j / G;
+            const int c = (int)(j % G) * 8;
+            st16(p.out + n * ((int64_t)p.T * p.H * p.W + 1) * p.ldo + c,
+                 ld16(p.dout + n * ((int64_t)p.T * p.Ho * p.Wo + 1) * p.lddo + c));
+            continue;
+        }
         uint32_t q, gcol, w, h, nt;
         fd_divmod((uint32_t)idx, p.fdG, q, gcol);
         fd_divmod(q, p.fdW, q, w);
@@ -107,7 +136,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
             for (int wo = wo_lo; wo <= wo_hi; ++wo) {
                 const int kws = (int)w - (wo * p.sW - p.pW);
                 const uint32_t me = (uint32_t)(khs * p.kW + kws);
-                const int64_t orow = ((int64_t)nt * p.Ho + ho) * p.Wo + wo;
+                const int64_t orow = pool_row(p, nt, p.Ho, p.Wo, ho, wo);
                 const u32x2 pk = *reinterpret_cast<const u32x2*>(p.argmax + orow * p.C + c);
                 const f16x8 d = ld16(p.dout + orow * p.lddo + c);
                 const f16x8 pv = ld16(p.pooled + orow * p.ldp + c);
@@ -122,7 +151,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (f16)g[e];
-        st16(p.out + (((int64_t)nt * p.H + h) * p.W + w) * p.ldo + c, o);
+        st16(p.out + pool_row(p, nt, p.H, p.W, (int)h, (int)w) * p.ldo + c, o);
     }
 }
 

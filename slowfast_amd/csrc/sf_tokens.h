@@ -1,0 +1,567 @@
+// Token-space kernels of the MViT path (HBM-bound): LayerNorm, GELU, column sums (bias / affine gradients),
+// pooled-attention softmax with the decomposed relative-position bias, K/V transposes.
+//
+// Reference call sites (slowfast/models): attention.py:428,456 (norm1/norm2), :240-268 (norm_q/k/v over
+// head_dim), common.py:7-34 (Mlp: fc1 -> exact-erf GELU -> fc2), attention.py:354-385 (scores, rel-pos bias,
+// softmax, attn @ v, residual pooling), :64-147 (cal_rel_pos_spatial / cal_rel_pos_temporal).
+// Token tensors are fp16 [rows][C] with a row pitch (elements); statistics and parameter gradients are fp32.
+#pragma once
+#include "sf_bn.h"
+#include "sf_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension.  L = lanes per row (power of two, 8 channels per lane per slot),
+// NS = slots per lane (C <= 8*L*NS).  A wave handles 64/L rows at once.
+struct LnParams {
+    int M, C;
+    const f16* x; int ldx;
+    const float* gamma; const float* beta;
+    float eps;
+    f16* y; int ldy;
+    float* mean; float* rstd;       // [M]
+    // backward
+    const f16* dy; int lddy;
+    const f16* resid; int ldr;      // optional: dx += resid (the skip path of a residual stream)
+    f16* dx; int lddx;
+    float* part;                    // [gridDim.x][2][C]: sum dy*xhat, sum dy
+    int rows_per_block;
+};
+
+template <int L>
+__device__ __forceinline__ float ln_group_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < L; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+template <int L, int NS>
+__global__ __launch_bounds__(SF_THREADS) void sf_layernorm_fwd_kernel(LnParams p) {
+    constexpr int RPB = SF_THREADS / L;        // rows per block pass
+    const int sub = threadIdx.x % L, rl = threadIdx.x / L;
+    float ga[NS][8], be[NS][8];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int c = (sub + s * L) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ga[s][e] = c < p.C ? p.gamma[c + e] : 0.f;
+            be[s][e] = c < p.C ? p.beta[c + e] : 0.f;
+        }
+    }
+    const float invC = 1.f / (float)p.C;
+    // all lanes of a wave stay in the loop together (shuffles): rows beyond M are computed on zeros, not stored
+    for (int base = blockIdx.x * RPB; base < p.M; base += gridDim.x * RPB) {
+        const int m = base + rl;
+        const bool rowok = m < p.M;
+        float v[NS][8];
+        float s1 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = (sub + s * L) * 8;
+            f16x8 h = (rowok && c < p.C) ? ld16(p.x + (int64_t)m * p.ldx + c) : zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[s][e] = (float)h[e]; s1 += v[s][e]; }
+        }
+        const float mean = ln_group_sum<L>(s1) * invC;
+        float s2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = (sub + s * L) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = c < p.C ? v[s][e] - mean : 0.f;
+                s2 += d * d;
+            }
+        }
+        const float var = ln_group_sum<L>(s2) * invC;
+        const float rstd = 1.0f / sqrtf(var + p.eps);
+        if (rowok) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int c = (sub + s * L) * 8;
+                if (c < p.C) {
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (f16)((v[s][e] - mean) * rstd * ga[s][e] + be[s][e]);
+                    st16(p.y + (int64_t)m * p.ldy + c, o);
+                }
+            }
+            if (sub == 0) {
+                if (p.mean) p.mean[m] = mean;
+                if (p.rstd) p.rstd[m] = rstd;
+            }
+        }
+    }
+}
+
+// dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * gamma;  per-block partial sums of
+// dy*xhat (dgamma) and dy (dbeta) for the column reduction.
+template <int L, int NS>
+__global__ __launch_bounds__(SF_THREADS) void sf_layernorm_bwd_kernel(LnParams p) {
+    constexpr int RPB = SF_THREADS / L;
+    __shared__ float s_acc[SF_THREADS][NS * 16 + 1];
+    const int sub = threadIdx.x % L, rl = threadIdx.x / L;
+    float ga[NS][8], ag[NS][8], ab[NS][8];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int c = (sub + s * L) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ga[s][e] = c < p.C ? p.gamma[c + e] : 0.f;
+            ag[s][e] = 0.f;
+            ab[s][e] = 0.f;
+        }
+    }
+    const float invC = 1.f / (float)p.C;
+    const int r0 = blockIdx.x * p.rows_per_block;
+    int r1 = r0 + p.rows_per_block;
+    if (r1 > p.M) r1 = p.M;
+    for (int base = r0; base < r1; base += RPB) {
+        const int m = base + rl;
+        const bool rowok = m < r1;
+        const float mean = rowok ? p.mean[m] : 0.f, rstd = rowok ? p.rstd[m] : 0.f;
+        float xh[NS][8], g[NS][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = (sub + s * L) * 8;
+            const bool ok = rowok && c < p.C;
+            f16x8 hx = ok ? ld16(p.x + (int64_t)m * p.ldx + c) : zero8();
+            f16x8 hd = ok ? ld16(p.dy + (int64_t)m * p.lddy + c) : zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)hd[e];
+                xh[s][e] = ok ? ((float)hx[e] - mean) * rstd : 0.f;
+                g[s][e] = d * ga[s][e];
+                s1 += g[s][e];
+                s2 += g[s][e] * xh[s][e];
+                ag[s][e] += d * xh[s][e];
+                ab[s][e] += d;
+            }
+        }
+        const float c1 = ln_group_sum<L>(s1) * invC, c2 = ln_group_sum<L>(s2) * invC;
+        if (rowok) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int c = (sub + s * L) * 8;
+                if (c < p.C) {
+                    f16x8 r = p.resid ? ld16(p.resid + (int64_t)m * p.ldr + c) : zero8();
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        o[e] = (f16)(rstd * (g[s][e] - c1 - xh[s][e] * c2) + (float)r[e]);
+                    st16(p.dx + (int64_t)m * p.lddx + c, o);
+                }
+            }
+        }
+    }
+    // fold the RPB row-lanes of the block (fixed order), write one partial row
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s_acc[threadIdx.x][s * 16 + e] = ag[s][e];
+            s_acc[threadIdx.x][s * 16 + 8 + e] = ab[s][e];
+        }
+    __syncthreads();
+    if (rl == 0) {
+        float* o = p.part + (int64_t)blockIdx.x * 2 * p.C;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = (sub + s * L) * 8;
+            if (c < p.C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a = 0.f, b = 0.f;
+                    for (int k = 0; k < RPB; ++k) {
+                        a += s_acc[sub + k * L][s * 16 + e];
+                        b += s_acc[sub + k * L][s * 16 + 8 + e];
+                    }
+                    o[c + e] = a;
+                    o[p.C + c + e] = b;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column sums of an [M][C] fp16 tensor (bias gradients): part[blk][0][c] = sum_m x[m][c], part[blk][1][c] = 0.
+struct ColSumParams {
+    RowTile rt;
+    const f16* x; int ldx;
+    float* part;
+};
+__global__ __launch_bounds__(SF_THREADS) void sf_colsum_kernel(ColSumParams p) {
+    __shared__ float s_red[SF_THREADS][17];
+    int gcol, r0, r1, rstep;
+    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const int c = gcol * 8;
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; }
+    if (active) {
+        for (int m = r0; m < r1; m += rstep) {
+            f16x8 v = ld16(p.x + (int64_t)m * p.ldx + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+        }
+    }
+    rowtile_reduce_store(p.rt, active, c, a, b, p.part + (int64_t)blockIdx.x * 2 * p.rt.C, s_red);
+}
+
+// out0[c % fold] (+)= scale * sum over rows and over the C/fold channel copies of part[.][0][c]; same for out1.
+struct ColFinalizeParams {
+    const float* part; int nblk; int row_stride; int C;
+    int fold;                // output length (C % fold == 0): channel c contributes to c % fold
+    float* out0; float* out1;
+    float scale;
+    int accumulate;
+};
+__global__ __launch_bounds__(SF_THREADS) void sf_colsum_finalize_kernel(ColFinalizeParams p) {
+    __shared__ double s_s[8][32];
+    __shared__ double s_q[8][32];
+    const int cx = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int co = blockIdx.x * 32 + cx;
+    double s = 0.0, q = 0.0;
+    if (co < p.fold) {
+        for (int c = co; c < p.C; c += p.fold) {
+            double a, b;
+            strided_col_sums(p.part, p.nblk, p.row_stride, p.C, c, seg, a, b);
+            s += a;
+            q += b;
+        }
+    }
+    s_s[seg][cx] = s;
+    s_q[seg][cx] = q;
+    __syncthreads();
+    if (seg == 0 && co < p.fold) {
+        for (int k = 1; k < 8; ++k) { s += s_s[k][cx]; q += s_q[k][cx]; }
+        const float v0 = (float)(s * p.scale), v1 = (float)(q * p.scale);
+        if (p.out0) p.out0[co] = p.accumulate ? p.out0[co] + v0 : v0;
+        if (p.out1) p.out1[co] = p.accumulate ? p.out1[co] + v1 : v1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GELU (exact, erf) on contiguous fp16 arrays; n8 = number of 8-element groups.
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+__global__ __launch_bounds__(SF_THREADS) void sf_gelu_fwd_kernel(const f16* h, f16* a, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; i < n8; i += (int64_t)gridDim.x * SF_THREADS) {
+        f16x8 v = ld16(h + i * 8), o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)gelu_f((float)v[e]);
+        st16(a + i * 8, o);
+    }
+}
+__global__ __launch_bounds__(SF_THREADS) void sf_gelu_bwd_kernel(const f16* h, const f16* da, f16* dh, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; i < n8; i += (int64_t)gridDim.x * SF_THREADS) {
+        f16x8 v = ld16(h + i * 8), d = ld16(da + i * 8), o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)d[e] * gelu_df((float)v[e]));
+        st16(dh + i * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decomposed relative-position terms of pooled attention.
+//   rq[row][j] = sum_c q[row][c] * table(j, q position)[c],   row = (b, token, head), j in [0, KH+KW+KT)
+// with table rows gathered through host-built index maps: idx_h[qh][kh], idx_w[qw][kw], idx_t[qt][kt]
+// (attention.py:64-147; the UNSCALED q is used).  The cls token (token 0 when cls=1) gets zeros.
+struct RelPosParams {
+    const f16* q; int ldq;          // [B][Nq][heads*D], pitch of a token row = ldq
+    int B, Nq, heads, D;            // D = head dim (96)
+    int cls, qT, qH, qW;            // Nq = cls + qT*qH*qW
+    int KH, KW, KT;
+    const float* rel_h; const float* rel_w; const float* rel_t;   // [rows][D] fp32 parameters
+    int rows_h, rows_w, rows_t;
+    const int32_t* idx_h; const int32_t* idx_w; const int32_t* idx_t;   // [qH][KH], [qW][KW], [qT][KT]
+    float* rq;                      // [B*Nq*heads][R] fp32, R = KH+KW+KT
+    // backward
+    const float* drq;               // [B*Nq*heads][R]
+    f16* dq; int lddq;              // dq += sum_j drq[j] * table_j   (read-modify-write of dq rows)
+    float* dtab_part;               // [gridDim.x][(rows_h+rows_w+rows_t)][D] per-block partial tables
+    int rows_per_block;
+    FastDiv fdHeads, fdNq, fdW, fdH;
+};
+
+__device__ __forceinline__ void relpos_row_decode(const RelPosParams& p, uint32_t row, uint32_t& b, uint32_t& tok,
+                                                  uint32_t& head, int& qt, int& qh, int& qw, bool& is_cls) {
+    uint32_t q;
+    fd_divmod(row, p.fdHeads, q, head);
+    fd_divmod(q, p.fdNq, b, tok);
+    is_cls = p.cls && tok == 0;
+    uint32_t pos = is_cls ? 0u : tok - (uint32_t)p.cls, r, w, h, t;
+    fd_divmod(pos, p.fdW, r, w);
+    fd_divmod(r, p.fdH, t, h);
+    qt = (int)t; qh = (int)h; qw = (int)w;
+}
+
+// one wave per row; lane j < R computes the j-th dot product (all waves of a block iterate together)
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_fwd_kernel(RelPosParams p) {
+    __shared__ float s_q[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = p.KH + p.KW + p.KT;
+    const int total = p.B * p.Nq * p.heads;
+    for (int base = blockIdx.x * 4; base < total; base += gridDim.x * 4) {
+        const int row = base + wave;
+        const bool ok = row < total;
+        uint32_t b = 0, tok = 0, head = 0;
+        int qt = 0, qh = 0, qw = 0;
+        bool is_cls = true;
+        if (ok) {
+            relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
+            const f16* qrow = p.q + ((int64_t)b * p.Nq + tok) * p.ldq + head * p.D;
+            for (int c = lane; c < p.D; c += 64) s_q[wave][c] = (float)qrow[c];
+        }
+        __syncthreads();
+        if (ok && lane < R) {
+            float acc = 0.f;
+            if (!is_cls) {
+                const float* tab;
+                if (lane < p.KH) tab = p.rel_h + (int64_t)p.idx_h[qh * p.KH + lane] * p.D;
+                else if (lane < p.KH + p.KW) tab = p.rel_w + (int64_t)p.idx_w[qw * p.KW + (lane - p.KH)] * p.D;
+                else tab = p.rel_t + (int64_t)p.idx_t[qt * p.KT + (lane - p.KH - p.KW)] * p.D;
+                for (int c = 0; c < p.D; ++c) acc += s_q[wave][c] * tab[c];
+            }
+            p.rq[(int64_t)row * R + lane] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// backward of the above: dq[row][c] += sum_j drq[row][j] * table_j[c]  and per-block partial table gradients
+// dtab[r][c] += drq[row][j] * q[row][c] for r = index of table row j.  A block walks its rows in order; thread
+// (group, c) owns channel c of the rel_h rows (group 0) or of the rel_w and rel_t rows (group 1), so every LDS
+// accumulator has exactly one writer and the result is deterministic.  D <= 128.
+#define SF_RELPOS_MAX_TAB (240 * 96)
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_bwd_kernel(RelPosParams p) {
+    __shared__ float s_tab[SF_RELPOS_MAX_TAB];
+    __shared__ float s_dr[64];
+    __shared__ float s_dq[128];
+    const int grp = threadIdx.x >> 7, c = threadIdx.x & 127;
+    const int R = p.KH + p.KW + p.KT;
+    const int TR = p.rows_h + p.rows_w + p.rows_t;
+    for (int i = threadIdx.x; i < TR * p.D; i += SF_THREADS) s_tab[i] = 0.f;
+    const int total = p.B * p.Nq * p.heads;
+    const int r0 = blockIdx.x * p.rows_per_block;
+    int r1 = r0 + p.rows_per_block;
+    if (r1 > total) r1 = total;
+    __syncthreads();
+    for (int row = r0; row < r1; ++row) {
+        uint32_t b, tok, head;
+        int qt, qh, qw;
+        bool is_cls;
+        relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
+        if (is_cls) continue;                       // block-uniform
+        if ((int)threadIdx.x < R) s_dr[threadIdx.x] = p.drq[(int64_t)row * R + threadIdx.x];
+        __syncthreads();
+        const f16* qrow = p.q + ((int64_t)b * p.Nq + tok) * p.ldq + head * p.D;
+        f16* dqrow = p.dq + ((int64_t)b * p.Nq + tok) * p.lddq + head * p.D;
+        float acc = 0.f;
+        if (c < p.D) {
+            const float qv = (float)qrow[c];
+            const int j0 = grp == 0 ? 0 : p.KH, j1 = grp == 0 ? p.KH : R;
+            for (int j = j0; j < j1; ++j) {
+                int r;
+                const float* tab;
+                if (j < p.KH) { r = p.idx_h[qh * p.KH + j]; tab = p.rel_h + (int64_t)r * p.D; }
+                else if (j < p.KH + p.KW) { r = p.idx_w[qw * p.KW + (j - p.KH)]; tab = p.rel_w + (int64_t)r * p.D; r += p.rows_h; }
+                else { r = p.idx_t[qt * p.KT + (j - p.KH - p.KW)]; tab = p.rel_t + (int64_t)r * p.D; r += p.rows_h + p.rows_w; }
+                const float d = s_dr[j];
+                acc += d * tab[c];
+                s_tab[r * p.D + c] += d * qv;
+            }
+            if (grp == 1) s_dq[c] = acc;
+        }
+        __syncthreads();
+        if (grp == 0 && c < p.D) dqrow[c] = (f16)((float)dqrow[c] + acc + s_dq[c]);
+    }
+    __syncthreads();
+    float* o = p.dtab_part + (int64_t)blockIdx.x * TR * p.D;
+    for (int i = threadIdx.x; i < TR * p.D; i += SF_THREADS) o[i] = s_tab[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row softmax of the pooled-attention scores with the rel-pos bias, in place:
+//   P[row][k] = softmax_k( scale * S[row][k] + bias(row, k) ),   bias = rq[row][kh] + rq[row][KH+kw] + rq[row][KH+KW+kt]
+// for non-cls query rows and non-cls keys (attention.py:101-106, 141-145), 0 otherwise.  One wave per row, a row
+// is up to 64*8*NSM keys.  Scores are [B][heads][Nq][lds] fp16 (lds = Nk rounded up to 8; pad columns get 0).
+struct SoftmaxParams {
+    f16* s; int lds;
+    int rows;                       // B*heads*Nq
+    int Nq, Nk, heads;
+    int cls, kT, kH, kW;            // Nk = cls + kT*kH*kW
+    float scale;
+    const float* rq;                // [B*Nq*heads][R] or null (no rel-pos)
+    int R, KH, KW;
+    // backward: s holds dP on entry and scale*dS on exit; p = saved probabilities
+    const f16* prob;
+    float* drq;                     // [B*Nq*heads][R]
+    FastDiv fdNq, fdHeads, fdkW, fdkH;
+};
+
+__device__ __forceinline__ int64_t softmax_rq_row(const SoftmaxParams& p, uint32_t row, bool& q_is_cls) {
+    // score rows are ordered (b, head, q); rq rows are ordered (b, q, head)
+    uint32_t bh, q, b, head;
+    fd_divmod(row, p.fdNq, bh, q);
+    fd_divmod(bh, p.fdHeads, b, head);
+    q_is_cls = p.cls && q == 0;
+    return ((int64_t)b * p.Nq + q) * p.heads + head;
+}
+
+template <int NSM>
+__global__ __launch_bounds__(SF_THREADS) void sf_softmax_fwd_kernel(SoftmaxParams p) {
+    __shared__ float s_rq[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = blockIdx.x * 4; base < p.rows; base += gridDim.x * 4) {
+        const int row = base + wave;
+        const bool rowok = row < p.rows;       // surplus waves of the last pass idle through the barriers
+        bool qcls = true;
+        const bool has_bias = p.rq != nullptr && rowok;
+        if (has_bias) {
+            const int64_t rr = softmax_rq_row(p, (uint32_t)row, qcls);
+            if (lane < p.R) s_rq[wave][lane] = p.rq[rr * p.R + lane];
+        }
+        __syncthreads();
+        f16* srow = p.s + (int64_t)(rowok ? row : 0) * p.lds;
+        float v[NSM][8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NSM; ++s) {
+            const int k0 = (lane + s * 64) * 8;
+            f16x8 h = (rowok && k0 < p.lds) ? ld16(srow + k0) : zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                float x = -INFINITY;
+                if (k < p.Nk) {
+                    x = (float)h[e] * p.scale;
+                    if (has_bias && !qcls && k >= p.cls) {
+                        uint32_t pos = (uint32_t)(k - p.cls), r, kw, kh, kt;
+                        fd_divmod(pos, p.fdkW, r, kw);
+                        fd_divmod(r, p.fdkH, kt, kh);
+                        x += s_rq[wave][kh] + s_rq[wave][p.KH + kw] + s_rq[wave][p.KH + p.KW + kt];
+                    }
+                }
+                v[s][e] = x;
+                mx = x > mx ? x : mx;
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+        mx = fmaxf(mx, __shfl_xor(mx, 8)); mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSM; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ex = v[s][e] == -INFINITY ? 0.f : expf(v[s][e] - mx);
+                v[s][e] = ex;
+                sum += ex;
+            }
+        sum = ln_group_sum<64>(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int s = 0; s < NSM; ++s) {
+            const int k0 = (lane + s * 64) * 8;
+            if (rowok && k0 < p.lds) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)(v[s][e] * inv);
+                st16(srow + k0, o);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dS = P * (dP - sum_k P*dP); writes scale*dS in place over dP and the bias gradients drq (sums of the UNSCALED dS
+// over the keys that share kh / kw / kt).
+template <int NSM>
+__global__ __launch_bounds__(SF_THREADS) void sf_softmax_bwd_kernel(SoftmaxParams p) {
+    __shared__ float s_dr[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = blockIdx.x * 4; base < p.rows; base += gridDim.x * 4) {
+        const int row = base + wave;
+        const bool rowok = row < p.rows;
+        bool qcls = true;
+        const bool has_bias = p.drq != nullptr && rowok;
+        int64_t rr = 0;
+        if (has_bias) rr = softmax_rq_row(p, (uint32_t)row, qcls);
+        s_dr[wave][lane] = 0.f;
+        __syncthreads();
+        f16* drow = p.s + (int64_t)(rowok ? row : 0) * p.lds;
+        const f16* prow = p.prob + (int64_t)(rowok ? row : 0) * p.lds;
+        float pv[NSM][8], dv[NSM][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSM; ++s) {
+            const int k0 = (lane + s * 64) * 8;
+            f16x8 hp = (rowok && k0 < p.lds) ? ld16(prow + k0) : zero8();
+            f16x8 hd = (rowok && k0 < p.lds) ? ld16(drow + k0) : zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = k0 + e < p.Nk;
+                pv[s][e] = ok ? (float)hp[e] : 0.f;
+                dv[s][e] = ok ? (float)hd[e] : 0.f;
+                dot += pv[s][e] * dv[s][e];
+            }
+        }
+        dot = ln_group_sum<64>(dot);
+#pragma unroll
+        for (int s = 0; s < NSM; ++s) {
+            const int k0 = (lane + s * 64) * 8;
+            if (rowok && k0 < p.lds) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ds = pv[s][e] * (dv[s][e] - dot);
+                    o[e] = (f16)(ds * p.scale);
+                    const int k = k0 + e;
+                    if (has_bias && !qcls && k >= p.cls && k < p.Nk) {
+                        uint32_t pos = (uint32_t)(k - p.cls), r, kw, kh, kt;
+                        fd_divmod(pos, p.fdkW, r, kw);
+                        fd_divmod(r, p.fdkH, kt, kh);
+                        atomicAdd(&s_dr[wave][kh], ds);
+                        atomicAdd(&s_dr[wave][p.KH + kw], ds);
+                        atomicAdd(&s_dr[wave][p.KH + p.KW + kt], ds);
+                    }
+                }
+                st16(drow + k0, o);
+            }
+        }
+        __syncthreads();
+        if (has_bias && lane < p.R) p.drq[rr * p.R + lane] = s_dr[wave][lane];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// xt[b][head][c][k] = x[b][k][head*D + c] for k < Nk, 0 for Nk <= k < ldk (K-contiguous operand of a GEMM whose
+// reduction runs over the keys: P.V and dS.K).
+struct TransposeParams {
+    const f16* x; int ldx;
+    f16* xt; int ldk;
+    int B, Nk, heads, D;
+    int64_t total;                  // B*heads*D*(ldk/8)
+    FastDiv fdK8, fdD, fdHeads;
+};
+__global__ __launch_bounds__(SF_THREADS) void sf_transpose_heads_kernel(TransposeParams p) {
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
+         idx += (int64_t)gridDim.x * SF_THREADS) {
+        uint32_t q, k8, c, head, b;
+        fd_divmod((uint32_t)idx, p.fdK8, q, k8);
+        fd_divmod(q, p.fdD, q, c);
+        fd_divmod(q, p.fdHeads, b, head);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = (int)k8 * 8 + e;
+            o[e] = k < p.Nk ? p.x[((int64_t)b * p.Nk + k) * p.ldx + head * p.D + c] : (f16)0;
+        }
+        st16(p.xt + (((int64_t)b * p.heads + head) * p.D + c) * p.ldk + k8 * 8, o);
+    }
+}

@@ -183,6 +183,11 @@ class StemConvUnit(ConvUnit):
         """NCTHW fp32 clip -> the W-pair view (N, 8, T, H, W/2) fp16."""
         return ops.ncthw_to_cl_wpairs(x.float())
 
+    @staticmethod
+    def prepare_shape(shape):
+        N, C, T, H, W = shape
+        return (N, 8, T, H, W // 2)
+
     def geom(self, in_shape):
         key = tuple(in_shape)
         g = self._geoms.get(key)

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvDesc(Structure):
@@ -21,6 +21,21 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in (
         "N", "Ci", "Ti", "Hi", "Wi", "Co", "To", "Ho", "Wo", "kT", "kH", "kW", "sT", "sH", "sW",
         "pT", "pH", "pW", "dT", "dH", "dW", "Cw", "ldx", "ldy")]
+
+
+class DwDesc(Structure):
+    """Mirror of ``sf_dw_desc``."""
+
+    _fields_ = [(n, c_int32) for n in (
+        "N", "C", "Cw", "cls", "Ti", "Hi", "Wi", "To", "Ho", "Wo", "kT", "kH", "kW", "sT", "sH", "sW",
+        "pT", "pH", "pW", "ldx", "ldy")]
+
+
+class AttnDesc(Structure):
+    """Mirror of ``sf_attn_desc``."""
+
+    _fields_ = [(n, c_int32) for n in (
+        "B", "heads", "D", "cls", "Nq", "qT", "qH", "qW", "Nk", "kT", "kH", "kW", "rows_h", "rows_w", "rows_t")]
 
 
 _P = c_void_p
@@ -43,10 +58,34 @@ _SIGNATURES = {
     "sf_bn_bwd_finalize": (c_int, [_F, c_int32, c_int32, c_float, _F, _F, _F, c_float, _F, _F, c_int, _F, _P]),
     "sf_bn_bwd_apply": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, _F, _F, c_int, _F, _P,
                                 c_int32, _P, c_int32, _P]),
-    "sf_pool_fwd": (c_int, [c_int32] * 11 + [_P, c_int32, _F, _F, c_int, _P, c_int32, _P, _P]),
-    "sf_pool_bwd": (c_int, [c_int32] * 11 + [_P, c_int32, _P, c_int, _P, c_int32, _P, c_int32, _P]),
+    "sf_pool_fwd": (c_int, [c_int32] * 11 + [_P, c_int32, _F, _F, c_int, _P, c_int32, _P, c_int32, _P]),
+    "sf_pool_bwd": (c_int, [c_int32] * 11 + [_P, c_int32, _P, c_int, _P, c_int32, _P, c_int32, c_int32, _P]),
     "sf_ncthw_to_cl": (c_int, [_F, c_int32, c_int32, c_int64, c_int32, _P, _P]),
     "sf_cl_to_ncthw": (c_int, [_P, c_int32, c_int32, c_int32, c_int64, _F, _P]),
+    "sf_bgemm": (c_int, [c_int64, c_int32, c_int32, _P, c_int32, _P, c_int32, _F, _P, c_int32, _P, c_int32, c_int32,
+                         c_int32] + [c_int64] * 8 + [c_int32, _P]),
+    "sf_bgemm_tn": (c_int, [c_int64, c_int32, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_float, c_int32, c_int32]
+                    + [c_int64] * 6 + [_P]),
+    "sf_layernorm_fwd": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, c_float, _P, c_int32, _F, _F, _P]),
+    "sf_layernorm_bwd_blocks": (c_int, [c_int64, c_int32]),
+    "sf_layernorm_bwd": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _F, _F, _F, _P, c_int32, _P, c_int32, _F, _P]),
+    "sf_colsum_blocks": (c_int, [c_int64, c_int32]),
+    "sf_colsum": (c_int, [c_int64, c_int32, _P, c_int32, _F, _P]),
+    "sf_colsum_finalize": (c_int, [_F, c_int32, c_int32, c_int32, _F, _F, c_float, c_int, _P]),
+    "sf_rows_sum": (c_int, [_F, c_int32, c_int64, c_int64, c_int32, _F, c_float, c_int, _P]),
+    "sf_gelu_fwd": (c_int, [c_int64, _P, _P, _P]),
+    "sf_gelu_bwd": (c_int, [c_int64, _P, _P, _P, _P]),
+    "sf_dwconv_fwd_blocks": (c_int, [POINTER(DwDesc)]),
+    "sf_dwconv_fwd": (c_int, [POINTER(DwDesc), _P, _F, _P, _F, _P]),
+    "sf_dwconv_dgrad": (c_int, [POINTER(DwDesc), _P, _F, _P, _P]),
+    "sf_dwconv_wgrad_workspace": (c_int64, [POINTER(DwDesc)]),
+    "sf_dwconv_wgrad": (c_int, [POINTER(DwDesc), _P, _P, _F, c_float, c_int, _P, c_int64, _P]),
+    "sf_relpos_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _F, _F, _F, _P, _P, _P, _F, _P]),
+    "sf_relpos_bwd_blocks": (c_int, [POINTER(AttnDesc)]),
+    "sf_relpos_bwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _F, _F, _F, _P, _P, _P, _F, _P, c_int32, _F, _P]),
+    "sf_softmax_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, c_float, _F, _P]),
+    "sf_softmax_bwd": (c_int, [POINTER(AttnDesc), _P, _P, c_int32, c_float, _F, _P]),
+    "sf_transpose_heads": (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1,0 +1,309 @@
+"""MViT drop-ins: ``PatchEmbed``, ``Mlp``, ``MultiScaleAttention``, ``MultiScaleBlock``, ``TransformerBasicHead`` and
+the ``MViT`` model builder with the reference's constructor signatures, cfg keys and state_dict names
+(slowfast/models/attention.py:150-514, common.py:7-34, stem_helper.py:288-320, head_helper.py:491-563,
+video_model_builder.py:805-1244), executed by the token-space engine (mvit_engine.py).
+
+Scope of this path (the MViTv2 configuration family of configs/Kinetics/MVITv2_*.yaml): MODE "conv", fused qkv,
+POOL_FIRST False, cls token on, decomposed relative positions, residual pooling, DIM_MUL_IN_ATT, no absolute
+position embedding.  Options outside it raise NotImplementedError instead of silently running something else.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+from torch.nn.init import trunc_normal_
+
+from .engine import StemConvUnit
+from .mvit_engine import AttentionPlan, ClsNormFn, LinearUnit, MultiScaleBlockFn, NormUnit, PatchEmbedFn
+from .registry import MODEL_REGISTRY
+
+
+def round_width(width, multiplier, min_width=1, divisor=1):
+    """slowfast/models/utils.py:10-23."""
+    if not multiplier:
+        return width
+    width *= multiplier
+    min_width = min_width or divisor
+    width_out = max(min_width, int(width + divisor / 2) // divisor * divisor)
+    if width_out < 0.9 * width:
+        width_out += divisor
+    return int(width_out)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, dim_in=3, dim_out=768, kernel=(1, 16, 16), stride=(1, 4, 4), padding=(1, 7, 7), conv_2d=False):
+        super().__init__()
+        if conv_2d:
+            raise NotImplementedError("2-D patch embedding (image models) is outside the video hot path")
+        self.proj = nn.Conv3d(dim_in, dim_out, kernel_size=tuple(kernel), stride=tuple(stride), padding=tuple(padding))
+        self._unit = StemConvUnit(self.proj, None)
+
+    def forward(self, x, cls_token=None):
+        """(B, 3, T, H, W) fp32 clip -> tokens (B, [1 +] T'H'W', C) fp16 and the (B, C, T', H', W') shape."""
+        out = PatchEmbedFn.apply(x, self, cls_token, self.proj.weight, self.proj.bias)
+        g = self._unit.geom(self._unit.prepare_shape(x.shape))
+        return out, (x.shape[0], self.proj.out_channels, g.To, g.Ho, g.Wo)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop_rate=0.0):
+        super().__init__()
+        if drop_rate > 0.0:
+            raise NotImplementedError("Mlp dropout (MVIT.DROPOUT_RATE > 0) is not on the built path")
+        if act_layer is not nn.GELU:
+            raise NotImplementedError("Mlp activation other than nn.GELU")
+        self.drop_rate = drop_rate
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self._fc1, self._fc2 = LinearUnit(self.fc1), LinearUnit(self.fc2)
+
+
+class MultiScaleAttention(nn.Module):
+    def __init__(self, dim, dim_out, input_size, num_heads=8, qkv_bias=False, drop_rate=0.0, kernel_q=(1, 1, 1),
+                 kernel_kv=(1, 1, 1), stride_q=(1, 1, 1), stride_kv=(1, 1, 1), norm_layer=nn.LayerNorm,
+                 has_cls_embed=True, mode="conv", pool_first=False, rel_pos_spatial=False, rel_pos_temporal=False,
+                 rel_pos_zero_init=False, residual_pooling=False, separate_qkv=False):
+        super().__init__()
+        if pool_first or separate_qkv or mode != "conv" or drop_rate > 0.0:
+            raise NotImplementedError("MultiScaleAttention: only mode='conv', fused qkv, pool_first=False, no dropout")
+        if len(kernel_q) == 0 or len(kernel_kv) == 0 or math.prod(kernel_q) == 1 or math.prod(kernel_kv) == 1:
+            raise NotImplementedError("MultiScaleAttention without q / kv pooling convs (MViTv1 blocks)")
+        self.pool_first, self.separate_qkv, self.drop_rate = pool_first, separate_qkv, drop_rate
+        self.num_heads, self.dim_out = num_heads, dim_out
+        head_dim = dim_out // num_heads
+        self.scale = head_dim ** -0.5
+        self.has_cls_embed, self.mode = has_cls_embed, mode
+        pad_q, pad_kv = [int(q // 2) for q in kernel_q], [int(kv // 2) for kv in kernel_kv]
+        self.qkv = nn.Linear(dim, dim_out * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim_out, dim_out)
+        conv = partial(nn.Conv3d, head_dim, head_dim, groups=head_dim, bias=False)
+        self.pool_q = conv(tuple(kernel_q), stride=tuple(stride_q), padding=tuple(pad_q))
+        self.norm_q = norm_layer(head_dim)
+        self.pool_k = conv(tuple(kernel_kv), stride=tuple(stride_kv), padding=tuple(pad_kv))
+        self.norm_k = norm_layer(head_dim)
+        self.pool_v = conv(tuple(kernel_kv), stride=tuple(stride_kv), padding=tuple(pad_kv))
+        self.norm_v = norm_layer(head_dim)
+        self.rel_pos_spatial, self.rel_pos_temporal = rel_pos_spatial, rel_pos_temporal
+        if rel_pos_spatial:
+            assert input_size[1] == input_size[2]
+            size = input_size[1]
+            q_size = size // stride_q[1] if len(stride_q) > 0 else size
+            kv_size = size // stride_kv[1] if len(stride_kv) > 0 else size
+            rel_sp_dim = 2 * max(q_size, kv_size) - 1
+            self.rel_pos_h = nn.Parameter(torch.zeros(rel_sp_dim, head_dim))
+            self.rel_pos_w = nn.Parameter(torch.zeros(rel_sp_dim, head_dim))
+            if not rel_pos_zero_init:
+                trunc_normal_(self.rel_pos_h, std=0.02)
+                trunc_normal_(self.rel_pos_w, std=0.02)
+        if rel_pos_temporal:
+            self.rel_pos_t = nn.Parameter(torch.zeros(2 * input_size[0] - 1, head_dim))
+            if not rel_pos_zero_init:
+                trunc_normal_(self.rel_pos_t, std=0.02)
+        self.residual_pooling = residual_pooling
+        self._qkv, self._proj = LinearUnit(self.qkv), LinearUnit(self.proj)
+        self._norm_q, self._norm_k, self._norm_v = NormUnit(self.norm_q), NormUnit(self.norm_k), NormUnit(self.norm_v)
+
+
+class MultiScaleBlock(nn.Module):
+    def __init__(self, dim, dim_out, num_heads, input_size, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop_rate=0.0,
+                 drop_path=0.0, layer_scale_init_value=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm, up_rate=None,
+                 kernel_q=(1, 1, 1), kernel_kv=(1, 1, 1), stride_q=(1, 1, 1), stride_kv=(1, 1, 1), mode="conv",
+                 has_cls_embed=True, pool_first=False, rel_pos_spatial=False, rel_pos_temporal=False,
+                 rel_pos_zero_init=False, residual_pooling=False, dim_mul_in_att=False, separate_qkv=False):
+        super().__init__()
+        if not dim_mul_in_att and dim != dim_out:
+            raise NotImplementedError("dimension change after the Mlp (DIM_MUL_IN_ATT False, MViTv1)")
+        if layer_scale_init_value > 0 or (up_rate is not None and up_rate > 1):
+            raise NotImplementedError("layer scale / up_rate")
+        self.dim, self.dim_out = dim, dim_out
+        self.norm1 = norm_layer(dim)
+        self.dim_mul_in_att = dim_mul_in_att
+        kernel_skip = [s + 1 if s > 1 else s for s in stride_q]
+        stride_skip = stride_q
+        padding_skip = [int(skip // 2) for skip in kernel_skip]
+        att_dim = dim_out if dim_mul_in_att else dim
+        self.attn = MultiScaleAttention(
+            dim, att_dim, num_heads=num_heads, input_size=input_size, qkv_bias=qkv_bias, drop_rate=drop_rate,
+            kernel_q=kernel_q, kernel_kv=kernel_kv, stride_q=stride_q, stride_kv=stride_kv, norm_layer=norm_layer,
+            has_cls_embed=has_cls_embed, mode=mode, pool_first=pool_first, rel_pos_spatial=rel_pos_spatial,
+            rel_pos_temporal=rel_pos_temporal, rel_pos_zero_init=rel_pos_zero_init, residual_pooling=residual_pooling,
+            separate_qkv=separate_qkv)
+        self.drop_path_rate = drop_path
+        self.drop_path = nn.Identity()          # stochastic depth: see forward()
+        self.norm2 = norm_layer(att_dim)
+        self.has_cls_embed = has_cls_embed
+        self.mlp = Mlp(in_features=att_dim, hidden_features=int(att_dim * mlp_ratio), out_features=dim_out,
+                       act_layer=act_layer, drop_rate=drop_rate)
+        self.gamma_1, self.gamma_2 = None, None
+        self._proj = None
+        if dim != dim_out:
+            self.proj = nn.Linear(dim, dim_out)
+            self._proj = LinearUnit(self.proj)
+        self.pool_skip = (nn.MaxPool3d(kernel_skip, stride_skip, padding_skip, ceil_mode=False)
+                          if len(stride_skip) > 0 and math.prod(stride_skip) > 1 else None)
+        self._norm1, self._norm2 = NormUnit(self.norm1), NormUnit(self.norm2)
+        self._plans = {}
+
+    def _plan(self, B, thw, device):
+        key = (B, tuple(thw), str(device))
+        p = self._plans.get(key)
+        if p is None:
+            p = self._plans[key] = AttentionPlan(self.attn, B, thw, device)
+        return p
+
+    @property
+    def _param_list(self):
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self.__dict__["_plist"] = list(self.parameters())
+        return plist
+
+    def forward(self, x, thw_shape=None):
+        if self.training and self.drop_path_rate > 0.0:
+            raise NotImplementedError("stochastic depth (MVIT.DROPPATH_RATE > 0) is not on the built path yet; "
+                                      "set MVIT.DROPPATH_RATE 0.0")
+        out = MultiScaleBlockFn.apply(x, self, tuple(thw_shape), *self._param_list)
+        return out, list(self._plan(x.shape[0], thw_shape, x.device).q_thw)
+
+
+class TransformerBasicHead(nn.Module):
+    """Dropout -> Linear on the (B, C) cls features, fp32 torch ops (< 1 MMAC; head_helper.py:491-563)."""
+
+    def __init__(self, dim_in, num_classes, dropout_rate=0.0, act_func="softmax", cfg=None):
+        super().__init__()
+        if dropout_rate > 0.0:
+            self.dropout = nn.Dropout(dropout_rate)
+        assert cfg is None or cfg.CONTRASTIVE.NUM_MLP_LAYERS == 1, "MLP heads belong to the SSL models (out of scope)"
+        self.projection = nn.Linear(dim_in, num_classes, bias=True)
+        self.detach_final_fc = cfg.MODEL.DETACH_FINAL_FC if cfg is not None else False
+        if act_func == "softmax":
+            self.act = nn.Softmax(dim=1)
+        elif act_func == "sigmoid":
+            self.act = nn.Sigmoid()
+        elif act_func == "none":
+            self.act = None
+        else:
+            raise NotImplementedError(f"{act_func} is not supported as an activationfunction.")
+
+    def forward(self, x):
+        x = x.float()
+        if hasattr(self, "dropout"):
+            x = self.dropout(x)
+        if self.detach_final_fc:
+            x = x.detach()
+        x = self.projection(x)
+        if not self.training and self.act is not None:
+            x = self.act(x)
+        return x.view(x.shape[0], -1)
+
+
+@MODEL_REGISTRY.register()
+class MViT(nn.Module):
+    """MViTv2 video transformer; forward(x=[clip NCTHW]) -> logits (B, num_classes)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        assert cfg.DATA.TRAIN_CROP_SIZE == cfg.DATA.TEST_CROP_SIZE
+        m = cfg.MVIT
+        unsupported = [k for k, bad in (
+            ("POOL_FIRST", m.POOL_FIRST), ("PATCH_2D", m.PATCH_2D), ("REV.ENABLE", m.REV.ENABLE),
+            ("USE_ABS_POS", m.USE_ABS_POS), ("USE_FIXED_SINCOS_POS", m.USE_FIXED_SINCOS_POS), ("NORM_STEM", m.NORM_STEM),
+            ("SEPARATE_QKV", m.SEPARATE_QKV), ("USE_MEAN_POOLING", m.USE_MEAN_POOLING),
+            ("not CLS_EMBED_ON", not m.CLS_EMBED_ON), ("not DIM_MUL_IN_ATT", not m.DIM_MUL_IN_ATT),
+            ("DETECTION.ENABLE", cfg.DETECTION.ENABLE), ("MODEL.ACT_CHECKPOINT", cfg.MODEL.ACT_CHECKPOINT)) if bad]
+        if unsupported or m.NORM != "layernorm" or m.MODE != "conv" or m.POOL_KVQ_KERNEL is None:
+            raise NotImplementedError(f"MViT options outside the MViTv2 hot path: {unsupported}")
+        self.cfg = cfg
+        self.enable_detection, self.enable_rev = False, False
+        self.patch_stride = list(m.PATCH_STRIDE)
+        self.T = cfg.DATA.NUM_FRAMES // self.patch_stride[0]
+        self.H = cfg.DATA.TRAIN_CROP_SIZE // self.patch_stride[1]
+        self.W = cfg.DATA.TRAIN_CROP_SIZE // self.patch_stride[2]
+        embed_dim, num_heads, depth = m.EMBED_DIM, m.NUM_HEADS, m.DEPTH
+        self.drop_rate = m.DROPOUT_RATE
+        self.cls_embed_on, self.use_mean_pooling = True, False
+        self.use_abs_pos, self.rel_pos_spatial, self.rel_pos_temporal = False, m.REL_POS_SPATIAL, m.REL_POS_TEMPORAL
+        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        self.num_classes = cfg.MODEL.NUM_CLASSES
+        self.patch_embed = PatchEmbed(dim_in=cfg.DATA.INPUT_CHANNEL_NUM[0], dim_out=embed_dim, kernel=m.PATCH_KERNEL,
+                                      stride=m.PATCH_STRIDE, padding=m.PATCH_PADDING)
+        self.input_dims = [cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE, cfg.DATA.TRAIN_CROP_SIZE]
+        self.patch_dims = [self.input_dims[i] // self.patch_stride[i] for i in range(3)]
+        dpr = [x.item() for x in torch.linspace(0, m.DROPPATH_RATE, depth)]
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        dim_mul, head_mul = torch.ones(depth + 1), torch.ones(depth + 1)
+        for i, v in m.DIM_MUL:
+            dim_mul[i] = v
+        for i, v in m.HEAD_MUL:
+            head_mul[i] = v
+        pool_q, pool_kv = [[] for _ in range(depth)], [[] for _ in range(depth)]
+        stride_q, stride_kv = [[] for _ in range(depth)], [[] for _ in range(depth)]
+        for e in m.POOL_Q_STRIDE:
+            stride_q[e[0]] = list(e[1:])
+            pool_q[e[0]] = list(m.POOL_KVQ_KERNEL)
+        kv_list = m.POOL_KV_STRIDE
+        if m.POOL_KV_STRIDE_ADAPTIVE is not None:
+            _kv = list(m.POOL_KV_STRIDE_ADAPTIVE)
+            kv_list = []
+            for i in range(depth):
+                if len(stride_q[i]) > 0:
+                    _kv = [max(_kv[d] // stride_q[i][d], 1) for d in range(3)]
+                kv_list.append([i] + _kv)
+        for e in kv_list:
+            stride_kv[e[0]] = list(e[1:])
+            pool_kv[e[0]] = list(m.POOL_KVQ_KERNEL)
+        self.pool_q, self.pool_kv, self.stride_q, self.stride_kv = pool_q, pool_kv, stride_q, stride_kv
+        self.norm_stem = None
+        input_size = self.patch_dims
+        self.blocks = nn.ModuleList()
+        for i in range(depth):
+            num_heads = round_width(num_heads, head_mul[i])
+            dim_out = round_width(embed_dim, dim_mul[i], divisor=round_width(num_heads, head_mul[i]))
+            self.blocks.append(MultiScaleBlock(
+                dim=embed_dim, dim_out=dim_out, num_heads=num_heads, input_size=input_size, mlp_ratio=m.MLP_RATIO,
+                qkv_bias=m.QKV_BIAS, drop_rate=self.drop_rate, drop_path=dpr[i], norm_layer=norm_layer,
+                kernel_q=pool_q[i], kernel_kv=pool_kv[i], stride_q=stride_q[i], stride_kv=stride_kv[i], mode=m.MODE,
+                has_cls_embed=True, pool_first=False, rel_pos_spatial=self.rel_pos_spatial,
+                rel_pos_temporal=self.rel_pos_temporal, rel_pos_zero_init=m.REL_POS_ZERO_INIT,
+                residual_pooling=m.RESIDUAL_POOLING, dim_mul_in_att=True, separate_qkv=False))
+            if len(stride_q[i]) > 0:
+                input_size = [size // stride for size, stride in zip(input_size, stride_q[i])]
+            embed_dim = dim_out
+        self.norm = norm_layer(embed_dim)
+        self._norm_unit = NormUnit(self.norm)
+        self.head = TransformerBasicHead(embed_dim, self.num_classes, dropout_rate=cfg.MODEL.DROPOUT_RATE,
+                                         act_func=cfg.MODEL.HEAD_ACT, cfg=cfg)
+        trunc_normal_(self.cls_token, std=0.02)
+        self.apply(self._init_weights)
+        self.head.projection.weight.data.mul_(m.HEAD_INIT_SCALE)
+        self.head.projection.bias.data.mul_(m.HEAD_INIT_SCALE)
+
+    def _init_weights(self, m):
+        """video_model_builder.py:1085-1092."""
+        if isinstance(m, (nn.Linear, nn.Conv2d, nn.Conv3d)):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                nn.init.constant_(m.bias, 0.02)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0.02)
+            nn.init.constant_(m.weight, 1.0)
+
+    def no_weight_decay(self):
+        names = []
+        if self.cfg.MVIT.ZERO_DECAY_POS_CLS:
+            names += ["rel_pos_h", "rel_pos_w", "rel_pos_hw", "rel_pos_t", "cls_token"]
+        return names
+
+    def forward(self, x, bboxes=None, return_attn=False):
+        x, bcthw = self.patch_embed(x[0], self.cls_token)
+        T, H, W = bcthw[-3], bcthw[-2], bcthw[-1]
+        assert (T, H, W) == (self.T, self.H, self.W), bcthw
+        thw = [T, H, W]
+        for blk in self.blocks:
+            x, thw = blk(x, thw)
+        x = ClsNormFn.apply(x, self, self.norm.weight, self.norm.bias)
+        return self.head(x)

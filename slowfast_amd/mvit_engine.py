@@ -1,0 +1,312 @@
+"""Forward/backward schedules of the MViT path on the token-space kernels (tokens.py).
+
+One ``torch.autograd.Function`` per reference block: PatchEmbed (+ cls token), MultiScaleBlock (LayerNorm ->
+pooled attention with relative positions and residual pooling -> skip pool / projection -> LayerNorm -> Mlp) and
+the final LayerNorm on the cls rows.  Inside a Function nothing goes through ATen math or the autograd tape except
+tiny parameter reshuffles; parameter gradients are written straight into ``param.grad`` (fp32) and announced to
+``grad_ready`` listeners like the ResNet engine does.
+
+Reference graph: slowfast/models/attention.py:293-392 (MultiScaleAttention.forward), :491-514
+(MultiScaleBlock.forward), :13-45 (attention_pool), :64-147 (relative positions), common.py:25-34 (Mlp.forward),
+stem_helper.py:315-320 (PatchEmbed.forward), video_model_builder.py:1166-1244 (MViT.forward).
+"""
+import math
+
+import torch
+
+from . import engine, tokens
+from .engine import _grad_dest, _notify
+
+_f16 = torch.float16
+
+
+class LinearUnit:
+    """nn.Linear parameter container bound to the GEMM kernels: fp16 operand caches + gradient writes."""
+
+    def __init__(self, lin):
+        self.lin = lin
+        self._key, self._w, self._wt = None, None, None
+
+    def _ops(self, fresh=False):
+        w = self.lin.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if (fresh and engine.FORCE_WEIGHT_PREP) or self._key != key:
+            wd = w.detach()
+            self._w = wd.to(_f16)                      # [N, K]  forward operand
+            self._wt = wd.t().contiguous().to(_f16)    # [K, N]  data-gradient operand
+            self._key = key
+        return self._w, self._wt
+
+    def forward(self, x, resid=None, out=None):
+        w, _ = self._ops(fresh=True)
+        return tokens.gemm(x, w, bias=self.lin.bias, resid=resid, out=out)
+
+    def backward(self, x, dy, need_dx=True, resid=None, out=None):
+        """weight/bias gradients into .grad; returns dx (+ resid)."""
+        lin = self.lin
+        if lin.weight.requires_grad:
+            dw, zero_first = _grad_dest(lin.weight)
+            tokens.linear_wgrad(x, dy, dw, zero_first=zero_first)
+        if lin.bias is not None and lin.bias.requires_grad:
+            db, zero_first = _grad_dest(lin.bias)
+            tokens.bias_grad(dy, db, accumulate=not zero_first)
+        if not need_dx:
+            return None
+        _, wt = self._ops()
+        return tokens.gemm(dy, wt, resid=resid, out=out)
+
+    def params(self):
+        return [p for p in (self.lin.weight, self.lin.bias) if p is not None]
+
+
+class NormUnit:
+    """nn.LayerNorm parameter container bound to the LayerNorm kernels."""
+
+    def __init__(self, ln):
+        self.ln = ln
+
+    def forward(self, x):
+        return tokens.layernorm_fwd(x, self.ln.weight, self.ln.bias, self.ln.eps)
+
+    def backward(self, dy, x, mean, rstd, resid=None):
+        ln = self.ln
+        dg, zg = _grad_dest(ln.weight)
+        db, zb = _grad_dest(ln.bias)
+        assert zg == zb
+        return tokens.layernorm_bwd(dy, x, ln.weight, mean, rstd, dg, db, resid=resid, accumulate=not zg)
+
+    def params(self):
+        return [self.ln.weight, self.ln.bias]
+
+
+def _rel_index(q_size, k_size, device):
+    """dist table of cal_rel_pos_spatial / cal_rel_pos_temporal (attention.py:76-88, 123-130) as int32."""
+    q_ratio = max(k_size / q_size, 1.0)
+    k_ratio = max(q_size / k_size, 1.0)
+    dist = torch.arange(q_size)[:, None] * q_ratio - torch.arange(k_size)[None, :] * k_ratio
+    dist += (k_size - 1) * k_ratio
+    return dist.long().to(torch.int32).contiguous().to(device)
+
+
+class AttentionPlan:
+    """Shapes and cached index tables of one MultiScaleAttention call at a given (B, thw)."""
+
+    def __init__(self, att, B, thw, device):
+        self.B, self.thw = B, tuple(thw)
+        self.heads, self.att = att.num_heads, att.dim_out
+        self.D = self.att // self.heads
+        cls = att.has_cls_embed
+        self.cls = int(cls)
+        C = self.att
+        kq, sq = tuple(att.pool_q.kernel_size), tuple(att.pool_q.stride)
+        kk, sk = tuple(att.pool_k.kernel_size), tuple(att.pool_k.stride)
+        pq, pk = tuple(att.pool_q.padding), tuple(att.pool_k.padding)
+        self.gq = tokens.DwGeom(B, C, self.D, thw, kq, sq, pq, cls)
+        self.gk = tokens.DwGeom(B, C, self.D, thw, kk, sk, pk, cls)
+        self.q_thw, self.k_thw = self.gq.out_thw, self.gk.out_thw
+        self.Nq = self.cls + math.prod(self.q_thw)
+        self.Nk = self.cls + math.prod(self.k_thw)
+        self.lds = (self.Nk + 7) // 8 * 8
+        self.rel = att.rel_pos_spatial and att.rel_pos_temporal
+        assert att.rel_pos_spatial == att.rel_pos_temporal, "spatial and temporal rel-pos are used together (MViTv2)"
+        rows = (att.rel_pos_h.shape[0], att.rel_pos_w.shape[0], att.rel_pos_t.shape[0]) if self.rel else (0, 0, 0)
+        self.desc = tokens.attn_desc(B, self.heads, self.D, cls, self.q_thw, self.k_thw, *rows)
+        self.idx = None
+        if self.rel:
+            (qt, qh, qw), (kt, kh, kw) = self.q_thw, self.k_thw
+            assert rows == (2 * max(qh, kh) - 1, 2 * max(qw, kw) - 1, 2 * max(qt, kt) - 1), \
+                "rel-pos tables are used at their constructed size (no interpolation on this path)"
+            self.idx = (_rel_index(qh, kh, device), _rel_index(qw, kw, device), _rel_index(qt, kt, device))
+
+
+def attention_forward(att, plan, qkv):
+    """qkv [B, N, 3*att] -> (o [B, Nq, att], saved tensors).  attention.py:318-385."""
+    B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
+    Nq, Nk, lds = plan.Nq, plan.Nk, plan.lds
+    q_in, k_in, v_in = qkv[..., 0:C], qkv[..., C:2 * C], qkv[..., 2 * C:3 * C]
+    qp = tokens.dwconv_fwd(q_in, att.pool_q.weight, plan.gq).view(B, Nq, C)
+    kp = tokens.dwconv_fwd(k_in, att.pool_k.weight, plan.gk).view(B, Nk, C)
+    vp = tokens.dwconv_fwd(v_in, att.pool_v.weight, plan.gk).view(B, Nk, C)
+    qn, mq, rq_ = att._norm_q.forward(qp.view(B * Nq * heads, D))
+    kn, mk, rk_ = att._norm_k.forward(kp.view(B * Nk * heads, D))
+    vn, mv, rv_ = att._norm_v.forward(vp.view(B * Nk * heads, D))
+    qn, kn, vn = qn.view(B, Nq, C), kn.view(B, Nk, C), vn.view(B, Nk, C)
+    tables = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t) if plan.rel else None
+    rq = tokens.relpos_fwd(plan.desc, qn, tables, plan.idx) if plan.rel else None
+    S = torch.empty((B, heads, Nq, lds), dtype=_f16, device=qkv.device)
+    tokens.bgemm_heads(qn, (Nq * C, D), Nq, D, C, kn, (Nk * C, D), Nk, C, S, (heads * Nq * lds, Nq * lds), lds, B, heads)
+    P = tokens.softmax_fwd(plan.desc, S, att.scale, rq)
+    vt = tokens.transpose_heads(vn, B, Nk, heads, D, lds)
+    o = torch.empty((B, Nq, C), dtype=_f16, device=qkv.device)
+    resid = qn if att.residual_pooling else None
+    tokens.bgemm_heads(P, (heads * Nq * lds, Nq * lds), Nq, lds, lds, vt, (heads * D * lds, D * lds), D, lds,
+                       o, (Nq * C, D), C, B, heads, resid=resid, r_strides=(Nq * C, D), ldr=C, resid_row0=plan.cls)
+    saved = dict(qp=qp, kp=kp, vp=vp, qn=qn, kn=kn, vn=vn, sq=(mq, rq_), sk=(mk, rk_), sv=(mv, rv_), P=P)
+    return o, saved
+
+
+def attention_backward(att, plan, qkv, sv, do):
+    """d(o) -> d(qkv) [B, N, 3*att]; writes the gradients of pool_{q,k,v}, norm_{q,k,v}, rel_pos_{h,w,t}."""
+    B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
+    Nq, Nk, lds = plan.Nq, plan.Nk, plan.lds
+    qn, kn, vn, P = sv["qn"], sv["kn"], sv["vn"], sv["P"]
+    dev = do.device
+    # dP = dO V^T ; dV = P^T dO
+    dP = torch.empty((B, heads, Nq, lds), dtype=_f16, device=dev)
+    tokens.bgemm_heads(do, (Nq * C, D), Nq, D, C, vn, (Nk * C, D), Nk, C, dP, (heads * Nq * lds, Nq * lds), lds, B, heads)
+    dvn = torch.empty((B, Nk, C), dtype=_f16, device=dev)
+    tokens.bgemm_tn_heads(P, (heads * Nq * lds, Nq * lds), lds, do, (Nq * C, D), C, Nq, Nk, D, dvn, (Nk * C, D), C,
+                          B, heads)
+    dS, drq = tokens.softmax_bwd(plan.desc, dP, P, att.scale, want_drq=plan.rel)      # dS already carries `scale`
+    # dQ = dS K (+ dO on the non-cls rows: residual pooling) ; dK = dS^T Q
+    kt = tokens.transpose_heads(kn, B, Nk, heads, D, lds)
+    dqn = torch.empty((B, Nq, C), dtype=_f16, device=dev)
+    resid = do if att.residual_pooling else None
+    tokens.bgemm_heads(dS, (heads * Nq * lds, Nq * lds), Nq, lds, lds, kt, (heads * D * lds, D * lds), D, lds,
+                       dqn, (Nq * C, D), C, B, heads, resid=resid, r_strides=(Nq * C, D), ldr=C, resid_row0=plan.cls)
+    dkn = torch.empty((B, Nk, C), dtype=_f16, device=dev)
+    tokens.bgemm_tn_heads(dS, (heads * Nq * lds, Nq * lds), lds, qn, (Nq * C, D), C, Nq, Nk, D, dkn, (Nk * C, D), C,
+                          B, heads)
+    if plan.rel:
+        tabs = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t)
+        dests = [_grad_dest(t) for t in tabs]
+        tokens.relpos_bwd(plan.desc, qn, tabs, plan.idx, drq, dqn, [d[0] for d in dests], [not d[1] for d in dests])
+    # LayerNorm(head_dim) backward
+    dqp = att._norm_q.backward(dqn.view(-1, D), sv["qp"].view(-1, D), *sv["sq"]).view(B, Nq, C)
+    dkp = att._norm_k.backward(dkn.view(-1, D), sv["kp"].view(-1, D), *sv["sk"]).view(B, Nk, C)
+    dvp = att._norm_v.backward(dvn.view(-1, D), sv["vp"].view(-1, D), *sv["sv"]).view(B, Nk, C)
+    # depthwise pooling backward into the three slices of d(qkv)
+    dqkv = torch.empty(qkv.shape, dtype=_f16, device=dev)
+    for i, (dy, pool, geom) in enumerate(((dqp, att.pool_q, plan.gq), (dkp, att.pool_k, plan.gk), (dvp, att.pool_v, plan.gk))):
+        x_in = qkv[..., i * C:(i + 1) * C]
+        tokens.dwconv_dgrad(dy.view(-1, C), pool.weight, geom, out=dqkv[..., i * C:(i + 1) * C])
+        dw, zero_first = _grad_dest(pool.weight)
+        tokens.dwconv_wgrad(x_in, dy.view(-1, C), geom, dw, zero_first=zero_first)
+    return dqkv
+
+
+class MultiScaleBlockFn(torch.autograd.Function):
+    """MultiScaleBlock.forward (attention.py:491-514) for DIM_MUL_IN_ATT, conv pooling, cls token."""
+
+    @staticmethod
+    def forward(ctx, x, mod, thw, *params):
+        att = mod.attn
+        B, N, dim = x.shape
+        plan = mod._plan(B, thw, x.device)
+        xn, m1, r1 = mod._norm1.forward(x)
+        qkv = att._qkv.forward(xn)
+        o, sv = attention_forward(att, plan, qkv)
+        if mod._proj is not None:
+            xs = mod._proj.forward(xn)                     # dim change on the normed input (attention.py:494-495)
+        else:
+            xs = x
+        pool = None
+        if mod.pool_skip is not None:
+            k, s, p = mod.pool_skip.kernel_size, mod.pool_skip.stride, mod.pool_skip.padding
+            xres, arg, _ = tokens.token_pool_fwd(xs, B, thw, k, s, p, cls=mod.has_cls_embed)
+            pool = (k, s, p, arg, xres)
+        else:
+            xres = xs
+        x1 = att._proj.forward(o, resid=xres)              # x_res + attention output
+        xn2, m2, r2 = mod._norm2.forward(x1)
+        h = mod.mlp._fc1.forward(xn2)
+        a = tokens.gelu_fwd(h)
+        out = mod.mlp._fc2.forward(a, resid=x1)
+        ctx.mod, ctx.plan, ctx.thw = mod, plan, tuple(thw)
+        ctx.sv = dict(x=x, xn=xn, s1=(m1, r1), qkv=qkv, att=sv, o=o, pool=pool, x1=x1, xn2=xn2, s2=(m2, r2), h=h, a=a)
+        ctx.out_thw = plan.q_thw
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod, plan, sv = ctx.mod, ctx.plan, ctx.sv
+        att = mod.attn
+        B = plan.B
+        dout = dout.contiguous() if dout.dtype == _f16 else dout.to(_f16).contiguous()
+        # Mlp
+        da = mod.mlp._fc2.backward(sv["a"], dout)
+        dh = tokens.gelu_bwd(sv["h"], da)
+        dxn2 = mod.mlp._fc1.backward(sv["xn2"], dh)
+        dx1 = mod._norm2.backward(dxn2, sv["x1"], *sv["s2"], resid=dout)
+        # attention output projection, attention core, qkv projection
+        do = att._proj.backward(sv["o"], dx1)
+        dqkv = attention_backward(att, plan, sv["qkv"], sv["att"], do)
+        dxn = att._qkv.backward(sv["xn"], dqkv)
+        # skip path
+        dxs = dx1
+        if sv["pool"] is not None:
+            k, s, p, arg, xres = sv["pool"]
+            dxs = tokens.token_pool_bwd(dx1, xres, arg, B, ctx.thw, k, s, p, xres.shape[-1], cls=mod.has_cls_embed)
+        if mod._proj is not None:
+            dxn = mod._proj.backward(sv["xn"], dxs, resid=dxn)
+            dx_skip = None
+        else:
+            dx_skip = dxs
+        dx = mod._norm1.backward(dxn, sv["x"], *sv["s1"], resid=dx_skip)
+        _notify(mod._param_list)
+        ctx.sv = None
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """PatchEmbed conv (+bias) -> tokens, with the cls token prepended (stem_helper.py:315-320,
+    video_model_builder.py:1180-1186)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, cls_token, *params):
+        unit = mod._unit
+        xcl = unit.prepare_input(x)
+        y, _ = unit.forward(xcl, None, mod.training)            # (B, C, T, H, W) channels-last == (B, THW, C) rows
+        B, C, T, H, W = y.shape
+        tok = y.permute(0, 2, 3, 4, 1).reshape(B, T * H * W, C)
+        if cls_token is not None:
+            out = torch.empty((B, 1 + T * H * W, C), dtype=_f16, device=y.device)
+            out[:, 0] = cls_token.detach().view(1, C).to(_f16)
+            out[:, 1:] = tok
+        else:
+            out = tok
+        ctx.mod, ctx.xcl, ctx.cls, ctx.yshape = mod, xcl, cls_token, tuple(y.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod, cls_token = ctx.mod, ctx.cls
+        unit = mod._unit
+        B, C, T, H, W = ctx.yshape
+        dout = dout.to(_f16)
+        if cls_token is not None:
+            if cls_token.requires_grad:
+                g, zero_first = _grad_dest(cls_token)
+                s = dout[:, 0].float().sum(0).view_as(g)
+                g.copy_(s) if zero_first else g.add_(s)
+            dtok = dout[:, 1:].contiguous()
+        else:
+            dtok = dout.contiguous()
+        dy = dtok.view(B, T, H, W, C).permute(0, 4, 1, 2, 3)
+        unit.backward(ctx.xcl, None, dy, need_dx=False)
+        if unit.conv.bias is not None and unit.conv.bias.requires_grad:
+            db, zero_first = _grad_dest(unit.conv.bias)
+            tokens.bias_grad(dtok.view(-1, C), db, accumulate=not zero_first)
+        _notify(unit.params() + ([cls_token] if cls_token is not None else []))
+        ctx.xcl = None
+        return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class ClsNormFn(torch.autograd.Function):
+    """Final LayerNorm on the cls rows only: norm(x)[:, 0] == norm(x[:, 0]) (video_model_builder.py:1236-1238)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        unit = mod._norm_unit
+        xc = x[:, 0].contiguous()
+        y, m, r = unit.forward(xc)
+        ctx.unit, ctx.xc, ctx.st, ctx.shape = unit, xc, (m, r), tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dxc = ctx.unit.backward(dy.to(_f16).contiguous(), ctx.xc, *ctx.st)
+        dx = torch.zeros(ctx.shape, dtype=_f16, device=dy.device)
+        dx[:, 0] = dxc
+        _notify(ctx.unit.params())
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)

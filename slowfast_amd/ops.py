@@ -317,7 +317,7 @@ def pool_fwd(y, kernel, stride, padding, affine=None, want_argmax=True):
     arg = torch.empty((N, T, Ho, Wo, C), dtype=torch.uint8, device=y.device) if want_argmax else None
     sc, sh, relu = _affine(affine)
     get_lib().call("sf_pool_fwd", *args, y.data_ptr(), cl_ld(y), _ptr(sc), _ptr(sh), relu, out.data_ptr(),
-                   cl_ld(out), _ptr(arg), _stream(y), work=dict(bytes=2.0 * (y.numel() + out.numel())))
+                   cl_ld(out), _ptr(arg), 0, _stream(y), work=dict(bytes=2.0 * (y.numel() + out.numel())))
     return out, arg
 
 
@@ -328,6 +328,6 @@ def pool_bwd(in_shape, pooled, argmax, dout, kernel, stride, padding, relu=True)
     assert tuple(dout.shape) == tuple(pooled.shape)
     g = cl_empty(in_shape, dout.device)
     get_lib().call("sf_pool_bwd", N, T, H, W, C, kH, kW, sH, sW, pH, pW, pooled.data_ptr(), cl_ld(pooled),
-                   argmax.data_ptr(), int(bool(relu)), dout.data_ptr(), cl_ld(dout), g.data_ptr(), cl_ld(g),
+                   argmax.data_ptr(), int(bool(relu)), dout.data_ptr(), cl_ld(dout), g.data_ptr(), cl_ld(g), 0,
                    _stream(dout), work=dict(bytes=2.0 * (g.numel() + 2.5 * dout.numel())))
     return g

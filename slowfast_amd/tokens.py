@@ -1,0 +1,316 @@
+"""Tensor-level wrappers over the token-space C ABI (include/sfamd.h, second half): batched GEMMs, LayerNorm,
+GELU, column sums, depthwise convolution, relative-position terms, softmax, transposes, token max-pool.
+
+Token tensors are fp16 with unit stride in the last (channel) dimension and a uniform row pitch: [B, N, C]
+contiguous, a channel slice of one, or a 2-D [M, C] view.  PyTorch is used for memory and streams only.
+"""
+from ctypes import byref
+
+import torch
+
+from .lib import AttnDesc, DwDesc, SfError, get_lib
+from .ops import _ptr, _stream, _workspace
+
+_f16 = torch.float16
+
+
+def rows_pitch(x):
+    """(rows, C, pitch) of a token tensor; raises unless rows are uniformly spaced with unit channel stride."""
+    if x.dtype != _f16 or x.dim() < 2:
+        raise SfError(f"expected an fp16 token tensor, got {tuple(x.shape)} {x.dtype}")
+    C = x.shape[-1]
+    if C > 1 and x.stride(-1) != 1:
+        raise SfError("token tensor must have unit channel stride")
+    ld = x.stride(-2) if x.shape[-2] > 1 else max(C, x.stride(-2))
+    rows = x.shape[-2]
+    for d in range(x.dim() - 3, -1, -1):
+        if x.shape[d] > 1 and x.stride(d) != rows * ld:
+            raise SfError(f"token tensor rows are not uniformly spaced: shape {tuple(x.shape)} strides {x.stride()}")
+        rows *= x.shape[d]
+    if ld % 8 or C % 8 or x.data_ptr() % 16:
+        raise SfError(f"token tensor needs C % 8 == 0, pitch % 8 == 0 and a 16-byte base (C={C}, pitch={ld})")
+    return rows, C, ld
+
+
+def _lib_call(name, *args, **kw):
+    return get_lib().call(name, *args, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMMs
+def gemm(a, w16, bias=None, resid=None, out=None):
+    """out[m][n] = sum_k a[m][k] * w16[n][k] (+ bias[n]) (+ resid[m][n]).  a: token tensor (..., K); w16: fp16
+    [N, K] (pitch = stride(0)); the nn.Linear forward with w16 = weight.half(), or its data gradient with
+    w16 = weight.t().half()."""
+    M, K, lda = rows_pitch(a)
+    N = w16.shape[0]
+    assert w16.dtype == _f16 and w16.shape[1] == K and w16.stride(1) == 1
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (N,), dtype=_f16, device=a.device)
+    Mo, No, ldy = rows_pitch(out)
+    assert (Mo, No) == (M, N)
+    ldr = 0
+    if resid is not None:
+        Mr, Nr, ldr = rows_pitch(resid)
+        assert (Mr, Nr) == (M, N)
+    _lib_call("sf_bgemm", M, N, K, a.data_ptr(), lda, w16.data_ptr(), w16.stride(0), _ptr(bias), _ptr(resid), ldr,
+              out.data_ptr(), ldy, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, _stream(a),
+              work=dict(flops=2.0 * M * N * K, bytes=2.0 * (M * K + M * N + N * K)))
+    return out
+
+
+def bgemm_heads(a, a_strides, M, K, lda, w, w_strides, N, ldw, out, o_strides, ldy, B, heads, resid=None,
+                r_strides=(0, 0), ldr=0, resid_row0=0):
+    """Per-(batch, head) GEMM: out[b,h][m][n] = sum_k a[b,h][m][k] * w[b,h][n][k] (+ resid).  *_strides = (per-batch,
+    per-head) element strides of the operand bases."""
+    _lib_call("sf_bgemm", M, N, K, a.data_ptr(), lda, w.data_ptr(), ldw, None, _ptr(resid), ldr, out.data_ptr(), ldy,
+              B * heads, heads, a_strides[0], a_strides[1], w_strides[0], w_strides[1], o_strides[0], o_strides[1],
+              r_strides[0], r_strides[1], resid_row0, _stream(a),
+              work=dict(flops=2.0 * B * heads * M * N * K, bytes=2.0 * B * heads * (M * K + N * K + M * N)))
+    return out
+
+
+def bgemm_tn_heads(p, p_strides, ldp, x, x_strides, ldx, M, R, Kc, out, o_strides, ldo, B, heads, scale=1.0):
+    """Per-(batch, head): out[b,h][r][c] = scale * sum_m p[b,h][m][r] * x[b,h][m][c]."""
+    _lib_call("sf_bgemm_tn", M, R, Kc, p.data_ptr(), ldp, x.data_ptr(), ldx, out.data_ptr(), ldo, float(scale),
+              B * heads, heads, p_strides[0], p_strides[1], x_strides[0], x_strides[1], o_strides[0], o_strides[1],
+              _stream(p), work=dict(flops=2.0 * B * heads * M * R * Kc, bytes=2.0 * B * heads * (M * R + M * Kc + R * Kc)))
+    return out
+
+
+def linear_wgrad(x, dy, dw, zero_first=True):
+    """dw[n][k] (+)= sum_m dy[m][n] * x[m][k] -- the nn.Linear weight gradient, through the conv weight-gradient
+    kernels on a 1x1x1 geometry (fp32, deterministic split reduction)."""
+    from . import ops
+    M, K, ldx = rows_pitch(x)
+    Md, N, ldy = rows_pitch(dy)
+    assert Md == M and tuple(dw.shape) == (N, K) and dw.dtype == torch.float32 and dw.is_contiguous()
+    geom = _linear_geom(M, K, N)
+    lib = get_lib()
+    d = geom.desc(ldx, ldy)
+    if geom.ws_bytes is None:
+        geom.ws_bytes = lib.call("sf_conv_wgrad_workspace", byref(d))
+    ws = _workspace(x.device, geom.ws_bytes)
+    lib.call("sf_conv_wgrad", byref(d), x.data_ptr(), None, None, 0, dy.data_ptr(), dw.data_ptr(), 1.0, int(zero_first),
+             ws.data_ptr(), ws.numel(), _stream(x), work=dict(flops=2.0 * M * N * K, bytes=2.0 * M * (N + K)))
+    return dw
+
+
+_geoms = {}
+
+
+def _linear_geom(M, K, N):
+    from . import ops
+    key = (M, K, N)
+    g = _geoms.get(key)
+    if g is None:
+        g = _geoms[key] = ops.ConvGeom((1, K, 1, 1, M), N, (1, 1, 1))
+    return g
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm / GELU / bias gradients
+def layernorm_fwd(x, gamma, beta, eps, out=None, save_stats=True):
+    M, C, ldx = rows_pitch(x)
+    y = torch.empty(x.shape, dtype=_f16, device=x.device) if out is None else out
+    _, _, ldy = rows_pitch(y)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    _lib_call("sf_layernorm_fwd", M, C, x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), float(eps), y.data_ptr(),
+              ldy, _ptr(mean), _ptr(rstd), _stream(x), work=dict(bytes=4.0 * M * C))
+    return y, mean, rstd
+
+
+def colsum_finalize(part, C, fold, out0, out1, scale=1.0, accumulate=False):
+    _lib_call("sf_colsum_finalize", part.data_ptr(), part.shape[0], C, fold, _ptr(out0), _ptr(out1), float(scale),
+              int(accumulate), _stream(part))
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, resid=None, accumulate=False, out=None):
+    """dx (+ resid); dgamma / dbeta written (or accumulated) in fp32."""
+    M, C, ldx = rows_pitch(x)
+    _, _, lddy = rows_pitch(dy)
+    dx = torch.empty(x.shape, dtype=_f16, device=x.device) if out is None else out
+    _, _, lddx = rows_pitch(dx)
+    ldr = rows_pitch(resid)[2] if resid is not None else 0
+    lib = get_lib()
+    nblk = lib.call("sf_layernorm_bwd_blocks", M, C)
+    part = torch.empty((nblk, 2, C), dtype=torch.float32, device=x.device)
+    lib.call("sf_layernorm_bwd", M, C, dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), mean.data_ptr(),
+             rstd.data_ptr(), _ptr(resid), ldr, dx.data_ptr(), lddx, part.data_ptr(), _stream(x),
+             work=dict(bytes=2.0 * M * C * (3 + int(resid is not None))))
+    colsum_finalize(part, C, C, dgamma, dbeta, 1.0, accumulate)
+    return dx
+
+
+def bias_grad(dy, dbias, accumulate=False, fold=None):
+    """dbias[c % fold] (+)= sum_m dy[m][c]."""
+    M, C, ld = rows_pitch(dy)
+    lib = get_lib()
+    nblk = lib.call("sf_colsum_blocks", M, C)
+    part = torch.empty((nblk, 2, C), dtype=torch.float32, device=dy.device)
+    lib.call("sf_colsum", M, C, dy.data_ptr(), ld, part.data_ptr(), _stream(dy), work=dict(bytes=2.0 * M * C))
+    colsum_finalize(part, C, fold or C, dbias, None, 1.0, accumulate)
+    return dbias
+
+
+def gelu_fwd(h):
+    assert h.is_contiguous() and h.dtype == _f16
+    a = torch.empty_like(h)
+    _lib_call("sf_gelu_fwd", h.numel(), h.data_ptr(), a.data_ptr(), _stream(h), work=dict(bytes=4.0 * h.numel()))
+    return a
+
+
+def gelu_bwd(h, da):
+    assert h.is_contiguous() and da.is_contiguous() and da.shape == h.shape
+    dh = torch.empty_like(h)
+    _lib_call("sf_gelu_bwd", h.numel(), h.data_ptr(), da.data_ptr(), dh.data_ptr(), _stream(h),
+              work=dict(bytes=6.0 * h.numel()))
+    return dh
+
+
+# ------------------------------------------------------------------------------------------------
+# depthwise convolution on token / channels-last rows
+class DwGeom:
+    """Depthwise Conv3d geometry over rows (n, [cls], t, h, w) with C channels (C % Cw == 0)."""
+
+    def __init__(self, N, C, Cw, thw, kernel, stride, padding, cls):
+        self.N, self.C, self.Cw, self.cls = N, C, Cw, int(bool(cls))
+        self.thw, self.k, self.s, self.p = tuple(thw), tuple(kernel), tuple(stride), tuple(padding)
+        self.out_thw = tuple((i + 2 * p - k) // s + 1 for i, k, s, p in zip(self.thw, self.k, self.s, self.p))
+        self.taps = self.k[0] * self.k[1] * self.k[2]
+        self.rows_in = N * (self.thw[0] * self.thw[1] * self.thw[2] + self.cls)
+        self.rows_out = N * (self.out_thw[0] * self.out_thw[1] * self.out_thw[2] + self.cls)
+        self.ws_bytes = None
+
+    def desc(self, ldx, ldy):
+        return DwDesc(self.N, self.C, self.Cw, self.cls, *self.thw, *self.out_thw, *self.k, *self.s, *self.p, ldx, ldy)
+
+
+def dwconv_fwd(x, w, geom, out=None, stats=False):
+    """x: token tensor with geom.rows_in rows of geom.C channels; w: fp32 nn.Conv3d weight [Cw,1,kT,kH,kW]."""
+    M, C, ldx = rows_pitch(x)
+    assert M == geom.rows_in and C == geom.C and w.dtype == torch.float32 and w.is_contiguous()
+    assert w.numel() == geom.Cw * geom.taps
+    y = torch.empty((geom.rows_out, C), dtype=_f16, device=x.device) if out is None else out
+    Mo, Co, ldy = rows_pitch(y)
+    assert Mo == geom.rows_out and Co == C
+    lib = get_lib()
+    d = geom.desc(ldx, ldy)
+    part = None
+    if stats:
+        part = torch.empty((lib.call("sf_dwconv_fwd_blocks", byref(d)), 2, C), dtype=torch.float32, device=x.device)
+    lib.call("sf_dwconv_fwd", byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), _ptr(part), _stream(x),
+             work=dict(bytes=2.0 * C * (geom.rows_in + geom.rows_out), flops=2.0 * geom.rows_out * C * geom.taps))
+    return (y, part) if stats else y
+
+
+def dwconv_dgrad(dy, w, geom, out=None):
+    M, C, lddy = rows_pitch(dy)
+    assert M == geom.rows_out and C == geom.C
+    dx = torch.empty((geom.rows_in, C), dtype=_f16, device=dy.device) if out is None else out
+    _, _, lddx = rows_pitch(dx)
+    _lib_call("sf_dwconv_dgrad", byref(geom.desc(lddx, lddy)), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), _stream(dy),
+              work=dict(bytes=2.0 * C * (geom.rows_in + geom.rows_out), flops=2.0 * geom.rows_out * C * geom.taps))
+    return dx
+
+
+def dwconv_wgrad(x, dy, geom, dw, zero_first=True, out_scale=1.0):
+    _, _, ldx = rows_pitch(x)
+    _, _, lddy = rows_pitch(dy)
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == geom.Cw * geom.taps
+    lib = get_lib()
+    d = geom.desc(ldx, lddy)
+    if geom.ws_bytes is None:
+        geom.ws_bytes = lib.call("sf_dwconv_wgrad_workspace", byref(d))
+    ws = _workspace(x.device, geom.ws_bytes)
+    lib.call("sf_dwconv_wgrad", byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), float(out_scale), int(zero_first),
+             ws.data_ptr(), ws.numel(), _stream(x),
+             work=dict(bytes=2.0 * geom.C * (3 * geom.rows_out + geom.rows_in), flops=2.0 * geom.rows_out * geom.C * geom.taps))
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------
+# token max-pool (MultiScaleBlock.pool_skip)
+def token_pool_fwd(x, B, thw, kernel, stride, padding, cls=True):
+    """MaxPool3d([1,kH,kW], [1,sH,sW], [0,pH,pW]) over the non-cls tokens of x [B, cls+T*H*W, C]."""
+    T, H, W = thw
+    assert kernel[0] == 1 and stride[0] == 1 and padding[0] == 0, "temporal pooling of the skip path is not used"
+    M, C, ldx = rows_pitch(x)
+    Ho, Wo = (H + 2 * padding[1] - kernel[1]) // stride[1] + 1, (W + 2 * padding[2] - kernel[2]) // stride[2] + 1
+    No = int(cls) + T * Ho * Wo
+    out = torch.empty((B, No, C), dtype=_f16, device=x.device)
+    arg = torch.empty((B, No, C), dtype=torch.uint8, device=x.device)
+    _lib_call("sf_pool_fwd", B, T, H, W, C, kernel[1], kernel[2], stride[1], stride[2], padding[1], padding[2],
+              x.data_ptr(), ldx, None, None, 0, out.data_ptr(), C, arg.data_ptr(), int(cls), _stream(x),
+              work=dict(bytes=2.0 * C * (M + B * No)))
+    return out, arg, (T, Ho, Wo)
+
+
+def token_pool_bwd(dout, pooled, arg, B, thw, kernel, stride, padding, C, cls=True):
+    T, H, W = thw
+    Ni = int(cls) + T * H * W
+    g = torch.empty((B, Ni, C), dtype=_f16, device=dout.device)
+    _lib_call("sf_pool_bwd", B, T, H, W, C, kernel[1], kernel[2], stride[1], stride[2], padding[1], padding[2],
+              pooled.data_ptr(), rows_pitch(pooled)[2], arg.data_ptr(), 0, dout.data_ptr(), rows_pitch(dout)[2],
+              g.data_ptr(), C, int(cls), _stream(dout), work=dict(bytes=2.0 * C * (B * Ni + 2.5 * dout.numel() / C)))
+    return g
+
+
+# ------------------------------------------------------------------------------------------------
+# pooled attention pieces
+def attn_desc(B, heads, D, cls, q_thw, k_thw, rows_h=0, rows_w=0, rows_t=0):
+    Nq = int(cls) + q_thw[0] * q_thw[1] * q_thw[2]
+    Nk = int(cls) + k_thw[0] * k_thw[1] * k_thw[2]
+    return AttnDesc(B, heads, D, int(cls), Nq, *q_thw, Nk, *k_thw, rows_h, rows_w, rows_t)
+
+
+def relpos_fwd(d, q, tables, idx):
+    """rq [B*Nq*heads, kH+kW+kT] fp32 from the UNSCALED q [B, Nq, heads*D]."""
+    R = d.kH + d.kW + d.kT
+    rq = torch.empty((d.B * d.Nq * d.heads, R), dtype=torch.float32, device=q.device)
+    _lib_call("sf_relpos_fwd", byref(d), q.data_ptr(), rows_pitch(q)[2], tables[0].data_ptr(), tables[1].data_ptr(),
+              tables[2].data_ptr(), idx[0].data_ptr(), idx[1].data_ptr(), idx[2].data_ptr(), rq.data_ptr(), _stream(q),
+              work=dict(bytes=2.0 * q.numel()))
+    return rq
+
+
+def relpos_bwd(d, q, tables, idx, drq, dq, dtables, accumulate):
+    """dq += table terms; dtables[i] (+)= gradients of rel_pos_h / rel_pos_w / rel_pos_t."""
+    lib = get_lib()
+    nblk = lib.call("sf_relpos_bwd_blocks", byref(d))
+    TR = d.rows_h + d.rows_w + d.rows_t
+    part = torch.empty((nblk, TR * d.D), dtype=torch.float32, device=q.device)
+    lib.call("sf_relpos_bwd", byref(d), q.data_ptr(), rows_pitch(q)[2], tables[0].data_ptr(), tables[1].data_ptr(),
+             tables[2].data_ptr(), idx[0].data_ptr(), idx[1].data_ptr(), idx[2].data_ptr(), drq.data_ptr(),
+             dq.data_ptr(), rows_pitch(dq)[2], part.data_ptr(), _stream(q), work=dict(bytes=6.0 * q.numel()))
+    off = 0
+    for t, g, acc in zip(tables, dtables, accumulate):
+        n = t.numel()
+        lib.call("sf_rows_sum", part.data_ptr(), nblk, TR * d.D, off, n, g.data_ptr(), 1.0, int(acc), _stream(q))
+        off += n
+
+
+def softmax_fwd(d, s, scale, rq=None):
+    lds = s.shape[-1]
+    _lib_call("sf_softmax_fwd", byref(d), s.data_ptr(), lds, float(scale), _ptr(rq), _stream(s),
+              work=dict(bytes=4.0 * s.numel()))
+    return s
+
+
+def softmax_bwd(d, dp, prob, scale, want_drq):
+    lds = dp.shape[-1]
+    drq = None
+    if want_drq:
+        drq = torch.empty((d.B * d.Nq * d.heads, d.kH + d.kW + d.kT), dtype=torch.float32, device=dp.device)
+    _lib_call("sf_softmax_bwd", byref(d), dp.data_ptr(), prob.data_ptr(), lds, float(scale), _ptr(drq), _stream(dp),
+              work=dict(bytes=6.0 * dp.numel()))
+    return dp, drq
+
+
+def transpose_heads(x, B, Nk, heads, D, ldk):
+    """[B, Nk, heads*D] -> [B, heads, D, ldk] (zero padded keys)."""
+    xt = torch.empty((B, heads, D, ldk), dtype=_f16, device=x.device)
+    _lib_call("sf_transpose_heads", x.data_ptr(), rows_pitch(x)[2], xt.data_ptr(), ldk, B, Nk, heads, D, _stream(x),
+              work=dict(bytes=4.0 * x.numel()))
+    return xt

@@ -11,7 +11,7 @@ import os
 import torch
 
 import slowfast_amd as sa
-from oracle import video_ref
+from oracle import mvit_ref, video_ref
 from slowfast_amd.config import preset_for_yaml
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -26,12 +26,18 @@ def cfg_for(gold, extra=()):
     return sa.get_preset(preset_for_yaml(gold["reference_yaml"]), list(gold["opts"]) + list(extra))
 
 
+def family(cfg):
+    """The oracle module restating the reference graph of this model family."""
+    return mvit_ref if cfg.MODEL.MODEL_NAME == "MViT" else video_ref
+
+
 def oracle_run(gold, cfg):
     model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)   # only used for the state_dict shapes
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = video_ref.randomize_state(shapes, gold["param_seed"])
+    fam = family(cfg)
+    sd = fam.randomize_state(shapes, gold["param_seed"])
     inputs, labels = video_ref.synthetic_batch(cfg, gold["batch"], gold["data_seed"])
-    logits, loss, grads, stats = video_ref.loss_and_grads(sd, cfg, inputs, labels)
+    logits, loss, grads, stats = fam.loss_and_grads(sd, cfg, inputs, labels)
     return model, sd, inputs, labels, logits, loss, grads, stats
 
 
@@ -77,7 +83,7 @@ def storage_model_yardstick(name, sd, cfg, inputs, labels, o_logits, o_loss, o_g
     if name in _yard_cache:
         return _yard_cache[name]
     with video_ref.fp16_storage_model():
-        logits, loss, grads, stats = video_ref.loss_and_grads(sd, cfg, inputs, labels)
+        logits, loss, grads, stats = family(cfg).loss_and_grads(sd, cfg, inputs, labels)
     ogn = float(video_ref.grad_norm(o_grads))
     y = {
         "logits": float((logits - o_logits).abs().max() / o_logits.abs().max()),
@@ -85,7 +91,8 @@ def storage_model_yardstick(name, sd, cfg, inputs, labels, o_logits, o_loss, o_g
         "grad_norm": abs(float(video_ref.grad_norm(grads)) - ogn) / ogn,
         "grad_global": _global_rel(grads, o_grads),
         "param_grad_worst": _param_worst(grads, o_grads, ogn)[0],
-        "running_stats": max(float((stats[k] - v).abs().max() / (v.abs().max() + 1e-6)) for k, v in o_stats.items()),
+        "running_stats": max([float((stats[k] - v).abs().max() / (v.abs().max() + 1e-6)) for k, v in o_stats.items()]
+                             + [0.0]),
     }
     _yard_cache[name] = y
     return y
@@ -118,7 +125,7 @@ def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, t
     res["param_grad_worst"], res["param_grad_worst_name"] = _param_worst(grads, o_grads, ogn)
     msd = model.state_dict()
     res["running_stats"] = max(
-        float((msd[k].float().cpu() - v).abs().max() / (v.abs().max() + 1e-6)) for k, v in o_stats.items())
+        [float((msd[k].float().cpu() - v).abs().max() / (v.abs().max() + 1e-6)) for k, v in o_stats.items()] + [0.0])
     res["yardstick"] = yard
     if report is not None:
         report[name] = res

@@ -111,3 +111,37 @@ def test_full_size_batch32_properties(gpu):
         assert torch.isfinite(loss) and abs(float(loss) - 5.99) < 0.5
         assert float((logits[:16] - logits[16:]).abs().max()) == 0.0
     assert abs(norms[0] - norms[1]) < 2e-3 * norms[1], norms
+
+
+@pytest.mark.parametrize("name", ["mvit_tiny", "mvit_s_mid"])
+def test_mvit_matches_reference(gpu, name):
+    """MViTv2 through the token-space engine vs the oracle and the golden numbers of the unmodified reference."""
+    rep = {}
+    try:
+        mc.check_engine(name, gpu, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.1,
+                        tol_global=1e-2, report=rep)
+    finally:
+        print(name, rep.get(name))
+
+
+def test_mvit_full_size_properties(gpu):
+    """BASELINE config 4 at full size (MViTv2-S, 16x224^2, batch 4): finite loss near ln 400 at init, clip
+    independence (identical clips give identical logits), loss-scale linearity of the gradients."""
+    import slowfast_amd as sa
+    cfg = sa.get_preset("MVITv2_S_16x4", ["NUM_GPUS", 1, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0])
+    torch.manual_seed(0)
+    model = sa.build_model(cfg).train()
+    x = torch.randn((4, 3, 16, 224, 224), device=gpu)
+    x[2:] = x[:2]
+    labels = torch.randint(0, 400, (4,), device=gpu)
+    norms = []
+    for scale in (16.0, 256.0):
+        model.zero_grad(set_to_none=True)
+        logits = model([x])
+        loss = torch.nn.functional.cross_entropy(logits.float(), labels)
+        (loss * scale).backward()
+        g = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())) / scale
+        norms.append(float(g))
+        assert torch.isfinite(loss) and abs(float(loss) - 5.99) < 0.5
+        assert float((logits[:2] - logits[2:]).abs().max()) == 0.0
+    assert abs(norms[0] - norms[1]) < 5e-3 * norms[1], norms

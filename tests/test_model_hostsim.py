@@ -12,3 +12,9 @@ from tests import model_checks as mc
 @pytest.mark.parametrize("name", ["slowfast_tiny", "c2d_tiny"])
 def test_engine_wiring_matches_oracle(sim, name):
     mc.check_engine(name, sim, tol_logits=0.15, tol_loss=0.02, tol_gnorm=0.35, tol_param=2.0, tol_stats=0.05)
+
+
+def test_mvit_engine_matches_oracle(sim):
+    """4-block MViTv2 miniature (q pooling, dimension change, k/v pooling, relative positions, residual pooling,
+    cls token) through every token-space kernel, forward and backward."""
+    mc.check_engine("mvit_tiny", sim, tol_logits=1e-2, tol_loss=2e-3, tol_gnorm=3e-3, tol_param=0.1, tol_global=2e-2)

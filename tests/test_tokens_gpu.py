@@ -1,0 +1,42 @@
+"""GPU (-m gpu): token-space kernels (MViT path) on a real MI355X against the torch fp32 reference ops."""
+import pytest
+
+from tests import token_checks as tc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gemm_linear(gpu):
+    tc.check_gemm(gpu, 6273, 192, 576)
+    tc.check_gemm(gpu, 1000, 96, 288)
+    tc.check_gemm(gpu, 394, 768, 3072, resid=False)
+    tc.check_gemm(gpu, 77, 32, 24, bias=False, resid=False)
+
+
+def test_layernorm(gpu):
+    for M, C in ((5000, 96), (3001, 192), (777, 384), (400, 768), (37, 32)):
+        tc.check_layernorm(gpu, M, C)
+
+
+def test_gelu(gpu):
+    tc.check_gelu(gpu, 1 << 16)
+
+
+def test_dwconv_tokens(gpu):
+    tc.check_dwconv(gpu, 2, 2, 96, (4, 14, 14), (3, 3, 3), (1, 2, 2), cls=1)
+    tc.check_dwconv(gpu, 2, 1, 96, (4, 28, 28), (3, 3, 3), (1, 4, 4), cls=1)
+    tc.check_dwconv(gpu, 1, 4, 96, (4, 7, 7), (3, 3, 3), (1, 1, 1), cls=1)
+    tc.check_dwconv(gpu, 2, 1, 24, (8, 12, 12), (5, 1, 1), (1, 1, 1), cls=0)
+    tc.check_dwconv(gpu, 2, 1, 216, (4, 14, 14), (3, 3, 3), (1, 2, 2), cls=0)
+
+
+def test_token_pool(gpu):
+    tc.check_token_pool(gpu, 2, 192, (4, 28, 28), (1, 2, 2))
+    tc.check_token_pool(gpu, 1, 96, (3, 13, 15), (1, 2, 2))
+
+
+def test_attention_core(gpu):
+    tc.check_attention_core(gpu, 2, 2, 96, (4, 14, 14), (4, 7, 7))
+    tc.check_attention_core(gpu, 1, 1, 96, (8, 28, 28), (8, 7, 7))     # Nk = 393: stage-1 key count
+    tc.check_attention_core(gpu, 1, 4, 96, (4, 7, 7), (4, 7, 7))
+    tc.check_attention_core(gpu, 1, 1, 32, (2, 30, 30), (2, 30, 30))   # 1801 keys: 4-slot softmax rows

@@ -1,0 +1,36 @@
+"""CPU: every token-space kernel (MViT path) through the host simulator against the torch fp32 reference ops."""
+from tests import token_checks as tc
+
+
+def test_gemm_linear(sim):
+    tc.check_gemm(sim, 200, 96, 288)
+    tc.check_gemm(sim, 77, 32, 24, bias=False, resid=False)
+    tc.check_gemm(sim, 130, 192, 8, bias=True, resid=False)
+
+
+def test_layernorm(sim):
+    tc.check_layernorm(sim, 300, 96)
+    tc.check_layernorm(sim, 37, 32)
+    tc.check_layernorm(sim, 50, 192)
+    tc.check_layernorm(sim, 21, 384)
+    tc.check_layernorm(sim, 19, 768)
+
+
+def test_gelu(sim):
+    tc.check_gelu(sim, 4096)
+
+
+def test_dwconv_tokens(sim):
+    tc.check_dwconv(sim, 2, 2, 16, (2, 6, 6), (3, 3, 3), (1, 2, 2), cls=1)
+    tc.check_dwconv(sim, 1, 1, 32, (4, 5, 5), (3, 3, 3), (1, 1, 1), cls=1)
+    tc.check_dwconv(sim, 2, 1, 24, (6, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)
+
+
+def test_token_pool(sim):
+    tc.check_token_pool(sim, 2, 16, (2, 6, 6), (1, 2, 2))
+    tc.check_token_pool(sim, 1, 8, (3, 5, 7), (1, 2, 2))
+
+
+def test_attention_core(sim):
+    tc.check_attention_core(sim, 2, 2, 32, (2, 4, 4), (2, 2, 2))
+    tc.check_attention_core(sim, 1, 1, 96, (2, 3, 3), (2, 3, 3))
