@@ -28,10 +28,10 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
 # per clip, SlowFast-8x8-R50 32x224^2: MAC_fwd 50.309 G -> 6*MAC train flops; boundary elements
 # E = 216.5 M -> byte floor 5*E*2 B = 2.165 GB
-TRAIN_GFLOP_PER_CLIP = {"SLOWFAST_8x8_R50": 301.9, "C2D_8x8_R50": 117.0, "MVITv2_S_16x4": 383.6}
-BYTE_FLOOR_GB_PER_CLIP = {"SLOWFAST_8x8_R50": 2.165, "C2D_8x8_R50": 1.019, "MVITv2_S_16x4": 1.845}
+TRAIN_GFLOP_PER_CLIP = {"SLOWFAST_8x8_R50": 301.9, "C2D_8x8_R50": 117.0, "MVITv2_S_16x4": 383.6, "X3D_M": 28.4}
+BYTE_FLOOR_GB_PER_CLIP = {"SLOWFAST_8x8_R50": 2.165, "C2D_8x8_R50": 1.019, "MVITv2_S_16x4": 1.845, "X3D_M": 0.989}
 METRIC_NAME = {"SLOWFAST_8x8_R50": "SlowFast-8x8-R50 32x224^2", "C2D_8x8_R50": "C2D-R50 8x224^2",
-               "MVITv2_S_16x4": "MViTv2-S 16x224^2"}
+               "MVITv2_S_16x4": "MViTv2-S 16x224^2", "X3D_M": "X3D-M 16x224^2"}
 # synthetic-run overrides: stochastic ops off so that runs are comparable and parity-checkable
 PRESET_OPTS = {"MVITv2_S_16x4": ["MVIT.DROPPATH_RATE", 0.0, "MODEL.DROPOUT_RATE", 0.0]}
 

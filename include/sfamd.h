@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 4
+#define SF_ABI_VERSION 5
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -32,6 +32,8 @@ typedef struct sf_conv_desc {
     int32_t dT, dH, dW;
     int32_t Cw;
     int32_t ldx, ldy; /* row pitch of the input / output activation buffers, in elements */
+    int32_t Cow;      /* channel count of the fp32 weight on the OUTPUT side (0 = Co): activation buffers hold Co =
+                         Cow rounded up to 8 channels, the pad channels are produced as exact zeros (X3D widths 54, 108) */
 } sf_conv_desc;
 
 int sf_abi_version(void);
@@ -65,10 +67,12 @@ int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, c
 /* ---- BatchNorm3d -- replaces nn.BatchNorm3d built by batchnorm_helper.py:16-37 (get_norm) at every
  * *_bn call site of resnet_helper.py / stem_helper.py / video_model_builder.py:155-159, plus the
  * nn.ReLU and the residual add of resnet_helper.py:512-521. */
-/* `part` is scratch: long tables are folded in place before the final reduction (contents are destroyed).
+/* Creal <= C: number of real channels (length of gamma/beta/running stats); channels [Creal, C) are zero padding of the
+ * activation buffer and get scale = shift = 0.
+ * `part` is scratch: long tables are folded in place before the final reduction (contents are destroyed).
  * nblk > 0: training (partials -> batch statistics, running stats updated when non-null);
  * nblk == 0: eval (running statistics).  Outputs scale = gamma*rstd, shift = beta - mean*scale. */
-int sf_bn_finalize(float* part, int32_t nblk, int32_t C, float count, const float* gamma, const float* beta,
+int sf_bn_finalize(float* part, int32_t nblk, int32_t C, int32_t Creal, float count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                    float* save_mean, float* save_rstd, sf_stream_t stream);
 /* out = relu?( y*scale+shift [+ r*rscale+rshift | + r] ); scale == NULL means identity */
@@ -82,7 +86,7 @@ int sf_bn_bwd_reduce(int64_t M, int32_t C, const void* dz, int32_t lddz, const v
                      int32_t ldy, const float* scale, const float* shift, int relu_self, float* part,
                      sf_stream_t stream);
 /* dgamma/dbeta (fp32, unscaled by inv_loss_scale) and coef[3][C] with dy = k1*g + k2 + k3*y */
-int sf_bn_bwd_finalize(float* part, int32_t nblk, int32_t C, float count, const float* gamma, const float* mean,
+int sf_bn_bwd_finalize(float* part, int32_t nblk, int32_t C, int32_t Creal, float count, const float* gamma, const float* mean,
                        const float* rstd, float inv_loss_scale, float* dgamma, float* dbeta, int accumulate,
                        float* coef, sf_stream_t stream);
 int sf_bn_bwd_apply(int64_t M, int32_t C, const void* dz, int32_t lddz, const void* zmask, int32_t ldm, const void* y,
@@ -159,6 +163,7 @@ typedef struct sf_dw_desc {
     int32_t Ti, Hi, Wi, To, Ho, Wo;
     int32_t kT, kH, kW, sT, sH, sW, pT, pH, pW;
     int32_t ldx, ldy;
+    int32_t Cwreal;   /* rows of the fp32 weight (0 = Cw); channels [Cwreal, Cw) are zero padding (X3D widths 54, 108) */
 } sf_dw_desc;
 int sf_dwconv_fwd_blocks(const sf_dw_desc* d);       /* rows of stat_part */
 /* stat_part (optional): [blocks][2][C] per-block sum / sum of squares of the outputs (BatchNorm statistics) */
@@ -193,6 +198,35 @@ int sf_softmax_bwd(const sf_attn_desc* d, void* dp, const void* prob, int32_t ld
 /* xt[b][head][c][k] = x[b][k][head*D + c], zero for k in [Nk, ldk): K-contiguous operand for P.V and dS.K */
 int sf_transpose_heads(const void* x, int32_t ldx, void* xt, int32_t ldk, int32_t B, int32_t Nk, int32_t heads, int32_t D,
                        sf_stream_t stream);
+
+/* =====================================================================================================
+ * X3D: SE block (operators.py:15-59), Swish (pytorchvideo), X3DHead average pool (head_helper.py:413-438).
+ * Rows of a tensor are (n, pos), S positions per sample, C channels (padded to 8).
+ * ===================================================================================================== */
+int sf_sample_chunks(int64_t S, int32_t C);          /* part needs N * chunks * 2 * C floats */
+/* out[n][c] = mean_pos relu?(y*scale + shift)  (nn.AdaptiveAvgPool3d(1) of SE on the BatchNorm output; the X3DHead
+ * AvgPool3d over the whole (T,H,W) extent after conv_5_bn + ReLU); scale/shift NULL = identity */
+int sf_sample_mean(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift,
+                   int relu, float* part, float* out, sf_stream_t stream);
+/* h = relu(W1 m + b1), gate = sigmoid(W2 h + b2) per sample; m, gate rows have pitch Cp >= C (pad gate = 0) */
+int sf_se_gate_fwd(int32_t N, int32_t C, int32_t Cp, int32_t F, const float* m, const float* w1, const float* b1,
+                   const float* w2, const float* b2, float* h, float* gate, sf_stream_t stream);
+/* z = act(gate[n][c] * (y*scale + shift)), act = swish (x*sigmoid(x)) or relu; gate NULL = 1 */
+int sf_gate_act_fwd(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift,
+                    const float* gate, int swish, void* z, int32_t ldz, sf_stream_t stream);
+/* dgate[n][c] = sum_pos dz * act'(gate*u) * u,  u = y*scale + shift */
+int sf_gate_grad(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift,
+                 const void* dz, int32_t lddz, const float* gate, int swish, float* part, float* dgate, sf_stream_t stream);
+/* per-sample backward of the gate: dpre2 = dgate*g*(1-g), dpre1 = (W2^T dpre2) masked by h > 0, dm = W1^T dpre1 */
+int sf_se_gate_bwd(int32_t N, int32_t C, int32_t Cp, int32_t F, const float* gate, const float* h, const float* w1,
+                   const float* w2, const float* dgate, float* dpre2, float* dpre1, float* dm, sf_stream_t stream);
+/* out[i][j] (+)= scale * sum_n a[n*lda + i] * b[n*ldb + j]  (SE weight/bias gradients; b NULL: J = 1, b = 1) */
+int sf_outer_sum(const float* a, int32_t lda, const float* b, int32_t ldb, int32_t N, int32_t I, int32_t J, float* out,
+                 float scale, int accumulate, sf_stream_t stream);
+/* du = dz * act'(gate*u) * gate + dmean[n][c] / S  (gradient w.r.t. the BatchNorm output u); dmean NULL = 0 */
+int sf_gate_act_bwd(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift,
+                    const float* gate, int swish, const void* dz, int32_t lddz, const float* dmean, void* du, int32_t lddu,
+                    sf_stream_t stream);
 
 #ifdef __cplusplus
 }

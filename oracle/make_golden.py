@@ -39,6 +39,12 @@ CASES = {
                     ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
     "i3d_r50_mid": ("configs/Kinetics/I3D_8x8_R50.yaml",
                     ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
+    # X3D-M (depthwise 3x3x3, SE, Swish, channel widths 54/108 that are not multiples of 8) at reduced clip size
+    "x3d_m_mid": ("configs/Kinetics/X3D_M.yaml",
+                  ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
+    "x3d_tiny": ("configs/Kinetics/X3D_M.yaml",
+                 ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 64,
+                  "DATA.NUM_FRAMES", 4, "X3D.DEPTH_FACTOR", 1.0, "X3D.DIM_C5", 256], 4),
     # MViTv2: a 4-block miniature (every block type: q-pooling, dim change, k/v pooling, rel-pos) and the full
     # 16-block MViTv2-S at a reduced clip size
     "mvit_tiny": ("configs/Kinetics/MVITv2_S_16x4.yaml",

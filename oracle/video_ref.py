@@ -120,6 +120,59 @@ def res_stage(xs, sd, name, strides, dilations, stride_1x1, training, stats_out)
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# X3D
+def x3d_stem(x, sd, prefix, training, stats_out):
+    """X3DStem.forward (stem_helper.py:279-285): conv_xy (1,3,3)/(1,2,2) -> depthwise (5,1,1) -> BN -> ReLU."""
+    w_xy, w_t = sd[prefix + ".conv_xy.weight"], sd[prefix + ".conv.weight"]
+    x = _conv(_STORE(x), w_xy, None, (1, 2, 2), (0, 1, 1))
+    x = _STORE(F.conv3d(x, _STORE(w_t), None, 1, (w_t.shape[2] // 2, 0, 0), 1, w_t.shape[0]))
+    return _STORE(F.relu(_bn(x, sd, prefix + ".bn", training, stats_out)))
+
+
+def x3d_block(x, sd, prefix, stride, training, stats_out):
+    """ResBlock.forward (resnet_helper.py:512-521) around X3DTransform.forward (:253-256): 1x1x1 -> BN -> ReLU ->
+    depthwise 3x3x3 (stride) -> BN -> [SE] -> Swish -> 1x1x1 -> BN; SE = operators.py:53-59."""
+    b2 = prefix + ".branch2"
+    y = _conv(x, sd[b2 + ".a.weight"])
+    y = _STORE(F.relu(_bn(y, sd, b2 + ".a_bn", training, stats_out)))
+    wb = sd[b2 + ".b.weight"]
+    y = _STORE(F.conv3d(y, _STORE(wb), None, (1, stride, stride), (wb.shape[2] // 2, 1, 1), 1, wb.shape[0]))
+    y = _bn(y, sd, b2 + ".b_bn", training, stats_out)
+    if b2 + ".se.fc1.weight" in sd:
+        g = y.mean((2, 3, 4), keepdim=True)
+        g = F.relu(F.conv3d(g, sd[b2 + ".se.fc1.weight"], sd[b2 + ".se.fc1.bias"]))
+        g = torch.sigmoid(F.conv3d(g, sd[b2 + ".se.fc2.weight"], sd[b2 + ".se.fc2.bias"]))
+        y = y * g
+    y = _STORE(y * torch.sigmoid(y))                   # Swish
+    y = _conv(y, sd[b2 + ".c.weight"])
+    y = _bn(y, sd, b2 + ".c_bn", training, stats_out)
+    if prefix + ".branch1.weight" in sd:
+        sc = _conv(x, sd[prefix + ".branch1.weight"], None, (1, stride, stride))
+        sc = _bn(sc, sd, prefix + ".branch1_bn", training, stats_out)
+    else:
+        sc = x
+    return _STORE(F.relu(sc + y))
+
+
+def x3d_forward(sd, cfg, inputs, training=True, stats_out=None):
+    """X3D.forward (video_model_builder.py:799-802) + X3DHead.forward (head_helper.py:461-488); BN_LIN5 False."""
+    x = x3d_stem(inputs[0], sd, "s1.pathway0_stem", training, stats_out)
+    for s in range(2, 6):
+        i = 0
+        while f"s{s}.pathway0_res{i}.branch2.a.weight" in sd:
+            x = x3d_block(x, sd, f"s{s}.pathway0_res{i}", 2 if i == 0 else 1, training, stats_out)
+            i += 1
+    x = _conv(x, sd["head.conv_5.weight"])
+    x = _STORE(F.relu(_bn(x, sd, "head.conv_5_bn", training, stats_out)))
+    x = x.mean((2, 3, 4), keepdim=True)
+    x = F.relu(F.conv3d(x, sd["head.lin_5.weight"]))
+    z = F.linear(x.permute(0, 2, 3, 4, 1), sd["head.projection.weight"], sd["head.projection.bias"])
+    if not training:
+        z = F.softmax(z, dim=4).mean([1, 2, 3])
+    return z.reshape(z.shape[0], -1)
+
+
 _POOL1_T = {"2d": 1, "c2d": 2, "slow_c2d": 1, "i3d": 2, "slow_i3d": 1, "slow": 1, "slowfast": 1}
 
 
@@ -201,7 +254,8 @@ def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32):
     params = {k: v.detach().to(dtype).clone().requires_grad_(v.is_floating_point() and "running" not in k)
               for k, v in sd.items() if v.is_floating_point()}
     stats = {}
-    logits = video_forward(params, cfg, [x.to(dtype) for x in inputs], training=True, stats_out=stats)
+    fwd = x3d_forward if cfg.MODEL.MODEL_NAME == "X3D" else video_forward
+    logits = fwd(params, cfg, [x.to(dtype) for x in inputs], training=True, stats_out=stats)
     loss = F.cross_entropy(logits, labels)
     loss.backward()
     grads = {k: v.grad for k, v in params.items() if v.requires_grad}

@@ -111,6 +111,9 @@ _DEFAULTS = {
              "REL_POS_TEMPORAL": False, "REL_POS_ZERO_INIT": False, "RESIDUAL_POOLING": False, "DIM_MUL_IN_ATT": False,
              "SEPARATE_QKV": False, "HEAD_INIT_SCALE": 1.0, "USE_MEAN_POOLING": False, "USE_FIXED_SINCOS_POS": False,
              "REV": {"ENABLE": False}},
+    # slowfast/config/defaults.py:333-358
+    "X3D": {"WIDTH_FACTOR": 1.0, "DEPTH_FACTOR": 1.0, "BOTTLENECK_FACTOR": 1.0, "DIM_C5": 2048, "DIM_C1": 12,
+            "SCALE_RES2": False, "BN_LIN5": False, "CHANNELWISE_3x3x3": True},
     "MIXUP": {"ENABLE": False},
     "NUM_GPUS": 1, "NUM_SHARDS": 1, "SHARD_ID": 0, "RNG_SEED": 1, "LOG_MODEL_INFO": True, "DIST_BACKEND": "nccl",
     "OUTPUT_DIR": ".",
@@ -170,6 +173,16 @@ PRESETS["MVITv2_S_16x4"] = {
                "ZERO_WD_1D_PARAM": True, "CLIP_GRAD_L2NORM": 1.0},
     "MODEL": {"NUM_CLASSES": 400, "ARCH": "mvit", "MODEL_NAME": "MViT", "LOSS_FUNC": "soft_cross_entropy",
               "DROPOUT_RATE": 0.5},
+}
+
+
+# configs/Kinetics/X3D_M.yaml
+PRESETS["X3D_M"] = {
+    "DATA": {"NUM_FRAMES": 16, "SAMPLING_RATE": 5, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256, "INPUT_CHANNEL_NUM": [3]},
+    "X3D": {"WIDTH_FACTOR": 2.0, "DEPTH_FACTOR": 2.2, "BOTTLENECK_FACTOR": 2.25, "DIM_C5": 2048, "DIM_C1": 12},
+    "RESNET": {"ZERO_INIT_FINAL_BN": True, "TRANS_FUNC": "x3d_transform", "STRIDE_1X1": False},
+    "SOLVER": {"BASE_LR": 0.1, "WEIGHT_DECAY": 5e-5, "OPTIMIZING_METHOD": "sgd"},
+    "MODEL": {"NUM_CLASSES": 400, "ARCH": "x3d", "MODEL_NAME": "X3D", "LOSS_FUNC": "cross_entropy", "DROPOUT_RATE": 0.5},
 }
 
 

@@ -6,6 +6,7 @@
 #include "sf_pool.h"
 #include "sf_dwconv.h"
 #include "sf_tokens.h"
+#include "sf_x3d.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -49,6 +50,7 @@ static int check_desc(const sf_conv_desc* d) {
     REQUIRE(d->Ci % 8 == 0 && d->Co % 8 == 0, "conv: channel counts must be multiples of 8 (Ci=%d Co=%d)", d->Ci, d->Co);
     REQUIRE(d->ldx >= d->Ci && d->ldx % 8 == 0 && d->ldy >= d->Co && d->ldy % 8 == 0, "conv: bad row pitch");
     REQUIRE(d->Cw > 0 && d->Cw <= d->Ci, "conv: Cw must be in (0, Ci]");
+    REQUIRE(d->Cow >= 0 && d->Cow <= d->Co, "conv: Cow must be in [0, Co]");
     REQUIRE(d->sT > 0 && d->sH > 0 && d->sW > 0 && d->dT > 0 && d->dH > 0 && d->dW > 0, "conv: stride/dilation");
     int To = (d->Ti + 2 * d->pT - d->dT * (d->kT - 1) - 1) / d->sT + 1;
     int Ho = (d->Hi + 2 * d->pH - d->dH * (d->kH - 1) - 1) / d->sH + 1;
@@ -139,7 +141,7 @@ extern "C" int sf_prep_weights(const sf_conv_desc* d, const float* w, void* wf, 
     if (check_desc(d)) return -1;
     REQUIRE(w && wf, "sf_prep_weights: null pointer");
     PrepParams p;
-    p.w = w; p.Co = d->Co; p.Cw = d->Cw; p.Cp = d->Ci; p.taps = d->kT * d->kH * d->kW;
+    p.w = w; p.Co = d->Co; p.Cow = d->Cow ? d->Cow : d->Co; p.Cw = d->Cw; p.Cp = d->Ci; p.taps = d->kT * d->kH * d->kW;
     int32_t ldf, ldd;
     sf_conv_weight_ld(d, &ldf, &ldd);
     p.wf = (f16*)wf; p.ldf = ldf; p.wd = (f16*)wd; p.ldd = ldd;
@@ -267,10 +269,10 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
     }
     if (check_launch("wgrad")) return -1;
     WgradReduceParams r;
-    r.ws = (const float*)workspace; r.splits = w.splits; r.Co = d->Co; r.Co_pad = w.Co_pad; r.Kpad = w.Kpad;
+    r.ws = (const float*)workspace; r.splits = w.splits; r.Co = d->Cow ? d->Cow : d->Co; r.Co_pad = w.Co_pad; r.Kpad = w.Kpad;
     r.Ktot = p.g.Ktot; r.fdC = p.g.fdC; r.dw = dw; r.Cw = d->Cw; r.taps = d->kT * d->kH * d->kW;
     r.out_scale = out_scale; r.accumulate = zero_first ? 0 : 1;
-    int64_t total = (int64_t)d->Co * w.Kpad;
+    int64_t total = (int64_t)r.Co * w.Kpad;
     int lanes = 1;
     while (lanes < 32 && lanes * 4 <= w.splits) lanes *= 2;   // ~>= 4 splits per lane, 8..256 elements per block
     r.lanes = lanes;
@@ -310,14 +312,15 @@ static int fold_partials(float* part, int& nblk, int C, hipStream_t s) {
     return group;
 }
 
-extern "C" int sf_bn_finalize(float* part, int32_t nblk, int32_t C, float count, const float* gamma,
+extern "C" int sf_bn_finalize(float* part, int32_t nblk, int32_t C, int32_t Creal, float count, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                               float* scale, float* shift, float* save_mean, float* save_rstd, sf_stream_t stream) {
     REQUIRE(gamma && beta && scale && shift, "sf_bn_finalize: null pointer");
     REQUIRE(nblk > 0 ? part != nullptr : (running_mean && running_var), "sf_bn_finalize: missing statistics source");
+    REQUIRE(Creal > 0 && Creal <= C, "sf_bn_finalize: Creal must be in (0, C]");
     BnFinalizeParams p;
     p.row_stride = nblk > 0 ? fold_partials(part, nblk, C, (hipStream_t)stream) : 1;
-    p.part = part; p.nblk = nblk; p.C = C; p.count = count; p.gamma = gamma; p.beta = beta;
+    p.part = part; p.nblk = nblk; p.C = C; p.Creal = Creal; p.count = count; p.gamma = gamma; p.beta = beta;
     p.running_mean = running_mean; p.running_var = running_var; p.momentum = momentum; p.eps = eps;
     p.scale = scale; p.shift = shift; p.save_mean = save_mean; p.save_rstd = save_rstd;
     hipLaunchKernelGGL(sf_bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
@@ -362,13 +365,14 @@ extern "C" int sf_bn_bwd_reduce(int64_t M, int32_t C, const void* dz, int32_t ld
     return check_launch("bn_bwd_reduce");
 }
 
-extern "C" int sf_bn_bwd_finalize(float* part, int32_t nblk, int32_t C, float count, const float* gamma,
+extern "C" int sf_bn_bwd_finalize(float* part, int32_t nblk, int32_t C, int32_t Creal, float count, const float* gamma,
                                   const float* mean, const float* rstd, float inv_loss_scale, float* dgamma,
                                   float* dbeta, int accumulate, float* coef, sf_stream_t stream) {
     REQUIRE(part && gamma && mean && rstd && dgamma && dbeta && coef, "sf_bn_bwd_finalize: null pointer");
     BnBwdFinalizeParams p;
     p.row_stride = fold_partials(part, nblk, C, (hipStream_t)stream);
-    p.part = part; p.nblk = nblk; p.C = C; p.count = count; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
+    REQUIRE(Creal > 0 && Creal <= C, "sf_bn_bwd_finalize: Creal must be in (0, C]");
+    p.part = part; p.nblk = nblk; p.C = C; p.Creal = Creal; p.count = count; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
     p.inv_loss_scale = inv_loss_scale; p.dgamma = dgamma; p.dbeta = dbeta; p.accumulate = accumulate; p.coef = coef;
     hipLaunchKernelGGL(sf_bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("bn_bwd_finalize");
@@ -662,7 +666,8 @@ static int fill_dw(DwParams& p, const sf_dw_desc* d, bool rows_are_outputs, int 
               Wo = (d->Wi + 2 * d->pW - d->kW) / d->sW + 1;
     REQUIRE(To == d->To && Ho == d->Ho && Wo == d->Wo, "dwconv: output dims do not match the geometry");
     memset(&p, 0, sizeof(p));
-    p.N = d->N; p.C = d->C; p.Cw = d->Cw; p.cls = d->cls ? 1 : 0;
+    REQUIRE(d->Cwreal >= 0 && d->Cwreal <= d->Cw, "dwconv: Cwreal must be in [0, Cw]");
+    p.N = d->N; p.C = d->C; p.Cw = d->Cw; p.Cwreal = d->Cwreal ? d->Cwreal : d->Cw; p.cls = d->cls ? 1 : 0;
     p.Ti = d->Ti; p.Hi = d->Hi; p.Wi = d->Wi; p.To = d->To; p.Ho = d->Ho; p.Wo = d->Wo;
     p.kT = d->kT; p.kH = d->kH; p.kW = d->kW; p.sT = d->sT; p.sH = d->sH; p.sW = d->sW;
     p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
@@ -723,8 +728,9 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
     if (check_launch("dwconv_wgrad")) return -1;
     DwFinalizeParams f;
     f.wpart = (const float*)workspace; f.nblk = grid.x; f.taps = taps; f.C = d->C; f.Cw = d->Cw;
+    f.Cwreal = d->Cwreal ? d->Cwreal : d->Cw;
     f.dw = dw; f.scale = out_scale; f.accumulate = zero_first ? 0 : 1;
-    hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, SF_THREADS)), dim3(SF_THREADS), 0,
+    hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, 32)), dim3(SF_THREADS), 0,
                        (hipStream_t)stream, f);
     return check_launch("dwconv_wgrad_finalize");
 }
@@ -772,6 +778,7 @@ extern "C" int sf_relpos_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, 
     if (fill_relpos(p, d)) return -1;
     REQUIRE(q && rel_h && rel_w && rel_t && idx_h && idx_w && idx_t && drq && dq && dtab_part, "sf_relpos_bwd: null pointer");
     REQUIRE((d->rows_h + d->rows_w + d->rows_t) * d->D <= SF_RELPOS_MAX_TAB, "sf_relpos_bwd: tables exceed the LDS stage");
+    REQUIRE(d->qH * d->kH + d->qW * d->kW + d->qT * d->kT <= 1024, "sf_relpos_bwd: index tables exceed the LDS stage");
     p.q = (const f16*)q; p.ldq = ldq; p.rel_h = rel_h; p.rel_w = rel_w; p.rel_t = rel_t;
     p.idx_h = idx_h; p.idx_w = idx_w; p.idx_t = idx_t; p.drq = drq; p.dq = (f16*)dq; p.lddq = lddq;
     p.dtab_part = dtab_part;
@@ -780,23 +787,30 @@ extern "C" int sf_relpos_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, 
     hipLaunchKernelGGL(sf_relpos_bwd_kernel, dim3(cdiv(rows, p.rows_per_block)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("relpos_bwd");
 }
-// out[i] (+)= scale * sum_b part[b*row_len + offset + i], i < n   (table gradients from per-block partials)
+// out[i] (+)= scale * sum_b part[b*row_len + offset + i], i < n   (table gradients from per-block partials):
+// 32 outputs per block x 8 segments of the block sum, fixed-order LDS fold
 __global__ __launch_bounds__(SF_THREADS) void sf_rows_sum_kernel(const float* part, int nblk, int64_t row_len, int64_t offset,
                                                                   int n, float* out, float scale, int accumulate) {
-    const int i = blockIdx.x * SF_THREADS + threadIdx.x;
-    if (i >= n) return;
-    double s0 = 0.0, s1 = 0.0;
-    const float* src = part + offset + i;
-    int b = 0;
-    for (; b + 2 <= nblk; b += 2) { s0 += (double)src[b * row_len]; s1 += (double)src[(b + 1) * row_len]; }
-    if (b < nblk) s0 += (double)src[b * row_len];
-    const float v = (float)((s0 + s1) * scale);
-    out[i] = accumulate ? out[i] + v : v;
+    __shared__ double s_acc[8][32];
+    const int ox = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + ox;
+    double s = 0.0;
+    if (i < n) {
+        const float* src = part + offset + i;
+        for (int b = seg; b < nblk; b += 8) s += (double)src[b * row_len];
+    }
+    s_acc[seg][ox] = s;
+    __syncthreads();
+    if (seg == 0 && i < n) {
+        for (int k = 1; k < 8; ++k) s += s_acc[k][ox];
+        const float v = (float)(s * scale);
+        out[i] = accumulate ? out[i] + v : v;
+    }
 }
 extern "C" int sf_rows_sum(const float* part, int32_t nblk, int64_t row_len, int64_t offset, int32_t n, float* out,
                            float scale, int accumulate, sf_stream_t stream) {
     REQUIRE(part && out && nblk > 0 && n > 0, "sf_rows_sum: bad arguments");
-    hipLaunchKernelGGL(sf_rows_sum_kernel, dim3(cdiv(n, SF_THREADS)), dim3(SF_THREADS), 0, (hipStream_t)stream, part, nblk,
+    hipLaunchKernelGGL(sf_rows_sum_kernel, dim3(cdiv(n, 32)), dim3(SF_THREADS), 0, (hipStream_t)stream, part, nblk,
                        row_len, offset, n, out, scale, accumulate);
     return check_launch("rows_sum");
 }
@@ -849,4 +863,114 @@ extern "C" int sf_transpose_heads(const void* x, int32_t ldx, void* xt, int32_t 
     p.fdK8 = make_fastdiv(ldk / 8); p.fdD = make_fastdiv(D); p.fdHeads = make_fastdiv(heads);
     hipLaunchKernelGGL(sf_transpose_heads_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("transpose_heads");
+}
+
+// ================================================================================================
+// X3D: per-sample channel means, SE gate, gate * BatchNorm -> Swish/ReLU
+static const int kSampleChunks = 64;
+static int sample_plan(int64_t S, int C, RowTile& rt, dim3& grid) {
+    rt = make_rowtile(S, C, kSampleChunks, grid);
+    return (int)grid.x;
+}
+extern "C" int sf_sample_chunks(int64_t S, int32_t C) {
+    if (check_rows("sf_sample_chunks", S, C)) return -1;
+    RowTile rt;
+    dim3 grid;
+    return sample_plan(S, C, rt, grid);
+}
+static int sample_sum(int mode, int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale,
+                      const float* shift, int relu, const void* dz, int32_t lddz, const float* gate, int swish,
+                      float* part, float* out, float inv_count, hipStream_t s) {
+    if (check_rows("sf_sample_sum", S, C)) return -1;
+    REQUIRE(N > 0 && N <= 65535 && y && part && out, "sf_sample_sum: bad arguments");
+    REQUIRE((scale == nullptr) == (shift == nullptr), "sf_sample_sum: scale/shift must come together");
+    SampleSumParams p;
+    memset(&p, 0, sizeof(p));
+    dim3 grid;
+    const int chunks = sample_plan(S, C, p.rt, grid);
+    REQUIRE(grid.y == 1, "sf_sample_sum: C > 2048 is not supported");
+    grid.z = N;
+    p.S = S; p.y = (const f16*)y; p.ldy = ldy; p.scale = scale; p.shift = shift; p.relu = relu; p.mode = mode;
+    p.dz = (const f16*)dz; p.lddz = lddz; p.gate = gate; p.swish = swish; p.part = part;
+    hipLaunchKernelGGL(sf_sample_sum_kernel, grid, dim3(SF_THREADS), 0, s, p);
+    if (check_launch("sample_sum")) return -1;
+    hipLaunchKernelGGL(sf_sample_fold_kernel, dim3(cdiv(C, SF_THREADS), N), dim3(SF_THREADS), 0, s, (const float*)part, chunks,
+                       C, inv_count, out);
+    return check_launch("sample_fold");
+}
+extern "C" int sf_sample_mean(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale,
+                              const float* shift, int relu, float* part, float* out, sf_stream_t stream) {
+    return sample_sum(0, N, S, C, y, ldy, scale, shift, relu, nullptr, 0, nullptr, 0, part, out, 1.0f / (float)S,
+                      (hipStream_t)stream);
+}
+extern "C" int sf_gate_grad(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale,
+                            const float* shift, const void* dz, int32_t lddz, const float* gate, int swish, float* part,
+                            float* dgate, sf_stream_t stream) {
+    REQUIRE(dz && scale, "sf_gate_grad: null pointer");
+    return sample_sum(1, N, S, C, y, ldy, scale, shift, 0, dz, lddz, gate, swish, part, dgate, 1.0f, (hipStream_t)stream);
+}
+static int fill_se(SeGateParams& p, int32_t C, int32_t Cp, int32_t F, const float* w1, const float* b1, const float* w2,
+                   const float* b2) {
+    REQUIRE(C > 0 && C <= Cp && Cp <= 1024 && F > 0 && F <= 1024, "SE gate: C, F must be <= 1024");
+    REQUIRE(w1 && b1 && w2 && b2, "SE gate: null weights");
+    memset(&p, 0, sizeof(p));
+    p.C = C; p.Cp = Cp; p.F = F; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2;
+    return 0;
+}
+extern "C" int sf_se_gate_fwd(int32_t N, int32_t C, int32_t Cp, int32_t F, const float* m, const float* w1,
+                              const float* b1, const float* w2, const float* b2, float* h, float* gate, sf_stream_t stream) {
+    SeGateParams p;
+    if (fill_se(p, C, Cp, F, w1, b1, w2, b2)) return -1;
+    REQUIRE(m && h && gate && N > 0, "sf_se_gate_fwd: null pointer");
+    p.m = m; p.h = h; p.gate = gate;
+    hipLaunchKernelGGL(sf_se_gate_fwd_kernel, dim3(N), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("se_gate_fwd");
+}
+extern "C" int sf_se_gate_bwd(int32_t N, int32_t C, int32_t Cp, int32_t F, const float* gate, const float* h,
+                              const float* w1, const float* w2, const float* dgate, float* dpre2, float* dpre1, float* dm,
+                              sf_stream_t stream) {
+    SeGateParams p;
+    if (fill_se(p, C, Cp, F, w1, w1, w2, w2)) return -1;
+    REQUIRE(gate && h && dgate && dpre2 && dpre1 && dm && N > 0, "sf_se_gate_bwd: null pointer");
+    p.gate = (float*)gate; p.h = (float*)h; p.dgate = dgate; p.dpre2 = dpre2; p.dpre1 = dpre1; p.dm = dm;
+    hipLaunchKernelGGL(sf_se_gate_bwd_kernel, dim3(N), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("se_gate_bwd");
+}
+extern "C" int sf_outer_sum(const float* a, int32_t lda, const float* b, int32_t ldb, int32_t N, int32_t I, int32_t J,
+                            float* out, float scale, int accumulate, sf_stream_t stream) {
+    REQUIRE(a && out && N > 0 && I > 0 && J > 0 && (b || J == 1), "sf_outer_sum: bad arguments");
+    hipLaunchKernelGGL(sf_outer_sum_kernel, dim3(cdiv((int64_t)I * J, SF_THREADS)), dim3(SF_THREADS), 0, (hipStream_t)stream,
+                       a, lda, b, ldb, N, I, J, out, scale, accumulate);
+    return check_launch("outer_sum");
+}
+static int fill_gate_act(GateActParams& p, int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale,
+                         const float* shift, const float* gate, int swish, dim3& grid) {
+    if (check_rows("gate_act", (int64_t)N * S, C)) return -1;
+    REQUIRE(y && scale && shift, "gate_act: null pointer");
+    memset(&p, 0, sizeof(p));
+    p.rt = make_rowtile((int64_t)N * S, C, 8192, grid);
+    p.S = S; p.y = (const f16*)y; p.ldy = ldy; p.scale = scale; p.shift = shift; p.gate = gate; p.swish = swish;
+    p.fdS = make_fastdiv((uint32_t)S);
+    return 0;
+}
+extern "C" int sf_gate_act_fwd(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale,
+                               const float* shift, const float* gate, int swish, void* z, int32_t ldz, sf_stream_t stream) {
+    GateActParams p;
+    dim3 grid;
+    if (fill_gate_act(p, N, S, C, y, ldy, scale, shift, gate, swish, grid)) return -1;
+    REQUIRE(z != nullptr, "sf_gate_act_fwd: null pointer");
+    p.z = (f16*)z; p.ldz = ldz;
+    hipLaunchKernelGGL(sf_gate_act_fwd_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("gate_act_fwd");
+}
+extern "C" int sf_gate_act_bwd(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale,
+                               const float* shift, const float* gate, int swish, const void* dz, int32_t lddz,
+                               const float* dmean, void* du, int32_t lddu, sf_stream_t stream) {
+    GateActParams p;
+    dim3 grid;
+    if (fill_gate_act(p, N, S, C, y, ldy, scale, shift, gate, swish, grid)) return -1;
+    REQUIRE(dz && du, "sf_gate_act_bwd: null pointer");
+    p.dz = (const f16*)dz; p.lddz = lddz; p.dmean = dmean; p.inv_S = 1.0f / (float)S; p.z = (f16*)du; p.ldz = lddu;
+    hipLaunchKernelGGL(sf_gate_act_bwd_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("gate_act_bwd");
 }

@@ -85,6 +85,7 @@ struct BnFinalizeParams {
     int nblk;
     int row_stride;
     int C;
+    int Creal;           // gamma/beta/running stats have Creal entries; channels [Creal, C) are zero padding
     float count;         // N*T*H*W
     const float* gamma;
     const float* beta;
@@ -109,7 +110,12 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_finalize_kernel(BnFinalizePa
     s_s[seg][cx] = s;
     s_q[seg][cx] = q;
     __syncthreads();
-    if (seg == 0 && c < p.C) {
+    if (seg == 0 && c < p.C && c >= p.Creal) {
+        p.scale[c] = 0.f;
+        p.shift[c] = 0.f;
+        if (p.save_mean) p.save_mean[c] = 0.f;
+        if (p.save_rstd) p.save_rstd[c] = 0.f;
+    } else if (seg == 0 && c < p.C) {
         float mean, var;
         if (p.nblk > 0) {
             for (int k = 1; k < 8; ++k) { s += s_s[k][cx]; q += s_q[k][cx]; }
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_reduce_kernel(BnBwdReduc
 }
 
 struct BnBwdFinalizeParams {
-    const float* part; int nblk; int row_stride; int C;
+    const float* part; int nblk; int row_stride; int C; int Creal;
     float count;
     const float* gamma; const float* mean; const float* rstd;
     float inv_loss_scale;
@@ -295,7 +301,11 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_finalize_kernel(BnBwdFin
     s_s[seg][cx] = s;
     s_q[seg][cx] = q;
     __syncthreads();
-    if (seg == 0 && c < p.C) {
+    if (seg == 0 && c < p.C && c >= p.Creal) {
+        p.coef[c] = 0.f;
+        p.coef[p.C + c] = 0.f;
+        p.coef[2 * p.C + c] = 0.f;
+    } else if (seg == 0 && c < p.C) {
         for (int k = 1; k < 8; ++k) { s += s_s[k][cx]; q += s_q[k][cx]; }
         const double mean = p.mean[c], rstd = p.rstd[c], gam = p.gamma[c];
         const double dbeta = s;                       // sum g

@@ -20,6 +20,7 @@ struct DwParams {
     f16* y; int ldy;                // fwd: output;       dgrad: dx (rows of the INPUT space)
     const f16* dy; int lddy;        // dgrad/wgrad: output gradient
     int N, C, Cw, cls;
+    int Cwreal;                     // rows of w; weight channels [Cwreal, Cw) are zero padding
     int Ti, Hi, Wi, To, Ho, Wo;
     int kT, kH, kW, sT, sH, sW, pT, pH, pW;
     RowTile rt;                     // rows iterated: fwd/wgrad N*(So+cls), dgrad N*(Si+cls)
@@ -34,7 +35,7 @@ __device__ __forceinline__ void dw_stage_weights(const DwParams& p, float* s_w) 
     const int taps = p.kT * p.kH * p.kW;
     for (int i = threadIdx.x; i < taps * p.Cw; i += SF_THREADS) {
         const int cw = i / taps, tap = i % taps;
-        s_w[tap * p.Cw + cw] = p.w[i];
+        s_w[tap * p.Cw + cw] = cw < p.Cwreal ? p.w[i] : 0.f;
     }
 }
 
@@ -224,22 +225,31 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_kernel(DwParams p)
 
 // dw[cw][tap] (+)= scale * sum over blocks and over the C/Cw channel copies of wpart[blk][tap][c]
 struct DwFinalizeParams {
-    const float* wpart; int nblk, taps, C, Cw;
+    const float* wpart; int nblk, taps, C, Cw, Cwreal;
     float* dw; float scale; int accumulate;
 };
 __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_finalize_kernel(DwFinalizeParams p) {
-    const int idx = blockIdx.x * SF_THREADS + threadIdx.x;      // (tap, cw), cw fastest
-    if (idx >= p.taps * p.Cw) return;
-    const int tap = idx / p.Cw, cw = idx % p.Cw;
-    double s0 = 0.0, s1 = 0.0;
-    for (int c = cw; c < p.C; c += p.Cw) {
-        const float* src = p.wpart + (int64_t)tap * p.C + c;
+    // 32 outputs (tap, cw) per block x 8 segments of the (block, channel-copy) sum; fixed-order LDS fold
+    __shared__ double s_acc[8][32];
+    const int ox = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + ox;      // (tap, cw), cw fastest
+    const bool ok = idx < p.taps * p.Cw;
+    const int tap = ok ? idx / p.Cw : 0, cw = ok ? idx % p.Cw : 0;
+    double s = 0.0;
+    if (ok && cw < p.Cwreal) {
+        const int copies = p.C / p.Cw;
         const int64_t bs = (int64_t)p.taps * p.C;
-        int b = 0;
-        for (; b + 2 <= p.nblk; b += 2) { s0 += (double)src[b * bs]; s1 += (double)src[(b + 1) * bs]; }
-        if (b < p.nblk) s0 += (double)src[b * bs];
+        for (int i = seg; i < p.nblk * copies; i += 8) {
+            const int b = i / copies, cp = i % copies;
+            s += (double)p.wpart[b * bs + (int64_t)tap * p.C + cp * p.Cw + cw];
+        }
     }
-    float* dst = p.dw + (int64_t)cw * p.taps + tap;
-    const float v = (float)((s0 + s1) * p.scale);
-    *dst = p.accumulate ? *dst + v : v;
+    s_acc[seg][ox] = s;
+    __syncthreads();
+    if (seg == 0 && ok && cw < p.Cwreal) {
+        for (int k = 1; k < 8; ++k) s += s_acc[k][ox];
+        float* dst = p.dw + (int64_t)cw * p.taps + tap;
+        const float v = (float)(s * p.scale);
+        *dst = p.accumulate ? *dst + v : v;
+    }
 }

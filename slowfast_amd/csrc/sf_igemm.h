@@ -243,7 +243,7 @@ struct WgradParams {
 // dw[Co][Cw][taps] (PyTorch Conv3d weight layout) (+)= out_scale * sum_splits ws[s][co][tap*C + ci]
 struct WgradReduceParams {
     const float* ws;
-    int splits, Co, Co_pad, Kpad, Ktot;
+    int splits, Co, Co_pad, Kpad, Ktot;   // Co = rows of dw (real output channels)
     FastDiv fdC;
     float* dw;
     int Cw, taps;

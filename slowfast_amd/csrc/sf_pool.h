@@ -201,7 +201,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_cl_to_ncthw_kernel(const f16* x
 // (fp16, zero padded: ci >= Cw, k >= Ktot).
 struct PrepParams {
     const float* w;
-    int Co, Cw, Cp, taps;
+    int Co, Cow, Cw, Cp, taps;   // Cow = rows of w (real output channels), Co - Cow zero rows
     f16* wf; int ldf;
     f16* wd; int ldd;
 };
@@ -215,14 +215,14 @@ __global__ __launch_bounds__(SF_THREADS) void sf_prep_weights_kernel(PrepParams 
             const int co = (int)(idx / p.ldf), k = (int)(idx % p.ldf);
             const int tap = k / p.Cp, ci = k % p.Cp;
             float v = 0.f;
-            if (tap < p.taps && ci < p.Cw) v = p.w[((int64_t)co * p.Cw + ci) * p.taps + tap];
+            if (tap < p.taps && ci < p.Cw && co < p.Cow) v = p.w[((int64_t)co * p.Cw + ci) * p.taps + tap];
             p.wf[idx] = (f16)v;
         } else {
             const int64_t j = idx - nf;
             const int ci = (int)(j / p.ldd), k = (int)(j % p.ldd);
             const int tap = k / p.Co, co = k % p.Co;
             float v = 0.f;
-            if (tap < p.taps && ci < p.Cw) v = p.w[((int64_t)co * p.Cw + ci) * p.taps + tap];
+            if (tap < p.taps && ci < p.Cw && co < p.Cow) v = p.w[((int64_t)co * p.Cw + ci) * p.taps + tap];
             p.wd[j] = (f16)v;
         }
     }

@@ -334,51 +334,95 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_fwd_kernel(RelPosParams 
 }
 
 // backward of the above: dq[row][c] += sum_j drq[row][j] * table_j[c]  and per-block partial table gradients
-// dtab[r][c] += drq[row][j] * q[row][c] for r = index of table row j.  A block walks its rows in order; thread
-// (group, c) owns channel c of the rel_h rows (group 0) or of the rel_w and rel_t rows (group 1), so every LDS
-// accumulator has exactly one writer and the result is deterministic.  D <= 128.
+// dtab[r][c] += drq[row][j] * q[row][c] for r = index of table row j.  A block walks its rows in tiles of 32 (staged
+// in LDS); thread (group, c) owns channel c of the rel_h rows (group 0) or of the rel_w and rel_t rows (group 1),
+// so every LDS accumulator has exactly one writer and rows are visited in order: deterministic.  D <= 128.
 #define SF_RELPOS_MAX_TAB (240 * 96)
+#define SF_RELPOS_TILE 32
 __global__ __launch_bounds__(SF_THREADS) void sf_relpos_bwd_kernel(RelPosParams p) {
     __shared__ float s_tab[SF_RELPOS_MAX_TAB];
-    __shared__ float s_dr[64];
-    __shared__ float s_dq[128];
+    __shared__ float s_dr[SF_RELPOS_TILE][64];
+    __shared__ float s_q[SF_RELPOS_TILE][128];
+    __shared__ float s_dq[2][SF_RELPOS_TILE][128];
+    __shared__ int s_pos[SF_RELPOS_TILE][4];         // qt, qh, qw, skip (cls row or beyond the block's range)
+    __shared__ int s_idx[1024];                      // idx_h | idx_w | idx_t
     const int grp = threadIdx.x >> 7, c = threadIdx.x & 127;
     const int R = p.KH + p.KW + p.KT;
     const int TR = p.rows_h + p.rows_w + p.rows_t;
+    const int nih = p.qH * p.KH, niw = p.qW * p.KW, nit = p.qT * p.KT;
     for (int i = threadIdx.x; i < TR * p.D; i += SF_THREADS) s_tab[i] = 0.f;
+    for (int i = threadIdx.x; i < nih + niw + nit; i += SF_THREADS)
+        s_idx[i] = i < nih ? p.idx_h[i] : i < nih + niw ? p.idx_w[i - nih] : p.idx_t[i - nih - niw];
     const int total = p.B * p.Nq * p.heads;
     const int r0 = blockIdx.x * p.rows_per_block;
     int r1 = r0 + p.rows_per_block;
     if (r1 > total) r1 = total;
-    __syncthreads();
-    for (int row = r0; row < r1; ++row) {
-        uint32_t b, tok, head;
-        int qt, qh, qw;
-        bool is_cls;
-        relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
-        if (is_cls) continue;                       // block-uniform
-        if ((int)threadIdx.x < R) s_dr[threadIdx.x] = p.drq[(int64_t)row * R + threadIdx.x];
-        __syncthreads();
-        const f16* qrow = p.q + ((int64_t)b * p.Nq + tok) * p.ldq + head * p.D;
-        f16* dqrow = p.dq + ((int64_t)b * p.Nq + tok) * p.lddq + head * p.D;
-        float acc = 0.f;
-        if (c < p.D) {
-            const float qv = (float)qrow[c];
-            const int j0 = grp == 0 ? 0 : p.KH, j1 = grp == 0 ? p.KH : R;
-            for (int j = j0; j < j1; ++j) {
-                int r;
-                const float* tab;
-                if (j < p.KH) { r = p.idx_h[qh * p.KH + j]; tab = p.rel_h + (int64_t)r * p.D; }
-                else if (j < p.KH + p.KW) { r = p.idx_w[qw * p.KW + (j - p.KH)]; tab = p.rel_w + (int64_t)r * p.D; r += p.rows_h; }
-                else { r = p.idx_t[qt * p.KT + (j - p.KH - p.KW)]; tab = p.rel_t + (int64_t)r * p.D; r += p.rows_h + p.rows_w; }
-                const float d = s_dr[j];
-                acc += d * tab[c];
-                s_tab[r * p.D + c] += d * qv;
+    for (int base = r0; base < r1; base += SF_RELPOS_TILE) {
+        __syncthreads();                             // previous tile fully consumed (and the tables initialised)
+        // ---- stage the tile: positions, drq rows, q rows
+        if (threadIdx.x < SF_RELPOS_TILE) {
+            const int row = base + threadIdx.x;
+            int qt = 0, qh = 0, qw = 0;
+            bool is_cls = true;
+            if (row < r1) {
+                uint32_t b, tok, head;
+                relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
             }
-            if (grp == 1) s_dq[c] = acc;
+            s_pos[threadIdx.x][0] = qt; s_pos[threadIdx.x][1] = qh; s_pos[threadIdx.x][2] = qw;
+            s_pos[threadIdx.x][3] = (row >= r1 || is_cls) ? 1 : 0;
+        }
+        for (int i = threadIdx.x; i < SF_RELPOS_TILE * R; i += SF_THREADS) {
+            const int r = i / R, j = i % R;
+            s_dr[r][j] = base + r < r1 ? p.drq[(int64_t)(base + r) * R + j] : 0.f;
+        }
+        for (int i = threadIdx.x; i < SF_RELPOS_TILE * p.D; i += SF_THREADS) {
+            const int r = i / p.D, cc = i % p.D;
+            float v = 0.f;
+            if (base + r < r1) {
+                uint32_t b, tok, head;
+                int qt, qh, qw;
+                bool is_cls;
+                relpos_row_decode(p, (uint32_t)(base + r), b, tok, head, qt, qh, qw, is_cls);
+                v = (float)p.q[((int64_t)b * p.Nq + tok) * p.ldq + head * p.D + cc];
+            }
+            s_q[r][cc] = v;
         }
         __syncthreads();
-        if (grp == 0 && c < p.D) dqrow[c] = (f16)((float)dqrow[c] + acc + s_dq[c]);
+        // ---- accumulate
+        if (c < p.D) {
+            const int j0 = grp == 0 ? 0 : p.KH, j1 = grp == 0 ? p.KH : R;
+            for (int r = 0; r < SF_RELPOS_TILE; ++r) {
+                float acc = 0.f;
+                if (!s_pos[r][3]) {
+                    const int qt = s_pos[r][0], qh = s_pos[r][1], qw = s_pos[r][2];
+                    const float qv = s_q[r][c];
+                    for (int j = j0; j < j1; ++j) {
+                        int ri;
+                        const float* tab;
+                        if (j < p.KH) { ri = s_idx[qh * p.KH + j]; tab = p.rel_h + (int64_t)ri * p.D; }
+                        else if (j < p.KH + p.KW) { ri = s_idx[nih + qw * p.KW + (j - p.KH)]; tab = p.rel_w + (int64_t)ri * p.D; ri += p.rows_h; }
+                        else { ri = s_idx[nih + niw + qt * p.KT + (j - p.KH - p.KW)]; tab = p.rel_t + (int64_t)ri * p.D; ri += p.rows_h + p.rows_w; }
+                        const float d = s_dr[r][j];
+                        acc += d * tab[c];
+                        s_tab[ri * p.D + c] += d * qv;
+                    }
+                }
+                s_dq[grp][r][c] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- dq += table terms (all threads, coalesced over channels)
+        for (int i = threadIdx.x; i < SF_RELPOS_TILE * p.D; i += SF_THREADS) {
+            const int r = i / p.D, cc = i % p.D;
+            if (base + r < r1 && !s_pos[r][3]) {
+                uint32_t b, tok, head;
+                int qt, qh, qw;
+                bool is_cls;
+                relpos_row_decode(p, (uint32_t)(base + r), b, tok, head, qt, qh, qw, is_cls);
+                f16* dst = p.dq + ((int64_t)b * p.Nq + tok) * p.lddq + head * p.D + cc;
+                *dst = (f16)((float)*dst + s_dq[0][r][cc] + s_dq[1][r][cc]);
+            }
+        }
     }
     __syncthreads();
     float* o = p.dtab_part + (int64_t)blockIdx.x * TR * p.D;
@@ -482,7 +526,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_softmax_fwd_kernel(SoftmaxParam
 // over the keys that share kh / kw / kt).
 template <int NSM>
 __global__ __launch_bounds__(SF_THREADS) void sf_softmax_bwd_kernel(SoftmaxParams p) {
-    __shared__ float s_dr[4][64];
+    __shared__ float s_ds[4][NSM * 512 + 8];     // the wave's unscaled dS row, for the per-(kh | kw | kt) sums
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int base = blockIdx.x * 4; base < p.rows; base += gridDim.x * 4) {
         const int row = base + wave;
@@ -491,8 +535,6 @@ __global__ __launch_bounds__(SF_THREADS) void sf_softmax_bwd_kernel(SoftmaxParam
         const bool has_bias = p.drq != nullptr && rowok;
         int64_t rr = 0;
         if (has_bias) rr = softmax_rq_row(p, (uint32_t)row, qcls);
-        s_dr[wave][lane] = 0.f;
-        __syncthreads();
         f16* drow = p.s + (int64_t)(rowok ? row : 0) * p.lds;
         const f16* prow = p.prob + (int64_t)(rowok ? row : 0) * p.lds;
         float pv[NSM][8], dv[NSM][8];
@@ -520,21 +562,31 @@ __global__ __launch_bounds__(SF_THREADS) void sf_softmax_bwd_kernel(SoftmaxParam
                 for (int e = 0; e < 8; ++e) {
                     const float ds = pv[s][e] * (dv[s][e] - dot);
                     o[e] = (f16)(ds * p.scale);
-                    const int k = k0 + e;
-                    if (has_bias && !qcls && k >= p.cls && k < p.Nk) {
-                        uint32_t pos = (uint32_t)(k - p.cls), r, kw, kh, kt;
-                        fd_divmod(pos, p.fdkW, r, kw);
-                        fd_divmod(r, p.fdkH, kt, kh);
-                        atomicAdd(&s_dr[wave][kh], ds);
-                        atomicAdd(&s_dr[wave][p.KH + kw], ds);
-                        atomicAdd(&s_dr[wave][p.KH + p.KW + kt], ds);
-                    }
+                    s_ds[wave][k0 + e] = ds;
                 }
                 st16(drow + k0, o);
             }
         }
         __syncthreads();
-        if (has_bias && lane < p.R) p.drq[rr * p.R + lane] = s_dr[wave][lane];
+        if (has_bias && lane < p.R) {
+            // lane j sums the keys (kt, kh, kw) that share its coordinate, in a fixed order
+            float acc = 0.f;
+            if (!qcls) {
+                const float* d = s_ds[wave] + p.cls;
+                if (lane < p.KH) {
+                    for (int kt = 0; kt < p.kT; ++kt)
+                        for (int kw = 0; kw < p.kW; ++kw) acc += d[(kt * p.kH + lane) * p.kW + kw];
+                } else if (lane < p.KH + p.KW) {
+                    const int kw = lane - p.KH;
+                    for (int kt = 0; kt < p.kT; ++kt)
+                        for (int kh = 0; kh < p.kH; ++kh) acc += d[(kt * p.kH + kh) * p.kW + kw];
+                } else {
+                    const int kt = lane - p.KH - p.KW;
+                    for (int i = 0; i < p.kH * p.kW; ++i) acc += d[kt * p.kH * p.kW + i];
+                }
+            }
+            p.drq[rr * p.R + lane] = acc;
+        }
         __syncthreads();
     }
 }

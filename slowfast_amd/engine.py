@@ -100,7 +100,8 @@ class ConvUnit:
         w = self.conv.weight
         key = (w.data_ptr(), w._version, geom.Ci, w.device)
         if (fresh and FORCE_WEIGHT_PREP) or self._wkey != key:
-            self._w = ops.prep_weights(w.detach(), geom, need_dgrad=(geom.Cw == geom.Ci))
+            # no data-gradient operand for the RGB stems (3 of 8 channels real); channel padding (54 -> 56) keeps it
+            self._w = ops.prep_weights(w.detach(), geom, need_dgrad=(geom.Ci - geom.Cw < 8))
             self._wkey = key
         return self._w
 
@@ -117,7 +118,7 @@ class ConvUnit:
         track = bn.track_running_stats and training
         st = ops.bn_finalize(part, geom.out_rows, bn.weight, bn.bias, bn.running_mean if track or not use_batch_stats else None,
                              bn.running_var if track or not use_batch_stats else None, bn.momentum, bn.eps,
-                             training=use_batch_stats)
+                             training=use_batch_stats, C=geom.Co)
         return y, BNState(*st)
 
     def backward(self, x, in_affine, dy, need_dx, resid=None):

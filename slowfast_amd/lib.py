@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConvDesc(Structure):
@@ -20,7 +20,7 @@ class ConvDesc(Structure):
 
     _fields_ = [(n, c_int32) for n in (
         "N", "Ci", "Ti", "Hi", "Wi", "Co", "To", "Ho", "Wo", "kT", "kH", "kW", "sT", "sH", "sW",
-        "pT", "pH", "pW", "dT", "dH", "dW", "Cw", "ldx", "ldy")]
+        "pT", "pH", "pW", "dT", "dH", "dW", "Cw", "ldx", "ldy", "Cow")]
 
 
 class DwDesc(Structure):
@@ -28,7 +28,7 @@ class DwDesc(Structure):
 
     _fields_ = [(n, c_int32) for n in (
         "N", "C", "Cw", "cls", "Ti", "Hi", "Wi", "To", "Ho", "Wo", "kT", "kH", "kW", "sT", "sH", "sW",
-        "pT", "pH", "pW", "ldx", "ldy")]
+        "pT", "pH", "pW", "ldx", "ldy", "Cwreal")]
 
 
 class AttnDesc(Structure):
@@ -51,11 +51,11 @@ _SIGNATURES = {
     "sf_conv_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P]),
     "sf_conv_wgrad_workspace": (c_int64, [POINTER(ConvDesc)]),
     "sf_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _F, _F, c_int, _P, _F, c_float, c_int, _P, c_int64, _P]),
-    "sf_bn_finalize": (c_int, [_F, c_int32, c_int32, c_float, _F, _F, _F, _F, c_float, c_float, _F, _F, _F, _F, _P]),
+    "sf_bn_finalize": (c_int, [_F, c_int32, c_int32, c_int32, c_float, _F, _F, _F, _F, c_float, c_float, _F, _F, _F, _F, _P]),
     "sf_bn_act": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, _P, c_int32, _F, _F, c_int, _P, c_int32, _P]),
     "sf_bn_bwd_blocks": (c_int, [c_int64, c_int32]),
     "sf_bn_bwd_reduce": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, _F, _F, c_int, _F, _P]),
-    "sf_bn_bwd_finalize": (c_int, [_F, c_int32, c_int32, c_float, _F, _F, _F, c_float, _F, _F, c_int, _F, _P]),
+    "sf_bn_bwd_finalize": (c_int, [_F, c_int32, c_int32, c_int32, c_float, _F, _F, _F, c_float, _F, _F, c_int, _F, _P]),
     "sf_bn_bwd_apply": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, _F, _F, c_int, _F, _P,
                                 c_int32, _P, c_int32, _P]),
     "sf_pool_fwd": (c_int, [c_int32] * 11 + [_P, c_int32, _F, _F, c_int, _P, c_int32, _P, c_int32, _P]),
@@ -86,6 +86,14 @@ _SIGNATURES = {
     "sf_softmax_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, c_float, _F, _P]),
     "sf_softmax_bwd": (c_int, [POINTER(AttnDesc), _P, _P, c_int32, c_float, _F, _P]),
     "sf_transpose_heads": (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    "sf_sample_chunks": (c_int, [c_int64, c_int32]),
+    "sf_sample_mean": (c_int, [c_int32, c_int64, c_int32, _P, c_int32, _F, _F, c_int, _F, _F, _P]),
+    "sf_se_gate_fwd": (c_int, [c_int32, c_int32, c_int32, c_int32, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "sf_gate_act_fwd": (c_int, [c_int32, c_int64, c_int32, _P, c_int32, _F, _F, _F, c_int, _P, c_int32, _P]),
+    "sf_gate_grad": (c_int, [c_int32, c_int64, c_int32, _P, c_int32, _F, _F, _P, c_int32, _F, c_int, _F, _F, _P]),
+    "sf_se_gate_bwd": (c_int, [c_int32, c_int32, c_int32, c_int32, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "sf_outer_sum": (c_int, [_F, c_int32, _F, c_int32, c_int32, c_int32, c_int32, _F, c_float, c_int, _P]),
+    "sf_gate_act_bwd": (c_int, [c_int32, c_int64, c_int32, _P, c_int32, _F, _F, _F, c_int, _P, c_int32, _F, _P, c_int32, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

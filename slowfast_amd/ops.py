@@ -126,7 +126,8 @@ class ConvGeom:
 
     def __init__(self, in_shape, Co, kernel, stride=1, padding=0, dilation=1, Cw=None, out_dims=None):
         self.N, self.Ci, self.Ti, self.Hi, self.Wi = in_shape
-        self.Co = Co
+        self.Cow = Co                       # channels of the fp32 weight on the output side
+        self.Co = (Co + 7) // 8 * 8         # channels of the output activation buffer (zero padded)
         self.k, self.s, self.p, self.d = _triple(kernel), _triple(stride), _triple(padding), _triple(dilation)
         self.Cw = self.Ci if Cw is None else Cw
         self.To, self.Ho, self.Wo = [
@@ -162,12 +163,12 @@ class ConvGeom:
 
     def desc(self, ldx, ldy):
         return ConvDesc(self.N, self.Ci, self.Ti, self.Hi, self.Wi, self.Co, self.To, self.Ho, self.Wo,
-                        *self.k, *self.s, *self.p, *self.d, self.Cw, ldx, ldy)
+                        *self.k, *self.s, *self.p, *self.d, self.Cw, ldx, ldy, self.Cow)
 
 
 def prep_weights(w, geom, need_dgrad=True):
     """fp32 Conv3d weight -> fp16 GEMM operands (forward [Co][ldf], dgrad [Ci][ldd])."""
-    assert w.dtype == torch.float32 and tuple(w.shape) == (geom.Co, geom.Cw) + geom.k, (w.shape, geom.Co, geom.Cw)
+    assert w.dtype == torch.float32 and tuple(w.shape) == (geom.Cow, geom.Cw) + geom.k, (w.shape, geom.Cow, geom.Cw)
     w = w.contiguous()
     wf = torch.empty((geom.Co, geom.ldf), dtype=_f16, device=w.device)
     wd = torch.empty((geom.Ci, geom.ldd), dtype=_f16, device=w.device) if need_dgrad else None
@@ -233,7 +234,7 @@ def _workspace(device, nbytes):
 def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True):
     """dw (+)= out_scale * d(loss)/d(weight); dw is an fp32 tensor shaped like the Conv3d weight."""
     assert tuple(x.shape) == geom.in_shape and tuple(dy.shape) == geom.out_shape
-    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == geom.Co * geom.Cw * geom.taps
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == geom.Cow * geom.Cw * geom.taps
     sc, sh, relu = _affine(in_affine)
     lib = get_lib()
     d = geom.desc(cl_ld(x), cl_ld(dy))
@@ -247,13 +248,15 @@ def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True):
 
 
 # ------------------------------------------------------------------------------------------------
-def bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum, eps, training=True):
-    """Per-tile sums -> (scale, shift, mean, rstd); updates running statistics in training mode."""
-    C = gamma.numel()
+def bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum, eps, training=True, C=None):
+    """Per-tile sums -> (scale, shift, mean, rstd); updates running statistics in training mode.  ``C`` = channel
+    count of the (zero padded) activation buffer when it exceeds the parameter length."""
+    Creal = gamma.numel()
+    C = C or (part.shape[2] if part is not None else Creal)
     dev = gamma.device
     scale, shift, mean, rstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
     nblk = part.shape[0] if training else 0
-    get_lib().call("sf_bn_finalize", _ptr(part) if training else None, nblk, C, float(count), gamma.data_ptr(),
+    get_lib().call("sf_bn_finalize", _ptr(part) if training else None, nblk, C, Creal, float(count), gamma.data_ptr(),
                    beta.data_ptr(), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
                    scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream(gamma))
     return scale, shift, mean, rstd
@@ -290,7 +293,7 @@ def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None
     lib.call("sf_bn_bwd_reduce", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
              relu_self, part.data_ptr(), s, work=dict(bytes=2.0 * y.numel() * (2 + int(zmask is not None))))
     coef = torch.empty((3, C), dtype=torch.float32, device=y.device)
-    lib.call("sf_bn_bwd_finalize", part.data_ptr(), nblk, C, float(M), gamma.data_ptr(), mean.data_ptr(),
+    lib.call("sf_bn_bwd_finalize", part.data_ptr(), nblk, C, gamma.numel(), float(M), gamma.data_ptr(), mean.data_ptr(),
              rstd.data_ptr(), float(inv_loss_scale), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
              coef.data_ptr(), s)
     dy = cl_empty(y.shape, y.device) if out is None else out

@@ -41,7 +41,7 @@ MODEL_REGISTRY = Registry("MODEL")
 def build_model(cfg, gpu_id=None):
     """Same contract as slowfast/models/build.py:22-81 (minus the DDP wrap, replaced by
     slowfast_amd.data_parallel.GradReducer when torch.distributed is initialised)."""
-    from . import mvit, video_models  # noqa: F401  (registers the model classes)
+    from . import mvit, video_models, x3d  # noqa: F401  (registers the model classes)
     if torch.cuda.is_available():
         assert cfg.NUM_GPUS <= torch.cuda.device_count(), "Cannot use more GPU devices than available"
     model = MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)

@@ -38,6 +38,7 @@ class BottleneckTransform(nn.Module):
         return x
 
 
+BottleneckTransform._block_fn = ResBlockFn
 _TRANS = {"bottleneck_transform": BottleneckTransform}
 
 
@@ -68,7 +69,7 @@ class ResBlock(nn.Module):
                                   stride_1x1=stride_1x1, inplace_relu=inplace_relu, dilation=dilation,
                                   norm_module=norm_module, block_idx=block_idx)
         self.relu = nn.ReLU(inplace_relu)
-        self._fused = isinstance(self.branch2, BottleneckTransform)
+        self._block_fn = getattr(type(self.branch2), "_block_fn", None)   # fused schedule of this transform type
 
     @property
     def _param_list(self):
@@ -78,8 +79,8 @@ class ResBlock(nn.Module):
         return plist
 
     def forward(self, x):
-        assert self._fused
-        return ResBlockFn.apply(x, self, *self._param_list)
+        assert self._block_fn is not None, f"no fused schedule for {type(self.branch2).__name__}"
+        return self._block_fn.apply(x, self, *self._param_list)
 
 
 class ResStage(nn.Module):

@@ -174,8 +174,9 @@ def gelu_bwd(h, da):
 class DwGeom:
     """Depthwise Conv3d geometry over rows (n, [cls], t, h, w) with C channels (C % Cw == 0)."""
 
-    def __init__(self, N, C, Cw, thw, kernel, stride, padding, cls):
+    def __init__(self, N, C, Cw, thw, kernel, stride, padding, cls, Cw_real=None):
         self.N, self.C, self.Cw, self.cls = N, C, Cw, int(bool(cls))
+        self.Cw_real = Cw if Cw_real is None else Cw_real    # rows of the fp32 weight (X3D widths 54, 108 pad to 56, 112)
         self.thw, self.k, self.s, self.p = tuple(thw), tuple(kernel), tuple(stride), tuple(padding)
         self.out_thw = tuple((i + 2 * p - k) // s + 1 for i, k, s, p in zip(self.thw, self.k, self.s, self.p))
         self.taps = self.k[0] * self.k[1] * self.k[2]
@@ -184,14 +185,15 @@ class DwGeom:
         self.ws_bytes = None
 
     def desc(self, ldx, ldy):
-        return DwDesc(self.N, self.C, self.Cw, self.cls, *self.thw, *self.out_thw, *self.k, *self.s, *self.p, ldx, ldy)
+        return DwDesc(self.N, self.C, self.Cw, self.cls, *self.thw, *self.out_thw, *self.k, *self.s, *self.p, ldx, ldy,
+                      self.Cw_real)
 
 
 def dwconv_fwd(x, w, geom, out=None, stats=False):
     """x: token tensor with geom.rows_in rows of geom.C channels; w: fp32 nn.Conv3d weight [Cw,1,kT,kH,kW]."""
     M, C, ldx = rows_pitch(x)
     assert M == geom.rows_in and C == geom.C and w.dtype == torch.float32 and w.is_contiguous()
-    assert w.numel() == geom.Cw * geom.taps
+    assert w.numel() == geom.Cw_real * geom.taps
     y = torch.empty((geom.rows_out, C), dtype=_f16, device=x.device) if out is None else out
     Mo, Co, ldy = rows_pitch(y)
     assert Mo == geom.rows_out and Co == C
@@ -218,7 +220,7 @@ def dwconv_dgrad(dy, w, geom, out=None):
 def dwconv_wgrad(x, dy, geom, dw, zero_first=True, out_scale=1.0):
     _, _, ldx = rows_pitch(x)
     _, _, lddy = rows_pitch(dy)
-    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == geom.Cw * geom.taps
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == geom.Cw_real * geom.taps
     lib = get_lib()
     d = geom.desc(ldx, lddy)
     if geom.ws_bytes is None:

@@ -170,32 +170,36 @@ def check_fuse(device, dim_in, ratio, kernel, alpha, shape_fast, seed=9):
 
 
 def check_bottleneck_alone(device, shape, seed=11):
+    """BottleneckTransform.forward on its own (a -> b -> c with every unit materialised)."""
+    import torch.nn.functional as F
     torch.manual_seed(seed)
     t = BottleneckTransform(shape[1], 32, 3, 1, 8, 1)
     sd = _load(t, seed)
     t = t.to(device).train()
     x = torch.randn(shape).half().float()
-    # oracle: identity-free evaluation of a -> b -> c through the block function with a zero shortcut is not
-    # available, so restate with torch modules holding the same parameters
-    import torch.nn as nn
-    import torch.nn.functional as F
-    ref = nn.ModuleDict({k: v for k, v in [("a", nn.Conv3d(shape[1], 8, (3, 1, 1), padding=(1, 0, 0), bias=False)),
-                                           ("a_bn", nn.BatchNorm3d(8)),
-                                           ("b", nn.Conv3d(8, 8, (1, 3, 3), padding=(0, 1, 1), bias=False)),
-                                           ("b_bn", nn.BatchNorm3d(8)), ("c", nn.Conv3d(8, 32, 1, bias=False)),
-                                           ("c_bn", nn.BatchNorm3d(32))]})
-    ref.load_state_dict(sd)
-    ref.train()
-    xr = x.clone().requires_grad_(True)
-    o = ref["c_bn"](ref["c"](F.relu(ref["b_bn"](ref["b"](F.relu(ref["a_bn"](ref["a"](xr))))))))
-    dout = torch.randn(o.shape).half().float()
-    o.backward(dout)
+    dout = torch.randn((shape[0], 32) + tuple(shape[2:])).half().float()
+
+    def body(p, st):
+        xr = x.clone().requires_grad_(True)
+        y = video_ref._conv(xr, p["t.a.weight"], None, 1, (1, 0, 0))
+        y = video_ref._STORE(F.relu(video_ref._bn(y, p, "t.a_bn", True, st)))
+        y = video_ref._conv(y, p["t.b.weight"], None, 1, (0, 1, 1))
+        y = video_ref._STORE(F.relu(video_ref._bn(y, p, "t.b_bn", True, st)))
+        y = video_ref._conv(y, p["t.c.weight"])
+        o = video_ref._STORE(video_ref._bn(y, p, "t.c_bn", True, st))
+        o.backward(dout)
+        return {"out": o.detach(), "dx": xr.grad}
+
+    ref, rg, st, yard = _oracle_twice(_Case(sd, "t.", body))
     xc = host_to_cl(x, device).requires_grad_(True)
     out = t(xc)
     out.backward(host_to_cl(dout, device))
-    errs = {"out": rel(cl_to_host(out), o.detach()), "dx": rel(cl_to_host(xc.grad), xr.grad)}
-    for (k, prm), (_, q) in zip(t.named_parameters(), ref.named_parameters()):
-        errs["grad:" + k] = rel(prm.grad.cpu(), q.grad)
-    # every unit materialises its activation in fp16 here (one extra rounding per layer vs the fused block)
-    bad = {k: v for k, v in errs.items() if v > 5 * TOL}
+    # every unit materialises its activation in fp16 here (one extra rounding per layer vs the fused block);
+    # the mask of interest for flips is the inner ReLUs, which the output does not expose: use the loose bound
+    got = {"out": cl_to_host(out), "dx": cl_to_host(xc.grad)}
+    errs = {k: rel(got[k], ref[k]) for k in ref}
+    for k, prm in t.named_parameters():
+        errs["grad:t." + k] = rel(prm.grad.cpu(), rg["t." + k])
+    bad = {k: (v, yard.get(k)) for k, v in errs.items()
+           if v > max(5 * TOL, YARD * yard.get(k, 0.0), TOL_FLIPPED if k != "out" else 0.0)}
     assert not bad, bad

@@ -228,7 +228,7 @@ def check_bn_finalize_long(device, nblk, C, seed=0):
     coef = torch.empty((3, C), device=device)
     pd = part.clone().to(device)
     stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None
-    get_lib().call("sf_bn_bwd_finalize", pd.data_ptr(), nblk, C, count, gamma.to(device).data_ptr(), m.data_ptr(),
+    get_lib().call("sf_bn_bwd_finalize", pd.data_ptr(), nblk, C, C, count, gamma.to(device).data_ptr(), m.data_ptr(),
                    r.data_ptr(), 1.0, dgamma.data_ptr(), dbeta.data_ptr(), 0, coef.data_ptr(), stream)
     sg, sgy = s.double().sum(0), q.double().sum(0)
     assert_close("bwd dbeta", dbeta.cpu(), sg.float(), 1e-6)

@@ -145,3 +145,14 @@ def test_mvit_full_size_properties(gpu):
         assert torch.isfinite(loss) and abs(float(loss) - 5.99) < 0.5
         assert float((logits[:2] - logits[2:]).abs().max()) == 0.0
     assert abs(norms[0] - norms[1]) < 5e-3 * norms[1], norms
+
+
+@pytest.mark.parametrize("name", ["x3d_tiny", "x3d_m_mid"])
+def test_x3d_matches_reference(gpu, name):
+    """X3D through the depthwise / SE / Swish kernels vs the oracle and the unmodified reference's golden numbers."""
+    rep = {}
+    try:
+        mc.check_engine(name, gpu, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.1,
+                        tol_global=1e-2, report=rep)
+    finally:
+        print(name, rep.get(name))

@@ -18,3 +18,10 @@ def test_mvit_engine_matches_oracle(sim):
     """4-block MViTv2 miniature (q pooling, dimension change, k/v pooling, relative positions, residual pooling,
     cls token) through every token-space kernel, forward and backward."""
     mc.check_engine("mvit_tiny", sim, tol_logits=1e-2, tol_loss=2e-3, tol_gnorm=3e-3, tol_param=0.1, tol_global=2e-2)
+
+
+def test_x3d_engine_matches_oracle(sim):
+    """X3D (depth factor 1): W-pair-folded stem conv, depthwise (5,1,1) and 3x3x3 stencils with BatchNorm statistics
+    epilogues, SE squeeze/gate, gate*BN->Swish, channel widths 54/108 padded to 56/112, X3DHead."""
+    mc.check_engine("x3d_tiny", sim, tol_logits=1e-2, tol_loss=2e-3, tol_gnorm=2e-2, tol_param=0.5, tol_global=0.3,
+                    tol_stats=5e-3)
