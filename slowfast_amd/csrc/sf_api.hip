@@ -682,10 +682,43 @@ static int fill_dw(DwParams& p, const sf_dw_desc* d, bool rows_are_outputs, int 
     return 0;
 }
 static const int kDwFwdBlocks = 2048, kDwWgradBlocks = 256;
+
+// W-blocked kernels: (kW, sW) in {(3,1), (3,2), (1,1)} with pW = kW/2; returns 0 when the geometry is not covered
+static int dw_blocked_kind(const sf_dw_desc* d) {
+    if (getenv("SF_DW_GENERIC") && atoi(getenv("SF_DW_GENERIC")) != 0) return 0;
+    if (d->pW != d->kW / 2) return 0;
+    if (d->kW == 3 && d->sW == 1) return 1;
+    if (d->kW == 3 && d->sW == 2) return 2;
+    if (d->kW == 1 && d->sW == 1 && d->kT * d->kH * d->Cw <= 3072) return 3;
+    return 0;
+}
+// re-plan the RowTile over line groups (4 columns each) of the iterated space + the cls items
+static void dw_block_plan(DwParams& p, DwBlockIdx& bi, const sf_dw_desc* d, bool rows_are_outputs, int max_blocks, dim3& grid) {
+    const int T = rows_are_outputs ? d->To : d->Ti, H = rows_are_outputs ? d->Ho : d->Hi, W = rows_are_outputs ? d->Wo : d->Wi;
+    bi.WG = cdiv(W, SF_DW_WB);
+    bi.fdWG = make_fastdiv(bi.WG); bi.fdH = make_fastdiv(H); bi.fdT = make_fastdiv(T);
+    bi.groups = (int64_t)d->N * T * H * bi.WG;
+    const int64_t items = bi.groups + (p.cls ? d->N : 0);
+    p.rt = make_rowtile(items, d->C, max_blocks, grid);
+}
+#define SF_DW_SMALL_W 3072
+#define SF_DW_DISPATCH(kind, KERNEL, grid, s, p, bi)                                                                    \
+    do {                                                                                                                  \
+        const bool small_w = (p).kT * (p).kH * (p).kW * (p).Cw <= SF_DW_SMALL_W;                                        \
+        if ((kind) == 1 && small_w) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+        else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_MAX_W>), grid, dim3(SF_THREADS), 0, s, p, bi);     \
+        else if ((kind) == 2 && small_w) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+        else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_MAX_W>), grid, dim3(SF_THREADS), 0, s, p, bi);     \
+        else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, s, p, bi);                    \
+    } while (0)
 extern "C" int sf_dwconv_fwd_blocks(const sf_dw_desc* d) {
     DwParams p;
     dim3 grid;
     if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
+    if (dw_blocked_kind(d)) {
+        DwBlockIdx bi;
+        dw_block_plan(p, bi, d, true, kDwFwdBlocks, grid);
+    }
     return (int)grid.x;
 }
 extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w, void* y, float* stat_part,
@@ -695,7 +728,14 @@ extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w,
     if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
     REQUIRE(x && w && y, "sf_dwconv_fwd: null pointer");
     p.x = (const f16*)x; p.ldx = d->ldx; p.w = w; p.y = (f16*)y; p.ldy = d->ldy; p.stat_part = stat_part;
-    hipLaunchKernelGGL(sf_dwconv_fwd_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    const int kind = dw_blocked_kind(d);
+    if (kind) {
+        DwBlockIdx bi;
+        dw_block_plan(p, bi, d, true, kDwFwdBlocks, grid);
+        SF_DW_DISPATCH(kind, sf_dwconv_fwd_blocked_kernel, grid, (hipStream_t)stream, p, bi);
+    } else {
+        hipLaunchKernelGGL(sf_dwconv_fwd_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    }
     return check_launch("dwconv_fwd");
 }
 extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float* w, void* dx, sf_stream_t stream) {
@@ -704,13 +744,24 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
     if (fill_dw(p, d, false, 8192, grid)) return -1;
     REQUIRE(dy && w && dx, "sf_dwconv_dgrad: null pointer");
     p.dy = (const f16*)dy; p.lddy = d->ldy; p.w = w; p.y = (f16*)dx; p.ldy = d->ldx;
-    hipLaunchKernelGGL(sf_dwconv_dgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    const int kind = dw_blocked_kind(d);
+    if (kind) {
+        DwBlockIdx bi;
+        dw_block_plan(p, bi, d, false, 8192, grid);
+        SF_DW_DISPATCH(kind, sf_dwconv_dgrad_blocked_kernel, grid, (hipStream_t)stream, p, bi);
+    } else {
+        hipLaunchKernelGGL(sf_dwconv_dgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    }
     return check_launch("dwconv_dgrad");
 }
 extern "C" int64_t sf_dwconv_wgrad_workspace(const sf_dw_desc* d) {
     DwParams p;
     dim3 grid;
     if (fill_dw(p, d, true, kDwWgradBlocks, grid)) return -1;
+    if (dw_blocked_kind(d)) {
+        DwBlockIdx bi;
+        dw_block_plan(p, bi, d, true, kDwWgradBlocks, grid);
+    }
     return (int64_t)grid.x * d->kT * d->kH * d->kW * d->C * 4;
 }
 extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* dy, float* dw, float out_scale,
@@ -720,11 +771,15 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
     if (fill_dw(p, d, true, kDwWgradBlocks, grid)) return -1;
     REQUIRE(x && dy && dw && workspace, "sf_dwconv_wgrad: null pointer");
     const int taps = d->kT * d->kH * d->kW;
+    const int kind = dw_blocked_kind(d);
+    DwBlockIdx bi;
+    if (kind) dw_block_plan(p, bi, d, true, kDwWgradBlocks, grid);
     REQUIRE(workspace_bytes >= (int64_t)grid.x * taps * d->C * 4, "sf_dwconv_wgrad: workspace too small");
     REQUIRE(grid.y == 1, "sf_dwconv_wgrad: C > 2048 is not supported");
     p.x = (const f16*)x; p.ldx = d->ldx; p.dy = (const f16*)dy; p.lddy = d->ldy; p.wpart = (float*)workspace;
     grid.z = d->kT;
-    hipLaunchKernelGGL(sf_dwconv_wgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    if (kind) SF_DW_DISPATCH(kind, sf_dwconv_wgrad_blocked_kernel, grid, (hipStream_t)stream, p, bi);
+    else hipLaunchKernelGGL(sf_dwconv_wgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     if (check_launch("dwconv_wgrad")) return -1;
     DwFinalizeParams f;
     f.wpart = (const float*)workspace; f.nblk = grid.x; f.taps = taps; f.C = d->C; f.Cw = d->Cw;
@@ -779,6 +834,7 @@ extern "C" int sf_relpos_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, 
     REQUIRE(q && rel_h && rel_w && rel_t && idx_h && idx_w && idx_t && drq && dq && dtab_part, "sf_relpos_bwd: null pointer");
     REQUIRE((d->rows_h + d->rows_w + d->rows_t) * d->D <= SF_RELPOS_MAX_TAB, "sf_relpos_bwd: tables exceed the LDS stage");
     REQUIRE(d->qH * d->kH + d->qW * d->kW + d->qT * d->kT <= 1024, "sf_relpos_bwd: index tables exceed the LDS stage");
+    REQUIRE(d->kH <= 16 && d->kW <= 16 && d->kT <= 16, "sf_relpos_bwd: at most 16 keys per axis");
     p.q = (const f16*)q; p.ldq = ldq; p.rel_h = rel_h; p.rel_w = rel_w; p.rel_t = rel_t;
     p.idx_h = idx_h; p.idx_w = idx_w; p.idx_t = idx_t; p.drq = drq; p.dq = (f16*)dq; p.lddq = lddq;
     p.dtab_part = dtab_part;

@@ -223,6 +223,269 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_kernel(DwParams p)
     }
 }
 
+// ================================================================================================
+// W-blocked variants for the common geometries (kW, sW) in {(3,1), (3,2), (1,1)} with pW = kW/2: a thread produces
+// WB = 4 consecutive columns of one (n, t, h) line for its 8 channels, so every input column loaded for a (kt, kh)
+// plane is reused by up to kW outputs and the per-tap address arithmetic is shared (2-3x fewer VALU operations per
+// byte than the one-output-per-thread kernels above, which remain the fallback for other strides).
+// Items iterated by the RowTile map: N*T*H*ceil(W/4) line groups of the ITERATED space, followed by N cls items.
+#define SF_DW_WB 4
+struct DwBlockIdx {
+    FastDiv fdWG, fdH, fdT;
+    int WG;
+    int64_t groups;
+};
+__device__ __forceinline__ bool dwb_decode(const DwBlockIdx& bi, uint32_t item, uint32_t& n, int& t, int& h, int& w0) {
+    if ((int64_t)item >= bi.groups) { n = (uint32_t)(item - bi.groups); t = h = w0 = 0; return true; }
+    uint32_t q, wg, hh, tt;
+    fd_divmod(item, bi.fdWG, q, wg);
+    fd_divmod(q, bi.fdH, q, hh);
+    fd_divmod(q, bi.fdT, n, tt);
+    t = (int)tt; h = (int)hh; w0 = (int)wg * SF_DW_WB;
+    return false;
+}
+__device__ __forceinline__ void cvt8(const f16x8& v, float (&o)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+}
+
+template <int KW, int SW, int WSZ>
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwParams p, DwBlockIdx bi) {
+    constexpr int NIN = (SF_DW_WB - 1) * SW + KW;
+    __shared__ float s_w[WSZ];            // taps*Cw floats: 12 KiB for Cw <= 112 (3 workgroups more per CU), else 48 KiB
+    __shared__ float s_red[SF_THREADS][17];
+    dw_stage_weights(p, s_w);
+    __syncthreads();
+    int gcol, r0, r1, rstep;
+    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const int c = gcol * 8;
+    const int cw = c % p.Cw;
+    const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls, So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    if (active) {
+        for (int m = r0; m < r1; m += rstep) {
+            uint32_t n;
+            int to, ho, wo0;
+            if (dwb_decode(bi, (uint32_t)m, n, to, ho, wo0)) {          // cls row: copy
+                f16x8 v = ld16(p.x + (int64_t)n * Si * p.ldx + c);
+                float f[8];
+                cvt8(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ssum[e] += f[e]; ssq[e] += f[e] * f[e]; }
+                st16(p.y + (int64_t)n * So * p.ldy + c, v);
+                continue;
+            }
+            const f16* xb = p.x + ((int64_t)n * Si + p.cls) * p.ldx + c;
+            float acc[SF_DW_WB][8];
+#pragma unroll
+            for (int i = 0; i < SF_DW_WB; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+            const int wi0 = wo0 * SW - p.pW;
+            for (int kt = 0; kt < p.kT; ++kt) {
+                const int t = to * p.sT - p.pT + kt;
+                if ((unsigned)t >= (unsigned)p.Ti) continue;
+                for (int kh = 0; kh < p.kH; ++kh) {
+                    const int h = ho * p.sH - p.pH + kh;
+                    if ((unsigned)h >= (unsigned)p.Hi) continue;
+                    const float* wt = s_w + ((kt * p.kH + kh) * KW) * p.Cw + cw;
+                    const f16* line = xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx;
+#pragma unroll
+                    for (int j = 0; j < NIN; ++j) {
+                        const int w = wi0 + j;
+                        float xin[8];
+                        if ((unsigned)w < (unsigned)p.Wi) cvt8(ld16(line + (int64_t)w * p.ldx), xin);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) xin[e] = 0.f;
+                        }
+#pragma unroll
+                        for (int i = 0; i < SF_DW_WB; ++i) {
+                            const int kw = j - i * SW;      // compile-time after unrolling
+                            if (kw >= 0 && kw < KW) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) acc[i][e] += xin[e] * wt[kw * p.Cw + e];
+                            }
+                        }
+                    }
+                }
+            }
+            f16* yrow = p.y + ((int64_t)n * So + p.cls + ((int64_t)to * p.Ho + ho) * p.Wo + wo0) * p.ldy + c;
+#pragma unroll
+            for (int i = 0; i < SF_DW_WB; ++i) {
+                if (wo0 + i < p.Wo) {
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        o[e] = (f16)acc[i][e];
+                        ssum[e] += acc[i][e];
+                        ssq[e] += acc[i][e] * acc[i][e];
+                    }
+                    st16(yrow + (int64_t)i * p.ldy, o);
+                }
+            }
+        }
+    }
+    if (p.stat_part)
+        rowtile_reduce_store(p.rt, active, c, ssum, ssq, p.stat_part + (int64_t)blockIdx.x * 2 * p.rt.C, s_red);
+}
+
+// data gradient, blocked over 4 consecutive INPUT columns w0..w0+3 (w0 % 4 == 0).  With pW = KW/2 the output
+// columns that can contribute are q0 + jj, q0 = (w0 + pW - (KW-1) + SW-1) / SW rounded as below, and the tap of
+// (input i, column jj) is kw = B0 + i - jj*SW with a compile-time B0.
+template <int KW, int SW, int WSZ>
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked_kernel(DwParams p, DwBlockIdx bi) {
+    constexpr int PW = KW / 2;
+    // smallest q with w0 + PW - q*SW <= KW-1  (w0 % 4 == 0, SW in {1, 2}):  SW=1: q0 = w0 + PW - (KW-1);  SW=2: q0 = w0/2
+    constexpr int B0 = SW == 1 ? KW - 1 : PW;                 // kw of (i = 0, jj = 0)
+    constexpr int NQ = SW == 1 ? SF_DW_WB + KW - 1 : (SF_DW_WB - 1 + B0) / SW + 1;
+    __shared__ float s_w[WSZ];
+    dw_stage_weights(p, s_w);
+    __syncthreads();
+    int gcol, r0, r1, rstep;
+    if (!p.rt.init(gcol, r0, r1, rstep)) return;
+    const int c = gcol * 8;
+    const int cw = c % p.Cw;
+    const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls, So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
+    for (int m = r0; m < r1; m += rstep) {
+        uint32_t n;
+        int t, h, w0;
+        if (dwb_decode(bi, (uint32_t)m, n, t, h, w0)) {
+            st16(p.y + (int64_t)n * Si * p.ldy + c, ld16(p.dy + (int64_t)n * So * p.lddy + c));
+            continue;
+        }
+        const f16* db = p.dy + ((int64_t)n * So + p.cls) * p.lddy + c;
+        float acc[SF_DW_WB][8];
+#pragma unroll
+        for (int i = 0; i < SF_DW_WB; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+        const int q0 = SW == 1 ? w0 + PW - (KW - 1) : w0 / 2;
+        for (int kt = 0; kt < p.kT; ++kt) {
+            const int ut = t + p.pT - kt;
+            if (ut < 0) continue;
+            uint32_t qt, rt;
+            fd_divmod((uint32_t)ut, p.fdsT, qt, rt);
+            if (rt || qt >= (uint32_t)p.To) continue;
+            for (int kh = 0; kh < p.kH; ++kh) {
+                const int uh = h + p.pH - kh;
+                if (uh < 0) continue;
+                uint32_t qh, rh;
+                fd_divmod((uint32_t)uh, p.fdsH, qh, rh);
+                if (rh || qh >= (uint32_t)p.Ho) continue;
+                const float* wt = s_w + ((kt * p.kH + kh) * KW) * p.Cw + cw;
+                const f16* line = db + (((int64_t)qt * p.Ho + qh) * p.Wo) * p.lddy;
+#pragma unroll
+                for (int jj = 0; jj < NQ; ++jj) {
+                    const int q = q0 + jj;
+                    if ((unsigned)q >= (unsigned)p.Wo) continue;
+                    float d[8];
+                    cvt8(ld16(line + (int64_t)q * p.lddy), d);
+#pragma unroll
+                    for (int i = 0; i < SF_DW_WB; ++i) {
+                        const int kw = B0 + i - jj * SW;
+                        if (kw >= 0 && kw < KW) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[i][e] += d[e] * wt[kw * p.Cw + e];
+                        }
+                    }
+                }
+            }
+        }
+        f16* xrow = p.y + ((int64_t)n * Si + p.cls + ((int64_t)t * p.Hi + h) * p.Wi + w0) * p.ldy + c;
+#pragma unroll
+        for (int i = 0; i < SF_DW_WB; ++i) {
+            if (w0 + i < p.Wi) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)acc[i][e];
+                st16(xrow + (int64_t)i * p.ldy, o);
+            }
+        }
+    }
+}
+
+// weight gradient, blocked over 4 consecutive OUTPUT columns; blockIdx.z = kt, kH*KW (<= 9) accumulators.
+template <int KW, int SW, int WSZ>
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_blocked_kernel(DwParams p, DwBlockIdx bi) {
+    constexpr int NIN = (SF_DW_WB - 1) * SW + KW;
+    __shared__ float s_red[SF_THREADS][9];
+    int gcol, r0, r1, rstep;
+    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const int c = gcol * 8;
+    const int kt = blockIdx.z;
+    const int nsp = p.kH * KW;
+    const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls, So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
+    float acc[9][8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+    if (active) {
+        for (int m = r0; m < r1; m += rstep) {
+            uint32_t n;
+            int to, ho, wo0;
+            if (dwb_decode(bi, (uint32_t)m, n, to, ho, wo0)) continue;
+            const int t = to * p.sT - p.pT + kt;
+            if ((unsigned)t >= (unsigned)p.Ti) continue;
+            const f16* drow = p.dy + ((int64_t)n * So + p.cls + ((int64_t)to * p.Ho + ho) * p.Wo + wo0) * p.lddy + c;
+            f16x8 d[SF_DW_WB];
+#pragma unroll
+            for (int i = 0; i < SF_DW_WB; ++i) d[i] = wo0 + i < p.Wo ? ld16(drow + (int64_t)i * p.lddy) : zero8();
+            const f16* xb = p.x + ((int64_t)n * Si + p.cls) * p.ldx + c;
+            const int wi0 = wo0 * SW - p.pW;
+#pragma unroll
+            for (int kh = 0; kh < 9 / KW; ++kh) {
+                if (kh < p.kH) {
+                    const int h = ho * p.sH - p.pH + kh;
+                    if ((unsigned)h < (unsigned)p.Hi) {
+                        const f16* line = xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx;
+#pragma unroll
+                        for (int j = 0; j < NIN; ++j) {
+                            const int w = wi0 + j;
+                            if ((unsigned)w >= (unsigned)p.Wi) continue;
+                            float xin[8];
+                            cvt8(ld16(line + (int64_t)w * p.ldx), xin);
+#pragma unroll
+                            for (int i = 0; i < SF_DW_WB; ++i) {
+                                const int kw = j - i * SW;
+                                if (kw >= 0 && kw < KW) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) acc[kh * KW + kw][e] += (float)d[i][e] * xin[e];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int G = p.rt.C >> 3;
+    const int TG = G < SF_THREADS ? G : SF_THREADS;
+    const int rpi = SF_THREADS / TG;
+    const int taps = p.kT * nsp;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if (i < nsp) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_red[threadIdx.x][e] = acc[i][e];
+            __syncthreads();
+            if (active && (int)threadIdx.x < TG) {
+                float* o = p.wpart + ((int64_t)blockIdx.x * taps + kt * nsp + i) * p.rt.C + c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a = 0.f;
+                    for (int k = 0; k < rpi; ++k) a += s_red[threadIdx.x + k * TG][e];
+                    o[e] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // dw[cw][tap] (+)= scale * sum over blocks and over the C/Cw channel copies of wpart[blk][tap][c]
 struct DwFinalizeParams {
     const float* wpart; int nblk, taps, C, Cw, Cwreal;

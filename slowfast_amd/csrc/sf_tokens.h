@@ -388,26 +388,105 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_bwd_kernel(RelPosParams 
             s_q[r][cc] = v;
         }
         __syncthreads();
-        // ---- accumulate
+        // ---- accumulate.  rel_h / rel_t rows are constant over long runs of consecutive rows (qh changes every
+        // qW*heads rows, qt every qH*qW*heads rows): their sums live in registers and touch LDS once per run;
+        // the rel_w rows change every row: one batched LDS gather / scatter per row (the KW addresses of a row are
+        // distinct, so the loads are independent and the read-modify-write chain is one step per row).
         if (c < p.D) {
-            const int j0 = grp == 0 ? 0 : p.KH, j1 = grp == 0 ? p.KH : R;
-            for (int r = 0; r < SF_RELPOS_TILE; ++r) {
-                float acc = 0.f;
-                if (!s_pos[r][3]) {
-                    const int qt = s_pos[r][0], qh = s_pos[r][1], qw = s_pos[r][2];
-                    const float qv = s_q[r][c];
-                    for (int j = j0; j < j1; ++j) {
-                        int ri;
-                        const float* tab;
-                        if (j < p.KH) { ri = s_idx[qh * p.KH + j]; tab = p.rel_h + (int64_t)ri * p.D; }
-                        else if (j < p.KH + p.KW) { ri = s_idx[nih + qw * p.KW + (j - p.KH)]; tab = p.rel_w + (int64_t)ri * p.D; ri += p.rows_h; }
-                        else { ri = s_idx[nih + niw + qt * p.KT + (j - p.KH - p.KW)]; tab = p.rel_t + (int64_t)ri * p.D; ri += p.rows_h + p.rows_w; }
-                        const float d = s_dr[r][j];
-                        acc += d * tab[c];
-                        s_tab[ri * p.D + c] += d * qv;
+            if (grp == 0) {
+                int cur = -1;
+                float acc[16], tb[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { acc[j] = 0.f; tb[j] = 0.f; }
+                for (int r = 0; r < SF_RELPOS_TILE; ++r) {
+                    float dq = 0.f;
+                    if (!s_pos[r][3]) {
+                        const int qh = s_pos[r][1];
+                        if (qh != cur) {
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) {
+                                if (j < p.KH) {
+                                    if (cur >= 0) s_tab[s_idx[cur * p.KH + j] * p.D + c] += acc[j];
+                                    acc[j] = 0.f;
+                                    tb[j] = p.rel_h[(int64_t)s_idx[qh * p.KH + j] * p.D + c];
+                                }
+                            }
+                            cur = qh;
+                        }
+                        const float qv = s_q[r][c];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            if (j < p.KH) {
+                                const float d = s_dr[r][j];
+                                acc[j] += d * qv;
+                                dq += d * tb[j];
+                            }
+                        }
                     }
+                    s_dq[0][r][c] = dq;
                 }
-                s_dq[grp][r][c] = acc;
+                if (cur >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (j < p.KH) s_tab[s_idx[cur * p.KH + j] * p.D + c] += acc[j];
+                }
+            } else {
+                int cur = -1;
+                float acc[16], tb[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { acc[j] = 0.f; tb[j] = 0.f; }
+                const int toff = p.rows_h + p.rows_w;
+                for (int r = 0; r < SF_RELPOS_TILE; ++r) {
+                    float dq = 0.f;
+                    if (!s_pos[r][3]) {
+                        const int qt = s_pos[r][0], qw = s_pos[r][2];
+                        if (qt != cur) {
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) {
+                                if (j < p.KT) {
+                                    if (cur >= 0) s_tab[(toff + s_idx[nih + niw + cur * p.KT + j]) * p.D + c] += acc[j];
+                                    acc[j] = 0.f;
+                                    tb[j] = p.rel_t[(int64_t)s_idx[nih + niw + qt * p.KT + j] * p.D + c];
+                                }
+                            }
+                            cur = qt;
+                        }
+                        const float qv = s_q[r][c];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            if (j < p.KT) {
+                                const float d = s_dr[r][p.KH + p.KW + j];
+                                acc[j] += d * qv;
+                                dq += d * tb[j];
+                            }
+                        }
+                        // rel_w: gather all, then scatter all
+                        float old[16], tw[16];
+                        int ri[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            if (j < p.KW) {
+                                ri[j] = s_idx[nih + qw * p.KW + j];
+                                old[j] = s_tab[(p.rows_h + ri[j]) * p.D + c];
+                                tw[j] = p.rel_w[(int64_t)ri[j] * p.D + c];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            if (j < p.KW) {
+                                const float d = s_dr[r][p.KH + j];
+                                s_tab[(p.rows_h + ri[j]) * p.D + c] = old[j] + d * qv;
+                                dq += d * tw[j];
+                            }
+                        }
+                    }
+                    s_dq[1][r][c] = dq;
+                }
+                if (cur >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (j < p.KT) s_tab[(toff + s_idx[nih + niw + cur * p.KT + j]) * p.D + c] += acc[j];
+                }
             }
         }
         __syncthreads();

@@ -24,6 +24,8 @@ def test_dwconv_tokens(sim):
     tc.check_dwconv(sim, 2, 2, 16, (2, 6, 6), (3, 3, 3), (1, 2, 2), cls=1)
     tc.check_dwconv(sim, 1, 1, 32, (4, 5, 5), (3, 3, 3), (1, 1, 1), cls=1)
     tc.check_dwconv(sim, 2, 1, 24, (6, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)
+    tc.check_dwconv(sim, 1, 1, 16, (2, 9, 9), (3, 3, 3), (1, 4, 4), cls=1)      # generic (non-blocked) kernels
+    tc.check_dwconv(sim, 1, 2, 8, (2, 7, 7), (3, 3, 3), (1, 2, 2), cls=0)       # odd width, stride 2
 
 
 def test_token_pool(sim):
