@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 5
+#define SF_ABI_VERSION 6
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -50,7 +50,7 @@ int sf_prep_weights(const sf_conv_desc* d, const float* w, void* wf, void* wd, s
 int sf_conv_fwd_mtiles(const sf_conv_desc* d);
 /* y = conv(act(x)), act(x) = x or relu?(x*in_scale + in_shift) applied on the fly (zero padding is
  * applied AFTER act, as in the reference where the padded tensor is the post-ReLU activation).
- * stat_part (optional) receives per-tile per-channel sum / sum of squares: [mtiles][2][Co] fp32. */
+ * stat_part (optional) receives per-tile per-channel sum / sum of squares of y (bias included): [mtiles][2][Co] fp32. */
 int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf, const float* in_scale, const float* in_shift,
                 int in_relu, const float* bias, void* y, float* stat_part, sf_stream_t stream);
 /* dx = conv_transpose(dy, w) (+ resid), dx pitch = d->ldx, dy pitch = d->ldy */
@@ -107,6 +107,13 @@ int sf_pool_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t k
 /* cls != 0 (both calls): TOKEN tensors -- every sample's T*H*W rows are preceded by one cls-token row that passes
  * through the pool unchanged; replaces attention_pool(x, pool_skip=nn.MaxPool3d) of attention.py:13-45, 485-498. */
 
+/* ---- nn.MaxPool3d(pool_size, stride = pool_size, padding 0) in front of conv_phi / conv_g of the Nonlocal block
+ * (nonlocal_helper.py:96-114); argmax: byte table [N,To,Ho,Wo][C] */
+int sf_pool3d_fwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kT, int32_t kH, int32_t kW, const void* x,
+                  int32_t ldx, void* out, int32_t ldo, void* argmax, sf_stream_t stream);
+int sf_pool3d_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kT, int32_t kH, int32_t kW,
+                  const void* argmax, const void* dout, int32_t lddo, void* dx, int32_t lddx, sf_stream_t stream);
+
 /* ---- layout: clips arrive NCTHW fp32 (tools/train_net.py:79-98) */
 int sf_ncthw_to_cl(const float* x, int32_t N, int32_t C, int64_t S, int32_t Cp, void* out, sf_stream_t stream);
 int sf_cl_to_ncthw(const void* x, int32_t ld, int32_t N, int32_t C, int64_t S, float* out, sf_stream_t stream);
@@ -123,7 +130,9 @@ int sf_cl_to_ncthw(const void* x, int32_t ld, int32_t N, int32_t C, int64_t S, f
 int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias,
              const void* resid, int32_t ldr, void* Y, int32_t ldy, int32_t nbatch, int32_t bh, int64_t sa_b, int64_t sa_h,
              int64_t sw_b, int64_t sw_h, int64_t sy_b, int64_t sy_h, int64_t sr_b, int64_t sr_h, int32_t resid_row0,
-             sf_stream_t stream);
+             float alpha, sf_stream_t stream);
+/* alpha scales the products before bias / residual (0 = 1): the 1/N normalisation of the Nonlocal "dot_product"
+ * affinity (nonlocal_helper.py:130-132). */
 /* resid_row0: the residual is added to rows m >= resid_row0 only (residual pooling skips the cls row,
  * attention.py:381-385).  N need not be a multiple of 8 when ldy covers N rounded up to 8 (pad columns <- 0). */
 /* Batched "TN" GEMM  Out[z][r][c] = scale * sum_m P[z][m][r] * X[z][m][c]  (fp16 out): the attention gradients

@@ -39,6 +39,14 @@ CASES = {
                     ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
     "i3d_r50_mid": ("configs/Kinetics/I3D_8x8_R50.yaml",
                     ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
+    # Nonlocal blocks: C2D-NLN (softmax affinity, (1,2,2) pooling) and SlowFast-NLN (dot-product affinity)
+    "c2d_nln_mid": ("configs/Kinetics/C2D_NLN_8x8_R50.yaml",
+                    ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
+    "slowfast_nln_tiny": ("configs/Kinetics/SLOWFAST_NLN_8x8_R50.yaml",
+                          TINY + ["DATA.NUM_FRAMES", 8, "SLOWFAST.BETA_INV", 2, "DATA.TRAIN_CROP_SIZE", 64,
+                                  "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2, 2], [2, 2], [2, 2], [2, 2]]",
+                                  "NONLOCAL.LOCATION", "[[[], []], [[1], []], [[1], []], [[], []]]",
+                                  "NONLOCAL.POOL", "[[[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]]]"], 4),
     # X3D-M (depthwise 3x3x3, SE, Swish, channel widths 54/108 that are not multiples of 8) at reduced clip size
     "x3d_m_mid": ("configs/Kinetics/X3D_M.yaml",
                   ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),

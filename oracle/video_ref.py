@@ -53,7 +53,7 @@ class fp16_storage_model:
 
 
 def _conv(x, w, *args):
-    return _STORE(F.conv3d(x, _STORE(w), *args))
+    return _STORE(F.conv3d(x, _STORE(w), *args))   # args = (bias, stride, padding, dilation)
 
 
 def _bn(x, sd, prefix, training, stats_out, momentum=0.1, eps=1e-5):
@@ -107,14 +107,42 @@ def res_block(x, sd, prefix, stride, dilation, stride_1x1, training, stats_out):
     return _STORE(F.relu(sc + y))
 
 
-def res_stage(xs, sd, name, strides, dilations, stride_1x1, training, stats_out):
-    """ResStage.forward (resnet_helper.py:697-726) without Nonlocal blocks."""
+def nonlocal_block(x, sd, prefix, pool_size, instantiation, training, stats_out):
+    """Nonlocal.forward (nonlocal_helper.py:103-144): theta/phi/g 1x1x1 convs (+bias), phi and g on the max-pooled
+    input, affinity theta^T phi normalised by softmax(./sqrt(C)) or by 1/N ("dot_product"), out conv + BN, residual."""
+    N, C, T, H, W = x.shape
+    theta = _conv(x, sd[prefix + ".conv_theta.weight"], sd[prefix + ".conv_theta.bias"])
+    xp = F.max_pool3d(x, tuple(pool_size), tuple(pool_size)) if any(s > 1 for s in pool_size) else x
+    phi = _conv(xp, sd[prefix + ".conv_phi.weight"], sd[prefix + ".conv_phi.bias"])
+    g = _conv(xp, sd[prefix + ".conv_g.weight"], sd[prefix + ".conv_g.bias"])
+    ci = theta.shape[1]
+    theta, phi, g = theta.view(N, ci, -1), phi.view(N, ci, -1), g.view(N, ci, -1)
+    a = _STORE(torch.einsum("nct,ncp->ntp", theta, phi))
+    if instantiation == "softmax":
+        a = F.softmax(a * (ci ** -0.5), dim=2)
+    elif instantiation == "dot_product":
+        a = a / a.shape[2]
+    else:
+        raise NotImplementedError(instantiation)
+    a = _STORE(a)
+    y = _STORE(torch.einsum("ntg,ncg->nct", a, g)).view(N, ci, T, H, W)
+    p = _conv(y, sd[prefix + ".conv_out.weight"], sd[prefix + ".conv_out.bias"])
+    p = _bn(p, sd, prefix + ".bn", training, stats_out)
+    return _STORE(x + p)
+
+
+def res_stage(xs, sd, name, strides, dilations, stride_1x1, training, stats_out, nonlocal_pool=None,
+              instantiation="dot_product"):
+    """ResStage.forward (resnet_helper.py:697-726); Nonlocal blocks (NONLOCAL.GROUP 1) after the listed blocks."""
     out = []
     for p, x in enumerate(xs):
         i = 0
         while f"{name}.pathway{p}_res{i}.branch2.a.weight" in sd:
             x = res_block(x, sd, f"{name}.pathway{p}_res{i}", strides[p] if i == 0 else 1, dilations[p], stride_1x1,
                           training, stats_out)
+            nl = f"{name}.pathway{p}_nonlocal{i}"
+            if nl + ".conv_theta.weight" in sd:
+                x = nonlocal_block(x, sd, nl, nonlocal_pool[p], instantiation, training, stats_out)
             i += 1
         out.append(x)
     return out
@@ -187,7 +215,7 @@ def video_forward(sd, cfg, inputs, training=True, stats_out=None):
     for i in range(4):
         name = f"s{i + 2}"
         x = res_stage(x, sd, name, cfg.RESNET.SPATIAL_STRIDES[i], cfg.RESNET.SPATIAL_DILATIONS[i],
-                      cfg.RESNET.STRIDE_1X1, training, stats_out)
+                      cfg.RESNET.STRIDE_1X1, training, stats_out, cfg.NONLOCAL.POOL[i], cfg.NONLOCAL.INSTANTIATION)
         if i == 0:
             pt = _POOL1_T[cfg.MODEL.ARCH]
             if pt != 1:

@@ -197,6 +197,16 @@ PRESETS["SLOW_8x8_R50"]["NONLOCAL"]["INSTANTIATION"] = "dot_product"
 PRESETS["I3D_8x8_R50"] = _variant("C2D_8x8_R50", ARCH="i3d")        # configs/Kinetics/I3D_8x8_R50.yaml
 
 
+# configs/Kinetics/C2D_NLN_8x8_R50.yaml, configs/Kinetics/SLOWFAST_NLN_8x8_R50.yaml
+PRESETS["C2D_NLN_8x8_R50"] = copy.deepcopy(PRESETS["C2D_8x8_R50"])
+PRESETS["C2D_NLN_8x8_R50"]["NONLOCAL"] = {"LOCATION": [[[]], [[1, 3]], [[1, 3, 5]], [[]]], "GROUP": [[1], [1], [1], [1]],
+                                          "INSTANTIATION": "softmax"}
+PRESETS["SLOWFAST_NLN_8x8_R50"] = copy.deepcopy(PRESETS["SLOWFAST_8x8_R50"])
+PRESETS["SLOWFAST_NLN_8x8_R50"]["SLOWFAST"]["FUSION_KERNEL_SZ"] = 5
+PRESETS["SLOWFAST_NLN_8x8_R50"]["NONLOCAL"] = {"LOCATION": [[[], []], [[1, 3], []], [[1, 3, 5], []], [[], []]],
+                                               "GROUP": [[1, 1], [1, 1], [1, 1], [1, 1]], "INSTANTIATION": "dot_product"}
+
+
 def preset_for_yaml(yaml_rel):
     """Preset name for a reference YAML path such as 'configs/Kinetics/SLOWFAST_8x8_R50.yaml'."""
     import os

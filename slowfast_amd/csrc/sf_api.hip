@@ -164,7 +164,6 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf,
     REQUIRE(x && wf && y, "sf_conv_fwd: null pointer");
     REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sf_conv_fwd: in_scale/in_shift must come together");
     REQUIRE(!in_scale || d->Ci <= 512, "sf_conv_fwd: fused input BatchNorm supports Ci <= 512 (got %d)", d->Ci);
-    REQUIRE(!(bias && stat_part), "sf_conv_fwd: bias together with BatchNorm statistics is not supported");
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.g = gather_fwd(d, x, in_scale, in_shift, in_relu);
@@ -451,6 +450,38 @@ extern "C" int sf_pool_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C
     return check_launch("pool_bwd");
 }
 
+// ---- MaxPool3d(kernel = stride, padding 0) of the Nonlocal block (nonlocal_helper.py:96-101)
+extern "C" int sf_pool3d_fwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kT, int32_t kH, int32_t kW,
+                             const void* x, int32_t ldx, void* out, int32_t ldo, void* argmax, sf_stream_t stream) {
+    REQUIRE(x && out && argmax && C > 0 && C % 8 == 0 && kT > 0 && kH > 0 && kW > 0 && kT * kH * kW <= 255,
+            "sf_pool3d_fwd: bad arguments");
+    Pool3dParams p;
+    p.N = N; p.T = T; p.H = H; p.W = W; p.C = C; p.kT = kT; p.kH = kH; p.kW = kW;
+    p.To = T / kT; p.Ho = H / kH; p.Wo = W / kW;
+    REQUIRE(p.To > 0 && p.Ho > 0 && p.Wo > 0, "sf_pool3d_fwd: window larger than the input");
+    p.x = (const f16*)x; p.ldx = ldx; p.out = (f16*)out; p.ldo = ldo; p.argmax = (uint8_t*)argmax;
+    p.dout = nullptr; p.lddo = 0;
+    p.fdG = make_fastdiv(C / 8); p.fdW = make_fastdiv(p.Wo); p.fdH = make_fastdiv(p.Ho); p.fdT = make_fastdiv(p.To);
+    p.total = (int64_t)N * p.To * p.Ho * p.Wo * (C / 8);
+    REQUIRE(p.total < (1ll << 31), "sf_pool3d_fwd: too many elements");
+    hipLaunchKernelGGL(sf_pool3d_fwd_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("pool3d_fwd");
+}
+extern "C" int sf_pool3d_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kT, int32_t kH, int32_t kW,
+                             const void* argmax, const void* dout, int32_t lddo, void* dx, int32_t lddx, sf_stream_t stream) {
+    REQUIRE(argmax && dout && dx && C > 0 && C % 8 == 0 && kT > 0 && kH > 0 && kW > 0, "sf_pool3d_bwd: bad arguments");
+    Pool3dParams p;
+    p.N = N; p.T = T; p.H = H; p.W = W; p.C = C; p.kT = kT; p.kH = kH; p.kW = kW;
+    p.To = T / kT; p.Ho = H / kH; p.Wo = W / kW;
+    p.x = nullptr; p.ldx = 0; p.out = (f16*)dx; p.ldo = lddx; p.argmax = (uint8_t*)argmax;
+    p.dout = (const f16*)dout; p.lddo = lddo;
+    p.fdG = make_fastdiv(C / 8); p.fdW = make_fastdiv(W); p.fdH = make_fastdiv(H); p.fdT = make_fastdiv(T);
+    p.total = (int64_t)N * T * H * W * (C / 8);
+    REQUIRE(p.total < (1ll << 31), "sf_pool3d_bwd: too many elements");
+    hipLaunchKernelGGL(sf_pool3d_bwd_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("pool3d_bwd");
+}
+
 extern "C" int sf_ncthw_to_cl(const float* x, int32_t N, int32_t C, int64_t S, int32_t Cp, void* out,
                               sf_stream_t stream) {
     REQUIRE(x && out && (Cp % 8 == 0 || Cp == 4) && Cp >= C, "sf_ncthw_to_cl: bad arguments");
@@ -488,7 +519,7 @@ static GatherSide gather_matrix(const void* a, int64_t M, int32_t K, int32_t lda
 extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
                         const float* bias, const void* resid, int32_t ldr, void* Y, int32_t ldy, int32_t nbatch,
                         int32_t bh, int64_t sa_b, int64_t sa_h, int64_t sw_b, int64_t sw_h, int64_t sy_b, int64_t sy_h,
-                        int64_t sr_b, int64_t sr_h, int32_t resid_row0, sf_stream_t stream) {
+                        int64_t sr_b, int64_t sr_h, int32_t resid_row0, float alpha, sf_stream_t stream) {
     REQUIRE(A && W && Y, "sf_bgemm: null pointer");
     REQUIRE(M > 0 && M < (1ll << 31) && N > 0 && K > 0, "sf_bgemm: bad shape");
     // rows of Y are written in 16-byte groups: the pitch must cover N rounded up to 8 (the pad columns get zeros)
@@ -505,7 +536,7 @@ extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t 
     p.ksteps = cdiv(K, 32);
     p.y = (f16*)Y; p.ldy = ldy; p.bias = bias; p.resid = (const f16*)resid; p.ldr = ldr;
     p.bh = bh; p.sa_b = sa_b; p.sa_h = sa_h; p.sw_b = sw_b; p.sw_h = sw_h; p.sy_b = sy_b; p.sy_h = sy_h;
-    p.sr_b = sr_b; p.sr_h = sr_h; p.resid_row0 = resid_row0;
+    p.sr_b = sr_b; p.sr_h = sr_h; p.resid_row0 = resid_row0; p.alpha = alpha;
     hipStream_t s = (hipStream_t)stream;
     const int mt = cdiv(M, 128);
 #define SF_BG(BN_, WM_, WN_)                                                                                   \
@@ -840,6 +871,12 @@ extern "C" int sf_relpos_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, 
     p.dtab_part = dtab_part;
     const int64_t rows = (int64_t)d->B * d->Nq * d->heads;
     p.rows_per_block = cdiv(rows, kRelposBwdBlocks);
+    {
+        int blocks = cdiv(rows, 4);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(sf_relpos_dq_kernel, dim3(blocks), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+        if (check_launch("relpos_dq")) return -1;
+    }
     hipLaunchKernelGGL(sf_relpos_bwd_kernel, dim3(cdiv(rows, p.rows_per_block)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("relpos_bwd");
 }

@@ -30,6 +30,7 @@ struct IgemmParams {
     int bh;
     int64_t sa_b, sa_h, sw_b, sw_h, sy_b, sy_h, sr_b, sr_h;
     int resid_row0;     // the residual is added to rows >= resid_row0 only (pooled attention: not to the cls row)
+    float alpha;        // accumulators are scaled by alpha before bias / residual (0 means 1)
 };
 
 template <int BN, int WM, int WN, bool PW>
@@ -157,7 +158,19 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    // ---------------- epilogue: BatchNorm partial statistics (fp32, from the accumulators)
+    // ---------------- epilogue: scale, bias, BatchNorm partial statistics (fp32, from the accumulators)
+    {
+        const float alpha = p.alpha != 0.f ? p.alpha : 1.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int colj = n0 + wn * WN + j * 16 + (lane & 15);
+            const float b = (p.bias && colj < p.Nout) ? p.bias[colj] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha + b;
+        }
+    }
     if (p.stat_part) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -166,7 +179,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r];
+                    // rows beyond M carry only the bias: keep them out of the statistics
+                    const bool rowok = m0 + wm * WM + i * 16 + 4 * (lane >> 4) + r < p.M;
+                    const float v = rowok ? acc[i][j][r] : 0.f;
                     s += v;
                     q += v * v;
                 }
@@ -185,11 +200,10 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * WN + j * 16 + (lane & 15);
-            const float b = (p.bias && (n0 + col) < p.Nout) ? p.bias[n0 + col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm * WM + i * 16 + 4 * (lane >> 4) + r;
-                stg[row * STG_LD + col] = (f16)(acc[i][j][r] + b);
+                stg[row * STG_LD + col] = (f16)acc[i][j][r];
             }
         }
     __syncthreads();

@@ -156,6 +156,82 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// MaxPool3d with kernel = stride, no padding (non-overlapping windows): nn.MaxPool3d(pool_size, pool_size, 0) in front
+// of conv_phi / conv_g of the Nonlocal block (slowfast/models/nonlocal_helper.py:96-114).
+struct Pool3dParams {
+    int N, T, H, W, C, kT, kH, kW, To, Ho, Wo;
+    const f16* x; int ldx;
+    f16* out; int ldo;              // fwd: pooled; bwd: dx
+    uint8_t* argmax;                // [N,To,Ho,Wo][C] window-local index (kt*kH + kh)*kW + kw of the first maximum
+    const f16* dout; int lddo;
+    FastDiv fdG, fdW, fdH, fdT;     // dims of the iterated space (fwd: output, bwd: input)
+    int64_t total;
+};
+__global__ __launch_bounds__(SF_THREADS) void sf_pool3d_fwd_kernel(Pool3dParams p) {
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
+         idx += (int64_t)gridDim.x * SF_THREADS) {
+        uint32_t q, gcol, wo, ho, to, n;
+        fd_divmod((uint32_t)idx, p.fdG, q, gcol);
+        fd_divmod(q, p.fdW, q, wo);
+        fd_divmod(q, p.fdH, q, ho);
+        fd_divmod(q, p.fdT, n, to);
+        const int c = gcol * 8;
+        float best[8];
+        uint32_t arg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = 0; }
+        uint32_t code = 0;
+        for (int kt = 0; kt < p.kT; ++kt)
+            for (int kh = 0; kh < p.kH; ++kh)
+                for (int kw = 0; kw < p.kW; ++kw, ++code) {
+                    const int64_t row = (((int64_t)n * p.T + to * p.kT + kt) * p.H + ho * p.kH + kh) * p.W + wo * p.kW + kw;
+                    f16x8 v = ld16(p.x + row * p.ldx + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float z = (float)v[e];
+                        const bool gt = z > best[e];
+                        best[e] = gt ? z : best[e];
+                        arg[e] = gt ? code : arg[e];
+                    }
+                }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)best[e];
+        const int64_t orow = (((int64_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+        st16(p.out + orow * p.ldo + c, o);
+        u32x2 pk;
+        pk.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+        pk.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+        *reinterpret_cast<u32x2*>(p.argmax + orow * p.C + c) = pk;
+    }
+}
+__global__ __launch_bounds__(SF_THREADS) void sf_pool3d_bwd_kernel(Pool3dParams p) {
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
+         idx += (int64_t)gridDim.x * SF_THREADS) {
+        uint32_t q, gcol, w, h, t, n;
+        fd_divmod((uint32_t)idx, p.fdG, q, gcol);
+        fd_divmod(q, p.fdW, q, w);
+        fd_divmod(q, p.fdH, q, h);
+        fd_divmod(q, p.fdT, n, t);
+        const int c = gcol * 8;
+        const int to = (int)t / p.kT, ho = (int)h / p.kH, wo = (int)w / p.kW;
+        f16x8 o = zero8();
+        if (to < p.To && ho < p.Ho && wo < p.Wo) {     // positions beyond the last full window receive no gradient
+            const uint32_t me = (uint32_t)((((int)t - to * p.kT) * p.kH + ((int)h - ho * p.kH)) * p.kW + ((int)w - wo * p.kW));
+            const int64_t orow = (((int64_t)n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+            const u32x2 pk = *reinterpret_cast<const u32x2*>(p.argmax + orow * p.C + c);
+            const f16x8 d = ld16(p.dout + orow * p.lddo + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t a = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
+                o[e] = a == me ? d[e] : (f16)0;
+            }
+        }
+        st16(p.out + ((((int64_t)n * p.T + t) * p.H + h) * p.W + w) * p.ldo + c, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // NCTHW fp32 -> channels-last fp16 with the channel count zero-padded to Cp (multiple of 8)
 __global__ __launch_bounds__(SF_THREADS) void sf_ncthw_to_cl_kernel(const float* x, f16* out, int N, int C, int64_t S,
                                                                     int Cp) {

@@ -333,6 +333,39 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_fwd_kernel(RelPosParams 
     }
 }
 
+// dq[row][c] += sum_j drq[row][j] * table_j[c]: one wave per row, many rows in flight (the per-row table reads are
+// L1/L2 hits whose latency only high occupancy hides -- which is why this is not part of the LDS-heavy kernel below).
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_dq_kernel(RelPosParams p) {
+    __shared__ float s_dr[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = p.KH + p.KW + p.KT;
+    const int total = p.B * p.Nq * p.heads;
+    for (int base = blockIdx.x * 4; base < total; base += gridDim.x * 4) {
+        const int row = base + wave;
+        const bool ok = row < total;
+        uint32_t b = 0, tok = 0, head = 0;
+        int qt = 0, qh = 0, qw = 0;
+        bool is_cls = true;
+        if (ok) {
+            relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
+            if (lane < R) s_dr[wave][lane] = p.drq[(int64_t)row * R + lane];
+        }
+        __syncthreads();
+        if (ok && !is_cls) {
+            f16* dqrow = p.dq + ((int64_t)b * p.Nq + tok) * p.lddq + head * p.D;
+            for (int c = lane; c < p.D; c += 64) {
+                float acc = (float)dqrow[c];
+                for (int j = 0; j < p.KH; ++j) acc += s_dr[wave][j] * p.rel_h[(int64_t)p.idx_h[qh * p.KH + j] * p.D + c];
+                for (int j = 0; j < p.KW; ++j) acc += s_dr[wave][p.KH + j] * p.rel_w[(int64_t)p.idx_w[qw * p.KW + j] * p.D + c];
+                for (int j = 0; j < p.KT; ++j)
+                    acc += s_dr[wave][p.KH + p.KW + j] * p.rel_t[(int64_t)p.idx_t[qt * p.KT + j] * p.D + c];
+                dqrow[c] = (f16)acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // backward of the above: dq[row][c] += sum_j drq[row][j] * table_j[c]  and per-block partial table gradients
 // dtab[r][c] += drq[row][j] * q[row][c] for r = index of table row j.  A block walks its rows in tiles of 32 (staged
 // in LDS); thread (group, c) owns channel c of the rel_h rows (group 0) or of the rel_w and rel_t rows (group 1),
@@ -343,7 +376,6 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_bwd_kernel(RelPosParams 
     __shared__ float s_tab[SF_RELPOS_MAX_TAB];
     __shared__ float s_dr[SF_RELPOS_TILE][64];
     __shared__ float s_q[SF_RELPOS_TILE][128];
-    __shared__ float s_dq[2][SF_RELPOS_TILE][128];
     __shared__ int s_pos[SF_RELPOS_TILE][4];         // qt, qh, qw, skip (cls row or beyond the block's range)
     __shared__ int s_idx[1024];                      // idx_h | idx_w | idx_t
     const int grp = threadIdx.x >> 7, c = threadIdx.x & 127;
@@ -395,11 +427,10 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_bwd_kernel(RelPosParams 
         if (c < p.D) {
             if (grp == 0) {
                 int cur = -1;
-                float acc[16], tb[16];
+                float acc[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { acc[j] = 0.f; tb[j] = 0.f; }
+                for (int j = 0; j < 16; ++j) acc[j] = 0.f;
                 for (int r = 0; r < SF_RELPOS_TILE; ++r) {
-                    float dq = 0.f;
                     if (!s_pos[r][3]) {
                         const int qh = s_pos[r][1];
                         if (qh != cur) {
@@ -408,22 +439,15 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_bwd_kernel(RelPosParams 
                                 if (j < p.KH) {
                                     if (cur >= 0) s_tab[s_idx[cur * p.KH + j] * p.D + c] += acc[j];
                                     acc[j] = 0.f;
-                                    tb[j] = p.rel_h[(int64_t)s_idx[qh * p.KH + j] * p.D + c];
                                 }
                             }
                             cur = qh;
                         }
                         const float qv = s_q[r][c];
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            if (j < p.KH) {
-                                const float d = s_dr[r][j];
-                                acc[j] += d * qv;
-                                dq += d * tb[j];
-                            }
-                        }
+                        for (int j = 0; j < 16; ++j)
+                            if (j < p.KH) acc[j] += s_dr[r][j] * qv;
                     }
-                    s_dq[0][r][c] = dq;
                 }
                 if (cur >= 0) {
 #pragma unroll
@@ -432,12 +456,11 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_bwd_kernel(RelPosParams 
                 }
             } else {
                 int cur = -1;
-                float acc[16], tb[16];
+                float acc[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { acc[j] = 0.f; tb[j] = 0.f; }
+                for (int j = 0; j < 16; ++j) acc[j] = 0.f;
                 const int toff = p.rows_h + p.rows_w;
                 for (int r = 0; r < SF_RELPOS_TILE; ++r) {
-                    float dq = 0.f;
                     if (!s_pos[r][3]) {
                         const int qt = s_pos[r][0], qw = s_pos[r][2];
                         if (qt != cur) {
@@ -446,60 +469,34 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_bwd_kernel(RelPosParams 
                                 if (j < p.KT) {
                                     if (cur >= 0) s_tab[(toff + s_idx[nih + niw + cur * p.KT + j]) * p.D + c] += acc[j];
                                     acc[j] = 0.f;
-                                    tb[j] = p.rel_t[(int64_t)s_idx[nih + niw + qt * p.KT + j] * p.D + c];
                                 }
                             }
                             cur = qt;
                         }
                         const float qv = s_q[r][c];
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            if (j < p.KT) {
-                                const float d = s_dr[r][p.KH + p.KW + j];
-                                acc[j] += d * qv;
-                                dq += d * tb[j];
-                            }
-                        }
+                        for (int j = 0; j < 16; ++j)
+                            if (j < p.KT) acc[j] += s_dr[r][p.KH + p.KW + j] * qv;
                         // rel_w: gather all, then scatter all
-                        float old[16], tw[16];
+                        float old[16];
                         int ri[16];
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
                             if (j < p.KW) {
                                 ri[j] = s_idx[nih + qw * p.KW + j];
                                 old[j] = s_tab[(p.rows_h + ri[j]) * p.D + c];
-                                tw[j] = p.rel_w[(int64_t)ri[j] * p.D + c];
                             }
                         }
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            if (j < p.KW) {
-                                const float d = s_dr[r][p.KH + j];
-                                s_tab[(p.rows_h + ri[j]) * p.D + c] = old[j] + d * qv;
-                                dq += d * tw[j];
-                            }
-                        }
+                        for (int j = 0; j < 16; ++j)
+                            if (j < p.KW) s_tab[(p.rows_h + ri[j]) * p.D + c] = old[j] + s_dr[r][p.KH + j] * qv;
                     }
-                    s_dq[1][r][c] = dq;
                 }
                 if (cur >= 0) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j)
                         if (j < p.KT) s_tab[(toff + s_idx[nih + niw + cur * p.KT + j]) * p.D + c] += acc[j];
                 }
-            }
-        }
-        __syncthreads();
-        // ---- dq += table terms (all threads, coalesced over channels)
-        for (int i = threadIdx.x; i < SF_RELPOS_TILE * p.D; i += SF_THREADS) {
-            const int r = i / p.D, cc = i % p.D;
-            if (base + r < r1 && !s_pos[r][3]) {
-                uint32_t b, tok, head;
-                int qt, qh, qw;
-                bool is_cls;
-                relpos_row_decode(p, (uint32_t)(base + r), b, tok, head, qt, qh, qw, is_cls);
-                f16* dst = p.dq + ((int64_t)b * p.Nq + tok) * p.lddq + head * p.D + cc;
-                *dst = (f16)((float)*dst + s_dq[0][r][cc] + s_dq[1][r][cc]);
             }
         }
     }

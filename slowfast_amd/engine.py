@@ -112,9 +112,8 @@ class ConvUnit:
         if bn is None:
             y, _ = ops.conv_fwd(x, wf, geom, in_affine=in_affine, bias=self.conv.bias, stats=False)
             return y, None
-        assert self.conv.bias is None
         use_batch_stats = training or bn.running_mean is None
-        y, part = ops.conv_fwd(x, wf, geom, in_affine=in_affine, stats=use_batch_stats)
+        y, part = ops.conv_fwd(x, wf, geom, in_affine=in_affine, bias=self.conv.bias, stats=use_batch_stats)
         track = bn.track_running_stats and training
         st = ops.bn_finalize(part, geom.out_rows, bn.weight, bn.bias, bn.running_mean if track or not use_batch_stats else None,
                              bn.running_var if track or not use_batch_stats else None, bn.momentum, bn.eps,

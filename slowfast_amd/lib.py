@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ConvDesc(Structure):
@@ -60,10 +60,12 @@ _SIGNATURES = {
                                 c_int32, _P, c_int32, _P]),
     "sf_pool_fwd": (c_int, [c_int32] * 11 + [_P, c_int32, _F, _F, c_int, _P, c_int32, _P, c_int32, _P]),
     "sf_pool_bwd": (c_int, [c_int32] * 11 + [_P, c_int32, _P, c_int, _P, c_int32, _P, c_int32, c_int32, _P]),
+    "sf_pool3d_fwd": (c_int, [c_int32] * 8 + [_P, c_int32, _P, c_int32, _P, _P]),
+    "sf_pool3d_bwd": (c_int, [c_int32] * 8 + [_P, _P, c_int32, _P, c_int32, _P]),
     "sf_ncthw_to_cl": (c_int, [_F, c_int32, c_int32, c_int64, c_int32, _P, _P]),
     "sf_cl_to_ncthw": (c_int, [_P, c_int32, c_int32, c_int32, c_int64, _F, _P]),
     "sf_bgemm": (c_int, [c_int64, c_int32, c_int32, _P, c_int32, _P, c_int32, _F, _P, c_int32, _P, c_int32, c_int32,
-                         c_int32] + [c_int64] * 8 + [c_int32, _P]),
+                         c_int32] + [c_int64] * 8 + [c_int32, c_float, _P]),
     "sf_bgemm_tn": (c_int, [c_int64, c_int32, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_float, c_int32, c_int32]
                     + [c_int64] * 6 + [_P]),
     "sf_layernorm_fwd": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, c_float, _P, c_int32, _F, _F, _P]),

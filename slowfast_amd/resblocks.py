@@ -103,13 +103,19 @@ class ResStage(nn.Module):
             + [1] * (num_blocks[p] - num_block_temp_kernel[p]) for p in range(P)]
         trans = get_trans_func(trans_func_name)
         for p in range(P):
-            assert not nonlocal_inds[p], "Nonlocal blocks are a later row of the hot-path scope table"
             for i in range(num_blocks[p]):
                 blk = ResBlock(dim_in[p] if i == 0 else dim_out[p], dim_out[p], self.temp_kernel_sizes[p][i],
                                stride[p] if i == 0 else 1, trans, dim_inner[p], num_groups[p],
                                stride_1x1=stride_1x1, inplace_relu=inplace_relu, dilation=dilation[p],
                                norm_module=norm_module, block_idx=i, drop_connect_rate=drop_connect_rate)
                 self.add_module(f"pathway{p}_res{i}", blk)
+                if i in nonlocal_inds[p]:
+                    if nonlocal_group[p] != 1:
+                        raise NotImplementedError("NONLOCAL.GROUP > 1 (temporal folding) is not on the built path")
+                    from .nonlocal_block import Nonlocal
+                    self.add_module(f"pathway{p}_nonlocal{i}",
+                                    Nonlocal(dim_out[p], dim_out[p] // 2, nonlocal_pool[p], instantiation=instantiation,
+                                             norm_module=norm_module))
 
     def forward(self, inputs):
         out = []
@@ -117,5 +123,8 @@ class ResStage(nn.Module):
             x = inputs[p]
             for i in range(self.num_blocks[p]):
                 x = getattr(self, f"pathway{p}_res{i}")(x)
+                nln = getattr(self, f"pathway{p}_nonlocal{i}", None)
+                if nln is not None:
+                    x = nln(x)
             out.append(x)
         return out

@@ -38,7 +38,7 @@ def _lib_call(name, *args, **kw):
 
 # ------------------------------------------------------------------------------------------------
 # GEMMs
-def gemm(a, w16, bias=None, resid=None, out=None):
+def gemm(a, w16, bias=None, resid=None, out=None, alpha=0.0):
     """out[m][n] = sum_k a[m][k] * w16[n][k] (+ bias[n]) (+ resid[m][n]).  a: token tensor (..., K); w16: fp16
     [N, K] (pitch = stride(0)); the nn.Linear forward with w16 = weight.half(), or its data gradient with
     w16 = weight.t().half()."""
@@ -54,18 +54,18 @@ def gemm(a, w16, bias=None, resid=None, out=None):
         Mr, Nr, ldr = rows_pitch(resid)
         assert (Mr, Nr) == (M, N)
     _lib_call("sf_bgemm", M, N, K, a.data_ptr(), lda, w16.data_ptr(), w16.stride(0), _ptr(bias), _ptr(resid), ldr,
-              out.data_ptr(), ldy, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, _stream(a),
+              out.data_ptr(), ldy, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, float(alpha), _stream(a),
               work=dict(flops=2.0 * M * N * K, bytes=2.0 * (M * K + M * N + N * K)))
     return out
 
 
 def bgemm_heads(a, a_strides, M, K, lda, w, w_strides, N, ldw, out, o_strides, ldy, B, heads, resid=None,
-                r_strides=(0, 0), ldr=0, resid_row0=0):
+                r_strides=(0, 0), ldr=0, resid_row0=0, alpha=0.0):
     """Per-(batch, head) GEMM: out[b,h][m][n] = sum_k a[b,h][m][k] * w[b,h][n][k] (+ resid).  *_strides = (per-batch,
     per-head) element strides of the operand bases."""
     _lib_call("sf_bgemm", M, N, K, a.data_ptr(), lda, w.data_ptr(), ldw, None, _ptr(resid), ldr, out.data_ptr(), ldy,
               B * heads, heads, a_strides[0], a_strides[1], w_strides[0], w_strides[1], o_strides[0], o_strides[1],
-              r_strides[0], r_strides[1], resid_row0, _stream(a),
+              r_strides[0], r_strides[1], resid_row0, float(alpha), _stream(a),
               work=dict(flops=2.0 * B * heads * M * N * K, bytes=2.0 * B * heads * (M * K + N * K + M * N)))
     return out
 

@@ -156,3 +156,14 @@ def test_x3d_matches_reference(gpu, name):
                         tol_global=1e-2, report=rep)
     finally:
         print(name, rep.get(name))
+
+
+@pytest.mark.parametrize("name", ["slowfast_nln_tiny", "c2d_nln_mid"])
+def test_nonlocal_matches_reference(gpu, name):
+    """Nonlocal blocks (softmax and dot-product affinities) vs the oracle / the unmodified reference's golden numbers."""
+    rep = {}
+    try:
+        mc.check_engine(name, gpu, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.1,
+                        tol_global=1e-2, report=rep)
+    finally:
+        print(name, rep.get(name))
