@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 6
+#define SF_ABI_VERSION 7
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -189,16 +189,16 @@ typedef struct sf_attn_desc {
     int32_t Nk, kT, kH, kW;        /* Nk = cls + kT*kH*kW */
     int32_t rows_h, rows_w, rows_t; /* rows of rel_pos_h / rel_pos_w / rel_pos_t */
 } sf_attn_desc;
-/* rq[(b,q,head)][kH+kW+kT] = <q_unscaled, rel_pos_{h,w,t}[idx]> (cal_rel_pos_spatial/temporal, attention.py:64-147);
- * idx_h [qH][kH], idx_w [qW][kW], idx_t [qT][kT] are the reference's dist_* tables as int32 */
-int sf_relpos_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, const float* rel_h, const float* rel_w,
-                  const float* rel_t, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t, float* rq,
-                  sf_stream_t stream);
-int sf_relpos_bwd_blocks(const sf_attn_desc* d);    /* blocks of dtab_part, each (rows_h+rows_w+rows_t)*D floats */
-/* dq += sum_j drq[j] * table_j; dtab_part = per-block partial gradients of the three tables (-> sf_rows_sum) */
-int sf_relpos_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, const float* rel_h, const float* rel_w,
-                  const float* rel_t, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t, const float* drq,
-                  void* dq, int32_t lddq, float* dtab_part, sf_stream_t stream);
+/* Decomposed relative positions (cal_rel_pos_spatial / cal_rel_pos_temporal, attention.py:64-147).  The contractions
+ * with the tables run as GEMMs over the concatenated table Tab = [rel_pos_h; rel_pos_w; rel_pos_t]:
+ *   forward   G = q_unscaled Tab^T (sf_bgemm), rq[(b,q,head)][kH+kW+kT] = G[row][column of table row j]   (gather)
+ *   backward  E[row][column of table row j] = drq[row][j] (scatter, zero elsewhere); dq += E Tab (sf_bgemm);
+ *             dTab = E^T q (sf_conv_wgrad on the 1x1x1 geometry).
+ * idx_h [qH][kH], idx_w [qW][kW], idx_t [qT][kT] are the reference's dist_* tables as int32; cls rows get zeros. */
+int sf_relpos_gather(const sf_attn_desc* d, const void* G, int32_t ldg, const int32_t* idx_h, const int32_t* idx_w,
+                     const int32_t* idx_t, float* rq, sf_stream_t stream);
+int sf_relpos_scatter(const sf_attn_desc* d, const float* drq, const int32_t* idx_h, const int32_t* idx_w,
+                      const int32_t* idx_t, void* E, int32_t lde, sf_stream_t stream);
 /* in place: s <- softmax_k(scale*s + bias), bias from rq (NULL = none); pad columns [Nk, lds) <- 0 */
 int sf_softmax_fwd(const sf_attn_desc* d, void* s, int32_t lds, float scale, const float* rq, sf_stream_t stream);
 /* in place: dp <- scale * P*(dp - sum_k P*dp); drq (optional) <- per-(kh|kw|kt) sums of the unscaled dS */

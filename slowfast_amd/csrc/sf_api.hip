@@ -117,6 +117,12 @@ template <int BN, int WM, int WN>
 static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s) {
     int mt = cdiv(p.M, 128);
     dim3 grid((unsigned)(mt * p.ntiles_n));
+    static const bool pf1 = getenv("SF_IGEMM_PF1") && atoi(getenv("SF_IGEMM_PF1")) != 0;   // A/B switch: one register stage
+    if (pf1) {
+        if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false>), grid, dim3(SF_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false>), grid, dim3(SF_THREADS), 0, s, p);
+        return;
+    }
     if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true>), grid, dim3(SF_THREADS), 0, s, p);
     else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false>), grid, dim3(SF_THREADS), 0, s, p);
 }
@@ -836,49 +842,32 @@ static int fill_relpos(RelPosParams& p, const sf_attn_desc* d) {
     p.fdW = make_fastdiv(d->qW); p.fdH = make_fastdiv(d->qH);
     return 0;
 }
-extern "C" int sf_relpos_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, const float* rel_h, const float* rel_w,
-                             const float* rel_t, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t,
-                             float* rq, sf_stream_t stream) {
-    RelPosParams p;
-    if (fill_relpos(p, d)) return -1;
-    REQUIRE(q && rel_h && rel_w && rel_t && idx_h && idx_w && idx_t && rq, "sf_relpos_fwd: null pointer");
-    p.q = (const f16*)q; p.ldq = ldq; p.rel_h = rel_h; p.rel_w = rel_w; p.rel_t = rel_t;
-    p.idx_h = idx_h; p.idx_w = idx_w; p.idx_t = idx_t; p.rq = rq;
+static int relpos_blocks(const sf_attn_desc* d) {
     const int64_t rows = (int64_t)d->B * d->Nq * d->heads;
     int blocks = cdiv(rows, 4);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(sf_relpos_fwd_kernel, dim3(blocks), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
-    return check_launch("relpos_fwd");
+    return blocks > 16384 ? 16384 : blocks;
 }
-static const int kRelposBwdBlocks = 512;
-extern "C" int sf_relpos_bwd_blocks(const sf_attn_desc* d) {
-    REQUIRE(d != nullptr, "sf_relpos_bwd_blocks: null descriptor");
-    const int64_t rows = (int64_t)d->B * d->Nq * d->heads;
-    const int rpb = cdiv(rows, kRelposBwdBlocks);
-    return cdiv(rows, rpb);
-}
-extern "C" int sf_relpos_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, const float* rel_h, const float* rel_w,
-                             const float* rel_t, const int32_t* idx_h, const int32_t* idx_w, const int32_t* idx_t,
-                             const float* drq, void* dq, int32_t lddq, float* dtab_part, sf_stream_t stream) {
+extern "C" int sf_relpos_gather(const sf_attn_desc* d, const void* G, int32_t ldg, const int32_t* idx_h,
+                                const int32_t* idx_w, const int32_t* idx_t, float* rq, sf_stream_t stream) {
     RelPosParams p;
     if (fill_relpos(p, d)) return -1;
-    REQUIRE(q && rel_h && rel_w && rel_t && idx_h && idx_w && idx_t && drq && dq && dtab_part, "sf_relpos_bwd: null pointer");
-    REQUIRE((d->rows_h + d->rows_w + d->rows_t) * d->D <= SF_RELPOS_MAX_TAB, "sf_relpos_bwd: tables exceed the LDS stage");
-    REQUIRE(d->qH * d->kH + d->qW * d->kW + d->qT * d->kT <= 1024, "sf_relpos_bwd: index tables exceed the LDS stage");
-    REQUIRE(d->kH <= 16 && d->kW <= 16 && d->kT <= 16, "sf_relpos_bwd: at most 16 keys per axis");
-    p.q = (const f16*)q; p.ldq = ldq; p.rel_h = rel_h; p.rel_w = rel_w; p.rel_t = rel_t;
-    p.idx_h = idx_h; p.idx_w = idx_w; p.idx_t = idx_t; p.drq = drq; p.dq = (f16*)dq; p.lddq = lddq;
-    p.dtab_part = dtab_part;
-    const int64_t rows = (int64_t)d->B * d->Nq * d->heads;
-    p.rows_per_block = cdiv(rows, kRelposBwdBlocks);
-    {
-        int blocks = cdiv(rows, 4);
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(sf_relpos_dq_kernel, dim3(blocks), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
-        if (check_launch("relpos_dq")) return -1;
-    }
-    hipLaunchKernelGGL(sf_relpos_bwd_kernel, dim3(cdiv(rows, p.rows_per_block)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
-    return check_launch("relpos_bwd");
+    REQUIRE(G && idx_h && idx_w && idx_t && rq, "sf_relpos_gather: null pointer");
+    REQUIRE(ldg >= d->rows_h + d->rows_w + d->rows_t, "sf_relpos_gather: pitch smaller than the table row count");
+    p.idx_h = idx_h; p.idx_w = idx_w; p.idx_t = idx_t; p.rq = rq;
+    hipLaunchKernelGGL(sf_relpos_gather_kernel, dim3(relpos_blocks(d)), dim3(SF_THREADS), 0, (hipStream_t)stream, p,
+                       (const f16*)G, ldg);
+    return check_launch("relpos_gather");
+}
+extern "C" int sf_relpos_scatter(const sf_attn_desc* d, const float* drq, const int32_t* idx_h, const int32_t* idx_w,
+                                 const int32_t* idx_t, void* E, int32_t lde, sf_stream_t stream) {
+    RelPosParams p;
+    if (fill_relpos(p, d)) return -1;
+    REQUIRE(drq && idx_h && idx_w && idx_t && E, "sf_relpos_scatter: null pointer");
+    REQUIRE(lde % 8 == 0 && lde >= d->rows_h + d->rows_w + d->rows_t, "sf_relpos_scatter: bad pitch");
+    p.idx_h = idx_h; p.idx_w = idx_w; p.idx_t = idx_t; p.drq = drq;
+    hipLaunchKernelGGL(sf_relpos_scatter_kernel, dim3(relpos_blocks(d)), dim3(SF_THREADS), 0, (hipStream_t)stream, p,
+                       (f16*)E, lde);
+    return check_launch("relpos_scatter");
 }
 // out[i] (+)= scale * sum_b part[b*row_len + offset + i], i < n   (table gradients from per-block partials):
 // 32 outputs per block x 8 segments of the block sum, fixed-order LDS fold

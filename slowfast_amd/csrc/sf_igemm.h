@@ -33,7 +33,8 @@ struct IgemmParams {
     float alpha;        // accumulators are scaled by alpha before bias / residual (0 means 1)
 };
 
-template <int BN, int WM, int WN, bool PW>
+// PF2 = two register stages (loads of K-step s+2 in flight under step s) / one stage (loads of s+1 only)
+template <int BN, int WM, int WN, bool PW, bool PF2 = true>
 __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
     constexpr int BM = 128, BK = 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
@@ -85,20 +86,25 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
         rp[j] = PW ? decode_row_pw(g, (uint32_t)row, row < p.M) : decode_row(g, (uint32_t)row, row < p.M);
     }
 
-    f16x8 ra[2], rb[NB];
-    bool ra_ok[2];
-    uint32_t ra_c0[2];
+    // Two register stages: the global loads of K-step s+2 are issued before the MFMAs of step s and consumed (written
+    // to LDS) one full iteration later, so two K-steps of HBM/L2 latency are covered per workgroup.
+    struct Stage {
+        f16x8 ra[2], rb[NB];
+        bool ok[2];
+        uint32_t c0[2];
+    };
+    Stage st0, st1;
 
-    auto load_tile = [&](int ks) {
+    auto load_tile = [&](int ks, Stage& st) {
         const uint32_t k0 = (uint32_t)(ks * BK + kq * 8);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int64_t off;
             uint32_t c0 = 0;
             bool ok = PW ? gather_offset_pw(g, rp[j], k0, off, c0) : gather_offset(g, rp[j], k0, off, c0);
-            ra[j] = ok ? ld16(a_src + off) : zero8();
-            ra_ok[j] = ok;
-            ra_c0[j] = c0;
+            st.ra[j] = ok ? ld16(a_src + off) : zero8();
+            st.ok[j] = ok;
+            st.c0[j] = c0;
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -106,22 +112,22 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
             int brow = idx >> 2;
             int co = n0 + brow;
             bool ok = (idx < BN * 4) && (co < p.Nout) && (k0 < (uint32_t)g.Ktot);
-            rb[j] = ok ? ld16(wmat + (int64_t)co * p.ldw + k0) : zero8();
+            st.rb[j] = ok ? ld16(wmat + (int64_t)co * p.ldw + k0) : zero8();
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const Stage& st) {
         f16* As = smem + buf * (A_ELEMS + B_ELEMS);
         f16* Bs = As + A_ELEMS;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f16x8 v = ra[j];
-            if (has_tf && ra_ok[j]) v = bn_relu8(v, s_scale + ra_c0[j], s_shift + ra_c0[j], g.relu);
+            f16x8 v = st.ra[j];
+            if (has_tf && st.ok[j]) v = bn_relu8(v, s_scale + st.c0[j], s_shift + st.c0[j], g.relu);
             st16(As + lds_tile_off((tid >> 2) + 64 * j, kq), v);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int idx = tid + SF_THREADS * j;
-            if (idx < BN * 4) st16(Bs + lds_tile_off(idx >> 2, kq), rb[j]);
+            if (idx < BN * 4) st16(Bs + lds_tile_off(idx >> 2, kq), st.rb[j]);
         }
     };
 
@@ -147,15 +153,32 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
     };
 
     if (has_tf) __syncthreads();  // scale/shift tables visible before the first store_tile
-    load_tile(0);
-    store_tile(0);
+    load_tile(0, st0);
+    if (PF2 && p.ksteps > 1) load_tile(1, st1);
+    store_tile(0, st0);
     __syncthreads();
-    for (int ks = 0; ks < p.ksteps; ++ks) {
-        const bool more = ks + 1 < p.ksteps;
-        if (more) load_tile(ks + 1);
-        compute(ks & 1);
-        if (more) store_tile((ks + 1) & 1);
+    if constexpr (!PF2) {
+        for (int ks = 0; ks < p.ksteps; ++ks) {
+            const bool more = ks + 1 < p.ksteps;
+            if (more) load_tile(ks + 1, st0);
+            compute(ks & 1);
+            if (more) store_tile((ks + 1) & 1, st0);
+            __syncthreads();
+        }
+    } else
+    for (int ks = 0; ks < p.ksteps;) {
+        // even step: LDS buffer 0 holds step ks, st1 holds step ks+1, st0 is free
+        if (ks + 2 < p.ksteps) load_tile(ks + 2, st0);
+        compute(0);
+        if (ks + 1 < p.ksteps) store_tile(1, st1);
         __syncthreads();
+        if (++ks >= p.ksteps) break;
+        // odd step: LDS buffer 1 holds step ks, st0 holds step ks+1, st1 is free
+        if (ks + 2 < p.ksteps) load_tile(ks + 2, st1);
+        compute(1);
+        if (ks + 1 < p.ksteps) store_tile(0, st0);
+        __syncthreads();
+        ++ks;
     }
 
     // ---------------- epilogue: scale, bias, BatchNorm partial statistics (fp32, from the accumulators)

@@ -300,209 +300,60 @@ __device__ __forceinline__ void relpos_row_decode(const RelPosParams& p, uint32_
     qt = (int)t; qh = (int)h; qw = (int)w;
 }
 
-// one wave per row; lane j < R computes the j-th dot product (all waves of a block iterate together)
-__global__ __launch_bounds__(SF_THREADS) void sf_relpos_fwd_kernel(RelPosParams p) {
-    __shared__ float s_q[4][128];
+// The three contractions with the rel-pos tables run on the MFMA GEMMs over the CONCATENATED table
+// Tab = [rel_pos_h; rel_pos_w; rel_pos_t] (TR rows):  G = q Tab^T  (forward),  dq += E Tab,  dTab = E^T q  (backward),
+// where E[row][r] scatters drq[row][j] to column r = column of table row j.  These two kernels are the gather
+// (G -> rq) and the scatter (drq -> E) between the dense GEMM operands and the per-row (kH+kW+kT) vectors.
+// One wave per row; the cls row (token 0 when cls = 1) gets zeros.
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_gather_kernel(RelPosParams p, const f16* G, int ldg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = p.KH + p.KW + p.KT;
     const int total = p.B * p.Nq * p.heads;
+    for (int row = blockIdx.x * 4 + wave; row < total; row += gridDim.x * 4) {
+        if (lane >= R) continue;
+        uint32_t b, tok, head;
+        int qt, qh, qw;
+        bool is_cls;
+        relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
+        float v = 0.f;
+        if (!is_cls) {
+            int col;
+            if (lane < p.KH) col = p.idx_h[qh * p.KH + lane];
+            else if (lane < p.KH + p.KW) col = p.rows_h + p.idx_w[qw * p.KW + (lane - p.KH)];
+            else col = p.rows_h + p.rows_w + p.idx_t[qt * p.KT + (lane - p.KH - p.KW)];
+            v = (float)G[(int64_t)row * ldg + col];
+        }
+        p.rq[(int64_t)row * R + lane] = v;
+    }
+}
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_scatter_kernel(RelPosParams p, f16* E, int lde) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = p.KH + p.KW + p.KT;
+    const int total = p.B * p.Nq * p.heads;
+    // all waves of a block iterate together (the scatter follows the zero fill of the same row by the same wave;
+    // within a wave the two phases are ordered by the barrier)
     for (int base = blockIdx.x * 4; base < total; base += gridDim.x * 4) {
         const int row = base + wave;
         const bool ok = row < total;
-        uint32_t b = 0, tok = 0, head = 0;
-        int qt = 0, qh = 0, qw = 0;
-        bool is_cls = true;
-        if (ok) {
-            relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
-            const f16* qrow = p.q + ((int64_t)b * p.Nq + tok) * p.ldq + head * p.D;
-            for (int c = lane; c < p.D; c += 64) s_q[wave][c] = (float)qrow[c];
-        }
+        f16* erow = E + (int64_t)(ok ? row : 0) * lde;
+        if (ok)
+            for (int k8 = lane; k8 < lde / 8; k8 += 64) st16(erow + k8 * 8, zero8());
         __syncthreads();
         if (ok && lane < R) {
-            float acc = 0.f;
-            if (!is_cls) {
-                const float* tab;
-                if (lane < p.KH) tab = p.rel_h + (int64_t)p.idx_h[qh * p.KH + lane] * p.D;
-                else if (lane < p.KH + p.KW) tab = p.rel_w + (int64_t)p.idx_w[qw * p.KW + (lane - p.KH)] * p.D;
-                else tab = p.rel_t + (int64_t)p.idx_t[qt * p.KT + (lane - p.KH - p.KW)] * p.D;
-                for (int c = 0; c < p.D; ++c) acc += s_q[wave][c] * tab[c];
-            }
-            p.rq[(int64_t)row * R + lane] = acc;
-        }
-        __syncthreads();
-    }
-}
-
-// dq[row][c] += sum_j drq[row][j] * table_j[c]: one wave per row, many rows in flight (the per-row table reads are
-// L1/L2 hits whose latency only high occupancy hides -- which is why this is not part of the LDS-heavy kernel below).
-__global__ __launch_bounds__(SF_THREADS) void sf_relpos_dq_kernel(RelPosParams p) {
-    __shared__ float s_dr[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int R = p.KH + p.KW + p.KT;
-    const int total = p.B * p.Nq * p.heads;
-    for (int base = blockIdx.x * 4; base < total; base += gridDim.x * 4) {
-        const int row = base + wave;
-        const bool ok = row < total;
-        uint32_t b = 0, tok = 0, head = 0;
-        int qt = 0, qh = 0, qw = 0;
-        bool is_cls = true;
-        if (ok) {
+            uint32_t b, tok, head;
+            int qt, qh, qw;
+            bool is_cls;
             relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
-            if (lane < R) s_dr[wave][lane] = p.drq[(int64_t)row * R + lane];
-        }
-        __syncthreads();
-        if (ok && !is_cls) {
-            f16* dqrow = p.dq + ((int64_t)b * p.Nq + tok) * p.lddq + head * p.D;
-            for (int c = lane; c < p.D; c += 64) {
-                float acc = (float)dqrow[c];
-                for (int j = 0; j < p.KH; ++j) acc += s_dr[wave][j] * p.rel_h[(int64_t)p.idx_h[qh * p.KH + j] * p.D + c];
-                for (int j = 0; j < p.KW; ++j) acc += s_dr[wave][p.KH + j] * p.rel_w[(int64_t)p.idx_w[qw * p.KW + j] * p.D + c];
-                for (int j = 0; j < p.KT; ++j)
-                    acc += s_dr[wave][p.KH + p.KW + j] * p.rel_t[(int64_t)p.idx_t[qt * p.KT + j] * p.D + c];
-                dqrow[c] = (f16)acc;
+            if (!is_cls) {
+                int col;
+                if (lane < p.KH) col = p.idx_h[qh * p.KH + lane];
+                else if (lane < p.KH + p.KW) col = p.rows_h + p.idx_w[qw * p.KW + (lane - p.KH)];
+                else col = p.rows_h + p.rows_w + p.idx_t[qt * p.KT + (lane - p.KH - p.KW)];
+                erow[col] = (f16)p.drq[(int64_t)row * R + lane];
             }
         }
         __syncthreads();
     }
-}
-
-// backward of the above: dq[row][c] += sum_j drq[row][j] * table_j[c]  and per-block partial table gradients
-// dtab[r][c] += drq[row][j] * q[row][c] for r = index of table row j.  A block walks its rows in tiles of 32 (staged
-// in LDS); thread (group, c) owns channel c of the rel_h rows (group 0) or of the rel_w and rel_t rows (group 1),
-// so every LDS accumulator has exactly one writer and rows are visited in order: deterministic.  D <= 128.
-#define SF_RELPOS_MAX_TAB (240 * 96)
-#define SF_RELPOS_TILE 32
-__global__ __launch_bounds__(SF_THREADS) void sf_relpos_bwd_kernel(RelPosParams p) {
-    __shared__ float s_tab[SF_RELPOS_MAX_TAB];
-    __shared__ float s_dr[SF_RELPOS_TILE][64];
-    __shared__ float s_q[SF_RELPOS_TILE][128];
-    __shared__ int s_pos[SF_RELPOS_TILE][4];         // qt, qh, qw, skip (cls row or beyond the block's range)
-    __shared__ int s_idx[1024];                      // idx_h | idx_w | idx_t
-    const int grp = threadIdx.x >> 7, c = threadIdx.x & 127;
-    const int R = p.KH + p.KW + p.KT;
-    const int TR = p.rows_h + p.rows_w + p.rows_t;
-    const int nih = p.qH * p.KH, niw = p.qW * p.KW, nit = p.qT * p.KT;
-    for (int i = threadIdx.x; i < TR * p.D; i += SF_THREADS) s_tab[i] = 0.f;
-    for (int i = threadIdx.x; i < nih + niw + nit; i += SF_THREADS)
-        s_idx[i] = i < nih ? p.idx_h[i] : i < nih + niw ? p.idx_w[i - nih] : p.idx_t[i - nih - niw];
-    const int total = p.B * p.Nq * p.heads;
-    const int r0 = blockIdx.x * p.rows_per_block;
-    int r1 = r0 + p.rows_per_block;
-    if (r1 > total) r1 = total;
-    for (int base = r0; base < r1; base += SF_RELPOS_TILE) {
-        __syncthreads();                             // previous tile fully consumed (and the tables initialised)
-        // ---- stage the tile: positions, drq rows, q rows
-        if (threadIdx.x < SF_RELPOS_TILE) {
-            const int row = base + threadIdx.x;
-            int qt = 0, qh = 0, qw = 0;
-            bool is_cls = true;
-            if (row < r1) {
-                uint32_t b, tok, head;
-                relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
-            }
-            s_pos[threadIdx.x][0] = qt; s_pos[threadIdx.x][1] = qh; s_pos[threadIdx.x][2] = qw;
-            s_pos[threadIdx.x][3] = (row >= r1 || is_cls) ? 1 : 0;
-        }
-        for (int i = threadIdx.x; i < SF_RELPOS_TILE * R; i += SF_THREADS) {
-            const int r = i / R, j = i % R;
-            s_dr[r][j] = base + r < r1 ? p.drq[(int64_t)(base + r) * R + j] : 0.f;
-        }
-        for (int i = threadIdx.x; i < SF_RELPOS_TILE * p.D; i += SF_THREADS) {
-            const int r = i / p.D, cc = i % p.D;
-            float v = 0.f;
-            if (base + r < r1) {
-                uint32_t b, tok, head;
-                int qt, qh, qw;
-                bool is_cls;
-                relpos_row_decode(p, (uint32_t)(base + r), b, tok, head, qt, qh, qw, is_cls);
-                v = (float)p.q[((int64_t)b * p.Nq + tok) * p.ldq + head * p.D + cc];
-            }
-            s_q[r][cc] = v;
-        }
-        __syncthreads();
-        // ---- accumulate.  rel_h / rel_t rows are constant over long runs of consecutive rows (qh changes every
-        // qW*heads rows, qt every qH*qW*heads rows): their sums live in registers and touch LDS once per run;
-        // the rel_w rows change every row: one batched LDS gather / scatter per row (the KW addresses of a row are
-        // distinct, so the loads are independent and the read-modify-write chain is one step per row).
-        if (c < p.D) {
-            if (grp == 0) {
-                int cur = -1;
-                float acc[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-                for (int r = 0; r < SF_RELPOS_TILE; ++r) {
-                    if (!s_pos[r][3]) {
-                        const int qh = s_pos[r][1];
-                        if (qh != cur) {
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) {
-                                if (j < p.KH) {
-                                    if (cur >= 0) s_tab[s_idx[cur * p.KH + j] * p.D + c] += acc[j];
-                                    acc[j] = 0.f;
-                                }
-                            }
-                            cur = qh;
-                        }
-                        const float qv = s_q[r][c];
-#pragma unroll
-                        for (int j = 0; j < 16; ++j)
-                            if (j < p.KH) acc[j] += s_dr[r][j] * qv;
-                    }
-                }
-                if (cur >= 0) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (j < p.KH) s_tab[s_idx[cur * p.KH + j] * p.D + c] += acc[j];
-                }
-            } else {
-                int cur = -1;
-                float acc[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-                const int toff = p.rows_h + p.rows_w;
-                for (int r = 0; r < SF_RELPOS_TILE; ++r) {
-                    if (!s_pos[r][3]) {
-                        const int qt = s_pos[r][0], qw = s_pos[r][2];
-                        if (qt != cur) {
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) {
-                                if (j < p.KT) {
-                                    if (cur >= 0) s_tab[(toff + s_idx[nih + niw + cur * p.KT + j]) * p.D + c] += acc[j];
-                                    acc[j] = 0.f;
-                                }
-                            }
-                            cur = qt;
-                        }
-                        const float qv = s_q[r][c];
-#pragma unroll
-                        for (int j = 0; j < 16; ++j)
-                            if (j < p.KT) acc[j] += s_dr[r][p.KH + p.KW + j] * qv;
-                        // rel_w: gather all, then scatter all
-                        float old[16];
-                        int ri[16];
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            if (j < p.KW) {
-                                ri[j] = s_idx[nih + qw * p.KW + j];
-                                old[j] = s_tab[(p.rows_h + ri[j]) * p.D + c];
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 16; ++j)
-                            if (j < p.KW) s_tab[(p.rows_h + ri[j]) * p.D + c] = old[j] + s_dr[r][p.KH + j] * qv;
-                    }
-                }
-                if (cur >= 0) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (j < p.KT) s_tab[(toff + s_idx[nih + niw + cur * p.KT + j]) * p.D + c] += acc[j];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    float* o = p.dtab_part + (int64_t)blockIdx.x * TR * p.D;
-    for (int i = threadIdx.x; i < TR * p.D; i += SF_THREADS) o[i] = s_tab[i];
 }
 
 // ------------------------------------------------------------------------------------------------

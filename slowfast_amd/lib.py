@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ConvDesc(Structure):
@@ -82,9 +82,8 @@ _SIGNATURES = {
     "sf_dwconv_dgrad": (c_int, [POINTER(DwDesc), _P, _F, _P, _P]),
     "sf_dwconv_wgrad_workspace": (c_int64, [POINTER(DwDesc)]),
     "sf_dwconv_wgrad": (c_int, [POINTER(DwDesc), _P, _P, _F, c_float, c_int, _P, c_int64, _P]),
-    "sf_relpos_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _F, _F, _F, _P, _P, _P, _F, _P]),
-    "sf_relpos_bwd_blocks": (c_int, [POINTER(AttnDesc)]),
-    "sf_relpos_bwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _F, _F, _F, _P, _P, _P, _F, _P, c_int32, _F, _P]),
+    "sf_relpos_gather": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, _P, _F, _P]),
+    "sf_relpos_scatter": (c_int, [POINTER(AttnDesc), _F, _P, _P, _P, _P, c_int32, _P]),
     "sf_softmax_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, c_float, _F, _P]),
     "sf_softmax_bwd": (c_int, [POINTER(AttnDesc), _P, _P, c_int32, c_float, _F, _P]),
     "sf_transpose_heads": (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),

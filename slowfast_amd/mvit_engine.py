@@ -132,7 +132,10 @@ def attention_forward(att, plan, qkv):
     vn, mv, rv_ = att._norm_v.forward(vp.view(B * Nk * heads, D))
     qn, kn, vn = qn.view(B, Nq, C), kn.view(B, Nk, C), vn.view(B, Nk, C)
     tables = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t) if plan.rel else None
-    rq = tokens.relpos_fwd(plan.desc, qn, tables, plan.idx) if plan.rel else None
+    t16 = t16t = None
+    if plan.rel:
+        t16, t16t = tokens.relpos_tables16(tables)
+    rq = tokens.relpos_fwd(plan.desc, qn, tables, plan.idx, t16=t16) if plan.rel else None
     S = torch.empty((B, heads, Nq, lds), dtype=_f16, device=qkv.device)
     tokens.bgemm_heads(qn, (Nq * C, D), Nq, D, C, kn, (Nk * C, D), Nk, C, S, (heads * Nq * lds, Nq * lds), lds, B, heads)
     P = tokens.softmax_fwd(plan.desc, S, att.scale, rq)
@@ -141,7 +144,7 @@ def attention_forward(att, plan, qkv):
     resid = qn if att.residual_pooling else None
     tokens.bgemm_heads(P, (heads * Nq * lds, Nq * lds), Nq, lds, lds, vt, (heads * D * lds, D * lds), D, lds,
                        o, (Nq * C, D), C, B, heads, resid=resid, r_strides=(Nq * C, D), ldr=C, resid_row0=plan.cls)
-    saved = dict(qp=qp, kp=kp, vp=vp, qn=qn, kn=kn, vn=vn, sq=(mq, rq_), sk=(mk, rk_), sv=(mv, rv_), P=P)
+    saved = dict(qp=qp, kp=kp, vp=vp, qn=qn, kn=kn, vn=vn, sq=(mq, rq_), sk=(mk, rk_), sv=(mv, rv_), P=P, t16t=t16t)
     return o, saved
 
 
@@ -170,7 +173,8 @@ def attention_backward(att, plan, qkv, sv, do):
     if plan.rel:
         tabs = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t)
         dests = [_grad_dest(t) for t in tabs]
-        tokens.relpos_bwd(plan.desc, qn, tabs, plan.idx, drq, dqn, [d[0] for d in dests], [not d[1] for d in dests])
+        tokens.relpos_bwd(plan.desc, qn, tabs, plan.idx, drq, dqn, [d[0] for d in dests], [not d[1] for d in dests],
+                          t16t=sv["t16t"])
     # LayerNorm(head_dim) backward
     dqp = att._norm_q.backward(dqn.view(-1, D), sv["qp"].view(-1, D), *sv["sq"]).view(B, Nq, C)
     dkp = att._norm_k.backward(dkn.view(-1, D), sv["kp"].view(-1, D), *sv["sk"]).view(B, Nk, C)

@@ -267,29 +267,47 @@ def attn_desc(B, heads, D, cls, q_thw, k_thw, rows_h=0, rows_w=0, rows_t=0):
     return AttnDesc(B, heads, D, int(cls), Nq, *q_thw, Nk, *k_thw, rows_h, rows_w, rows_t)
 
 
-def relpos_fwd(d, q, tables, idx):
-    """rq [B*Nq*heads, kH+kW+kT] fp32 from the UNSCALED q [B, Nq, heads*D]."""
+def relpos_tables16(tables):
+    """Concatenated table [rel_pos_h; rel_pos_w; rel_pos_t] as fp16 GEMM operands: (Tab [TRp, D], Tab^T [D, TRp]),
+    TRp = row count rounded up to 8 (zero rows)."""
+    tab = torch.cat([t.detach() for t in tables], 0)
+    TR, D = tab.shape
+    TRp = (TR + 7) // 8 * 8
+    t16 = torch.zeros((TRp, D), dtype=_f16, device=tab.device)
+    t16[:TR] = tab
+    return t16, t16.t().contiguous()
+
+
+def relpos_fwd(d, q, tables, idx, t16=None):
+    """rq [B*Nq*heads, kH+kW+kT] fp32 from the UNSCALED q [B, Nq, heads*D]: G = q Tab^T on the MFMA GEMM, then the
+    per-row gather of the kH+kW+kT columns the row's position selects."""
+    if t16 is None:
+        t16 = relpos_tables16(tables)[0]
     R = d.kH + d.kW + d.kT
-    rq = torch.empty((d.B * d.Nq * d.heads, R), dtype=torch.float32, device=q.device)
-    _lib_call("sf_relpos_fwd", byref(d), q.data_ptr(), rows_pitch(q)[2], tables[0].data_ptr(), tables[1].data_ptr(),
-              tables[2].data_ptr(), idx[0].data_ptr(), idx[1].data_ptr(), idx[2].data_ptr(), rq.data_ptr(), _stream(q),
-              work=dict(bytes=2.0 * q.numel()))
+    q2d = q.reshape(-1, d.D)
+    G = gemm(q2d, t16)
+    rq = torch.empty((q2d.shape[0], R), dtype=torch.float32, device=q.device)
+    _lib_call("sf_relpos_gather", byref(d), G.data_ptr(), G.shape[1], idx[0].data_ptr(), idx[1].data_ptr(),
+              idx[2].data_ptr(), rq.data_ptr(), _stream(q), work=dict(bytes=2.0 * G.numel()))
     return rq
 
 
-def relpos_bwd(d, q, tables, idx, drq, dq, dtables, accumulate):
-    """dq += table terms; dtables[i] (+)= gradients of rel_pos_h / rel_pos_w / rel_pos_t."""
-    lib = get_lib()
-    nblk = lib.call("sf_relpos_bwd_blocks", byref(d))
-    TR = d.rows_h + d.rows_w + d.rows_t
-    part = torch.empty((nblk, TR * d.D), dtype=torch.float32, device=q.device)
-    lib.call("sf_relpos_bwd", byref(d), q.data_ptr(), rows_pitch(q)[2], tables[0].data_ptr(), tables[1].data_ptr(),
-             tables[2].data_ptr(), idx[0].data_ptr(), idx[1].data_ptr(), idx[2].data_ptr(), drq.data_ptr(),
-             dq.data_ptr(), rows_pitch(dq)[2], part.data_ptr(), _stream(q), work=dict(bytes=6.0 * q.numel()))
+def relpos_bwd(d, q, tables, idx, drq, dq, dtables, accumulate, t16t=None):
+    """dq += E Tab; dtables[i] (+)= rows of E^T q, with E the scatter of drq onto the table-row columns."""
+    if t16t is None:
+        t16t = relpos_tables16(tables)[1]
+    TRp = t16t.shape[1]
+    q2d, dq2d = q.reshape(-1, d.D), dq.view(-1, d.D)
+    E = torch.empty((q2d.shape[0], TRp), dtype=_f16, device=q.device)
+    _lib_call("sf_relpos_scatter", byref(d), drq.data_ptr(), idx[0].data_ptr(), idx[1].data_ptr(), idx[2].data_ptr(),
+              E.data_ptr(), TRp, _stream(q), work=dict(bytes=2.0 * E.numel()))
+    gemm(E, t16t, resid=dq2d, out=dq2d)                     # in place: each element is read then written by one thread
+    dtab = torch.empty((TRp, d.D), dtype=torch.float32, device=q.device)
+    linear_wgrad(q2d, E, dtab, zero_first=True)
     off = 0
     for t, g, acc in zip(tables, dtables, accumulate):
-        n = t.numel()
-        lib.call("sf_rows_sum", part.data_ptr(), nblk, TR * d.D, off, n, g.data_ptr(), 1.0, int(acc), _stream(q))
+        n = t.shape[0]
+        g.add_(dtab[off:off + n]) if acc else g.copy_(dtab[off:off + n])
         off += n
 
 
