@@ -36,6 +36,36 @@ METRIC_NAME = {"SLOWFAST_8x8_R50": "SlowFast-8x8-R50 32x224^2", "C2D_8x8_R50": "
 PRESET_OPTS = {"MVITv2_S_16x4": ["MVIT.DROPPATH_RATE", 0.0, "MODEL.DROPOUT_RATE", 0.0]}
 
 
+# libsfamd entry point -> the HIP kernels it launches (for mapping rocprofv3 PMC traffic, collected per kernel in a
+# separate --pmc pass and committed under profiles/, onto the entry point the in-process profiler times)
+ENTRY_KERNELS = {
+    "sf_conv_wgrad": ("sf_wgrad_kernel", "sf_wgrad_reduce_kernel"),
+    "sf_bn_bwd_apply": ("sf_bn_bwd_apply_kernel",), "sf_bn_bwd_reduce": ("sf_bn_bwd_reduce_kernel",),
+    "sf_bn_act": ("sf_bn_act_kernel",), "sf_dwconv_fwd": ("sf_dwconv_fwd",), "sf_dwconv_dgrad": ("sf_dwconv_dgrad",),
+    "sf_dwconv_wgrad": ("sf_dwconv_wgrad",), "sf_softmax_fwd": ("sf_softmax_fwd_kernel",),
+    "sf_softmax_bwd": ("sf_softmax_bwd_kernel",),
+}
+
+
+def pmc_traffic(entry, preset, launches_per_step):
+    """HBM bytes per launch of `entry` from the committed PMC pass of this preset (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md, WRITE_SIZE as reported; tools/pmc_traffic.py), or None."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{preset}.json")
+    if entry not in ENTRY_KERNELS or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        kern = json.load(f)["kernels"]
+    tot, steps = 0.0, None
+    for name, v in kern.items():
+        if any(name.replace("void ", "").startswith(k) for k in ENTRY_KERNELS[entry]):
+            tot += v["hbm_bytes_per_launch_corrected"] * v["launches"]
+            if name.replace("void ", "").startswith(ENTRY_KERNELS[entry][-1]):
+                steps = (steps or 0) + v["launches"]
+    if not tot or not steps:
+        return None
+    return tot / steps          # per launch of the entry point (its last kernel runs once per call)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +250,12 @@ def main():
         else:
             roof = {"kernel": name, "bound": "hbm", "achieved": round(v["gbs"], 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(v["gbs"] / HBM_PEAK_GBS, 4), "traffic": None}
+        t = pmc_traffic(name, a.preset, v["calls"])
+        if t is not None:
+            roof["traffic"] = round(t, 0)
+            roof["traffic_note"] = ("HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                    f"(profiles/pmc_traffic_{a.preset}.json); algorithmic bytes per launch = "
+                                    f"{v['bytes'] / max(v['calls'], 1):.0f}")
         roof["avg_launch_ms"] = round(v["avg_ms"], 4)
         roof["launches_per_step"] = v["calls"]
         roof["kernel_ms_per_step"] = round(tot, 2)

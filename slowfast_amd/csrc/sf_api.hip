@@ -117,10 +117,10 @@ template <int BN, int WM, int WN>
 static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s) {
     int mt = cdiv(p.M, 128);
     dim3 grid((unsigned)(mt * p.ntiles_n));
-    static const bool pf1 = getenv("SF_IGEMM_PF1") && atoi(getenv("SF_IGEMM_PF1")) != 0;   // A/B switch: one register stage
-    if (pf1) {
-        if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false>), grid, dim3(SF_THREADS), 0, s, p);
-        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false>), grid, dim3(SF_THREADS), 0, s, p);
+    static const bool pf2 = getenv("SF_IGEMM_PF2") && atoi(getenv("SF_IGEMM_PF2")) != 0;   // A/B switch: two register stages
+    if (pf2) {
+        if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true>), grid, dim3(SF_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, true>), grid, dim3(SF_THREADS), 0, s, p);
         return;
     }
     if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true>), grid, dim3(SF_THREADS), 0, s, p);
@@ -203,7 +203,9 @@ extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* 
 }
 
 template <int BMW, int WM, int WN, int KS>
-static void launch_wgrad(const WgradParams& p, dim3 grid, bool scalar, hipStream_t s) {
+static void launch_wgrad(WgradParams& p, dim3 grid3, bool scalar, hipStream_t s) {
+    p.tiles_k = grid3.x; p.tiles_c = grid3.y;
+    const dim3 grid(grid3.x * grid3.y * grid3.z);
     if (scalar) hipLaunchKernelGGL((sf_wgrad_kernel<BMW, WM, WN, KS, false>), grid, dim3(SF_THREADS), 0, s, p);
     else hipLaunchKernelGGL((sf_wgrad_kernel<BMW, WM, WN, KS, true>), grid, dim3(SF_THREADS), 0, s, p);
 }

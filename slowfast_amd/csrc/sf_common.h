@@ -52,6 +52,17 @@ __device__ __forceinline__ void fd_divmod(uint32_t x, const FastDiv& f, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// XCD-aware workgroup order.  Workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md); each XCD
+// has its own L2.  Remapping the linear id so that every XCD walks a CONTIGUOUS range of tiles keeps the tiles that
+// share an operand panel (same rows, neighbouring columns / same split) behind one L2 instead of eight.  Bijective for
+// any grid size; affects speed only.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t total) {
+    const uint32_t q = total >> 3, r = total & 7u;
+    const uint32_t xcd = bid & 7u, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// ---------------------------------------------------------------------------------------------
 // 16-byte global/LDS moves.
 __device__ __forceinline__ f16x8 ld16(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
 __device__ __forceinline__ void st16(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }

@@ -33,8 +33,11 @@ struct IgemmParams {
     float alpha;        // accumulators are scaled by alpha before bias / residual (0 means 1)
 };
 
-// PF2 = two register stages (loads of K-step s+2 in flight under step s) / one stage (loads of s+1 only)
-template <int BN, int WM, int WN, bool PW, bool PF2 = true>
+// PF2 = two register stages (loads of K-step s+2 in flight under step s) / one stage (loads of s+1 only).
+// Measured on MI355X (profiles/r1_visit7_*): the second stage costs ~90 VGPRs and one resident workgroup per CU
+// and is SLOWER end to end (SlowFast 383 vs 507 clips/s, X3D-M 809 vs 860, MViTv2-S equal): one stage is the default,
+// SF_IGEMM_PF2=1 selects the other for A/B runs.
+template <int BN, int WM, int WN, bool PW, bool PF2 = false>
 __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
     constexpr int BM = 128, BK = 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
@@ -54,7 +57,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int nt = blockIdx.x % p.ntiles_n, mt = blockIdx.x / p.ntiles_n;
+    const int tile = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = tile % p.ntiles_n, mt = tile / p.ntiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
     const GatherSide& g = p.g;
     const bool has_tf = g.scale != nullptr;
@@ -270,6 +274,7 @@ struct WgradParams {
     int Co_pad, Kpad;
     int nchunks;        // ceil(M / 32)
     int chunks_per_split;
+    int tiles_k, tiles_c;   // grid decomposition (1-D launch, XCD-remapped)
     // batched "TN" GEMM mode (attention dV / dK): blockIdx.z = b*bh + j selects the operands, one split, and the
     // tile is written directly as fp16: out[co][k] = out_scale * sum_m dy[m][co] * x[m][k]
     int bh;
@@ -389,7 +394,12 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int n0 = blockIdx.x * BNW, c0 = blockIdx.y * BMW;
+    // 1-D grid over (tile_k fastest, tile_c, split | batch), XCD-remapped: the tiles of one split share dy / x panels
+    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = (int)(wg % (uint32_t)p.tiles_k);
+    const int by = (int)((wg / (uint32_t)p.tiles_k) % (uint32_t)p.tiles_c);
+    const int bz = (int)(wg / ((uint32_t)p.tiles_k * (uint32_t)p.tiles_c));
+    const int n0 = bx * BNW, c0 = by * BMW;
     const GatherSide& g = p.g;
     const bool has_tf = g.scale != nullptr;
     if (has_tf) {
@@ -403,10 +413,10 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
     f16* out16 = p.out16;
     const int nstages = (p.nchunks + KS - 1) / KS;
     // this split's stages (chunks_per_split counts 32-position chunks and is a multiple of KS)
-    int sb = blockIdx.z * (p.chunks_per_split / KS);
+    int sb = bz * (p.chunks_per_split / KS);
     int se = sb + p.chunks_per_split / KS;
     if (p.bh > 0) {
-        const int zb = blockIdx.z / p.bh, zj = blockIdx.z % p.bh;
+        const int zb = bz / p.bh, zj = bz % p.bh;
         dy_src += zb * p.sp_b + zj * p.sp_h;
         x_src += zb * p.sx_b + zj * p.sx_h;
         out16 += zb * p.so_b + zj * p.so_h;
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
         return;
     }
     // every split owns its slab: plain (non-atomic) stores, also when it had no rows to reduce (zeros)
-    float* slab = p.ws + (int64_t)blockIdx.z * p.Co_pad * p.Kpad;
+    float* slab = p.ws + (int64_t)bz * p.Co_pad * p.Kpad;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int kcol = n0 + wn * WN + j * 16 + pl;
