@@ -244,6 +244,10 @@ __device__ __forceinline__ bool dwb_decode(const DwBlockIdx& bi, uint32_t item, 
     t = (int)tt; h = (int)hh; w0 = (int)wg * SF_DW_WB;
     return false;
 }
+// Out-of-range taps are read from a clamped (always valid) address and zeroed afterwards: the loads of a plane stay
+// unconditional, so they are issued back to back instead of one branch + s_waitcnt vmcnt(0) per tap.
+__device__ __forceinline__ f16x8 keep8(const f16x8& v, bool ok) { return ok ? v : zero8(); }
+__device__ __forceinline__ int clampi(int x, int hi) { return x < 0 ? 0 : (x > hi ? hi : x); }
 __device__ __forceinline__ void cvt8(const f16x8& v, float (&o)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
@@ -292,15 +296,13 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwPar
                     if ((unsigned)h >= (unsigned)p.Hi) continue;
                     const float* wt = s_w + ((kt * p.kH + kh) * KW) * p.Cw + cw;
                     const f16* line = xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx;
+                    f16x8 raw[NIN];
+#pragma unroll
+                    for (int j = 0; j < NIN; ++j) raw[j] = ld16(line + (int64_t)clampi(wi0 + j, p.Wi - 1) * p.ldx);
 #pragma unroll
                     for (int j = 0; j < NIN; ++j) {
-                        const int w = wi0 + j;
                         float xin[8];
-                        if ((unsigned)w < (unsigned)p.Wi) cvt8(ld16(line + (int64_t)w * p.ldx), xin);
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) xin[e] = 0.f;
-                        }
+                        cvt8(keep8(raw[j], (unsigned)(wi0 + j) < (unsigned)p.Wi), xin);
 #pragma unroll
                         for (int i = 0; i < SF_DW_WB; ++i) {
                             const int kw = j - i * SW;      // compile-time after unrolling
@@ -377,12 +379,13 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked_kernel(DwP
                 if (rh || qh >= (uint32_t)p.Ho) continue;
                 const float* wt = s_w + ((kt * p.kH + kh) * KW) * p.Cw + cw;
                 const f16* line = db + (((int64_t)qt * p.Ho + qh) * p.Wo) * p.lddy;
+                f16x8 raw[NQ];
+#pragma unroll
+                for (int jj = 0; jj < NQ; ++jj) raw[jj] = ld16(line + (int64_t)clampi(q0 + jj, p.Wo - 1) * p.lddy);
 #pragma unroll
                 for (int jj = 0; jj < NQ; ++jj) {
-                    const int q = q0 + jj;
-                    if ((unsigned)q >= (unsigned)p.Wo) continue;
                     float d[8];
-                    cvt8(ld16(line + (int64_t)q * p.lddy), d);
+                    cvt8(keep8(raw[jj], (unsigned)(q0 + jj) < (unsigned)p.Wo), d);
 #pragma unroll
                     for (int i = 0; i < SF_DW_WB; ++i) {
                         const int kw = B0 + i - jj * SW;
@@ -433,7 +436,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_blocked_kernel(DwP
             const f16* drow = p.dy + ((int64_t)n * So + p.cls + ((int64_t)to * p.Ho + ho) * p.Wo + wo0) * p.lddy + c;
             f16x8 d[SF_DW_WB];
 #pragma unroll
-            for (int i = 0; i < SF_DW_WB; ++i) d[i] = wo0 + i < p.Wo ? ld16(drow + (int64_t)i * p.lddy) : zero8();
+            for (int i = 0; i < SF_DW_WB; ++i)
+                d[i] = keep8(ld16(drow + (int64_t)(wo0 + i < p.Wo ? i : 0) * p.lddy), wo0 + i < p.Wo);
             const f16* xb = p.x + ((int64_t)n * Si + p.cls) * p.ldx + c;
             const int wi0 = wo0 * SW - p.pW;
 #pragma unroll
@@ -442,12 +446,13 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_blocked_kernel(DwP
                     const int h = ho * p.sH - p.pH + kh;
                     if ((unsigned)h < (unsigned)p.Hi) {
                         const f16* line = xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx;
+                        f16x8 raw[NIN];
+#pragma unroll
+                        for (int j = 0; j < NIN; ++j) raw[j] = ld16(line + (int64_t)clampi(wi0 + j, p.Wi - 1) * p.ldx);
 #pragma unroll
                         for (int j = 0; j < NIN; ++j) {
-                            const int w = wi0 + j;
-                            if ((unsigned)w >= (unsigned)p.Wi) continue;
                             float xin[8];
-                            cvt8(ld16(line + (int64_t)w * p.ldx), xin);
+                            cvt8(keep8(raw[j], (unsigned)(wi0 + j) < (unsigned)p.Wi), xin);
 #pragma unroll
                             for (int i = 0; i < SF_DW_WB; ++i) {
                                 const int kw = j - i * SW;
