@@ -7,6 +7,7 @@
 #include "sf_dwconv.h"
 #include "sf_tokens.h"
 #include "sf_x3d.h"
+#include "sf_stem.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -123,6 +124,14 @@ static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s) {
         else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, true>), grid, dim3(SF_THREADS), 0, s, p);
         return;
     }
+    static const bool occ4 = getenv("SF_IGEMM_OCC4") && atoi(getenv("SF_IGEMM_OCC4")) != 0;  // A/B switch: 128-VGPR cap
+    if constexpr (BN == 128) {
+        if (occ4) {
+            if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, true>), grid, dim3(SF_THREADS), 0, s, p);
+            else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, true>), grid, dim3(SF_THREADS), 0, s, p);
+            return;
+        }
+    }
     if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true>), grid, dim3(SF_THREADS), 0, s, p);
     else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false>), grid, dim3(SF_THREADS), 0, s, p);
 }
@@ -133,6 +142,56 @@ static int run_igemm(IgemmParams& p, bool pw, hipStream_t s) {
     else if (p.Nout > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, pw, s); }
     else { p.ntiles_n = 1; launch_igemm<16, 32, 16>(p, pw, s); }
     return check_launch("igemm");
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-patch direct convolution for the thin W-pair-folded stems (sf_stem.h); SF_STEM_GENERIC=1 keeps the implicit GEMM.
+struct StemPlan {
+    bool ok;
+    int tiles_w, tiles_h, tiles_t, ntiles, F, PR;
+    int wg_blocks, tiles_per_block, Kpad;
+    size_t ws_bytes;
+};
+static StemPlan plan_stem(const sf_conv_desc* d) {
+    StemPlan s;
+    memset(&s, 0, sizeof(s));
+    static const bool off = getenv("SF_STEM_GENERIC") && atoi(getenv("SF_STEM_GENERIC")) != 0;
+    if (off) return s;
+    if (d->Ci != 8 || d->Cw != 8 || d->kW != 4 || d->sW != 1 || d->pW != 2 || d->dT != 1 || d->dH != 1 || d->dW != 1)
+        return s;
+    if (d->Co > 16 || d->Co % 8 != 0 || (d->Cow && d->Cow != d->Co)) return s;
+    if (d->kT * d->kH > SF_STEM_MAX_SLICES) return s;
+    s.F = (SF_STEM_TT - 1) * d->sT + d->kT;
+    s.PR = (SF_STEM_TH - 1) * d->sH + d->kH;
+    if ((int64_t)s.F * s.PR * SF_STEM_PC > SF_STEM_CHUNKS) return s;
+    s.tiles_w = cdiv(d->Wo, SF_STEM_TW);
+    s.tiles_h = cdiv(d->Ho, SF_STEM_TH);
+    s.tiles_t = cdiv(d->To, SF_STEM_TT);
+    const int64_t nt = (int64_t)d->N * s.tiles_t * s.tiles_h * s.tiles_w;
+    if (nt >= (1ll << 30)) return s;
+    s.ntiles = (int)nt;
+    int g = s.ntiles < 512 ? s.ntiles : 512;             // 2 persistent 8-wave workgroups per CU
+    s.tiles_per_block = cdiv(s.ntiles, g);
+    s.wg_blocks = cdiv(s.ntiles, s.tiles_per_block);
+    s.Kpad = roundup(d->kT * d->kH * 32, 128);
+    s.ws_bytes = (size_t)s.wg_blocks * 16 * s.Kpad * 4;
+    s.ok = true;
+    return s;
+}
+static StemParams stem_params(const sf_conv_desc* d, const StemPlan& s, const void* x) {
+    StemParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const f16*)x; p.ldx = d->ldx;
+    p.N = d->N; p.Ti = d->Ti; p.Hi = d->Hi; p.Wi = d->Wi;
+    p.To = d->To; p.Ho = d->Ho; p.Wo = d->Wo; p.Co = d->Co;
+    p.kT = d->kT; p.kH = d->kH; p.sT = d->sT; p.sH = d->sH; p.pT = d->pT; p.pH = d->pH;
+    p.ldy = d->ldy;
+    p.tiles_w = s.tiles_w; p.tiles_h = s.tiles_h; p.tiles_t = s.tiles_t; p.ntiles = s.ntiles;
+    p.fd_tw = make_fastdiv(s.tiles_w); p.fd_th = make_fastdiv(s.tiles_h); p.fd_tt = make_fastdiv(s.tiles_t);
+    p.F = s.F; p.PR = s.PR;
+    p.fd_pc = make_fastdiv(SF_STEM_PC); p.fd_prpc = make_fastdiv(s.PR * SF_STEM_PC);
+    p.Kpad = s.Kpad; p.tiles_per_block = s.tiles_per_block;
+    return p;
 }
 
 extern "C" int sf_conv_weight_ld(const sf_conv_desc* d, int32_t* ldf, int32_t* ldd) {
@@ -170,6 +229,20 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf,
     REQUIRE(x && wf && y, "sf_conv_fwd: null pointer");
     REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sf_conv_fwd: in_scale/in_shift must come together");
     REQUIRE(!in_scale || d->Ci <= 512, "sf_conv_fwd: fused input BatchNorm supports Ci <= 512 (got %d)", d->Ci);
+    if (!in_scale && !bias) {
+        const StemPlan sp = plan_stem(d);
+        if (sp.ok && (!stat_part || sp.ntiles <= sf_conv_fwd_mtiles(d))) {
+            StemParams q = stem_params(d, sp, x);
+            int32_t ldf0, ldd0;
+            sf_conv_weight_ld(d, &ldf0, &ldd0);
+            q.wmat = (const f16*)wf; q.ldw = ldf0; q.y = (f16*)y;
+            q.stat_part = stat_part; q.stat_rows = sf_conv_fwd_mtiles(d);
+            static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+            if (trace) fprintf(stderr, "[sfamd] stem_fwd: %d tiles, patch %dx%dx%d chunks\n", sp.ntiles, sp.F, sp.PR, SF_STEM_PC);
+            hipLaunchKernelGGL(sf_stem_fwd_kernel, dim3(sp.ntiles), dim3(SF_THREADS), 0, (hipStream_t)stream, q);
+            return check_launch("stem_fwd");
+        }
+    }
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.g = gather_fwd(d, x, in_scale, in_shift, in_relu);
@@ -244,7 +317,9 @@ static WgradPlan plan_wgrad(const sf_conv_desc* d) {
 
 extern "C" int64_t sf_conv_wgrad_workspace(const sf_conv_desc* d) {
     if (check_desc(d)) return -1;
-    return (int64_t)plan_wgrad(d).ws_bytes;
+    const int64_t generic = (int64_t)plan_wgrad(d).ws_bytes;
+    const StemPlan sp = plan_stem(d);
+    return sp.ok && (int64_t)sp.ws_bytes > generic ? (int64_t)sp.ws_bytes : generic;
 }
 
 extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
@@ -256,32 +331,48 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
     REQUIRE(!in_scale || d->Ci <= 512, "sf_conv_wgrad: fused input BatchNorm supports Ci <= 512 (got %d)", d->Ci);
     static const bool scalar = getenv("SF_WGRAD_SCALAR") && atoi(getenv("SF_WGRAD_SCALAR")) != 0;
     hipStream_t s = (hipStream_t)stream;
-    const WgradPlan w = plan_wgrad(d);
-    REQUIRE(workspace_bytes >= (int64_t)w.ws_bytes, "sf_conv_wgrad: workspace too small (%lld < %lld bytes)",
-            (long long)workspace_bytes, (long long)w.ws_bytes);
-    REQUIRE(w.splits <= 65535, "sf_conv_wgrad: too many splits");
-    WgradParams p;
-    memset(&p, 0, sizeof(p));
-    p.g = gather_fwd(d, x, in_scale, in_shift, in_relu);
-    p.dy = (const f16*)dy; p.ldy = d->ldy; p.Co = d->Co;
-    p.M = d->N * d->To * d->Ho * d->Wo;
-    p.ws = (float*)workspace; p.Co_pad = w.Co_pad; p.Kpad = w.Kpad;
-    p.nchunks = w.nchunks; p.chunks_per_split = w.chunks_per_split;
-    dim3 grid(w.tiles_k, w.tiles_c, w.splits);
-    switch (w.BMW) {
-        case 128: launch_wgrad<128, 64, 64, 1>(p, grid, scalar, s); break;
-        case 64: launch_wgrad<64, 32, 64, 1>(p, grid, scalar, s); break;
-        case 32: launch_wgrad<32, 32, 32, 4>(p, grid, scalar, s); break;
-        default: launch_wgrad<16, 16, 32, 4>(p, grid, scalar, s); break;
+    int splits, Co_pad, Kpad;
+    GatherSide gk = gather_fwd(d, x, in_scale, in_shift, in_relu);
+    const StemPlan sp = plan_stem(d);
+    if (sp.ok && !in_scale) {
+        REQUIRE(workspace_bytes >= (int64_t)sp.ws_bytes, "sf_conv_wgrad: workspace too small (%lld < %lld bytes)",
+                (long long)workspace_bytes, (long long)sp.ws_bytes);
+        StemParams q = stem_params(d, sp, x);
+        q.dy = (const f16*)dy; q.ws = (float*)workspace;
+        static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+        if (trace) fprintf(stderr, "[sfamd] stem_wgrad: %d workgroups x %d tiles\n", sp.wg_blocks, sp.tiles_per_block);
+        if (d->Co <= 8) hipLaunchKernelGGL((sf_stem_wgrad_kernel<8>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
+        else hipLaunchKernelGGL((sf_stem_wgrad_kernel<16>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
+        splits = sp.wg_blocks; Co_pad = 16; Kpad = sp.Kpad;
+    } else {
+        const WgradPlan w = plan_wgrad(d);
+        REQUIRE(workspace_bytes >= (int64_t)w.ws_bytes, "sf_conv_wgrad: workspace too small (%lld < %lld bytes)",
+                (long long)workspace_bytes, (long long)w.ws_bytes);
+        REQUIRE(w.splits <= 65535, "sf_conv_wgrad: too many splits");
+        WgradParams p;
+        memset(&p, 0, sizeof(p));
+        p.g = gk;
+        p.dy = (const f16*)dy; p.ldy = d->ldy; p.Co = d->Co;
+        p.M = d->N * d->To * d->Ho * d->Wo;
+        p.ws = (float*)workspace; p.Co_pad = w.Co_pad; p.Kpad = w.Kpad;
+        p.nchunks = w.nchunks; p.chunks_per_split = w.chunks_per_split;
+        dim3 grid(w.tiles_k, w.tiles_c, w.splits);
+        switch (w.BMW) {
+            case 128: launch_wgrad<128, 64, 64, 1>(p, grid, scalar, s); break;
+            case 64: launch_wgrad<64, 32, 64, 1>(p, grid, scalar, s); break;
+            case 32: launch_wgrad<32, 32, 32, 4>(p, grid, scalar, s); break;
+            default: launch_wgrad<16, 16, 32, 4>(p, grid, scalar, s); break;
+        }
+        splits = w.splits; Co_pad = w.Co_pad; Kpad = w.Kpad;
     }
     if (check_launch("wgrad")) return -1;
     WgradReduceParams r;
-    r.ws = (const float*)workspace; r.splits = w.splits; r.Co = d->Cow ? d->Cow : d->Co; r.Co_pad = w.Co_pad; r.Kpad = w.Kpad;
-    r.Ktot = p.g.Ktot; r.fdC = p.g.fdC; r.dw = dw; r.Cw = d->Cw; r.taps = d->kT * d->kH * d->kW;
+    r.ws = (const float*)workspace; r.splits = splits; r.Co = d->Cow ? d->Cow : d->Co; r.Co_pad = Co_pad; r.Kpad = Kpad;
+    r.Ktot = gk.Ktot; r.fdC = gk.fdC; r.dw = dw; r.Cw = d->Cw; r.taps = d->kT * d->kH * d->kW;
     r.out_scale = out_scale; r.accumulate = zero_first ? 0 : 1;
-    int64_t total = (int64_t)r.Co * w.Kpad;
+    int64_t total = (int64_t)r.Co * Kpad;
     int lanes = 1;
-    while (lanes < 32 && lanes * 4 <= w.splits) lanes *= 2;   // ~>= 4 splits per lane, 8..256 elements per block
+    while (lanes < 32 && lanes * 4 <= splits) lanes *= 2;   // ~>= 4 splits per lane, 8..256 elements per block
     r.lanes = lanes;
     const int per_block = SF_THREADS / lanes;
     hipLaunchKernelGGL(sf_wgrad_reduce_kernel, dim3(cdiv(total, per_block)), dim3(SF_THREADS), 0, s, r);

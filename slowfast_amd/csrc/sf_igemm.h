@@ -37,8 +37,10 @@ struct IgemmParams {
 // Measured on MI355X (profiles/r1_visit7_*): the second stage costs ~90 VGPRs and one resident workgroup per CU
 // and is SLOWER end to end (SlowFast 383 vs 507 clips/s, X3D-M 809 vs 860, MViTv2-S equal): one stage is the default,
 // SF_IGEMM_PF2=1 selects the other for A/B runs.
-template <int BN, int WM, int WN, bool PW, bool PF2 = false>
-__global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
+// OCC4 caps the kernel at 128 VGPRs (4 workgroups = 16 waves per CU for the 128-wide tile, whose 40 KiB of LDS allow
+// exactly 4): SF_IGEMM_OCC4=1 selects it for A/B runs.
+template <int BN, int WM, int WN, bool PW, bool PF2 = false, bool OCC4 = false>
+__global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(IgemmParams p) {
     constexpr int BM = 128, BK = 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -106,7 +108,10 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
             int64_t off;
             uint32_t c0 = 0;
             bool ok = PW ? gather_offset_pw(g, rp[j], k0, off, c0) : gather_offset(g, rp[j], k0, off, c0);
-            st.ra[j] = ok ? ld16(a_src + off) : zero8();
+            // unconditional load from a valid address, zeroed afterwards: keeps the loads out of exec-masked branches
+            // so that the compiler can count them (s_waitcnt vmcnt(N)) instead of draining the queue
+            const f16x8 v = ld16(a_src + (ok ? off : 0));
+            st.ra[j] = ok ? v : zero8();
             st.ok[j] = ok;
             st.c0[j] = c0;
         }
@@ -116,7 +121,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_igemm_kernel(IgemmParams p) {
             int brow = idx >> 2;
             int co = n0 + brow;
             bool ok = (idx < BN * 4) && (co < p.Nout) && (k0 < (uint32_t)g.Ktot);
-            st.rb[j] = ok ? ld16(wmat + (int64_t)co * p.ldw + k0) : zero8();
+            const f16x8 v = ld16(wmat + (ok ? (int64_t)co * p.ldw + k0 : 0));
+            st.rb[j] = ok ? v : zero8();
         }
     };
     auto store_tile = [&](int buf, const Stage& st) {
@@ -437,7 +443,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             int ml = idx / (BMW / 8), cg = idx % (BMW / 8);
             int m = mbase + ml, co = c0 + cg * 8;
             bool ok = (idx < ROWS * (BMW / 8)) && (m < p.M) && (co < p.Co);
-            ra[j] = ok ? ld16(dy_src + (int64_t)m * p.ldy + co) : zero8();
+            const f16x8 v = ld16(dy_src + (ok ? (int64_t)m * p.ldy + co : 0));
+            ra[j] = ok ? v : zero8();
         }
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
@@ -445,7 +452,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             RowPos rp = decode_row(g, (uint32_t)m, m < p.M);
             int64_t off;
             bool ok = gather_offset_tap(g, rp, tp, off);
-            rb[j] = ok ? ld16(x_src + off) : zero8();
+            const f16x8 v = ld16(x_src + (ok ? off : 0));
+            rb[j] = ok ? v : zero8();
             rb_ok[j] = ok;
         }
     };

@@ -1,0 +1,269 @@
+// Direct convolution for the thin RGB stems (forward + weight gradient), LDS-patch based.
+//
+// Reference call sites: slowfast/models/stem_helper.py:182-189 (ResNetBasicStem.conv, the Fast pathway's
+// Conv3d(3, 8, [5,7,7], stride [1,2,2], padding [2,3,3])) and its autograd backward w.r.t. the weight.
+//
+// The generic implicit GEMM (sf_igemm.h) gathers every im2col element with its own global load: for the Fast
+// stem that is M*K*2 B = 12.8M x 1120 x 2 = 28.7 GB through the vector L1 per pass, although the clip itself is
+// only 0.41 GB.  Here a workgroup stages the input PATCH of its output tile in LDS once and the MFMA operands are
+// read straight out of that patch -- no im2col matrix exists anywhere:
+//
+//   * the clip is the W-pair view N,T,H,W/2,8 (engine.StemConvUnit): one 16-byte chunk = 2 pixels x 4 channels,
+//     the kernel is (kT, kH, 4 pairs) with pair stride 1, pair padding 2;
+//   * for a fixed (kt, kh) the K-slice of an output pixel (4 pairs x 8 = 32 halfs) is CONTIGUOUS in the patch row
+//     and the slices of neighbouring pixels overlap, 16 bytes apart: a 16x16x32 MFMA operand is one ds_read_b128
+//     per lane at  patch[frame][row][pixel + lane/16];
+//   * forward:  D[co][pixel] += W[co][slice] * patch-slice[pixel]      (A = weights, B = pixels)
+//     wgrad:    D[co][k]     += dy^T[co][pixel] * patch-slice[pixel][k] (32 pixels reduced per MFMA; both operands
+//               come from ds_read_b64_tr_b16 with per-lane row addresses, the "rows" being overlapping windows).
+//
+// Tile: 4 output frames x 8 rows x 16 pixels per workgroup; patch = (3 sT + kT) x (7 sH + kH) x 19 chunks.
+#pragma once
+#include "sf_common.h"
+
+#define SF_STEM_TT 4
+#define SF_STEM_TH 8
+#define SF_STEM_TW 16
+#define SF_STEM_PC (SF_STEM_TW + 3)
+#define SF_STEM_CHUNKS 3328          // 16-byte chunks of LDS for the patch (52 KiB)
+#define SF_STEM_WG_THREADS 512
+#define SF_STEM_MAX_SLICES 40        // kT * kH
+
+struct StemParams {
+    const f16* x; int ldx;            // W-pair view rows (n, t, h, w2), 8 channels
+    int N, Ti, Hi, Wi;                // Wi counts pairs
+    int To, Ho, Wo, Co;
+    int kT, kH, sT, sH, pT, pH;       // kW = 4 pairs, sW = 1 pair, pW = 2 pairs
+    const f16* wmat; int ldw;         // [Co][ldw], k = (kt*kH + kh)*32 + pair*8 + e
+    f16* y; int ldy;
+    float* stat_part; int stat_rows;  // [stat_rows][2][Co]; rows beyond the workgroup count are zeroed here
+    int tiles_w, tiles_h, tiles_t, ntiles;
+    FastDiv fd_tw, fd_th, fd_tt;
+    int F, PR;                        // patch frames / rows
+    FastDiv fd_pc, fd_prpc;
+    // weight gradient
+    const f16* dy;
+    float* ws; int Kpad;              // per-workgroup slab [16][Kpad] fp32
+    int tiles_per_block;
+};
+
+struct StemTile { int n, t0, h0, w0; };
+__device__ __forceinline__ StemTile stem_tile(const StemParams& p, uint32_t tile) {
+    StemTile t;
+    uint32_t a = fd_div(tile, p.fd_tw);
+    t.w0 = (int)(tile - a * (uint32_t)p.tiles_w) * SF_STEM_TW;
+    uint32_t b = fd_div(a, p.fd_th);
+    t.h0 = (int)(a - b * (uint32_t)p.tiles_h) * SF_STEM_TH;
+    uint32_t c = fd_div(b, p.fd_tt);
+    t.t0 = (int)(b - c * (uint32_t)p.tiles_t) * SF_STEM_TT;
+    t.n = (int)c;
+    return t;
+}
+
+// stage the input patch of one tile: chunk (f, r, c) <- x[n][t0*sT - pT + f][h0*sH - pH + r][w0 - 2 + c], zeros outside
+template <int NTHREADS>
+__device__ __forceinline__ void stem_load_patch(const StemParams& p, f16* patch, const StemTile& t, int tid) {
+    constexpr int U = 7;               // 16-byte loads in flight per thread (the Fast stem's patch is 12.5 / 6.2 per thread)
+    const int nch = p.F * p.PR * SF_STEM_PC;
+    const int tin0 = t.t0 * p.sT - p.pT, hin0 = t.h0 * p.sH - p.pH, win0 = t.w0 - 2;
+    for (int base = 0; base < nch; base += NTHREADS * U) {
+        f16x8 v[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t c = (uint32_t)(base + tid + NTHREADS * u);
+            const uint32_t f = fd_div(c, p.fd_prpc);
+            const uint32_t rem = c - f * (uint32_t)(p.PR * SF_STEM_PC);
+            const uint32_t r = fd_div(rem, p.fd_pc);
+            const int col = (int)(rem - r * SF_STEM_PC);
+            const int tin = tin0 + (int)f, hin = hin0 + (int)r, win = win0 + col;
+            ok[u] = (int)c < nch && (unsigned)tin < (unsigned)p.Ti && (unsigned)hin < (unsigned)p.Hi &&
+                    (unsigned)win < (unsigned)p.Wi;
+            const int64_t off = ok[u] ? ((((int64_t)t.n * p.Ti + tin) * p.Hi + hin) * p.Wi + win) * p.ldx : 0;
+            v[u] = ld16(p.x + off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = base + tid + NTHREADS * u;
+            if (c < nch) st16(patch + (int64_t)c * 8, ok[u] ? v[u] : zero8());
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: wave w owns output frame t0 + w of the tile (8 rows x 16 pixels = 8 MFMA column tiles)
+__global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_kernel(StemParams p) {
+    __shared__ __attribute__((aligned(16))) f16 patch[SF_STEM_CHUNKS * 8];
+    __shared__ float s_red[4][2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g4 = lane >> 4;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const StemTile t = stem_tile(p, bid);
+    stem_load_patch<SF_THREADS>(p, patch, t, tid);
+
+    f32x4 acc[SF_STEM_TH];
+#pragma unroll
+    for (int i = 0; i < SF_STEM_TH; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool co_ok = pl < p.Co;
+    const f16* wrow = p.wmat + (co_ok ? (int64_t)pl * p.ldw : 0) + 8 * g4;
+    const int nsl = p.kT * p.kH;
+    f16x8 wf = ld16(wrow);
+    __syncthreads();
+    int kt = 0, kh = 0;
+    const int row_step = p.sH * SF_STEM_PC * 8;
+    for (int s = 0; s < nsl; ++s) {
+        const int sn = s + 1 < nsl ? s + 1 : s;
+        const f16x8 wnext = ld16(wrow + sn * 32);
+        const f16x8 a = co_ok ? wf : zero8();
+        const f16* base = patch + (((wave * p.sT + kt) * p.PR + kh) * SF_STEM_PC + pl + g4) * 8;
+        f16x8 px[SF_STEM_TH];
+#pragma unroll
+        for (int i = 0; i < SF_STEM_TH; ++i) px[i] = ld16(base + i * row_step);
+#pragma unroll
+        for (int i = 0; i < SF_STEM_TH; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, px[i], acc[i], 0, 0, 0);
+        wf = wnext;
+        if (++kh == p.kH) { kh = 0; ++kt; }
+    }
+
+    // lane: channels 4*g4 .. 4*g4+3 of pixel (t0 + wave, h0 + i, w0 + pl)
+    const int to = t.t0 + wave, wo = t.w0 + pl;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < SF_STEM_TH; ++i) {
+        const int ho = t.h0 + i;
+        const bool ok = to < p.To && ho < p.Ho && wo < p.Wo;
+        if (ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s4[r] += acc[i][r]; q4[r] += acc[i][r] * acc[i][r]; }
+            if (4 * g4 < p.Co) {
+                const int64_t m = (((int64_t)t.n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+                f16x4 o = {(f16)acc[i][0], (f16)acc[i][1], (f16)acc[i][2], (f16)acc[i][3]};
+                *reinterpret_cast<f16x4*>(p.y + m * p.ldy + 4 * g4) = o;
+            }
+        }
+    }
+    if (p.stat_part) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int mask = 1; mask < 16; mask <<= 1) {
+                s4[r] += __shfl_xor(s4[r], mask);
+                q4[r] += __shfl_xor(q4[r], mask);
+            }
+            if (pl == 0) {
+                s_red[wave][0][4 * g4 + r] = s4[r];
+                s_red[wave][1][4 * g4 + r] = q4[r];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * p.Co) {
+            const int which = tid / p.Co, co = tid % p.Co;
+            const float v = s_red[0][which][co] + s_red[1][which][co] + s_red[2][which][co] + s_red[3][which][co];
+            p.stat_part[((int64_t)bid * 2 + which) * p.Co + co] = v;
+            // the table has one row per 128 output positions: rows no workgroup owns must read as zero
+            for (int64_t row = (int64_t)bid + gridDim.x; row < p.stat_rows; row += gridDim.x)
+                p.stat_part[(row * 2 + which) * p.Co + co] = 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: persistent workgroups (8 waves) over a contiguous range of tiles; wave w accumulates the
+// K-slices s = w, w+8, ... (s = kt*kH + kh, 32 weights each, two 16-column MFMA tiles) for all 16 channel rows.
+template <int COP>
+__global__ __launch_bounds__(SF_STEM_WG_THREADS, 4) void sf_stem_wgrad_kernel(StemParams p) {
+    constexpr int NW = SF_STEM_WG_THREADS / 64;
+    constexpr int NQ = SF_STEM_MAX_SLICES / NW;
+    constexpr int NPIX = SF_STEM_TT * SF_STEM_TH * SF_STEM_TW;
+    __shared__ __attribute__((aligned(16))) f16 patch[SF_STEM_CHUNKS * 8];
+    __shared__ __attribute__((aligned(16))) f16 dyt[NPIX * COP + 8];     // + 8 zeros: the channel chunks beyond COP
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g4 = lane >> 4;
+    const int nsl = p.kT * p.kH;
+
+    f32x4 acc[NQ][2];
+    int koff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int s = wave + NW * q;
+        const int kt = s / p.kH, kh = s - kt * p.kH;
+        koff[q] = (kt * p.PR + kh) * SF_STEM_PC;
+    }
+    if (tid < 8) dyt[NPIX * COP + tid] = (f16)0;
+
+    // per-lane pixel of the transposed reads: kk = 8*g4 + 4*h + (pl>>2) -> (row offset kk>>4, column kk&15)
+    int pix_row[2], pix_col[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int kk = 8 * g4 + 4 * h + (pl >> 2);
+        pix_row[h] = kk >> 4;
+        pix_col[h] = kk & 15;
+    }
+    const int cchunk = 4 * (pl & 3);
+    const int frame_step = p.sT * p.PR * SF_STEM_PC;
+
+    const int tile_begin = blockIdx.x * p.tiles_per_block;
+    int tile_end = tile_begin + p.tiles_per_block;
+    if (tile_end > p.ntiles) tile_end = p.ntiles;
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const StemTile t = stem_tile(p, (uint32_t)tile);
+        __syncthreads();
+        stem_load_patch<SF_STEM_WG_THREADS>(p, patch, t, tid);
+        for (int idx = tid; idx < NPIX * (COP / 8); idx += SF_STEM_WG_THREADS) {
+            const int pix = idx / (COP / 8), cg = idx % (COP / 8);
+            const int w = pix % SF_STEM_TW, hh = (pix / SF_STEM_TW) % SF_STEM_TH, tt = pix / (SF_STEM_TW * SF_STEM_TH);
+            const int to = t.t0 + tt, ho = t.h0 + hh, wo = t.w0 + w;
+            const bool ok = to < p.To && ho < p.Ho && wo < p.Wo && cg * 8 < p.Co;
+            const int64_t m = (((int64_t)t.n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+            const f16x8 v = ld16(p.dy + (ok ? m * p.ldy + cg * 8 : 0));
+            st16(dyt + pix * COP + cg * 8, ok ? v : zero8());
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tc = 0; tc < SF_STEM_TT * (SF_STEM_TH / 2); ++tc) {
+            {
+                const int tt = tc / (SF_STEM_TH / 2), c = tc % (SF_STEM_TH / 2);
+                f16x8 af;
+                int xoff[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int hh = 2 * c + pix_row[h];
+                    const int pix = (tt * SF_STEM_TH + hh) * SF_STEM_TW + pix_col[h];
+                    const f16* ptr = cchunk < COP ? dyt + pix * COP + cchunk : dyt + NPIX * COP + (cchunk & 4);
+                    f16x4 tv = as_f16x4(SF_LDS_TR16(ptr));
+                    af[4 * h + 0] = tv[0]; af[4 * h + 1] = tv[1]; af[4 * h + 2] = tv[2]; af[4 * h + 3] = tv[3];
+                    xoff[h] = (tt * frame_step + hh * p.sH * SF_STEM_PC + pix_col[h]) * 8 + cchunk;
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (wave + NW * q < nsl) {
+#pragma unroll
+                        for (int jh = 0; jh < 2; ++jh) {
+                            f16x8 bf;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                f16x4 tv = as_f16x4(SF_LDS_TR16(patch + xoff[h] + (koff[q] + 2 * jh) * 8));
+                                bf[4 * h + 0] = tv[0]; bf[4 * h + 1] = tv[1]; bf[4 * h + 2] = tv[2]; bf[4 * h + 3] = tv[3];
+                            }
+                            acc[q][jh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[q][jh], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // slab[co][k]: co = 4*g4 + r, k = s*32 + 16*jh + pl
+    float* slab = p.ws + (int64_t)blockIdx.x * 16 * p.Kpad;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int s = wave + NW * q;
+        if (s < nsl) {
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(int64_t)(4 * g4 + r) * p.Kpad + s * 32 + 16 * jh + pl] = acc[q][jh][r];
+        }
+    }
+}

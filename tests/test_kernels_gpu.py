@@ -53,6 +53,21 @@ def test_conv_stem(gpu):
     kc.check_conv_wgrad(gpu, (1, 8, 8, 32, 32), 8, (5, 7, 7), (1, 2, 2), (2, 3, 3), Cw=3)
 
 
+STEM_DIRECT_CASES = [
+    ((2, 8, 6, 36, 22), 8, (5, 7, 4), (1, 2, 1), (2, 3, 2)),      # ragged tiles in t, h and w
+    ((1, 8, 3, 20, 20), 16, (1, 7, 4), (1, 2, 1), (0, 3, 2)),     # kT = 1, 16 output channels
+    ((1, 8, 9, 10, 9), 8, (3, 5, 4), (2, 1, 1), (1, 2, 2)),       # temporal stride 2, spatial stride 1
+    ((2, 8, 16, 112, 56), 8, (5, 7, 4), (1, 2, 1), (2, 3, 2)),    # Fast-stem geometry, many workgroups per CU
+]
+
+
+@pytest.mark.parametrize("case", STEM_DIRECT_CASES)
+def test_stem_direct(gpu, case):
+    """W-pair-folded thin stems: the LDS-patch direct convolution of sf_stem.h (forward + weight gradient)."""
+    kc.check_conv_fwd(gpu, *case, Cw=8)
+    kc.check_conv_wgrad(gpu, *case, Cw=8)
+
+
 def test_wgrad_scalar_fragment_path(gpu):
     """The transpose-read (ds_read_b64_tr_b16) and the scalar LDS fragment paths must agree with torch."""
     code = ("import torch; from tests import kernel_checks as kc; d=torch.device('cuda:0');"

@@ -35,6 +35,24 @@ def test_conv_fwd_stem(sim):
     kc.check_conv_fwd(sim, (1, 8, 5, 6, 6), 8, (5, 7, 7), (1, 2, 2), (2, 3, 3), Cw=3)
 
 
+# W-pair-folded thin stems (engine.StemConvUnit geometry): the LDS-patch direct convolution of sf_stem.h
+STEM_CASES = [
+    ((2, 8, 6, 36, 22), 8, (5, 7, 4), (1, 2, 1), (2, 3, 2)),     # Fast stem, ragged tiles in t, h and w
+    ((1, 8, 3, 20, 20), 16, (1, 7, 4), (1, 2, 1), (0, 3, 2)),    # kT = 1, 16 output channels
+    ((1, 8, 9, 10, 9), 8, (3, 5, 4), (2, 1, 1), (1, 2, 2)),      # temporal stride 2, spatial stride 1
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_stem_direct_fwd(sim, case):
+    kc.check_conv_fwd(sim, *case, Cw=8)
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_stem_direct_wgrad(sim, case):
+    kc.check_conv_wgrad(sim, *case, Cw=8)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_dgrad(sim, case):
     kc.check_conv_dgrad(sim, *case)

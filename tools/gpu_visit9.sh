@@ -1,0 +1,14 @@
+#!/bin/bash
+# GPU visit 9: LDS-patch stem kernels (sf_stem.h), unconditional igemm/wgrad operand loads, OCC4 A/B.
+mkdir -p gpurun_out
+export PYTHONPATH=$PWD
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -q -m gpu --tb=short > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest gpu rc=$?" | tee -a gpurun_out/pytest_gpu.log
+grep -E "passed|failed|rc=|Error|FAILED" gpurun_out/pytest_gpu.log | tail -12 | cut -c1-600
+for P in "SLOWFAST_8x8_R50 32 slowfast" "MVITv2_S_16x4 32 mvit" "X3D_M 64 x3d"; do
+  set -- $P
+  timeout 600 python bench.py --preset $1 --batch $2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_$3.log 2>&1; echo "bench $3 rc=$?"; tail -1 gpurun_out/bench_$3.log | cut -c1-1800
+  SF_IGEMM_OCC4=1 timeout 600 python bench.py --preset $1 --batch $2 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-profile > gpurun_out/bench_$3_occ4.log 2>&1; echo "bench $3 (occ4) rc=$?"; tail -1 gpurun_out/bench_$3_occ4.log | cut -c1-400
+done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1v9_slowfast -- python bench.py --preset SLOWFAST_8x8_R50 --batch 32 --steps 2 --warmup 2 --no-cpu-baseline --no-kernel-profile > gpurun_out/rocprof_slowfast.log 2>&1; echo "rocprof slowfast rc=$?"
