@@ -28,12 +28,26 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
 # per clip, SlowFast-8x8-R50 32x224^2: MAC_fwd 50.309 G -> 6*MAC train flops; boundary elements
 # E = 216.5 M -> byte floor 5*E*2 B = 2.165 GB
-TRAIN_GFLOP_PER_CLIP = {"SLOWFAST_8x8_R50": 301.9, "C2D_8x8_R50": 117.0, "MVITv2_S_16x4": 383.6, "X3D_M": 28.4}
-BYTE_FLOOR_GB_PER_CLIP = {"SLOWFAST_8x8_R50": 2.165, "C2D_8x8_R50": 1.019, "MVITv2_S_16x4": 1.845, "X3D_M": 0.989}
+TRAIN_GFLOP_PER_CLIP = {"SLOWFAST_8x8_R50": 301.9, "C2D_8x8_R50": 117.0, "MVITv2_S_16x4": 383.6, "X3D_M": 28.4,
+                        "SLOWFAST_32x2_R101_50_50": 879.4}
+BYTE_FLOOR_GB_PER_CLIP = {"SLOWFAST_8x8_R50": 2.165, "C2D_8x8_R50": 1.019, "MVITv2_S_16x4": 1.845, "X3D_M": 0.989,
+                          "SLOWFAST_32x2_R101_50_50": 4.729}
 METRIC_NAME = {"SLOWFAST_8x8_R50": "SlowFast-8x8-R50 32x224^2", "C2D_8x8_R50": "C2D-R50 8x224^2",
-               "MVITv2_S_16x4": "MViTv2-S 16x224^2", "X3D_M": "X3D-M 16x224^2"}
-# synthetic-run overrides: stochastic ops off so that runs are comparable and parity-checkable
-PRESET_OPTS = {"MVITv2_S_16x4": ["MVIT.DROPPATH_RATE", 0.0, "MODEL.DROPOUT_RATE", 0.0]}
+               "MVITv2_S_16x4": "MViTv2-S 16x224^2", "X3D_M": "X3D-M 16x224^2",
+               "SLOWFAST_32x2_R101_50_50": "SlowFast-32x2-R101+Nonlocal (basic head) 32x256^2"}
+# synthetic-run overrides: stochastic ops off so that runs are comparable and parity-checkable;
+# BASELINE config 5 is quoted on AVA-shaped 32x256^2 clips; its res5 keeps stride 1 (16x16 map), so the basic head that
+# stands in for the RoI head pools globally (pool_size None, head_helper.py:251-252, selected by MULTIGRID.SHORT_CYCLE)
+PRESET_OPTS = {"MVITv2_S_16x4": ["MVIT.DROPPATH_RATE", 0.0, "MODEL.DROPOUT_RATE", 0.0],
+               "SLOWFAST_32x2_R101_50_50": ["DATA.TRAIN_CROP_SIZE", 256, "MULTIGRID.SHORT_CYCLE", True]}
+
+
+def make_loss(cfg):
+    """slowfast/models/losses.py:61-69: cross_entropy | soft_cross_entropy | bce.  With the basic head the network
+    returns logits in train mode, so "bce" is evaluated as BCE-with-logits on multi-hot float labels."""
+    if cfg.MODEL.LOSS_FUNC == "bce":
+        return F.binary_cross_entropy_with_logits
+    return F.cross_entropy
 
 
 # libsfamd entry point -> the HIP kernels it launches (for mapping rocprofv3 PMC traffic, collected per kernel in a
@@ -189,7 +203,11 @@ def main():
     g = torch.Generator(device=dev).manual_seed(cfg.RNG_SEED + rank)
     T, S = cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE
     fast = torch.randn((a.batch, 3, T, S, S), generator=g, device=dev)
-    labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (a.batch,), generator=g, device=dev)
+    if cfg.MODEL.LOSS_FUNC == "bce":     # AVA: multi-hot action labels
+        labels = (torch.rand((a.batch, cfg.MODEL.NUM_CLASSES), generator=g, device=dev) < 0.05).float()
+    else:
+        labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (a.batch,), generator=g, device=dev)
+    loss_fn = make_loss(cfg)
     if len(cfg.DATA.INPUT_CHANNEL_NUM) == 2:
         idx = torch.linspace(0, T - 1, T // cfg.SLOWFAST.ALPHA).long().to(dev)
         inputs = [torch.index_select(fast, 2, idx).contiguous(), fast]
@@ -197,7 +215,7 @@ def main():
         inputs = [fast]
 
     from slowfast_amd.step import TrainStep
-    train_step = TrainStep(model, reducer, opt, F.cross_entropy, loss_scale=a.loss_scale,
+    train_step = TrainStep(model, reducer, opt, loss_fn, loss_scale=a.loss_scale,
                            use_graph=not a.no_graph, warmup=1)
 
     def step():
@@ -206,7 +224,7 @@ def main():
     def eager_step():
         reducer.zero_grad()
         logits = model(inputs)
-        loss = F.cross_entropy(logits.float(), labels)
+        loss = loss_fn(logits.float(), labels)
         (loss * a.loss_scale).backward()
         reducer.finish(loss_scale=a.loss_scale)
         opt.step()
@@ -270,7 +288,7 @@ def main():
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": f"{a.preset}: forward + cross-entropy + backward + {cfg.SOLVER.OPTIMIZING_METHOD} step, "
+            "config": {"workload": f"{a.preset}: forward + {cfg.MODEL.LOSS_FUNC} loss + backward + {cfg.SOLVER.OPTIMIZING_METHOD} step, "
                                    f"inputs resident in HBM, "
                                    f"per-GPU batch {a.batch}", "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "loss_scale": a.loss_scale, "bucket_mb": a.bucket_mb,

@@ -47,6 +47,13 @@ CASES = {
                                   "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2, 2], [2, 2], [2, 2], [2, 2]]",
                                   "NONLOCAL.LOCATION", "[[[], []], [[1], []], [[1], []], [[], []]]",
                                   "NONLOCAL.POOL", "[[[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]]]"], 4),
+    # BASELINE config 5 backbone: SlowFast-R101 (23 res4 blocks, the first 6 temporal), dot-product Nonlocal after res4
+    # blocks 6/13/20 with (2,2,2) pooling, res5 at stride 1 / dilation 2; closed with the basic head (global pooling)
+    "slowfast_r101_nl_tiny": ("configs/AVA/c2/SLOWFAST_32x2_R101_50_50.yaml",
+                              ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DETECTION.ENABLE", False,
+                               "MULTIGRID.SHORT_CYCLE", True, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 64,
+                               "DATA.NUM_FRAMES", 8, "RESNET.WIDTH_PER_GROUP", 16, "SLOWFAST.BETA_INV", 2], 4,
+                              {"final_bn_gamma_scale": 0.25}),
     # X3D-M (depthwise 3x3x3, SE, Swish, channel widths 54/108 that are not multiples of 8) at reduced clip size
     "x3d_m_mid": ("configs/Kinetics/X3D_M.yaml",
                   ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
@@ -72,13 +79,16 @@ def _family(cfg):
 
 
 def run_case(name):
-    yaml_rel, opts, batch = CASES[name]
+    yaml_rel, opts, batch = CASES[name][:3]
+    tweaks = CASES[name][3] if len(CASES[name]) > 3 else {}
     cfg = refshim.reference_cfg(yaml_rel, opts)
     torch.manual_seed(0)
     model = refshim.reference_model(cfg)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     fam = _family(cfg)
     sd = fam.randomize_state(shapes, seed=1234)
+    if "final_bn_gamma_scale" in tweaks:
+        video_ref.scale_final_bn(sd, tweaks["final_bn_gamma_scale"])
     model.load_state_dict(sd)
     model.train()
     inputs, labels = video_ref.synthetic_batch(cfg, batch, seed=4321)
@@ -107,6 +117,7 @@ def run_case(name):
           f"grad_norm {gn:.6f}  oracle-vs-reference logits {err:.1e} grads {worst:.1e}")
     return {
         "reference_yaml": yaml_rel, "opts": opts, "batch": batch, "param_seed": 1234, "data_seed": 4321,
+        "state_tweaks": tweaks,
         "logits": logits.detach().tolist(), "loss": float(loss), "grad_norm": gn,
         "param_grad_norms": {k: float(g.norm()) for k, g in ref_grads.items()},
         "running_stat_sums": {k: float(v.double().sum()) for k, v in ref_stats.items()},

@@ -225,7 +225,10 @@ def video_forward(sd, cfg, inputs, training=True, stats_out=None):
     crop = cfg.DATA.TRAIN_CROP_SIZE // 32
     frames = [cfg.DATA.NUM_FRAMES // cfg.SLOWFAST.ALPHA, cfg.DATA.NUM_FRAMES] if two else \
         [cfg.DATA.NUM_FRAMES // _POOL1_T[cfg.MODEL.ARCH]]
-    feats = [F.avg_pool3d(v, (frames[p], crop, crop), 1) for p, v in enumerate(x)]
+    if cfg.MULTIGRID.SHORT_CYCLE:      # pool_size None -> nn.AdaptiveAvgPool3d((1,1,1)) (head_helper.py:251-252)
+        feats = [v.mean((2, 3, 4), keepdim=True) for v in x]
+    else:
+        feats = [F.avg_pool3d(v, (frames[p], crop, crop), 1) for p, v in enumerate(x)]
     z = torch.cat(feats, 1).permute(0, 2, 3, 4, 1)
     z = F.linear(z, sd["head.projection.weight"], sd["head.projection.bias"])
     if not training:
@@ -261,6 +264,17 @@ def randomize_state(shapes, seed, dtype=torch.float32):
             sd[name] = (torch.rand(shape, generator=g) + 0.5).to(dtype)
         else:                   # biases
             sd[name] = (torch.randn(shape, generator=g) * 0.1).to(dtype)
+    return sd
+
+
+def scale_final_bn(sd, factor):
+    """Multiplies the block-final BatchNorm gammas (BottleneckTransform c_bn, Nonlocal bn) in place.  Deep parity cases
+    (R101: 33 residual blocks) use a factor < 1 so the residual stream stays O(1): with O(1) gammas it grows like
+    sqrt(depth), and the un-normalised dot-product Nonlocal (theta^T phi g ~ |x|^3) then exceeds the fp16 range that
+    the engine -- and the reference under autocast -- store activations in."""
+    for k in sd:
+        if k.endswith("c_bn.weight") or ("nonlocal" in k and k.endswith(".bn.weight")):
+            sd[k] = sd[k] * factor
     return sd
 
 

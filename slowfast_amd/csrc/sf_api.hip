@@ -114,17 +114,29 @@ static GatherSide gather_dgrad(const sf_conv_desc* d, const void* dy) {
     return g;
 }
 
+// direct global -> LDS operand copies (GL): plain row-major GEMM operands only -- one tap, no fused input BatchNorm,
+// K a multiple of the 32-wide K step, 16-byte aligned rows.  SF_IGEMM_GLDS=0 keeps the register-staged loads.
+static bool igemm_glds_ok(const IgemmParams& p, bool pw) {
+    static const bool off = getenv("SF_IGEMM_GLDS") && atoi(getenv("SF_IGEMM_GLDS")) == 0;
+    if (off || !pw || p.g.scale) return false;
+    if (p.g.Ktot != p.g.C || p.g.Ktot % 32 != 0 || p.g.ld % 8 != 0 || p.ldw % 8 != 0) return false;
+    if (p.g.padT != 0) return false;
+    if (((uintptr_t)p.g.src | (uintptr_t)p.wmat) & 15) return false;
+    if (p.bh > 0 && ((p.sa_b | p.sa_h | p.sw_b | p.sw_h) & 7)) return false;
+    return true;
+}
+
 template <int BN, int WM, int WN>
-static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s) {
+static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s, int nbatch = 1) {
     int mt = cdiv(p.M, 128);
-    dim3 grid((unsigned)(mt * p.ntiles_n));
-    static const bool pf2 = getenv("SF_IGEMM_PF2") && atoi(getenv("SF_IGEMM_PF2")) != 0;   // A/B switch: two register stages
-    if (pf2) {
-        if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true>), grid, dim3(SF_THREADS), 0, s, p);
-        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, true>), grid, dim3(SF_THREADS), 0, s, p);
+    dim3 grid((unsigned)(mt * p.ntiles_n), (unsigned)nbatch);
+    // 128-VGPR cap (4 workgroups per CU) for the 128-wide tile: +0.2..1.2 % end to end (profiles/r1_visit9_*_occ4.json);
+    // SF_IGEMM_OCC4=0 restores the uncapped build for A/B runs
+    static const bool occ4 = !(getenv("SF_IGEMM_OCC4") && atoi(getenv("SF_IGEMM_OCC4")) == 0);
+    if (igemm_glds_ok(p, pw)) {
+        hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, BN == 128>), grid, dim3(SF_THREADS), 0, s, p);
         return;
     }
-    static const bool occ4 = getenv("SF_IGEMM_OCC4") && atoi(getenv("SF_IGEMM_OCC4")) != 0;  // A/B switch: 128-VGPR cap
     if constexpr (BN == 128) {
         if (occ4) {
             if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, true>), grid, dim3(SF_THREADS), 0, s, p);
@@ -370,7 +382,7 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
     r.ws = (const float*)workspace; r.splits = splits; r.Co = d->Cow ? d->Cow : d->Co; r.Co_pad = Co_pad; r.Kpad = Kpad;
     r.Ktot = gk.Ktot; r.fdC = gk.fdC; r.dw = dw; r.Cw = d->Cw; r.taps = d->kT * d->kH * d->kW;
     r.out_scale = out_scale; r.accumulate = zero_first ? 0 : 1;
-    int64_t total = (int64_t)r.Co * Kpad;
+    int64_t total = (int64_t)r.Co * Kpad / 4;              // element quads
     int lanes = 1;
     while (lanes < 32 && lanes * 4 <= splits) lanes *= 2;   // ~>= 4 splits per lane, 8..256 elements per block
     r.lanes = lanes;
@@ -637,18 +649,10 @@ extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t 
     p.bh = bh; p.sa_b = sa_b; p.sa_h = sa_h; p.sw_b = sw_b; p.sw_h = sw_h; p.sy_b = sy_b; p.sy_h = sy_h;
     p.sr_b = sr_b; p.sr_h = sr_h; p.resid_row0 = resid_row0; p.alpha = alpha;
     hipStream_t s = (hipStream_t)stream;
-    const int mt = cdiv(M, 128);
-#define SF_BG(BN_, WM_, WN_)                                                                                   \
-    do {                                                                                                       \
-        p.ntiles_n = cdiv(N, BN_);                                                                             \
-        hipLaunchKernelGGL((sf_igemm_kernel<BN_, WM_, WN_, true>), dim3((unsigned)(mt * p.ntiles_n), nbatch), \
-                           dim3(SF_THREADS), 0, s, p);                                                         \
-    } while (0)
-    if (N > 64) SF_BG(128, 64, 64);
-    else if (N > 32) SF_BG(64, 32, 64);
-    else if (N > 16) SF_BG(32, 32, 32);
-    else SF_BG(16, 32, 16);
-#undef SF_BG
+    if (N > 64) { p.ntiles_n = cdiv(N, 128); launch_igemm<128, 64, 64>(p, true, s, nbatch); }
+    else if (N > 32) { p.ntiles_n = 1; launch_igemm<64, 32, 64>(p, true, s, nbatch); }
+    else if (N > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, true, s, nbatch); }
+    else { p.ntiles_n = 1; launch_igemm<16, 32, 16>(p, true, s, nbatch); }
     return check_launch("bgemm");
 }
 

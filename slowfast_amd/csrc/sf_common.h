@@ -23,6 +23,19 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
     __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(p))
 #endif
 
+// Direct global -> LDS copy (global_load_lds_dwordx4): each lane supplies its own 16-byte global source, the wave's
+// 64 x 16 B land contiguously at the wave-uniform LDS base (+ 16 * lane).  SF_WAIT_VMEM() retires them.
+#ifndef SF_GLOBAL_LOAD_LDS16
+#define SF_GLOBAL_LOAD_LDS16(g, l)                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),                \
+                                     (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
+#define SF_WAIT_VMEM()                                                          \
+    do {                                                                        \
+        __builtin_amdgcn_sched_barrier(0); /* keep the MFMAs of the step above the wait */ \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    } while (0)
+#endif
+
 #define SF_WAVE 64
 #define SF_THREADS 256
 

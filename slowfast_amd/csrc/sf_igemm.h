@@ -33,13 +33,15 @@ struct IgemmParams {
     float alpha;        // accumulators are scaled by alpha before bias / residual (0 means 1)
 };
 
-// PF2 = two register stages (loads of K-step s+2 in flight under step s) / one stage (loads of s+1 only).
-// Measured on MI355X (profiles/r1_visit7_*): the second stage costs ~90 VGPRs and one resident workgroup per CU
-// and is SLOWER end to end (SlowFast 383 vs 507 clips/s, X3D-M 809 vs 860, MViTv2-S equal): one stage is the default,
-// SF_IGEMM_PF2=1 selects the other for A/B runs.
-// OCC4 caps the kernel at 128 VGPRs (4 workgroups = 16 waves per CU for the 128-wide tile, whose 40 KiB of LDS allow
-// exactly 4): SF_IGEMM_OCC4=1 selects it for A/B runs.
-template <int BN, int WM, int WN, bool PW, bool PF2 = false, bool OCC4 = false>
+// GL = plain-GEMM operands (1x1x1 unit-stride convolutions without a fused input BatchNorm, linear layers, attention
+// products; K a multiple of 32) are copied global -> LDS directly (global_load_lds_dwordx4): no staging registers, no
+// ds_write pass, no per-element address arithmetic in the K loop.  The LDS image is lane-linear (16 rows x 64 B per
+// wave instruction), so the XOR swizzle of lds_tile_off() is applied on the SOURCE side: lane l of a 16-row chunk
+// fetches the logical 16-byte slot that belongs at physical slot l & 3 of row l >> 2.  Rows beyond M / Nout are clamped
+// to the last valid row (their results are never stored).
+// (A second register stage, "PF2", was measured and removed: +90 VGPRs, one resident workgroup, SlowFast 383 vs 507
+// clips/s -- profiles/r1_visit7_*_pf2.json.)
+template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false>
 __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(IgemmParams p) {
     constexpr int BM = 128, BK = 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
@@ -51,13 +53,17 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
     constexpr int SMEM = SMEM_MAIN > SMEM_STG ? SMEM_MAIN : SMEM_STG;
     constexpr int NB = (BN * 4 + SF_THREADS - 1) / SF_THREADS;
 
-    __shared__ __attribute__((aligned(16))) f16 smem[SMEM];
-    __shared__ float s_scale[512];
-    __shared__ float s_shift[512];
-    __shared__ float s_red[WAVES_M][2][BN];
+    // ONE LDS object (hipcc serialises direct-to-LDS copies against ds_reads of any OTHER __shared__ object):
+    // [operand stages | epilogue staging] [BatchNorm scale/shift tables (register-staged variant only)] [stat partials]
+    constexpr int TF_BYTES = GL ? 0 : 2 * 512 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SMEM * 2 + TF_BYTES + WAVES_M * 2 * BN * 4];
+    f16* const smem = reinterpret_cast<f16*>(lds_raw);
+    float* const s_scale = reinterpret_cast<float*>(lds_raw + SMEM * 2);
+    float* const s_shift = s_scale + 512;
+    float (*const s_red)[2][BN] = reinterpret_cast<float (*)[2][BN]>(lds_raw + SMEM * 2 + TF_BYTES);
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tile = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int nt = tile % p.ntiles_n, mt = tile / p.ntiles_n;
@@ -76,30 +82,63 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
         if (resid) resid += zb * p.sr_b + zj * p.sr_h;
     }
 
-    if (has_tf) {
-        for (int c = tid; c < g.C; c += SF_THREADS) {
-            s_scale[c] = g.scale[c];
-            s_shift[c] = g.shift[c];
+    if constexpr (!GL) {
+        if (has_tf) {
+            for (int c = tid; c < g.C; c += SF_THREADS) {
+                s_scale[c] = g.scale[c];
+                s_shift[c] = g.shift[c];
+            }
         }
     }
 
     // loader assignment: A rows (tid>>2) and (tid>>2)+64, 16-byte slot tid&3
     const int kq = tid & 3;
     RowPos rp[2];
+    if constexpr (!GL) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int row = m0 + (tid >> 2) + 64 * j;
-        rp[j] = PW ? decode_row_pw(g, (uint32_t)row, row < p.M) : decode_row(g, (uint32_t)row, row < p.M);
+        for (int j = 0; j < 2; ++j) {
+            int row = m0 + (tid >> 2) + 64 * j;
+            rp[j] = PW ? decode_row_pw(g, (uint32_t)row, row < p.M) : decode_row(g, (uint32_t)row, row < p.M);
+        }
     }
+    // GL: wave w copies the 16-row chunks w and w + 4 of the A tile and chunks w, w + 4, ... of the B tile
+    constexpr int NBC = (BN / 16 + 3) / 4;
+    const f16* ga[2];
+    const f16* gb[NBC];
+    if constexpr (GL) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave + 4 * j) * 16 + (lane >> 2);
+            const int slot = ((lane & 3) - 2 * ((row >> 2) & 3)) & 3;
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            ga[j] = a_src + (int64_t)m * g.ld + slot * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < NBC; ++j) {
+            const int row = (wave + 4 * j) * 16 + (lane >> 2);
+            const int slot = ((lane & 3) - 2 * ((row >> 2) & 3)) & 3;
+            int co = n0 + row;
+            if (co >= p.Nout) co = p.Nout - 1;
+            gb[j] = wmat + (int64_t)co * p.ldw + slot * 8;
+        }
+    }
+    auto issue_tile = [&](int ks, int buf) {
+        f16* As = smem + buf * (A_ELEMS + B_ELEMS);
+        f16* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) SF_GLOBAL_LOAD_LDS16(ga[j] + ks * BK, As + (wave + 4 * j) * 16 * BK);
+#pragma unroll
+        for (int j = 0; j < NBC; ++j)
+            if ((wave + 4 * j) * 16 < BN) SF_GLOBAL_LOAD_LDS16(gb[j] + ks * BK, Bs + (wave + 4 * j) * 16 * BK);
+    };
 
-    // Two register stages: the global loads of K-step s+2 are issued before the MFMAs of step s and consumed (written
-    // to LDS) one full iteration later, so two K-steps of HBM/L2 latency are covered per workgroup.
     struct Stage {
         f16x8 ra[2], rb[NB];
         bool ok[2];
         uint32_t c0[2];
     };
-    Stage st0, st1;
+    Stage st0;
 
     auto load_tile = [&](int ks, Stage& st) {
         const uint32_t k0 = (uint32_t)(ks * BK + kq * 8);
@@ -108,10 +147,9 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
             int64_t off;
             uint32_t c0 = 0;
             bool ok = PW ? gather_offset_pw(g, rp[j], k0, off, c0) : gather_offset(g, rp[j], k0, off, c0);
-            // unconditional load from a valid address, zeroed afterwards: keeps the loads out of exec-masked branches
-            // so that the compiler can count them (s_waitcnt vmcnt(N)) instead of draining the queue
-            const f16x8 v = ld16(a_src + (ok ? off : 0));
-            st.ra[j] = ok ? v : zero8();
+            // masked lanes issue no request (measured: an unconditional clamped load + select is 8-13 % SLOWER here,
+            // profiles/r1_visit9_*; the four loads of a stage are in flight together either way)
+            st.ra[j] = ok ? ld16(a_src + off) : zero8();
             st.ok[j] = ok;
             st.c0[j] = c0;
         }
@@ -121,8 +159,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
             int brow = idx >> 2;
             int co = n0 + brow;
             bool ok = (idx < BN * 4) && (co < p.Nout) && (k0 < (uint32_t)g.Ktot);
-            const f16x8 v = ld16(wmat + (ok ? (int64_t)co * p.ldw + k0 : 0));
-            st.rb[j] = ok ? v : zero8();
+            st.rb[j] = ok ? ld16(wmat + (int64_t)co * p.ldw + k0) : zero8();
         }
     };
     auto store_tile = [&](int buf, const Stage& st) {
@@ -162,12 +199,21 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
 
-    if (has_tf) __syncthreads();  // scale/shift tables visible before the first store_tile
-    load_tile(0, st0);
-    if (PF2 && p.ksteps > 1) load_tile(1, st1);
-    store_tile(0, st0);
-    __syncthreads();
-    if constexpr (!PF2) {
+    if constexpr (GL) {
+        issue_tile(0, 0);
+        SF_WAIT_VMEM();
+        __syncthreads();
+        for (int ks = 0; ks < p.ksteps; ++ks) {
+            if (ks + 1 < p.ksteps) issue_tile(ks + 1, (ks + 1) & 1);
+            compute(ks & 1);
+            SF_WAIT_VMEM();
+            __syncthreads();
+        }
+    } else {
+        if (has_tf) __syncthreads();  // scale/shift tables visible before the first store_tile
+        load_tile(0, st0);
+        store_tile(0, st0);
+        __syncthreads();
         for (int ks = 0; ks < p.ksteps; ++ks) {
             const bool more = ks + 1 < p.ksteps;
             if (more) load_tile(ks + 1, st0);
@@ -175,20 +221,6 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
             if (more) store_tile((ks + 1) & 1, st0);
             __syncthreads();
         }
-    } else
-    for (int ks = 0; ks < p.ksteps;) {
-        // even step: LDS buffer 0 holds step ks, st1 holds step ks+1, st0 is free
-        if (ks + 2 < p.ksteps) load_tile(ks + 2, st0);
-        compute(0);
-        if (ks + 1 < p.ksteps) store_tile(1, st1);
-        __syncthreads();
-        if (++ks >= p.ksteps) break;
-        // odd step: LDS buffer 1 holds step ks, st0 holds step ks+1, st1 is free
-        if (ks + 2 < p.ksteps) load_tile(ks + 2, st1);
-        compute(1);
-        if (ks + 1 < p.ksteps) store_tile(0, st0);
-        __syncthreads();
-        ++ks;
     }
 
     // ---------------- epilogue: scale, bias, BatchNorm partial statistics (fp32, from the accumulators)
@@ -300,42 +332,50 @@ struct WgradReduceParams {
     int lanes;          // split lanes per output element (power of two, 1..32)
 };
 
-// 256 threads = E output elements x L split lanes (L = p.lanes, a power of two <= 32): lane z of an element sums
-// splits z, z+L, ... with two independent accumulators, an LDS tree folds the L lanes (fixed order: the result
-// does not depend on scheduling).  Consecutive elements are consecutive kcol, i.e. contiguous in every slab.
+// 256 threads = E element quads x L split lanes (L = p.lanes, a power of two <= 32): lane z of a quad sums splits
+// z, z+L, ... of four consecutive kcol (one 16-byte load per slab, four loads in flight), an LDS tree folds the L lanes
+// (fixed order: the result does not depend on scheduling).  Consecutive quads are contiguous in every slab, so the
+// E threads of one lane read E*16 contiguous bytes (a full 128-byte line for E >= 8).
 __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_reduce_kernel(WgradReduceParams p) {
-    __shared__ float s_acc[SF_THREADS];
+    __shared__ f32x4 s_acc[SF_THREADS];
     const int L = p.lanes, E = SF_THREADS / L;
     const int e = threadIdx.x % E, z0 = threadIdx.x / E;
-    const int64_t total = (int64_t)p.Co * p.Kpad;
+    const int64_t total = (int64_t)p.Co * p.Kpad;           // Kpad is a multiple of 128
     const int64_t slab = (int64_t)p.Co_pad * p.Kpad;
-    const int64_t idx = (int64_t)blockIdx.x * E + e;
-    float a0 = 0.f, a1 = 0.f;
+    const int64_t idx = ((int64_t)blockIdx.x * E + e) * 4;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     if (idx < total) {
         const float* src = p.ws + idx;          // element (co, kcol) sits at co*Kpad + kcol = idx in every slab
         int z = z0;
-        for (; z + L < p.splits; z += 2 * L) {
-            const float v0 = src[(int64_t)z * slab], v1 = src[(int64_t)(z + L) * slab];
-            a0 += v0;
-            a1 += v1;
+        for (; z + 3 * L < p.splits; z += 4 * L) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (int64_t)z * slab);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + L) * slab);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 2 * L) * slab);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + 3 * L) * slab);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
         }
-        if (z < p.splits) a0 += src[(int64_t)z * slab];
+        for (; z < p.splits; z += L) a0 += *reinterpret_cast<const f32x4*>(src + (int64_t)z * slab);
     }
-    s_acc[threadIdx.x] = a0 + a1;
+    s_acc[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     for (int half = L >> 1; half >= 1; half >>= 1) {
         if (z0 < half) s_acc[threadIdx.x] += s_acc[threadIdx.x + half * E];
         __syncthreads();
     }
     if (z0 == 0 && idx < total) {
-        const int co = (int)(idx / p.Kpad), kcol = (int)(idx % p.Kpad);
-        if (kcol < p.Ktot) {
-            uint32_t tap, ci;
-            fd_divmod((uint32_t)kcol, p.fdC, tap, ci);
-            if (ci < (uint32_t)p.Cw) {
-                float* dst = p.dw + ((int64_t)co * p.Cw + ci) * p.taps + tap;
-                const float v = s_acc[threadIdx.x] * p.out_scale;
-                *dst = p.accumulate ? *dst + v : v;
+        const int co = (int)(idx / p.Kpad), kcol0 = (int)(idx % p.Kpad);
+        const f32x4 r = s_acc[threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kcol = kcol0 + j;
+            if (kcol < p.Ktot) {
+                uint32_t tap, ci;
+                fd_divmod((uint32_t)kcol, p.fdC, tap, ci);
+                if (ci < (uint32_t)p.Cw) {
+                    float* dst = p.dw + ((int64_t)co * p.Cw + ci) * p.taps + tap;
+                    const float v = r[j] * p.out_scale;
+                    *dst = p.accumulate ? *dst + v : v;
+                }
             }
         }
     }
@@ -443,8 +483,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             int ml = idx / (BMW / 8), cg = idx % (BMW / 8);
             int m = mbase + ml, co = c0 + cg * 8;
             bool ok = (idx < ROWS * (BMW / 8)) && (m < p.M) && (co < p.Co);
-            const f16x8 v = ld16(dy_src + (ok ? (int64_t)m * p.ldy + co : 0));
-            ra[j] = ok ? v : zero8();
+            ra[j] = ok ? ld16(dy_src + (int64_t)m * p.ldy + co) : zero8();
         }
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
@@ -452,8 +491,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             RowPos rp = decode_row(g, (uint32_t)m, m < p.M);
             int64_t off;
             bool ok = gather_offset_tap(g, rp, tp, off);
-            const f16x8 v = ld16(x_src + (ok ? off : 0));
-            rb[j] = ok ? v : zero8();
+            rb[j] = ok ? ld16(x_src + off) : zero8();
             rb_ok[j] = ok;
         }
     };

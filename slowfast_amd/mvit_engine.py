@@ -106,7 +106,7 @@ class AttentionPlan:
         self.q_thw, self.k_thw = self.gq.out_thw, self.gk.out_thw
         self.Nq = self.cls + math.prod(self.q_thw)
         self.Nk = self.cls + math.prod(self.k_thw)
-        self.lds = (self.Nk + 7) // 8 * 8
+        self.lds = (self.Nk + 31) // 32 * 32     # score-row pitch: zero pad columns, a whole number of 32-wide GEMM K steps
         self.rel = att.rel_pos_spatial and att.rel_pos_temporal
         assert att.rel_pos_spatial == att.rel_pos_temporal, "spatial and temporal rel-pos are used together (MViTv2)"
         rows = (att.rel_pos_h.shape[0], att.rel_pos_w.shape[0], att.rel_pos_t.shape[0]) if self.rel else (0, 0, 0)

@@ -273,6 +273,20 @@ inline hipsim_f16x4 hipsim_ds_read_tr16(const void* p) {
 }
 #define SF_LDS_TR16(p) hipsim_ds_read_tr16((const void*)(p))
 
+// global_load_lds_dwordx4: every lane fetches 16 bytes from its own global address; the wave's 1 KiB lands in LDS
+// at (wave-uniform base = lane 0's destination operand) + 16 * lane.
+inline void hipsim_global_load_lds16(const void* gptr, void* lds_base) {
+    hipsim::WaveScratch& w = hipsim::wave();
+    int l = hipsim::lane_id();
+    w.ptr[l] = lds_base;
+    hipsim::wave_sync();
+    unsigned char* base = (unsigned char*)w.ptr[0];
+    hipsim::wave_sync();
+    memcpy(base + 16 * l, gptr, 16);
+}
+#define SF_GLOBAL_LOAD_LDS16(g, l) hipsim_global_load_lds16((const void*)(g), (void*)(l))
+#define SF_WAIT_VMEM() ((void)0)
+
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

@@ -36,6 +36,8 @@ def oracle_run(gold, cfg):
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     fam = family(cfg)
     sd = fam.randomize_state(shapes, gold["param_seed"])
+    if "final_bn_gamma_scale" in gold.get("state_tweaks", {}):
+        video_ref.scale_final_bn(sd, gold["state_tweaks"]["final_bn_gamma_scale"])
     inputs, labels = video_ref.synthetic_batch(cfg, gold["batch"], gold["data_seed"])
     logits, loss, grads, stats = fam.loss_and_grads(sd, cfg, inputs, labels)
     return model, sd, inputs, labels, logits, loss, grads, stats
