@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 7
+#define SF_ABI_VERSION 8
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -205,6 +205,11 @@ int sf_softmax_fwd(const sf_attn_desc* d, void* s, int32_t lds, float scale, con
 int sf_softmax_bwd(const sf_attn_desc* d, void* dp, const void* prob, int32_t lds, float scale, float* drq,
                    sf_stream_t stream);
 /* xt[b][head][c][k] = x[b][k][head*D + c], zero for k in [Nk, ldk): K-contiguous operand for P.V and dS.K */
+/* Stochastic depth -- replaces drop_path() (slowfast/models/common.py:46-59) at the two residual additions of
+ * MultiScaleBlock (attention.py:500-510): y[m] = (resid ? resid[m] : 0) + scale[m / rows_per_sample] * x[m], with
+ * scale[b] = floor(keep_prob + u_b) / keep_prob sampled by the caller.  Rows are fp16 [M][C], C % 8 == 0. */
+int sf_row_scale_add(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,
+                     int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C, sf_stream_t stream);
 int sf_transpose_heads(const void* x, int32_t ldx, void* xt, int32_t ldk, int32_t B, int32_t Nk, int32_t heads, int32_t D,
                        sf_stream_t stream);
 

@@ -119,8 +119,9 @@ def attention(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, resi
     return _linear(o, sd, prefix + ".proj"), q_shape
 
 
-def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True):
-    """MultiScaleBlock.forward (attention.py:491-514) with DIM_MUL_IN_ATT (proj applied to the normed input)."""
+def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, drop=None):
+    """MultiScaleBlock.forward (attention.py:491-514) with DIM_MUL_IN_ATT (proj applied to the normed input).
+    drop = (s1, s2): per-sample scales mask/keep_prob of the two drop_path() calls (common.py:46-59), None = off."""
     x_norm = _ln(x, sd, prefix + ".norm1")
     x_block, thw_new = attention(x_norm, sd, prefix + ".attn", thw, heads, stride_q, stride_kv, has_cls)
     if prefix + ".proj.weight" in sd:
@@ -129,11 +130,15 @@ def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True):
         x_res, _ = attention_pool(x, None, stride_q, thw, has_cls, pool_mode="max")
     else:
         x_res = x
+    if drop is not None:
+        x_block = _store(x_block) * drop[0].view(-1, 1, 1)
     x = _store(x_res + x_block)
     x_norm = _ln(x, sd, prefix + ".norm2")
     h = _linear(x_norm, sd, prefix + ".mlp.fc1")
     h = _store(F.gelu(h))
     x_mlp = F.linear(h, _store(sd[prefix + ".mlp.fc2.weight"]), sd[prefix + ".mlp.fc2.bias"])
+    if drop is not None:
+        x_mlp = _store(x_mlp) * drop[1].view(-1, 1, 1)
     return _store(x + x_mlp), thw_new
 
 
@@ -160,9 +165,10 @@ def mvit_plan(cfg):
     return plan
 
 
-def mvit_forward(sd, cfg, inputs, training=True):
-    """MViT.forward (video_model_builder.py:1166-1244) for CLS_EMBED_ON, no abs-pos, no dropout / drop-path
-    (the parity harness sets them to 0), + TransformerBasicHead.forward (head_helper.py:538-563)."""
+def mvit_forward(sd, cfg, inputs, training=True, drop=None):
+    """MViT.forward (video_model_builder.py:1166-1244) for CLS_EMBED_ON, no abs-pos, no dropout,
+    + TransformerBasicHead.forward (head_helper.py:538-563).  drop = per-block (s1, s2) stochastic-depth scales
+    (the sampled masks of drop_path(), common.py:46-59, divided by keep_prob) or None (rate 0)."""
     x = inputs[0]
     w = sd["patch_embed.proj.weight"]
     stride, pad = tuple(cfg.MVIT.PATCH_STRIDE), tuple(cfg.MVIT.PATCH_PADDING)
@@ -173,7 +179,7 @@ def mvit_forward(sd, cfg, inputs, training=True):
     x = _store(x)
     thw = [T, H, W]
     for i, (heads, sq, skv) in enumerate(mvit_plan(cfg)):
-        x, thw = block(x, sd, f"blocks.{i}", thw, heads, sq, skv)
+        x, thw = block(x, sd, f"blocks.{i}", thw, heads, sq, skv, drop=None if drop is None else drop[i])
     x = _ln(x[:, 0], sd, "norm")
     z = F.linear(x, sd["head.projection.weight"], sd["head.projection.bias"])
     if not training and cfg.MODEL.HEAD_ACT == "softmax":
@@ -204,9 +210,9 @@ def randomize_state(shapes, seed, dtype=torch.float32):
     return sd
 
 
-def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32):
+def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32, drop=None):
     params = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
-    logits = mvit_forward(params, cfg, [x.to(dtype) for x in inputs], training=True)
+    logits = mvit_forward(params, cfg, [x.to(dtype) for x in inputs], training=True, drop=drop)
     loss = F.cross_entropy(logits, labels)
     loss.backward()
     grads = {k: v.grad for k, v in params.items() if v.grad is not None}

@@ -1032,6 +1032,22 @@ extern "C" int sf_softmax_bwd(const sf_attn_desc* d, void* dp, const void* prob,
     return check_launch("softmax_bwd");
 }
 
+extern "C" int sf_row_scale_add(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,
+                                int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C, sf_stream_t stream) {
+    REQUIRE(x && scale && y, "sf_row_scale_add: null pointer");
+    if (check_rows("sf_row_scale_add", M, C)) return -1;
+    REQUIRE(rows_per_sample > 0 && rows_per_sample < (1ll << 31), "sf_row_scale_add: bad rows_per_sample");
+    REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && (!resid || ldr % 8 == 0), "sf_row_scale_add: pitches must be multiples of 8");
+    RowScaleParams p;
+    p.x = (const f16*)x; p.ldx = ldx; p.scale = scale; p.resid = (const f16*)resid; p.ldr = ldr;
+    p.y = (f16*)y; p.ldy = ldy;
+    p.total = M * (C / 8);
+    REQUIRE(p.total < (1ll << 31), "sf_row_scale_add: too many elements");
+    p.fdG = make_fastdiv(C / 8); p.fdRows = make_fastdiv((uint32_t)rows_per_sample);
+    hipLaunchKernelGGL(sf_row_scale_add_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("row_scale_add");
+}
+
 extern "C" int sf_transpose_heads(const void* x, int32_t ldx, void* xt, int32_t ldk, int32_t B, int32_t Nk, int32_t heads,
                                   int32_t D, sf_stream_t stream) {
     REQUIRE(x && xt && ldk % 8 == 0 && ldk >= Nk && B > 0 && heads > 0 && D > 0, "sf_transpose_heads: bad arguments");

@@ -132,19 +132,27 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_kernel(DwParams p)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = (float)v[e];
         } else {
-            int tap = 0;
+            // the stride divisions are hoisted per axis: with strides >= the kernel extent (MViT k/v pooling, stride
+            // (1,8,8) / (1,4,4)) most positions have no contributing tap along h or w and leave after 3-6 divisions
             for (int kt = 0; kt < p.kT; ++kt) {
                 const int ut = t + p.pT - kt;
+                if (ut < 0) continue;
+                uint32_t qt, rt;
+                fd_divmod((uint32_t)ut, p.fdsT, qt, rt);
+                if (rt || qt >= (uint32_t)p.To) continue;
                 for (int kh = 0; kh < p.kH; ++kh) {
                     const int uh = h + p.pH - kh;
-                    for (int kw = 0; kw < p.kW; ++kw, ++tap) {
+                    if (uh < 0) continue;
+                    uint32_t qh, rh;
+                    fd_divmod((uint32_t)uh, p.fdsH, qh, rh);
+                    if (rh || qh >= (uint32_t)p.Ho) continue;
+                    for (int kw = 0; kw < p.kW; ++kw) {
                         const int uw = w + p.pW - kw;
-                        if (ut < 0 || uh < 0 || uw < 0) continue;
-                        uint32_t qt, rt, qh, rh, qw, rw;
-                        fd_divmod((uint32_t)ut, p.fdsT, qt, rt);
-                        fd_divmod((uint32_t)uh, p.fdsH, qh, rh);
+                        if (uw < 0) continue;
+                        uint32_t qw, rw;
                         fd_divmod((uint32_t)uw, p.fdsW, qw, rw);
-                        if ((rt | rh | rw) || qt >= (uint32_t)p.To || qh >= (uint32_t)p.Ho || qw >= (uint32_t)p.Wo) continue;
+                        if (rw || qw >= (uint32_t)p.Wo) continue;
+                        const int tap = (kt * p.kH + kh) * p.kW + kw;
                         f16x8 v = ld16(db + (p.cls + ((int64_t)qt * p.Ho + qh) * p.Wo + qw) * p.lddy);
                         const float* wt = s_w + tap * p.Cw + cw;
 #pragma unroll
@@ -507,10 +515,20 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_finalize_kernel(Dw
     if (ok && cw < p.Cwreal) {
         const int copies = p.C / p.Cw;
         const int64_t bs = (int64_t)p.taps * p.C;
-        for (int i = seg; i < p.nblk * copies; i += 8) {
-            const int b = i / copies, cp = i % copies;
-            s += (double)p.wpart[b * bs + (int64_t)tap * p.C + cp * p.Cw + cw];
+        const float* src = p.wpart + (int64_t)tap * p.C + cw;
+        // four independent partial sums (loads of four table rows in flight), folded in a fixed order
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b = seg;
+        for (; b + 24 < p.nblk; b += 32) {
+            for (int cp = 0; cp < copies; ++cp) {
+                const float v0 = src[(int64_t)b * bs + cp * p.Cw], v1 = src[(int64_t)(b + 8) * bs + cp * p.Cw];
+                const float v2 = src[(int64_t)(b + 16) * bs + cp * p.Cw], v3 = src[(int64_t)(b + 24) * bs + cp * p.Cw];
+                s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+            }
         }
+        for (; b < p.nblk; b += 8)
+            for (int cp = 0; cp < copies; ++cp) s0 += (double)src[(int64_t)b * bs + cp * p.Cw];
+        s = (s0 + s1) + (s2 + s3);
     }
     s_acc[seg][ox] = s;
     __syncthreads();

@@ -544,3 +544,29 @@ __global__ __launch_bounds__(SF_THREADS) void sf_transpose_heads_kernel(Transpos
         st16(p.xt + (((int64_t)b * p.heads + head) * p.D + c) * p.ldk + k8 * 8, o);
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stochastic depth (slowfast/models/common.py:46-59 drop_path, used at attention.py:500-510):
+//   y[m][c] = (resid ? resid[m][c] : 0) + scale[m / rows_per_sample] * x[m][c],  scale[b] = mask_b / keep_prob.
+struct RowScaleParams {
+    const f16* x; int ldx;
+    const float* scale;
+    const f16* resid; int ldr;
+    f16* y; int ldy;
+    int64_t total;                  // M * (C/8)
+    FastDiv fdG, fdRows;            // C/8, rows per sample
+};
+__global__ __launch_bounds__(SF_THREADS) void sf_row_scale_add_kernel(RowScaleParams p) {
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
+         idx += (int64_t)gridDim.x * SF_THREADS) {
+        uint32_t m, g8;
+        fd_divmod((uint32_t)idx, p.fdG, m, g8);
+        const float sc = p.scale[fd_div(m, p.fdRows)];
+        const f16x8 v = ld16(p.x + (int64_t)m * p.ldx + g8 * 8);
+        f16x8 r = zero8(), o;
+        if (p.resid) r = ld16(p.resid + (int64_t)m * p.ldr + g8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)r[e] + sc * (float)v[e]);
+        st16(p.y + (int64_t)m * p.ldy + g8 * 8, o);
+    }
+}

@@ -162,11 +162,21 @@ class MultiScaleBlock(nn.Module):
             plist = self.__dict__["_plist"] = list(self.parameters())
         return plist
 
+    def _drop_scales(self, B, device):
+        """Per-sample residual-branch scales of the two drop_path() calls (common.py:46-59): floor(keep + u) / keep."""
+        fixed = self.__dict__.get("_fixed_drop_scales")       # tests pin the masks
+        if fixed is not None:
+            return tuple(t.to(device=device, dtype=torch.float32) for t in fixed)
+        keep = 1.0 - self.drop_path_rate
+        u = torch.rand((2, B), dtype=torch.float32, device=device)
+        s = torch.floor(keep + u) / keep
+        return s[0].contiguous(), s[1].contiguous()
+
     def forward(self, x, thw_shape=None):
+        drop = None
         if self.training and self.drop_path_rate > 0.0:
-            raise NotImplementedError("stochastic depth (MVIT.DROPPATH_RATE > 0) is not on the built path yet; "
-                                      "set MVIT.DROPPATH_RATE 0.0")
-        out = MultiScaleBlockFn.apply(x, self, tuple(thw_shape), *self._param_list)
+            drop = self._drop_scales(x.shape[0], x.device)
+        out = MultiScaleBlockFn.apply(x, self, tuple(thw_shape), drop, *self._param_list)
         return out, list(self._plan(x.shape[0], thw_shape, x.device).q_thw)
 
 

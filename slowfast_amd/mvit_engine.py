@@ -193,7 +193,7 @@ class MultiScaleBlockFn(torch.autograd.Function):
     """MultiScaleBlock.forward (attention.py:491-514) for DIM_MUL_IN_ATT, conv pooling, cls token."""
 
     @staticmethod
-    def forward(ctx, x, mod, thw, *params):
+    def forward(ctx, x, mod, thw, drop, *params):
         att = mod.attn
         B, N, dim = x.shape
         plan = mod._plan(B, thw, x.device)
@@ -211,11 +211,18 @@ class MultiScaleBlockFn(torch.autograd.Function):
             pool = (k, s, p, arg, xres)
         else:
             xres = xs
-        x1 = att._proj.forward(o, resid=xres)              # x_res + attention output
+        if drop is None:
+            x1 = att._proj.forward(o, resid=xres)          # x_res + attention output
+        else:                                              # x_res + drop_path(attention output), attention.py:500-502
+            x1 = tokens.row_scale_add(att._proj.forward(o), drop[0], xres.shape[1], resid=xres)
         xn2, m2, r2 = mod._norm2.forward(x1)
         h = mod.mlp._fc1.forward(xn2)
         a = tokens.gelu_fwd(h)
-        out = mod.mlp._fc2.forward(a, resid=x1)
+        if drop is None:
+            out = mod.mlp._fc2.forward(a, resid=x1)
+        else:                                              # x + drop_path(mlp), attention.py:508-510
+            out = tokens.row_scale_add(mod.mlp._fc2.forward(a), drop[1], x1.shape[1], resid=x1)
+        ctx.drop = drop
         ctx.mod, ctx.plan, ctx.thw = mod, plan, tuple(thw)
         ctx.sv = dict(x=x, xn=xn, s1=(m1, r1), qkv=qkv, att=sv, o=o, pool=pool, x1=x1, xn2=xn2, s2=(m2, r2), h=h, a=a)
         ctx.out_thw = plan.q_thw
@@ -227,13 +234,14 @@ class MultiScaleBlockFn(torch.autograd.Function):
         att = mod.attn
         B = plan.B
         dout = dout.contiguous() if dout.dtype == _f16 else dout.to(_f16).contiguous()
+        drop = ctx.drop
         # Mlp
-        da = mod.mlp._fc2.backward(sv["a"], dout)
+        da = mod.mlp._fc2.backward(sv["a"], dout if drop is None else tokens.row_scale_add(dout, drop[1], dout.shape[1]))
         dh = tokens.gelu_bwd(sv["h"], da)
         dxn2 = mod.mlp._fc1.backward(sv["xn2"], dh)
         dx1 = mod._norm2.backward(dxn2, sv["x1"], *sv["s2"], resid=dout)
         # attention output projection, attention core, qkv projection
-        do = att._proj.backward(sv["o"], dx1)
+        do = att._proj.backward(sv["o"], dx1 if drop is None else tokens.row_scale_add(dx1, drop[0], dx1.shape[1]))
         dqkv = attention_backward(att, plan, sv["qkv"], sv["att"], do)
         dxn = att._qkv.backward(sv["xn"], dqkv)
         # skip path
@@ -249,7 +257,7 @@ class MultiScaleBlockFn(torch.autograd.Function):
         dx = mod._norm1.backward(dxn, sv["x"], *sv["s1"], resid=dx_skip)
         _notify(mod._param_list)
         ctx.sv = None
-        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
 class PatchEmbedFn(torch.autograd.Function):

@@ -328,6 +328,17 @@ def softmax_bwd(d, dp, prob, scale, want_drq):
     return dp, drq
 
 
+def row_scale_add(x, scale, rows_per_sample, resid=None):
+    """y = resid + scale[row // rows_per_sample] * x on token rows (stochastic depth, common.py:46-59)."""
+    M, C, ldx = rows_pitch(x)
+    y = torch.empty(x.shape, dtype=_f16, device=x.device)
+    assert scale.dtype == torch.float32 and scale.numel() * rows_per_sample == M
+    r_ptr, ldr = (resid.data_ptr(), rows_pitch(resid)[2]) if resid is not None else (None, 0)
+    _lib_call("sf_row_scale_add", x.data_ptr(), ldx, scale.data_ptr(), rows_per_sample, r_ptr, ldr, y.data_ptr(),
+              rows_pitch(y)[2], M, C, _stream(x), work=dict(bytes=2.0 * x.numel() * (3 if resid is not None else 2)))
+    return y
+
+
 def transpose_heads(x, B, Nk, heads, D, ldk):
     """[B, Nk, heads*D] -> [B, heads, D, ldk] (zero padded keys)."""
     xt = torch.empty((B, heads, D, ldk), dtype=_f16, device=x.device)

@@ -143,3 +143,49 @@ def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, t
     assert res["param_grad_worst"] <= bound("param_grad_worst", tol_param), res
     assert res["running_stats"] <= bound("running_stats", tol_stats), res
     return res
+
+
+def check_mvit_drop_path(device, rate=0.5, tol_logits=1e-2, tol_gnorm=1e-2, tol_global=3e-2):
+    """Stochastic depth (MVIT.DROPPATH_RATE > 0): the engine with pinned per-sample masks vs the oracle with the same
+    masks (drop_path(), common.py:46-59; attention.py:500-510).  Also checks that the sampler draws masks in
+    {0, 1/keep} when nothing is pinned."""
+    gold = load_golden("mvit_tiny")
+    opts = [o for o in gold["opts"]]
+    i = opts.index("MVIT.DROPPATH_RATE")
+    opts[i + 1] = rate
+    cfg = sa.get_preset(preset_for_yaml(gold["reference_yaml"]), opts)
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = mvit_ref.randomize_state(shapes, gold["param_seed"])
+    inputs, labels = video_ref.synthetic_batch(cfg, 4, gold["data_seed"])
+    g = torch.Generator().manual_seed(99)
+    drop = []
+    for blk in model.blocks:
+        keep = 1.0 - blk.drop_path_rate
+        assert 0.0 < keep <= 1.0
+        sc = torch.floor(keep + torch.rand((2, 4), generator=g)) / keep
+        drop.append((sc[0].clone(), sc[1].clone()))
+    assert any(float(s.min()) == 0.0 for pair in drop for s in pair), "no sample was dropped: the test is vacuous"
+    o_logits, o_loss, o_grads, _ = mvit_ref.loss_and_grads(sd, cfg, inputs, labels, drop=drop)
+    model.load_state_dict(sd)
+    model = model.to(device).train()
+    for blk, pair in zip(model.blocks, drop):
+        blk.__dict__["_fixed_drop_scales"] = pair
+    logits = model([x.to(device) for x in inputs])
+    loss = torch.nn.functional.cross_entropy(logits.float(), labels.to(device))
+    loss.backward()
+    grads = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
+    res = {"logits": float((logits.detach().float().cpu() - o_logits).abs().max() / o_logits.abs().max()),
+           "grad_norm": abs(float(video_ref.grad_norm(grads)) - float(video_ref.grad_norm(o_grads)))
+           / float(video_ref.grad_norm(o_grads)),
+           "grad_global": _global_rel(grads, o_grads)}
+    assert res["logits"] <= tol_logits and res["grad_norm"] <= tol_gnorm and res["grad_global"] <= tol_global, res
+    # the live sampler
+    blk = model.blocks[-1]
+    blk.__dict__.pop("_fixed_drop_scales")
+    s1, s2 = blk._drop_scales(64, torch.device(device))
+    keep = 1.0 - blk.drop_path_rate
+    for s in (s1, s2):
+        vals = set(round(float(v), 5) for v in s.cpu())
+        assert vals <= {0.0, round(1.0 / keep, 5)}, vals
+    return res

@@ -167,3 +167,8 @@ def test_nonlocal_matches_reference(gpu, name):
                         tol_global=1e-2, report=rep)
     finally:
         print(name, rep.get(name))
+
+
+def test_mvit_drop_path(gpu):
+    """Stochastic depth (MVIT.DROPPATH_RATE 0.5) with pinned masks vs the oracle with the same masks."""
+    print(mc.check_mvit_drop_path(gpu))

@@ -31,3 +31,8 @@ def test_nonlocal_engine_matches_oracle(sim):
     """SlowFast with Nonlocal blocks (dot-product affinity, (2,2,2) max-pool of the phi/g input) on res3/res4."""
     mc.check_engine("slowfast_nln_tiny", sim, tol_logits=2e-2, tol_loss=5e-3, tol_gnorm=2e-2, tol_param=1.0, tol_global=0.5,
                     tol_stats=2e-2)
+
+
+def test_mvit_drop_path_matches_oracle(sim):
+    """MVIT.DROPPATH_RATE > 0: per-sample stochastic depth on both residual branches of every block."""
+    mc.check_mvit_drop_path(sim)
