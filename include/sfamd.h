@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 8
+#define SF_ABI_VERSION 9
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -204,12 +204,25 @@ int sf_softmax_fwd(const sf_attn_desc* d, void* s, int32_t lds, float scale, con
 /* in place: dp <- scale * P*(dp - sum_k P*dp); drq (optional) <- per-(kh|kw|kt) sums of the unscaled dS */
 int sf_softmax_bwd(const sf_attn_desc* d, void* dp, const void* prob, int32_t lds, float scale, float* drq,
                    sf_stream_t stream);
-/* xt[b][head][c][k] = x[b][k][head*D + c], zero for k in [Nk, ldk): K-contiguous operand for P.V and dS.K */
+/* Fused attention core -- replaces attention.py:355-385 (scores, decomposed rel-pos bias, softmax, attn @ v, residual
+ * pooling) without materialising the [B, heads, Nq, Nk] score tensors (online softmax, fp32 statistics).
+ *   o[b][q][head*D + :] = softmax_k(scale * q.k + bias(q, k)) v  (+ q on the rows >= cls when `residual`)
+ * q, o, dq: [B][Nq][.] rows of pitch ldq / ldo / lddq; k, v, dk, dv: [B][Nk][.] rows of pitch ldk / lddk; head h occupies
+ * columns [h*D, (h+1)*D), D in {32, 64, 96, 128}.  rq (optional) is sf_relpos_gather's output
+ * [(b*Nq + q)*heads + head][kH + kW + kT] fp32; lse / delta are [(b*heads + head)*Nq + q] fp32 scratch the forward
+ * writes (log-sum-exp) and the backward fills (delta) -- caller-owned.  sf_attn_bwd returns dq (incl. the residual's
+ * dout on the rows >= cls), dk, dv and drq (the bias gradient, input of sf_relpos_scatter). */
+int sf_attn_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, const void* k, const void* v, int32_t ldk, float scale,
+                const float* rq, int32_t residual, void* o, int32_t ldo, float* lse, sf_stream_t stream);
+int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, const void* k, const void* v, int32_t ldk, float scale,
+                const float* rq, int32_t residual, const void* o, const void* dout, int32_t ldo, const float* lse,
+                float* delta, void* dq, int32_t lddq, void* dk, void* dv, int32_t lddk, float* drq, sf_stream_t stream);
 /* Stochastic depth -- replaces drop_path() (slowfast/models/common.py:46-59) at the two residual additions of
  * MultiScaleBlock (attention.py:500-510): y[m] = (resid ? resid[m] : 0) + scale[m / rows_per_sample] * x[m], with
  * scale[b] = floor(keep_prob + u_b) / keep_prob sampled by the caller.  Rows are fp16 [M][C], C % 8 == 0. */
 int sf_row_scale_add(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,
                      int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C, sf_stream_t stream);
+/* xt[b][head][c][k] = x[b][k][head*D + c], zero for k in [Nk, ldk): K-contiguous operand for P.V and dS.K */
 int sf_transpose_heads(const void* x, int32_t ldx, void* xt, int32_t ldk, int32_t B, int32_t Nk, int32_t heads, int32_t D,
                        sf_stream_t stream);
 

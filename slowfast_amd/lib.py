@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ConvDesc(Structure):
@@ -86,6 +86,9 @@ _SIGNATURES = {
     "sf_relpos_scatter": (c_int, [POINTER(AttnDesc), _F, _P, _P, _P, _P, c_int32, _P]),
     "sf_softmax_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, c_float, _F, _P]),
     "sf_softmax_bwd": (c_int, [POINTER(AttnDesc), _P, _P, c_int32, c_float, _F, _P]),
+    "sf_attn_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, c_int32, c_float, _F, c_int32, _P, c_int32, _F, _P]),
+    "sf_attn_bwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, c_int32, c_float, _F, c_int32, _P, _P, c_int32, _F, _F,
+                            _P, c_int32, _P, _P, c_int32, _F, _P]),
     "sf_row_scale_add": (c_int, [_P, c_int32, _P, c_int64, _P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     "sf_transpose_heads": (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "sf_sample_chunks": (c_int, [c_int64, c_int32]),

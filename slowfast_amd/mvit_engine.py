@@ -11,6 +11,7 @@ Reference graph: slowfast/models/attention.py:293-392 (MultiScaleAttention.forwa
 stem_helper.py:315-320 (PatchEmbed.forward), video_model_builder.py:1166-1244 (MViT.forward).
 """
 import math
+import os
 
 import torch
 
@@ -119,6 +120,15 @@ class AttentionPlan:
             self.idx = (_rel_index(qh, kh, device), _rel_index(qw, kw, device), _rel_index(qt, kt, device))
 
 
+def _fused_attention(plan):
+    """The flash-style kernels (sf_attn_*) cover head dims 32/64/96/128 and key grids with kH + kW + kT <= 48;
+    SF_ATTN_FUSED=0 selects the unfused GEMM / softmax / GEMM chain (kept for A/B runs and other shapes)."""
+    if os.environ.get("SF_ATTN_FUSED", "1") == "0":
+        return False
+    kt, kh, kw = plan.k_thw
+    return plan.D % 32 == 0 and plan.D <= 128 and (not plan.rel or kt + kh + kw <= 48)
+
+
 def attention_forward(att, plan, qkv):
     """qkv [B, N, 3*att] -> (o [B, Nq, att], saved tensors).  attention.py:318-385."""
     B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
@@ -136,6 +146,11 @@ def attention_forward(att, plan, qkv):
     if plan.rel:
         t16, t16t = tokens.relpos_tables16(tables)
     rq = tokens.relpos_fwd(plan.desc, qn, tables, plan.idx, t16=t16) if plan.rel else None
+    if _fused_attention(plan):
+        o, lse = tokens.attn_fwd(plan.desc, qn, kn, vn, att.scale, rq, att.residual_pooling)
+        saved = dict(qp=qp, kp=kp, vp=vp, qn=qn, kn=kn, vn=vn, sq=(mq, rq_), sk=(mk, rk_), sv=(mv, rv_), t16t=t16t,
+                     fused=(o, lse, rq))
+        return o, saved
     S = torch.empty((B, heads, Nq, lds), dtype=_f16, device=qkv.device)
     tokens.bgemm_heads(qn, (Nq * C, D), Nq, D, C, kn, (Nk * C, D), Nk, C, S, (heads * Nq * lds, Nq * lds), lds, B, heads)
     P = tokens.softmax_fwd(plan.desc, S, att.scale, rq)
@@ -152,8 +167,13 @@ def attention_backward(att, plan, qkv, sv, do):
     """d(o) -> d(qkv) [B, N, 3*att]; writes the gradients of pool_{q,k,v}, norm_{q,k,v}, rel_pos_{h,w,t}."""
     B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
     Nq, Nk, lds = plan.Nq, plan.Nk, plan.lds
-    qn, kn, vn, P = sv["qn"], sv["kn"], sv["vn"], sv["P"]
+    qn, kn, vn = sv["qn"], sv["kn"], sv["vn"]
     dev = do.device
+    if "fused" in sv:
+        o, lse, rq = sv["fused"]
+        dqn, dkn, dvn, drq = tokens.attn_bwd(plan.desc, qn, kn, vn, att.scale, rq, att.residual_pooling, o, do, lse)
+        return _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq)
+    P = sv["P"]
     # dP = dO V^T ; dV = P^T dO
     dP = torch.empty((B, heads, Nq, lds), dtype=_f16, device=dev)
     tokens.bgemm_heads(do, (Nq * C, D), Nq, D, C, vn, (Nk * C, D), Nk, C, dP, (heads * Nq * lds, Nq * lds), lds, B, heads)
@@ -170,6 +190,14 @@ def attention_backward(att, plan, qkv, sv, do):
     dkn = torch.empty((B, Nk, C), dtype=_f16, device=dev)
     tokens.bgemm_tn_heads(dS, (heads * Nq * lds, Nq * lds), lds, qn, (Nq * C, D), C, Nq, Nk, D, dkn, (Nk * C, D), C,
                           B, heads)
+    return _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq)
+
+
+def _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq):
+    """rel-pos table gradients (+ their dq term), LayerNorm(head_dim) and depthwise pooling backward."""
+    B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
+    Nq, Nk = plan.Nq, plan.Nk
+    dev = dqn.device
     if plan.rel:
         tabs = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t)
         dests = [_grad_dest(t) for t in tabs]

@@ -328,6 +328,34 @@ def softmax_bwd(d, dp, prob, scale, want_drq):
     return dp, drq
 
 
+def attn_fwd(d, q, k, v, scale, rq, residual):
+    """Fused softmax(scale q k^T + bias) v (+ q): q [B, Nq, heads*D], k/v [B, Nk, heads*D] -> (o, lse)."""
+    B, Nq, C = q.shape
+    o = torch.empty((B, Nq, C), dtype=_f16, device=q.device)
+    lse = torch.empty((B * d.heads * Nq,), dtype=torch.float32, device=q.device)
+    flops = 4.0 * B * d.heads * Nq * d.Nk * d.D
+    _lib_call("sf_attn_fwd", byref(d), q.data_ptr(), rows_pitch(q)[2], k.data_ptr(), v.data_ptr(), rows_pitch(k)[2],
+              float(scale), _ptr(rq), int(bool(residual)), o.data_ptr(), C, lse.data_ptr(), _stream(q),
+              work=dict(bytes=2.0 * (2 * q.numel() + 2 * k.numel()), flops=flops))
+    return o, lse
+
+
+def attn_bwd(d, q, k, v, scale, rq, residual, o, do, lse):
+    """Backward of attn_fwd: (dq, dk, dv, drq)."""
+    B, Nq, C = q.shape
+    dq = torch.empty((B, Nq, C), dtype=_f16, device=q.device)
+    dk = torch.empty(k.shape, dtype=_f16, device=q.device)
+    dv = torch.empty(k.shape, dtype=_f16, device=q.device)
+    delta = torch.empty_like(lse)
+    drq = torch.empty(rq.shape, dtype=torch.float32, device=q.device) if rq is not None else None
+    flops = 14.0 * B * d.heads * Nq * d.Nk * d.D
+    _lib_call("sf_attn_bwd", byref(d), q.data_ptr(), rows_pitch(q)[2], k.data_ptr(), v.data_ptr(), rows_pitch(k)[2],
+              float(scale), _ptr(rq), int(bool(residual)), o.data_ptr(), do.data_ptr(), rows_pitch(o)[2],
+              lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), C, dk.data_ptr(), dv.data_ptr(), rows_pitch(dk)[2],
+              _ptr(drq), _stream(q), work=dict(bytes=2.0 * (4 * q.numel() + 4 * k.numel()), flops=flops))
+    return dq, dk, dv, drq
+
+
 def row_scale_add(x, scale, rows_per_sample, resid=None):
     """y = resid + scale[row // rows_per_sample] * x on token rows (stochastic depth, common.py:46-59)."""
     M, C, ldx = rows_pitch(x)

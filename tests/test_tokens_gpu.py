@@ -40,3 +40,16 @@ def test_attention_core(gpu):
     tc.check_attention_core(gpu, 1, 1, 96, (8, 28, 28), (8, 7, 7))     # Nk = 393: stage-1 key count
     tc.check_attention_core(gpu, 1, 4, 96, (4, 7, 7), (4, 7, 7))
     tc.check_attention_core(gpu, 1, 1, 32, (4, 16, 16), (4, 16, 16))   # 1025 keys: 4-slot softmax rows
+
+
+@pytest.mark.parametrize("case", [
+    (2, 1, 96, (8, 56, 56), (8, 7, 7), True, True, True),      # MViTv2-S block 0: 25089 queries x 393 keys
+    (1, 2, 96, (8, 28, 28), (8, 14, 14), True, True, True),    # block 1: 6273 x 1569, 14+14+8 bias buckets
+    (2, 8, 96, (8, 7, 7), (8, 7, 7), True, True, True),        # stage 4: 8 heads, 393 x 393
+    (1, 2, 32, (2, 6, 6), (2, 3, 3), True, True, True),
+    (1, 1, 64, (1, 5, 9), (1, 5, 9), False, False, False),
+    (1, 1, 128, (2, 9, 9), (2, 5, 5), True, False, True),
+])
+def test_attention_fused(gpu, case):
+    """sf_attn_fwd / sf_attn_bwd (no score tensor) vs the reference attention math incl. rel-pos table gradients."""
+    tc.check_attention_fused(gpu, *case)

@@ -1,4 +1,6 @@
 """CPU: every token-space kernel (MViT path) through the host simulator against the torch fp32 reference ops."""
+import pytest
+
 from tests import token_checks as tc
 
 
@@ -36,3 +38,13 @@ def test_token_pool(sim):
 def test_attention_core(sim):
     tc.check_attention_core(sim, 2, 2, 32, (2, 4, 4), (2, 2, 2))
     tc.check_attention_core(sim, 1, 1, 96, (2, 3, 3), (2, 3, 3))
+
+
+@pytest.mark.parametrize("case", [
+    (1, 1, 32, (2, 3, 3), (2, 3, 3), True, True, True),        # one partial key chunk, cls, rel-pos, residual pooling
+    (2, 2, 32, (2, 6, 6), (2, 3, 3), True, True, True),        # 73 queries (two query tiles), two heads
+    (1, 2, 96, (2, 8, 8), (2, 4, 4), True, True, True),        # MViTv2 head dim, 33 keys (two key chunks)
+    (1, 1, 64, (1, 5, 9), (1, 5, 9), False, False, False),     # no cls / no rel-pos / no residual
+])
+def test_attention_fused(sim, case):
+    tc.check_attention_fused(sim, *case)

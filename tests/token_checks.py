@@ -175,3 +175,51 @@ def check_attention_core(device, B, heads, D, q_thw, k_thw, seed=0):
     assert_close("dQ", dq.float().cpu(), qr.grad, 6 * F16_EPS)
     for name, got, ref in zip(("d rel_pos_h", "d rel_pos_w", "d rel_pos_t"), dts, tr):
         assert_close(name, got.cpu(), ref.grad, 5e-3)
+
+
+def check_attention_fused(device, B, heads, D, q_thw, k_thw, cls=True, rel=True, residual=True, seed=0):
+    """sf_attn_fwd / sf_attn_bwd (flash-style, no score tensor) against the reference attention math: output,
+    dQ / dK / dV and the rel-pos table gradients."""
+    from slowfast_amd.mvit_engine import _rel_index
+    g = torch.Generator().manual_seed(seed)
+    C = heads * D
+    c = int(cls)
+    Nq, Nk = c + q_thw[0] * q_thw[1] * q_thw[2], c + k_thw[0] * k_thw[1] * k_thw[2]
+    q = torch.randn((B, Nq, C), generator=g).half().float()
+    k = torch.randn((B, Nk, C), generator=g).half().float()
+    v = torch.randn((B, Nk, C), generator=g).half().float()
+    rows = (2 * max(q_thw[1], k_thw[1]) - 1, 2 * max(q_thw[2], k_thw[2]) - 1, 2 * max(q_thw[0], k_thw[0]) - 1)
+    tabs = [torch.randn((r, D), generator=g) * 0.3 for r in rows]
+    do = torch.randn((B, Nq, C), generator=g).half().float()
+    scale = D ** -0.5
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    tr = [t.clone().requires_grad_(True) for t in tabs]
+    qh, kh, vh = (t.reshape(B, -1, heads, D).permute(0, 2, 1, 3) for t in (qr, kr, vr))
+    attn = (qh * scale) @ kh.transpose(-2, -1)
+    if rel:
+        attn = mvit_ref._rel_pos_bias(attn, qh, cls, q_thw, k_thw, tr[0], tr[1], tr[2])
+    attn = attn.softmax(-1)
+    o = attn @ vh
+    if residual:
+        o = torch.cat([o[:, :, :c], o[:, :, c:] + qh[:, :, c:]], 2) if cls else o + qh
+    o = o.transpose(1, 2).reshape(B, Nq, C)
+    o.backward(do)
+    d = tokens.attn_desc(B, heads, D, cls, q_thw, k_thw, *(rows if rel else (0, 0, 0)))
+    qd, kd, vd, tabd, dod = _h(q, device), _h(k, device), _h(v, device), [t.to(device) for t in tabs], _h(do, device)
+    rq = None
+    idx = None
+    if rel:
+        idx = (_rel_index(q_thw[1], k_thw[1], device), _rel_index(q_thw[2], k_thw[2], device),
+               _rel_index(q_thw[0], k_thw[0], device))
+        rq = tokens.relpos_fwd(d, qd, tabd, idx)
+    of, lse = tokens.attn_fwd(d, qd, kd, vd, scale, rq, residual)
+    assert_close("fused attention out", of.float().cpu(), o.detach(), 3 * F16_EPS)
+    dq, dk, dv, drq = tokens.attn_bwd(d, qd, kd, vd, scale, rq, residual, of, dod, lse)
+    assert_close("fused dV", dv.float().cpu(), vr.grad, 4 * F16_EPS)
+    assert_close("fused dK", dk.float().cpu(), kr.grad, 6 * F16_EPS)
+    if rel:
+        dts = [torch.full(t.shape, 2.0, device=device) for t in tabs]
+        tokens.relpos_bwd(d, qd, tabd, idx, drq, dq, dts, [False, False, False])
+        for name, got, ref in zip(("d rel_pos_h", "d rel_pos_w", "d rel_pos_t"), dts, tr):
+            assert_close("fused " + name, got.cpu(), ref.grad, 5e-3)
+    assert_close("fused dQ", dq.float().cpu(), qr.grad, 6 * F16_EPS)
