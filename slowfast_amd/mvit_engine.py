@@ -120,10 +120,16 @@ class AttentionPlan:
             self.idx = (_rel_index(qh, kh, device), _rel_index(qw, kw, device), _rel_index(qt, kt, device))
 
 
+# Measured on MI355X (profiles/r1_visit12_bench_mvit_{fused,unfused}.json): the first version of the fused kernels is
+# VALU-bound (bias lookups, expf, per-chunk rescale) and its dK/dV kernel under-fills the GPU when Nk is small:
+# 414 vs 445 clips/s.  The unfused chain therefore stays the default until the fused path wins; SF_ATTN_FUSED=1 selects it.
+_FUSED_DEFAULT = "0"
+
+
 def _fused_attention(plan):
     """The flash-style kernels (sf_attn_*) cover head dims 32/64/96/128 and key grids with kH + kW + kT <= 48;
     SF_ATTN_FUSED=0 selects the unfused GEMM / softmax / GEMM chain (kept for A/B runs and other shapes)."""
-    if os.environ.get("SF_ATTN_FUSED", "1") == "0":
+    if os.environ.get("SF_ATTN_FUSED", _FUSED_DEFAULT) == "0":
         return False
     kt, kh, kw = plan.k_thw
     return plan.D % 32 == 0 and plan.D <= 128 and (not plan.rel or kt + kh + kw <= 48)
