@@ -209,14 +209,20 @@ int sf_softmax_bwd(const sf_attn_desc* d, void* dp, const void* prob, int32_t ld
  *   o[b][q][head*D + :] = softmax_k(scale * q.k + bias(q, k)) v  (+ q on the rows >= cls when `residual`)
  * q, o, dq: [B][Nq][.] rows of pitch ldq / ldo / lddq; k, v, dk, dv: [B][Nk][.] rows of pitch ldk / lddk; head h occupies
  * columns [h*D, (h+1)*D), D in {32, 64, 96, 128}.  rq (optional) is sf_relpos_gather's output
- * [(b*Nq + q)*heads + head][kH + kW + kT] fp32; lse / delta are [(b*heads + head)*Nq + q] fp32 scratch the forward
- * writes (log-sum-exp) and the backward fills (delta) -- caller-owned.  sf_attn_bwd returns dq (incl. the residual's
- * dout on the rows >= cls), dk, dv and drq (the bias gradient, input of sf_relpos_scatter). */
+ * [(b*Nq + q)*heads + head][kH + kW + kT] fp32 and `onehot` the constant fp16 matrix [roundup(Nk, 32)][64] with
+ * onehot[key][j] = 1 for j in {kh, kH + kw, kH + kW + kt} of a non-cls key (zero rows for the cls key and the padding):
+ * bias(q, key) = sum_j rq[q][j] onehot[key][j] runs on the matrix cores.  lse / delta are
+ * [(b*heads + head)*Nq + q] fp32 scratch (caller-owned) that the forward / backward fill.  sf_attn_bwd returns dq (incl.
+ * the residual's dout on the rows >= cls), dk, dv and drq (the bias gradient, input of sf_relpos_scatter); `workspace`
+ * (>= sf_attn_bwd_workspace(d) bytes, may be 0) holds the dK/dV partials of the query splits. */
 int sf_attn_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, const void* k, const void* v, int32_t ldk, float scale,
-                const float* rq, int32_t residual, void* o, int32_t ldo, float* lse, sf_stream_t stream);
+                const float* rq, const void* onehot, int32_t residual, void* o, int32_t ldo, float* lse,
+                sf_stream_t stream);
+int64_t sf_attn_bwd_workspace(const sf_attn_desc* d);
 int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, const void* k, const void* v, int32_t ldk, float scale,
-                const float* rq, int32_t residual, const void* o, const void* dout, int32_t ldo, const float* lse,
-                float* delta, void* dq, int32_t lddq, void* dk, void* dv, int32_t lddk, float* drq, sf_stream_t stream);
+                const float* rq, const void* onehot, int32_t residual, const void* o, const void* dout, int32_t ldo,
+                const float* lse, float* delta, void* dq, int32_t lddq, void* dk, void* dv, int32_t lddk, float* drq,
+                void* workspace, int64_t workspace_bytes, sf_stream_t stream);
 /* Stochastic depth -- replaces drop_path() (slowfast/models/common.py:46-59) at the two residual additions of
  * MultiScaleBlock (attention.py:500-510): y[m] = (resid ? resid[m] : 0) + scale[m / rows_per_sample] * x[m], with
  * scale[b] = floor(keep_prob + u_b) / keep_prob sampled by the caller.  Rows are fp16 [M][C], C % 8 == 0. */

@@ -1040,14 +1040,22 @@ static int fill_attn(AttnParams& p, const sf_attn_desc* d, const char* who) {
     REQUIRE(d->B > 0 && d->heads > 0 && d->Nq > 0 && d->Nk > 0, "%s: empty problem", who);
     REQUIRE(d->D % 32 == 0 && d->D >= 32 && d->D <= 128, "%s: head dim must be 32, 64, 96 or 128 (got %d)", who, d->D);
     REQUIRE(d->Nq == d->cls + d->qT * d->qH * d->qW && d->Nk == d->cls + d->kT * d->kH * d->kW, "%s: inconsistent descriptor", who);
-    REQUIRE(d->kH < 256 && d->kW < 256 && d->kT < 256, "%s: key grid too large", who);
     memset(&p, 0, sizeof(p));
-    p.B = d->B; p.heads = d->heads; p.Nq = d->Nq; p.Nk = d->Nk; p.cls = d->cls; p.KH = d->kH; p.KW = d->kW;
-    p.fdKW = make_fastdiv(d->kW); p.fdKH = make_fastdiv(d->kH);
+    p.B = d->B; p.heads = d->heads; p.Nq = d->Nq; p.Nk = d->Nk; p.cls = d->cls;
     p.R = d->kH + d->kW + d->kT;
     p.qtiles = cdiv(d->Nq, 64); p.ktiles = cdiv(d->Nk, 64);
-    REQUIRE((int64_t)d->B * d->heads * (p.qtiles > p.ktiles ? p.qtiles : p.ktiles) < (1ll << 31), "%s: too many tiles", who);
+    REQUIRE((int64_t)d->B * d->heads * (p.qtiles > p.ktiles ? p.qtiles : p.ktiles) < (1ll << 28), "%s: too many tiles", who);
+    // dK/dV: split the queries so that ~1024 workgroups exist (Nk is small), at least 8 query chunks per split
+    const int nchq = cdiv(d->Nq, 32);
+    int splits = cdiv(1024, (int64_t)d->B * d->heads * p.ktiles);
+    if (splits > nchq / 8) splits = nchq / 8;
+    if (splits < 1) splits = 1;
+    p.chunks_per_split = cdiv(nchq, splits);
+    p.qsplits = cdiv(nchq, p.chunks_per_split);
     return 0;
+}
+static int64_t attn_ws_bytes(const AttnParams& p, const sf_attn_desc* d) {
+    return p.qsplits > 1 ? (int64_t)p.qsplits * 2 * d->B * d->Nk * d->heads * d->D * 4 : 0;
 }
 #define SF_ATTN_LAUNCH(KERNEL, D_, grid, st, p)                                                     \
     do {                                                                                            \
@@ -1060,40 +1068,62 @@ static int fill_attn(AttnParams& p, const sf_attn_desc* d, const char* who) {
     } while (0)
 
 extern "C" int sf_attn_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, const void* k, const void* v, int32_t ldk,
-                           float scale, const float* rq, int32_t residual, void* o, int32_t ldo, float* lse,
-                           sf_stream_t stream) {
+                           float scale, const float* rq, const void* onehot, int32_t residual, void* o, int32_t ldo,
+                           float* lse, sf_stream_t stream) {
     AttnParams p;
     if (fill_attn(p, d, "sf_attn_fwd")) return -1;
     REQUIRE(q && k && v && o && lse, "sf_attn_fwd: null pointer");
     REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "sf_attn_fwd: row pitches must be multiples of 8");
+    REQUIRE((rq == nullptr) == (onehot == nullptr), "sf_attn_fwd: rq and onehot come together");
     REQUIRE(!rq || p.R <= SF_ATTN_RMAX, "sf_attn_fwd: kH + kW + kT = %d exceeds %d", p.R, SF_ATTN_RMAX);
     p.q = (const f16*)q; p.k = (const f16*)k; p.v = (const f16*)v; p.ldq = ldq; p.ldk = ldk;
-    p.out = (f16*)o; p.ldout = ldo; p.rq = rq; p.lse = lse; p.scale = scale; p.residual = residual;
+    p.out = (f16*)o; p.ldout = ldo; p.rq = rq; p.oh = (const f16*)onehot; p.lse = lse;
+    p.scale = scale; p.scale2 = scale * SF_LOG2E; p.residual = residual;
     if (!rq) p.R = 0;
     SF_ATTN_LAUNCH(sf_attn_fwd_kernel, d->D, d->B * d->heads * p.qtiles, (hipStream_t)stream, p);
     return check_launch("attn_fwd");
 }
 
+extern "C" int64_t sf_attn_bwd_workspace(const sf_attn_desc* d) {
+    AttnParams p;
+    if (fill_attn(p, d, "sf_attn_bwd_workspace")) return -1;
+    return attn_ws_bytes(p, d);
+}
+
 extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, const void* k, const void* v, int32_t ldk,
-                           float scale, const float* rq, int32_t residual, const void* o, const void* dout, int32_t ldo,
-                           const float* lse, float* delta, void* dq, int32_t lddq, void* dk, void* dv, int32_t lddk,
-                           float* drq, sf_stream_t stream) {
+                           float scale, const float* rq, const void* onehot, int32_t residual, const void* o,
+                           const void* dout, int32_t ldo, const float* lse, float* delta, void* dq, int32_t lddq, void* dk,
+                           void* dv, int32_t lddk, float* drq, void* workspace, int64_t workspace_bytes,
+                           sf_stream_t stream) {
     AttnParams p;
     if (fill_attn(p, d, "sf_attn_bwd")) return -1;
     REQUIRE(q && k && v && o && dout && lse && delta && dq && dk && dv, "sf_attn_bwd: null pointer");
-    REQUIRE((rq == nullptr) == (drq == nullptr), "sf_attn_bwd: rq and drq come together");
+    REQUIRE((rq == nullptr) == (drq == nullptr) && (rq == nullptr) == (onehot == nullptr),
+            "sf_attn_bwd: rq, onehot and drq come together");
     REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0, "sf_attn_bwd: bad row pitch");
     REQUIRE(!rq || p.R <= SF_ATTN_RMAX, "sf_attn_bwd: kH + kW + kT = %d exceeds %d", p.R, SF_ATTN_RMAX);
+    const int64_t need = attn_ws_bytes(p, d);
+    REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "sf_attn_bwd: workspace too small (%lld < %lld bytes)",
+            (long long)workspace_bytes, (long long)need);
     p.q = (const f16*)q; p.k = (const f16*)k; p.v = (const f16*)v; p.ldq = ldq; p.ldk = ldk;
     p.o = (const f16*)o; p.dout = (const f16*)dout; p.ldo = ldo;
     p.out = (f16*)dq; p.ldout = lddq; p.dk = (f16*)dk; p.dv = (f16*)dv; p.lddk = lddk;
-    p.rq = rq; p.drq = drq; p.lse = const_cast<float*>(lse); p.delta = delta; p.scale = scale; p.residual = residual;
+    p.rq = rq; p.drq = drq; p.oh = (const f16*)onehot; p.lse = const_cast<float*>(lse); p.delta = delta;
+    p.scale = scale; p.scale2 = scale * SF_LOG2E; p.residual = residual; p.part = (float*)workspace;
     if (!rq) p.R = 0;
     hipStream_t st = (hipStream_t)stream;
     SF_ATTN_LAUNCH(sf_attn_bwd_dq_kernel, d->D, d->B * d->heads * p.qtiles, st, p);       // also writes delta
     if (check_launch("attn_bwd_dq")) return -1;
-    SF_ATTN_LAUNCH(sf_attn_bwd_dkv_kernel, d->D, d->B * d->heads * p.ktiles, st, p);
-    return check_launch("attn_bwd_dkv");
+    SF_ATTN_LAUNCH(sf_attn_bwd_dkv_kernel, d->D, d->B * d->heads * p.ktiles * p.qsplits, st, p);
+    if (check_launch("attn_bwd_dkv")) return -1;
+    if (p.qsplits > 1) {
+        AttnReduceParams r;
+        r.part = p.part; r.qsplits = p.qsplits; r.C = d->heads * d->D; r.slab = (int64_t)d->B * d->Nk * r.C;
+        r.dk = p.dk; r.dv = p.dv; r.lddk = lddk; r.scale = scale; r.fdC4 = make_fastdiv(r.C / 4);
+        hipLaunchKernelGGL(sf_attn_reduce_kernel, dim3(pool_grid(r.slab / 2)), dim3(SF_THREADS), 0, st, r);
+        return check_launch("attn_reduce");
+    }
+    return 0;
 }
 
 extern "C" int sf_row_scale_add(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,

@@ -13,40 +13,42 @@
 //       O^T[d][q]  += V^T[d][key] P^T[key][q]          A = V^T (LDS, ds_read_b64_tr_b16), B = P^T = the S^T
 //                                                      accumulators of two 16-key tiles, exponentiated, as they are:
 //       MFMA k-slot (g, j) <-> key 4g + j (j < 4) of the first tile, key 16 + 4g + (j - 4) of the second.
-//   dK/dV kernel: the roles swap -- a wave owns 16 keys and walks the queries in chunks of 32.
-// The rel-pos bias is bias(q, key) = rq[q][kh] + rq[q][KH + kw] + rq[q][KH + KW + kt] (rq from sf_relpos_gather);
-// its gradient drq[q][j] = sum over the keys of bucket j of dS is one more MFMA against a 0/1 operand built in
-// registers.  fp32 softmax statistics; P and dS enter the MFMAs as fp16, exactly like the unfused path stores them.
+//   dK/dV kernel: the roles swap -- a wave owns 16 keys and walks (a split of) the queries in chunks of 32; the query
+//       splits write fp32 partials that sf_attn_reduce_kernel sums (Nk is small: without the split only
+//       B*heads*Nk/64 workgroups exist).
+// The VALU budget per score is what bounds these kernels (12-20 MFMAs vs 8 scores per lane and chunk), so nothing
+// per-score goes through lookups or libm:
+//   * rel-pos bias(q, key) = rq[q][kh] + rq[q][KH+kw] + rq[q][KH+KW+kt] is ONE more contraction on the matrix cores,
+//     OH[key][j] (a constant 0/1 matrix with three ones per row, built once per shape by the caller) times rq[q][j]
+//     split into fp16 hi + lo parts (exact to 2^-22); its gradient drq = OH^T dS likewise;
+//   * log2(e) is folded into `scale` and rq, exponentials are raw v_exp_f32;
+//   * the running maximum is only advanced (and the accumulators rescaled) when it grows by more than 2^8
+//     -- P stays <= 256, far inside fp16 -- which makes the rescale a rare wave-uniform branch.
+// fp32 softmax statistics; P and dS enter the MFMAs as fp16, exactly like the unfused path stores them.
 #pragma once
 #include "sf_common.h"
 #include "sf_igemm.h"
 
-#define SF_ATTN_RMAX 48            // kH + kW + kT of the key grid (MViTv2-S: 7+7+8 .. 14+14+8)
+#define SF_ATTN_RMAX 64            // kH + kW + kT of the key grid (MViTv2-S: 7+7+8 .. 14+14+8), columns of OH
+#define SF_ATTN_OHP 72             // LDS pitch of an OH / rq row (64 + 8: conflict-free ds_read_b128)
+#define SF_LOG2E 1.4426950408889634f
+#define SF_LN2 0.6931471805599453f
 
 struct AttnParams {
     const f16* q; const f16* k; const f16* v; int ldq, ldk;   // [B][N][heads*D] rows, head h at column h*D
     const f16* o; const f16* dout; int ldo;                   // backward inputs (o includes the residual)
     f16* out; int ldout;                                      // forward: o; dq kernel: dq
     f16* dk; f16* dv; int lddk;
-    const float* rq; float* drq; int R;                       // [(b*Nq + q)*heads + head][R]
-    float* lse; float* delta;                                 // [(b*heads + head)*Nq + q]
+    const float* rq; float* drq; int R;                       // [(b*Nq + q)*heads + head][R]; R = 0: no bias
+    const f16* oh;                                            // [roundup(Nk, 32)][64] 0/1
+    float* lse; float* delta;                                 // [(b*heads + head)*Nq + q]; lse in log2 units
+    float scale2;                                             // scale * log2(e)
     float scale; int residual;
-    int B, heads, Nq, Nk, cls, KH, KW;
-    FastDiv fdKW, fdKH;
+    int B, heads, Nq, Nk, cls;
     int qtiles, ktiles;
+    int qsplits, chunks_per_split;                            // dK/dV kernel: query chunks per split
+    float* part;                                              // [qsplits][2][B][Nk][heads*D] fp32 (qsplits > 1)
 };
-
-// packed (kh | kw << 8 | kt << 16) of a key, -1 for the cls key and for keys beyond Nk
-__device__ __forceinline__ int attn_key_code(const AttnParams& p, int key) {
-    if (key < p.cls || key >= p.Nk) return -1;
-    uint32_t r, kw, kt, kh;
-    fd_divmod((uint32_t)(key - p.cls), p.fdKW, r, kw);
-    fd_divmod(r, p.fdKH, kt, kh);
-    return (int)(kh | (kw << 8) | (kt << 16));
-}
-__device__ __forceinline__ float attn_bias(const float* rqrow, int code, int KH, int KW) {
-    return rqrow[code & 255] + rqrow[KH + ((code >> 8) & 255)] + rqrow[KH + KW + (code >> 16)];
-}
 
 // stage rows [r0, r0 + 32) of a [N][ld] matrix (columns [0, D)) into LDS rows of pitch KP; rows >= N are zero
 template <int D, int KP>
@@ -83,6 +85,17 @@ __device__ __forceinline__ f16x8 attn_tr_frag(const f16* s, int KP, int col0, in
     return a;
 }
 
+// 8 consecutive fp32 (times log2 e) -> fp16 hi / lo parts; elements with index >= n are zero
+__device__ __forceinline__ void attn_split8(const float* src, int n, bool on, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = (on && e < n) ? src[e] * SF_LOG2E : 0.f;
+        const f16 h = (f16)v;
+        hi[e] = h;
+        lo[e] = (f16)(v - (float)h);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: workgroup = 64 queries of one (batch, head); wave w owns queries 16w .. 16w+15
 template <int KD>
@@ -90,8 +103,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_fwd_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 8, DT = D / 16;
     __shared__ __attribute__((aligned(16))) f16 Ks[32 * KP];
     __shared__ __attribute__((aligned(16))) f16 Vs[32 * KP];
-    __shared__ float s_rq[4][16][SF_ATTN_RMAX];
-    __shared__ int s_code[32];
+    __shared__ __attribute__((aligned(16))) f16 OHs[32 * SF_ATTN_OHP];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -104,15 +116,17 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_fwd_kernel(AttnParams p) {
     f16x8 qf[KD];
 #pragma unroll
     for (int s = 0; s < KD; ++s) qf[s] = ld16(qptr + 32 * s + 8 * g);
-    for (int i = lane; i < 16 * p.R; i += 64) {
-        const int rr = i / p.R, j = i - rr * p.R;
-        const int qr = qt * 64 + wave * 16 + rr;
-        float v = 0.f;
-        if (p.rq && qr < p.Nq && qr >= p.cls) v = p.rq[(((int64_t)b * p.Nq + qr) * p.heads + head) * p.R + j];
-        s_rq[wave][rr][j] = v;
+    const bool bias = p.R > 0, bias2 = p.R > 32;
+    f16x8 rqh[2], rql[2];
+    {
+        const bool on = bias && qc >= p.cls;
+        const float* rqrow = p.rq + (((int64_t)b * p.Nq + qc) * p.heads + head) * p.R;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int j0 = 32 * ks + 8 * g;
+            attn_split8(on ? rqrow + (j0 < p.R ? j0 : 0) : nullptr, p.R - j0, on && j0 < p.R, rqh[ks], rql[ks]);
+        }
     }
-    const bool qbias = p.rq != nullptr && qc >= p.cls;
-    const float* rqrow = s_rq[wave][pl];
     const f16* kbase = p.k + (int64_t)b * p.Nk * p.ldk + head * D;
     const f16* vbase = p.v + (int64_t)b * p.Nk * p.ldk + head * D;
     const int nch = (p.Nk + 31) / 32;
@@ -122,52 +136,64 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     RowChunk<D, KP> kc, vc;
+    f16x8 ohr = zero8();
     kc.load(kbase, p.ldk, 0, p.Nk, tid);
     vc.load(vbase, p.ldk, 0, p.Nk, tid);
+    if (bias) ohr = ld16(p.oh + (int64_t)tid * 8);
     for (int c = 0; c < nch; ++c) {
         __syncthreads();
         kc.store(Ks, tid);
         vc.store(Vs, tid);
-        if (tid < 32) s_code[tid] = attn_key_code(p, c * 32 + tid);
+        if (bias) st16(OHs + (tid >> 3) * SF_ATTN_OHP + (tid & 7) * 8, ohr);
         __syncthreads();
         if (c + 1 < nch) {
             kc.load(kbase, p.ldk, (c + 1) * 32, p.Nk, tid);
             vc.load(vbase, p.ldk, (c + 1) * 32, p.Nk, tid);
+            if (bias) ohr = ld16(p.oh + ((int64_t)(c + 1) * 32 * 64) + (int64_t)tid * 8);
         }
         float x[8];
-        float cmax = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 st = {0.f, 0.f, 0.f, 0.f};
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KD; ++s)
                 st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Ks + (16 * t + pl) * KP + 32 * s + 8 * g), qf[s], st, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kk = 16 * t + 4 * g + r;
-                float v = st[r] * p.scale;
-                const int code = s_code[kk];
-                if (qbias && code >= 0) v += attn_bias(rqrow, code, p.KH, p.KW);
-                if (c * 32 + kk >= p.Nk) v = -INFINITY;
-                x[4 * t + r] = v;
-                cmax = fmaxf(cmax, v);
+            if (bias) {
+                const f16x8 a0 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
+                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[0], bt, 0, 0, 0);
+                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[0], bt, 0, 0, 0);
+                if (bias2) {
+                    const f16x8 a1 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
+                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[1], bt, 0, 0, 0);
+                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[1], bt, 0, 0, 0);
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[4 * t + r] = st[r] * p.scale2 + bt[r];
         }
+        if (c == nch - 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (c * 32 + 16 * (i >> 2) + 4 * g + (i & 3) >= p.Nk) x[i] = -INFINITY;
+        }
+        float cmax = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const float m_new = fmaxf(m, cmax);
-        const float alpha = expf(m - m_new);
-        l *= alpha;
+        const bool grow = cmax > m + 8.f;          // also true on the first chunk (m = -inf)
+        if (__any(grow)) {
+            const float alpha = grow ? SF_EXP2(m - cmax) : 1.f;
+            if (grow) m = cmax;
+            l *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) oacc[dt] *= alpha;
+            for (int dt = 0; dt < DT; ++dt) oacc[dt] *= alpha;
+        }
         f16x8 pf;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float pv = expf(x[i] - m_new);
+            const float pv = SF_EXP2(x[i] - m);
             l += pv;
             pf[i] = (f16)pv;
         }
-        m = m_new;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
             oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_tr_frag(Vs, KP, dt * 16, pl, g), pf, oacc[dt], 0, 0, 0);
@@ -188,7 +214,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_fwd_kernel(AttnParams p) {
             for (int r = 0; r < 4; ++r) ov[r] = (f16)(oacc[dt][r] * inv + (float)rv[r]);
             *reinterpret_cast<f16x4*>(orow + d0) = ov;
         }
-        if (g == 0) p.lse[(int64_t)bh * p.Nq + qrow] = m + logf(l);
+        if (g == 0) p.lse[(int64_t)bh * p.Nq + qrow] = m + log2f(l);
     }
 }
 
@@ -199,8 +225,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dq_kernel(AttnParams p
     constexpr int D = 32 * KD, KP = D + 8, DT = D / 16, JT = SF_ATTN_RMAX / 16;
     __shared__ __attribute__((aligned(16))) f16 Ks[32 * KP];
     __shared__ __attribute__((aligned(16))) f16 Vs[32 * KP];
-    __shared__ float s_rq[4][16][SF_ATTN_RMAX];
-    __shared__ int s_code[32];
+    __shared__ __attribute__((aligned(16))) f16 OHs[32 * SF_ATTN_OHP];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -227,15 +252,17 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dq_kernel(AttnParams p
     dl += __shfl_xor(dl, 32);
     const float lse = p.lse[(int64_t)bh * p.Nq + qc];
     if (qok && g == 0) p.delta[(int64_t)bh * p.Nq + qrow] = dl;
-    for (int i = lane; i < 16 * p.R; i += 64) {
-        const int rr = i / p.R, j = i - rr * p.R;
-        const int qr = qt * 64 + wave * 16 + rr;
-        float v = 0.f;
-        if (p.rq && qr < p.Nq && qr >= p.cls) v = p.rq[(((int64_t)b * p.Nq + qr) * p.heads + head) * p.R + j];
-        s_rq[wave][rr][j] = v;
+    const bool bias = p.R > 0, bias2 = p.R > 32;
+    f16x8 rqh[2], rql[2];
+    {
+        const bool on = bias && qc >= p.cls;
+        const float* rqrow = p.rq + (((int64_t)b * p.Nq + qc) * p.heads + head) * p.R;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int j0 = 32 * ks + 8 * g;
+            attn_split8(on ? rqrow + (j0 < p.R ? j0 : 0) : nullptr, p.R - j0, on && j0 < p.R, rqh[ks], rql[ks]);
+        }
     }
-    const bool qbias = p.rq != nullptr && qc >= p.cls;
-    const float* rqrow = s_rq[wave][pl];
     const f16* kbase = p.k + (int64_t)b * p.Nk * p.ldk + head * D;
     const f16* vbase = p.v + (int64_t)b * p.Nk * p.ldk + head * D;
     const int nch = (p.Nk + 31) / 32;
@@ -246,61 +273,57 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dq_kernel(AttnParams p
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) drqacc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     RowChunk<D, KP> kc, vc;
+    f16x8 ohr = zero8();
     kc.load(kbase, p.ldk, 0, p.Nk, tid);
     vc.load(vbase, p.ldk, 0, p.Nk, tid);
+    if (bias) ohr = ld16(p.oh + (int64_t)tid * 8);
     for (int c = 0; c < nch; ++c) {
         __syncthreads();
         kc.store(Ks, tid);
         vc.store(Vs, tid);
-        if (tid < 32) s_code[tid] = attn_key_code(p, c * 32 + tid);
+        if (bias) st16(OHs + (tid >> 3) * SF_ATTN_OHP + (tid & 7) * 8, ohr);
         __syncthreads();
         if (c + 1 < nch) {
             kc.load(kbase, p.ldk, (c + 1) * 32, p.Nk, tid);
             vc.load(vbase, p.ldk, (c + 1) * 32, p.Nk, tid);
+            if (bias) ohr = ld16(p.oh + ((int64_t)(c + 1) * 32 * 64) + (int64_t)tid * 8);
         }
         f16x8 dsf;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
                 st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Ks + (16 * t + pl) * KP + 32 * s + 8 * g), qf[s], st, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Vs + (16 * t + pl) * KP + 32 * s + 8 * g), dof[s], dp, 0, 0, 0);
             }
+            if (bias) {
+                const f16x8 a0 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
+                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[0], bt, 0, 0, 0);
+                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[0], bt, 0, 0, 0);
+                if (bias2) {
+                    const f16x8 a1 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
+                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[1], bt, 0, 0, 0);
+                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[1], bt, 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int kk = 16 * t + 4 * g + r;
-                float v = st[r] * p.scale;
-                const int code = s_code[kk];
-                if (qbias && code >= 0) v += attn_bias(rqrow, code, p.KH, p.KW);
-                const float pv = c * 32 + kk < p.Nk ? expf(v - lse) : 0.f;
+                // keys beyond Nk: K, V rows are zero -> x = 0, dp = 0; their p must not reach dq / drq
+                const bool kin = c * 32 + 16 * t + 4 * g + r < p.Nk;
+                const float pv = kin ? SF_EXP2(st[r] * p.scale2 + bt[r] - lse) : 0.f;
                 dsf[4 * t + r] = (f16)(pv * (dp[r] - dl));
             }
         }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
             dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_tr_frag(Ks, KP, dt * 16, pl, g), dsf, dqacc[dt], 0, 0, 0);
-        if (p.drq) {
-            int codes[8];
+        if (bias) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) codes[4 * h + e] = s_code[16 * h + 4 * g + e];
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                if (jt * 16 < p.R) {
-                    const int j = jt * 16 + pl;
-                    f16x8 a;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int code = codes[e];
-                        const bool hit = code >= 0 && (j == (code & 255) || j == p.KH + ((code >> 8) & 255) ||
-                                                       j == p.KH + p.KW + (code >> 16));
-                        a[e] = hit ? (f16)1 : (f16)0;
-                    }
-                    drqacc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, dsf, drqacc[jt], 0, 0, 0);
-                }
-            }
+            for (int jt = 0; jt < JT; ++jt)
+                if (jt * 16 < p.R)
+                    drqacc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_tr_frag(OHs, SF_ATTN_OHP, jt * 16, pl, g), dsf,
+                                                                        drqacc[jt], 0, 0, 0);
         }
     }
     if (qok) {
@@ -315,7 +338,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dq_kernel(AttnParams p
             for (int r = 0; r < 4; ++r) ov[r] = (f16)(dqacc[dt][r] * p.scale + (float)rv[r]);
             *reinterpret_cast<f16x4*>(dqrow + d0) = ov;
         }
-        if (p.drq) {
+        if (bias) {
             float* drow = p.drq + (((int64_t)b * p.Nq + qrow) * p.heads + head) * p.R;
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
@@ -329,18 +352,22 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dq_kernel(AttnParams p
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, key side: workgroup = 64 keys of one (batch, head); wave w owns keys 16w .. 16w+15 and walks the queries
+// backward, key side: workgroup = 64 keys of one (batch, head) x one split of the queries; wave w owns keys
+// 16w .. 16w+15 and walks the split's queries in chunks of 32
 template <int KD>
 __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dkv_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 8, DT = D / 16;
     __shared__ __attribute__((aligned(16))) f16 Qs[32 * KP];
     __shared__ __attribute__((aligned(16))) f16 Os[32 * KP];      // dO rows
-    __shared__ float s_rq[32][SF_ATTN_RMAX];
+    __shared__ __attribute__((aligned(16))) f16 Rh[32 * SF_ATTN_OHP];   // rq rows (times log2 e), fp16 hi / lo parts
+    __shared__ __attribute__((aligned(16))) f16 Rl[32 * SF_ATTN_OHP];
     __shared__ float s_lse[32], s_delta[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = (int)(bid / (uint32_t)p.ktiles), kt = (int)(bid % (uint32_t)p.ktiles);
+    const int split = (int)(bid % (uint32_t)p.qsplits);
+    const int rest = (int)(bid / (uint32_t)p.qsplits);
+    const int bh = rest / p.ktiles, kt = rest % p.ktiles;
     const int b = bh / p.heads, head = bh % p.heads;
     const int key = kt * 64 + wave * 16 + pl;
     const bool kok = key < p.Nk;
@@ -353,11 +380,18 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dkv_kernel(AttnParams 
         kf[s] = ld16(kptr + 32 * s + 8 * g);
         vf[s] = ld16(vptr + 32 * s + 8 * g);
     }
-    const int code = attn_key_code(p, kc_);
-    const bool kbias = p.rq != nullptr && code >= 0;
+    const bool bias = p.R > 0, bias2 = p.R > 32;
+    f16x8 ohb[2] = {zero8(), zero8()};
+    if (bias) {
+        ohb[0] = ld16(p.oh + (int64_t)kc_ * 64 + 8 * g);
+        ohb[1] = ld16(p.oh + (int64_t)kc_ * 64 + 32 + 8 * g);
+    }
     const f16* qbase = p.q + (int64_t)b * p.Nq * p.ldq + head * D;
     const f16* dobase = p.dout + (int64_t)b * p.Nq * p.ldo + head * D;
-    const int nch = (p.Nq + 31) / 32;
+    const int nch_all = (p.Nq + 31) / 32;
+    const int c0 = split * p.chunks_per_split;
+    int c1 = c0 + p.chunks_per_split;
+    if (c1 > nch_all) c1 = nch_all;
 
     f32x4 dkacc[DT], dvacc[DT];
 #pragma unroll
@@ -366,9 +400,11 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dkv_kernel(AttnParams 
         dvacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     RowChunk<D, KP> qc, oc;
-    qc.load(qbase, p.ldq, 0, p.Nq, tid);
-    oc.load(dobase, p.ldo, 0, p.Nq, tid);
-    for (int c = 0; c < nch; ++c) {
+    if (c0 < c1) {
+        qc.load(qbase, p.ldq, c0 * 32, p.Nq, tid);
+        oc.load(dobase, p.ldo, c0 * 32, p.Nq, tid);
+    }
+    for (int c = c0; c < c1; ++c) {
         __syncthreads();
         qc.store(Qs, tid);
         oc.store(Os, tid);
@@ -377,34 +413,42 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dkv_kernel(AttnParams 
             s_lse[tid] = qr < p.Nq ? p.lse[(int64_t)bh * p.Nq + qr] : 0.f;
             s_delta[tid] = qr < p.Nq ? p.delta[(int64_t)bh * p.Nq + qr] : 0.f;
         }
-        if (p.rq) {
-            for (int i = tid; i < 32 * p.R; i += SF_THREADS) {
-                const int rr = i / p.R, j = i - rr * p.R;
-                const int qr = c * 32 + rr;
-                s_rq[rr][j] = (qr < p.Nq && qr >= p.cls) ? p.rq[(((int64_t)b * p.Nq + qr) * p.heads + head) * p.R + j] : 0.f;
-            }
+        if (bias) {
+            // 32 rows x 64 columns, 8 per thread
+            const int rr = tid >> 3, j0 = (tid & 7) * 8;
+            const int qr = c * 32 + rr;
+            const bool on = qr < p.Nq && qr >= p.cls && j0 < p.R;
+            f16x8 hi, lo;
+            attn_split8(on ? p.rq + (((int64_t)b * p.Nq + qr) * p.heads + head) * p.R + j0 : nullptr, p.R - j0, on, hi, lo);
+            st16(Rh + rr * SF_ATTN_OHP + j0, hi);
+            st16(Rl + rr * SF_ATTN_OHP + j0, lo);
         }
         __syncthreads();
-        if (c + 1 < nch) {
+        if (c + 1 < c1) {
             qc.load(qbase, p.ldq, (c + 1) * 32, p.Nq, tid);
             oc.load(dobase, p.ldo, (c + 1) * 32, p.Nq, tid);
         }
         f16x8 pf, dsf;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
                 st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Qs + (16 * t + pl) * KP + 32 * s + 8 * g), kf[s], st, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Os + (16 * t + pl) * KP + 32 * s + 8 * g), vf[s], dp, 0, 0, 0);
             }
+            if (bias) {
+                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], bt, 0, 0, 0);
+                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], bt, 0, 0, 0);
+                if (bias2) {
+                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], bt, 0, 0, 0);
+                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], bt, 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = 16 * t + 4 * g + r;
-                const int qr = c * 32 + qi;
-                float v = st[r] * p.scale;
-                if (kbias && qr >= p.cls) v += attn_bias(s_rq[qi], code, p.KH, p.KW);
-                const float pv = qr < p.Nq ? expf(v - s_lse[qi]) : 0.f;
+                const float pv = c * 32 + qi < p.Nq ? SF_EXP2(st[r] * p.scale2 + bt[r] - s_lse[qi]) : 0.f;
                 pf[4 * t + r] = (f16)pv;
                 dsf[4 * t + r] = (f16)(pv * (dp[r] - s_delta[qi]));
             }
@@ -415,20 +459,57 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dkv_kernel(AttnParams 
             dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_tr_frag(Qs, KP, dt * 16, pl, g), dsf, dkacc[dt], 0, 0, 0);
         }
     }
-    if (kok) {
-        f16* dkrow = p.dk + ((int64_t)b * p.Nk + key) * p.lddk + head * D;
-        f16* dvrow = p.dv + ((int64_t)b * p.Nk + key) * p.lddk + head * D;
+    if (!kok) return;
+    if (p.qsplits > 1) {
+        const int64_t C = (int64_t)p.heads * D;
+        const int64_t slab = (int64_t)p.B * p.Nk * C;
+        float* pk = p.part + ((int64_t)split * 2) * slab + ((int64_t)b * p.Nk + key) * C + head * D;
+        float* pv_ = pk + slab;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = dt * 16 + 4 * g;
-            f16x4 a, c2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                a[r] = (f16)(dkacc[dt][r] * p.scale);
-                c2[r] = (f16)dvacc[dt][r];
-            }
-            *reinterpret_cast<f16x4*>(dkrow + d0) = a;
-            *reinterpret_cast<f16x4*>(dvrow + d0) = c2;
+            *reinterpret_cast<f32x4*>(pk + d0) = dkacc[dt];
+            *reinterpret_cast<f32x4*>(pv_ + d0) = dvacc[dt];
         }
+        return;
+    }
+    f16* dkrow = p.dk + ((int64_t)b * p.Nk + key) * p.lddk + head * D;
+    f16* dvrow = p.dv + ((int64_t)b * p.Nk + key) * p.lddk + head * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d0 = dt * 16 + 4 * g;
+        f16x4 a, c2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[r] = (f16)(dkacc[dt][r] * p.scale);
+            c2[r] = (f16)dvacc[dt][r];
+        }
+        *reinterpret_cast<f16x4*>(dkrow + d0) = a;
+        *reinterpret_cast<f16x4*>(dvrow + d0) = c2;
+    }
+}
+
+// dk = scale * sum_splits part[s][0], dv = sum_splits part[s][1]  (fixed order), fp32 -> fp16
+struct AttnReduceParams {
+    const float* part; int qsplits;
+    int64_t slab;                   // B*Nk*C
+    int C;
+    f16* dk; f16* dv; int lddk;
+    float scale;
+    FastDiv fdC4;                   // C / 4
+};
+__global__ __launch_bounds__(SF_THREADS) void sf_attn_reduce_kernel(AttnReduceParams p) {
+    const int64_t total = p.slab / 4 * 2;
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * SF_THREADS) {
+        const int which = idx >= p.slab / 4;
+        const int64_t e4 = idx - (which ? p.slab / 4 : 0);
+        const float* src = p.part + (int64_t)which * p.slab + e4 * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < p.qsplits; ++k) s += *reinterpret_cast<const f32x4*>(src + (int64_t)k * 2 * p.slab);
+        uint32_t row, c4;
+        fd_divmod((uint32_t)e4, p.fdC4, row, c4);
+        const float sc = which ? 1.f : p.scale;
+        f16x4 o = {(f16)(s[0] * sc), (f16)(s[1] * sc), (f16)(s[2] * sc), (f16)(s[3] * sc)};
+        *reinterpret_cast<f16x4*>((which ? p.dv : p.dk) + (int64_t)row * p.lddk + c4 * 4) = o;
     }
 }

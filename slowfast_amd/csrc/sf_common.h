@@ -36,6 +36,11 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
     } while (0)
 #endif
 
+// 2^x on the transcendental unit (v_exp_f32: -inf -> 0, no range fix-ups)
+#ifndef SF_EXP2
+#define SF_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+
 #define SF_WAVE 64
 #define SF_THREADS 256
 

@@ -86,9 +86,10 @@ _SIGNATURES = {
     "sf_relpos_scatter": (c_int, [POINTER(AttnDesc), _F, _P, _P, _P, _P, c_int32, _P]),
     "sf_softmax_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, c_float, _F, _P]),
     "sf_softmax_bwd": (c_int, [POINTER(AttnDesc), _P, _P, c_int32, c_float, _F, _P]),
-    "sf_attn_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, c_int32, c_float, _F, c_int32, _P, c_int32, _F, _P]),
-    "sf_attn_bwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, c_int32, c_float, _F, c_int32, _P, _P, c_int32, _F, _F,
-                            _P, c_int32, _P, _P, c_int32, _F, _P]),
+    "sf_attn_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, c_int32, c_float, _F, _P, c_int32, _P, c_int32, _F, _P]),
+    "sf_attn_bwd_workspace": (c_int64, [POINTER(AttnDesc)]),
+    "sf_attn_bwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, c_int32, c_float, _F, _P, c_int32, _P, _P, c_int32, _F,
+                            _F, _P, c_int32, _P, _P, c_int32, _F, _P, c_int64, _P]),
     "sf_row_scale_add": (c_int, [_P, c_int32, _P, c_int64, _P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     "sf_transpose_heads": (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "sf_sample_chunks": (c_int, [c_int64, c_int32]),

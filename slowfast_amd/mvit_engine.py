@@ -113,6 +113,7 @@ class AttentionPlan:
         rows = (att.rel_pos_h.shape[0], att.rel_pos_w.shape[0], att.rel_pos_t.shape[0]) if self.rel else (0, 0, 0)
         self.desc = tokens.attn_desc(B, self.heads, self.D, cls, self.q_thw, self.k_thw, *rows)
         self.idx = None
+        self.onehot = None          # fused attention: bias-bucket indicator matrix (tokens.attn_onehot), built on first use
         if self.rel:
             (qt, qh, qw), (kt, kh, kw) = self.q_thw, self.k_thw
             assert rows == (2 * max(qh, kh) - 1, 2 * max(qw, kw) - 1, 2 * max(qt, kt) - 1), \
@@ -132,7 +133,7 @@ def _fused_attention(plan):
     if os.environ.get("SF_ATTN_FUSED", _FUSED_DEFAULT) == "0":
         return False
     kt, kh, kw = plan.k_thw
-    return plan.D % 32 == 0 and plan.D <= 128 and (not plan.rel or kt + kh + kw <= 48)
+    return plan.D % 32 == 0 and plan.D <= 128 and (not plan.rel or kt + kh + kw <= 64)
 
 
 def attention_forward(att, plan, qkv):
@@ -153,7 +154,9 @@ def attention_forward(att, plan, qkv):
         t16, t16t = tokens.relpos_tables16(tables)
     rq = tokens.relpos_fwd(plan.desc, qn, tables, plan.idx, t16=t16) if plan.rel else None
     if _fused_attention(plan):
-        o, lse = tokens.attn_fwd(plan.desc, qn, kn, vn, att.scale, rq, att.residual_pooling)
+        if plan.rel and plan.onehot is None:
+            plan.onehot = tokens.attn_onehot(plan.desc, qkv.device)
+        o, lse = tokens.attn_fwd(plan.desc, qn, kn, vn, att.scale, rq, att.residual_pooling, onehot=plan.onehot)
         saved = dict(qp=qp, kp=kp, vp=vp, qn=qn, kn=kn, vn=vn, sq=(mq, rq_), sk=(mk, rk_), sv=(mv, rv_), t16t=t16t,
                      fused=(o, lse, rq))
         return o, saved
@@ -177,7 +180,8 @@ def attention_backward(att, plan, qkv, sv, do):
     dev = do.device
     if "fused" in sv:
         o, lse, rq = sv["fused"]
-        dqn, dkn, dvn, drq = tokens.attn_bwd(plan.desc, qn, kn, vn, att.scale, rq, att.residual_pooling, o, do, lse)
+        dqn, dkn, dvn, drq = tokens.attn_bwd(plan.desc, qn, kn, vn, att.scale, rq, att.residual_pooling, o, do, lse,
+                                             onehot=plan.onehot)
         return _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq)
     P = sv["P"]
     # dP = dO V^T ; dV = P^T dO

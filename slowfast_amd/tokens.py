@@ -328,19 +328,34 @@ def softmax_bwd(d, dp, prob, scale, want_drq):
     return dp, drq
 
 
-def attn_fwd(d, q, k, v, scale, rq, residual):
+def attn_onehot(d, device):
+    """Constant [roundup(Nk, 32), 64] fp16 matrix with ones at columns kh, kH + kw, kH + kW + kt of every non-cls key
+    row (index bookkeeping of the decomposed rel-pos bias, built once per attention shape)."""
+    NkP = (d.Nk + 31) // 32 * 32
+    oh = torch.zeros((NkP, 64), dtype=_f16)
+    pos = torch.arange(d.kT * d.kH * d.kW)
+    kw, kh, kt = pos % d.kW, (pos // d.kW) % d.kH, pos // (d.kW * d.kH)
+    rows = pos + d.cls
+    oh[rows, kh] = 1
+    oh[rows, d.kH + kw] = 1
+    oh[rows, d.kH + d.kW + kt] = 1
+    return oh.to(device)
+
+
+def attn_fwd(d, q, k, v, scale, rq, residual, onehot=None):
     """Fused softmax(scale q k^T + bias) v (+ q): q [B, Nq, heads*D], k/v [B, Nk, heads*D] -> (o, lse)."""
     B, Nq, C = q.shape
     o = torch.empty((B, Nq, C), dtype=_f16, device=q.device)
     lse = torch.empty((B * d.heads * Nq,), dtype=torch.float32, device=q.device)
+    assert (rq is None) == (onehot is None)
     flops = 4.0 * B * d.heads * Nq * d.Nk * d.D
     _lib_call("sf_attn_fwd", byref(d), q.data_ptr(), rows_pitch(q)[2], k.data_ptr(), v.data_ptr(), rows_pitch(k)[2],
-              float(scale), _ptr(rq), int(bool(residual)), o.data_ptr(), C, lse.data_ptr(), _stream(q),
+              float(scale), _ptr(rq), _ptr(onehot), int(bool(residual)), o.data_ptr(), C, lse.data_ptr(), _stream(q),
               work=dict(bytes=2.0 * (2 * q.numel() + 2 * k.numel()), flops=flops))
     return o, lse
 
 
-def attn_bwd(d, q, k, v, scale, rq, residual, o, do, lse):
+def attn_bwd(d, q, k, v, scale, rq, residual, o, do, lse, onehot=None):
     """Backward of attn_fwd: (dq, dk, dv, drq)."""
     B, Nq, C = q.shape
     dq = torch.empty((B, Nq, C), dtype=_f16, device=q.device)
@@ -348,11 +363,13 @@ def attn_bwd(d, q, k, v, scale, rq, residual, o, do, lse):
     dv = torch.empty(k.shape, dtype=_f16, device=q.device)
     delta = torch.empty_like(lse)
     drq = torch.empty(rq.shape, dtype=torch.float32, device=q.device) if rq is not None else None
+    nbytes = _lib_call("sf_attn_bwd_workspace", byref(d))
+    ws = _workspace(q.device, nbytes) if nbytes > 0 else None
     flops = 14.0 * B * d.heads * Nq * d.Nk * d.D
     _lib_call("sf_attn_bwd", byref(d), q.data_ptr(), rows_pitch(q)[2], k.data_ptr(), v.data_ptr(), rows_pitch(k)[2],
-              float(scale), _ptr(rq), int(bool(residual)), o.data_ptr(), do.data_ptr(), rows_pitch(o)[2],
+              float(scale), _ptr(rq), _ptr(onehot), int(bool(residual)), o.data_ptr(), do.data_ptr(), rows_pitch(o)[2],
               lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), C, dk.data_ptr(), dv.data_ptr(), rows_pitch(dk)[2],
-              _ptr(drq), _stream(q), work=dict(bytes=2.0 * (4 * q.numel() + 4 * k.numel()), flops=flops))
+              _ptr(drq), _ptr(ws), nbytes, _stream(q), work=dict(bytes=2.0 * (4 * q.numel() + 4 * k.numel()), flops=flops))
     return dq, dk, dv, drq
 
 

@@ -224,6 +224,19 @@ inline T __shfl_down(T v, int delta) {
     return out;
 }
 
+// wave vote: non-zero when the predicate holds on any lane
+inline int __any(int pred) {
+    hipsim::WaveScratch& w = hipsim::wave();
+    int l = hipsim::lane_id();
+    w.u[l] = pred ? 1ull : 0ull;
+    hipsim::wave_sync();
+    int r = 0;
+    for (int i = 0; i < w.nlanes; ++i) r |= (int)w.u[i];
+    hipsim::wave_sync();
+    return r;
+}
+#define SF_EXP2(x) exp2f(x)
+
 typedef _Float16 hipsim_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 hipsim_f16x4 __attribute__((ext_vector_type(4)));
 typedef float hipsim_f32x4 __attribute__((ext_vector_type(4)));

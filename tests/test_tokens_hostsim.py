@@ -45,6 +45,8 @@ def test_attention_core(sim):
     (2, 2, 32, (2, 6, 6), (2, 3, 3), True, True, True),        # 73 queries (two query tiles), two heads
     (1, 2, 96, (2, 8, 8), (2, 4, 4), True, True, True),        # MViTv2 head dim, 33 keys (two key chunks)
     (1, 1, 64, (1, 5, 9), (1, 5, 9), False, False, False),     # no cls / no rel-pos / no residual
+    (1, 1, 32, (2, 16, 16), (2, 3, 3), True, True, True),      # 513 queries: the dK/dV kernel splits them in two
+    (1, 1, 32, (4, 5, 5), (4, 15, 15), True, True, True),      # kH + kW + kT = 34 > 32: second bias K-step
 ])
 def test_attention_fused(sim, case):
     tc.check_attention_fused(sim, *case)

@@ -212,9 +212,10 @@ def check_attention_fused(device, B, heads, D, q_thw, k_thw, cls=True, rel=True,
         idx = (_rel_index(q_thw[1], k_thw[1], device), _rel_index(q_thw[2], k_thw[2], device),
                _rel_index(q_thw[0], k_thw[0], device))
         rq = tokens.relpos_fwd(d, qd, tabd, idx)
-    of, lse = tokens.attn_fwd(d, qd, kd, vd, scale, rq, residual)
+    oh = tokens.attn_onehot(d, device) if rel else None
+    of, lse = tokens.attn_fwd(d, qd, kd, vd, scale, rq, residual, onehot=oh)
     assert_close("fused attention out", of.float().cpu(), o.detach(), 3 * F16_EPS)
-    dq, dk, dv, drq = tokens.attn_bwd(d, qd, kd, vd, scale, rq, residual, of, dod, lse)
+    dq, dk, dv, drq = tokens.attn_bwd(d, qd, kd, vd, scale, rq, residual, of, dod, lse, onehot=oh)
     assert_close("fused dV", dv.float().cpu(), vr.grad, 4 * F16_EPS)
     assert_close("fused dK", dk.float().cpu(), kr.grad, 6 * F16_EPS)
     if rel:
