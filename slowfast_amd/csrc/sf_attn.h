@@ -221,7 +221,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_fwd_kernel(AttnParams p) {
 // ---------------------------------------------------------------------------------------------
 // backward, query side: dq, drq and delta[q] = sum_d dO (O - residual); same tiling as the forward kernel
 template <int KD>
-__global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(SF_THREADS, 3) void sf_attn_bwd_dq_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 8, DT = D / 16, JT = SF_ATTN_RMAX / 16;
     __shared__ __attribute__((aligned(16))) f16 Ks[32 * KP];
     __shared__ __attribute__((aligned(16))) f16 Vs[32 * KP];
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dq_kernel(AttnParams p
 // backward, key side: workgroup = 64 keys of one (batch, head) x one split of the queries; wave w owns keys
 // 16w .. 16w+15 and walks the split's queries in chunks of 32
 template <int KD>
-__global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(SF_THREADS, 3) void sf_attn_bwd_dkv_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 8, DT = D / 16;
     __shared__ __attribute__((aligned(16))) f16 Qs[32 * KP];
     __shared__ __attribute__((aligned(16))) f16 Os[32 * KP];      // dO rows
@@ -400,26 +400,50 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dkv_kernel(AttnParams 
         dvacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     RowChunk<D, KP> qc, oc;
+    // per-chunk side inputs, prefetched into registers like the Q / dO rows: 8 rq values per thread (row tid >> 3,
+    // columns 8 * (tid & 7) ..), log-sum-exp and delta of row tid (tid < 32)
+    float rqv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lsev = 0.f, deltav = 0.f;
+    const int rr = tid >> 3, j0 = (tid & 7) * 8;
+    auto side_load = [&](int c) {
+        const int qr = c * 32 + rr;
+        const bool on = bias && qr < p.Nq && qr >= p.cls;
+        if (bias) {
+            // unconditional loads from clamped (always valid) addresses, masked afterwards: eight loads in flight
+            const float* src = p.rq + (((int64_t)b * p.Nq + (on ? qr : 0)) * p.heads + head) * p.R;
+            float raw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[e] = src[j0 + e < p.R ? j0 + e : p.R - 1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rqv[e] = (on && j0 + e < p.R) ? raw[e] : 0.f;
+        }
+        if (tid < 32) {
+            const int q2 = c * 32 + tid;
+            lsev = q2 < p.Nq ? p.lse[(int64_t)bh * p.Nq + q2] : 0.f;
+            deltav = q2 < p.Nq ? p.delta[(int64_t)bh * p.Nq + q2] : 0.f;
+        }
+    };
     if (c0 < c1) {
         qc.load(qbase, p.ldq, c0 * 32, p.Nq, tid);
         oc.load(dobase, p.ldo, c0 * 32, p.Nq, tid);
+        side_load(c0);
     }
     for (int c = c0; c < c1; ++c) {
         __syncthreads();
         qc.store(Qs, tid);
         oc.store(Os, tid);
         if (tid < 32) {
-            const int qr = c * 32 + tid;
-            s_lse[tid] = qr < p.Nq ? p.lse[(int64_t)bh * p.Nq + qr] : 0.f;
-            s_delta[tid] = qr < p.Nq ? p.delta[(int64_t)bh * p.Nq + qr] : 0.f;
+            s_lse[tid] = lsev;
+            s_delta[tid] = deltav;
         }
         if (bias) {
-            // 32 rows x 64 columns, 8 per thread
-            const int rr = tid >> 3, j0 = (tid & 7) * 8;
-            const int qr = c * 32 + rr;
-            const bool on = qr < p.Nq && qr >= p.cls && j0 < p.R;
             f16x8 hi, lo;
-            attn_split8(on ? p.rq + (((int64_t)b * p.Nq + qr) * p.heads + head) * p.R + j0 : nullptr, p.R - j0, on, hi, lo);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = rqv[e] * SF_LOG2E;
+                const f16 h = (f16)v;
+                hi[e] = h;
+                lo[e] = (f16)(v - (float)h);
+            }
             st16(Rh + rr * SF_ATTN_OHP + j0, hi);
             st16(Rl + rr * SF_ATTN_OHP + j0, lo);
         }
@@ -427,6 +451,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_bwd_dkv_kernel(AttnParams 
         if (c + 1 < c1) {
             qc.load(qbase, p.ldq, (c + 1) * 32, p.Nq, tid);
             oc.load(dobase, p.ldo, (c + 1) * 32, p.Nq, tid);
+            side_load(c + 1);
         }
         f16x8 pf, dsf;
 #pragma unroll
