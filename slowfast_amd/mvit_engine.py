@@ -121,10 +121,10 @@ class AttentionPlan:
             self.idx = (_rel_index(qh, kh, device), _rel_index(qw, kw, device), _rel_index(qt, kt, device))
 
 
-# Measured on MI355X (profiles/r1_visit12_bench_mvit_{fused,unfused}.json): the first version of the fused kernels is
-# VALU-bound (bias lookups, expf, per-chunk rescale) and its dK/dV kernel under-fills the GPU when Nk is small:
-# 414 vs 445 clips/s.  The unfused chain therefore stays the default until the fused path wins; SF_ATTN_FUSED=1 selects it.
-_FUSED_DEFAULT = "0"
+# Measured on MI355X: the first version of the fused kernels (bias lookups, expf, per-chunk rescale, no query split in
+# the dK/dV kernel) lost to the unfused chain, 414 vs 445 clips/s (profiles/r1_visit12_bench_mvit_*.json); with the
+# bias on the matrix cores, exp2, lazy rescale and the query split it wins, 488 vs 439 (profiles/r1_visit13_*).
+_FUSED_DEFAULT = "1"
 
 
 def _fused_attention(plan):

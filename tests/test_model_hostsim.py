@@ -17,7 +17,9 @@ def test_engine_wiring_matches_oracle(sim, name):
 def test_mvit_engine_matches_oracle(sim):
     """4-block MViTv2 miniature (q pooling, dimension change, k/v pooling, relative positions, residual pooling,
     cls token) through every token-space kernel, forward and backward."""
-    mc.check_engine("mvit_tiny", sim, tol_logits=1e-2, tol_loss=2e-3, tol_gnorm=3e-3, tol_param=0.1, tol_global=2e-2)
+    # tol_param: the worst parameter is attn.norm_k.bias, whose true gradient vanishes identically (a constant added to
+    # every key shifts all scores of a query equally): its computed value is pure round-off of the dK column sums
+    mc.check_engine("mvit_tiny", sim, tol_logits=1e-2, tol_loss=2e-3, tol_gnorm=3e-3, tol_param=0.2, tol_global=2e-2)
 
 
 def test_x3d_engine_matches_oracle(sim):
