@@ -434,7 +434,7 @@ extern "C" int sf_bn_finalize(float* part, int32_t nblk, int32_t C, int32_t Crea
     p.part = part; p.nblk = nblk; p.C = C; p.Creal = Creal; p.count = count; p.gamma = gamma; p.beta = beta;
     p.running_mean = running_mean; p.running_var = running_var; p.momentum = momentum; p.eps = eps;
     p.scale = scale; p.shift = shift; p.save_mean = save_mean; p.save_rstd = save_rstd;
-    hipLaunchKernelGGL(sf_bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sf_bn_finalize_kernel, dim3(cdiv(C, SF_FIN_CH)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("bn_finalize");
 }
 
@@ -485,7 +485,7 @@ extern "C" int sf_bn_bwd_finalize(float* part, int32_t nblk, int32_t C, int32_t 
     REQUIRE(Creal > 0 && Creal <= C, "sf_bn_bwd_finalize: Creal must be in (0, C]");
     p.part = part; p.nblk = nblk; p.C = C; p.Creal = Creal; p.count = count; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
     p.inv_loss_scale = inv_loss_scale; p.dgamma = dgamma; p.dbeta = dbeta; p.accumulate = accumulate; p.coef = coef;
-    hipLaunchKernelGGL(sf_bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sf_bn_bwd_finalize_kernel, dim3(cdiv(C, SF_FIN_CH)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("bn_bwd_finalize");
 }
 
@@ -771,7 +771,7 @@ extern "C" int sf_colsum_finalize(float* part, int32_t nblk, int32_t C, int32_t 
     p.row_stride = fold_partials(part, nblk, C, (hipStream_t)stream);
     p.part = part; p.nblk = nblk; p.C = C; p.fold = fold; p.out0 = out0; p.out1 = out1; p.scale = scale;
     p.accumulate = accumulate;
-    hipLaunchKernelGGL(sf_colsum_finalize_kernel, dim3(cdiv(fold, 32)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sf_colsum_finalize_kernel, dim3(cdiv(fold, SF_FIN_CH)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("colsum_finalize");
 }
 

@@ -58,24 +58,45 @@ __global__ __launch_bounds__(SF_THREADS) void sf_part_fold_kernel(float* part, i
     base[0] = (float)((a0 + a1) + (a2 + a3));
 }
 
-// sums of rows seg, seg+8, ... (< nrows) of a [nrows][2][C] table whose rows are `stride` table-rows apart
+// Finalize kernels: SF_FIN_CH channels per 256-thread block x SF_FIN_SEG row segments per channel.  A thread walks at
+// most nrows / 32 (<= 8 after sf_part_fold) table rows -- the kernels are pure load-latency chains, so short chains
+// matter more than coalescing here -- and an LDS tree folds the segments in a fixed order.
+#define SF_FIN_SEG 32
+#define SF_FIN_CH 8
+// sums of rows seg, seg+SEG, ... (< nrows) of a [nrows][2][C] table whose rows are `stride` table-rows apart
 __device__ __forceinline__ void strided_col_sums(const float* part, int nrows, int stride, int C, int c, int seg,
                                                  double& s, double& q) {
     double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
     const int64_t rs = (int64_t)stride * 2 * C;
     int b = seg;
-    for (; b + 8 < nrows; b += 16) {
+    for (; b + SF_FIN_SEG < nrows; b += 2 * SF_FIN_SEG) {
         const float* p0 = part + (int64_t)b * rs + c;
-        const float* p1 = p0 + 8 * rs;
+        const float* p1 = p0 + SF_FIN_SEG * rs;
         const float u0 = p0[0], w0 = p0[C], u1 = p1[0], w1 = p1[C];
         s0 += (double)u0; q0 += (double)w0; s1 += (double)u1; q1 += (double)w1;
     }
-    for (; b < nrows; b += 8) {
+    for (; b < nrows; b += SF_FIN_SEG) {
         const float* p0 = part + (int64_t)b * rs + c;
         s0 += (double)p0[0]; q0 += (double)p0[C];
     }
     s = s0 + s1;
     q = q0 + q1;
+}
+// folds the SF_FIN_SEG per-segment sums of every channel; all threads call it, the totals come back on every thread
+__device__ __forceinline__ void fin_fold(double (*s_s)[SF_FIN_CH], double (*s_q)[SF_FIN_CH], int seg, int cx, double& s,
+                                         double& q) {
+    s_s[seg][cx] = s;
+    s_q[seg][cx] = q;
+    __syncthreads();
+    for (int h = SF_FIN_SEG / 2; h >= 1; h >>= 1) {
+        if (seg < h) {
+            s_s[seg][cx] += s_s[seg + h][cx];
+            s_q[seg][cx] += s_q[seg + h][cx];
+        }
+        __syncthreads();
+    }
+    s = s_s[0][cx];
+    q = s_q[0][cx];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -100,16 +121,13 @@ struct BnFinalizeParams {
 };
 
 __global__ __launch_bounds__(SF_THREADS) void sf_bn_finalize_kernel(BnFinalizeParams p) {
-    // 32 channels per block, 8 partial-row segments per channel
-    __shared__ double s_s[8][32];
-    __shared__ double s_q[8][32];
-    const int cx = threadIdx.x & 31, seg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+    __shared__ double s_s[SF_FIN_SEG][SF_FIN_CH];
+    __shared__ double s_q[SF_FIN_SEG][SF_FIN_CH];
+    const int cx = threadIdx.x % SF_FIN_CH, seg = threadIdx.x / SF_FIN_CH;
+    const int c = blockIdx.x * SF_FIN_CH + cx;
     double s = 0.0, q = 0.0;
     if (c < p.C && p.nblk > 0) strided_col_sums(p.part, p.nblk, p.row_stride, p.C, c, seg, s, q);
-    s_s[seg][cx] = s;
-    s_q[seg][cx] = q;
-    __syncthreads();
+    fin_fold(s_s, s_q, seg, cx, s, q);
     if (seg == 0 && c < p.C && c >= p.Creal) {
         p.scale[c] = 0.f;
         p.shift[c] = 0.f;
@@ -118,7 +136,6 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_finalize_kernel(BnFinalizePa
     } else if (seg == 0 && c < p.C) {
         float mean, var;
         if (p.nblk > 0) {
-            for (int k = 1; k < 8; ++k) { s += s_s[k][cx]; q += s_q[k][cx]; }
             double m = s / (double)p.count;
             double v = q / (double)p.count - m * m;
             if (v < 0.0) v = 0.0;
@@ -292,21 +309,18 @@ struct BnBwdFinalizeParams {
 };
 
 __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_finalize_kernel(BnBwdFinalizeParams p) {
-    __shared__ double s_s[8][32];
-    __shared__ double s_q[8][32];
-    const int cx = threadIdx.x & 31, seg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+    __shared__ double s_s[SF_FIN_SEG][SF_FIN_CH];
+    __shared__ double s_q[SF_FIN_SEG][SF_FIN_CH];
+    const int cx = threadIdx.x % SF_FIN_CH, seg = threadIdx.x / SF_FIN_CH;
+    const int c = blockIdx.x * SF_FIN_CH + cx;
     double s = 0.0, q = 0.0;
     if (c < p.C) strided_col_sums(p.part, p.nblk, p.row_stride, p.C, c, seg, s, q);
-    s_s[seg][cx] = s;
-    s_q[seg][cx] = q;
-    __syncthreads();
+    fin_fold(s_s, s_q, seg, cx, s, q);
     if (seg == 0 && c < p.C && c >= p.Creal) {
         p.coef[c] = 0.f;
         p.coef[p.C + c] = 0.f;
         p.coef[2 * p.C + c] = 0.f;
     } else if (seg == 0 && c < p.C) {
-        for (int k = 1; k < 8; ++k) { s += s_s[k][cx]; q += s_q[k][cx]; }
         const double mean = p.mean[c], rstd = p.rstd[c], gam = p.gamma[c];
         const double dbeta = s;                       // sum g
         const double dgamma = rstd * (q - mean * s);  // sum g*xhat

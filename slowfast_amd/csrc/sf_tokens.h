@@ -219,10 +219,10 @@ struct ColFinalizeParams {
     int accumulate;
 };
 __global__ __launch_bounds__(SF_THREADS) void sf_colsum_finalize_kernel(ColFinalizeParams p) {
-    __shared__ double s_s[8][32];
-    __shared__ double s_q[8][32];
-    const int cx = threadIdx.x & 31, seg = threadIdx.x >> 5;
-    const int co = blockIdx.x * 32 + cx;
+    __shared__ double s_s[SF_FIN_SEG][SF_FIN_CH];
+    __shared__ double s_q[SF_FIN_SEG][SF_FIN_CH];
+    const int cx = threadIdx.x % SF_FIN_CH, seg = threadIdx.x / SF_FIN_CH;
+    const int co = blockIdx.x * SF_FIN_CH + cx;
     double s = 0.0, q = 0.0;
     if (co < p.fold) {
         for (int c = co; c < p.C; c += p.fold) {
@@ -232,11 +232,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_colsum_finalize_kernel(ColFinal
             q += b;
         }
     }
-    s_s[seg][cx] = s;
-    s_q[seg][cx] = q;
-    __syncthreads();
+    fin_fold(s_s, s_q, seg, cx, s, q);
     if (seg == 0 && co < p.fold) {
-        for (int k = 1; k < 8; ++k) { s += s_s[k][cx]; q += s_q[k][cx]; }
         const float v0 = (float)(s * p.scale), v1 = (float)(q * p.scale);
         if (p.out0) p.out0[co] = p.accumulate ? p.out0[co] + v0 : v0;
         if (p.out1) p.out1[co] = p.accumulate ? p.out1[co] + v1 : v1;

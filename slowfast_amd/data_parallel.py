@@ -17,10 +17,12 @@ from . import engine
 
 
 class GradReducer:
-    def __init__(self, model, bucket_mb=48, process_group=None, comm_dtype=None):
+    def __init__(self, model, bucket_mb=48, process_group=None, comm_dtype=None, force_collectives=False):
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # world 1 normally skips the collectives; tests force them to drive the RCCL calls on a single GPU
+        self.collectives = self.world > 1 or (force_collectives and dist.is_available() and dist.is_initialized())
         self.comm_dtype = comm_dtype            # torch.float16 mirrors MODEL.FP16_ALLREDUCE
         params = [p for p in model.parameters() if p.requires_grad]
         self.params = params[::-1]              # reverse registration order ~ order in which backward finishes them
@@ -89,7 +91,7 @@ class GradReducer:
                 self._launch(bi)
 
     def _launch(self, bi):
-        if self.world == 1 or self.capturing:
+        if not self.collectives or self.capturing:
             return
         s, e, _ = self.buckets[bi]
         view = self.flat[s:e]
@@ -103,7 +105,7 @@ class GradReducer:
 
     def finish(self, loss_scale=1.0):
         """Wait for outstanding collectives; gradients become mean over ranks of the unscaled gradients."""
-        if self.world > 1:
+        if self.collectives:
             for bi, n in enumerate(self._pending):
                 if n > 0:                         # parameters that got no gradient this iteration
                     self._pending[bi] = 0
