@@ -1057,6 +1057,27 @@ static int fill_attn(AttnParams& p, const sf_attn_desc* d, const char* who) {
 static int64_t attn_ws_bytes(const AttnParams& p, const sf_attn_desc* d) {
     return p.qsplits > 1 ? (int64_t)p.qsplits * 2 * d->B * d->Nk * d->heads * d->D * 4 : 0;
 }
+// two 16-query column tiles per wave (halves the LDS operand traffic per MFMA) once there are enough workgroups;
+// SF_ATTN_QT=1|2 forces either form
+static bool attn_two_tiles(const sf_attn_desc* d) {
+    static const int qt_env = getenv("SF_ATTN_QT") ? atoi(getenv("SF_ATTN_QT")) : 0;
+    return qt_env ? qt_env == 2 : (int64_t)d->B * d->heads * cdiv(d->Nq, 128) >= 1024;
+}
+#define SF_ATTN_LAUNCH_Q(KERNEL, D_, two, grid, st, p)                                                     \
+    do {                                                                                                   \
+        const int kd_ = (D_) / 32;                                                                         \
+        if (two) {                                                                                         \
+            if (kd_ == 1) hipLaunchKernelGGL((KERNEL<1, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p);      \
+            else if (kd_ == 2) hipLaunchKernelGGL((KERNEL<2, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
+            else if (kd_ == 3) hipLaunchKernelGGL((KERNEL<3, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
+            else hipLaunchKernelGGL((KERNEL<4, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p);               \
+        } else {                                                                                           \
+            if (kd_ == 1) hipLaunchKernelGGL((KERNEL<1, 1>), dim3(grid), dim3(SF_THREADS), 0, st, p);      \
+            else if (kd_ == 2) hipLaunchKernelGGL((KERNEL<2, 1>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
+            else if (kd_ == 3) hipLaunchKernelGGL((KERNEL<3, 1>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
+            else hipLaunchKernelGGL((KERNEL<4, 1>), dim3(grid), dim3(SF_THREADS), 0, st, p);               \
+        }                                                                                                  \
+    } while (0)
 #define SF_ATTN_LAUNCH(KERNEL, D_, grid, st, p)                                                     \
     do {                                                                                            \
         switch ((D_) / 32) {                                                                        \
@@ -1080,7 +1101,9 @@ extern "C" int sf_attn_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     p.out = (f16*)o; p.ldout = ldo; p.rq = rq; p.oh = (const f16*)onehot; p.lse = lse;
     p.scale = scale; p.scale2 = scale * SF_LOG2E; p.residual = residual;
     if (!rq) p.R = 0;
-    SF_ATTN_LAUNCH(sf_attn_fwd_kernel, d->D, d->B * d->heads * p.qtiles, (hipStream_t)stream, p);
+    const bool qt2 = attn_two_tiles(d);
+    if (qt2) p.qtiles = cdiv(d->Nq, 128);
+    SF_ATTN_LAUNCH_Q(sf_attn_fwd_kernel, d->D, qt2, d->B * d->heads * p.qtiles, (hipStream_t)stream, p);
     return check_launch("attn_fwd");
 }
 
@@ -1112,9 +1135,27 @@ extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     p.scale = scale; p.scale2 = scale * SF_LOG2E; p.residual = residual; p.part = (float*)workspace;
     if (!rq) p.R = 0;
     hipStream_t st = (hipStream_t)stream;
-    SF_ATTN_LAUNCH(sf_attn_bwd_dq_kernel, d->D, d->B * d->heads * p.qtiles, st, p);       // also writes delta
+    {
+        const bool qt2 = attn_two_tiles(d);
+        const int qtiles = qt2 ? cdiv(d->Nq, 128) : p.qtiles;
+        AttnParams pq = p;
+        pq.qtiles = qtiles;
+        SF_ATTN_LAUNCH_Q(sf_attn_bwd_dq_kernel, d->D, qt2, d->B * d->heads * qtiles, st, pq);   // also writes delta
+    }
     if (check_launch("attn_bwd_dq")) return -1;
-    SF_ATTN_LAUNCH(sf_attn_bwd_dkv_kernel, d->D, d->B * d->heads * p.ktiles * p.qsplits, st, p);
+    {
+        // waves per SIMD the key-side kernel is compiled for: 3 (168 VGPRs, a few spilled address registers) or 2
+        static const int occ = getenv("SF_ATTN_DKV_OCC") ? atoi(getenv("SF_ATTN_DKV_OCC")) : 3;
+        const int grid = d->B * d->heads * p.ktiles * p.qsplits;
+        const int kd = d->D / 32;
+#define SF_DKV(KD_)                                                                                              \
+    do {                                                                                                         \
+        if (occ == 2) hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
+        else hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 3>), dim3(grid), dim3(SF_THREADS), 0, st, p);      \
+    } while (0)
+        if (kd == 1) SF_DKV(1); else if (kd == 2) SF_DKV(2); else if (kd == 3) SF_DKV(3); else SF_DKV(4);
+#undef SF_DKV
+    }
     if (check_launch("attn_bwd_dkv")) return -1;
     if (p.qsplits > 1) {
         AttnReduceParams r;

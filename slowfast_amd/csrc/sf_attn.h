@@ -29,7 +29,7 @@
 #include "sf_common.h"
 #include "sf_igemm.h"
 
-#define SF_ATTN_RMAX 64            // kH + kW + kT of the key grid (MViTv2-S: 7+7+8 .. 14+14+8), columns of OH
+#define SF_ATTN_RMAX 48            // max kH + kW + kT of the key grid (MViTv2-S: 7+7+8 .. 14+14+8); OH has 64 columns
 #define SF_ATTN_OHP 72             // LDS pitch of an OH / rq row (64 + 8: conflict-free ds_read_b128)
 #define SF_LOG2E 1.4426950408889634f
 #define SF_LN2 0.6931471805599453f
@@ -97,9 +97,11 @@ __device__ __forceinline__ void attn_split8(const float* src, int n, bool on, f1
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward: workgroup = 64 queries of one (batch, head); wave w owns queries 16w .. 16w+15
-template <int KD>
-__global__ __launch_bounds__(SF_THREADS) void sf_attn_fwd_kernel(AttnParams p) {
+// forward: workgroup = 64*QT queries of one (batch, head); wave w owns QT column tiles of 16 queries.  With QT = 2
+// every K / V / OH fragment read from LDS feeds two MFMAs (these kernels are LDS-bandwidth bound: 1 KB of operand per
+// 16x16x32 MFMA at QT = 1), and the K/V chunks are re-staged half as often.
+template <int KD, int QT>
+__global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 8, DT = D / 16;
     __shared__ __attribute__((aligned(16))) f16 Ks[32 * KP];
     __shared__ __attribute__((aligned(16))) f16 Vs[32 * KP];
@@ -109,32 +111,38 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_fwd_kernel(AttnParams p) {
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = (int)(bid / (uint32_t)p.qtiles), qt = (int)(bid % (uint32_t)p.qtiles);
     const int b = bh / p.heads, head = bh % p.heads;
-    const int qrow = qt * 64 + wave * 16 + pl;
-    const bool qok = qrow < p.Nq;
-    const int qc = qok ? qrow : p.Nq - 1;
-    const f16* qptr = p.q + ((int64_t)b * p.Nq + qc) * p.ldq + head * D;
-    f16x8 qf[KD];
-#pragma unroll
-    for (int s = 0; s < KD; ++s) qf[s] = ld16(qptr + 32 * s + 8 * g);
     const bool bias = p.R > 0, bias2 = p.R > 32;
-    f16x8 rqh[2], rql[2];
-    {
+    int qrow[QT];
+    const f16* qptr[QT];
+    f16x8 qf[QT][KD], rqh[QT][2], rql[QT][2];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        qrow[u] = qt * 64 * QT + (wave * QT + u) * 16 + pl;
+        const int qc = qrow[u] < p.Nq ? qrow[u] : p.Nq - 1;
+        qptr[u] = p.q + ((int64_t)b * p.Nq + qc) * p.ldq + head * D;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) qf[u][s] = ld16(qptr[u] + 32 * s + 8 * g);
         const bool on = bias && qc >= p.cls;
         const float* rqrow = p.rq + (((int64_t)b * p.Nq + qc) * p.heads + head) * p.R;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int j0 = 32 * ks + 8 * g;
-            attn_split8(on ? rqrow + (j0 < p.R ? j0 : 0) : nullptr, p.R - j0, on && j0 < p.R, rqh[ks], rql[ks]);
+            attn_split8(on ? rqrow + (j0 < p.R ? j0 : 0) : nullptr, p.R - j0, on && j0 < p.R, rqh[u][ks], rql[u][ks]);
         }
     }
     const f16* kbase = p.k + (int64_t)b * p.Nk * p.ldk + head * D;
     const f16* vbase = p.v + (int64_t)b * p.Nk * p.ldk + head * D;
     const int nch = (p.Nk + 31) / 32;
 
-    float m = -INFINITY, l = 0.f;
-    f32x4 oacc[DT];
+    float m[QT], l[QT];
+    f32x4 oacc[QT][DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < QT; ++u) {
+        m[u] = -INFINITY;
+        l[u] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     RowChunk<D, KP> kc, vc;
     f16x8 ohr = zero8();
     kc.load(kbase, p.ldk, 0, p.Nk, tid);
@@ -151,77 +159,107 @@ __global__ __launch_bounds__(SF_THREADS) void sf_attn_fwd_kernel(AttnParams p) {
             vc.load(vbase, p.ldk, (c + 1) * 32, p.Nk, tid);
             if (bias) ohr = ld16(p.oh + ((int64_t)(c + 1) * 32 * 64) + (int64_t)tid * 8);
         }
-        float x[8];
+        float x[QT][8];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
+            f32x4 st[QT], bt[QT];
 #pragma unroll
-            for (int s = 0; s < KD; ++s)
-                st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Ks + (16 * t + pl) * KP + 32 * s + 8 * g), qf[s], st, 0, 0, 0);
+            for (int u = 0; u < QT; ++u) {
+                st[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                bt[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                const f16x8 kf = ld16(Ks + (16 * t + pl) * KP + 32 * s + 8 * g);
+#pragma unroll
+                for (int u = 0; u < QT; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][s], st[u], 0, 0, 0);
+            }
             if (bias) {
                 const f16x8 a0 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
-                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[0], bt, 0, 0, 0);
-                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[0], bt, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < QT; ++u) {
+                    bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[u][0], bt[u], 0, 0, 0);
+                    bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[u][0], bt[u], 0, 0, 0);
+                }
                 if (bias2) {
                     const f16x8 a1 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
-                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[1], bt, 0, 0, 0);
-                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[1], bt, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < QT; ++u) {
+                        bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[u][1], bt[u], 0, 0, 0);
+                        bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[u][1], bt[u], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[4 * t + r] = st[r] * p.scale2 + bt[r];
+            for (int u = 0; u < QT; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[u][4 * t + r] = st[u][r] * p.scale2 + bt[u][r];
         }
         if (c == nch - 1) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (c * 32 + 16 * (i >> 2) + 4 * g + (i & 3) >= p.Nk) x[i] = -INFINITY;
-        }
-        float cmax = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const bool grow = cmax > m + 8.f;          // also true on the first chunk (m = -inf)
-        if (__any(grow)) {
-            const float alpha = grow ? SF_EXP2(m - cmax) : 1.f;
-            if (grow) m = cmax;
-            l *= alpha;
+                if (c * 32 + 16 * (i >> 2) + 4 * g + (i & 3) >= p.Nk) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) oacc[dt] *= alpha;
+                    for (int u = 0; u < QT; ++u) x[u][i] = -INFINITY;
+                }
         }
-        f16x8 pf;
+        f16x8 pf[QT];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float pv = SF_EXP2(x[i] - m);
-            l += pv;
-            pf[i] = (f16)pv;
+        for (int u = 0; u < QT; ++u) {
+            float cmax = fmaxf(fmaxf(fmaxf(x[u][0], x[u][1]), fmaxf(x[u][2], x[u][3])),
+                               fmaxf(fmaxf(x[u][4], x[u][5]), fmaxf(x[u][6], x[u][7])));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            const bool grow = cmax > m[u] + 8.f;          // also true on the first chunk (m = -inf)
+            if (__any(grow)) {
+                const float alpha = grow ? SF_EXP2(m[u] - cmax) : 1.f;
+                if (grow) m[u] = cmax;
+                l[u] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) oacc[u][dt] *= alpha;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float pv = SF_EXP2(x[u][i] - m[u]);
+                l[u] += pv;
+                pf[u][i] = (f16)pv;
+            }
         }
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_tr_frag(Vs, KP, dt * 16, pl, g), pf, oacc[dt], 0, 0, 0);
-    }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const float inv = 1.f / l;
-    if (qok) {
-        const bool res = p.residual && qrow >= p.cls;
-        f16* orow = p.out + ((int64_t)b * p.Nq + qrow) * p.ldout + head * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const int d0 = dt * 16 + 4 * g;
-            f16x4 rv = {(f16)0, (f16)0, (f16)0, (f16)0};
-            if (res) rv = *reinterpret_cast<const f16x4*>(qptr + d0);
-            f16x4 ov;
+            const f16x8 vt = attn_tr_frag(Vs, KP, dt * 16, pl, g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (f16)(oacc[dt][r] * inv + (float)rv[r]);
-            *reinterpret_cast<f16x4*>(orow + d0) = ov;
+            for (int u = 0; u < QT; ++u) oacc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pf[u], oacc[u][dt], 0, 0, 0);
         }
-        if (g == 0) p.lse[(int64_t)bh * p.Nq + qrow] = m + log2f(l);
+    }
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        float lt = l[u];
+        lt += __shfl_xor(lt, 16);
+        lt += __shfl_xor(lt, 32);
+        const float inv = 1.f / lt;
+        if (qrow[u] < p.Nq) {
+            const bool res = p.residual && qrow[u] >= p.cls;
+            f16* orow = p.out + ((int64_t)b * p.Nq + qrow[u]) * p.ldout + head * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d0 = dt * 16 + 4 * g;
+                f16x4 rv = {(f16)0, (f16)0, (f16)0, (f16)0};
+                if (res) rv = *reinterpret_cast<const f16x4*>(qptr[u] + d0);
+                f16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (f16)(oacc[u][dt][r] * inv + (float)rv[r]);
+                *reinterpret_cast<f16x4*>(orow + d0) = ov;
+            }
+            if (g == 0) p.lse[(int64_t)bh * p.Nq + qrow[u]] = m[u] + log2f(lt);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward, query side: dq, drq and delta[q] = sum_d dO (O - residual); same tiling as the forward kernel
-template <int KD>
-__global__ __launch_bounds__(SF_THREADS, 3) void sf_attn_bwd_dq_kernel(AttnParams p) {
+template <int KD, int QT>
+__global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 8, DT = D / 16, JT = SF_ATTN_RMAX / 16;
     __shared__ __attribute__((aligned(16))) f16 Ks[32 * KP];
     __shared__ __attribute__((aligned(16))) f16 Vs[32 * KP];
@@ -231,47 +269,55 @@ __global__ __launch_bounds__(SF_THREADS, 3) void sf_attn_bwd_dq_kernel(AttnParam
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = (int)(bid / (uint32_t)p.qtiles), qt = (int)(bid % (uint32_t)p.qtiles);
     const int b = bh / p.heads, head = bh % p.heads;
-    const int qrow = qt * 64 + wave * 16 + pl;
-    const bool qok = qrow < p.Nq;
-    const int qc = qok ? qrow : p.Nq - 1;
-    const bool res = p.residual && qc >= p.cls;
-    const f16* qptr = p.q + ((int64_t)b * p.Nq + qc) * p.ldq + head * D;
-    const f16* doptr = p.dout + ((int64_t)b * p.Nq + qc) * p.ldo + head * D;
-    const f16* optr = p.o + ((int64_t)b * p.Nq + qc) * p.ldo + head * D;
-    f16x8 qf[KD], dof[KD];
-    float dl = 0.f;
-#pragma unroll
-    for (int s = 0; s < KD; ++s) {
-        qf[s] = ld16(qptr + 32 * s + 8 * g);
-        dof[s] = ld16(doptr + 32 * s + 8 * g);
-        const f16x8 ov = ld16(optr + 32 * s + 8 * g);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += (float)dof[s][e] * ((float)ov[e] - (res ? (float)qf[s][e] : 0.f));
-    }
-    dl += __shfl_xor(dl, 16);
-    dl += __shfl_xor(dl, 32);
-    const float lse = p.lse[(int64_t)bh * p.Nq + qc];
-    if (qok && g == 0) p.delta[(int64_t)bh * p.Nq + qrow] = dl;
     const bool bias = p.R > 0, bias2 = p.R > 32;
-    f16x8 rqh[2], rql[2];
-    {
+    int qrow[QT];
+    const f16* doptr[QT];
+    bool res[QT];
+    f16x8 qf[QT][KD], dof[QT][KD], rqh[QT][2], rql[QT][2];
+    float dl[QT], lse[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        qrow[u] = qt * 64 * QT + (wave * QT + u) * 16 + pl;
+        const bool qok = qrow[u] < p.Nq;
+        const int qc = qok ? qrow[u] : p.Nq - 1;
+        res[u] = p.residual && qc >= p.cls;
+        const f16* qptr = p.q + ((int64_t)b * p.Nq + qc) * p.ldq + head * D;
+        doptr[u] = p.dout + ((int64_t)b * p.Nq + qc) * p.ldo + head * D;
+        const f16* optr = p.o + ((int64_t)b * p.Nq + qc) * p.ldo + head * D;
+        float d = 0.f;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            qf[u][s] = ld16(qptr + 32 * s + 8 * g);
+            dof[u][s] = ld16(doptr[u] + 32 * s + 8 * g);
+            const f16x8 ov = ld16(optr + 32 * s + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += (float)dof[u][s][e] * ((float)ov[e] - (res[u] ? (float)qf[u][s][e] : 0.f));
+        }
+        d += __shfl_xor(d, 16);
+        d += __shfl_xor(d, 32);
+        dl[u] = d;
+        lse[u] = p.lse[(int64_t)bh * p.Nq + qc];
+        if (qok && g == 0) p.delta[(int64_t)bh * p.Nq + qrow[u]] = d;
         const bool on = bias && qc >= p.cls;
         const float* rqrow = p.rq + (((int64_t)b * p.Nq + qc) * p.heads + head) * p.R;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int j0 = 32 * ks + 8 * g;
-            attn_split8(on ? rqrow + (j0 < p.R ? j0 : 0) : nullptr, p.R - j0, on && j0 < p.R, rqh[ks], rql[ks]);
+            attn_split8(on ? rqrow + (j0 < p.R ? j0 : 0) : nullptr, p.R - j0, on && j0 < p.R, rqh[u][ks], rql[u][ks]);
         }
     }
     const f16* kbase = p.k + (int64_t)b * p.Nk * p.ldk + head * D;
     const f16* vbase = p.v + (int64_t)b * p.Nk * p.ldk + head * D;
     const int nch = (p.Nk + 31) / 32;
 
-    f32x4 dqacc[DT], drqacc[JT];
+    f32x4 dqacc[QT][DT], drqacc[QT][JT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) dqacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < QT; ++u) {
 #pragma unroll
-    for (int jt = 0; jt < JT; ++jt) drqacc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) dqacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) drqacc[u][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     RowChunk<D, KP> kc, vc;
     f16x8 ohr = zero8();
     kc.load(kbase, p.ldk, 0, p.Nk, tid);
@@ -288,64 +334,92 @@ __global__ __launch_bounds__(SF_THREADS, 3) void sf_attn_bwd_dq_kernel(AttnParam
             vc.load(vbase, p.ldk, (c + 1) * 32, p.Nk, tid);
             if (bias) ohr = ld16(p.oh + ((int64_t)(c + 1) * 32 * 64) + (int64_t)tid * 8);
         }
-        f16x8 dsf;
+        f16x8 dsf[QT];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            f32x4 st[QT], bt[QT], dp[QT];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) {
+                st[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                bt[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dp[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
-                st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Ks + (16 * t + pl) * KP + 32 * s + 8 * g), qf[s], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Vs + (16 * t + pl) * KP + 32 * s + 8 * g), dof[s], dp, 0, 0, 0);
+                const f16x8 kf = ld16(Ks + (16 * t + pl) * KP + 32 * s + 8 * g);
+                const f16x8 vf = ld16(Vs + (16 * t + pl) * KP + 32 * s + 8 * g);
+#pragma unroll
+                for (int u = 0; u < QT; ++u) {
+                    st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][s], st[u], 0, 0, 0);
+                    dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof[u][s], dp[u], 0, 0, 0);
+                }
             }
             if (bias) {
                 const f16x8 a0 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
-                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[0], bt, 0, 0, 0);
-                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[0], bt, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < QT; ++u) {
+                    bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[u][0], bt[u], 0, 0, 0);
+                    bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[u][0], bt[u], 0, 0, 0);
+                }
                 if (bias2) {
                     const f16x8 a1 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
-                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[1], bt, 0, 0, 0);
-                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[1], bt, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < QT; ++u) {
+                        bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[u][1], bt[u], 0, 0, 0);
+                        bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[u][1], bt[u], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // keys beyond Nk: K, V rows are zero -> x = 0, dp = 0; their p must not reach dq / drq
                 const bool kin = c * 32 + 16 * t + 4 * g + r < p.Nk;
-                const float pv = kin ? SF_EXP2(st[r] * p.scale2 + bt[r] - lse) : 0.f;
-                dsf[4 * t + r] = (f16)(pv * (dp[r] - dl));
+#pragma unroll
+                for (int u = 0; u < QT; ++u) {
+                    const float pv = kin ? SF_EXP2(st[u][r] * p.scale2 + bt[u][r] - lse[u]) : 0.f;
+                    dsf[u][4 * t + r] = (f16)(pv * (dp[u][r] - dl[u]));
+                }
             }
         }
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_tr_frag(Ks, KP, dt * 16, pl, g), dsf, dqacc[dt], 0, 0, 0);
+        for (int dt = 0; dt < DT; ++dt) {
+            const f16x8 kt_ = attn_tr_frag(Ks, KP, dt * 16, pl, g);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) dqacc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kt_, dsf[u], dqacc[u][dt], 0, 0, 0);
+        }
         if (bias) {
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
-                if (jt * 16 < p.R)
-                    drqacc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_tr_frag(OHs, SF_ATTN_OHP, jt * 16, pl, g), dsf,
-                                                                        drqacc[jt], 0, 0, 0);
+                if (jt * 16 < p.R) {
+                    const f16x8 oht = attn_tr_frag(OHs, SF_ATTN_OHP, jt * 16, pl, g);
+#pragma unroll
+                    for (int u = 0; u < QT; ++u)
+                        drqacc[u][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oht, dsf[u], drqacc[u][jt], 0, 0, 0);
+                }
         }
     }
-    if (qok) {
-        f16* dqrow = p.out + ((int64_t)b * p.Nq + qrow) * p.ldout + head * D;
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        if (qrow[u] >= p.Nq) continue;
+        f16* dqrow = p.out + ((int64_t)b * p.Nq + qrow[u]) * p.ldout + head * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = dt * 16 + 4 * g;
             f16x4 rv = {(f16)0, (f16)0, (f16)0, (f16)0};
-            if (res) rv = *reinterpret_cast<const f16x4*>(doptr + d0);
+            if (res[u]) rv = *reinterpret_cast<const f16x4*>(doptr[u] + d0);
             f16x4 ov;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (f16)(dqacc[dt][r] * p.scale + (float)rv[r]);
+            for (int r = 0; r < 4; ++r) ov[r] = (f16)(dqacc[u][dt][r] * p.scale + (float)rv[r]);
             *reinterpret_cast<f16x4*>(dqrow + d0) = ov;
         }
         if (bias) {
-            float* drow = p.drq + (((int64_t)b * p.Nq + qrow) * p.heads + head) * p.R;
+            float* drow = p.drq + (((int64_t)b * p.Nq + qrow[u]) * p.heads + head) * p.R;
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = jt * 16 + 4 * g + r;
-                    if (j < p.R) drow[j] = qrow >= p.cls ? drqacc[jt][r] : 0.f;
+                    if (j < p.R) drow[j] = qrow[u] >= p.cls ? drqacc[u][jt][r] : 0.f;
                 }
         }
     }
@@ -354,8 +428,8 @@ __global__ __launch_bounds__(SF_THREADS, 3) void sf_attn_bwd_dq_kernel(AttnParam
 // ---------------------------------------------------------------------------------------------
 // backward, key side: workgroup = 64 keys of one (batch, head) x one split of the queries; wave w owns keys
 // 16w .. 16w+15 and walks the split's queries in chunks of 32
-template <int KD>
-__global__ __launch_bounds__(SF_THREADS, 3) void sf_attn_bwd_dkv_kernel(AttnParams p) {
+template <int KD, int OCC>
+__global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 8, DT = D / 16;
     __shared__ __attribute__((aligned(16))) f16 Qs[32 * KP];
     __shared__ __attribute__((aligned(16))) f16 Os[32 * KP];      // dO rows

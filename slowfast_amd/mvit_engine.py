@@ -133,7 +133,7 @@ def _fused_attention(plan):
     if os.environ.get("SF_ATTN_FUSED", _FUSED_DEFAULT) == "0":
         return False
     kt, kh, kw = plan.k_thw
-    return plan.D % 32 == 0 and plan.D <= 128 and (not plan.rel or kt + kh + kw <= 64)
+    return plan.D % 32 == 0 and plan.D <= 128 and (not plan.rel or kt + kh + kw <= 48)
 
 
 def attention_forward(att, plan, qkv):
