@@ -1144,8 +1144,8 @@ extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     }
     if (check_launch("attn_bwd_dq")) return -1;
     {
-        // waves per SIMD the key-side kernel is compiled for: 3 (168 VGPRs, a few spilled address registers) or 2
-        static const int occ = getenv("SF_ATTN_DKV_OCC") ? atoi(getenv("SF_ATTN_DKV_OCC")) : 3;
+        // waves per SIMD the key-side kernel is compiled for: 2 (no spills; 508 vs 505 clips/s, profiles/r1_visit14_*) or 3
+        static const int occ = getenv("SF_ATTN_DKV_OCC") ? atoi(getenv("SF_ATTN_DKV_OCC")) : 2;
         const int grid = d->B * d->heads * p.ktiles * p.qsplits;
         const int kd = d->D / 32;
 #define SF_DKV(KD_)                                                                                              \
