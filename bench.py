@@ -216,7 +216,8 @@ def main():
 
     from slowfast_amd.step import TrainStep
     train_step = TrainStep(model, reducer, opt, loss_fn, loss_scale=a.loss_scale,
-                           use_graph=not a.no_graph, warmup=1)
+                           use_graph=not a.no_graph, warmup=1, clip_grad_l2norm=cfg.SOLVER.CLIP_GRAD_L2NORM,
+                           clip_grad_val=cfg.SOLVER.CLIP_GRAD_VAL)
 
     def step():
         return train_step(inputs, labels)

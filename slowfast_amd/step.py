@@ -18,9 +18,14 @@ from . import engine
 
 
 class TrainStep:
-    def __init__(self, model, reducer, optimizer, loss_fn, loss_scale=1.0, use_graph=None, warmup=2):
+    def __init__(self, model, reducer, optimizer, loss_fn, loss_scale=1.0, use_graph=None, warmup=2, clip_grad_l2norm=None,
+                 clip_grad_val=None):
         self.model, self.reducer, self.optimizer, self.loss_fn = model, reducer, optimizer, loss_fn
         self.loss_scale = float(loss_scale)
+        # SOLVER.CLIP_GRAD_L2NORM / CLIP_GRAD_VAL (tools/train_net.py:156-166); the global gradient norm is always
+        # computed, as the reference does, but stays on the device (self.grad_norm) -- no host sync per iteration
+        self.clip_grad_l2norm, self.clip_grad_val = clip_grad_l2norm, clip_grad_val
+        self.grad_norm = None
         dev = next(model.parameters()).device
         self.use_graph = (dev.type == "cuda") if use_graph is None else bool(use_graph)
         self.warmup = warmup
@@ -41,6 +46,14 @@ class TrainStep:
 
     def _finish(self):
         self.reducer.finish(loss_scale=self.loss_scale)
+        if self.clip_grad_val:
+            self.reducer.flat.clamp_(-float(self.clip_grad_val), float(self.clip_grad_val))
+            self.grad_norm = self.reducer.grad_norm()
+        else:
+            self.grad_norm = self.reducer.grad_norm()
+            if self.clip_grad_l2norm:       # torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (norm + 1e-6))
+                coef = torch.clamp(float(self.clip_grad_l2norm) / (self.grad_norm + 1e-6), max=1.0)
+                self.reducer.flat.mul_(coef)
         if self.optimizer is not None:
             self.optimizer.step()
 
@@ -52,8 +65,12 @@ class TrainStep:
         g = torch.cuda.CUDAGraph()
         engine.FORCE_WEIGHT_PREP = True
         self.reducer.capturing = True
+        # with a process group alive, its watchdog thread polls events while this thread captures: restrict the capture
+        # checks to the capturing thread then (the default "global" mode would fail the capture on such a query)
+        import torch.distributed as dist
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 logits, loss = self._fwd_bwd(self._static_in, self._static_labels)
         finally:
             engine.FORCE_WEIGHT_PREP = False

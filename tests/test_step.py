@@ -95,3 +95,41 @@ def test_train_step_with_rccl_collectives(gpu):
     import sys
     r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_train_step_gradient_clipping(sim):
+    """SOLVER.CLIP_GRAD_L2NORM / CLIP_GRAD_VAL as in tools/train_net.py:156-166, computed on the flat gradient buffer:
+    same parameters as torch.nn.utils.clip_grad_norm_ / clip_grad_value_ on the per-parameter gradients."""
+    from slowfast_amd.data_parallel import GradReducer
+    from slowfast_amd.step import TrainStep
+    for kind in ("norm", "value"):
+        results = []
+        for native in (True, False):
+            torch.manual_seed(0)
+            net = _build().train()
+            opt = torch.optim.SGD(net.parameters(), lr=0.05)
+            red = GradReducer(net)
+            red.attach_torch_param_hooks(net.fc.parameters())
+            g = torch.Generator().manual_seed(5)
+            x = host_to_cl(torch.randn((4, 16, 2, 8, 8), generator=g), sim)
+            y = torch.randint(0, 5, (4,), generator=g)
+            if native:
+                step = TrainStep(net, red, opt, F.cross_entropy, loss_scale=4.0, use_graph=False,
+                                 clip_grad_l2norm=0.05 if kind == "norm" else None,
+                                 clip_grad_val=0.002 if kind == "value" else None)
+                step(x, y)
+                assert step.grad_norm is not None and float(step.grad_norm) > 0
+            else:
+                red.zero_grad()
+                (F.cross_entropy(net(x).float(), y) * 4.0).backward()
+                red.finish(loss_scale=4.0)
+                if kind == "norm":
+                    total = torch.nn.utils.clip_grad_norm_(net.parameters(), 0.05)
+                    assert float(total) > 0.05, "the test must actually clip"
+                else:
+                    torch.nn.utils.clip_grad_value_(net.parameters(), 0.002)
+                opt.step()
+            results.append([p.detach().clone() for p in net.parameters()])
+            red.close()
+        for a, b in zip(*results):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
