@@ -34,19 +34,19 @@ BYTE_FLOOR_GB_PER_CLIP = {"SLOWFAST_8x8_R50": 2.165, "C2D_8x8_R50": 1.019, "MVIT
                           "SLOWFAST_32x2_R101_50_50": 4.729}
 METRIC_NAME = {"SLOWFAST_8x8_R50": "SlowFast-8x8-R50 32x224^2", "C2D_8x8_R50": "C2D-R50 8x224^2",
                "MVITv2_S_16x4": "MViTv2-S 16x224^2", "X3D_M": "X3D-M 16x224^2",
-               "SLOWFAST_32x2_R101_50_50": "SlowFast-32x2-R101+Nonlocal (basic head) 32x256^2"}
+               "SLOWFAST_32x2_R101_50_50": "SlowFast-32x2-R101+Nonlocal (AVA RoI head, 3 boxes/clip) 32x256^2"}
 # synthetic-run overrides: stochastic ops off so that runs are comparable and parity-checkable;
-# BASELINE config 5 is quoted on AVA-shaped 32x256^2 clips; its res5 keeps stride 1 (16x16 map), so the basic head that
-# stands in for the RoI head pools globally (pool_size None, head_helper.py:251-252, selected by MULTIGRID.SHORT_CYCLE)
+# BASELINE config 5 is quoted on AVA-shaped 32x256^2 clips (ResNetRoIHead on 3 synthetic boxes per clip)
 PRESET_OPTS = {"MVITv2_S_16x4": ["MVIT.DROPPATH_RATE", 0.0, "MODEL.DROPOUT_RATE", 0.0],
-               "SLOWFAST_32x2_R101_50_50": ["DATA.TRAIN_CROP_SIZE", 256, "MULTIGRID.SHORT_CYCLE", True]}
+               "SLOWFAST_32x2_R101_50_50": ["DATA.TRAIN_CROP_SIZE", 256]}
+BOXES_PER_CLIP = 3           # synthetic AVA batches: boxes (R, 5) = [batch index, x1, y1, x2, y2] in crop pixels
 
 
 def make_loss(cfg):
-    """slowfast/models/losses.py:61-69: cross_entropy | soft_cross_entropy | bce.  With the basic head the network
-    returns logits in train mode, so "bce" is evaluated as BCE-with-logits on multi-hot float labels."""
+    """slowfast/models/losses.py:61-69: cross_entropy | soft_cross_entropy | bce (nn.BCELoss on the RoI head's sigmoid
+    outputs; BCE-with-logits if the detection head is switched off and the basic head returns logits)."""
     if cfg.MODEL.LOSS_FUNC == "bce":
-        return F.binary_cross_entropy_with_logits
+        return F.binary_cross_entropy if cfg.DETECTION.ENABLE else F.binary_cross_entropy_with_logits
     return F.cross_entropy
 
 
@@ -156,11 +156,15 @@ def cpu_baseline(cfg, clips, threads=0):
         if k.endswith("c_bn.weight"):
             sd[k].fill_(1.0)
     inputs, labels = video_ref.synthetic_batch(cfg, clips, seed=0)
-    fam.loss_and_grads(sd, cfg, inputs, labels)            # warm-up
+    kw = {}
+    if cfg.DETECTION.ENABLE:
+        kw["bboxes"] = video_ref.synthetic_boxes(cfg, clips, seed=1, per_clip=BOXES_PER_CLIP)
+        labels = (torch.rand((kw["bboxes"].shape[0], cfg.MODEL.NUM_CLASSES)) < 0.05).float()
+    fam.loss_and_grads(sd, cfg, inputs, labels, **kw)      # warm-up
     best, iters = 1e30, 2
     for _ in range(iters):
         t0 = time.perf_counter()
-        fam.loss_and_grads(sd, cfg, inputs, labels)
+        fam.loss_and_grads(sd, cfg, inputs, labels, **kw)
         best = min(best, time.perf_counter() - t0)
     return {"value": clips / best, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{clips} clips x (fwd + cross-entropy + bwd), best of {iters} timed iterations after 1 warm-up, "
@@ -203,7 +207,15 @@ def main():
     g = torch.Generator(device=dev).manual_seed(cfg.RNG_SEED + rank)
     T, S = cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE
     fast = torch.randn((a.batch, 3, T, S, S), generator=g, device=dev)
-    if cfg.MODEL.LOSS_FUNC == "bce":     # AVA: multi-hot action labels
+    bboxes = None
+    if cfg.DETECTION.ENABLE:             # AVA: boxes + one multi-hot action label row per box
+        R = a.batch * BOXES_PER_CLIP
+        xy = torch.rand((R, 2), generator=g, device=dev) * 0.6 * S
+        wh = (torch.rand((R, 2), generator=g, device=dev) * 0.35 + 0.05) * S
+        bidx = torch.arange(a.batch, device=dev).repeat_interleave(BOXES_PER_CLIP).float()[:, None]
+        bboxes = torch.cat([bidx, xy, torch.minimum(xy + wh, torch.full_like(xy, S - 1.0))], 1)
+        labels = (torch.rand((R, cfg.MODEL.NUM_CLASSES), generator=g, device=dev) < 0.05).float()
+    elif cfg.MODEL.LOSS_FUNC == "bce":
         labels = (torch.rand((a.batch, cfg.MODEL.NUM_CLASSES), generator=g, device=dev) < 0.05).float()
     else:
         labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (a.batch,), generator=g, device=dev)
@@ -214,8 +226,20 @@ def main():
     else:
         inputs = [fast]
 
+    step_model = model
+    if bboxes is not None:               # the boxes travel as the last element of the (static) input list
+        class _WithBoxes(torch.nn.Module):
+            def __init__(self, m):
+                super().__init__()
+                self.m = m
+
+            def forward(self, xs):
+                return self.m(xs[:-1], xs[-1])
+        step_model = _WithBoxes(model)
+        inputs = inputs + [bboxes]
+
     from slowfast_amd.step import TrainStep
-    train_step = TrainStep(model, reducer, opt, loss_fn, loss_scale=a.loss_scale,
+    train_step = TrainStep(step_model, reducer, opt, loss_fn, loss_scale=a.loss_scale,
                            use_graph=not a.no_graph, warmup=1, clip_grad_l2norm=cfg.SOLVER.CLIP_GRAD_L2NORM,
                            clip_grad_val=cfg.SOLVER.CLIP_GRAD_VAL)
 
@@ -224,7 +248,7 @@ def main():
 
     def eager_step():
         reducer.zero_grad()
-        logits = model(inputs)
+        logits = step_model(inputs)
         loss = loss_fn(logits.float(), labels)
         (loss * a.loss_scale).backward()
         reducer.finish(loss_scale=a.loss_scale)

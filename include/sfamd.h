@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 9
+#define SF_ABI_VERSION 10
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -223,6 +223,22 @@ int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, const void* k
                 const float* rq, const void* onehot, int32_t residual, const void* o, const void* dout, int32_t ldo,
                 const float* lse, float* delta, void* dq, int32_t lddq, void* dk, void* dv, int32_t lddk, float* drq,
                 void* workspace, int64_t workspace_bytes, sf_stream_t stream);
+/* RoI head -- replaces head_helper.py:85-97 / 116-133 (ResNetRoIHead): AvgPool3d([T,1,1]) then ROIAlign(res x res,
+ * spatial_scale, sampling_ratio 0, aligned) fused with MaxPool2d(res).
+ *   sf_tmean_fwd: m[b][hw][c] = mean_t x[b][t][hw][c]   (x channels-last fp16 rows of pitch ldx, m fp32 [B*HW][C])
+ *   sf_roi_align_max_fwd: out[r][col0 + c] = max over the res*res bins of ROIAlign(m, rois[r]) (rois [R][5] fp32 =
+ *       batch index, x1, y1, x2, y2 in input pixels); argmax [R][C] uint8 records the winning bin
+ *   sf_roi_align_max_bwd: dm (pre-zeroed by the caller, fp32) += the gradient routed to the arg-max bin's bilinear samples
+ *       (fp32 atomics: overlapping boxes); sf_tmean_bwd: dx[b][t][hw][c] = dm[b][hw][c] / T.
+ * ROIAlign is detectron2.layers.ROIAlign in the reference (not vendored): see oracle/video_ref.py:roi_align. */
+int sf_tmean_fwd(int32_t B, int32_t T, int64_t HW, int32_t C, const void* x, int32_t ldx, float* m, sf_stream_t stream);
+int sf_tmean_bwd(int32_t B, int32_t T, int64_t HW, int32_t C, const float* dm, void* dx, int32_t lddx, sf_stream_t stream);
+int sf_roi_align_max_fwd(int32_t R, int32_t B, int32_t H, int32_t W, int32_t C, int32_t res, float scale, int32_t aligned,
+                         const float* m, const float* rois, float* out, int32_t ldo, int32_t col0, void* argmax,
+                         sf_stream_t stream);
+int sf_roi_align_max_bwd(int32_t R, int32_t B, int32_t H, int32_t W, int32_t C, int32_t res, float scale, int32_t aligned,
+                         const float* rois, const float* dout, int32_t lddo, int32_t col0, const void* argmax, float* dm,
+                         sf_stream_t stream);
 /* Stochastic depth -- replaces drop_path() (slowfast/models/common.py:46-59) at the two residual additions of
  * MultiScaleBlock (attention.py:500-510): y[m] = (resid ? resid[m] : 0) + scale[m / rows_per_sample] * x[m], with
  * scale[b] = floor(keep_prob + u_b) / keep_prob sampled by the caller.  Rows are fp16 [M][C], C % 8 == 0. */

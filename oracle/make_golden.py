@@ -54,6 +54,15 @@ CASES = {
                                "MULTIGRID.SHORT_CYCLE", True, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 64,
                                "DATA.NUM_FRAMES", 8, "RESNET.WIDTH_PER_GROUP", 16, "SLOWFAST.BETA_INV", 2], 4,
                               {"final_bn_gamma_scale": 0.25}),
+    # BASELINE config 5 with its true AVA head: ResNetRoIHead (temporal average pool -> ROIAlign 7x7 @ 1/16 -> max pool ->
+    # Linear -> sigmoid), 3 boxes per clip, BCE on multi-hot labels.  ROIAlign runs on the oracle's restatement inside
+    # the reference model as well (detectron2 is not installed): it is the one op of this case that is not pinned.
+    "slowfast_ava_roi_tiny": ("configs/AVA/c2/SLOWFAST_32x2_R101_50_50.yaml",
+                              ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MODEL.NUM_CLASSES", 10,
+                               "DATA.TRAIN_CROP_SIZE", 64, "DATA.NUM_FRAMES", 8, "RESNET.WIDTH_PER_GROUP", 16,
+                               "RESNET.DEPTH", 50, "SLOWFAST.BETA_INV", 2,
+                               "NONLOCAL.LOCATION", "[[[], []], [[], []], [[1], []], [[], []]]"], 4,
+                              {"final_bn_gamma_scale": 0.25, "boxes": 3}),
     # X3D-M (depthwise 3x3x3, SE, Swish, channel widths 54/108 that are not multiples of 8) at reduced clip size
     "x3d_m_mid": ("configs/Kinetics/X3D_M.yaml",
                   ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8], 4),
@@ -92,13 +101,22 @@ def run_case(name):
     model.load_state_dict(sd)
     model.train()
     inputs, labels = video_ref.synthetic_batch(cfg, batch, seed=4321)
-    logits = model([x.clone() for x in inputs])
-    loss = torch.nn.functional.cross_entropy(logits, labels)
+    bboxes = None
+    if tweaks.get("boxes"):
+        bboxes = video_ref.synthetic_boxes(cfg, batch, seed=77, per_clip=tweaks["boxes"])
+        g = torch.Generator().manual_seed(78)
+        labels = (torch.rand((bboxes.shape[0], cfg.MODEL.NUM_CLASSES), generator=g) < 0.2).float()
+        logits = model([x.clone() for x in inputs], bboxes)
+        loss = torch.nn.functional.binary_cross_entropy(logits, labels)
+    else:
+        logits = model([x.clone() for x in inputs])
+        loss = torch.nn.functional.cross_entropy(logits, labels)
     loss.backward()
     ref_grads = {k: p.grad for k, p in model.named_parameters()}
     ref_stats = {k: v for k, v in model.state_dict().items() if "running" in k}
 
-    o_logits, o_loss, o_grads, o_stats = fam.loss_and_grads(sd, cfg, inputs, labels)
+    o_logits, o_loss, o_grads, o_stats = (fam.loss_and_grads(sd, cfg, inputs, labels, bboxes=bboxes) if bboxes is not None
+                                          else fam.loss_and_grads(sd, cfg, inputs, labels))
     err = float((o_logits - logits.detach()).abs().max() / logits.detach().abs().max())
     assert err < 1e-5, f"{name}: oracle logits differ from the reference ({err:.2e})"
     assert abs(float(o_loss) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))

@@ -8,7 +8,7 @@ registering small stand-ins for exactly the symbols its model code imports (SURV
   fvcore.nn.weight_init            -> c2_msra_fill = kaiming_normal_(fan_out, relu); c2_xavier_fill = kaiming_uniform_(a=1)
   pytorchvideo.layers.swish.Swish, pytorchvideo.layers.batch_norm.NaiveSyncBatchNorm{1d,3d} (import-time only)
   pytorchvideo.losses.soft_target_cross_entropy.SoftTargetCrossEntropyLoss
-  detectron2.layers.ROIAlign (import-time only), slowfast.utils.logging -> stdlib logging
+  detectron2.layers.ROIAlign (the oracle's restatement of the published algorithm), slowfast.utils.logging -> stdlib logging
 ``slowfast`` and ``slowfast.models`` are pre-seeded as path-only packages so that their __init__.py
 (which drags in cv2 / torchvision through the SSL models) is bypassed.  Nothing here is shipped with
 or imported by the product package; it does not exist on the GPU box and no `-m gpu` test needs it.
@@ -97,8 +97,22 @@ def install():
     _module("pytorchvideo.layers.batch_norm", NaiveSyncBatchNorm1d=_ImportOnly, NaiveSyncBatchNorm3d=_ImportOnly)
     _module("pytorchvideo.losses")
     _module("pytorchvideo.losses.soft_target_cross_entropy", SoftTargetCrossEntropyLoss=SoftTargetCrossEntropyLoss)
+    class ROIAlign(nn.Module):
+        """detectron2.layers.ROIAlign is not installed here: the unmodified reference head runs on the oracle's
+        restatement of the published algorithm (oracle/video_ref.py:roi_align) -- everything around ROIAlign is pinned
+        by the reference, ROIAlign itself is 'parity unpinned'."""
+
+        def __init__(self, output_size, spatial_scale, sampling_ratio, aligned=True):
+            super().__init__()
+            self.output_size = tuple(output_size) if isinstance(output_size, (list, tuple)) else (output_size, output_size)
+            self.spatial_scale, self.sampling_ratio, self.aligned = spatial_scale, sampling_ratio, aligned
+
+        def forward(self, input, rois):
+            from oracle import video_ref
+            return video_ref.roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned)
+
     _module("detectron2")
-    _module("detectron2.layers", ROIAlign=_ImportOnly)
+    _module("detectron2.layers", ROIAlign=ROIAlign)
 
     ref = os.path.join(REFERENCE_ROOT, "slowfast")
     _package("slowfast", ref)

@@ -8,6 +8,8 @@ and the values are committed under tests/golden/.  Each function cites the refer
 The graph is driven by a flat ``state_dict`` (reference key names) and the cfg; every op is the torch
 functional the reference's nn.Module would dispatch to, so autograd gives the reference backward.
 """
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -204,7 +206,68 @@ def x3d_forward(sd, cfg, inputs, training=True, stats_out=None):
 _POOL1_T = {"2d": 1, "c2d": 2, "slow_c2d": 1, "i3d": 2, "slow_i3d": 1, "slow": 1, "slowfast": 1}
 
 
-def video_forward(sd, cfg, inputs, training=True, stats_out=None):
+def roi_align(feat, rois, out_size, spatial_scale, sampling_ratio=0, aligned=True):
+    """ROIAlign on a (B, C, H, W) map for rois (R, 5) = [batch index, x1, y1, x2, y2] -> (R, C, out_h, out_w).
+
+    PARITY UNPINNED: the reference takes this op from detectron2.layers.ROIAlign (-> torchvision.ops.roi_align), which is
+    not vendored under /root/reference and not installed here.  This restates the published algorithm (Mask R-CNN
+    ROIAlign as implemented in torchvision/csrc/ops/cpu/roi_align_kernel.cpp): continuous coordinates scaled by
+    spatial_scale, shifted by -0.5 when `aligned`; legacy (aligned=False) clamps the RoI size to >= 1; every output bin
+    averages a grid of ceil(roi_size / out_size) (or sampling_ratio) bilinear samples per axis; samples outside
+    [-1, size] contribute 0, coordinates are clamped into the map.  Call sites in the reference:
+    head_helper.py:88-94, 126-127."""
+    R = rois.shape[0]
+    B, C, H, W = feat.shape
+    oh, ow = out_size
+    out = []
+    off = 0.5 if aligned else 0.0
+    for r in range(R):
+        b = int(rois[r, 0])
+        x1, y1, x2, y2 = [float(v) * spatial_scale - off for v in rois[r, 1:5]]
+        rw, rh = x2 - x1, y2 - y1
+        if not aligned:
+            rw, rh = max(rw, 1.0), max(rh, 1.0)
+        bh, bw = rh / oh, rw / ow
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rh / oh))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rw / ow))
+        count = max(gh * gw, 1)
+        ys = y1 + (torch.arange(oh, dtype=feat.dtype)[:, None] * bh + (torch.arange(gh, dtype=feat.dtype)[None, :] + 0.5) * bh / max(gh, 1))
+        xs = x1 + (torch.arange(ow, dtype=feat.dtype)[:, None] * bw + (torch.arange(gw, dtype=feat.dtype)[None, :] + 0.5) * bw / max(gw, 1))
+        ys, xs = ys.reshape(-1), xs.reshape(-1)                  # (oh*gh), (ow*gw)
+        vy = ((ys >= -1.0) & (ys <= H)).to(feat.dtype)
+        vx = ((xs >= -1.0) & (xs <= W)).to(feat.dtype)
+        yc, xc = ys.clamp(min=0.0), xs.clamp(min=0.0)
+        y0, x0 = yc.floor().long(), xc.floor().long()
+        top, left = y0 >= H - 1, x0 >= W - 1
+        y0, x0 = torch.where(top, torch.full_like(y0, H - 1), y0), torch.where(left, torch.full_like(x0, W - 1), x0)
+        y1i, x1i = torch.where(top, y0, y0 + 1), torch.where(left, x0, x0 + 1)
+        ly = torch.where(top, torch.zeros_like(yc), yc - y0.to(feat.dtype))
+        lx = torch.where(left, torch.zeros_like(xc), xc - x0.to(feat.dtype))
+        hy, hx = 1.0 - ly, 1.0 - lx
+        f = feat[b]                                              # (C, H, W)
+        v = (f[:, y0][:, :, x0] * (hy[:, None] * hx[None, :]) + f[:, y0][:, :, x1i] * (hy[:, None] * lx[None, :])
+             + f[:, y1i][:, :, x0] * (ly[:, None] * hx[None, :]) + f[:, y1i][:, :, x1i] * (ly[:, None] * lx[None, :]))
+        v = v * (vy[:, None] * vx[None, :])
+        v = v.reshape(C, oh, gh, ow, gw).sum((2, 4)) / count if gh * gw > 0 else torch.zeros((C, oh, ow), dtype=feat.dtype)
+        out.append(v)
+    return torch.stack(out, 0) if out else feat.new_zeros((0, C, oh, ow))
+
+
+def roi_head(x, sd, cfg, bboxes, training):
+    """ResNetRoIHead.forward (head_helper.py:116-144): temporal average pool -> ROIAlign(7x7, 1/16) -> MaxPool2d(7) per
+    pathway, concat, (dropout off), Linear, activation (applied in training too)."""
+    res = cfg.DETECTION.ROI_XFORM_RESOLUTION
+    pooled = []
+    for v in x:
+        m = _STORE(v).mean(2)                                    # AvgPool3d([T, 1, 1]) + squeeze
+        r = roi_align(m, bboxes, (res, res), 1.0 / cfg.DETECTION.SPATIAL_SCALE_FACTOR, 0, cfg.DETECTION.ALIGNED)
+        pooled.append(r.amax((2, 3)))
+    z = torch.cat(pooled, 1)
+    z = F.linear(z, sd["head.projection.weight"], sd["head.projection.bias"])
+    return torch.sigmoid(z) if cfg.MODEL.HEAD_ACT == "sigmoid" else F.softmax(z, dim=1)
+
+
+def video_forward(sd, cfg, inputs, training=True, stats_out=None, bboxes=None):
     """SlowFast.forward (video_model_builder.py:423-441) / ResNet.forward (:645-660) + ResNetBasicHead.forward
     (head_helper.py:305-350).  Dropout is not applied (the parity harness sets MODEL.DROPOUT_RATE 0)."""
     P = len(inputs)
@@ -222,6 +285,8 @@ def video_forward(sd, cfg, inputs, training=True, stats_out=None):
                 x = [F.max_pool3d(v, (pt, 1, 1), (pt, 1, 1)) for v in x]
         if two and i < 3:
             x[0] = fuse(x[0], x[1], sd, f"{name}_fuse", cfg.SLOWFAST.ALPHA, training, stats_out)
+    if cfg.DETECTION.ENABLE:
+        return roi_head(x, sd, cfg, bboxes, training)
     crop = cfg.DATA.TRAIN_CROP_SIZE // 32
     frames = [cfg.DATA.NUM_FRAMES // cfg.SLOWFAST.ALPHA, cfg.DATA.NUM_FRAMES] if two else \
         [cfg.DATA.NUM_FRAMES // _POOL1_T[cfg.MODEL.ARCH]]
@@ -291,14 +356,32 @@ def synthetic_batch(cfg, batch, seed, num_classes=None):
     return [fast], labels
 
 
-def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32):
-    """Training-mode forward + mean cross-entropy + backward; returns logits, loss, {name: grad}, new running stats."""
+def synthetic_boxes(cfg, batch, seed, per_clip=3):
+    """(R, 5) boxes [batch index, x1, y1, x2, y2] in crop pixels (slowfast/datasets/loader.py:66-75 layout)."""
+    g = torch.Generator().manual_seed(seed)
+    S = float(cfg.DATA.TRAIN_CROP_SIZE)
+    rows = []
+    for b in range(batch):
+        for _ in range(per_clip):
+            x1, y1 = (torch.rand(2, generator=g) * 0.6 * S).tolist()
+            w, h = ((torch.rand(2, generator=g) * 0.35 + 0.05) * S).tolist()
+            rows.append([float(b), x1, y1, min(x1 + w, S - 1.0), min(y1 + h, S - 1.0)])
+    return torch.tensor(rows, dtype=torch.float32)
+
+
+def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32, bboxes=None):
+    """Training-mode forward + mean cross-entropy (BCE on the activated outputs for the detection head, losses.py:61-69
+    "bce") + backward; returns logits, loss, {name: grad}, new running stats."""
     params = {k: v.detach().to(dtype).clone().requires_grad_(v.is_floating_point() and "running" not in k)
               for k, v in sd.items() if v.is_floating_point()}
     stats = {}
     fwd = x3d_forward if cfg.MODEL.MODEL_NAME == "X3D" else video_forward
-    logits = fwd(params, cfg, [x.to(dtype) for x in inputs], training=True, stats_out=stats)
-    loss = F.cross_entropy(logits, labels)
+    if bboxes is not None:
+        logits = fwd(params, cfg, [x.to(dtype) for x in inputs], training=True, stats_out=stats, bboxes=bboxes)
+        loss = F.binary_cross_entropy(logits, labels.to(dtype))
+    else:
+        logits = fwd(params, cfg, [x.to(dtype) for x in inputs], training=True, stats_out=stats)
+        loss = F.cross_entropy(logits, labels)
     loss.backward()
     grads = {k: v.grad for k, v in params.items() if v.requires_grad}
     return logits.detach(), loss.detach(), grads, stats

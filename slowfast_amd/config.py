@@ -207,9 +207,8 @@ PRESETS["SLOWFAST_NLN_8x8_R50"]["NONLOCAL"] = {"LOCATION": [[[], []], [[1, 3], [
                                                "GROUP": [[1, 1], [1, 1], [1, 1], [1, 1]], "INSTANTIATION": "dot_product"}
 
 
-# configs/AVA/c2/SLOWFAST_32x2_R101_50_50.yaml -- the backbone + Nonlocal of BASELINE config 5.  DETECTION.ENABLE is
-# False here: the RoI head (head_helper.py:20-144) is not part of this engine yet, the network is
-# closed with ResNetBasicHead (80 classes, BCE on logits) as SURVEY.md 8(c) prescribes for measuring this backbone.
+# configs/AVA/c2/SLOWFAST_32x2_R101_50_50.yaml -- BASELINE config 5: SlowFast-R101 + Nonlocal with the AVA RoI head
+# (DETECTION.ENABLE, legacy ROIAlign alignment, sigmoid outputs, BCE).
 PRESETS["SLOWFAST_32x2_R101_50_50"] = copy.deepcopy(PRESETS["SLOWFAST_8x8_R50"])
 PRESETS["SLOWFAST_32x2_R101_50_50"]["DATA"].update({"TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256})
 PRESETS["SLOWFAST_32x2_R101_50_50"]["SLOWFAST"]["FUSION_KERNEL_SZ"] = 5
@@ -221,6 +220,7 @@ PRESETS["SLOWFAST_32x2_R101_50_50"]["NONLOCAL"] = {
     "POOL": [[[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]]]}
 PRESETS["SLOWFAST_32x2_R101_50_50"]["SOLVER"] = {"MOMENTUM": 0.9, "WEIGHT_DECAY": 1e-7, "OPTIMIZING_METHOD": "sgd"}
 PRESETS["SLOWFAST_32x2_R101_50_50"]["MODEL"].update({"NUM_CLASSES": 80, "LOSS_FUNC": "bce", "HEAD_ACT": "sigmoid"})
+PRESETS["SLOWFAST_32x2_R101_50_50"]["DETECTION"] = {"ENABLE": True, "ALIGNED": False}
 
 
 def preset_for_yaml(yaml_rel):

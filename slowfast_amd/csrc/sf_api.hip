@@ -9,6 +9,7 @@
 #include "sf_x3d.h"
 #include "sf_stem.h"
 #include "sf_attn.h"
+#include "sf_roi.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -1165,6 +1166,66 @@ extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
         return check_launch("attn_reduce");
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoI head (sf_roi.h)
+static int fill_tmean(TMeanParams& p, int32_t B, int32_t T, int64_t HW, int32_t C, const char* who) {
+    REQUIRE(B > 0 && T > 0 && HW > 0 && C > 0 && C % 8 == 0, "%s: bad shape", who);
+    memset(&p, 0, sizeof(p));
+    p.T = T; p.C = C; p.HW = HW;
+    p.total = (int64_t)B * HW * (C / 8);
+    REQUIRE(p.total < (1ll << 31) && (int64_t)B * HW < (1ll << 31), "%s: too many elements", who);
+    p.fdG = make_fastdiv(C / 8); p.fdHW = make_fastdiv((uint32_t)HW);
+    return 0;
+}
+extern "C" int sf_tmean_fwd(int32_t B, int32_t T, int64_t HW, int32_t C, const void* x, int32_t ldx, float* m,
+                            sf_stream_t stream) {
+    TMeanParams p;
+    if (fill_tmean(p, B, T, HW, C, "sf_tmean_fwd")) return -1;
+    REQUIRE(x && m && ldx % 8 == 0 && ldx >= C, "sf_tmean_fwd: bad arguments");
+    p.x = (const f16*)x; p.ldx = ldx; p.m = m;
+    hipLaunchKernelGGL(sf_tmean_fwd_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("tmean_fwd");
+}
+extern "C" int sf_tmean_bwd(int32_t B, int32_t T, int64_t HW, int32_t C, const float* dm, void* dx, int32_t lddx,
+                            sf_stream_t stream) {
+    TMeanParams p;
+    if (fill_tmean(p, B, T, HW, C, "sf_tmean_bwd")) return -1;
+    REQUIRE(dm && dx && lddx % 8 == 0 && lddx >= C, "sf_tmean_bwd: bad arguments");
+    p.dm = dm; p.dx = (f16*)dx; p.lddx = lddx;
+    hipLaunchKernelGGL(sf_tmean_bwd_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("tmean_bwd");
+}
+static int fill_roi(RoiParams& p, int32_t R, int32_t B, int32_t H, int32_t W, int32_t C, int32_t res, float scale,
+                    int32_t aligned, const float* rois, const char* who) {
+    REQUIRE(R > 0 && B > 0 && H > 0 && W > 0 && C > 0 && rois, "%s: bad arguments", who);
+    REQUIRE(res >= 1 && res * res <= 255, "%s: resolution must satisfy res*res <= 255 (got %d)", who, res);
+    memset(&p, 0, sizeof(p));
+    p.R = R; p.B = B; p.H = H; p.W = W; p.C = C; p.res = res; p.scale = scale; p.aligned = aligned; p.rois = rois;
+    return 0;
+}
+extern "C" int sf_roi_align_max_fwd(int32_t R, int32_t B, int32_t H, int32_t W, int32_t C, int32_t res, float scale,
+                                    int32_t aligned, const float* m, const float* rois, float* out, int32_t ldo,
+                                    int32_t col0, void* argmax, sf_stream_t stream) {
+    RoiParams p;
+    if (fill_roi(p, R, B, H, W, C, res, scale, aligned, rois, "sf_roi_align_max_fwd")) return -1;
+    REQUIRE(m && out && argmax && col0 >= 0 && col0 + C <= ldo, "sf_roi_align_max_fwd: bad output placement");
+    p.m = m; p.out = out; p.ldo = ldo; p.col0 = col0; p.arg = (unsigned char*)argmax;
+    hipLaunchKernelGGL(sf_roi_align_max_fwd_kernel, dim3(cdiv((int64_t)R * C, SF_THREADS)), dim3(SF_THREADS), 0,
+                       (hipStream_t)stream, p);
+    return check_launch("roi_align_max_fwd");
+}
+extern "C" int sf_roi_align_max_bwd(int32_t R, int32_t B, int32_t H, int32_t W, int32_t C, int32_t res, float scale,
+                                    int32_t aligned, const float* rois, const float* dout, int32_t lddo, int32_t col0,
+                                    const void* argmax, float* dm, sf_stream_t stream) {
+    RoiParams p;
+    if (fill_roi(p, R, B, H, W, C, res, scale, aligned, rois, "sf_roi_align_max_bwd")) return -1;
+    REQUIRE(dout && argmax && dm && col0 >= 0 && col0 + C <= lddo, "sf_roi_align_max_bwd: bad arguments");
+    p.dout = dout; p.lddo = lddo; p.col0 = col0; p.arg = (unsigned char*)const_cast<void*>(argmax); p.dm = dm;
+    hipLaunchKernelGGL(sf_roi_align_max_bwd_kernel, dim3(cdiv((int64_t)R * C, SF_THREADS)), dim3(SF_THREADS), 0,
+                       (hipStream_t)stream, p);
+    return check_launch("roi_align_max_bwd");
 }
 
 extern "C" int sf_row_scale_add(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,

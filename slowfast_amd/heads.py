@@ -6,6 +6,9 @@ mean in eval.  It runs on torch fp32 ops over the (tiny) res5 outputs."""
 import torch
 import torch.nn as nn
 
+from . import ops
+from .lib import get_lib
+
 
 class ResNetBasicHead(nn.Module):
     def __init__(self, dim_in, num_classes, pool_size, dropout_rate=0.0, act_func="softmax", detach_final_fc=False,
@@ -56,3 +59,84 @@ class ResNetBasicHead(nn.Module):
                 x = self.act(x)
             x = x.mean([1, 2, 3])
         return x.view(x.shape[0], -1)
+
+
+class _RoiPoolFn(torch.autograd.Function):
+    """AvgPool3d([T,1,1]) -> ROIAlign(res, 1/scale_factor, sampling_ratio 0, aligned) -> MaxPool2d(res) of one pathway
+    on the libsfamd kernels (sf_tmean_*, sf_roi_align_max_*): x channels-last fp16 (N,C,T,H,W) -> (R, C) fp32."""
+
+    @staticmethod
+    def forward(ctx, x, rois, res, scale, aligned):
+        x = ops.to_cl(x)
+        lib = get_lib()
+        N, C, T, H, W = x.shape
+        s = ops._stream(x)
+        m = torch.empty((N * H * W, C), dtype=torch.float32, device=x.device)
+        lib.call("sf_tmean_fwd", N, T, H * W, C, x.data_ptr(), ops.cl_ld(x), m.data_ptr(), s,
+                 work=dict(bytes=2.0 * x.numel()))
+        rois = rois.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        R = rois.shape[0]
+        out = torch.empty((R, C), dtype=torch.float32, device=x.device)
+        arg = torch.empty((R, C), dtype=torch.uint8, device=x.device)
+        lib.call("sf_roi_align_max_fwd", R, N, H, W, C, res, float(scale), int(bool(aligned)), m.data_ptr(),
+                 rois.data_ptr(), out.data_ptr(), C, 0, arg.data_ptr(), s, work=dict(bytes=4.0 * R * C * res * res))
+        ctx.geom = (N, C, T, H, W, res, float(scale), int(bool(aligned)))
+        ctx.save_for_backward(rois, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        rois, arg = ctx.saved_tensors
+        N, C, T, H, W, res, scale, aligned = ctx.geom
+        lib = get_lib()
+        dout = dout.contiguous().float()
+        s = ops._stream(dout)
+        dm = torch.zeros((N * H * W, C), dtype=torch.float32, device=dout.device)
+        lib.call("sf_roi_align_max_bwd", rois.shape[0], N, H, W, C, res, scale, aligned, rois.data_ptr(), dout.data_ptr(),
+                 C, 0, arg.data_ptr(), dm.data_ptr(), s)
+        dx = ops.cl_empty((N, C, T, H, W), dout.device)
+        lib.call("sf_tmean_bwd", N, T, H * W, C, dm.data_ptr(), dx.data_ptr(), ops.cl_ld(dx), s,
+                 work=dict(bytes=2.0 * dx.numel()))
+        return dx, None, None, None, None
+
+
+class ResNetRoIHead(nn.Module):
+    """ResNe(X)t RoI head with the reference's constructor and state_dict (slowfast/models/head_helper.py:20-144):
+    per pathway temporal average pool -> ROIAlign -> spatial max pool, concat, dropout, Linear, activation (applied in
+    training as well, as the reference does).  forward(inputs, bboxes) with bboxes (R, 5) = [batch index, x1, y1, x2, y2]."""
+
+    def __init__(self, dim_in, num_classes, pool_size, resolution, scale_factor, dropout_rate=0.0, act_func="softmax",
+                 aligned=True, detach_final_fc=False):
+        super().__init__()
+        assert len({len(pool_size), len(dim_in)}) == 1, "pathway dimensions are not consistent."
+        self.num_pathways = len(pool_size)
+        self.detach_final_fc = detach_final_fc
+        self.pool_size, self.resolution, self.scale_factor, self.aligned = pool_size, resolution, scale_factor, aligned
+        for p in range(self.num_pathways):       # parameter-free children kept for module-tree parity
+            self.add_module(f"s{p}_tpool", nn.AvgPool3d([pool_size[p][0], 1, 1], stride=1))
+            self.add_module(f"s{p}_spool", nn.MaxPool2d(resolution[p], stride=1))
+        if dropout_rate > 0.0:
+            self.dropout = nn.Dropout(dropout_rate)
+        self.projection = nn.Linear(sum(dim_in), num_classes, bias=True)
+        if act_func == "softmax":
+            self.act = nn.Softmax(dim=1)
+        elif act_func == "sigmoid":
+            self.act = nn.Sigmoid()
+        else:
+            raise NotImplementedError(f"{act_func} is not supported as an activationfunction.")
+
+    def forward(self, inputs, bboxes):
+        assert len(inputs) == self.num_pathways, f"Input tensor does not contain {self.num_pathways} pathway"
+        assert bboxes is not None and bboxes.dim() == 2 and bboxes.shape[1] == 5, "bboxes: (R, 5) = [batch idx, x1, y1, x2, y2]"
+        pooled = []
+        for p, x in enumerate(inputs):
+            assert x.shape[2] == self.pool_size[p][0], "the temporal pool must cover the pathway's frames"
+            res = self.resolution[p]
+            assert res[0] == res[1]
+            pooled.append(_RoiPoolFn.apply(x, bboxes, int(res[0]), 1.0 / self.scale_factor[p], self.aligned))
+        x = torch.cat(pooled, 1)
+        if hasattr(self, "dropout"):
+            x = self.dropout(x)
+        if self.detach_final_fc:
+            x = x.detach()
+        return self.act(self.projection(x))

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ConvDesc(Structure):
@@ -90,6 +90,12 @@ _SIGNATURES = {
     "sf_attn_bwd_workspace": (c_int64, [POINTER(AttnDesc)]),
     "sf_attn_bwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, c_int32, c_float, _F, _P, c_int32, _P, _P, c_int32, _F,
                             _F, _P, c_int32, _P, _P, c_int32, _F, _P, c_int64, _P]),
+    "sf_tmean_fwd": (c_int, [c_int32, c_int32, c_int64, c_int32, _P, c_int32, _F, _P]),
+    "sf_tmean_bwd": (c_int, [c_int32, c_int32, c_int64, c_int32, _F, _P, c_int32, _P]),
+    "sf_roi_align_max_fwd": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _F, _F, _F,
+                                     c_int32, c_int32, _P, _P]),
+    "sf_roi_align_max_bwd": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _F, _F,
+                                     c_int32, c_int32, _P, _F, _P]),
     "sf_row_scale_add": (c_int, [_P, c_int32, _P, c_int64, _P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     "sf_transpose_heads": (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "sf_sample_chunks": (c_int, [c_int64, c_int32]),

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from .engine import ConvUnit, FuseFn
-from .heads import ResNetBasicHead
+from .heads import ResNetBasicHead, ResNetRoIHead
 from .registry import MODEL_REGISTRY
 from .resblocks import ResStage
 from .stems import VideoModelStem
@@ -104,8 +104,15 @@ class _ResNetBase(nn.Module):
             dilation=cfg.RESNET.SPATIAL_DILATIONS[idx], norm_module=self.norm_module)
 
     def _head(self, cfg, dim_in, frames):
-        assert not cfg.DETECTION.ENABLE, "ResNetRoIHead (AVA) is a 'next' row of the scope table"
         pool = _POOL1[cfg.MODEL.ARCH]
+        if cfg.DETECTION.ENABLE:              # video_model_builder.py:369-390, 611-622
+            P = len(dim_in)
+            return ResNetRoIHead(dim_in=dim_in, num_classes=cfg.MODEL.NUM_CLASSES,
+                                 pool_size=[[frames[p] // pool[p][0], 1, 1] for p in range(P)],
+                                 resolution=[[cfg.DETECTION.ROI_XFORM_RESOLUTION] * 2] * P,
+                                 scale_factor=[cfg.DETECTION.SPATIAL_SCALE_FACTOR] * P,
+                                 dropout_rate=cfg.MODEL.DROPOUT_RATE, act_func=cfg.MODEL.HEAD_ACT,
+                                 aligned=cfg.DETECTION.ALIGNED, detach_final_fc=cfg.MODEL.DETACH_FINAL_FC)
         if cfg.MULTIGRID.SHORT_CYCLE or cfg.MODEL.MODEL_NAME == "ContrastiveModel":
             pool_size = [None] * len(dim_in)
         else:
@@ -178,7 +185,7 @@ class SlowFast(_ResNetBase):
         x = self.s3_fuse(self.s3(x))
         x = self.s4_fuse(self.s4(x))
         x = self.s5(x)
-        return self.head(x)
+        return self.head(x, bboxes) if self.enable_detection else self.head(x)
 
 
 @MODEL_REGISTRY.register()
@@ -218,4 +225,4 @@ class ResNet(_ResNetBase):
         if tuple(pool.kernel_size) != (1, 1, 1):
             x[0] = pool(x[0])
         x = self.s5(self.s4(self.s3(x)))
-        return self.head(x)
+        return self.head(x, bboxes) if self.enable_detection else self.head(x)

@@ -233,3 +233,26 @@ def check_bn_finalize_long(device, nblk, C, seed=0):
     sg, sgy = s.double().sum(0), q.double().sum(0)
     assert_close("bwd dbeta", dbeta.cpu(), sg.float(), 1e-6)
     assert_close("bwd dgamma", dgamma.cpu(), (rstd * (sgy - mean * sg)).float(), 1e-5)
+
+
+def check_roi_pool(device, shape=(2, 16, 3, 10, 12), aligned=True, seed=0):
+    """AvgPool3d([T,1,1]) -> ROIAlign(7x7, 1/16, adaptive sampling) -> MaxPool2d(7) forward and backward
+    (sf_tmean_*, sf_roi_align_max_*) against the oracle's ROIAlign restatement, incl. boxes that leave the map."""
+    from oracle import video_ref
+    from slowfast_amd.heads import _RoiPoolFn
+    g = torch.Generator().manual_seed(seed)
+    N, C, T, H, W = shape
+    x = torch.randn(shape, generator=g).half().float()
+    S = 16.0 * max(H, W)
+    rois = torch.tensor([[0, 0.06 * S, 0.12 * S, 0.8 * S, 0.7 * S], [N - 1, 0., 0., 16. * W - 1, 16. * H - 1],
+                         [N - 1, 0.3 * S, 0.2 * S, 0.45 * S, 0.36 * S], [0, -0.1 * S, 0.15 * S, 0.4 * S, 1.5 * S],
+                         [0, 0.5 * S, 0.5 * S, 0.5 * S + 3.0, 0.5 * S + 2.0]])
+    xr = x.clone().requires_grad_(True)
+    ref = video_ref.roi_align(xr.mean(2), rois, (7, 7), 1 / 16., 0, aligned).amax((2, 3))
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    xc = host_to_cl(x, device).requires_grad_(True)
+    out = _RoiPoolFn.apply(xc, rois.to(device), 7, 1 / 16., aligned)
+    (out * w.to(device)).sum().backward()
+    assert_close("roi pooled", out.cpu(), ref.detach(), 1e-5)
+    assert_close("roi d(features)", cl_to_host(xc.grad), xr.grad, 2 * F16_EPS)

@@ -31,6 +31,27 @@ def family(cfg):
     return mvit_ref if cfg.MODEL.MODEL_NAME == "MViT" else video_ref
 
 
+class _WithBoxes(list):
+    """The clip list of a detection batch, carrying its (R, 5) boxes."""
+
+    def __init__(self, clips, bboxes):
+        super().__init__(clips)
+        self.bboxes = bboxes
+
+
+def _loss(logits, labels, inputs):
+    if isinstance(inputs, _WithBoxes):                  # "bce" on the activated outputs (losses.py:61-69)
+        return torch.nn.functional.binary_cross_entropy(logits.float(), labels.to(logits.device))
+    return torch.nn.functional.cross_entropy(logits.float(), labels.to(logits.device))
+
+
+def _forward(model, inputs, device):
+    clips = [x.to(device) for x in inputs]
+    if isinstance(inputs, _WithBoxes):
+        return model(clips, inputs.bboxes.to(device))
+    return model(clips)
+
+
 def oracle_run(gold, cfg):
     model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)   # only used for the state_dict shapes
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -39,7 +60,15 @@ def oracle_run(gold, cfg):
     if "final_bn_gamma_scale" in gold.get("state_tweaks", {}):
         video_ref.scale_final_bn(sd, gold["state_tweaks"]["final_bn_gamma_scale"])
     inputs, labels = video_ref.synthetic_batch(cfg, gold["batch"], gold["data_seed"])
-    logits, loss, grads, stats = fam.loss_and_grads(sd, cfg, inputs, labels)
+    bboxes = None
+    if gold.get("state_tweaks", {}).get("boxes"):      # detection head: boxes + multi-hot labels (make_golden.py)
+        bboxes = video_ref.synthetic_boxes(cfg, gold["batch"], seed=77, per_clip=gold["state_tweaks"]["boxes"])
+        g = torch.Generator().manual_seed(78)
+        labels = (torch.rand((bboxes.shape[0], cfg.MODEL.NUM_CLASSES), generator=g) < 0.2).float()
+        inputs = _WithBoxes(inputs, bboxes)
+        logits, loss, grads, stats = fam.loss_and_grads(sd, cfg, list(inputs), labels, bboxes=bboxes)
+    else:
+        logits, loss, grads, stats = fam.loss_and_grads(sd, cfg, inputs, labels)
     return model, sd, inputs, labels, logits, loss, grads, stats
 
 
@@ -85,7 +114,10 @@ def storage_model_yardstick(name, sd, cfg, inputs, labels, o_logits, o_loss, o_g
     if name in _yard_cache:
         return _yard_cache[name]
     with video_ref.fp16_storage_model():
-        logits, loss, grads, stats = family(cfg).loss_and_grads(sd, cfg, inputs, labels)
+        if isinstance(inputs, _WithBoxes):
+            logits, loss, grads, stats = family(cfg).loss_and_grads(sd, cfg, list(inputs), labels, bboxes=inputs.bboxes)
+        else:
+            logits, loss, grads, stats = family(cfg).loss_and_grads(sd, cfg, inputs, labels)
     ogn = float(video_ref.grad_norm(o_grads))
     y = {
         "logits": float((logits - o_logits).abs().max() / o_logits.abs().max()),
@@ -112,8 +144,8 @@ def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, t
     yard = storage_model_yardstick(name, sd, cfg, inputs, labels, o_logits, o_loss, o_grads, o_stats)
     model.load_state_dict(sd)
     model = model.to(device).train()
-    logits = model([x.to(device) for x in inputs])
-    loss = torch.nn.functional.cross_entropy(logits.float(), labels.to(device))
+    logits = _forward(model, inputs, device)
+    loss = _loss(logits, labels, inputs)
     (loss * loss_scale).backward()
     res = {}
     res["logits"] = float((logits.detach().float().cpu() - o_logits).abs().max() / o_logits.abs().max())

@@ -113,3 +113,10 @@ def test_wgrad_many_splits(gpu):
     kc.check_conv_wgrad(gpu, (4, 8, 16, 56, 56), 8, (1, 1, 1), (1, 1, 1), (0, 0, 0))
     kc.check_conv_wgrad(gpu, (4, 32, 16, 56, 56), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0))
     kc.check_conv_wgrad(gpu, (4, 8, 16, 56, 56), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+
+
+@pytest.mark.parametrize("aligned", [True, False])
+def test_roi_pool(gpu, aligned):
+    """RoI head pooling (temporal mean -> ROIAlign -> max) vs the oracle's ROIAlign restatement."""
+    kc.check_roi_pool(gpu, aligned=aligned)
+    kc.check_roi_pool(gpu, shape=(4, 256, 8, 16, 16), aligned=aligned, seed=3)

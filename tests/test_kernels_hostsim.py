@@ -107,3 +107,8 @@ def test_wgrad_many_splits(sim):
     """Tiny-channel layer with a long position axis: many split partials, multi-lane reduce kernel."""
     kc.check_conv_wgrad(sim, (2, 8, 8, 24, 24), 8, (1, 1, 1), (1, 1, 1), (0, 0, 0))
     kc.check_conv_wgrad(sim, (1, 8, 4, 32, 32), 32, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+
+
+@pytest.mark.parametrize("aligned", [True, False])
+def test_roi_pool(sim, aligned):
+    kc.check_roi_pool(sim, aligned=aligned)
