@@ -32,10 +32,20 @@ def main():
     rows.sort(key=lambda r: -r[0])
     with open(out, "w") as f:
         f.write(f"# {title}\n\nsource: rocprofv3 --pmc {' '.join(counters)} (per-dispatch samples averaged per kernel)\n\n")
-        f.write("| kernel | dispatches | " + " | ".join(counters) + " |\n|---|---:|" + "---:|" * len(counters) + "\n")
+        derived = "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "GRBM_GUI_ACTIVE" in counters
+        if derived:
+            f.write("MfmaUtil % = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 128): MFMA-busy cycles summed over the 1024 "
+                    "SIMDs against the kernel's active cycles (GRBM_GUI_ACTIVE is the sum over the 8 XCDs: a 53 us kernel "
+                    "reads ~1.0 M at 2.4 GHz), i.e. the gfx94x MfmaUtil formula written for 8 XCDs x 32 CUs x 4 SIMDs.\n\n")
+        f.write("| kernel | dispatches | " + " | ".join(counters) + (" | MfmaUtil % |" if derived else " |") + "\n|---|---:|"
+                + "---:|" * (len(counters) + int(derived)) + "\n")
         for n, k, m in rows[:40]:
             name = k if len(k) <= 90 else k[:87] + "..."
-            f.write(f"| `{name}` | {n} | " + " | ".join(f"{m.get(c, float('nan')):.2f}" for c in counters) + " |\n")
+            line = f"| `{name}` | {n} | " + " | ".join(f"{m.get(c, float('nan')):.0f}" for c in counters)
+            if derived:
+                g = m.get("GRBM_GUI_ACTIVE", 0.0)
+                line += f" | {100.0 * m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (g * 128.0):.1f}" if g else " | -"
+            f.write(line + " |\n")
     print(open(out).read()[:3000])
 
 
