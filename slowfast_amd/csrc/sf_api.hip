@@ -317,7 +317,8 @@ static WgradPlan plan_wgrad(const sf_conv_desc* d) {
     w.Co_pad = w.tiles_c * w.BMW;
     w.nchunks = cdiv(M, 32);
     const int64_t slab = (int64_t)w.Co_pad * w.Kpad * 4;
-    int splits = cdiv(1024, (int64_t)w.tiles_k * w.tiles_c);
+    static const int target = getenv("SF_WGRAD_BLOCKS") ? atoi(getenv("SF_WGRAD_BLOCKS")) : 1024;   // A/B knob
+    int splits = cdiv(target, (int64_t)w.tiles_k * w.tiles_c);
     const int64_t cap = (256ll << 20) / slab;            // keep the workspace <= 256 MiB
     if (splits > cap) splits = (int)(cap < 1 ? 1 : cap);
     const int nstages = cdiv(w.nchunks, w.KS);
@@ -454,7 +455,8 @@ extern "C" int sf_bn_act(int64_t M, int32_t C, const void* y, int32_t ldy, const
     return check_launch("bn_act");
 }
 
-static const int kBwdBlocks = 1024;
+// row blocks of the BatchNorm-backward reduce (= rows of its partial table); SF_BN_BWD_BLOCKS is an A/B knob
+static const int kBwdBlocks = getenv("SF_BN_BWD_BLOCKS") ? atoi(getenv("SF_BN_BWD_BLOCKS")) : 1024;
 extern "C" int sf_bn_bwd_blocks(int64_t M, int32_t C) {
     if (check_rows("sf_bn_bwd_blocks", M, C)) return -1;
     dim3 grid;
