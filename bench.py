@@ -167,7 +167,7 @@ def cpu_baseline(cfg, clips, threads=0):
         fam.loss_and_grads(sd, cfg, inputs, labels, **kw)
         best = min(best, time.perf_counter() - t0)
     return {"value": clips / best, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{clips} clips x (fwd + cross-entropy + bwd), best of {iters} timed iterations after 1 warm-up, "
+            "sample": f"{clips} clips x (fwd + {cfg.MODEL.LOSS_FUNC} loss + bwd), best of {iters} timed iterations after 1 warm-up, "
                       f"torch {torch.__version__} CPU fp32"}
 
 
