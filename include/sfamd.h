@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 10
+#define SF_ABI_VERSION 11
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -239,6 +239,12 @@ int sf_roi_align_max_fwd(int32_t R, int32_t B, int32_t H, int32_t W, int32_t C, 
 int sf_roi_align_max_bwd(int32_t R, int32_t B, int32_t H, int32_t W, int32_t C, int32_t res, float scale, int32_t aligned,
                          const float* rois, const float* dout, int32_t lddo, int32_t col0, const void* argmax, float* dm,
                          sf_stream_t stream);
+/* Linear layers of the Mlp with the GELU fused into the GEMM epilogue (slowfast/models/common.py:25-34):
+ *   mode 1 (fc1 forward):   Y = A W^T + bias,  aux = gelu(Y)        (Y is kept for the backward)
+ *   mode 2 (fc2 data grad):  Y = (A W^T) * gelu'(aux)                (aux = the saved pre-activation)
+ * A [M][K], W [N][K], Y / aux [M][N] fp16, row pitches in elements. */
+int sf_gemm_act(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias,
+                void* Y, int32_t ldy, int32_t mode, void* aux, int32_t ldaux, sf_stream_t stream);
 /* Stochastic depth -- replaces drop_path() (slowfast/models/common.py:46-59) at the two residual additions of
  * MultiScaleBlock (attention.py:500-510): y[m] = (resid ? resid[m] : 0) + scale[m / rows_per_sample] * x[m], with
  * scale[b] = floor(keep_prob + u_b) / keep_prob sampled by the caller.  Rows are fp16 [M][C], C % 8 == 0. */

@@ -660,6 +660,31 @@ extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t 
     return check_launch("bgemm");
 }
 
+extern "C" int sf_gemm_act(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
+                           const float* bias, void* Y, int32_t ldy, int32_t mode, void* aux, int32_t ldaux,
+                           sf_stream_t stream) {
+    REQUIRE(A && W && Y && aux, "sf_gemm_act: null pointer");
+    REQUIRE(M > 0 && M < (1ll << 31) && N > 0 && K > 0, "sf_gemm_act: bad shape");
+    REQUIRE(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 && ldaux % 8 == 0 && ldaux >= N,
+            "sf_gemm_act: N, K and the pitches must be multiples of 8");
+    REQUIRE(mode == 1 || mode == 2, "sf_gemm_act: mode must be 1 (write gelu(y)) or 2 (multiply by gelu'(aux))");
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.g = gather_matrix(A, M, K, lda);
+    p.M = (int)M;
+    p.wmat = (const f16*)W; p.ldw = ldw; p.Nout = N;
+    p.ksteps = cdiv(K, 32);
+    p.y = (f16*)Y; p.ldy = ldy; p.bias = bias;
+    p.bh = 1;
+    p.act_mode = mode; p.act_aux = (f16*)aux; p.ld_aux = ldaux;
+    hipStream_t s = (hipStream_t)stream;
+    if (N > 64) { p.ntiles_n = cdiv(N, 128); launch_igemm<128, 64, 64>(p, true, s, 1); }
+    else if (N > 32) { p.ntiles_n = 1; launch_igemm<64, 32, 64>(p, true, s, 1); }
+    else if (N > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, true, s, 1); }
+    else { p.ntiles_n = 1; launch_igemm<16, 32, 16>(p, true, s, 1); }
+    return check_launch("gemm_act");
+}
+
 extern "C" int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int32_t ldp, const void* X, int32_t ldx,
                            void* Out, int32_t ldo, float scale, int32_t nbatch, int32_t bh, int64_t sp_b, int64_t sp_h,
                            int64_t sx_b, int64_t sx_h, int64_t so_b, int64_t so_h, sf_stream_t stream) {

@@ -41,6 +41,12 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define SF_EXP2(x) __builtin_amdgcn_exp2f(x)
 #endif
 
+// GELU (exact, erf) and its derivative (nn.GELU, slowfast/models/common.py:17)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
 #define SF_WAVE 64
 #define SF_THREADS 256
 

@@ -29,6 +29,11 @@ struct IgemmParams {
     // batched GEMMs (attention): blockIdx.y = b*bh + j, operands advance by (b, j) strides (elements)
     int bh;
     int64_t sa_b, sa_h, sw_b, sw_h, sy_b, sy_h, sr_b, sr_h;
+    // fused activation epilogues of the Mlp (common.py:25-34): act_mode 1 writes act_aux = gelu(y) next to y (fc1),
+    // act_mode 2 multiplies y by gelu'(act_aux) (data gradient of fc2 -> gradient of fc1's output)
+    int act_mode;
+    f16* act_aux;
+    int ld_aux;
     int resid_row0;     // the residual is added to rows >= resid_row0 only (pooled attention: not to the cls row)
     float alpha;        // accumulators are scaled by alpha before bias / residual (0 means 1)
 };
@@ -296,7 +301,18 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)r[e]);
             }
+            if (p.act_mode == 2) {
+                const f16x8 h = ld16(p.act_aux + (int64_t)m * p.ld_aux + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * gelu_df((float)h[e]));
+            }
             st16(yout + (int64_t)m * p.ldy + col, v);
+            if (p.act_mode == 1) {
+                f16x8 a;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
+                st16(p.act_aux + (int64_t)m * p.ld_aux + col, a);
+            }
         }
     }
 }

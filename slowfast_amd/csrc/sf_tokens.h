@@ -242,10 +242,6 @@ __global__ __launch_bounds__(SF_THREADS) void sf_colsum_finalize_kernel(ColFinal
 
 // ------------------------------------------------------------------------------------------------
 // GELU (exact, erf) on contiguous fp16 arrays; n8 = number of 8-element groups.
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_df(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-}
 __global__ __launch_bounds__(SF_THREADS) void sf_gelu_fwd_kernel(const f16* h, f16* a, int64_t n8) {
     for (int64_t i = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; i < n8; i += (int64_t)gridDim.x * SF_THREADS) {
         f16x8 v = ld16(h + i * 8), o;

@@ -42,6 +42,23 @@ class LinearUnit:
         w, _ = self._ops(fresh=True)
         return tokens.gemm(x, w, bias=self.lin.bias, resid=resid, out=out)
 
+    def forward_gelu(self, x):
+        """(pre-activation, gelu(pre-activation)) with the GELU in the GEMM epilogue."""
+        w, _ = self._ops(fresh=True)
+        return tokens.gemm_gelu(x, w, bias=self.lin.bias)
+
+    def backward_through_gelu(self, x, dy, h):
+        """Like backward(), but returns d(loss)/d(h) for x = gelu(h): the data gradient times gelu'(h) in one GEMM."""
+        lin = self.lin
+        if lin.weight.requires_grad:
+            dw, zero_first = _grad_dest(lin.weight)
+            tokens.linear_wgrad(x, dy, dw, zero_first=zero_first)
+        if lin.bias is not None and lin.bias.requires_grad:
+            db, zero_first = _grad_dest(lin.bias)
+            tokens.bias_grad(dy, db, accumulate=not zero_first)
+        _, wt = self._ops()
+        return tokens.gemm_gelu_grad(dy, wt, h)
+
     def backward(self, x, dy, need_dx=True, resid=None, out=None):
         """weight/bias gradients into .grad; returns dx (+ resid)."""
         lin = self.lin
@@ -125,6 +142,8 @@ class AttentionPlan:
 # the dK/dV kernel) lost to the unfused chain, 414 vs 445 clips/s (profiles/r1_visit12_bench_mvit_*.json); with the
 # bias on the matrix cores, exp2, lazy rescale and the query split it wins, 488 vs 439 (profiles/r1_visit13_*).
 _FUSED_DEFAULT = "1"
+# GELU in the fc1 GEMM epilogue / gelu' in the fc2 data-gradient epilogue (SF_GELU_FUSED=0: separate elementwise passes)
+_FUSED_GELU = os.environ.get("SF_GELU_FUSED", "1") != "0"
 
 
 def _fused_attention(plan):
@@ -254,8 +273,11 @@ class MultiScaleBlockFn(torch.autograd.Function):
         else:                                              # x_res + drop_path(attention output), attention.py:500-502
             x1 = tokens.row_scale_add(att._proj.forward(o), drop[0], xres.shape[1], resid=xres)
         xn2, m2, r2 = mod._norm2.forward(x1)
-        h = mod.mlp._fc1.forward(xn2)
-        a = tokens.gelu_fwd(h)
+        if _FUSED_GELU:
+            h, a = mod.mlp._fc1.forward_gelu(xn2)
+        else:
+            h = mod.mlp._fc1.forward(xn2)
+            a = tokens.gelu_fwd(h)
         if drop is None:
             out = mod.mlp._fc2.forward(a, resid=x1)
         else:                                              # x + drop_path(mlp), attention.py:508-510
@@ -274,8 +296,12 @@ class MultiScaleBlockFn(torch.autograd.Function):
         dout = dout.contiguous() if dout.dtype == _f16 else dout.to(_f16).contiguous()
         drop = ctx.drop
         # Mlp
-        da = mod.mlp._fc2.backward(sv["a"], dout if drop is None else tokens.row_scale_add(dout, drop[1], dout.shape[1]))
-        dh = tokens.gelu_bwd(sv["h"], da)
+        dbr = dout if drop is None else tokens.row_scale_add(dout, drop[1], dout.shape[1])
+        if _FUSED_GELU:
+            dh = mod.mlp._fc2.backward_through_gelu(sv["a"], dbr, sv["h"])
+        else:
+            da = mod.mlp._fc2.backward(sv["a"], dbr)
+            dh = tokens.gelu_bwd(sv["h"], da)
         dxn2 = mod.mlp._fc1.backward(sv["xn2"], dh)
         dx1 = mod._norm2.backward(dxn2, sv["x1"], *sv["s2"], resid=dout)
         # attention output projection, attention core, qkv projection

@@ -59,6 +59,28 @@ def gemm(a, w16, bias=None, resid=None, out=None, alpha=0.0):
     return out
 
 
+def gemm_gelu(a, w16, bias=None):
+    """fc1 of the Mlp with the GELU in the GEMM epilogue: returns (h = a w^T + bias, gelu(h))."""
+    M, K, lda = rows_pitch(a)
+    N = w16.shape[0]
+    h = torch.empty(a.shape[:-1] + (N,), dtype=_f16, device=a.device)
+    act = torch.empty_like(h)
+    _lib_call("sf_gemm_act", M, N, K, a.data_ptr(), lda, w16.data_ptr(), w16.stride(0), _ptr(bias), h.data_ptr(), N, 1,
+              act.data_ptr(), N, _stream(a), work=dict(flops=2.0 * M * N * K, bytes=2.0 * (M * K + 2 * M * N + N * K)))
+    return h, act
+
+
+def gemm_gelu_grad(dy, wt16, h):
+    """Data gradient of fc2 times gelu'(h): d(loss)/d(fc1 output) in one GEMM."""
+    M, K, lda = rows_pitch(dy)
+    N = wt16.shape[0]
+    assert rows_pitch(h)[:2] == (M, N)
+    dh = torch.empty(h.shape, dtype=_f16, device=dy.device)
+    _lib_call("sf_gemm_act", M, N, K, dy.data_ptr(), lda, wt16.data_ptr(), wt16.stride(0), None, dh.data_ptr(), N, 2,
+              h.data_ptr(), rows_pitch(h)[2], _stream(dy), work=dict(flops=2.0 * M * N * K, bytes=2.0 * (M * K + 2 * M * N + N * K)))
+    return dh
+
+
 def bgemm_heads(a, a_strides, M, K, lda, w, w_strides, N, ldw, out, o_strides, ldy, B, heads, resid=None,
                 r_strides=(0, 0), ldr=0, resid_row0=0, alpha=0.0):
     """Per-(batch, head) GEMM: out[b,h][m][n] = sum_k a[b,h][m][k] * w[b,h][n][k] (+ resid).  *_strides = (per-batch,

@@ -53,3 +53,8 @@ def test_attention_core(gpu):
 def test_attention_fused(gpu, case):
     """sf_attn_fwd / sf_attn_bwd (no score tensor) vs the reference attention math incl. rel-pos table gradients."""
     tc.check_attention_fused(gpu, *case)
+
+
+def test_gemm_gelu_epilogues(gpu):
+    tc.check_gemm_gelu(gpu, 6273, 192, 768)
+    tc.check_gemm_gelu(gpu, 1000, 96, 384, seed=1)

@@ -50,3 +50,8 @@ def test_attention_core(sim):
 ])
 def test_attention_fused(sim, case):
     tc.check_attention_fused(sim, *case)
+
+
+def test_gemm_gelu_epilogues(sim):
+    tc.check_gemm_gelu(sim, 200, 96, 384)
+    tc.check_gemm_gelu(sim, 77, 32, 128, seed=1)

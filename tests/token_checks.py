@@ -224,3 +224,21 @@ def check_attention_fused(device, B, heads, D, q_thw, k_thw, cls=True, rel=True,
         for name, got, ref in zip(("d rel_pos_h", "d rel_pos_w", "d rel_pos_t"), dts, tr):
             assert_close("fused " + name, got.cpu(), ref.grad, 5e-3)
     assert_close("fused dQ", dq.float().cpu(), qr.grad, 6 * F16_EPS)
+
+
+def check_gemm_gelu(device, M, K, N, seed=0):
+    """sf_gemm_act: fc1 with the GELU in the epilogue (both outputs) and the fc2 data gradient times gelu'(h)."""
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn((M, K), generator=g) * 0.7).half().float()
+    w = (torch.randn((N, K), generator=g) * (1.0 / K ** 0.5)).half().float()
+    b = torch.randn(N, generator=g) * 0.2
+    h_ref = a @ w.t() + b
+    h, act = tokens.gemm_gelu(_h(a, device), _h(w, device), bias=b.to(device))
+    assert_close("fc1 pre-activation", h.float().cpu(), h_ref, 2 * F16_EPS)
+    assert_close("gelu(fc1)", act.float().cpu(), torch.nn.functional.gelu(h.float().cpu()), 2 * F16_EPS)
+    dy = torch.randn((M, K), generator=g).half().float()       # gradient w.r.t. an [M, K] output of a Linear(N -> K)
+    w2 = (torch.randn((K, N), generator=g) * (1.0 / N ** 0.5)).half().float()        # that Linear's weight [K, N]
+    hh = h.float().cpu().requires_grad_(True)
+    (torch.nn.functional.gelu(hh) @ w2.t()).backward(dy)
+    dh = tokens.gemm_gelu_grad(_h(dy, device), _h(w2.t().contiguous(), device), h)
+    assert_close("d(fc1 output)", dh.float().cpu(), hh.grad, 3 * F16_EPS)
