@@ -139,15 +139,28 @@ static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s, int nbatc
         hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, BN == 128>), grid, dim3(SF_THREADS), 0, s, p);
         return;
     }
-    if constexpr (BN == 128) {
-        if (occ4) {
-            if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, true>), grid, dim3(SF_THREADS), 0, s, p);
-            else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, true>), grid, dim3(SF_THREADS), 0, s, p);
-            return;
+    // strided data gradients keep the dividing gather; everything else runs the incremental (LEAN) loader
+    static const bool lean_off = getenv("SF_IGEMM_LEAN") && atoi(getenv("SF_IGEMM_LEAN")) == 0;
+    const bool lean = gather_is_lean(p.g) && !lean_off;
+    constexpr bool kCap = BN == 128;        // 128-VGPR cap only matters (and is only compiled) for the 128-wide tile
+    const bool cap = kCap && occ4;
+    if (!lean) {
+        if (pw) {
+            if (cap) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, kCap, false>), grid, dim3(SF_THREADS), 0, s, p);
+            else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, false, false>), grid, dim3(SF_THREADS), 0, s, p);
+        } else {
+            if (cap) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, kCap, false>), grid, dim3(SF_THREADS), 0, s, p);
+            else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, false, false>), grid, dim3(SF_THREADS), 0, s, p);
         }
+        return;
     }
-    if (pw) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true>), grid, dim3(SF_THREADS), 0, s, p);
-    else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false>), grid, dim3(SF_THREADS), 0, s, p);
+    if (pw) {
+        if (cap) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, kCap, true>), grid, dim3(SF_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, false, true>), grid, dim3(SF_THREADS), 0, s, p);
+    } else {
+        if (cap) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, kCap, true>), grid, dim3(SF_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, false, true>), grid, dim3(SF_THREADS), 0, s, p);
+    }
 }
 
 static int run_igemm(IgemmParams& p, bool pw, hipStream_t s) {

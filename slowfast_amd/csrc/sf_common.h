@@ -205,6 +205,73 @@ __device__ __forceinline__ bool gather_offset_pw(const GatherSide& g, const RowP
     return true;
 }
 
+// Incremental tap decomposition of the K axis for the GEMM loaders: a loader thread visits k0, k0 + 32, k0 + 64, ...
+// (one 8-channel slot per K step), so (tap, channel) advance by carries instead of divisions, and a source position is
+// rowpos + dpos with one 32x32->64 multiply for the byte offset.  Valid for forward gathers (mode 0, any stride) and for
+// data-gradient gathers with unit strides (mode 1); strided data gradients need the divisions of gather_offset().
+struct TapIter {
+    int k0, c0, kt, kh, kw;
+    int dt, dh, dw, dpos;
+};
+__device__ __forceinline__ void tap_set_deltas(const GatherSide& g, TapIter& it) {
+    const int sgn = g.mode == 0 ? 1 : -1;
+    it.dt = sgn * it.kt * g.dilT;
+    it.dh = sgn * it.kh * g.dilH;
+    it.dw = sgn * it.kw * g.dilW;
+    it.dpos = (it.dt * g.sH + it.dh) * g.sW + it.dw;
+}
+__device__ __forceinline__ void tap_init(const GatherSide& g, TapIter& it, uint32_t k0) {
+    uint32_t tap, c0, q, kw, kt, kh;
+    fd_divmod(k0 < (uint32_t)g.Ktot ? k0 : 0u, g.fdC, tap, c0);
+    fd_divmod(tap, g.fdkW, q, kw);
+    fd_divmod(q, g.fdkH, kt, kh);
+    it.k0 = (int)k0; it.c0 = (int)c0; it.kt = (int)kt; it.kh = (int)kh; it.kw = (int)kw;
+    tap_set_deltas(g, it);
+}
+__device__ __forceinline__ void tap_next(const GatherSide& g, TapIter& it) {
+    it.k0 += 32;
+    it.c0 += 32;
+    if (it.c0 >= g.C) {
+        do {
+            it.c0 -= g.C;
+            if (++it.kw == g.kW) {
+                it.kw = 0;
+                if (++it.kh == g.kH) { it.kh = 0; ++it.kt; }
+            }
+        } while (it.c0 >= g.C);
+        tap_set_deltas(g, it);
+    }
+}
+// a loader row: linear source position of its base point and the base coordinates for the bounds checks
+struct RowLean {
+    int pos, bt, bh, bw;
+    bool valid;
+};
+__device__ __forceinline__ RowLean lean_row(const GatherSide& g, uint32_t row, bool valid) {
+    const RowPos r = decode_row(g, valid ? row : 0u, valid);
+    RowLean l;
+    l.bt = r.bt; l.bh = r.bh; l.bw = r.bw; l.valid = valid;
+    l.pos = ((r.n * g.sT + r.bt) * g.sH + r.bh) * g.sW + r.bw;
+    return l;
+}
+static inline bool gather_is_lean(const GatherSide& g) {
+    return g.mode == 0 || (g.strT == 1 && g.strH == 1 && g.strW == 1);
+}
+
+// y = max(lo, x*scale + shift) on 8 consecutive channels (lo = 0: ReLU, -inf: none), fp32 math, tables in LDS read as
+// four 16-byte vectors
+__device__ __forceinline__ f16x8 bn_act8(f16x8 v, const float* sc, const float* sh, float lo) {
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh), h1 = *reinterpret_cast<const f32x4*>(sh + 4);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] = (f16)fmaxf((float)v[e] * s0[e] + h0[e], lo);
+        o[e + 4] = (f16)fmaxf((float)v[e + 4] * s1[e] + h1[e], lo);
+    }
+    return o;
+}
+
 // y = max(0, x*scale + shift) on 8 consecutive channels, fp32 math, tables in LDS.
 __device__ __forceinline__ f16x8 bn_relu8(f16x8 v, const float* sc, const float* sh, int relu) {
     f16x8 o;

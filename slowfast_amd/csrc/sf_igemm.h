@@ -46,7 +46,10 @@ struct IgemmParams {
 // to the last valid row (their results are never stored).
 // (A second register stage, "PF2", was measured and removed: +90 VGPRs, one resident workgroup, SlowFast 383 vs 507
 // clips/s -- profiles/r1_visit7_*_pf2.json.)
-template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false>
+// LEAN = the register-staged loader advances its tap decomposition incrementally (TapIter) instead of dividing in every K
+// step: the gather was ~650 VALU instructions per K step against 16 MFMAs (VALU-bound by ~10x); false only for strided
+// data gradients.
+template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false, bool LEAN = true>
 __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(IgemmParams p) {
     constexpr int BM = 128, BK = 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
@@ -99,13 +102,29 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
     // loader assignment: A rows (tid>>2) and (tid>>2)+64, 16-byte slot tid&3
     const int kq = tid & 3;
     RowPos rp[2];
+    RowLean rl[2];
+    TapIter it;
+    const f16* wptr[NB];
+    bool wok[NB];
     if constexpr (!GL) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int row = m0 + (tid >> 2) + 64 * j;
-            rp[j] = PW ? decode_row_pw(g, (uint32_t)row, row < p.M) : decode_row(g, (uint32_t)row, row < p.M);
+            if constexpr (LEAN) rl[j] = lean_row(g, (uint32_t)row, row < p.M);
+            else rp[j] = PW ? decode_row_pw(g, (uint32_t)row, row < p.M) : decode_row(g, (uint32_t)row, row < p.M);
+        }
+        if constexpr (LEAN) {
+            tap_init(g, it, (uint32_t)(kq * 8));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int idx = tid + SF_THREADS * j;
+                const int co = n0 + (idx >> 2);
+                wok[j] = (idx < BN * 4) && (co < p.Nout);
+                wptr[j] = wmat + (wok[j] ? (int64_t)co * p.ldw : 0) + kq * 8;
+            }
         }
     }
+    const float act_lo = g.relu ? 0.f : -INFINITY;
     // GL: wave w copies the 16-row chunks w and w + 4 of the A tile and chunks w, w + 4, ... of the B tile
     constexpr int NBC = (BN / 16 + 3) / 4;
     const f16* ga[2];
@@ -141,30 +160,49 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
     struct Stage {
         f16x8 ra[2], rb[NB];
         bool ok[2];
-        uint32_t c0[2];
+        uint32_t c0;
     };
     Stage st0;
 
     auto load_tile = [&](int ks, Stage& st) {
-        const uint32_t k0 = (uint32_t)(ks * BK + kq * 8);
+        if constexpr (LEAN) {
+            // called for ks = 0, 1, 2, ... in order: `it` holds the (tap, channel) of this thread's slot at step ks
+            const bool kin = it.k0 < g.Ktot;
+            const int t0 = it.dt, h0 = it.dh, w0 = it.dw;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int64_t off;
-            uint32_t c0 = 0;
-            bool ok = PW ? gather_offset_pw(g, rp[j], k0, off, c0) : gather_offset(g, rp[j], k0, off, c0);
-            // masked lanes issue no request (measured: an unconditional clamped load + select is 8-13 % SLOWER here,
-            // profiles/r1_visit9_*; the four loads of a stage are in flight together either way)
-            st.ra[j] = ok ? ld16(a_src + off) : zero8();
-            st.ok[j] = ok;
-            st.c0[j] = c0;
-        }
+            for (int j = 0; j < 2; ++j) {
+                bool ok = rl[j].valid && kin && (unsigned)(rl[j].bt + t0) < (unsigned)g.sT;
+                if constexpr (!PW)
+                    ok = ok && (unsigned)(rl[j].bh + h0) < (unsigned)g.sH && (unsigned)(rl[j].bw + w0) < (unsigned)g.sW;
+                const int64_t off = (int64_t)(rl[j].pos + it.dpos) * g.ld + it.c0;
+                // masked lanes issue no request (measured: an unconditional clamped load + select is 8-13 % SLOWER
+                // here, profiles/r1_visit9_*; the four loads of a stage are in flight together either way)
+                st.ra[j] = ok ? ld16(a_src + off) : zero8();
+                st.ok[j] = ok;
+            }
+            st.c0 = (uint32_t)it.c0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            int idx = tid + SF_THREADS * j;
-            int brow = idx >> 2;
-            int co = n0 + brow;
-            bool ok = (idx < BN * 4) && (co < p.Nout) && (k0 < (uint32_t)g.Ktot);
-            st.rb[j] = ok ? ld16(wmat + (int64_t)co * p.ldw + k0) : zero8();
+            for (int j = 0; j < NB; ++j) st.rb[j] = (wok[j] && kin) ? ld16(wptr[j] + ks * BK) : zero8();
+            tap_next(g, it);
+        } else {
+            const uint32_t k0 = (uint32_t)(ks * BK + kq * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int64_t off;
+                uint32_t c0 = 0;
+                bool ok = PW ? gather_offset_pw(g, rp[j], k0, off, c0) : gather_offset(g, rp[j], k0, off, c0);
+                st.ra[j] = ok ? ld16(a_src + off) : zero8();
+                st.ok[j] = ok;
+                if (ok) st.c0 = c0;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                int idx = tid + SF_THREADS * j;
+                int brow = idx >> 2;
+                int co = n0 + brow;
+                bool ok = (idx < BN * 4) && (co < p.Nout) && (k0 < (uint32_t)g.Ktot);
+                st.rb[j] = ok ? ld16(wmat + (int64_t)co * p.ldw + k0) : zero8();
+            }
         }
     };
     auto store_tile = [&](int buf, const Stage& st) {
@@ -173,7 +211,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             f16x8 v = st.ra[j];
-            if (has_tf && st.ok[j]) v = bn_relu8(v, s_scale + st.c0[j], s_shift + st.c0[j], g.relu);
+            if (has_tf && st.ok[j]) v = bn_act8(v, s_scale + st.c0, s_shift + st.c0, act_lo);
             st16(As + lds_tile_off((tid >> 2) + 64 * j, kq), v);
         }
 #pragma unroll
