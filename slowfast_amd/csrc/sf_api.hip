@@ -139,9 +139,11 @@ static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s, int nbatc
         hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, BN == 128>), grid, dim3(SF_THREADS), 0, s, p);
         return;
     }
-    // strided data gradients keep the dividing gather; everything else runs the incremental (LEAN) loader
-    static const bool lean_off = getenv("SF_IGEMM_LEAN") && atoi(getenv("SF_IGEMM_LEAN")) == 0;
-    const bool lean = gather_is_lean(p.g) && !lean_off;
+    // The incremental (LEAN) loader is an A/B option (SF_IGEMM_LEAN=1): measured 3 % SLOWER than the dividing gather on
+    // SlowFast (594 vs 614 clips/s, profiles/r1_visit19_ab.txt) -- hipcc already hoists / strength-reduces the divisions,
+    // and the iterator's carried state costs more scalar work and registers than it saves.
+    static const bool lean_on = getenv("SF_IGEMM_LEAN") && atoi(getenv("SF_IGEMM_LEAN")) != 0;
+    const bool lean = gather_is_lean(p.g) && lean_on;
     constexpr bool kCap = BN == 128;        // 128-VGPR cap only matters (and is only compiled) for the 128-wide tile
     const bool cap = kCap && occ4;
     if (!lean) {

@@ -47,9 +47,8 @@ struct IgemmParams {
 // (A second register stage, "PF2", was measured and removed: +90 VGPRs, one resident workgroup, SlowFast 383 vs 507
 // clips/s -- profiles/r1_visit7_*_pf2.json.)
 // LEAN = the register-staged loader advances its tap decomposition incrementally (TapIter) instead of dividing in every K
-// step: the gather was ~650 VALU instructions per K step against 16 MFMAs (VALU-bound by ~10x); false only for strided
-// data gradients.
-template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false, bool LEAN = true>
+// step.  An experiment kept behind SF_IGEMM_LEAN=1: it measured 3 % slower end to end than the dividing gather.
+template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false, bool LEAN = false>
 __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(IgemmParams p) {
     constexpr int BM = 128, BK = 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
