@@ -487,8 +487,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
     constexpr int NX = 2 * KS;
 
     __shared__ __attribute__((aligned(16))) f16 smem[NBUF * BUF];
-    __shared__ float s_scale[512];
-    __shared__ float s_shift[512];
+    __shared__ __attribute__((aligned(16))) float s_scale[512];
+    __shared__ __attribute__((aligned(16))) float s_shift[512];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             f16x8 v = rb[j];
-            if (has_tf && rb_ok[j]) v = bn_relu8(v, s_scale + tp.c0, s_shift + tp.c0, g.relu);
+            if (has_tf && rb_ok[j]) v = bn_act8(v, s_scale + tp.c0, s_shift + tp.c0, g.relu ? 0.f : -INFINITY);
             st16(Xs + ((tid >> 4) + 16 * j) * LDB + (tid & 15) * 8, v);
         }
     };
