@@ -266,9 +266,12 @@ __device__ __forceinline__ f16x8 bn_act8(f16x8 v, const float* sc, const float* 
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        o[e] = (f16)fmaxf((float)v[e] * s0[e] + h0[e], lo);
-        o[e + 4] = (f16)fmaxf((float)v[e + 4] * s1[e] + h1[e], lo);
+        o[e] = (f16)((float)v[e] * s0[e] + h0[e]);
+        o[e + 4] = (f16)((float)v[e + 4] * s1[e] + h1[e]);
     }
+    // ReLU after the fp16 rounding (rounding is monotonic and keeps the sign, so max(round(x), 0) == round(max(x, 0))):
+    // four packed fp16 max instead of eight fp32 ones
+    if (lo == 0.f) o = __builtin_elementwise_max(o, zero8());
     return o;
 }
 
