@@ -85,6 +85,15 @@ __device__ __forceinline__ f16x8 attn_tr_frag(const f16* s, int KP, int col0, in
     return a;
 }
 
+// q (or k) times scale * log2(e), rounded to fp16 once (what the reference's `q * self.scale` does under autocast): the
+// S^T accumulators then hold the scaled logits and the bias MFMAs chain onto them -- no per-score multiply-add
+__device__ __forceinline__ f16x8 attn_scale8(f16x8 v, float s) {
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)((float)v[e] * s);
+    return o;
+}
+
 // 8 consecutive fp32 (times log2 e) -> fp16 hi / lo parts; elements with index >= n are zero
 __device__ __forceinline__ void attn_split8(const float* src, int n, bool on, f16x8& hi, f16x8& lo) {
 #pragma unroll
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
         const int qc = qrow[u] < p.Nq ? qrow[u] : p.Nq - 1;
         qptr[u] = p.q + ((int64_t)b * p.Nq + qc) * p.ldq + head * D;
 #pragma unroll
-        for (int s = 0; s < KD; ++s) qf[u][s] = ld16(qptr[u] + 32 * s + 8 * g);
+        for (int s = 0; s < KD; ++s) qf[u][s] = attn_scale8(ld16(qptr[u] + 32 * s + 8 * g), p.scale2);
         const bool on = bias && qc >= p.cls;
         const float* rqrow = p.rq + (((int64_t)b * p.Nq + qc) * p.heads + head) * p.R;
 #pragma unroll
@@ -162,12 +171,9 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
         float x[QT][8];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 st[QT], bt[QT];
+            f32x4 st[QT];
 #pragma unroll
-            for (int u = 0; u < QT; ++u) {
-                st[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                bt[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            for (int u = 0; u < QT; ++u) st[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
                 const f16x8 kf = ld16(Ks + (16 * t + pl) * KP + 32 * s + 8 * g);
@@ -178,22 +184,22 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
                 const f16x8 a0 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
 #pragma unroll
                 for (int u = 0; u < QT; ++u) {
-                    bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[u][0], bt[u], 0, 0, 0);
-                    bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[u][0], bt[u], 0, 0, 0);
+                    st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[u][0], st[u], 0, 0, 0);
+                    st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[u][0], st[u], 0, 0, 0);
                 }
                 if (bias2) {
                     const f16x8 a1 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
 #pragma unroll
                     for (int u = 0; u < QT; ++u) {
-                        bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[u][1], bt[u], 0, 0, 0);
-                        bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[u][1], bt[u], 0, 0, 0);
+                        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[u][1], st[u], 0, 0, 0);
+                        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[u][1], st[u], 0, 0, 0);
                     }
                 }
             }
 #pragma unroll
             for (int u = 0; u < QT; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[u][4 * t + r] = st[u][r] * p.scale2 + bt[u][r];
+                for (int r = 0; r < 4; ++r) x[u][4 * t + r] = st[u][r];
         }
         if (c == nch - 1) {
 #pragma unroll
@@ -296,6 +302,8 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
         d += __shfl_xor(d, 16);
         d += __shfl_xor(d, 32);
         dl[u] = d;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) qf[u][s] = attn_scale8(qf[u][s], p.scale2);      // from here on only S^T uses q
         lse[u] = p.lse[(int64_t)bh * p.Nq + qc];
         if (qok && g == 0) p.delta[(int64_t)bh * p.Nq + qrow[u]] = d;
         const bool on = bias && qc >= p.cls;
@@ -337,11 +345,10 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
         f16x8 dsf[QT];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 st[QT], bt[QT], dp[QT];
+            f32x4 st[QT], dp[QT];
 #pragma unroll
             for (int u = 0; u < QT; ++u) {
                 st[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                bt[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 dp[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -358,15 +365,15 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
                 const f16x8 a0 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
 #pragma unroll
                 for (int u = 0; u < QT; ++u) {
-                    bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[u][0], bt[u], 0, 0, 0);
-                    bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[u][0], bt[u], 0, 0, 0);
+                    st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[u][0], st[u], 0, 0, 0);
+                    st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[u][0], st[u], 0, 0, 0);
                 }
                 if (bias2) {
                     const f16x8 a1 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
 #pragma unroll
                     for (int u = 0; u < QT; ++u) {
-                        bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[u][1], bt[u], 0, 0, 0);
-                        bt[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[u][1], bt[u], 0, 0, 0);
+                        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[u][1], st[u], 0, 0, 0);
+                        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[u][1], st[u], 0, 0, 0);
                     }
                 }
             }
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
                 const bool kin = c * 32 + 16 * t + 4 * g + r < p.Nk;
 #pragma unroll
                 for (int u = 0; u < QT; ++u) {
-                    const float pv = kin ? SF_EXP2(st[u][r] * p.scale2 + bt[u][r] - lse[u]) : 0.f;
+                    const float pv = kin ? SF_EXP2(st[u][r] - lse[u]) : 0.f;
                     dsf[u][4 * t + r] = (f16)(pv * (dp[u][r] - dl[u]));
                 }
             }
@@ -451,7 +458,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
     f16x8 kf[KD], vf[KD];
 #pragma unroll
     for (int s = 0; s < KD; ++s) {
-        kf[s] = ld16(kptr + 32 * s + 8 * g);
+        kf[s] = attn_scale8(ld16(kptr + 32 * s + 8 * g), p.scale2);      // only S = Q K^T uses the wave's own key rows
         vf[s] = ld16(vptr + 32 * s + 8 * g);
     }
     const bool bias = p.R > 0, bias2 = p.R > 32;
@@ -530,24 +537,24 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
         f16x8 pf, dsf;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
                 st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Qs + (16 * t + pl) * KP + 32 * s + 8 * g), kf[s], st, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Os + (16 * t + pl) * KP + 32 * s + 8 * g), vf[s], dp, 0, 0, 0);
             }
             if (bias) {
-                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], bt, 0, 0, 0);
-                bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], bt, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], st, 0, 0, 0);
                 if (bias2) {
-                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], bt, 0, 0, 0);
-                    bt = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], bt, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], st, 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = 16 * t + 4 * g + r;
-                const float pv = c * 32 + qi < p.Nq ? SF_EXP2(st[r] * p.scale2 + bt[r] - s_lse[qi]) : 0.f;
+                const float pv = c * 32 + qi < p.Nq ? SF_EXP2(st[r] - s_lse[qi]) : 0.f;
                 pf[4 * t + r] = (f16)pv;
                 dsf[4 * t + r] = (f16)(pv * (dp[r] - s_delta[qi]));
             }
