@@ -889,6 +889,25 @@ static void dw_block_plan(DwParams& p, DwBlockIdx& bi, const sf_dw_desc* d, bool
         else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_MAX_W>), grid, dim3(SF_THREADS), 0, s, p, bi);     \
         else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, s, p, bi);                    \
     } while (0)
+// forward / data-gradient stencils: PF = one-plane software prefetch (SF_DW_PREFETCH=0 selects the plain loop)
+#define SF_DW_DISPATCH_PF(kind, KERNEL, grid, s, p, bi)                                                                 \
+    do {                                                                                                                  \
+        static const bool pf_ = !(getenv("SF_DW_PREFETCH") && atoi(getenv("SF_DW_PREFETCH")) == 0);                      \
+        const bool small_w = (p).kT * (p).kH * (p).kW * (p).Cw <= SF_DW_SMALL_W;                                        \
+        if (pf_) {                                                                                                        \
+            if ((kind) == 1 && small_w) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+            else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_MAX_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+            else if ((kind) == 2 && small_w) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_SMALL_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+            else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_MAX_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+            else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi);            \
+        } else {                                                                                                          \
+            if ((kind) == 1 && small_w) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+            else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_MAX_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+            else if ((kind) == 2 && small_w) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_SMALL_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+            else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_MAX_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+            else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi);           \
+        }                                                                                                                 \
+    } while (0)
 extern "C" int sf_dwconv_fwd_blocks(const sf_dw_desc* d) {
     DwParams p;
     dim3 grid;
@@ -910,7 +929,7 @@ extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w,
     if (kind) {
         DwBlockIdx bi;
         dw_block_plan(p, bi, d, true, kDwFwdBlocks, grid);
-        SF_DW_DISPATCH(kind, sf_dwconv_fwd_blocked_kernel, grid, (hipStream_t)stream, p, bi);
+        SF_DW_DISPATCH_PF(kind, sf_dwconv_fwd_blocked_kernel, grid, (hipStream_t)stream, p, bi);
     } else {
         hipLaunchKernelGGL(sf_dwconv_fwd_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     }
@@ -926,7 +945,7 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
     if (kind) {
         DwBlockIdx bi;
         dw_block_plan(p, bi, d, false, 8192, grid);
-        SF_DW_DISPATCH(kind, sf_dwconv_dgrad_blocked_kernel, grid, (hipStream_t)stream, p, bi);
+        SF_DW_DISPATCH_PF(kind, sf_dwconv_dgrad_blocked_kernel, grid, (hipStream_t)stream, p, bi);
     } else {
         hipLaunchKernelGGL(sf_dwconv_dgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     }

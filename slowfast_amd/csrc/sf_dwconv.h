@@ -39,6 +39,17 @@ __device__ __forceinline__ void dw_stage_weights(const DwParams& p, float* s_w) 
     }
 }
 
+// fp16 copy of the weights for the W-blocked kernels ([tap][Cw] like dw_stage_weights): half the LDS (one more resident
+// workgroup per CU for the wide layers), one ds_read_b128 per tap, and the products run as v_fma_mix (fp16 x fp16 -> fp32
+// accumulate) without separate conversions -- the same operand precision as the MFMA convolutions.
+__device__ __forceinline__ void dw_stage_weights16(const DwParams& p, f16* s_w) {
+    const int taps = p.kT * p.kH * p.kW;
+    for (int i = threadIdx.x; i < taps * p.Cw; i += SF_THREADS) {
+        const int cw = i / taps, tap = i % taps;
+        s_w[tap * p.Cw + cw] = cw < p.Cwreal ? (f16)p.w[i] : (f16)0;
+    }
+}
+
 __device__ __forceinline__ bool dw_decode(const DwParams& p, uint32_t row, uint32_t& n, int& t, int& h, int& w) {
     // returns true for the cls row of a sample
     uint32_t r, q, ww, hh, tt;
@@ -261,12 +272,12 @@ __device__ __forceinline__ void cvt8(const f16x8& v, float (&o)[8]) {
     for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
 }
 
-template <int KW, int SW, int WSZ>
+template <int KW, int SW, int WSZ, bool PF>
 __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwParams p, DwBlockIdx bi) {
     constexpr int NIN = (SF_DW_WB - 1) * SW + KW;
-    __shared__ float s_w[WSZ];            // taps*Cw floats: 12 KiB for Cw <= 112 (3 workgroups more per CU), else 48 KiB
+    __shared__ __attribute__((aligned(16))) f16 s_w[WSZ];   // taps*Cw halfs: 6 KiB for Cw <= 112, else 24 KiB
     __shared__ float s_red[SF_THREADS][17];
-    dw_stage_weights(p, s_w);
+    dw_stage_weights16(p, s_w);
     __syncthreads();
     int gcol, r0, r1, rstep;
     const bool active = p.rt.init(gcol, r0, r1, rstep);
@@ -296,30 +307,66 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwPar
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
             const int wi0 = wo0 * SW - p.pW;
-            for (int kt = 0; kt < p.kT; ++kt) {
-                const int t = to * p.sT - p.pT + kt;
-                if ((unsigned)t >= (unsigned)p.Ti) continue;
-                for (int kh = 0; kh < p.kH; ++kh) {
-                    const int h = ho * p.sH - p.pH + kh;
-                    if ((unsigned)h >= (unsigned)p.Hi) continue;
-                    const float* wt = s_w + ((kt * p.kH + kh) * KW) * p.Cw + cw;
-                    const f16* line = xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx;
-                    f16x8 raw[NIN];
+            // The valid (kt, kh) planes are walked with a one-plane software prefetch (two register sets A / B): the
+            // NIN loads of the next plane are in flight while the current plane's 3*4*8 FMAs run -- with 2-3 resident
+            // waves per SIMD the un-prefetched loop was load-latency bound (~4x off its VALU time).
+            int kt_n = 0, kh_n = 0;
+            auto next_plane = [&](const f16*& line, int& tap) -> bool {
+                while (kt_n < p.kT) {
+                    const int kt = kt_n, kh = kh_n;
+                    if (++kh_n == p.kH) { kh_n = 0; ++kt_n; }
+                    const int t = to * p.sT - p.pT + kt, h = ho * p.sH - p.pH + kh;
+                    if ((unsigned)t < (unsigned)p.Ti && (unsigned)h < (unsigned)p.Hi) {
+                        line = xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx;
+                        tap = (kt * p.kH + kh) * KW;
+                        return true;
+                    }
+                }
+                return false;
+            };
+            auto load_plane = [&](f16x8 (&raw)[NIN], const f16* line) {
 #pragma unroll
-                    for (int j = 0; j < NIN; ++j) raw[j] = ld16(line + (int64_t)clampi(wi0 + j, p.Wi - 1) * p.ldx);
+                for (int j = 0; j < NIN; ++j) raw[j] = ld16(line + (int64_t)clampi(wi0 + j, p.Wi - 1) * p.ldx);
+            };
+            auto fma_plane = [&](const f16x8 (&raw)[NIN], int tap) {
+                f16x8 wv[KW];
 #pragma unroll
-                    for (int j = 0; j < NIN; ++j) {
-                        float xin[8];
-                        cvt8(keep8(raw[j], (unsigned)(wi0 + j) < (unsigned)p.Wi), xin);
+                for (int kw = 0; kw < KW; ++kw) wv[kw] = ld16(s_w + (tap + kw) * p.Cw + cw);
 #pragma unroll
-                        for (int i = 0; i < SF_DW_WB; ++i) {
-                            const int kw = j - i * SW;      // compile-time after unrolling
-                            if (kw >= 0 && kw < KW) {
+                for (int j = 0; j < NIN; ++j) {
+                    const f16x8 xin = keep8(raw[j], (unsigned)(wi0 + j) < (unsigned)p.Wi);
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) acc[i][e] += xin[e] * wt[kw * p.Cw + e];
-                            }
+                    for (int i = 0; i < SF_DW_WB; ++i) {
+                        const int kw = j - i * SW;      // compile-time after unrolling
+                        if (kw >= 0 && kw < KW) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[i][e] += (float)xin[e] * (float)wv[kw][e];
                         }
                     }
+                }
+            };
+            f16x8 rawA[NIN];
+            const f16* la = nullptr;
+            int ta = 0;
+            if constexpr (PF) {
+                f16x8 rawB[NIN];
+                const f16* lb = nullptr;
+                int tb = 0;
+                bool ha = next_plane(la, ta);
+                if (ha) load_plane(rawA, la);
+                while (ha) {
+                    const bool hb = next_plane(lb, tb);
+                    if (hb) load_plane(rawB, lb);
+                    fma_plane(rawA, ta);
+                    if (!hb) break;
+                    ha = next_plane(la, ta);
+                    if (ha) load_plane(rawA, la);
+                    fma_plane(rawB, tb);
+                }
+            } else {
+                while (next_plane(la, ta)) {
+                    load_plane(rawA, la);
+                    fma_plane(rawA, ta);
                 }
             }
             f16* yrow = p.y + ((int64_t)n * So + p.cls + ((int64_t)to * p.Ho + ho) * p.Wo + wo0) * p.ldy + c;
@@ -345,14 +392,14 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwPar
 // data gradient, blocked over 4 consecutive INPUT columns w0..w0+3 (w0 % 4 == 0).  With pW = KW/2 the output
 // columns that can contribute are q0 + jj, q0 = (w0 + pW - (KW-1) + SW-1) / SW rounded as below, and the tap of
 // (input i, column jj) is kw = B0 + i - jj*SW with a compile-time B0.
-template <int KW, int SW, int WSZ>
+template <int KW, int SW, int WSZ, bool PF>
 __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked_kernel(DwParams p, DwBlockIdx bi) {
     constexpr int PW = KW / 2;
     // smallest q with w0 + PW - q*SW <= KW-1  (w0 % 4 == 0, SW in {1, 2}):  SW=1: q0 = w0 + PW - (KW-1);  SW=2: q0 = w0/2
     constexpr int B0 = SW == 1 ? KW - 1 : PW;                 // kw of (i = 0, jj = 0)
     constexpr int NQ = SW == 1 ? SF_DW_WB + KW - 1 : (SF_DW_WB - 1 + B0) / SW + 1;
-    __shared__ float s_w[WSZ];
-    dw_stage_weights(p, s_w);
+    __shared__ __attribute__((aligned(16))) f16 s_w[WSZ];
+    dw_stage_weights16(p, s_w);
     __syncthreads();
     int gcol, r0, r1, rstep;
     if (!p.rt.init(gcol, r0, r1, rstep)) return;
@@ -373,36 +420,67 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked_kernel(DwP
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
         const int q0 = SW == 1 ? w0 + PW - (KW - 1) : w0 / 2;
-        for (int kt = 0; kt < p.kT; ++kt) {
-            const int ut = t + p.pT - kt;
-            if (ut < 0) continue;
-            uint32_t qt, rt;
-            fd_divmod((uint32_t)ut, p.fdsT, qt, rt);
-            if (rt || qt >= (uint32_t)p.To) continue;
-            for (int kh = 0; kh < p.kH; ++kh) {
-                const int uh = h + p.pH - kh;
-                if (uh < 0) continue;
-                uint32_t qh, rh;
+        // contributing (kt, kh) planes with a one-plane software prefetch, as in the forward kernel
+        int kt_n = 0, kh_n = 0;
+        auto next_plane = [&](const f16*& line, int& tap) -> bool {
+            while (kt_n < p.kT) {
+                const int kt = kt_n, kh = kh_n;
+                if (++kh_n == p.kH) { kh_n = 0; ++kt_n; }
+                const int ut = t + p.pT - kt, uh = h + p.pH - kh;
+                if (ut < 0 || uh < 0) continue;
+                uint32_t qt, rt, qh, rh;
+                fd_divmod((uint32_t)ut, p.fdsT, qt, rt);
                 fd_divmod((uint32_t)uh, p.fdsH, qh, rh);
-                if (rh || qh >= (uint32_t)p.Ho) continue;
-                const float* wt = s_w + ((kt * p.kH + kh) * KW) * p.Cw + cw;
-                const f16* line = db + (((int64_t)qt * p.Ho + qh) * p.Wo) * p.lddy;
-                f16x8 raw[NQ];
+                if (rt || rh || qt >= (uint32_t)p.To || qh >= (uint32_t)p.Ho) continue;
+                line = db + (((int64_t)qt * p.Ho + qh) * p.Wo) * p.lddy;
+                tap = (kt * p.kH + kh) * KW;
+                return true;
+            }
+            return false;
+        };
+        auto load_plane = [&](f16x8 (&raw)[NQ], const f16* line) {
 #pragma unroll
-                for (int jj = 0; jj < NQ; ++jj) raw[jj] = ld16(line + (int64_t)clampi(q0 + jj, p.Wo - 1) * p.lddy);
+            for (int jj = 0; jj < NQ; ++jj) raw[jj] = ld16(line + (int64_t)clampi(q0 + jj, p.Wo - 1) * p.lddy);
+        };
+        auto fma_plane = [&](const f16x8 (&raw)[NQ], int tap) {
+            f16x8 wv[KW];
 #pragma unroll
-                for (int jj = 0; jj < NQ; ++jj) {
-                    float d[8];
-                    cvt8(keep8(raw[jj], (unsigned)(q0 + jj) < (unsigned)p.Wo), d);
+            for (int kw = 0; kw < KW; ++kw) wv[kw] = ld16(s_w + (tap + kw) * p.Cw + cw);
 #pragma unroll
-                    for (int i = 0; i < SF_DW_WB; ++i) {
-                        const int kw = B0 + i - jj * SW;
-                        if (kw >= 0 && kw < KW) {
+            for (int jj = 0; jj < NQ; ++jj) {
+                const f16x8 d = keep8(raw[jj], (unsigned)(q0 + jj) < (unsigned)p.Wo);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) acc[i][e] += d[e] * wt[kw * p.Cw + e];
-                        }
+                for (int i = 0; i < SF_DW_WB; ++i) {
+                    const int kw = B0 + i - jj * SW;
+                    if (kw >= 0 && kw < KW) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[i][e] += (float)d[e] * (float)wv[kw][e];
                     }
                 }
+            }
+        };
+        f16x8 rawA[NQ];
+        const f16* la = nullptr;
+        int ta = 0;
+        if constexpr (PF) {
+            f16x8 rawB[NQ];
+            const f16* lb = nullptr;
+            int tb = 0;
+            bool ha = next_plane(la, ta);
+            if (ha) load_plane(rawA, la);
+            while (ha) {
+                const bool hb = next_plane(lb, tb);
+                if (hb) load_plane(rawB, lb);
+                fma_plane(rawA, ta);
+                if (!hb) break;
+                ha = next_plane(la, ta);
+                if (ha) load_plane(rawA, la);
+                fma_plane(rawB, tb);
+            }
+        } else {
+            while (next_plane(la, ta)) {
+                load_plane(rawA, la);
+                fma_plane(rawA, ta);
             }
         }
         f16* xrow = p.y + ((int64_t)n * Si + p.cls + ((int64_t)t * p.Hi + h) * p.Wi + w0) * p.ldy + c;
