@@ -889,10 +889,12 @@ static void dw_block_plan(DwParams& p, DwBlockIdx& bi, const sf_dw_desc* d, bool
         else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_MAX_W>), grid, dim3(SF_THREADS), 0, s, p, bi);     \
         else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, s, p, bi);                    \
     } while (0)
-// forward / data-gradient stencils: PF = one-plane software prefetch (SF_DW_PREFETCH=0 selects the plain loop)
+// forward / data-gradient stencils: PF = one-plane software prefetch, an A/B option (SF_DW_PREFETCH=1): it costs ~90
+// VGPRs (2 instead of 3 waves per SIMD) and measured SLOWER than the plain loop (X3D-M 1092 vs 1137 clips/s,
+// profiles/r1_visit22_ab.txt)
 #define SF_DW_DISPATCH_PF(kind, KERNEL, grid, s, p, bi)                                                                 \
     do {                                                                                                                  \
-        static const bool pf_ = !(getenv("SF_DW_PREFETCH") && atoi(getenv("SF_DW_PREFETCH")) == 0);                      \
+        static const bool pf_ = getenv("SF_DW_PREFETCH") && atoi(getenv("SF_DW_PREFETCH")) != 0;                         \
         const bool small_w = (p).kT * (p).kH * (p).kW * (p).Cw <= SF_DW_SMALL_W;                                        \
         if (pf_) {                                                                                                        \
             if ((kind) == 1 && small_w) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi); \

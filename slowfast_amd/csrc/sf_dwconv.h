@@ -307,9 +307,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwPar
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
             const int wi0 = wo0 * SW - p.pW;
-            // The valid (kt, kh) planes are walked with a one-plane software prefetch (two register sets A / B): the
-            // NIN loads of the next plane are in flight while the current plane's 3*4*8 FMAs run -- with 2-3 resident
-            // waves per SIMD the un-prefetched loop was load-latency bound (~4x off its VALU time).
+            // The valid (kt, kh) planes are walked in order; PF adds a one-plane software prefetch (two register sets
+            // A / B).  Measured: the prefetch's extra registers cost a resident wave and it is slower (see sf_api.hip).
             int kt_n = 0, kh_n = 0;
             auto next_plane = [&](const f16*& line, int& tap) -> bool {
                 while (kt_n < p.kT) {
