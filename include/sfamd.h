@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 11
+#define SF_ABI_VERSION 12
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -245,6 +245,14 @@ int sf_roi_align_max_bwd(int32_t R, int32_t B, int32_t H, int32_t W, int32_t C, 
  * A [M][K], W [N][K], Y / aux [M][N] fp16, row pitches in elements. */
 int sf_gemm_act(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias,
                 void* Y, int32_t ldy, int32_t mode, void* aux, int32_t ldaux, sf_stream_t stream);
+/* Input side -- replaces tensor_normalize (slowfast/datasets/utils.py:278-297), the THWC -> CTHW
+ * permute (datasets/kinetics.py:375-408) and pack_pathway_output (datasets/utils.py:78-111) for one pathway:
+ *   out[n][to][h][w][c] = ((frames[n][t_index[to]][h][w][s] / 255) - mean[s]) / std[s]   (s = c, or 2 - c when `reverse`),
+ * frames uint8 [N][Tin][H][W][3] on the device, out fp16 [N][Tout][H][W][4] (4th channel zero) = the buffer the stems read
+ * as W pairs; t_index [Tout] int32 on the device (NULL = identity; the Slow pathway passes linspace(0, T-1, T/alpha)). */
+int sf_pack_clip_u8(const void* frames, int32_t N, int32_t Tin, int32_t H, int32_t W, const int32_t* t_index, int32_t Tout,
+                    float mean0, float mean1, float mean2, float std0, float std1, float std2, int32_t reverse, void* out,
+                    sf_stream_t stream);
 /* Stochastic depth -- replaces drop_path() (slowfast/models/common.py:46-59) at the two residual additions of
  * MultiScaleBlock (attention.py:500-510): y[m] = (resid ? resid[m] : 0) + scale[m / rows_per_sample] * x[m], with
  * scale[b] = floor(keep_prob + u_b) / keep_prob sampled by the caller.  Rows are fp16 [M][C], C % 8 == 0. */

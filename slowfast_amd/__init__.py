@@ -10,3 +10,4 @@ __version__ = "0.1.0"
 from . import video_models  # noqa: F401,E402  (registers SlowFast / ResNet in MODEL_REGISTRY)
 from . import mvit  # noqa: F401,E402  (registers MViT)
 from . import x3d  # noqa: F401,E402  (registers X3D, the x3d_stem and x3d_transform factories)
+from .data import pack_pathways_u8  # noqa: F401,E402  (uint8 frames -> stem operand layout)

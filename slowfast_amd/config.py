@@ -93,7 +93,8 @@ _DEFAULTS = {
               "FP16_ALLREDUCE": False},
     "SLOWFAST": {"BETA_INV": 8, "ALPHA": 8, "FUSION_CONV_CHANNEL_RATIO": 2, "FUSION_KERNEL_SZ": 5},
     "DATA": {"NUM_FRAMES": 8, "SAMPLING_RATE": 8, "MEAN": [0.45, 0.45, 0.45], "INPUT_CHANNEL_NUM": [3, 3],
-             "STD": [0.225, 0.225, 0.225], "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256},
+             "STD": [0.225, 0.225, 0.225], "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256,
+             "REVERSE_INPUT_CHANNEL": False},
     "SOLVER": {"BASE_LR": 0.1, "MOMENTUM": 0.9, "DAMPENING": 0.0, "NESTEROV": True, "WEIGHT_DECAY": 1e-4,
                "OPTIMIZING_METHOD": "sgd", "ZERO_WD_1D_PARAM": False, "CLIP_GRAD_VAL": None,
                "CLIP_GRAD_L2NORM": None, "LAYER_DECAY": 1.0},

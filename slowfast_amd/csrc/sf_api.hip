@@ -1291,6 +1291,24 @@ extern "C" int sf_roi_align_max_bwd(int32_t R, int32_t B, int32_t H, int32_t W, 
     return check_launch("roi_align_max_bwd");
 }
 
+extern "C" int sf_pack_clip_u8(const void* frames, int32_t N, int32_t Tin, int32_t H, int32_t W, const int32_t* t_index,
+                               int32_t Tout, float mean0, float mean1, float mean2, float std0, float std1, float std2,
+                               int32_t reverse, void* out, sf_stream_t stream) {
+    REQUIRE(frames && out, "sf_pack_clip_u8: null pointer");
+    REQUIRE(N > 0 && Tin > 0 && Tout > 0 && H > 0 && W > 0 && W % 2 == 0, "sf_pack_clip_u8: bad shape (W must be even)");
+    REQUIRE(std0 != 0.f && std1 != 0.f && std2 != 0.f, "sf_pack_clip_u8: zero std");
+    PackClipParams p;
+    memset(&p, 0, sizeof(p));
+    p.frames = (const unsigned char*)frames; p.N = N; p.Tin = Tin; p.Tout = Tout; p.HW = (int64_t)H * W;
+    p.t_index = t_index; p.reverse = reverse; p.out = (f16*)out;
+    p.mean[0] = mean0; p.mean[1] = mean1; p.mean[2] = mean2; p.stdv[0] = std0; p.stdv[1] = std1; p.stdv[2] = std2;
+    p.total = (int64_t)N * Tout * p.HW;
+    REQUIRE(p.total < (1ll << 31) && (int64_t)N * Tin * p.HW < (1ll << 40), "sf_pack_clip_u8: too many pixels");
+    p.fdHW = make_fastdiv((uint32_t)p.HW); p.fdT = make_fastdiv((uint32_t)Tout);
+    hipLaunchKernelGGL(sf_pack_clip_u8_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("pack_clip_u8");
+}
+
 extern "C" int sf_row_scale_add(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,
                                 int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C, sf_stream_t stream) {
     REQUIRE(x && scale && y, "sf_row_scale_add: null pointer");

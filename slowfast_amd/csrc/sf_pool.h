@@ -303,3 +303,40 @@ __global__ __launch_bounds__(SF_THREADS) void sf_prep_weights_kernel(PrepParams 
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Input side of the path: decoded uint8 frames -> normalised fp16 clip in the stem's layout, one
+// launch per pathway.  Replaces tensor_normalize (slowfast/datasets/utils.py:278-297: x/255, - mean, / std, in that
+// order, fp32) + the THWC -> CTHW permute (datasets/kinetics.py:375-408) + pack_pathway_output's temporal
+// index_select / channel reversal (datasets/utils.py:78-111):
+//   out[n][to][h][w][c] = ((frames[n][t_index[to]][h][w][s] / 255) - mean[s]) / std[s],  s = c (2 - c when reversed)
+// out is the N,T,H,W,4 fp16 buffer that engine.StemConvUnit reads as W pairs.
+struct PackClipParams {
+    const unsigned char* frames;    // [N][Tin][H][W][3]
+    int N, Tin, Tout;
+    int64_t HW;
+    const int* t_index;             // [Tout] source frame of every output frame (null: identity)
+    float mean[3], stdv[3];
+    int reverse;                    // DATA.REVERSE_INPUT_CHANNEL: channel c reads source channel 2 - c
+    f16* out;
+    int64_t total;                  // N*Tout*HW
+    FastDiv fdHW, fdT;
+};
+__global__ __launch_bounds__(SF_THREADS) void sf_pack_clip_u8_kernel(PackClipParams p) {
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total; idx += (int64_t)gridDim.x * SF_THREADS) {
+        uint32_t q, hw, n, to;
+        fd_divmod((uint32_t)idx, p.fdHW, q, hw);
+        fd_divmod(q, p.fdT, n, to);
+        const int ts = p.t_index ? p.t_index[to] : (int)to;
+        const unsigned char* src = p.frames + (((int64_t)n * p.Tin + ts) * p.HW + hw) * 3;
+        f16x4 o;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int sc = p.reverse ? 2 - c : c;           // normalisation happens before the channel reversal
+            const float v = (float)src[sc] / 255.0f;
+            o[c] = (f16)((v - p.mean[sc]) / p.stdv[sc]);
+        }
+        o[3] = (f16)0;
+        *reinterpret_cast<f16x4*>(p.out + idx * 4) = o;
+    }
+}

@@ -180,7 +180,10 @@ class StemConvUnit(ConvUnit):
         self.p2 = (pT, pH, (pW + self.lead) // 2)
 
     def prepare_input(self, x):
-        """NCTHW fp32 clip -> the W-pair view (N, 8, T, H, W/2) fp16."""
+        """NCTHW fp32 clip -> the W-pair view (N, 8, T, H, W/2) fp16; clips packed by data.pack_pathways_u8 are already
+        in that layout."""
+        if getattr(x, "_sf_wpairs", False):
+            return x
         return ops.ncthw_to_cl_wpairs(x.float())
 
     @staticmethod

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class ConvDesc(Structure):
@@ -97,6 +97,8 @@ _SIGNATURES = {
     "sf_roi_align_max_bwd": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _F, _F,
                                      c_int32, c_int32, _P, _F, _P]),
     "sf_gemm_act": (c_int, [c_int64, c_int32, c_int32, _P, c_int32, _P, c_int32, _F, _P, c_int32, c_int32, _P, c_int32, _P]),
+    "sf_pack_clip_u8": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_float, c_float, c_float, c_float,
+                                c_float, c_float, c_int32, _P, _P]),
     "sf_row_scale_add": (c_int, [_P, c_int32, _P, c_int64, _P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     "sf_transpose_heads": (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "sf_sample_chunks": (c_int, [c_int64, c_int32]),

@@ -256,3 +256,25 @@ def check_roi_pool(device, shape=(2, 16, 3, 10, 12), aligned=True, seed=0):
     (out * w.to(device)).sum().backward()
     assert_close("roi pooled", out.cpu(), ref.detach(), 1e-5)
     assert_close("roi d(features)", cl_to_host(xc.grad), xr.grad, 2 * F16_EPS)
+
+
+def check_pack_clip(device, arch="slowfast", reverse=False, seed=0):
+    """sf_pack_clip_u8 (uint8 frames -> normalised fp16 W-pair clips per pathway) is bit-exact with the fp16 rounding
+    of the reference's tensor_normalize + permute + pack_pathway_output (oracle/data_ref.py)."""
+    import slowfast_amd as sa
+    from oracle import data_ref
+    cfg = sa.get_preset("SLOWFAST_8x8_R50" if arch == "slowfast" else "C2D_8x8_R50",
+                        ["DATA.MEAN", [0.45, 0.40, 0.35], "DATA.STD", [0.225, 0.25, 0.2],
+                         "DATA.REVERSE_INPUT_CHANNEL", reverse])
+    g = torch.Generator().manual_seed(seed)
+    frames = torch.randint(0, 256, (2, 8, 6, 10, 3), generator=g, dtype=torch.int64).to(torch.uint8)
+    ref = data_ref.pack_pathways(frames, cfg)
+    got = sa.pack_pathways_u8(frames.to(device), cfg)
+    assert len(got) == len(ref)
+    for x, r in zip(got, ref):
+        N, C8, T, H, W2 = x.shape
+        assert C8 == 8 and getattr(x, "_sf_wpairs", False)
+        # (N, 8, T, H, W/2) view of the N,T,H,W,4 buffer: channel = (w & 1) * 4 + c
+        buf = x.permute(0, 2, 3, 4, 1).reshape(N, T, H, W2 * 2, 4).cpu()
+        assert torch.equal(buf[..., :3].permute(0, 4, 1, 2, 3).contiguous(), r.half()), "normalised clip differs"
+        assert float(buf[..., 3].abs().max()) == 0.0

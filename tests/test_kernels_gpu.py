@@ -120,3 +120,8 @@ def test_roi_pool(gpu, aligned):
     """RoI head pooling (temporal mean -> ROIAlign -> max) vs the oracle's ROIAlign restatement."""
     kc.check_roi_pool(gpu, aligned=aligned)
     kc.check_roi_pool(gpu, shape=(4, 256, 8, 16, 16), aligned=aligned, seed=3)
+
+
+@pytest.mark.parametrize("arch,reverse", [("slowfast", False), ("slowfast", True), ("c2d", False)])
+def test_pack_clip_u8(gpu, arch, reverse):
+    kc.check_pack_clip(gpu, arch, reverse)

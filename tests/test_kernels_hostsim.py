@@ -112,3 +112,8 @@ def test_wgrad_many_splits(sim):
 @pytest.mark.parametrize("aligned", [True, False])
 def test_roi_pool(sim, aligned):
     kc.check_roi_pool(sim, aligned=aligned)
+
+
+@pytest.mark.parametrize("arch,reverse", [("slowfast", False), ("slowfast", True), ("c2d", False)])
+def test_pack_clip_u8(sim, arch, reverse):
+    kc.check_pack_clip(sim, arch, reverse)

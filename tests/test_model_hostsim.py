@@ -38,3 +38,22 @@ def test_nonlocal_engine_matches_oracle(sim):
 def test_mvit_drop_path_matches_oracle(sim):
     """MVIT.DROPPATH_RATE > 0: per-sample stochastic depth on both residual branches of every block."""
     mc.check_mvit_drop_path(sim)
+
+
+def test_packed_uint8_input_equals_float_input(sim):
+    """A SlowFast forward on clips packed by sf_pack_clip_u8 gives exactly the logits of the float path fed with the
+    reference's normalised fp32 clips (oracle/data_ref.py): both round the same fp32 values to fp16 once."""
+    import torch
+    import slowfast_amd as sa
+    from oracle import data_ref
+    gold = mc.load_golden("slowfast_tiny")
+    cfg = mc.cfg_for(gold)
+    torch.manual_seed(0)
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg).eval()
+    g = torch.Generator().manual_seed(3)
+    S = cfg.DATA.TRAIN_CROP_SIZE
+    frames = torch.randint(0, 256, (2, cfg.DATA.NUM_FRAMES, S, S, 3), generator=g, dtype=torch.int64).to(torch.uint8)
+    with torch.no_grad():
+        a = model(sa.pack_pathways_u8(frames, cfg))
+        b = model(data_ref.pack_pathways(frames, cfg))
+    assert torch.equal(a, b)
