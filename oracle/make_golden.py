@@ -47,6 +47,13 @@ CASES = {
                                   "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2, 2], [2, 2], [2, 2], [2, 2]]",
                                   "NONLOCAL.LOCATION", "[[[], []], [[1], []], [[1], []], [[], []]]",
                                   "NONLOCAL.POOL", "[[[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]], [[2, 2, 2], [2, 2, 2]]]"], 4),
+    # NONLOCAL.GROUP 2: the Slow pathway's frames are folded into the batch around the Nonlocal blocks
+    "slowfast_nln_group_tiny": ("configs/Kinetics/SLOWFAST_NLN_8x8_R50.yaml",
+                                TINY + ["DATA.NUM_FRAMES", 16, "SLOWFAST.BETA_INV", 2, "DATA.TRAIN_CROP_SIZE", 64,
+                                        "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2, 2], [2, 2], [2, 2], [2, 2]]",
+                                        "NONLOCAL.LOCATION", "[[[], []], [[1], []], [[1], []], [[], []]]",
+                                        "NONLOCAL.GROUP", "[[1, 1], [2, 1], [2, 1], [1, 1]]",
+                                        "NONLOCAL.POOL", "[[[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]]]"], 4),
     # BASELINE config 5 backbone: SlowFast-R101 (23 res4 blocks, the first 6 temporal), dot-product Nonlocal after res4
     # blocks 6/13/20 with (2,2,2) pooling, res5 at stride 1 / dilation 2; closed with the basic head (global pooling)
     "slowfast_r101_nl_tiny": ("configs/AVA/c2/SLOWFAST_32x2_R101_50_50.yaml",

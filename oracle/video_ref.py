@@ -134,8 +134,9 @@ def nonlocal_block(x, sd, prefix, pool_size, instantiation, training, stats_out)
 
 
 def res_stage(xs, sd, name, strides, dilations, stride_1x1, training, stats_out, nonlocal_pool=None,
-              instantiation="dot_product"):
-    """ResStage.forward (resnet_helper.py:697-726); Nonlocal blocks (NONLOCAL.GROUP 1) after the listed blocks."""
+              instantiation="dot_product", nonlocal_group=None):
+    """ResStage.forward (resnet_helper.py:697-726); Nonlocal blocks after the listed blocks, with NONLOCAL.GROUP > 1
+    folding T into the batch around the block (:706-723)."""
     out = []
     for p, x in enumerate(xs):
         i = 0
@@ -144,7 +145,13 @@ def res_stage(xs, sd, name, strides, dilations, stride_1x1, training, stats_out,
                           training, stats_out)
             nl = f"{name}.pathway{p}_nonlocal{i}"
             if nl + ".conv_theta.weight" in sd:
+                g = nonlocal_group[p] if nonlocal_group is not None else 1
+                b, c, t, h, w = x.shape
+                if g > 1:
+                    x = x.permute(0, 2, 1, 3, 4).reshape(b * g, t // g, c, h, w).permute(0, 2, 1, 3, 4)
                 x = nonlocal_block(x, sd, nl, nonlocal_pool[p], instantiation, training, stats_out)
+                if g > 1:
+                    x = x.permute(0, 2, 1, 3, 4).reshape(b, t, c, h, w).permute(0, 2, 1, 3, 4)
             i += 1
         out.append(x)
     return out
@@ -278,7 +285,8 @@ def video_forward(sd, cfg, inputs, training=True, stats_out=None, bboxes=None):
     for i in range(4):
         name = f"s{i + 2}"
         x = res_stage(x, sd, name, cfg.RESNET.SPATIAL_STRIDES[i], cfg.RESNET.SPATIAL_DILATIONS[i],
-                      cfg.RESNET.STRIDE_1X1, training, stats_out, cfg.NONLOCAL.POOL[i], cfg.NONLOCAL.INSTANTIATION)
+                      cfg.RESNET.STRIDE_1X1, training, stats_out, cfg.NONLOCAL.POOL[i], cfg.NONLOCAL.INSTANTIATION,
+                      cfg.NONLOCAL.GROUP[i])
         if i == 0:
             pt = _POOL1_T[cfg.MODEL.ARCH]
             if pt != 1:

@@ -83,6 +83,16 @@ class ResBlock(nn.Module):
         return self._block_fn.apply(x, self, *self._param_list)
 
 
+def _fold_time(x, n, t):
+    """(N, C, T, H, W) channels-last tensor viewed as (n, C, t, H, W) with n*t == N*T (no copy)."""
+    from . import ops
+    x = ops.to_cl(x)
+    N, C, T, H, W = x.shape
+    rows = x.permute(0, 2, 3, 4, 1)                      # N, T, H, W, C strided view of the storage
+    assert rows.stride(0) == T * rows.stride(1), "batch and time must be uniformly spaced to fold"
+    return rows.reshape(n, t, H, W, C).permute(0, 4, 1, 2, 3)
+
+
 class ResStage(nn.Module):
     """Per-pathway sequence of ResBlocks, registered as ``pathway{p}_res{i}``."""
 
@@ -110,8 +120,6 @@ class ResStage(nn.Module):
                                norm_module=norm_module, block_idx=i, drop_connect_rate=drop_connect_rate)
                 self.add_module(f"pathway{p}_res{i}", blk)
                 if i in nonlocal_inds[p]:
-                    if nonlocal_group[p] != 1:
-                        raise NotImplementedError("NONLOCAL.GROUP > 1 (temporal folding) is not on the built path")
                     from .nonlocal_block import Nonlocal
                     self.add_module(f"pathway{p}_nonlocal{i}",
                                     Nonlocal(dim_out[p], dim_out[p] // 2, nonlocal_pool[p], instantiation=instantiation,
@@ -125,6 +133,14 @@ class ResStage(nn.Module):
                 x = getattr(self, f"pathway{p}_res{i}")(x)
                 nln = getattr(self, f"pathway{p}_nonlocal{i}", None)
                 if nln is not None:
-                    x = nln(x)
+                    g = self.nonlocal_group[p]
+                    if g > 1:
+                        # fold T into the batch around the block (resnet_helper.py:706-723); channels-last memory is
+                        # N,T,H,W,C, so both folds are views of the same rows
+                        b, c, t, h, w = x.shape
+                        x = _fold_time(x, b * g, t // g)
+                        x = _fold_time(nln(x), b, t)
+                    else:
+                        x = nln(x)
             out.append(x)
         return out

@@ -159,7 +159,7 @@ def test_x3d_matches_reference(gpu, name):
         print(name, rep.get(name))
 
 
-@pytest.mark.parametrize("name", ["slowfast_nln_tiny", "c2d_nln_mid", "slowfast_r101_nl_tiny"])
+@pytest.mark.parametrize("name", ["slowfast_nln_tiny", "c2d_nln_mid", "slowfast_r101_nl_tiny", "slowfast_nln_group_tiny"])
 def test_nonlocal_matches_reference(gpu, name):
     """Nonlocal blocks (softmax and dot-product affinities) vs the oracle / the unmodified reference's golden numbers."""
     rep = {}

@@ -57,3 +57,9 @@ def test_packed_uint8_input_equals_float_input(sim):
         a = model(sa.pack_pathways_u8(frames, cfg))
         b = model(data_ref.pack_pathways(frames, cfg))
     assert torch.equal(a, b)
+
+
+def test_nonlocal_group_folding_matches_oracle(sim):
+    """NONLOCAL.GROUP 2: the temporal fold around the Nonlocal block is a view of the channels-last rows."""
+    mc.check_engine("slowfast_nln_group_tiny", sim, tol_logits=2e-2, tol_loss=5e-3, tol_gnorm=2e-2, tol_param=1.0,
+                    tol_global=0.5, tol_stats=2e-2)
