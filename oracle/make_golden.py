@@ -53,7 +53,8 @@ CASES = {
                                         "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2, 2], [2, 2], [2, 2], [2, 2]]",
                                         "NONLOCAL.LOCATION", "[[[], []], [[1], []], [[1], []], [[], []]]",
                                         "NONLOCAL.GROUP", "[[1, 1], [2, 1], [2, 1], [1, 1]]",
-                                        "NONLOCAL.POOL", "[[[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]]]"], 4),
+                                        "NONLOCAL.POOL", "[[[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]]]"], 4,
+                                {"final_bn_gamma_scale": 0.25}),     # better conditioned: fp16-storage deviation 3x lower
     # BASELINE config 5 backbone: SlowFast-R101 (23 res4 blocks, the first 6 temporal), dot-product Nonlocal after res4
     # blocks 6/13/20 with (2,2,2) pooling, res5 at stride 1 / dilation 2; closed with the basic head (global pooling)
     "slowfast_r101_nl_tiny": ("configs/AVA/c2/SLOWFAST_32x2_R101_50_50.yaml",

@@ -61,5 +61,9 @@ def test_packed_uint8_input_equals_float_input(sim):
 
 def test_nonlocal_group_folding_matches_oracle(sim):
     """NONLOCAL.GROUP 2: the temporal fold around the Nonlocal block is a view of the channels-last rows."""
-    mc.check_engine("slowfast_nln_group_tiny", sim, tol_logits=2e-2, tol_loss=5e-3, tol_gnorm=2e-2, tol_param=1.0,
-                    tol_global=0.5, tol_stats=2e-2)
+    rep = {}
+    try:
+        mc.check_engine("slowfast_nln_group_tiny", sim, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.1,
+                        tol_global=1e-2, report=rep)
+    finally:
+        print(rep)
