@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 12
+#define SF_ABI_VERSION 13
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -53,6 +53,12 @@ int sf_conv_fwd_mtiles(const sf_conv_desc* d);
  * stat_part (optional) receives per-tile per-channel sum / sum of squares of y (bias included): [mtiles][2][Co] fp32. */
 int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf, const float* in_scale, const float* in_shift,
                 int in_relu, const float* bias, void* y, float* stat_part, sf_stream_t stream);
+/* Inference-fused convolution (the eval / multi-view test path, tools/test_net.py:25-151):
+ * eval-mode nn.BatchNorm3d is an affine map of its input, so the caller folds it into the weights (wf = pack(w * scale))
+ * and a bias (shift); the nn.ReLU and the residual addition of resnet_helper.py:377-392, 512-521 run in the epilogue:
+ *   y = act(conv(x) + bias [+ resid]),   act = ReLU when out_relu.   bias [Co] fp32 (may be NULL), resid [M][ldr] fp16. */
+int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const void* wf, const float* bias, const void* resid,
+                      int32_t ldr, int out_relu, void* y, sf_stream_t stream);
 /* dx = conv_transpose(dy, w) (+ resid), dx pitch = d->ldx, dy pitch = d->ldy */
 int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr, void* dx,
                   sf_stream_t stream);

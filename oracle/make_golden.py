@@ -152,11 +152,62 @@ def run_case(name):
     }
 
 
+# Eval / multi-view test path (tools/test_net.py:25-151): the reference model in eval mode (running-statistics
+# BatchNorm, activation + spatial mean in the head) on DATA.TEST_CROP_SIZE clips.  name: (training case whose yaml /
+# overrides / parameters are reused, test crop).  A test crop larger than the training crop makes the heads run
+# fully-convolutionally (AvgPool3d window < feature extent), as the Kinetics configs do (224 -> 256).
+EVAL_CASES = {
+    "eval_slowfast_tiny": ("slowfast_tiny", 64),
+    "eval_c2d_tiny": ("c2d_tiny", 64),
+    "eval_slowfast_nln_tiny": ("slowfast_nln_tiny", 96),
+    "eval_slowfast_r50_mid": ("slowfast_r50_mid", 128),
+    "eval_x3d_tiny": ("x3d_tiny", 96),
+    "eval_mvit_tiny": ("mvit_tiny", 64),
+}
+
+
+def run_eval_case(name):
+    base, crop = EVAL_CASES[name]
+    yaml_rel, opts, batch = CASES[base][:3]
+    tweaks = CASES[base][3] if len(CASES[base]) > 3 else {}
+    cfg = refshim.reference_cfg(yaml_rel, list(opts) + ["DATA.TEST_CROP_SIZE", crop])
+    torch.manual_seed(0)
+    model = refshim.reference_model(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    fam = _family(cfg)
+    sd = fam.randomize_state(shapes, seed=1234)
+    if "final_bn_gamma_scale" in tweaks:
+        video_ref.scale_final_bn(sd, tweaks["final_bn_gamma_scale"])
+    inputs, _ = video_ref.synthetic_batch(cfg, batch, seed=4321, crop=crop)
+    if fam is video_ref:
+        sd = video_ref.calibrate_running_stats(sd, cfg, inputs)
+    model.load_state_dict(sd)
+    model.eval()
+    with torch.no_grad():
+        probs = model([x.clone() for x in inputs])
+        o_probs = eval_forward(sd, cfg, inputs)
+    err = float((o_probs - probs).abs().max() / probs.abs().max())
+    assert err < 1e-5, f"{name}: oracle eval outputs differ from the reference ({err:.2e})"
+    assert float((probs.sum(1) - 1).abs().max()) < 1e-5
+    print(f"{name}: probs {tuple(probs.shape)} max {float(probs.max()):.4f}  oracle-vs-reference {err:.1e}")
+    return {"base_case": base, "reference_yaml": yaml_rel, "opts": list(opts) + ["DATA.TEST_CROP_SIZE", crop],
+            "batch": batch, "test_crop": crop, "param_seed": 1234, "data_seed": 4321, "state_tweaks": tweaks,
+            "probs": probs.tolist(), "torch_version": torch.__version__}
+
+
+def eval_forward(sd, cfg, inputs):
+    """The oracle's eval-mode forward of whichever family ``cfg`` names."""
+    if cfg.MODEL.MODEL_NAME == "MViT":
+        return mvit_ref.mvit_forward(sd, cfg, inputs, training=False)
+    fwd = video_ref.x3d_forward if cfg.MODEL.MODEL_NAME == "X3D" else video_ref.video_forward
+    return fwd(sd, cfg, inputs, training=False)
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
-    for name in (sys.argv[1:] or CASES):
-        rec = run_case(name)
+    for name in (sys.argv[1:] or list(CASES) + list(EVAL_CASES)):
+        rec = run_eval_case(name) if name in EVAL_CASES else run_case(name)
         with open(os.path.join(out_dir, name + ".json"), "w") as f:
             json.dump(rec, f)
     print("wrote", out_dir)

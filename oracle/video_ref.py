@@ -202,7 +202,10 @@ def x3d_forward(sd, cfg, inputs, training=True, stats_out=None):
             i += 1
     x = _conv(x, sd["head.conv_5.weight"])
     x = _STORE(F.relu(_bn(x, sd, "head.conv_5_bn", training, stats_out)))
-    x = x.mean((2, 3, 4), keepdim=True)
+    # nn.AvgPool3d([NUM_FRAMES, ceil(crop/32), ceil(crop/32)], stride=1) (video_model_builder.py:783-797): the whole
+    # extent at the training crop, a sliding window (fully-convolutional inference) at a larger test crop
+    spat = -(-cfg.DATA.TRAIN_CROP_SIZE // 32)
+    x = F.avg_pool3d(x, (cfg.DATA.NUM_FRAMES, spat, spat), 1)
     x = F.relu(F.conv3d(x, sd["head.lin_5.weight"]))
     z = F.linear(x.permute(0, 2, 3, 4, 1), sd["head.projection.weight"], sd["head.projection.bias"])
     if not training:
@@ -351,11 +354,30 @@ def scale_final_bn(sd, factor):
     return sd
 
 
-def synthetic_batch(cfg, batch, seed, num_classes=None):
+def calibrate_running_stats(sd, cfg, inputs):
+    """Returns a copy of ``sd`` whose BatchNorm running statistics are the batch statistics of ``inputs`` (the fixed
+    point of the momentum average on that batch).  Random running statistics do not match the activations' real
+    scale, so an eval-mode forward would saturate the softmax and test conditioning instead of kernels; calibrated
+    statistics give eval outputs as well spread as the training-mode ones.  One training-mode oracle forward with the
+    reference's momentum 0.1: new = 0.9 * old + 0.1 * batch  =>  batch = (new - 0.9 * old) / 0.1."""
+    stats = {}
+    fwd = x3d_forward if cfg.MODEL.MODEL_NAME == "X3D" else video_forward
+    with torch.no_grad():
+        fwd(sd, cfg, inputs, training=True, stats_out=stats)
+    out = dict(sd)
+    for k, new in stats.items():
+        out[k] = (new - 0.9 * sd[k]) / 0.1
+        if k.endswith("running_var"):
+            out[k] = out[k].clamp_min(1e-4)
+    return out
+
+
+def synthetic_batch(cfg, batch, seed, num_classes=None, crop=None):
     """Kinetics-shaped synthetic clips: x = randn(B,3,T,S,S); SlowFast slow pathway =
-    index_select(fast, 2, linspace(0, T-1, T//alpha)) (slowfast/datasets/utils.py:96-102); integer labels."""
+    index_select(fast, 2, linspace(0, T-1, T//alpha)) (slowfast/datasets/utils.py:96-102); integer labels.
+    ``crop`` overrides the spatial size (DATA.TEST_CROP_SIZE clips of the multi-view test path)."""
     g = torch.Generator().manual_seed(seed)
-    T, S = cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE
+    T, S = cfg.DATA.NUM_FRAMES, crop or cfg.DATA.TRAIN_CROP_SIZE
     fast = torch.randn((batch, 3, T, S, S), generator=g)
     labels = torch.randint(0, num_classes or cfg.MODEL.NUM_CLASSES, (batch,), generator=g)
     if len(cfg.DATA.INPUT_CHANNEL_NUM) == 2:

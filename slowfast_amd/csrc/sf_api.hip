@@ -286,6 +286,25 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf,
     return run_igemm(p, is_pointwise(d), (hipStream_t)stream);
 }
 
+extern "C" int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const void* wf, const float* bias,
+                                 const void* resid, int32_t ldr, int out_relu, void* y, sf_stream_t stream) {
+    if (check_desc(d)) return -1;
+    REQUIRE(x && wf && y, "sf_conv_fwd_fused: null pointer");
+    REQUIRE(!resid || (ldr >= d->Co && ldr % 8 == 0), "sf_conv_fwd_fused: bad residual pitch");
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.g = gather_fwd(d, x, nullptr, nullptr, 0);
+    p.M = d->N * d->To * d->Ho * d->Wo;
+    int32_t ldf, ldd;
+    sf_conv_weight_ld(d, &ldf, &ldd);
+    p.wmat = (const f16*)wf; p.ldw = ldf; p.Nout = d->Co;
+    p.ksteps = cdiv(p.g.Ktot, 32);
+    p.y = (f16*)y; p.ldy = d->ldy;
+    p.bias = bias; p.resid = (const f16*)resid; p.ldr = ldr;
+    p.act_mode = out_relu ? 3 : 0;
+    return run_igemm(p, is_pointwise(d), (hipStream_t)stream);
+}
+
 extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
                              void* dx, sf_stream_t stream) {
     if (check_desc(d)) return -1;

@@ -30,7 +30,8 @@ struct IgemmParams {
     int bh;
     int64_t sa_b, sa_h, sw_b, sw_h, sy_b, sy_h, sr_b, sr_h;
     // fused activation epilogues of the Mlp (common.py:25-34): act_mode 1 writes act_aux = gelu(y) next to y (fc1),
-    // act_mode 2 multiplies y by gelu'(act_aux) (data gradient of fc2 -> gradient of fc1's output)
+    // act_mode 2 multiplies y by gelu'(act_aux) (data gradient of fc2 -> gradient of fc1's output);
+    // act_mode 3 = ReLU on the stored value (eval-mode convolutions with BatchNorm folded into weights + bias)
     int act_mode;
     f16* act_aux;
     int ld_aux;
@@ -342,6 +343,10 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
                 const f16x8 h = ld16(p.act_aux + (int64_t)m * p.ld_aux + col);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * gelu_df((float)h[e]));
+            }
+            if (p.act_mode == 3) {          // inference-fused convolution: ReLU after bias (+ residual)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > (f16)0.f ? v[e] : (f16)0.f;
             }
             st16(yout + (int64_t)m * p.ldy + col, v);
             if (p.act_mode == 1) {

@@ -156,6 +156,42 @@ class ConvUnit:
             p += [self.bn.weight, self.bn.bias]
         return p
 
+    # ---- inference fusion (slowfast_amd.inference) --------------------------------------
+    def _fold_source(self, w):
+        """The fp32 Conv3d-layout weight the packed operand is made from (hook for the W-pair-folded stems)."""
+        return w
+
+    def fold(self):
+        """Fold the eval-mode BatchNorm (an affine map of the running statistics, as F.batch_norm applies it with
+        training=False) into the convolution: w' = w * scale[co], b' = (conv.bias) * scale + shift.  One-time
+        preparation on the parameters' device; the packed fp16 operands are cached per input geometry."""
+        w = self.conv.weight.detach().float()
+        b = self.conv.bias.detach().float() if self.conv.bias is not None else None
+        bn = self.bn
+        if bn is not None:
+            assert bn.running_mean is not None, "BatchNorm without running statistics cannot be folded"
+            scale = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+            if bn.weight is not None:
+                scale = scale * bn.weight.detach().float()
+            shift = -bn.running_mean.detach().float() * scale
+            if bn.bias is not None:
+                shift = shift + bn.bias.detach().float()
+            w = w * scale.view(-1, 1, 1, 1, 1)
+            b = shift if b is None else b * scale + shift
+        self._fold_w, self._fold_b, self._fold_packed = self._fold_source(w).contiguous(), b, {}
+
+    def infer(self, x, relu=False, resid=None, out=None):
+        """relu?(bn(conv(x)) [+ resid]) in ONE launch from the folded operands (no statistics, nothing saved)."""
+        geom = self.geom(x.shape)
+        packed = self._fold_packed.get(geom.in_shape)
+        if packed is None:
+            wf, _ = ops.prep_weights(self._fold_w, geom, need_dgrad=False)
+            b = self._fold_b
+            if b is not None and b.numel() < geom.Co:      # channel padding: pad channels stay exact zeros
+                b = torch.nn.functional.pad(b, (0, geom.Co - b.numel()))
+            packed = self._fold_packed[geom.in_shape] = (wf, None if b is None else b.contiguous())
+        return ops.conv_fwd_fused(x, packed[0], geom, bias=packed[1], resid=resid, relu=relu, out=out)
+
 
 class StemConvUnit(ConvUnit):
     """Conv3d with <= 4 input channels (the RGB stems) as a W-pair-folded implicit GEMM.
@@ -210,6 +246,9 @@ class StemConvUnit(ConvUnit):
         wv = torch.nn.functional.pad(w, (self.lead, self.kext - kW - self.lead, 0, 0, 0, 0, 0, 4 - Cin))
         wv = wv.view(Co, 4, kT, kH, self.kext // 2, 2).permute(0, 5, 1, 2, 3, 4)
         return wv.reshape(Co, 8, kT, kH, self.kext // 2).contiguous()
+
+    def _fold_source(self, w):
+        return self._virtual_weight(w)
 
     def weights(self, geom, fresh=False):
         w = self.conv.weight

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class ConvDesc(Structure):
@@ -48,6 +48,7 @@ _SIGNATURES = {
     "sf_prep_weights": (c_int, [POINTER(ConvDesc), _F, _P, _P, _P]),
     "sf_conv_fwd_mtiles": (c_int, [POINTER(ConvDesc)]),
     "sf_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _F, _F, c_int, _F, _P, _F, _P]),
+    "sf_conv_fwd_fused": (c_int, [POINTER(ConvDesc), _P, _P, _F, _P, c_int32, c_int, _P, _P]),
     "sf_conv_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P]),
     "sf_conv_wgrad_workspace": (c_int64, [POINTER(ConvDesc)]),
     "sf_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _F, _F, c_int, _P, _F, c_float, c_int, _P, c_int64, _P]),

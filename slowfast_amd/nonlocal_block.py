@@ -43,6 +43,29 @@ class BiasConvUnit(ConvUnit):
         return super().backward(x, in_affine, dy, need_dx, resid=resid)
 
 
+def _affinity(mod, theta, phi, g, N, S, T, H, W, device):
+    """y = softmax(theta^T phi / sqrt(Ci)) g^T  or  (theta^T phi / P) g^T (nonlocal_helper.py:117-137) as per-sample batched
+    GEMMs; returns y (N, Ci, T, H, W) and what the backward needs."""
+    Ci = mod.dim_inner
+    P = ops.rows(phi) // N
+    ldp = (P + 7) // 8 * 8
+    th2, ph2, g2 = rows2d(theta), rows2d(phi), rows2d(g)                # [N*S, Ci], [N*P, Ci]
+    A = torch.empty((N, 1, S, ldp), dtype=_f16, device=device)
+    softmax = mod.instantiation == "softmax"
+    alpha = 0.0 if softmax else 1.0 / P
+    tokens.bgemm_heads(th2, (S * Ci, 0), S, Ci, Ci, ph2, (P * Ci, 0), P, Ci, A, (S * ldp, 0), ldp, N, 1, alpha=alpha)
+    desc = tokens.attn_desc(N, 1, Ci, False, (1, 1, S), (1, 1, P))
+    if softmax:
+        tokens.softmax_fwd(desc, A, Ci ** -0.5, None)
+    elif ldp > P:
+        A[..., P:].zero_()                                              # pad columns feed the next contraction
+    gt = tokens.transpose_heads(g2, N, P, 1, Ci, ldp)                   # [N, 1, Ci, ldp]
+    y2 = torch.empty((N * S, Ci), dtype=_f16, device=device)
+    tokens.bgemm_heads(A, (S * ldp, 0), S, ldp, ldp, gt, (Ci * ldp, 0), Ci, ldp, y2, (S * Ci, 0), Ci, N, 1)
+    y = cl5d(y2, N, Ci, (T, H, W))
+    return y, A, desc, P, ldp
+
+
 class NonlocalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, *params):
@@ -58,22 +81,7 @@ class NonlocalFn(torch.autograd.Function):
             xp, arg = x, None
         phi, _ = mod._phi.forward(xp, None, tr)
         g, _ = mod._g.forward(xp, None, tr)
-        P = ops.rows(phi) // N
-        ldp = (P + 7) // 8 * 8
-        th2, ph2, g2 = rows2d(theta), rows2d(phi), rows2d(g)                # [N*S, Ci], [N*P, Ci]
-        A = torch.empty((N, 1, S, ldp), dtype=_f16, device=x.device)
-        softmax = mod.instantiation == "softmax"
-        alpha = 0.0 if softmax else 1.0 / P
-        tokens.bgemm_heads(th2, (S * Ci, 0), S, Ci, Ci, ph2, (P * Ci, 0), P, Ci, A, (S * ldp, 0), ldp, N, 1, alpha=alpha)
-        desc = tokens.attn_desc(N, 1, Ci, False, (1, 1, S), (1, 1, P))
-        if softmax:
-            tokens.softmax_fwd(desc, A, Ci ** -0.5, None)
-        elif ldp > P:
-            A[..., P:].zero_()                                              # pad columns feed the next contraction
-        gt = tokens.transpose_heads(g2, N, P, 1, Ci, ldp)                   # [N, 1, Ci, ldp]
-        y2 = torch.empty((N * S, Ci), dtype=_f16, device=x.device)
-        tokens.bgemm_heads(A, (S * ldp, 0), S, ldp, ldp, gt, (Ci * ldp, 0), Ci, ldp, y2, (S * Ci, 0), Ci, N, 1)
-        y = cl5d(y2, N, Ci, (T, H, W))
+        y, A, desc, P, ldp = _affinity(mod, theta, phi, g, N, S, T, H, W, x.device)
         praw, st = mod._out.forward(y, None, tr)
         out = ops.bn_act(praw, st.scale, st.shift, relu=False, resid=x)
         ctx.mod = mod
@@ -146,4 +154,20 @@ class Nonlocal(nn.Module):
         self._out = BiasConvUnit(self.conv_out, self.bn)
 
     def forward(self, x):
+        if not self.training and self.__dict__.get("_sf_infer"):
+            return self._infer(x)
         return NonlocalFn.apply(x, self, *self.parameters())
+
+    # inference fusion (slowfast_amd.inference): x + bn(conv_out(y)) is one launch (BatchNorm folded, residual epilogue)
+    def _sf_fold(self):
+        for u in (self._theta, self._phi, self._g, self._out):
+            u.fold()
+
+    def _infer(self, x):
+        x = as_cl(x)
+        N, C, T, H, W = x.shape
+        theta = self._theta.infer(x)
+        xp = pool3d_fwd(x, tuple(self.pool_size))[0] if self.use_pool else x
+        phi, g = self._phi.infer(xp), self._g.infer(xp)
+        y = _affinity(self, theta, phi, g, N, T * H * W, T, H, W, x.device)[0]
+        return self._out.infer(y, relu=False, resid=x)

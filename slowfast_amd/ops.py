@@ -203,6 +203,24 @@ def conv_fwd(x, wf, geom, in_affine=None, bias=None, stats=True, out=None):
     return y, part
 
 
+def conv_fwd_fused(x, wf, geom, bias=None, resid=None, relu=False, out=None):
+    """y = relu?(conv3d(x) + bias [+ resid]): the eval-mode convolution with BatchNorm folded into ``wf`` / ``bias``
+    (sf_conv_fwd_fused)."""
+    assert tuple(x.shape) == geom.in_shape, (x.shape, geom.in_shape)
+    y = cl_empty(geom.out_shape, x.device) if out is None else out
+    assert tuple(y.shape) == geom.out_shape
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == geom.Co, "bias must cover the padded channel count"
+    ldr = 0
+    if resid is not None:
+        assert tuple(resid.shape) == geom.out_shape
+        ldr = cl_ld(resid)
+    get_lib().call("sf_conv_fwd_fused", byref(geom.desc(cl_ld(x), cl_ld(y))), x.data_ptr(), wf.data_ptr(), _ptr(bias),
+                   _ptr(resid), ldr, int(bool(relu)), y.data_ptr(), _stream(x),
+                   work=geom.work(reads_x=1, reads_y=int(resid is not None), writes_y=1))
+    return y
+
+
 def conv_dgrad(dy, wd, geom, resid=None, out=None):
     """dx = conv_transpose3d(dy, w) [+ resid]."""
     assert tuple(dy.shape) == geom.out_shape

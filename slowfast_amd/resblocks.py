@@ -4,7 +4,7 @@ the fully fused schedule of engine.ResBlockFn; ``BottleneckTransform`` on its ow
 three conv+BN units materialised."""
 import torch.nn as nn
 
-from .engine import ConvBNActFn, ConvUnit, ResBlockFn
+from .engine import ConvBNActFn, ConvUnit, ResBlockFn, as_cl
 
 
 class BottleneckTransform(nn.Module):
@@ -80,7 +80,28 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         assert self._block_fn is not None, f"no fused schedule for {type(self.branch2).__name__}"
+        if not self.training and self.__dict__.get("_sf_infer"):
+            return self._infer(x)
         return self._block_fn.apply(x, self, *self._param_list)
+
+    # inference fusion (slowfast_amd.inference): 3 launches (4 with the projection shortcut), BatchNorm folded into
+    # the weights, ReLU and the residual addition in the GEMM epilogues
+    def _sf_fold(self):
+        t = self.branch2
+        if not isinstance(t, BottleneckTransform):
+            return False                     # X3DTransform keeps its running-statistics schedule
+        for u in (t._a, t._b, t._c, self._proj):
+            if u is not None:
+                u.fold()
+        return True
+
+    def _infer(self, x):
+        x = as_cl(x)
+        t = self.branch2
+        ya = t._a.infer(x, relu=True)
+        yb = t._b.infer(ya, relu=True)
+        sc = x if self._proj is None else self._proj.infer(x)
+        return t._c.infer(yb, relu=True, resid=sc)
 
 
 def _fold_time(x, n, t):

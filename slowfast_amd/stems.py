@@ -3,6 +3,7 @@ state_dict keys (slowfast/models/stem_helper.py:20-201), executed by the fused e
 conv -> [BN statistics in the conv epilogue] -> BN+ReLU+MaxPool in one pass (engine.StemFn)."""
 import torch.nn as nn
 
+from . import ops
 from .engine import ConvUnit, StemConvUnit, StemFn
 
 
@@ -21,7 +22,21 @@ class ResNetBasicStem(nn.Module):
         self._unit = (StemConvUnit if foldable else ConvUnit)(self.conv, self.bn)
 
     def forward(self, x):
+        if not self.training and self.__dict__.get("_sf_infer"):
+            return self._infer(x)
         return StemFn.apply(x, self, self.conv.weight, self.bn.weight, self.bn.bias)
+
+    # inference fusion (slowfast_amd.inference): conv with BatchNorm folded + ReLU in one launch, then the max-pool
+    def _sf_fold(self):
+        self._unit.fold()
+
+    def _infer(self, x):
+        unit = self._unit
+        xcl = unit.prepare_input(x) if isinstance(unit, StemConvUnit) else ops.to_cl(x)
+        y = unit.infer(xcl, relu=True)
+        k, s, p = self.pool_layer.kernel_size, self.pool_layer.stride, self.pool_layer.padding
+        out, _ = ops.pool_fwd(y, k[1:], s[1:], p[1:], affine=None, want_argmax=False)
+        return out
 
 
 _STEMS = {"basic_stem": ResNetBasicStem}

@@ -6,7 +6,8 @@ from per-stage tables instead of the reference's unrolled constructor."""
 import torch
 import torch.nn as nn
 
-from .engine import ConvUnit, FuseFn
+from . import ops
+from .engine import ConvUnit, FuseFn, as_cl
 from .heads import ResNetBasicHead, ResNetRoIHead
 from .registry import MODEL_REGISTRY
 from .resblocks import ResStage
@@ -74,8 +75,51 @@ class FuseFastToSlow(nn.Module):
         self._unit = ConvUnit(self.conv_f2s, self.bn)
 
     def forward(self, x):
+        if not self.training and self.__dict__.get("_sf_infer"):
+            return self._infer(x)
         x_s_fuse, x_f = FuseFn.apply(x[0], x[1], self, self.conv_f2s.weight, self.bn.weight, self.bn.bias)
         return [x_s_fuse, x_f]
+
+    # inference fusion (slowfast_amd.inference): the lateral conv (BatchNorm folded, ReLU in the epilogue) writes its
+    # channel slice of the concatenated buffer directly
+    def _sf_fold(self):
+        self._unit.fold()
+
+    def _infer(self, x):
+        x_s, x_f = as_cl(x[0]), as_cl(x[1])
+        N, Cs, T, H, W = x_s.shape
+        Cf = self.conv_f2s.out_channels
+        cat = ops.cl_empty((N, Cs + Cf, T, H, W), x_s.device)
+        ops.bn_act(x_s, out=cat[:, :Cs])
+        self._unit.infer(x_f, relu=True, out=cat[:, Cs:])
+        return [cat, x_f]
+
+
+class PathwayPoolFn(torch.autograd.Function):
+    """The non-overlapping nn.MaxPool3d applied after res2 (pathway{p}_pool, video_model_builder.py:330-338, 575-581:
+    kernel == stride, no padding) on the sf_pool3d kernels (byte arg-max, gather backward) instead of ATen."""
+
+    @staticmethod
+    def forward(ctx, x, kernel):
+        from .nonlocal_block import pool3d_fwd
+        x = as_cl(x)
+        out, arg = pool3d_fwd(x, tuple(kernel))
+        ctx.arg, ctx.in_shape, ctx.kernel = arg, tuple(x.shape), tuple(kernel)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .nonlocal_block import pool3d_bwd
+        return pool3d_bwd(as_cl(dout), ctx.arg, ctx.in_shape, ctx.kernel), None
+
+
+def _pathway_pool(pool, x):
+    assert tuple(pool.stride) == tuple(pool.kernel_size) and not any(_t(pool.padding)), "pathway pools do not overlap"
+    return PathwayPoolFn.apply(x, tuple(pool.kernel_size))
+
+
+def _t(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
 
 
 def _bump_batches_tracked(model):
@@ -181,7 +225,7 @@ class SlowFast(_ResNetBase):
         for p in range(self.num_pathways):
             pool = getattr(self, f"pathway{p}_pool")
             if tuple(pool.kernel_size) != (1, 1, 1):
-                x[p] = pool(x[p])
+                x[p] = _pathway_pool(pool, x[p])
         x = self.s3_fuse(self.s3(x))
         x = self.s4_fuse(self.s4(x))
         x = self.s5(x)
@@ -223,6 +267,6 @@ class ResNet(_ResNetBase):
         x = self.s2(self.s1(list(x)))
         pool = self.pathway0_pool
         if tuple(pool.kernel_size) != (1, 1, 1):
-            x[0] = pool(x[0])
+            x[0] = _pathway_pool(pool, x[0])
         x = self.s5(self.s4(self.s3(x)))
         return self.head(x, bboxes) if self.enable_detection else self.head(x)

@@ -416,7 +416,7 @@ class X3DHead(nn.Module):
         assert len(inputs) == 1, "Input tensor does not contain 1 pathway"
         x = inputs[0]
         if self.pool_size is not None and tuple(self.pool_size) != tuple(x.shape[2:]):
-            raise NotImplementedError("X3DHead on inputs larger than the pooling window (fully convolutional test)")
+            return self._forward_sliding(x)
         m = X3DHeadPoolFn.apply(x, self, self.conv_5.weight, self.conv_5_bn.weight, self.conv_5_bn.bias)
         z = torch.relu(torch.nn.functional.linear(m, self.lin_5.weight.view(self.lin_5.out_channels, -1)))
         if hasattr(self, "dropout"):
@@ -425,6 +425,23 @@ class X3DHead(nn.Module):
         if not self.training:
             z = torch.softmax(z, 1) if self.act_func == "softmax" else torch.sigmoid(z)
         return z.view(z.shape[0], -1)
+
+    def _forward_sliding(self, x):
+        """Fully-convolutional inference (head_helper.py:461-488 on DATA.TEST_CROP_SIZE > TRAIN_CROP_SIZE clips, e.g.
+        X3D-M 224 -> 256): conv_5 + BN + ReLU on the kernels, then the AvgPool3d window slides over the (tiny)
+        feature map and lin_5 / projection / activation / spatial mean run per window position in fp32."""
+        from .engine import ConvBNActFn
+        unit = self._conv5
+        y = ConvBNActFn.apply(x, unit, True, self.training, *unit.params())
+        y = y[:, :self.conv_5.out_channels].float()
+        z = self.avg_pool(y.contiguous())
+        z = torch.relu(torch.nn.functional.conv3d(z, self.lin_5.weight)).permute(0, 2, 3, 4, 1)
+        if hasattr(self, "dropout"):
+            z = self.dropout(z)
+        z = self.projection(z)
+        if not self.training:
+            z = self.act(z).mean([1, 2, 3])
+        return z.reshape(z.shape[0], -1)
 
 
 def round_width(width, multiplier, min_width=8, divisor=8):

@@ -76,6 +76,30 @@ def check_conv_fwd(device, in_shape, Co, k, s, p, d=(1, 1, 1), Cw=None, affine=F
     return e
 
 
+def check_conv_fwd_fused(device, in_shape, Co, k, s, p, d=(1, 1, 1), resid=False, relu=True, bias=True, seed=0):
+    """sf_conv_fwd_fused (eval-mode conv with BatchNorm folded into weights + bias, residual / ReLU epilogue) vs
+    relu(F.conv3d(x, w, b) + resid) on the same fp16-rounded operands."""
+    x, w = make_conv_case(seed, in_shape, Co, k, s, p, d)
+    geom = ops.ConvGeom(in_shape, Co, k, s, p, d)
+    wf, _ = ops.prep_weights(w.to(device), geom, need_dgrad=False)
+    g = torch.Generator().manual_seed(seed + 5)
+    b = torch.randn(Co, generator=g) * 0.5 if bias else None
+    ref = F.conv3d(x, w.half().float(), b, s, p, d)
+    r = None
+    if resid:
+        rr = torch.randn(ref.shape, generator=g).half().float()
+        ref = ref.half().float() + rr          # the epilogue adds the residual to the fp16-rounded tile
+        r = host_to_cl(rr, device)
+    if relu:
+        ref = F.relu(ref)
+    y = ops.conv_fwd_fused(host_to_cl(x, device), wf, geom, bias=None if b is None else b.to(device), resid=r, relu=relu)
+    assert tuple(y.shape) == tuple(ref.shape)
+    got = cl_to_host(y)
+    if relu:
+        assert float(got.min()) >= 0.0
+    return assert_close("conv_fwd_fused", got, ref, 2 * F16_EPS)
+
+
 def check_conv_dgrad(device, in_shape, Co, k, s, p, d=(1, 1, 1), resid=False, seed=0):
     x, w = make_conv_case(seed, in_shape, Co, k, s, p, d)
     geom = ops.ConvGeom(in_shape, Co, k, s, p, d)

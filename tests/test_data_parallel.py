@@ -110,3 +110,60 @@ def test_grad_reducer_single_process(sim):
         assert p.grad.data_ptr() >= red.flat.data_ptr()
         assert float((p.grad - r).norm()) <= 1e-3 * float(r.norm()) + 1e-7   # loss scaled by 4: fp16 rounding differs
     red.close()
+
+
+def _test_worker(rank, world, port, simlib, q):
+    """Multi-view testing across 2 ranks: each rank scores its shard of the clips with the inference-fused model, the
+    scores are all-gathered (du.all_gather semantics) and every rank ends with the same per-video ensemble."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SFAMD_LIBRARY=simlib, SF_SIM_THREADS="2")
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from slowfast_amd import inference
+    from tests.kernel_checks import host_to_cl
+    net = _build()
+    for m in net.modules():                       # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    inference.fuse_for_inference(net)
+
+    class Scores(torch.nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x):
+            return torch.softmax(self.net(x[0]), 1)
+
+    V, K, C = 4, 2, 5
+    g = torch.Generator().manual_seed(7)
+    clips = torch.randn((V * K, 16, 2, 8, 8), generator=g)
+    labels_of = torch.randint(0, C, (V,), generator=g)
+    step = inference.TestStep(Scores(net), V, K, C, use_graph=False)
+    # reference: all clips on one rank, no gather
+    with torch.no_grad():
+        ref = Scores(net)([host_to_cl(clips, "cpu")])
+    ref_video = ref.view(V, K, C).sum(1)
+    for it in range(V * K // (2 * world)):        # 2 clips per rank per iteration, clip ids interleaved over the ranks
+        ids = torch.tensor([(it * world + rank) * 2, (it * world + rank) * 2 + 1])
+        preds, labels, vidx = step.step([host_to_cl(clips[ids], "cpu")], labels_of[ids // K], ids)
+        assert preds.shape[0] == 2 * world and vidx.shape[0] == 2 * world
+    err = float((step.video_preds - ref_video).abs().max())
+    q.put((rank, err, step.clip_count.tolist(), bool(torch.equal(step.video_labels, labels_of))))
+    dist.destroy_process_group()
+
+
+def test_multi_view_test_step_two_ranks(hostsim_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_test_worker, args=(r, 2, port, hostsim_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(2)]
+    for rank, err, counts, labels_ok in res:
+        assert err < 1e-5, res          # same kernels on the same clips: only the batch composition differs
+        assert counts == [2, 2, 2, 2] and labels_ok, res

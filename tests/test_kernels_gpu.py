@@ -125,3 +125,13 @@ def test_roi_pool(gpu, aligned):
 @pytest.mark.parametrize("arch,reverse", [("slowfast", False), ("slowfast", True), ("c2d", False)])
 def test_pack_clip_u8(gpu, arch, reverse):
     kc.check_pack_clip(gpu, arch, reverse)
+
+
+def test_conv_fwd_fused(gpu):
+    """sf_conv_fwd_fused at res-stage geometries: direct-to-LDS 1x1x1 with residual + ReLU, strided 1x3x3, temporal
+    3x1x1, a strided projection shortcut without ReLU."""
+    kc.check_conv_fwd_fused(gpu, (2, 64, 4, 14, 14), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), resid=True)
+    kc.check_conv_fwd_fused(gpu, (2, 64, 4, 14, 14), 64, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    kc.check_conv_fwd_fused(gpu, (2, 256, 4, 7, 7), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+    kc.check_conv_fwd_fused(gpu, (2, 80, 4, 14, 14), 136, (1, 1, 1), (1, 2, 2), (0, 0, 0), relu=False)
+    kc.check_conv_fwd_fused(gpu, (1, 32, 8, 7, 7), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), resid=True, bias=False)

@@ -186,3 +186,46 @@ def test_ava_roi_head_matches_reference(gpu):
 def test_mvit_drop_path(gpu):
     """Stochastic depth (MVIT.DROPPATH_RATE 0.5) with pinned masks vs the oracle with the same masks."""
     print(mc.check_mvit_drop_path(gpu))
+
+
+@pytest.mark.parametrize("name", ["eval_slowfast_tiny", "eval_c2d_tiny", "eval_slowfast_nln_tiny", "eval_slowfast_r50_mid"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_eval_path_matches_reference(gpu, name, fused):
+    """tools/test_net.py path: eval-mode forward on DATA.TEST_CROP_SIZE clips (fully-convolutional head) vs the
+    probabilities of the unmodified reference (tests/golden/eval_*.json); ``fused`` = BatchNorm folded into the
+    convolutions, ReLU / residual in the GEMM epilogues (sf_conv_fwd_fused)."""
+    rep = {}
+    try:
+        mc.check_eval(name, gpu, fused=fused, report=rep)
+    finally:
+        print(name, fused, rep.get(name))
+
+
+@pytest.mark.parametrize("name", ["eval_x3d_tiny", "eval_mvit_tiny"])
+def test_eval_path_x3d_mvit(gpu, name):
+    rep = {}
+    try:
+        mc.check_eval(name, gpu, fused=True, report=rep)
+    finally:
+        print(name, rep.get(name))
+
+
+def test_test_step_graph_replay_equals_eager(gpu):
+    """inference.TestStep: the captured eval forward replays to the same scores as the eager call, for new inputs."""
+    import slowfast_amd as sa
+    from oracle import video_ref
+    from slowfast_amd import inference
+    gold = mc.load_golden("slowfast_tiny")
+    cfg = mc.cfg_for(gold)
+    torch.manual_seed(0)
+    model = inference.fuse_for_inference(sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg).to(gpu))
+    step = inference.TestStep(model, num_videos=4, num_clips=2, num_cls=cfg.MODEL.NUM_CLASSES, warmup=1)
+    for it in range(4):
+        inputs, labels = video_ref.synthetic_batch(cfg, 2, 100 + it)
+        inputs = [x.to(gpu) for x in inputs]
+        ids = torch.tensor([2 * it, 2 * it + 1])
+        preds, _, _ = step.step(inputs, labels, ids)
+        with torch.no_grad():
+            eager = model(inputs).float()
+        assert torch.equal(preds, eager), it
+    assert step._graph is not None and step.clip_count.tolist() == [2, 2, 2, 2]
