@@ -61,6 +61,8 @@ def _conv(x, w, *args):
 def _bn(x, sd, prefix, training, stats_out, momentum=0.1, eps=1e-5):
     """nn.BatchNorm3d (slowfast/models/batchnorm_helper.py:24-25 -> torch BatchNorm3d; eps/momentum as passed at
     every construction site, e.g. resnet_helper.py:340-342)."""
+    if prefix + ".split_bn.running_mean" in sd:
+        return _sub_bn(x, sd, prefix, training, stats_out, momentum, eps)
     rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
     if training:
         rm, rv = rm.clone(), rv.clone()
@@ -69,6 +71,23 @@ def _bn(x, sd, prefix, training, stats_out, momentum=0.1, eps=1e-5):
             stats_out[prefix + ".running_mean"], stats_out[prefix + ".running_var"] = rm, rv
         return y
     return F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"], False, momentum, eps)
+
+
+def _sub_bn(x, sd, prefix, training, stats_out, momentum, eps):
+    """SubBatchNorm3d.forward (slowfast/models/batchnorm_helper.py:99-112): training = BatchNorm (no affine) over the
+    batch viewed as (n / S, c * S, t, h, w), i.e. statistics per split of samples n % S; eval = ``bn`` with the
+    aggregated running statistics; then the shared affine pair."""
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    if training:
+        rm, rv = sd[prefix + ".split_bn.running_mean"].clone(), sd[prefix + ".split_bn.running_var"].clone()
+        S = rm.numel() // w.numel()
+        n, c, t, h, ww = x.shape
+        y = F.batch_norm(x.reshape(n // S, c * S, t, h, ww), rm, rv, None, None, True, momentum, eps).reshape(n, c, t, h, ww)
+        if stats_out is not None:
+            stats_out[prefix + ".split_bn.running_mean"], stats_out[prefix + ".split_bn.running_var"] = rm, rv
+    else:
+        y = F.batch_norm(x, sd[prefix + ".bn.running_mean"], sd[prefix + ".bn.running_var"], None, None, False, momentum, eps)
+    return y * w.view(-1, 1, 1, 1) + b.view(-1, 1, 1, 1)
 
 
 def stem(x, sd, prefix, training, stats_out):

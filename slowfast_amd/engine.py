@@ -41,9 +41,68 @@ def remove_grad_ready_listener(fn):
         _listeners.remove(fn)
 
 
+_sub_passes = 1
+_sub_counts = {}
+
+
+def hold_notifications(passes):
+    """A SubBatchNorm3d(S) training step runs S sub-batch passes whose backward passes all add into the same
+    parameter gradients (batchnorm.run_in_splits): a parameter is announced final after its S-th contribution."""
+    global _sub_passes
+    _sub_passes = max(int(passes), 1)
+    _sub_counts.clear()
+
+
 def _notify(params):
+    if _sub_passes > 1:
+        final = []
+        for p in params:
+            c = _sub_counts.get(p, 0) + 1
+            if c >= _sub_passes:
+                _sub_counts.pop(p, None)
+                final.append(p)
+            else:
+                _sub_counts[p] = c
+        params = final
+        if not params:
+            return
     for fn in _listeners:
         fn(params)
+
+
+def _sync_of(bn):
+    """(process group, group size) when ``bn`` exchanges its statistics across ranks (NaiveSyncBatchNorm3d), else None."""
+    fn = getattr(bn, "sync_group", None)
+    return fn() if fn is not None else None
+
+
+def bn_statistics(bn, part, count, C, training):
+    """Partial sums of a producer epilogue -> BNState (scale, shift, mean, rstd); running statistics updated in
+    training mode.  Shared by ConvUnit and the X3D units.  With a sync group the [2, C] sums are all-reduced first
+    (equal per-rank counts, as pytorchvideo's NaiveSyncBatchNorm assumes) and the running statistics follow that class:
+    momentum update with the BIASED batch variance."""
+    use_batch = training or bn.running_mean is None
+    track = bn.track_running_stats and training
+    sync = _sync_of(bn) if use_batch else None
+    if sync is None:
+        st = ops.bn_finalize(part if use_batch else None, count, bn.weight, bn.bias,
+                             bn.running_mean if track or not use_batch else None,
+                             bn.running_var if track or not use_batch else None, bn.momentum, bn.eps,
+                             training=use_batch, C=C)
+        return BNState(*st)
+    import torch.distributed as dist
+    group, gsize = sync
+    tot = part.sum(0, keepdim=True)                      # [1, 2, C] fp32
+    dist.all_reduce(tot, group=group)
+    total = float(count) * gsize
+    if track:
+        Cr = bn.weight.numel()
+        mean = tot[0, 0, :Cr] / total
+        var = tot[0, 1, :Cr] / total - mean * mean
+        bn.running_mean.add_(bn.momentum * (mean - bn.running_mean))
+        bn.running_var.add_(bn.momentum * (var - bn.running_var))
+    st = ops.bn_finalize(tot, total, bn.weight, bn.bias, None, None, bn.momentum, bn.eps, training=True, C=C)
+    return BNState(*st)
 
 
 def as_cl(t):
@@ -114,11 +173,7 @@ class ConvUnit:
             return y, None
         use_batch_stats = training or bn.running_mean is None
         y, part = ops.conv_fwd(x, wf, geom, in_affine=in_affine, bias=self.conv.bias, stats=use_batch_stats)
-        track = bn.track_running_stats and training
-        st = ops.bn_finalize(part, geom.out_rows, bn.weight, bn.bias, bn.running_mean if track or not use_batch_stats else None,
-                             bn.running_var if track or not use_batch_stats else None, bn.momentum, bn.eps,
-                             training=use_batch_stats, C=geom.Co)
-        return y, BNState(*st)
+        return y, bn_statistics(bn, part, geom.out_rows, geom.Co, training)
 
     def backward(self, x, in_affine, dy, need_dx, resid=None):
         """Weight gradient into conv.weight.grad; returns dx (+ resid) when need_dx."""
@@ -146,7 +201,7 @@ class ConvUnit:
             accumulate = False
         return ops.bn_bwd(dz, y, bn.weight, st.mean, st.rstd, dgamma, dbeta, zmask=zmask,
                           relu_affine=(st.scale, st.shift) if relu_self else None, inv_loss_scale=1.0,
-                          accumulate=accumulate, want_g=want_g)
+                          accumulate=accumulate, want_g=want_g, sync=_sync_of(bn))
 
     def params(self):
         p = [self.conv.weight]

@@ -294,7 +294,7 @@ def bn_act(y, scale=None, shift=None, relu=False, resid=None, rscale=None, rshif
 
 
 def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None, inv_loss_scale=1.0,
-           accumulate=False, want_g=False, out=None):
+           accumulate=False, want_g=False, out=None, sync=None):
     """BatchNorm3d (training) backward through an optional ReLU.
 
     dz: gradient w.r.t. act(bn(y)); the ReLU mask is ``zmask > 0`` (block output) or recomputed from
@@ -311,9 +311,26 @@ def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None
     lib.call("sf_bn_bwd_reduce", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
              relu_self, part.data_ptr(), s, work=dict(bytes=2.0 * y.numel() * (2 + int(zmask is not None))))
     coef = torch.empty((3, C), dtype=torch.float32, device=y.device)
-    lib.call("sf_bn_bwd_finalize", part.data_ptr(), nblk, C, gamma.numel(), float(M), gamma.data_ptr(), mean.data_ptr(),
-             rstd.data_ptr(), float(inv_loss_scale), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
-             coef.data_ptr(), s)
+    if sync is None:
+        lib.call("sf_bn_bwd_finalize", part.data_ptr(), nblk, C, gamma.numel(), float(M), gamma.data_ptr(), mean.data_ptr(),
+                 rstd.data_ptr(), float(inv_loss_scale), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
+                 coef.data_ptr(), s)
+    else:
+        # synchronised BatchNorm (NaiveSyncBatchNorm3d): the affine gradients are sums over the LOCAL samples, the
+        # input gradient uses the sums over the whole sync group (autograd of the differentiable all-reduce of the
+        # batch moments): finalize once on the local sums for dgamma / dbeta, once on the all-reduced sums for coef
+        import torch.distributed as dist
+        group, gsize = sync
+        tot = part.sum(0, keepdim=True)                   # [1, 2, C]
+        loc = tot.clone()
+        lib.call("sf_bn_bwd_finalize", loc.data_ptr(), 1, C, gamma.numel(), float(M), gamma.data_ptr(), mean.data_ptr(),
+                 rstd.data_ptr(), float(inv_loss_scale), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
+                 coef.data_ptr(), s)
+        dist.all_reduce(tot, group=group)
+        scratch = torch.empty((2, gamma.numel()), dtype=torch.float32, device=y.device)
+        lib.call("sf_bn_bwd_finalize", tot.data_ptr(), 1, C, gamma.numel(), float(M) * gsize, gamma.data_ptr(),
+                 mean.data_ptr(), rstd.data_ptr(), float(inv_loss_scale), scratch[0].data_ptr(), scratch[1].data_ptr(), 0,
+                 coef.data_ptr(), s)
     dy = cl_empty(y.shape, y.device) if out is None else out
     g = cl_empty(y.shape, y.device) if want_g else None
     lib.call("sf_bn_bwd_apply", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .engine import ConvUnit, FuseFn, as_cl
+from .engine import ConvUnit, FuseFn, as_cl, hold_notifications
 from .heads import ResNetBasicHead, ResNetRoIHead
 from .registry import MODEL_REGISTRY
 from .resblocks import ResStage
@@ -30,12 +30,7 @@ _POOL1 = {"2d": [[1, 1, 1]], "c2d": [[2, 1, 1]], "slow_c2d": [[1, 1, 1]], "i3d":
           "slow_i3d": [[1, 1, 1]], "slow": [[1, 1, 1]], "slowfast": [[1, 1, 1], [1, 1, 1]]}
 
 
-def get_norm(cfg):
-    """BN.NORM_TYPE -> norm layer class (slowfast/models/batchnorm_helper.py:16-37); the hot path uses
-    per-GPU local statistics, i.e. nn.BatchNorm3d as the parameter container."""
-    if cfg.BN.NORM_TYPE == "batchnorm":
-        return nn.BatchNorm3d
-    raise NotImplementedError(f"Norm type {cfg.BN.NORM_TYPE} is outside the hot path (sub/sync BN are multigrid/SSL only)")
+from .batchnorm import get_norm, num_splits_of, run_in_splits  # noqa: E402,F401  (batchnorm_helper.py:16-37)
 
 
 def init_weights(model, fc_init_std=0.01, zero_init_final_bn=True, zero_init_final_conv=False):
@@ -128,7 +123,7 @@ def _bump_batches_tracked(model):
     if bufs is None:
         bufs = model.__dict__["_nbt"] = [m.num_batches_tracked for m in model.modules()
                                          if isinstance(m, nn.modules.batchnorm._BatchNorm)
-                                         and m.num_batches_tracked is not None]
+                                         and m.num_batches_tracked is not None and not m.__dict__.get("_sf_no_bump")]
     if bufs:
         torch._foreach_add_(bufs, 1)
 
@@ -220,6 +215,14 @@ class SlowFast(_ResNetBase):
     def forward(self, x, bboxes=None):
         if self.training:
             _bump_batches_tracked(self)
+            S = num_splits_of(self)
+            hold_notifications(S)
+            if S > 1:                    # SubBatchNorm3d: S sub-batch passes (batchnorm.run_in_splits)
+                assert bboxes is None, "detection batches are not split"
+                return run_in_splits(self, self._forward, list(x), S)
+        return self._forward(x, bboxes)
+
+    def _forward(self, x, bboxes=None):
         x = self.s1_fuse(self.s1(list(x)))
         x = self.s2_fuse(self.s2(x))
         for p in range(self.num_pathways):
@@ -264,6 +267,14 @@ class ResNet(_ResNetBase):
     def forward(self, x, bboxes=None):
         if self.training:
             _bump_batches_tracked(self)
+            S = num_splits_of(self)
+            hold_notifications(S)
+            if S > 1:                    # SubBatchNorm3d: S sub-batch passes (batchnorm.run_in_splits)
+                assert bboxes is None, "detection batches are not split"
+                return run_in_splits(self, self._forward, list(x), S)
+        return self._forward(x, bboxes)
+
+    def _forward(self, x, bboxes=None):
         x = self.s2(self.s1(list(x)))
         pool = self.pathway0_pool
         if tuple(pool.kernel_size) != (1, 1, 1):

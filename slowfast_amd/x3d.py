@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, tokens
-from .engine import BNState, ConvUnit, StemConvUnit, _grad_dest, _notify, as_cl
+from .engine import BNState, ConvUnit, StemConvUnit, _grad_dest, _notify, _sync_of, as_cl, bn_statistics
 from .lib import get_lib
 from .registry import MODEL_REGISTRY
 from .resblocks import ResStage, _TRANS
@@ -95,14 +95,7 @@ class BNUnit:
         self.bn = bn
 
     def finalize(self, part, count, C, training):
-        bn = self.bn
-        use_batch = training or bn.running_mean is None
-        track = bn.track_running_stats and training
-        st = ops.bn_finalize(part if use_batch else None, count, bn.weight, bn.bias,
-                             bn.running_mean if track or not use_batch else None,
-                             bn.running_var if track or not use_batch else None, bn.momentum, bn.eps,
-                             training=use_batch, C=C)
-        return BNState(*st)
+        return bn_statistics(self.bn, part, count, C, training)
 
     def backward(self, dz, y, st, relu_self=False):
         bn = self.bn
@@ -110,7 +103,7 @@ class BNUnit:
         dbeta, zb = _grad_dest(bn.bias)
         assert zg == zb
         return ops.bn_bwd(dz, y, bn.weight, st.mean, st.rstd, dgamma, dbeta,
-                          relu_affine=(st.scale, st.shift) if relu_self else None, accumulate=not zg)
+                          relu_affine=(st.scale, st.shift) if relu_self else None, accumulate=not zg, sync=_sync_of(bn))
 
 
 class DwUnit:
@@ -500,9 +493,16 @@ class X3D(nn.Module):
         init_weights(self, cfg.MODEL.FC_INIT_STD, cfg.RESNET.ZERO_INIT_FINAL_BN)
 
     def forward(self, x, bboxes=None):
-        from .video_models import _bump_batches_tracked
+        from .video_models import _bump_batches_tracked, hold_notifications, num_splits_of, run_in_splits
         if self.training:
             _bump_batches_tracked(self)
+            S = num_splits_of(self)
+            hold_notifications(S)
+            if S > 1:                    # SubBatchNorm3d: S sub-batch passes (batchnorm.run_in_splits)
+                return run_in_splits(self, self._forward, list(x), S)
+        return self._forward(x)
+
+    def _forward(self, x):
         x = self.s1(list(x))
         for s in (self.s2, self.s3, self.s4, self.s5):
             x = s(x)

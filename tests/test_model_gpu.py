@@ -229,3 +229,13 @@ def test_test_step_graph_replay_equals_eager(gpu):
             eager = model(inputs).float()
         assert torch.equal(preds, eager), it
     assert step._graph is not None and step.clip_count.tolist() == [2, 2, 2, 2]
+
+
+def test_sub_batchnorm_matches_reference(gpu):
+    """BN.NORM_TYPE sub_batchnorm (NUM_SPLITS 2) through the engine's sub-batch passes vs the unmodified reference."""
+    rep = {}
+    try:
+        mc.check_engine("slowfast_subbn_tiny", gpu, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.1,
+                        tol_global=1e-2, report=rep)
+    finally:
+        print(rep)

@@ -67,3 +67,38 @@ def test_nonlocal_group_folding_matches_oracle(sim):
                         tol_global=1e-2, report=rep)
     finally:
         print(rep)
+
+
+def test_sub_batchnorm_matches_reference(sim):
+    """BN.NORM_TYPE sub_batchnorm, NUM_SPLITS 2 (multigrid training): the engine's sub-batch passes (batchnorm.run_in_splits)
+    vs the unmodified reference's SubBatchNorm3d -- logits, loss, every parameter gradient and the per-split running
+    statistics; then aggregate_stats() + eval against the oracle's eval forward."""
+    import torch
+    import slowfast_amd as sa
+    from oracle import video_ref
+    rep = {}
+    try:
+        mc.check_engine("slowfast_subbn_tiny", sim, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.1,
+                        tol_global=1e-2, report=rep)
+    finally:
+        print(rep)
+    gold = mc.load_golden("slowfast_subbn_tiny")
+    cfg = mc.cfg_for(gold)
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    sd = video_ref.randomize_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, 5)
+    model.load_state_dict(sd)
+    from slowfast_amd.batchnorm import SubBatchNorm3d
+    subs = [m for m in model.modules() if isinstance(m, SubBatchNorm3d)]
+    assert subs and all(m.num_splits == 2 for m in subs)
+    for m in subs:
+        m.aggregate_stats()
+    m = subs[0]
+    C = m.num_features
+    means, vars_ = m.split_bn.running_mean.view(2, C), m.split_bn.running_var.view(2, C)
+    assert torch.allclose(m.bn.running_mean, means.mean(0))
+    assert torch.allclose(m.bn.running_var, vars_.mean(0) + ((means - means.mean(0)) ** 2).mean(0))
+    inputs, _ = video_ref.synthetic_batch(cfg, 2, 11)
+    ref = video_ref.video_forward(model.state_dict(), cfg, inputs, training=False)
+    with torch.no_grad():
+        out = model.eval()(inputs).float()
+    assert float((out - ref).abs().max()) < 0.05 * float(ref.abs().max())     # tiny-model conditioning (see module docstring)
