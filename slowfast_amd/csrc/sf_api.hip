@@ -291,6 +291,18 @@ extern "C" int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const voi
     if (check_desc(d)) return -1;
     REQUIRE(x && wf && y, "sf_conv_fwd_fused: null pointer");
     REQUIRE(!resid || (ldr >= d->Co && ldr % 8 == 0), "sf_conv_fwd_fused: bad residual pitch");
+    if (!resid) {        // thin W-pair-folded stems: the LDS-patch direct convolution with bias / ReLU in its epilogue
+        const StemPlan sp = plan_stem(d);
+        if (sp.ok) {
+            StemParams q = stem_params(d, sp, x);
+            int32_t ldf0, ldd0;
+            sf_conv_weight_ld(d, &ldf0, &ldd0);
+            q.wmat = (const f16*)wf; q.ldw = ldf0; q.y = (f16*)y;
+            q.bias = bias; q.out_relu = out_relu;
+            hipLaunchKernelGGL(sf_stem_fwd_kernel, dim3(sp.ntiles), dim3(SF_THREADS), 0, (hipStream_t)stream, q);
+            return check_launch("stem_fwd_fused");
+        }
+    }
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.g = gather_fwd(d, x, nullptr, nullptr, 0);

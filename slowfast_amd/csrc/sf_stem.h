@@ -37,6 +37,7 @@ struct StemParams {
     const f16* wmat; int ldw;         // [Co][ldw], k = (kt*kH + kh)*32 + pair*8 + e
     f16* y; int ldy;
     float* stat_part; int stat_rows;  // [stat_rows][2][Co]; rows beyond the workgroup count are zeroed here
+    const float* bias; int out_relu;  // inference-fused forward (sf_conv_fwd_fused): y = relu?(conv + bias[co])
     int tiles_w, tiles_h, tiles_t, ntiles;
     FastDiv fd_tw, fd_th, fd_tt;
     int F, PR;                        // patch frames / rows
@@ -128,6 +129,12 @@ __global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_kernel(StemParams p) {
     // lane: channels 4*g4 .. 4*g4+3 of pixel (t0 + wave, h0 + i, w0 + pl)
     const int to = t.t0 + wave, wo = t.w0 + pl;
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && 4 * g4 < p.Co) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4[r] = p.bias[4 * g4 + r];
+    }
+    const float lo = p.out_relu ? 0.f : -INFINITY;
 #pragma unroll
     for (int i = 0; i < SF_STEM_TH; ++i) {
         const int ho = t.h0 + i;
@@ -137,7 +144,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_kernel(StemParams p) {
             for (int r = 0; r < 4; ++r) { s4[r] += acc[i][r]; q4[r] += acc[i][r] * acc[i][r]; }
             if (4 * g4 < p.Co) {
                 const int64_t m = (((int64_t)t.n * p.To + to) * p.Ho + ho) * p.Wo + wo;
-                f16x4 o = {(f16)acc[i][0], (f16)acc[i][1], (f16)acc[i][2], (f16)acc[i][3]};
+                f16x4 o = {(f16)fmaxf(acc[i][0] + b4[0], lo), (f16)fmaxf(acc[i][1] + b4[1], lo),
+                           (f16)fmaxf(acc[i][2] + b4[2], lo), (f16)fmaxf(acc[i][3] + b4[3], lo)};
                 *reinterpret_cast<f16x4*>(p.y + m * p.ldy + 4 * g4) = o;
             }
         }

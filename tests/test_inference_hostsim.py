@@ -16,6 +16,13 @@ def test_conv_fwd_fused_kernel(sim):
     kc.check_conv_fwd_fused(sim, (1, 24, 1, 6, 6), 136, (1, 1, 1), (1, 2, 2), (0, 0, 0), resid=True, bias=False)
 
 
+def test_conv_fwd_fused_thin_stem(sim):
+    """W-pair-folded thin stems take the LDS-patch direct convolution with the bias / ReLU epilogue (sf_stem.h)."""
+    kc.check_conv_fwd_fused(sim, (2, 8, 6, 36, 22), 8, (5, 7, 4), (1, 2, 1), (2, 3, 2))
+    kc.check_conv_fwd_fused(sim, (1, 8, 3, 20, 20), 16, (1, 7, 4), (1, 2, 1), (0, 3, 2), relu=False)
+    kc.check_conv_fwd_fused(sim, (1, 8, 9, 10, 9), 8, (3, 5, 4), (2, 1, 1), (1, 2, 2), bias=False)
+
+
 @pytest.mark.parametrize("name", ["eval_slowfast_tiny", "eval_c2d_tiny", "eval_slowfast_nln_tiny"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_eval_resnet_family_matches_reference(sim, name, fused):

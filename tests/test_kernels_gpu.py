@@ -135,3 +135,6 @@ def test_conv_fwd_fused(gpu):
     kc.check_conv_fwd_fused(gpu, (2, 256, 4, 7, 7), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0))
     kc.check_conv_fwd_fused(gpu, (2, 80, 4, 14, 14), 136, (1, 1, 1), (1, 2, 2), (0, 0, 0), relu=False)
     kc.check_conv_fwd_fused(gpu, (1, 32, 8, 7, 7), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), resid=True, bias=False)
+    # thin W-pair-folded stems: LDS-patch direct convolution with the bias / ReLU epilogue
+    kc.check_conv_fwd_fused(gpu, (2, 8, 8, 64, 32), 8, (5, 7, 4), (1, 2, 1), (2, 3, 2))
+    kc.check_conv_fwd_fused(gpu, (2, 8, 3, 36, 22), 16, (1, 7, 4), (1, 2, 1), (0, 3, 2), relu=False)

@@ -54,6 +54,14 @@ def main():
         dt = time.perf_counter() - t0
         out["fused" if fused else "running_stats"] = {"clips_per_s": round(a.batch * a.steps / dt, 1),
                                                       "ms_per_step": round(dt / a.steps * 1e3, 3)}
+    from slowfast_amd.profiler import KernelProfiler
+    with KernelProfiler() as prof, torch.no_grad():          # one eager fused forward with HIP events per launch
+        model(inputs)
+    summ = prof.summary()
+    tot = sum(v["ms"] for v in summ.values())
+    out["fused_kernels"] = {k: {"calls": v["calls"], "ms": round(v["ms"], 3), "share": round(v["ms"] / tot, 3),
+                                "GB/s": round(v["gbs"], 1), "TFLOP/s": round(v["tflops"], 1)}
+                            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:6]}
     print(json.dumps(out), flush=True)
 
 
