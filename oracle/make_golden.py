@@ -91,6 +91,20 @@ CASES = {
                    "MVIT.EMBED_DIM", 32, "MVIT.DIM_MUL", "[[1, 2.0], [3, 2.0]]", "MVIT.HEAD_MUL", "[[1, 2.0], [3, 2.0]]",
                    "MVIT.POOL_Q_STRIDE", "[[0, 1, 1, 1], [1, 1, 2, 2], [2, 1, 1, 1], [3, 1, 2, 2]]",
                    "MVIT.POOL_KV_STRIDE_ADAPTIVE", "[1, 4, 4]", "MIXUP.ENABLE", False], 2),
+    # MViTv1 family (configs/Kinetics/MVIT_B_16x4_CONV.yaml): separate learned position embeddings, dimension change after
+    # the Mlp, blocks 0 and 2 without q pooling, no relative positions, no residual pooling
+    "mvit_v1_tiny": ("configs/Kinetics/MVIT_B_16x4_CONV.yaml",
+                     ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "MODEL.NUM_CLASSES", 10,
+                      "DATA.TRAIN_CROP_SIZE", 64, "DATA.TEST_CROP_SIZE", 64, "DATA.NUM_FRAMES", 8, "MVIT.DEPTH", 4,
+                      "MVIT.EMBED_DIM", 32, "MVIT.DIM_MUL", "[[1, 2.0], [3, 2.0]]", "MVIT.HEAD_MUL", "[[1, 2.0], [3, 2.0]]",
+                      "MVIT.POOL_Q_STRIDE", "[[1, 1, 2, 2], [3, 1, 2, 2]]", "MVIT.POOL_KV_STRIDE_ADAPTIVE", "[1, 4, 4]",
+                      "MIXUP.ENABLE", False], 2),
+    # plain video ViT as the masked-SSL fine-tuning configs build it (configs/masked_ssl/k400_VIT_B_16x4_FT.yaml): no
+    # pooling anywhere, separate position embeddings, mean pooling of the patch tokens before the final norm
+    "vit_tiny": ("configs/masked_ssl/k400_VIT_B_16x4_FT.yaml",
+                 ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "MODEL.NUM_CLASSES", 10,
+                  "DATA.TRAIN_CROP_SIZE", 64, "DATA.TEST_CROP_SIZE", 64, "DATA.NUM_FRAMES", 8, "MVIT.DEPTH", 2,
+                  "MVIT.EMBED_DIM", 64, "MVIT.NUM_HEADS", 2, "MIXUP.ENABLE", False], 2),
     "mvit_s_mid": ("configs/Kinetics/MVITv2_S_16x4.yaml",
                    ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96,
                     "DATA.TEST_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8, "MIXUP.ENABLE", False], 2),

@@ -1,5 +1,6 @@
-"""CPU restatement (plain torch fp32/fp64) of the reference's MViT forward graph (MViTv2 configuration family:
-conv pooling, cls token, decomposed relative positions, residual pooling, DIM_MUL_IN_ATT).
+"""CPU restatement (plain torch fp32/fp64) of the reference's MViT forward graph: the MViTv2 configuration family
+(conv pooling, cls token, decomposed relative positions, residual pooling, DIM_MUL_IN_ATT) and the MViTv1 / ViT one
+(learned absolute position embedding, dimension change after the Mlp, blocks without q or k/v pooling, mean pooling).
 
 TEST INFRASTRUCTURE: the oracle the HIP engine's MViT path is checked against.  Pinned to the unmodified reference
 by oracle/make_golden.py (golden fixtures tests/golden/mvit_*.json).  Each function cites the reference lines it
@@ -94,19 +95,25 @@ def _rel_pos_bias(attn, q, has_cls, q_shape, k_shape, rel_h, rel_w, rel_t):
 
 
 def attention(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, residual_pooling=True):
-    """MultiScaleAttention.forward (attention.py:293-392), mode "conv", pool_first False, fused qkv."""
+    """MultiScaleAttention.forward (attention.py:293-392), mode "conv", pool_first False, fused qkv.  q (k / v) is left
+    un-pooled and un-normed when the block has no pool_q (pool_k / pool_v) -- attention.py:199-203, 236-262: kernel ()
+    when both kernel and stride are all ones (MViTv1 blocks outside POOL_Q_STRIDE)."""
     B, N, _ = x.shape
     qkv = _linear(x, sd, prefix + ".qkv").reshape(B, N, 3, heads, -1).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    q, q_shape = attention_pool(q, sd[prefix + ".pool_q.weight"], stride_q, thw, has_cls, prefix + ".norm_q", sd)
-    k, k_shape = attention_pool(k, sd[prefix + ".pool_k.weight"], stride_kv, thw, has_cls, prefix + ".norm_k", sd)
-    v, _ = attention_pool(v, sd[prefix + ".pool_v.weight"], stride_kv, thw, has_cls, prefix + ".norm_v", sd)
+    q_shape = k_shape = list(thw)
+    if prefix + ".pool_q.weight" in sd:
+        q, q_shape = attention_pool(q, sd[prefix + ".pool_q.weight"], stride_q, thw, has_cls, prefix + ".norm_q", sd)
+    if prefix + ".pool_k.weight" in sd:
+        k, k_shape = attention_pool(k, sd[prefix + ".pool_k.weight"], stride_kv, thw, has_cls, prefix + ".norm_k", sd)
+        v, _ = attention_pool(v, sd[prefix + ".pool_v.weight"], stride_kv, thw, has_cls, prefix + ".norm_v", sd)
     head_dim = q.shape[-1]
     scale = head_dim ** -0.5
     attn = (q * scale) @ k.transpose(-2, -1)
     attn = _store(attn)
-    attn = _rel_pos_bias(attn, q, has_cls, q_shape, k_shape, sd.get(prefix + ".rel_pos_h"), sd.get(prefix + ".rel_pos_w"),
-                         sd.get(prefix + ".rel_pos_t"))
+    if prefix + ".rel_pos_h" in sd or prefix + ".rel_pos_t" in sd:
+        attn = _rel_pos_bias(attn, q, has_cls, q_shape, k_shape, sd.get(prefix + ".rel_pos_h"), sd.get(prefix + ".rel_pos_w"),
+                             sd.get(prefix + ".rel_pos_t"))
     attn = _store(attn.softmax(dim=-1))
     o = attn @ v
     if residual_pooling:
@@ -119,12 +126,15 @@ def attention(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, resi
     return _linear(o, sd, prefix + ".proj"), q_shape
 
 
-def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, drop=None):
-    """MultiScaleBlock.forward (attention.py:491-514) with DIM_MUL_IN_ATT (proj applied to the normed input).
+def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, drop=None, residual_pooling=True,
+          dim_mul_in_att=True):
+    """MultiScaleBlock.forward (attention.py:491-514).  The dimension change (``proj``) acts on the normed block input
+    with DIM_MUL_IN_ATT (MViTv2) and on the normed Mlp input without it (MViTv1, attention.py:507-508).
     drop = (s1, s2): per-sample scales mask/keep_prob of the two drop_path() calls (common.py:46-59), None = off."""
     x_norm = _ln(x, sd, prefix + ".norm1")
-    x_block, thw_new = attention(x_norm, sd, prefix + ".attn", thw, heads, stride_q, stride_kv, has_cls)
-    if prefix + ".proj.weight" in sd:
+    x_block, thw_new = attention(x_norm, sd, prefix + ".attn", thw, heads, stride_q, stride_kv, has_cls, residual_pooling)
+    has_proj = prefix + ".proj.weight" in sd
+    if has_proj and dim_mul_in_att:
         x = _linear(x_norm, sd, prefix + ".proj")
     if math.prod(stride_q) > 1:
         x_res, _ = attention_pool(x, None, stride_q, thw, has_cls, pool_mode="max")
@@ -137,6 +147,8 @@ def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, drop=Non
     h = _linear(x_norm, sd, prefix + ".mlp.fc1")
     h = _store(F.gelu(h))
     x_mlp = F.linear(h, _store(sd[prefix + ".mlp.fc2.weight"]), sd[prefix + ".mlp.fc2.bias"])
+    if has_proj and not dim_mul_in_att:
+        x = _linear(x_norm, sd, prefix + ".proj")
     if drop is not None:
         x_mlp = _store(x_mlp) * drop[1].view(-1, 1, 1)
     return _store(x + x_mlp), thw_new
@@ -152,12 +164,16 @@ def mvit_plan(cfg):
     stride_q = [[1, 1, 1] for _ in range(depth)]
     for e in cfg.MVIT.POOL_Q_STRIDE:
         stride_q[e[0]] = list(e[1:])
-    stride_kv = []
-    _kv = list(cfg.MVIT.POOL_KV_STRIDE_ADAPTIVE)
-    for i in range(depth):
-        if math.prod(stride_q[i]) > 1:
-            _kv = [max(_kv[d] // stride_q[i][d], 1) for d in range(3)]
-        stride_kv.append(list(_kv))
+    stride_kv = [[1, 1, 1] for _ in range(depth)]
+    if cfg.MVIT.POOL_KV_STRIDE_ADAPTIVE is not None:
+        _kv = list(cfg.MVIT.POOL_KV_STRIDE_ADAPTIVE)
+        for i in range(depth):
+            if math.prod(stride_q[i]) > 1:
+                _kv = [max(_kv[d] // stride_q[i][d], 1) for d in range(3)]
+            stride_kv[i] = list(_kv)
+    else:
+        for e in cfg.MVIT.POOL_KV_STRIDE:
+            stride_kv[e[0]] = list(e[1:])
     heads, plan = cfg.MVIT.NUM_HEADS, []
     for i in range(depth):
         heads = int(round(heads * head_mul[i]))
@@ -166,9 +182,9 @@ def mvit_plan(cfg):
 
 
 def mvit_forward(sd, cfg, inputs, training=True, drop=None):
-    """MViT.forward (video_model_builder.py:1166-1244) for CLS_EMBED_ON, no abs-pos, no dropout,
-    + TransformerBasicHead.forward (head_helper.py:538-563).  drop = per-block (s1, s2) stochastic-depth scales
-    (the sampled masks of drop_path(), common.py:46-59, divided by keep_prob) or None (rate 0)."""
+    """MViT.forward (video_model_builder.py:1166-1244) for CLS_EMBED_ON, learned absolute position embedding (joint or
+    SEP_POS_EMBED) or none, no dropout, + TransformerBasicHead.forward (head_helper.py:538-563).  drop = per-block
+    (s1, s2) stochastic-depth scales (the sampled masks of drop_path(), common.py:46-59, divided by keep_prob) or None."""
     x = inputs[0]
     w = sd["patch_embed.proj.weight"]
     stride, pad = tuple(cfg.MVIT.PATCH_STRIDE), tuple(cfg.MVIT.PATCH_PADDING)
@@ -176,11 +192,22 @@ def mvit_forward(sd, cfg, inputs, training=True, drop=None):
     B, C, T, H, W = x.shape
     x = x.flatten(2).transpose(1, 2)
     x = torch.cat((sd["cls_token"].expand(B, -1, -1), x), dim=1)
+    if cfg.MVIT.USE_ABS_POS:            # video_model_builder.py:1189-1203 (same clip size as constructed: no interpolation)
+        if cfg.MVIT.SEP_POS_EMBED:
+            pos = sd["pos_embed_spatial"].repeat(1, T, 1) + torch.repeat_interleave(sd["pos_embed_temporal"], H * W, dim=1)
+            pos = torch.cat([sd["pos_embed_class"], pos], 1)
+        else:
+            pos = sd["pos_embed"]
+        x = x + pos
     x = _store(x)
     thw = [T, H, W]
     for i, (heads, sq, skv) in enumerate(mvit_plan(cfg)):
-        x, thw = block(x, sd, f"blocks.{i}", thw, heads, sq, skv, drop=None if drop is None else drop[i])
-    x = _ln(x[:, 0], sd, "norm")
+        x, thw = block(x, sd, f"blocks.{i}", thw, heads, sq, skv, drop=None if drop is None else drop[i],
+                       residual_pooling=cfg.MVIT.RESIDUAL_POOLING, dim_mul_in_att=cfg.MVIT.DIM_MUL_IN_ATT)
+    if cfg.MVIT.USE_MEAN_POOLING:       # video_model_builder.py:1228-1232: mean over the patch tokens, then norm
+        x = _ln(x[:, 1:].mean(1), sd, "norm")
+    else:
+        x = _ln(x[:, 0], sd, "norm")
     z = F.linear(x, sd["head.projection.weight"], sd["head.projection.bias"])
     if not training and cfg.MODEL.HEAD_ACT == "softmax":
         z = F.softmax(z, dim=1)
@@ -198,6 +225,8 @@ def randomize_state(shapes, seed, dtype=torch.float32):
             sd[name] = (torch.randn(shape, generator=g) * 0.1).to(dtype)
         elif "rel_pos" in name:
             sd[name] = (torch.randn(shape, generator=g) * 0.2).to(dtype)
+        elif name.startswith("pos_embed"):
+            sd[name] = (torch.randn(shape, generator=g) * 0.5).to(dtype)
         elif name == "cls_token":
             sd[name] = (torch.randn(shape, generator=g) * 0.5).to(dtype)
         elif len(shape) == 5:                                     # conv weights: fan-in scaled

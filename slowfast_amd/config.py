@@ -177,6 +177,38 @@ PRESETS["MVITv2_S_16x4"] = {
 }
 
 
+# configs/Kinetics/MVIT_B_16x4_CONV.yaml (MViTv1: separate learned position embeddings, dimension change after the Mlp,
+# q pooling in blocks 1 / 3 / 14 only)
+PRESETS["MVIT_B_16x4_CONV"] = {
+    "DATA": {"NUM_FRAMES": 16, "SAMPLING_RATE": 4, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 224,
+             "INPUT_CHANNEL_NUM": [3]},
+    "MVIT": {"ZERO_DECAY_POS_CLS": False, "SEP_POS_EMBED": True, "DEPTH": 16, "NUM_HEADS": 1, "EMBED_DIM": 96,
+             "PATCH_KERNEL": [3, 7, 7], "PATCH_STRIDE": [2, 4, 4], "PATCH_PADDING": [1, 3, 3], "MLP_RATIO": 4.0,
+             "QKV_BIAS": True, "DROPPATH_RATE": 0.2, "NORM": "layernorm", "MODE": "conv", "CLS_EMBED_ON": True,
+             "DIM_MUL": [[1, 2.0], [3, 2.0], [14, 2.0]], "HEAD_MUL": [[1, 2.0], [3, 2.0], [14, 2.0]],
+             "POOL_KVQ_KERNEL": [3, 3, 3], "POOL_KV_STRIDE_ADAPTIVE": [1, 8, 8],
+             "POOL_Q_STRIDE": [[1, 1, 2, 2], [3, 1, 2, 2], [14, 1, 2, 2]], "DROPOUT_RATE": 0.0},
+    "SOLVER": {"BASE_LR": 0.0001, "MOMENTUM": 0.9, "WEIGHT_DECAY": 0.05, "OPTIMIZING_METHOD": "adamw",
+               "ZERO_WD_1D_PARAM": True, "CLIP_GRAD_L2NORM": 1.0},
+    "MODEL": {"NUM_CLASSES": 400, "ARCH": "mvit", "MODEL_NAME": "MViT", "LOSS_FUNC": "soft_cross_entropy",
+              "DROPOUT_RATE": 0.5},
+}
+
+# configs/masked_ssl/k400_VIT_B_16x4_FT.yaml (plain video ViT-B fine-tuning: no pooling, mean pooling before the norm)
+PRESETS["k400_VIT_B_16x4_FT"] = {
+    "DATA": {"NUM_FRAMES": 16, "SAMPLING_RATE": 4, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 224,
+             "INPUT_CHANNEL_NUM": [3]},
+    "MVIT": {"ZERO_DECAY_POS_CLS": False, "SEP_POS_EMBED": True, "PATCH_KERNEL": [2, 16, 16], "PATCH_STRIDE": [2, 16, 16],
+             "PATCH_PADDING": [0, 0, 0], "EMBED_DIM": 768, "NUM_HEADS": 12, "MLP_RATIO": 4.0, "QKV_BIAS": True,
+             "NORM": "layernorm", "DEPTH": 12, "MODE": "conv", "DROPPATH_RATE": 0.1, "LAYER_SCALE_INIT_VALUE": 0.0,
+             "USE_MEAN_POOLING": True, "HEAD_INIT_SCALE": 0.001},
+    "SOLVER": {"BASE_LR": 6e-4, "WEIGHT_DECAY": 0.05, "OPTIMIZING_METHOD": "adamw", "ZERO_WD_1D_PARAM": True,
+               "CLIP_GRAD_L2NORM": 5.0},
+    "MODEL": {"NUM_CLASSES": 400, "ARCH": "mvit", "MODEL_NAME": "MViT", "LOSS_FUNC": "soft_cross_entropy",
+              "DROPOUT_RATE": 0.3},
+}
+
+
 # configs/Kinetics/X3D_M.yaml
 PRESETS["X3D_M"] = {
     "DATA": {"NUM_FRAMES": 16, "SAMPLING_RATE": 5, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256, "INPUT_CHANNEL_NUM": [3]},

@@ -3,9 +3,11 @@ the ``MViT`` model builder with the reference's constructor signatures, cfg keys
 (slowfast/models/attention.py:150-514, common.py:7-34, stem_helper.py:288-320, head_helper.py:491-563,
 video_model_builder.py:805-1244), executed by the token-space engine (mvit_engine.py).
 
-Scope of this path (the MViTv2 configuration family of configs/Kinetics/MVITv2_*.yaml): MODE "conv", fused qkv,
-POOL_FIRST False, cls token on, decomposed relative positions, residual pooling, DIM_MUL_IN_ATT, no absolute
-position embedding.  Options outside it raise NotImplementedError instead of silently running something else.
+Scope of this path: MODE "conv", fused qkv, POOL_FIRST False, cls token on -- i.e. the MViTv2 family of
+configs/Kinetics/MVITv2_*.yaml (decomposed relative positions, residual pooling, DIM_MUL_IN_ATT), the MViTv1 family of
+configs/Kinetics/MVIT_B_*_CONV.yaml (learned absolute position embeddings, dimension change after the Mlp, blocks
+without q pooling) and the plain video ViT of configs/masked_ssl/k400_VIT_*_FT.yaml (no pooling, mean pooling before
+the final norm).  Options outside it raise NotImplementedError instead of silently running something else.
 """
 import math
 from functools import partial
@@ -39,9 +41,10 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv3d(dim_in, dim_out, kernel_size=tuple(kernel), stride=tuple(stride), padding=tuple(padding))
         self._unit = StemConvUnit(self.proj, None)
 
-    def forward(self, x, cls_token=None):
-        """(B, 3, T, H, W) fp32 clip -> tokens (B, [1 +] T'H'W', C) fp16 and the (B, C, T', H', W') shape."""
-        out = PatchEmbedFn.apply(x, self, cls_token, self.proj.weight, self.proj.bias)
+    def forward(self, x, cls_token=None, pos_embed=None):
+        """(B, 3, T, H, W) fp32 clip -> tokens (B, [1 +] T'H'W', C) fp16 (+ the absolute position embedding
+        [1, N, C] when given) and the (B, C, T', H', W') shape."""
+        out = PatchEmbedFn.apply(x, self, cls_token, pos_embed, self.proj.weight, self.proj.bias)
         g = self._unit.geom(self._unit.prepare_shape(x.shape))
         return out, (x.shape[0], self.proj.out_channels, g.To, g.Ho, g.Wo)
 
@@ -70,8 +73,11 @@ class MultiScaleAttention(nn.Module):
         super().__init__()
         if pool_first or separate_qkv or mode != "conv" or drop_rate > 0.0:
             raise NotImplementedError("MultiScaleAttention: only mode='conv', fused qkv, pool_first=False, no dropout")
-        if len(kernel_q) == 0 or len(kernel_kv) == 0 or math.prod(kernel_q) == 1 or math.prod(kernel_kv) == 1:
-            raise NotImplementedError("MultiScaleAttention without q / kv pooling convs (MViTv1 blocks)")
+        # "Skip pooling with kernel and stride size of (1, 1, 1)" (attention.py:199-203)
+        if math.prod(kernel_q) == 1 and math.prod(stride_q) == 1:
+            kernel_q = ()
+        if math.prod(kernel_kv) == 1 and math.prod(stride_kv) == 1:
+            kernel_kv = ()
         self.pool_first, self.separate_qkv, self.drop_rate = pool_first, separate_qkv, drop_rate
         self.num_heads, self.dim_out = num_heads, dim_out
         head_dim = dim_out // num_heads
@@ -81,12 +87,13 @@ class MultiScaleAttention(nn.Module):
         self.qkv = nn.Linear(dim, dim_out * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim_out, dim_out)
         conv = partial(nn.Conv3d, head_dim, head_dim, groups=head_dim, bias=False)
-        self.pool_q = conv(tuple(kernel_q), stride=tuple(stride_q), padding=tuple(pad_q))
-        self.norm_q = norm_layer(head_dim)
-        self.pool_k = conv(tuple(kernel_kv), stride=tuple(stride_kv), padding=tuple(pad_kv))
-        self.norm_k = norm_layer(head_dim)
-        self.pool_v = conv(tuple(kernel_kv), stride=tuple(stride_kv), padding=tuple(pad_kv))
-        self.norm_v = norm_layer(head_dim)
+        has_q, has_kv = len(kernel_q) > 0, len(kernel_kv) > 0
+        self.pool_q = conv(tuple(kernel_q), stride=tuple(stride_q), padding=tuple(pad_q)) if has_q else None
+        self.norm_q = norm_layer(head_dim) if has_q else None
+        self.pool_k = conv(tuple(kernel_kv), stride=tuple(stride_kv), padding=tuple(pad_kv)) if has_kv else None
+        self.norm_k = norm_layer(head_dim) if has_kv else None
+        self.pool_v = conv(tuple(kernel_kv), stride=tuple(stride_kv), padding=tuple(pad_kv)) if has_kv else None
+        self.norm_v = norm_layer(head_dim) if has_kv else None
         self.rel_pos_spatial, self.rel_pos_temporal = rel_pos_spatial, rel_pos_temporal
         if rel_pos_spatial:
             assert input_size[1] == input_size[2]
@@ -105,7 +112,8 @@ class MultiScaleAttention(nn.Module):
                 trunc_normal_(self.rel_pos_t, std=0.02)
         self.residual_pooling = residual_pooling
         self._qkv, self._proj = LinearUnit(self.qkv), LinearUnit(self.proj)
-        self._norm_q, self._norm_k, self._norm_v = NormUnit(self.norm_q), NormUnit(self.norm_k), NormUnit(self.norm_v)
+        self._norm_q = NormUnit(self.norm_q) if has_q else None
+        self._norm_k, self._norm_v = (NormUnit(self.norm_k), NormUnit(self.norm_v)) if has_kv else (None, None)
 
 
 class MultiScaleBlock(nn.Module):
@@ -115,8 +123,6 @@ class MultiScaleBlock(nn.Module):
                  has_cls_embed=True, pool_first=False, rel_pos_spatial=False, rel_pos_temporal=False,
                  rel_pos_zero_init=False, residual_pooling=False, dim_mul_in_att=False, separate_qkv=False):
         super().__init__()
-        if not dim_mul_in_att and dim != dim_out:
-            raise NotImplementedError("dimension change after the Mlp (DIM_MUL_IN_ATT False, MViTv1)")
         if layer_scale_init_value > 0 or (up_rate is not None and up_rate > 1):
             raise NotImplementedError("layer scale / up_rate")
         self.dim, self.dim_out = dim, dim_out
@@ -221,12 +227,12 @@ class MViT(nn.Module):
         m = cfg.MVIT
         unsupported = [k for k, bad in (
             ("POOL_FIRST", m.POOL_FIRST), ("PATCH_2D", m.PATCH_2D), ("REV.ENABLE", m.REV.ENABLE),
-            ("USE_ABS_POS", m.USE_ABS_POS), ("USE_FIXED_SINCOS_POS", m.USE_FIXED_SINCOS_POS), ("NORM_STEM", m.NORM_STEM),
-            ("SEPARATE_QKV", m.SEPARATE_QKV), ("USE_MEAN_POOLING", m.USE_MEAN_POOLING),
-            ("not CLS_EMBED_ON", not m.CLS_EMBED_ON), ("not DIM_MUL_IN_ATT", not m.DIM_MUL_IN_ATT),
+            ("USE_FIXED_SINCOS_POS", m.USE_FIXED_SINCOS_POS), ("NORM_STEM", m.NORM_STEM),
+            ("SEPARATE_QKV", m.SEPARATE_QKV), ("not CLS_EMBED_ON", not m.CLS_EMBED_ON),
+            ("LAYER_SCALE_INIT_VALUE", m.LAYER_SCALE_INIT_VALUE > 0), ("DROPOUT_RATE", m.DROPOUT_RATE > 0),
             ("DETECTION.ENABLE", cfg.DETECTION.ENABLE), ("MODEL.ACT_CHECKPOINT", cfg.MODEL.ACT_CHECKPOINT)) if bad]
-        if unsupported or m.NORM != "layernorm" or m.MODE != "conv" or m.POOL_KVQ_KERNEL is None:
-            raise NotImplementedError(f"MViT options outside the MViTv2 hot path: {unsupported}")
+        if unsupported or m.NORM != "layernorm" or m.MODE != "conv":
+            raise NotImplementedError(f"MViT options outside the built video path: {unsupported}")
         self.cfg = cfg
         self.enable_detection, self.enable_rev = False, False
         self.patch_stride = list(m.PATCH_STRIDE)
@@ -235,8 +241,9 @@ class MViT(nn.Module):
         self.W = cfg.DATA.TRAIN_CROP_SIZE // self.patch_stride[2]
         embed_dim, num_heads, depth = m.EMBED_DIM, m.NUM_HEADS, m.DEPTH
         self.drop_rate = m.DROPOUT_RATE
-        self.cls_embed_on, self.use_mean_pooling = True, False
-        self.use_abs_pos, self.rel_pos_spatial, self.rel_pos_temporal = False, m.REL_POS_SPATIAL, m.REL_POS_TEMPORAL
+        self.cls_embed_on, self.use_mean_pooling = True, m.USE_MEAN_POOLING
+        self.use_abs_pos, self.sep_pos_embed = m.USE_ABS_POS, m.SEP_POS_EMBED
+        self.rel_pos_spatial, self.rel_pos_temporal = m.REL_POS_SPATIAL, m.REL_POS_TEMPORAL
         norm_layer = partial(nn.LayerNorm, eps=1e-6)
         self.num_classes = cfg.MODEL.NUM_CLASSES
         self.patch_embed = PatchEmbed(dim_in=cfg.DATA.INPUT_CHANNEL_NUM[0], dim_out=embed_dim, kernel=m.PATCH_KERNEL,
@@ -245,6 +252,13 @@ class MViT(nn.Module):
         self.patch_dims = [self.input_dims[i] // self.patch_stride[i] for i in range(3)]
         dpr = [x.item() for x in torch.linspace(0, m.DROPPATH_RATE, depth)]
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        if self.use_abs_pos:                       # video_model_builder.py:888-911
+            if self.sep_pos_embed:
+                self.pos_embed_spatial = nn.Parameter(torch.zeros(1, self.patch_dims[1] * self.patch_dims[2], embed_dim))
+                self.pos_embed_temporal = nn.Parameter(torch.zeros(1, self.patch_dims[0], embed_dim))
+                self.pos_embed_class = nn.Parameter(torch.zeros(1, 1, embed_dim))
+            else:
+                self.pos_embed = nn.Parameter(torch.zeros(1, math.prod(self.patch_dims) + 1, embed_dim))
         dim_mul, head_mul = torch.ones(depth + 1), torch.ones(depth + 1)
         for i, v in m.DIM_MUL:
             dim_mul[i] = v
@@ -252,9 +266,12 @@ class MViT(nn.Module):
             head_mul[i] = v
         pool_q, pool_kv = [[] for _ in range(depth)], [[] for _ in range(depth)]
         stride_q, stride_kv = [[] for _ in range(depth)], [[] for _ in range(depth)]
+        def kernel_for(stride):                    # video_model_builder.py:926-933, 950-957
+            return list(m.POOL_KVQ_KERNEL) if m.POOL_KVQ_KERNEL is not None else [v + 1 if v > 1 else v for v in stride]
+
         for e in m.POOL_Q_STRIDE:
             stride_q[e[0]] = list(e[1:])
-            pool_q[e[0]] = list(m.POOL_KVQ_KERNEL)
+            pool_q[e[0]] = kernel_for(e[1:])
         kv_list = m.POOL_KV_STRIDE
         if m.POOL_KV_STRIDE_ADAPTIVE is not None:
             _kv = list(m.POOL_KV_STRIDE_ADAPTIVE)
@@ -265,21 +282,24 @@ class MViT(nn.Module):
                 kv_list.append([i] + _kv)
         for e in kv_list:
             stride_kv[e[0]] = list(e[1:])
-            pool_kv[e[0]] = list(m.POOL_KVQ_KERNEL)
+            pool_kv[e[0]] = kernel_for(e[1:])
         self.pool_q, self.pool_kv, self.stride_q, self.stride_kv = pool_q, pool_kv, stride_q, stride_kv
         self.norm_stem = None
         input_size = self.patch_dims
         self.blocks = nn.ModuleList()
         for i in range(depth):
             num_heads = round_width(num_heads, head_mul[i])
-            dim_out = round_width(embed_dim, dim_mul[i], divisor=round_width(num_heads, head_mul[i]))
+            if m.DIM_MUL_IN_ATT:
+                dim_out = round_width(embed_dim, dim_mul[i], divisor=round_width(num_heads, head_mul[i]))
+            else:                                  # MViTv1: the block's Mlp widens to the NEXT block's dimension
+                dim_out = round_width(embed_dim, dim_mul[i + 1], divisor=round_width(num_heads, head_mul[i + 1]))
             self.blocks.append(MultiScaleBlock(
                 dim=embed_dim, dim_out=dim_out, num_heads=num_heads, input_size=input_size, mlp_ratio=m.MLP_RATIO,
                 qkv_bias=m.QKV_BIAS, drop_rate=self.drop_rate, drop_path=dpr[i], norm_layer=norm_layer,
                 kernel_q=pool_q[i], kernel_kv=pool_kv[i], stride_q=stride_q[i], stride_kv=stride_kv[i], mode=m.MODE,
                 has_cls_embed=True, pool_first=False, rel_pos_spatial=self.rel_pos_spatial,
                 rel_pos_temporal=self.rel_pos_temporal, rel_pos_zero_init=m.REL_POS_ZERO_INIT,
-                residual_pooling=m.RESIDUAL_POOLING, dim_mul_in_att=True, separate_qkv=False))
+                residual_pooling=m.RESIDUAL_POOLING, dim_mul_in_att=m.DIM_MUL_IN_ATT, separate_qkv=False))
             if len(stride_q[i]) > 0:
                 input_size = [size // stride for size, stride in zip(input_size, stride_q[i])]
             embed_dim = dim_out
@@ -287,6 +307,13 @@ class MViT(nn.Module):
         self._norm_unit = NormUnit(self.norm)
         self.head = TransformerBasicHead(embed_dim, self.num_classes, dropout_rate=cfg.MODEL.DROPOUT_RATE,
                                          act_func=cfg.MODEL.HEAD_ACT, cfg=cfg)
+        if self.use_abs_pos:                       # video_model_builder.py:1066-1075
+            if self.sep_pos_embed:
+                trunc_normal_(self.pos_embed_spatial, std=0.02)
+                trunc_normal_(self.pos_embed_temporal, std=0.02)
+                trunc_normal_(self.pos_embed_class, std=0.02)
+            else:
+                trunc_normal_(self.pos_embed, std=0.02)
         trunc_normal_(self.cls_token, std=0.02)
         self.apply(self._init_weights)
         self.head.projection.weight.data.mul_(m.HEAD_INIT_SCALE)
@@ -304,16 +331,31 @@ class MViT(nn.Module):
 
     def no_weight_decay(self):
         names = []
-        if self.cfg.MVIT.ZERO_DECAY_POS_CLS:
-            names += ["rel_pos_h", "rel_pos_w", "rel_pos_hw", "rel_pos_t", "cls_token"]
+        if self.cfg.MVIT.ZERO_DECAY_POS_CLS:       # video_model_builder.py:1095-1117
+            if self.use_abs_pos:
+                names += (["pos_embed_spatial", "pos_embed_temporal", "pos_embed_class"] if self.sep_pos_embed
+                          else ["pos_embed"])
+            if self.rel_pos_spatial:
+                names += ["rel_pos_h", "rel_pos_w", "rel_pos_hw"]
+            if self.rel_pos_temporal:
+                names += ["rel_pos_t"]
+            names += ["cls_token"]
         return names
 
     def forward(self, x, bboxes=None, return_attn=False):
-        x, bcthw = self.patch_embed(x[0], self.cls_token)
+        pos = None
+        if self.use_abs_pos:                       # video_model_builder.py:1189-1203; tiny [1, N, C] parameter algebra
+            if self.sep_pos_embed:
+                pos = self.pos_embed_spatial.repeat(1, self.patch_dims[0], 1) + torch.repeat_interleave(
+                    self.pos_embed_temporal, self.patch_dims[1] * self.patch_dims[2], dim=1)
+                pos = torch.cat([self.pos_embed_class, pos], 1)
+            else:
+                pos = self.pos_embed
+        x, bcthw = self.patch_embed(x[0], self.cls_token, pos)
         T, H, W = bcthw[-3], bcthw[-2], bcthw[-1]
         assert (T, H, W) == (self.T, self.H, self.W), bcthw
         thw = [T, H, W]
         for blk in self.blocks:
             x, thw = blk(x, thw)
-        x = ClsNormFn.apply(x, self, self.norm.weight, self.norm.bias)
+        x = ClsNormFn.apply(x, self, self.use_mean_pooling, self.norm.weight, self.norm.bias)
         return self.head(x)

@@ -116,17 +116,23 @@ class AttentionPlan:
         cls = att.has_cls_embed
         self.cls = int(cls)
         C = self.att
-        kq, sq = tuple(att.pool_q.kernel_size), tuple(att.pool_q.stride)
-        kk, sk = tuple(att.pool_k.kernel_size), tuple(att.pool_k.stride)
-        pq, pk = tuple(att.pool_q.padding), tuple(att.pool_k.padding)
-        self.gq = tokens.DwGeom(B, C, self.D, thw, kq, sq, pq, cls)
-        self.gk = tokens.DwGeom(B, C, self.D, thw, kk, sk, pk, cls)
-        self.q_thw, self.k_thw = self.gq.out_thw, self.gk.out_thw
+        # blocks without a q (k / v) pooling conv leave that tensor as the qkv projection produced it
+        # (attention.py:199-203, 236-262: MViTv1 blocks outside POOL_Q_STRIDE, plain ViT blocks)
+        self.gq = self.gk = None
+        if att.pool_q is not None:
+            kq, sq, pq = tuple(att.pool_q.kernel_size), tuple(att.pool_q.stride), tuple(att.pool_q.padding)
+            self.gq = tokens.DwGeom(B, C, self.D, thw, kq, sq, pq, cls)
+        if att.pool_k is not None:
+            kk, sk, pk = tuple(att.pool_k.kernel_size), tuple(att.pool_k.stride), tuple(att.pool_k.padding)
+            self.gk = tokens.DwGeom(B, C, self.D, thw, kk, sk, pk, cls)
+        self.q_thw = self.gq.out_thw if self.gq is not None else tuple(thw)
+        self.k_thw = self.gk.out_thw if self.gk is not None else tuple(thw)
         self.Nq = self.cls + math.prod(self.q_thw)
         self.Nk = self.cls + math.prod(self.k_thw)
         self.lds = (self.Nk + 31) // 32 * 32     # score-row pitch: zero pad columns, a whole number of 32-wide GEMM K steps
         self.rel = att.rel_pos_spatial and att.rel_pos_temporal
-        assert att.rel_pos_spatial == att.rel_pos_temporal, "spatial and temporal rel-pos are used together (MViTv2)"
+        if att.rel_pos_spatial != att.rel_pos_temporal:
+            raise NotImplementedError("spatial and temporal relative positions are used together on this path (MViTv2)")
         rows = (att.rel_pos_h.shape[0], att.rel_pos_w.shape[0], att.rel_pos_t.shape[0]) if self.rel else (0, 0, 0)
         self.desc = tokens.attn_desc(B, self.heads, self.D, cls, self.q_thw, self.k_thw, *rows)
         self.idx = None
@@ -160,13 +166,22 @@ def attention_forward(att, plan, qkv):
     B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
     Nq, Nk, lds = plan.Nq, plan.Nk, plan.lds
     q_in, k_in, v_in = qkv[..., 0:C], qkv[..., C:2 * C], qkv[..., 2 * C:3 * C]
-    qp = tokens.dwconv_fwd(q_in, att.pool_q.weight, plan.gq).view(B, Nq, C)
-    kp = tokens.dwconv_fwd(k_in, att.pool_k.weight, plan.gk).view(B, Nk, C)
-    vp = tokens.dwconv_fwd(v_in, att.pool_v.weight, plan.gk).view(B, Nk, C)
-    qn, mq, rq_ = att._norm_q.forward(qp.view(B * Nq * heads, D))
-    kn, mk, rk_ = att._norm_k.forward(kp.view(B * Nk * heads, D))
-    vn, mv, rv_ = att._norm_v.forward(vp.view(B * Nk * heads, D))
-    qn, kn, vn = qn.view(B, Nq, C), kn.view(B, Nk, C), vn.view(B, Nk, C)
+    qp = kp = vp = None
+    mq = rq_ = mk = rk_ = mv = rv_ = None
+    if plan.gq is not None:
+        qp = tokens.dwconv_fwd(q_in, att.pool_q.weight, plan.gq).view(B, Nq, C)
+        qn, mq, rq_ = att._norm_q.forward(qp.view(B * Nq * heads, D))
+        qn = qn.view(B, Nq, C)
+    else:
+        qn = q_in                                   # channel slice of qkv (row pitch 3C): used in place
+    if plan.gk is not None:
+        kp = tokens.dwconv_fwd(k_in, att.pool_k.weight, plan.gk).view(B, Nk, C)
+        vp = tokens.dwconv_fwd(v_in, att.pool_v.weight, plan.gk).view(B, Nk, C)
+        kn, mk, rk_ = att._norm_k.forward(kp.view(B * Nk * heads, D))
+        vn, mv, rv_ = att._norm_v.forward(vp.view(B * Nk * heads, D))
+        kn, vn = kn.view(B, Nk, C), vn.view(B, Nk, C)
+    else:
+        kn, vn = k_in, v_in
     tables = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t) if plan.rel else None
     t16 = t16t = None
     if plan.rel:
@@ -179,6 +194,9 @@ def attention_forward(att, plan, qkv):
         saved = dict(qp=qp, kp=kp, vp=vp, qn=qn, kn=kn, vn=vn, sq=(mq, rq_), sk=(mk, rk_), sv=(mv, rv_), t16t=t16t,
                      fused=(o, lse, rq))
         return o, saved
+    if plan.gq is None or plan.gk is None:
+        # the unfused chain (A/B runs, head dims the fused kernels do not cover) addresses contiguous operands
+        qn, kn, vn = qn.contiguous(), kn.contiguous(), vn.contiguous()
     S = torch.empty((B, heads, Nq, lds), dtype=_f16, device=qkv.device)
     tokens.bgemm_heads(qn, (Nq * C, D), Nq, D, C, kn, (Nk * C, D), Nk, C, S, (heads * Nq * lds, Nq * lds), lds, B, heads)
     P = tokens.softmax_fwd(plan.desc, S, att.scale, rq)
@@ -199,10 +217,16 @@ def attention_backward(att, plan, qkv, sv, do):
     dev = do.device
     if "fused" in sv:
         o, lse, rq = sv["fused"]
+        dqkv = torch.empty(qkv.shape, dtype=_f16, device=dev)
+        # gradients of un-pooled q / k / v ARE slices of d(qkv): the kernels write them in place (row pitch 3C)
+        dq_out = dqkv[..., 0:C] if plan.gq is None and not plan.rel else None
+        dkv_out = (dqkv[..., C:2 * C], dqkv[..., 2 * C:3 * C]) if plan.gk is None else None
         dqn, dkn, dvn, drq = tokens.attn_bwd(plan.desc, qn, kn, vn, att.scale, rq, att.residual_pooling, o, do, lse,
-                                             onehot=plan.onehot)
-        return _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq)
+                                             onehot=plan.onehot, dq_out=dq_out, dkv_out=dkv_out)
+        return _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq, dqkv)
     P = sv["P"]
+    if plan.gq is None or plan.gk is None:
+        qn, kn, vn = qn.contiguous(), kn.contiguous(), vn.contiguous()
     # dP = dO V^T ; dV = P^T dO
     dP = torch.empty((B, heads, Nq, lds), dtype=_f16, device=dev)
     tokens.bgemm_heads(do, (Nq * C, D), Nq, D, C, vn, (Nk * C, D), Nk, C, dP, (heads * Nq * lds, Nq * lds), lds, B, heads)
@@ -222,8 +246,9 @@ def attention_backward(att, plan, qkv, sv, do):
     return _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq)
 
 
-def _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq):
-    """rel-pos table gradients (+ their dq term), LayerNorm(head_dim) and depthwise pooling backward."""
+def _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq, dqkv=None):
+    """rel-pos table gradients (+ their dq term), LayerNorm(head_dim) and depthwise pooling backward.  Tensors that were
+    not pooled skip both: their gradient is (or is copied into) the matching slice of d(qkv)."""
     B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
     Nq, Nk = plan.Nq, plan.Nk
     dev = dqn.device
@@ -232,13 +257,23 @@ def _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq):
         dests = [_grad_dest(t) for t in tabs]
         tokens.relpos_bwd(plan.desc, qn, tabs, plan.idx, drq, dqn, [d[0] for d in dests], [not d[1] for d in dests],
                           t16t=sv["t16t"])
-    # LayerNorm(head_dim) backward
-    dqp = att._norm_q.backward(dqn.view(-1, D), sv["qp"].view(-1, D), *sv["sq"]).view(B, Nq, C)
-    dkp = att._norm_k.backward(dkn.view(-1, D), sv["kp"].view(-1, D), *sv["sk"]).view(B, Nk, C)
-    dvp = att._norm_v.backward(dvn.view(-1, D), sv["vp"].view(-1, D), *sv["sv"]).view(B, Nk, C)
-    # depthwise pooling backward into the three slices of d(qkv)
-    dqkv = torch.empty(qkv.shape, dtype=_f16, device=dev)
-    for i, (dy, pool, geom) in enumerate(((dqp, att.pool_q, plan.gq), (dkp, att.pool_k, plan.gk), (dvp, att.pool_v, plan.gk))):
+    if dqkv is None:
+        dqkv = torch.empty(qkv.shape, dtype=_f16, device=dev)
+    work = []
+    if plan.gq is not None:                                  # LayerNorm(head_dim) backward, then the pooling conv
+        dqp = att._norm_q.backward(dqn.view(-1, D), sv["qp"].view(-1, D), *sv["sq"]).view(B, Nq, C)
+        work.append((0, dqp, att.pool_q, plan.gq))
+    elif dqn.data_ptr() != dqkv.data_ptr():
+        dqkv[..., 0:C].copy_(dqn)
+    if plan.gk is not None:
+        dkp = att._norm_k.backward(dkn.view(-1, D), sv["kp"].view(-1, D), *sv["sk"]).view(B, Nk, C)
+        dvp = att._norm_v.backward(dvn.view(-1, D), sv["vp"].view(-1, D), *sv["sv"]).view(B, Nk, C)
+        work += [(1, dkp, att.pool_k, plan.gk), (2, dvp, att.pool_v, plan.gk)]
+    elif dkn.data_ptr() != dqkv[..., C:2 * C].data_ptr():
+        dqkv[..., C:2 * C].copy_(dkn)
+        dqkv[..., 2 * C:3 * C].copy_(dvn)
+    # depthwise pooling backward into the slices of d(qkv)
+    for i, dy, pool, geom in work:
         x_in = qkv[..., i * C:(i + 1) * C]
         tokens.dwconv_dgrad(dy.view(-1, C), pool.weight, geom, out=dqkv[..., i * C:(i + 1) * C])
         dw, zero_first = _grad_dest(pool.weight)
@@ -247,7 +282,8 @@ def _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq):
 
 
 class MultiScaleBlockFn(torch.autograd.Function):
-    """MultiScaleBlock.forward (attention.py:491-514) for DIM_MUL_IN_ATT, conv pooling, cls token."""
+    """MultiScaleBlock.forward (attention.py:491-514): conv pooling (or none), cls token, dimension change before the
+    attention residual (DIM_MUL_IN_ATT, MViTv2) or after the Mlp (MViTv1)."""
 
     @staticmethod
     def forward(ctx, x, mod, thw, drop, *params):
@@ -257,7 +293,9 @@ class MultiScaleBlockFn(torch.autograd.Function):
         xn, m1, r1 = mod._norm1.forward(x)
         qkv = att._qkv.forward(xn)
         o, sv = attention_forward(att, plan, qkv)
-        if mod._proj is not None:
+        proj_first = mod._proj is not None and mod.dim_mul_in_att
+        proj_last = mod._proj is not None and not mod.dim_mul_in_att
+        if proj_first:
             xs = mod._proj.forward(xn)                     # dim change on the normed input (attention.py:494-495)
         else:
             xs = x
@@ -278,10 +316,12 @@ class MultiScaleBlockFn(torch.autograd.Function):
         else:
             h = mod.mlp._fc1.forward(xn2)
             a = tokens.gelu_fwd(h)
+        # MViTv1 (DIM_MUL_IN_ATT False): the dimension change acts on the normed Mlp input (attention.py:507-508)
+        xb = mod._proj.forward(xn2) if proj_last else x1
         if drop is None:
-            out = mod.mlp._fc2.forward(a, resid=x1)
+            out = mod.mlp._fc2.forward(a, resid=xb)
         else:                                              # x + drop_path(mlp), attention.py:508-510
-            out = tokens.row_scale_add(mod.mlp._fc2.forward(a), drop[1], x1.shape[1], resid=x1)
+            out = tokens.row_scale_add(mod.mlp._fc2.forward(a), drop[1], xb.shape[1], resid=xb)
         ctx.drop = drop
         ctx.mod, ctx.plan, ctx.thw = mod, plan, tuple(thw)
         ctx.sv = dict(x=x, xn=xn, s1=(m1, r1), qkv=qkv, att=sv, o=o, pool=pool, x1=x1, xn2=xn2, s2=(m2, r2), h=h, a=a)
@@ -303,7 +343,12 @@ class MultiScaleBlockFn(torch.autograd.Function):
             da = mod.mlp._fc2.backward(sv["a"], dbr)
             dh = tokens.gelu_bwd(sv["h"], da)
         dxn2 = mod.mlp._fc1.backward(sv["xn2"], dh)
-        dx1 = mod._norm2.backward(dxn2, sv["x1"], *sv["s2"], resid=dout)
+        proj_first = mod._proj is not None and mod.dim_mul_in_att
+        if mod._proj is not None and not proj_first:       # the skip path went through proj(norm2(x1))
+            dxn2 = mod._proj.backward(sv["xn2"], dout, resid=dxn2)
+            dx1 = mod._norm2.backward(dxn2, sv["x1"], *sv["s2"])
+        else:
+            dx1 = mod._norm2.backward(dxn2, sv["x1"], *sv["s2"], resid=dout)
         # attention output projection, attention core, qkv projection
         do = att._proj.backward(sv["o"], dx1 if drop is None else tokens.row_scale_add(dx1, drop[0], dx1.shape[1]))
         dqkv = attention_backward(att, plan, sv["qkv"], sv["att"], do)
@@ -313,7 +358,7 @@ class MultiScaleBlockFn(torch.autograd.Function):
         if sv["pool"] is not None:
             k, s, p, arg, xres = sv["pool"]
             dxs = tokens.token_pool_bwd(dx1, xres, arg, B, ctx.thw, k, s, p, xres.shape[-1], cls=mod.has_cls_embed)
-        if mod._proj is not None:
+        if proj_first:
             dxn = mod._proj.backward(sv["xn"], dxs, resid=dxn)
             dx_skip = None
         else:
@@ -329,19 +374,25 @@ class PatchEmbedFn(torch.autograd.Function):
     video_model_builder.py:1180-1186)."""
 
     @staticmethod
-    def forward(ctx, x, mod, cls_token, *params):
+    def forward(ctx, x, mod, cls_token, pos, *params):
         unit = mod._unit
         xcl = unit.prepare_input(x)
         y, _ = unit.forward(xcl, None, mod.training)            # (B, C, T, H, W) channels-last == (B, THW, C) rows
         B, C, T, H, W = y.shape
         tok = y.permute(0, 2, 3, 4, 1).reshape(B, T * H * W, C)
+        p16 = pos.detach().to(_f16) if pos is not None else None   # [1, cls + THW, C]: x += pos_embed (fp16 storage)
         if cls_token is not None:
             out = torch.empty((B, 1 + T * H * W, C), dtype=_f16, device=y.device)
-            out[:, 0] = cls_token.detach().view(1, C).to(_f16)
-            out[:, 1:] = tok
+            c16 = cls_token.detach().view(1, C).to(_f16)
+            if p16 is None:
+                out[:, 0] = c16
+                out[:, 1:] = tok
+            else:                                               # the copy that prepends the cls row becomes an add
+                out[:, 0] = c16 + p16[0, :1]
+                torch.add(tok, p16[:, 1:], out=out[:, 1:])
         else:
-            out = tok
-        ctx.mod, ctx.xcl, ctx.cls, ctx.yshape = mod, xcl, cls_token, tuple(y.shape)
+            out = tok if p16 is None else tok + p16
+        ctx.mod, ctx.xcl, ctx.cls, ctx.yshape, ctx.has_pos = mod, xcl, cls_token, tuple(y.shape), pos is not None
         return out
 
     @staticmethod
@@ -365,24 +416,36 @@ class PatchEmbedFn(torch.autograd.Function):
             tokens.bias_grad(dtok.view(-1, C), db, accumulate=not zero_first)
         _notify(unit.params() + ([cls_token] if cls_token is not None else []))
         ctx.xcl = None
-        return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+        # d(pos_embed) = sum over the batch of d(tokens), fp32; autograd routes it to the (separate) embedding tables
+        dpos = dout.float().sum(0, keepdim=True) if ctx.has_pos and ctx.needs_input_grad[3] else None
+        return (None, None, None, dpos) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
 class ClsNormFn(torch.autograd.Function):
-    """Final LayerNorm on the cls rows only: norm(x)[:, 0] == norm(x[:, 0]) (video_model_builder.py:1236-1238)."""
+    """Final LayerNorm on what the head consumes (video_model_builder.py:1226-1238): the cls rows
+    (norm(x)[:, 0] == norm(x[:, 0])), or with USE_MEAN_POOLING the mean of the patch tokens (mean first, then norm)."""
 
     @staticmethod
-    def forward(ctx, x, mod, *params):
+    def forward(ctx, x, mod, mean_pool, *params):
         unit = mod._norm_unit
-        xc = x[:, 0].contiguous()
+        if mean_pool:
+            xc = x[:, 1:].float().mean(1).to(_f16)
+        else:
+            xc = x[:, 0].contiguous()
         y, m, r = unit.forward(xc)
-        ctx.unit, ctx.xc, ctx.st, ctx.shape = unit, xc, (m, r), tuple(x.shape)
+        ctx.unit, ctx.xc, ctx.st, ctx.shape, ctx.mean_pool = unit, xc, (m, r), tuple(x.shape), mean_pool
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dxc = ctx.unit.backward(dy.to(_f16).contiguous(), ctx.xc, *ctx.st)
-        dx = torch.zeros(ctx.shape, dtype=_f16, device=dy.device)
-        dx[:, 0] = dxc
+        if ctx.mean_pool:
+            B, N, C = ctx.shape
+            dx = torch.empty(ctx.shape, dtype=_f16, device=dy.device)
+            dx[:, 0] = 0
+            dx[:, 1:] = (dxc.float() / (N - 1)).to(_f16)[:, None, :]
+        else:
+            dx = torch.zeros(ctx.shape, dtype=_f16, device=dy.device)
+            dx[:, 0] = dxc
         _notify(ctx.unit.params())
-        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

@@ -377,12 +377,18 @@ def attn_fwd(d, q, k, v, scale, rq, residual, onehot=None):
     return o, lse
 
 
-def attn_bwd(d, q, k, v, scale, rq, residual, o, do, lse, onehot=None):
-    """Backward of attn_fwd: (dq, dk, dv, drq)."""
+def attn_bwd(d, q, k, v, scale, rq, residual, o, do, lse, onehot=None, dq_out=None, dkv_out=None):
+    """Backward of attn_fwd: (dq, dk, dv, drq).  ``dq_out`` / ``dkv_out = (dk, dv)`` let the gradients land directly in
+    channel slices of a wider buffer (the d(qkv) tensor when q or k/v are not pooled); dk and dv share one pitch."""
     B, Nq, C = q.shape
-    dq = torch.empty((B, Nq, C), dtype=_f16, device=q.device)
-    dk = torch.empty(k.shape, dtype=_f16, device=q.device)
-    dv = torch.empty(k.shape, dtype=_f16, device=q.device)
+    dq = torch.empty((B, Nq, C), dtype=_f16, device=q.device) if dq_out is None else dq_out
+    if dkv_out is None:
+        dk = torch.empty(k.shape, dtype=_f16, device=q.device)
+        dv = torch.empty(k.shape, dtype=_f16, device=q.device)
+    else:
+        dk, dv = dkv_out
+        assert rows_pitch(dk)[2] == rows_pitch(dv)[2]
+    assert tuple(dq.shape) == tuple(q.shape) and tuple(dk.shape) == tuple(k.shape) == tuple(dv.shape)
     delta = torch.empty_like(lse)
     drq = torch.empty(rq.shape, dtype=torch.float32, device=q.device) if rq is not None else None
     nbytes = _lib_call("sf_attn_bwd_workspace", byref(d))
@@ -390,7 +396,7 @@ def attn_bwd(d, q, k, v, scale, rq, residual, o, do, lse, onehot=None):
     flops = 14.0 * B * d.heads * Nq * d.Nk * d.D
     _lib_call("sf_attn_bwd", byref(d), q.data_ptr(), rows_pitch(q)[2], k.data_ptr(), v.data_ptr(), rows_pitch(k)[2],
               float(scale), _ptr(rq), _ptr(onehot), int(bool(residual)), o.data_ptr(), do.data_ptr(), rows_pitch(o)[2],
-              lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), C, dk.data_ptr(), dv.data_ptr(), rows_pitch(dk)[2],
+              lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), rows_pitch(dq)[2], dk.data_ptr(), dv.data_ptr(), rows_pitch(dk)[2],
               _ptr(drq), _ptr(ws), nbytes, _stream(q), work=dict(bytes=2.0 * (4 * q.numel() + 4 * k.numel()), flops=flops))
     return dq, dk, dv, drq
 

@@ -239,3 +239,16 @@ def test_sub_batchnorm_matches_reference(gpu):
                         tol_global=1e-2, report=rep)
     finally:
         print(rep)
+
+
+@pytest.mark.parametrize("name", ["mvit_v1_tiny", "vit_tiny"])
+@pytest.mark.parametrize("fused_attn", ["1", "0"])
+def test_mvit_v1_and_vit_match_reference(gpu, name, fused_attn, monkeypatch):
+    """MViTv1 / plain video ViT option family (absolute position embeddings, proj after the Mlp, un-pooled q / k / v used
+    and differentiated in place as slices of the qkv tensor, mean pooling) through the fused and the unfused attention."""
+    monkeypatch.setenv("SF_ATTN_FUSED", fused_attn)
+    rep = {}
+    try:
+        mc.check_engine(name, gpu, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.2, tol_global=1e-2, report=rep)
+    finally:
+        print(name, fused_attn, rep)
