@@ -139,6 +139,17 @@ def get_norm(cfg):
     raise NotImplementedError(f"Norm type {t} is not supported")
 
 
+def aggregate_sub_bn_stats(module):
+    """slowfast/utils/misc.py:372-387 for the drop-in class: aggregate_stats() on every SubBatchNorm3d (call before
+    evaluation / checkpointing, as train_net.py:710 does); returns how many layers were aggregated."""
+    count = 0
+    for m in module.modules():
+        if isinstance(m, SubBatchNorm3d):
+            m.aggregate_stats()
+            count += 1
+    return count
+
+
 def num_splits_of(model):
     """num_splits shared by the model's SubBatchNorm3d layers (1 when it has none); cached on the model."""
     s = model.__dict__.get("_sf_num_splits")
