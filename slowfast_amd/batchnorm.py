@@ -175,7 +175,7 @@ def run_in_splits(model, forward_once, inputs, S):
     subs = [m for m in model.modules() if isinstance(m, SubBatchNorm3d)]
     N = inputs[0].shape[0]
     assert N % S == 0, f"batch {N} is not divisible by BN.NUM_SPLITS {S}"
-    engine.hold_notifications(S)
+    engine.hold_notifications(S, model.parameters())
     outs = []
     try:
         for j in range(S):

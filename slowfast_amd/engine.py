@@ -45,11 +45,16 @@ _sub_passes = 1
 _sub_counts = {}
 
 
-def hold_notifications(passes):
+_sub_params = None
+
+
+def hold_notifications(passes, params=None):
     """A SubBatchNorm3d(S) training step runs S sub-batch passes whose backward passes all add into the same
-    parameter gradients (batchnorm.run_in_splits): a parameter is announced final after its S-th contribution."""
-    global _sub_passes
+    parameter gradients (batchnorm.run_in_splits): a parameter is announced final after its S-th contribution.
+    ``params`` restricts the rule to one model's parameters (others are announced immediately)."""
+    global _sub_passes, _sub_params
     _sub_passes = max(int(passes), 1)
+    _sub_params = None if params is None or _sub_passes == 1 else set(params)
     _sub_counts.clear()
 
 
@@ -57,6 +62,9 @@ def _notify(params):
     if _sub_passes > 1:
         final = []
         for p in params:
+            if _sub_params is not None and p not in _sub_params:
+                final.append(p)
+                continue
             c = _sub_counts.get(p, 0) + 1
             if c >= _sub_passes:
                 _sub_counts.pop(p, None)

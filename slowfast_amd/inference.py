@@ -9,7 +9,9 @@ nonlocal_helper.py:139-144) collapses into ONE implicit-GEMM launch: BatchNorm f
 and a bias, ReLU and the residual addition in the epilogue (``sf_conv_fwd_fused``).  A bottleneck block is then 3
 launches (4 with a projection shortcut) instead of 4-5 convolutions + 4-5 statistics finalisations + one
 elementwise pass, no activation is ever re-normalised on load, and all 1x1x1 operands take the direct-to-LDS path.
-X3D keeps its running-statistics schedule (depthwise stencil + SE + Swish), MViT has no BatchNorm to fold.
+X3D blocks fold their two 1x1x1 convolutions and the shortcut the same way (two elementwise passes fewer per block);
+the depthwise 3x3x3 -> BN -> SE -> Swish middle and the X3D stem keep the running-statistics schedule.  MViT has no
+BatchNorm to fold.
 
 ``TestStep`` -- one iteration of ``perform_test``: eval forward (captured once into a HIP graph and replayed, like
 ``step.TrainStep``), all-gather of (preds, labels, video_idx) across ranks (``du.all_gather``,

@@ -89,7 +89,8 @@ class ResBlock(nn.Module):
     def _sf_fold(self):
         t = self.branch2
         if not isinstance(t, BottleneckTransform):
-            return False                     # X3DTransform keeps its running-statistics schedule
+            fold = getattr(t, "_sf_fold_in_block", None)     # X3DTransform: its 1x1x1 convolutions fold, the
+            return fold(self) if fold is not None else False  # depthwise / SE / Swish middle keeps running statistics
         for u in (t._a, t._b, t._c, self._proj):
             if u is not None:
                 u.fold()
@@ -98,6 +99,8 @@ class ResBlock(nn.Module):
     def _infer(self, x):
         x = as_cl(x)
         t = self.branch2
+        if not isinstance(t, BottleneckTransform):
+            return t._infer_in_block(self, x)
         ya = t._a.infer(x, relu=True)
         yb = t._b.infer(ya, relu=True)
         sc = x if self._proj is None else self._proj.infer(x)

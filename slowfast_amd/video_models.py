@@ -216,7 +216,7 @@ class SlowFast(_ResNetBase):
         if self.training:
             _bump_batches_tracked(self)
             S = num_splits_of(self)
-            hold_notifications(S)
+            hold_notifications(S, self.parameters() if S > 1 else None)
             if S > 1:                    # SubBatchNorm3d: S sub-batch passes (batchnorm.run_in_splits)
                 assert bboxes is None, "detection batches are not split"
                 return run_in_splits(self, self._forward, list(x), S)
@@ -268,7 +268,7 @@ class ResNet(_ResNetBase):
         if self.training:
             _bump_batches_tracked(self)
             S = num_splits_of(self)
-            hold_notifications(S)
+            hold_notifications(S, self.parameters() if S > 1 else None)
             if S > 1:                    # SubBatchNorm3d: S sub-batch passes (batchnorm.run_in_splits)
                 assert bboxes is None, "detection batches are not split"
                 return run_in_splits(self, self._forward, list(x), S)

@@ -376,6 +376,26 @@ class X3DTransform(nn.Module):
     def forward(self, x):
         raise NotImplementedError("X3DTransform runs fused inside ResBlock (engine X3DBlockFn)")
 
+    # inference fusion (slowfast_amd.inference): the two 1x1x1 convolutions and the projection shortcut take the folded
+    # single-launch form (BatchNorm in the weights, ReLU / residual in the epilogue) -- two full elementwise passes
+    # fewer per block on a bandwidth-bound network; depthwise 3x3x3 -> BN -> SE -> Swish keeps running statistics
+    def _sf_fold_in_block(self, block):
+        for u in (self._a, self._c, block._proj):
+            if u is not None:
+                u.fold()
+        return True
+
+    def _infer_in_block(self, block, x):
+        za = self._a.infer(x, relu=True)
+        yb, _, g = self._b.forward(za, stats=False)
+        sb = self._b_bn.finalize(None, g.rows_out, yb.shape[1], False)
+        gate = None
+        if self._se is not None:
+            gate = self._se.gate_fwd(sample_mean(yb, sb.scale, sb.shift, relu=False))[1]
+        zb = gate_act_fwd(yb, sb.scale, sb.shift, gate, self._swish_inner)
+        sc = x if block._proj is None else block._proj.infer(x)
+        return self._c.infer(zb, relu=True, resid=sc)
+
 
 _TRANS["x3d_transform"] = X3DTransform
 
@@ -497,7 +517,7 @@ class X3D(nn.Module):
         if self.training:
             _bump_batches_tracked(self)
             S = num_splits_of(self)
-            hold_notifications(S)
+            hold_notifications(S, self.parameters() if S > 1 else None)
             if S > 1:                    # SubBatchNorm3d: S sub-batch passes (batchnorm.run_in_splits)
                 return run_in_splits(self, self._forward, list(x), S)
         return self._forward(x)
