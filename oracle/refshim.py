@@ -81,6 +81,20 @@ def install():
             loss = torch.sum(-target * torch.nn.functional.log_softmax(x, dim=-1), dim=-1)
             return loss.mean() if self.reduction == "mean" else loss
 
+    class NaiveSyncBatchNorm3d(nn.BatchNorm3d):
+        """Stand-in for pytorchvideo.layers.batch_norm.NaiveSyncBatchNorm3d (un-vendored): its constructor contract and
+        the single-process behaviour (plain BatchNorm3d when the sync group has one rank or in eval mode).  The
+        cross-rank branch is not restated here -- tests cover it through slowfast_amd.batchnorm against plain
+        BatchNorm over the concatenated batch."""
+
+        def __init__(self, num_sync_devices=None, global_sync=False, **args):
+            if global_sync and num_sync_devices is not None:
+                raise ValueError(f"Cannot set num_sync_devices separately when global_sync = {global_sync}")
+            if not global_sync and num_sync_devices is None:
+                raise ValueError(f"num_sync_devices cannot be None when global_sync = {global_sync}")
+            self.global_sync, self.num_sync_devices = global_sync, num_sync_devices
+            super().__init__(**args)
+
     class _ImportOnly(nn.Module):
         def __init__(self, *a, **k):
             raise NotImplementedError("stand-in for an un-vendored dependency (import-time only)")
@@ -94,7 +108,7 @@ def install():
     _module("pytorchvideo")
     _module("pytorchvideo.layers")
     _module("pytorchvideo.layers.swish", Swish=Swish)
-    _module("pytorchvideo.layers.batch_norm", NaiveSyncBatchNorm1d=_ImportOnly, NaiveSyncBatchNorm3d=_ImportOnly)
+    _module("pytorchvideo.layers.batch_norm", NaiveSyncBatchNorm1d=_ImportOnly, NaiveSyncBatchNorm3d=NaiveSyncBatchNorm3d)
     _module("pytorchvideo.losses")
     _module("pytorchvideo.losses.soft_target_cross_entropy", SoftTargetCrossEntropyLoss=SoftTargetCrossEntropyLoss)
     class ROIAlign(nn.Module):
