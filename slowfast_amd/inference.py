@@ -61,6 +61,28 @@ def all_gather_cat(tensors, group=None):
     return out
 
 
+def all_gather_unaligned(tensors, group=None):
+    """The tensor case of ``du.all_gather_unaligned`` (slowfast/utils/distributed.py:225-258), used by the detection branch
+    of perform_test (test_net.py:76-79) where every rank holds a different number of boxes: sizes are exchanged first,
+    rows padded to the largest count, gathered, trimmed and concatenated along dim 0.  World size 1 returns the inputs."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(tensors)
+    world = dist.get_world_size(group)
+    out = []
+    for t in tensors:
+        t = t.contiguous()
+        n = torch.tensor([t.shape[0]], dtype=torch.long, device=t.device)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n, group=group)
+        sizes = [int(v) for v in sizes]
+        pad = torch.zeros((max(sizes),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        out.append(torch.cat([p[:k] for p, k in zip(parts, sizes)], dim=0))
+    return out
+
+
 class TestStep:
     """perform_test's loop body for the classification path.
 
@@ -133,6 +155,14 @@ class TestStep:
         preds, labels, video_idx = all_gather_cat([preds, labels.to(self.device), video_idx.to(self.device)], self.group)
         self.update(preds, labels, video_idx)
         return preds, labels, video_idx
+
+    def step_detection(self, inputs, boxes, ori_boxes, metadata):
+        """perform_test's detection branch (test_net.py:68-86): ``model(inputs, boxes)`` on the (R, 5) boxes of this rank's
+        clips, then (preds, ori_boxes, metadata) gathered from all ranks (different R per rank) for the AVA meter.  Runs
+        eagerly: the number of boxes changes from batch to batch, so there is no static graph to replay."""
+        with torch.no_grad():
+            preds = self.model(list(inputs), boxes.to(self.device)).float()
+        return all_gather_unaligned([preds, ori_boxes.to(self.device), metadata.to(self.device)], self.group)
 
     def finalize(self, ks=(1, 5)):
         """{'top1_acc': .., 'top5_acc': ..} in percent over the ensembled videos (meters.py:366-400, single-label)."""

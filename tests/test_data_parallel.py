@@ -150,6 +150,11 @@ def _test_worker(rank, world, port, simlib, q):
         preds, labels, vidx = step.step([host_to_cl(clips[ids], "cpu")], labels_of[ids // K], ids)
         assert preds.shape[0] == 2 * world and vidx.shape[0] == 2 * world
     err = float((step.video_preds - ref_video).abs().max())
+    # detection branch: a different number of rows on every rank (rank r holds r + 1 rows)
+    rows = torch.arange((rank + 1) * 3, dtype=torch.float32).view(rank + 1, 3) + 100 * rank
+    (gathered,) = inference.all_gather_unaligned([rows])
+    expect = torch.cat([torch.arange((r + 1) * 3, dtype=torch.float32).view(r + 1, 3) + 100 * r for r in range(world)])
+    assert torch.equal(gathered, expect), (gathered, expect)
     q.put((rank, err, step.clip_count.tolist(), bool(torch.equal(step.video_labels, labels_of))))
     dist.destroy_process_group()
 
