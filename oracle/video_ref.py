@@ -373,7 +373,7 @@ def scale_final_bn(sd, factor):
     return sd
 
 
-def calibrate_running_stats(sd, cfg, inputs):
+def calibrate_running_stats(sd, cfg, inputs, bboxes=None):
     """Returns a copy of ``sd`` whose BatchNorm running statistics are the batch statistics of ``inputs`` (the fixed
     point of the momentum average on that batch).  Random running statistics do not match the activations' real
     scale, so an eval-mode forward would saturate the softmax and test conditioning instead of kernels; calibrated
@@ -382,7 +382,10 @@ def calibrate_running_stats(sd, cfg, inputs):
     stats = {}
     fwd = x3d_forward if cfg.MODEL.MODEL_NAME == "X3D" else video_forward
     with torch.no_grad():
-        fwd(sd, cfg, inputs, training=True, stats_out=stats)
+        if bboxes is not None:
+            fwd(sd, cfg, inputs, training=True, stats_out=stats, bboxes=bboxes)
+        else:
+            fwd(sd, cfg, inputs, training=True, stats_out=stats)
     out = dict(sd)
     for k, new in stats.items():
         out[k] = (new - 0.9 * sd[k]) / 0.1

@@ -114,3 +114,31 @@ def test_view_ensemble_matches_testmeter(method):
     stats = step.finalize()
     top1 = float((vp.argmax(1) == vl).float().mean() * 100)
     assert abs(stats["top1_acc"] - top1) < 1e-4 and stats["all_clips_seen"]
+
+
+def test_fused_eval_with_roi_head_and_nonlocal(sim):
+    """Detection models (SlowFast + Nonlocal + ResNetRoIHead on boxes): the inference-fused backbone feeds the RoI head the
+    same features as the running-statistics schedule, and both agree with the oracle's eval forward."""
+    import slowfast_amd as sa
+    from oracle import video_ref
+    from slowfast_amd import inference
+    gold = mc.load_golden("slowfast_ava_roi_tiny")
+    cfg = mc.cfg_for(gold)
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    sd = video_ref.randomize_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, gold["param_seed"])
+    video_ref.scale_final_bn(sd, gold["state_tweaks"]["final_bn_gamma_scale"])
+    inputs, _ = video_ref.synthetic_batch(cfg, 2, gold["data_seed"])
+    boxes = video_ref.synthetic_boxes(cfg, 2, seed=77, per_clip=2)
+    sd = video_ref.calibrate_running_stats(sd, cfg, inputs, bboxes=boxes)
+    with torch.no_grad():
+        ref = video_ref.video_forward(sd, cfg, inputs, training=False, bboxes=boxes)
+    model.load_state_dict(sd)
+    model.eval()
+    with torch.no_grad():
+        plain = model(inputs, boxes).float()
+        inference.fuse_for_inference(model)
+        fused = model(inputs, boxes).float()
+    assert plain.shape == ref.shape == fused.shape == (4, cfg.MODEL.NUM_CLASSES)
+    scale = float(ref.abs().max())
+    assert float((plain - ref).abs().max()) < 2e-2 * scale and float((fused - ref).abs().max()) < 2e-2 * scale
+    assert float((fused - plain).abs().max()) < 2e-2 * scale
