@@ -941,6 +941,22 @@ static void dw_block_plan(DwParams& p, DwBlockIdx& bi, const sf_dw_desc* d, bool
             else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi);           \
         }                                                                                                                 \
     } while (0)
+#define SF_DW_DISPATCH_B(kind, KERNEL, FLAG, grid, s, p, bi)                                                            \
+    do {                                                                                                                  \
+        if ((kind) == 1) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W, FLAG>), grid, dim3(SF_THREADS), 0, s, p, bi);   \
+        else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_SMALL_W, FLAG>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+        else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W, FLAG>), grid, dim3(SF_THREADS), 0, s, p, bi);               \
+    } while (0)
+// version-2 stencils: fp32 LDS weights for the narrow layers, fp16 for the wide ones
+#define SF_DW_DISPATCH_V2(kind, KERNEL, grid, s, p, bi)                                                                 \
+    do {                                                                                                                  \
+        const bool small_w = (p).kT * (p).kH * (p).kW * (p).Cw <= SF_DW_SMALL_W;                                        \
+        if ((kind) == 1 && small_w) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W, float>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+        else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_MAX_W, f16>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+        else if ((kind) == 2 && small_w) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_SMALL_W, float>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+        else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_MAX_W, f16>), grid, dim3(SF_THREADS), 0, s, p, bi); \
+        else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W, float>), grid, dim3(SF_THREADS), 0, s, p, bi);             \
+    } while (0)
 extern "C" int sf_dwconv_fwd_blocks(const sf_dw_desc* d) {
     DwParams p;
     dim3 grid;
@@ -962,7 +978,11 @@ extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w,
     if (kind) {
         DwBlockIdx bi;
         dw_block_plan(p, bi, d, true, kDwFwdBlocks, grid);
-        SF_DW_DISPATCH_PF(kind, sf_dwconv_fwd_blocked_kernel, grid, (hipStream_t)stream, p, bi);
+        // version 2 (uniform plane loop, address-selected zero taps, fp32 LDS weights: ~40 % fewer VALU instructions per
+        // plane in the gfx950 ISA, see sf_dwconv.h); SF_DW_FWD_V2=0 keeps version 1 for A/B runs
+        static const bool v2 = !(getenv("SF_DW_FWD_V2") && atoi(getenv("SF_DW_FWD_V2")) == 0);
+        if (v2) SF_DW_DISPATCH_V2(kind, sf_dwconv_fwd_blocked2_kernel, grid, (hipStream_t)stream, p, bi);
+        else SF_DW_DISPATCH_PF(kind, sf_dwconv_fwd_blocked_kernel, grid, (hipStream_t)stream, p, bi);
     } else {
         hipLaunchKernelGGL(sf_dwconv_fwd_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     }
@@ -978,7 +998,9 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
     if (kind) {
         DwBlockIdx bi;
         dw_block_plan(p, bi, d, false, 8192, grid);
-        SF_DW_DISPATCH_PF(kind, sf_dwconv_dgrad_blocked_kernel, grid, (hipStream_t)stream, p, bi);
+        static const bool v2 = !(getenv("SF_DW_DGRAD_V2") && atoi(getenv("SF_DW_DGRAD_V2")) == 0);   // A/B: =0 -> version 1
+        if (v2) SF_DW_DISPATCH_V2(kind, sf_dwconv_dgrad_blocked2_kernel, grid, (hipStream_t)stream, p, bi);
+        else SF_DW_DISPATCH_PF(kind, sf_dwconv_dgrad_blocked_kernel, grid, (hipStream_t)stream, p, bi);
     } else {
         hipLaunchKernelGGL(sf_dwconv_dgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     }
@@ -1008,7 +1030,9 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
     REQUIRE(grid.y == 1, "sf_dwconv_wgrad: C > 2048 is not supported");
     p.x = (const f16*)x; p.ldx = d->ldx; p.dy = (const f16*)dy; p.lddy = d->ldy; p.wpart = (float*)workspace;
     grid.z = d->kT;
-    if (kind) SF_DW_DISPATCH(kind, sf_dwconv_wgrad_blocked_kernel, grid, (hipStream_t)stream, p, bi);
+    static const bool v2 = !(getenv("SF_DW_WGRAD_V2") && atoi(getenv("SF_DW_WGRAD_V2")) == 0);       // A/B: =0 -> version 1
+    if (kind && v2) SF_DW_DISPATCH_B(kind, sf_dwconv_wgrad_blocked_kernel, true, grid, (hipStream_t)stream, p, bi);
+    else if (kind) SF_DW_DISPATCH_B(kind, sf_dwconv_wgrad_blocked_kernel, false, grid, (hipStream_t)stream, p, bi);
     else hipLaunchKernelGGL(sf_dwconv_wgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     if (check_launch("dwconv_wgrad")) return -1;
     DwFinalizeParams f;

@@ -388,6 +388,122 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwPar
         rowtile_reduce_store(p.rt, active, c, ssum, ssq, p.stat_part + (int64_t)blockIdx.x * 2 * p.rt.C, s_red);
 }
 
+// ---- version 2 of the W-blocked forward stencil ------------------------------------------------------------------
+// The ISA of the kernel above (gfx950, hipcc 7.2) spends ~215 VALU instructions per (kt, kh) plane on 48 packed FMAs:
+// 72 fp16->fp32 converts (48 inputs + 24 weights), 24 v_cndmask zeroing out-of-range taps dword by dword, 32 v_mov
+// copying the accumulators around the divergent "next valid plane" search loop, and that loop's exec-mask bookkeeping.
+// Version 2 keeps the arithmetic (fp32 accumulate, same operand rounding) and removes the overhead:
+//   * every plane of the kT x kH window is visited (a uniform loop: accumulators stay in place, no divergence);
+//   * a tap outside the input is redirected to a 16-byte line of zeros in global memory by selecting the ADDRESS
+//     (one 64-bit select per plane, plus one per edge column) instead of zeroing the loaded DATA;
+//   * when the row length is a multiple of the 4-column block only column 0 of a group can fall outside (uniform test);
+//   * weights are staged as fp32 (no per-plane weight converts; the 141 VGPRs of this kernel cap residency at 3 waves
+//     per SIMD long before the larger LDS footprint does).
+__device__ __attribute__((aligned(16))) f16 sf_dw_zero_line[8] = {};
+
+// 8 consecutive weights of one tap as fp32 from either LDS image (two ds_read_b128, or one + 8 converts)
+__device__ __forceinline__ void dw_load_w8(const float* w, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w), b = *reinterpret_cast<const f32x4*>(w + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+}
+__device__ __forceinline__ void dw_load_w8(const f16* w, float (&o)[8]) { cvt8(ld16(w), o); }
+__device__ __forceinline__ void dw_stage_weights_t(const DwParams& p, float* s_w) { dw_stage_weights(p, s_w); }
+__device__ __forceinline__ void dw_stage_weights_t(const DwParams& p, f16* s_w) { dw_stage_weights16(p, s_w); }
+
+// WT = float for the narrow layers (taps*Cw <= 3072: 12 KiB of LDS), f16 for the wide ones (24 KiB instead of 48 KiB, so
+// that LDS does not cap residency below what the registers allow; costs 24 converts per plane)
+template <int KW, int SW, int WSZ, typename WT>
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked2_kernel(DwParams p, DwBlockIdx bi) {
+    constexpr int NIN = (SF_DW_WB - 1) * SW + KW;
+    __shared__ __attribute__((aligned(16))) WT s_w[WSZ];        // taps*Cw weights, [tap][Cw]
+    __shared__ float s_red[SF_THREADS][17];
+    dw_stage_weights_t(p, s_w);
+    __syncthreads();
+    int gcol, r0, r1, rstep;
+    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const int c = gcol * 8;
+    const int cw = c % p.Cw;
+    const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls, So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
+    // columns 1 .. NIN-1 of every group are inside the row when the row is a whole number of groups (block-uniform)
+    const bool edge_free = (p.Wo % SF_DW_WB) == 0 && (p.Wo - SF_DW_WB) * SW - p.pW + NIN - 1 < p.Wi;
+    const f16* const zline = sf_dw_zero_line;
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    if (active) {
+        for (int m = r0; m < r1; m += rstep) {
+            uint32_t n;
+            int to, ho, wo0;
+            if (dwb_decode(bi, (uint32_t)m, n, to, ho, wo0)) {          // cls row: copy
+                f16x8 v = ld16(p.x + (int64_t)n * Si * p.ldx + c);
+                float f[8];
+                cvt8(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ssum[e] += f[e]; ssq[e] += f[e] * f[e]; }
+                st16(p.y + (int64_t)n * So * p.ldy + c, v);
+                continue;
+            }
+            const f16* xb = p.x + ((int64_t)n * Si + p.cls) * p.ldx + c;
+            float acc[SF_DW_WB][8];
+#pragma unroll
+            for (int i = 0; i < SF_DW_WB; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+            const int wi0 = wo0 * SW - p.pW;
+            const int t0 = to * p.sT - p.pT, h0 = ho * p.sH - p.pH;
+            int tap = 0;
+            for (int kt = 0; kt < p.kT; ++kt) {
+                const int t = t0 + kt;
+                const bool tv = (unsigned)t < (unsigned)p.Ti;
+                for (int kh = 0; kh < p.kH; ++kh, tap += KW) {
+                    const int h = h0 + kh;
+                    const bool pv = tv && (unsigned)h < (unsigned)p.Hi;
+                    // an invalid plane reads the zero line for every column (column stride 0)
+                    const f16* line = pv ? xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx : zline;
+                    const int64_t cstride = pv ? (int64_t)p.ldx : 0;
+                    f16x8 raw[NIN];
+#pragma unroll
+                    for (int j = 0; j < NIN; ++j) {
+                        const int col = wi0 + j;
+                        const f16* a = line + (int64_t)col * cstride;
+                        if (!(edge_free && j > 0)) a = (unsigned)col < (unsigned)p.Wi ? a : zline;
+                        raw[j] = ld16(a);
+                    }
+                    const WT* wt = s_w + tap * p.Cw + cw;
+#pragma unroll
+                    for (int kw = 0; kw < KW; ++kw) {
+                        float wv[8];
+                        dw_load_w8(wt + kw * p.Cw, wv);
+#pragma unroll
+                        for (int i = 0; i < SF_DW_WB; ++i) {
+                            const int j = i * SW + kw;      // compile-time after unrolling
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[i][e] += (float)raw[j][e] * wv[e];
+                        }
+                    }
+                }
+            }
+            f16* yrow = p.y + ((int64_t)n * So + p.cls + ((int64_t)to * p.Ho + ho) * p.Wo + wo0) * p.ldy + c;
+#pragma unroll
+            for (int i = 0; i < SF_DW_WB; ++i) {
+                if (wo0 + i < p.Wo) {
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        o[e] = (f16)acc[i][e];
+                        ssum[e] += acc[i][e];
+                        ssq[e] += acc[i][e] * acc[i][e];
+                    }
+                    st16(yrow + (int64_t)i * p.ldy, o);
+                }
+            }
+        }
+    }
+    if (p.stat_part)
+        rowtile_reduce_store(p.rt, active, c, ssum, ssq, p.stat_part + (int64_t)blockIdx.x * 2 * p.rt.C, s_red);
+}
+
 // data gradient, blocked over 4 consecutive INPUT columns w0..w0+3 (w0 % 4 == 0).  With pW = KW/2 the output
 // columns that can contribute are q0 + jj, q0 = (w0 + pW - (KW-1) + SW-1) / SW rounded as below, and the tap of
 // (input i, column jj) is kw = B0 + i - jj*SW with a compile-time B0.
@@ -495,11 +611,103 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked_kernel(DwP
     }
 }
 
+// ---- version 2 of the W-blocked data-gradient stencil (same restructuring as the forward, see above) ----------------
+// The planes that can contribute to input row (t, h) are kt = kt0 + a*sT, kh = kh0 + b*sH with kt0 = (t + pT) % sT,
+// kh0 = (h + pH) % sH: a uniform loop over (a, b) visits exactly those candidates (no divisibility test, no skipped
+// iterations for strided convolutions); a candidate outside the kernel or the output is read from the zero line.
+template <int KW, int SW, int WSZ, typename WT>
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked2_kernel(DwParams p, DwBlockIdx bi) {
+    constexpr int PW = KW / 2;
+    constexpr int B0 = SW == 1 ? KW - 1 : PW;                 // kw of (i = 0, jj = 0)
+    constexpr int NQ = SW == 1 ? SF_DW_WB + KW - 1 : (SF_DW_WB - 1 + B0) / SW + 1;
+    __shared__ __attribute__((aligned(16))) WT s_w[WSZ];
+    dw_stage_weights_t(p, s_w);
+    __syncthreads();
+    int gcol, r0, r1, rstep;
+    if (!p.rt.init(gcol, r0, r1, rstep)) return;
+    const int c = gcol * 8;
+    const int cw = c % p.Cw;
+    const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls, So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
+    const int na = (p.kT + p.sT - 1) / p.sT, nb = (p.kH + p.sH - 1) / p.sH;
+    // output columns q0 + jj, jj = 1 .. NQ-2, exist for every group when the input row is a whole number of groups and the
+    // last group's columns stay below Wo (block-uniform); the first and the last column are always range-checked
+    const int q_last0 = SW == 1 ? (p.Wi - SF_DW_WB) + PW - (KW - 1) : (p.Wi - SF_DW_WB) / 2;
+    const bool edge_free = (p.Wi % SF_DW_WB) == 0 && q_last0 + NQ - 2 < p.Wo && (SW == 1 ? PW - (KW - 1) + 1 >= 0 : true);
+    const f16* const zline = sf_dw_zero_line;
+    for (int m = r0; m < r1; m += rstep) {
+        uint32_t n;
+        int t, h, w0;
+        if (dwb_decode(bi, (uint32_t)m, n, t, h, w0)) {
+            st16(p.y + (int64_t)n * Si * p.ldy + c, ld16(p.dy + (int64_t)n * So * p.lddy + c));
+            continue;
+        }
+        const f16* db = p.dy + ((int64_t)n * So + p.cls) * p.lddy + c;
+        float acc[SF_DW_WB][8];
+#pragma unroll
+        for (int i = 0; i < SF_DW_WB; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+        const int q0 = SW == 1 ? w0 + PW - (KW - 1) : w0 / 2;
+        uint32_t qt0, kt0, qh0, kh0;
+        fd_divmod((uint32_t)(t + p.pT), p.fdsT, qt0, kt0);      // t + pT = qt0*sT + kt0
+        fd_divmod((uint32_t)(h + p.pH), p.fdsH, qh0, kh0);
+        for (int a = 0; a < na; ++a) {
+            const int kt = (int)kt0 + a * p.sT, qt = (int)qt0 - a;
+            const bool tv = kt < p.kT && (unsigned)qt < (unsigned)p.To;
+            for (int b = 0; b < nb; ++b) {
+                const int kh = (int)kh0 + b * p.sH, qh = (int)qh0 - b;
+                const bool pv = tv && kh < p.kH && (unsigned)qh < (unsigned)p.Ho;
+                const f16* line = pv ? db + (((int64_t)qt * p.Ho + qh) * p.Wo) * p.lddy : zline;
+                const int64_t cstride = pv ? (int64_t)p.lddy : 0;
+                const int tap = pv ? (kt * p.kH + kh) * KW : 0;
+                f16x8 raw[NQ];
+#pragma unroll
+                for (int jj = 0; jj < NQ; ++jj) {
+                    const int q = q0 + jj;
+                    const f16* aq = line + (int64_t)q * cstride;
+                    if (!(edge_free && jj > 0 && jj < NQ - 1)) aq = (unsigned)q < (unsigned)p.Wo ? aq : zline;
+                    raw[jj] = ld16(aq);
+                }
+                const WT* wt = s_w + tap * p.Cw + cw;
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    float wv[8];
+                    dw_load_w8(wt + kw * p.Cw, wv);
+#pragma unroll
+                    for (int i = 0; i < SF_DW_WB; ++i) {
+                        // kw = B0 + i - jj*SW  <=>  jj = (B0 + i - kw) / SW when divisible (compile-time)
+                        const int num = B0 + i - kw;
+                        if (num >= 0 && num % SW == 0 && num / SW < NQ) {
+                            const int jj = num / SW;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[i][e] += (float)raw[jj][e] * wv[e];
+                        }
+                    }
+                }
+            }
+        }
+        f16* xrow = p.y + ((int64_t)n * Si + p.cls + ((int64_t)t * p.Hi + h) * p.Wi + w0) * p.ldy + c;
+#pragma unroll
+        for (int i = 0; i < SF_DW_WB; ++i) {
+            if (w0 + i < p.Wi) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)acc[i][e];
+                st16(xrow + (int64_t)i * p.ldy, o);
+            }
+        }
+    }
+}
+
 // weight gradient, blocked over 4 consecutive OUTPUT columns; blockIdx.z = kt, kH*KW (<= 9) accumulators.
-template <int KW, int SW, int WSZ>
-__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_blocked_kernel(DwParams p, DwBlockIdx bi) {
+// V2: out-of-range taps are redirected to the zero line by ADDRESS (see the version-2 forward kernel) instead of being
+// zeroed dword by dword after the load, and the (kh) planes are visited uniformly.
+template <int KW, int SW, int WSZ, bool V2 = false>
+__global__ __launch_bounds__(SF_THREADS, 3) void sf_dwconv_wgrad_blocked_kernel(DwParams p, DwBlockIdx bi) {
     constexpr int NIN = (SF_DW_WB - 1) * SW + KW;
     __shared__ float s_red[SF_THREADS][9];
+    const bool edge_free = (p.Wo % SF_DW_WB) == 0 && (p.Wo - SF_DW_WB) * SW - p.pW + NIN - 1 < p.Wi;   // block-uniform
+    const f16* const zline = sf_dw_zero_line;
     int gcol, r0, r1, rstep;
     const bool active = p.rt.init(gcol, r0, r1, rstep);
     const int c = gcol * 8;
@@ -521,15 +729,47 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_blocked_kernel(DwP
             const f16* drow = p.dy + ((int64_t)n * So + p.cls + ((int64_t)to * p.Ho + ho) * p.Wo + wo0) * p.lddy + c;
             f16x8 d[SF_DW_WB];
 #pragma unroll
-            for (int i = 0; i < SF_DW_WB; ++i)
-                d[i] = keep8(ld16(drow + (int64_t)(wo0 + i < p.Wo ? i : 0) * p.lddy), wo0 + i < p.Wo);
+            for (int i = 0; i < SF_DW_WB; ++i) {
+                if constexpr (V2) {
+                    const f16* a = drow + (int64_t)i * p.lddy;
+                    if (!edge_free) a = wo0 + i < p.Wo ? a : zline;
+                    d[i] = ld16(a);
+                } else {
+                    d[i] = keep8(ld16(drow + (int64_t)(wo0 + i < p.Wo ? i : 0) * p.lddy), wo0 + i < p.Wo);
+                }
+            }
             const f16* xb = p.x + ((int64_t)n * Si + p.cls) * p.ldx + c;
             const int wi0 = wo0 * SW - p.pW;
 #pragma unroll
             for (int kh = 0; kh < 9 / KW; ++kh) {
                 if (kh < p.kH) {
                     const int h = ho * p.sH - p.pH + kh;
-                    if ((unsigned)h < (unsigned)p.Hi) {
+                    if constexpr (V2) {
+                        const bool pv = (unsigned)h < (unsigned)p.Hi;
+                        const f16* line = pv ? xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx : zline;
+                        const int64_t cstride = pv ? (int64_t)p.ldx : 0;
+                        f16x8 raw[NIN];
+#pragma unroll
+                        for (int j = 0; j < NIN; ++j) {
+                            const int col = wi0 + j;
+                            const f16* a = line + (int64_t)col * cstride;
+                            if (!(edge_free && j > 0)) a = (unsigned)col < (unsigned)p.Wi ? a : zline;
+                            raw[j] = ld16(a);
+                        }
+#pragma unroll
+                        for (int j = 0; j < NIN; ++j) {
+                            float xin[8];
+                            cvt8(raw[j], xin);
+#pragma unroll
+                            for (int i = 0; i < SF_DW_WB; ++i) {
+                                const int kw = j - i * SW;
+                                if (kw >= 0 && kw < KW) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) acc[kh * KW + kw][e] += (float)d[i][e] * xin[e];
+                                }
+                            }
+                        }
+                    } else if ((unsigned)h < (unsigned)p.Hi) {
                         const f16* line = xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx;
                         f16x8 raw[NIN];
 #pragma unroll

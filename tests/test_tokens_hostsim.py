@@ -28,6 +28,11 @@ def test_dwconv_tokens(sim):
     tc.check_dwconv(sim, 2, 1, 24, (6, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)
     tc.check_dwconv(sim, 1, 1, 16, (2, 9, 9), (3, 3, 3), (1, 4, 4), cls=1)      # generic (non-blocked) kernels
     tc.check_dwconv(sim, 1, 2, 8, (2, 7, 7), (3, 3, 3), (1, 2, 2), cls=0)       # odd width, stride 2
+    # rows that are a whole number of 4-column groups (only column 0 of a group can fall outside the row)
+    tc.check_dwconv(sim, 1, 1, 16, (3, 5, 8), (3, 3, 3), (1, 1, 1), cls=0)
+    tc.check_dwconv(sim, 1, 1, 8, (2, 6, 16), (3, 3, 3), (1, 2, 2), cls=1)
+    tc.check_dwconv(sim, 1, 1, 120, (2, 4, 8), (3, 3, 3), (1, 1, 1), cls=0)     # taps * Cw > 3072: fp16 LDS weights
+    tc.check_dwconv(sim, 1, 1, 16, (5, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)      # X3D stem temporal conv, whole groups
 
 
 def test_token_pool(sim):
