@@ -150,13 +150,17 @@ def aggregate_sub_bn_stats(module):
     return count
 
 
-def num_splits_of(model):
-    """num_splits shared by the model's SubBatchNorm3d layers (1 when it has none); cached on the model."""
+def num_splits_of(model, full_batch=()):
+    """num_splits shared by the model's SubBatchNorm3d layers (1 when it has none); cached on the model.  ``full_batch``:
+    child modules that run on the whole batch after the split passes (the X3D head keeps a plain BatchNorm3d in the
+    reference, video_model_builder.py:788-797 / head_helper.py:374)."""
     s = model.__dict__.get("_sf_num_splits")
     if s is None:
         vals = {m.num_splits for m in model.modules() if isinstance(m, SubBatchNorm3d)}
         assert len(vals) <= 1, f"SubBatchNorm3d layers with different num_splits: {vals}"
-        plain = any(isinstance(m, nn.modules.batchnorm._BatchNorm) and not _inside_sub(model, m) for m in model.modules())
+        outside = {id(b) for top in full_batch for b in top.modules()}
+        plain = any(isinstance(m, nn.modules.batchnorm._BatchNorm) and id(m) not in outside and not _inside_sub(model, m)
+                    for m in model.modules())
         s = vals.pop() if vals else 1
         assert s == 1 or not plain, "sub-batch execution needs every norm layer of the model to be SubBatchNorm3d"
         model.__dict__["_sf_num_splits"] = s
@@ -167,7 +171,7 @@ def _inside_sub(model, bn):
     return any(isinstance(m, SubBatchNorm3d) and (bn is m.bn or bn is m.split_bn) for m in model.modules())
 
 
-def run_in_splits(model, forward_once, inputs, S):
+def run_in_splits(model, forward_once, inputs, S, params=None):
     """Training forward of a SubBatchNorm3d(S) model: S passes over the sub-batches x[j::S] (see the module docstring);
     returns the outputs re-interleaved to the original sample order.  Gradient-ready notifications of the engine are
     held back until all S passes have contributed (engine.hold_notifications)."""
@@ -175,7 +179,7 @@ def run_in_splits(model, forward_once, inputs, S):
     subs = [m for m in model.modules() if isinstance(m, SubBatchNorm3d)]
     N = inputs[0].shape[0]
     assert N % S == 0, f"batch {N} is not divisible by BN.NUM_SPLITS {S}"
-    engine.hold_notifications(S, model.parameters())
+    engine.hold_notifications(S, model.parameters() if params is None else params)   # params: the split-pass parameters
     outs = []
     try:
         for j in range(S):
@@ -185,5 +189,10 @@ def run_in_splits(model, forward_once, inputs, S):
     finally:
         for m in subs:
             m.__dict__["_active_split"] = None
+    return interleave(outs)
+
+
+def interleave(outs):
+    """[S tensors (N/S, ...)] -> (N, ...) with sample i*S + j taken from outs[j][i] (the inverse of x[j::S])."""
     out = torch.stack(outs, 1)
-    return out.reshape((N,) + tuple(out.shape[2:]))
+    return out.reshape((out.shape[0] * out.shape[1],) + tuple(out.shape[2:]))

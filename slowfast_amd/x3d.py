@@ -516,17 +516,21 @@ class X3D(nn.Module):
         from .video_models import _bump_batches_tracked, hold_notifications, num_splits_of, run_in_splits
         if self.training:
             _bump_batches_tracked(self)
-            S = num_splits_of(self)
-            hold_notifications(S, self.parameters() if S > 1 else None)
-            if S > 1:                    # SubBatchNorm3d: S sub-batch passes (batchnorm.run_in_splits)
-                return run_in_splits(self, self._forward, list(x), S)
-        return self._forward(x)
+            S = num_splits_of(self, full_batch=(self.head,))
+            # only the backbone's parameters receive S contributions; the head (plain BatchNorm3d in the reference too)
+            # runs once on the re-interleaved features of the whole batch
+            hold_notifications(1)
+            if S > 1:                    # SubBatchNorm3d: S sub-batch passes over the backbone (batchnorm.run_in_splits)
+                backbone = [p for m in (self.s1, self.s2, self.s3, self.s4, self.s5) for p in m.parameters()]
+                feats = run_in_splits(self, lambda xs: self._backbone(xs)[0], list(x), S, params=backbone)
+                return self.head([feats])
+        return self.head(self._backbone(x))
 
-    def _forward(self, x):
+    def _backbone(self, x):
         x = self.s1(list(x))
         for s in (self.s2, self.s3, self.s4, self.s5):
             x = s(x)
-        return self.head(x)
+        return x
 
 
 from . import stems as _stems  # noqa: E402

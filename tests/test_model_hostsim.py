@@ -115,3 +115,34 @@ def test_mvit_v1_and_vit_match_reference(sim, name):
         mc.check_engine(name, sim, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.2, tol_global=1e-2, report=rep)
     finally:
         print(rep)
+
+
+def test_x3d_sub_batchnorm_backbone_with_full_batch_head(sim):
+    """X3D with BN.NORM_TYPE sub_batchnorm: the reference builds the backbone with SubBatchNorm3d but leaves the head's
+    conv_5_bn a plain BatchNorm3d over the whole batch; the engine runs the backbone in sub-batch passes and the head once
+    on the re-interleaved features.  Checked against the oracle (whose SubBatchNorm3d and X3D restatements are both pinned
+    to the reference)."""
+    import torch
+    import slowfast_amd as sa
+    from oracle import video_ref
+    gold = mc.load_golden("x3d_tiny")
+    cfg = mc.cfg_for(gold, ["BN.NORM_TYPE", "sub_batchnorm", "BN.NUM_SPLITS", 2])
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    sd = video_ref.randomize_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, 21)
+    model.load_state_dict(sd)
+    inputs, labels = video_ref.synthetic_batch(cfg, 4, 22)
+    o_logits, o_loss, o_grads, o_stats = video_ref.loss_and_grads(sd, cfg, inputs, labels)
+    model.train()
+    logits = model(inputs)
+    loss = torch.nn.functional.cross_entropy(logits.float(), labels)
+    (loss * 64.0).backward()
+    grads = {k: p.grad.float() / 64.0 for k, p in model.named_parameters()}
+    assert float((logits.detach().float() - o_logits).abs().max()) < 2e-2 * float(o_logits.abs().max())
+    gn, ogn = float(video_ref.grad_norm(grads)), float(video_ref.grad_norm(o_grads))
+    assert abs(gn - ogn) < 5e-2 * ogn, (gn, ogn)
+    num = sum(float((grads[k].double() - g.double()).pow(2).sum()) for k, g in o_grads.items())
+    den = sum(float(g.double().pow(2).sum()) for g in o_grads.values())
+    assert (num / den) ** 0.5 < 0.3, (num / den) ** 0.5          # tiny-model conditioning (2 samples per split)
+    msd = model.state_dict()
+    for k, v in o_stats.items():
+        assert float((msd[k].float() - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-4, k
