@@ -984,7 +984,10 @@ extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w,
         if (v2) SF_DW_DISPATCH_V2(kind, sf_dwconv_fwd_blocked2_kernel, grid, (hipStream_t)stream, p, bi);
         else SF_DW_DISPATCH_PF(kind, sf_dwconv_fwd_blocked_kernel, grid, (hipStream_t)stream, p, bi);
     } else {
-        hipLaunchKernelGGL(sf_dwconv_fwd_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+        if (p.kT * p.kH * p.kW * p.Cw <= SF_DW_SMALL_W)
+            hipLaunchKernelGGL(sf_dwconv_fwd_kernel<SF_DW_SMALL_W>, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(sf_dwconv_fwd_kernel<SF_DW_MAX_W>, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     }
     return check_launch("dwconv_fwd");
 }
@@ -1002,7 +1005,10 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
         if (v2) SF_DW_DISPATCH_V2(kind, sf_dwconv_dgrad_blocked2_kernel, grid, (hipStream_t)stream, p, bi);
         else SF_DW_DISPATCH_PF(kind, sf_dwconv_dgrad_blocked_kernel, grid, (hipStream_t)stream, p, bi);
     } else {
-        hipLaunchKernelGGL(sf_dwconv_dgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+        if (p.kT * p.kH * p.kW * p.Cw <= SF_DW_SMALL_W)
+            hipLaunchKernelGGL(sf_dwconv_dgrad_kernel<SF_DW_SMALL_W>, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(sf_dwconv_dgrad_kernel<SF_DW_MAX_W>, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     }
     return check_launch("dwconv_dgrad");
 }

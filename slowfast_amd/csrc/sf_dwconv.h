@@ -61,8 +61,11 @@ __device__ __forceinline__ bool dw_decode(const DwParams& p, uint32_t row, uint3
     return false;
 }
 
+// WSZ floats of LDS for the weights: 3072 (12 KiB) covers MViT's 27 x 96; the 48 KiB image is only taken when needed
+// (with it the static LDS footprint, 66 KiB with the reduction scratch, allowed two workgroups per CU)
+template <int WSZ>
 __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_kernel(DwParams p) {
-    __shared__ float s_w[SF_DW_MAX_W];
+    __shared__ float s_w[WSZ];
     __shared__ float s_red[SF_THREADS][17];
     dw_stage_weights(p, s_w);
     __syncthreads();
@@ -121,8 +124,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_kernel(DwParams p) {
 
 // dx[n, t, h, w, c] = sum_taps w[c][tap] * dy[n, (t + pT - kt)/sT, (h + pH - kh)/sH, (w + pW - kw)/sW, c]
 // (terms with a non-integral or out-of-range quotient vanish); the cls row passes through.
+template <int WSZ>
 __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_kernel(DwParams p) {
-    __shared__ float s_w[SF_DW_MAX_W];
+    __shared__ float s_w[WSZ];
     dw_stage_weights(p, s_w);
     __syncthreads();
     int gcol, r0, r1, rstep;
