@@ -28,7 +28,7 @@ def test_dwconv_tokens(gpu):
     tc.check_dwconv(gpu, 1, 4, 96, (4, 7, 7), (3, 3, 3), (1, 1, 1), cls=1)
     tc.check_dwconv(gpu, 2, 1, 24, (8, 12, 12), (5, 1, 1), (1, 1, 1), cls=0)
     tc.check_dwconv(gpu, 2, 1, 216, (4, 14, 14), (3, 3, 3), (1, 2, 2), cls=0)
-    # version-2 stencils: whole 4-column groups (edge-free fast path), narrow (fp32 LDS weights) and wide (fp16) layers
+    # X3D widths: narrow (56) and wide (432) layers, whole 4-column groups
     tc.check_dwconv(gpu, 2, 1, 56, (4, 28, 28), (3, 3, 3), (1, 1, 1), cls=0)
     tc.check_dwconv(gpu, 2, 1, 56, (4, 56, 56), (3, 3, 3), (1, 2, 2), cls=0)
     tc.check_dwconv(gpu, 1, 1, 432, (4, 8, 8), (3, 3, 3), (1, 1, 1), cls=0)

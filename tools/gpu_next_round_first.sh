@@ -16,6 +16,12 @@ for P in "MVITv2_S_16x4 32 mvit" "X3D_M 64 x3d" "C2D_8x8_R50 32 c2d" "SLOWFAST_3
 done
 timeout 100 python tools/bench_eval.py --steps 5 > gpurun_out/bench_eval_slowfast.log 2>&1; tail -1 gpurun_out/bench_eval_slowfast.log | cut -c1-300
 timeout 100 python tools/bench_eval.py --preset X3D_M --batch 64 --steps 5 > gpurun_out/bench_eval_x3d.log 2>&1; tail -1 gpurun_out/bench_eval_x3d.log | cut -c1-300
+# A/B of the opt-in version-2 depthwise stencils (profiles/r1_isa_dwconv_v2.md)
+for P in "X3D_M 64 x3d" "MVITv2_S_16x4 32 mvit"; do
+  set -- $P
+  SF_DW_FWD_V2=1 SF_DW_DGRAD_V2=1 SF_DW_WGRAD_V2=1 timeout 200 python bench.py --preset $1 --batch $2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_$3_dwv2.log 2>&1
+  echo "bench $3 dw-v2 rc=$?"; tail -1 gpurun_out/bench_$3_dwv2.log | cut -c1-330
+done
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o slowfast -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile > $GRAFT_REPO_ROOT/gpurun_out/rocprof_slowfast.log 2>&1; echo "rocprof rc=$?"
 cd $GRAFT_REPO_ROOT
