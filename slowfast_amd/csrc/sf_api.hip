@@ -136,6 +136,14 @@ static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s, int nbatc
     // SF_IGEMM_OCC4=0 restores the uncapped build for A/B runs
     static const bool occ4 = !(getenv("SF_IGEMM_OCC4") && atoi(getenv("SF_IGEMM_OCC4")) == 0);
     if (igemm_glds_ok(p, pw)) {
+        // SF_IGEMM_GL3=1: three LDS stages (two copy stages in flight) for the 128- and 64-wide tiles -- opt-in, unmeasured
+        static const bool gl3 = getenv("SF_IGEMM_GL3") && atoi(getenv("SF_IGEMM_GL3")) != 0;
+        if constexpr (BN >= 64) {
+            if (gl3 && p.ksteps >= 3) {
+                hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, BN == 128, false, true>), grid, dim3(SF_THREADS), 0, s, p);
+                return;
+            }
+        }
         hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, BN == 128>), grid, dim3(SF_THREADS), 0, s, p);
         return;
     }

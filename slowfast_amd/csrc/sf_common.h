@@ -35,6 +35,15 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
     } while (0)
 #endif
+// wait until at most N (compile-time) of this wave's vector-memory operations are outstanding: retires everything but
+// the newest N, i.e. a whole copy stage while the next one stays in flight
+#ifndef SF_WAIT_VMEM_N
+#define SF_WAIT_VMEM_N(N)                                                       \
+    do {                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                      \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                \
+    } while (0)
+#endif
 
 // 2^x on the transcendental unit (v_exp_f32: -inf -> 0, no range fix-ups)
 #ifndef SF_EXP2

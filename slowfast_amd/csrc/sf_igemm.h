@@ -49,15 +49,21 @@ struct IgemmParams {
 // clips/s -- profiles/r1_visit7_*_pf2.json.)
 // LEAN = the register-staged loader advances its tap decomposition incrementally (TapIter) instead of dividing in every K
 // step.  An experiment kept behind SF_IGEMM_LEAN=1: it measured 3 % slower end to end than the dividing gather.
-template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false, bool LEAN = false>
-__global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(IgemmParams p) {
+// GL3 (with GL) = THREE LDS stages: the copies of stage k+2 are issued while stage k+1 is still in flight and stage k is
+// being multiplied, so two 16 KiB stages per workgroup are always outstanding instead of one (an experiment aimed at the
+// memory-level parallelism of the K loop; 48 KiB of LDS -> 3 workgroups per CU).  Opt-in
+// (SF_IGEMM_GL3=1) until it has been timed on hardware.
+template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false, bool LEAN = false, bool GL3 = false>
+__global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm_kernel(IgemmParams p) {
     constexpr int BM = 128, BK = 32;
+    static_assert(!GL3 || (GL && BN >= 64), "three stages: direct-to-LDS tiles whose waves all issue the same copy count");
+    constexpr int NST = GL3 ? 3 : 2;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
     constexpr int STG_LD = BN + 8;
-    constexpr int SMEM_MAIN = 2 * (A_ELEMS + B_ELEMS), SMEM_STG = BM * STG_LD;
+    constexpr int SMEM_MAIN = NST * (A_ELEMS + B_ELEMS), SMEM_STG = BM * STG_LD;
     constexpr int SMEM = SMEM_MAIN > SMEM_STG ? SMEM_MAIN : SMEM_STG;
     constexpr int NB = (BN * 4 + SF_THREADS - 1) / SF_THREADS;
 
@@ -242,7 +248,22 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
 
-    if constexpr (GL) {
+    if constexpr (GL && GL3) {
+        constexpr int COPIES = 2 + NBC;          // global_load_lds per wave and stage (uniform over the waves for BN >= 64)
+        issue_tile(0, 0);
+        if (p.ksteps > 1) issue_tile(1, 1);
+        int cur = 0, nxt = 2;                    // ring positions of stage ks and of stage ks + 2
+        for (int ks = 0; ks < p.ksteps; ++ks) {
+            if (ks + 1 < p.ksteps) SF_WAIT_VMEM_N(COPIES);   // stage ks landed, stage ks + 1 may still be in flight
+            else SF_WAIT_VMEM();
+            __syncthreads();                     // ... for every wave; also: all waves are done reading stage ks - 1
+            if (ks + 2 < p.ksteps) issue_tile(ks + 2, nxt);  // into the buffer stage ks - 1 occupied
+            compute(cur);
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt = nxt == 2 ? 0 : nxt + 1;
+        }
+        __syncthreads();                         // the epilogue staging reuses the operand buffers
+    } else if constexpr (GL) {
         issue_tile(0, 0);
         SF_WAIT_VMEM();
         __syncthreads();

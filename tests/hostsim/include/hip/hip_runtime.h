@@ -66,6 +66,25 @@ struct WaveScratch {
     int nlanes = kWave;
 };
 
+// Fiber stacks are recycled through a process-wide pool: launch() starts fresh worker threads for every kernel launch,
+// and a worker's BlockCtx (thread_local) dies with its thread -- without the pool every launch leaked its mmap'ed stacks
+// (tens of GB of resident memory over a test session).
+struct StackPool {
+    std::mutex mu;
+    std::vector<void*> free_list;
+    void* get() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!free_list.empty()) { void* s = free_list.back(); free_list.pop_back(); return s; }
+        }
+        void* s = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (s == MAP_FAILED) { perror("mmap"); abort(); }
+        return s;
+    }
+    void put(void* s) { std::lock_guard<std::mutex> lk(mu); free_list.push_back(s); }
+};
+inline StackPool& stack_pool() { static StackPool* p = new StackPool(); return *p; }   // never destroyed: threads may outlive main
+
 struct BlockCtx {
     std::vector<Fiber> fibers;
     std::vector<WaveScratch> waves;
@@ -74,6 +93,10 @@ struct BlockCtx {
     int nthreads = 0;
     int cur = -1;
     const std::function<void()>* body = nullptr;
+    ~BlockCtx() {
+        for (Fiber& f : fibers)
+            if (f.stack) stack_pool().put(f.stack);
+    }
 };
 
 inline thread_local BlockCtx* g_ctx = nullptr;
@@ -106,10 +129,7 @@ inline void run_block(BlockCtx& c, dim3 block, dim3 bidx, dim3 grid, const std::
     if ((int)c.fibers.size() < n) {
         size_t old = c.fibers.size();
         c.fibers.resize(n);
-        for (size_t i = old; i < (size_t)n; ++i) {
-            c.fibers[i].stack = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-            if (c.fibers[i].stack == MAP_FAILED) { perror("mmap"); abort(); }
-        }
+        for (size_t i = old; i < (size_t)n; ++i) c.fibers[i].stack = stack_pool().get();
     }
     c.nthreads = n;
     c.body = &body;
@@ -299,6 +319,7 @@ inline void hipsim_global_load_lds16(const void* gptr, void* lds_base) {
 }
 #define SF_GLOBAL_LOAD_LDS16(g, l) hipsim_global_load_lds16((const void*)(g), (void*)(l))
 #define SF_WAIT_VMEM() ((void)0)
+#define SF_WAIT_VMEM_N(N) ((void)0)
 
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
