@@ -105,6 +105,23 @@ CASES = {
                  ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "MODEL.NUM_CLASSES", 10,
                   "DATA.TRAIN_CROP_SIZE", 64, "DATA.TEST_CROP_SIZE", 64, "DATA.NUM_FRAMES", 8, "MVIT.DEPTH", 2,
                   "MVIT.EMBED_DIM", 64, "MVIT.NUM_HEADS", 2, "MIXUP.ENABLE", False], 2),
+    # MViTv2 without the cls token (CLS_EMBED_ON False: norm -> mean over all tokens feeds the head) and with separate
+    # q / k / v Linears (SEPARATE_QKV), as configs/ImageNet/MVITv2_*.yaml and the reversible configs select them
+    "mvit_nocls_sepqkv_tiny": ("configs/Kinetics/MVITv2_S_16x4.yaml",
+                  ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "MODEL.NUM_CLASSES", 10,
+                   "DATA.TRAIN_CROP_SIZE", 64, "DATA.TEST_CROP_SIZE", 64, "DATA.NUM_FRAMES", 8, "MVIT.DEPTH", 4,
+                   "MVIT.EMBED_DIM", 32, "MVIT.DIM_MUL", "[[1, 2.0], [3, 2.0]]", "MVIT.HEAD_MUL", "[[1, 2.0], [3, 2.0]]",
+                   "MVIT.POOL_Q_STRIDE", "[[0, 1, 1, 1], [1, 1, 2, 2], [2, 1, 1, 1], [3, 1, 2, 2]]",
+                   "MVIT.POOL_KV_STRIDE_ADAPTIVE", "[1, 4, 4]", "MIXUP.ENABLE", False,
+                   "MVIT.CLS_EMBED_ON", False, "MVIT.SEPARATE_QKV", True], 2),
+    # POOL_FIRST (attention.py:296-301, 339-351): the normed block input is folded into heads and pooled before the
+    # q / k / v Linears; MViTv1 layout (the family POOL_FIRST was introduced with), cls token on
+    "mvit_poolfirst_tiny": ("configs/Kinetics/MVIT_B_16x4_CONV.yaml",
+                     ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "MODEL.NUM_CLASSES", 10,
+                      "DATA.TRAIN_CROP_SIZE", 64, "DATA.TEST_CROP_SIZE", 64, "DATA.NUM_FRAMES", 8, "MVIT.DEPTH", 4,
+                      "MVIT.EMBED_DIM", 32, "MVIT.DIM_MUL", "[[1, 2.0], [3, 2.0]]", "MVIT.HEAD_MUL", "[[1, 2.0], [3, 2.0]]",
+                      "MVIT.POOL_Q_STRIDE", "[[1, 1, 2, 2], [3, 1, 2, 2]]", "MVIT.POOL_KV_STRIDE_ADAPTIVE", "[1, 4, 4]",
+                      "MIXUP.ENABLE", False, "MVIT.POOL_FIRST", True], 2),
     "mvit_s_mid": ("configs/Kinetics/MVITv2_S_16x4.yaml",
                    ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "DATA.TRAIN_CROP_SIZE", 96,
                     "DATA.TEST_CROP_SIZE", 96, "DATA.NUM_FRAMES", 8, "MIXUP.ENABLE", False], 2),

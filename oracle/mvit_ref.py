@@ -94,19 +94,29 @@ def _rel_pos_bias(attn, q, has_cls, q_shape, k_shape, rel_h, rel_w, rel_t):
     return out
 
 
-def attention(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, residual_pooling=True):
-    """MultiScaleAttention.forward (attention.py:293-392), mode "conv", pool_first False, fused qkv.  q (k / v) is left
-    un-pooled and un-normed when the block has no pool_q (pool_k / pool_v) -- attention.py:199-203, 236-262: kernel ()
-    when both kernel and stride are all ones (MViTv1 blocks outside POOL_Q_STRIDE)."""
+def attention(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, residual_pooling=True, pool_first=False):
+    """MultiScaleAttention.forward (attention.py:293-392), mode "conv".  Fused qkv projection, or separate q / k / v
+    Linears (SEPARATE_QKV, attention.py:188-191, 310-314), or POOL_FIRST (attention.py:296-301, 339-351: the block input
+    is folded into heads and pooled BEFORE the q / k / v Linears; the pooling convs then have dim // heads channels).
+    q (k / v) is left un-pooled and un-normed when the block has no pool_q (pool_k / pool_v) -- attention.py:199-203,
+    236-262: kernel () when both kernel and stride are all ones (MViTv1 blocks outside POOL_Q_STRIDE)."""
     B, N, _ = x.shape
-    qkv = _linear(x, sd, prefix + ".qkv").reshape(B, N, 3, heads, -1).permute(2, 0, 3, 1, 4)
-    q, k, v = qkv[0], qkv[1], qkv[2]
+    if pool_first:
+        q = k = v = x.reshape(B, N, heads, -1).permute(0, 2, 1, 3)
+    elif prefix + ".qkv.weight" in sd:
+        qkv = _linear(x, sd, prefix + ".qkv").reshape(B, N, 3, heads, -1).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+    else:
+        q, k, v = (_linear(x, sd, prefix + "." + n).reshape(B, N, heads, -1).permute(0, 2, 1, 3) for n in "qkv")
     q_shape = k_shape = list(thw)
     if prefix + ".pool_q.weight" in sd:
         q, q_shape = attention_pool(q, sd[prefix + ".pool_q.weight"], stride_q, thw, has_cls, prefix + ".norm_q", sd)
     if prefix + ".pool_k.weight" in sd:
         k, k_shape = attention_pool(k, sd[prefix + ".pool_k.weight"], stride_kv, thw, has_cls, prefix + ".norm_k", sd)
         v, _ = attention_pool(v, sd[prefix + ".pool_v.weight"], stride_kv, thw, has_cls, prefix + ".norm_v", sd)
+    if pool_first:
+        q, k, v = (_linear(t.permute(0, 2, 1, 3).reshape(B, t.shape[2], -1), sd, prefix + "." + n)
+                   .reshape(B, t.shape[2], heads, -1).permute(0, 2, 1, 3) for t, n in ((q, "q"), (k, "k"), (v, "v")))
     head_dim = q.shape[-1]
     scale = head_dim ** -0.5
     attn = (q * scale) @ k.transpose(-2, -1)
@@ -127,12 +137,13 @@ def attention(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, resi
 
 
 def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, drop=None, residual_pooling=True,
-          dim_mul_in_att=True):
+          dim_mul_in_att=True, pool_first=False):
     """MultiScaleBlock.forward (attention.py:491-514).  The dimension change (``proj``) acts on the normed block input
     with DIM_MUL_IN_ATT (MViTv2) and on the normed Mlp input without it (MViTv1, attention.py:507-508).
     drop = (s1, s2): per-sample scales mask/keep_prob of the two drop_path() calls (common.py:46-59), None = off."""
     x_norm = _ln(x, sd, prefix + ".norm1")
-    x_block, thw_new = attention(x_norm, sd, prefix + ".attn", thw, heads, stride_q, stride_kv, has_cls, residual_pooling)
+    x_block, thw_new = attention(x_norm, sd, prefix + ".attn", thw, heads, stride_q, stride_kv, has_cls, residual_pooling,
+                                 pool_first)
     has_proj = prefix + ".proj.weight" in sd
     if has_proj and dim_mul_in_att:
         x = _linear(x_norm, sd, prefix + ".proj")
@@ -182,8 +193,9 @@ def mvit_plan(cfg):
 
 
 def mvit_forward(sd, cfg, inputs, training=True, drop=None):
-    """MViT.forward (video_model_builder.py:1166-1244) for CLS_EMBED_ON, learned absolute position embedding (joint or
-    SEP_POS_EMBED) or none, no dropout, + TransformerBasicHead.forward (head_helper.py:538-563).  drop = per-block
+    """MViT.forward (video_model_builder.py:1166-1244) with or without the cls token (CLS_EMBED_ON), learned absolute
+    position embedding (joint or SEP_POS_EMBED) or none, no dropout, + TransformerBasicHead.forward
+    (head_helper.py:538-563).  drop = per-block
     (s1, s2) stochastic-depth scales (the sampled masks of drop_path(), common.py:46-59, divided by keep_prob) or None."""
     x = inputs[0]
     w = sd["patch_embed.proj.weight"]
@@ -191,23 +203,29 @@ def mvit_forward(sd, cfg, inputs, training=True, drop=None):
     x = _store(F.conv3d(_store(x), _store(w), sd["patch_embed.proj.bias"], stride, pad))
     B, C, T, H, W = x.shape
     x = x.flatten(2).transpose(1, 2)
-    x = torch.cat((sd["cls_token"].expand(B, -1, -1), x), dim=1)
+    has_cls = bool(cfg.MVIT.CLS_EMBED_ON)
+    if has_cls:
+        x = torch.cat((sd["cls_token"].expand(B, -1, -1), x), dim=1)
     if cfg.MVIT.USE_ABS_POS:            # video_model_builder.py:1189-1203 (same clip size as constructed: no interpolation)
         if cfg.MVIT.SEP_POS_EMBED:
             pos = sd["pos_embed_spatial"].repeat(1, T, 1) + torch.repeat_interleave(sd["pos_embed_temporal"], H * W, dim=1)
-            pos = torch.cat([sd["pos_embed_class"], pos], 1)
+            if has_cls:
+                pos = torch.cat([sd["pos_embed_class"], pos], 1)
         else:
             pos = sd["pos_embed"]
         x = x + pos
     x = _store(x)
     thw = [T, H, W]
     for i, (heads, sq, skv) in enumerate(mvit_plan(cfg)):
-        x, thw = block(x, sd, f"blocks.{i}", thw, heads, sq, skv, drop=None if drop is None else drop[i],
-                       residual_pooling=cfg.MVIT.RESIDUAL_POOLING, dim_mul_in_att=cfg.MVIT.DIM_MUL_IN_ATT)
+        x, thw = block(x, sd, f"blocks.{i}", thw, heads, sq, skv, has_cls=has_cls, drop=None if drop is None else drop[i],
+                       residual_pooling=cfg.MVIT.RESIDUAL_POOLING, dim_mul_in_att=cfg.MVIT.DIM_MUL_IN_ATT,
+                       pool_first=cfg.MVIT.POOL_FIRST)
     if cfg.MVIT.USE_MEAN_POOLING:       # video_model_builder.py:1228-1232: mean over the patch tokens, then norm
-        x = _ln(x[:, 1:].mean(1), sd, "norm")
-    else:
+        x = _ln(x[:, 1:].mean(1) if has_cls else x.mean(1), sd, "norm")
+    elif has_cls:
         x = _ln(x[:, 0], sd, "norm")
+    else:                               # video_model_builder.py:1236-1238: norm, then mean over all tokens
+        x = _ln(x, sd, "norm").mean(1)
     z = F.linear(x, sd["head.projection.weight"], sd["head.projection.bias"])
     if not training and cfg.MODEL.HEAD_ACT == "softmax":
         z = F.softmax(z, dim=1)

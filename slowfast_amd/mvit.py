@@ -17,7 +17,7 @@ import torch.nn as nn
 from torch.nn.init import trunc_normal_
 
 from .engine import StemConvUnit
-from .mvit_engine import AttentionPlan, ClsNormFn, LinearUnit, MultiScaleBlockFn, NormUnit, PatchEmbedFn
+from .mvit_engine import AttentionPlan, ClsNormFn, LinearUnit, MultiScaleBlockFn, NormUnit, PatchEmbedFn, QKVUnit
 from .registry import MODEL_REGISTRY
 
 
@@ -71,29 +71,36 @@ class MultiScaleAttention(nn.Module):
                  has_cls_embed=True, mode="conv", pool_first=False, rel_pos_spatial=False, rel_pos_temporal=False,
                  rel_pos_zero_init=False, residual_pooling=False, separate_qkv=False):
         super().__init__()
-        if pool_first or separate_qkv or mode != "conv" or drop_rate > 0.0:
-            raise NotImplementedError("MultiScaleAttention: only mode='conv', fused qkv, pool_first=False, no dropout")
+        if mode != "conv" or drop_rate > 0.0:
+            raise NotImplementedError("MultiScaleAttention: only mode='conv' (depthwise conv pooling), no dropout")
         # "Skip pooling with kernel and stride size of (1, 1, 1)" (attention.py:199-203)
         if math.prod(kernel_q) == 1 and math.prod(stride_q) == 1:
             kernel_q = ()
         if math.prod(kernel_kv) == 1 and math.prod(stride_kv) == 1:
             kernel_kv = ()
         self.pool_first, self.separate_qkv, self.drop_rate = pool_first, separate_qkv, drop_rate
-        self.num_heads, self.dim_out = num_heads, dim_out
+        self.num_heads, self.dim_in, self.dim_out = num_heads, dim, dim_out
         head_dim = dim_out // num_heads
         self.scale = head_dim ** -0.5
         self.has_cls_embed, self.mode = has_cls_embed, mode
         pad_q, pad_kv = [int(q // 2) for q in kernel_q], [int(kv // 2) for kv in kernel_kv]
-        self.qkv = nn.Linear(dim, dim_out * 3, bias=qkv_bias)
+        if pool_first or separate_qkv:              # attention.py:188-193
+            self.q = nn.Linear(dim, dim_out, bias=qkv_bias)
+            self.k = nn.Linear(dim, dim_out, bias=qkv_bias)
+            self.v = nn.Linear(dim, dim_out, bias=qkv_bias)
+        else:
+            self.qkv = nn.Linear(dim, dim_out * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim_out, dim_out)
-        conv = partial(nn.Conv3d, head_dim, head_dim, groups=head_dim, bias=False)
+        # POOL_FIRST pools the block input folded into heads: dim // heads conv channels (attention.py:236-241)
+        dim_conv = dim // num_heads if pool_first else head_dim
+        conv = partial(nn.Conv3d, dim_conv, dim_conv, groups=dim_conv, bias=False)
         has_q, has_kv = len(kernel_q) > 0, len(kernel_kv) > 0
         self.pool_q = conv(tuple(kernel_q), stride=tuple(stride_q), padding=tuple(pad_q)) if has_q else None
-        self.norm_q = norm_layer(head_dim) if has_q else None
+        self.norm_q = norm_layer(dim_conv) if has_q else None
         self.pool_k = conv(tuple(kernel_kv), stride=tuple(stride_kv), padding=tuple(pad_kv)) if has_kv else None
-        self.norm_k = norm_layer(head_dim) if has_kv else None
+        self.norm_k = norm_layer(dim_conv) if has_kv else None
         self.pool_v = conv(tuple(kernel_kv), stride=tuple(stride_kv), padding=tuple(pad_kv)) if has_kv else None
-        self.norm_v = norm_layer(head_dim) if has_kv else None
+        self.norm_v = norm_layer(dim_conv) if has_kv else None
         self.rel_pos_spatial, self.rel_pos_temporal = rel_pos_spatial, rel_pos_temporal
         if rel_pos_spatial:
             assert input_size[1] == input_size[2]
@@ -111,7 +118,11 @@ class MultiScaleAttention(nn.Module):
             if not rel_pos_zero_init:
                 trunc_normal_(self.rel_pos_t, std=0.02)
         self.residual_pooling = residual_pooling
-        self._qkv, self._proj = LinearUnit(self.qkv), LinearUnit(self.proj)
+        self._proj = LinearUnit(self.proj)
+        if pool_first:
+            self._q, self._k, self._v = LinearUnit(self.q), LinearUnit(self.k), LinearUnit(self.v)
+        else:
+            self._qkv = QKVUnit(self.q, self.k, self.v) if separate_qkv else LinearUnit(self.qkv)
         self._norm_q = NormUnit(self.norm_q) if has_q else None
         self._norm_k, self._norm_v = (NormUnit(self.norm_k), NormUnit(self.norm_v)) if has_kv else (None, None)
 
@@ -226,11 +237,13 @@ class MViT(nn.Module):
         assert cfg.DATA.TRAIN_CROP_SIZE == cfg.DATA.TEST_CROP_SIZE
         m = cfg.MVIT
         unsupported = [k for k, bad in (
-            ("POOL_FIRST", m.POOL_FIRST), ("PATCH_2D", m.PATCH_2D), ("REV.ENABLE", m.REV.ENABLE),
+            ("PATCH_2D", m.PATCH_2D), ("REV.ENABLE", m.REV.ENABLE),
             ("USE_FIXED_SINCOS_POS", m.USE_FIXED_SINCOS_POS), ("NORM_STEM", m.NORM_STEM),
-            ("SEPARATE_QKV", m.SEPARATE_QKV), ("not CLS_EMBED_ON", not m.CLS_EMBED_ON),
             ("LAYER_SCALE_INIT_VALUE", m.LAYER_SCALE_INIT_VALUE > 0), ("DROPOUT_RATE", m.DROPOUT_RATE > 0),
-            ("DETECTION.ENABLE", cfg.DETECTION.ENABLE), ("MODEL.ACT_CHECKPOINT", cfg.MODEL.ACT_CHECKPOINT)) if bad]
+            ("DETECTION.ENABLE", cfg.DETECTION.ENABLE)) if bad]
+        # MODEL.ACT_CHECKPOINT (video_model_builder.py:1041-1042: torch checkpoint_wrapper around every block) trades
+        # recomputation for activation memory and changes no value; the engine already saves only GEMM / pooling
+        # outputs and sizes for 288 GB of HBM, so the key is accepted and has no effect.
         if unsupported or m.NORM != "layernorm" or m.MODE != "conv":
             raise NotImplementedError(f"MViT options outside the built video path: {unsupported}")
         self.cfg = cfg
@@ -241,7 +254,7 @@ class MViT(nn.Module):
         self.W = cfg.DATA.TRAIN_CROP_SIZE // self.patch_stride[2]
         embed_dim, num_heads, depth = m.EMBED_DIM, m.NUM_HEADS, m.DEPTH
         self.drop_rate = m.DROPOUT_RATE
-        self.cls_embed_on, self.use_mean_pooling = True, m.USE_MEAN_POOLING
+        self.cls_embed_on, self.use_mean_pooling = bool(m.CLS_EMBED_ON), m.USE_MEAN_POOLING
         self.use_abs_pos, self.sep_pos_embed = m.USE_ABS_POS, m.SEP_POS_EMBED
         self.rel_pos_spatial, self.rel_pos_temporal = m.REL_POS_SPATIAL, m.REL_POS_TEMPORAL
         norm_layer = partial(nn.LayerNorm, eps=1e-6)
@@ -251,14 +264,16 @@ class MViT(nn.Module):
         self.input_dims = [cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE, cfg.DATA.TRAIN_CROP_SIZE]
         self.patch_dims = [self.input_dims[i] // self.patch_stride[i] for i in range(3)]
         dpr = [x.item() for x in torch.linspace(0, m.DROPPATH_RATE, depth)]
-        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        if self.cls_embed_on:
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         if self.use_abs_pos:                       # video_model_builder.py:888-911
             if self.sep_pos_embed:
                 self.pos_embed_spatial = nn.Parameter(torch.zeros(1, self.patch_dims[1] * self.patch_dims[2], embed_dim))
                 self.pos_embed_temporal = nn.Parameter(torch.zeros(1, self.patch_dims[0], embed_dim))
-                self.pos_embed_class = nn.Parameter(torch.zeros(1, 1, embed_dim))
+                if self.cls_embed_on:
+                    self.pos_embed_class = nn.Parameter(torch.zeros(1, 1, embed_dim))
             else:
-                self.pos_embed = nn.Parameter(torch.zeros(1, math.prod(self.patch_dims) + 1, embed_dim))
+                self.pos_embed = nn.Parameter(torch.zeros(1, math.prod(self.patch_dims) + int(self.cls_embed_on), embed_dim))
         dim_mul, head_mul = torch.ones(depth + 1), torch.ones(depth + 1)
         for i, v in m.DIM_MUL:
             dim_mul[i] = v
@@ -297,9 +312,9 @@ class MViT(nn.Module):
                 dim=embed_dim, dim_out=dim_out, num_heads=num_heads, input_size=input_size, mlp_ratio=m.MLP_RATIO,
                 qkv_bias=m.QKV_BIAS, drop_rate=self.drop_rate, drop_path=dpr[i], norm_layer=norm_layer,
                 kernel_q=pool_q[i], kernel_kv=pool_kv[i], stride_q=stride_q[i], stride_kv=stride_kv[i], mode=m.MODE,
-                has_cls_embed=True, pool_first=False, rel_pos_spatial=self.rel_pos_spatial,
+                has_cls_embed=self.cls_embed_on, pool_first=m.POOL_FIRST, rel_pos_spatial=self.rel_pos_spatial,
                 rel_pos_temporal=self.rel_pos_temporal, rel_pos_zero_init=m.REL_POS_ZERO_INIT,
-                residual_pooling=m.RESIDUAL_POOLING, dim_mul_in_att=m.DIM_MUL_IN_ATT, separate_qkv=False))
+                residual_pooling=m.RESIDUAL_POOLING, dim_mul_in_att=m.DIM_MUL_IN_ATT, separate_qkv=m.SEPARATE_QKV))
             if len(stride_q[i]) > 0:
                 input_size = [size // stride for size, stride in zip(input_size, stride_q[i])]
             embed_dim = dim_out
@@ -311,10 +326,12 @@ class MViT(nn.Module):
             if self.sep_pos_embed:
                 trunc_normal_(self.pos_embed_spatial, std=0.02)
                 trunc_normal_(self.pos_embed_temporal, std=0.02)
-                trunc_normal_(self.pos_embed_class, std=0.02)
+                if self.cls_embed_on:
+                    trunc_normal_(self.pos_embed_class, std=0.02)
             else:
                 trunc_normal_(self.pos_embed, std=0.02)
-        trunc_normal_(self.cls_token, std=0.02)
+        if self.cls_embed_on:
+            trunc_normal_(self.cls_token, std=0.02)
         self.apply(self._init_weights)
         self.head.projection.weight.data.mul_(m.HEAD_INIT_SCALE)
         self.head.projection.bias.data.mul_(m.HEAD_INIT_SCALE)
@@ -339,7 +356,8 @@ class MViT(nn.Module):
                 names += ["rel_pos_h", "rel_pos_w", "rel_pos_hw"]
             if self.rel_pos_temporal:
                 names += ["rel_pos_t"]
-            names += ["cls_token"]
+            if self.cls_embed_on:
+                names += ["cls_token"]
         return names
 
     def forward(self, x, bboxes=None, return_attn=False):
@@ -348,14 +366,17 @@ class MViT(nn.Module):
             if self.sep_pos_embed:
                 pos = self.pos_embed_spatial.repeat(1, self.patch_dims[0], 1) + torch.repeat_interleave(
                     self.pos_embed_temporal, self.patch_dims[1] * self.patch_dims[2], dim=1)
-                pos = torch.cat([self.pos_embed_class, pos], 1)
+                if self.cls_embed_on:
+                    pos = torch.cat([self.pos_embed_class, pos], 1)
             else:
                 pos = self.pos_embed
-        x, bcthw = self.patch_embed(x[0], self.cls_token, pos)
+        x, bcthw = self.patch_embed(x[0], self.cls_token if self.cls_embed_on else None, pos)
         T, H, W = bcthw[-3], bcthw[-2], bcthw[-1]
         assert (T, H, W) == (self.T, self.H, self.W), bcthw
         thw = [T, H, W]
         for blk in self.blocks:
             x, thw = blk(x, thw)
-        x = ClsNormFn.apply(x, self, self.use_mean_pooling, self.norm.weight, self.norm.bias)
+        # video_model_builder.py:1226-1238: mean of the patch tokens then norm / norm of the cls rows / norm then mean
+        mode = "mean_norm" if self.use_mean_pooling else ("cls" if self.cls_embed_on else "norm_mean")
+        x = ClsNormFn.apply(x, self, mode, self.cls_embed_on, self.norm.weight, self.norm.bias)
         return self.head(x)

@@ -77,6 +77,48 @@ class LinearUnit:
         return [p for p in (self.lin.weight, self.lin.bias) if p is not None]
 
 
+class QKVUnit:
+    """SEPARATE_QKV (attention.py:188-191, 310-314): three nn.Linear layers of the same input, run as ONE GEMM against
+    the row-concatenated fp16 operand [3*att, dim] (the same arithmetic as the fused ``qkv`` Linear); the weight / bias
+    gradients go to the three parameters from channel slices of d(qkv), the data gradient is again one GEMM."""
+
+    def __init__(self, q, k, v):
+        self.lins = (q, k, v)
+        self._key, self._w, self._wt = None, None, None
+
+    def _ops(self, fresh=False):
+        key = tuple((lin.weight.data_ptr(), lin.weight._version, lin.weight.device) for lin in self.lins)
+        if (fresh and engine.FORCE_WEIGHT_PREP) or self._key != key:
+            w = torch.cat([lin.weight.detach() for lin in self.lins], 0)
+            self._w = w.to(_f16)                       # [3*att, dim]  forward operand
+            self._wt = w.t().contiguous().to(_f16)     # [dim, 3*att]  data-gradient operand
+            self._key = key
+        return self._w, self._wt
+
+    def forward(self, x):
+        w, _ = self._ops(fresh=True)
+        bias = None
+        if self.lins[0].bias is not None:
+            bias = torch.cat([lin.bias.detach() for lin in self.lins])
+        return tokens.gemm(x, w, bias=bias)
+
+    def backward(self, x, dqkv):
+        C = self.lins[0].out_features
+        for i, lin in enumerate(self.lins):
+            dy = dqkv[..., i * C:(i + 1) * C]
+            if lin.weight.requires_grad:
+                dw, zero_first = _grad_dest(lin.weight)
+                tokens.linear_wgrad(x, dy, dw, zero_first=zero_first)
+            if lin.bias is not None and lin.bias.requires_grad:
+                db, zero_first = _grad_dest(lin.bias)
+                tokens.bias_grad(dy, db, accumulate=not zero_first)
+        _, wt = self._ops()
+        return tokens.gemm(dqkv, wt)
+
+    def params(self):
+        return [p for lin in self.lins for p in (lin.weight, lin.bias) if p is not None]
+
+
 class NormUnit:
     """nn.LayerNorm parameter container bound to the LayerNorm kernels."""
 
@@ -115,16 +157,20 @@ class AttentionPlan:
         self.D = self.att // self.heads
         cls = att.has_cls_embed
         self.cls = int(cls)
-        C = self.att
+        # POOL_FIRST pools the block input (dim channels = heads x dim / heads) before the q / k / v Linears
+        # (attention.py:236-241); otherwise the pooling acts on the projected q / k / v (att channels)
+        self.dim_in = att.dim_in
+        C = self.dim_in if att.pool_first else self.att
+        Cw = C // self.heads
         # blocks without a q (k / v) pooling conv leave that tensor as the qkv projection produced it
         # (attention.py:199-203, 236-262: MViTv1 blocks outside POOL_Q_STRIDE, plain ViT blocks)
         self.gq = self.gk = None
         if att.pool_q is not None:
             kq, sq, pq = tuple(att.pool_q.kernel_size), tuple(att.pool_q.stride), tuple(att.pool_q.padding)
-            self.gq = tokens.DwGeom(B, C, self.D, thw, kq, sq, pq, cls)
+            self.gq = tokens.DwGeom(B, C, Cw, thw, kq, sq, pq, cls)
         if att.pool_k is not None:
             kk, sk, pk = tuple(att.pool_k.kernel_size), tuple(att.pool_k.stride), tuple(att.pool_k.padding)
-            self.gk = tokens.DwGeom(B, C, self.D, thw, kk, sk, pk, cls)
+            self.gk = tokens.DwGeom(B, C, Cw, thw, kk, sk, pk, cls)
         self.q_thw = self.gq.out_thw if self.gq is not None else tuple(thw)
         self.k_thw = self.gk.out_thw if self.gk is not None else tuple(thw)
         self.Nq = self.cls + math.prod(self.q_thw)
@@ -161,27 +207,11 @@ def _fused_attention(plan):
     return plan.D % 32 == 0 and plan.D <= 128 and (not plan.rel or kt + kh + kw <= 48)
 
 
-def attention_forward(att, plan, qkv):
-    """qkv [B, N, 3*att] -> (o [B, Nq, att], saved tensors).  attention.py:318-385."""
+def _core_forward(att, plan, qn, kn, vn):
+    """softmax(q*scale k^T + rel-pos bias) v (+ q on the non-cls rows: residual pooling), attention.py:355-385.
+    qn / kn / vn: [B, N*, att] token tensors of any row pitch -> (o [B, Nq, att], saved tensors of the core)."""
     B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
     Nq, Nk, lds = plan.Nq, plan.Nk, plan.lds
-    q_in, k_in, v_in = qkv[..., 0:C], qkv[..., C:2 * C], qkv[..., 2 * C:3 * C]
-    qp = kp = vp = None
-    mq = rq_ = mk = rk_ = mv = rv_ = None
-    if plan.gq is not None:
-        qp = tokens.dwconv_fwd(q_in, att.pool_q.weight, plan.gq).view(B, Nq, C)
-        qn, mq, rq_ = att._norm_q.forward(qp.view(B * Nq * heads, D))
-        qn = qn.view(B, Nq, C)
-    else:
-        qn = q_in                                   # channel slice of qkv (row pitch 3C): used in place
-    if plan.gk is not None:
-        kp = tokens.dwconv_fwd(k_in, att.pool_k.weight, plan.gk).view(B, Nk, C)
-        vp = tokens.dwconv_fwd(v_in, att.pool_v.weight, plan.gk).view(B, Nk, C)
-        kn, mk, rk_ = att._norm_k.forward(kp.view(B * Nk * heads, D))
-        vn, mv, rv_ = att._norm_v.forward(vp.view(B * Nk * heads, D))
-        kn, vn = kn.view(B, Nk, C), vn.view(B, Nk, C)
-    else:
-        kn, vn = k_in, v_in
     tables = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t) if plan.rel else None
     t16 = t16t = None
     if plan.rel:
@@ -189,76 +219,104 @@ def attention_forward(att, plan, qkv):
     rq = tokens.relpos_fwd(plan.desc, qn, tables, plan.idx, t16=t16) if plan.rel else None
     if _fused_attention(plan):
         if plan.rel and plan.onehot is None:
-            plan.onehot = tokens.attn_onehot(plan.desc, qkv.device)
+            plan.onehot = tokens.attn_onehot(plan.desc, qn.device)
         o, lse = tokens.attn_fwd(plan.desc, qn, kn, vn, att.scale, rq, att.residual_pooling, onehot=plan.onehot)
-        saved = dict(qp=qp, kp=kp, vp=vp, qn=qn, kn=kn, vn=vn, sq=(mq, rq_), sk=(mk, rk_), sv=(mv, rv_), t16t=t16t,
-                     fused=(o, lse, rq))
-        return o, saved
-    if plan.gq is None or plan.gk is None:
+        return o, dict(qn=qn, kn=kn, vn=vn, t16t=t16t, fused=(o, lse, rq))
+    if rows_not_dense(qn) or rows_not_dense(kn) or rows_not_dense(vn):
         # the unfused chain (A/B runs, head dims the fused kernels do not cover) addresses contiguous operands
         qn, kn, vn = qn.contiguous(), kn.contiguous(), vn.contiguous()
-    S = torch.empty((B, heads, Nq, lds), dtype=_f16, device=qkv.device)
+    S = torch.empty((B, heads, Nq, lds), dtype=_f16, device=qn.device)
     tokens.bgemm_heads(qn, (Nq * C, D), Nq, D, C, kn, (Nk * C, D), Nk, C, S, (heads * Nq * lds, Nq * lds), lds, B, heads)
     P = tokens.softmax_fwd(plan.desc, S, att.scale, rq)
     vt = tokens.transpose_heads(vn, B, Nk, heads, D, lds)
-    o = torch.empty((B, Nq, C), dtype=_f16, device=qkv.device)
+    o = torch.empty((B, Nq, C), dtype=_f16, device=qn.device)
     resid = qn if att.residual_pooling else None
     tokens.bgemm_heads(P, (heads * Nq * lds, Nq * lds), Nq, lds, lds, vt, (heads * D * lds, D * lds), D, lds,
                        o, (Nq * C, D), C, B, heads, resid=resid, r_strides=(Nq * C, D), ldr=C, resid_row0=plan.cls)
-    saved = dict(qp=qp, kp=kp, vp=vp, qn=qn, kn=kn, vn=vn, sq=(mq, rq_), sk=(mk, rk_), sv=(mv, rv_), P=P, t16t=t16t)
-    return o, saved
+    return o, dict(qn=qn, kn=kn, vn=vn, P=P, t16t=t16t)
 
 
-def attention_backward(att, plan, qkv, sv, do):
-    """d(o) -> d(qkv) [B, N, 3*att]; writes the gradients of pool_{q,k,v}, norm_{q,k,v}, rel_pos_{h,w,t}."""
+def rows_not_dense(x):
+    return x.stride(-2) != x.shape[-1]
+
+
+def _core_backward(att, plan, core, do, dq_out=None, dkv_out=None):
+    """d(o) -> (dq, dk, dv) of the attention core, each [B, N*, att]; writes the gradients of rel_pos_{h,w,t} and adds
+    their term to dq.  dq_out / dkv_out: destinations the fused kernels may write in place (slices of d(qkv))."""
     B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
     Nq, Nk, lds = plan.Nq, plan.Nk, plan.lds
-    qn, kn, vn = sv["qn"], sv["kn"], sv["vn"]
+    qn, kn, vn = core["qn"], core["kn"], core["vn"]
     dev = do.device
-    if "fused" in sv:
-        o, lse, rq = sv["fused"]
-        dqkv = torch.empty(qkv.shape, dtype=_f16, device=dev)
-        # gradients of un-pooled q / k / v ARE slices of d(qkv): the kernels write them in place (row pitch 3C)
-        dq_out = dqkv[..., 0:C] if plan.gq is None and not plan.rel else None
-        dkv_out = (dqkv[..., C:2 * C], dqkv[..., 2 * C:3 * C]) if plan.gk is None else None
+    if "fused" in core:
+        o, lse, rq = core["fused"]
         dqn, dkn, dvn, drq = tokens.attn_bwd(plan.desc, qn, kn, vn, att.scale, rq, att.residual_pooling, o, do, lse,
                                              onehot=plan.onehot, dq_out=dq_out, dkv_out=dkv_out)
-        return _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq, dqkv)
-    P = sv["P"]
-    if plan.gq is None or plan.gk is None:
-        qn, kn, vn = qn.contiguous(), kn.contiguous(), vn.contiguous()
-    # dP = dO V^T ; dV = P^T dO
-    dP = torch.empty((B, heads, Nq, lds), dtype=_f16, device=dev)
-    tokens.bgemm_heads(do, (Nq * C, D), Nq, D, C, vn, (Nk * C, D), Nk, C, dP, (heads * Nq * lds, Nq * lds), lds, B, heads)
-    dvn = torch.empty((B, Nk, C), dtype=_f16, device=dev)
-    tokens.bgemm_tn_heads(P, (heads * Nq * lds, Nq * lds), lds, do, (Nq * C, D), C, Nq, Nk, D, dvn, (Nk * C, D), C,
-                          B, heads)
-    dS, drq = tokens.softmax_bwd(plan.desc, dP, P, att.scale, want_drq=plan.rel)      # dS already carries `scale`
-    # dQ = dS K (+ dO on the non-cls rows: residual pooling) ; dK = dS^T Q
-    kt = tokens.transpose_heads(kn, B, Nk, heads, D, lds)
-    dqn = torch.empty((B, Nq, C), dtype=_f16, device=dev)
-    resid = do if att.residual_pooling else None
-    tokens.bgemm_heads(dS, (heads * Nq * lds, Nq * lds), Nq, lds, lds, kt, (heads * D * lds, D * lds), D, lds,
-                       dqn, (Nq * C, D), C, B, heads, resid=resid, r_strides=(Nq * C, D), ldr=C, resid_row0=plan.cls)
-    dkn = torch.empty((B, Nk, C), dtype=_f16, device=dev)
-    tokens.bgemm_tn_heads(dS, (heads * Nq * lds, Nq * lds), lds, qn, (Nq * C, D), C, Nq, Nk, D, dkn, (Nk * C, D), C,
-                          B, heads)
-    return _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq)
-
-
-def _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq, dqkv=None):
-    """rel-pos table gradients (+ their dq term), LayerNorm(head_dim) and depthwise pooling backward.  Tensors that were
-    not pooled skip both: their gradient is (or is copied into) the matching slice of d(qkv)."""
-    B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
-    Nq, Nk = plan.Nq, plan.Nk
-    dev = dqn.device
+    else:
+        P = core["P"]
+        # dP = dO V^T ; dV = P^T dO
+        dP = torch.empty((B, heads, Nq, lds), dtype=_f16, device=dev)
+        tokens.bgemm_heads(do, (Nq * C, D), Nq, D, C, vn, (Nk * C, D), Nk, C, dP, (heads * Nq * lds, Nq * lds), lds, B, heads)
+        dvn = torch.empty((B, Nk, C), dtype=_f16, device=dev)
+        tokens.bgemm_tn_heads(P, (heads * Nq * lds, Nq * lds), lds, do, (Nq * C, D), C, Nq, Nk, D, dvn, (Nk * C, D), C,
+                              B, heads)
+        dS, drq = tokens.softmax_bwd(plan.desc, dP, P, att.scale, want_drq=plan.rel)      # dS already carries `scale`
+        # dQ = dS K (+ dO on the non-cls rows: residual pooling) ; dK = dS^T Q
+        kt = tokens.transpose_heads(kn, B, Nk, heads, D, lds)
+        dqn = torch.empty((B, Nq, C), dtype=_f16, device=dev)
+        resid = do if att.residual_pooling else None
+        tokens.bgemm_heads(dS, (heads * Nq * lds, Nq * lds), Nq, lds, lds, kt, (heads * D * lds, D * lds), D, lds,
+                           dqn, (Nq * C, D), C, B, heads, resid=resid, r_strides=(Nq * C, D), ldr=C, resid_row0=plan.cls)
+        dkn = torch.empty((B, Nk, C), dtype=_f16, device=dev)
+        tokens.bgemm_tn_heads(dS, (heads * Nq * lds, Nq * lds), lds, qn, (Nq * C, D), C, Nq, Nk, D, dkn, (Nk * C, D), C,
+                              B, heads)
     if plan.rel:
         tabs = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t)
         dests = [_grad_dest(t) for t in tabs]
         tokens.relpos_bwd(plan.desc, qn, tabs, plan.idx, drq, dqn, [d[0] for d in dests], [not d[1] for d in dests],
-                          t16t=sv["t16t"])
-    if dqkv is None:
-        dqkv = torch.empty(qkv.shape, dtype=_f16, device=dev)
+                          t16t=core["t16t"])
+    return dqn, dkn, dvn
+
+
+def _pool_norm(x_in, pool, norm_unit, geom, B, N, C, D):
+    """attention_pool (attention.py:13-45): depthwise conv over the non-cls tokens, LayerNorm over the head channels."""
+    xp = tokens.dwconv_fwd(x_in, pool.weight, geom).view(B, N, C)
+    xn, m, r = norm_unit.forward(xp.view(-1, D))
+    return xp, xn.view(B, N, C), (m, r)
+
+
+def attention_forward(att, plan, qkv):
+    """qkv [B, N, 3*att] -> (o [B, Nq, att], saved tensors).  attention.py:318-385."""
+    B, D, C = plan.B, plan.D, plan.att
+    Nq, Nk = plan.Nq, plan.Nk
+    q_in, k_in, v_in = qkv[..., 0:C], qkv[..., C:2 * C], qkv[..., 2 * C:3 * C]
+    qp = kp = vp = sq = sk = sv_ = None
+    if plan.gq is not None:
+        qp, qn, sq = _pool_norm(q_in, att.pool_q, att._norm_q, plan.gq, B, Nq, C, D)
+    else:
+        qn = q_in                                   # channel slice of qkv (row pitch 3C): used in place
+    if plan.gk is not None:
+        kp, kn, sk = _pool_norm(k_in, att.pool_k, att._norm_k, plan.gk, B, Nk, C, D)
+        vp, vn, sv_ = _pool_norm(v_in, att.pool_v, att._norm_v, plan.gk, B, Nk, C, D)
+    else:
+        kn, vn = k_in, v_in
+    o, core = _core_forward(att, plan, qn, kn, vn)
+    return o, dict(qp=qp, kp=kp, vp=vp, sq=sq, sk=sk, sv=sv_, core=core)
+
+
+def attention_backward(att, plan, qkv, sv, do):
+    """d(o) -> d(qkv) [B, N, 3*att]; writes the gradients of pool_{q,k,v}, norm_{q,k,v}, rel_pos_{h,w,t}."""
+    B, D, C = plan.B, plan.D, plan.att
+    Nq, Nk = plan.Nq, plan.Nk
+    core = sv["core"]
+    dqkv = torch.empty(qkv.shape, dtype=_f16, device=do.device)
+    dq_out = dkv_out = None
+    if "fused" in core:
+        # gradients of un-pooled q / k / v ARE slices of d(qkv): the kernels write them in place (row pitch 3C)
+        dq_out = dqkv[..., 0:C] if plan.gq is None and not plan.rel else None
+        dkv_out = (dqkv[..., C:2 * C], dqkv[..., 2 * C:3 * C]) if plan.gk is None else None
+    dqn, dkn, dvn = _core_backward(att, plan, core, do, dq_out=dq_out, dkv_out=dkv_out)
+    # LayerNorm(head_dim) and depthwise pooling backward.  Tensors that were not pooled skip both: their gradient is
+    # (or is copied into) the matching slice of d(qkv).
     work = []
     if plan.gq is not None:                                  # LayerNorm(head_dim) backward, then the pooling conv
         dqp = att._norm_q.backward(dqn.view(-1, D), sv["qp"].view(-1, D), *sv["sq"]).view(B, Nq, C)
@@ -281,6 +339,48 @@ def _attention_backward_tail(att, plan, qkv, sv, qn, dqn, dkn, dvn, drq, dqkv=No
     return dqkv
 
 
+def attention_forward_pool_first(att, plan, xn):
+    """POOL_FIRST (attention.py:296-301, 318-351): the normed block input xn [B, N, dim], read as heads x (dim / heads)
+    channels, is pooled (+ LayerNorm over dim / heads) three times, and the q / k / v Linears run on the POOLED tokens
+    (fewer GEMM rows for k / v).  -> (o [B, Nq, att], saved tensors)."""
+    B, Ci = plan.B, plan.dim_in
+    Dc = Ci // plan.heads
+    Nq, Nk = plan.Nq, plan.Nk
+    qp = kp = vp = sq = sk = sv_ = None
+    xq = xk = xv = xn
+    if plan.gq is not None:
+        qp, xq, sq = _pool_norm(xn, att.pool_q, att._norm_q, plan.gq, B, Nq, Ci, Dc)
+    if plan.gk is not None:
+        kp, xk, sk = _pool_norm(xn, att.pool_k, att._norm_k, plan.gk, B, Nk, Ci, Dc)
+        vp, xv, sv_ = _pool_norm(xn, att.pool_v, att._norm_v, plan.gk, B, Nk, Ci, Dc)
+    qn, kn, vn = att._q.forward(xq), att._k.forward(xk), att._v.forward(xv)
+    o, core = _core_forward(att, plan, qn, kn, vn)
+    return o, dict(qp=qp, kp=kp, vp=vp, sq=sq, sk=sk, sv=sv_, xq=xq, xk=xk, xv=xv, core=core)
+
+
+def attention_backward_pool_first(att, plan, xn, sv, do):
+    """d(o) -> d(xn) [B, N, dim] of the POOL_FIRST attention: core, q / k / v Linears, LayerNorm(dim / heads), pooling
+    convs; the three branches' input gradients are summed."""
+    B, Ci = plan.B, plan.dim_in
+    Dc = Ci // plan.heads
+    dqn, dkn, dvn = _core_backward(att, plan, sv["core"], do)
+    dxn = None
+    for name, dy, unit, pool, norm, geom, N in (
+            ("q", dqn, att._q, att.pool_q, att._norm_q, plan.gq, plan.Nq),
+            ("k", dkn, att._k, att.pool_k, att._norm_k, plan.gk, plan.Nk),
+            ("v", dvn, att._v, att.pool_v, att._norm_v, plan.gk, plan.Nk)):
+        if geom is None:                                     # Linear on xn itself: chain the sum through the GEMM residual
+            dxn = unit.backward(xn, dy, resid=dxn)
+            continue
+        dxp = unit.backward(sv["x" + name], dy)
+        dpool = norm.backward(dxp.view(-1, Dc), sv[name + "p"].view(-1, Dc), *sv["s" + name]).view(B, N, Ci)
+        g = tokens.dwconv_dgrad(dpool.view(-1, Ci), pool.weight, geom).view(xn.shape)
+        dw, zero_first = _grad_dest(pool.weight)
+        tokens.dwconv_wgrad(xn, dpool.view(-1, Ci), geom, dw, zero_first=zero_first)
+        dxn = g if dxn is None else dxn.add_(g)
+    return dxn
+
+
 class MultiScaleBlockFn(torch.autograd.Function):
     """MultiScaleBlock.forward (attention.py:491-514): conv pooling (or none), cls token, dimension change before the
     attention residual (DIM_MUL_IN_ATT, MViTv2) or after the Mlp (MViTv1)."""
@@ -291,8 +391,12 @@ class MultiScaleBlockFn(torch.autograd.Function):
         B, N, dim = x.shape
         plan = mod._plan(B, thw, x.device)
         xn, m1, r1 = mod._norm1.forward(x)
-        qkv = att._qkv.forward(xn)
-        o, sv = attention_forward(att, plan, qkv)
+        if att.pool_first:
+            qkv = None
+            o, sv = attention_forward_pool_first(att, plan, xn)
+        else:
+            qkv = att._qkv.forward(xn)
+            o, sv = attention_forward(att, plan, qkv)
         proj_first = mod._proj is not None and mod.dim_mul_in_att
         proj_last = mod._proj is not None and not mod.dim_mul_in_att
         if proj_first:
@@ -351,8 +455,11 @@ class MultiScaleBlockFn(torch.autograd.Function):
             dx1 = mod._norm2.backward(dxn2, sv["x1"], *sv["s2"], resid=dout)
         # attention output projection, attention core, qkv projection
         do = att._proj.backward(sv["o"], dx1 if drop is None else tokens.row_scale_add(dx1, drop[0], dx1.shape[1]))
-        dqkv = attention_backward(att, plan, sv["qkv"], sv["att"], do)
-        dxn = att._qkv.backward(sv["xn"], dqkv)
+        if att.pool_first:
+            dxn = attention_backward_pool_first(att, plan, sv["xn"], sv["att"], do)
+        else:
+            dqkv = attention_backward(att, plan, sv["qkv"], sv["att"], do)
+            dxn = att._qkv.backward(sv["xn"], dqkv)
         # skip path
         dxs = dx1
         if sv["pool"] is not None:
@@ -422,30 +529,40 @@ class PatchEmbedFn(torch.autograd.Function):
 
 
 class ClsNormFn(torch.autograd.Function):
-    """Final LayerNorm on what the head consumes (video_model_builder.py:1226-1238): the cls rows
-    (norm(x)[:, 0] == norm(x[:, 0])), or with USE_MEAN_POOLING the mean of the patch tokens (mean first, then norm)."""
+    """Final LayerNorm on what the head consumes (video_model_builder.py:1226-1238).  mode "cls": the cls rows
+    (norm(x)[:, 0] == norm(x[:, 0])); "mean_norm" (USE_MEAN_POOLING): the mean of the patch tokens, then norm;
+    "norm_mean" (no cls token, the reference's default there): norm of every token, then the mean over tokens."""
 
     @staticmethod
-    def forward(ctx, x, mod, mean_pool, *params):
+    def forward(ctx, x, mod, mode, has_cls, *params):
         unit = mod._norm_unit
-        if mean_pool:
-            xc = x[:, 1:].float().mean(1).to(_f16)
+        s = int(bool(has_cls))
+        if mode == "norm_mean":
+            B, N, C = x.shape
+            xc = x
+            yt, m, r = unit.forward(x.view(B * N, C))
+            y = yt.view(B, N, C).float().mean(1).to(_f16)
         else:
-            xc = x[:, 0].contiguous()
-        y, m, r = unit.forward(xc)
-        ctx.unit, ctx.xc, ctx.st, ctx.shape, ctx.mean_pool = unit, xc, (m, r), tuple(x.shape), mean_pool
+            xc = x[:, s:].float().mean(1).to(_f16) if mode == "mean_norm" else x[:, 0].contiguous()
+            y, m, r = unit.forward(xc)
+        ctx.unit, ctx.xc, ctx.st, ctx.shape, ctx.mode, ctx.s = unit, xc, (m, r), tuple(x.shape), mode, s
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        dxc = ctx.unit.backward(dy.to(_f16).contiguous(), ctx.xc, *ctx.st)
-        if ctx.mean_pool:
-            B, N, C = ctx.shape
-            dx = torch.empty(ctx.shape, dtype=_f16, device=dy.device)
-            dx[:, 0] = 0
-            dx[:, 1:] = (dxc.float() / (N - 1)).to(_f16)[:, None, :]
+        B, N, C = ctx.shape
+        s = ctx.s
+        if ctx.mode == "norm_mean":
+            dyt = (dy.float() / N).to(_f16)[:, None, :].expand(B, N, C).contiguous()
+            dx = ctx.unit.backward(dyt.view(B * N, C), ctx.xc.view(B * N, C), *ctx.st).view(B, N, C)
         else:
-            dx = torch.zeros(ctx.shape, dtype=_f16, device=dy.device)
-            dx[:, 0] = dxc
+            dxc = ctx.unit.backward(dy.to(_f16).contiguous(), ctx.xc, *ctx.st)
+            if ctx.mode == "mean_norm":
+                dx = torch.empty(ctx.shape, dtype=_f16, device=dy.device)
+                dx[:, :s] = 0
+                dx[:, s:] = (dxc.float() / (N - s)).to(_f16)[:, None, :]
+            else:
+                dx = torch.zeros(ctx.shape, dtype=_f16, device=dy.device)
+                dx[:, 0] = dxc
         _notify(ctx.unit.params())
-        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)

@@ -117,6 +117,21 @@ def test_mvit_v1_and_vit_match_reference(sim, name):
         print(rep)
 
 
+@pytest.mark.parametrize("name", ["mvit_nocls_sepqkv_tiny", "mvit_poolfirst_tiny"])
+@pytest.mark.parametrize("fused_attn", ["1", "0"])
+def test_mvit_attention_options_match_reference(sim, name, fused_attn, monkeypatch):
+    """MultiScaleAttention options vs the unmodified reference: no cls token (CLS_EMBED_ON False: pooling, relative
+    positions, residual pooling and the skip max-pool over all rows; norm -> mean feeds the head), separate q / k / v
+    Linears (SEPARATE_QKV: one GEMM against the concatenated operand) and POOL_FIRST (pooling convs of dim / heads
+    channels on the block input, q / k / v Linears on the pooled tokens), fused and unfused attention core."""
+    monkeypatch.setenv("SF_ATTN_FUSED", fused_attn)
+    rep = {}
+    try:
+        mc.check_engine(name, sim, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.2, tol_global=1e-2, report=rep)
+    finally:
+        print(rep)
+
+
 def test_x3d_sub_batchnorm_backbone_with_full_batch_head(sim):
     """X3D with BN.NORM_TYPE sub_batchnorm: the reference builds the backbone with SubBatchNorm3d but leaves the head's
     conv_5_bn a plain BatchNorm3d over the whole batch; the engine runs the backbone in sub-batch passes and the head once

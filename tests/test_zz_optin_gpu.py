@@ -1,5 +1,6 @@
-"""GPU (-m gpu), opt-in code paths: kept in a file that sorts last, so that with ``pytest -x`` a failure of code that is not
-on the default path cannot hide the results of the default-path tests."""
+"""GPU (-m gpu), opt-in code paths and option families written after the round's GPU budget ended (green on the host
+simulator, not yet run on hardware): kept in a file that sorts last, so that with ``pytest -x`` a failure here cannot hide
+the results of the default-path tests."""
 import os
 import subprocess
 import sys
@@ -27,3 +28,16 @@ def test_depthwise_version2_kernels_gpu(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ["mvit_nocls_sepqkv_tiny", "mvit_poolfirst_tiny"])
+@pytest.mark.parametrize("fused_attn", ["1", "0"])
+def test_mvit_attention_options_match_reference_gpu(gpu, name, fused_attn, monkeypatch):
+    """CLS_EMBED_ON False + SEPARATE_QKV, and POOL_FIRST, vs the reference's outputs (tests/golden)."""
+    from tests import model_checks as mc
+    monkeypatch.setenv("SF_ATTN_FUSED", fused_attn)
+    rep = {}
+    try:
+        mc.check_engine(name, gpu, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.2, tol_global=1e-2, report=rep)
+    finally:
+        print(name, fused_attn, rep)
