@@ -114,6 +114,14 @@ CASES = {
                    "MVIT.POOL_Q_STRIDE", "[[0, 1, 1, 1], [1, 1, 2, 2], [2, 1, 1, 1], [3, 1, 2, 2]]",
                    "MVIT.POOL_KV_STRIDE_ADAPTIVE", "[1, 4, 4]", "MIXUP.ENABLE", False,
                    "MVIT.CLS_EMBED_ON", False, "MVIT.SEPARATE_QKV", True], 2),
+    # odd pooled extents (72^2 crop: 18 -> 9 -> 5 tokens per side): block 3's relative-position tables are constructed with
+    # 2*4-1 rows (9 // 2) but used at 2*5-1 -> get_rel_pos interpolation (attention.py:48-61), as in MViTv2-L 40x3 at 312^2
+    "mvit_relinterp_tiny": ("configs/Kinetics/MVITv2_S_16x4.yaml",
+                  ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "MODEL.NUM_CLASSES", 10,
+                   "DATA.TRAIN_CROP_SIZE", 72, "DATA.TEST_CROP_SIZE", 72, "DATA.NUM_FRAMES", 8, "MVIT.DEPTH", 4,
+                   "MVIT.EMBED_DIM", 32, "MVIT.DIM_MUL", "[[1, 2.0], [3, 2.0]]", "MVIT.HEAD_MUL", "[[1, 2.0], [3, 2.0]]",
+                   "MVIT.POOL_Q_STRIDE", "[[0, 1, 1, 1], [1, 1, 2, 2], [2, 1, 2, 2], [3, 1, 1, 1]]",
+                   "MVIT.POOL_KV_STRIDE_ADAPTIVE", "[1, 4, 4]", "MIXUP.ENABLE", False], 2),
     # POOL_FIRST (attention.py:296-301, 339-351): the normed block input is folded into heads and pooled before the
     # q / k / v Linears; MViTv1 layout (the family POOL_FIRST was introduced with), cls token on
     "mvit_poolfirst_tiny": ("configs/Kinetics/MVIT_B_16x4_CONV.yaml",

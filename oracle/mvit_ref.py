@@ -65,9 +65,20 @@ def rel_pos_index(q_size, k_size):
     return dist.long()
 
 
+def get_rel_pos(rel_pos, d):
+    """get_rel_pos (attention.py:48-61): a table whose row count differs from 2*max(q,k)-1 is resampled along its rows
+    with F.interpolate(mode="linear").  (Happens when a pooled extent is odd: the constructor sizes the tables with
+    size // stride, the pooling convs produce ceil(size / stride), e.g. MViTv2-L at 312^2: 39 -> 20, not 19.)"""
+    ori_d = rel_pos.shape[0]
+    if ori_d == d:
+        return rel_pos
+    new = F.interpolate(rel_pos.reshape(1, ori_d, -1).permute(0, 2, 1), size=d, mode="linear")
+    return new.reshape(-1, d).permute(1, 0)
+
+
 def _rel_pos_bias(attn, q, has_cls, q_shape, k_shape, rel_h, rel_w, rel_t):
-    """cal_rel_pos_spatial + cal_rel_pos_temporal (attention.py:64-147); tables are used at their native size
-    (no interpolation: 2*max(q,k)-1 rows, as constructed at attention.py:271-287)."""
+    """cal_rel_pos_spatial + cal_rel_pos_temporal (attention.py:64-147); tables constructed with 2*max(q,k)-1 rows
+    (attention.py:271-287) are used as they are, others go through get_rel_pos."""
     sp = 1 if has_cls else 0
     q_t, q_h, q_w = q_shape
     k_t, k_h, k_w = k_shape
@@ -75,15 +86,13 @@ def _rel_pos_bias(attn, q, has_cls, q_shape, k_shape, rel_h, rel_w, rel_t):
     r_q = q[:, :, sp:].reshape(B, nh, q_t, q_h, q_w, dim)
     out = attn[:, :, sp:, sp:].reshape(B, nh, q_t, q_h, q_w, k_t, k_h, k_w)
     if rel_h is not None:
-        assert rel_h.shape[0] == 2 * max(q_h, k_h) - 1 and rel_w.shape[0] == 2 * max(q_w, k_w) - 1
-        Rh = rel_h[rel_pos_index(q_h, k_h)]
-        Rw = rel_w[rel_pos_index(q_w, k_w)]
+        Rh = get_rel_pos(rel_h, 2 * max(q_h, k_h) - 1)[rel_pos_index(q_h, k_h)]
+        Rw = get_rel_pos(rel_w, 2 * max(q_w, k_w) - 1)[rel_pos_index(q_w, k_w)]
         rel_h_q = torch.einsum("bythwc,hkc->bythwk", r_q, Rh)
         rel_w_q = torch.einsum("bythwc,wkc->bythwk", r_q, Rw)
         out = out + rel_h_q[:, :, :, :, :, None, :, None] + rel_w_q[:, :, :, :, :, None, None, :]
     if rel_t is not None:
-        assert rel_t.shape[0] == 2 * max(q_t, k_t) - 1
-        Rt = rel_t[rel_pos_index(q_t, k_t)]
+        Rt = get_rel_pos(rel_t, 2 * max(q_t, k_t) - 1)[rel_pos_index(q_t, k_t)]
         rel_t_q = torch.einsum("bythwc,tkc->bythwk", r_q, Rt)
         out = out + rel_t_q[:, :, :, :, :, :, None, None]
     out = out.reshape(B, nh, q_t * q_h * q_w, k_t * k_h * k_w)

@@ -878,7 +878,6 @@ static int fill_dw(DwParams& p, const sf_dw_desc* d, bool rows_are_outputs, int 
             "dwconv: C and Cw must be multiples of 8 with C %% Cw == 0 (C=%d Cw=%d)", d->C, d->Cw);
     const int taps = d->kT * d->kH * d->kW;
     REQUIRE(taps * d->Cw <= SF_DW_MAX_W, "dwconv: taps*Cw = %d exceeds the LDS weight stage (%d)", taps * d->Cw, SF_DW_MAX_W);
-    REQUIRE(d->kH * d->kW <= 9, "dwconv: at most 9 spatial taps");
     const int To = (d->Ti + 2 * d->pT - d->kT) / d->sT + 1, Ho = (d->Hi + 2 * d->pH - d->kH) / d->sH + 1,
               Wo = (d->Wi + 2 * d->pW - d->kW) / d->sW + 1;
     REQUIRE(To == d->To && Ho == d->Ho && Wo == d->Wo, "dwconv: output dims do not match the geometry");
@@ -903,7 +902,7 @@ static const int kDwFwdBlocks = 2048, kDwWgradBlocks = 256;
 // W-blocked kernels: (kW, sW) in {(3,1), (3,2), (1,1)} with pW = kW/2; returns 0 when the geometry is not covered
 static int dw_blocked_kind(const sf_dw_desc* d) {
     if (getenv("SF_DW_GENERIC") && atoi(getenv("SF_DW_GENERIC")) != 0) return 0;
-    if (d->pW != d->kW / 2) return 0;
+    if (d->pW != d->kW / 2 || d->kH * d->kW > 9) return 0;      // the blocked weight gradient keeps <= 9 taps per plane
     if (d->kW == 3 && d->sW == 1) return 1;
     if (d->kW == 3 && d->sW == 2) return 2;
     if (d->kW == 1 && d->sW == 1 && d->kT * d->kH * d->Cw <= 3072) return 3;
@@ -1044,7 +1043,7 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
     REQUIRE(workspace_bytes >= (int64_t)grid.x * taps * d->C * 4, "sf_dwconv_wgrad: workspace too small");
     REQUIRE(grid.y == 1, "sf_dwconv_wgrad: C > 2048 is not supported");
     p.x = (const f16*)x; p.ldx = d->ldx; p.dy = (const f16*)dy; p.lddy = d->ldy; p.wpart = (float*)workspace;
-    grid.z = d->kT;
+    grid.z = kind ? d->kT : d->kT * cdiv(d->kH * d->kW, 9);
     static const bool v2 = (getenv("SF_DW_WGRAD_V2") && atoi(getenv("SF_DW_WGRAD_V2")) != 0);       // opt-in: =1 -> version 2 (unmeasured)
     if (kind && v2) SF_DW_DISPATCH_B(kind, sf_dwconv_wgrad_blocked_kernel, true, grid, (hipStream_t)stream, p, bi);
     else if (kind) SF_DW_DISPATCH_B(kind, sf_dwconv_wgrad_blocked_kernel, false, grid, (hipStream_t)stream, p, bi);

@@ -184,14 +184,19 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_kernel(DwParams p)
 }
 
 // Per-block partial weight gradients: wpart[blk][tap][c] = sum over the block's output rows of dy * x(tap).
-// blockIdx.z selects the temporal tap kt; the kH*kW (<= 9) taps of that plane are accumulated in registers.
+// blockIdx.z selects the temporal tap kt and a chunk of 9 of that plane's kH*kW taps, which are accumulated in registers
+// (one chunk for the 3x3 planes of every MViTv2 / X3D config; MViTv1's stride+1 pooling kernels, 1x5x5 and 1x9x9 in
+// configs/Kinetics/MVIT_B_32x3_CONV.yaml, take 3 and 9 chunks, each re-reading dy).
 __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_kernel(DwParams p) {
     __shared__ float s_red[SF_THREADS][9];
     int gcol, r0, r1, rstep;
     const bool active = p.rt.init(gcol, r0, r1, rstep);
     const int c = gcol * 8;
-    const int kt = blockIdx.z;
-    const int nsp = p.kH * p.kW;
+    const int nsp_all = p.kH * p.kW;
+    const int nchunk = (nsp_all + 8) / 9;
+    const int kt = blockIdx.z / nchunk;
+    const int i0 = (blockIdx.z % nchunk) * 9;
+    const int nsp = nsp_all - i0 < 9 ? nsp_all - i0 : 9;
     const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls;
     float acc[9][8];
 #pragma unroll
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_kernel(DwParams p)
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 if (i < nsp) {
-                    const int kh = i / p.kW, kw = i % p.kW;
+                    const int kh = (i0 + i) / p.kW, kw = (i0 + i) % p.kW;
                     const int h = ho * p.sH - p.pH + kh, w = wo * p.sW - p.pW + kw;
                     if ((unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi) {
                         f16x8 v = ld16(xb + (((int64_t)t * p.Hi + h) * p.Wi + w) * p.ldx);
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_kernel(DwParams p)
     const int G = p.rt.C >> 3;
     const int TG = G < SF_THREADS ? G : SF_THREADS;
     const int rpi = SF_THREADS / TG;
-    const int taps = p.kT * nsp;
+    const int taps = p.kT * nsp_all;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {       // static register indices: a runtime-indexed acc[] would live in scratch
         if (i < nsp) {                  // block-uniform
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_kernel(DwParams p)
             for (int e = 0; e < 8; ++e) s_red[threadIdx.x][e] = acc[i][e];
             __syncthreads();
             if (active && (int)threadIdx.x < TG) {
-                float* o = p.wpart + ((int64_t)blockIdx.x * taps + kt * nsp + i) * p.rt.C + c;
+                float* o = p.wpart + ((int64_t)blockIdx.x * taps + kt * nsp_all + i0 + i) * p.rt.C + c;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float a = 0.f;

@@ -148,6 +148,15 @@ def _rel_index(q_size, k_size, device):
     return dist.long().to(torch.int32).contiguous().to(device)
 
 
+def _interp_matrix(stored, used, device):
+    """W [used, stored] with get_rel_pos(table, used) == W @ table; None when the table is used as stored."""
+    if stored == used:
+        return None
+    eye = torch.eye(stored, dtype=torch.float32)
+    w = torch.nn.functional.interpolate(eye.reshape(1, stored, stored).permute(0, 2, 1), size=used, mode="linear")
+    return w.reshape(stored, used).permute(1, 0).contiguous().to(device)
+
+
 class AttentionPlan:
     """Shapes and cached index tables of one MultiScaleAttention call at a given (B, thw)."""
 
@@ -179,15 +188,24 @@ class AttentionPlan:
         self.rel = att.rel_pos_spatial and att.rel_pos_temporal
         if att.rel_pos_spatial != att.rel_pos_temporal:
             raise NotImplementedError("spatial and temporal relative positions are used together on this path (MViTv2)")
-        rows = (att.rel_pos_h.shape[0], att.rel_pos_w.shape[0], att.rel_pos_t.shape[0]) if self.rel else (0, 0, 0)
+        (qt, qh, qw), (kt, kh, kw) = self.q_thw, self.k_thw
+        rows = (2 * max(qh, kh) - 1, 2 * max(qw, kw) - 1, 2 * max(qt, kt) - 1) if self.rel else (0, 0, 0)
         self.desc = tokens.attn_desc(B, self.heads, self.D, cls, self.q_thw, self.k_thw, *rows)
         self.idx = None
         self.onehot = None          # fused attention: bias-bucket indicator matrix (tokens.attn_onehot), built on first use
+        self.interp = (None, None, None)
         if self.rel:
-            (qt, qh, qw), (kt, kh, kw) = self.q_thw, self.k_thw
-            assert rows == (2 * max(qh, kh) - 1, 2 * max(qw, kw) - 1, 2 * max(qt, kt) - 1), \
-                "rel-pos tables are used at their constructed size (no interpolation on this path)"
+            # get_rel_pos (attention.py:48-61): a table constructed with another row count (size // stride at construction
+            # vs the pooling conv's ceil(size / stride): odd extents, e.g. MViTv2-L at 312^2) is resampled along its rows by
+            # F.interpolate(mode="linear") -- a fixed linear map, kept as a [rows used, rows stored] fp32 matrix
+            self.interp = tuple(_interp_matrix(t.shape[0], r, device)
+                                for t, r in zip((att.rel_pos_h, att.rel_pos_w, att.rel_pos_t), rows))
             self.idx = (_rel_index(qh, kh, device), _rel_index(qw, kw, device), _rel_index(qt, kt, device))
+
+    def tables(self, att):
+        """rel_pos_{h,w,t} at the row counts this call uses (resampled where they were constructed differently)."""
+        return tuple(t if w is None else w @ t.detach()
+                     for t, w in zip((att.rel_pos_h, att.rel_pos_w, att.rel_pos_t), self.interp))
 
 
 # Measured on MI355X: the first version of the fused kernels (bias lookups, expf, per-chunk rescale, no query split in
@@ -212,7 +230,7 @@ def _core_forward(att, plan, qn, kn, vn):
     qn / kn / vn: [B, N*, att] token tensors of any row pitch -> (o [B, Nq, att], saved tensors of the core)."""
     B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
     Nq, Nk, lds = plan.Nq, plan.Nk, plan.lds
-    tables = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t) if plan.rel else None
+    tables = plan.tables(att) if plan.rel else None
     t16 = t16t = None
     if plan.rel:
         t16, t16t = tokens.relpos_tables16(tables)
@@ -270,10 +288,17 @@ def _core_backward(att, plan, core, do, dq_out=None, dkv_out=None):
         tokens.bgemm_tn_heads(dS, (heads * Nq * lds, Nq * lds), lds, qn, (Nq * C, D), C, Nq, Nk, D, dkn, (Nk * C, D), C,
                               B, heads)
     if plan.rel:
-        tabs = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t)
-        dests = [_grad_dest(t) for t in tabs]
-        tokens.relpos_bwd(plan.desc, qn, tabs, plan.idx, drq, dqn, [d[0] for d in dests], [not d[1] for d in dests],
-                          t16t=core["t16t"])
+        params = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t)
+        dests = [_grad_dest(t) for t in params]
+        # a resampled table receives its gradient through the transposed interpolation map
+        tmp = [None if w is None else torch.empty((w.shape[0], plan.D), dtype=torch.float32, device=do.device)
+               for w in plan.interp]
+        tokens.relpos_bwd(plan.desc, qn, [d[0] if t is None else t for d, t in zip(dests, tmp)], plan.idx, drq, dqn,
+                          [d[0] if t is None else t for d, t in zip(dests, tmp)],
+                          [(not d[1]) and t is None for d, t in zip(dests, tmp)], t16t=core["t16t"])
+        for (g, zero_first), t, w in zip(dests, tmp, plan.interp):
+            if w is not None:
+                g.copy_(w.t() @ t) if zero_first else g.add_(w.t() @ t)
     return dqn, dkn, dvn
 
 

@@ -117,13 +117,14 @@ def test_mvit_v1_and_vit_match_reference(sim, name):
         print(rep)
 
 
-@pytest.mark.parametrize("name", ["mvit_nocls_sepqkv_tiny", "mvit_poolfirst_tiny"])
+@pytest.mark.parametrize("name", ["mvit_nocls_sepqkv_tiny", "mvit_poolfirst_tiny", "mvit_relinterp_tiny"])
 @pytest.mark.parametrize("fused_attn", ["1", "0"])
 def test_mvit_attention_options_match_reference(sim, name, fused_attn, monkeypatch):
     """MultiScaleAttention options vs the unmodified reference: no cls token (CLS_EMBED_ON False: pooling, relative
     positions, residual pooling and the skip max-pool over all rows; norm -> mean feeds the head), separate q / k / v
     Linears (SEPARATE_QKV: one GEMM against the concatenated operand) and POOL_FIRST (pooling convs of dim / heads
-    channels on the block input, q / k / v Linears on the pooled tokens), fused and unfused attention core."""
+    channels on the block input, q / k / v Linears on the pooled tokens) and relative-position tables resampled by
+    get_rel_pos (odd pooled extents, as in MViTv2-L 40x3 at 312^2), fused and unfused attention core."""
     monkeypatch.setenv("SF_ATTN_FUSED", fused_attn)
     rep = {}
     try:

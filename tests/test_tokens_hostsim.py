@@ -33,6 +33,9 @@ def test_dwconv_tokens(sim):
     tc.check_dwconv(sim, 1, 1, 8, (2, 6, 16), (3, 3, 3), (1, 2, 2), cls=1)
     tc.check_dwconv(sim, 1, 1, 120, (2, 4, 8), (3, 3, 3), (1, 1, 1), cls=0)     # taps * Cw > 3072: fp16 LDS weights
     tc.check_dwconv(sim, 1, 1, 16, (5, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)      # X3D stem temporal conv, whole groups
+    # MViTv1 stride+1 pooling kernels (configs/Kinetics/MVIT_B_32x3_CONV.yaml): more than 9 taps per plane
+    tc.check_dwconv(sim, 1, 2, 8, (2, 9, 9), (1, 5, 5), (1, 4, 4), cls=1)
+    tc.check_dwconv(sim, 1, 1, 16, (2, 17, 17), (1, 9, 9), (1, 8, 8), cls=1)
 
 
 def test_token_pool(sim):

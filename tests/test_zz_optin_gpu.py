@@ -30,7 +30,7 @@ def test_depthwise_version2_kernels_gpu(gpu):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("name", ["mvit_nocls_sepqkv_tiny", "mvit_poolfirst_tiny"])
+@pytest.mark.parametrize("name", ["mvit_nocls_sepqkv_tiny", "mvit_poolfirst_tiny", "mvit_relinterp_tiny"])
 @pytest.mark.parametrize("fused_attn", ["1", "0"])
 def test_mvit_attention_options_match_reference_gpu(gpu, name, fused_attn, monkeypatch):
     """CLS_EMBED_ON False + SEPARATE_QKV, and POOL_FIRST, vs the reference's outputs (tests/golden)."""
@@ -41,3 +41,11 @@ def test_mvit_attention_options_match_reference_gpu(gpu, name, fused_attn, monke
         mc.check_engine(name, gpu, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.2, tol_global=1e-2, report=rep)
     finally:
         print(name, fused_attn, rep)
+
+
+def test_wide_pooling_kernels_gpu(gpu):
+    """Depthwise pooling kernels with more than 9 taps per plane (MViTv1 stride+1 kernels 1x5x5 / 1x9x9,
+    configs/Kinetics/MVIT_B_32x3_CONV.yaml): generic forward / data gradient, chunked weight gradient."""
+    from tests import token_checks as tc
+    tc.check_dwconv(gpu, 2, 2, 96, (4, 28, 28), (1, 5, 5), (1, 4, 4), cls=1)
+    tc.check_dwconv(gpu, 2, 1, 96, (4, 56, 56), (1, 9, 9), (1, 8, 8), cls=1)
