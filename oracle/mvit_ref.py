@@ -174,6 +174,66 @@ def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, drop=Non
     return _store(x + x_mlp), thw_new
 
 
+def _mlp(x, sd, prefix):
+    """Mlp.forward (common.py:25-34), GELU, no dropout."""
+    h = _store(F.gelu(_linear(x, sd, prefix + ".fc1")))
+    return F.linear(h, _store(sd[prefix + ".fc2.weight"]), sd[prefix + ".fc2.bias"])
+
+
+def rev_backbone(x, sd, cfg, thw, drop=None):
+    """ReversibleMViT.forward (reversible_mvit.py:141-174) in its eval / "vanilla" form (:128-139), which computes the same
+    values as the RevBackProp path (:177-263; that one only re-derives activations in backward instead of storing them).
+    ReversibleBlock (:491-526): Y1 = X1 + F(X2), Y2 = X2 + G(Y1), F = attention(norm(.)), G = mlp(norm(.)) (:593-672).
+    StageTransitionBlock (:350-409) for MVIT.REV.PRE_Q_FUSION "avg" and RES_PATH "conv": x = mean of the two streams;
+    residual = [res_proj] -> pool_q conv + norm_q (the attention's own q pooling parameters) -> [res_proj if POOL_FIRST];
+    x = residual + F(x); x = x + G(x); drop_path(x).  drop[i] = per-sample scale of layer i's stochastic depth (both
+    branches of a ReversibleBlock draw the same mask: the generator is re-seeded with the "droppath" seed, :500-519)."""
+    assert cfg.MVIT.REV.PRE_Q_FUSION == "avg" and cfg.MVIT.REV.RES_PATH == "conv" and not cfg.MVIT.CLS_EMBED_ON
+    plan = mvit_plan(cfg)
+    pool_first, res_pool = cfg.MVIT.POOL_FIRST, cfg.MVIT.RESIDUAL_POOLING
+    a = h = None
+    for i, (heads, sq, skv) in enumerate(plan):
+        pre = f"rev_backbone.layers.{i}"
+        s = None if drop is None else drop[i].view(-1, 1, 1)
+
+        def f_att(t):
+            return attention(_ln(t, sd, pre + ".F.norm"), sd, pre + ".F.attn", thw, heads, sq, skv, False, res_pool,
+                             pool_first)
+
+        def g_mlp(t):
+            return _mlp(_ln(t, sd, pre + ".G.norm"), sd, pre + ".G.mlp")
+
+        if i in cfg.MVIT.REV.BUFFER_LAYERS:
+            if a is not None:
+                x = _store((a + h) * 0.5)                     # TwoStreamFusion("avg") (common.py:99-100)
+            x_res = x
+            has_proj = pre + ".res_proj.weight" in sd
+            if has_proj and not pool_first:
+                x_res = _linear(x_res, sd, pre + ".res_proj")
+            B, L, C = x_res.shape
+            t = x_res.reshape(B, L, heads, C // heads).permute(0, 2, 1, 3)
+            t, _ = attention_pool(t, sd[pre + ".F.attn.pool_q.weight"], sq, thw, False, pre + ".F.attn.norm_q", sd)
+            x_res = t.permute(0, 2, 1, 3).reshape(B, t.shape[2], C)
+            if has_proj and pool_first:
+                x_res = _linear(x_res, sd, pre + ".res_proj")
+            xa, thw_new = f_att(x)
+            x = _store(x_res + xa)
+            x = _store(x + g_mlp(x))
+            if s is not None:
+                x = _store(x * s)
+            thw = thw_new
+            a = h = None
+        else:
+            if a is None:
+                a = h = x                                   # torch.cat([x, x], -1) then chunk (:157, :135)
+            fa, _ = f_att(h)
+            y1 = _store(a + (fa if s is None else _store(fa) * s))
+            g = g_mlp(y1)
+            y2 = _store(h + (g if s is None else _store(g) * s))
+            a, h = y1, y2
+    return torch.cat([a, h], dim=-1) if a is not None else x
+
+
 def mvit_plan(cfg):
     """Per-block (heads, stride_q, stride_kv) from the cfg, as MViT.__init__ derives them
     (video_model_builder.py:906-1004)."""
@@ -225,6 +285,14 @@ def mvit_forward(sd, cfg, inputs, training=True, drop=None):
         x = x + pos
     x = _store(x)
     thw = [T, H, W]
+    if cfg.MVIT.REV.ENABLE:             # MViT._forward_reversible (video_model_builder.py:1141-1164), RESPATH_FUSE "concat"
+        assert cfg.MVIT.REV.RESPATH_FUSE == "concat"
+        x = rev_backbone(x, sd, cfg, thw, drop)
+        x = _ln(x.mean(1), sd, "norm") if cfg.MVIT.USE_MEAN_POOLING else _ln(x, sd, "norm").mean(1)
+        z = F.linear(x, sd["head.projection.weight"], sd["head.projection.bias"])
+        if not training and cfg.MODEL.HEAD_ACT == "softmax":
+            z = F.softmax(z, dim=1)
+        return z
     for i, (heads, sq, skv) in enumerate(mvit_plan(cfg)):
         x, thw = block(x, sd, f"blocks.{i}", thw, heads, sq, skv, has_cls=has_cls, drop=None if drop is None else drop[i],
                        residual_pooling=cfg.MVIT.RESIDUAL_POOLING, dim_mul_in_att=cfg.MVIT.DIM_MUL_IN_ATT,

@@ -111,7 +111,9 @@ _DEFAULTS = {
              "SEP_POS_EMBED": False, "DROPOUT_RATE": 0.0, "USE_ABS_POS": True, "REL_POS_SPATIAL": False,
              "REL_POS_TEMPORAL": False, "REL_POS_ZERO_INIT": False, "RESIDUAL_POOLING": False, "DIM_MUL_IN_ATT": False,
              "SEPARATE_QKV": False, "HEAD_INIT_SCALE": 1.0, "USE_MEAN_POOLING": False, "USE_FIXED_SINCOS_POS": False,
-             "REV": {"ENABLE": False}},
+             # slowfast/config/defaults.py:612-628
+             "REV": {"ENABLE": False, "RESPATH_FUSE": "concat", "BUFFER_LAYERS": [], "RES_PATH": "conv",
+                     "PRE_Q_FUSION": "avg"}},
     # slowfast/config/defaults.py:333-358
     "X3D": {"WIDTH_FACTOR": 1.0, "DEPTH_FACTOR": 1.0, "BOTTLENECK_FACTOR": 1.0, "DIM_C5": 2048, "DIM_C1": 12,
             "SCALE_RES2": False, "BN_LIN5": False, "CHANNELWISE_3x3x3": True},
@@ -191,6 +193,25 @@ PRESETS["MVIT_B_16x4_CONV"] = {
     "SOLVER": {"BASE_LR": 0.0001, "MOMENTUM": 0.9, "WEIGHT_DECAY": 0.05, "OPTIMIZING_METHOD": "adamw",
                "ZERO_WD_1D_PARAM": True, "CLIP_GRAD_L2NORM": 1.0},
     "MODEL": {"NUM_CLASSES": 400, "ARCH": "mvit", "MODEL_NAME": "MViT", "LOSS_FUNC": "soft_cross_entropy",
+              "DROPOUT_RATE": 0.5},
+}
+
+# configs/Kinetics/REV_MVIT_B_16x4_CONV.yaml (reversible MViT-B).  CLS_EMBED_ON is True in the shipped yaml, which the
+# reference's constructor rejects ("rev does not allow cls token", video_model_builder.py:966): pass
+# MVIT.CLS_EMBED_ON False, as a user of the reference has to.
+PRESETS["REV_MVIT_B_16x4_CONV"] = {
+    "DATA": {"NUM_FRAMES": 16, "SAMPLING_RATE": 4, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 224,
+             "INPUT_CHANNEL_NUM": [3]},
+    "MVIT": {"ZERO_DECAY_POS_CLS": False, "CLS_EMBED_ON": True, "SEP_POS_EMBED": True, "USE_ABS_POS": True, "DEPTH": 16,
+             "NUM_HEADS": 1, "EMBED_DIM": 96, "PATCH_KERNEL": [3, 7, 7], "PATCH_STRIDE": [2, 4, 4],
+             "PATCH_PADDING": [1, 3, 3], "MLP_RATIO": 4.0, "QKV_BIAS": False, "DROPPATH_RATE": 0.05, "NORM": "layernorm",
+             "MODE": "conv", "DIM_MUL": [[1, 2.0], [3, 2.0], [14, 2.0]], "HEAD_MUL": [[1, 2.0], [3, 2.0], [14, 2.0]],
+             "POOL_KVQ_KERNEL": [3, 3, 3], "POOL_KV_STRIDE_ADAPTIVE": [1, 8, 8],
+             "POOL_Q_STRIDE": [[1, 1, 2, 2], [3, 1, 2, 2], [14, 1, 2, 2]],
+             "REV": {"ENABLE": True, "RESPATH_FUSE": "concat", "BUFFER_LAYERS": [1, 3, 14], "RES_PATH": "conv"}},
+    "SOLVER": {"BASE_LR": 0.0001, "MOMENTUM": 0.9, "WEIGHT_DECAY": 7e-2, "OPTIMIZING_METHOD": "adamw",
+               "ZERO_WD_1D_PARAM": True},
+    "MODEL": {"NUM_CLASSES": 400, "ARCH": "slow", "MODEL_NAME": "MViT", "LOSS_FUNC": "soft_cross_entropy",
               "DROPOUT_RATE": 0.5},
 }
 

@@ -237,7 +237,7 @@ class MViT(nn.Module):
         assert cfg.DATA.TRAIN_CROP_SIZE == cfg.DATA.TEST_CROP_SIZE
         m = cfg.MVIT
         unsupported = [k for k, bad in (
-            ("PATCH_2D", m.PATCH_2D), ("REV.ENABLE", m.REV.ENABLE),
+            ("PATCH_2D", m.PATCH_2D),
             ("USE_FIXED_SINCOS_POS", m.USE_FIXED_SINCOS_POS), ("NORM_STEM", m.NORM_STEM),
             ("LAYER_SCALE_INIT_VALUE", m.LAYER_SCALE_INIT_VALUE > 0), ("DROPOUT_RATE", m.DROPOUT_RATE > 0),
             ("DETECTION.ENABLE", cfg.DETECTION.ENABLE)) if bad]
@@ -247,7 +247,7 @@ class MViT(nn.Module):
         if unsupported or m.NORM != "layernorm" or m.MODE != "conv":
             raise NotImplementedError(f"MViT options outside the built video path: {unsupported}")
         self.cfg = cfg
-        self.enable_detection, self.enable_rev = False, False
+        self.enable_detection, self.enable_rev = False, bool(m.REV.ENABLE)
         self.patch_stride = list(m.PATCH_STRIDE)
         self.T = cfg.DATA.NUM_FRAMES // self.patch_stride[0]
         self.H = cfg.DATA.TRAIN_CROP_SIZE // self.patch_stride[1]
@@ -301,8 +301,18 @@ class MViT(nn.Module):
         self.pool_q, self.pool_kv, self.stride_q, self.stride_kv = pool_q, pool_kv, stride_q, stride_kv
         self.norm_stem = None
         input_size = self.patch_dims
-        self.blocks = nn.ModuleList()
-        for i in range(depth):
+        if self.enable_rev:                        # video_model_builder.py:964-978
+            assert not self.cls_embed_on, "rev does not allow cls token"
+            if m.REV.RESPATH_FUSE != "concat":
+                raise NotImplementedError("MVIT.REV.RESPATH_FUSE: only 'concat' (norm and head on both streams) is built")
+            from .rev_mvit import ReversibleMViT, TwoStreamFusion
+            self.rev_backbone = ReversibleMViT(cfg, self)
+            embed_dim = round_width(embed_dim, dim_mul.prod(), divisor=num_heads)
+            self.fuse = TwoStreamFusion(m.REV.RESPATH_FUSE, dim=2 * embed_dim)
+            embed_dim = 2 * embed_dim              # the final norm and the head see the concatenated streams
+        else:
+            self.blocks = nn.ModuleList()
+        for i in range(0 if self.enable_rev else depth):
             num_heads = round_width(num_heads, head_mul[i])
             if m.DIM_MUL_IN_ATT:
                 dim_out = round_width(embed_dim, dim_mul[i], divisor=round_width(num_heads, head_mul[i]))
@@ -374,9 +384,12 @@ class MViT(nn.Module):
         T, H, W = bcthw[-3], bcthw[-2], bcthw[-1]
         assert (T, H, W) == (self.T, self.H, self.W), bcthw
         thw = [T, H, W]
-        for blk in self.blocks:
-            x, thw = blk(x, thw)
-        # video_model_builder.py:1226-1238: mean of the patch tokens then norm / norm of the cls rows / norm then mean
+        if self.enable_rev:                        # _forward_reversible, video_model_builder.py:1141-1164
+            x = self.rev_backbone(x)               # fuse("concat") is the identity on the concatenated streams
+        else:
+            for blk in self.blocks:
+                x, thw = blk(x, thw)
+        # video_model_builder.py:1154-1161, 1226-1238: mean of the patch tokens then norm / norm of the cls rows / norm then mean
         mode = "mean_norm" if self.use_mean_pooling else ("cls" if self.cls_embed_on else "norm_mean")
         x = ClsNormFn.apply(x, self, mode, self.cls_embed_on, self.norm.weight, self.norm.bias)
         return self.head(x)

@@ -501,6 +501,150 @@ class MultiScaleBlockFn(torch.autograd.Function):
         return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
+def _attention_sub_forward(sub, plan, x):
+    """AttentionSubBlock.forward (reversible_mvit.py:670-672): attention(norm(x)) up to (not including) the output
+    projection -> (o, saved)."""
+    att = sub.attn
+    xn, m, r = sub._norm.forward(x)
+    if att.pool_first:
+        qkv = None
+        o, sv = attention_forward_pool_first(att, plan, xn)
+    else:
+        qkv = att._qkv.forward(xn)
+        o, sv = attention_forward(att, plan, qkv)
+    return o, dict(x=x, xn=xn, st=(m, r), qkv=qkv, att=sv, o=o)
+
+
+def _attention_sub_backward(sub, plan, sv, d_out, resid=None):
+    """d(proj output) -> d(x) (+ resid): output projection, attention core, pooling, qkv projection, LayerNorm."""
+    att = sub.attn
+    do = att._proj.backward(sv["o"], d_out)
+    if att.pool_first:
+        dxn = attention_backward_pool_first(att, plan, sv["xn"], sv["att"], do)
+    else:
+        dxn = att._qkv.backward(sv["xn"], attention_backward(att, plan, sv["qkv"], sv["att"], do))
+    return sub._norm.backward(dxn, sv["x"], *sv["st"], resid=resid)
+
+
+def _mlp_sub_forward(sub, x):
+    """MLPSubblock.forward (reversible_mvit.py:616-617) up to (not including) fc2 -> (gelu(fc1(norm(x))), saved)."""
+    xn, m, r = sub._norm.forward(x)
+    if _FUSED_GELU:
+        h, a = sub.mlp._fc1.forward_gelu(xn)
+    else:
+        h = sub.mlp._fc1.forward(xn)
+        a = tokens.gelu_fwd(h)
+    return a, dict(x=x, xn=xn, st=(m, r), h=h, a=a)
+
+
+def _mlp_sub_backward(sub, sv, d_out, resid=None):
+    if _FUSED_GELU:
+        dh = sub.mlp._fc2.backward_through_gelu(sv["a"], d_out, sv["h"])
+    else:
+        dh = tokens.gelu_bwd(sv["h"], sub.mlp._fc2.backward(sv["a"], d_out))
+    dxn = sub.mlp._fc1.backward(sv["xn"], dh)
+    return sub._norm.backward(dxn, sv["x"], *sv["st"], resid=resid)
+
+
+def _f16c(t):
+    return t.contiguous() if t.dtype == _f16 else t.to(_f16).contiguous()
+
+
+class RevBlockFn(torch.autograd.Function):
+    """ReversibleBlock.forward (reversible_mvit.py:491-526): Y1 = X1 + drop(F(X2)), Y2 = X2 + drop(G(Y1)), the two
+    streams kept as two token tensors (the reference concatenates them only to pass them through RevBackProp).  The
+    reference re-derives X1 / X2 from Y1 / Y2 in backward to avoid storing them (:528-590); here the block inputs and
+    the usual GEMM / pooling outputs are kept (288 GB of HBM; identical values, no recomputation pass)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, mod, thw, drop, *params):
+        B, N, _ = x2.shape
+        plan = mod._plan(B, thw, x2.device)
+        att = mod.F.attn
+        o, sf = _attention_sub_forward(mod.F, plan, x2)
+        if drop is None:
+            y1 = att._proj.forward(o, resid=x1)
+        else:
+            y1 = tokens.row_scale_add(att._proj.forward(o), drop, N, resid=x1)
+        a, sg = _mlp_sub_forward(mod.G, y1)
+        if drop is None:
+            y2 = mod.G.mlp._fc2.forward(a, resid=x2)
+        else:
+            y2 = tokens.row_scale_add(mod.G.mlp._fc2.forward(a), drop, N, resid=x2)
+        ctx.mod, ctx.plan, ctx.drop, ctx.sf, ctx.sg = mod, plan, drop, sf, sg
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        mod, plan, drop = ctx.mod, ctx.plan, ctx.drop
+        dy1, dy2 = _f16c(dy1), _f16c(dy2)
+        N = dy1.shape[1]
+        dg = dy2 if drop is None else tokens.row_scale_add(dy2, drop, N)
+        dy1t = _mlp_sub_backward(mod.G, ctx.sg, dg, resid=dy1)              # d(Y1) = dY1 + G'(Y1)^T d(G)
+        df = dy1t if drop is None else tokens.row_scale_add(dy1t, drop, N)
+        dx2 = _attention_sub_backward(mod.F, plan, ctx.sf, df, resid=dy2)  # d(X2) = dY2 + F'(X2)^T d(F)
+        _notify(mod._param_list)
+        ctx.sf = ctx.sg = None
+        return (dy1t, dx2) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class StageTransitionFn(torch.autograd.Function):
+    """StageTransitionBlock.forward (reversible_mvit.py:350-409), PRE_Q_FUSION "avg", RES_PATH "conv": the mean of the
+    two streams goes through attention with q pooling; the residual takes the attention's OWN pool_q conv + norm_q (and
+    res_proj when the width changes, before the pooling or -- POOL_FIRST -- after it); then x + G(x), drop_path on the sum."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, mod, thw, drop, *params):
+        B, N, C = x1.shape
+        plan = mod._plan(B, thw, x1.device)
+        att = mod.F.attn
+        half = mod._half(B, x1.device)
+        x = x1 if x2 is None else tokens.row_scale_add(x1, half, N, resid=tokens.row_scale_add(x2, half, N))
+        o, sf = _attention_sub_forward(mod.F, plan, x)
+        proj_before = mod._res_proj is not None and not att.pool_first
+        xr = mod._res_proj.forward(x) if proj_before else x
+        # the residual has the channel count the q pooling acts on in either order (dim_out after res_proj, dim under
+        # POOL_FIRST), so it shares the attention's pooling geometry plan.gq
+        rp, rn, rst = _pool_norm(xr, att.pool_q, att._norm_q, plan.gq, B, plan.Nq, xr.shape[-1], plan.gq.Cw)
+        xres = mod._res_proj.forward(rn) if mod._res_proj is not None and not proj_before else rn
+        xa = att._proj.forward(o, resid=xres)
+        a, sg = _mlp_sub_forward(mod.G, xa)
+        out = mod.G.mlp._fc2.forward(a, resid=xa)
+        if drop is not None:                                   # drop_path on the block output (:407)
+            out = tokens.row_scale_add(out, drop, out.shape[1])
+        ctx.mod, ctx.plan, ctx.drop, ctx.sf, ctx.sg = mod, plan, drop, sf, sg
+        ctx.res = dict(x=x, xr=xr, rp=rp, rn=rn, rst=rst, proj_before=proj_before, two=x2 is not None, N=N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod, plan, drop, res = ctx.mod, ctx.plan, ctx.drop, ctx.res
+        att = mod.F.attn
+        B = plan.B
+        dout = _f16c(dout)
+        if drop is not None:
+            dout = tokens.row_scale_add(dout, drop, dout.shape[1])
+        dxa = _mlp_sub_backward(mod.G, ctx.sg, dout, resid=dout)             # x + G(x)
+        # residual path: [res_proj] <- norm_q <- pool_q <- [res_proj]; parameters shared with the attention accumulate
+        dres = dxa
+        if mod._res_proj is not None and not res["proj_before"]:
+            dres = mod._res_proj.backward(res["rn"], dres)
+        Cr, Dc = res["xr"].shape[-1], plan.gq.Cw
+        drp = att._norm_q.backward(dres.view(-1, Dc), res["rp"].view(-1, Dc), *res["rst"]).view(B, plan.Nq, Cr)
+        dxr = tokens.dwconv_dgrad(drp.view(-1, Cr), att.pool_q.weight, plan.gq).view(res["xr"].shape)
+        dw, zero_first = _grad_dest(att.pool_q.weight)
+        tokens.dwconv_wgrad(res["xr"], drp.view(-1, Cr), plan.gq, dw, zero_first=zero_first)
+        dx_res = mod._res_proj.backward(res["x"], dxr) if res["proj_before"] else dxr
+        dx = _attention_sub_backward(mod.F, plan, ctx.sf, dxa, resid=dx_res)
+        _notify(mod._param_list)
+        ctx.sf = ctx.sg = ctx.res = None
+        if res["two"]:
+            half = mod._half(B, dx.device)
+            g1 = tokens.row_scale_add(dx, half, res["N"])
+            return (g1, g1.clone()) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
 class PatchEmbedFn(torch.autograd.Function):
     """PatchEmbed conv (+bias) -> tokens, with the cls token prepended (stem_helper.py:315-320,
     video_model_builder.py:1180-1186)."""

@@ -177,6 +177,50 @@ def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, t
     return res
 
 
+def check_rev_mvit_drop_path(device, rate=0.5, tol_logits=1e-2, tol_gnorm=1e-2, tol_global=3e-2):
+    """Reversible MViT with stochastic depth: one per-sample mask per layer -- both branches of a ReversibleBlock share it
+    (the reference re-seeds the generator, reversible_mvit.py:500-519), a StageTransitionBlock drops its whole output
+    (:407).  Engine with pinned masks vs the oracle with the same masks."""
+    gold = load_golden("mvit_rev_tiny")
+    opts = [o for o in gold["opts"]]
+    opts[opts.index("MVIT.DROPPATH_RATE") + 1] = rate
+    cfg = sa.get_preset(preset_for_yaml(gold["reference_yaml"]), opts)
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = mvit_ref.randomize_state(shapes, gold["param_seed"])
+    inputs, labels = video_ref.synthetic_batch(cfg, 4, gold["data_seed"])
+    g = torch.Generator().manual_seed(98)
+    drop = []
+    for layer in model.rev_backbone.layers:
+        keep = 1.0 - layer.drop_path_rate
+        drop.append(torch.floor(keep + torch.rand((4,), generator=g)) / keep)
+    # a dropped stage transition zeroes the sample's whole stream; keep those alive so that later layers are exercised
+    for i in cfg.MVIT.REV.BUFFER_LAYERS:
+        drop[i] = torch.full((4,), 1.0 / (1.0 - model.rev_backbone.layers[i].drop_path_rate))
+        drop[i][i % 4] = 0.0
+    assert any(float(s.min()) == 0.0 for s in drop), "no sample was dropped: the test is vacuous"
+    o_logits, o_loss, o_grads, _ = mvit_ref.loss_and_grads(sd, cfg, inputs, labels, drop=drop)
+    model.load_state_dict(sd)
+    model = model.to(device).train()
+    for layer, sc in zip(model.rev_backbone.layers, drop):
+        layer.__dict__["_fixed_drop_scale"] = sc
+    logits = model([x.to(device) for x in inputs])
+    loss = torch.nn.functional.cross_entropy(logits.float(), labels.to(device))
+    loss.backward()
+    grads = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
+    res = {"logits": float((logits.detach().float().cpu() - o_logits).abs().max() / o_logits.abs().max()),
+           "grad_norm": abs(float(video_ref.grad_norm(grads)) - float(video_ref.grad_norm(o_grads)))
+           / float(video_ref.grad_norm(o_grads)),
+           "grad_global": _global_rel(grads, o_grads)}
+    assert res["logits"] <= tol_logits and res["grad_norm"] <= tol_gnorm and res["grad_global"] <= tol_global, res
+    layer = model.rev_backbone.layers[-1]
+    layer.__dict__.pop("_fixed_drop_scale")
+    keep = 1.0 - layer.drop_path_rate
+    vals = set(round(float(v), 5) for v in layer._drop_scale(64, torch.device(device)).cpu())
+    assert vals <= {0.0, round(1.0 / keep, 5)}, vals
+    return res
+
+
 def check_mvit_drop_path(device, rate=0.5, tol_logits=1e-2, tol_gnorm=1e-2, tol_global=3e-2):
     """Stochastic depth (MVIT.DROPPATH_RATE > 0): the engine with pinned per-sample masks vs the oracle with the same
     masks (drop_path(), common.py:46-59; attention.py:500-510).  Also checks that the sampler draws masks in

@@ -133,6 +133,22 @@ def test_mvit_attention_options_match_reference(sim, name, fused_attn, monkeypat
         print(rep)
 
 
+def test_reversible_mvit_matches_reference(sim):
+    """Reversible MViT (configs/Kinetics/REV_MVIT_B_16x4_CONV.yaml family): two-stream ReversibleBlocks, StageTransitionBlocks
+    (stream average, residual through the attention's own pool_q + norm_q and res_proj), norm over the concatenated
+    streams -> mean.  The golden numbers come from the reference's RevBackProp training path."""
+    rep = {}
+    try:
+        mc.check_engine("mvit_rev_tiny", sim, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.2, tol_global=1e-2,
+                        report=rep)
+    finally:
+        print(rep)
+
+
+def test_reversible_mvit_drop_path(sim):
+    print(mc.check_rev_mvit_drop_path(sim))
+
+
 def test_x3d_sub_batchnorm_backbone_with_full_batch_head(sim):
     """X3D with BN.NORM_TYPE sub_batchnorm: the reference builds the backbone with SubBatchNorm3d but leaves the head's
     conv_5_bn a plain BatchNorm3d over the whole batch; the engine runs the backbone in sub-batch passes and the head once

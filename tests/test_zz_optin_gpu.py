@@ -49,3 +49,15 @@ def test_wide_pooling_kernels_gpu(gpu):
     from tests import token_checks as tc
     tc.check_dwconv(gpu, 2, 2, 96, (4, 28, 28), (1, 5, 5), (1, 4, 4), cls=1)
     tc.check_dwconv(gpu, 2, 1, 96, (4, 56, 56), (1, 9, 9), (1, 8, 8), cls=1)
+
+
+def test_reversible_mvit_gpu(gpu):
+    """Reversible MViT vs the reference's outputs (tests/golden/mvit_rev_tiny.json), then with pinned stochastic depth."""
+    from tests import model_checks as mc
+    rep = {}
+    try:
+        mc.check_engine("mvit_rev_tiny", gpu, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.2, tol_global=1e-2,
+                        report=rep)
+    finally:
+        print(rep)
+    print(mc.check_rev_mvit_drop_path(gpu))
