@@ -30,6 +30,12 @@ CASES = {
                  TINY + ["DATA.NUM_FRAMES", 4, "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2], [2], [2], [2]]"], 2),
     "slow_tiny": ("configs/Kinetics/SLOW_8x8_R50.yaml",
                   TINY + ["DATA.NUM_FRAMES", 4, "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2], [2], [2], [2]]"], 2),
+    # RESNET.TRANS_FUNC basic_transform (resnet_helper.py:27-115; ResNet-18/34 style blocks: Tx3x3 -> 1x3x3), I3D
+    # temporal kernels so that the first convolution of res2..res5 blocks is a true 3x3x3
+    "i3d_basic_tiny": ("configs/Kinetics/I3D_8x8_R50.yaml",
+                       ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 64,
+                        "RESNET.WIDTH_PER_GROUP", 8, "RESNET.DEPTH", 18, "DATA.NUM_FRAMES", 4,
+                        "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2], [2], [2], [2]]", "RESNET.TRANS_FUNC", "basic_transform"], 4),
     # full-width R50 models at reduced clip size, batch chosen so every BatchNorm sees >= 100 samples
     # (a BN over a handful of samples amplifies fp16 round-off and would test conditioning, not kernels)
     "slowfast_r50_mid": ("configs/Kinetics/SLOWFAST_8x8_R50.yaml",
@@ -215,6 +221,7 @@ EVAL_CASES = {
     "eval_c2d_tiny": ("c2d_tiny", 64),
     "eval_slowfast_nln_tiny": ("slowfast_nln_tiny", 96),
     "eval_slowfast_r50_mid": ("slowfast_r50_mid", 128, {"final_bn_gamma_scale": 0.25}),   # residual stream stays O(1)
+    "eval_i3d_basic_tiny": ("i3d_basic_tiny", 96),
     "eval_x3d_tiny": ("x3d_tiny", 96),
     "eval_mvit_tiny": ("mvit_tiny", 64),
 }

@@ -109,17 +109,24 @@ def fuse(xs, xf, sd, prefix, alpha, training, stats_out):
 
 
 def res_block(x, sd, prefix, stride, dilation, stride_1x1, training, stats_out):
-    """ResBlock.forward (resnet_helper.py:512-521) around BottleneckTransform.forward (:377-392)."""
+    """ResBlock.forward (resnet_helper.py:512-521) around BottleneckTransform.forward (:377-392) or, when the block has
+    no ``c`` convolution, BasicTransform.forward (:105-115: Tx3x3 stride s -> BN -> ReLU -> 1x3x3 dilated -> BN)."""
     s_a, s_b = (stride, 1) if stride_1x1 else (1, stride)
     b2 = prefix + ".branch2"
     wa = sd[b2 + ".a.weight"]
     kt = wa.shape[2]
-    y = _conv(x, wa, None, (1, s_a, s_a), (kt // 2, 0, 0))
-    y = _STORE(F.relu(_bn(y, sd, b2 + ".a_bn", training, stats_out)))
-    y = _conv(y, sd[b2 + ".b.weight"], None, (1, s_b, s_b), (0, dilation, dilation), (1, dilation, dilation))
-    y = _STORE(F.relu(_bn(y, sd, b2 + ".b_bn", training, stats_out)))
-    y = _conv(y, sd[b2 + ".c.weight"])
-    y = _bn(y, sd, b2 + ".c_bn", training, stats_out)
+    if b2 + ".c.weight" not in sd:
+        y = _conv(x, wa, None, (1, stride, stride), (kt // 2, 1, 1))
+        y = _STORE(F.relu(_bn(y, sd, b2 + ".a_bn", training, stats_out)))
+        y = _conv(y, sd[b2 + ".b.weight"], None, (1, 1, 1), (0, dilation, dilation), (1, dilation, dilation))
+        y = _bn(y, sd, b2 + ".b_bn", training, stats_out)
+    else:
+        y = _conv(x, wa, None, (1, s_a, s_a), (kt // 2, 0, 0))
+        y = _STORE(F.relu(_bn(y, sd, b2 + ".a_bn", training, stats_out)))
+        y = _conv(y, sd[b2 + ".b.weight"], None, (1, s_b, s_b), (0, dilation, dilation), (1, dilation, dilation))
+        y = _STORE(F.relu(_bn(y, sd, b2 + ".b_bn", training, stats_out)))
+        y = _conv(y, sd[b2 + ".c.weight"])
+        y = _bn(y, sd, b2 + ".c_bn", training, stats_out)
     if prefix + ".branch1.weight" in sd:
         sc = _conv(x, sd[prefix + ".branch1.weight"], None, (1, stride, stride))
         sc = _bn(sc, sd, prefix + ".branch1_bn", training, stats_out)

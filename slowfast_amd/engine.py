@@ -403,17 +403,23 @@ class FuseFn(torch.autograd.Function):
 
 
 class ResBlockFn(torch.autograd.Function):
-    """relu(shortcut(x) + bottleneck(x)) (slowfast/models/resnet_helper.py:377-392, 512-521)."""
+    """relu(shortcut(x) + transform(x)) (slowfast/models/resnet_helper.py:512-521) for a transform that is a chain of
+    conv -> BN [-> ReLU] units ending in the block-final BN: BottleneckTransform (a, b, c; :377-392) and BasicTransform
+    (a, b; :105-115).  Every unit after the first applies its producer's BatchNorm + ReLU in its operand loads."""
 
     @staticmethod
     def forward(ctx, x, mod, *params):
         x = as_cl(x)
-        t = mod.branch2
-        A, B, C, P = t._a, t._b, t._c, mod._proj
+        units, P = mod.branch2._chain, mod._proj
         tr = mod.training
-        ya, sa = A.forward(x, None, tr)
-        yb, sb = B.forward(ya, (sa.scale, sa.shift, True), tr)
-        yc, sc = C.forward(yb, (sb.scale, sb.shift, True), tr)
+        raw, bn = [], []
+        h, prologue = x, None
+        for u in units:
+            h, st = u.forward(h, prologue, tr)
+            raw.append(h)
+            bn.append(st)
+            prologue = (st.scale, st.shift, True)
+        yc, sc = raw[-1], bn[-1]
         if P is not None:
             y1, s1 = P.forward(x, None, tr)
             out = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=y1, rscale=s1.scale, rshift=s1.shift)
@@ -421,36 +427,35 @@ class ResBlockFn(torch.autograd.Function):
             y1, s1 = None, None
             out = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x)
         ctx.mod = mod
-        ctx.raw = (ya, yb, yc, y1)
-        ctx.bn = (sa, sb, sc, s1)
+        ctx.raw = (raw, y1)
+        ctx.bn = (bn, s1)
         ctx.save_for_backward(x, out)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         mod = ctx.mod
-        t = mod.branch2
-        A, B, C, P = t._a, t._b, t._c, mod._proj
+        units, P = mod.branch2._chain, mod._proj
         x, out = ctx.saved_tensors
-        ya, yb, yc, y1 = ctx.raw
-        sa, sb, sc, s1 = ctx.bn
+        raw, y1 = ctx.raw
+        bn, s1 = ctx.bn
         dout = as_cl(dout)
         need_dx = ctx.needs_input_grad[0]
+        last = len(units) - 1
         if P is not None:
-            dyc = C.bn_backward(dout, yc, sc, zmask=out)
+            dy = units[last].bn_backward(dout, raw[last], bn[last], zmask=out)
             dy1 = P.bn_backward(dout, y1, s1, zmask=out)
             g = None
         else:
-            dyc, g = C.bn_backward(dout, yc, sc, zmask=out, want_g=True)
-        d_ab = C.backward(yb, (sb.scale, sb.shift, True), dyc, need_dx=True)
-        dyb = B.bn_backward(d_ab, yb, sb, relu_self=True)
-        d_aa = B.backward(ya, (sa.scale, sa.shift, True), dyb, need_dx=True)
-        dya = A.bn_backward(d_aa, ya, sa, relu_self=True)
+            dy, g = units[last].bn_backward(dout, raw[last], bn[last], zmask=out, want_g=True)
+        for i in range(last, 0, -1):
+            d_in = units[i].backward(raw[i - 1], (bn[i - 1].scale, bn[i - 1].shift, True), dy, need_dx=True)
+            dy = units[i - 1].bn_backward(d_in, raw[i - 1], bn[i - 1], relu_self=True)
         if P is not None:
             dx1 = P.backward(x, None, dy1, need_dx=need_dx)
-            dx = A.backward(x, None, dya, need_dx=need_dx, resid=dx1)
+            dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=dx1)
         else:
-            dx = A.backward(x, None, dya, need_dx=need_dx, resid=g)
+            dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=g)
         _notify(mod._param_list)
         ctx.raw = ctx.bn = None
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)

@@ -31,6 +31,7 @@ class BottleneckTransform(nn.Module):
         self.c_bn = norm_module(num_features=dim_out, **bn)
         self.c_bn.transform_final_bn = True
         self._a, self._b, self._c = ConvUnit(self.a, self.a_bn), ConvUnit(self.b, self.b_bn), ConvUnit(self.c, self.c_bn)
+        self._chain = (self._a, self._b, self._c)
 
     def forward(self, x):
         for unit, relu in ((self._a, True), (self._b, True), (self._c, False)):
@@ -38,8 +39,37 @@ class BottleneckTransform(nn.Module):
         return x
 
 
+class BasicTransform(nn.Module):
+    """Tx3x3 (stride) -> BN -> ReLU -> 1x3x3 (dilated) -> BN; children a, a_bn, a_relu, b, b_bn
+    (slowfast/models/resnet_helper.py:27-115; the ResNet-18/34 style block, RESNET.TRANS_FUNC "basic_transform")."""
+
+    def __init__(self, dim_in, dim_out, temp_kernel_size, stride, dim_inner=None, num_groups=1, stride_1x1=None,
+                 inplace_relu=True, eps=1e-5, bn_mmt=0.1, dilation=1, norm_module=nn.BatchNorm3d, block_idx=0):
+        super().__init__()
+        self.temp_kernel_size = temp_kernel_size
+        self._inplace_relu, self._eps, self._bn_mmt = inplace_relu, eps, bn_mmt
+        bn = dict(eps=eps, momentum=bn_mmt)
+        self.a = nn.Conv3d(dim_in, dim_out, (temp_kernel_size, 3, 3), stride=(1, stride, stride),
+                           padding=(temp_kernel_size // 2, 1, 1), bias=False)
+        self.a_bn = norm_module(num_features=dim_out, **bn)
+        self.a_relu = nn.ReLU(inplace=inplace_relu)
+        self.b = nn.Conv3d(dim_out, dim_out, (1, 3, 3), stride=(1, 1, 1), padding=(0, dilation, dilation),
+                           dilation=(1, dilation, dilation), bias=False)
+        self.b.final_conv = True
+        self.b_bn = norm_module(num_features=dim_out, **bn)
+        self.b_bn.transform_final_bn = True
+        self._a, self._b = ConvUnit(self.a, self.a_bn), ConvUnit(self.b, self.b_bn)
+        self._chain = (self._a, self._b)
+
+    def forward(self, x):
+        for unit, relu in ((self._a, True), (self._b, False)):
+            x = ConvBNActFn.apply(x, unit, relu, self.training, *unit.params())
+        return x
+
+
 BottleneckTransform._block_fn = ResBlockFn
-_TRANS = {"bottleneck_transform": BottleneckTransform}
+BasicTransform._block_fn = ResBlockFn
+_TRANS = {"bottleneck_transform": BottleneckTransform, "basic_transform": BasicTransform}
 
 
 def get_trans_func(name):
@@ -88,10 +118,10 @@ class ResBlock(nn.Module):
     # the weights, ReLU and the residual addition in the GEMM epilogues
     def _sf_fold(self):
         t = self.branch2
-        if not isinstance(t, BottleneckTransform):
+        if not hasattr(t, "_chain"):
             fold = getattr(t, "_sf_fold_in_block", None)     # X3DTransform: its 1x1x1 convolutions fold, the
             return fold(self) if fold is not None else False  # depthwise / SE / Swish middle keeps running statistics
-        for u in (t._a, t._b, t._c, self._proj):
+        for u in tuple(t._chain) + (self._proj,):
             if u is not None:
                 u.fold()
         return True
@@ -99,12 +129,13 @@ class ResBlock(nn.Module):
     def _infer(self, x):
         x = as_cl(x)
         t = self.branch2
-        if not isinstance(t, BottleneckTransform):
+        if not hasattr(t, "_chain"):
             return t._infer_in_block(self, x)
-        ya = t._a.infer(x, relu=True)
-        yb = t._b.infer(ya, relu=True)
+        h = x
+        for u in t._chain[:-1]:
+            h = u.infer(h, relu=True)
         sc = x if self._proj is None else self._proj.infer(x)
-        return t._c.infer(yb, relu=True, resid=sc)
+        return t._chain[-1].infer(h, relu=True, resid=sc)
 
 
 def _fold_time(x, n, t):

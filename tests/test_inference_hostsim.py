@@ -23,7 +23,7 @@ def test_conv_fwd_fused_thin_stem(sim):
     kc.check_conv_fwd_fused(sim, (1, 8, 9, 10, 9), 8, (3, 5, 4), (2, 1, 1), (1, 2, 2), bias=False)
 
 
-@pytest.mark.parametrize("name", ["eval_slowfast_tiny", "eval_c2d_tiny", "eval_slowfast_nln_tiny"])
+@pytest.mark.parametrize("name", ["eval_slowfast_tiny", "eval_c2d_tiny", "eval_slowfast_nln_tiny", "eval_i3d_basic_tiny"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_eval_resnet_family_matches_reference(sim, name, fused):
     """Running-statistics BatchNorm, fully-convolutional head (test crop > train crop), softmax + spatial mean; with

@@ -9,7 +9,7 @@ import pytest
 from tests import model_checks as mc
 
 
-@pytest.mark.parametrize("name", ["slowfast_tiny", "c2d_tiny"])
+@pytest.mark.parametrize("name", ["slowfast_tiny", "c2d_tiny", "i3d_basic_tiny"])       # i3d_basic: RESNET.TRANS_FUNC basic_transform
 def test_engine_wiring_matches_oracle(sim, name):
     mc.check_engine(name, sim, tol_logits=0.15, tol_loss=0.02, tol_gnorm=0.35, tol_param=2.0, tol_stats=0.05)
 

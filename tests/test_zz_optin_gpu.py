@@ -61,3 +61,17 @@ def test_reversible_mvit_gpu(gpu):
     finally:
         print(rep)
     print(mc.check_rev_mvit_drop_path(gpu))
+
+
+def test_basic_transform_gpu(gpu):
+    """RESNET.TRANS_FUNC basic_transform (Tx3x3 -> 1x3x3 blocks) vs the reference: training step, then the eval path
+    running-statistics and inference-fused."""
+    from tests import model_checks as mc
+    rep = {}
+    try:
+        mc.check_engine("i3d_basic_tiny", gpu, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.1, tol_global=1e-2,
+                        report=rep)
+        mc.check_eval("eval_i3d_basic_tiny", gpu, fused=False, report=rep)
+        mc.check_eval("eval_i3d_basic_tiny", gpu, fused=True, report=rep)
+    finally:
+        print(rep)
