@@ -38,7 +38,9 @@ METRIC_NAME = {"SLOWFAST_8x8_R50": "SlowFast-8x8-R50 32x224^2", "C2D_8x8_R50": "
 # synthetic-run overrides: stochastic ops off so that runs are comparable and parity-checkable;
 # BASELINE config 5 is quoted on AVA-shaped 32x256^2 clips (ResNetRoIHead on 3 synthetic boxes per clip)
 PRESET_OPTS = {"MVITv2_S_16x4": ["MVIT.DROPPATH_RATE", 0.0, "MODEL.DROPOUT_RATE", 0.0],
-               "SLOWFAST_32x2_R101_50_50": ["DATA.TRAIN_CROP_SIZE", 256]}
+               "SLOWFAST_32x2_R101_50_50": ["DATA.TRAIN_CROP_SIZE", 256],
+               # the shipped yaml's CLS_EMBED_ON True is rejected by the reference's own constructor (no cls token in rev)
+               "REV_MVIT_B_16x4_CONV": ["MVIT.CLS_EMBED_ON", False, "MVIT.DROPPATH_RATE", 0.0, "MODEL.DROPOUT_RATE", 0.0]}
 BOXES_PER_CLIP = 3           # synthetic AVA batches: boxes (R, 5) = [batch index, x1, y1, x2, y2] in crop pixels
 
 

@@ -22,6 +22,18 @@ for P in "X3D_M 64 x3d" "MVITv2_S_16x4 32 mvit"; do
   SF_DW_FWD_V2=1 SF_DW_DGRAD_V2=1 SF_DW_WGRAD_V2=1 timeout 200 python bench.py --preset $1 --batch $2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_$3_dwv2.log 2>&1
   echo "bench $3 dw-v2 rc=$?"; tail -1 gpurun_out/bench_$3_dwv2.log | cut -c1-330
 done
+# A/B of the opt-in three-stage direct-to-LDS implicit GEMM (SF_IGEMM_GL3=1, DESIGN.md 7: memory-level-parallelism hypothesis)
+for P in "SLOWFAST_8x8_R50 32 slowfast" "MVITv2_S_16x4 32 mvit"; do
+  set -- $P
+  SF_IGEMM_GL3=1 timeout 200 python bench.py --preset $1 --batch $2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_$3_gl3.log 2>&1
+  echo "bench $3 gl3 rc=$?"; tail -1 gpurun_out/bench_$3_gl3.log | cut -c1-330
+done
+# option families added after the round-1 GPU budget ended (hostsim-green): first timing of the larger MViT presets
+for P in "MVIT_B_16x4_CONV 32 mvit_v1" "REV_MVIT_B_16x4_CONV 32 rev_mvit"; do
+  set -- $P
+  timeout 200 python bench.py --preset $1 --batch $2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_$3.log 2>&1
+  echo "bench $3 rc=$?"; tail -1 gpurun_out/bench_$3.log | cut -c1-330
+done
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o slowfast -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile > $GRAFT_REPO_ROOT/gpurun_out/rocprof_slowfast.log 2>&1; echo "rocprof rc=$?"
 cd $GRAFT_REPO_ROOT
