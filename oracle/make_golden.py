@@ -89,6 +89,10 @@ CASES = {
     "x3d_tiny": ("configs/Kinetics/X3D_M.yaml",
                  ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 64,
                   "DATA.NUM_FRAMES", 4, "X3D.DEPTH_FACTOR", 1.0, "X3D.DIM_C5", 256], 4),
+    # X3D.BN_LIN5: BatchNorm between the head's lin_5 and its ReLU (head_helper.py:440-443)
+    "x3d_bnlin5_tiny": ("configs/Kinetics/X3D_M.yaml",
+                        ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 64,
+                         "DATA.NUM_FRAMES", 4, "X3D.DEPTH_FACTOR", 1.0, "X3D.DIM_C5", 256, "X3D.BN_LIN5", True], 4),
     # MViTv2: a 4-block miniature (every block type: q-pooling, dim change, k/v pooling, rel-pos) and the full
     # 16-block MViTv2-S at a reduced clip size
     "mvit_tiny": ("configs/Kinetics/MVITv2_S_16x4.yaml",

@@ -219,7 +219,8 @@ def x3d_block(x, sd, prefix, stride, training, stats_out):
 
 
 def x3d_forward(sd, cfg, inputs, training=True, stats_out=None):
-    """X3D.forward (video_model_builder.py:799-802) + X3DHead.forward (head_helper.py:461-488); BN_LIN5 False."""
+    """X3D.forward (video_model_builder.py:799-802) + X3DHead.forward (head_helper.py:461-488); with X3D.BN_LIN5 the
+    head has a BatchNorm between lin_5 and its ReLU (head_helper.py:440-443, 470-471)."""
     x = x3d_stem(inputs[0], sd, "s1.pathway0_stem", training, stats_out)
     for s in range(2, 6):
         i = 0
@@ -232,7 +233,10 @@ def x3d_forward(sd, cfg, inputs, training=True, stats_out=None):
     # extent at the training crop, a sliding window (fully-convolutional inference) at a larger test crop
     spat = -(-cfg.DATA.TRAIN_CROP_SIZE // 32)
     x = F.avg_pool3d(x, (cfg.DATA.NUM_FRAMES, spat, spat), 1)
-    x = F.relu(F.conv3d(x, sd["head.lin_5.weight"]))
+    x = F.conv3d(x, sd["head.lin_5.weight"])
+    if "head.lin_5_bn.weight" in sd:
+        x = _bn(x, sd, "head.lin_5_bn", training, stats_out)
+    x = F.relu(x)
     z = F.linear(x.permute(0, 2, 3, 4, 1), sd["head.projection.weight"], sd["head.projection.bias"])
     if not training:
         z = F.softmax(z, dim=4).mean([1, 2, 3])

@@ -404,8 +404,6 @@ class X3DHead(nn.Module):
     def __init__(self, dim_in, dim_inner, dim_out, num_classes, pool_size, dropout_rate=0.0, act_func="softmax",
                  inplace_relu=True, eps=1e-5, bn_mmt=0.1, norm_module=nn.BatchNorm3d, bn_lin5_on=False):
         super().__init__()
-        if bn_lin5_on:
-            raise NotImplementedError("X3D.BN_LIN5")
         self.pool_size, self.dropout_rate, self.num_classes, self.act_func = pool_size, dropout_rate, num_classes, act_func
         self.eps, self.bn_mmt, self.inplace_relu, self.bn_lin5_on = eps, bn_mmt, inplace_relu, bn_lin5_on
         self.conv_5 = nn.Conv3d(dim_in, dim_inner, kernel_size=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0), bias=False)
@@ -413,6 +411,8 @@ class X3DHead(nn.Module):
         self.conv_5_relu = nn.ReLU(inplace_relu)
         self.avg_pool = nn.AdaptiveAvgPool3d((1, 1, 1)) if pool_size is None else nn.AvgPool3d(pool_size, stride=1)
         self.lin_5 = nn.Conv3d(dim_inner, dim_out, kernel_size=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0), bias=False)
+        if bn_lin5_on:                      # X3D.BN_LIN5 (head_helper.py:440-443): on the pooled (B, dim_out, 1, 1, 1) features,
+            self.lin_5_bn = norm_module(num_features=dim_out, eps=eps, momentum=bn_mmt)   # fp32 torch like the FC layers
         self.lin_5_relu = nn.ReLU(inplace_relu)
         if dropout_rate > 0.0:
             self.dropout = nn.Dropout(dropout_rate)
@@ -431,7 +431,10 @@ class X3DHead(nn.Module):
         if self.pool_size is not None and tuple(self.pool_size) != tuple(x.shape[2:]):
             return self._forward_sliding(x)
         m = X3DHeadPoolFn.apply(x, self, self.conv_5.weight, self.conv_5_bn.weight, self.conv_5_bn.bias)
-        z = torch.relu(torch.nn.functional.linear(m, self.lin_5.weight.view(self.lin_5.out_channels, -1)))
+        z = torch.nn.functional.linear(m, self.lin_5.weight.view(self.lin_5.out_channels, -1))
+        if self.bn_lin5_on:
+            z = self.lin_5_bn(z.view(z.shape[0], -1, 1, 1, 1)).view(z.shape[0], -1)
+        z = torch.relu(z)
         if hasattr(self, "dropout"):
             z = self.dropout(z)
         z = self.projection(z)
@@ -448,7 +451,10 @@ class X3DHead(nn.Module):
         y = ConvBNActFn.apply(x, unit, True, self.training, *unit.params())
         y = y[:, :self.conv_5.out_channels].float()
         z = self.avg_pool(y.contiguous())
-        z = torch.relu(torch.nn.functional.conv3d(z, self.lin_5.weight)).permute(0, 2, 3, 4, 1)
+        z = torch.nn.functional.conv3d(z, self.lin_5.weight)
+        if self.bn_lin5_on:
+            z = self.lin_5_bn(z)
+        z = torch.relu(z).permute(0, 2, 3, 4, 1)
         if hasattr(self, "dropout"):
             z = self.dropout(z)
         z = self.projection(z)

@@ -29,6 +29,12 @@ def test_x3d_engine_matches_oracle(sim):
                     tol_stats=5e-3)
 
 
+def test_x3d_bn_lin5_matches_oracle(sim):
+    """X3D.BN_LIN5: BatchNorm between the head's lin_5 and its ReLU (head_helper.py:440-443, 470-471)."""
+    mc.check_engine("x3d_bnlin5_tiny", sim, tol_logits=1e-2, tol_loss=2e-3, tol_gnorm=2e-2, tol_param=0.5, tol_global=0.3,
+                    tol_stats=5e-3)
+
+
 def test_nonlocal_engine_matches_oracle(sim):
     """SlowFast with Nonlocal blocks (dot-product affinity, (2,2,2) max-pool of the phi/g input) on res3/res4."""
     mc.check_engine("slowfast_nln_tiny", sim, tol_logits=2e-2, tol_loss=5e-3, tol_gnorm=2e-2, tol_param=1.0, tol_global=0.5,

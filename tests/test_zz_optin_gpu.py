@@ -75,3 +75,9 @@ def test_basic_transform_gpu(gpu):
         mc.check_eval("eval_i3d_basic_tiny", gpu, fused=True, report=rep)
     finally:
         print(rep)
+
+
+def test_x3d_bn_lin5_gpu(gpu):
+    from tests import model_checks as mc
+    print(mc.check_engine("x3d_bnlin5_tiny", gpu, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.1,
+                          tol_global=1e-2))
