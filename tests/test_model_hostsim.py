@@ -29,6 +29,44 @@ def test_x3d_engine_matches_oracle(sim):
                     tol_stats=5e-3)
 
 
+def test_precise_bn_protocol_on_drop_ins(sim):
+    """`calculate_and_update_precise_bn` (tools/train_net.py:425-446) hands the model to fvcore's ``update_bn_stats``, which
+    relies on three properties of the BatchNorm modules it finds by isinstance: a train-mode forward under
+    ``torch.no_grad()`` updates ``running_mean`` / ``running_var``, the update honours the module's CURRENT ``momentum``
+    (fvcore sets it to 1.0 so that the buffers hold the batch statistics of the last forward), and the buffers are plain
+    tensors it may overwrite afterwards.  Checked on the SlowFast drop-in against the oracle's batch statistics."""
+    import torch
+    import slowfast_amd as sa
+    from oracle import video_ref
+    gold = mc.load_golden("slowfast_tiny")
+    cfg = mc.cfg_for(gold)
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    sd = video_ref.randomize_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, gold["param_seed"])
+    model.load_state_dict(sd)
+    inputs, labels = video_ref.synthetic_batch(cfg, gold["batch"], gold["data_seed"])
+    _, _, _, o_stats = video_ref.loss_and_grads(sd, cfg, inputs, labels)        # oracle: momentum 0.1 update of sd's buffers
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    assert len(bns) > 20
+    for bn in bns:
+        bn.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(inputs)
+    msd = model.state_dict()
+    worst = 0.0
+    for k, new in o_stats.items():
+        batch_stat = (new - 0.9 * sd[k]) / 0.1                  # what the oracle's update averaged in
+        err = float((msd[k].float() - batch_stat).abs().max() / (batch_stat.abs().max() + 1e-6))
+        worst = max(worst, err)
+    assert worst < 5e-2, worst                                  # tiny-model conditioning (see module docstring)
+    for bn in bns:                                              # fvcore then writes its averages back and restores momentum
+        bn.running_mean.copy_(torch.zeros_like(bn.running_mean))
+        bn.momentum = 0.1
+    with torch.no_grad():
+        out = model.eval()(inputs)
+    assert torch.isfinite(out.float()).all()
+
+
 def test_x3d_bn_lin5_matches_oracle(sim):
     """X3D.BN_LIN5: BatchNorm between the head's lin_5 and its ReLU (head_helper.py:440-443, 470-471)."""
     mc.check_engine("x3d_bnlin5_tiny", sim, tol_logits=1e-2, tol_loss=2e-3, tol_gnorm=2e-2, tol_param=0.5, tol_global=0.3,
