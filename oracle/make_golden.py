@@ -141,6 +141,15 @@ CASES = {
                        "MVIT.EMBED_DIM", 32, "MVIT.DIM_MUL", "[[1, 2.0], [3, 2.0]]", "MVIT.HEAD_MUL", "[[1, 2.0], [3, 2.0]]",
                        "MVIT.POOL_Q_STRIDE", "[[1, 1, 2, 2], [3, 1, 2, 2]]", "MVIT.POOL_KV_STRIDE_ADAPTIVE", "[1, 4, 4]",
                        "MVIT.REV.BUFFER_LAYERS", "[1, 3]", "MVIT.CLS_EMBED_ON", False, "MIXUP.ENABLE", False], 2),
+    # MViT detection (video_model_builder.py:1034-1045, 1218-1226): the final norm on every token, tokens back to
+    # (B, C, T, H, W), ResNetRoIHead on 3 boxes per clip with BCE (ROIAlign: the oracle's restatement, as in slowfast_ava_roi_tiny)
+    "mvit_ava_roi_tiny": ("configs/Kinetics/MVITv2_S_16x4.yaml",
+                  ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MVIT.DROPPATH_RATE", 0.0, "MODEL.NUM_CLASSES", 10,
+                   "DATA.TRAIN_CROP_SIZE", 64, "DATA.TEST_CROP_SIZE", 64, "DATA.NUM_FRAMES", 8, "MVIT.DEPTH", 4,
+                   "MVIT.EMBED_DIM", 32, "MVIT.DIM_MUL", "[[1, 2.0], [3, 2.0]]", "MVIT.HEAD_MUL", "[[1, 2.0], [3, 2.0]]",
+                   "MVIT.POOL_Q_STRIDE", "[[0, 1, 1, 1], [1, 1, 2, 2], [2, 1, 1, 1], [3, 1, 2, 2]]",
+                   "MVIT.POOL_KV_STRIDE_ADAPTIVE", "[1, 4, 4]", "MIXUP.ENABLE", False, "DETECTION.ENABLE", True,
+                   "MODEL.HEAD_ACT", "sigmoid", "MODEL.LOSS_FUNC", "bce"], 2, {"boxes": 3}),
     # POOL_FIRST (attention.py:296-301, 339-351): the normed block input is folded into heads and pooled before the
     # q / k / v Linears; MViTv1 layout (the family POOL_FIRST was introduced with), cls token on
     "mvit_poolfirst_tiny": ("configs/Kinetics/MVIT_B_16x4_CONV.yaml",

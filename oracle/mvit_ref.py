@@ -261,7 +261,7 @@ def mvit_plan(cfg):
     return plan
 
 
-def mvit_forward(sd, cfg, inputs, training=True, drop=None):
+def mvit_forward(sd, cfg, inputs, training=True, drop=None, bboxes=None):
     """MViT.forward (video_model_builder.py:1166-1244) with or without the cls token (CLS_EMBED_ON), learned absolute
     position embedding (joint or SEP_POS_EMBED) or none, no dropout, + TransformerBasicHead.forward
     (head_helper.py:538-563).  drop = per-block
@@ -297,6 +297,11 @@ def mvit_forward(sd, cfg, inputs, training=True, drop=None):
         x, thw = block(x, sd, f"blocks.{i}", thw, heads, sq, skv, has_cls=has_cls, drop=None if drop is None else drop[i],
                        residual_pooling=cfg.MVIT.RESIDUAL_POOLING, dim_mul_in_att=cfg.MVIT.DIM_MUL_IN_ATT,
                        pool_first=cfg.MVIT.POOL_FIRST)
+    if cfg.DETECTION.ENABLE:            # video_model_builder.py:1218-1226: norm, drop cls, tokens -> (B, C, T, H, W), RoI head
+        x = _ln(x, sd, "norm")
+        x = x[:, 1:] if has_cls else x
+        x = x.transpose(1, 2).reshape(x.shape[0], x.shape[2], thw[0], thw[1], thw[2])
+        return _vr.roi_head([x], sd, cfg, bboxes, training)
     if cfg.MVIT.USE_MEAN_POOLING:       # video_model_builder.py:1228-1232: mean over the patch tokens, then norm
         x = _ln(x[:, 1:].mean(1) if has_cls else x.mean(1), sd, "norm")
     elif has_cls:
@@ -334,10 +339,11 @@ def randomize_state(shapes, seed, dtype=torch.float32):
     return sd
 
 
-def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32, drop=None):
+def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32, drop=None, bboxes=None):
     params = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
-    logits = mvit_forward(params, cfg, [x.to(dtype) for x in inputs], training=True, drop=drop)
-    loss = F.cross_entropy(logits, labels)
+    logits = mvit_forward(params, cfg, [x.to(dtype) for x in inputs], training=True, drop=drop, bboxes=bboxes)
+    # detection head: BCE on the activated outputs (losses.py:61-69 "bce")
+    loss = F.binary_cross_entropy(logits, labels.to(dtype)) if bboxes is not None else F.cross_entropy(logits, labels)
     loss.backward()
     grads = {k: v.grad for k, v in params.items() if v.grad is not None}
     return logits.detach(), loss.detach(), grads, {}

@@ -17,7 +17,8 @@ import torch.nn as nn
 from torch.nn.init import trunc_normal_
 
 from .engine import StemConvUnit
-from .mvit_engine import AttentionPlan, ClsNormFn, LinearUnit, MultiScaleBlockFn, NormUnit, PatchEmbedFn, QKVUnit
+from .mvit_engine import (AttentionPlan, ClsNormFn, LinearUnit, MultiScaleBlockFn, NormUnit, PatchEmbedFn, QKVUnit,
+                          TokenNormFn)
 from .registry import MODEL_REGISTRY
 
 
@@ -239,15 +240,15 @@ class MViT(nn.Module):
         unsupported = [k for k, bad in (
             ("PATCH_2D", m.PATCH_2D),
             ("USE_FIXED_SINCOS_POS", m.USE_FIXED_SINCOS_POS), ("NORM_STEM", m.NORM_STEM),
-            ("LAYER_SCALE_INIT_VALUE", m.LAYER_SCALE_INIT_VALUE > 0), ("DROPOUT_RATE", m.DROPOUT_RATE > 0),
-            ("DETECTION.ENABLE", cfg.DETECTION.ENABLE)) if bad]
+            ("LAYER_SCALE_INIT_VALUE", m.LAYER_SCALE_INIT_VALUE > 0), ("DROPOUT_RATE", m.DROPOUT_RATE > 0)) if bad]
         # MODEL.ACT_CHECKPOINT (video_model_builder.py:1041-1042: torch checkpoint_wrapper around every block) trades
         # recomputation for activation memory and changes no value; the engine already saves only GEMM / pooling
         # outputs and sizes for 288 GB of HBM, so the key is accepted and has no effect.
         if unsupported or m.NORM != "layernorm" or m.MODE != "conv":
             raise NotImplementedError(f"MViT options outside the built video path: {unsupported}")
         self.cfg = cfg
-        self.enable_detection, self.enable_rev = False, bool(m.REV.ENABLE)
+        self.enable_detection, self.enable_rev = bool(cfg.DETECTION.ENABLE), bool(m.REV.ENABLE)
+        assert not (self.enable_detection and self.enable_rev), "rev does not support detection"
         self.patch_stride = list(m.PATCH_STRIDE)
         self.T = cfg.DATA.NUM_FRAMES // self.patch_stride[0]
         self.H = cfg.DATA.TRAIN_CROP_SIZE // self.patch_stride[1]
@@ -330,8 +331,17 @@ class MViT(nn.Module):
             embed_dim = dim_out
         self.norm = norm_layer(embed_dim)
         self._norm_unit = NormUnit(self.norm)
-        self.head = TransformerBasicHead(embed_dim, self.num_classes, dropout_rate=cfg.MODEL.DROPOUT_RATE,
-                                         act_func=cfg.MODEL.HEAD_ACT, cfg=cfg)
+        if self.enable_detection:                  # video_model_builder.py:1034-1045
+            from .heads import ResNetRoIHead
+            self.head = ResNetRoIHead(dim_in=[embed_dim], num_classes=self.num_classes,
+                                      pool_size=[[cfg.DATA.NUM_FRAMES // self.patch_stride[0], 1, 1]],
+                                      resolution=[[cfg.DETECTION.ROI_XFORM_RESOLUTION] * 2],
+                                      scale_factor=[cfg.DETECTION.SPATIAL_SCALE_FACTOR],
+                                      dropout_rate=cfg.MODEL.DROPOUT_RATE, act_func=cfg.MODEL.HEAD_ACT,
+                                      aligned=cfg.DETECTION.ALIGNED)
+        else:
+            self.head = TransformerBasicHead(embed_dim, self.num_classes, dropout_rate=cfg.MODEL.DROPOUT_RATE,
+                                             act_func=cfg.MODEL.HEAD_ACT, cfg=cfg)
         if self.use_abs_pos:                       # video_model_builder.py:1066-1075
             if self.sep_pos_embed:
                 trunc_normal_(self.pos_embed_spatial, std=0.02)
@@ -389,6 +399,11 @@ class MViT(nn.Module):
         else:
             for blk in self.blocks:
                 x, thw = blk(x, thw)
+        if self.enable_detection:                  # video_model_builder.py:1218-1226
+            x = TokenNormFn.apply(x, self, self.cls_embed_on, self.norm.weight, self.norm.bias)
+            B, _, C = x.shape
+            x = x.view(B, thw[0], thw[1], thw[2], C).permute(0, 4, 1, 2, 3)     # channels-last (B, C, T, H, W), no copy
+            return self.head([x], bboxes)
         # video_model_builder.py:1154-1161, 1226-1238: mean of the patch tokens then norm / norm of the cls rows / norm then mean
         mode = "mean_norm" if self.use_mean_pooling else ("cls" if self.cls_embed_on else "norm_mean")
         x = ClsNormFn.apply(x, self, mode, self.cls_embed_on, self.norm.weight, self.norm.bias)

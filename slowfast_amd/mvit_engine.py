@@ -735,3 +735,32 @@ class ClsNormFn(torch.autograd.Function):
                 dx[:, 0] = dxc
         _notify(ctx.unit.params())
         return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class TokenNormFn(torch.autograd.Function):
+    """The detection path's final LayerNorm (video_model_builder.py:1218-1224): norm of every token, cls row dropped;
+    the (B, T*H*W, C) result IS the channels-last memory of the (B, C, T, H, W) feature map the RoI head consumes."""
+
+    @staticmethod
+    def forward(ctx, x, mod, has_cls, *params):
+        unit = mod._norm_unit
+        s = int(bool(has_cls))
+        B, N, C = x.shape
+        xt = x[:, s:].contiguous() if s else x
+        y, m, r = unit.forward(xt.view(B * (N - s), C))
+        ctx.unit, ctx.xt, ctx.st, ctx.shape, ctx.s = unit, xt, (m, r), tuple(x.shape), s
+        return y.view(B, N - s, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, C = ctx.shape
+        s = ctx.s
+        dxt = ctx.unit.backward(_f16c(dy).view(-1, C), ctx.xt.view(-1, C), *ctx.st).view(B, N - s, C)
+        if s:
+            dx = torch.empty(ctx.shape, dtype=_f16, device=dy.device)
+            dx[:, :1] = 0
+            dx[:, 1:] = dxt
+        else:
+            dx = dxt
+        _notify(ctx.unit.params())
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

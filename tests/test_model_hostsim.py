@@ -177,6 +177,17 @@ def test_mvit_attention_options_match_reference(sim, name, fused_attn, monkeypat
         print(rep)
 
 
+def test_mvit_detection_matches_reference(sim):
+    """MViT with DETECTION.ENABLE (video_model_builder.py:1034-1045, 1218-1226): final norm on every token, the token tensor
+    viewed as the channels-last (B, C, T, H, W) feature map, ResNetRoIHead on 3 boxes per clip, BCE."""
+    rep = {}
+    try:
+        mc.check_engine("mvit_ava_roi_tiny", sim, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.2, tol_global=1e-2,
+                        report=rep)
+    finally:
+        print(rep)
+
+
 def test_reversible_mvit_matches_reference(sim):
     """Reversible MViT (configs/Kinetics/REV_MVIT_B_16x4_CONV.yaml family): two-stream ReversibleBlocks, StageTransitionBlocks
     (stream average, residual through the attention's own pool_q + norm_q and res_proj), norm over the concatenated

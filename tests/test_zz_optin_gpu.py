@@ -81,3 +81,9 @@ def test_x3d_bn_lin5_gpu(gpu):
     from tests import model_checks as mc
     print(mc.check_engine("x3d_bnlin5_tiny", gpu, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.1,
                           tol_global=1e-2))
+
+
+def test_mvit_detection_gpu(gpu):
+    from tests import model_checks as mc
+    print(mc.check_engine("mvit_ava_roi_tiny", gpu, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=2e-3, tol_param=0.2,
+                          tol_global=1e-2))
