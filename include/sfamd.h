@@ -172,7 +172,9 @@ int sf_gelu_bwd(int64_t n, const void* h, const void* da, void* dh, sf_stream_t 
 /* Depthwise Conv3d(C, C, k, stride, padding, groups = C) on channels-last rows; C may be heads*Cw with one weight
  * [Cw][taps] shared by the heads (MViT pool_q/k/v, attention.py:227-266); cls != 0: token tensors whose cls row is
  * routed around the convolution (attention.py:24-36).  Also X3DTransform.b (resnet_helper.py:214-224) and the
- * X3D stem's (5,1,1) temporal conv (stem_helper.py:267-275).  ldx / ldy = pitches of input / output rows. */
+ * X3D stem's (5,1,1) temporal conv (stem_helper.py:267-275).  ldx / ldy = pitches of input / output rows.
+ * Any kernel extent with kT*kH*kW*Cw <= 12288 (LDS weight image): 3x3x3 / (5,1,1) take the W-blocked stencils, wider planes
+ * (MViTv1's stride+1 pooling kernels 1x5x5, 1x9x9) the generic ones, their weight gradient in chunks of 9 taps. */
 typedef struct sf_dw_desc {
     int32_t N, C, Cw, cls;
     int32_t Ti, Hi, Wi, To, Ho, Wo;
