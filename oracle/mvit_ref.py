@@ -339,11 +339,23 @@ def randomize_state(shapes, seed, dtype=torch.float32):
     return sd
 
 
-def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32, drop=None, bboxes=None):
-    params = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
-    logits = mvit_forward(params, cfg, [x.to(dtype) for x in inputs], training=True, drop=drop, bboxes=bboxes)
+def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32, drop=None, bboxes=None, device=None,
+                   autocast_dtype=None, loss_scale=1.0):
+    """fp32 oracle by default; ``device`` / ``autocast_dtype`` / ``loss_scale``: the same graph under torch.autocast with
+    a fixed loss scale, as the reference trains with TRAIN.MIXED_PRECISION (see video_ref.loss_and_grads)."""
+    import contextlib
+    dev = torch.device(device or "cpu")
+    params = {k: v.detach().to(dev, dtype).clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    ctx = torch.autocast(dev.type, dtype=autocast_dtype) if autocast_dtype is not None else contextlib.nullcontext()
+    if drop is not None and dev.type != "cpu":
+        drop = [tuple(s.to(dev) for s in d) if isinstance(d, (tuple, list)) else d.to(dev) for d in drop]
+    with ctx:
+        logits = mvit_forward(params, cfg, [x.to(dev, dtype) for x in inputs], training=True, drop=drop,
+                              bboxes=bboxes.to(dev) if bboxes is not None else None)
+    labels = labels.to(dev)
     # detection head: BCE on the activated outputs (losses.py:61-69 "bce")
-    loss = F.binary_cross_entropy(logits, labels.to(dtype)) if bboxes is not None else F.cross_entropy(logits, labels)
-    loss.backward()
-    grads = {k: v.grad for k, v in params.items() if v.grad is not None}
-    return logits.detach(), loss.detach(), grads, {}
+    loss = F.binary_cross_entropy(logits.float(), labels.float()) if bboxes is not None else F.cross_entropy(logits.float(), labels)
+    (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+    grads = {k: (v.grad.float() / loss_scale).cpu() if (loss_scale != 1.0 or dev.type != "cpu") else v.grad
+             for k, v in params.items() if v.grad is not None}
+    return logits.detach().float().cpu(), loss.detach().float().cpu(), grads, {}

@@ -271,8 +271,8 @@ def roi_align(feat, rois, out_size, spatial_scale, sampling_ratio=0, aligned=Tru
         gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rh / oh))
         gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rw / ow))
         count = max(gh * gw, 1)
-        ys = y1 + (torch.arange(oh, dtype=feat.dtype)[:, None] * bh + (torch.arange(gh, dtype=feat.dtype)[None, :] + 0.5) * bh / max(gh, 1))
-        xs = x1 + (torch.arange(ow, dtype=feat.dtype)[:, None] * bw + (torch.arange(gw, dtype=feat.dtype)[None, :] + 0.5) * bw / max(gw, 1))
+        ys = y1 + (torch.arange(oh, dtype=feat.dtype, device=feat.device)[:, None] * bh + (torch.arange(gh, dtype=feat.dtype, device=feat.device)[None, :] + 0.5) * bh / max(gh, 1))
+        xs = x1 + (torch.arange(ow, dtype=feat.dtype, device=feat.device)[:, None] * bw + (torch.arange(gw, dtype=feat.dtype, device=feat.device)[None, :] + 0.5) * bw / max(gw, 1))
         ys, xs = ys.reshape(-1), xs.reshape(-1)                  # (oh*gh), (ow*gw)
         vy = ((ys >= -1.0) & (ys <= H)).to(feat.dtype)
         vx = ((xs >= -1.0) & (xs <= W)).to(feat.dtype)
@@ -288,7 +288,7 @@ def roi_align(feat, rois, out_size, spatial_scale, sampling_ratio=0, aligned=Tru
         v = (f[:, y0][:, :, x0] * (hy[:, None] * hx[None, :]) + f[:, y0][:, :, x1i] * (hy[:, None] * lx[None, :])
              + f[:, y1i][:, :, x0] * (ly[:, None] * hx[None, :]) + f[:, y1i][:, :, x1i] * (ly[:, None] * lx[None, :]))
         v = v * (vy[:, None] * vx[None, :])
-        v = v.reshape(C, oh, gh, ow, gw).sum((2, 4)) / count if gh * gw > 0 else torch.zeros((C, oh, ow), dtype=feat.dtype)
+        v = v.reshape(C, oh, gh, ow, gw).sum((2, 4)) / count if gh * gw > 0 else torch.zeros((C, oh, ow), dtype=feat.dtype, device=feat.device)
         out.append(v)
     return torch.stack(out, 0) if out else feat.new_zeros((0, C, oh, ow))
 
@@ -432,22 +432,38 @@ def synthetic_boxes(cfg, batch, seed, per_clip=3):
     return torch.tensor(rows, dtype=torch.float32)
 
 
-def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32, bboxes=None):
+def loss_and_grads(sd, cfg, inputs, labels, dtype=torch.float32, bboxes=None, device=None, autocast_dtype=None,
+                   loss_scale=1.0):
     """Training-mode forward + mean cross-entropy (BCE on the activated outputs for the detection head, losses.py:61-69
-    "bce") + backward; returns logits, loss, {name: grad}, new running stats."""
-    params = {k: v.detach().to(dtype).clone().requires_grad_(v.is_floating_point() and "running" not in k)
+    "bce") + backward; returns logits, loss, {name: grad}, new running stats (all on the CPU).
+
+    ``device`` / ``autocast_dtype`` / ``loss_scale`` run the SAME graph the way the reference trains under
+    TRAIN.MIXED_PRECISION (tools/train_net.py:113-172): forward and loss under ``torch.autocast``, ``scale * loss``
+    backward, gradients unscaled afterwards (GradScaler with a fixed scale).  That mode is the reference-derived
+    yardstick for what fp16 compute costs on a case (tools/autocast_yardstick.py); the default is the fp32 oracle."""
+    import contextlib
+    dev = torch.device(device or "cpu")
+    params = {k: v.detach().to(dev, dtype).clone().requires_grad_(v.is_floating_point() and "running" not in k)
               for k, v in sd.items() if v.is_floating_point()}
     stats = {}
     fwd = x3d_forward if cfg.MODEL.MODEL_NAME == "X3D" else video_forward
+    ctx = torch.autocast(dev.type, dtype=autocast_dtype) if autocast_dtype is not None else contextlib.nullcontext()
+    xs = [x.to(dev, dtype) for x in inputs]
+    labels = labels.to(dev)
+    with ctx:
+        if bboxes is not None:
+            logits = fwd(params, cfg, xs, training=True, stats_out=stats, bboxes=bboxes.to(dev))
+        else:
+            logits = fwd(params, cfg, xs, training=True, stats_out=stats)
     if bboxes is not None:
-        logits = fwd(params, cfg, [x.to(dtype) for x in inputs], training=True, stats_out=stats, bboxes=bboxes)
-        loss = F.binary_cross_entropy(logits, labels.to(dtype))
+        loss = F.binary_cross_entropy(logits.float(), labels.float())
     else:
-        logits = fwd(params, cfg, [x.to(dtype) for x in inputs], training=True, stats_out=stats)
-        loss = F.cross_entropy(logits, labels)
-    loss.backward()
-    grads = {k: v.grad for k, v in params.items() if v.requires_grad}
-    return logits.detach(), loss.detach(), grads, stats
+        loss = F.cross_entropy(logits.float(), labels)
+    (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+    grads = {k: (v.grad.float() / loss_scale).cpu() if (loss_scale != 1.0 or dev.type != "cpu") else v.grad
+             for k, v in params.items() if v.requires_grad}
+    stats = {k: v.detach().float().cpu() for k, v in stats.items()}
+    return logits.detach().float().cpu(), loss.detach().float().cpu(), grads, stats
 
 
 def grad_norm(grads):
