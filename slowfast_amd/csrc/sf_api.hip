@@ -3,6 +3,7 @@
 #include "sf_bn.h"
 #include "sf_common.h"
 #include "sf_igemm.h"
+#include "sf_igemm2.h"
 #include "sf_pool.h"
 #include "sf_dwconv.h"
 #include "sf_tokens.h"
@@ -173,7 +174,67 @@ static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s, int nbatc
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second-generation implicit GEMM (sf_igemm2.h): taken when the contraction is deep enough to pay for a 256-row tile
+// with a three-stage direct-to-LDS pipeline.  SF_IGEMM2=0 disables it, SF_IGEMM2_MINK sets the smallest K (default 512).
+template <int BN, int BK>
+static void launch_igemm2(Igemm2Params& q, hipStream_t s) {
+    q.ntiles_n = cdiv(q.Nout, BN);
+    const dim3 grid((unsigned)(cdiv(q.M, 256) * q.ntiles_n));
+    hipLaunchKernelGGL((sf_igemm2_kernel<256, BN, 4, 2, BK, 3>), grid, dim3(512), 0, s, q);
+}
+static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
+    // read on every call (three getenv per launch are noise): tests lower the thresholds for single cases
+    const char* e;
+    const bool off = (e = getenv("SF_IGEMM2")) && atoi(e) == 0;
+    const int mink = (e = getenv("SF_IGEMM2_MINK")) ? atoi(e) : 512;
+    const int minrows = (e = getenv("SF_IGEMM2_MINROWS")) ? atoi(e) : 4096;
+    const GatherSide& g = p.g;
+    if (off || nbatch != 1 || g.scale) return false;
+    if (p.bh > 1 || (p.bh == 1 && (p.sa_b | p.sa_h | p.sw_b | p.sw_h | p.sy_b | p.sy_h | p.sr_b | p.sr_h))) return false;
+    const int taps = g.kT * g.kH * g.kW;
+    if (taps > SF_I2_MAXTAPS || g.C % 32 != 0 || g.Ktot != taps * g.C || g.Ktot < mink) return false;
+    if (p.Nout <= 32 || p.M < minrows) return false;
+    if (g.mode == 1 && !(g.strT == 1 && g.strH == 1 && g.strW == 1)) return false;
+    if (g.ld % 8 != 0 || p.ldw % 8 != 0 || p.ldw < g.Ktot) return false;
+    if (((uintptr_t)g.src | (uintptr_t)p.wmat) & 15) return false;
+    if ((g.kT - 1) * g.dilT > 127 || (g.kH - 1) * g.dilH > 127 || (g.kW - 1) * g.dilW > 127) return false;
+    Igemm2Params q;
+    memset(&q, 0, sizeof(q));
+    q.src = g.src; q.ld = g.ld; q.C = g.C;
+    q.sT = g.sT; q.sH = g.sH; q.sW = g.sW;
+    q.fdrW = g.fdrW; q.fdrH = g.fdrH; q.fdrT = g.fdrT;
+    const int sgn = g.mode == 0 ? 1 : -1;
+    if (g.mode == 0) {
+        q.mulT = g.strT; q.mulH = g.strH; q.mulW = g.strW;
+        q.offT = -g.padT; q.offH = -g.padH; q.offW = -g.padW;
+    } else {
+        q.mulT = q.mulH = q.mulW = 1;
+        q.offT = g.padT; q.offH = g.padH; q.offW = g.padW;
+    }
+    q.ntaps = taps;
+    int t = 0;
+    for (int kt = 0; kt < g.kT; ++kt)
+        for (int kh = 0; kh < g.kH; ++kh)
+            for (int kw = 0; kw < g.kW; ++kw, ++t) {
+                const int dt = sgn * kt * g.dilT, dh = sgn * kh * g.dilH, dw = sgn * kw * g.dilW;
+                q.dt[t] = (int8_t)dt; q.dh[t] = (int8_t)dh; q.dw[t] = (int8_t)dw;
+                q.taps[t].dlin = (dt * g.sH + dh) * g.sW + dw;
+                q.taps[t].wcol = t * g.C;
+            }
+    q.M = p.M; q.wmat = p.wmat; q.ldw = p.ldw; q.Nout = p.Nout;
+    q.y = p.y; q.ldy = p.ldy; q.bias = p.bias; q.resid = p.resid; q.ldr = p.ldr; q.stat_part = p.stat_part;
+    q.act_mode = p.act_mode; q.act_aux = p.act_aux; q.ld_aux = p.ld_aux; q.resid_row0 = p.resid_row0; q.alpha = p.alpha;
+    const bool bk64 = g.C % 64 == 0;
+    static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+    if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d K=%d taps=%d BK=%d mode=%d\n", p.M, p.Nout, g.Ktot, taps, bk64 ? 64 : 32, g.mode);
+    if (p.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }
+    else { if (bk64) launch_igemm2<64, 64>(q, s); else launch_igemm2<64, 32>(q, s); }
+    return true;
+}
+
 static int run_igemm(IgemmParams& p, bool pw, hipStream_t s) {
+    if (try_igemm2(p, s)) return check_launch("igemm2");
     if (p.Nout > 64) { p.ntiles_n = cdiv(p.Nout, 128); launch_igemm<128, 64, 64>(p, pw, s); }
     else if (p.Nout > 32) { p.ntiles_n = 1; launch_igemm<64, 32, 64>(p, pw, s); }
     else if (p.Nout > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, pw, s); }
@@ -707,6 +768,7 @@ extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t 
     p.bh = bh; p.sa_b = sa_b; p.sa_h = sa_h; p.sw_b = sw_b; p.sw_h = sw_h; p.sy_b = sy_b; p.sy_h = sy_h;
     p.sr_b = sr_b; p.sr_h = sr_h; p.resid_row0 = resid_row0; p.alpha = alpha;
     hipStream_t s = (hipStream_t)stream;
+    if (try_igemm2(p, s, nbatch)) return check_launch("bgemm2");
     if (N > 64) { p.ntiles_n = cdiv(N, 128); launch_igemm<128, 64, 64>(p, true, s, nbatch); }
     else if (N > 32) { p.ntiles_n = 1; launch_igemm<64, 32, 64>(p, true, s, nbatch); }
     else if (N > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, true, s, nbatch); }
@@ -732,6 +794,7 @@ extern "C" int sf_gemm_act(int64_t M, int32_t N, int32_t K, const void* A, int32
     p.bh = 1;
     p.act_mode = mode; p.act_aux = (f16*)aux; p.ld_aux = ldaux;
     hipStream_t s = (hipStream_t)stream;
+    if (try_igemm2(p, s, 1)) return check_launch("gemm_act2");
     if (N > 64) { p.ntiles_n = cdiv(N, 128); launch_igemm<128, 64, 64>(p, true, s, 1); }
     else if (N > 32) { p.ntiles_n = 1; launch_igemm<64, 32, 64>(p, true, s, 1); }
     else if (N > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, true, s, 1); }

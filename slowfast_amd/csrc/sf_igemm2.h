@@ -1,0 +1,302 @@
+// Implicit-GEMM convolution, second generation (gfx950): every operand travels global -> LDS directly.
+//
+// Same contraction as sf_igemm.h (reference call sites: slowfast/models/resnet_helper.py:331-369 BottleneckTransform a/b/c,
+// :485-493 ResBlock.branch1, video_model_builder.py:147-154 FuseFastToSlow.conv_f2s; nn.Linear of attention.py / common.py):
+//   Y[m, n] = sum_{tap, c} SRC[pos(m) + delta(tap)][c] * W[n][wcol(tap) + c]
+// What changed against the first kernel (profiles/r2_*: its loaders were VALU-bound -- three magic-number divisions, bounds
+// checks and a BatchNorm transform per 16-byte operand group and K step -- and every 32-deep K step ended in vmcnt(0) + barrier):
+//   * a K step never straddles a tap (C % BK == 0), so the tap of a step is WAVE-UNIFORM: one scalar table lookup per step,
+//     no per-lane tap decomposition.  A lane keeps, for the rows it copies, the element offset of the row's base position and
+//     a bit mask "tap t stays inside the source" (decoded once, before the loop).
+//   * operands are copied with global_load_lds_dwordx4 (per-lane source address, lane-linear LDS image): padding taps read a
+//     16-byte line of zeros instead of the tensor.  No staging registers, no ds_write pass.  The XOR bank swizzle of the
+//     ds_read_b128 fragment reads is applied on the SOURCE side (which 16-byte K slot a lane fetches).
+//   * BK = 64 (one 128-byte line per row and step), a ring of THREE stages and counted s_waitcnt vmcnt: two stages are in
+//     flight while one is multiplied; ONE raw s_barrier per step.
+//   * 256 x BN tiles, 8 waves (2 per SIMD): (256 + BN) * 64 * 2 bytes per 256 * BN * 64 MACs -- 48 B/clk/CU at BN = 128,
+//     under what the L2 delivers (~56 B/clk/CU); the 128 x 128 x 32 tile needed 64 B/clk/CU.
+// The producer's BatchNorm + ReLU is NOT applied here: engine.ResBlockFn materialises relu(bn(y)) once (engine.MATERIALIZE).
+#pragma once
+#include "sf_common.h"
+
+#define SF_I2_MAXTAPS 32
+
+// raw workgroup barrier that does NOT drain the direct-to-LDS copies in flight (__syncthreads() would: its fence waits
+// vmcnt(0)).  LDS reads of this wave are retired first (WAR: another wave may overwrite the stage after the barrier).
+#ifndef SF_BARRIER_KEEP_VMEM
+#define SF_BARRIER_KEEP_VMEM()                                          \
+    do {                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+        __builtin_amdgcn_s_barrier();                                   \
+        asm volatile("" ::: "memory");                                  \
+    } while (0)
+#endif
+
+// 16 bytes of zeros every padding tap reads (the module's own constant: the callee allocates nothing)
+__device__ __attribute__((aligned(64))) const uint32_t sf_zero_line[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+struct Igemm2Tap {
+    int32_t dlin;       // linear source-position offset of the tap: (dt*sH + dh)*sW + dw
+    int32_t wcol;       // first column of the tap in the weight matrix
+};
+
+struct Igemm2Params {
+    const f16* src;     // gathered operand, rows of C channels at pitch ld
+    int ld, C;
+    int sT, sH, sW;     // source extents
+    FastDiv fdrW, fdrH, fdrT;               // row -> (n, a, b, c) over the row space
+    int mulT, mulH, mulW, offT, offH, offW; // base source coordinate of a row: a*mulT + offT, ...
+    int ntaps;
+    int8_t dt[SF_I2_MAXTAPS], dh[SF_I2_MAXTAPS], dw[SF_I2_MAXTAPS];    // tap displacement (source coordinates)
+    Igemm2Tap taps[SF_I2_MAXTAPS];
+    int M;
+    const f16* wmat;    // [Nout][ldw]
+    int ldw, Nout;
+    f16* y;
+    int ldy;
+    const float* bias;
+    const f16* resid;
+    int ldr;
+    float* stat_part;   // [ceil(M / 128)][2][Nout]
+    int ntiles_n;
+    int act_mode;
+    f16* act_aux;
+    int ld_aux;
+    int resid_row0;
+    float alpha;
+};
+
+// LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase
+// serves hit 16 distinct bank slots (MI355X_MICROARCH.md, LDS table; checked for every lane group by tools/lds_swizzle_check.py)
+template <int BK>
+__device__ __forceinline__ int i2_lds_off(int row, int kslot) {
+    if constexpr (BK == 64) return row * 64 + ((kslot ^ (row & 7)) << 3);
+    else return lds_tile_off(row, kslot);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NST>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) void sf_igemm2_kernel(Igemm2Params p) {
+    constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int KSL = BK / 8;                 // 16-byte slots per row
+    constexpr int RPI = 64 / KSL;               // rows one wave instruction copies (8 at BK = 64, 16 at BK = 32)
+    constexpr int NA = BM / RPI / NW;           // A copies per wave and stage
+    constexpr int NBI = BN / RPI;               // B copy instructions per stage (all waves together)
+    constexpr int NB = (NBI + NW - 1) / NW;
+    static_assert(BM % (RPI * NW) == 0, "A tile: whole copy instructions per wave");
+    static_assert(NBI % NW == 0 || NBI < NW, "B tile: uniform copy count per wave or one partial round");
+    static_assert(BM % 128 == 0, "statistics are kept per 128 rows");
+    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int STG_LD = BN + 8;
+    constexpr int SMEM_MAIN = NST * STAGE, SMEM_STG = BM * STG_LD;
+    constexpr int SMEM = SMEM_MAIN > SMEM_STG ? SMEM_MAIN : SMEM_STG;
+    constexpr int HALVES = BM / 128, WPH = WAVES_M / HALVES;    // 128-row statistic groups, wave rows per group
+    static_assert(WAVES_M % HALVES == 0, "a wave row belongs to one 128-row group");
+
+    // ONE LDS object (hipcc serialises direct-to-LDS copies against ds_reads of any other __shared__ object)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SMEM * 2 + WAVES_M * 2 * BN * 4];
+    f16* const smem = reinterpret_cast<f16*>(lds_raw);
+    float (*const s_red)[2][BN] = reinterpret_cast<float (*)[2][BN]>(lds_raw + SMEM * 2);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tile = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = tile % p.ntiles_n, mt = tile / p.ntiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- loader state: the rows this lane copies in every stage (instruction j of the wave -> rows (wave + NW*j)*RPI ..)
+    const int lrow = lane / KSL;                                    // row inside a copy instruction
+    int kslot;                                                      // logical 16-byte K slot this lane fetches
+    if constexpr (BK == 64) kslot = (lane & 7) ^ (lrow & 7);
+    else kslot = ((lane & 3) - 2 * ((lrow >> 2) & 3)) & 3;          // inverse of lds_tile_off()'s rotation
+    int64_t aoff[NA];
+    uint32_t amask[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int m = m0 + (wave + NW * j) * RPI + lrow;
+        if (m >= p.M) m = p.M - 1;                                  // clamped rows are computed and never stored
+        uint32_t q, a, b, c, n;
+        fd_divmod((uint32_t)m, p.fdrW, q, c);
+        fd_divmod(q, p.fdrH, q, b);
+        fd_divmod(q, p.fdrT, n, a);
+        const int bt = (int)a * p.mulT + p.offT, bh = (int)b * p.mulH + p.offH, bw = (int)c * p.mulW + p.offW;
+        aoff[j] = ((((int64_t)n * p.sT + bt) * p.sH + bh) * p.sW + bw) * (int64_t)p.ld + kslot * 8;
+        uint32_t mk = 0;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int st = bt + p.dt[t], sh = bh + p.dh[t], sw = bw + p.dw[t];
+            const bool ok = (unsigned)st < (unsigned)p.sT && (unsigned)sh < (unsigned)p.sH && (unsigned)sw < (unsigned)p.sW;
+            mk |= (ok ? 1u : 0u) << t;
+        }
+        amask[j] = mk;
+    }
+    const f16* bptr[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int co = n0 + (wave + NW * j) * RPI + lrow;
+        if (co >= p.Nout) co = p.Nout - 1;
+        bptr[j] = p.wmat + (int64_t)co * p.ldw + kslot * 8;
+    }
+    const f16* const zline = reinterpret_cast<const f16*>(sf_zero_line);
+    const int csteps = p.C / BK;                                    // K steps per tap
+    const int ksteps = p.ntaps * csteps;
+
+    // stage (tap, channel chunk c0) -> LDS buffer `buf`
+    auto issue = [&](int tap, int c0, int buf) {
+        f16* As = smem + buf * STAGE;
+        f16* Bs = As + A_ELEMS;
+        const int64_t dsrc = (int64_t)p.taps[tap].dlin * p.ld + c0;
+        const int wk = p.taps[tap].wcol + c0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const f16* g = ((amask[j] >> tap) & 1u) ? p.src + (aoff[j] + dsrc) : zline;
+            SF_GLOBAL_LOAD_LDS16(g, As + (wave + NW * j) * 512);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (NBI % NW == 0 || wave + NW * j < NBI) SF_GLOBAL_LOAD_LDS16(bptr[j] + wk, Bs + (wave + NW * j) * 512);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const f16* As = smem + buf * STAGE;
+        const f16* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = ld16(As + i2_lds_off<BK>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = ld16(Bs + i2_lds_off<BK>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: stages ks + 1 (and ks + 2 at NST == 3) are in flight while stage ks is multiplied
+    {
+        // copies one wave issues per stage: the count s_waitcnt vmcnt leaves outstanding (uniform over the waves whenever
+        // NBI % NW == 0; a partial last round only makes some waves wait for one copy more than necessary)
+        constexpr int COPIES = NA + (NBI % NW == 0 ? NB : NB - 1);
+        int tap_i = 0, c_i = 0;                                     // (tap, chunk) of the next stage to issue
+        auto advance = [&]() { c_i += BK; if (c_i == p.C) { c_i = 0; ++tap_i; } };
+        int issued = 0;
+        for (; issued < NST - 1 && issued < ksteps; ++issued) { issue(tap_i, c_i, issued); advance(); }
+        int cur = 0, nxt = NST - 1;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            if constexpr (NST == 3) {
+                if (ks + 1 < ksteps) SF_WAIT_VMEM_N(COPIES);        // stage ks landed, stage ks + 1 may still be in flight
+                else SF_WAIT_VMEM();
+            } else {
+                SF_WAIT_VMEM();
+            }
+            SF_BARRIER_KEEP_VMEM();                                 // ... for every wave; stage ks - 1 is no longer read
+            if (issued < ksteps) { issue(tap_i, c_i, nxt); advance(); ++issued; }
+            compute(cur);
+            cur = cur == NST - 1 ? 0 : cur + 1;
+            nxt = nxt == NST - 1 ? 0 : nxt + 1;
+        }
+        __syncthreads();                                            // the epilogue staging reuses the operand buffers
+    }
+
+    // ---------------- epilogue: scale, bias, BatchNorm partial statistics (fp32, from the accumulators)
+    {
+        const float alpha = p.alpha != 0.f ? p.alpha : 1.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int colj = n0 + wn * WN + j * 16 + (lane & 15);
+            const float b = (p.bias && colj < p.Nout) ? p.bias[colj] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha + b;
+        }
+    }
+    if (p.stat_part) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool rowok = m0 + wm * WM + i * 16 + 4 * (lane >> 4) + r < p.M;
+                    const float v = rowok ? acc[i][j][r] : 0.f;
+                    s += v;
+                    q += v * v;
+                }
+            s = wave_sum_over_row_groups(s);
+            q = wave_sum_over_row_groups(q);
+            if (lane < 16) {
+                s_red[wm][0][wn * WN + j * 16 + lane] = s;
+                s_red[wm][1][wn * WN + j * 16 + lane] = q;
+            }
+        }
+    }
+    f16* stg = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * WN + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * WM + i * 16 + 4 * (lane >> 4) + r;
+                stg[row * STG_LD + col] = (f16)acc[i][j][r];
+            }
+        }
+    __syncthreads();
+    if (p.stat_part && tid < HALVES * BN) {
+        const int half = tid / BN, c = tid % BN;
+        const int col = n0 + c;
+        const int prow = mt * HALVES + half;                        // statistics rows are 128 positions each
+        if (col < p.Nout && (int64_t)prow * 128 < p.M) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPH; ++w) {
+                s += s_red[half * WPH + w][0][c];
+                q += s_red[half * WPH + w][1][c];
+            }
+            p.stat_part[((int64_t)prow * 2 + 0) * p.Nout + col] = s;
+            p.stat_part[((int64_t)prow * 2 + 1) * p.Nout + col] = q;
+        }
+    }
+    constexpr int CG = BN / 8;
+    for (int idx = tid; idx < BM * CG; idx += NT) {
+        const int row = idx / CG, cg = idx % CG;
+        const int m = m0 + row, col = n0 + cg * 8;
+        if (m < p.M && col < p.Nout) {
+            f16x8 v = ld16(stg + row * STG_LD + cg * 8);
+            if (p.resid && m >= p.resid_row0) {
+                f16x8 r = ld16(p.resid + (int64_t)m * p.ldr + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)r[e]);
+            }
+            if (p.act_mode == 2) {
+                const f16x8 h = ld16(p.act_aux + (int64_t)m * p.ld_aux + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * gelu_df((float)h[e]));
+            }
+            if (p.act_mode == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > (f16)0.f ? v[e] : (f16)0.f;
+            }
+            st16(p.y + (int64_t)m * p.ldy + col, v);
+            if (p.act_mode == 1) {
+                f16x8 a;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
+                st16(p.act_aux + (int64_t)m * p.ld_aux + col, a);
+            }
+        }
+    }
+}

@@ -19,6 +19,8 @@ Parameter gradients are written straight into ``param.grad`` (fp32; accumulated 
 exists, which is how GradReducer's flat bucket views receive them) and ``grad_ready`` listeners are
 told which parameters are final, so the gradient all-reduce can overlap the rest of backward.
 """
+import os
+
 import torch
 
 from . import ops
@@ -29,6 +31,9 @@ _listeners = []
 # repack must be part of the captured work unconditionally: a replay runs after an optimizer update that the
 # host-side version check below never sees.
 FORCE_WEIGHT_PREP = False
+# Intermediate activations of a block (relu(bn_a(ya)), relu(bn_b(yb))) are materialised in fp16 (default) or recomputed
+# in the consumer's operand loads (SF_MATERIALIZE=0, the round-1 schedule; kept for A/B runs).
+MATERIALIZE = os.environ.get("SF_MATERIALIZE", "1") != "0"
 
 
 def add_grad_ready_listener(fn):
@@ -412,13 +417,21 @@ class ResBlockFn(torch.autograd.Function):
         x = as_cl(x)
         units, P = mod.branch2._chain, mod._proj
         tr = mod.training
-        raw, bn = [], []
+        raw, bn, act = [], [], []
         h, prologue = x, None
-        for u in units:
+        for i, u in enumerate(units):
             h, st = u.forward(h, prologue, tr)
             raw.append(h)
             bn.append(st)
-            prologue = (st.scale, st.shift, True)
+            if MATERIALIZE and i + 1 < len(units):
+                # z = relu(bn(y)) written once (C/4-wide tensors): the consumer convolution and its weight gradient
+                # then read a plain operand -- direct-to-LDS copies, no per-element work in the GEMM loaders
+                h = ops.bn_act(h, st.scale, st.shift, relu=True)
+                act.append(h)
+                prologue = None
+            else:
+                act.append(None)
+                prologue = (st.scale, st.shift, True)
         yc, sc = raw[-1], bn[-1]
         if P is not None:
             y1, s1 = P.forward(x, None, tr)
@@ -427,7 +440,7 @@ class ResBlockFn(torch.autograd.Function):
             y1, s1 = None, None
             out = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x)
         ctx.mod = mod
-        ctx.raw = (raw, y1)
+        ctx.raw = (raw, y1, act)
         ctx.bn = (bn, s1)
         ctx.save_for_backward(x, out)
         return out
@@ -437,7 +450,7 @@ class ResBlockFn(torch.autograd.Function):
         mod = ctx.mod
         units, P = mod.branch2._chain, mod._proj
         x, out = ctx.saved_tensors
-        raw, y1 = ctx.raw
+        raw, y1, act = ctx.raw
         bn, s1 = ctx.bn
         dout = as_cl(dout)
         need_dx = ctx.needs_input_grad[0]
@@ -449,7 +462,10 @@ class ResBlockFn(torch.autograd.Function):
         else:
             dy, g = units[last].bn_backward(dout, raw[last], bn[last], zmask=out, want_g=True)
         for i in range(last, 0, -1):
-            d_in = units[i].backward(raw[i - 1], (bn[i - 1].scale, bn[i - 1].shift, True), dy, need_dx=True)
+            if act[i - 1] is not None:
+                d_in = units[i].backward(act[i - 1], None, dy, need_dx=True)
+            else:
+                d_in = units[i].backward(raw[i - 1], (bn[i - 1].scale, bn[i - 1].shift, True), dy, need_dx=True)
             dy = units[i - 1].bn_backward(d_in, raw[i - 1], bn[i - 1], relu_self=True)
         if P is not None:
             dx1 = P.backward(x, None, dy1, need_dx=need_dx)

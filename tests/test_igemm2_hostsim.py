@@ -1,0 +1,49 @@
+"""CPU: the second-generation implicit GEMM (csrc/sf_igemm2.h: wave-uniform taps, direct-to-LDS gathered operands, 256-row
+tiles, three-stage ring) through the host functional simulator, against F.conv3d on identical fp16-rounded operands.
+
+The launcher only takes this kernel for deep contractions on many rows; the ``force_v2`` fixture lowers the thresholds
+(environment knobs the dispatcher reads on every call) so that small shapes run it too."""
+import pytest
+
+from tests import kernel_checks as kc
+
+
+@pytest.fixture()
+def force_v2(monkeypatch):
+    monkeypatch.setenv("SF_IGEMM2", "1")
+    monkeypatch.setenv("SF_IGEMM2_MINK", "32")
+    monkeypatch.setenv("SF_IGEMM2_MINROWS", "1")
+
+CASES = [
+    # in_shape (N,Ci,T,H,W), Co, kernel, stride, pad, dil
+    ((1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),       # BK 64, 9 taps, M=162 (one ragged tile), BN 64
+    ((2, 64, 3, 12, 12), 136, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),    # M=864 (4 tiles), two N tiles, ragged N
+    ((1, 128, 4, 6, 6), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),      # temporal taps, two channel chunks per tap
+    ((1, 32, 2, 10, 10), 40, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),     # BK 32, stride 2 (forward only takes it)
+    ((1, 96, 1, 8, 8), 72, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),       # BK 32 (96 = 3 x 32), dilation 2
+    ((1, 64, 8, 4, 4), 128, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 1, 1)),      # lateral: 7 temporal taps, stride 4
+    ((2, 192, 1, 20, 20), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),   # plain GEMM, K=192 (3 steps), 800 rows
+    ((1, 64, 3, 5, 5), 96, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),       # 27 taps
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_igemm2_fwd(sim, force_v2, case):
+    kc.check_conv_fwd(sim, *case)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_igemm2_dgrad(sim, force_v2, case):
+    kc.check_conv_dgrad(sim, *case)
+
+
+def test_igemm2_dgrad_residual(sim, force_v2):
+    kc.check_conv_dgrad(sim, (1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), resid=True)
+
+
+def test_igemm2_fused_epilogue(sim, force_v2):
+    kc.check_conv_fwd_fused(sim, (1, 64, 2, 9, 9), 72, (1, 3, 3), (1, 1, 1), (0, 1, 1), resid=True, relu=True)
+
+
+def test_igemm2_channel_slice_input(sim, force_v2):
+    kc.check_conv_fwd(sim, (1, 64, 1, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), ldx_extra=16)

@@ -24,6 +24,39 @@ BIG_CASES = [
 ]
 
 
+# deep contractions on many rows: the launcher takes the second-generation implicit GEMM (csrc/sf_igemm2.h: 256-row tiles,
+# three-stage direct-to-LDS ring) -- many tiles per CU and tens of K steps, which is what exposes a pipelining race
+IGEMM2_CASES = [
+    ((8, 64, 4, 28, 28), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),       # 25088 rows, BN 64, 9 taps
+    ((8, 256, 4, 14, 14), 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),     # 6272 rows, K 2304
+    ((4, 1024, 4, 14, 14), 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),    # K 3072, temporal taps
+    ((8, 128, 4, 28, 28), 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),     # stride 2 (forward)
+    ((4, 2048, 4, 7, 7), 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),      # res5: 784 rows x K 6144 (below the row cut)
+    ((16, 96, 2, 20, 20), 288, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),     # BK 32 (96 channels), ragged N
+]
+
+
+@pytest.mark.parametrize("case", IGEMM2_CASES)
+def test_igemm2(gpu, case):
+    kc.check_conv_fwd(gpu, *case)
+    kc.check_conv_dgrad(gpu, *case)
+
+
+def test_igemm2_small_shapes_forced(gpu):
+    """The hostsim case list of the second-generation kernel on hardware, thresholds lowered through the environment
+    (a subprocess: the dispatcher reads them once)."""
+    code = ("import torch; from tests import kernel_checks as kc; from tests.test_igemm2_hostsim import CASES;"
+            "d=torch.device('cuda:0');"
+            "[ (kc.check_conv_fwd(d,*c), kc.check_conv_dgrad(d,*c)) for c in CASES ];"
+            "kc.check_conv_dgrad(d,(1,64,2,9,9),64,(1,3,3),(1,1,1),(0,1,1),resid=True);"
+            "kc.check_conv_fwd_fused(d,(1,64,2,9,9),72,(1,3,3),(1,1,1),(0,1,1),resid=True,relu=True); print('ok')")
+    env = dict(os.environ, SF_IGEMM2_MINK="32", SF_IGEMM2_MINROWS="1")
+    env.pop("SFAMD_LIBRARY", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("case", CONV_CASES + BIG_CASES)
 def test_conv_fwd(gpu, case):
     kc.check_conv_fwd(gpu, *case)
