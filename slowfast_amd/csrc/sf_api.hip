@@ -225,7 +225,11 @@ static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     q.M = p.M; q.wmat = p.wmat; q.ldw = p.ldw; q.Nout = p.Nout;
     q.y = p.y; q.ldy = p.ldy; q.bias = p.bias; q.resid = p.resid; q.ldr = p.ldr; q.stat_part = p.stat_part;
     q.act_mode = p.act_mode; q.act_aux = p.act_aux; q.ld_aux = p.ld_aux; q.resid_row0 = p.resid_row0; q.alpha = p.alpha;
-    const bool bk64 = g.C % 64 == 0;
+    // SF_IGEMM2_BK=32 forces the 32-deep K step (24 KB stages: two workgroups per CU) for A/B runs
+    // SF_IGEMM2_BK64_MINK: contractions shallower than this take the 32-deep step (two workgroups per CU overlap one
+    // tile's epilogue with the other's loads, which is what short-K, bandwidth-bound layers need)
+    const int bk64_mink = (e = getenv("SF_IGEMM2_BK64_MINK")) ? atoi(e) : 1024;
+    const bool bk64 = g.C % 64 == 0 && g.Ktot >= bk64_mink && !((e = getenv("SF_IGEMM2_BK")) && atoi(e) == 32);
     static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d K=%d taps=%d BK=%d mode=%d\n", p.M, p.Nout, g.Ktot, taps, bk64 ? 64 : 32, g.mode);
     if (p.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }

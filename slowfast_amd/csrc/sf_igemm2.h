@@ -187,8 +187,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) vo
         // copies one wave issues per stage: the count s_waitcnt vmcnt leaves outstanding (uniform over the waves whenever
         // NBI % NW == 0; a partial last round only makes some waves wait for one copy more than necessary)
         constexpr int COPIES = NA + (NBI % NW == 0 ? NB : NB - 1);
+        // K order: channel chunk OUTER, tap INNER -- the taps of a chunk re-read (shifted) the same 128-byte lines of the
+        // rows around the tile, so 8 of 9 gathers of a 3x3 convolution hit the caches instead of walking the whole row
+        // set once per tap (reuse distance rows * 128 B instead of rows * C * 2 B)
         int tap_i = 0, c_i = 0;                                     // (tap, chunk) of the next stage to issue
-        auto advance = [&]() { c_i += BK; if (c_i == p.C) { c_i = 0; ++tap_i; } };
+        auto advance = [&]() { if (++tap_i == p.ntaps) { tap_i = 0; c_i += BK; } };
         int issued = 0;
         for (; issued < NST - 1 && issued < ksteps; ++issued) { issue(tap_i, c_i, issued); advance(); }
         int cur = 0, nxt = NST - 1;

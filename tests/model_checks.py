@@ -88,8 +88,30 @@ def check_oracle_against_golden(name):
         assert abs(float(stats.get(k, sd[k]).double().sum()) - s) <= 1e-4 * max(1.0, abs(s)), k
 
 
-YARD = 2.5
+# How far the engine may sit above the reference-derived yardstick of a case (one realisation of rounding noise against
+# another: a factor, not equality).
+YARD = 1.5
 _yard_cache = {}
+_autocast = None
+
+
+def autocast_yardstick(name):
+    """What the reference's OWN mixed-precision path costs on this case: the deviation of the pinned oracle graph under
+    ``torch.autocast(float16)`` on PyTorch-ROCm (MIOpen / rocBLAS kernels, fixed loss scale) from its fp32 run, measured on
+    an MI355X by tools/autocast_yardstick.py and committed as tests/golden/autocast_yardstick.json (the GPU box of the
+    test run has no /root/reference, and the number must not depend on this repository's kernels).  None when the case
+    has no finite entry."""
+    global _autocast
+    if _autocast is None:
+        path = os.path.join(GOLDEN_DIR, "autocast_yardstick.json")
+        _autocast = json.load(open(path)) if os.path.exists(path) else {}
+    rec = _autocast.get(name)
+    if not rec or "error" in rec or not rec.get("finite", False):
+        return None
+    keys = ("logits", "loss", "grad_norm", "grad_global", "param_grad_worst", "running_stats")
+    if not all(isinstance(rec.get(k), float) and rec[k] == rec[k] and rec[k] != float("inf") for k in keys):
+        return None
+    return {k: rec[k] for k in keys}
 
 
 def _global_rel(grads, ref):
@@ -134,14 +156,21 @@ def storage_model_yardstick(name, sd, cfg, inputs, labels, o_logits, o_loss, o_g
 
 def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=1e-3, tol_param=2e-2,
                  tol_stats=2e-3, tol_global=1e-2, report=None):
-    """Forward + CE + backward of the drop-in model on `device` vs the oracle (and the golden numbers).
+    """Forward + CE + backward of the drop-in model on `device` vs the fp32 oracle (and the golden numbers).
 
-    Each bound is max(tol_*, YARD x the fp16-storage-model deviation of the same quantity), see
-    storage_model_yardstick()."""
+    Bound per quantity: ``max(tol_*, YARD x yardstick)`` where the yardstick is REFERENCE-DERIVED -- the deviation of the
+    reference graph itself under torch.autocast(float16) on the same case (autocast_yardstick()).  A case without a finite
+    autocast entry falls back to the oracle's fp16 storage model (storage_model_yardstick(); reported as such).  The
+    gradient-norm bound also admits 0.5 * bound(grad_global)^2: an error vector of relative size e that is uncorrelated
+    with the gradient lengthens it by e^2 / 2 (|g + d|^2 = |g|^2 + |d|^2), whatever produced it."""
     gold = load_golden(name)
     cfg = cfg_for(gold)
     model, sd, inputs, labels, o_logits, o_loss, o_grads, o_stats = oracle_run(gold, cfg)
-    yard = storage_model_yardstick(name, sd, cfg, inputs, labels, o_logits, o_loss, o_grads, o_stats)
+    yard = autocast_yardstick(name)
+    kind = "autocast"
+    if yard is None:
+        yard = storage_model_yardstick(name, sd, cfg, inputs, labels, o_logits, o_loss, o_grads, o_stats)
+        kind = "storage-model"
     model.load_state_dict(sd)
     model = model.to(device).train()
     logits = _forward(model, inputs, device)
@@ -149,11 +178,11 @@ def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, t
     (loss * loss_scale).backward()
     res = {}
     res["logits"] = float((logits.detach().float().cpu() - o_logits).abs().max() / o_logits.abs().max())
-    res["loss"] = abs(float(loss) - float(o_loss)) / max(1.0, abs(float(o_loss)))
+    res["loss"] = abs(float(loss.detach()) - float(o_loss)) / max(1.0, abs(float(o_loss)))
     grads = {k: p.grad.detach().float().cpu() / loss_scale for k, p in model.named_parameters()}
     gn, ogn = float(video_ref.grad_norm(grads)), float(video_ref.grad_norm(o_grads))
     res["grad_norm"] = abs(gn - ogn) / ogn
-    res["golden_loss"] = abs(float(loss) - gold["loss"]) / max(1.0, abs(gold["loss"]))
+    res["golden_loss"] = abs(float(loss.detach()) - gold["loss"]) / max(1.0, abs(gold["loss"]))
     res["golden_grad_norm"] = abs(gn - gold["grad_norm"]) / gold["grad_norm"]
     res["grad_global"] = _global_rel(grads, o_grads)
     res["param_grad_worst"], res["param_grad_worst_name"] = _param_worst(grads, o_grads, ogn)
@@ -161,20 +190,35 @@ def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, t
     res["running_stats"] = max(
         [float((msd[k].float().cpu() - v).abs().max() / (v.abs().max() + 1e-6)) for k, v in o_stats.items()] + [0.0])
     res["yardstick"] = yard
-    if report is not None:
-        report[name] = res
+    res["yardstick_kind"] = kind
 
     def bound(key, tol):
         return max(tol, YARD * yard[key])
 
+    b_gnorm = max(bound("grad_norm", tol_gnorm), 0.5 * bound("grad_global", tol_global) ** 2)
+    res["bounds"] = {"logits": bound("logits", tol_logits), "loss": bound("loss", tol_loss), "grad_norm": b_gnorm,
+                     "grad_global": bound("grad_global", tol_global), "param_grad_worst": bound("param_grad_worst", tol_param),
+                     "running_stats": bound("running_stats", tol_stats)}
+    if report is not None:
+        report[name] = res
+    _record(name, device, res)
     assert res["logits"] <= bound("logits", tol_logits), res
     assert res["loss"] <= bound("loss", tol_loss) and res["golden_loss"] <= bound("loss", tol_loss), res
-    assert res["grad_norm"] <= bound("grad_norm", tol_gnorm), res
-    assert res["golden_grad_norm"] <= bound("grad_norm", tol_gnorm) + 1e-4, res
+    assert res["grad_norm"] <= b_gnorm, res
+    assert res["golden_grad_norm"] <= b_gnorm + 1e-4, res
     assert res["grad_global"] <= bound("grad_global", tol_global), res
     assert res["param_grad_worst"] <= bound("param_grad_worst", tol_param), res
     assert res["running_stats"] <= bound("running_stats", tol_stats), res
     return res
+
+
+def _record(name, device, res):
+    """Append the measured deviations to $SF_PARITY_REPORT (a JSON-lines file): the GPU visit scripts collect them so the
+    margins against the yardstick are on record (profiles/)."""
+    path = os.environ.get("SF_PARITY_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"case": name, "device": str(device), **{k: v for k, v in res.items()}}) + "\n")
 
 
 def check_rev_mvit_drop_path(device, rate=0.5, tol_logits=1e-2, tol_gnorm=1e-2, tol_global=3e-2):

@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--json", default="")
     ap.add_argument("--filter", default="")
+    ap.add_argument("--no-bn", action="store_true", help="skip the BatchNorm / activation kernels (GEMM variant sweeps)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
@@ -87,7 +88,7 @@ def main():
         sh = torch.zeros(Ci, device=dev)
         macs = geom.out_rows * Co * (3 * k[0] * 49 if stem else Cw * geom.taps)   # useful MACs
         t_f = timeit(lambda: ops.conv_fwd(x, wf, geom, out=y), a.iters)
-        t_fa = timeit(lambda: ops.conv_fwd(x, wf, geom, in_affine=(sc, sh, True), out=y), a.iters) if Ci <= 512 else float("nan")
+        t_fa = timeit(lambda: ops.conv_fwd(x, wf, geom, in_affine=(sc, sh, True), out=y), a.iters) if Ci <= 512 and not a.no_bn else float("nan")
         dx = ops.cl_empty(geom.in_shape, dev)
         t_d = timeit(lambda: ops.conv_dgrad(dy, wd, geom, out=dx), a.iters) if "stem" not in name else 0.0
         t_w = timeit(lambda: ops.conv_wgrad(x, dy, geom, dw), a.iters)
@@ -95,9 +96,12 @@ def main():
         rm = torch.zeros(Co, device=dev); rv = torch.ones(Co, device=dev)
         scale, shift, mean, rstd = ops.bn_finalize(part, geom.out_rows, gamma, beta, rm, rv, 0.1, 1e-5)
         z = ops.cl_empty(geom.out_shape, dev)
-        t_act = timeit(lambda: ops.bn_act(y, scale, shift, relu=True, out=z), a.iters)
         dgm = torch.empty(Co, device=dev); dbt = torch.empty(Co, device=dev)
-        t_bb = timeit(lambda: ops.bn_bwd(dy, y, gamma, mean, rstd, dgm, dbt, relu_affine=(scale, shift), out=z), a.iters)
+        if a.no_bn:
+            t_act = t_bb = float("nan")
+        else:
+            t_act = timeit(lambda: ops.bn_act(y, scale, shift, relu=True, out=z), a.iters)
+            t_bb = timeit(lambda: ops.bn_bwd(dy, y, gamma, mean, rstd, dgm, dbt, relu_affine=(scale, shift), out=z), a.iters)
         bytes_io = 2.0 * (x.numel() * Cw / Ci + y.numel())
         row = dict(name=name, count=cnt, gmac=macs / 1e9, fwd_ms=t_f, fwd_affine_ms=t_fa, dgrad_ms=t_d, wgrad_ms=t_w,
                    bn_act_ms=t_act, bn_bwd_ms=t_bb, fwd_tflops=2 * macs / t_f / 1e9,
@@ -105,7 +109,7 @@ def main():
                    fwd_gbs=bytes_io / t_f / 1e6, act_gbs=2.0 * 2 * y.numel() / t_act / 1e6,
                    bnbwd_gbs=2.0 * 5 * y.numel() / t_bb / 1e6)
         rows.append(row)
-        tot["fwd"] += cnt * t_f; tot["dgrad"] += cnt * t_d; tot["wgrad"] += cnt * t_w; tot["bn"] += cnt * (t_act + t_bb)
+        tot["fwd"] += cnt * t_f; tot["dgrad"] += cnt * t_d; tot["wgrad"] += cnt * t_w; tot["bn"] += 0.0 if a.no_bn else cnt * (t_act + t_bb)
         print(f"{name:30s} x{cnt} {macs/1e9:7.1f} GMAC | fwd {t_f:7.3f} ms {row['fwd_tflops']:7.1f} TF {row['fwd_gbs']:7.0f} GB/s "
               f"(+bn {t_fa:7.3f}) | dgrad {t_d:7.3f} ms {row['dgrad_tflops']:7.1f} TF | wgrad {t_w:7.3f} ms {row['wgrad_tflops']:7.1f} TF "
               f"| act {t_act:6.3f} ms {row['act_gbs']:6.0f} GB/s | bnbwd {t_bb:6.3f} ms {row['bnbwd_gbs']:6.0f} GB/s", flush=True)
