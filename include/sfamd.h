@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 13
+#define SF_ABI_VERSION 14
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -59,9 +59,12 @@ int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf, const floa
  *   y = act(conv(x) + bias [+ resid]),   act = ReLU when out_relu.   bias [Co] fp32 (may be NULL), resid [M][ldr] fp16. */
 int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const void* wf, const float* bias, const void* resid,
                       int32_t ldr, int out_relu, void* y, sf_stream_t stream);
-/* dx = conv_transpose(dy, w) (+ resid), dx pitch = d->ldx, dy pitch = d->ldy */
-int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr, void* dx,
-                  sf_stream_t stream);
+/* dx = conv_transpose(dy, w) (+ resid), dx pitch = d->ldx, dy pitch = d->ldy.  resid_bits (optional, with resid): the
+ * 1-bit ReLU mask sf_bn_act wrote for the block input ([positions][Ci/8] bytes): only residual elements whose bit is set
+ * are added -- the masked block-output gradient of the identity shortcut (resnet_helper.py:512-521 backward) without
+ * materialising it. */
+int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
+                  const void* resid_bits, void* dx, sf_stream_t stream);
 /* dw[Co][Cw][taps] = (zero_first ? 0 : dw) + out_scale * sum_m dy[m] (x) act(x)[m].  The reduction over positions
  * is split; `workspace` (>= sf_conv_wgrad_workspace(d) bytes, caller-owned) holds the per-split partials, which a
  * second kernel sums in a fixed order (no atomics: results are run-to-run reproducible). */
@@ -81,13 +84,16 @@ int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, c
 int sf_bn_finalize(float* part, int32_t nblk, int32_t C, int32_t Creal, float count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                    float* save_mean, float* save_rstd, sf_stream_t stream);
-/* out = relu?( y*scale+shift [+ r*rscale+rshift | + r] ); scale == NULL means identity */
+/* out = relu?( y*scale+shift [+ r*rscale+rshift | + r] ); scale == NULL means identity.  mask_out (optional): [M][C/8]
+ * bytes, bit e of byte (m, c/8) = out[m][c+e] > 0 -- the ReLU mask the backward kernels read instead of `out` (1/16 of
+ * the bytes). */
 int sf_bn_act(int64_t M, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift, const void* r,
-              int32_t ldr, const float* rscale, const float* rshift, int relu, void* out, int32_t ldo,
+              int32_t ldr, const float* rscale, const float* rshift, int relu, void* out, int32_t ldo, void* mask_out,
               sf_stream_t stream);
 int sf_bn_bwd_blocks(int64_t M, int32_t C); /* rows of `part` for the two calls below */
 /* part[blk][0][c] = sum g, part[blk][1][c] = sum g*y, g = dz masked by (zmask > 0) or by
- * (y*scale+shift > 0) when relu_self */
+ * (y*scale+shift > 0) when relu_self.  ldm == 0 with a non-NULL zmask: zmask is the BIT mask written by sf_bn_act
+ * ([M][C/8] bytes); same convention in sf_bn_bwd_apply. */
 int sf_bn_bwd_reduce(int64_t M, int32_t C, const void* dz, int32_t lddz, const void* zmask, int32_t ldm, const void* y,
                      int32_t ldy, const float* scale, const float* shift, int relu_self, float* part,
                      sf_stream_t stream);

@@ -183,6 +183,41 @@ static void launch_igemm2(Igemm2Params& q, hipStream_t s) {
     const dim3 grid((unsigned)(cdiv(q.M, 256) * q.ntiles_n));
     hipLaunchKernelGGL((sf_igemm2_kernel<256, BN, 4, 2, BK, 3>), grid, dim3(512), 0, s, q);
 }
+// K step: 64 deep (48 KB stages, ONE 8-wave workgroup per CU) when the grid is at most ~one tile per CU anyway -- the
+// res5-sized layers; otherwise 32 deep (24 KB stages, TWO workgroups per CU: one tile's epilogue and pipeline fill hide
+// behind the other's K loop).  Measured per layer in profiles/r2_v3_igemm2_variants.md.  SF_IGEMM2_BK=32|64 forces one.
+static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
+    const char* e;
+    const int tiles = cdiv(q.M, 256) * cdiv(q.Nout, q.Nout > 64 ? 128 : 64);
+    const int force_bk = (e = getenv("SF_IGEMM2_BK")) ? atoi(e) : 0;
+    const bool bk64 = q.C % 64 == 0 && force_bk != 32 && (force_bk == 64 || tiles <= 320);
+    static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+    if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);
+    if (q.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }
+    else if (q.Nout > 32) { if (bk64) launch_igemm2<64, 64>(q, s); else launch_igemm2<64, 32>(q, s); }
+    else launch_igemm2<32, 32>(q, s);
+}
+static bool igemm2_operands_ok(const IgemmParams& p, int nbatch) {
+    const GatherSide& g = p.g;
+    if (nbatch != 1 || g.scale) return false;
+    if (p.bh > 1 || (p.bh == 1 && (p.sa_b | p.sa_h | p.sw_b | p.sw_h | p.sy_b | p.sy_h | p.sr_b | p.sr_h))) return false;
+    const int taps = g.kT * g.kH * g.kW;
+    if (taps > SF_I2_MAXTAPS || g.C % 32 != 0 || g.Ktot != taps * g.C) return false;
+    if (g.ld % 8 != 0 || p.ldw % 8 != 0 || p.ldw < g.Ktot) return false;
+    if (((uintptr_t)g.src | (uintptr_t)p.wmat) & 15) return false;
+    if ((g.kT - 1) * g.dilT > 127 || (g.kH - 1) * g.dilH > 127 || (g.kW - 1) * g.dilW > 127) return false;
+    return true;
+}
+static void igemm2_common(Igemm2Params& q, const IgemmParams& p) {
+    const GatherSide& g = p.g;
+    memset(&q, 0, sizeof(q));
+    q.src = g.src; q.ld = g.ld; q.C = g.C;
+    q.sT = g.sT; q.sH = g.sH; q.sW = g.sW;
+    q.wmat = p.wmat; q.ldw = p.ldw; q.Nout = p.Nout;
+    q.y = p.y; q.ldy = p.ldy; q.bias = p.bias; q.resid = p.resid; q.ldr = p.ldr; q.stat_part = p.stat_part;
+    q.act_mode = p.act_mode; q.act_aux = p.act_aux; q.ld_aux = p.ld_aux; q.resid_row0 = p.resid_row0; q.alpha = p.alpha;
+    q.resid_bits = p.resid_bits;
+}
 static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     // read on every call (three getenv per launch are noise): tests lower the thresholds for single cases
     const char* e;
@@ -190,19 +225,12 @@ static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     const int mink = (e = getenv("SF_IGEMM2_MINK")) ? atoi(e) : 512;
     const int minrows = (e = getenv("SF_IGEMM2_MINROWS")) ? atoi(e) : 4096;
     const GatherSide& g = p.g;
-    if (off || nbatch != 1 || g.scale) return false;
-    if (p.bh > 1 || (p.bh == 1 && (p.sa_b | p.sa_h | p.sw_b | p.sw_h | p.sy_b | p.sy_h | p.sr_b | p.sr_h))) return false;
-    const int taps = g.kT * g.kH * g.kW;
-    if (taps > SF_I2_MAXTAPS || g.C % 32 != 0 || g.Ktot != taps * g.C || g.Ktot < mink) return false;
-    if (p.Nout <= 32 || p.M < minrows) return false;
+    if (off || !igemm2_operands_ok(p, nbatch)) return false;
+    if (g.Ktot < mink || p.Nout <= 32 || p.M < minrows) return false;
     if (g.mode == 1 && !(g.strT == 1 && g.strH == 1 && g.strW == 1)) return false;
-    if (g.ld % 8 != 0 || p.ldw % 8 != 0 || p.ldw < g.Ktot) return false;
-    if (((uintptr_t)g.src | (uintptr_t)p.wmat) & 15) return false;
-    if ((g.kT - 1) * g.dilT > 127 || (g.kH - 1) * g.dilH > 127 || (g.kW - 1) * g.dilW > 127) return false;
+    const int taps = g.kT * g.kH * g.kW;
     Igemm2Params q;
-    memset(&q, 0, sizeof(q));
-    q.src = g.src; q.ld = g.ld; q.C = g.C;
-    q.sT = g.sT; q.sH = g.sH; q.sW = g.sW;
+    igemm2_common(q, p);
     q.fdrW = g.fdrW; q.fdrH = g.fdrH; q.fdrT = g.fdrT;
     const int sgn = g.mode == 0 ? 1 : -1;
     if (g.mode == 0) {
@@ -222,23 +250,82 @@ static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
                 q.taps[t].dlin = (dt * g.sH + dh) * g.sW + dw;
                 q.taps[t].wcol = t * g.C;
             }
-    q.M = p.M; q.wmat = p.wmat; q.ldw = p.ldw; q.Nout = p.Nout;
-    q.y = p.y; q.ldy = p.ldy; q.bias = p.bias; q.resid = p.resid; q.ldr = p.ldr; q.stat_part = p.stat_part;
-    q.act_mode = p.act_mode; q.act_aux = p.act_aux; q.ld_aux = p.ld_aux; q.resid_row0 = p.resid_row0; q.alpha = p.alpha;
-    // SF_IGEMM2_BK=32 forces the 32-deep K step (24 KB stages: two workgroups per CU) for A/B runs
-    // SF_IGEMM2_BK64_MINK: contractions shallower than this take the 32-deep step (two workgroups per CU overlap one
-    // tile's epilogue with the other's loads, which is what short-K, bandwidth-bound layers need)
-    const int bk64_mink = (e = getenv("SF_IGEMM2_BK64_MINK")) ? atoi(e) : 1024;
-    const bool bk64 = g.C % 64 == 0 && g.Ktot >= bk64_mink && !((e = getenv("SF_IGEMM2_BK")) && atoi(e) == 32);
-    static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
-    if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d K=%d taps=%d BK=%d mode=%d\n", p.M, p.Nout, g.Ktot, taps, bk64 ? 64 : 32, g.mode);
-    if (p.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }
-    else { if (bk64) launch_igemm2<64, 64>(q, s); else launch_igemm2<64, 32>(q, s); }
+    q.M = p.M;
+    launch_igemm2_auto(q, s);
+    return true;
+}
+
+// Strided data gradient as sub-convolutions (reference op: the backward of nn.Conv3d with stride > 1 -- ResBlock.branch1
+// and BottleneckTransform.b at the first block of a stage, resnet_helper.py:346-358, 485-493; FuseFastToSlow.conv_f2s,
+// video_model_builder.py:147-154).  dx[i] = sum over the taps k with (i + pad - k*dil) divisible by the stride of
+// dy[(i + pad - k*dil) / stride] . w[k]: input positions of one residue class r = (i + pad) mod stride share their tap set,
+// and inside a class both the source position and the output position are affine in the class coordinates.  One launch
+// per class: no all-padding K steps (a 3x3 stride-2 convolution wastes 3/4 of them in the gather formulation, a strided
+// 1x1 shortcut 3/4 of its ROWS), every tap of a step real, wave-uniform and direct-to-LDS.  Classes without any tap
+// (1x1 kernels) just store the residual / zeros.
+static bool try_igemm2_strided_dgrad(const IgemmParams& p, hipStream_t s) {
+    const char* e;
+    const bool off = ((e = getenv("SF_IGEMM2")) && atoi(e) == 0) || ((e = getenv("SF_IGEMM2_STRIDED")) && atoi(e) == 0);
+    const int minrows = (e = getenv("SF_IGEMM2_MINROWS")) ? atoi(e) : 4096;
+    const GatherSide& g = p.g;
+    if (off || g.mode != 1 || (g.strT == 1 && g.strH == 1 && g.strW == 1)) return false;
+    if (!igemm2_operands_ok(p, 1) || p.Nout <= 16 || p.M < minrows || p.stat_part || p.act_mode) return false;
+    const int Ti = (int)g.fdrT.d, Hi = (int)g.fdrH.d, Wi = (int)g.fdrW.d;      // rows = input positions
+    const int N = p.M / (Ti * Hi * Wi);
+    const int str[3] = {g.strT, g.strH, g.strW}, pad[3] = {g.padT, g.padH, g.padW}, dil[3] = {g.dilT, g.dilH, g.dilW};
+    const int ker[3] = {g.kT, g.kH, g.kW}, ext[3] = {Ti, Hi, Wi};
+    for (int rt = 0; rt < str[0]; ++rt)
+        for (int rh = 0; rh < str[1]; ++rh)
+            for (int rw = 0; rw < str[2]; ++rw) {
+                const int r[3] = {rt, rh, rw};
+                int q0[3], cnt[3];
+                bool empty = false;
+                for (int a = 0; a < 3; ++a) {
+                    const int num = pad[a] - r[a];
+                    q0[a] = num > 0 ? (num + str[a] - 1) / str[a] : 0;
+                    const int top = ext[a] - 1 + pad[a] - r[a];
+                    const int q1 = top >= 0 ? top / str[a] : -1;
+                    cnt[a] = q1 - q0[a] + 1;
+                    if (cnt[a] <= 0) empty = true;
+                }
+                if (empty) continue;
+                Igemm2Params q;
+                igemm2_common(q, p);
+                q.fdrT = make_fastdiv(cnt[0]); q.fdrH = make_fastdiv(cnt[1]); q.fdrW = make_fastdiv(cnt[2]);
+                q.mulT = q.mulH = q.mulW = 1;
+                q.offT = q0[0]; q.offH = q0[1]; q.offW = q0[2];
+                int nt = 0, tap = 0;
+                for (int kt = 0; kt < ker[0]; ++kt)
+                    for (int kh = 0; kh < ker[1]; ++kh)
+                        for (int kw = 0; kw < ker[2]; ++kw, ++tap) {
+                            const int k[3] = {kt, kh, kw};
+                            int d[3];
+                            bool ok = true;
+                            for (int a = 0; a < 3; ++a) {
+                                const int v = r[a] - k[a] * dil[a];
+                                if (v % str[a] != 0) { ok = false; break; }
+                                d[a] = v / str[a];
+                            }
+                            if (!ok) continue;
+                            q.dt[nt] = (int8_t)d[0]; q.dh[nt] = (int8_t)d[1]; q.dw[nt] = (int8_t)d[2];
+                            q.taps[nt].dlin = (d[0] * g.sH + d[1]) * g.sW + d[2];
+                            q.taps[nt].wcol = tap * g.C;
+                            ++nt;
+                        }
+                q.ntaps = nt;
+                q.M = N * cnt[0] * cnt[1] * cnt[2];
+                q.omap = 1;
+                q.oT = Ti; q.oH = Hi; q.oW = Wi;
+                q.omT = str[0]; q.omH = str[1]; q.omW = str[2];
+                q.ooT = str[0] * q0[0] + r[0] - pad[0]; q.ooH = str[1] * q0[1] + r[1] - pad[1]; q.ooW = str[2] * q0[2] + r[2] - pad[2];
+                launch_igemm2_auto(q, s);
+            }
     return true;
 }
 
 static int run_igemm(IgemmParams& p, bool pw, hipStream_t s) {
     if (try_igemm2(p, s)) return check_launch("igemm2");
+    if (try_igemm2_strided_dgrad(p, s)) return check_launch("igemm2 strided dgrad");
     if (p.Nout > 64) { p.ntiles_n = cdiv(p.Nout, 128); launch_igemm<128, 64, 64>(p, pw, s); }
     else if (p.Nout > 32) { p.ntiles_n = 1; launch_igemm<64, 32, 64>(p, pw, s); }
     else if (p.Nout > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, pw, s); }
@@ -391,7 +478,7 @@ extern "C" int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const voi
 }
 
 extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
-                             void* dx, sf_stream_t stream) {
+                             const void* resid_bits, void* dx, sf_stream_t stream) {
     if (check_desc(d)) return -1;
     REQUIRE(dy && wd && dx, "sf_conv_dgrad: null pointer");
     REQUIRE(!resid || (ldr >= d->Ci && ldr % 8 == 0), "sf_conv_dgrad: bad residual pitch");
@@ -405,6 +492,8 @@ extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* 
     p.ksteps = cdiv(p.g.Ktot, 32);
     p.y = (f16*)dx; p.ldy = d->ldx;
     p.resid = (const f16*)resid; p.ldr = ldr;
+    REQUIRE(!resid_bits || resid, "sf_conv_dgrad: resid_bits without a residual");
+    p.resid_bits = (const uint8_t*)resid_bits;
     return run_igemm(p, is_pointwise(d), (hipStream_t)stream);
 }
 
@@ -561,7 +650,7 @@ extern "C" int sf_bn_finalize(float* part, int32_t nblk, int32_t C, int32_t Crea
 
 extern "C" int sf_bn_act(int64_t M, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift,
                          const void* r, int32_t ldr, const float* rscale, const float* rshift, int relu, void* out,
-                         int32_t ldo, sf_stream_t stream) {
+                         int32_t ldo, void* mask_out, sf_stream_t stream) {
     if (check_rows("sf_bn_act", M, C)) return -1;
     REQUIRE(y && out, "sf_bn_act: null pointer");
     BnActParams p;
@@ -569,7 +658,7 @@ extern "C" int sf_bn_act(int64_t M, int32_t C, const void* y, int32_t ldy, const
     p.rt = make_rowtile(M, C, 8192, grid);
     p.y = (const f16*)y; p.ldy = ldy; p.scale = scale; p.shift = shift;
     p.r = (const f16*)r; p.ldr = ldr; p.rscale = rscale; p.rshift = rshift;
-    p.relu = relu; p.out = (f16*)out; p.ldo = ldo;
+    p.relu = relu; p.out = (f16*)out; p.ldo = ldo; p.mask_out = (uint8_t*)mask_out;
     hipLaunchKernelGGL(sf_bn_act_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("bn_act");
 }

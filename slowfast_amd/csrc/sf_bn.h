@@ -169,6 +169,7 @@ struct BnActParams {
     const float* rscale; const float* rshift;   // rscale == nullptr: plain add
     int relu;
     f16* out; int ldo;
+    uint8_t* mask_out;                          // optional [M][C/8]: bit e of byte (m, c/8) = out[m][c+e] > 0
 };
 
 __global__ __launch_bounds__(SF_THREADS) void sf_bn_act_kernel(BnActParams p) {
@@ -191,13 +192,16 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_act_kernel(BnActParams p) {
             for (int e = 0; e < 8; ++e) x[e] += (float)rv[e] * rsc[e] + rsh[e];
         }
         f16x8 o;
+        uint32_t bits = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float t = x[e];
             if (p.relu) t = t > 0.f ? t : 0.f;
             o[e] = (f16)t;
+            bits |= (o[e] > (f16)0.f ? 1u : 0u) << e;       // the mask of the STORED value (what a reader of `out` sees)
         }
         st16(p.out + (int64_t)m * p.ldo + c, o);
+        if (p.mask_out) p.mask_out[(int64_t)m * (p.rt.C >> 3) + gcol] = (uint8_t)bits;
     }
 }
 
@@ -255,7 +259,8 @@ __device__ __forceinline__ void rowtile_reduce_store(const RowTile& rt, bool act
 struct BnBwdReduceParams {
     RowTile rt;
     const f16* dz; int lddz;
-    const f16* zmask; int ldm;                  // optional: mask = zmask > 0 (block-output ReLU)
+    const f16* zmask; int ldm;                  // optional: mask = zmask > 0 (block-output ReLU); ldm == 0: zmask is the
+                                                // BIT mask sf_bn_act wrote ([M][C/8] bytes) -- 1/16 of the bytes
     const f16* y; int ldy;
     const float* scale; const float* shift;     // for relu_self: mask = y*scale+shift > 0
     int relu_self;
@@ -263,10 +268,15 @@ struct BnBwdReduceParams {
 };
 
 __device__ __forceinline__ void masked_grad8(const f16x8& dz, const f16x8& yv, const f16* zmask_ptr, int relu_self,
-                                             const float (&sc)[8], const float (&sh)[8], float (&g)[8]) {
+                                             const float (&sc)[8], const float (&sh)[8], float (&g)[8],
+                                             const uint8_t* bits_ptr = nullptr) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = (float)dz[e];
-    if (zmask_ptr) {
+    if (bits_ptr) {
+        const uint32_t b = *bits_ptr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((b >> e) & 1u) ? g[e] : 0.f;
+    } else if (zmask_ptr) {
         f16x8 z = ld16(zmask_ptr);
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = ((float)z[e] > 0.f) ? g[e] : 0.f;
@@ -290,7 +300,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_reduce_kernel(BnBwdReduc
             f16x8 dz = ld16(p.dz + (int64_t)m * p.lddz + c);
             f16x8 yv = ld16(p.y + (int64_t)m * p.ldy + c);
             float g[8];
-            masked_grad8(dz, yv, p.zmask ? p.zmask + (int64_t)m * p.ldm + c : nullptr, p.relu_self, sc, sh, g);
+            const bool bitm = p.zmask && p.ldm == 0;
+            masked_grad8(dz, yv, (p.zmask && !bitm) ? p.zmask + (int64_t)m * p.ldm + c : nullptr, p.relu_self, sc, sh, g,
+                         bitm ? reinterpret_cast<const uint8_t*>(p.zmask) + (int64_t)m * (p.rt.C >> 3) + gcol : nullptr);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sg[e] += g[e]; sgy[e] += g[e] * (float)yv[e]; }
         }
@@ -364,7 +376,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_apply_kernel(BnBwdApplyP
         f16x8 dz = ld16(p.dz + (int64_t)m * p.lddz + c);
         f16x8 yv = ld16(p.y + (int64_t)m * p.ldy + c);
         float g[8];
-        masked_grad8(dz, yv, p.zmask ? p.zmask + (int64_t)m * p.ldm + c : nullptr, p.relu_self, sc, sh, g);
+        const bool bitm = p.zmask && p.ldm == 0;
+        masked_grad8(dz, yv, (p.zmask && !bitm) ? p.zmask + (int64_t)m * p.ldm + c : nullptr, p.relu_self, sc, sh, g,
+                     bitm ? reinterpret_cast<const uint8_t*>(p.zmask) + (int64_t)m * (C >> 3) + gcol : nullptr);
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (f16)(k1[e] * g[e] + k2[e] + k3[e] * (float)yv[e]);

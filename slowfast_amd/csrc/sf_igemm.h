@@ -36,6 +36,7 @@ struct IgemmParams {
     f16* act_aux;
     int ld_aux;
     int resid_row0;     // the residual is added to rows >= resid_row0 only (pooled attention: not to the cls row)
+    const uint8_t* resid_bits;  // optional [M][Nout/8] bit mask: residual element (m, c) counts only when its bit is set
     float alpha;        // accumulators are scaled by alpha before bias / residual (0 means 1)
 };
 
@@ -357,6 +358,11 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
             f16x8 v = ld16(stg + row * STG_LD + cg * 8);
             if (resid && m >= p.resid_row0) {
                 f16x8 r = ld16(resid + (int64_t)m * p.ldr + col);
+                if (p.resid_bits) {
+                    const uint32_t b = p.resid_bits[(int64_t)m * (p.Nout >> 3) + (col >> 3)];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = ((b >> e) & 1u) ? r[e] : (f16)0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)r[e]);
             }

@@ -64,6 +64,12 @@ struct Igemm2Params {
     int ld_aux;
     int resid_row0;
     float alpha;
+    const uint8_t* resid_bits;  // optional [rows][Nout/8] bit mask of the residual (see IgemmParams)
+    // output-row map (strided data gradients run one launch per stride-residue class of input positions, see
+    // launch_igemm2_strided_dgrad): row (n, a, b, c) of the class is stored at position
+    // ((n*oT + a*omT + ooT)*oH + b*omH + ooH)*oW + c*omW + ooW of y / resid.  omap == 0: rows are stored densely.
+    int omap;
+    int oT, oH, oW, omT, omH, omW, ooT, ooH, ooW;
 };
 
 // LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase
@@ -95,9 +101,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) vo
     static_assert(WAVES_M % HALVES == 0, "a wave row belongs to one 128-row group");
 
     // ONE LDS object (hipcc serialises direct-to-LDS copies against ds_reads of any other __shared__ object)
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SMEM * 2 + WAVES_M * 2 * BN * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SMEM * 2 + WAVES_M * 2 * BN * 4 + BM * 4];
     f16* const smem = reinterpret_cast<f16*>(lds_raw);
     float (*const s_red)[2][BN] = reinterpret_cast<float (*)[2][BN]>(lds_raw + SMEM * 2);
+    int* const s_orow = reinterpret_cast<int*>(lds_raw + SMEM * 2 + WAVES_M * 2 * BN * 4);   // output row of a tile row
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -130,6 +137,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) vo
             mk |= (ok ? 1u : 0u) << t;
         }
         amask[j] = mk;
+    }
+    if (p.omap) {
+        for (int r = tid; r < BM; r += NT) {
+            int m = m0 + r;
+            if (m >= p.M) m = p.M - 1;
+            uint32_t q, a, b, c, n;
+            fd_divmod((uint32_t)m, p.fdrW, q, c);
+            fd_divmod(q, p.fdrH, q, b);
+            fd_divmod(q, p.fdrT, n, a);
+            s_orow[r] = (((int)n * p.oT + (int)a * p.omT + p.ooT) * p.oH + (int)b * p.omH + p.ooH) * p.oW + (int)c * p.omW + p.ooW;
+        }
     }
     const f16* bptr[NB];
 #pragma unroll
@@ -276,11 +294,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) vo
     constexpr int CG = BN / 8;
     for (int idx = tid; idx < BM * CG; idx += NT) {
         const int row = idx / CG, cg = idx % CG;
-        const int m = m0 + row, col = n0 + cg * 8;
-        if (m < p.M && col < p.Nout) {
+        const int mr = m0 + row, col = n0 + cg * 8;
+        if (mr < p.M && col < p.Nout) {
+            const int m = p.omap ? s_orow[row] : mr;
             f16x8 v = ld16(stg + row * STG_LD + cg * 8);
             if (p.resid && m >= p.resid_row0) {
                 f16x8 r = ld16(p.resid + (int64_t)m * p.ldr + col);
+                if (p.resid_bits) {
+                    const uint32_t b = p.resid_bits[(int64_t)m * (p.Nout >> 3) + (col >> 3)];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = ((b >> e) & 1u) ? r[e] : (f16)0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)r[e]);
             }

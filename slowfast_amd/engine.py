@@ -188,8 +188,8 @@ class ConvUnit:
         y, part = ops.conv_fwd(x, wf, geom, in_affine=in_affine, bias=self.conv.bias, stats=use_batch_stats)
         return y, bn_statistics(bn, part, geom.out_rows, geom.Co, training)
 
-    def backward(self, x, in_affine, dy, need_dx, resid=None):
-        """Weight gradient into conv.weight.grad; returns dx (+ resid) when need_dx."""
+    def backward(self, x, in_affine, dy, need_dx, resid=None, resid_bits=None):
+        """Weight gradient into conv.weight.grad; returns dx (+ resid, masked by resid_bits when given) when need_dx."""
         geom = self.geom(x.shape)
         w = self.conv.weight
         if w.requires_grad:
@@ -198,7 +198,7 @@ class ConvUnit:
         if not need_dx:
             return None
         _, wd = self.weights(geom)
-        return ops.conv_dgrad(dy, wd, geom, resid=resid)
+        return ops.conv_dgrad(dy, wd, geom, resid=resid, resid_bits=resid_bits)
 
     def bn_backward(self, dz, y, st, zmask=None, relu_self=False, want_g=False):
         """BatchNorm3d backward (through ReLU) -> dy; writes bn.weight.grad / bn.bias.grad."""
@@ -433,34 +433,34 @@ class ResBlockFn(torch.autograd.Function):
                 act.append(None)
                 prologue = (st.scale, st.shift, True)
         yc, sc = raw[-1], bn[-1]
+        # the backward pass needs only the SIGN of the block output (ReLU mask): one bit per element, written here, stands
+        # in for two full reads of `out` in BatchNorm backward (and for the masked gradient tensor of the identity shortcut)
         if P is not None:
             y1, s1 = P.forward(x, None, tr)
-            out = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=y1, rscale=s1.scale, rshift=s1.shift)
+            out, bits = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=y1, rscale=s1.scale, rshift=s1.shift,
+                                   want_mask=True)
         else:
             y1, s1 = None, None
-            out = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x)
+            out, bits = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x, want_mask=True)
         ctx.mod = mod
-        ctx.raw = (raw, y1, act)
+        ctx.raw = (raw, y1, act, bits)
         ctx.bn = (bn, s1)
-        ctx.save_for_backward(x, out)
+        ctx.save_for_backward(x)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         mod = ctx.mod
         units, P = mod.branch2._chain, mod._proj
-        x, out = ctx.saved_tensors
-        raw, y1, act = ctx.raw
+        (x,) = ctx.saved_tensors
+        raw, y1, act, bits = ctx.raw
         bn, s1 = ctx.bn
         dout = as_cl(dout)
         need_dx = ctx.needs_input_grad[0]
         last = len(units) - 1
+        dy = units[last].bn_backward(dout, raw[last], bn[last], zmask=bits)
         if P is not None:
-            dy = units[last].bn_backward(dout, raw[last], bn[last], zmask=out)
-            dy1 = P.bn_backward(dout, y1, s1, zmask=out)
-            g = None
-        else:
-            dy, g = units[last].bn_backward(dout, raw[last], bn[last], zmask=out, want_g=True)
+            dy1 = P.bn_backward(dout, y1, s1, zmask=bits)
         for i in range(last, 0, -1):
             if act[i - 1] is not None:
                 d_in = units[i].backward(act[i - 1], None, dy, need_dx=True)
@@ -470,8 +470,8 @@ class ResBlockFn(torch.autograd.Function):
         if P is not None:
             dx1 = P.backward(x, None, dy1, need_dx=need_dx)
             dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=dx1)
-        else:
-            dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=g)
+        else:       # identity shortcut: dx = dgrad_a + dout * (out > 0), the mask applied to the residual in the epilogue
+            dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=dout, resid_bits=bits)
         _notify(mod._param_list)
         ctx.raw = ctx.bn = None
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class ConvDesc(Structure):
@@ -49,11 +49,11 @@ _SIGNATURES = {
     "sf_conv_fwd_mtiles": (c_int, [POINTER(ConvDesc)]),
     "sf_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _F, _F, c_int, _F, _P, _F, _P]),
     "sf_conv_fwd_fused": (c_int, [POINTER(ConvDesc), _P, _P, _F, _P, c_int32, c_int, _P, _P]),
-    "sf_conv_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P]),
+    "sf_conv_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P, _P]),
     "sf_conv_wgrad_workspace": (c_int64, [POINTER(ConvDesc)]),
     "sf_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _F, _F, c_int, _P, _F, c_float, c_int, _P, c_int64, _P]),
     "sf_bn_finalize": (c_int, [_F, c_int32, c_int32, c_int32, c_float, _F, _F, _F, _F, c_float, c_float, _F, _F, _F, _F, _P]),
-    "sf_bn_act": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, _P, c_int32, _F, _F, c_int, _P, c_int32, _P]),
+    "sf_bn_act": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, _P, c_int32, _F, _F, c_int, _P, c_int32, _P, _P]),
     "sf_bn_bwd_blocks": (c_int, [c_int64, c_int32]),
     "sf_bn_bwd_reduce": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, _F, _F, c_int, _F, _P]),
     "sf_bn_bwd_finalize": (c_int, [_F, c_int32, c_int32, c_int32, c_float, _F, _F, _F, c_float, _F, _F, c_int, _F, _P]),

@@ -221,8 +221,9 @@ def conv_fwd_fused(x, wf, geom, bias=None, resid=None, relu=False, out=None):
     return y
 
 
-def conv_dgrad(dy, wd, geom, resid=None, out=None):
-    """dx = conv_transpose3d(dy, w) [+ resid]."""
+def conv_dgrad(dy, wd, geom, resid=None, out=None, resid_bits=None):
+    """dx = conv_transpose3d(dy, w) [+ resid].  ``resid_bits``: the bit mask bn_act(..., want_mask=True) wrote for the
+    tensor ``resid`` is the gradient of; only residual elements whose bit is set are added."""
     assert tuple(dy.shape) == geom.out_shape
     ldy = cl_ld(dy)
     dx = cl_empty(geom.in_shape, dy.device) if out is None else out
@@ -230,8 +231,10 @@ def conv_dgrad(dy, wd, geom, resid=None, out=None):
     ldr = cl_ld(resid) if resid is not None else 0
     if resid is not None:
         assert tuple(resid.shape) == geom.in_shape
+    if resid_bits is not None:
+        assert resid is not None and resid_bits.dtype == torch.uint8 and resid_bits.numel() == rows(resid) * (geom.Ci // 8)
     get_lib().call("sf_conv_dgrad", byref(geom.desc(ldx, ldy)), dy.data_ptr(), wd.data_ptr(), _ptr(resid), ldr,
-                   dx.data_ptr(), _stream(dy),
+                   _ptr(resid_bits), dx.data_ptr(), _stream(dy),
                    work=geom.work(reads_x=int(resid is not None), reads_y=1, writes_x=1))
     return dx
 
@@ -280,17 +283,19 @@ def bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum, e
     return scale, shift, mean, rstd
 
 
-def bn_act(y, scale=None, shift=None, relu=False, resid=None, rscale=None, rshift=None, out=None):
-    """out = relu?(y*scale+shift [+ resid*rscale+rshift | + resid]) materialised in fp16."""
+def bn_act(y, scale=None, shift=None, relu=False, resid=None, rscale=None, rshift=None, out=None, want_mask=False):
+    """out = relu?(y*scale+shift [+ resid*rscale+rshift | + resid]) materialised in fp16.  ``want_mask``: also returns the
+    1-bit mask ``out > 0`` ([rows, C/8] uint8) that bn_bwd / conv_dgrad read instead of ``out`` (1/16 of the bytes)."""
     ldy = cl_ld(y)
     N, C, T, H, W = y.shape
     out = cl_empty(y.shape, y.device) if out is None else out
     assert tuple(out.shape) == tuple(y.shape)
+    mask = torch.empty((rows(y), C // 8), dtype=torch.uint8, device=y.device) if want_mask else None
     get_lib().call("sf_bn_act", rows(y), C, y.data_ptr(), ldy, _ptr(scale), _ptr(shift), _ptr(resid),
                    cl_ld(resid) if resid is not None else 0, _ptr(rscale), _ptr(rshift), int(bool(relu)),
-                   out.data_ptr(), cl_ld(out), _stream(y),
-                   work=dict(bytes=2.0 * y.numel() * (2 + int(resid is not None))))
-    return out
+                   out.data_ptr(), cl_ld(out), _ptr(mask), _stream(y),
+                   work=dict(bytes=2.0 * y.numel() * (2 + int(resid is not None) + (1 / 16 if want_mask else 0))))
+    return (out, mask) if want_mask else out
 
 
 def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None, inv_loss_scale=1.0,
@@ -307,9 +312,13 @@ def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None
     part = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
     sc, sh = (relu_affine if relu_affine is not None else (None, None))
     relu_self = int(relu_affine is not None)
-    lddz, ldy, ldm = cl_ld(dz), cl_ld(y), (cl_ld(zmask) if zmask is not None else 0)
+    bits = zmask is not None and zmask.dtype == torch.uint8     # the 1-bit mask of bn_act(..., want_mask=True)
+    if bits:
+        assert zmask.numel() == M * (C // 8) and zmask.is_contiguous()
+    mcost = 0.0 if zmask is None else (1 / 16 if bits else 1.0)
+    lddz, ldy, ldm = cl_ld(dz), cl_ld(y), (0 if bits or zmask is None else cl_ld(zmask))
     lib.call("sf_bn_bwd_reduce", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
-             relu_self, part.data_ptr(), s, work=dict(bytes=2.0 * y.numel() * (2 + int(zmask is not None))))
+             relu_self, part.data_ptr(), s, work=dict(bytes=2.0 * y.numel() * (2 + mcost)))
     coef = torch.empty((3, C), dtype=torch.float32, device=y.device)
     if sync is None:
         lib.call("sf_bn_bwd_finalize", part.data_ptr(), nblk, C, gamma.numel(), float(M), gamma.data_ptr(), mean.data_ptr(),
@@ -335,7 +344,7 @@ def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None
     g = cl_empty(y.shape, y.device) if want_g else None
     lib.call("sf_bn_bwd_apply", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
              relu_self, coef.data_ptr(), dy.data_ptr(), cl_ld(dy), _ptr(g), cl_ld(g) if g is not None else 0, s,
-             work=dict(bytes=2.0 * y.numel() * (3 + int(zmask is not None) + int(want_g))))
+             work=dict(bytes=2.0 * y.numel() * (3 + mcost + int(want_g))))
     return (dy, g) if want_g else dy
 
 

@@ -116,7 +116,17 @@ def check_conv_dgrad(device, in_shape, Co, k, s, p, d=(1, 1, 1), resid=False, se
         ref = (ref.half().float() + rr)
         r = host_to_cl(rr, device)
     dx = ops.conv_dgrad(host_to_cl(dy, device), wd, geom, resid=r)
-    return assert_close("conv_dgrad", cl_to_host(dx), ref, 2 * F16_EPS)
+    e = assert_close("conv_dgrad", cl_to_host(dx), ref, 2 * F16_EPS)
+    if resid:           # masked residual: only elements whose mask bit is set are added
+        N, Ci, T, H, W = in_shape
+        Mi = N * T * H * W
+        bits = torch.randint(0, 256, (Mi, Ci // 8), generator=g, dtype=torch.int32)
+        keep = ((bits.unsqueeze(-1) >> torch.arange(8, dtype=torch.int32)) & 1).reshape(Mi, Ci).bool()
+        keep5 = keep.reshape(N, T, H, W, Ci).permute(0, 4, 1, 2, 3)
+        ref2 = xr.grad.half().float() + rr * keep5
+        dx2 = ops.conv_dgrad(host_to_cl(dy, device), wd, geom, resid=r, resid_bits=bits.to(torch.uint8).to(device))
+        assert_close("conv_dgrad masked residual", cl_to_host(dx2), ref2, 2 * F16_EPS)
+    return e
 
 
 def check_conv_wgrad(device, in_shape, Co, k, s, p, d=(1, 1, 1), Cw=None, affine=False, out_scale=1.0, seed=0):
@@ -173,8 +183,12 @@ def check_bn_chain(device, shape, relu=True, residual=None, seed=0):
     assert_close("running_var", rvd.cpu(), rv_ref, 1e-5)
     yc = host_to_cl(y, device)
     rc = host_to_cl(res, device) if res is not None else None
-    z = ops.bn_act(yc, scale, shift, relu=relu, resid=rc)
+    z, bits = ops.bn_act(yc, scale, shift, relu=relu, resid=rc, want_mask=True)
     assert_close("bn_act", cl_to_host(z), zr.detach(), 2 * F16_EPS)
+    # the 1-bit mask is exactly the sign of the stored activation
+    zrow = z.permute(0, 2, 3, 4, 1).reshape(M, C).cpu()
+    ref_bits = ((zrow > 0).reshape(M, C // 8, 8).to(torch.int32) << torch.arange(8, dtype=torch.int32)).sum(-1)
+    assert torch.equal(bits.cpu().to(torch.int32), ref_bits), "bn_act bit mask"
     dgamma = torch.empty(C, device=device)
     dbeta = torch.empty(C, device=device)
     dzc = host_to_cl(dz, device)
@@ -183,6 +197,10 @@ def check_bn_chain(device, shape, relu=True, residual=None, seed=0):
                             inv_loss_scale=0.5)
         gref = dz * (zr.detach() > 0) if relu else dz
         assert_close("bn_bwd g", cl_to_host(gm), gref, 1e-6)
+        if relu:        # the bit-mask form must give the same gradients bit for bit
+            dg2, db2 = torch.empty(C, device=device), torch.empty(C, device=device)
+            dy2 = ops.bn_bwd(dzc, yc, gd, mean, rstd, dg2, db2, zmask=bits, inv_loss_scale=0.5)
+            assert torch.equal(dy2.cpu(), dy.cpu()) and torch.equal(dg2.cpu(), dgamma.cpu()) and torch.equal(db2.cpu(), dbeta.cpu())
     else:
         dy = ops.bn_bwd(dzc, yc, gd, mean, rstd, dgamma, dbeta, relu_affine=(scale, shift) if relu else None,
                         inv_loss_scale=0.5)

@@ -33,6 +33,8 @@ IGEMM2_CASES = [
     ((8, 128, 4, 28, 28), 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),     # stride 2 (forward)
     ((4, 2048, 4, 7, 7), 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),      # res5: 784 rows x K 6144 (below the row cut)
     ((16, 96, 2, 20, 20), 288, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),     # BK 32 (96 channels), ragged N
+    ((8, 320, 2, 28, 28), 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),     # strided shortcut: dgrad = 4 residue classes
+    ((2, 64, 16, 28, 28), 128, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 1, 1)),     # lateral connection: temporal stride 4
 ]
 
 
@@ -47,7 +49,10 @@ def test_igemm2_small_shapes_forced(gpu):
     (a subprocess: the dispatcher reads them once)."""
     code = ("import torch; from tests import kernel_checks as kc; from tests.test_igemm2_hostsim import CASES;"
             "d=torch.device('cuda:0');"
+            "from tests.test_igemm2_hostsim import STRIDED;"
             "[ (kc.check_conv_fwd(d,*c), kc.check_conv_dgrad(d,*c)) for c in CASES ];"
+            "[ kc.check_conv_dgrad(d,*c) for c in STRIDED ];"
+            "kc.check_conv_dgrad(d,(1,32,9,4,4),64,(7,1,1),(4,1,1),(3,0,0),resid=True);"
             "kc.check_conv_dgrad(d,(1,64,2,9,9),64,(1,3,3),(1,1,1),(0,1,1),resid=True);"
             "kc.check_conv_fwd_fused(d,(1,64,2,9,9),72,(1,3,3),(1,1,1),(0,1,1),resid=True,relu=True); print('ok')")
     env = dict(os.environ, SF_IGEMM2_MINK="32", SF_IGEMM2_MINROWS="1")
