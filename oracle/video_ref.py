@@ -54,6 +54,29 @@ class fp16_storage_model:
         _STORE = self._old
 
 
+class _ReluFixedMask(torch.autograd.Function):
+    """relu(x) in forward; the BACKWARD mask is supplied by the caller instead of being x > 0.  Parity tests of fused
+    blocks take the masks the engine under test actually used: an element whose pre-activation lies within fp16 round-off
+    of zero may legitimately land on either side in two correct fp16 realisations, and its O(1) effect on the gradients
+    would otherwise drown the 2e-3 comparison of everything else (tests/block_checks.py)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return x.clamp_min(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask.to(g.dtype), None
+
+
+def _relu(x, masks=None, key=None):
+    if masks is not None and masks.get(key) is not None:
+        return _ReluFixedMask.apply(x, masks[key])
+    return F.relu(x)
+
+
 def _conv(x, w, *args):
     return _STORE(F.conv3d(x, _STORE(w), *args))   # args = (bias, stride, padding, dilation)
 
@@ -90,41 +113,48 @@ def _sub_bn(x, sd, prefix, training, stats_out, momentum, eps):
     return y * w.view(-1, 1, 1, 1) + b.view(-1, 1, 1, 1)
 
 
-def stem(x, sd, prefix, training, stats_out):
-    """ResNetBasicStem.forward: conv -> bn -> relu -> MaxPool3d([1,3,3],[1,2,2],[0,1,1]) (stem_helper.py:182-201)."""
+def stem(x, sd, prefix, training, stats_out, masks=None):
+    """ResNetBasicStem.forward: conv -> bn -> relu -> MaxPool3d([1,3,3],[1,2,2],[0,1,1]) (stem_helper.py:182-201).
+    ``masks`` (tests only, see _ReluFixedMask): {"relu": 0/1 tensor, "pool_index": int64 (N, C, T, Ho, Wo) flat h*W + w of the
+    element each pooled output is routed to} -- the backward runs through the routes the engine under test took."""
     w = sd[prefix + ".conv.weight"]
     kt = w.shape[2]
     x = _conv(_STORE(x), w, None, (1, 2, 2), (kt // 2, 3, 3))
-    x = _STORE(F.relu(_bn(x, sd, prefix + ".bn", training, stats_out)))
+    x = _STORE(_relu(_bn(x, sd, prefix + ".bn", training, stats_out), masks, "relu"))
+    if masks is not None and masks.get("pool_index") is not None:
+        N, C, T, H, W = x.shape
+        idx = masks["pool_index"]
+        return x.reshape(N, C, T, H * W).gather(3, idx.reshape(N, C, T, -1)).reshape(idx.shape)
     return F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
 
 
-def fuse(xs, xf, sd, prefix, alpha, training, stats_out):
+def fuse(xs, xf, sd, prefix, alpha, training, stats_out, masks=None):
     """FuseFastToSlow.forward (video_model_builder.py:162-169): time-strided conv on Fast, BN, ReLU, concat."""
     w = sd[prefix + ".conv_f2s.weight"]
     k = w.shape[2]
     f = _conv(xf, w, None, (alpha, 1, 1), (k // 2, 0, 0))
-    f = _STORE(F.relu(_bn(f, sd, prefix + ".bn", training, stats_out)))
+    f = _STORE(_relu(_bn(f, sd, prefix + ".bn", training, stats_out), masks, "relu"))
     return torch.cat([xs, f], 1)
 
 
-def res_block(x, sd, prefix, stride, dilation, stride_1x1, training, stats_out):
+def res_block(x, sd, prefix, stride, dilation, stride_1x1, training, stats_out, masks=None):
     """ResBlock.forward (resnet_helper.py:512-521) around BottleneckTransform.forward (:377-392) or, when the block has
-    no ``c`` convolution, BasicTransform.forward (:105-115: Tx3x3 stride s -> BN -> ReLU -> 1x3x3 dilated -> BN)."""
+    no ``c`` convolution, BasicTransform.forward (:105-115: Tx3x3 stride s -> BN -> ReLU -> 1x3x3 dilated -> BN).
+    ``masks`` ({"a", "b", "out"} -> 0/1 tensors): backward masks of the three ReLUs (see _ReluFixedMask; tests only)."""
     s_a, s_b = (stride, 1) if stride_1x1 else (1, stride)
     b2 = prefix + ".branch2"
     wa = sd[b2 + ".a.weight"]
     kt = wa.shape[2]
     if b2 + ".c.weight" not in sd:
         y = _conv(x, wa, None, (1, stride, stride), (kt // 2, 1, 1))
-        y = _STORE(F.relu(_bn(y, sd, b2 + ".a_bn", training, stats_out)))
+        y = _STORE(_relu(_bn(y, sd, b2 + ".a_bn", training, stats_out), masks, "a"))
         y = _conv(y, sd[b2 + ".b.weight"], None, (1, 1, 1), (0, dilation, dilation), (1, dilation, dilation))
         y = _bn(y, sd, b2 + ".b_bn", training, stats_out)
     else:
         y = _conv(x, wa, None, (1, s_a, s_a), (kt // 2, 0, 0))
-        y = _STORE(F.relu(_bn(y, sd, b2 + ".a_bn", training, stats_out)))
+        y = _STORE(_relu(_bn(y, sd, b2 + ".a_bn", training, stats_out), masks, "a"))
         y = _conv(y, sd[b2 + ".b.weight"], None, (1, s_b, s_b), (0, dilation, dilation), (1, dilation, dilation))
-        y = _STORE(F.relu(_bn(y, sd, b2 + ".b_bn", training, stats_out)))
+        y = _STORE(_relu(_bn(y, sd, b2 + ".b_bn", training, stats_out), masks, "b"))
         y = _conv(y, sd[b2 + ".c.weight"])
         y = _bn(y, sd, b2 + ".c_bn", training, stats_out)
     if prefix + ".branch1.weight" in sd:
@@ -132,7 +162,7 @@ def res_block(x, sd, prefix, stride, dilation, stride_1x1, training, stats_out):
         sc = _bn(sc, sd, prefix + ".branch1_bn", training, stats_out)
     else:
         sc = x
-    return _STORE(F.relu(sc + y))
+    return _STORE(_relu(sc + y, masks, "out"))
 
 
 def nonlocal_block(x, sd, prefix, pool_size, instantiation, training, stats_out):

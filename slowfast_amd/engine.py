@@ -34,6 +34,9 @@ FORCE_WEIGHT_PREP = False
 # Intermediate activations of a block (relu(bn_a(ya)), relu(bn_b(yb))) are materialised in fp16 (default) or recomputed
 # in the consumer's operand loads (SF_MATERIALIZE=0, the round-1 schedule; kept for A/B runs).
 MATERIALIZE = os.environ.get("SF_MATERIALIZE", "1") != "0"
+# Test hook: when a list, ResBlockFn.forward appends the tensors that decide its ReLU masks (raw conv outputs + BatchNorm
+# scale / shift, the block output) so that a parity test can hand the SAME masks to the oracle (tests/block_checks.py).
+CAPTURE = None
 
 
 def add_grad_ready_listener(fn):
@@ -356,6 +359,8 @@ class StemFn(torch.autograd.Function):
         k, s, p = mod.pool_layer.kernel_size, mod.pool_layer.stride, mod.pool_layer.padding
         assert k[0] == 1 and s[0] == 1 and p[0] == 0, "stem pooling is spatial-only in every reference config"
         out, arg = ops.pool_fwd(y, k[1:], s[1:], p[1:], affine=(st.scale, st.shift, True))
+        if CAPTURE is not None:
+            CAPTURE.append({"raw": [y], "bn": [(st.scale, st.shift)], "out": out, "argmax": arg})
         ctx.mod, ctx.xcl, ctx.y, ctx.st = mod, xcl, y, st
         ctx.pool = (tuple(k[1:]), tuple(s[1:]), tuple(p[1:]))
         ctx.pooled, ctx.arg = out, arg
@@ -442,6 +447,8 @@ class ResBlockFn(torch.autograd.Function):
         else:
             y1, s1 = None, None
             out, bits = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x, want_mask=True)
+        if CAPTURE is not None:
+            CAPTURE.append({"raw": list(raw), "bn": [(b.scale, b.shift) for b in bn], "out": out})
         ctx.mod = mod
         ctx.raw = (raw, y1, act, bits)
         ctx.bn = (bn, s1)
@@ -485,6 +492,8 @@ class ConvBNActFn(torch.autograd.Function):
         x = as_cl(x)
         y, st = unit.forward(x, None, training)
         out = ops.bn_act(y, st.scale, st.shift, relu=relu)
+        if CAPTURE is not None:
+            CAPTURE.append({"raw": [y], "bn": [(st.scale, st.shift)], "out": out})
         ctx.unit, ctx.relu, ctx.y, ctx.st = unit, relu, y, st
         ctx.save_for_backward(x)
         return out

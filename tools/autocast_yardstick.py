@@ -50,8 +50,13 @@ def run_case(name, device, dtype, loss_scale):
     kw = dict(device=device, autocast_dtype=dtype, loss_scale=loss_scale)
     if isinstance(inputs, mc._WithBoxes):
         kw["bboxes"] = inputs.bboxes
-    logits, loss, grads, stats = fam.loss_and_grads(sd, cfg, list(inputs), labels, **kw)
+    while True:         # GradScaler semantics: an overflowing step is skipped and the scale halved (train_net.py:152-172)
+        logits, loss, grads, stats = fam.loss_and_grads(sd, cfg, list(inputs), labels, **kw)
+        if all(torch.isfinite(g).all() for g in grads.values()) or kw["loss_scale"] <= 1.0:
+            break
+        kw["loss_scale"] /= 2.0
     rec = deviation(logits, loss, grads, stats, o_logits, o_loss, o_grads, o_stats)
+    rec["loss_scale_used"] = kw["loss_scale"]
     rec["storage_model"] = {k: v for k, v in mc.storage_model_yardstick(
         name, sd, cfg, inputs, labels, o_logits, o_loss, o_grads, o_stats).items()}
     return rec
