@@ -4,6 +4,7 @@
 #include "sf_common.h"
 #include "sf_igemm.h"
 #include "sf_igemm2.h"
+#include "sf_wgrad2.h"
 #include "sf_pool.h"
 #include "sf_dwconv.h"
 #include "sf_tokens.h"
@@ -538,9 +539,50 @@ static WgradPlan plan_wgrad(const sf_conv_desc* d) {
     return w;
 }
 
+// Second-generation weight gradient (sf_wgrad2.h): plain (already activated) input, at least 33 output channels, a K axis
+// that fills most of a 256-wide tile.  SF_WGRAD2=0 keeps the first kernel.
+struct Wgrad2Plan {
+    bool ok;
+    int BMW, tiles_k, tiles_c, Co_pad, Kpad, rows_per_split, splits;
+    size_t tab_bytes, ws_bytes;
+};
+static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
+    Wgrad2Plan w;
+    memset(&w, 0, sizeof(w));
+    const char* e;
+    if ((e = getenv("SF_WGRAD2")) && atoi(e) == 0) return w;
+    const int mink = (e = getenv("SF_WGRAD2_MINK")) ? atoi(e) : 192;
+    const int minrows = (e = getenv("SF_WGRAD2_MINROWS")) ? atoi(e) : 4096;
+    const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : 512;
+    const int taps = d->kT * d->kH * d->kW;
+    const int Ktot = taps * d->Ci;
+    const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
+    if (taps > SF_I2_MAXTAPS || d->Co <= 32 || Ktot < mink || M < minrows) return w;
+    if ((d->kT - 1) * d->dT > 127 || (d->kH - 1) * d->dH > 127 || (d->kW - 1) * d->dW > 127) return w;
+    if (plan_stem(d).ok) return w;
+    w.BMW = d->Co > 64 ? 128 : 64;
+    w.tiles_k = cdiv(Ktot, 256);
+    w.tiles_c = cdiv(d->Co, w.BMW);
+    w.Kpad = w.tiles_k * 256;
+    w.Co_pad = w.tiles_c * w.BMW;
+    int splits = cdiv(target, (int64_t)w.tiles_k * w.tiles_c);
+    const int64_t slab = (int64_t)w.Co_pad * w.Kpad * 4;
+    const int64_t cap = (256ll << 20) / slab;
+    if (splits > cap) splits = (int)(cap < 1 ? 1 : cap);
+    if (splits < 1) splits = 1;
+    w.rows_per_split = roundup(cdiv(M, splits), 32);
+    w.splits = cdiv(M, w.rows_per_split);
+    w.tab_bytes = ((size_t)M * 8 + 255) / 256 * 256;
+    w.ws_bytes = w.tab_bytes + (size_t)slab * w.splits;
+    w.ok = true;
+    return w;
+}
+
 extern "C" int64_t sf_conv_wgrad_workspace(const sf_conv_desc* d) {
     if (check_desc(d)) return -1;
-    const int64_t generic = (int64_t)plan_wgrad(d).ws_bytes;
+    int64_t generic = (int64_t)plan_wgrad(d).ws_bytes;
+    const Wgrad2Plan w2 = plan_wgrad2(d);
+    if (w2.ok && (int64_t)w2.ws_bytes > generic) generic = (int64_t)w2.ws_bytes;
     const StemPlan sp = plan_stem(d);
     return sp.ok && (int64_t)sp.ws_bytes > generic ? (int64_t)sp.ws_bytes : generic;
 }
@@ -557,7 +599,45 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
     int splits, Co_pad, Kpad;
     GatherSide gk = gather_fwd(d, x, in_scale, in_shift, in_relu);
     const StemPlan sp = plan_stem(d);
-    if (sp.ok && !in_scale) {
+    const Wgrad2Plan w2 = in_scale ? Wgrad2Plan{} : plan_wgrad2(d);
+    float* slabs = (float*)workspace;
+    if (w2.ok) {
+        REQUIRE(workspace_bytes >= (int64_t)w2.ws_bytes, "sf_conv_wgrad: workspace too small (%lld < %lld bytes)",
+                (long long)workspace_bytes, (long long)w2.ws_bytes);
+        REQUIRE(((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace) % 16 == 0, "sf_conv_wgrad: operands must be 16-byte aligned");
+        const int taps = d->kT * d->kH * d->kW;
+        RowtabParams t;
+        memset(&t, 0, sizeof(t));
+        t.tab = (i32x2*)workspace;
+        t.M = d->N * d->To * d->Ho * d->Wo;
+        t.fdW = make_fastdiv(d->Wo); t.fdH = make_fastdiv(d->Ho); t.fdT = make_fastdiv(d->To);
+        t.sT = d->Ti; t.sH = d->Hi; t.sW = d->Wi;
+        t.strT = d->sT; t.strH = d->sH; t.strW = d->sW; t.padT = d->pT; t.padH = d->pH; t.padW = d->pW;
+        t.ntaps = taps;
+        Wgrad2Params q;
+        memset(&q, 0, sizeof(q));
+        int ti = 0;
+        for (int kt = 0; kt < d->kT; ++kt)
+            for (int kh = 0; kh < d->kH; ++kh)
+                for (int kw = 0; kw < d->kW; ++kw, ++ti) {
+                    t.dt[ti] = (int8_t)(kt * d->dT); t.dh[ti] = (int8_t)(kh * d->dH); t.dw[ti] = (int8_t)(kw * d->dW);
+                    q.dlin[ti] = (kt * d->dT * d->Hi + kh * d->dH) * d->Wi + kw * d->dW;
+                }
+        hipLaunchKernelGGL(sf_wgrad2_rowtab_kernel, dim3(cdiv(t.M, SF_THREADS)), dim3(SF_THREADS), 0, s, t);
+        q.x = (const f16*)x; q.ldx = d->ldx; q.C = d->Ci;
+        q.dy = (const f16*)dy; q.ldy = d->ldy; q.Co = d->Co;
+        q.M = t.M; q.Ktot = gk.Ktot;
+        q.rowtab = (const i32x2*)workspace;
+        slabs = (float*)((char*)workspace + w2.tab_bytes);
+        q.ws = slabs; q.Co_pad = w2.Co_pad; q.Kpad = w2.Kpad;
+        q.tiles_k = w2.tiles_k; q.tiles_c = w2.tiles_c; q.rows_per_split = w2.rows_per_split;
+        const dim3 grid((unsigned)(w2.tiles_k * w2.tiles_c * w2.splits));
+        static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+        if (trace) fprintf(stderr, "[sfamd] wgrad2: M=%d Co=%d K=%d tiles %dx%d splits %d\n", q.M, q.Co, q.Ktot, w2.tiles_c, w2.tiles_k, w2.splits);
+        if (w2.BMW == 128) hipLaunchKernelGGL((sf_wgrad2_kernel<128>), grid, dim3(512), 0, s, q);
+        else hipLaunchKernelGGL((sf_wgrad2_kernel<64>), grid, dim3(512), 0, s, q);
+        splits = w2.splits; Co_pad = w2.Co_pad; Kpad = w2.Kpad;
+    } else if (sp.ok && !in_scale) {
         REQUIRE(workspace_bytes >= (int64_t)sp.ws_bytes, "sf_conv_wgrad: workspace too small (%lld < %lld bytes)",
                 (long long)workspace_bytes, (long long)sp.ws_bytes);
         StemParams q = stem_params(d, sp, x);
@@ -590,7 +670,7 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
     }
     if (check_launch("wgrad")) return -1;
     WgradReduceParams r;
-    r.ws = (const float*)workspace; r.splits = splits; r.Co = d->Cow ? d->Cow : d->Co; r.Co_pad = Co_pad; r.Kpad = Kpad;
+    r.ws = slabs; r.splits = splits; r.Co = d->Cow ? d->Cow : d->Co; r.Co_pad = Co_pad; r.Kpad = Kpad;
     r.Ktot = gk.Ktot; r.fdC = gk.fdC; r.dw = dw; r.Cw = d->Cw; r.taps = d->kT * d->kH * d->kW;
     r.out_scale = out_scale; r.accumulate = zero_first ? 0 : 1;
     int64_t total = (int64_t)r.Co * Kpad / 4;              // element quads

@@ -45,6 +45,14 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
     } while (0)
 #endif
 
+// Read-only table read through the SCALAR cache: a wave-uniform index into constant-address-space memory becomes s_load
+// (lgkmcnt), which keeps it out of the vector-memory queue whose counted waits pace the direct-to-LDS copies (an ordinary
+// global_load beside them makes hipcc wait vmcnt(0) at its first use and drains the pipeline).  The table must have been
+// written by an EARLIER kernel.
+#ifndef SF_SCALAR_PTR
+#define SF_SCALAR_PTR(T, p) ((const __attribute__((address_space(4))) T*)(p))
+#endif
+
 // 2^x on the transcendental unit (v_exp_f32: -inf -> 0, no range fix-ups)
 #ifndef SF_EXP2
 #define SF_EXP2(x) __builtin_amdgcn_exp2f(x)

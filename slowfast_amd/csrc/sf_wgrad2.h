@@ -1,0 +1,234 @@
+// Weight gradient of the implicit-GEMM convolutions, second generation (gfx950).
+//
+//   dW[co][tap*C + ci] = sum_m dY[m][co] * X[pos(m) + delta(tap)][ci]          (nn.Conv3d backward w.r.t. weight:
+//   BottleneckTransform a/b/c resnet_helper.py:331-369, ResBlock.branch1 :485-493, FuseFastToSlow video_model_builder.py:147-154)
+//
+// A "TN" GEMM whose reduction axis is the position axis m (12 544 ... 802 816 rows) and whose output is small, so the
+// parallelism comes from splitting m; each split leaves an fp32 partial tile and sf_wgrad_reduce_kernel sums them in a
+// fixed order.  What changed against sf_wgrad_kernel (sf_igemm.h), whose loaders decoded every row with three magic
+// divisions per 32-row step, staged both operands through registers and ended each step in a full barrier:
+//   * a ROW TABLE (sf_wgrad2_rowtab_kernel, one 8-byte entry per output position: linear source position of the row's
+//     base coordinate + a bit mask "tap t stays inside the source") is built once per call into the caller's workspace;
+//     the main loop reads it with SCALAR loads (rows of a copy instruction are wave-uniform), one step ahead;
+//   * both operands travel global -> LDS directly (global_load_lds_dwordx4), padding taps and rows beyond the split read a
+//     line of zeros; three stages, counted vmcnt, one raw barrier per 32-row step; two workgroups per CU;
+//   * both operands are position-major in memory ([m][channel]), the MFMA wants 8 consecutive m per lane: fragments come
+//     from ds_read_b64_tr_b16 (hardware transpose read).  The lane-linear LDS image is made conflict-free by an XOR of
+//     the 32-byte column pair with (m & 3) | ((m >> 3) & 1) << 2, applied on the SOURCE side;
+//   * 128 (co) x 256 (k) tiles: operand bytes per MAC 25 % below the 128 x 128 tile, half as many split partials.
+#pragma once
+#include "sf_common.h"
+#include "sf_igemm2.h"
+
+struct __attribute__((aligned(8))) i32x2 { int32_t x, y; };
+
+struct Wgrad2Params {
+    const f16* x; int ldx, C;           // forward input, rows of C channels
+    const f16* dy; int ldy, Co;
+    int M;                              // output positions
+    int Ktot;                           // taps * C
+    const i32x2* rowtab;                 // [M] {base position, tap mask}
+    int32_t dlin[SF_I2_MAXTAPS];        // linear source-position offset of tap t
+    float* ws;                          // split partials [splits][Co_pad][Kpad] fp32
+    int Co_pad, Kpad;
+    int tiles_k, tiles_c;
+    int rows_per_split;                 // multiple of 32
+};
+
+struct RowtabParams {
+    i32x2* tab;
+    int M;
+    FastDiv fdW, fdH, fdT;              // output extents
+    int sT, sH, sW;                     // source (input) extents
+    int strT, strH, strW, padT, padH, padW;
+    int ntaps;
+    int8_t dt[SF_I2_MAXTAPS], dh[SF_I2_MAXTAPS], dw[SF_I2_MAXTAPS];
+};
+
+__global__ __launch_bounds__(SF_THREADS) void sf_wgrad2_rowtab_kernel(RowtabParams p) {
+    const int m = blockIdx.x * SF_THREADS + threadIdx.x;
+    if (m >= p.M) return;
+    uint32_t q, a, b, c, n;
+    fd_divmod((uint32_t)m, p.fdW, q, c);
+    fd_divmod(q, p.fdH, q, b);
+    fd_divmod(q, p.fdT, n, a);
+    const int bt = (int)a * p.strT - p.padT, bh = (int)b * p.strH - p.padH, bw = (int)c * p.strW - p.padW;
+    uint32_t mk = 0;
+    for (int t = 0; t < p.ntaps; ++t) {
+        const int st = bt + p.dt[t], sh = bh + p.dh[t], sw = bw + p.dw[t];
+        const bool ok = (unsigned)st < (unsigned)p.sT && (unsigned)sh < (unsigned)p.sH && (unsigned)sw < (unsigned)p.sW;
+        mk |= (ok ? 1u : 0u) << t;
+    }
+    i32x2 e;
+    e.x = (((int)n * p.sT + bt) * p.sH + bh) * p.sW + bw;
+    e.y = (int)mk;
+    p.tab[m] = e;
+}
+
+// swizzle of the 32-byte column pair of row m inside its 256-byte window (see the header comment)
+__device__ __forceinline__ int w2_swz(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
+
+// BMW = 128: 8 waves as 2 (co) x 4 (k), wave tile 64 x 64.   BMW = 64: 8 waves as 1 x 8, wave tile 64 x 32.
+template <int BMW>
+__global__ __launch_bounds__(512, 4) void sf_wgrad2_kernel(Wgrad2Params p) {
+    constexpr int BKW = 256, ROWS = 32, NST = 3, NW = 8;
+    constexpr int WAVES_C = BMW / 64, WAVES_K = NW / WAVES_C;
+    constexpr int WN = BKW / WAVES_K;                   // 64 or 32 columns of k per wave
+    constexpr int TM = 4, TN = WN / 16;
+    constexpr int Y_ELEMS = ROWS * BMW, X_ELEMS = ROWS * BKW, STAGE = Y_ELEMS + X_ELEMS;
+    constexpr int YI = Y_ELEMS / 512;                   // dY copy instructions per stage (8 or 4), 512 halfs = 1 KB each
+    constexpr int YRPI = 512 / BMW;                     // dY rows per instruction (4 or 8)
+    constexpr int YCH = BMW / 8;                        // 16-byte chunks per dY row (16 or 8)
+    __shared__ __attribute__((aligned(16))) f16 smem[NST * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave / WAVES_K, wk = wave % WAVES_K;
+    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = (int)(wg % (uint32_t)p.tiles_k);
+    const int by = (int)((wg / (uint32_t)p.tiles_k) % (uint32_t)p.tiles_c);
+    const int bz = (int)(wg / ((uint32_t)p.tiles_k * (uint32_t)p.tiles_c));
+    const int k0 = bx * BKW, c0 = by * BMW;
+    const int r0 = bz * p.rows_per_split;
+    int r1 = r0 + p.rows_per_split;
+    if (r1 > p.M) r1 = p.M;
+    const int nsteps = r1 > r0 ? (r1 - r0 + ROWS - 1) / ROWS : 0;
+    const f16* const zline = reinterpret_cast<const f16*>(sf_zero_line);
+
+    // ---- X loader: instruction j of the wave (2 per stage) copies stage rows 2*(wave + 8j) + {0, 1}; lane -> row bit
+    // lane >> 5, physical 16-byte chunk lane & 31 of the 512-byte row; the logical chunk un-does the pair swizzle
+    const int xrr = lane >> 5, xpc = lane & 31;
+    int64_t xcol[2];        // channel offset + tap displacement (elements) of the logical chunk of instruction j
+    uint32_t xbit[2];       // mask bit of the chunk's tap (0: column beyond Ktot, never valid)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int mrow = 2 * (wave + 8 * j) + xrr;                      // stage-local row
+        const int lchunk = (((xpc >> 1) ^ w2_swz(mrow)) << 1) | (xpc & 1);
+        const int k = k0 + lchunk * 8;
+        if (k < p.Ktot) {
+            const int tap = k / p.C, ci = k - tap * p.C;
+            xbit[j] = 1u << tap;
+            xcol[j] = (int64_t)p.dlin[tap] * p.ldx + ci;
+        } else {
+            xbit[j] = 0u;
+            xcol[j] = 0;
+        }
+    }
+    // ---- dY loader: instruction wave (+ 8 only when YI > 8: never) copies stage rows YRPI*wave + lane / YCH
+    const int yrr = lane / YCH, ypc = lane % YCH;
+    const bool ywave = wave < YI;
+    const int ymrow = YRPI * wave + yrr;
+    int ylchunk;
+    if constexpr (BMW == 128) ylchunk = (((ypc >> 1) ^ w2_swz(ymrow)) << 1) | (ypc & 1);
+    else ylchunk = (((ypc >> 1) ^ (((ymrow >> 1) & 1) | (((ymrow >> 3) & 1) << 1))) << 1) | (ypc & 1);
+    const int yco = c0 + ylchunk * 8;
+    const bool yok = yco < p.Co;
+
+    // row-table entries of the two X rows of each of this wave's copy instructions: wave-uniform -> scalar loads
+    auto tab_rows = [&](int step, i32x2 (&e)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int m = r0 + step * ROWS + 2 * (wave + 8 * j) + r;
+                i32x2 v;
+                v.x = 0; v.y = 0;
+                if (m < r1) {
+                    v.x = SF_SCALAR_PTR(i32x2, p.rowtab)[m].x;
+                    v.y = SF_SCALAR_PTR(i32x2, p.rowtab)[m].y;
+                }
+                e[j][r] = v;
+            }
+    };
+    auto issue = [&](int step, int buf, const i32x2 (&e)[2][2]) {
+        f16* Ys = smem + buf * STAGE;
+        f16* Xs = Ys + Y_ELEMS;
+        if (ywave) {
+            const int m = r0 + step * ROWS + ymrow;
+            const f16* g = (m < r1 && yok) ? p.dy + (int64_t)m * p.ldy + yco : zline;
+            SF_GLOBAL_LOAD_LDS16(g, Ys + wave * 512);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pos = xrr ? e[j][1].x : e[j][0].x;
+            const uint32_t mk = (uint32_t)(xrr ? e[j][1].y : e[j][0].y);
+            const bool ok = (mk & xbit[j]) != 0u;
+            const f16* g = ok ? p.x + ((int64_t)pos * p.ldx + xcol[j]) : zline;
+            SF_GLOBAL_LOAD_LDS16(g, Xs + (wave + 8 * j) * 512);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int pl = lane & 15, g4 = lane >> 4;
+    auto compute = [&](int buf) {
+        const f16* Ys = smem + buf * STAGE;
+        const f16* Xs = Ys + Y_ELEMS;
+        f16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = 8 * g4 + 4 * h + (pl >> 2);                  // stage row this lane addresses
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int col = wc * 64 + i * 16;                       // first channel of the 16-wide fragment
+                int off;
+                if constexpr (BMW == 128) off = m * BMW + ((((col >> 4) ^ w2_swz(m)) << 4) | (4 * (pl & 3)));
+                else off = m * BMW + ((((col >> 4) ^ (((m >> 1) & 1) | (((m >> 3) & 1) << 1))) << 4) | (4 * (pl & 3)));
+                const f16x4 t = as_f16x4(SF_LDS_TR16(Ys + off));
+                af[i][4 * h + 0] = t[0]; af[i][4 * h + 1] = t[1]; af[i][4 * h + 2] = t[2]; af[i][4 * h + 3] = t[3];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wk * WN + j * 16;
+                const int off = m * BKW + ((((col >> 4) ^ w2_swz(m)) << 4) | (4 * (pl & 3)));
+                const f16x4 t = as_f16x4(SF_LDS_TR16(Xs + off));
+                bf[j][4 * h + 0] = t[0]; bf[j][4 * h + 1] = t[1]; bf[j][4 * h + 2] = t[2]; bf[j][4 * h + 3] = t[3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+
+    {
+        constexpr int COPIES = 2;           // X copies per wave and stage; waves 0 .. YI-1 carry one dY copy more and wait for it too
+        i32x2 e[2][2];
+        int issued = 0;
+        for (; issued < NST - 1 && issued < nsteps; ++issued) { tab_rows(issued, e); issue(issued, issued, e); }
+        if (issued < nsteps) tab_rows(issued, e);                       // entries of the next step to issue
+        int cur = 0, nxt = NST - 1;
+        for (int ks = 0; ks < nsteps; ++ks) {
+            if (ks + 1 < nsteps) SF_WAIT_VMEM_N(COPIES);
+            else SF_WAIT_VMEM();
+            SF_BARRIER_KEEP_VMEM();
+            if (issued < nsteps) {
+                issue(issued, nxt, e);
+                ++issued;
+                if (issued < nsteps) tab_rows(issued, e);               // scalar loads, consumed one step later
+            }
+            compute(cur);
+            cur = cur == NST - 1 ? 0 : cur + 1;
+            nxt = nxt == NST - 1 ? 0 : nxt + 1;
+        }
+    }
+
+    // every split owns its slab: plain stores, also when it had no rows to reduce (zeros)
+    float* slab = p.ws + (int64_t)bz * p.Co_pad * p.Kpad;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int kcol = k0 + wk * WN + j * 16 + pl;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = c0 + wc * 64 + i * 16 + 4 * g4 + r;
+                slab[(int64_t)co * p.Kpad + kcol] = acc[i][j][r];
+            }
+    }
+}

@@ -321,6 +321,7 @@ inline void hipsim_global_load_lds16(const void* gptr, void* lds_base) {
 #define SF_WAIT_VMEM() ((void)0)
 #define SF_WAIT_VMEM_N(N) ((void)0)
 #define SF_BARRIER_KEEP_VMEM() __syncthreads()
+#define SF_SCALAR_PTR(T, p) ((const T*)(p))
 
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -67,3 +67,34 @@ def test_igemm2_strided_dgrad(sim, force_v2, case):
 def test_igemm2_strided_dgrad_residual(sim, force_v2):
     kc.check_conv_dgrad(sim, (1, 32, 9, 4, 4), 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), resid=True)
     kc.check_conv_dgrad(sim, (1, 32, 2, 9, 9), 64, (1, 1, 1), (1, 2, 2), (0, 0, 0), resid=True)
+
+
+# ---- second-generation weight gradient (csrc/sf_wgrad2.h: row table, direct-to-LDS operands, transpose reads)
+@pytest.fixture()
+def force_w2(monkeypatch):
+    monkeypatch.setenv("SF_WGRAD2", "1")
+    monkeypatch.setenv("SF_WGRAD2_MINK", "32")
+    monkeypatch.setenv("SF_WGRAD2_MINROWS", "1")
+    monkeypatch.setenv("SF_WGRAD2_BLOCKS", "6")       # several splits even on tiny shapes
+
+
+WGRAD2_CASES = [
+    ((1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),       # BMW 64, K 576 = 2.25 tiles (partial last tile)
+    ((2, 64, 3, 12, 12), 136, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),    # BMW 128, two co tiles (ragged), 4 taps per k tile
+    ((1, 128, 4, 6, 6), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),      # temporal taps, 2 taps per k tile
+    ((1, 32, 2, 10, 10), 40, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),     # stride 2, 32 channels: 8 taps in the first k tile
+    ((1, 96, 1, 8, 8), 72, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),       # dilation 2, taps straddle k-tile boundaries (96 ch)
+    ((1, 64, 8, 4, 4), 128, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 1, 1)),      # lateral: 7 temporal taps, stride 4
+    ((2, 320, 1, 20, 20), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),   # plain GEMM K 320, 800 rows
+    ((1, 40, 3, 5, 5), 96, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),       # 27 taps, 40 channels (taps split inside 16-byte-chunk runs)
+    ((1, 24, 2, 7, 7), 48, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),       # K 216 < one tile
+]
+
+
+@pytest.mark.parametrize("case", WGRAD2_CASES)
+def test_wgrad2(sim, force_w2, case):
+    kc.check_conv_wgrad(sim, *case)
+
+
+def test_wgrad2_accumulate_and_scale(sim, force_w2):
+    kc.check_conv_wgrad(sim, (1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), out_scale=0.25)

@@ -42,6 +42,7 @@ IGEMM2_CASES = [
 def test_igemm2(gpu, case):
     kc.check_conv_fwd(gpu, *case)
     kc.check_conv_dgrad(gpu, *case)
+    kc.check_conv_wgrad(gpu, *case)       # sf_wgrad2.h (row table + direct-to-LDS + transpose reads) at these sizes
 
 
 def test_igemm2_small_shapes_forced(gpu):
@@ -53,9 +54,12 @@ def test_igemm2_small_shapes_forced(gpu):
             "[ (kc.check_conv_fwd(d,*c), kc.check_conv_dgrad(d,*c)) for c in CASES ];"
             "[ kc.check_conv_dgrad(d,*c) for c in STRIDED ];"
             "kc.check_conv_dgrad(d,(1,32,9,4,4),64,(7,1,1),(4,1,1),(3,0,0),resid=True);"
+            "from tests.test_igemm2_hostsim import WGRAD2_CASES;"
+            "[ kc.check_conv_wgrad(d,*c) for c in WGRAD2_CASES ];"
             "kc.check_conv_dgrad(d,(1,64,2,9,9),64,(1,3,3),(1,1,1),(0,1,1),resid=True);"
             "kc.check_conv_fwd_fused(d,(1,64,2,9,9),72,(1,3,3),(1,1,1),(0,1,1),resid=True,relu=True); print('ok')")
-    env = dict(os.environ, SF_IGEMM2_MINK="32", SF_IGEMM2_MINROWS="1")
+    env = dict(os.environ, SF_IGEMM2_MINK="32", SF_IGEMM2_MINROWS="1", SF_WGRAD2_MINK="32", SF_WGRAD2_MINROWS="1",
+               SF_WGRAD2_BLOCKS="6")
     env.pop("SFAMD_LIBRARY", None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
