@@ -98,6 +98,9 @@ def parse():
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU oracle and exit")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of a HIP graph")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the second model of BASELINE.json's metric (MViTv2-S) that the default run appends as `secondary`")
+    ap.add_argument("--master-port", type=int, default=0, help="(self-spawned multi-GPU runs) rendezvous port, 0 = pick a free one")
     return ap.parse_args()
 
 
@@ -170,33 +173,33 @@ def cpu_baseline(cfg, clips, threads=0):
         best = min(best, time.perf_counter() - t0)
     return {"value": clips / best, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{clips} clips x (fwd + {cfg.MODEL.LOSS_FUNC} loss + bwd), best of {iters} timed iterations after 1 warm-up, "
-                      f"torch {torch.__version__} CPU fp32"}
+                      f"torch {torch.__version__} CPU fp32; 'port' = the oracle restatement of the reference graph (oracle/), "
+                      "pinned bit-for-bit to the unmodified reference by tests/golden -- /root/reference does not exist on the GPU box"}
 
 
-def main():
-    a = parse()
-    if a.cpu_baseline_only:
-        import slowfast_amd as sa
-        cfg = sa.get_preset(a.preset, ["NUM_GPUS", 0, "TRAIN.BATCH_SIZE", a.cpu_baseline_clips]
-                            + PRESET_OPTS.get(a.preset, []))
-        print(json.dumps(cpu_baseline(cfg, a.cpu_baseline_clips, a.cpu_baseline_threads)), flush=True)
-        return
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a torchrun environment: re-execute under torch.distributed.run, one rank per
+    GPU on 127.0.0.1 (the contract's own launch line), and pass its exit code through."""
+    import socket
+    import subprocess
+    port = a.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
+
+def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_profile, cpu_base):
+    """Builds the model of `preset`, times `steps` training steps, returns the result object (rank 0) or None."""
     import slowfast_amd as sa
     from slowfast_amd.data_parallel import GradReducer
-    from slowfast_amd.lib import get_lib
     from slowfast_amd.profiler import KernelProfiler
-    assert get_lib().backend == "gfx950", "bench.py measures the HIP library only"
 
-    cfg = sa.get_preset(a.preset, ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", a.batch * world] + PRESET_OPTS.get(a.preset, []))
+    cfg = sa.get_preset(preset, ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", batch * world] + PRESET_OPTS.get(preset, []))
     torch.manual_seed(cfg.RNG_SEED)
     model = sa.build_model(cfg, gpu_id=local).train()
     if world > 1:                        # replicas start identical (DDP's initial broadcast)
@@ -208,19 +211,19 @@ def main():
 
     g = torch.Generator(device=dev).manual_seed(cfg.RNG_SEED + rank)
     T, S = cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE
-    fast = torch.randn((a.batch, 3, T, S, S), generator=g, device=dev)
+    fast = torch.randn((batch, 3, T, S, S), generator=g, device=dev)
     bboxes = None
     if cfg.DETECTION.ENABLE:             # AVA: boxes + one multi-hot action label row per box
-        R = a.batch * BOXES_PER_CLIP
+        R = batch * BOXES_PER_CLIP
         xy = torch.rand((R, 2), generator=g, device=dev) * 0.6 * S
         wh = (torch.rand((R, 2), generator=g, device=dev) * 0.35 + 0.05) * S
-        bidx = torch.arange(a.batch, device=dev).repeat_interleave(BOXES_PER_CLIP).float()[:, None]
+        bidx = torch.arange(batch, device=dev).repeat_interleave(BOXES_PER_CLIP).float()[:, None]
         bboxes = torch.cat([bidx, xy, torch.minimum(xy + wh, torch.full_like(xy, S - 1.0))], 1)
         labels = (torch.rand((R, cfg.MODEL.NUM_CLASSES), generator=g, device=dev) < 0.05).float()
     elif cfg.MODEL.LOSS_FUNC == "bce":
-        labels = (torch.rand((a.batch, cfg.MODEL.NUM_CLASSES), generator=g, device=dev) < 0.05).float()
+        labels = (torch.rand((batch, cfg.MODEL.NUM_CLASSES), generator=g, device=dev) < 0.05).float()
     else:
-        labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (a.batch,), generator=g, device=dev)
+        labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (batch,), generator=g, device=dev)
     loss_fn = make_loss(cfg)
     if len(cfg.DATA.INPUT_CHANNEL_NUM) == 2:
         idx = torch.linspace(0, T - 1, T // cfg.SLOWFAST.ALPHA).long().to(dev)
@@ -263,12 +266,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    a.warmup = max(a.warmup, 0 if a.no_graph else 2)         # graph mode: 1 eager step + the capturing step
-    for _ in range(a.warmup):
+    warmup = max(warmup, 0 if a.no_graph else 2)             # graph mode: 1 eager step + the capturing step
+    for _ in range(warmup):
         loss = step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
@@ -279,7 +282,7 @@ def main():
     final_loss = float(loss.detach())
 
     kernels, roof = {}, None
-    if not a.no_kernel_profile:
+    if kernel_profile:
         with KernelProfiler() as prof:
             eager_step()
         summ = prof.summary()
@@ -295,45 +298,95 @@ def main():
         else:
             roof = {"kernel": name, "bound": "hbm", "achieved": round(v["gbs"], 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(v["gbs"] / HBM_PEAK_GBS, 4), "traffic": None}
-        t = pmc_traffic(name, a.preset, v["calls"])
+        t = pmc_traffic(name, preset, v["calls"])
         if t is not None:
             roof["traffic"] = round(t, 0)
-            roof["traffic_note"] = ("HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                    f"(profiles/pmc_traffic_{a.preset}.json); algorithmic bytes per launch = "
+            roof["traffic_note"] = ("HBM bytes per launch from the COMMITTED rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                    f"(profiles/pmc_traffic_{preset}.json, not this run); algorithmic bytes per launch = "
                                     f"{v['bytes'] / max(v['calls'], 1):.0f}")
         roof["avg_launch_ms"] = round(v["avg_ms"], 4)
         roof["launches_per_step"] = v["calls"]
         roof["kernel_ms_per_step"] = round(tot, 2)
+        roof["timing_note"] = ("entry points timed with HIP events on the launch stream in ONE extra EAGER step after the timed "
+                               "region: includes event / launch overhead (the per-kernel sum exceeds the graph-replayed "
+                               "ms_per_step by a few per cent); the rocprofv3 --kernel-trace table of the same command is under "
+                               "profiles/")
 
+    out = None
     if rank == 0:
-        clips = a.batch * world * a.steps
+        clips = batch * world * steps
         value = clips / dt
-        ms = dt / a.steps * 1e3
+        ms = dt / steps * 1e3
         out = {
-            "metric": f"clips/sec (fwd+bwd), {METRIC_NAME.get(a.preset, a.preset)} synthetic clips, "
-                      f"per-GPU batch {a.batch}",
-            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": f"clips/sec (fwd+bwd), {METRIC_NAME.get(preset, preset)} synthetic clips, "
+                      f"per-GPU batch {batch}",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": f"{a.preset}: forward + {cfg.MODEL.LOSS_FUNC} loss + backward + {cfg.SOLVER.OPTIMIZING_METHOD} step, "
+            "config": {"workload": f"{preset}: forward + {cfg.MODEL.LOSS_FUNC} loss + backward + {cfg.SOLVER.OPTIMIZING_METHOD} step, "
                                    f"inputs resident in HBM, "
-                                   f"per-GPU batch {a.batch}", "global_batch": a.batch * world,
+                                   f"per-GPU batch {batch}", "global_batch": batch * world,
                        "parallelism": f"dp{world}", "loss_scale": a.loss_scale, "bucket_mb": a.bucket_mb,
                        "launch": "eager" if a.no_graph else "hip-graph(fwd+bwd) + eager all-reduce/SGD"},
             "per_gpu_clips_per_s": round(value / world, 2), "final_loss": round(final_loss, 4),
         }
-        if a.preset in BYTE_FLOOR_GB_PER_CLIP:
+        if preset in BYTE_FLOOR_GB_PER_CLIP:
             per_gpu = value / world
             out["model_roofline"] = {
-                "bound": "hbm", "achieved": round(per_gpu * BYTE_FLOOR_GB_PER_CLIP[a.preset], 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(per_gpu * BYTE_FLOOR_GB_PER_CLIP[a.preset] / HBM_PEAK_GBS, 4),
+                "bound": "hbm", "achieved": round(per_gpu * BYTE_FLOOR_GB_PER_CLIP[preset], 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(per_gpu * BYTE_FLOOR_GB_PER_CLIP[preset] / HBM_PEAK_GBS, 4),
                 "note": "whole step vs the fused-ideal byte floor 5*E*2B per clip (SURVEY.md 8d)",
-                "mfma_tflops": round(per_gpu * TRAIN_GFLOP_PER_CLIP[a.preset] / 1e3, 1)}
+                "mfma_tflops": round(per_gpu * TRAIN_GFLOP_PER_CLIP[preset] / 1e3, 1)}
         if roof is not None:
             out["roofline"] = roof
             out["kernels"] = kernels
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_subprocess(a)
+        if cpu_base:
+            a2 = argparse.Namespace(**vars(a))
+            a2.preset = preset
+            out["cpu_baseline"] = cpu_baseline_subprocess(a2)
+    # release this model before another preset is built in the same process
+    reducer.close()
+    del train_step, reducer, opt, model, step_model, inputs, fast
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    a = parse()
+    if a.cpu_baseline_only:
+        import slowfast_amd as sa
+        cfg = sa.get_preset(a.preset, ["NUM_GPUS", 0, "TRAIN.BATCH_SIZE", a.cpu_baseline_clips]
+                            + PRESET_OPTS.get(a.preset, []))
+        print(json.dumps(cpu_baseline(cfg, a.cpu_baseline_clips, a.cpu_baseline_threads)), flush=True)
+        return
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from slowfast_amd.lib import get_lib
+    assert get_lib().backend == "gfx950", "bench.py measures the HIP library only"
+
+    out = run_preset(a, a.preset, a.batch, a.steps, a.warmup, rank, local, world, dev,
+                     kernel_profile=not a.no_kernel_profile, cpu_base=(world == 1 and not a.no_cpu_baseline))
+    # BASELINE.json's metric names two models: the default single-GPU run appends the second one (MViTv2-S 16x224^2, batch
+    # 32) measured the same way in the same process, so that the driver's line carries both
+    if a.preset == "SLOWFAST_8x8_R50" and world == 1 and not a.no_secondary and a.batch == 32:
+        sec = run_preset(a, "MVITv2_S_16x4", 32, min(a.steps, 10), min(a.warmup, 3), rank, local, world, dev,
+                         kernel_profile=not a.no_kernel_profile, cpu_base=False)
+        if out is not None and sec is not None:
+            out["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config",
+                                                    "model_roofline", "roofline", "kernels", "final_loss") if k in sec}
+            out["secondary"]["preset"] = "MVITv2_S_16x4"
+    if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -240,14 +240,23 @@ def conv_dgrad(dy, wd, geom, resid=None, out=None, resid_bits=None):
 
 
 _workspaces = {}
+_retired_workspaces = []
 
 
 def _workspace(device, nbytes):
     """One grow-only scratch buffer per device: every user is enqueued on the same stream, so launches that
-    share it are ordered (the callee allocates nothing, SURVEY.md 8b 'Ownership')."""
+    share it are ordered (the callee allocates nothing, SURVEY.md 8b 'Ownership').
+
+    A captured HIP graph (slowfast_amd.step.TrainStep) bakes the buffer's ADDRESS into its kernel nodes.  When a later,
+    larger request replaces the buffer, the superseded one is therefore kept alive (never handed back to the caching
+    allocator): a graph captured earlier keeps writing its split-K partials into memory that is still reserved for
+    exactly that, instead of into whatever tensor the allocator would have placed there.  Growth happens a handful of
+    times per process (the largest layer geometry wins), so the retained memory is bounded by ~2x the final size."""
     ws = _workspaces.get(device)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if ws is not None:
+            _retired_workspaces.append(ws)
+        ws = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[device] = ws
     return ws
 

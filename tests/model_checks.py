@@ -339,8 +339,15 @@ def check_eval(name, device, fused=False, tol=2e-3, report=None):
         o_probs = eval_forward(sd, cfg, inputs)
     g_probs = torch.tensor(gold["probs"])
     assert float((o_probs - g_probs).abs().max()) <= 1e-5 * float(g_probs.max()), "oracle drifted from the golden fixture"
-    with video_ref.fp16_storage_model(), torch.no_grad():      # what fp16 storage alone costs on this case
-        yard = float((eval_forward(sd, cfg, inputs) - o_probs).abs().max() / g_probs.max())
+    rec = (_autocast if _autocast is not None else (autocast_yardstick(name), _autocast)[1]).get(name) or {}
+    if rec.get("finite") and isinstance(rec.get("probs"), float):
+        # reference-derived: the oracle's eval forward under torch.autocast(float16) on MI355X (tools/autocast_yardstick.py),
+        # max-ed with the storage-model figure recorded beside it (two realisations of the same rounding noise)
+        yard, factor = max(rec["probs"], float(rec.get("storage_model", {}).get("probs", 0.0))), YARD
+    else:
+        with video_ref.fp16_storage_model(), torch.no_grad():  # no autocast entry yet: storage model alone, wider factor
+            yard = float((eval_forward(sd, cfg, inputs) - o_probs).abs().max() / g_probs.max())
+        factor = 2.5
     model.load_state_dict(sd)
     model = model.to(device).eval()
     if fused:
@@ -354,5 +361,5 @@ def check_eval(name, device, fused=False, tol=2e-3, report=None):
            "argmax_equal": bool((probs.argmax(1) == g_probs.argmax(1)).all()), "yardstick": yard}
     if report is not None:
         report[name] = res
-    assert res["vs_golden"] <= max(tol, YARD * yard) and res["row_sum"] <= 2e-3, res
+    assert res["vs_golden"] <= max(tol, factor * yard) and res["row_sum"] <= 2e-3, res
     return res

@@ -62,6 +62,33 @@ def run_case(name, device, dtype, loss_scale):
     return rec
 
 
+def run_eval_case(name, device, dtype):
+    """Eval / multi-view test path (tools/test_net.py): the oracle's eval forward under autocast vs its fp32 run."""
+    from oracle.make_golden import eval_forward
+    import slowfast_amd as sa
+    gold = mc.load_golden(name)
+    cfg = mc.cfg_for(gold)
+    model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    fam = mc.family(cfg)
+    sd = fam.randomize_state(shapes, gold["param_seed"])
+    if "final_bn_gamma_scale" in gold.get("state_tweaks", {}):
+        video_ref.scale_final_bn(sd, gold["state_tweaks"]["final_bn_gamma_scale"])
+    inputs, _ = video_ref.synthetic_batch(cfg, gold["batch"], gold["data_seed"], crop=gold["test_crop"])
+    if fam is video_ref:
+        sd = video_ref.calibrate_running_stats(sd, cfg, inputs)
+    with torch.no_grad():
+        o_probs = eval_forward(sd, cfg, inputs)
+        sdd = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in sd.items()}
+        with torch.autocast(torch.device(device).type, dtype=dtype):
+            probs = eval_forward(sdd, cfg, [x.to(device) for x in inputs]).float().cpu()
+        with video_ref.fp16_storage_model():
+            sm = eval_forward(sd, cfg, inputs)
+    pmax = float(o_probs.max())
+    return {"probs": float((probs - o_probs).abs().max() / pmax), "finite": bool(torch.isfinite(probs).all()),
+            "storage_model": {"probs": float((sm - o_probs).abs().max() / pmax)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*")
@@ -71,7 +98,7 @@ def main():
     ap.add_argument("--loss-scale", type=float, default=1024.0)
     a = ap.parse_args()
     names = a.cases or sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(mc.GOLDEN_DIR, "*.json"))
-                              if not os.path.basename(p).startswith(("eval_", "autocast_")))
+                              if not os.path.basename(p).startswith("autocast_"))
     out = {"_meta": {"torch": torch.__version__, "device": a.device, "dtype": a.dtype, "loss_scale": a.loss_scale,
                      "device_name": torch.cuda.get_device_name(0) if a.device.startswith("cuda") else "cpu",
                      "what": "deviation of the pinned oracle graph under torch.autocast from its fp32 CPU run"}}
@@ -80,7 +107,10 @@ def main():
     for name in names:
         t = time.time()
         try:
-            out[name] = run_case(name, a.device, getattr(torch, a.dtype), a.loss_scale)
+            if name.startswith("eval_"):
+                out[name] = run_eval_case(name, a.device, getattr(torch, a.dtype))
+            else:
+                out[name] = run_case(name, a.device, getattr(torch, a.dtype), a.loss_scale)
             print(name, {k: (round(v, 6) if isinstance(v, float) else v) for k, v in out[name].items() if k != "storage_model"},
                   f"{time.time() - t:.1f}s", flush=True)
         except Exception as e:       # noqa: BLE001 -- a case the stock kernels cannot run is recorded, not fatal
