@@ -55,7 +55,8 @@ def make_loss(cfg):
 # libsfamd entry point -> the HIP kernels it launches (for mapping rocprofv3 PMC traffic, collected per kernel in a
 # separate --pmc pass and committed under profiles/, onto the entry point the in-process profiler times)
 ENTRY_KERNELS = {
-    "sf_conv_wgrad": ("sf_wgrad_kernel", "sf_wgrad_reduce_kernel"),
+    "sf_conv_wgrad": ("sf_wgrad_kernel", "sf_wgrad2_kernel", "sf_wgrad2_rowtab_kernel", "sf_stem_wgrad_kernel",
+                      "sf_wgrad_reduce_kernel"),
     "sf_bn_bwd_apply": ("sf_bn_bwd_apply_kernel",), "sf_bn_bwd_reduce": ("sf_bn_bwd_reduce_kernel",),
     "sf_bn_act": ("sf_bn_act_kernel",), "sf_dwconv_fwd": ("sf_dwconv_fwd",), "sf_dwconv_dgrad": ("sf_dwconv_dgrad",),
     "sf_dwconv_wgrad": ("sf_dwconv_wgrad",), "sf_softmax_fwd": ("sf_softmax_fwd_kernel",),

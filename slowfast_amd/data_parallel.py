@@ -49,6 +49,7 @@ class GradReducer:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._torch_hooks = []
+        self._prescale, self._prescaled = 1.0 / self.world, set()   # compressed buckets are averaged before the cast
         self._listener = engine.add_grad_ready_listener(self._on_ready)
         # parameters owned by plain torch modules (the head) announce themselves through autograd hooks
         self._hooked = set()
@@ -65,6 +66,7 @@ class GradReducer:
         self._pending = [len(ps) for _, _, ps in self.buckets]
         self._ready = set()
         self._handles = []
+        self._prescaled = set()
 
     def begin_replay(self):
         """Before replaying a captured forward/backward (slowfast_amd.step.TrainStep): the captured work clears
@@ -73,6 +75,7 @@ class GradReducer:
         self._pending = [len(ps) for _, _, ps in self.buckets]
         self._ready = set()
         self._handles = []
+        self._prescaled = set()
 
     def attach_torch_param_hooks(self, params):
         for p in params:
@@ -96,9 +99,12 @@ class GradReducer:
         s, e, _ = self.buckets[bi]
         view = self.flat[s:e]
         if self.comm_dtype is not None:
-            low = view.to(self.comm_dtype)
+            # divide by world * loss_scale in fp32 BEFORE compressing (torch's fp16_compress_hook order): a loss-scaled
+            # sum over the ranks would leave the fp16 range at |g| ~ 65504 / (world * loss_scale)
+            low = (view * self._prescale).to(self.comm_dtype)
             h = dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._handles.append((h, view, low))
+            self._prescaled.add(bi)
         else:
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._handles.append((h, None, None))
@@ -115,6 +121,13 @@ class GradReducer:
                 if low is not None:
                     view.copy_(low)
             self._handles = []
+        if self._prescaled:             # compressed buckets already carry 1/world: only the loss scale is left for them
+            for bi, (s, e, _) in enumerate(self.buckets):
+                k = 1.0 / loss_scale if bi in self._prescaled else 1.0 / (self.world * loss_scale)
+                if k != 1.0:
+                    self.flat[s:e].mul_(k)
+            self._prescaled = set()
+            return
         k = 1.0 / (self.world * loss_scale)
         if k != 1.0:
             self.flat.mul_(k)
@@ -127,3 +140,49 @@ class GradReducer:
         engine.remove_grad_ready_listener(self._listener)
         for h in self._torch_hooks:
             h.remove()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's own boundary: torch DDP + comm hook (slowfast/models/build.py:64-80)
+def xgmi_allreduce_hook(state, bucket):
+    """DDP communication hook (``register_comm_hook(state, hook)`` API: hook(state, GradBucket) -> Future[Tensor]):
+    mean all-reduce of the bucket in fp32 over the process group in ``state`` (None = default group).  Semantically DDP's
+    built-in allreduce_hook; installed explicitly so that the bucket size chosen in wrap_ddp (large buckets: xGMI links
+    are point-to-point, a ring is bound per link, so few large collectives beat many 25 MiB ones) travels with it."""
+    group = state if state is not None else dist.group.WORLD
+    world = dist.get_world_size(group)
+    t = bucket.buffer()
+    t.div_(world)
+    fut = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True).get_future()
+    return fut.then(lambda f: f.value()[0])
+
+
+def fp16_compress_hook(state, bucket):
+    """MODEL.FP16_ALLREDUCE (build.py:77-80 installs torch's fp16_compress_hook): divide by the world size FIRST, then
+    compress to fp16, all-reduce, decompress into the bucket -- the division before the cast is what keeps loss-scaled
+    gradients inside the fp16 range."""
+    group = state if state is not None else dist.group.WORLD
+    world = dist.get_world_size(group)
+    buf = bucket.buffer()
+    low = (buf / world).to(torch.float16)
+    fut = dist.all_reduce(low, op=dist.ReduceOp.SUM, group=group, async_op=True).get_future()
+
+    def decompress(f):
+        buf.copy_(f.value()[0])
+        return buf
+    return fut.then(decompress)
+
+
+def wrap_ddp(model, device=None, find_unused_parameters=False, fp16_allreduce=False, bucket_cap_mb=64, process_group=None):
+    """torch.nn.parallel.DistributedDataParallel around the drop-in model, as slowfast/models/build.py:64-80 wraps the
+    reference model.  Switches the engine to autograd-delivered parameter gradients (engine.GRADS_VIA_AUTOGRAD): DDP's
+    reducer hooks the parameters' AccumulateGrad nodes, so gradients written straight into ``param.grad`` would never be
+    all-reduced."""
+    engine.GRADS_VIA_AUTOGRAD = True
+    kw = dict(find_unused_parameters=find_unused_parameters, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
+              process_group=process_group)
+    if device is not None:
+        kw.update(device_ids=[device], output_device=device)
+    ddp = torch.nn.parallel.DistributedDataParallel(module=model, **kw)
+    ddp.register_comm_hook(state=process_group, hook=fp16_compress_hook if fp16_allreduce else xgmi_allreduce_hook)
+    return ddp

@@ -67,6 +67,8 @@ def hold_notifications(passes, params=None):
 
 
 def _notify(params):
+    if GRADS_VIA_AUTOGRAD:          # the consumer of the gradients (DDP's reducer) hooks autograd itself
+        return
     if _sub_passes > 1:
         final = []
         for p in params:
@@ -128,14 +130,45 @@ def as_cl(t):
     return ops.to_cl(t)
 
 
+# Gradient delivery.  Default (False): backward kernels write d(loss)/d(param) straight into ``param.grad`` -- views of
+# GradReducer's flat bucket memory -- and announce finished parameters to the grad-ready listeners.  True: every
+# autograd.Function RETURNS its parameter gradients instead, so that they reach the parameters through autograd's
+# AccumulateGrad nodes -- which is where torch.nn.parallel.DistributedDataParallel (the wrap the reference's build_model
+# applies, slowfast/models/build.py:64-80) hooks its bucketed all-reduce and any register_comm_hook() hook.
+GRADS_VIA_AUTOGRAD = False
+_pending_grads = {}
+
+
 def _grad_dest(param):
     """(tensor to write d(loss)/d(param) into, whether the kernel must clear it first)."""
+    if GRADS_VIA_AUTOGRAD:
+        g = _pending_grads.get(id(param))
+        if g is not None:
+            return g, False
+        g = torch.empty_like(param, memory_format=torch.contiguous_format)
+        _pending_grads[id(param)] = g
+        return g, True
     if param.grad is not None:
         assert param.grad.dtype == torch.float32 and param.grad.is_contiguous()
         return param.grad, False
     g = torch.empty_like(param, memory_format=torch.contiguous_format)
     param.grad = g
     return g, True
+
+
+def param_grads(ctx, lead, extra=()):
+    """The entries of a Function.backward return that belong to the ``*params`` the forward received after its ``lead``
+    leading arguments: Nones when gradients are written in place, the collected tensors under GRADS_VIA_AUTOGRAD.
+    ``extra``: parameters passed among the leading arguments; their collected gradients are returned as a second tuple."""
+    n = len(ctx.needs_input_grad) - lead
+    if not GRADS_VIA_AUTOGRAD:
+        return ((None,) * n, (None,) * len(extra)) if extra else (None,) * n
+    ps = getattr(ctx, "_sf_params", ())
+    assert len(ps) == n, "Function.forward must record its *params (ctx._sf_params)"
+    out = tuple(_pending_grads.pop(id(p), None) for p in ps)
+    if extra:
+        return out, tuple(_pending_grads.pop(id(p), None) for p in extra)
+    return out
 
 
 class BNState:
@@ -353,6 +386,7 @@ class StemFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
+        ctx._sf_params = params
         unit = mod._unit
         xcl = unit.prepare_input(x) if isinstance(unit, StemConvUnit) else ops.to_cl(x)
         y, st = unit.forward(xcl, None, mod.training)
@@ -375,7 +409,7 @@ class StemFn(torch.autograd.Function):
         unit.backward(ctx.xcl, None, dy, need_dx=False)
         _notify(unit.params())
         ctx.xcl = ctx.y = ctx.pooled = ctx.arg = None
-        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return (None, None) + param_grads(ctx, 2)
 
 
 class FuseFn(torch.autograd.Function):
@@ -385,6 +419,7 @@ class FuseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_s, x_f, mod, *params):
+        ctx._sf_params = params
         unit = mod._unit
         x_s, x_f = as_cl(x_s), as_cl(x_f)
         yf, st = unit.forward(x_f, None, mod.training)
@@ -409,7 +444,7 @@ class FuseFn(torch.autograd.Function):
         _notify(unit.params())
         ctx.yf = None
         dx_s = dcat[:, :ctx.Cs] if ctx.needs_input_grad[0] else None
-        return (dx_s, dx_f, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+        return (dx_s, dx_f, None) + param_grads(ctx, 3)
 
 
 class ResBlockFn(torch.autograd.Function):
@@ -419,6 +454,7 @@ class ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
+        ctx._sf_params = params
         x = as_cl(x)
         units, P = mod.branch2._chain, mod._proj
         tr = mod.training
@@ -481,7 +517,7 @@ class ResBlockFn(torch.autograd.Function):
             dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=dout, resid_bits=bits)
         _notify(mod._param_list)
         ctx.raw = ctx.bn = None
-        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return (dx, None) + param_grads(ctx, 2)
 
 
 class ConvBNActFn(torch.autograd.Function):
@@ -489,6 +525,7 @@ class ConvBNActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, unit, relu, training, *params):
+        ctx._sf_params = params
         x = as_cl(x)
         y, st = unit.forward(x, None, training)
         out = ops.bn_act(y, st.scale, st.shift, relu=relu)
@@ -506,4 +543,4 @@ class ConvBNActFn(torch.autograd.Function):
         dx = unit.backward(x, None, dy, need_dx=ctx.needs_input_grad[0])
         _notify(unit.params())
         ctx.y = None
-        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+        return (dx, None, None, None) + param_grads(ctx, 4)

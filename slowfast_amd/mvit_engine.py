@@ -16,7 +16,7 @@ import os
 import torch
 
 from . import engine, tokens
-from .engine import _grad_dest, _notify
+from .engine import _grad_dest, _notify, param_grads
 
 _f16 = torch.float16
 
@@ -412,6 +412,7 @@ class MultiScaleBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, thw, drop, *params):
+        ctx._sf_params = params
         att = mod.attn
         B, N, dim = x.shape
         plan = mod._plan(B, thw, x.device)
@@ -498,7 +499,7 @@ class MultiScaleBlockFn(torch.autograd.Function):
         dx = mod._norm1.backward(dxn, sv["x"], *sv["s1"], resid=dx_skip)
         _notify(mod._param_list)
         ctx.sv = None
-        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+        return (dx, None, None, None) + param_grads(ctx, 4)
 
 
 def _attention_sub_forward(sub, plan, x):
@@ -558,6 +559,7 @@ class RevBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, mod, thw, drop, *params):
+        ctx._sf_params = params
         B, N, _ = x2.shape
         plan = mod._plan(B, thw, x2.device)
         att = mod.F.attn
@@ -585,7 +587,7 @@ class RevBlockFn(torch.autograd.Function):
         dx2 = _attention_sub_backward(mod.F, plan, ctx.sf, df, resid=dy2)  # d(X2) = dY2 + F'(X2)^T d(F)
         _notify(mod._param_list)
         ctx.sf = ctx.sg = None
-        return (dy1t, dx2) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return (dy1t, dx2) + param_grads(ctx, 2)
 
 
 class StageTransitionFn(torch.autograd.Function):
@@ -595,6 +597,7 @@ class StageTransitionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, mod, thw, drop, *params):
+        ctx._sf_params = params
         B, N, C = x1.shape
         plan = mod._plan(B, thw, x1.device)
         att = mod.F.attn
@@ -641,8 +644,8 @@ class StageTransitionFn(torch.autograd.Function):
         if res["two"]:
             half = mod._half(B, dx.device)
             g1 = tokens.row_scale_add(dx, half, res["N"])
-            return (g1, g1.clone()) + (None,) * (len(ctx.needs_input_grad) - 2)
-        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+            return (g1, g1.clone()) + param_grads(ctx, 2)
+        return (dx, None) + param_grads(ctx, 2)
 
 
 class PatchEmbedFn(torch.autograd.Function):
@@ -651,6 +654,7 @@ class PatchEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, cls_token, pos, *params):
+        ctx._sf_params = params
         unit = mod._unit
         xcl = unit.prepare_input(x)
         y, _ = unit.forward(xcl, None, mod.training)            # (B, C, T, H, W) channels-last == (B, THW, C) rows
@@ -694,7 +698,8 @@ class PatchEmbedFn(torch.autograd.Function):
         ctx.xcl = None
         # d(pos_embed) = sum over the batch of d(tokens), fp32; autograd routes it to the (separate) embedding tables
         dpos = dout.float().sum(0, keepdim=True) if ctx.has_pos and ctx.needs_input_grad[3] else None
-        return (None, None, None, dpos) + (None,) * (len(ctx.needs_input_grad) - 4)
+        pg, (dcls,) = param_grads(ctx, 4, extra=(cls_token,)) if cls_token is not None else (param_grads(ctx, 4), (None,))
+        return (None, None, dcls, dpos) + pg
 
 
 class ClsNormFn(torch.autograd.Function):
@@ -704,6 +709,7 @@ class ClsNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, mode, has_cls, *params):
+        ctx._sf_params = params
         unit = mod._norm_unit
         s = int(bool(has_cls))
         if mode == "norm_mean":
@@ -734,7 +740,7 @@ class ClsNormFn(torch.autograd.Function):
                 dx = torch.zeros(ctx.shape, dtype=_f16, device=dy.device)
                 dx[:, 0] = dxc
         _notify(ctx.unit.params())
-        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+        return (dx, None, None, None) + param_grads(ctx, 4)
 
 
 class TokenNormFn(torch.autograd.Function):
@@ -743,6 +749,7 @@ class TokenNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, has_cls, *params):
+        ctx._sf_params = params
         unit = mod._norm_unit
         s = int(bool(has_cls))
         B, N, C = x.shape
@@ -763,4 +770,4 @@ class TokenNormFn(torch.autograd.Function):
         else:
             dx = dxt
         _notify(ctx.unit.params())
-        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+        return (dx, None, None) + param_grads(ctx, 3)

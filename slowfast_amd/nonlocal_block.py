@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, tokens
-from .engine import ConvUnit, _grad_dest, _notify, as_cl
+from .engine import ConvUnit, _grad_dest, _notify, as_cl, param_grads
 from .lib import get_lib
 from .x3d import cl5d, rows2d
 
@@ -69,6 +69,7 @@ def _affinity(mod, theta, phi, g, N, S, T, H, W, device):
 class NonlocalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, *params):
+        ctx._sf_params = params
         x = as_cl(x)
         N, C, T, H, W = x.shape
         tr = mod.training
@@ -129,7 +130,7 @@ class NonlocalFn(torch.autograd.Function):
         dx = mod._theta.backward(x, None, cl5d(dth2, N, Ci, (T, H, W)), need_dx=True, resid=dxskip)
         _notify(list(mod.parameters()))
         ctx.sv = None
-        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return (dx, None) + param_grads(ctx, 2)
 
 
 class Nonlocal(nn.Module):

@@ -38,14 +38,34 @@ class Registry:
 MODEL_REGISTRY = Registry("MODEL")
 
 
-def build_model(cfg, gpu_id=None):
-    """Same contract as slowfast/models/build.py:22-81 (minus the DDP wrap, replaced by
-    slowfast_amd.data_parallel.GradReducer when torch.distributed is initialised)."""
+def build_model(cfg, gpu_id=None, data_parallel=None):
+    """Same contract as slowfast/models/build.py:22-81: construct ``MODEL_REGISTRY[cfg.MODEL.MODEL_NAME](cfg)``, move it
+    to the process's GPU and -- with ``cfg.NUM_GPUS > 1`` inside an initialised process group -- return it wrapped for
+    multi-process data parallelism, so tools/train_net.py keeps working unchanged.
+
+    ``data_parallel`` (default: env SF_DATA_PARALLEL or "ddp"):
+      * "ddp": ``torch.nn.parallel.DistributedDataParallel`` exactly as the reference wraps (device_ids / output_device /
+        find_unused_parameters; backend "nccl" is RCCL over xGMI on ROCm).  The engine then returns parameter gradients
+        through autograd (engine.GRADS_VIA_AUTOGRAD) so that DDP's reducer -- its bucketing, its overlap with backward and
+        any ``register_comm_hook`` hook -- sees them.  MODEL.FP16_ALLREDUCE installs
+        data_parallel.fp16_compress_hook (the reference's comm_hooks_default.fp16_compress_hook semantics); otherwise
+        data_parallel.xgmi_allreduce_hook (few, large fp32 collectives sized for point-to-point xGMI links).
+      * "reducer" / False: the bare module; the caller drives slowfast_amd.data_parallel.GradReducer + step.TrainStep
+        (flat gradient memory written in place by the backward kernels, HIP-graph replay -- what bench.py times)."""
+    import os
+
     from . import mvit, video_models, x3d  # noqa: F401  (registers the model classes)
     if torch.cuda.is_available():
         assert cfg.NUM_GPUS <= torch.cuda.device_count(), "Cannot use more GPU devices than available"
     model = MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    dev = None
     if cfg.NUM_GPUS:
         dev = torch.cuda.current_device() if gpu_id is None else gpu_id
         model = model.cuda(device=dev)
+    mode = os.environ.get("SF_DATA_PARALLEL", "ddp") if data_parallel is None else data_parallel
+    import torch.distributed as dist
+    if cfg.NUM_GPUS > 1 and mode not in (False, "reducer") and dist.is_available() and dist.is_initialized():
+        from . import data_parallel as dp
+        model = dp.wrap_ddp(model, device=dev, find_unused_parameters=bool(cfg.MODEL.DETACH_FINAL_FC),
+                            fp16_allreduce=bool(cfg.MODEL.FP16_ALLREDUCE))
     return model

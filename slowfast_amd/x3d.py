@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, tokens
-from .engine import BNState, ConvUnit, StemConvUnit, _grad_dest, _notify, _sync_of, as_cl, bn_statistics
+from .engine import BNState, ConvUnit, StemConvUnit, _grad_dest, _notify, _sync_of, as_cl, bn_statistics, param_grads
 from .lib import get_lib
 from .registry import MODEL_REGISTRY
 from .resblocks import ResStage, _TRANS
@@ -149,6 +149,7 @@ class X3DStemFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
+        ctx._sf_params = params
         xy, dw, bn = mod._xy, mod._dw, mod._bn
         xcl = xy.prepare_input(x)
         y1, _ = xy.forward(xcl, None, mod.training)
@@ -167,7 +168,7 @@ class X3DStemFn(torch.autograd.Function):
         mod._xy.backward(xcl, None, dy1, need_dx=False)
         _notify(list(mod.parameters()))
         ctx.sv = None
-        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return (None, None) + param_grads(ctx, 2)
 
 
 class X3DBlockFn(torch.autograd.Function):
@@ -175,6 +176,7 @@ class X3DBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
+        ctx._sf_params = params
         x = as_cl(x)
         t = mod.branch2
         tr = mod.training
@@ -232,7 +234,7 @@ class X3DBlockFn(torch.autograd.Function):
             dx = A.backward(x, None, dya, need_dx=need_dx, resid=g)
         _notify(mod._param_list)
         ctx.sv = None
-        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return (dx, None) + param_grads(ctx, 2)
 
 
 class X3DHeadPoolFn(torch.autograd.Function):
@@ -241,6 +243,7 @@ class X3DHeadPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
+        ctx._sf_params = params
         x = as_cl(x)
         unit = mod._conv5
         y, st = unit.forward(x, None, mod.training)
@@ -264,7 +267,7 @@ class X3DHeadPoolFn(torch.autograd.Function):
         dx = unit.backward(x, None, dy, need_dx=ctx.needs_input_grad[0])
         _notify(unit.params())
         ctx.y = None
-        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return (dx, None) + param_grads(ctx, 2)
 
 
 # ------------------------------------------------------------------------------------------------

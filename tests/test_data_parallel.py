@@ -266,3 +266,95 @@ def test_sync_batchnorm_two_ranks(hostsim_path):
         # last fp16 bit, and each flip moves a 128-term gradient sum by a percent -- wiring check only (measured 3-8 %)
         assert worst < 0.2, (rank, worst)
         assert e_mean < 1e-4 and e_var < 1e-3, (rank, e_mean, e_var)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's own boundary: torch DDP + register_comm_hook (slowfast/models/build.py:64-80)
+@pytest.mark.parametrize("name", ["slowfast_tiny", "mvit_tiny", "x3d_tiny"])
+def test_param_grads_through_autograd_equal_in_place(sim, name):
+    """engine.GRADS_VIA_AUTOGRAD (the mode DDP needs: parameter gradients returned by every autograd.Function) gives the
+    same gradients as the in-place mode, for every parameter, and leaves no collected tensor behind."""
+    import slowfast_amd as sa
+    from slowfast_amd import engine
+    from tests import model_checks as mc
+    gold = mc.load_golden(name)
+    cfg = mc.cfg_for(gold)
+    model, sd, inputs, labels, *_ = mc.oracle_run(gold, cfg)
+    model.load_state_dict(sd)
+    model.train()
+
+    def grads():
+        for p in model.parameters():
+            p.grad = None
+        torch.nn.functional.cross_entropy(model([x.clone() for x in inputs]).float(), labels).backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    ref = grads()
+    engine.GRADS_VIA_AUTOGRAD = True
+    try:
+        got = grads()
+        assert not engine._pending_grads, "a collected gradient was never returned to autograd"
+    finally:
+        engine.GRADS_VIA_AUTOGRAD = False
+        engine._pending_grads.clear()
+    assert set(got) == set(ref)
+    for k, r in ref.items():
+        assert float((got[k] - r).norm()) <= 1e-5 * float(r.norm()) + 1e-9, k
+
+
+def _ddp_worker(rank, world, port, simlib, q, fp16):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SFAMD_LIBRARY=simlib, SF_SIM_THREADS="2")
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from slowfast_amd import data_parallel as dp
+    from slowfast_amd import engine
+    from tests.kernel_checks import host_to_cl
+    net = _build().train()
+    g = torch.Generator().manual_seed(100 + rank)
+    x = host_to_cl(torch.randn((2, 16, 2, 8, 8), generator=g), "cpu")
+    y = torch.randint(0, 5, (2,), generator=g)
+    torch.nn.functional.cross_entropy(net(x), y).backward()
+    mean = torch.cat([p.grad.flatten() for p in net.parameters()])
+    dist.all_reduce(mean)
+    mean /= world
+    for p in net.parameters():
+        p.grad = None
+    fired = []
+    ddp = dp.wrap_ddp(net, device=None, fp16_allreduce=fp16, bucket_cap_mb=0.002)     # tiny buckets: several hooks per step
+    assert engine.GRADS_VIA_AUTOGRAD
+    # count hook invocations without replacing the installed hook: DDP exposes its logging data only -> wrap the reducer's
+    # collective instead
+    orig = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        fired.append(t.numel())
+        return orig(t, *a, **k)
+    dist.all_reduce = counting_all_reduce
+    try:
+        torch.nn.functional.cross_entropy(ddp(x), y).backward()
+    finally:
+        dist.all_reduce = orig
+    got = torch.cat([p.grad.flatten() for p in net.parameters()])
+    q.put((rank, float((got - mean).norm() / mean.norm()), len(fired), len(engine._pending_grads)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_ddp_wrap_two_ranks(hostsim_path, fp16):
+    """The drop-in blocks inside torch DDP as build_model(cfg) wraps them for NUM_GPUS > 1: gradients reach DDP's
+    reducer through autograd, the installed comm hook (xgmi_allreduce_hook / fp16_compress_hook) all-reduces every bucket,
+    and each rank ends with the mean of the local gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, hostsim_path, q, fp16)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(2)]
+    for rank, err, nfired, pending in res:
+        assert err < (2e-3 if fp16 else 1e-6), res
+        assert nfired >= 1, "the installed comm hook must carry the all-reduce (DDP packs this small net into one bucket)"
+        assert pending == 0
