@@ -233,3 +233,9 @@ def test_x3d_sub_batchnorm_backbone_with_full_batch_head(sim):
     msd = model.state_dict()
     for k, v in o_stats.items():
         assert float((msd[k].float() - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-4, k
+
+
+def test_well_conditioned_1e3_no_yardstick(sim):
+    """The north-star bar asserted directly (no yardstick) on a well-conditioned C2D-R50 (tests/golden/c2d_wc.json); the
+    GPU suite runs the SlowFast / X3D / R101+Nonlocal cases as well."""
+    mc.check_well_conditioned("c2d_wc", sim)
