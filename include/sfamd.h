@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 14
+#define SF_ABI_VERSION 15
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -304,6 +304,26 @@ int sf_outer_sum(const float* a, int32_t lda, const float* b, int32_t ldb, int32
 int sf_gate_act_bwd(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift,
                     const float* gate, int swish, const void* dz, int32_t lddz, const float* dmean, void* du, int32_t lddu,
                     sf_stream_t stream);
+
+/* ---- training-step glue on the flat gradient memory -- replaces tools/train_net.py:150-172 (GradScaler.unscale_ / step /
+ * update, clip_grad_norm_ / clip_grad_value_, optimizer.get_grad_norm_, misc.check_nan_losses) and optimizer.step()
+ * (slowfast/models/optimizer.py:100-140: SGD with momentum / dampening / nesterov, AdamW), SURVEY.md 8f-1.  No host sync:
+ * everything the next launch needs travels through the control block `ctl` (8 fp32 words in device memory):
+ *   [0] loss scale  [1] growth tracker  [2] found_inf of this step  [3] global gradient norm (unscaled, mean over ranks)
+ *   [4] multiplier applied to the raw gradients = clip_coef / (world * scale)  [5] clean optimizer steps  [6] skipped steps. */
+int sf_flat_blocks(int64_t n);                                  /* rows of `part` ([rows][2] fp32) for sf_flat_sumsq */
+int sf_flat_sumsq(const float* g, int64_t n, float* part, sf_stream_t stream);
+/* one workgroup: norm / found_inf / clip coefficient into ctl; GradScaler.update() when `dynamic` */
+int sf_step_control(const float* part, int32_t nblk, float* ctl, float world, float clip_norm, int dynamic, float growth,
+                    float backoff, int32_t growth_interval, sf_stream_t stream);
+/* segs: [nseg] {int64 start, int64 end, int32 group, int32 pad}; blk_seg / blk_off: per launched block its segment and its first
+ * element inside it (multiples of 1024); lr / wd: HOST arrays, one entry per parameter group.  Skipped when ctl[2] != 0. */
+int sf_flat_sgd(float* param, const float* grad, float* mom, const void* segs, const int32_t* blk_seg, const int32_t* blk_off,
+                int32_t nblocks, const float* ctl, const float* lr, const float* wd, int32_t ngroups, float clip_val,
+                float momentum, float dampening, int nesterov, sf_stream_t stream);
+int sf_flat_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const void* segs, const int32_t* blk_seg,
+                  const int32_t* blk_off, int32_t nblocks, const float* ctl, const float* lr, const float* wd, int32_t ngroups,
+                  float clip_val, float beta1, float beta2, float eps, sf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -166,9 +166,9 @@ CASES = {
     # with random-sign weights every logit is a cancelling sum whose relative fp16 noise is |w|.|f| / |logit| ~ 2x the
     # per-element noise (1e-3 exactly at the bar, pass or fail by luck); without cancellation the logits are a
     # well-conditioned function of the features and the comparison tests the backbone, not the conditioning of a random FC.
-    "slowfast_wc": ("configs/Kinetics/SLOWFAST_8x8_R50.yaml",
+    "slowfast_wc": ("configs/Kinetics/SLOWFAST_8x8_R50.yaml",       # full R50 width (the Fast pathway keeps 8 real channels)
                     ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 64,
-                     "RESNET.WIDTH_PER_GROUP", 16, "DATA.NUM_FRAMES", 16, "SLOWFAST.BETA_INV", 4], 8,
+                     "DATA.NUM_FRAMES", 16], 8,
                     {"final_bn_gamma_scale": 0.05, "head_weight_abs": True}),
     "c2d_wc": ("configs/Kinetics/C2D_8x8_R50.yaml",
                ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 64,

@@ -12,6 +12,7 @@
 #include "sf_stem.h"
 #include "sf_attn.h"
 #include "sf_roi.h"
+#include "sf_optim.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -1750,4 +1751,64 @@ extern "C" int sf_gate_act_bwd(int32_t N, int64_t S, int32_t C, const void* y, i
     p.dz = (const f16*)dz; p.lddz = lddz; p.dmean = dmean; p.inv_S = 1.0f / (float)S; p.z = (f16*)du; p.ldz = lddu;
     hipLaunchKernelGGL(sf_gate_act_bwd_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("gate_act_bwd");
+}
+
+
+// ================================================================================================
+// Training-step glue on the flat gradient memory (sf_optim.h; replaces tools/train_net.py:150-172 + optimizer.step()).
+static const int kFlatBlocks = 1024;
+extern "C" int sf_flat_blocks(int64_t n) {
+    if (n <= 0) return fail("sf_flat_blocks: empty buffer");
+    int64_t b = (n / 4 + SF_THREADS - 1) / SF_THREADS;
+    return (int)(b < 1 ? 1 : (b > kFlatBlocks ? kFlatBlocks : b));
+}
+extern "C" int sf_flat_sumsq(const float* g, int64_t n, float* part, sf_stream_t stream) {
+    REQUIRE(g && part && n > 0, "sf_flat_sumsq: bad arguments");
+    REQUIRE((uintptr_t)g % 16 == 0, "sf_flat_sumsq: the buffer must be 16-byte aligned");
+    FlatSumsqParams p;
+    p.g = g; p.n = n; p.part = part;
+    hipLaunchKernelGGL(sf_flat_sumsq_kernel, dim3(sf_flat_blocks(n)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("flat_sumsq");
+}
+extern "C" int sf_step_control(const float* part, int32_t nblk, float* ctl, float world, float clip_norm, int dynamic,
+                               float growth, float backoff, int32_t growth_interval, sf_stream_t stream) {
+    REQUIRE(part && ctl && nblk > 0 && world >= 1.f, "sf_step_control: bad arguments");
+    REQUIRE(!dynamic || (growth >= 1.f && backoff > 0.f && backoff <= 1.f && growth_interval >= 1), "sf_step_control: bad GradScaler constants");
+    StepControlParams p;
+    p.part = part; p.nblk = nblk; p.ctl = ctl; p.world = world; p.clip_norm = clip_norm; p.dynamic = dynamic;
+    p.growth = growth; p.backoff = backoff; p.growth_interval = growth_interval;
+    hipLaunchKernelGGL(sf_step_control_kernel, dim3(1), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("step_control");
+}
+static int fill_flat_update(FlatUpdateParams& p, float* param, const float* grad, float* m1, float* m2, const void* segs,
+                            const int32_t* blk_seg, const int32_t* blk_off, const float* ctl, const float* lr, const float* wd,
+                            int32_t ngroups, float clip_val) {
+    REQUIRE(param && grad && segs && blk_seg && blk_off && ctl && lr && wd, "flat update: null pointer");
+    REQUIRE(ngroups >= 1 && ngroups <= SF_OPT_MAX_GROUPS, "flat update: 1..%d parameter groups", SF_OPT_MAX_GROUPS);
+    memset(&p, 0, sizeof(p));
+    p.param = param; p.grad = grad; p.m1 = m1; p.m2 = m2; p.segs = (const FlatSeg*)segs; p.blk_seg = blk_seg; p.blk_off = blk_off;
+    p.ctl = ctl; p.clip_val = clip_val;
+    for (int g = 0; g < ngroups; ++g) { p.lr[g] = lr[g]; p.wd[g] = wd[g]; }   // host arrays (a handful of floats per step)
+    return 0;
+}
+extern "C" int sf_flat_sgd(float* param, const float* grad, float* mom, const void* segs, const int32_t* blk_seg,
+                           const int32_t* blk_off, int32_t nblocks, const float* ctl, const float* lr, const float* wd,
+                           int32_t ngroups, float clip_val, float momentum, float dampening, int nesterov, sf_stream_t stream) {
+    FlatUpdateParams p;
+    if (fill_flat_update(p, param, grad, mom, nullptr, segs, blk_seg, blk_off, ctl, lr, wd, ngroups, clip_val)) return -1;
+    REQUIRE(nblocks > 0 && (momentum == 0.f || mom), "sf_flat_sgd: momentum needs a buffer");
+    p.momentum = momentum; p.dampening = dampening; p.nesterov = nesterov;
+    hipLaunchKernelGGL(sf_flat_sgd_kernel, dim3(nblocks), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("flat_sgd");
+}
+extern "C" int sf_flat_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const void* segs,
+                             const int32_t* blk_seg, const int32_t* blk_off, int32_t nblocks, const float* ctl, const float* lr,
+                             const float* wd, int32_t ngroups, float clip_val, float beta1, float beta2, float eps,
+                             sf_stream_t stream) {
+    FlatUpdateParams p;
+    if (fill_flat_update(p, param, grad, exp_avg, exp_avg_sq, segs, blk_seg, blk_off, ctl, lr, wd, ngroups, clip_val)) return -1;
+    REQUIRE(nblocks > 0 && exp_avg && exp_avg_sq, "sf_flat_adamw: moment buffers");
+    p.beta1 = beta1; p.beta2 = beta2; p.eps = eps;
+    hipLaunchKernelGGL(sf_flat_adamw_kernel, dim3(nblocks), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("flat_adamw");
 }

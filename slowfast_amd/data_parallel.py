@@ -110,7 +110,9 @@ class GradReducer:
             self._handles.append((h, None, None))
 
     def finish(self, loss_scale=1.0):
-        """Wait for outstanding collectives; gradients become mean over ranks of the unscaled gradients."""
+        """Wait for outstanding collectives; gradients become mean over ranks of the unscaled gradients.
+        ``loss_scale=None``: only wait -- the buffer keeps the loss-scaled SUM over ranks, which is what
+        slowfast_amd.optim.FlatOptimizer.step() expects (it folds 1 / (world * scale) into its single update pass)."""
         if self.collectives:
             for bi, n in enumerate(self._pending):
                 if n > 0:                         # parameters that got no gradient this iteration
@@ -121,6 +123,12 @@ class GradReducer:
                 if low is not None:
                     view.copy_(low)
             self._handles = []
+        if loss_scale is None:
+            for bi in self._prescaled:      # compressed buckets were averaged before the cast: back to a sum
+                s, e, _ = self.buckets[bi]
+                self.flat[s:e].mul_(float(self.world))
+            self._prescaled = set()
+            return
         if self._prescaled:             # compressed buckets already carry 1/world: only the loss scale is left for them
             for bi, (s, e, _) in enumerate(self.buckets):
                 k = 1.0 / loss_scale if bi in self._prescaled else 1.0 / (self.world * loss_scale)

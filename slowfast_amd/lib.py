@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class ConvDesc(Structure):
@@ -55,6 +55,11 @@ _SIGNATURES = {
     "sf_bn_finalize": (c_int, [_F, c_int32, c_int32, c_int32, c_float, _F, _F, _F, _F, c_float, c_float, _F, _F, _F, _F, _P]),
     "sf_bn_act": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, _P, c_int32, _F, _F, c_int, _P, c_int32, _P, _P]),
     "sf_bn_bwd_blocks": (c_int, [c_int64, c_int32]),
+    "sf_flat_blocks": (c_int, [c_int64]),
+    "sf_flat_sumsq": (c_int, [_F, c_int64, _F, _P]),
+    "sf_step_control": (c_int, [_F, c_int32, _F, c_float, c_float, c_int, c_float, c_float, c_int32, _P]),
+    "sf_flat_sgd": (c_int, [_F, _F, _F, _P, _P, _P, c_int32, _F, _P, _P, c_int32, c_float, c_float, c_float, c_int, _P]),
+    "sf_flat_adamw": (c_int, [_F, _F, _F, _F, _P, _P, _P, c_int32, _F, _P, _P, c_int32, c_float, c_float, c_float, c_float, _P]),
     "sf_bn_bwd_reduce": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, _F, _F, c_int, _F, _P]),
     "sf_bn_bwd_finalize": (c_int, [_F, c_int32, c_int32, c_int32, c_float, _F, _F, _F, c_float, _F, _F, c_int, _F, _P]),
     "sf_bn_bwd_apply": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, _F, _F, c_int, _F, _P,

@@ -1,0 +1,163 @@
+"""Optimizer + loss scaling on the flat gradient memory.
+
+Replaces, for the GradReducer / TrainStep path, what tools/train_net.py:150-172 runs between ``loss.backward()`` and the
+next iteration -- ``scaler.unscale_``, ``clip_grad_norm_`` / ``clip_grad_value_``, ``optimizer.get_grad_norm_``,
+``scaler.step(optimizer)``, ``scaler.update()`` and ``misc.check_nan_losses`` -- and ``optimizer.step()`` itself
+(slowfast/models/optimizer.py:100-140: SGD with momentum / dampening / Nesterov, AdamW).  Three libsfamd launches per
+iteration (csrc/sf_optim.h), no host synchronisation: the dynamic loss scale, the overflow flag and the gradient norm live in
+an 8-word control block in device memory.
+
+Parameters are re-pointed to views of ONE flat fp32 buffer laid out like GradReducer.flat (gradients) and the optimizer
+state, so the update is a single pass over contiguous memory.  ``param_groups`` mirrors torch.optim (lists of dicts with
+"lr" / "weight_decay"), so the reference's ``optim.set_lr(optimizer, lr)`` (slowfast/models/optimizer.py:143-152) keeps
+working on it.
+"""
+from ctypes import c_float
+
+import numpy as np
+import torch
+
+from .lib import get_lib
+
+_SEG_DTYPE = np.dtype([("start", "<i8"), ("end", "<i8"), ("group", "<i4"), ("pad", "<i4")])
+_BLOCK = 1024       # elements per workgroup of the update kernels (SF_OPT_BLOCK_ELEMS)
+CTL_SCALE, CTL_TRACKER, CTL_FOUND_INF, CTL_GRAD_NORM, CTL_MULT, CTL_STEPS, CTL_SKIPPED = range(7)
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+
+
+class FlatOptimizer:
+    def __init__(self, param_groups, reducer, method="sgd", momentum=0.0, dampening=0.0, nesterov=False, betas=(0.9, 0.999),
+                 eps=1e-8, loss_scale=1.0, dynamic_loss_scale=False, growth_factor=2.0, backoff_factor=0.5,
+                 growth_interval=2000, clip_grad_l2norm=None, clip_grad_val=None):
+        assert method in ("sgd", "adamw")
+        groups = [dict(g) for g in param_groups]
+        assert 1 <= len(groups) <= 8, "1..8 parameter groups"
+        self.param_groups = groups
+        self.method, self.momentum, self.dampening, self.nesterov = method, float(momentum), float(dampening), bool(nesterov)
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        self.dynamic = bool(dynamic_loss_scale)
+        self.growth, self.backoff, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.clip_norm = float(clip_grad_l2norm) if clip_grad_l2norm else 0.0
+        self.clip_val = float(clip_grad_val) if clip_grad_val else 0.0
+        self.reducer = reducer
+        flat_g = reducer.flat
+        dev = flat_g.device
+        group_of = {}
+        for gi, g in enumerate(groups):
+            for p in g["params"]:
+                group_of[p] = gi
+        # parameters become views of one flat buffer with the gradient buffer's layout
+        self.flat_param = torch.empty_like(flat_g)
+        segs, blk_seg, blk_off = [], [], []
+        off = 0
+        for p in reducer.params:
+            n = p.numel()
+            assert p in group_of, "every parameter of the reducer must belong to a parameter group"
+            view = self.flat_param[off:off + n].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            si = len(segs)
+            segs.append((off, off + n, group_of[p], 0))
+            for b in range(0, n, _BLOCK):
+                blk_seg.append(si)
+                blk_off.append(b)
+            off += n
+        assert off == flat_g.numel()
+        self.m1 = torch.zeros_like(flat_g) if (method == "adamw" or self.momentum != 0.0) else None
+        self.m2 = torch.zeros_like(flat_g) if method == "adamw" else None
+        self.segs = torch.from_numpy(np.array(segs, dtype=_SEG_DTYPE).view(np.uint8).copy()).to(dev)
+        self.blk_seg = torch.tensor(blk_seg, dtype=torch.int32, device=dev)
+        self.blk_off = torch.tensor(blk_off, dtype=torch.int32, device=dev)
+        self.nblocks = len(blk_seg)
+        self.ctl = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.ctl[CTL_SCALE] = float(loss_scale)
+        self._part = torch.empty((get_lib().call("sf_flat_blocks", flat_g.numel()), 2), dtype=torch.float32, device=dev)
+
+    # -- what the training loop touches ---------------------------------------------------------------------------
+    @property
+    def loss_scale(self):
+        """0-d device tensor: multiply the loss by it (``(loss * opt.loss_scale).backward()``); under a captured graph the
+        replay reads the current value from device memory, so a scale change needs no re-capture."""
+        return self.ctl[CTL_SCALE]
+
+    @property
+    def grad_norm(self):
+        """Global L2 norm of the unscaled, rank-averaged gradients of the last step (device tensor; inf on overflow)."""
+        return self.ctl[CTL_GRAD_NORM]
+
+    @property
+    def found_inf(self):
+        return self.ctl[CTL_FOUND_INF]
+
+    def step(self):
+        """Call after the gradient all-reduce finished (GradReducer.finish(loss_scale=None)): norm + overflow check,
+        GradScaler update, clipped / unscaled parameter update -- skipped as a whole on overflow."""
+        lib, g = get_lib(), self.reducer.flat
+        s = _stream(g)
+        lib.call("sf_flat_sumsq", g.data_ptr(), g.numel(), self._part.data_ptr(), s, work=dict(bytes=4.0 * g.numel()))
+        lib.call("sf_step_control", self._part.data_ptr(), self._part.shape[0], self.ctl.data_ptr(), float(self.reducer.world),
+                 self.clip_norm, int(self.dynamic), self.growth, self.backoff, self.growth_interval, s)
+        ng = len(self.param_groups)
+        lr = (c_float * ng)(*[float(gp["lr"]) for gp in self.param_groups])
+        wd = (c_float * ng)(*[float(gp.get("weight_decay", 0.0)) for gp in self.param_groups])
+        if self.method == "sgd":
+            lib.call("sf_flat_sgd", self.flat_param.data_ptr(), g.data_ptr(), self.m1.data_ptr() if self.m1 is not None else None,
+                     self.segs.data_ptr(), self.blk_seg.data_ptr(), self.blk_off.data_ptr(), self.nblocks, self.ctl.data_ptr(),
+                     lr, wd, ng, self.clip_val, self.momentum, self.dampening, int(self.nesterov), s,
+                     work=dict(bytes=4.0 * g.numel() * (3 + 2 * int(self.m1 is not None))))
+        else:
+            lib.call("sf_flat_adamw", self.flat_param.data_ptr(), g.data_ptr(), self.m1.data_ptr(), self.m2.data_ptr(),
+                     self.segs.data_ptr(), self.blk_seg.data_ptr(), self.blk_off.data_ptr(), self.nblocks, self.ctl.data_ptr(),
+                     lr, wd, ng, self.clip_val, self.betas[0], self.betas[1], self.eps, s, work=dict(bytes=4.0 * g.numel() * 7))
+
+    def zero_grad(self, set_to_none=False):
+        self.reducer.zero_grad()
+
+    # -- checkpoint surface (utils/checkpoint.py saves optimizer.state_dict()) ---------------------------------------------
+    def state_dict(self):
+        return {"ctl": self.ctl.detach().cpu(), "m1": None if self.m1 is None else self.m1.detach().cpu(),
+                "m2": None if self.m2 is None else self.m2.detach().cpu(),
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.ctl.copy_(sd["ctl"])
+        if self.m1 is not None and sd.get("m1") is not None:
+            self.m1.copy_(sd["m1"])
+        if self.m2 is not None and sd.get("m2") is not None:
+            self.m2.copy_(sd["m2"])
+        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update(s)
+
+
+def construct_optimizer(model, cfg, reducer, loss_scale=1.0, dynamic_loss_scale=None):
+    """FlatOptimizer configured as slowfast/models/optimizer.py:15-140 configures torch's: BatchNorm parameters get
+    BN.WEIGHT_DECAY, 1-D parameters no decay when SOLVER.ZERO_WD_1D_PARAM, the rest SOLVER.WEIGHT_DECAY; SOLVER.OPTIMIZING_METHOD
+    "sgd" (momentum / dampening / nesterov) or "adamw"; clipping from SOLVER.CLIP_GRAD_L2NORM / CLIP_GRAD_VAL; the dynamic
+    loss scale defaults to TRAIN.MIXED_PRECISION (GradScaler's constants)."""
+    bn, rest, zero = [], [], []
+    for m in model.modules():
+        is_bn = isinstance(m, torch.nn.modules.batchnorm._NormBase)
+        for p in m.parameters(recurse=False):
+            if not p.requires_grad:
+                continue
+            if is_bn:
+                bn.append(p)
+            elif cfg.SOLVER.ZERO_WD_1D_PARAM and (p.dim() == 1 or p.shape == (1, 1, p.shape[-1])):
+                zero.append(p)
+            else:
+                rest.append(p)
+    lr = cfg.SOLVER.BASE_LR
+    groups = [g for g in ({"params": bn, "weight_decay": cfg.BN.WEIGHT_DECAY, "lr": lr},
+                          {"params": rest, "weight_decay": cfg.SOLVER.WEIGHT_DECAY, "lr": lr},
+                          {"params": zero, "weight_decay": 0.0, "lr": lr}) if g["params"]]
+    dyn = bool(cfg.TRAIN.MIXED_PRECISION) if dynamic_loss_scale is None else dynamic_loss_scale
+    kw = dict(loss_scale=loss_scale, dynamic_loss_scale=dyn, clip_grad_l2norm=cfg.SOLVER.CLIP_GRAD_L2NORM,
+              clip_grad_val=cfg.SOLVER.CLIP_GRAD_VAL)
+    if cfg.SOLVER.OPTIMIZING_METHOD == "adamw":
+        return FlatOptimizer(groups, reducer, method="adamw", betas=(0.9, 0.999), eps=1e-8, **kw)
+    assert cfg.SOLVER.OPTIMIZING_METHOD == "sgd", cfg.SOLVER.OPTIMIZING_METHOD
+    return FlatOptimizer(groups, reducer, method="sgd", momentum=cfg.SOLVER.MOMENTUM, dampening=cfg.SOLVER.DAMPENING,
+                         nesterov=cfg.SOLVER.NESTEROV, **kw)

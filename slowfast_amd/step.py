@@ -19,7 +19,7 @@ from . import engine
 
 class TrainStep:
     def __init__(self, model, reducer, optimizer, loss_fn, loss_scale=1.0, use_graph=None, warmup=2, clip_grad_l2norm=None,
-                 clip_grad_val=None):
+                 clip_grad_val=None, track_stats=False):
         self.model, self.reducer, self.optimizer, self.loss_fn = model, reducer, optimizer, loss_fn
         self.loss_scale = float(loss_scale)
         # SOLVER.CLIP_GRAD_L2NORM / CLIP_GRAD_VAL (tools/train_net.py:156-166); the global gradient norm is always
@@ -35,16 +35,32 @@ class TrainStep:
         self._loss = None
         self._logits = None
         self._calls = 0
+        from .optim import FlatOptimizer
+        self._flat = isinstance(optimizer, FlatOptimizer)
+        import collections
+        self.track_stats, self.stats_depth = track_stats, 8
+        self._stats = collections.deque()
+        self._last_labels = None
 
     # ------------------------------------------------------------------------------------------------
     def _fwd_bwd(self, inputs, labels):
         self.reducer.zero_grad()
         logits = self.model(inputs)
         loss = self.loss_fn(logits.float(), labels)
-        (loss * self.loss_scale).backward()
+        # FlatOptimizer: the (dynamic) loss scale is a device scalar -- a captured graph reads its current value at replay
+        scale = self.optimizer.loss_scale if self._flat else self.loss_scale
+        (loss * scale).backward()
         return logits, loss
 
     def _finish(self):
+        if self._flat:
+            # one norm pass + one control launch + one fused update over the flat buffers (csrc/sf_optim.h): unscale, inf /
+            # NaN check with skip-step, GradScaler update, clipping and the optimizer arithmetic -- no host sync
+            self.reducer.finish(loss_scale=None)
+            self.optimizer.step()
+            self.grad_norm = self.optimizer.grad_norm
+            self._queue_stats()
+            return
         self.reducer.finish(loss_scale=self.loss_scale)
         if self.clip_grad_val:
             self.reducer.flat.clamp_(-float(self.clip_grad_val), float(self.clip_grad_val))
@@ -56,6 +72,42 @@ class TrainStep:
                 self.reducer.flat.mul_(coef)
         if self.optimizer is not None:
             self.optimizer.step()
+        self._queue_stats()
+
+    # ------------------------------------------------------------------------------------------------
+    def _queue_stats(self):
+        """[loss, grad_norm, top1_err, top5_err] of this iteration as ONE device tensor, mean-all-reduced asynchronously
+        (tools/train_net.py:225-241 does four blocking .item() calls and a du.all_reduce per iteration); read it later
+        with pop_stats() -- by then the values have long arrived, so the read does not stall the launch queue."""
+        if not self.track_stats:
+            return
+        logits, labels = self._logits, self._last_labels
+        stats = torch.zeros(4, dtype=torch.float32, device=logits.device)
+        stats[0] = self._loss.float()
+        stats[1] = self.grad_norm.float() if torch.is_tensor(self.grad_norm) else float(self.grad_norm or 0.0)
+        if labels is not None and labels.dim() == 1 and logits.dim() == 2:
+            k = min(5, logits.shape[1])
+            top = logits.float().topk(k, dim=1).indices
+            hit = top.eq(labels.view(-1, 1))
+            stats[2] = 100.0 * (1.0 - hit[:, :1].any(1).float().mean())
+            stats[3] = 100.0 * (1.0 - hit.any(1).float().mean())
+        handle = None
+        import torch.distributed as dist
+        if self.reducer.world > 1 and dist.is_available() and dist.is_initialized():
+            stats /= self.reducer.world
+            handle = dist.all_reduce(stats, group=self.reducer.group, async_op=True)
+        self._stats.append((stats, handle))
+        while len(self._stats) > self.stats_depth:
+            self._stats.popleft()
+
+    def pop_stats(self):
+        """Oldest queued [loss, grad_norm, top1_err, top5_err] as floats (None when nothing is queued)."""
+        if not self._stats:
+            return None
+        stats, handle = self._stats.popleft()
+        if handle is not None:
+            handle.wait()
+        return [float(v) for v in stats.cpu()]
 
     def _capture(self, inputs, labels):
         self._is_list = isinstance(inputs, (list, tuple))
@@ -80,6 +132,7 @@ class TrainStep:
     def __call__(self, inputs, labels):
         """Runs one iteration; returns the (unscaled) loss tensor of this iteration."""
         self._calls += 1
+        self._last_labels = labels
         if not self.use_graph or self._calls <= self.warmup:
             logits, loss = self._fwd_bwd(inputs, labels)
             self._logits, self._loss = logits.detach(), loss.detach()
