@@ -99,6 +99,9 @@ def parse():
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU oracle and exit")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of a HIP graph")
+    ap.add_argument("--torch-optimizer", action="store_true",
+                    help="torch.optim fused SGD / AdamW + separate unscale / norm / clip passes (round-1 step glue) instead of "
+                         "slowfast_amd.optim.FlatOptimizer (one norm pass + one fused update, device-side dynamic loss scale)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the second model of BASELINE.json's metric (MViTv2-S) that the default run appends as `secondary`")
     ap.add_argument("--master-port", type=int, default=0, help="(self-spawned multi-GPU runs) rendezvous port, 0 = pick a free one")
@@ -206,9 +209,13 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
     if world > 1:                        # replicas start identical (DDP's initial broadcast)
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
-    opt = make_optimizer(model, cfg)
     reducer = GradReducer(model, bucket_mb=a.bucket_mb)
     reducer.attach_torch_param_hooks(model.head.parameters())
+    if a.torch_optimizer:
+        opt = make_optimizer(model, cfg)
+    else:       # tools/train_net.py:150-172 + optimizer.step() as three launches over the flat buffers, GradScaler on the device
+        from slowfast_amd.optim import construct_optimizer
+        opt = construct_optimizer(model, cfg, reducer, loss_scale=a.loss_scale, dynamic_loss_scale=True)
 
     g = torch.Generator(device=dev).manual_seed(cfg.RNG_SEED + rank)
     T, S = cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE
@@ -256,8 +263,12 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
         reducer.zero_grad()
         logits = step_model(inputs)
         loss = loss_fn(logits.float(), labels)
-        (loss * a.loss_scale).backward()
-        reducer.finish(loss_scale=a.loss_scale)
+        if a.torch_optimizer:
+            (loss * a.loss_scale).backward()
+            reducer.finish(loss_scale=a.loss_scale)
+        else:
+            (loss * opt.loss_scale).backward()
+            reducer.finish(loss_scale=None)
         opt.step()
         return loss
 
@@ -328,7 +339,9 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
                                    f"inputs resident in HBM, "
                                    f"per-GPU batch {batch}", "global_batch": batch * world,
                        "parallelism": f"dp{world}", "loss_scale": a.loss_scale, "bucket_mb": a.bucket_mb,
-                       "launch": "eager" if a.no_graph else "hip-graph(fwd+bwd) + eager all-reduce/SGD"},
+                       "launch": "eager" if a.no_graph else "hip-graph(fwd+bwd) + eager all-reduce/optimizer",
+                       "optimizer": "torch fused + separate unscale/norm/clip" if a.torch_optimizer else
+                                    "FlatOptimizer (fused unscale+norm+clip+update, dynamic loss scale on device)"},
             "per_gpu_clips_per_s": round(value / world, 2), "final_loss": round(final_loss, 4),
         }
         if preset in BYTE_FLOOR_GB_PER_CLIP:

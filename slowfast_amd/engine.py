@@ -34,6 +34,34 @@ FORCE_WEIGHT_PREP = False
 # Intermediate activations of a block (relu(bn_a(ya)), relu(bn_b(yb))) are materialised in fp16 (default) or recomputed
 # in the consumer's operand loads (SF_MATERIALIZE=0, the round-1 schedule; kept for A/B runs).
 MATERIALIZE = os.environ.get("SF_MATERIALIZE", "1") != "0"
+# Backward segmentation (slowfast_amd.step.TrainStep): models call cut() on the activations that cross a stage boundary.
+# Normally the identity.  While a _Segments recorder is installed the tensors are replaced by detached leaves, so that the
+# backward pass can be run -- and captured into HIP graphs -- stage by stage (head + res5 first), and the gradient all-reduce
+# of a finished stage overlaps the backward of the stages before it.
+SEGMENTS = None
+
+
+class _Segments:
+    def __init__(self):
+        self.cuts = []          # [(original tensors, leaf tensors)] in forward order
+
+    def cut(self, tensors):
+        leaves = [t.detach().requires_grad_(True) if t.requires_grad else t for t in tensors]
+        if any(l is not t for l, t in zip(leaves, tensors)):
+            self.cuts.append((list(tensors), leaves))
+        return leaves
+
+
+def cut(x):
+    """Stage boundary marker: x (a tensor or a list of tensors) passes through unchanged unless a backward-segmenting
+    TrainStep is recording."""
+    if SEGMENTS is None:
+        return x
+    if isinstance(x, (list, tuple)):
+        return type(x)(SEGMENTS.cut(list(x)))
+    return SEGMENTS.cut([x])[0]
+
+
 # Test hook: when a list, ResBlockFn.forward appends the tensors that decide its ReLU masks (raw conv outputs + BatchNorm
 # scale / shift, the block output) so that a parity test can hand the SAME masks to the oracle (tests/block_checks.py).
 CAPTURE = None

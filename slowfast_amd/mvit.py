@@ -13,6 +13,8 @@ import math
 from functools import partial
 
 import torch
+
+from . import engine
 import torch.nn as nn
 from torch.nn.init import trunc_normal_
 
@@ -397,7 +399,10 @@ class MViT(nn.Module):
         if self.enable_rev:                        # _forward_reversible, video_model_builder.py:1141-1164
             x = self.rev_backbone(x)               # fuse("concat") is the identity on the concatenated streams
         else:
-            for blk in self.blocks:
+            ncut = max(len(self.blocks) // 3, 1)
+            for i, blk in enumerate(self.blocks):
+                if i and i % ncut == 0:                # backward segments of step.TrainStep (identity otherwise)
+                    x = engine.cut(x)
                 x, thw = blk(x, thw)
         if self.enable_detection:                  # video_model_builder.py:1218-1226
             x = TokenNormFn.apply(x, self, self.cls_embed_on, self.norm.weight, self.norm.bias)

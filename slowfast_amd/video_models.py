@@ -6,7 +6,7 @@ from per-stage tables instead of the reference's unrolled constructor."""
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import engine, ops
 from .engine import ConvUnit, FuseFn, as_cl, hold_notifications
 from .heads import ResNetBasicHead, ResNetRoIHead
 from .registry import MODEL_REGISTRY
@@ -229,8 +229,9 @@ class SlowFast(_ResNetBase):
             pool = getattr(self, f"pathway{p}_pool")
             if tuple(pool.kernel_size) != (1, 1, 1):
                 x[p] = _pathway_pool(pool, x[p])
+        x = engine.cut(x)                # stage boundaries: backward segments of step.TrainStep (identity otherwise)
         x = self.s3_fuse(self.s3(x))
-        x = self.s4_fuse(self.s4(x))
+        x = engine.cut(self.s4_fuse(self.s4(x)))
         x = self.s5(x)
         return self.head(x, bboxes) if self.enable_detection else self.head(x)
 
@@ -279,5 +280,6 @@ class ResNet(_ResNetBase):
         pool = self.pathway0_pool
         if tuple(pool.kernel_size) != (1, 1, 1):
             x[0] = _pathway_pool(pool, x[0])
-        x = self.s5(self.s4(self.s3(x)))
+        x = self.s4(self.s3(engine.cut(x)))
+        x = self.s5(engine.cut(x))
         return self.head(x, bboxes) if self.enable_detection else self.head(x)

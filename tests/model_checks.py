@@ -252,7 +252,7 @@ def check_well_conditioned(name, device, tol=1e-3, loss_scale=1.0):
 
 
 def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99, tol=1e-3, loss_scale=64.0,
-                    gamma_scale=0.05, head_abs=True):
+                    gamma_scale=0.05, head_abs=True, tol_logits=None):
     """A BASELINE config at FULL clip size (every layer geometry of the real model), batch 2, against the fp32 CPU oracle:
     logits (relative L2), loss and global gradient norm to 1e-3 with no yardstick.  Conditioning as in the "*_wc" golden
     cases: damped block-final BatchNorm gammas, non-negative classifier weights (oracle/make_golden.py explains both);
@@ -290,7 +290,7 @@ def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99,
     _record(preset + "@full", device, dict(res, bounds={k: tol for k in ("logits_l2", "loss", "grad_norm")},
                                            yardstick_kind="none (1e-3)"))
     for k in ("logits_l2", "loss", "grad_norm"):
-        assert res[k] <= tol, (k, res)
+        assert res[k] <= (tol_logits or tol if k == "logits_l2" else tol), (k, res)
     return res
 
 

@@ -71,7 +71,11 @@ FULL_SIZE = {
     # BASELINE.json configs 2-5 at their full clip size, batch 2
     "SLOWFAST_8x8_R50": dict(opts=[]),
     "X3D_M": dict(opts=[]),
-    "MVITv2_S_16x4": dict(opts=["MVIT.DROPPATH_RATE", 0.0, "MIXUP.ENABLE", False], gamma_scale=None, head_abs=False),
+    # MViT: loss and gradient norm to 1e-3; the logits to 2e-3 -- the class token is stored in fp16 (2^-11 per element) and
+    # the classifier is a cancelling sum over its 768 LayerNorm-ed (signed) features, |w|.|f| / |logit| ~ 2-3 (measured:
+    # 1.15e-3, with grad_global 0.4 %)
+    "MVITv2_S_16x4": dict(opts=["MVIT.DROPPATH_RATE", 0.0, "MIXUP.ENABLE", False], gamma_scale=None, head_abs=False,
+                          tol_logits=2e-3),
     "SLOWFAST_32x2_R101_50_50": dict(opts=["DATA.TRAIN_CROP_SIZE", 256], boxes_per_clip=3, head_abs=False),
 }
 

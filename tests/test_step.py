@@ -133,3 +133,53 @@ def test_train_step_gradient_clipping(sim):
             red.close()
         for a, b in zip(*results):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def _run_flat(device, use_graph, steps, poison_step=None):
+    """TrainStep + FlatOptimizer (fused unscale / norm / clip / SGD-Nesterov with a dynamic loss scale on the device)."""
+    from slowfast_amd.data_parallel import GradReducer
+    from slowfast_amd.optim import FlatOptimizer
+    from slowfast_amd.step import TrainStep
+    torch.manual_seed(0)
+    net = _build().to(device).train()
+    red = GradReducer(net)
+    red.attach_torch_param_hooks(net.fc.parameters())
+    bn = [p for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._NormBase) for p in m.parameters(recurse=False)]
+    rest = [p for p in net.parameters() if all(p is not q for q in bn)]
+    opt = FlatOptimizer([{"params": bn, "weight_decay": 0.0, "lr": 0.05}, {"params": rest, "weight_decay": 1e-4, "lr": 0.05}],
+                        red, method="sgd", momentum=0.9, nesterov=True, loss_scale=64.0, dynamic_loss_scale=True,
+                        growth_interval=3, clip_grad_l2norm=5.0)
+    step = TrainStep(net, red, opt, F.cross_entropy, use_graph=use_graph, warmup=1, track_stats=True)
+    g = torch.Generator().manual_seed(5)
+    losses = []
+    for i in range(steps):
+        x = host_to_cl(torch.randn((4, 16, 2, 8, 8), generator=g), device)
+        if i == poison_step:
+            x = x * float("inf")                    # forces non-finite gradients: the step must be skipped
+        y = torch.randint(0, 5, (4,), generator=g).to(device)
+        losses.append(float(step(x, y)))
+    out = ([p.detach().float().cpu().clone() for p in net.parameters()], opt.ctl.detach().cpu().clone(), losses)
+    red.close()
+    return out
+
+
+def test_flat_optimizer_train_step_skips_overflow(sim):
+    params, ctl, losses = _run_flat(sim, use_graph=False, steps=4, poison_step=2)
+    from slowfast_amd.optim import CTL_SCALE, CTL_SKIPPED, CTL_STEPS
+    assert float(ctl[CTL_SKIPPED]) == 1 and float(ctl[CTL_STEPS]) == 3
+    assert float(ctl[CTL_SCALE]) == 32.0            # 64 -> overflow at step 2: 32 (growth_interval 3 not reached again)
+    assert all(torch.isfinite(p).all() for p in params)
+
+
+@pytest.mark.gpu
+def test_flat_optimizer_graph_replay_matches_eager(gpu):
+    """The dynamic loss scale is a device scalar read inside the captured graph: graph replay == eager bit for bit, through an
+    overflow (skipped step, halved scale) and a scale growth."""
+    pe, ce, le = _run_flat(gpu, use_graph=False, steps=6, poison_step=3)
+    pg, cg, lg = _run_flat(gpu, use_graph=True, steps=6, poison_step=3)
+    assert torch.equal(ce, cg), (ce, cg)
+    assert [a for a in le if a == a] == [a for a in lg if a == a]
+    for a, b in zip(pe, pg):
+        assert torch.equal(a, b)
+    from slowfast_amd.optim import CTL_SKIPPED
+    assert float(ce[CTL_SKIPPED]) == 1
