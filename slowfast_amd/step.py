@@ -7,8 +7,15 @@ kernels of a bs32 step take tens of milliseconds, the same order as the host tim
 one.  ``TrainStep`` therefore captures [zero_grad, forward, loss, backward] ONCE into a HIP graph
 (``torch.cuda.CUDAGraph`` is hipGraph on ROCm; every libsfamd launch goes to the capturing stream) and replays
 it per iteration; shapes are static (synthetic or fixed-size clips), inputs are copied into static buffers.
-The gradient all-reduce (RCCL, flat fp32 buckets) and the optimizer update run eagerly after the replay, so
-the 1-GPU and N-GPU paths execute the same captured work.
+The optimizer update runs eagerly after the replay.
+
+Multi-GPU overlap.  The backward pass is SEGMENTED at the stage boundaries the models mark with ``engine.cut()``: the
+forward (+ loss) is one graph, the backward of [head + res5], [res4], [res3 .. stem] are separate graphs replayed in that
+order.  After each backward segment the buckets of the flat gradient buffer that are now complete are all-reduced
+asynchronously (RCCL runs on its own stream; c10d orders it after the segment's kernels), i.e. the reduction of the late
+stages -- res5 alone holds ~60 % of SlowFast-R50's parameters -- overlaps the backward of the early, activation-heavy
+stages, as DDP's reducer does for the reference (slowfast/models/build.py:64-76).  With one rank the segments still
+replay back to back and execute the same kernels as the unsegmented graph.
 
 Without a GPU (host-simulator tests) or with ``use_graph=False`` the same sequence runs eagerly.
 """
@@ -19,7 +26,7 @@ from . import engine
 
 class TrainStep:
     def __init__(self, model, reducer, optimizer, loss_fn, loss_scale=1.0, use_graph=None, warmup=2, clip_grad_l2norm=None,
-                 clip_grad_val=None, track_stats=False):
+                 clip_grad_val=None, track_stats=False, segmented=None):
         self.model, self.reducer, self.optimizer, self.loss_fn = model, reducer, optimizer, loss_fn
         self.loss_scale = float(loss_scale)
         # SOLVER.CLIP_GRAD_L2NORM / CLIP_GRAD_VAL (tools/train_net.py:156-166); the global gradient norm is always
@@ -37,6 +44,11 @@ class TrainStep:
         self._calls = 0
         from .optim import FlatOptimizer
         self._flat = isinstance(optimizer, FlatOptimizer)
+        # backward in per-stage segments (all-reduce of a finished stage overlaps the backward of the earlier ones):
+        # default on whenever gradients are actually exchanged
+        self.segmented = bool(reducer.collectives) if segmented is None else bool(segmented)
+        self._bwd_graphs, self._seg_params = [], []
+        self.overlap_log = []           # per iteration: collectives in flight when the LAST backward segment starts
         import collections
         self.track_stats, self.stats_depth = track_stats, 8
         self._stats = collections.deque()
@@ -50,6 +62,50 @@ class TrainStep:
         # FlatOptimizer: the (dynamic) loss scale is a device scalar -- a captured graph reads its current value at replay
         scale = self.optimizer.loss_scale if self._flat else self.loss_scale
         (loss * scale).backward()
+        return logits, loss
+
+    # ---- segmented iteration --------------------------------------------------------------------------------------
+    def _forward_segmented(self, inputs, labels):
+        """zero_grad + forward + loss with the stage boundaries cut (engine.cut -> detached leaves); returns the pieces
+        _backward_segment() needs."""
+        self.reducer.zero_grad()
+        rec = engine._Segments()
+        engine.SEGMENTS = rec
+        try:
+            logits = self.model(inputs)
+        finally:
+            engine.SEGMENTS = None
+        loss = self.loss_fn(logits.float(), labels)
+        scale = self.optimizer.loss_scale if self._flat else self.loss_scale
+        return logits, loss, loss * scale, rec.cuts
+
+    @staticmethod
+    def _backward_segment(k, nseg, scaled_loss, cuts):
+        """Segment k of the backward pass, k = nseg-1 (head side) ... 0 (input side)."""
+        if k == nseg - 1:
+            torch.autograd.backward([scaled_loss])
+        else:
+            origs, leaves = cuts[k]
+            pairs = [(o, l.grad) for o, l in zip(origs, leaves) if l is not o and l.grad is not None]
+            if pairs:
+                torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+
+    def _iteration_segmented_eager(self, inputs, labels, record=False):
+        logits, loss, scaled, cuts = self._forward_segmented(inputs, labels)
+        nseg = len(cuts) + 1
+        if record or not self._seg_params:
+            self._seg_params = [[] for _ in range(nseg)]
+        for k in range(nseg - 1, -1, -1):
+            if k == 0:
+                self.overlap_log.append(len(self.reducer._handles))
+            seen = []
+            listener = engine.add_grad_ready_listener(lambda ps, seen=seen: seen.extend(ps))
+            try:
+                self._backward_segment(k, nseg, scaled, cuts)
+            finally:
+                engine.remove_grad_ready_listener(listener)
+            if record or not self._seg_params[k]:
+                self._seg_params[k] = seen
         return logits, loss
 
     def _finish(self):
@@ -122,8 +178,29 @@ class TrainStep:
         import torch.distributed as dist
         mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
         try:
-            with torch.cuda.graph(g, capture_error_mode=mode):
-                logits, loss = self._fwd_bwd(self._static_in, self._static_labels)
+            if not self.segmented:
+                with torch.cuda.graph(g, capture_error_mode=mode):
+                    logits, loss = self._fwd_bwd(self._static_in, self._static_labels)
+            else:
+                with torch.cuda.graph(g, capture_error_mode=mode):
+                    logits, loss, scaled, cuts = self._forward_segmented(self._static_in, self._static_labels)
+                nseg = len(cuts) + 1
+                self._bwd_graphs = [None] * nseg
+                self._seg_params = [[] for _ in range(nseg)]
+                pool = g.pool()
+                for k in range(nseg - 1, -1, -1):          # one graph per backward segment, same memory pool, replay order
+                    gk = torch.cuda.CUDAGraph()
+                    seen = []
+                    listener = engine.add_grad_ready_listener(lambda ps, seen=seen: seen.extend(ps))
+                    try:
+                        with torch.cuda.graph(gk, pool=pool, capture_error_mode=mode):
+                            self._backward_segment(k, nseg, scaled, cuts)
+                    finally:
+                        engine.remove_grad_ready_listener(listener)
+                    self._bwd_graphs[k] = gk
+                    self._seg_params[k] = seen
+                # parameters that autograd accumulates itself (the torch head) finish with the head-side segment
+                self._seg_params[nseg - 1] = self._seg_params[nseg - 1] + [p for p in self.reducer._hooked]
         finally:
             engine.FORCE_WEIGHT_PREP = False
             self.reducer.capturing = False
@@ -134,7 +211,10 @@ class TrainStep:
         self._calls += 1
         self._last_labels = labels
         if not self.use_graph or self._calls <= self.warmup:
-            logits, loss = self._fwd_bwd(inputs, labels)
+            if self.segmented:
+                logits, loss = self._iteration_segmented_eager(inputs, labels)
+            else:
+                logits, loss = self._fwd_bwd(inputs, labels)
             self._logits, self._loss = logits.detach(), loss.detach()
             self._finish()
             return self._loss
@@ -149,6 +229,13 @@ class TrainStep:
                 self._static_labels.copy_(labels, non_blocking=True)
         self.reducer.begin_replay()
         self._graph.replay()
+        if self.segmented:
+            n = len(self._bwd_graphs)
+            for k in range(n - 1, -1, -1):
+                if k == 0:
+                    self.overlap_log.append(len(self.reducer._handles))
+                self._bwd_graphs[k].replay()
+                self.reducer._on_ready(self._seg_params[k])     # finished buckets: all-reduce overlaps the next segment
         self._finish()
         return self._loss
 

@@ -358,3 +358,65 @@ def test_ddp_wrap_two_ranks(hostsim_path, fp16):
         assert err < (2e-3 if fp16 else 1e-6), res
         assert nfired >= 1, "the installed comm hook must carry the all-reduce (DDP packs this small net into one bucket)"
         assert pending == 0
+
+
+def _overlap_worker(rank, world, port, simlib, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SFAMD_LIBRARY=simlib, SF_SIM_THREADS="2")
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch.nn.functional as F
+    from slowfast_amd.data_parallel import GradReducer
+    from slowfast_amd.optim import construct_optimizer
+    from slowfast_amd.step import TrainStep
+    from tests import model_checks as mc
+    gold = mc.load_golden("slowfast_tiny")
+    cfg = mc.cfg_for(gold)
+    model, sd, inputs, labels, *_ = mc.oracle_run(gold, cfg)
+    model.load_state_dict(sd)
+    model.train()
+    g = torch.Generator().manual_seed(50 + rank)
+    inputs = [x + 0.1 * torch.randn(x.shape, generator=g) for x in inputs]         # ranks see different clips
+    # reference: local gradients averaged over the ranks
+    F.cross_entropy(model(inputs).float(), labels).backward()
+    mean = torch.cat([p.grad.flatten() for p in model.parameters()])
+    dist.all_reduce(mean)
+    mean /= world
+    for p in model.parameters():
+        p.grad = None
+    red = GradReducer(model, bucket_mb=0.02)
+    red.attach_torch_param_hooks(model.head.parameters())
+    opt = construct_optimizer(model, cfg, red, loss_scale=1.0, dynamic_loss_scale=False)
+    for gp in opt.param_groups:
+        gp["lr"] = 0.0                                   # keep the parameters: only the gradient exchange is under test
+    step = TrainStep(model, red, opt, F.cross_entropy, use_graph=False)
+    assert step.segmented, "gradients are exchanged: the backward must be segmented by default"
+    step(inputs, labels)
+    got = red.flat.clone() / world                       # FlatOptimizer leaves the (loss-scaled) SUM in the buffer
+    offs, o = {}, 0
+    for p in model.parameters():
+        offs[p] = o
+        o += p.numel()
+    ref = torch.cat([mean[offs[p]:offs[p] + p.numel()] for p in red.params])
+    q.put((rank, float((got - ref).norm() / ref.norm()), step.overlap_log[-1], len(step._seg_params), len(red.buckets)))
+    red.close()
+    dist.destroy_process_group()
+
+
+def test_allreduce_overlaps_backward_segments(hostsim_path):
+    """World size 2: TrainStep segments the backward at the model's stage boundaries and all-reduces finished buckets
+    between segments -- collectives are IN FLIGHT when the last (input-side) segment starts, and the exchanged gradients
+    are the mean over the ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, hostsim_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(2)]
+    for rank, err, inflight, nseg, nbuckets in res:
+        assert err < 1e-5, res
+        assert nseg >= 3 and nbuckets >= 3, res
+        assert inflight >= 1, "no collective was in flight when the last backward segment started"

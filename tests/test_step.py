@@ -183,3 +183,50 @@ def test_flat_optimizer_graph_replay_matches_eager(gpu):
         assert torch.equal(a, b)
     from slowfast_amd.optim import CTL_SKIPPED
     assert float(ce[CTL_SKIPPED]) == 1
+
+
+def _run_model(device, name, segmented, use_graph, steps=2):
+    """TrainStep on a golden-case model (its forward marks stage boundaries with engine.cut)."""
+    from slowfast_amd.data_parallel import GradReducer
+    from slowfast_amd.optim import construct_optimizer
+    from slowfast_amd.step import TrainStep
+    from tests import model_checks as mc
+    gold = mc.load_golden(name)
+    cfg = mc.cfg_for(gold)
+    model, sd, inputs, labels, *_ = mc.oracle_run(gold, cfg)
+    model.load_state_dict(sd)
+    model = model.to(device).train()
+    red = GradReducer(model, bucket_mb=0.05)
+    red.attach_torch_param_hooks(model.head.parameters())
+    opt = construct_optimizer(model, cfg, red, loss_scale=64.0, dynamic_loss_scale=False)
+    for g in opt.param_groups:
+        g["lr"] = 0.01
+    step = TrainStep(model, red, opt, F.cross_entropy, use_graph=use_graph, warmup=1, segmented=segmented)
+    xs, ys = [x.to(device) for x in inputs], labels.to(device)
+    losses = [float(step(xs, ys)) for _ in range(steps)]
+    out = (losses, [p.detach().float().cpu().clone() for p in model.parameters()], len(step._seg_params), list(step.overlap_log))
+    red.close()
+    return out
+
+
+@pytest.mark.parametrize("name", ["slowfast_tiny", "mvit_tiny"])
+def test_segmented_backward_equals_unsegmented(sim, name):
+    """Backward run stage by stage across engine.cut() boundaries == one backward pass: same losses, same parameters."""
+    l0, p0, n0, _ = _run_model(sim, name, segmented=False, use_graph=False)
+    l1, p1, n1, _ = _run_model(sim, name, segmented=True, use_graph=False)
+    assert n1 >= 3, "the model must expose at least two stage boundaries"
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["slowfast_tiny", "mvit_tiny"])
+def test_segmented_graph_replay_matches_eager(gpu, name):
+    """Forward graph + one graph per backward segment (shared memory pool) replayed in order == the eager iteration."""
+    l0, p0, _, _ = _run_model(gpu, name, segmented=False, use_graph=False, steps=4)
+    l1, p1, n1, _ = _run_model(gpu, name, segmented=True, use_graph=True, steps=4)
+    assert n1 >= 3
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
