@@ -31,6 +31,9 @@ _listeners = []
 # repack must be part of the captured work unconditionally: a replay runs after an optimizer update that the
 # host-side version check below never sees.
 FORCE_WEIGHT_PREP = False
+# Bumped by writers that update parameters behind torch's back (slowfast_amd.optim.FlatOptimizer's fused update kernel does
+# not touch tensor._version): part of every packed-weight cache key, so the eager path re-packs after such an update.
+PARAM_EPOCH = 0
 # Intermediate activations of a block (relu(bn_a(ya)), relu(bn_b(yb))) are materialised in fp16 (default) or recomputed
 # in the consumer's operand loads (SF_MATERIALIZE=0, the round-1 schedule; kept for A/B runs).
 MATERIALIZE = os.environ.get("SF_MATERIALIZE", "1") != "0"
@@ -234,7 +237,7 @@ class ConvUnit:
         """fp16 GEMM operands of the current weight.  ``fresh`` (forward pass) forces the repack while a training
         step is being captured; the backward pass of the same step reuses what its forward packed."""
         w = self.conv.weight
-        key = (w.data_ptr(), w._version, geom.Ci, w.device)
+        key = (w.data_ptr(), w._version, geom.Ci, w.device, PARAM_EPOCH)
         if (fresh and FORCE_WEIGHT_PREP) or self._wkey != key:
             # no data-gradient operand for the RGB stems (3 of 8 channels real); channel padding (54 -> 56) keeps it
             self._w = ops.prep_weights(w.detach(), geom, need_dgrad=(geom.Ci - geom.Cw < 8))
@@ -384,7 +387,7 @@ class StemConvUnit(ConvUnit):
 
     def weights(self, geom, fresh=False):
         w = self.conv.weight
-        key = (w.data_ptr(), w._version, geom.Ci, w.device)
+        key = (w.data_ptr(), w._version, geom.Ci, w.device, PARAM_EPOCH)
         if (fresh and FORCE_WEIGHT_PREP) or self._wkey != key:
             self._w = ops.prep_weights(self._virtual_weight(w.detach()), geom, need_dgrad=False)
             self._wkey = key

@@ -16,6 +16,7 @@ import os
 import torch
 
 from . import engine, tokens
+from . import engine as _engine
 from .engine import _grad_dest, _notify, param_grads
 
 _f16 = torch.float16
@@ -30,7 +31,7 @@ class LinearUnit:
 
     def _ops(self, fresh=False):
         w = self.lin.weight
-        key = (w.data_ptr(), w._version, w.device)
+        key = (w.data_ptr(), w._version, w.device, _engine.PARAM_EPOCH)
         if (fresh and engine.FORCE_WEIGHT_PREP) or self._key != key:
             wd = w.detach()
             self._w = wd.to(_f16)                      # [N, K]  forward operand
@@ -87,7 +88,7 @@ class QKVUnit:
         self._key, self._w, self._wt = None, None, None
 
     def _ops(self, fresh=False):
-        key = tuple((lin.weight.data_ptr(), lin.weight._version, lin.weight.device) for lin in self.lins)
+        key = tuple((lin.weight.data_ptr(), lin.weight._version, lin.weight.device) for lin in self.lins) + (_engine.PARAM_EPOCH,)
         if (fresh and engine.FORCE_WEIGHT_PREP) or self._key != key:
             w = torch.cat([lin.weight.detach() for lin in self.lins], 0)
             self._w = w.to(_f16)                       # [3*att, dim]  forward operand

@@ -17,6 +17,7 @@ from ctypes import c_float
 import numpy as np
 import torch
 
+from . import engine
 from .lib import get_lib
 
 _SEG_DTYPE = np.dtype([("start", "<i8"), ("end", "<i8"), ("group", "<i4"), ("pad", "<i4")])
@@ -112,6 +113,8 @@ class FlatOptimizer:
             lib.call("sf_flat_adamw", self.flat_param.data_ptr(), g.data_ptr(), self.m1.data_ptr(), self.m2.data_ptr(),
                      self.segs.data_ptr(), self.blk_seg.data_ptr(), self.blk_off.data_ptr(), self.nblocks, self.ctl.data_ptr(),
                      lr, wd, ng, self.clip_val, self.betas[0], self.betas[1], self.eps, s, work=dict(bytes=4.0 * g.numel() * 7))
+        engine.PARAM_EPOCH += 1         # the kernels wrote the parameters without bumping tensor._version: packed-weight
+                                        # caches of the eager path must not be reused (a captured graph re-packs anyway)
 
     def zero_grad(self, set_to_none=False):
         self.reducer.zero_grad()

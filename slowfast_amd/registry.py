@@ -2,7 +2,7 @@
 
 Mirrors slowfast/models/build.py:13-81: ``MODEL_REGISTRY.register()`` decorates a class whose
 constructor takes ``cfg``; ``build_model(cfg, gpu_id)`` instantiates ``cfg.MODEL.MODEL_NAME`` and
-moves it to the current device.  Data parallelism is NOT torch DDP here: see data_parallel.py.
+moves it to the current device and, for NUM_GPUS > 1, wraps it for data parallelism (see build_model).
 """
 import torch
 
