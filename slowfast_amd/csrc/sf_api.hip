@@ -192,6 +192,7 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     const char* e;
     const int tiles = cdiv(q.M, 256) * cdiv(q.Nout, q.Nout > 64 ? 128 : 64);
     const int force_bk = (e = getenv("SF_IGEMM2_BK")) ? atoi(e) : 0;
+    q.variant = (e = getenv("SF_IGEMM2_VARIANT")) ? atoi(e) : 0;
     const bool bk64 = q.C % 64 == 0 && force_bk != 32 && (force_bk == 64 || tiles <= 320);
     static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);
@@ -554,8 +555,10 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     if ((e = getenv("SF_WGRAD2")) && atoi(e) == 0) return w;
     const int mink = (e = getenv("SF_WGRAD2_MINK")) ? atoi(e) : 192;
     const int minrows = (e = getenv("SF_WGRAD2_MINROWS")) ? atoi(e) : 4096;
-    const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : 512;
     const int taps = d->kT * d->kH * d->kW;
+    // workgroups to aim for: 2 per CU for pointwise layers, 4 per CU when the K axis spans several taps (measured per layer,
+    // profiles/r2_v6_wgrad2_variants.md: the gathers of neighbouring taps overlap in L2, more splits in flight hide them)
+    const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : (taps > 1 ? 1024 : 512);
     const int Ktot = taps * d->Ci;
     const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
     if (taps > SF_I2_MAXTAPS || d->Co <= 32 || Ktot < mink || M < minrows) return w;
