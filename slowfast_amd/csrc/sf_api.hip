@@ -192,7 +192,6 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     const char* e;
     const int tiles = cdiv(q.M, 256) * cdiv(q.Nout, q.Nout > 64 ? 128 : 64);
     const int force_bk = (e = getenv("SF_IGEMM2_BK")) ? atoi(e) : 0;
-    q.variant = (e = getenv("SF_IGEMM2_VARIANT")) ? atoi(e) : 0;
     const bool bk64 = q.C % 64 == 0 && force_bk != 32 && (force_bk == 64 || tiles <= 320);
     static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);

@@ -65,7 +65,6 @@ struct Igemm2Params {
     int resid_row0;
     float alpha;
     const uint8_t* resid_bits;  // optional [rows][Nout/8] bit mask of the residual (see IgemmParams)
-    int variant;        // A/B switches of the K loop: bit 0 = fragment reads before the next stage's copies, bit 1 = s_setprio
     // output-row map (strided data gradients run one launch per stride-residue class of input positions, see
     // launch_igemm2_strided_dgrad): row (n, a, b, c) of the class is stored at position
     // ((n*oT + a*omT + ooT)*oH + b*omH + ooH)*oW + c*omW + ooW of y / resid.  omap == 0: rows are stored densely.
@@ -82,7 +81,8 @@ __device__ __forceinline__ int i2_lds_off(int row, int kslot) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NST>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) void sf_igemm2_kernel(Igemm2Params p) {
+// register cap: the 32-deep variant must fit TWO workgroups per CU (4 waves per SIMD -> 128 VGPRs), the 64-deep one runs alone
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES_M * WAVES_N) / 4) void sf_igemm2_kernel(Igemm2Params p) {
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;
@@ -183,30 +183,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) vo
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // K = 32 slice kk of stage `buf`: fragments from LDS, then the TM x TN MFMAs
-    f16x8 af[TM], bf[TN];
-    auto frags = [&](int buf, int kk) {
+    auto compute = [&](int buf) {
         const f16* As = smem + buf * STAGE;
         const f16* Bs = As + A_ELEMS;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = ld16(As + i2_lds_off<BK>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = ld16(Bs + i2_lds_off<BK>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
-    };
-    auto mma = [&]() {
-        if (p.variant & 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        if (p.variant & 2) __builtin_amdgcn_s_setprio(0);
-    };
-    auto compute = [&](int buf) {
-#pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
-            frags(buf, kk);
-            mma();
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = ld16(As + i2_lds_off<BK>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = ld16(Bs + i2_lds_off<BK>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -231,19 +222,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 4) vo
                 SF_WAIT_VMEM();
             }
             SF_BARRIER_KEEP_VMEM();                                 // ... for every wave; stage ks - 1 is no longer read
-            if (p.variant & 1) {
-                // fragment reads FIRST: their LDS latency runs under the (slow to issue) direct-to-LDS copies of the next stage
-                frags(cur, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (issued < ksteps) { issue(tap_i, c_i, nxt); advance(); ++issued; }
-                __builtin_amdgcn_sched_barrier(0);
-                mma();
-#pragma unroll
-                for (int kk = 1; kk < BK / 32; ++kk) { frags(cur, kk); mma(); }
-            } else {
-                if (issued < ksteps) { issue(tap_i, c_i, nxt); advance(); ++issued; }
-                compute(cur);
-            }
+            if (issued < ksteps) { issue(tap_i, c_i, nxt); advance(); ++issued; }
+            compute(cur);
             cur = cur == NST - 1 ? 0 : cur + 1;
             nxt = nxt == NST - 1 ? 0 : nxt + 1;
         }

@@ -26,7 +26,8 @@ import torch.distributed as dist
 def fuse_for_inference(model):
     """Switch ``model`` to eval mode and fold BatchNorm into every fusable unit.  The folded operands are snapshots of
     the current parameters / running statistics: call again after loading a checkpoint or training further.
-    ``model.train()`` leaves the fused path automatically (modules only take it when ``not self.training``)."""
+    ``model.train()`` DROPS the fused state (the snapshots would be stale after the next optimizer step); a later
+    ``model.eval()`` then runs the un-fused running-statistics schedule until this function is called again."""
     model.eval()
     n = 0
     for m in model.modules():
@@ -35,6 +36,18 @@ def fuse_for_inference(model):
             m.__dict__["_sf_infer"] = True
             n += 1
     model.__dict__["_sf_fused_modules"] = n
+    # the folded operands are snapshots: going back to training invalidates them, so the usual
+    # train -> eval-per-epoch loop can never evaluate with stale weights / statistics -- it falls back to the
+    # running-statistics schedule until fuse_for_inference() is called again
+    if "_sf_train_guard" not in model.__dict__:
+        plain_train = model.train
+
+        def train(mode=True):
+            if mode:
+                unfuse(model)
+            return plain_train(mode)
+        model.__dict__["_sf_train_guard"] = True
+        model.train = train
     return model
 
 
@@ -135,7 +148,9 @@ class TestStep:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
         self._graph.replay()
-        return self._preds
+        # the graph's output buffer is overwritten by the next replay: hand out a copy (B x num_cls floats), so callers may
+        # collect the scores of several iterations (e.g. to feed a reference TestMeter)
+        return self._preds.clone()
 
     def update(self, preds, labels, clip_ids):
         """TestMeter.update_stats (meters.py:305-336) without leaving the device: clips of one video may arrive in any

@@ -207,7 +207,8 @@ class TrainStep:
         self._graph, self._logits, self._loss = g, logits.detach(), loss.detach()
 
     def __call__(self, inputs, labels):
-        """Runs one iteration; returns the (unscaled) loss tensor of this iteration."""
+        """Runs one iteration; returns the (unscaled) loss of this iteration as a 0-d device tensor.  The tensor (and
+        ``.logits``) are copies: the captured graph's own output buffers are overwritten by the next replay."""
         self._calls += 1
         self._last_labels = labels
         if not self.use_graph or self._calls <= self.warmup:
@@ -237,8 +238,8 @@ class TrainStep:
                 self._bwd_graphs[k].replay()
                 self.reducer._on_ready(self._seg_params[k])     # finished buckets: all-reduce overlaps the next segment
         self._finish()
-        return self._loss
+        return self._loss.clone() if self._graph is not None else self._loss
 
     @property
     def logits(self):
-        return self._logits
+        return self._logits.clone() if self._graph is not None and self._logits is not None else self._logits

@@ -421,7 +421,9 @@ def check_eval(name, device, fused=False, tol=2e-3, report=None):
     if rec.get("finite") and isinstance(rec.get("probs"), float):
         # reference-derived: the oracle's eval forward under torch.autocast(float16) on MI355X (tools/autocast_yardstick.py),
         # max-ed with the storage-model figure recorded beside it (two realisations of the same rounding noise)
-        yard, factor = max(rec["probs"], float(rec.get("storage_model", {}).get("probs", 0.0))), YARD
+        # factor 2 (not YARD = 1.5): the compared quantity is a MAXIMUM over a few dozen probabilities of one realisation
+        # of rounding noise against another -- its run-to-run ratio is wider than that of the L2-type quantities
+        yard, factor = max(rec["probs"], float(rec.get("storage_model", {}).get("probs", 0.0))), 2.0
     else:
         with video_ref.fp16_storage_model(), torch.no_grad():  # no autocast entry yet: storage model alone, wider factor
             yard = float((eval_forward(sd, cfg, inputs) - o_probs).abs().max() / g_probs.max())
