@@ -192,15 +192,17 @@ class X3DBlockFn(torch.autograd.Function):
             se = (m, h)
         zb = gate_act_fwd(yb, sb.scale, sb.shift, gate, t._swish_inner)
         yc, sc = C.forward(zb, None, tr)
+        # the backward pass needs only the sign of the block output: a 1-bit mask stands in for it (engine.ResBlockFn)
         if P is not None:
             y1, s1 = P.forward(x, None, tr)
-            out = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=y1, rscale=s1.scale, rshift=s1.shift)
+            out, bits = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=y1, rscale=s1.scale, rshift=s1.shift,
+                                   want_mask=True)
         else:
             y1, s1 = None, None
-            out = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x)
+            out, bits = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x, want_mask=True)
         ctx.mod = mod
-        ctx.sv = dict(ya=ya, sa=sa, za=za, yb=yb, sb=sb, gate=gate, se=se, zb=zb, yc=yc, sc=sc, y1=y1, s1=s1)
-        ctx.save_for_backward(x, out)
+        ctx.sv = dict(ya=ya, sa=sa, za=za, yb=yb, sb=sb, gate=gate, se=se, zb=zb, yc=yc, sc=sc, y1=y1, s1=s1, bits=bits)
+        ctx.save_for_backward(x)
         return out
 
     @staticmethod
@@ -208,15 +210,13 @@ class X3DBlockFn(torch.autograd.Function):
         mod, sv = ctx.mod, ctx.sv
         t = mod.branch2
         A, C, P = t._a, t._c, mod._proj
-        x, out = ctx.saved_tensors
+        (x,) = ctx.saved_tensors
         dout = as_cl(dout)
         need_dx = ctx.needs_input_grad[0]
+        bits = sv["bits"]
+        dyc = C.bn_backward(dout, sv["yc"], sv["sc"], zmask=bits)
         if P is not None:
-            dyc = C.bn_backward(dout, sv["yc"], sv["sc"], zmask=out)
-            dy1 = P.bn_backward(dout, sv["y1"], sv["s1"], zmask=out)
-            g = None
-        else:
-            dyc, g = C.bn_backward(dout, sv["yc"], sv["sc"], zmask=out, want_g=True)
+            dy1 = P.bn_backward(dout, sv["y1"], sv["s1"], zmask=bits)
         dzb = C.backward(sv["zb"], None, dyc, need_dx=True)
         yb, sb, gate = sv["yb"], sv["sb"], sv["gate"]
         dmean = None
@@ -230,8 +230,8 @@ class X3DBlockFn(torch.autograd.Function):
         if P is not None:
             dx1 = P.backward(x, None, dy1, need_dx=need_dx)
             dx = A.backward(x, None, dya, need_dx=need_dx, resid=dx1)
-        else:
-            dx = A.backward(x, None, dya, need_dx=need_dx, resid=g)
+        else:       # identity shortcut: the masked block-output gradient is added in the dgrad epilogue
+            dx = A.backward(x, None, dya, need_dx=need_dx, resid=dout, resid_bits=bits)
         _notify(mod._param_list)
         ctx.sv = None
         return (dx, None) + param_grads(ctx, 2)
