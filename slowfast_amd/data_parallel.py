@@ -50,7 +50,12 @@ class GradReducer:
         self._handles = []
         self._torch_hooks = []
         self._prescale, self._prescaled = 1.0 / self.world, set()   # compressed buckets are averaged before the cast
-        self._listener = engine.add_grad_ready_listener(self._on_ready)
+        def listener(params):
+            self._on_ready(params)
+        # weight gradients may still be running on the engine's side stream when a block announces its parameters: only a
+        # reducer that is about to launch a collective on them needs them joined (not world size 1, not while capturing)
+        listener.needs_join = lambda: self.collectives and not self.capturing
+        self._listener = engine.add_grad_ready_listener(listener)
         # parameters owned by plain torch modules (the head) announce themselves through autograd hooks
         self._hooked = set()
         self.capturing = False                  # True while TrainStep records the HIP graph: no collectives

@@ -65,6 +65,46 @@ def cut(x):
     return SEGMENTS.cut([x])[0]
 
 
+# Weight gradients on a SIDE STREAM.  The backward critical path is the data-gradient chain (dgrad -> BatchNorm backward ->
+# dgrad ...); a layer's weight gradient depends on the same dy but nothing downstream depends on IT until the optimizer (or
+# the all-reduce of its bucket).  Forked to a second HIP stream it runs concurrently with the bandwidth-bound BatchNorm
+# backward / elementwise kernels of the chain -- an MFMA- and latency-bound kernel beside HBM-bound ones, the pairing that
+# actually overlaps.  Works under graph capture too (the fork / join become graph edges).  SF_WGRAD_STREAM=0 disables.
+WGRAD_STREAM = os.environ.get("SF_WGRAD_STREAM", "1") != "0"
+_side_streams = {}
+_side_keep = []          # tensors the side stream still reads: kept alive until the join (no allocator stream bookkeeping)
+_side_pending = set()    # devices with un-joined side-stream work
+_join_queued = False
+
+
+def _fork_wgrad(device):
+    """Side stream of `device`, ordered after everything already enqueued on the current stream."""
+    global _join_queued
+    side = _side_streams.get(device)
+    if side is None:
+        side = _side_streams[device] = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    _side_pending.add(device)
+    if not _join_queued:
+        try:            # join when the backward pass that started this ends (plain ``loss.backward()`` callers)
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+            _join_queued = True
+        except RuntimeError:
+            pass        # not inside a backward pass: the caller joins explicitly
+    return side
+
+
+def join_side_streams():
+    """The current stream waits for the forked weight-gradient work; called at the end of every backward pass / backward
+    segment, and before parameters are announced final to a gradient reducer."""
+    global _join_queued
+    _join_queued = False
+    for device in list(_side_pending):
+        torch.cuda.current_stream(device).wait_stream(_side_streams[device])
+    _side_pending.clear()
+    _side_keep.clear()
+
+
 # Test hook: when a list, ResBlockFn.forward appends the tensors that decide its ReLU masks (raw conv outputs + BatchNorm
 # scale / shift, the block output) so that a parity test can hand the SAME masks to the oracle (tests/block_checks.py).
 CAPTURE = None
@@ -97,9 +137,15 @@ def hold_notifications(passes, params=None):
     _sub_counts.clear()
 
 
+def _always():
+    return True
+
+
 def _notify(params):
     if GRADS_VIA_AUTOGRAD:          # the consumer of the gradients (DDP's reducer) hooks autograd itself
         return
+    if _side_pending and any(getattr(fn, "needs_join", _always)() for fn in _listeners):
+        join_side_streams()         # a listener is about to start the all-reduce of these gradients: they must be complete
     if _sub_passes > 1:
         final = []
         for p in params:
@@ -261,7 +307,13 @@ class ConvUnit:
         w = self.conv.weight
         if w.requires_grad:
             dw, zero_first = _grad_dest(w)
-            ops.conv_wgrad(x, dy, geom, dw, in_affine=in_affine, out_scale=1.0, zero_first=zero_first)
+            if WGRAD_STREAM and x.is_cuda and not GRADS_VIA_AUTOGRAD:
+                side = _fork_wgrad(x.device)
+                _side_keep.extend((x, dy))
+                with torch.cuda.stream(side):
+                    ops.conv_wgrad(x, dy, geom, dw, in_affine=in_affine, out_scale=1.0, zero_first=zero_first, side=True)
+            else:
+                ops.conv_wgrad(x, dy, geom, dw, in_affine=in_affine, out_scale=1.0, zero_first=zero_first)
         if not need_dx:
             return None
         _, wd = self.weights(geom)

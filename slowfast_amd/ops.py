@@ -243,7 +243,7 @@ _workspaces = {}
 _retired_workspaces = []
 
 
-def _workspace(device, nbytes):
+def _workspace(device, nbytes, key=None):
     """One grow-only scratch buffer per device: every user is enqueued on the same stream, so launches that
     share it are ordered (the callee allocates nothing, SURVEY.md 8b 'Ownership').
 
@@ -252,16 +252,17 @@ def _workspace(device, nbytes):
     allocator): a graph captured earlier keeps writing its split-K partials into memory that is still reserved for
     exactly that, instead of into whatever tensor the allocator would have placed there.  Growth happens a handful of
     times per process (the largest layer geometry wins), so the retained memory is bounded by ~2x the final size."""
-    ws = _workspaces.get(device)
+    k = (device, key)           # launches on different streams (engine.WGRAD_STREAM) must not share scratch memory
+    ws = _workspaces.get(k)
     if ws is None or ws.numel() < nbytes:
         if ws is not None:
             _retired_workspaces.append(ws)
         ws = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[k] = ws
     return ws
 
 
-def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True):
+def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True, side=False):
     """dw (+)= out_scale * d(loss)/d(weight); dw is an fp32 tensor shaped like the Conv3d weight."""
     assert tuple(x.shape) == geom.in_shape and tuple(dy.shape) == geom.out_shape
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == geom.Cow * geom.Cw * geom.taps
@@ -270,7 +271,7 @@ def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True):
     d = geom.desc(cl_ld(x), cl_ld(dy))
     if geom.ws_bytes is None:
         geom.ws_bytes = lib.call("sf_conv_wgrad_workspace", byref(d))
-    ws = _workspace(x.device, geom.ws_bytes)
+    ws = _workspace(x.device, geom.ws_bytes, "wgrad-side" if side else None)
     lib.call("sf_conv_wgrad", byref(d), x.data_ptr(), _ptr(sc), _ptr(sh), relu,
                    dy.data_ptr(), dw.data_ptr(), float(out_scale), int(zero_first), ws.data_ptr(), ws.numel(), _stream(x),
                    work=geom.work(reads_x=1, reads_y=1))

@@ -62,6 +62,7 @@ class TrainStep:
         # FlatOptimizer: the (dynamic) loss scale is a device scalar -- a captured graph reads its current value at replay
         scale = self.optimizer.loss_scale if self._flat else self.loss_scale
         (loss * scale).backward()
+        engine.join_side_streams()      # weight gradients forked to the side stream (engine.WGRAD_STREAM)
         return logits, loss
 
     # ---- segmented iteration --------------------------------------------------------------------------------------
@@ -89,6 +90,7 @@ class TrainStep:
             pairs = [(o, l.grad) for o, l in zip(origs, leaves) if l is not o and l.grad is not None]
             if pairs:
                 torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+        engine.join_side_streams()      # a backward segment (and its graph) ends with every forked stream joined
 
     def _iteration_segmented_eager(self, inputs, labels, record=False):
         logits, loss, scaled, cuts = self._forward_segmented(inputs, labels)
