@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 15
+#define SF_ABI_VERSION 16
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -46,6 +46,22 @@ const char* sf_last_error(void); /* host string, thread-local */
 int sf_conv_weight_ld(const sf_conv_desc* d, int32_t* ldf, int32_t* ldd);
 /* fp32 [Co][Cw][kT][kH][kW] -> fp16 forward operand wf[Co][ldf] and (optional) dgrad operand wd[Ci][ldd] */
 int sf_prep_weights(const sf_conv_desc* d, const float* w, void* wf, void* wd, sf_stream_t stream);
+/* The same packing for MANY weights in one launch (a training step re-packs every layer after the optimizer update: one
+ * launch instead of one per nn.Conv3d / nn.Linear).  `items` is a DEVICE array the caller uploads once; sf_prep_item_fill
+ * writes the host copy of one entry from a descriptor (an nn.Linear [N][K] is the 1x1x1 case Co=N, Ci=Cw=K: wf = fp16
+ * weight, wd = its transpose).  blk_item / blk_off (device, int32): workgroup b packs 4096 consecutive output elements
+ * (forward operand first, then the dgrad operand) of items[blk_item[b]] starting at element blk_off[b];
+ * sf_prep_item_blocks(item) = number of workgroups an item needs. */
+typedef struct sf_prep_item {
+    const float* w;   /* fp32 [Cow][Cw][taps] */
+    void* wf;         /* fp16 [Co][ldf] */
+    void* wd;         /* fp16 [Cp][ldd], or NULL */
+    int32_t Co, Cow, Cw, Cp, taps, ldf, ldd, pad;
+} sf_prep_item;
+int sf_prep_item_fill(const sf_conv_desc* d, const float* w, void* wf, void* wd, sf_prep_item* item);
+int64_t sf_prep_item_blocks(const sf_prep_item* item);
+int sf_prep_weights_batch(const sf_prep_item* items, const int32_t* blk_item, const int32_t* blk_off, int32_t nblocks,
+                          sf_stream_t stream);
 /* number of 128-row tiles = rows of `stat_part` */
 int sf_conv_fwd_mtiles(const sf_conv_desc* d);
 /* y = conv(act(x)), act(x) = x or relu?(x*in_scale + in_shift) applied on the fly (zero padding is
@@ -69,9 +85,14 @@ int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const v
  * is split; `workspace` (>= sf_conv_wgrad_workspace(d) bytes, caller-owned) holds the per-split partials, which a
  * second kernel sums in a fixed order (no atomics: results are run-to-run reproducible). */
 int64_t sf_conv_wgrad_workspace(const sf_conv_desc* d);
+/* `rowtab` (optional): the per-output-row table {first input position, tap-validity mask} of the large-K kernel.  It
+ * depends on the geometry only: build it once with sf_conv_wgrad_rowtab into sf_conv_wgrad_rowtab_bytes(d) bytes (0: this
+ * geometry takes another kernel, pass NULL) and hand it to every call; NULL rebuilds it in the workspace per call. */
+int64_t sf_conv_wgrad_rowtab_bytes(const sf_conv_desc* d);
+int sf_conv_wgrad_rowtab(const sf_conv_desc* d, void* tab, sf_stream_t stream);
 int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, int in_relu,
                   const void* dy, float* dw, float out_scale, int zero_first, void* workspace, int64_t workspace_bytes,
-                  sf_stream_t stream);
+                  const void* rowtab, sf_stream_t stream);
 
 /* ---- BatchNorm3d -- replaces nn.BatchNorm3d built by batchnorm_helper.py:16-37 (get_norm) at every
  * *_bn call site of resnet_helper.py / stem_helper.py / video_model_builder.py:155-159, plus the

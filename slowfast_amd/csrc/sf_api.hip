@@ -393,19 +393,49 @@ extern "C" int sf_conv_weight_ld(const sf_conv_desc* d, int32_t* ldf, int32_t* l
     return 0;
 }
 
-extern "C" int sf_prep_weights(const sf_conv_desc* d, const float* w, void* wf, void* wd, sf_stream_t stream) {
-    if (check_desc(d)) return -1;
-    REQUIRE(w && wf, "sf_prep_weights: null pointer");
+static PrepParams prep_params(const sf_conv_desc* d, const float* w, void* wf, void* wd) {
     PrepParams p;
+    memset(&p, 0, sizeof(p));
     p.w = w; p.Co = d->Co; p.Cow = d->Cow ? d->Cow : d->Co; p.Cw = d->Cw; p.Cp = d->Ci; p.taps = d->kT * d->kH * d->kW;
     int32_t ldf, ldd;
     sf_conv_weight_ld(d, &ldf, &ldd);
     p.wf = (f16*)wf; p.ldf = ldf; p.wd = (f16*)wd; p.ldd = ldd;
-    int64_t total = (int64_t)p.Co * ldf + (wd ? (int64_t)p.Cp * ldd : 0);
+    return p;
+}
+
+extern "C" int sf_prep_weights(const sf_conv_desc* d, const float* w, void* wf, void* wd, sf_stream_t stream) {
+    if (check_desc(d)) return -1;
+    REQUIRE(w && wf, "sf_prep_weights: null pointer");
+    const PrepParams p = prep_params(d, w, wf, wd);
+    int64_t total = (int64_t)p.Co * p.ldf + (wd ? (int64_t)p.Cp * p.ldd : 0);
     int blocks = (int)((total + SF_THREADS - 1) / SF_THREADS);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(sf_prep_weights_kernel, dim3(blocks), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("prep_weights");
+}
+
+static_assert(sizeof(sf_prep_item) == sizeof(PrepParams), "sf_prep_item must mirror PrepParams");
+extern "C" int sf_prep_item_fill(const sf_conv_desc* d, const float* w, void* wf, void* wd, sf_prep_item* item) {
+    if (check_desc(d)) return -1;
+    REQUIRE(w && wf && item, "sf_prep_item_fill: null pointer");
+    const PrepParams p = prep_params(d, w, wf, wd);
+    memcpy(item, &p, sizeof(p));
+    return 0;
+}
+
+extern "C" int64_t sf_prep_item_blocks(const sf_prep_item* item) {
+    REQUIRE(item && item->Co > 0 && item->ldf > 0, "sf_prep_item_blocks: bad item");
+    const int64_t n = (int64_t)item->Co * item->ldf + (item->wd ? (int64_t)item->Cp * item->ldd : 0);
+    REQUIRE(n < (1ll << 31), "sf_prep_item_blocks: operand too large");
+    return cdiv(n, SF_PREP_BLOCK_ELEMS);
+}
+
+extern "C" int sf_prep_weights_batch(const sf_prep_item* items, const int32_t* blk_item, const int32_t* blk_off,
+                                     int32_t nblocks, sf_stream_t stream) {
+    REQUIRE(items && blk_item && blk_off && nblocks > 0, "sf_prep_weights_batch: bad arguments");
+    hipLaunchKernelGGL(sf_prep_weights_batch_kernel, dim3(nblocks), dim3(SF_THREADS), 0, (hipStream_t)stream,
+                       (const PrepParams*)items, blk_item, blk_off);
+    return check_launch("prep_weights_batch");
 }
 
 extern "C" int sf_conv_fwd_mtiles(const sf_conv_desc* d) {
@@ -581,6 +611,40 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     return w;
 }
 
+// Row table of the v2 weight-gradient kernel ({first input position, tap-validity mask} per output row): a function of the
+// convolution geometry alone, so a caller may build it once (sf_conv_wgrad_rowtab) and pass it to every sf_conv_wgrad call.
+static void launch_rowtab(const sf_conv_desc* d, void* tab, hipStream_t s) {
+    RowtabParams t;
+    memset(&t, 0, sizeof(t));
+    t.tab = (i32x2*)tab;
+    t.M = d->N * d->To * d->Ho * d->Wo;
+    t.fdW = make_fastdiv(d->Wo); t.fdH = make_fastdiv(d->Ho); t.fdT = make_fastdiv(d->To);
+    t.sT = d->Ti; t.sH = d->Hi; t.sW = d->Wi;
+    t.strT = d->sT; t.strH = d->sH; t.strW = d->sW; t.padT = d->pT; t.padH = d->pH; t.padW = d->pW;
+    t.ntaps = d->kT * d->kH * d->kW;
+    int ti = 0;
+    for (int kt = 0; kt < d->kT; ++kt)
+        for (int kh = 0; kh < d->kH; ++kh)
+            for (int kw = 0; kw < d->kW; ++kw, ++ti) {
+                t.dt[ti] = (int8_t)(kt * d->dT); t.dh[ti] = (int8_t)(kh * d->dH); t.dw[ti] = (int8_t)(kw * d->dW);
+            }
+    hipLaunchKernelGGL(sf_wgrad2_rowtab_kernel, dim3(cdiv(t.M, SF_THREADS)), dim3(SF_THREADS), 0, s, t);
+}
+
+extern "C" int64_t sf_conv_wgrad_rowtab_bytes(const sf_conv_desc* d) {
+    if (check_desc(d)) return -1;
+    const Wgrad2Plan w2 = plan_wgrad2(d);
+    return w2.ok ? (int64_t)w2.tab_bytes : 0;
+}
+
+extern "C" int sf_conv_wgrad_rowtab(const sf_conv_desc* d, void* tab, sf_stream_t stream) {
+    if (check_desc(d)) return -1;
+    REQUIRE(tab && (uintptr_t)tab % 16 == 0, "sf_conv_wgrad_rowtab: tab must be a 16-byte aligned device pointer");
+    REQUIRE(plan_wgrad2(d).ok, "sf_conv_wgrad_rowtab: this geometry does not take the row-table kernel (sf_conv_wgrad_rowtab_bytes == 0)");
+    launch_rowtab(d, tab, (hipStream_t)stream);
+    return check_launch("wgrad_rowtab");
+}
+
 extern "C" int64_t sf_conv_wgrad_workspace(const sf_conv_desc* d) {
     if (check_desc(d)) return -1;
     int64_t generic = (int64_t)plan_wgrad(d).ws_bytes;
@@ -592,7 +656,7 @@ extern "C" int64_t sf_conv_wgrad_workspace(const sf_conv_desc* d) {
 
 extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
                              int in_relu, const void* dy, float* dw, float out_scale, int zero_first,
-                             void* workspace, int64_t workspace_bytes, sf_stream_t stream) {
+                             void* workspace, int64_t workspace_bytes, const void* rowtab, sf_stream_t stream) {
     if (check_desc(d)) return -1;
     REQUIRE(x && dy && dw && workspace, "sf_conv_wgrad: null pointer");
     REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sf_conv_wgrad: in_scale/in_shift must come together");
@@ -608,29 +672,18 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
         REQUIRE(workspace_bytes >= (int64_t)w2.ws_bytes, "sf_conv_wgrad: workspace too small (%lld < %lld bytes)",
                 (long long)workspace_bytes, (long long)w2.ws_bytes);
         REQUIRE(((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace) % 16 == 0, "sf_conv_wgrad: operands must be 16-byte aligned");
-        const int taps = d->kT * d->kH * d->kW;
-        RowtabParams t;
-        memset(&t, 0, sizeof(t));
-        t.tab = (i32x2*)workspace;
-        t.M = d->N * d->To * d->Ho * d->Wo;
-        t.fdW = make_fastdiv(d->Wo); t.fdH = make_fastdiv(d->Ho); t.fdT = make_fastdiv(d->To);
-        t.sT = d->Ti; t.sH = d->Hi; t.sW = d->Wi;
-        t.strT = d->sT; t.strH = d->sH; t.strW = d->sW; t.padT = d->pT; t.padH = d->pH; t.padW = d->pW;
-        t.ntaps = taps;
         Wgrad2Params q;
         memset(&q, 0, sizeof(q));
         int ti = 0;
         for (int kt = 0; kt < d->kT; ++kt)
             for (int kh = 0; kh < d->kH; ++kh)
-                for (int kw = 0; kw < d->kW; ++kw, ++ti) {
-                    t.dt[ti] = (int8_t)(kt * d->dT); t.dh[ti] = (int8_t)(kh * d->dH); t.dw[ti] = (int8_t)(kw * d->dW);
-                    q.dlin[ti] = (kt * d->dT * d->Hi + kh * d->dH) * d->Wi + kw * d->dW;
-                }
-        hipLaunchKernelGGL(sf_wgrad2_rowtab_kernel, dim3(cdiv(t.M, SF_THREADS)), dim3(SF_THREADS), 0, s, t);
+                for (int kw = 0; kw < d->kW; ++kw, ++ti) q.dlin[ti] = (kt * d->dT * d->Hi + kh * d->dH) * d->Wi + kw * d->dW;
+        if (!rowtab) launch_rowtab(d, workspace, s);     // the caller keeps no table for this geometry: build it per call
+        else REQUIRE((uintptr_t)rowtab % 16 == 0, "sf_conv_wgrad: rowtab must be 16-byte aligned");
         q.x = (const f16*)x; q.ldx = d->ldx; q.C = d->Ci;
         q.dy = (const f16*)dy; q.ldy = d->ldy; q.Co = d->Co;
-        q.M = t.M; q.Ktot = gk.Ktot;
-        q.rowtab = (const i32x2*)workspace;
+        q.M = d->N * d->To * d->Ho * d->Wo; q.Ktot = gk.Ktot;
+        q.rowtab = (const i32x2*)(rowtab ? rowtab : workspace);
         slabs = (float*)((char*)workspace + w2.tab_bytes);
         q.ws = slabs; q.Co_pad = w2.Co_pad; q.Kpad = w2.Kpad;
         q.tiles_k = w2.tiles_k; q.tiles_c = w2.tiles_c; q.rows_per_split = w2.rows_per_split;
@@ -706,8 +759,10 @@ static int check_rows(const char* who, int64_t M, int C) {
 
 // Folds a long partial table in place (sf_part_fold_kernel) so that the single-workgroup-per-32-channels
 // finalize kernels never walk more than a few hundred rows; returns the row stride of the surviving rows.
+// Tables up to kFoldAbove rows are finalized directly by a 1024-thread block per 8 channels (<= 128 rows per thread).
+static const int kFoldAbove = getenv("SF_FOLD_ABOVE") ? atoi(getenv("SF_FOLD_ABOVE")) : 16384;
 static int fold_partials(float* part, int& nblk, int C, hipStream_t s) {
-    if (nblk <= 256) return 1;
+    if (nblk <= kFoldAbove || nblk <= 256) return 1;
     const int group = nblk <= 2048 ? 16 : nblk <= 8192 ? 32 : 64;
     const int cols = 2 * C;
     dim3 grid(cdiv(cols, SF_THREADS), cdiv(nblk, group));
@@ -727,7 +782,7 @@ extern "C" int sf_bn_finalize(float* part, int32_t nblk, int32_t C, int32_t Crea
     p.part = part; p.nblk = nblk; p.C = C; p.Creal = Creal; p.count = count; p.gamma = gamma; p.beta = beta;
     p.running_mean = running_mean; p.running_var = running_var; p.momentum = momentum; p.eps = eps;
     p.scale = scale; p.shift = shift; p.save_mean = save_mean; p.save_rstd = save_rstd;
-    hipLaunchKernelGGL(sf_bn_finalize_kernel, dim3(cdiv(C, SF_FIN_CH)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sf_bn_finalize_kernel, dim3(cdiv(C, SF_FIN_CH)), dim3(sf_fin_threads(p.nblk)), 0, (hipStream_t)stream, p);
     return check_launch("bn_finalize");
 }
 
@@ -779,7 +834,7 @@ extern "C" int sf_bn_bwd_finalize(float* part, int32_t nblk, int32_t C, int32_t 
     REQUIRE(Creal > 0 && Creal <= C, "sf_bn_bwd_finalize: Creal must be in (0, C]");
     p.part = part; p.nblk = nblk; p.C = C; p.Creal = Creal; p.count = count; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
     p.inv_loss_scale = inv_loss_scale; p.dgamma = dgamma; p.dbeta = dbeta; p.accumulate = accumulate; p.coef = coef;
-    hipLaunchKernelGGL(sf_bn_bwd_finalize_kernel, dim3(cdiv(C, SF_FIN_CH)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sf_bn_bwd_finalize_kernel, dim3(cdiv(C, SF_FIN_CH)), dim3(sf_fin_threads(p.nblk)), 0, (hipStream_t)stream, p);
     return check_launch("bn_bwd_finalize");
 }
 
@@ -1092,7 +1147,7 @@ extern "C" int sf_colsum_finalize(float* part, int32_t nblk, int32_t C, int32_t 
     p.row_stride = fold_partials(part, nblk, C, (hipStream_t)stream);
     p.part = part; p.nblk = nblk; p.C = C; p.fold = fold; p.out0 = out0; p.out1 = out1; p.scale = scale;
     p.accumulate = accumulate;
-    hipLaunchKernelGGL(sf_colsum_finalize_kernel, dim3(cdiv(fold, SF_FIN_CH)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sf_colsum_finalize_kernel, dim3(cdiv(fold, SF_FIN_CH)), dim3(sf_fin_threads(p.nblk)), 0, (hipStream_t)stream, p);
     return check_launch("colsum_finalize");
 }
 

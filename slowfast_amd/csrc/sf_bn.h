@@ -58,37 +58,44 @@ __global__ __launch_bounds__(SF_THREADS) void sf_part_fold_kernel(float* part, i
     base[0] = (float)((a0 + a1) + (a2 + a3));
 }
 
-// Finalize kernels: SF_FIN_CH channels per 256-thread block x SF_FIN_SEG row segments per channel.  A thread walks at
+// Finalize kernels: SF_FIN_CH channels per block x (blockDim.x / SF_FIN_CH) row segments per channel: 32 segments in a
+// 256-thread block for short tables, 128 in a 1024-thread block for long ones (one launch instead of fold + finalize; the
+// table was just written and sits in L2).  A thread walks at
 // most nrows / 32 (<= 8 after sf_part_fold) table rows -- the kernels are pure load-latency chains, so short chains
 // matter more than coalescing here -- and an LDS tree folds the segments in a fixed order.
 #define SF_FIN_SEG 32
+#define SF_FIN_SEG_MAX 128
 #define SF_FIN_CH 8
+#define SF_FIN_THREADS_MAX (SF_FIN_SEG_MAX * SF_FIN_CH)
+// block size of a finalize launch over an nrows-row table
+static inline int sf_fin_threads(int nrows) { return nrows > 256 ? SF_FIN_THREADS_MAX : SF_FIN_SEG * SF_FIN_CH; }
 // sums of rows seg, seg+SEG, ... (< nrows) of a [nrows][2][C] table whose rows are `stride` table-rows apart
 __device__ __forceinline__ void strided_col_sums(const float* part, int nrows, int stride, int C, int c, int seg,
                                                  double& s, double& q) {
     double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
     const int64_t rs = (int64_t)stride * 2 * C;
+    const int nseg = (int)blockDim.x / SF_FIN_CH;
     int b = seg;
-    for (; b + SF_FIN_SEG < nrows; b += 2 * SF_FIN_SEG) {
+    for (; b + nseg < nrows; b += 2 * nseg) {
         const float* p0 = part + (int64_t)b * rs + c;
-        const float* p1 = p0 + SF_FIN_SEG * rs;
+        const float* p1 = p0 + nseg * rs;
         const float u0 = p0[0], w0 = p0[C], u1 = p1[0], w1 = p1[C];
         s0 += (double)u0; q0 += (double)w0; s1 += (double)u1; q1 += (double)w1;
     }
-    for (; b < nrows; b += SF_FIN_SEG) {
+    for (; b < nrows; b += nseg) {
         const float* p0 = part + (int64_t)b * rs + c;
         s0 += (double)p0[0]; q0 += (double)p0[C];
     }
     s = s0 + s1;
     q = q0 + q1;
 }
-// folds the SF_FIN_SEG per-segment sums of every channel; all threads call it, the totals come back on every thread
+// folds the per-segment sums of every channel; all threads call it, the totals come back on every thread
 __device__ __forceinline__ void fin_fold(double (*s_s)[SF_FIN_CH], double (*s_q)[SF_FIN_CH], int seg, int cx, double& s,
                                          double& q) {
     s_s[seg][cx] = s;
     s_q[seg][cx] = q;
     __syncthreads();
-    for (int h = SF_FIN_SEG / 2; h >= 1; h >>= 1) {
+    for (int h = (int)blockDim.x / SF_FIN_CH / 2; h >= 1; h >>= 1) {
         if (seg < h) {
             s_s[seg][cx] += s_s[seg + h][cx];
             s_q[seg][cx] += s_q[seg + h][cx];
@@ -120,9 +127,9 @@ struct BnFinalizeParams {
     float* save_rstd;    // out [C]
 };
 
-__global__ __launch_bounds__(SF_THREADS) void sf_bn_finalize_kernel(BnFinalizeParams p) {
-    __shared__ double s_s[SF_FIN_SEG][SF_FIN_CH];
-    __shared__ double s_q[SF_FIN_SEG][SF_FIN_CH];
+__global__ __launch_bounds__(SF_FIN_THREADS_MAX) void sf_bn_finalize_kernel(BnFinalizeParams p) {
+    __shared__ double s_s[SF_FIN_SEG_MAX][SF_FIN_CH];
+    __shared__ double s_q[SF_FIN_SEG_MAX][SF_FIN_CH];
     const int cx = threadIdx.x % SF_FIN_CH, seg = threadIdx.x / SF_FIN_CH;
     const int c = blockIdx.x * SF_FIN_CH + cx;
     double s = 0.0, q = 0.0;
@@ -320,9 +327,9 @@ struct BnBwdFinalizeParams {
     float* coef;                   // out [3][C]: dy = k1*g + k2 + k3*y
 };
 
-__global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_finalize_kernel(BnBwdFinalizeParams p) {
-    __shared__ double s_s[SF_FIN_SEG][SF_FIN_CH];
-    __shared__ double s_q[SF_FIN_SEG][SF_FIN_CH];
+__global__ __launch_bounds__(SF_FIN_THREADS_MAX) void sf_bn_bwd_finalize_kernel(BnBwdFinalizeParams p) {
+    __shared__ double s_s[SF_FIN_SEG_MAX][SF_FIN_CH];
+    __shared__ double s_q[SF_FIN_SEG_MAX][SF_FIN_CH];
     const int cx = threadIdx.x % SF_FIN_CH, seg = threadIdx.x / SF_FIN_CH;
     const int c = blockIdx.x * SF_FIN_CH + cx;
     double s = 0.0, q = 0.0;

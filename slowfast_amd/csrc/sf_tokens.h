@@ -218,9 +218,9 @@ struct ColFinalizeParams {
     float scale;
     int accumulate;
 };
-__global__ __launch_bounds__(SF_THREADS) void sf_colsum_finalize_kernel(ColFinalizeParams p) {
-    __shared__ double s_s[SF_FIN_SEG][SF_FIN_CH];
-    __shared__ double s_q[SF_FIN_SEG][SF_FIN_CH];
+__global__ __launch_bounds__(SF_FIN_THREADS_MAX) void sf_colsum_finalize_kernel(ColFinalizeParams p) {
+    __shared__ double s_s[SF_FIN_SEG_MAX][SF_FIN_CH];
+    __shared__ double s_q[SF_FIN_SEG_MAX][SF_FIN_CH];
     const int cx = threadIdx.x % SF_FIN_CH, seg = threadIdx.x / SF_FIN_CH;
     const int co = blockIdx.x * SF_FIN_CH + cx;
     double s = 0.0, q = 0.0;

@@ -34,6 +34,11 @@ FORCE_WEIGHT_PREP = False
 # Bumped by writers that update parameters behind torch's back (slowfast_amd.optim.FlatOptimizer's fused update kernel does
 # not touch tensor._version): part of every packed-weight cache key, so the eager path re-packs after such an update.
 PARAM_EPOCH = 0
+# Batched weight packing (WeightPackPlan below).  While PACK_RECORD is a list, every unit that packs its weight through a
+# per-layer launch appends itself; step.TrainStep turns the record of its first iteration into one sf_prep_weights_batch
+# launch per iteration.  SF_PACK_PLAN=0 keeps the per-layer launches (A/B).
+PACK_RECORD = None
+PACK_PLAN = os.environ.get("SF_PACK_PLAN", "1") != "0"
 # Intermediate activations of a block (relu(bn_a(ya)), relu(bn_b(yb))) are materialised in fp16 (default) or recomputed
 # in the consumer's operand loads (SF_MATERIALIZE=0, the round-1 schedule; kept for A/B runs).
 MATERIALIZE = os.environ.get("SF_MATERIALIZE", "1") != "0"
@@ -53,6 +58,69 @@ class _Segments:
         if any(l is not t for l, t in zip(leaves, tensors)):
             self.cuts.append((list(tensors), leaves))
         return leaves
+
+
+class WeightPackPlan:
+    """fp32 -> fp16 operand packing of MANY weights in one launch (sf_prep_weights_batch).  A training step re-packs every
+    layer after the optimizer update; per layer that is ~110 (SlowFast-R50) launches of a few microseconds of work each.
+    Built from the units that packed during one recorded iteration (engine.PACK_RECORD); ``run()`` packs them all into
+    persistent buffers and marks every unit's operand cache fresh, so their per-layer launches do not happen -- eagerly or
+    inside a captured graph (the one launch is captured instead)."""
+
+    def __init__(self, record):
+        from ctypes import byref, sizeof
+        import numpy as np
+        from .lib import PrepItem, get_lib
+        lib = get_lib()
+        seen, self.entries = set(), []
+        for unit, geom, need_dgrad in record:
+            k = (id(unit), None if geom is None else geom.Ci)
+            if k in seen:
+                continue
+            seen.add(k)
+            self.entries.append((unit, geom, need_dgrad))
+        self.device = None
+        items = (PrepItem * max(1, len(self.entries)))()
+        blk_item, blk_off = [], []
+        self._bufs, self._src = [], []
+        for i, (unit, geom, need_dgrad) in enumerate(self.entries):
+            w, desc, wf, wd = unit.pack_item(geom, need_dgrad)
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            self.device = w.device
+            lib.call("sf_prep_item_fill", byref(desc), w.data_ptr(), wf.data_ptr(), None if wd is None else wd.data_ptr(),
+                     byref(items[i]))
+            nb = lib.call("sf_prep_item_blocks", byref(items[i]))
+            blk_item += [i] * nb
+            blk_off += [b * 4096 for b in range(nb)]
+            self._bufs.append((wf, wd))
+            self._src.append((w, w.data_ptr()))
+        self.nblocks = len(blk_item)
+        if self.entries:
+            raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
+            self.items = torch.from_numpy(raw).to(self.device)
+            self.blk_item = torch.tensor(blk_item, dtype=torch.int32, device=self.device)
+            self.blk_off = torch.tensor(blk_off, dtype=torch.int32, device=self.device)
+
+    def __len__(self):
+        return len(self.entries)
+
+    def valid(self):
+        """False once a planned parameter's storage moved (e.g. an optimizer re-pointed it): build a new plan then."""
+        return all(w.data_ptr() == ptr for w, ptr in self._src)
+
+    def run(self):
+        if not self.entries:
+            return
+        from .lib import get_lib
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+        get_lib().call("sf_prep_weights_batch", self.items.data_ptr(), self.blk_item.data_ptr(), self.blk_off.data_ptr(),
+                       self.nblocks, stream)
+        for (unit, geom, _), (wf, wd) in zip(self.entries, self._bufs):
+            unit.pack_assign(geom, wf, wd)
+
+    def release(self):
+        for unit, _, _ in self.entries:
+            unit._planned = False
 
 
 def cut(x):
@@ -270,7 +338,7 @@ class ConvUnit:
         assert bn is None or bn.momentum is not None, "cumulative-average BatchNorm is not supported"
         self.conv, self.bn = conv, bn
         self._geoms = {}
-        self._wkey, self._w = None, None
+        self._wkey, self._w, self._planned = None, None, False
 
     def geom(self, in_shape):
         key = tuple(in_shape)
@@ -286,11 +354,28 @@ class ConvUnit:
         step is being captured; the backward pass of the same step reuses what its forward packed."""
         w = self.conv.weight
         key = (w.data_ptr(), w._version, geom.Ci, w.device, PARAM_EPOCH)
-        if (fresh and FORCE_WEIGHT_PREP) or self._wkey != key:
+        if (fresh and FORCE_WEIGHT_PREP and not self._planned) or self._wkey != key:
             # no data-gradient operand for the RGB stems (3 of 8 channels real); channel padding (54 -> 56) keeps it
-            self._w = ops.prep_weights(w.detach(), geom, need_dgrad=(geom.Ci - geom.Cw < 8))
+            need_dgrad = geom.Ci - geom.Cw < 8
+            self._w = ops.prep_weights(w.detach(), geom, need_dgrad=need_dgrad)
             self._wkey = key
+            if PACK_RECORD is not None:
+                PACK_RECORD.append((self, geom, need_dgrad))
         return self._w
+
+    # -- WeightPackPlan protocol: one entry of the batched packing launch ------------------------------------------------
+    def pack_item(self, geom, need_dgrad):
+        w = self.conv.weight
+        wf = torch.empty((geom.Co, geom.ldf), dtype=_f16, device=w.device)
+        wd = torch.empty((geom.Ci, geom.ldd), dtype=_f16, device=w.device) if need_dgrad else None
+        return w, geom.desc(geom.Ci, geom.Co), wf, wd
+
+    def pack_key(self, geom):
+        w = self.conv.weight
+        return (w.data_ptr(), w._version, geom.Ci, w.device, PARAM_EPOCH)
+
+    def pack_assign(self, geom, wf, wd):
+        self._w, self._wkey, self._planned = (wf, wd), self.pack_key(geom), True
 
     def forward(self, x, in_affine, training):
         geom = self.geom(x.shape)

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class ConvDesc(Structure):
@@ -21,6 +21,13 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in (
         "N", "Ci", "Ti", "Hi", "Wi", "Co", "To", "Ho", "Wo", "kT", "kH", "kW", "sT", "sH", "sW",
         "pT", "pH", "pW", "dT", "dH", "dW", "Cw", "ldx", "ldy", "Cow")]
+
+
+class PrepItem(Structure):
+    """Mirror of ``sf_prep_item`` (one weight of a batched sf_prep_weights_batch launch)."""
+
+    _fields_ = [("w", c_void_p), ("wf", c_void_p), ("wd", c_void_p)] + [(n, c_int32) for n in (
+        "Co", "Cow", "Cw", "Cp", "taps", "ldf", "ldd", "pad")]
 
 
 class DwDesc(Structure):
@@ -46,12 +53,17 @@ _SIGNATURES = {
     "sf_last_error": (c_char_p, []),
     "sf_conv_weight_ld": (c_int, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
     "sf_prep_weights": (c_int, [POINTER(ConvDesc), _F, _P, _P, _P]),
+    "sf_prep_item_fill": (c_int, [POINTER(ConvDesc), _F, _P, _P, POINTER(PrepItem)]),
+    "sf_prep_item_blocks": (c_int64, [POINTER(PrepItem)]),
+    "sf_prep_weights_batch": (c_int, [_P, _P, _P, c_int32, _P]),
     "sf_conv_fwd_mtiles": (c_int, [POINTER(ConvDesc)]),
     "sf_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _F, _F, c_int, _F, _P, _F, _P]),
     "sf_conv_fwd_fused": (c_int, [POINTER(ConvDesc), _P, _P, _F, _P, c_int32, c_int, _P, _P]),
     "sf_conv_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P, _P]),
     "sf_conv_wgrad_workspace": (c_int64, [POINTER(ConvDesc)]),
-    "sf_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _F, _F, c_int, _P, _F, c_float, c_int, _P, c_int64, _P]),
+    "sf_conv_wgrad_rowtab_bytes": (c_int64, [POINTER(ConvDesc)]),
+    "sf_conv_wgrad_rowtab": (c_int, [POINTER(ConvDesc), _P, _P]),
+    "sf_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _F, _F, c_int, _P, _F, c_float, c_int, _P, c_int64, _P, _P]),
     "sf_bn_finalize": (c_int, [_F, c_int32, c_int32, c_int32, c_float, _F, _F, _F, _F, c_float, c_float, _F, _F, _F, _F, _P]),
     "sf_bn_act": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, _P, c_int32, _F, _F, c_int, _P, c_int32, _P, _P]),
     "sf_bn_bwd_blocks": (c_int, [c_int64, c_int32]),

@@ -27,17 +27,35 @@ class LinearUnit:
 
     def __init__(self, lin):
         self.lin = lin
-        self._key, self._w, self._wt = None, None, None
+        self._key, self._w, self._wt, self._planned = None, None, None, False
 
     def _ops(self, fresh=False):
         w = self.lin.weight
         key = (w.data_ptr(), w._version, w.device, _engine.PARAM_EPOCH)
-        if (fresh and engine.FORCE_WEIGHT_PREP) or self._key != key:
+        if (fresh and engine.FORCE_WEIGHT_PREP and not self._planned) or self._key != key:
             wd = w.detach()
             self._w = wd.to(_f16)                      # [N, K]  forward operand
             self._wt = wd.t().contiguous().to(_f16)    # [K, N]  data-gradient operand
             self._key = key
+            N, K = w.shape
+            if _engine.PACK_RECORD is not None and N % 32 == 0 and K % 32 == 0 and w.is_contiguous():
+                _engine.PACK_RECORD.append((self, None, True))
         return self._w, self._wt
+
+    # -- engine.WeightPackPlan protocol: the Linear weight is the 1x1x1 convolution case of the packing kernel --------------
+    def pack_item(self, geom, need_dgrad):
+        from . import ops
+        w = self.lin.weight
+        N, K = w.shape
+        g = ops.ConvGeom((1, K, 1, 1, 1), N, 1)
+        assert g.ldf == K and g.ldd == N
+        return (w, g.desc(K, N), torch.empty((N, K), dtype=_f16, device=w.device),
+                torch.empty((K, N), dtype=_f16, device=w.device))
+
+    def pack_assign(self, geom, wf, wd):
+        w = self.lin.weight
+        self._w, self._wt, self._planned = wf, wd, True
+        self._key = (w.data_ptr(), w._version, w.device, _engine.PARAM_EPOCH)
 
     def forward(self, x, resid=None, out=None):
         w, _ = self._ops(fresh=True)
@@ -210,8 +228,8 @@ class AttentionPlan:
 
 
 # Measured on MI355X: the first version of the fused kernels (bias lookups, expf, per-chunk rescale, no query split in
-# the dK/dV kernel) lost to the unfused chain, 414 vs 445 clips/s (profiles/r1_visit12_bench_mvit_*.json); with the
-# bias on the matrix cores, exp2, lazy rescale and the query split it wins, 488 vs 439 (profiles/r1_visit13_*).
+# the dK/dV kernel) lost to the unfused chain, 414 vs 445 clips/s (profiles/r1/r1_visit12_bench_mvit_*.json); with the
+# bias on the matrix cores, exp2, lazy rescale and the query split it wins, 488 vs 439 (profiles/r1/r1_visit13_*).
 _FUSED_DEFAULT = "1"
 # GELU in the fc1 GEMM epilogue / gelu' in the fc2 data-gradient epilogue (SF_GELU_FUSED=0: separate elementwise passes)
 _FUSED_GELU = os.environ.get("SF_GELU_FUSED", "1") != "0"

@@ -273,9 +273,31 @@ def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True, 
         geom.ws_bytes = lib.call("sf_conv_wgrad_workspace", byref(d))
     ws = _workspace(x.device, geom.ws_bytes, "wgrad-side" if side else None)
     lib.call("sf_conv_wgrad", byref(d), x.data_ptr(), _ptr(sc), _ptr(sh), relu,
-                   dy.data_ptr(), dw.data_ptr(), float(out_scale), int(zero_first), ws.data_ptr(), ws.numel(), _stream(x),
+                   dy.data_ptr(), dw.data_ptr(), float(out_scale), int(zero_first), ws.data_ptr(), ws.numel(),
+                   _ptr(_wgrad_rowtab(geom, d, x.device)) if sc is None else None, _stream(x),
                    work=geom.work(reads_x=1, reads_y=1))
     return dw
+
+
+_rowtabs = {}       # (device, spatial geometry) -> row table of the large-K weight-gradient kernel
+
+
+def _wgrad_rowtab(geom, d, device):
+    """The {first input position, tap mask} table of sf_conv_wgrad's large-K kernel is a function of the geometry alone:
+    built once per (device, geometry) -- shared by every layer of that shape -- instead of once per call.  Built on first
+    use, i.e. during the eager warm-up iterations of step.TrainStep; a build that happens while a graph is being captured
+    is simply replayed with the graph."""
+    nbytes = getattr(geom, "_rowtab_bytes", None)
+    if nbytes is None:
+        nbytes = geom._rowtab_bytes = get_lib().call("sf_conv_wgrad_rowtab_bytes", byref(d))
+    if nbytes <= 0:
+        return None                     # this layer takes another kernel
+    key = (device, geom.N, geom.Ti, geom.Hi, geom.Wi, geom.To, geom.Ho, geom.Wo, geom.k, geom.s, geom.p, geom.d)
+    if key not in _rowtabs:
+        tab = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        get_lib().call("sf_conv_wgrad_rowtab", byref(d), tab.data_ptr(), _stream(tab))
+        _rowtabs[key] = tab
+    return _rowtabs[key]
 
 
 # ------------------------------------------------------------------------------------------------

@@ -53,10 +53,33 @@ class TrainStep:
         self.track_stats, self.stats_depth = track_stats, 8
         self._stats = collections.deque()
         self._last_labels = None
+        self._pack_plan, self._pack_recorded = None, False
 
     # ------------------------------------------------------------------------------------------------
+    def _pack_weights(self):
+        """All fp16 weight operands in one launch (engine.WeightPackPlan) -- eagerly, or as the first node of the captured
+        forward graph.  The plan is built from the layers that packed during the first iteration."""
+        plan = self._pack_plan
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if plan is not None and not capturing and not plan.valid():
+            plan.release()
+            plan = self._pack_plan = None
+            self._pack_recorded = False
+        if plan is not None:
+            plan.run()
+        elif engine.PACK_PLAN and not self._pack_recorded and engine.PACK_RECORD is None and not capturing:
+            engine.PACK_RECORD = []
+
+    def _pack_recorded_done(self):
+        if engine.PACK_RECORD is not None and not self._pack_recorded:
+            record, engine.PACK_RECORD = engine.PACK_RECORD, None
+            self._pack_recorded = True
+            if record:
+                self._pack_plan = engine.WeightPackPlan(record)
+
     def _fwd_bwd(self, inputs, labels):
         self.reducer.zero_grad()
+        self._pack_weights()
         logits = self.model(inputs)
         loss = self.loss_fn(logits.float(), labels)
         # FlatOptimizer: the (dynamic) loss scale is a device scalar -- a captured graph reads its current value at replay
@@ -70,6 +93,7 @@ class TrainStep:
         """zero_grad + forward + loss with the stage boundaries cut (engine.cut -> detached leaves); returns the pieces
         _backward_segment() needs."""
         self.reducer.zero_grad()
+        self._pack_weights()
         rec = engine._Segments()
         engine.SEGMENTS = rec
         try:
@@ -219,6 +243,7 @@ class TrainStep:
             else:
                 logits, loss = self._fwd_bwd(inputs, labels)
             self._logits, self._loss = logits.detach(), loss.detach()
+            self._pack_recorded_done()
             self._finish()
             return self._loss
         if self._graph is None:

@@ -114,7 +114,8 @@ def linear_wgrad(x, dy, dw, zero_first=True):
         geom.ws_bytes = lib.call("sf_conv_wgrad_workspace", byref(d))
     ws = _workspace(x.device, geom.ws_bytes)
     lib.call("sf_conv_wgrad", byref(d), x.data_ptr(), None, None, 0, dy.data_ptr(), dw.data_ptr(), 1.0, int(zero_first),
-             ws.data_ptr(), ws.numel(), _stream(x), work=dict(flops=2.0 * M * N * K, bytes=2.0 * M * (N + K)))
+             ws.data_ptr(), ws.numel(), _ptr(ops._wgrad_rowtab(geom, d, x.device)), _stream(x),
+             work=dict(flops=2.0 * M * N * K, bytes=2.0 * M * (N + K)))
     return dw
 
 

@@ -246,8 +246,8 @@ def check_layout(device, shape, seed=0):
 
 
 def check_bn_finalize_long(device, nblk, C, seed=0):
-    """Long partial tables take the in-place fold stage (sf_part_fold_kernel) before the final reduction, in
-    the forward (sf_bn_finalize) and the backward (sf_bn_bwd_finalize) statistics."""
+    """Long partial tables: 1024-thread finalize blocks up to 16384 rows, the in-place fold stage (sf_part_fold_kernel)
+    beyond, in the forward (sf_bn_finalize) and the backward (sf_bn_bwd_finalize) statistics."""
     from slowfast_amd.lib import get_lib
     g = torch.Generator().manual_seed(seed)
     rows = 128

@@ -98,3 +98,38 @@ def test_wgrad2(sim, force_w2, case):
 
 def test_wgrad2_accumulate_and_scale(sim, force_w2):
     kc.check_conv_wgrad(sim, (1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), out_scale=0.25)
+
+
+def test_wgrad2_row_table_is_built_once_per_geometry(sim, force_w2):
+    """ops.conv_wgrad keeps the {first input position, tap mask} row table per (device, geometry): the second layer of the
+    same shape -- and every later call -- passes the cached table instead of rebuilding it; same result as the per-call build
+    (the plain check above runs the first call of a geometry)."""
+    import torch
+    from slowfast_amd import lib, ops
+    counts = {}
+
+    def observer(name, thunk, work):
+        counts[name] = counts.get(name, 0) + 1
+        return thunk()
+    ops._rowtabs.clear()
+    g = torch.Generator().manual_seed(3)
+    shape = (1, 64, 2, 9, 9)
+    geoms = [ops.ConvGeom(shape, co, (1, 3, 3), 1, (0, 1, 1)) for co in (64, 72)]
+    lib.set_call_observer(observer)
+    try:
+        outs = []
+        for rep in range(2):
+            for geom in geoms:
+                x = kc.host_to_cl(torch.randn(shape, generator=torch.Generator().manual_seed(5)), sim)
+                dy = kc.host_to_cl(torch.randn((1, geom.Cow, 2, 9, 9), generator=torch.Generator().manual_seed(6)), sim)
+                dw = torch.zeros((geom.Cow, 64, 1, 3, 3), dtype=torch.float32)
+                outs.append(ops.conv_wgrad(x, dy, geom, dw).clone())
+    finally:
+        lib.set_call_observer(None)
+    assert counts["sf_conv_wgrad"] == 4 and counts["sf_conv_wgrad_rowtab"] == 1
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    ref = torch.nn.grad.conv3d_weight(
+        kc.cl_to_host(kc.host_to_cl(torch.randn(shape, generator=torch.Generator().manual_seed(5)), sim)).float(), (64, 64, 1, 3, 3),
+        kc.cl_to_host(kc.host_to_cl(torch.randn((1, 64, 2, 9, 9), generator=torch.Generator().manual_seed(6)), sim)).float(),
+        padding=(0, 1, 1))
+    assert float((outs[0] - ref).abs().max() / ref.abs().max()) < 2e-3

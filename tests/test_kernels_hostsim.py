@@ -97,10 +97,11 @@ def test_layout(sim):
 
 
 def test_bn_finalize_long_tables(sim):
-    kc.check_bn_finalize_long(sim, 300, 24)      # folded with group 16
-    kc.check_bn_finalize_long(sim, 2500, 8)      # group 32
-    kc.check_bn_finalize_long(sim, 9000, 16)     # group 64, ragged last group
-    kc.check_bn_finalize_long(sim, 200, 40)      # short table: no fold
+    kc.check_bn_finalize_long(sim, 300, 24)      # 1024-thread finalize (128 row segments per channel), no fold
+    kc.check_bn_finalize_long(sim, 2500, 8)
+    kc.check_bn_finalize_long(sim, 9000, 16)     # ragged segments
+    kc.check_bn_finalize_long(sim, 200, 40)      # short table: 256-thread finalize
+    kc.check_bn_finalize_long(sim, 17000, 8)     # > 16384 rows: in-place fold (group 64, ragged last group) first
 
 
 def test_wgrad_many_splits(sim):

@@ -230,3 +230,45 @@ def test_segmented_graph_replay_matches_eager(gpu, name):
     assert l0 == l1, (l0, l1)
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)
+
+
+def _count_calls(fn):
+    """Runs fn() with a libsfamd call observer; returns (result, {entry point: calls})."""
+    from slowfast_amd import lib
+    counts = {}
+
+    def observer(name, thunk, work):
+        counts[name] = counts.get(name, 0) + 1
+        return thunk()
+    lib.set_call_observer(observer)
+    try:
+        return fn(), counts
+    finally:
+        lib.set_call_observer(None)
+
+
+def test_weight_pack_plan_one_launch_same_result(sim, monkeypatch):
+    """engine.WeightPackPlan: after the recorded first iteration every conv weight of the step is packed by ONE
+    sf_prep_weights_batch launch -- same operands bit for bit, so same parameters after training as with per-layer packing."""
+    from slowfast_amd import engine
+    (params, ctl, losses), counts = _count_calls(lambda: _run_flat(sim, use_graph=False, steps=3))
+    nconv = 7                                            # 2 bottleneck blocks: a, b, c (+ projection shortcut of the first)
+    assert counts["sf_prep_weights"] == nconv            # first (recorded) iteration only
+    assert counts["sf_prep_weights_batch"] == 2
+    monkeypatch.setattr(engine, "PACK_PLAN", False)
+    (params0, ctl0, losses0), counts0 = _count_calls(lambda: _run_flat(sim, use_graph=False, steps=3))
+    assert counts0["sf_prep_weights"] == 3 * nconv and "sf_prep_weights_batch" not in counts0
+    assert losses == losses0 and torch.equal(ctl, ctl0)
+    for a, b in zip(params, params0):
+        assert torch.equal(a, b)
+
+
+def test_weight_pack_plan_covers_mvit_linears(sim, monkeypatch):
+    from slowfast_amd import engine
+    (la, pa, _, _), counts = _count_calls(lambda: _run_model(sim, "mvit_tiny", segmented=False, use_graph=False, steps=2))
+    assert counts.get("sf_prep_weights_batch", 0) == 1
+    monkeypatch.setattr(engine, "PACK_PLAN", False)
+    (lb, pb, _, _), _ = _count_calls(lambda: _run_model(sim, "mvit_tiny", segmented=False, use_graph=False, steps=2))
+    assert la == lb
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)

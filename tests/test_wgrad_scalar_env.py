@@ -15,7 +15,7 @@ def test_wgrad_scalar_path(hostsim_path):
 
 def test_depthwise_version2_kernels(hostsim_path):
     """SF_DW_FWD_V2=1 / SF_DW_DGRAD_V2=1 / SF_DW_WGRAD_V2=1 select the second-generation W-blocked depthwise stencils
-    (opt-in until they have been timed on hardware; profiles/r1_isa_dwconv_v2.md)."""
+    (opt-in until they have been timed on hardware; profiles/r1/r1_isa_dwconv_v2.md)."""
     code = ("import torch; from tests import token_checks as tc; d=torch.device('cpu');"
             "tc.check_dwconv(d,2,2,16,(2,6,6),(3,3,3),(1,2,2),cls=1);"
             "tc.check_dwconv(d,1,1,32,(4,5,5),(3,3,3),(1,1,1),cls=1);"

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_depthwise_version2_kernels_gpu(gpu):
-    """The version-2 depthwise stencils (SF_DW_*_V2=1, profiles/r1_isa_dwconv_v2.md) on the real kernels: narrow (fp32 LDS
+    """The version-2 depthwise stencils (SF_DW_*_V2=1, profiles/r1/r1_isa_dwconv_v2.md) on the real kernels: narrow (fp32 LDS
     weights) and wide (fp16) layers, stride 1 and 2, whole and ragged 4-column groups, cls rows; then X3D end to end."""
     code = ("import torch; from tests import token_checks as tc, model_checks as mc; d=torch.device('cuda:0');"
             "tc.check_dwconv(d,2,2,96,(4,14,14),(3,3,3),(1,2,2),cls=1);"
