@@ -49,14 +49,14 @@ int sf_prep_weights(const sf_conv_desc* d, const float* w, void* wf, void* wd, s
 /* The same packing for MANY weights in one launch (a training step re-packs every layer after the optimizer update: one
  * launch instead of one per nn.Conv3d / nn.Linear).  `items` is a DEVICE array the caller uploads once; sf_prep_item_fill
  * writes the host copy of one entry from a descriptor (an nn.Linear [N][K] is the 1x1x1 case Co=N, Ci=Cw=K: wf = fp16
- * weight, wd = its transpose).  blk_item / blk_off (device, int32): workgroup b packs 4096 consecutive output elements
- * (forward operand first, then the dgrad operand) of items[blk_item[b]] starting at element blk_off[b];
- * sf_prep_item_blocks(item) = number of workgroups an item needs. */
+ * weight, wd = its transpose).  An item is cut into sf_prep_item_blocks(item) bricks; blk_item / blk_off (device, int32):
+ * workgroup b packs brick blk_off[b] (0 .. blocks-1) of items[blk_item[b]]. */
 typedef struct sf_prep_item {
     const float* w;   /* fp32 [Cow][Cw][taps] */
     void* wf;         /* fp16 [Co][ldf] */
     void* wd;         /* fp16 [Cp][ldd], or NULL */
-    int32_t Co, Cow, Cw, Cp, taps, ldf, ldd, pad;
+    int32_t Co, Cow, Cw, Cp, taps, ldf, ldd;
+    int32_t pad;      /* brick shape, written by sf_prep_item_fill */
 } sf_prep_item;
 int sf_prep_item_fill(const sf_conv_desc* d, const float* w, void* wf, void* wd, sf_prep_item* item);
 int64_t sf_prep_item_blocks(const sf_prep_item* item);

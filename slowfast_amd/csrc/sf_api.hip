@@ -418,15 +418,17 @@ static_assert(sizeof(sf_prep_item) == sizeof(PrepParams), "sf_prep_item must mir
 extern "C" int sf_prep_item_fill(const sf_conv_desc* d, const float* w, void* wf, void* wd, sf_prep_item* item) {
     if (check_desc(d)) return -1;
     REQUIRE(w && wf && item, "sf_prep_item_fill: null pointer");
-    const PrepParams p = prep_params(d, w, wf, wd);
+    PrepParams p = prep_params(d, w, wf, wd);
+    p.pad = sf_prep_tile_co(p.taps);
     memcpy(item, &p, sizeof(p));
     return 0;
 }
 
 extern "C" int64_t sf_prep_item_blocks(const sf_prep_item* item) {
-    REQUIRE(item && item->Co > 0 && item->ldf > 0, "sf_prep_item_blocks: bad item");
+    REQUIRE(item && item->Co > 0 && item->ldf > 0 && item->taps > 0, "sf_prep_item_blocks: bad item");
+    REQUIRE(item->pad == sf_prep_tile_co(item->taps), "sf_prep_item_blocks: item was not written by sf_prep_item_fill");
+    if (item->pad > 0) return (int64_t)cdiv(item->Co, item->pad) * cdiv(item->Cp, SF_PREP_TILE_CI);
     const int64_t n = (int64_t)item->Co * item->ldf + (item->wd ? (int64_t)item->Cp * item->ldd : 0);
-    REQUIRE(n < (1ll << 31), "sf_prep_item_blocks: operand too large");
     return cdiv(n, SF_PREP_BLOCK_ELEMS);
 }
 
@@ -759,8 +761,10 @@ static int check_rows(const char* who, int64_t M, int C) {
 
 // Folds a long partial table in place (sf_part_fold_kernel) so that the single-workgroup-per-32-channels
 // finalize kernels never walk more than a few hundred rows; returns the row stride of the surviving rows.
-// Tables up to kFoldAbove rows are finalized directly by a 1024-thread block per 8 channels (<= 128 rows per thread).
-static const int kFoldAbove = getenv("SF_FOLD_ABOVE") ? atoi(getenv("SF_FOLD_ABOVE")) : 16384;
+// Tables up to kFoldAbove rows are finalized directly by a 1024-thread block per 8 channels (<= 16 rows per thread:
+// 7.5 us for the 1024-row tables of the backward pass against 5 + 5 us for fold + finalize); longer tables (the per-tile
+// partials of a forward convolution over 800k positions) measured no faster that way and keep the fold stage.
+static const int kFoldAbove = getenv("SF_FOLD_ABOVE") ? atoi(getenv("SF_FOLD_ABOVE")) : 2048;
 static int fold_partials(float* part, int& nblk, int C, hipStream_t s) {
     if (nblk <= kFoldAbove || nblk <= 256) return 1;
     const int group = nblk <= 2048 ? 16 : nblk <= 8192 ? 32 : 64;

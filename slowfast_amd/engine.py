@@ -91,7 +91,7 @@ class WeightPackPlan:
                      byref(items[i]))
             nb = lib.call("sf_prep_item_blocks", byref(items[i]))
             blk_item += [i] * nb
-            blk_off += [b * 4096 for b in range(nb)]
+            blk_off += list(range(nb))
             self._bufs.append((wf, wd))
             self._src.append((w, w.data_ptr()))
         self.nblocks = len(blk_item)

@@ -320,3 +320,35 @@ def check_pack_clip(device, arch="slowfast", reverse=False, seed=0):
         buf = x.permute(0, 2, 3, 4, 1).reshape(N, T, H, W2 * 2, 4).cpu()
         assert torch.equal(buf[..., :3].permute(0, 4, 1, 2, 3).contiguous(), r.half()), "normalised clip differs"
         assert float(buf[..., 3].abs().max()) == 0.0
+
+
+def check_prep_weights_batch(device, cases, seed=0):
+    """sf_prep_weights_batch (every weight of a model packed by one launch, LDS bricks) == sf_prep_weights per layer, bit for
+    bit, including the zero padding of both operands.  cases: (Co_real, Cw, Ci_padded, kernel, need_dgrad)."""
+    from ctypes import byref
+    import numpy as np
+    from slowfast_amd.lib import PrepItem, get_lib
+    lib = get_lib()
+    g = torch.Generator().manual_seed(seed)
+    items = (PrepItem * len(cases))()
+    blk_item, blk_off, keep, want = [], [], [], []
+    for i, (Co, Cw, Ci, k, need_dgrad) in enumerate(cases):
+        geom = ops.ConvGeom((1, Ci, 4, 8, 8), Co, k, 1, tuple(x // 2 for x in k), Cw=Cw)
+        w = torch.randn((Co, Cw) + tuple(k), generator=g).to(device)
+        want.append(ops.prep_weights(w, geom, need_dgrad=need_dgrad))
+        wf = torch.full((geom.Co, geom.ldf), float("nan"), dtype=torch.float16, device=device)
+        wd = torch.full((geom.Ci, geom.ldd), float("nan"), dtype=torch.float16, device=device) if need_dgrad else None
+        lib.call("sf_prep_item_fill", byref(geom.desc(geom.Ci, geom.Co)), w.data_ptr(), wf.data_ptr(),
+                 None if wd is None else wd.data_ptr(), byref(items[i]))
+        nb = lib.call("sf_prep_item_blocks", byref(items[i]))
+        blk_item += [i] * nb
+        blk_off += list(range(nb))
+        keep.append((w, wf, wd))
+    tab = torch.from_numpy(np.frombuffer(bytes(items), dtype=np.uint8).copy()).to(device)
+    bi = torch.tensor(blk_item, dtype=torch.int32, device=device)
+    bo = torch.tensor(blk_off, dtype=torch.int32, device=device)
+    lib.call("sf_prep_weights_batch", tab.data_ptr(), bi.data_ptr(), bo.data_ptr(), len(blk_item), ops._stream(tab))
+    for (w, wf, wd), (rf, rd), case in zip(keep, want, cases):
+        assert torch.equal(wf.cpu(), rf.cpu()), ("forward operand", case)
+        if wd is not None:
+            assert torch.equal(wd.cpu(), rd.cpu()), ("dgrad operand", case)

@@ -180,3 +180,11 @@ def test_conv_fwd_fused(gpu):
     # thin W-pair-folded stems: LDS-patch direct convolution with the bias / ReLU epilogue
     kc.check_conv_fwd_fused(gpu, (2, 8, 8, 64, 32), 8, (5, 7, 4), (1, 2, 1), (2, 3, 2))
     kc.check_conv_fwd_fused(gpu, (2, 8, 3, 36, 22), 16, (1, 7, 4), (1, 2, 1), (0, 3, 2), relu=False)
+
+
+@pytest.mark.gpu
+def test_prep_weights_batch_equals_per_layer_gpu(gpu):
+    kc.check_prep_weights_batch(gpu, [
+        (64, 64, 64, (1, 3, 3), True), (2048, 512, 512, (1, 1, 1), True), (8, 32, 32, (3, 1, 1), True),
+        (54, 40, 40, (1, 1, 1), True), (64, 3, 8, (1, 7, 7), False), (16, 16, 16, (3, 3, 3), True),
+        (512, 512, 512, (1, 3, 3), True), (8, 8, 8, (5, 11, 11), True)])

@@ -118,3 +118,15 @@ def test_roi_pool(sim, aligned):
 @pytest.mark.parametrize("arch,reverse", [("slowfast", False), ("slowfast", True), ("c2d", False)])
 def test_pack_clip_u8(sim, arch, reverse):
     kc.check_pack_clip(sim, arch, reverse)
+
+
+def test_prep_weights_batch_equals_per_layer(sim):
+    kc.check_prep_weights_batch(sim, [
+        (64, 64, 64, (1, 3, 3), True),        # 3x3 bottleneck conv
+        (256, 64, 64, (1, 1, 1), True),       # pointwise, several brick rows / columns
+        (8, 32, 32, (3, 1, 1), True),         # Fast pathway: fewer output channels than a brick holds
+        (54, 40, 40, (1, 1, 1), True),        # ragged: Co 54 -> 56 padded rows, 40 channels = 1.25 bricks
+        (64, 3, 8, (1, 7, 7), False),         # RGB stem: 3 of 8 channels real, 49 taps, no dgrad operand
+        (16, 16, 16, (3, 3, 3), True),        # 27 taps: 16-channel bricks
+        (8, 8, 8, (5, 11, 11), True),         # 605 taps: does not fit a brick -> element-wise blocks
+    ])

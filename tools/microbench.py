@@ -59,6 +59,44 @@ def timeit(fn, iters):
     return st.elapsed_time(en) / iters
 
 
+HBM_PEAK_GBS, MFMA_PEAK_TF = 8000.0, 2500.0
+
+
+def write_markdown(path, batch, rows, tot):
+    """Per-geometry table: microseconds, algorithmic GB/s (operand + result bytes crossing HBM once), TFLOP/s and the
+    roofline fraction max(GB/s / 8 TB/s, TFLOP/s / 2.5 PFLOP/s) of each entry point; worst shapes by time lost."""
+    def frac(gbs, tf):
+        return max(gbs / HBM_PEAK_GBS, tf / MFMA_PEAK_TF)
+    lines = [f"# libsfamd entry points on the SlowFast-8x8-R50 layer geometries, batch {batch} (tools/microbench.py, HIP events)", "",
+             "us per call; GB/s = algorithmic bytes (input + output activations once, fp16) / time; TF = useful TFLOP/s; "
+             "frac = max(GB/s / 8000, TF / 2500) = distance to whichever roofline bounds the layer", "",
+             "| layer | x | fwd us | GB/s | TF | frac | dgrad us | GB/s | TF | frac | wgrad us | GB/s | TF | frac | bn_act us | GB/s | bn_bwd us | GB/s |",
+             "|---|---:|" + "---:|" * 16]
+    lost = []
+    for r in rows:
+        io = r["io_bytes"]
+        cells = [r["name"], str(r["count"])]
+        for op in ("fwd", "dgrad", "wgrad"):
+            ms = r[f"{op}_ms"]
+            if not ms:
+                cells += ["-", "-", "-", "-"]
+                continue
+            gbs, tf = io / ms / 1e6, r[f"{op}_tflops"]
+            f = frac(gbs, tf)
+            cells += [f"{ms * 1e3:.0f}", f"{gbs:.0f}", f"{tf:.0f}", f"{f:.2f}"]
+            lost.append((r["count"] * ms * (1 - f), f"{r['name']} {op}", r["count"], ms, gbs, tf, f))
+        cells += [f"{r['bn_act_ms'] * 1e3:.0f}", f"{r['act_gbs']:.0f}", f"{r['bn_bwd_ms'] * 1e3:.0f}", f"{r['bnbwd_gbs']:.0f}"]
+        lines.append("| " + " | ".join(cells) + " |")
+    lines += ["", "weighted totals per step (ms): " + ", ".join(f"{k} {v:.2f}" for k, v in tot.items()), "",
+              "## Worst shapes (count x time x (1 - frac) = ms per step above the roofline)", "",
+              "| layer / op | x | us | GB/s | TF | frac | ms lost |", "|---|---:|---:|---:|---:|---:|---:|"]
+    for l, name, cnt, ms, gbs, tf, f in sorted(lost, reverse=True)[:15]:
+        lines.append(f"| {name} | {cnt} | {ms * 1e3:.0f} | {gbs:.0f} | {tf:.0f} | {f:.2f} | {l:.2f} |")
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
@@ -66,6 +104,7 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--filter", default="")
     ap.add_argument("--no-bn", action="store_true", help="skip the BatchNorm / activation kernels (GEMM variant sweeps)")
+    ap.add_argument("--md", default="", help="write the per-geometry table (us, GB/s, TFLOP/s, roofline fraction) as markdown")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
@@ -103,7 +142,7 @@ def main():
             t_act = timeit(lambda: ops.bn_act(y, scale, shift, relu=True, out=z), a.iters)
             t_bb = timeit(lambda: ops.bn_bwd(dy, y, gamma, mean, rstd, dgm, dbt, relu_affine=(scale, shift), out=z), a.iters)
         bytes_io = 2.0 * (x.numel() * Cw / Ci + y.numel())
-        row = dict(name=name, count=cnt, gmac=macs / 1e9, fwd_ms=t_f, fwd_affine_ms=t_fa, dgrad_ms=t_d, wgrad_ms=t_w,
+        row = dict(name=name, count=cnt, gmac=macs / 1e9, io_bytes=bytes_io, fwd_ms=t_f, fwd_affine_ms=t_fa, dgrad_ms=t_d, wgrad_ms=t_w,
                    bn_act_ms=t_act, bn_bwd_ms=t_bb, fwd_tflops=2 * macs / t_f / 1e9,
                    dgrad_tflops=(2 * macs / t_d / 1e9 if t_d else 0), wgrad_tflops=2 * macs / t_w / 1e9,
                    fwd_gbs=bytes_io / t_f / 1e6, act_gbs=2.0 * 2 * y.numel() / t_act / 1e6,
@@ -114,6 +153,8 @@ def main():
               f"(+bn {t_fa:7.3f}) | dgrad {t_d:7.3f} ms {row['dgrad_tflops']:7.1f} TF | wgrad {t_w:7.3f} ms {row['wgrad_tflops']:7.1f} TF "
               f"| act {t_act:6.3f} ms {row['act_gbs']:6.0f} GB/s | bnbwd {t_bb:6.3f} ms {row['bnbwd_gbs']:6.0f} GB/s", flush=True)
     print("weighted totals (ms):", {k: round(v, 2) for k, v in tot.items()}, "sum", round(sum(tot.values()), 2))
+    if a.md:
+        write_markdown(a.md, a.batch, rows, tot)
     if a.json:
         os.makedirs(os.path.dirname(a.json) or ".", exist_ok=True)
         with open(a.json, "w") as f:
