@@ -318,7 +318,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_prep_weights_kernel(PrepParams 
 // 4096-element blocks of the element-wise form.
 #define SF_PREP_BLOCK_ELEMS (SF_THREADS * 16)
 #define SF_PREP_TILE_CI 32
-#define SF_PREP_LDS_HALFS 16384
+#define SF_PREP_LDS_HALFS 4096
 // output channels per brick (power of two <= 32; 0: brick does not fit, element-wise fallback)
 static inline int sf_prep_tile_co(int taps) {
     const int row = SF_PREP_TILE_CI * taps + 2;
