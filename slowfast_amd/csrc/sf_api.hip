@@ -575,8 +575,8 @@ static WgradPlan plan_wgrad(const sf_conv_desc* d) {
 // Second-generation weight gradient (sf_wgrad2.h): plain (already activated) input, at least 33 output channels, a K axis
 // that fills most of a 256-wide tile.  SF_WGRAD2=0 keeps the first kernel.
 struct Wgrad2Plan {
-    bool ok;
-    int BMW, tiles_k, tiles_c, Co_pad, Kpad, rows_per_split, splits;
+    bool ok, thin;
+    int BMW, BKW, tiles_k, tiles_c, Co_pad, Kpad, rows_per_split, splits;
     size_t tab_bytes, ws_bytes;
 };
 static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
@@ -592,9 +592,34 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : (taps > 1 ? 1024 : 512);
     const int Ktot = taps * d->Ci;
     const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
-    if (taps > SF_I2_MAXTAPS || d->Co <= 32 || Ktot < mink || M < minrows) return w;
+    if (taps > SF_I2_MAXTAPS || M < minrows) return w;
     if ((d->kT - 1) * d->dT > 127 || (d->kH - 1) * d->dH > 127 || (d->kW - 1) * d->dW > 127) return w;
     if (plan_stem(d).ok) return w;
+    if (d->Co <= 32) {
+        // thin layers (sf_wgrad2t_kernel): one workgroup tile holds every output channel; SF_WGRAD2T=0 keeps the first kernel
+        if ((e = getenv("SF_WGRAD2T")) && atoi(e) == 0) return w;
+        const int minrows_t = (e = getenv("SF_WGRAD2T_MINROWS")) ? atoi(e) : 16384;
+        if (M < minrows_t) return w;
+        w.thin = true;
+        w.BMW = d->Co <= 16 ? 16 : 32;
+        w.BKW = Ktot <= 32 ? 32 : 128;
+        w.tiles_k = cdiv(Ktot, w.BKW);
+        w.tiles_c = 1;
+        w.Kpad = w.tiles_k * w.BKW;
+        w.Co_pad = w.BMW;
+        // one resident round of workgroups: LDS allows 2 per CU with 128-wide tiles (2 x 37-41 KB stages), 3 (BMW 32) or 4 (BMW 16)
+        // with 32-wide ones; measured per layer, 512 / 768 / 1024 / 1536 / 2048: profiles/r2_v24_wgrad_thin.md
+        const int target_t = (e = getenv("SF_WGRAD2T_BLOCKS")) ? atoi(e) : (w.BKW == 128 ? 512 : w.BMW == 32 ? 768 : 1024);
+        int splits = cdiv(target_t, w.tiles_k);
+        if (splits < 1) splits = 1;
+        w.rows_per_split = roundup(cdiv(M, splits), 128);
+        w.splits = cdiv(M, w.rows_per_split);
+        w.tab_bytes = ((size_t)M * 8 + 255) / 256 * 256 + 1280;  // pad: the thin kernel reads whole 32-byte groups up to one 128-position stage past M
+        w.ws_bytes = w.tab_bytes + (size_t)w.Co_pad * w.Kpad * 4 * w.splits;
+        w.ok = true;
+        return w;
+    }
+    if (Ktot < mink) return w;
     w.BMW = d->Co > 64 ? 128 : 64;
     w.tiles_k = cdiv(Ktot, 256);
     w.tiles_c = cdiv(d->Co, w.BMW);
@@ -607,7 +632,7 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     if (splits < 1) splits = 1;
     w.rows_per_split = roundup(cdiv(M, splits), 32);
     w.splits = cdiv(M, w.rows_per_split);
-    w.tab_bytes = ((size_t)M * 8 + 255) / 256 * 256;
+    w.tab_bytes = ((size_t)M * 8 + 255) / 256 * 256 + 1280;  // pad: the thin kernel reads whole 32-byte groups up to one 128-position stage past M
     w.ws_bytes = w.tab_bytes + (size_t)slab * w.splits;
     w.ok = true;
     return w;
@@ -689,10 +714,16 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
         slabs = (float*)((char*)workspace + w2.tab_bytes);
         q.ws = slabs; q.Co_pad = w2.Co_pad; q.Kpad = w2.Kpad;
         q.tiles_k = w2.tiles_k; q.tiles_c = w2.tiles_c; q.rows_per_split = w2.rows_per_split;
+        { const char* e = getenv("SF_WGRAD2T_RR"); q.stage_stride = (w2.thin && !(e && atoi(e) == 0)) ? w2.splits : 0; }
         const dim3 grid((unsigned)(w2.tiles_k * w2.tiles_c * w2.splits));
         static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
         if (trace) fprintf(stderr, "[sfamd] wgrad2: M=%d Co=%d K=%d tiles %dx%d splits %d\n", q.M, q.Co, q.Ktot, w2.tiles_c, w2.tiles_k, w2.splits);
-        if (w2.BMW == 128) hipLaunchKernelGGL((sf_wgrad2_kernel<128>), grid, dim3(512), 0, s, q);
+        if (w2.thin) {
+            if (w2.BMW == 16 && w2.BKW == 128) hipLaunchKernelGGL((sf_wgrad2t_kernel<16, 128, 2>), grid, dim3(256), 0, s, q);
+            else if (w2.BMW == 32 && w2.BKW == 128) hipLaunchKernelGGL((sf_wgrad2t_kernel<32, 128, 2>), grid, dim3(256), 0, s, q);
+            else if (w2.BMW == 16) hipLaunchKernelGGL((sf_wgrad2t_kernel<16, 32, 3>), grid, dim3(256), 0, s, q);
+            else hipLaunchKernelGGL((sf_wgrad2t_kernel<32, 32, 3>), grid, dim3(256), 0, s, q);
+        } else if (w2.BMW == 128) hipLaunchKernelGGL((sf_wgrad2_kernel<128>), grid, dim3(512), 0, s, q);
         else hipLaunchKernelGGL((sf_wgrad2_kernel<64>), grid, dim3(512), 0, s, q);
         splits = w2.splits; Co_pad = w2.Co_pad; Kpad = w2.Kpad;
     } else if (sp.ok && !in_scale) {

@@ -35,6 +35,39 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
     } while (0)
 #endif
+// The same copy as an INLINE-ASM statement.  hipcc keeps its own books on the builtin above: every LDS read it cannot prove
+// disjoint from the copy's destination -- in particular the ds_read_b64_tr_b16 intrinsic, which carries no address
+// information -- gets an `s_waitcnt vmcnt(0)` in front of it, which drains the copies of the NEXT stage before the current one
+// is computed (the three-stage ring of the weight-gradient kernels then runs as load -> wait -> compute, serially).  An asm
+// copy is absent from that bookkeeping; its completion is counted by the kernel's own SF_WAIT_VMEM_N + barrier.  M0 (the
+// LDS-DMA destination base) is compiler-reserved: saved and restored inside the statement; the LDS byte address must be
+// wave-uniform.
+#ifndef SF_GLOBAL_LOAD_LDS16_ASM
+#ifdef SF_GLDS_KEEP_M0
+#define SF_GLOBAL_LOAD_LDS16_ASM(g, l)                                                                               \
+    do {                                                                                                                \
+        unsigned sf_keep_m0_;                                                                                           \
+        const unsigned sf_lds_addr_ = (unsigned)__builtin_amdgcn_readfirstlane(                                         \
+            (int)(uintptr_t)(__attribute__((address_space(3))) void*)(l));                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(sf_keep_m0_)                                                                               \
+                     : "v"((const void*)(g)), "s"(sf_lds_addr_)                                                         \
+                     : "memory");                                                                                       \
+    } while (0)
+#else
+// default: M0 is written and left (nothing else in these kernels reads it: no builtin LDS-DMA, no s_movrel / s_sendmsg between
+// the copies; hipcc itself never assumes a value in M0 across an asm statement) -- two scalar instructions fewer per copy
+#define SF_GLOBAL_LOAD_LDS16_ASM(g, l)                                                                               \
+    do {                                                                                                                \
+        const unsigned sf_lds_addr_ = (unsigned)__builtin_amdgcn_readfirstlane(                                         \
+            (int)(uintptr_t)(__attribute__((address_space(3))) void*)(l));                                              \
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"                                 \
+                     :                                                                                                  \
+                     : "v"((const void*)(g)), "s"(sf_lds_addr_)                                                         \
+                     : "memory");                                                                                       \
+    } while (0)
+#endif
+#endif
 // wait until at most N (compile-time) of this wave's vector-memory operations are outstanding: retires everything but
 // the newest N, i.e. a whole copy stage while the next one stays in flight
 #ifndef SF_WAIT_VMEM_N

@@ -21,6 +21,7 @@
 #include "sf_igemm2.h"
 
 struct __attribute__((aligned(8))) i32x2 { int32_t x, y; };
+typedef int32_t i32x8 __attribute__((ext_vector_type(8)));      // four consecutive row-table entries
 
 struct Wgrad2Params {
     const f16* x; int ldx, C;           // forward input, rows of C channels
@@ -33,6 +34,9 @@ struct Wgrad2Params {
     int Co_pad, Kpad;
     int tiles_k, tiles_c;
     int rows_per_split;                 // multiple of 32
+    int stage_stride;                   // thin kernel: 0 = a split is one contiguous run of rows_per_split positions; S > 0 =
+                                        // round robin, split z takes the 128-position stages z, z + S, z + 2S, ... (at any
+                                        // moment the resident workgroups then stream through ONE contiguous region)
 };
 
 struct RowtabParams {
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(512, 4) void sf_wgrad2_kernel(Wgrad2Params p) {
         if (ywave) {
             const int m = r0 + step * ROWS + ymrow;
             const f16* g = (m < r1 && yok) ? p.dy + (int64_t)m * p.ldy + yco : zline;
-            SF_GLOBAL_LOAD_LDS16(g, Ys + wave * 512);
+            SF_GLOBAL_LOAD_LDS16_ASM(g, Ys + wave * 512);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(512, 4) void sf_wgrad2_kernel(Wgrad2Params p) {
             const uint32_t mk = (uint32_t)(xrr ? e[j][1].y : e[j][0].y);
             const bool ok = (mk & xbit[j]) != 0u;
             const f16* g = ok ? p.x + ((int64_t)pos * p.ldx + xcol[j]) : zline;
-            SF_GLOBAL_LOAD_LDS16(g, Xs + (wave + 8 * j) * 512);
+            SF_GLOBAL_LOAD_LDS16_ASM(g, Xs + (wave + 8 * j) * 512);
         }
     };
 
@@ -230,5 +234,215 @@ __global__ __launch_bounds__(512, 4) void sf_wgrad2_kernel(Wgrad2Params p) {
                 const int co = c0 + wc * 64 + i * 16 + 4 * g4 + r;
                 slab[(int64_t)co * p.Kpad + kcol] = acc[i][j][r];
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Thin weight gradient: at most 32 output channels (the Fast pathway: 8 .. 32 wide bottlenecks over 0.8 .. 3.2 M positions).
+// dW is tiny (16|32 x K), the layer is a pure stream over dY and X -- what bounds it is the bytes a CU keeps in flight, and
+// the 128 x 16 register-staged tiles of sf_wgrad_kernel spend their life in per-workgroup prologues (row decode by division,
+// one staged step in flight): 0.8 - 1.9 TB/s measured.  Here:
+//   * ONE workgroup tile covers all output channels (BMW = 16 | 32) and 128 (or 32, for K <= 32) columns of K; the grid is
+//     k-tiles x position splits;
+//   * a stage is 128 positions; the FOUR WAVES SPLIT THE POSITIONS (32 each) and every wave accumulates the whole tile, so
+//     each LDS byte is read exactly once; the four partial tiles are summed through LDS at the end;
+//   * operands travel global -> LDS directly as in sf_wgrad2_kernel (row table through scalar loads, zero line for padding
+//     taps / channels / rows beyond the split), two stages of 37 - 41 KB (two workgroups per CU) or three of 12 - 16 KB;
+//   * bank conflicts of the transpose reads are avoided on the source side: 256-byte rows use the pair swizzle of
+//     sf_wgrad2_kernel, 64-byte rows flip their 32-byte pair with bit 3 of the row, 32-byte rows (BMW = 16) swap bits 2 and 3
+//     of the row position inside a copy block.
+__device__ __forceinline__ int w2t_swap23(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
+// element offset of the 16-column fragment `tile` of logical stage row m in a [rows][W] operand image
+template <int W>
+__device__ __forceinline__ int w2t_frag_off(int m, int tile) {
+    if constexpr (W == 128) return m * 128 + ((tile ^ w2_swz(m)) << 4);
+    else if constexpr (W == 32) return m * 32 + ((tile ^ ((m >> 3) & 1)) << 4);
+    else return w2t_swap23(m) * 16;
+}
+// loader side: the lane-linear slot (physical row position `prow` inside the stage, physical 16-byte chunk `pc`) holds
+// logical row / logical chunk:
+template <int W>
+__device__ __forceinline__ void w2t_slot(int prow, int pc, int& row, int& chunk) {
+    if constexpr (W == 128) { row = prow; chunk = (((pc >> 1) ^ w2_swz(prow)) << 1) | (pc & 1); }
+    else if constexpr (W == 32) { row = prow; chunk = (((pc >> 1) ^ ((prow >> 3) & 1)) << 1) | (pc & 1); }
+    else { row = w2t_swap23(prow); chunk = pc; }
+}
+
+template <int BMW, int BKW, int NST>
+__global__ __launch_bounds__(256) void sf_wgrad2t_kernel(Wgrad2Params p) {
+    constexpr int ROWS = 128, NW = 4;
+    constexpr int TMC = BMW / 16, TNK = BKW / 16;
+    constexpr int YCH = BMW / 8, XCH = BKW / 8;         // 16-byte chunks per row
+    constexpr int YRPI = 64 / YCH, XRPI = 64 / XCH;     // rows per copy instruction (64 lanes x 16 B)
+    constexpr int YPW = ROWS / YRPI / NW, XPW = ROWS / XRPI / NW;   // copy instructions per wave and stage
+    constexpr int COPIES = YPW + XPW;
+    constexpr int Y_ELEMS = ROWS * BMW, X_ELEMS = ROWS * BKW, STAGE = Y_ELEMS + X_ELEMS;
+    static_assert(NST * STAGE * 2 >= NW * TMC * TNK * 256 * 4, "the cross-wave reduction reuses the stage buffers");
+    __shared__ __attribute__((aligned(16))) f16 smem[NST * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = (int)(wg % (uint32_t)p.tiles_k);
+    const int bz = (int)(wg / (uint32_t)p.tiles_k);
+    const int k0 = bx * BKW;
+    // first position of step s of this split: r0 + s * rstep
+    const int rr = p.stage_stride > 0;
+    const int r0 = rr ? bz * ROWS : bz * p.rows_per_split;
+    const int rstep = rr ? p.stage_stride * ROWS : ROWS;
+    int r1 = rr ? p.M : r0 + p.rows_per_split;
+    if (r1 > p.M) r1 = p.M;
+    const int nsteps = r1 > r0 ? (r1 - r0 + rstep - 1) / rstep : 0;
+    const f16* const zline = reinterpret_cast<const f16*>(sf_zero_line);
+
+    // ---- X loader: instruction j of the wave is copy block q = wave + NW * j of the stage (rows q * XRPI ...)
+    int xrow[XPW];          // logical stage row of this lane's slot
+    int xsel[XPW];          // its index inside the block's XRPI row-table entries
+    int64_t xcol[XPW];      // channel offset + tap displacement (elements) of this lane's logical chunk
+    uint32_t xbit[XPW];     // mask bit of the chunk's tap (0: column beyond Ktot)
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+        const int q = wave + NW * j;
+        int row, chunk;
+        w2t_slot<BKW>(q * XRPI + lane / XCH, lane % XCH, row, chunk);
+        xrow[j] = row;
+        xsel[j] = row - q * XRPI;
+        const int k = k0 + chunk * 8;
+        if (k < p.Ktot) {
+            const int tap = k / p.C, ci = k - tap * p.C;
+            xbit[j] = 1u << tap;
+            xcol[j] = (int64_t)p.dlin[tap] * p.ldx + ci;
+        } else {
+            xbit[j] = 0u;
+            xcol[j] = 0;
+        }
+    }
+    // ---- dY loader
+    int yrow[YPW];
+    int yco[YPW];
+#pragma unroll
+    for (int j = 0; j < YPW; ++j) {
+        const int q = wave + NW * j;
+        int row, chunk;
+        w2t_slot<BMW>(q * YRPI + lane / YCH, lane % YCH, row, chunk);
+        yrow[j] = row;
+        yco[j] = chunk * 8;
+    }
+
+    // row-table entries of the XRPI consecutive rows of each of this wave's X copy blocks: wave-uniform -> WIDE scalar loads
+    // (32 bytes = 4 entries each, all issued before the first use: one entry per load with its use right behind it made the
+    // compiler wait for every load in turn, ~4 us of serial scalar-cache latency per stage).  Entries of positions beyond the
+    // table (the plan pads it by one stage) or beyond this split are garbage and masked by the position test.
+    auto tab_rows = [&](int step, int (&epos)[XPW], uint32_t (&emk)[XPW]) {
+        i32x8 t[XPW][XRPI / 4];
+#pragma unroll
+        for (int j = 0; j < XPW; ++j) {
+            const int m0 = r0 + step * rstep + (wave + NW * j) * XRPI;
+#pragma unroll
+            for (int r = 0; r < XRPI / 4; ++r) t[j][r] = SF_SCALAR_PTR(i32x8, p.rowtab + m0)[r];
+        }
+#pragma unroll
+        for (int j = 0; j < XPW; ++j) {
+            const int m0 = r0 + step * rstep + (wave + NW * j) * XRPI;
+            int pos = 0;
+            uint32_t mk = 0u;
+#pragma unroll
+            for (int r = 0; r < XRPI; ++r)
+                if (xsel[j] == r) { pos = t[j][r / 4][2 * (r % 4)]; mk = (uint32_t)t[j][r / 4][2 * (r % 4) + 1]; }
+            epos[j] = pos;
+            emk[j] = (m0 + xsel[j] < r1) ? mk : 0u;
+        }
+    };
+    auto issue = [&](int step, int buf, const int (&epos)[XPW], const uint32_t (&emk)[XPW]) {
+        f16* Ys = smem + buf * STAGE;
+        f16* Xs = Ys + Y_ELEMS;
+#pragma unroll
+        for (int j = 0; j < YPW; ++j) {
+            const int m = r0 + step * rstep + yrow[j];
+            const f16* g = (m < r1 && yco[j] < p.Co) ? p.dy + (int64_t)m * p.ldy + yco[j] : zline;
+            SF_GLOBAL_LOAD_LDS16_ASM(g, Ys + (wave + NW * j) * 512);
+        }
+#pragma unroll
+        for (int j = 0; j < XPW; ++j) {
+            const bool ok = (emk[j] & xbit[j]) != 0u;
+            const f16* g = ok ? p.x + ((int64_t)epos[j] * p.ldx + xcol[j]) : zline;
+            SF_GLOBAL_LOAD_LDS16_ASM(g, Xs + (wave + NW * j) * 512);
+        }
+    };
+
+    f32x4 acc[TMC][TNK];
+#pragma unroll
+    for (int i = 0; i < TMC; ++i)
+#pragma unroll
+        for (int j = 0; j < TNK; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int pl = lane & 15, g4 = lane >> 4;
+    auto compute = [&](int buf) {
+        const f16* Ys = smem + buf * STAGE;
+        const f16* Xs = Ys + Y_ELEMS;
+        f16x8 af[TMC], bf[TNK];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = wave * 32 + 8 * g4 + 4 * h + (pl >> 2);      // this wave's quarter of the stage
+#pragma unroll
+            for (int i = 0; i < TMC; ++i) {
+                const f16x4 t = as_f16x4(SF_LDS_TR16(Ys + w2t_frag_off<BMW>(m, i) + 4 * (pl & 3)));
+                af[i][4 * h + 0] = t[0]; af[i][4 * h + 1] = t[1]; af[i][4 * h + 2] = t[2]; af[i][4 * h + 3] = t[3];
+            }
+#pragma unroll
+            for (int j = 0; j < TNK; ++j) {
+                const f16x4 t = as_f16x4(SF_LDS_TR16(Xs + w2t_frag_off<BKW>(m, j) + 4 * (pl & 3)));
+                bf[j][4 * h + 0] = t[0]; bf[j][4 * h + 1] = t[1]; bf[j][4 * h + 2] = t[2]; bf[j][4 * h + 3] = t[3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TMC; ++i)
+#pragma unroll
+            for (int j = 0; j < TNK; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+
+    {
+        int epos[XPW];
+        uint32_t emk[XPW];
+        int issued = 0;
+        for (; issued < NST - 1 && issued < nsteps; ++issued) { tab_rows(issued, epos, emk); issue(issued, issued, epos, emk); }
+        if (issued < nsteps) tab_rows(issued, epos, emk);
+        int cur = 0, nxt = NST - 1;
+        for (int ks = 0; ks < nsteps; ++ks) {
+            // stages ks .. ks + NST - 2 are in flight (fewer at the tail): stage ks must have landed
+            if (NST > 2 && ks + NST - 2 < nsteps) SF_WAIT_VMEM_N((NST - 2) * COPIES);
+            else SF_WAIT_VMEM();
+            SF_BARRIER_KEEP_VMEM();
+            if (issued < nsteps) {
+                issue(issued, nxt, epos, emk);
+                ++issued;
+                if (issued < nsteps) tab_rows(issued, epos, emk);
+            }
+            compute(cur);
+            cur = cur == NST - 1 ? 0 : cur + 1;
+            nxt = nxt == NST - 1 ? 0 : nxt + 1;
+        }
+    }
+
+    // ---- sum the four waves' partial tiles through LDS, store the split's slab (plain stores; zeros when it had no rows)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TMC; ++i)
+#pragma unroll
+        for (int j = 0; j < TNK; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((wave * TMC + i) * TNK + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+    __syncthreads();
+    float* slab = p.ws + (int64_t)bz * p.Co_pad * p.Kpad;
+    constexpr int TILE_ELEMS = TMC * TNK * 256;
+    for (int e = tid; e < TILE_ELEMS; e += 256) {
+        const float v = (red[e] + red[TILE_ELEMS + e]) + (red[2 * TILE_ELEMS + e] + red[3 * TILE_ELEMS + e]);
+        const int ln = e & 63, r = (e >> 6) & 3, t = e >> 8;
+        const int i = t / TNK, j = t - i * TNK;
+        const int co = i * 16 + 4 * (ln >> 4) + r;
+        const int kcol = k0 + j * 16 + (ln & 15);
+        slab[(int64_t)co * p.Kpad + kcol] = v;
     }
 }

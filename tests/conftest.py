@@ -16,6 +16,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X GPU")
+    config.addinivalue_line("markers", "slow: minute-long host-simulator twin of a test that also runs on the GPU (-m gpu); "
+                                       "skipped unless SF_RUN_SLOW=1 or selected with -m slow")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("SF_RUN_SLOW") or "slow" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="slow host-simulator twin of a -m gpu test (SF_RUN_SLOW=1 runs it)")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 def _use_library(path):

@@ -318,6 +318,7 @@ inline void hipsim_global_load_lds16(const void* gptr, void* lds_base) {
     memcpy(base + 16 * l, gptr, 16);
 }
 #define SF_GLOBAL_LOAD_LDS16(g, l) hipsim_global_load_lds16((const void*)(g), (void*)(l))
+#define SF_GLOBAL_LOAD_LDS16_ASM(g, l) hipsim_global_load_lds16((const void*)(g), (void*)(l))
 #define SF_WAIT_VMEM() ((void)0)
 #define SF_WAIT_VMEM_N(N) ((void)0)
 #define SF_BARRIER_KEEP_VMEM() __syncthreads()

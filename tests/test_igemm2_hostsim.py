@@ -133,3 +133,37 @@ def test_wgrad2_row_table_is_built_once_per_geometry(sim, force_w2):
         kc.cl_to_host(kc.host_to_cl(torch.randn((1, 64, 2, 9, 9), generator=torch.Generator().manual_seed(6)), sim)).float(),
         padding=(0, 1, 1))
     assert float((outs[0] - ref).abs().max() / ref.abs().max()) < 2e-3
+
+
+# ---- thin weight gradient (sf_wgrad2t_kernel: <= 32 output channels, waves split the positions of a stage)
+@pytest.fixture()
+def force_w2t(monkeypatch, force_w2):
+    monkeypatch.setenv("SF_WGRAD2T", "1")
+    monkeypatch.setenv("SF_WGRAD2T_MINROWS", "1")
+    monkeypatch.setenv("SF_WGRAD2T_BLOCKS", "5")
+
+
+WGRAD2T_CASES = [
+    ((2, 8, 3, 10, 10), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),      # Fast res2 b: BMW 16, K 72 in one 128 tile, 600 rows
+    ((1, 32, 6, 8, 8), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),       # Fast res2 a: temporal taps, K 96
+    ((2, 8, 2, 9, 9), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),       # Fast res2 c: BMW 32, K 8 -> 32-wide tile, 3 stages
+    ((1, 16, 2, 12, 12), 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),    # BMW 16, K 16 -> 32-wide tile
+    ((1, 64, 4, 6, 6), 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),      # K 192: two 128-wide k tiles
+    ((1, 16, 2, 11, 11), 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),    # stride 2, Co 24 (BMW 32, ragged), K 144
+    ((1, 24, 5, 7, 7), 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),      # 27 taps x 24 channels: taps straddle chunks and tiles
+    ((3, 8, 1, 7, 7), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),        # 147 rows: splits of one ragged stage
+]
+
+
+@pytest.mark.parametrize("case", WGRAD2T_CASES)
+def test_wgrad2_thin(sim, force_w2t, case):
+    kc.check_conv_wgrad(sim, *case)
+
+
+def test_wgrad2_thin_is_taken(sim, force_w2t):
+    """The thin plan must actually be the one that runs (row-table bytes > 0 for a 16-channel layer)."""
+    from ctypes import byref
+    from slowfast_amd import ops
+    from slowfast_amd.lib import get_lib
+    geom = ops.ConvGeom((2, 8, 3, 10, 10), 8, (1, 3, 3), 1, (0, 1, 1))
+    assert get_lib().call("sf_conv_wgrad_rowtab_bytes", byref(geom.desc(8, 8))) > 0

@@ -38,6 +38,23 @@ IGEMM2_CASES = [
 ]
 
 
+# thin weight gradients (sf_wgrad2t_kernel: <= 32 output channels) at Fast-pathway sizes: hundreds of 128-row stages per
+# workgroup, every tile / stage-count combination of the kernel
+WGRAD2T_GPU_CASES = [
+    ((4, 8, 16, 56, 56), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),        # res2 b: 200k rows, BMW 16 x BKW 128 (K 72)
+    ((4, 32, 16, 56, 56), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),       # res2 a: K 96
+    ((4, 8, 16, 56, 56), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),       # res2 c: BMW 32 x BKW 32, three stages
+    ((4, 16, 16, 28, 28), 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),      # res3 b first block: stride 2, K 144 (two k tiles)
+    ((4, 128, 16, 14, 14), 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),     # res4 a: BMW 32 x BKW 128, K 384
+    ((8, 16, 8, 28, 28), 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),       # BMW 16 x BKW 32
+]
+
+
+@pytest.mark.parametrize("case", WGRAD2T_GPU_CASES)
+def test_wgrad2_thin(gpu, case):
+    kc.check_conv_wgrad(gpu, *case)
+
+
 @pytest.mark.parametrize("case", IGEMM2_CASES)
 def test_igemm2(gpu, case):
     kc.check_conv_fwd(gpu, *case)
@@ -56,10 +73,12 @@ def test_igemm2_small_shapes_forced(gpu):
             "kc.check_conv_dgrad(d,(1,32,9,4,4),64,(7,1,1),(4,1,1),(3,0,0),resid=True);"
             "from tests.test_igemm2_hostsim import WGRAD2_CASES;"
             "[ kc.check_conv_wgrad(d,*c) for c in WGRAD2_CASES ];"
+            "from tests.test_igemm2_hostsim import WGRAD2T_CASES;"
+            "[ kc.check_conv_wgrad(d,*c) for c in WGRAD2T_CASES ];"
             "kc.check_conv_dgrad(d,(1,64,2,9,9),64,(1,3,3),(1,1,1),(0,1,1),resid=True);"
             "kc.check_conv_fwd_fused(d,(1,64,2,9,9),72,(1,3,3),(1,1,1),(0,1,1),resid=True,relu=True); print('ok')")
     env = dict(os.environ, SF_IGEMM2_MINK="32", SF_IGEMM2_MINROWS="1", SF_WGRAD2_MINK="32", SF_WGRAD2_MINROWS="1",
-               SF_WGRAD2_BLOCKS="6")
+               SF_WGRAD2_BLOCKS="6", SF_WGRAD2T_MINROWS="1", SF_WGRAD2T_BLOCKS="5")
     env.pop("SFAMD_LIBRARY", None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)

@@ -73,6 +73,7 @@ def test_x3d_bn_lin5_matches_oracle(sim):
                     tol_stats=5e-3)
 
 
+@pytest.mark.slow
 def test_nonlocal_engine_matches_oracle(sim):
     """SlowFast with Nonlocal blocks (dot-product affinity, (2,2,2) max-pool of the phi/g input) on res3/res4."""
     mc.check_engine("slowfast_nln_tiny", sim, tol_logits=2e-2, tol_loss=5e-3, tol_gnorm=2e-2, tol_param=1.0, tol_global=0.5,
@@ -103,6 +104,7 @@ def test_packed_uint8_input_equals_float_input(sim):
     assert torch.equal(a, b)
 
 
+@pytest.mark.slow
 def test_nonlocal_group_folding_matches_oracle(sim):
     """NONLOCAL.GROUP 2: the temporal fold around the Nonlocal block is a view of the channels-last rows."""
     rep = {}
@@ -113,6 +115,7 @@ def test_nonlocal_group_folding_matches_oracle(sim):
         print(rep)
 
 
+@pytest.mark.slow
 def test_sub_batchnorm_matches_reference(sim):
     """BN.NORM_TYPE sub_batchnorm, NUM_SPLITS 2 (multigrid training): the engine's sub-batch passes (batchnorm.run_in_splits)
     vs the unmodified reference's SubBatchNorm3d -- logits, loss, every parameter gradient and the per-split running

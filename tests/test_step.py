@@ -209,7 +209,7 @@ def _run_model(device, name, segmented, use_graph, steps=2):
     return out
 
 
-@pytest.mark.parametrize("name", ["slowfast_tiny", "mvit_tiny"])
+@pytest.mark.parametrize("name", [pytest.param("slowfast_tiny", marks=pytest.mark.slow), "mvit_tiny"])
 def test_segmented_backward_equals_unsegmented(sim, name):
     """Backward run stage by stage across engine.cut() boundaries == one backward pass: same losses, same parameters."""
     l0, p0, n0, _ = _run_model(sim, name, segmented=False, use_graph=False)
