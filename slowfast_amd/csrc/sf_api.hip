@@ -5,6 +5,7 @@
 #include "sf_igemm.h"
 #include "sf_igemm2.h"
 #include "sf_wgrad2.h"
+#include "sf_igemm2t.h"
 #include "sf_pool.h"
 #include "sf_dwconv.h"
 #include "sf_tokens.h"
@@ -670,6 +671,140 @@ extern "C" int sf_conv_wgrad_rowtab(const sf_conv_desc* d, void* tab, sf_stream_
     REQUIRE(plan_wgrad2(d).ok, "sf_conv_wgrad_rowtab: this geometry does not take the row-table kernel (sf_conv_wgrad_rowtab_bytes == 0)");
     launch_rowtab(d, tab, (hipStream_t)stream);
     return check_launch("wgrad_rowtab");
+}
+
+// ---- thin layers (sf_igemm2t.h): <= 32 output columns, contraction <= 128, streamed by independent waves -------------------
+// direction 0: forward (rows = output positions, operand x, columns Co); 1: data gradient (rows = input positions, operand dy,
+// columns Ci; stride 1 only).  SF_IGEMM2T=1 enables (see plan_thin), SF_IGEMM2T_MINROWS / SF_IGEMM2T_BLOCKS are A/B knobs.
+struct ThinPlan {
+    bool ok;
+    int BN, KP, blocks, nstages, Ktot;
+    int64_t M;
+    size_t tab_bytes;
+};
+static ThinPlan plan_thin(const sf_conv_desc* d, int dgrad) {
+    ThinPlan t;
+    memset(&t, 0, sizeof(t));
+    const char* e;
+    // OPT-IN (SF_IGEMM2T=1): parity-green on MI355X, but measured slower than sf_igemm_kernel's 128 x 16 tiles on the pointwise and
+    // temporal Fast-pathway layers (fwd 78 -> 102 us, dgrad 37 -> 63 us) and only 5-12 % faster on the 1x3x3 ones; -0.5 % on the
+    // SlowFast step (profiles/r2_v27_thin_fwd_ab.txt).  One wave per 32-position slice is too long an instruction stream per byte.
+    if (!((e = getenv("SF_IGEMM2T")) && atoi(e) != 0)) return t;
+    const int taps = d->kT * d->kH * d->kW;
+    const int N = dgrad ? d->Ci : d->Co, C = dgrad ? d->Co : d->Ci;
+    const int64_t M = dgrad ? (int64_t)d->N * d->Ti * d->Hi * d->Wi : (int64_t)d->N * d->To * d->Ho * d->Wo;
+    const int minrows = (e = getenv("SF_IGEMM2T_MINROWS")) ? atoi(e) : 16384;
+    if (N > 32 || N % 8 || C % 8 || taps * C > 128 || taps > SF_I2_MAXTAPS || M < minrows || M >= (1ll << 31) - 256) return t;
+    if ((d->kT - 1) * d->dT > 127 || (d->kH - 1) * d->dH > 127 || (d->kW - 1) * d->dW > 127) return t;
+    if (dgrad && (d->sT != 1 || d->sH != 1 || d->sW != 1)) return t;
+    if (!dgrad && plan_stem(d).ok) return t;
+    t.M = M;
+    t.Ktot = taps * C;
+    t.BN = N <= 16 ? 16 : 32;
+    t.KP = t.Ktot <= 32 ? 32 : 128;
+    t.nstages = (int)cdiv(M, 128);
+    // one resident round: 2 workgroups per CU with 128-wide slices (2 x 8 KB per wave), 4 with 32-wide ones
+    int target = (e = getenv("SF_IGEMM2T_BLOCKS")) ? atoi(e) : (t.KP == 128 ? 512 : 1024);
+    t.blocks = target < t.nstages ? target : t.nstages;
+    t.tab_bytes = ((size_t)M * 8 + 255) / 256 * 256 + 1280;
+    t.ok = true;
+    return t;
+}
+
+static void launch_rowtab_dgrad(const sf_conv_desc* d, void* tab, hipStream_t s) {
+    // the data gradient as a stride-1 convolution of dy: position i reads dy[i + pad - tap * dil]
+    RowtabParams t;
+    memset(&t, 0, sizeof(t));
+    t.tab = (i32x2*)tab;
+    t.M = d->N * d->Ti * d->Hi * d->Wi;
+    t.fdW = make_fastdiv(d->Wi); t.fdH = make_fastdiv(d->Hi); t.fdT = make_fastdiv(d->Ti);
+    t.sT = d->To; t.sH = d->Ho; t.sW = d->Wo;
+    t.strT = t.strH = t.strW = 1;
+    t.padT = (d->kT - 1) * d->dT - d->pT; t.padH = (d->kH - 1) * d->dH - d->pH; t.padW = (d->kW - 1) * d->dW - d->pW;
+    t.ntaps = d->kT * d->kH * d->kW;
+    int ti = 0;
+    for (int kt = 0; kt < d->kT; ++kt)
+        for (int kh = 0; kh < d->kH; ++kh)
+            for (int kw = 0; kw < d->kW; ++kw, ++ti) {
+                t.dt[ti] = (int8_t)((d->kT - 1 - kt) * d->dT); t.dh[ti] = (int8_t)((d->kH - 1 - kh) * d->dH);
+                t.dw[ti] = (int8_t)((d->kW - 1 - kw) * d->dW);
+            }
+    hipLaunchKernelGGL(sf_wgrad2_rowtab_kernel, dim3(cdiv(t.M, SF_THREADS)), dim3(SF_THREADS), 0, s, t);
+}
+
+extern "C" int64_t sf_conv_thin_rowtab_bytes(const sf_conv_desc* d, int dgrad) {
+    if (check_desc(d)) return -1;
+    const ThinPlan t = plan_thin(d, dgrad);
+    return t.ok ? (int64_t)t.tab_bytes : 0;
+}
+
+extern "C" int sf_conv_thin_blocks(const sf_conv_desc* d, int dgrad) {
+    if (check_desc(d)) return -1;
+    const ThinPlan t = plan_thin(d, dgrad);
+    return t.ok ? t.blocks : 0;
+}
+
+extern "C" int sf_conv_thin_rowtab(const sf_conv_desc* d, int dgrad, void* tab, sf_stream_t stream) {
+    if (check_desc(d)) return -1;
+    REQUIRE(tab && (uintptr_t)tab % 32 == 0, "sf_conv_thin_rowtab: tab must be a 32-byte aligned device pointer");
+    REQUIRE(plan_thin(d, dgrad).ok, "sf_conv_thin_rowtab: not a thin layer (sf_conv_thin_rowtab_bytes == 0)");
+    if (dgrad) launch_rowtab_dgrad(d, tab, (hipStream_t)stream);
+    else launch_rowtab(d, tab, (hipStream_t)stream);
+    return check_launch("thin_rowtab");
+}
+
+static int launch_thin(const ThinPlan& t, Igemm2tParams& q, hipStream_t s) {
+    const dim3 grid(t.blocks), block(256);
+    if (t.BN == 16 && t.KP == 128) hipLaunchKernelGGL((sf_igemm2t_kernel<16, 128, 2>), grid, block, 0, s, q);
+    else if (t.BN == 32 && t.KP == 128) hipLaunchKernelGGL((sf_igemm2t_kernel<32, 128, 2>), grid, block, 0, s, q);
+    else if (t.BN == 16) hipLaunchKernelGGL((sf_igemm2t_kernel<16, 32, 3>), grid, block, 0, s, q);
+    else hipLaunchKernelGGL((sf_igemm2t_kernel<32, 32, 3>), grid, block, 0, s, q);
+    return check_launch("igemm2t");
+}
+
+extern "C" int sf_conv_fwd_thin(const sf_conv_desc* d, const void* x, const void* wf, const float* bias, void* y,
+                                float* stat_part, const void* rowtab, sf_stream_t stream) {
+    if (check_desc(d)) return -1;
+    const ThinPlan t = plan_thin(d, 0);
+    REQUIRE(t.ok, "sf_conv_fwd_thin: not a thin layer");
+    REQUIRE(x && wf && y && rowtab, "sf_conv_fwd_thin: null pointer");
+    REQUIRE(((uintptr_t)x | (uintptr_t)wf | (uintptr_t)y) % 16 == 0 && (uintptr_t)rowtab % 32 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0,
+            "sf_conv_fwd_thin: operands must be 16-byte aligned (row table: 32)");
+    Igemm2tParams q;
+    memset(&q, 0, sizeof(q));
+    q.src = (const f16*)x; q.ld = d->ldx; q.C = d->Ci; q.M = (int)t.M; q.Ktot = t.Ktot; q.rowtab = (const i32x2*)rowtab;
+    int ti = 0;
+    for (int kt = 0; kt < d->kT; ++kt)
+        for (int kh = 0; kh < d->kH; ++kh)
+            for (int kw = 0; kw < d->kW; ++kw, ++ti) q.dlin[ti] = (kt * d->dT * d->Hi + kh * d->dH) * d->Wi + kw * d->dW;
+    int32_t ldf, ldd;
+    sf_conv_weight_ld(d, &ldf, &ldd);
+    q.wmat = (const f16*)wf; q.ldw = ldf; q.Nout = d->Co;
+    q.y = (f16*)y; q.ldy = d->ldy; q.bias = bias; q.stat_part = stat_part; q.nstages = t.nstages;
+    return launch_thin(t, q, (hipStream_t)stream);
+}
+
+extern "C" int sf_conv_dgrad_thin(const sf_conv_desc* d, const void* dy, const void* wd, void* dx, const void* rowtab,
+                                  sf_stream_t stream) {
+    if (check_desc(d)) return -1;
+    const ThinPlan t = plan_thin(d, 1);
+    REQUIRE(t.ok, "sf_conv_dgrad_thin: not a thin layer");
+    REQUIRE(dy && wd && dx && rowtab, "sf_conv_dgrad_thin: null pointer");
+    REQUIRE(((uintptr_t)dy | (uintptr_t)wd | (uintptr_t)dx) % 16 == 0 && (uintptr_t)rowtab % 32 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0,
+            "sf_conv_dgrad_thin: operands must be 16-byte aligned (row table: 32)");
+    Igemm2tParams q;
+    memset(&q, 0, sizeof(q));
+    q.src = (const f16*)dy; q.ld = d->ldy; q.C = d->Co; q.M = (int)t.M; q.Ktot = t.Ktot; q.rowtab = (const i32x2*)rowtab;
+    int ti = 0;
+    for (int kt = 0; kt < d->kT; ++kt)
+        for (int kh = 0; kh < d->kH; ++kh)
+            for (int kw = 0; kw < d->kW; ++kw, ++ti)
+                q.dlin[ti] = ((d->kT - 1 - kt) * d->dT * d->Ho + (d->kH - 1 - kh) * d->dH) * d->Wo + (d->kW - 1 - kw) * d->dW;
+    int32_t ldf, ldd;
+    sf_conv_weight_ld(d, &ldf, &ldd);
+    q.wmat = (const f16*)wd; q.ldw = ldd; q.Nout = d->Ci;
+    q.y = (f16*)dx; q.ldy = d->ldx; q.nstages = t.nstages;
+    return launch_thin(t, q, (hipStream_t)stream);
 }
 
 extern "C" int64_t sf_conv_wgrad_workspace(const sf_conv_desc* d) {

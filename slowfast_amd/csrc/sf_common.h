@@ -68,6 +68,16 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
     } while (0)
 #endif
 #endif
+// LDS hand-over between the lanes of ONE wave (ds_write by some lanes, ds_read of the same bytes by others): the hardware runs
+// a wave's LDS instructions in order, so only the compiler must be kept from reordering them; the host simulator, whose lanes
+// are fibers, needs a real rendezvous here
+#ifndef SF_WAVE_LDS_SYNC
+#define SF_WAVE_LDS_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+// make hipcc treat a (vector-register) value as read and rewritten here: loads that produced it are waited for at this point
+#ifndef SF_CONSUME_V
+#define SF_CONSUME_V(x) asm volatile("" : "+v"(x))
+#endif
 // wait until at most N (compile-time) of this wave's vector-memory operations are outstanding: retires everything but
 // the newest N, i.e. a whole copy stage while the next one stays in flight
 #ifndef SF_WAIT_VMEM_N

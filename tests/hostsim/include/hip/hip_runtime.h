@@ -319,8 +319,12 @@ inline void hipsim_global_load_lds16(const void* gptr, void* lds_base) {
 }
 #define SF_GLOBAL_LOAD_LDS16(g, l) hipsim_global_load_lds16((const void*)(g), (void*)(l))
 #define SF_GLOBAL_LOAD_LDS16_ASM(g, l) hipsim_global_load_lds16((const void*)(g), (void*)(l))
-#define SF_WAIT_VMEM() ((void)0)
-#define SF_WAIT_VMEM_N(N) ((void)0)
+// a wave's own vmcnt wait makes its LDS-DMA data visible to all of ITS lanes (no workgroup barrier needed for a wave that reads
+// only what it copied itself): the emulated copies above finish with a per-lane memcpy, so the wait is a wave rendezvous here
+#define SF_WAIT_VMEM() hipsim::wave_sync()
+#define SF_CONSUME_V(x) ((void)0)
+#define SF_WAVE_LDS_SYNC() hipsim::wave_sync()
+#define SF_WAIT_VMEM_N(N) hipsim::wave_sync()
 #define SF_BARRIER_KEEP_VMEM() __syncthreads()
 #define SF_SCALAR_PTR(T, p) ((const T*)(p))
 

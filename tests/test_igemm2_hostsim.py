@@ -167,3 +167,43 @@ def test_wgrad2_thin_is_taken(sim, force_w2t):
     from slowfast_amd.lib import get_lib
     geom = ops.ConvGeom((2, 8, 3, 10, 10), 8, (1, 3, 3), 1, (0, 1, 1))
     assert get_lib().call("sf_conv_wgrad_rowtab_bytes", byref(geom.desc(8, 8))) > 0
+
+
+# ---- thin forward / data gradient (sf_igemm2t.h: <= 32 output columns, K <= 128, independent waves, weights in registers)
+@pytest.fixture()
+def force_thin(monkeypatch):
+    monkeypatch.setenv("SF_IGEMM2T", "1")
+    monkeypatch.setenv("SF_IGEMM2T_MINROWS", "1")
+    monkeypatch.setenv("SF_IGEMM2T_BLOCKS", "3")      # several stages per workgroup even on tiny shapes
+
+
+# (in_shape, Co, kernel, stride, pad, dilation): forward is thin when Co <= 32 and taps*Ci <= 128, the data gradient when
+# Ci <= 32, taps*Co <= 128 and the stride is 1
+THIN_CASES = [
+    ((2, 8, 3, 10, 10), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),      # Fast res2 b: BN 16, K 72 (128-wide slices), 600 rows
+    ((1, 32, 6, 8, 8), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),       # Fast res2 a: fwd K 96 / dgrad K 24 (32-wide), BN 32
+    ((2, 8, 2, 9, 9), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),       # Fast res2 c: fwd BN 32 K 8 / dgrad BN 16 K 32
+    ((1, 16, 2, 12, 12), 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),    # K 16, 288 rows: ragged last slice
+    ((1, 8, 2, 11, 11), 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),     # stride 2: forward only (Co 24: BN 32, ragged columns)
+    ((3, 8, 1, 7, 7), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),        # 147 rows: two stages, mostly padding taps
+    ((1, 8, 4, 6, 6), 16, (3, 3, 1), (1, 1, 1), (1, 1, 0), (1, 1, 1)),       # 9 taps over T and H
+    ((1, 16, 2, 9, 9), 8, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),       # dilation 2; fwd K 144 is NOT thin, dgrad K 72 is
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_igemm2_thin(sim, force_thin, case):
+    kc.check_conv_fwd(sim, *case)
+    kc.check_conv_dgrad(sim, *case)
+
+
+def test_igemm2_thin_is_taken(sim, force_thin):
+    from ctypes import byref
+    from slowfast_amd import ops
+    from slowfast_amd.lib import get_lib
+    geom = ops.ConvGeom((2, 8, 3, 10, 10), 8, (1, 3, 3), 1, (0, 1, 1))
+    d = geom.desc(8, 8)
+    assert get_lib().call("sf_conv_thin_rowtab_bytes", byref(d), 0) > 0 and get_lib().call("sf_conv_thin_rowtab_bytes", byref(d), 1) > 0
+    assert get_lib().call("sf_conv_thin_blocks", byref(d), 0) == 3
+    geom2 = ops.ConvGeom((1, 64, 2, 9, 9), 64, (1, 3, 3), 1, (0, 1, 1))
+    assert get_lib().call("sf_conv_thin_rowtab_bytes", byref(geom2.desc(64, 64)), 0) == 0

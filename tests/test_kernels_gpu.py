@@ -55,6 +55,25 @@ def test_wgrad2_thin(gpu, case):
     kc.check_conv_wgrad(gpu, *case)
 
 
+# thin forward / data gradient (sf_igemm2t.h: independent waves streaming 32-position slices, counted vmcnt over copies AND
+# stores): Fast-pathway sizes, i.e. dozens of slices per wave -- what a pipelining mistake needs to show
+THIN_GPU_CASES = [
+    ((4, 8, 16, 56, 56), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),        # res2 b: both directions 128-wide, BN 16
+    ((4, 32, 16, 56, 56), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),       # res2 a: fwd K 96 BN 16 / dgrad K 24 BN 32 (32-wide)
+    ((4, 8, 16, 56, 56), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),       # res2 c: fwd K 8 BN 32 / dgrad K 32 BN 16
+    ((4, 16, 16, 28, 28), 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),      # K 16
+    ((3, 8, 7, 30, 30), 24, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),        # 18900 rows (ragged last stage), Co 24
+    ((4, 8, 16, 57, 57), 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),       # stride 2: thin forward, general data gradient
+]
+
+
+@pytest.mark.parametrize("case", THIN_GPU_CASES)
+def test_igemm2_thin(gpu, case, monkeypatch):
+    monkeypatch.setenv("SF_IGEMM2T", "1")       # opt-in kernel (slower than the general one on most thin layers, see sf_api.hip)
+    kc.check_conv_fwd(gpu, *case)
+    kc.check_conv_dgrad(gpu, *case)
+
+
 @pytest.mark.parametrize("case", IGEMM2_CASES)
 def test_igemm2(gpu, case):
     kc.check_conv_fwd(gpu, *case)
@@ -73,12 +92,14 @@ def test_igemm2_small_shapes_forced(gpu):
             "kc.check_conv_dgrad(d,(1,32,9,4,4),64,(7,1,1),(4,1,1),(3,0,0),resid=True);"
             "from tests.test_igemm2_hostsim import WGRAD2_CASES;"
             "[ kc.check_conv_wgrad(d,*c) for c in WGRAD2_CASES ];"
-            "from tests.test_igemm2_hostsim import WGRAD2T_CASES;"
+            "from tests.test_igemm2_hostsim import WGRAD2T_CASES, THIN_CASES;"
             "[ kc.check_conv_wgrad(d,*c) for c in WGRAD2T_CASES ];"
+            "[ (kc.check_conv_fwd(d,*c), kc.check_conv_dgrad(d,*c)) for c in THIN_CASES ];"
             "kc.check_conv_dgrad(d,(1,64,2,9,9),64,(1,3,3),(1,1,1),(0,1,1),resid=True);"
             "kc.check_conv_fwd_fused(d,(1,64,2,9,9),72,(1,3,3),(1,1,1),(0,1,1),resid=True,relu=True); print('ok')")
     env = dict(os.environ, SF_IGEMM2_MINK="32", SF_IGEMM2_MINROWS="1", SF_WGRAD2_MINK="32", SF_WGRAD2_MINROWS="1",
-               SF_WGRAD2_BLOCKS="6", SF_WGRAD2T_MINROWS="1", SF_WGRAD2T_BLOCKS="5")
+               SF_WGRAD2_BLOCKS="6", SF_WGRAD2T_MINROWS="1", SF_WGRAD2T_BLOCKS="5",
+               SF_IGEMM2T="1", SF_IGEMM2T_MINROWS="1", SF_IGEMM2T_BLOCKS="3")
     env.pop("SFAMD_LIBRARY", None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
