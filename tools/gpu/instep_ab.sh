@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 2, visit 26: in-step A/B of dispatch thresholds (cold operands: what a warm microbenchmark cannot show)
-mkdir -p gpurun_out/v26
+# in-step A/B of dispatch knobs through bench.py (cold operands: what a warm microbenchmark cannot show; visit 26)
+mkdir -p gpurun_out/ab
 export PYTHONPATH=$PWD TMPDIR=/tmp
 B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-secondary"
-run() { timeout 300 env "$@" $B > gpurun_out/v26/$TAG.json 2>/dev/null; echo "$TAG: $(python -c "import json;d=json.loads(open('gpurun_out/v26/$TAG.json').read().strip().splitlines()[-1]);print(d['value'],d['ms_per_step'])")"; }
+run() { timeout 300 env "$@" $B > gpurun_out/ab/$TAG.json 2>/dev/null; echo "$TAG: $(python -c "import json;d=json.loads(open('gpurun_out/ab/$TAG.json').read().strip().splitlines()[-1]);print(d['value'],d['ms_per_step'])")"; }
 TAG=base;            run SF_DUMMY=1
 TAG=base2;           run SF_DUMMY=1
 TAG=i2_mink256;      run SF_IGEMM2_MINK=256
