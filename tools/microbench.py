@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--filter", default="")
     ap.add_argument("--no-bn", action="store_true", help="skip the BatchNorm / activation kernels (GEMM variant sweeps)")
+    ap.add_argument("--markers", action="store_true", help="launch a torch.arange kernel before the fwd / dgrad / wgrad phase of "
+                    "every layer and after the last one: phase separators for tools/pmc_per_layer.py under rocprofv3 --pmc")
     ap.add_argument("--md", default="", help="write the per-geometry table (us, GB/s, TFLOP/s, roofline fraction) as markdown")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -126,11 +128,16 @@ def main():
         sc = torch.ones(Ci, device=dev)
         sh = torch.zeros(Ci, device=dev)
         macs = geom.out_rows * Co * (3 * k[0] * 49 if stem else Cw * geom.taps)   # useful MACs
+        mark = (lambda: torch.arange(16, device=dev)) if a.markers else (lambda: None)
+        mark()
         t_f = timeit(lambda: ops.conv_fwd(x, wf, geom, out=y), a.iters)
+        mark()
         t_fa = timeit(lambda: ops.conv_fwd(x, wf, geom, in_affine=(sc, sh, True), out=y), a.iters) if Ci <= 512 and not a.no_bn else float("nan")
         dx = ops.cl_empty(geom.in_shape, dev)
         t_d = timeit(lambda: ops.conv_dgrad(dy, wd, geom, out=dx), a.iters) if "stem" not in name else 0.0
+        mark()
         t_w = timeit(lambda: ops.conv_wgrad(x, dy, geom, dw), a.iters)
+        mark()
         gamma = torch.ones(Co, device=dev); beta = torch.zeros(Co, device=dev)
         rm = torch.zeros(Co, device=dev); rv = torch.ones(Co, device=dev)
         scale, shift, mean, rstd = ops.bn_finalize(part, geom.out_rows, gamma, beta, rm, rv, 0.1, 1e-5)
