@@ -3,14 +3,16 @@
 mkdir -p gpurun_out/ab
 export PYTHONPATH=$PWD TMPDIR=/tmp
 B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-secondary"
-run() { timeout 300 env "$@" $B > gpurun_out/ab/$TAG.json 2>/dev/null; echo "$TAG: $(python -c "import json;d=json.loads(open('gpurun_out/ab/$TAG.json').read().strip().splitlines()[-1]);print(d['value'],d['ms_per_step'])")"; }
-TAG=base;            run SF_DUMMY=1
-TAG=bnblocks512;     run SF_BN_BWD_BLOCKS=512
-TAG=bnblocks2048;    run SF_BN_BWD_BLOCKS=2048
-TAG=fold256;         run SF_FOLD_ABOVE=256
-TAG=fold16384;       run SF_FOLD_ABOVE=16384
-TAG=wgrad_stream;    run SF_WGRAD_STREAM=1
-TAG=w2t_minrows;     run SF_WGRAD2T_MINROWS=4096
-TAG=wgrad_blocks512; run SF_WGRAD_BLOCKS=512
-TAG=wgrad_blocks2048; run SF_WGRAD_BLOCKS=2048
-TAG=base2;           run SF_DUMMY=1
+run() { timeout 300 env "$@" $B $P > gpurun_out/ab/$TAG.json 2>/dev/null; echo "$TAG: $(python -c "import json;d=json.loads(open('gpurun_out/ab/$TAG.json').read().strip().splitlines()[-1]);print(d['value'],d['ms_per_step'])")"; }
+P=""
+TAG=sf_base;      run SF_DUMMY=1
+TAG=sf_gl3;       run SF_IGEMM_GL3=1
+TAG=sf_occ3;      run SF_IGEMM_OCC4=0
+P="--preset MVITv2_S_16x4"
+TAG=mvit_base;    run SF_DUMMY=1
+TAG=mvit_gl3;     run SF_IGEMM_GL3=1
+TAG=mvit_occ3;    run SF_IGEMM_OCC4=0
+P="--preset X3D_M --batch 64"
+TAG=x3d_base;     run SF_DUMMY=1
+TAG=x3d_gl3;      run SF_IGEMM_GL3=1
+TAG=x3d_dwv2;     run SF_DW_FWD_V2=1 SF_DW_DGRAD_V2=1 SF_DW_WGRAD_V2=1
