@@ -99,6 +99,10 @@ def parse():
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU oracle and exit")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of a HIP graph")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="NOT a measurement: run the same launch plumbing (rank spawn, process group, reducer, TrainStep, JSON line) on CPU "
+                         "through the host functional simulator (tests/hostsim) with gloo and a shrunken model -- checks that "
+                         "`bench.py --gpus N` works without a GPU node")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="torch.optim fused SGD / AdamW + separate unscale / norm / clip passes (round-1 step glue) instead of "
                          "slowfast_amd.optim.FlatOptimizer (one norm pass + one fused update, device-side dynamic loss scale)")
@@ -181,6 +185,12 @@ def cpu_baseline(cfg, clips, threads=0):
                       "pinned bit-for-bit to the unmodified reference by tests/golden -- /root/reference does not exist on the GPU box"}
 
 
+# --dry-run-cpu: SlowFast-R18-like widths on 8 x 32^2 clips (the geometry of tests/golden/slowfast_tiny.json)
+DRY_RUN_OPTS = ["NUM_GPUS", 0, "MODEL.DROPOUT_RATE", 0.0, "MODEL.NUM_CLASSES", 10, "DATA.TRAIN_CROP_SIZE", 32,
+                "RESNET.WIDTH_PER_GROUP", 16, "RESNET.DEPTH", 18, "DATA.NUM_FRAMES", 8, "SLOWFAST.BETA_INV", 2,
+                "RESNET.NUM_BLOCK_TEMP_KERNEL", "[[2, 2], [2, 2], [2, 2], [2, 2]]"]
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a torchrun environment: re-execute under torch.distributed.run, one rank per
     GPU on 127.0.0.1 (the contract's own launch line), and pass its exit code through."""
@@ -203,7 +213,8 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
     from slowfast_amd.data_parallel import GradReducer
     from slowfast_amd.profiler import KernelProfiler
 
-    cfg = sa.get_preset(preset, ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", batch * world] + PRESET_OPTS.get(preset, []))
+    cfg = sa.get_preset(preset, ["NUM_GPUS", 1, "TRAIN.BATCH_SIZE", batch * world] + PRESET_OPTS.get(preset, [])
+                        + (DRY_RUN_OPTS if a.dry_run_cpu else []))
     torch.manual_seed(cfg.RNG_SEED)
     model = sa.build_model(cfg, gpu_id=local).train()
     if world > 1:                        # replicas start identical (DDP's initial broadcast)
@@ -273,10 +284,12 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
         return loss
 
     def fence():
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     warmup = max(warmup, 0 if a.no_graph else 2)             # graph mode: 1 eager step + the capturing step
     for _ in range(warmup):
@@ -334,7 +347,7 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
                       f"per-GPU batch {batch}",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp16", "data": "synthetic",
+            "dtype": "fp16", "data": "DRY RUN on the CPU host simulator with a shrunken model -- not a measurement" if a.dry_run_cpu else "synthetic",
             "config": {"workload": f"{preset}: forward + {cfg.MODEL.LOSS_FUNC} loss + backward + {cfg.SOLVER.OPTIMIZING_METHOD} step, "
                                    f"inputs resident in HBM, "
                                    f"per-GPU batch {batch}", "global_batch": batch * world,
@@ -375,19 +388,29 @@ def main():
                             + PRESET_OPTS.get(a.preset, []))
         print(json.dumps(cpu_baseline(cfg, a.cpu_baseline_clips, a.cpu_baseline_threads)), flush=True)
         return
+    if a.dry_run_cpu and "SFAMD_LIBRARY" not in os.environ:
+        from slowfast_amd import build_ext
+        os.environ["SFAMD_LIBRARY"] = build_ext.build_hostsim()      # inherited by the spawned ranks
+        os.environ.setdefault("SF_SIM_THREADS", "2")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
-
     from slowfast_amd.lib import get_lib
-    assert get_lib().backend == "gfx950", "bench.py measures the HIP library only"
+    if a.dry_run_cpu:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+        assert get_lib().backend == "hostsim", "--dry-run-cpu runs on the host simulator (SFAMD_LIBRARY)"
+        a.no_graph, a.no_secondary, a.no_kernel_profile, a.no_cpu_baseline = True, True, True, True
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:
+            dist.init_process_group(backend="nccl", device_id=dev)
+        assert get_lib().backend == "gfx950", "bench.py measures the HIP library only"
 
     out = run_preset(a, a.preset, a.batch, a.steps, a.warmup, rank, local, world, dev,
                      kernel_profile=not a.no_kernel_profile, cpu_base=(world == 1 and not a.no_cpu_baseline))
