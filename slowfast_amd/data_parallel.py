@@ -64,6 +64,7 @@ class GradReducer:
     # -- per-iteration protocol -------------------------------------------------------------------------
     def zero_grad(self):
         """Clear the flat buffer and (re)attach the gradient views; call before every forward."""
+        engine.GRADS_VIA_AUTOGRAD = False       # this model's gradients are written in place (see wrap_ddp)
         self.flat.zero_()
         for p, v in self._views.items():
             if p.grad is not v:
@@ -104,8 +105,10 @@ class GradReducer:
         s, e, _ = self.buckets[bi]
         view = self.flat[s:e]
         if self.comm_dtype is not None:
-            # divide by world * loss_scale in fp32 BEFORE compressing (torch's fp16_compress_hook order): a loss-scaled
-            # sum over the ranks would leave the fp16 range at |g| ~ 65504 / (world * loss_scale)
+            # divide by the world size in fp32 BEFORE compressing (torch's fp16_compress_hook order), so the SUM over ranks
+            # cannot leave the fp16 range when every rank's value is inside it.  The loss scale is NOT removed here (it is
+            # dynamic and lives on the device): a loss-scaled |g| * S > 65504 overflows to inf in the cast exactly as it does
+            # under torch's hook; FlatOptimizer's inf check then skips the step and backs the scale off.
             low = (view * self._prescale).to(self.comm_dtype)
             h = dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._handles.append((h, view, low))
@@ -190,12 +193,18 @@ def wrap_ddp(model, device=None, find_unused_parameters=False, fp16_allreduce=Fa
     """torch.nn.parallel.DistributedDataParallel around the drop-in model, as slowfast/models/build.py:64-80 wraps the
     reference model.  Switches the engine to autograd-delivered parameter gradients (engine.GRADS_VIA_AUTOGRAD): DDP's
     reducer hooks the parameters' AccumulateGrad nodes, so gradients written straight into ``param.grad`` would never be
-    all-reduced."""
+    all-reduced.  The switch is process-global but FOLLOWS THE MODEL whose iteration is running: the wrapper's forward
+    pre-hook turns it on, GradReducer.zero_grad() (first call of every in-place iteration) turns it off, so a DDP-wrapped
+    model and a GradReducer-driven one can alternate in one process."""
     engine.GRADS_VIA_AUTOGRAD = True
+
+    def _via_autograd(module, args):
+        engine.GRADS_VIA_AUTOGRAD = True
     kw = dict(find_unused_parameters=find_unused_parameters, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
               process_group=process_group)
     if device is not None:
         kw.update(device_ids=[device], output_device=device)
     ddp = torch.nn.parallel.DistributedDataParallel(module=model, **kw)
     ddp.register_comm_hook(state=process_group, hook=fp16_compress_hook if fp16_allreduce else xgmi_allreduce_hook)
+    ddp.register_forward_pre_hook(_via_autograd)
     return ddp

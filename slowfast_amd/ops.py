@@ -297,6 +297,14 @@ def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True, 
 _rowtabs = {}       # (device, direction, spatial geometry) -> row table ({first source position, tap mask} per row)
 
 
+def _capturing(device):
+    """A table first needed while a HIP graph is being captured is allocated from the graph's private pool and only filled
+    when the graph is replayed: such a table is used by the captured launch alone and NOT put into the process-wide cache
+    (a later eager user of the same geometry, or a side stream, would read memory that is unordered with its fill).
+    Geometries met during the eager warm-up iterations (the normal case) are cached as before."""
+    return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+
 def _thin_rowtab(geom, d, device, dgrad):
     """Row table of the thin forward (dgrad=0) / data-gradient (dgrad=1) kernel for this geometry, or None when the layer takes
     the general kernels.  The forward table is the one the weight gradient uses (same geometry, same content)."""
@@ -311,6 +319,8 @@ def _thin_rowtab(geom, d, device, dgrad):
     if key not in _rowtabs:
         tab = torch.empty(nbytes, dtype=torch.uint8, device=device)
         get_lib().call("sf_conv_thin_rowtab", byref(d), dgrad, tab.data_ptr(), _stream(tab))
+        if _capturing(device):
+            return tab                  # lives in the graph's pool, rebuilt by every replay: never shared through the cache
         _rowtabs[key] = tab
     return _rowtabs[key]
 
@@ -320,7 +330,7 @@ def _wgrad_rowtab(geom, d, device):
     """The {first input position, tap mask} table of sf_conv_wgrad's large-K kernel is a function of the geometry alone:
     built once per (device, geometry) -- shared by every layer of that shape -- instead of once per call.  Built on first
     use, i.e. during the eager warm-up iterations of step.TrainStep; a build that happens while a graph is being captured
-    is simply replayed with the graph."""
+    is replayed with the graph and stays private to it (_capturing)."""
     nbytes = getattr(geom, "_rowtab_bytes", None)
     if nbytes is None:
         nbytes = geom._rowtab_bytes = get_lib().call("sf_conv_wgrad_rowtab_bytes", byref(d))
@@ -330,6 +340,8 @@ def _wgrad_rowtab(geom, d, device):
     if key not in _rowtabs:
         tab = torch.empty(nbytes, dtype=torch.uint8, device=device)
         get_lib().call("sf_conv_wgrad_rowtab", byref(d), tab.data_ptr(), _stream(tab))
+        if _capturing(device):
+            return tab                  # see _thin_rowtab
         _rowtabs[key] = tab
     return _rowtabs[key]
 

@@ -41,8 +41,9 @@ class FlatOptimizer:
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
         self.dynamic = bool(dynamic_loss_scale)
         self.growth, self.backoff, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
-        self.clip_norm = float(clip_grad_l2norm) if clip_grad_l2norm else 0.0
+        # tools/train_net.py:154-163: CLIP_GRAD_VAL takes precedence, the L2-norm clip only runs when no value clip is set
         self.clip_val = float(clip_grad_val) if clip_grad_val else 0.0
+        self.clip_norm = float(clip_grad_l2norm) if (clip_grad_l2norm and not self.clip_val) else 0.0
         self.reducer = reducer
         flat_g = reducer.flat
         dev = flat_g.device
@@ -75,6 +76,7 @@ class FlatOptimizer:
         self.nblocks = len(blk_seg)
         self.ctl = torch.zeros(8, dtype=torch.float32, device=dev)
         self.ctl[CTL_SCALE] = float(loss_scale)
+        self.init_loss_scale = float(loss_scale)
         self._part = torch.empty((get_lib().call("sf_flat_blocks", flat_g.numel()), 2), dtype=torch.float32, device=dev)
 
     # -- what the training loop touches ---------------------------------------------------------------------------
@@ -136,19 +138,37 @@ class FlatOptimizer:
 
 
 def construct_optimizer(model, cfg, reducer, loss_scale=1.0, dynamic_loss_scale=None):
-    """FlatOptimizer configured as slowfast/models/optimizer.py:15-140 configures torch's: BatchNorm parameters get
-    BN.WEIGHT_DECAY, 1-D parameters no decay when SOLVER.ZERO_WD_1D_PARAM, the rest SOLVER.WEIGHT_DECAY; SOLVER.OPTIMIZING_METHOD
-    "sgd" (momentum / dampening / nesterov) or "adamw"; clipping from SOLVER.CLIP_GRAD_L2NORM / CLIP_GRAD_VAL; the dynamic
-    loss scale defaults to TRAIN.MIXED_PRECISION (GradScaler's constants)."""
+    """FlatOptimizer configured as slowfast/models/optimizer.py:9-140 configures torch's (the ``LAYER_DECAY == 1.0`` branch,
+    :26-92): BatchNorm parameters get BN.WEIGHT_DECAY; parameters whose dotted name contains an entry of
+    ``model.no_weight_decay()`` (MViT: pos_embed* / rel_pos_* / cls_token under MVIT.ZERO_DECAY_POS_CLS) get no decay; so do
+    1-D parameters and every ``*.bias`` when SOLVER.ZERO_WD_1D_PARAM; the rest SOLVER.WEIGHT_DECAY.
+    SOLVER.OPTIMIZING_METHOD "sgd" (momentum / dampening / nesterov) or "adamw" / "mt_adamw" (SOLVER.BETAS, eps 1e-8);
+    clipping from SOLVER.CLIP_GRAD_L2NORM / CLIP_GRAD_VAL; the dynamic loss scale defaults to TRAIN.MIXED_PRECISION
+    (GradScaler's constants).  Options the fused kernels do not implement raise instead of silently changing the update rule:
+    SOLVER.LAYER_DECAY != 1 (per-layer lr scale, optimizer.py:155-220), SOLVER.LARS_ON, "adam" (L2-coupled decay)."""
+    layer_decay = float(cfg.SOLVER.get("LAYER_DECAY", 1.0))
+    if not 0.0 < layer_decay <= 1.0:
+        raise ValueError("Layer decay should be in (0, 1], but is {}".format(layer_decay))
+    if layer_decay != 1.0:
+        raise NotImplementedError("SOLVER.LAYER_DECAY < 1 (per-layer learning-rate scale) is not built into FlatOptimizer")
+    if cfg.SOLVER.get("LARS_ON", False):
+        raise NotImplementedError("SOLVER.LARS_ON is not built into FlatOptimizer")
+    inner = model.module if hasattr(model, "module") and isinstance(model.module, torch.nn.Module) else model
+    skip = inner.no_weight_decay() if hasattr(inner, "no_weight_decay") else ()
     bn, rest, zero = [], [], []
-    for m in model.modules():
+    seen = set()
+    for name_m, m in inner.named_modules():
         is_bn = isinstance(m, torch.nn.modules.batchnorm._NormBase)
-        for p in m.parameters(recurse=False):
-            if not p.requires_grad:
+        for name_p, p in m.named_parameters(recurse=False):
+            name = "{}.{}".format(name_m, name_p).strip(".")
+            if not p.requires_grad or id(p) in seen:
                 continue
+            seen.add(id(p))
             if is_bn:
                 bn.append(p)
-            elif cfg.SOLVER.ZERO_WD_1D_PARAM and (p.dim() == 1 or p.shape == (1, 1, p.shape[-1])):
+            elif any(k in name for k in skip):
+                zero.append(p)
+            elif cfg.SOLVER.ZERO_WD_1D_PARAM and (p.dim() == 1 or name.endswith(".bias")):
                 zero.append(p)
             else:
                 rest.append(p)
@@ -159,8 +179,11 @@ def construct_optimizer(model, cfg, reducer, loss_scale=1.0, dynamic_loss_scale=
     dyn = bool(cfg.TRAIN.MIXED_PRECISION) if dynamic_loss_scale is None else dynamic_loss_scale
     kw = dict(loss_scale=loss_scale, dynamic_loss_scale=dyn, clip_grad_l2norm=cfg.SOLVER.CLIP_GRAD_L2NORM,
               clip_grad_val=cfg.SOLVER.CLIP_GRAD_VAL)
-    if cfg.SOLVER.OPTIMIZING_METHOD == "adamw":
-        return FlatOptimizer(groups, reducer, method="adamw", betas=(0.9, 0.999), eps=1e-8, **kw)
-    assert cfg.SOLVER.OPTIMIZING_METHOD == "sgd", cfg.SOLVER.OPTIMIZING_METHOD
-    return FlatOptimizer(groups, reducer, method="sgd", momentum=cfg.SOLVER.MOMENTUM, dampening=cfg.SOLVER.DAMPENING,
-                         nesterov=cfg.SOLVER.NESTEROV, **kw)
+    method = cfg.SOLVER.OPTIMIZING_METHOD
+    if method in ("adamw", "mt_adamw"):
+        betas = tuple(cfg.SOLVER.get("BETAS", (0.9, 0.999)))
+        return FlatOptimizer(groups, reducer, method="adamw", betas=betas, eps=1e-8, **kw)
+    if method == "sgd":
+        return FlatOptimizer(groups, reducer, method="sgd", momentum=cfg.SOLVER.MOMENTUM, dampening=cfg.SOLVER.DAMPENING,
+                             nesterov=cfg.SOLVER.NESTEROV, **kw)
+    raise NotImplementedError("Does not support {} optimizer".format(method))

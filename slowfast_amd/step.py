@@ -44,6 +44,21 @@ class TrainStep:
         self._calls = 0
         from .optim import FlatOptimizer
         self._flat = isinstance(optimizer, FlatOptimizer)
+        if self._flat:
+            # the fused update owns unscale / clipping / loss scale (csrc/sf_optim.h): arguments given HERE are forwarded into
+            # it when it has none of its own, and a disagreement is an error -- never silently dropped
+            for name, attr in (("clip_grad_val", "clip_val"), ("clip_grad_l2norm", "clip_norm")):
+                want = float(getattr(self, name) or 0.0)
+                have = float(getattr(optimizer, attr))
+                if want and not have and not (attr == "clip_norm" and optimizer.clip_val):
+                    setattr(optimizer, attr, want)
+                elif want and have and abs(want - have) > 1e-12 * max(want, have):
+                    raise ValueError("TrainStep(%s=%g) disagrees with the FlatOptimizer's %g" % (name, want, have))
+            if optimizer.clip_val:
+                optimizer.clip_norm = 0.0       # tools/train_net.py:154-163: the value clip takes precedence
+            if self.loss_scale != 1.0 and self.loss_scale != optimizer.init_loss_scale:
+                raise ValueError("with a FlatOptimizer the loss scale lives in the optimizer (FlatOptimizer(loss_scale=%g)): "
+                                 "TrainStep(loss_scale=%g) would be ignored" % (optimizer.init_loss_scale, self.loss_scale))
         # backward in per-stage segments (all-reduce of a finished stage overlaps the backward of the earlier ones):
         # default on whenever gradients are actually exchanged
         self.segmented = bool(reducer.collectives) if segmented is None else bool(segmented)

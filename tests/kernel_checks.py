@@ -300,6 +300,48 @@ def check_roi_pool(device, shape=(2, 16, 3, 10, 12), aligned=True, seed=0):
     assert_close("roi d(features)", cl_to_host(xc.grad), xr.grad, 2 * F16_EPS)
 
 
+def check_roi_known_answer(device):
+    """sf_roi_align_max_fwd against detectron2's PUBLISHED ROIAlign vectors (tests/golden/roi_align_detectron2.json:
+    detectron2 tests/layers/test_roi_align.py, arange 5x5 map, box [1, 1, 3, 3], 4x4 output, aligned False / True) -- the
+    pin for the op the reference imports from detectron2 (head_helper.py:11, 88-94).  The kernel fuses the max-pool over the
+    bins, so (a) the 4x4 call must return the table's maximum for +ramp and minus its minimum for -ramp in both modes, and
+    (b) every one of the 32 published bin values is read back through a 1x1 call on the box of that bin (aligned mode, box
+    = the bin's sample cell shifted by +0.5: same single bilinear sample as the published 4x4 call takes for that bin).
+    Also test_empty_box (zero-height box -> zeros)."""
+    import json
+    import os
+    from slowfast_amd.heads import _RoiPoolFn
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "roi_align_detectron2.json")))
+    f = gold["forward_output"]
+    H, W = f["input_hw"]
+    ramp = torch.arange(H * W, dtype=torch.float32).reshape(H, W)
+    x = torch.zeros((1, 8, 1, H, W))
+    x[0, 0, 0], x[0, 1, 0], x[0, 2, 0] = ramp, -ramp, 2.0 * ramp
+    xc = host_to_cl(x, device)
+    box = torch.tensor([f["box"]], dtype=torch.float32)
+    for aligned, key in ((False, "aligned_false"), (True, "aligned_true")):
+        tab = torch.tensor(f[key])
+        out = _RoiPoolFn.apply(xc, box.to(device), f["output_size"][0], f["spatial_scale"], aligned).cpu()
+        assert abs(float(out[0, 0]) - float(tab.max())) < 1e-6, (key, out[0, :3], tab.max())
+        assert abs(float(out[0, 1]) + float(tab.min())) < 1e-6, (key, out[0, :3], tab.min())
+        assert abs(float(out[0, 2]) - 2.0 * float(tab.max())) < 1e-6, (key, out[0, :3])
+        # every published bin through a 1x1 aligned call on that bin's cell
+        x1, y1 = float(f["box"][1]) - (0.5 if aligned else 0.0), float(f["box"][2]) - (0.5 if aligned else 0.0)
+        bw = (f["box"][3] - f["box"][1]) / f["output_size"][1]
+        bh = (f["box"][4] - f["box"][2]) / f["output_size"][0]
+        cells = [[0.0, x1 + j * bw + 0.5, y1 + i * bh + 0.5, x1 + (j + 1) * bw + 0.5, y1 + (i + 1) * bh + 0.5]
+                 for i in range(f["output_size"][0]) for j in range(f["output_size"][1])]
+        out = _RoiPoolFn.apply(xc, torch.tensor(cells).to(device), 1, 1.0, True).cpu()
+        assert_close("published bins " + key, out[:, 0], tab.reshape(-1), 1e-6)
+    e = gold["empty_box"]
+    g = torch.Generator().manual_seed(0)
+    xr = torch.zeros((1, 8, 1, 5, 5))
+    xr[0, :, 0] = torch.rand((8, 5, 5), generator=g).half().float() + 0.5
+    out = _RoiPoolFn.apply(host_to_cl(xr, device), torch.tensor([e["box"]], dtype=torch.float32).to(device),
+                           e["output_size"][0], 1.0, e["aligned"]).cpu()
+    assert float(out.abs().max()) == e["expected_all"], out
+
+
 def check_pack_clip(device, arch="slowfast", reverse=False, seed=0):
     """sf_pack_clip_u8 (uint8 frames -> normalised fp16 W-pair clips per pathway) is bit-exact with the fp16 rounding
     of the reference's tensor_normalize + permute + pack_pathway_output (oracle/data_ref.py)."""

@@ -290,7 +290,8 @@ def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99,
     _record(preset + "@full", device, dict(res, bounds={k: tol for k in ("logits_l2", "loss", "grad_norm")},
                                            yardstick_kind="none (1e-3)"))
     for k in ("logits_l2", "loss", "grad_norm"):
-        assert res[k] <= (tol_logits or tol if k == "logits_l2" else tol), (k, res)
+        bound = (tol_logits or tol) if k == "logits_l2" else tol
+        assert res[k] <= bound, (k, res)
     return res
 
 

@@ -1,0 +1,200 @@
+"""The training-step glue on the HIP build against the reference's own sequence.
+
+What is replaced (tools/train_net.py:150-172 + slowfast/models/optimizer.py:100-140):
+
+    scaler.scale(loss).backward(); scaler.unscale_(optimizer); clip_grad_value_ | clip_grad_norm_ | get_grad_norm_;
+    scaler.step(optimizer); scaler.update()            with optimizer = torch.optim.SGD(nesterov) | AdamW over the
+    BN / non-BN / zero-decay parameter groups of construct_optimizer
+
+Two comparisons per iteration of ``step.TrainStep`` + ``optim.FlatOptimizer`` (three launches of csrc/sf_optim.h):
+
+(A) *optimizer arithmetic, tight*: the gradients the engine produced (a snapshot of the flat buffer taken right before
+    ``FlatOptimizer.step``) are handed -- loss-scaled, exactly as the reference's backward leaves them -- to
+    ``torch.amp.GradScaler`` + ``torch.optim`` on CPU fp32 copies of the same parameters.  Parameters after every step, the
+    skip decision, the scale trajectory and the gradient norm must agree to fp32 round-off: any wrong momentum / Nesterov /
+    weight-decay / bias-correction / clipping term in the HIP kernels fails here, independent of fp16 activation noise.
+(B) *end to end against the oracle*: the fp32 CPU oracle graph (oracle/video_ref.py | mvit_ref.py, pinned to the reference)
+    + the same torch.optim / GradScaler sequence, run for the same iterations from the same state.  Parameters after the
+    last step within ``tol_param`` (relative L2 over all parameters), every loss within ``tol_loss``, identical skip
+    decisions, identical scale trajectory.
+
+An overflow is injected at one iteration by multiplying the loss with a device scalar that is +inf for that iteration (the
+forward -- BatchNorm running statistics included -- stays clean on both sides; every gradient becomes non-finite)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+import slowfast_amd as sa
+from oracle import video_ref
+from slowfast_amd.data_parallel import GradReducer
+from slowfast_amd.optim import CTL_SCALE, CTL_SKIPPED, CTL_STEPS, construct_optimizer
+from slowfast_amd.step import TrainStep
+from tests import model_checks as mc
+
+
+def _torch_optimizer(cfg, groups, lr):
+    """torch.optim as slowfast/models/optimizer.py:100-140 builds it."""
+    if cfg.SOLVER.OPTIMIZING_METHOD == "sgd":
+        return torch.optim.SGD(groups, lr=lr, momentum=cfg.SOLVER.MOMENTUM, weight_decay=cfg.SOLVER.WEIGHT_DECAY,
+                               dampening=cfg.SOLVER.DAMPENING, nesterov=cfg.SOLVER.NESTEROV)
+    assert cfg.SOLVER.OPTIMIZING_METHOD == "adamw"
+    return torch.optim.AdamW(groups, lr=lr, betas=tuple(cfg.SOLVER.get("BETAS", (0.9, 0.999))), eps=1e-08,
+                             weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+
+
+class _RefLoop:
+    """The reference's post-backward sequence on CPU fp32 parameters (tools/train_net.py:150-172)."""
+
+    def __init__(self, cfg, named, group_names, group_cfg, lr, init_scale, growth_interval):
+        self.cfg = cfg
+        self.params = {k: torch.nn.Parameter(v.detach().float().cpu().clone()) for k, v in named.items()}
+        groups = [{"params": [self.params[k] for k in names], "weight_decay": float(g.get("weight_decay", 0.0)), "lr": lr}
+                  for names, g in zip(group_names, group_cfg)]
+        self.opt = _torch_optimizer(cfg, groups, lr)
+        self.scaler = torch.amp.GradScaler("cpu", init_scale=init_scale, growth_interval=growth_interval, enabled=True)
+        self.scaler.scale(torch.zeros(()))                 # lazily creates the scale tensor, as scaler.scale(loss) does
+        self.skipped = []
+        self.scales = []
+        self.grad_norms = []
+
+    def step(self, scaled_grads):
+        """scaled_grads: {name: d(scale * loss)/d(param)} as the reference's backward leaves them in param.grad."""
+        cfg = self.cfg
+        self.scales.append(float(self.scaler.get_scale()))
+        self.opt.zero_grad()
+        for k, p in self.params.items():
+            p.grad = scaled_grads[k].detach().float().cpu().clone()
+        self.scaler.unscale_(self.opt)
+        plist = list(self.params.values())
+        if cfg.SOLVER.CLIP_GRAD_VAL:
+            torch.nn.utils.clip_grad_value_(plist, cfg.SOLVER.CLIP_GRAD_VAL)
+            gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in plist))
+        elif cfg.SOLVER.CLIP_GRAD_L2NORM:
+            gn = torch.nn.utils.clip_grad_norm_(plist, cfg.SOLVER.CLIP_GRAD_L2NORM)
+        else:
+            gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in plist))       # optim.get_grad_norm_
+        self.grad_norms.append(float(gn))
+        before = [p.detach().clone() for p in plist]
+        self.scaler.step(self.opt)
+        self.scaler.update()
+        self.skipped.append(all(torch.equal(a, p.detach()) for a, p in zip(before, plist)))
+
+
+def _rel_l2(a, b):
+    num = sum(float((a[k].double() - b[k].double()).pow(2).sum()) for k in b)
+    den = sum(float(b[k].double().pow(2).sum()) for k in b)
+    return math.sqrt(num / max(den, 1e-300))
+
+
+def check_train_step_vs_torch(device, case, solver_opts, steps=5, overflow_at=2, lr=None, use_graph=None, init_scale=256.0,
+                              growth_interval=2, tol_arith=3e-6, tol_param=1e-3, tol_loss=2e-3, tol_update=5e-2, compare_oracle=True,
+                              report=None):
+    gold = mc.load_golden(case)
+    cfg = mc.cfg_for(gold, extra=["TRAIN.MIXED_PRECISION", True] + list(solver_opts))
+    model, sd, inputs, labels, *_ = mc.oracle_run(gold, cfg)
+    fam = mc.family(cfg)
+    model.load_state_dict(sd)
+    model = model.to(device).train()
+    lr = float(cfg.SOLVER.BASE_LR if lr is None else lr)
+    red = GradReducer(model)
+    red.attach_torch_param_hooks(model.head.parameters())
+    opt = construct_optimizer(model, cfg, red, loss_scale=init_scale, dynamic_loss_scale=True)
+    opt.growth_interval = int(growth_interval)
+    for g in opt.param_groups:
+        g["lr"] = lr                                       # optim.set_lr(optimizer, lr), train_net.py:104-106
+    name_of = {id(p): k for k, p in model.named_parameters()}
+    group_names = [[name_of[id(p)] for p in g["params"]] for g in opt.param_groups]
+    assert sorted(k for names in group_names for k in names) == sorted(name_of.values())
+    named0 = {k: p.detach().float().cpu().clone() for k, p in model.named_parameters()}
+
+    poison = torch.ones((), dtype=torch.float32, device=device)
+
+    def loss_fn(logits, y):
+        return F.cross_entropy(logits, y) * poison
+
+    if use_graph is None:
+        use_graph = device.type == "cuda"
+    step = TrainStep(model, red, opt, loss_fn, use_graph=use_graph, warmup=1)
+    snaps = []
+    orig_step = opt.step
+
+    def snap_step():
+        snaps.append(red.flat.detach().float().cpu().clone())      # loss-scaled gradients, right before the fused update
+        orig_step()
+    opt.step = snap_step
+
+    # (A) torch.optim + GradScaler on the engine's own gradients; (B) the same sequence on the oracle's
+    ref_a = _RefLoop(cfg, named0, group_names, opt.param_groups, lr, init_scale, growth_interval)
+    ref_b = _RefLoop(cfg, named0, group_names, opt.param_groups, lr, init_scale, growth_interval)
+    sd_b = {k: v.clone() for k, v in sd.items()}
+    xs, ys = [x.to(device) for x in inputs], labels.to(device)
+    views = []
+    off = 0
+    for p in red.params:
+        views.append((name_of[id(p)], off, p.numel(), tuple(p.shape)))
+        off += p.numel()
+    res = {"case": case, "arith": 0.0, "loss": 0.0, "engine_scales": [], "engine_skipped": [], "losses": []}
+    for it in range(steps):
+        bad = it == overflow_at
+        poison.fill_(float("inf") if bad else 1.0)
+        res["engine_scales"].append(float(opt.ctl[CTL_SCALE]))
+        skipped_before = float(opt.ctl[CTL_SKIPPED])
+        loss = float(step(xs, ys))
+        res["engine_skipped"].append(float(opt.ctl[CTL_SKIPPED]) > skipped_before)
+        res["losses"].append(loss)
+        # ---- (A) ----
+        flat = snaps[-1]
+        ref_a.step({k: flat[o:o + n].view(shape) for k, o, n, shape in views})
+        eng = {k: p.detach().float().cpu() for k, p in model.named_parameters()}
+        res["arith"] = max(res["arith"], max(
+            float((eng[k] - q.detach()).abs().max() / (q.detach().abs().max() + 1e-12)) for k, q in ref_a.params.items()))
+        if not bad:
+            gn_e = float(opt.grad_norm)
+            assert abs(gn_e - ref_a.grad_norms[-1]) <= 1e-4 * ref_a.grad_norms[-1], (it, gn_e, ref_a.grad_norms[-1])
+        # ---- (B) ----
+        if not compare_oracle:
+            continue
+        for k, q in ref_b.params.items():
+            sd_b[k] = q.detach().clone()
+        o_logits, o_loss, o_grads, o_stats = fam.loss_and_grads(sd_b, cfg, inputs, labels)
+        sd_b.update({k: v.clone() for k, v in o_stats.items()})
+        scale_b = float(ref_b.scaler.get_scale())
+        mult = scale_b * (float("inf") if bad else 1.0)
+        ref_b.step({k: g * mult for k, g in o_grads.items()})
+        if not bad:
+            res["loss"] = max(res["loss"], abs(loss - float(o_loss)) / max(1.0, abs(float(o_loss))))
+    eng = {k: p.detach().float().cpu() for k, p in model.named_parameters()}
+    ref = {k: q.detach() for k, q in ref_b.params.items()}
+    res["param_rel_l2"] = _rel_l2(eng, ref)
+    upd_e = {k: eng[k] - named0[k] for k in eng}
+    upd_r = {k: ref[k] - named0[k] for k in ref}
+    res["update_rel_l2"] = _rel_l2(upd_e, upd_r)
+    res["update_over_param"] = math.sqrt(sum(float(v.double().pow(2).sum()) for v in upd_r.values())
+                                         / sum(float(v.double().pow(2).sum()) for v in named0.values()))
+    res["ref_scales"], res["ref_skipped"] = ref_b.scales, ref_b.skipped
+    res["final_scale"] = (float(opt.ctl[CTL_SCALE]), float(ref_b.scaler.get_scale()))
+    res["steps_skipped"] = (float(opt.ctl[CTL_STEPS]), float(opt.ctl[CTL_SKIPPED]))
+    msd = model.state_dict()
+    res["running_stats"] = max([float((msd[k].float().cpu() - sd_b[k]).abs().max() / (sd_b[k].abs().max() + 1e-6))
+                                for k in sd_b if "running_" in k] + [0.0])
+    red.close()
+    if report is not None:
+        report[case] = res
+    mc._record(case + "@train_step", device, dict(res))
+    want_skip = [i == overflow_at for i in range(steps)]
+    assert res["engine_skipped"] == want_skip == ref_a.skipped, res
+    assert res["engine_scales"] == ref_a.scales, res
+    assert res["final_scale"][0] == float(ref_a.scaler.get_scale()), res
+    assert res["arith"] <= tol_arith, res
+    assert all(math.isfinite(v) for i, v in enumerate(res["losses"]) if i != overflow_at), res
+    if compare_oracle:
+        assert want_skip == ref_b.skipped and res["engine_scales"] == ref_b.scales, res
+        assert res["final_scale"][0] == res["final_scale"][1], res
+        assert res["loss"] <= tol_loss, res
+        assert res["param_rel_l2"] <= tol_param, res
+        # the parameters barely move in a few iterations, so the bound above alone would also pass a wrong update rule whose
+        # error is small against |param|: the UPDATE itself (p_end - p_0) must match the reference's to the size of the
+        # engine's gradient deviation on this case (grad_global of the model-level parity tests, 2-3 %)
+        assert res["update_rel_l2"] <= tol_update, res
+    return res

@@ -420,3 +420,91 @@ def test_allreduce_overlaps_backward_segments(hostsim_path):
         assert err < 1e-5, res
         assert nseg >= 3 and nbuckets >= 3, res
         assert inflight >= 1, "no collective was in flight when the last backward segment started"
+
+
+# ---- the reference's own boundary on the GPU: build_model -> DistributedDataParallel + register_comm_hook over RCCL -----------
+_DDP_RCCL_SCRIPT = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch.nn.functional as F
+import slowfast_amd as sa
+from slowfast_amd import engine, registry
+from slowfast_amd.data_parallel import GradReducer
+from tests import model_checks as mc
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", device_id=dev)
+# one GPU on this box: cfg.NUM_GPUS = 2 is what makes build_model wrap (slowfast/models/build.py:64), the process group has
+# one rank -- the all-reduce runs on RCCL with world size 1 (mean over one rank = identity), every hook and stream hand-over
+# is the real one
+_real_count = torch.cuda.device_count
+for name in ("slowfast_tiny", "mvit_tiny"):
+    gold = mc.load_golden(name)
+    cfg1 = mc.cfg_for(gold, extra=["NUM_GPUS", 1])
+    _, sd, inputs, labels, *_ = mc.oracle_run(gold, cfg1)
+    xs, ys = [x.to(dev) for x in inputs], labels.to(dev)
+    # in-place path (what bench.py times): gradients written into GradReducer's flat buffer by the backward kernels
+    model = registry.build_model(cfg1, gpu_id=0, data_parallel="reducer")
+    assert not isinstance(model, torch.nn.parallel.DistributedDataParallel)
+    model.load_state_dict(sd)
+    model.train()
+    red = GradReducer(model)
+    red.attach_torch_param_hooks(model.head.parameters())
+    red.zero_grad()
+    (F.cross_entropy(model(xs).float(), ys) * 64.0).backward()
+    red.finish(loss_scale=64.0)
+    ref = {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
+    red.close()
+    for fp16 in (False, True):
+        cfg2 = mc.cfg_for(gold, extra=["NUM_GPUS", 2, "MODEL.FP16_ALLREDUCE", fp16])
+        torch.cuda.device_count = lambda: 2
+        try:
+            ddp = registry.build_model(cfg2, gpu_id=0, data_parallel="ddp")
+        finally:
+            torch.cuda.device_count = _real_count
+        assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel), type(ddp)
+        ddp.module.load_state_dict(sd)
+        ddp.train()
+        calls = []
+        orig = dist.all_reduce
+        def counting(t, *a, **k):
+            calls.append((t.dtype, t.numel()))
+            return orig(t, *a, **k)
+        dist.all_reduce = counting
+        try:
+            for it in range(2):          # second iteration: DDP has rebuilt its buckets in gradient-ready order
+                ddp.zero_grad(set_to_none=True)
+                (F.cross_entropy(ddp(xs).float(), ys) * 64.0).backward()
+        finally:
+            dist.all_reduce = orig
+        torch.cuda.synchronize()
+        assert engine.GRADS_VIA_AUTOGRAD and not engine._pending_grads
+        assert calls and all(d == (torch.float16 if fp16 else torch.float32) for d, _ in calls), calls[:4]
+        got = {k: p.grad.detach().float() / 64.0 for k, p in ddp.module.named_parameters()}
+        assert set(got) == set(ref)
+        num = sum(float((got[k] - ref[k]).double().pow(2).sum()) for k in ref)
+        den = sum(float(ref[k].double().pow(2).sum()) for k in ref)
+        err = (num / den) ** 0.5
+        worst = max(float((got[k] - ref[k]).norm() / (ref[k].norm() + 1e-12)) for k in ref)
+        print(name, "fp16" if fp16 else "fp32", "global", err, "worst", worst, "collectives", len(calls))
+        if fp16:
+            assert err <= 1e-3, err           # one fp16 rounding of every gradient element
+        else:
+            assert err <= 1e-6 and worst <= 1e-5, (err, worst)   # same kernels on the same operands; DDP only adds a /1 and a copy
+        del ddp
+dist.destroy_process_group()
+print("ddp-rccl-ok")
+"""
+
+
+@pytest.mark.gpu
+def test_build_model_ddp_comm_hooks_on_rccl(gpu):
+    """registry.build_model(cfg with NUM_GPUS > 1) wraps the drop-in model in DistributedDataParallel and installs
+    xgmi_allreduce_hook / fp16_compress_hook exactly where slowfast/models/build.py:64-80 wraps the reference; on the GPU,
+    over RCCL (world 1), the gradients that arrive through autograd + DDP's reducer + the hook equal the in-place
+    GradReducer path to fp32 round-off (fp32 hook) / to one fp16 rounding (MODEL.FP16_ALLREDUCE)."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", _DDP_RCCL_SCRIPT], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ddp-rccl-ok" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]

@@ -197,6 +197,13 @@ def test_wgrad_many_splits(gpu):
     kc.check_conv_wgrad(gpu, (4, 8, 16, 56, 56), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0))
 
 
+@pytest.mark.gpu
+def test_roi_align_published_vectors(gpu):
+    """ROIAlign kernel pinned to detectron2's published unit-test vectors (tests/golden/roi_align_detectron2.json)."""
+    kc.check_roi_known_answer(gpu)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("aligned", [True, False])
 def test_roi_pool(gpu, aligned):
     """RoI head pooling (temporal mean -> ROIAlign -> max) vs the oracle's ROIAlign restatement."""

@@ -272,3 +272,56 @@ def test_weight_pack_plan_covers_mvit_linears(sim, monkeypatch):
     assert la == lb
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
+
+
+# ---- the step glue against the reference's own sequence: torch.optim + torch.amp.GradScaler (rows a20 / f1) ------------------
+_SGD_OPTS = ["SOLVER.OPTIMIZING_METHOD", "sgd", "SOLVER.MOMENTUM", 0.9, "SOLVER.NESTEROV", True, "SOLVER.WEIGHT_DECAY", 1e-4,
+             "BN.WEIGHT_DECAY", 0.0]
+_ADAMW_OPTS = ["SOLVER.OPTIMIZING_METHOD", "adamw", "SOLVER.WEIGHT_DECAY", 0.05, "SOLVER.ZERO_WD_1D_PARAM", True,
+               "SOLVER.CLIP_GRAD_L2NORM", 1.0]
+
+
+def test_train_step_arithmetic_vs_torch_optim_sgd_hostsim(sim):
+    """Comparison (A) of tests/step_checks.py on the host simulator: FlatOptimizer's SGD-Nesterov / GradScaler arithmetic, skip
+    decisions and scale trajectory == torch.optim.SGD + torch.amp.GradScaler fed the engine's own gradients."""
+    from tests import step_checks
+    step_checks.check_train_step_vs_torch(sim, "c2d_tiny", _SGD_OPTS, steps=4, overflow_at=1, lr=1e-6, compare_oracle=False)
+
+
+def test_train_step_vs_torch_optim_adamw_hostsim(sim):
+    """Host-simulator twin of the GPU test below (comparisons (A) and (B), eager)."""
+    from tests import step_checks
+    step_checks.check_train_step_vs_torch(sim, "mvit_tiny", _ADAMW_OPTS, steps=4, overflow_at=2, lr=2e-4)
+
+
+@pytest.mark.slow
+def test_train_step_vs_torch_optim_sgd_hostsim(sim):
+    """Host-simulator twin of test_train_step_vs_torch_optim_sgd (minutes on the CPU: SF_RUN_SLOW=1)."""
+    from tests import step_checks
+    step_checks.check_train_step_vs_torch(sim, "c2d_wc", _SGD_OPTS, steps=3, overflow_at=1, lr=0.02)
+
+
+@pytest.mark.gpu
+def test_train_step_vs_torch_optim_sgd(gpu):
+    """TrainStep (HIP graphs) + FlatOptimizer (sf_flat_sumsq / sf_step_control / sf_flat_sgd) on c2d_wc: SGD-Nesterov with the
+    BN / non-BN weight-decay groups, dynamic loss scale, one injected overflow -- against torch.optim.SGD +
+    torch.amp.GradScaler fed (A) the engine's gradients (fp32 round-off) and (B) the fp32 oracle's (1e-3 on the parameters
+    after 5 steps; identical skip decisions and scale trajectory).  tools/train_net.py:150-172, optimizer.py:100-140."""
+    from tests import step_checks
+    rep = {}
+    try:
+        step_checks.check_train_step_vs_torch(gpu, "c2d_wc", _SGD_OPTS, steps=5, overflow_at=2, lr=0.02, report=rep)
+    finally:
+        print("train_step sgd", rep)
+
+
+@pytest.mark.gpu
+def test_train_step_vs_torch_optim_adamw(gpu):
+    """The same with AdamW (decoupled decay, zero-decay group from no_weight_decay() + 1-D parameters) and
+    SOLVER.CLIP_GRAD_L2NORM 1.0 on mvit_tiny (gradient norm ~35: every step is clipped)."""
+    from tests import step_checks
+    rep = {}
+    try:
+        step_checks.check_train_step_vs_torch(gpu, "mvit_tiny", _ADAMW_OPTS, steps=5, overflow_at=3, lr=2e-4, report=rep)
+    finally:
+        print("train_step adamw", rep)
