@@ -77,6 +77,60 @@ def _relu(x, masks=None, key=None):
     return F.relu(x)
 
 
+class _MaxPoolRouted(torch.autograd.Function):
+    """max_pool3d(x) in forward (the true maximum); the BACKWARD sends each output's gradient to the input element the
+    caller names (``index``: int64 (N, C, To, Ho, Wo), flat t*H*W + h*W + w) instead of to the arg-max.  Same purpose as
+    _ReluFixedMask: a window whose two largest entries differ by less than fp16 round-off may be routed to either by a correct
+    fp16 implementation, which moves an O(1) gradient contribution between two positions."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding, index):
+        ctx.save_for_backward(index)
+        ctx.in_shape = tuple(x.shape)
+        return F.max_pool3d(x, kernel, stride, padding)
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        N, C, T, H, W = ctx.in_shape
+        dx = torch.zeros((N, C, T * H * W), dtype=g.dtype, device=g.device)
+        dx.scatter_add_(2, index.reshape(N, C, -1), g.reshape(N, C, -1))
+        return dx.reshape(ctx.in_shape), None, None, None, None
+
+
+def _max_pool(x, kernel, stride, padding, masks=None, key="pool_route"):
+    if masks is not None and masks.get(key) is not None:
+        return _MaxPoolRouted.apply(x, tuple(kernel), tuple(stride), tuple(padding), masks[key])
+    return F.max_pool3d(x, tuple(kernel), tuple(stride), tuple(padding))
+
+
+# Whole-model hand-over (tests only): {module prefix: {key: mask / route}} of the engine under test, looked up by every
+# block below when its own ``masks`` argument is None.  See tests/model_checks.py:engine_masks.
+_HANDED = None
+
+
+class handed_masks:
+    """Context manager: the BACKWARD of every ReLU / max-pool whose module prefix appears in ``table`` runs through the mask /
+    routes given there (the forward stays the exact fp32 reference)."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def __enter__(self):
+        global _HANDED
+        self._old, _HANDED = _HANDED, self.table
+
+    def __exit__(self, *exc):
+        global _HANDED
+        _HANDED = self._old
+
+
+def _handed(prefix, masks):
+    if masks is not None:
+        return masks
+    return _HANDED.get(prefix) if _HANDED is not None else None
+
+
 def _conv(x, w, *args):
     return _STORE(F.conv3d(x, _STORE(w), *args))   # args = (bias, stride, padding, dilation)
 
@@ -117,6 +171,7 @@ def stem(x, sd, prefix, training, stats_out, masks=None):
     """ResNetBasicStem.forward: conv -> bn -> relu -> MaxPool3d([1,3,3],[1,2,2],[0,1,1]) (stem_helper.py:182-201).
     ``masks`` (tests only, see _ReluFixedMask): {"relu": 0/1 tensor, "pool_index": int64 (N, C, T, Ho, Wo) flat h*W + w of the
     element each pooled output is routed to} -- the backward runs through the routes the engine under test took."""
+    masks = _handed(prefix, masks)
     w = sd[prefix + ".conv.weight"]
     kt = w.shape[2]
     x = _conv(_STORE(x), w, None, (1, 2, 2), (kt // 2, 3, 3))
@@ -125,11 +180,12 @@ def stem(x, sd, prefix, training, stats_out, masks=None):
         N, C, T, H, W = x.shape
         idx = masks["pool_index"]
         return x.reshape(N, C, T, H * W).gather(3, idx.reshape(N, C, T, -1)).reshape(idx.shape)
-    return F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    return _max_pool(x, (1, 3, 3), (1, 2, 2), (0, 1, 1), masks)      # "pool_route": true maximum forward, routed backward
 
 
 def fuse(xs, xf, sd, prefix, alpha, training, stats_out, masks=None):
     """FuseFastToSlow.forward (video_model_builder.py:162-169): time-strided conv on Fast, BN, ReLU, concat."""
+    masks = _handed(prefix, masks)
     w = sd[prefix + ".conv_f2s.weight"]
     k = w.shape[2]
     f = _conv(xf, w, None, (alpha, 1, 1), (k // 2, 0, 0))
@@ -141,6 +197,7 @@ def res_block(x, sd, prefix, stride, dilation, stride_1x1, training, stats_out, 
     """ResBlock.forward (resnet_helper.py:512-521) around BottleneckTransform.forward (:377-392) or, when the block has
     no ``c`` convolution, BasicTransform.forward (:105-115: Tx3x3 stride s -> BN -> ReLU -> 1x3x3 dilated -> BN).
     ``masks`` ({"a", "b", "out"} -> 0/1 tensors): backward masks of the three ReLUs (see _ReluFixedMask; tests only)."""
+    masks = _handed(prefix, masks)
     s_a, s_b = (stride, 1) if stride_1x1 else (1, stride)
     b2 = prefix + ".branch2"
     wa = sd[b2 + ".a.weight"]
@@ -170,7 +227,7 @@ def nonlocal_block(x, sd, prefix, pool_size, instantiation, training, stats_out)
     input, affinity theta^T phi normalised by softmax(./sqrt(C)) or by 1/N ("dot_product"), out conv + BN, residual."""
     N, C, T, H, W = x.shape
     theta = _conv(x, sd[prefix + ".conv_theta.weight"], sd[prefix + ".conv_theta.bias"])
-    xp = F.max_pool3d(x, tuple(pool_size), tuple(pool_size)) if any(s > 1 for s in pool_size) else x
+    xp = _max_pool(x, pool_size, pool_size, (0, 0, 0), _handed(prefix, None)) if any(s > 1 for s in pool_size) else x
     phi = _conv(xp, sd[prefix + ".conv_phi.weight"], sd[prefix + ".conv_phi.bias"])
     g = _conv(xp, sd[prefix + ".conv_g.weight"], sd[prefix + ".conv_g.bias"])
     ci = theta.shape[1]
@@ -220,21 +277,22 @@ def x3d_stem(x, sd, prefix, training, stats_out):
     w_xy, w_t = sd[prefix + ".conv_xy.weight"], sd[prefix + ".conv.weight"]
     x = _conv(_STORE(x), w_xy, None, (1, 2, 2), (0, 1, 1))
     x = _STORE(F.conv3d(x, _STORE(w_t), None, 1, (w_t.shape[2] // 2, 0, 0), 1, w_t.shape[0]))
-    return _STORE(F.relu(_bn(x, sd, prefix + ".bn", training, stats_out)))
+    return _STORE(_relu(_bn(x, sd, prefix + ".bn", training, stats_out), _handed(prefix, None), "relu"))
 
 
 def x3d_block(x, sd, prefix, stride, training, stats_out):
     """ResBlock.forward (resnet_helper.py:512-521) around X3DTransform.forward (:253-256): 1x1x1 -> BN -> ReLU ->
     depthwise 3x3x3 (stride) -> BN -> [SE] -> Swish -> 1x1x1 -> BN; SE = operators.py:53-59."""
+    masks = _handed(prefix, None)
     b2 = prefix + ".branch2"
     y = _conv(x, sd[b2 + ".a.weight"])
-    y = _STORE(F.relu(_bn(y, sd, b2 + ".a_bn", training, stats_out)))
+    y = _STORE(_relu(_bn(y, sd, b2 + ".a_bn", training, stats_out), masks, "a"))
     wb = sd[b2 + ".b.weight"]
     y = _STORE(F.conv3d(y, _STORE(wb), None, (1, stride, stride), (wb.shape[2] // 2, 1, 1), 1, wb.shape[0]))
     y = _bn(y, sd, b2 + ".b_bn", training, stats_out)
     if b2 + ".se.fc1.weight" in sd:
         g = y.mean((2, 3, 4), keepdim=True)
-        g = F.relu(F.conv3d(g, sd[b2 + ".se.fc1.weight"], sd[b2 + ".se.fc1.bias"]))
+        g = _relu(F.conv3d(g, sd[b2 + ".se.fc1.weight"], sd[b2 + ".se.fc1.bias"]), masks, "se")
         g = torch.sigmoid(F.conv3d(g, sd[b2 + ".se.fc2.weight"], sd[b2 + ".se.fc2.bias"]))
         y = y * g
     y = _STORE(y * torch.sigmoid(y))                   # Swish
@@ -245,7 +303,7 @@ def x3d_block(x, sd, prefix, stride, training, stats_out):
         sc = _bn(sc, sd, prefix + ".branch1_bn", training, stats_out)
     else:
         sc = x
-    return _STORE(F.relu(sc + y))
+    return _STORE(_relu(sc + y, masks, "out"))
 
 
 def x3d_forward(sd, cfg, inputs, training=True, stats_out=None):
@@ -258,7 +316,7 @@ def x3d_forward(sd, cfg, inputs, training=True, stats_out=None):
             x = x3d_block(x, sd, f"s{s}.pathway0_res{i}", 2 if i == 0 else 1, training, stats_out)
             i += 1
     x = _conv(x, sd["head.conv_5.weight"])
-    x = _STORE(F.relu(_bn(x, sd, "head.conv_5_bn", training, stats_out)))
+    x = _STORE(_relu(_bn(x, sd, "head.conv_5_bn", training, stats_out), _handed("head", None), "conv_5"))
     # nn.AvgPool3d([NUM_FRAMES, ceil(crop/32), ceil(crop/32)], stride=1) (video_model_builder.py:783-797): the whole
     # extent at the training crop, a sliding window (fully-convolutional inference) at a larger test crop
     spat = -(-cfg.DATA.TRAIN_CROP_SIZE // 32)
@@ -266,7 +324,7 @@ def x3d_forward(sd, cfg, inputs, training=True, stats_out=None):
     x = F.conv3d(x, sd["head.lin_5.weight"])
     if "head.lin_5_bn.weight" in sd:
         x = _bn(x, sd, "head.lin_5_bn", training, stats_out)
-    x = F.relu(x)
+    x = _relu(x, _handed("head", None), "lin_5")
     z = F.linear(x.permute(0, 2, 3, 4, 1), sd["head.projection.weight"], sd["head.projection.bias"])
     if not training:
         z = F.softmax(z, dim=4).mean([1, 2, 3])
@@ -353,7 +411,7 @@ def video_forward(sd, cfg, inputs, training=True, stats_out=None, bboxes=None):
         if i == 0:
             pt = _POOL1_T[cfg.MODEL.ARCH]
             if pt != 1:
-                x = [F.max_pool3d(v, (pt, 1, 1), (pt, 1, 1)) for v in x]
+                x = [_max_pool(v, (pt, 1, 1), (pt, 1, 1), (0, 0, 0), _handed(f"pathway{p}_pool", None)) for p, v in enumerate(x)]
         if two and i < 3:
             x[0] = fuse(x[0], x[1], sd, f"{name}_fuse", cfg.SLOWFAST.ALPHA, training, stats_out)
     if cfg.DETECTION.ENABLE:

@@ -175,8 +175,10 @@ def join_side_streams():
     _side_keep.clear()
 
 
-# Test hook: when a list, ResBlockFn.forward appends the tensors that decide its ReLU masks (raw conv outputs + BatchNorm
-# scale / shift, the block output) so that a parity test can hand the SAME masks to the oracle (tests/block_checks.py).
+# Test hook: when a list, every Function with a ReLU or a max-pool appends the tensors that decide its backward routing (raw conv
+# outputs + BatchNorm scale / shift, the block output, byte arg-max tables) together with its module, so that a parity test
+# can hand the SAME masks / routes to the oracle's backward -- per block (tests/block_checks.py) and for a whole model
+# (tests/model_checks.py:engine_masks).
 CAPTURE = None
 
 
@@ -564,7 +566,7 @@ class StemFn(torch.autograd.Function):
         assert k[0] == 1 and s[0] == 1 and p[0] == 0, "stem pooling is spatial-only in every reference config"
         out, arg = ops.pool_fwd(y, k[1:], s[1:], p[1:], affine=(st.scale, st.shift, True))
         if CAPTURE is not None:
-            CAPTURE.append({"raw": [y], "bn": [(st.scale, st.shift)], "out": out, "argmax": arg})
+            CAPTURE.append({"kind": "stem", "mod": mod, "raw": [y], "bn": [(st.scale, st.shift)], "out": out, "argmax": arg})
         ctx.mod, ctx.xcl, ctx.y, ctx.st = mod, xcl, y, st
         ctx.pool = (tuple(k[1:]), tuple(s[1:]), tuple(p[1:]))
         ctx.pooled, ctx.arg = out, arg
@@ -599,6 +601,8 @@ class FuseFn(torch.autograd.Function):
         cat = ops.cl_empty((N, Cs + Cf, T, H, W), x_s.device)
         ops.bn_act(x_s, out=cat[:, :Cs])
         ops.bn_act(yf, st.scale, st.shift, relu=True, out=cat[:, Cs:])
+        if CAPTURE is not None:
+            CAPTURE.append({"kind": "fuse", "mod": mod, "raw": [yf], "bn": [(st.scale, st.shift)]})
         ctx.mod, ctx.yf, ctx.st, ctx.Cs = mod, yf, st, Cs
         ctx.save_for_backward(x_f)
         return cat, x_f.view_as(x_f)
@@ -654,7 +658,7 @@ class ResBlockFn(torch.autograd.Function):
             y1, s1 = None, None
             out, bits = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x, want_mask=True)
         if CAPTURE is not None:
-            CAPTURE.append({"raw": list(raw), "bn": [(b.scale, b.shift) for b in bn], "out": out})
+            CAPTURE.append({"kind": "resblock", "mod": mod, "raw": list(raw), "bn": [(b.scale, b.shift) for b in bn], "out": out})
         ctx.mod = mod
         ctx.raw = (raw, y1, act, bits)
         ctx.bn = (bn, s1)
@@ -700,7 +704,7 @@ class ConvBNActFn(torch.autograd.Function):
         y, st = unit.forward(x, None, training)
         out = ops.bn_act(y, st.scale, st.shift, relu=relu)
         if CAPTURE is not None:
-            CAPTURE.append({"raw": [y], "bn": [(st.scale, st.shift)], "out": out})
+            CAPTURE.append({"kind": "convbnact", "mod": None, "raw": [y], "bn": [(st.scale, st.shift)], "out": out})
         ctx.unit, ctx.relu, ctx.y, ctx.st = unit, relu, y, st
         ctx.save_for_backward(x)
         return out

@@ -6,7 +6,7 @@ Same constructor, children (conv_theta, conv_phi, conv_g, conv_out, bn, pool) an
 import torch
 import torch.nn as nn
 
-from . import ops, tokens
+from . import engine, ops, tokens
 from .engine import ConvUnit, _grad_dest, _notify, as_cl, param_grads
 from .lib import get_lib
 from .x3d import cl5d, rows2d
@@ -78,6 +78,9 @@ class NonlocalFn(torch.autograd.Function):
         theta, _ = mod._theta.forward(x, None, tr)                         # (N, Ci, T, H, W)
         if mod.use_pool:
             xp, arg = pool3d_fwd(x, tuple(mod.pool_size))
+            if engine.CAPTURE is not None:
+                engine.CAPTURE.append({"kind": "nonlocal", "mod": mod, "argmax": arg, "kernel": tuple(mod.pool_size),
+                                       "in_shape": tuple(x.shape)})
         else:
             xp, arg = x, None
         phi, _ = mod._phi.forward(xp, None, tr)

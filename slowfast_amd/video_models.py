@@ -95,22 +95,25 @@ class PathwayPoolFn(torch.autograd.Function):
     kernel == stride, no padding) on the sf_pool3d kernels (byte arg-max, gather backward) instead of ATen."""
 
     @staticmethod
-    def forward(ctx, x, kernel):
+    def forward(ctx, x, kernel, pool=None):
         from .nonlocal_block import pool3d_fwd
         x = as_cl(x)
         out, arg = pool3d_fwd(x, tuple(kernel))
+        if engine.CAPTURE is not None:
+            engine.CAPTURE.append({"kind": "pathway_pool", "mod": pool, "argmax": arg, "kernel": tuple(kernel),
+                                   "in_shape": tuple(x.shape)})
         ctx.arg, ctx.in_shape, ctx.kernel = arg, tuple(x.shape), tuple(kernel)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         from .nonlocal_block import pool3d_bwd
-        return pool3d_bwd(as_cl(dout), ctx.arg, ctx.in_shape, ctx.kernel), None
+        return pool3d_bwd(as_cl(dout), ctx.arg, ctx.in_shape, ctx.kernel), None, None
 
 
 def _pathway_pool(pool, x):
     assert tuple(pool.stride) == tuple(pool.kernel_size) and not any(_t(pool.padding)), "pathway pools do not overlap"
-    return PathwayPoolFn.apply(x, tuple(pool.kernel_size))
+    return PathwayPoolFn.apply(x, tuple(pool.kernel_size), pool)
 
 
 def _t(v):

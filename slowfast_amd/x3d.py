@@ -13,7 +13,7 @@ from ctypes import byref
 import torch
 import torch.nn as nn
 
-from . import ops, tokens
+from . import engine, ops, tokens
 from .engine import BNState, ConvUnit, StemConvUnit, _grad_dest, _notify, _sync_of, as_cl, bn_statistics, param_grads
 from .lib import get_lib
 from .registry import MODEL_REGISTRY
@@ -156,6 +156,8 @@ class X3DStemFn(torch.autograd.Function):
         y2, part, g = dw.forward(y1, stats=True)
         st = bn.finalize(part, g.rows_out, y2.shape[1], mod.training)
         out = ops.bn_act(y2, st.scale, st.shift, relu=True)
+        if engine.CAPTURE is not None:
+            engine.CAPTURE.append({"kind": "x3d_stem", "mod": mod, "raw": [y2], "bn": [(st.scale, st.shift)]})
         ctx.mod, ctx.sv = mod, (xcl, y1, y2, st)
         return out
 
@@ -200,6 +202,9 @@ class X3DBlockFn(torch.autograd.Function):
         else:
             y1, s1 = None, None
             out, bits = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x, want_mask=True)
+        if engine.CAPTURE is not None:
+            engine.CAPTURE.append({"kind": "x3d_block", "mod": mod, "raw": [ya], "bn": [(sa.scale, sa.shift)], "out": out,
+                                   "se_h": None if se is None else se[1]})
         ctx.mod = mod
         ctx.sv = dict(ya=ya, sa=sa, za=za, yb=yb, sb=sb, gate=gate, se=se, zb=zb, yc=yc, sc=sc, y1=y1, s1=s1, bits=bits)
         ctx.save_for_backward(x)
@@ -248,6 +253,8 @@ class X3DHeadPoolFn(torch.autograd.Function):
         unit = mod._conv5
         y, st = unit.forward(x, None, mod.training)
         m = sample_mean(y, st.scale, st.shift, relu=True)
+        if engine.CAPTURE is not None:
+            engine.CAPTURE.append({"kind": "x3d_head", "mod": mod, "raw": [y], "bn": [(st.scale, st.shift)]})
         ctx.mod, ctx.y, ctx.st = mod, y, st
         ctx.save_for_backward(x)
         return m[:, :unit.conv.out_channels].contiguous()
@@ -437,6 +444,8 @@ class X3DHead(nn.Module):
         z = torch.nn.functional.linear(m, self.lin_5.weight.view(self.lin_5.out_channels, -1))
         if self.bn_lin5_on:
             z = self.lin_5_bn(z.view(z.shape[0], -1, 1, 1, 1)).view(z.shape[0], -1)
+        if engine.CAPTURE is not None:
+            engine.CAPTURE.append({"kind": "x3d_lin5", "mod": self, "pre": z.detach()})
         z = torch.relu(z)
         if hasattr(self, "dropout"):
             z = self.dropout(z)

@@ -160,6 +160,121 @@ def storage_model_yardstick(name, sd, cfg, inputs, labels, o_logits, o_loss, o_g
     return y
 
 
+# ---- whole-model mask / route hand-over ------------------------------------------------------------------------------------
+# A ReLU whose pre-activation lies within fp16 round-off of zero (or a max-pool window whose two largest entries do) lands on
+# either side in two correct fp16 realisations; its forward effect is O(round-off), its backward effect O(1).  ~0.05 % of the
+# elements per layer, compounded over 50-100 layers, is 1-7 % of the gradient VECTOR in relative L2 -- for the reference under
+# autocast as well -- while the gradient NORM moves by e^2/2.  To constrain the gradient vector itself (not only its norm) the
+# engine's own masks and routes are handed to the oracle's BACKWARD (oracle.video_ref.handed_masks; the forward stays the exact
+# fp32 reference): flipped elements are thereby excluded and every other element of every parameter gradient must agree.
+TOL_GRAD_GLOBAL = 5e-3
+
+
+def _premask(raw, scale, shift, channels=None):
+    pre = raw.float() * scale.float().view(1, -1, 1, 1, 1) + shift.float().view(1, -1, 1, 1, 1)
+    m = pre > 0
+    if channels is not None:
+        m = m[:, :channels]
+    return m.cpu().contiguous()
+
+
+def _window_route(arg, kernel, stride, padding, in_thw):
+    """Byte arg-max table [N, To, Ho, Wo, C] (window-local index (kt*kH + kh)*kW + kw) -> int64 (N, C, To, Ho, Wo) flat input
+    position t*H*W + h*W + w of the element each pooled output was routed to."""
+    kT, kH, kW = kernel
+    T, H, W = in_thw
+    a = arg.long().cpu()
+    N, To, Ho, Wo, C = a.shape
+    to = torch.arange(To).view(1, To, 1, 1, 1)
+    ho = torch.arange(Ho).view(1, 1, Ho, 1, 1)
+    wo = torch.arange(Wo).view(1, 1, 1, Wo, 1)
+    t = (to * stride[0] - padding[0] + a // (kH * kW)).clamp(0, T - 1)
+    h = (ho * stride[1] - padding[1] + (a // kW) % kH).clamp(0, H - 1)
+    w = (wo * stride[2] - padding[2] + a % kW).clamp(0, W - 1)
+    return ((t * H + h) * W + w).permute(0, 4, 1, 2, 3).contiguous()
+
+
+def engine_masks(model, caps):
+    """engine.CAPTURE entries of one forward pass -> {oracle module prefix: masks / routes} for video_ref.handed_masks."""
+    names = {m: n for n, m in model.named_modules()}
+    table = {}
+    for c in caps:
+        name = names.get(c.get("mod"))
+        if name is None:
+            continue
+        kind = c["kind"]
+        if kind == "stem":
+            pl = c["mod"].pool_layer
+            raw = c["raw"][0]
+            k = (1,) + tuple(pl.kernel_size[1:])
+            st = (1,) + tuple(pl.stride[1:])
+            pd = (0,) + tuple(pl.padding[1:])
+            Cr = c["mod"].conv.out_channels           # activations narrower than 8 channels are zero-padded in HBM
+            table[name] = {"relu": _premask(raw, *c["bn"][0], channels=Cr),
+                           "pool_route": _window_route(c["argmax"], k, st, pd, tuple(raw.shape[2:]))[:, :Cr].contiguous()}
+        elif kind == "fuse":
+            table[name] = {"relu": _premask(c["raw"][0], *c["bn"][0], channels=c["mod"].conv_f2s.out_channels)}
+        elif kind == "resblock":
+            t = c["mod"].branch2
+            convs = [t.a, t.b] + ([t.c] if hasattr(t, "c") else [])
+            e = {key: _premask(raw, *bn, channels=cv.out_channels)
+                 for key, raw, bn, cv in zip(("a", "b"), c["raw"][:-1], c["bn"][:-1], convs)}
+            e["out"] = (c["out"] > 0)[:, :convs[-1].out_channels].cpu().contiguous()
+            table[name] = e
+        elif kind in ("pathway_pool", "nonlocal"):
+            Cr = c["mod"].dim if kind == "nonlocal" else None
+            r = _window_route(c["argmax"], c["kernel"], c["kernel"], (0, 0, 0), c["in_shape"][2:])
+            table[name] = {"pool_route": r if Cr is None else r[:, :Cr].contiguous()}
+        elif kind == "x3d_stem":
+            table[name] = {"relu": _premask(c["raw"][0], *c["bn"][0], channels=c["mod"].conv.out_channels)}
+        elif kind == "x3d_block":
+            t = c["mod"].branch2
+            table[name] = {"a": _premask(c["raw"][0], *c["bn"][0], channels=t.a.out_channels),
+                           "out": (c["out"] > 0)[:, :t.c.out_channels].cpu().contiguous()}
+            if c.get("se_h") is not None:       # the squeeze-excitation's own ReLU (N x dim_fc units)
+                table[name]["se"] = (c["se_h"] > 0).cpu().view(c["se_h"].shape[0], -1, 1, 1, 1)
+        elif kind == "x3d_head":
+            table.setdefault(name, {})["conv_5"] = _premask(c["raw"][0], *c["bn"][0], channels=c["mod"].conv_5.out_channels)
+        elif kind == "x3d_lin5":        # (N, dim_out) fp32 pre-activations of the head's second ReLU: few units, each one
+            table.setdefault(name, {})["lin_5"] = (c["pre"] > 0).cpu().view(c["pre"].shape[0], -1, 1, 1, 1)   # carries weight
+    return table
+
+
+def _engine_run(model, inputs, labels, device, loss_scale, capture):
+    """Forward + loss + backward of the drop-in model; with ``capture`` also the engine's masks / routes of this pass."""
+    from slowfast_amd import engine
+    table = None
+    if capture:
+        engine.CAPTURE = []
+    try:
+        logits = _forward(model, inputs, device)
+        if capture:
+            table = engine_masks(model, engine.CAPTURE)
+    finally:
+        engine.CAPTURE = None
+    loss = _loss(logits, labels, inputs)
+    (loss * loss_scale).backward()
+    return logits, loss, table
+
+
+def masked_grad_global(fam, sd, cfg, inputs, labels, table, grads, tol_global=TOL_GRAD_GLOBAL, **kw):
+    """grad_global of the engine's gradients against the oracle's backward run through the engine's masks / routes ->
+    (value, bound, yardstick).  bound = tol_global, unless the value exceeds it: then the same comparison is made for the
+    oracle's OWN fp16 storage model (torch fp32 arithmetic on the pinned reference graph, stored tensors rounded to fp16, the
+    same masks handed) -- what any correct fp16-storage implementation shows on this case -- and the bound becomes
+    max(tol_global, YARD x that).  (r101nl_wc: 1.18 % engine, 1.31 % storage model, per-parameter figures equal to two digits:
+    the dot-product Nonlocal blocks on post-ReLU activations are ill-conditioned against storage rounding itself.)"""
+    with video_ref.handed_masks(table):
+        _, _, m_grads, _ = fam.loss_and_grads(sd, cfg, list(inputs), labels, **kw)
+    val = _global_rel(grads, m_grads)
+    if val <= tol_global:
+        return val, tol_global, None
+    with video_ref.fp16_storage_model(), video_ref.handed_masks(table):
+        _, _, s_grads, _ = fam.loss_and_grads(sd, cfg, list(inputs), labels, **kw)
+    yard = _global_rel(s_grads, m_grads)
+    return val, max(tol_global, YARD * yard), yard
+
+
 def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=1e-3, tol_param=2e-2,
                  tol_stats=2e-3, tol_global=1e-2, report=None):
     """Forward + CE + backward of the drop-in model on `device` vs the fp32 oracle (and the golden numbers).
@@ -218,7 +333,7 @@ def check_engine(name, device, loss_scale=1.0, tol_logits=4e-3, tol_loss=1e-3, t
     return res
 
 
-def check_well_conditioned(name, device, tol=1e-3, loss_scale=1.0):
+def check_well_conditioned(name, device, tol=1e-3, loss_scale=1.0, tol_global=TOL_GRAD_GLOBAL):
     """The north star's bar with NO yardstick: on a well-conditioned case (oracle/make_golden.py "*_wc": >= 1000 samples
     under every BatchNorm, damped block-final gammas) the drop-in model's logits (relative L2 over the batch), loss and
     global gradient norm agree with the fp32 oracle -- and with the numbers the unmodified reference produced -- to 1e-3."""
@@ -227,13 +342,15 @@ def check_well_conditioned(name, device, tol=1e-3, loss_scale=1.0):
     model, sd, inputs, labels, o_logits, o_loss, o_grads, o_stats = oracle_run(gold, cfg)
     model.load_state_dict(sd)
     model = model.to(device).train()
-    logits = _forward(model, inputs, device)
-    loss = _loss(logits, labels, inputs)
-    (loss * loss_scale).backward()
+    fam = family(cfg)
+    logits, loss, table = _engine_run(model, inputs, labels, device, loss_scale, capture=fam is video_ref)
     lg = logits.detach().float().cpu()
     grads = {k: p.grad.detach().float().cpu() / loss_scale for k, p in model.named_parameters()}
     gn, ogn = float(video_ref.grad_norm(grads)), float(video_ref.grad_norm(o_grads))
     g_logits = torch.tensor(gold["logits"])
+    kw = {"bboxes": inputs.bboxes} if isinstance(inputs, _WithBoxes) else {}
+    gg_masked, gg_bound, gg_yard = masked_grad_global(fam, sd, cfg, inputs, labels, table, grads, tol_global, **kw) if table \
+        else (None, tol_global, None)
     res = {
         "logits_l2": float((lg - o_logits).norm() / o_logits.norm()),
         "logits_max": float((lg - o_logits).abs().max() / o_logits.abs().max()),
@@ -244,15 +361,22 @@ def check_well_conditioned(name, device, tol=1e-3, loss_scale=1.0):
         "golden_grad_norm": abs(gn - gold["grad_norm"]) / gold["grad_norm"],
         "grad_global": _global_rel(grads, o_grads),
     }
-    _record(name, device, dict(res, bounds={k: tol for k in ("logits_l2", "loss", "grad_norm")}, yardstick_kind="none (1e-3)"))
+    res["grad_global_masked"] = res["grad_global"] if gg_masked is None else gg_masked
+    res["masked_modules"] = len(table) if table else 0
+    res["grad_global_storage_model"] = gg_yard
+    _record(name, device, dict(res, bounds=dict({k: tol for k in ("logits_l2", "loss", "grad_norm")},
+                                                grad_global_masked=gg_bound), yardstick_kind="none (1e-3)"))
     for k in ("logits_l2", "loss", "grad_norm", "golden_logits_l2", "golden_loss", "golden_grad_norm"):
         assert res[k] <= tol, (k, res)
-    assert res["logits_max"] <= 3 * tol, res        # worst single logit of the batch (a maximum over 80 values)
+    assert res["logits_max"] <= 2 * tol, res        # worst single logit of the batch (a maximum over 80 values)
+    # the gradient VECTOR (not only its norm): every parameter gradient against the oracle's backward through the engine's
+    # own ReLU masks / max-pool routes (families without either: the plain comparison)
+    assert res["grad_global_masked"] <= gg_bound, res
     return res
 
 
 def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99, tol=1e-3, loss_scale=64.0,
-                    gamma_scale=0.05, head_abs=True, tol_logits=None):
+                    gamma_scale=0.05, head_abs=True, tol_logits=None, tol_global=TOL_GRAD_GLOBAL):
     """A BASELINE config at FULL clip size (every layer geometry of the real model), batch 2, against the fp32 CPU oracle:
     logits (relative L2), loss and global gradient norm to 1e-3 with no yardstick.  Conditioning as in the "*_wc" golden
     cases: damped block-final BatchNorm gammas, non-negative classifier weights (oracle/make_golden.py explains both);
@@ -277,21 +401,27 @@ def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99,
         kw["bboxes"] = bboxes
     o_logits, o_loss, o_grads, _ = fam.loss_and_grads(sd, cfg, list(inputs), labels, **kw)
     model = model.to(device).train()
-    logits = _forward(model, inputs, device)
-    loss = _loss(logits, labels, inputs)
-    (loss * loss_scale).backward()
+    logits, loss, table = _engine_run(model, inputs, labels, device, loss_scale, capture=fam is video_ref)
     lg = logits.detach().float().cpu()
     grads = {k: p.grad.detach().float().cpu() / loss_scale for k, p in model.named_parameters()}
+    del model
     gn, ogn = float(video_ref.grad_norm(grads)), float(video_ref.grad_norm(o_grads))
     res = {"logits_l2": float((lg - o_logits).norm() / o_logits.norm()),
            "logits_max": float((lg - o_logits).abs().max() / o_logits.abs().max()),
            "loss": abs(float(loss.detach()) - float(o_loss)) / max(1.0, abs(float(o_loss))),
            "grad_norm": abs(gn - ogn) / ogn, "grad_global": _global_rel(grads, o_grads)}
-    _record(preset + "@full", device, dict(res, bounds={k: tol for k in ("logits_l2", "loss", "grad_norm")},
+    res["grad_global_masked"], gg_bound, res["grad_global_storage_model"] = \
+        masked_grad_global(fam, sd, cfg, inputs, labels, table, grads, tol_global, **kw) if table \
+        else (res["grad_global"], tol_global, None)
+    res["masked_modules"] = len(table) if table else 0
+    _record(preset + "@full", device, dict(res, bounds=dict({k: tol for k in ("logits_l2", "loss", "grad_norm")},
+                                                            logits_max=2 * tol, grad_global_masked=gg_bound),
                                            yardstick_kind="none (1e-3)"))
     for k in ("logits_l2", "loss", "grad_norm"):
         bound = (tol_logits or tol) if k == "logits_l2" else tol
         assert res[k] <= bound, (k, res)
+    assert res["logits_max"] <= 2 * (tol_logits or tol), res
+    assert res["grad_global_masked"] <= gg_bound, res
     return res
 
 

@@ -25,3 +25,18 @@ def test_fuse_fast_to_slow(sim):
 
 def test_bottleneck_transform_standalone(sim):
     bc.check_bottleneck_alone(sim, (2, 16, 2, 8, 8))
+
+
+def test_x3d_block_masks_handed(sim):
+    bc.check_x3d_block(sim, 24, 48, 2, 108, (4, 24, 4, 16, 16))              # projection shortcut, stride 2, SE block
+    bc.check_x3d_block(sim, 48, 48, 1, 108, (4, 48, 4, 8, 8), block_idx=1)   # identity shortcut, no SE
+
+
+def test_nonlocal_block_routes_handed(sim):
+    bc.check_nonlocal(sim, 64, 32, [1, 2, 2], (4, 64, 4, 8, 8), "softmax")
+    bc.check_nonlocal(sim, 64, 32, [1, 2, 2], (4, 64, 4, 8, 8), "dot_product")
+
+
+def test_multiscale_block(sim):
+    bc.check_multiscale_block(sim, 96, 192, 2, (2, 8, 8), (1, 2, 2), (1, 2, 2))      # dim change + q pooling + max-pooled skip
+    bc.check_multiscale_block(sim, 96, 96, 1, (2, 8, 8), (1, 1, 1), (1, 4, 4))
