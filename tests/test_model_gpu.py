@@ -51,6 +51,11 @@ def test_blocks_strict_x3d_nonlocal_mvit(gpu):
 @pytest.mark.parametrize("name", ["slowfast_r50_mid", "c2d_r50_mid", "i3d_r50_mid"])
 @pytest.mark.parametrize("loss_scale", [1.0, 256.0])
 def test_model_matches_reference(gpu, name, loss_scale):
+    """Full-width R50 models on small clips, batch 2: ILL-CONDITIONED cases (a few dozen samples under the deep BatchNorms; the
+    reference under autocast deviates by 2e-2 on the logits and ~0.7 on the gradient vector here).  What these assert is the
+    LOGITS / LOSS / running statistics against the oracle and the golden numbers; their gradient bounds (grad_global ~1.0,
+    param-worst ~2.3 = 1.5 x the reference-under-autocast figures) cannot fail on a gradient defect -- gradients are
+    constrained by the kernel checks, the mask-handed block checks and the well-conditioned / full-size cases below."""
     rep = {}
     try:
         mc.check_engine(name, gpu, loss_scale=loss_scale, tol_logits=4e-3, tol_loss=1e-3, tol_gnorm=1e-3,
@@ -61,6 +66,8 @@ def test_model_matches_reference(gpu, name, loss_scale):
 
 @pytest.mark.parametrize("name", ["slowfast_tiny", "c2d_tiny", "slow_tiny"])
 def test_tiny_wiring(gpu, name):
+    """Wiring tests (module tree, shapes, every option path executes, finite values, logits / loss in the right place): tiny
+    models whose bounds are far too wide to say anything about gradient accuracy -- see test_model_matches_reference."""
     mc.check_engine(name, gpu, tol_logits=0.15, tol_loss=0.02, tol_gnorm=0.35, tol_param=2.0, tol_stats=0.05)
 
 
@@ -96,11 +103,10 @@ FULL_SIZE = {
     # BASELINE.json configs 2-5 at their full clip size, batch 2
     "SLOWFAST_8x8_R50": dict(opts=[]),
     "X3D_M": dict(opts=[]),
-    # MViT: loss and gradient norm to 1e-3; the logits to 2e-3 -- the class token is stored in fp16 (2^-11 per element) and
-    # the classifier is a cancelling sum over its 768 LayerNorm-ed (signed) features, |w|.|f| / |logit| ~ 2-3 (measured:
-    # 1.15e-3, with grad_global 0.4 %)
-    "MVITv2_S_16x4": dict(opts=["MVIT.DROPPATH_RATE", 0.0, "MIXUP.ENABLE", False], gamma_scale=None, head_abs=False,
-                          tol_logits=2e-3),
+    # MViT: loss, gradient norm and gradient vector as everywhere; logits 1e-3 or, above that, no worse than the oracle's own
+    # fp16 storage model on the same logits (check_full_size: 1.26e-3 for the model, 1.15e-3 measured for the engine; the
+    # rounding is spread over every block and tensor class -- profiles/r3_mvit_logits_bisect.md)
+    "MVITv2_S_16x4": dict(opts=["MVIT.DROPPATH_RATE", 0.0, "MIXUP.ENABLE", False], gamma_scale=None, head_abs=False),
     "SLOWFAST_32x2_R101_50_50": dict(opts=["DATA.TRAIN_CROP_SIZE", 256], boxes_per_clip=3, head_abs=False),
 }
 
@@ -109,7 +115,8 @@ FULL_SIZE = {
 def test_full_size_batch2_against_oracle(gpu, preset):
     """Every layer geometry of BASELINE configs 2 (SlowFast-8x8-R50 32x224^2), 3 (X3D-M 16x224^2), 4 (MViTv2-S 16x224^2) and
     5 (SlowFast-R101 + Nonlocal + the AVA RoI head, 32x256^2, 3 boxes per clip, BCE) at batch 2 against the CPU oracle:
-    logits, loss and gradient norm to 1e-3, no yardstick (reference yamls: configs/Kinetics/{SLOWFAST_8x8_R50,X3D_M,
+    logits, loss and gradient norm to 1e-3, no yardstick; worst single logit 2e-3; the gradient VECTOR to 5e-3 against the
+    oracle's backward through the engine's own ReLU masks / max-pool routes (reference yamls: configs/Kinetics/{SLOWFAST_8x8_R50,X3D_M,
     MVITv2_S_16x4}.yaml, configs/AVA/c2/SLOWFAST_32x2_R101_50_50.yaml)."""
     print(preset, mc.check_full_size(preset, gpu, **FULL_SIZE[preset]))
 
