@@ -61,6 +61,8 @@ ENTRY_KERNELS = {
     "sf_bn_act": ("sf_bn_act_kernel",), "sf_dwconv_fwd": ("sf_dwconv_fwd",), "sf_dwconv_dgrad": ("sf_dwconv_dgrad",),
     "sf_dwconv_wgrad": ("sf_dwconv_wgrad",), "sf_softmax_fwd": ("sf_softmax_fwd_kernel",),
     "sf_softmax_bwd": ("sf_softmax_bwd_kernel",),
+    "sf_attn_fwd": ("sf_attn_fwd_kernel",),
+    "sf_attn_bwd": ("sf_attn_bwd_dq_kernel", "sf_attn_reduce_kernel", "sf_attn_bwd_dkv_kernel"),
 }
 
 
@@ -417,11 +419,13 @@ def main():
     # BASELINE.json's metric names two models: the default single-GPU run appends the second one (MViTv2-S 16x224^2, batch
     # 32) measured the same way in the same process, so that the driver's line carries both
     if a.preset == "SLOWFAST_8x8_R50" and world == 1 and not a.no_secondary and a.batch == 32:
+        a.cpu_baseline_timeout = min(a.cpu_baseline_timeout, 150.0)     # the second model's CPU sample is bounded harder
         sec = run_preset(a, "MVITv2_S_16x4", 32, min(a.steps, 10), min(a.warmup, 3), rank, local, world, dev,
-                         kernel_profile=not a.no_kernel_profile, cpu_base=False)
+                         kernel_profile=not a.no_kernel_profile, cpu_base=not a.no_cpu_baseline)
         if out is not None and sec is not None:
             out["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config",
-                                                    "model_roofline", "roofline", "kernels", "final_loss") if k in sec}
+                                                    "model_roofline", "roofline", "kernels", "final_loss", "cpu_baseline")
+                                if k in sec}
             out["secondary"]["preset"] = "MVITv2_S_16x4"
     if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)

@@ -98,6 +98,24 @@ class _MaxPoolRouted(torch.autograd.Function):
         return dx.reshape(ctx.in_shape), None, None, None, None
 
 
+class _AmaxRouted(torch.autograd.Function):
+    """x.amax(-1) in forward; the backward sends the gradient to the element ``index`` names instead of to the arg-max (the
+    RoI head's max over the ROIAlign bins, head_helper.py:97 MaxPool2d(resolution); see _MaxPoolRouted)."""
+
+    @staticmethod
+    def forward(ctx, x, index):
+        ctx.save_for_backward(index)
+        ctx.n = x.shape[-1]
+        return x.amax(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        dx = torch.zeros(tuple(g.shape) + (ctx.n,), dtype=g.dtype, device=g.device)
+        dx.scatter_(-1, index.unsqueeze(-1), g.unsqueeze(-1))
+        return dx, None
+
+
 def _max_pool(x, kernel, stride, padding, masks=None, key="pool_route"):
     if masks is not None and masks.get(key) is not None:
         return _MaxPoolRouted.apply(x, tuple(kernel), tuple(stride), tuple(padding), masks[key])
@@ -386,10 +404,14 @@ def roi_head(x, sd, cfg, bboxes, training):
     pathway, concat, (dropout off), Linear, activation (applied in training too)."""
     res = cfg.DETECTION.ROI_XFORM_RESOLUTION
     pooled = []
-    for v in x:
+    handed = _handed("head", None)
+    for p, v in enumerate(x):
         m = _STORE(v).mean(2)                                    # AvgPool3d([T, 1, 1]) + squeeze
         r = roi_align(m, bboxes, (res, res), 1.0 / cfg.DETECTION.SPATIAL_SCALE_FACTOR, 0, cfg.DETECTION.ALIGNED)
-        pooled.append(r.amax((2, 3)))
+        if handed is not None and handed.get(f"roi_bin{p}") is not None:      # tests only: the engine's arg-max bins
+            pooled.append(_AmaxRouted.apply(r.flatten(2), handed[f"roi_bin{p}"]))
+        else:
+            pooled.append(r.amax((2, 3)))
     z = torch.cat(pooled, 1)
     z = F.linear(z, sd["head.projection.weight"], sd["head.projection.bias"])
     return torch.sigmoid(z) if cfg.MODEL.HEAD_ACT == "sigmoid" else F.softmax(z, dim=1)

@@ -38,7 +38,62 @@ struct IgemmParams {
     int resid_row0;     // the residual is added to rows >= resid_row0 only (pooled attention: not to the cls row)
     const uint8_t* resid_bits;  // optional [M][Nout/8] bit mask: residual element (m, c) counts only when its bit is set
     float alpha;        // accumulators are scaled by alpha before bias / residual (0 means 1)
+    // Fused BatchNorm-backward reduction (data gradients of a convolution whose INPUT was relu(bn(bnb_y)), engine.ResBlockFn):
+    // the tile this workgroup stores IS the gradient dz w.r.t. that activation, so the per-channel sums sf_bn_bwd_reduce would
+    // make in a separate pass over dz and y -- sum g and sum g * y with g = dz masked by (y * scale + shift > 0) -- are taken
+    // here from the stored (fp16-rounded) values: one read of the y tile instead of a pass over dz AND y, one launch less.
+    // bnb_part[mt][2][Nout] gets one row per M tile (fixed summation order: deterministic); nullptr = off.
+    const f16* bnb_y; int bnb_ld;
+    const float* bnb_scale; const float* bnb_shift;
+    float* bnb_part;
 };
+
+// g = dz masked by the producer's ReLU (same expression as masked_grad8 / sf_bn_bwd_apply use), accumulated per channel
+__device__ __forceinline__ void bnb_accumulate(const f16x8& dz, const f16x8& yv, const float (&sc)[8], const float (&sh)[8],
+                                               float (&sg)[8], float (&sgy)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float g = ((float)yv[e] * sc[e] + sh[e] > 0.f) ? (float)dz[e] : 0.f;
+        sg[e] += g;
+        sgy[e] += g * (float)yv[e];
+    }
+}
+
+// Workgroup reduction of the per-thread 8-channel sums of the store loop (thread t keeps column group t % CG): butterfly over
+// the lanes of a wave that share a group, waves through LDS in a fixed order, one partial-table row [2][Nout] per M tile.
+template <int NW, int CG>
+__device__ __forceinline__ void bnb_reduce_store(float (&sg)[8], float (&sgy)[8], float* red, float* prow, int n0, int Nout) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        for (int mask = CG; mask < 64; mask <<= 1) {
+            sg[e] += __shfl_xor(sg[e], mask);
+            sgy[e] += __shfl_xor(sgy[e], mask);
+        }
+    __syncthreads();                                   // every thread is done with the staging buffer `red` overlays
+    if (lane < CG) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(wave * CG + lane) * 16 + e] = sg[e];
+            red[(wave * CG + lane) * 16 + 8 + e] = sgy[e];
+        }
+    }
+    __syncthreads();
+    if (tid < CG * 8) {
+        const int cgi = tid >> 3, e = tid & 7;
+        const int col = n0 + cgi * 8 + e;
+        if (col < Nout) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                s += red[(w * CG + cgi) * 16 + e];
+                q += red[(w * CG + cgi) * 16 + 8 + e];
+            }
+            prow[col] = s;
+            prow[Nout + col] = q;
+        }
+    }
+}
 
 // GL = plain-GEMM operands (1x1x1 unit-stride convolutions without a fused input BatchNorm, linear layers, attention
 // products; K a multiple of 32) are copied global -> LDS directly (global_load_lds_dwordx4): no staging registers, no
@@ -351,6 +406,12 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
         }
     }
     constexpr int CG = BN / 8;
+    static_assert(SF_THREADS % CG == 0 && 64 % CG == 0, "a thread keeps one column group over the whole store loop");
+    const bool bnb = p.bnb_part != nullptr;
+    float bsg[8], bsgy[8], bsc[8], bsh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
+    if (bnb && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
     for (int idx = tid; idx < BM * CG; idx += SF_THREADS) {
         const int row = idx / CG, cg = idx % CG;
         const int m = m0 + row, col = n0 + cg * 8;
@@ -382,8 +443,10 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
                 for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
                 st16(p.act_aux + (int64_t)m * p.ld_aux + col, a);
             }
+            if (bnb) bnb_accumulate(v, ld16(p.bnb_y + (int64_t)m * p.bnb_ld + col), bsc, bsh, bsg, bsgy);
         }
     }
+    if (bnb) bnb_reduce_store<4, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -70,6 +70,11 @@ struct Igemm2Params {
     // ((n*oT + a*omT + ooT)*oH + b*omH + ooH)*oW + c*omW + ooW of y / resid.  omap == 0: rows are stored densely.
     int omap;
     int oT, oH, oW, omT, omH, omW, ooT, ooH, ooW;
+    // fused BatchNorm-backward reduction (data gradients only; see IgemmParams): per-tile column sums of g and g * bnb_y,
+    // g = stored output masked by (bnb_y * bnb_scale + bnb_shift > 0), into bnb_part[mt][2][Nout]
+    const f16* bnb_y; int bnb_ld;
+    const float* bnb_scale; const float* bnb_shift;
+    float* bnb_part;
 };
 
 // LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase
@@ -293,6 +298,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
         }
     }
     constexpr int CG = BN / 8;
+    static_assert(NT % CG == 0 && 64 % CG == 0, "a thread keeps one column group over the whole store loop");
+    const bool bnb = p.bnb_part != nullptr;
+    float bsg[8], bsgy[8], bsc[8], bsh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
+    if (bnb && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
     for (int idx = tid; idx < BM * CG; idx += NT) {
         const int row = idx / CG, cg = idx % CG;
         const int mr = m0 + row, col = n0 + cg * 8;
@@ -325,6 +336,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
                 st16(p.act_aux + (int64_t)m * p.ld_aux + col, a);
             }
+            if (bnb) bnb_accumulate(v, ld16(p.bnb_y + (int64_t)m * p.bnb_ld + col), bsc, bsh, bsg, bsgy);
         }
     }
+    if (bnb) bnb_reduce_store<NW, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);
 }

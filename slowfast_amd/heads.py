@@ -6,7 +6,7 @@ mean in eval.  It runs on torch fp32 ops over the (tiny) res5 outputs."""
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import engine, ops
 from .lib import get_lib
 
 
@@ -82,6 +82,7 @@ class _RoiPoolFn(torch.autograd.Function):
                  rois.data_ptr(), out.data_ptr(), C, 0, arg.data_ptr(), s, work=dict(bytes=4.0 * R * C * res * res))
         ctx.geom = (N, C, T, H, W, res, float(scale), int(bool(aligned)))
         ctx.save_for_backward(rois, arg)
+        ctx.arg_bins = arg            # test hook: the arg-max bin of every (roi, channel), see ResNetRoIHead.forward
         return out
 
     @staticmethod
@@ -134,6 +135,8 @@ class ResNetRoIHead(nn.Module):
             res = self.resolution[p]
             assert res[0] == res[1]
             pooled.append(_RoiPoolFn.apply(x, bboxes, int(res[0]), 1.0 / self.scale_factor[p], self.aligned))
+            if engine.CAPTURE is not None and pooled[-1].grad_fn is not None:
+                engine.CAPTURE.append({"kind": "roi_pool", "mod": self, "pathway": p, "argmax": pooled[-1].grad_fn.arg_bins})
         x = torch.cat(pooled, 1)
         if hasattr(self, "dropout"):
             x = self.dropout(x)

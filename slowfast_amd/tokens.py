@@ -394,7 +394,10 @@ def attn_bwd(d, q, k, v, scale, rq, residual, o, do, lse, onehot=None, dq_out=No
     drq = torch.empty(rq.shape, dtype=torch.float32, device=q.device) if rq is not None else None
     nbytes = _lib_call("sf_attn_bwd_workspace", byref(d))
     ws = _workspace(q.device, nbytes) if nbytes > 0 else None
-    flops = 14.0 * B * d.heads * Nq * d.Nk * d.D
+    # ALGORITHMIC flops of the attention backward: dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q -> 8 * Nq * Nk * D per
+    # (batch, head).  The two kernels (query side, key side) each recompute S and dP on top of that (14 executed); the
+    # roofline fraction bench.py reports is priced on the algorithmic count.
+    flops = 8.0 * B * d.heads * Nq * d.Nk * d.D
     _lib_call("sf_attn_bwd", byref(d), q.data_ptr(), rows_pitch(q)[2], k.data_ptr(), v.data_ptr(), rows_pitch(k)[2],
               float(scale), _ptr(rq), _ptr(onehot), int(bool(residual)), o.data_ptr(), do.data_ptr(), rows_pitch(o)[2],
               lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), rows_pitch(dq)[2], dk.data_ptr(), dv.data_ptr(), rows_pitch(dk)[2],

@@ -126,6 +126,18 @@ def _global_rel(grads, ref):
     return (num / den) ** 0.5
 
 
+def _worst_contributors(grads, ref, top=8):
+    """[(parameter, share of the squared global error, own relative error)] of the largest contributors to grad_global."""
+    tot = sum(float(g.double().pow(2).sum()) for g in ref.values())
+    rows = []
+    for k, g in ref.items():
+        e = float((grads[k].double() - g.double()).pow(2).sum())
+        rows.append((e / tot, k, float((grads[k] - g).norm() / (g.norm() + 1e-12))))
+    rows.sort(reverse=True)
+    err = sum(r[0] for r in rows)
+    return [(k, round(s / max(err, 1e-300), 4), round(r, 5)) for s, k, r in rows[:top]]
+
+
 def _param_worst(grads, ref, ogn):
     worst, worst_k = 0.0, None
     for k, g in ref.items():
@@ -233,6 +245,8 @@ def engine_masks(model, caps):
                            "out": (c["out"] > 0)[:, :t.c.out_channels].cpu().contiguous()}
             if c.get("se_h") is not None:       # the squeeze-excitation's own ReLU (N x dim_fc units)
                 table[name]["se"] = (c["se_h"] > 0).cpu().view(c["se_h"].shape[0], -1, 1, 1, 1)
+        elif kind == "roi_pool":        # ResNetRoIHead: arg-max bin of every (roi, channel) of one pathway
+            table.setdefault(name, {})["roi_bin%d" % c["pathway"]] = c["argmax"].long().cpu()
         elif kind == "x3d_head":
             table.setdefault(name, {})["conv_5"] = _premask(c["raw"][0], *c["bn"][0], channels=c["mod"].conv_5.out_channels)
         elif kind == "x3d_lin5":        # (N, dim_out) fp32 pre-activations of the head's second ReLU: few units, each one
@@ -414,6 +428,7 @@ def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99,
         masked_grad_global(fam, sd, cfg, inputs, labels, table, grads, tol_global, **kw) if table \
         else (res["grad_global"], tol_global, None)
     res["masked_modules"] = len(table) if table else 0
+    res["worst_params_unmasked"] = _worst_contributors(grads, o_grads)
     _record(preset + "@full", device, dict(res, bounds=dict({k: tol for k in ("logits_l2", "loss", "grad_norm")},
                                                             logits_max=2 * tol, grad_global_masked=gg_bound),
                                            yardstick_kind="none (1e-3)"))
