@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 17
+#define SF_ABI_VERSION 18
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -81,6 +81,17 @@ int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const void* wf, cons
  * materialising it. */
 int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
                   const void* resid_bits, void* dx, sf_stream_t stream);
+/* sf_conv_dgrad + the reduction pass of the BatchNorm backward that consumes dx (round 3).  When this convolution's INPUT
+ * was relu(bn(bn_y)) (BottleneckTransform b / c reading relu(a_bn(a(x))) / relu(b_bn(b(..))), resnet_helper.py:377-392), the
+ * gradient dx it stores is dz of that BatchNorm-ReLU, whose backward first needs the per-channel sums of g and g * bn_y,
+ * g = dz masked by (bn_y * bn_scale + bn_shift > 0) (sf_bn_bwd_reduce).  The epilogue takes them from the stored fp16 tile:
+ * bn_part[row][2][Ci] fp32, one row per M tile of the kernel that ran (deterministic order); *bn_rows = rows written, to be
+ * passed to sf_bn_bwd_finalize as nblk -- or 0 when the geometry keeps the separate pass (strided data gradients), in which
+ * case bn_part is untouched and the caller runs sf_bn_bwd_reduce.  bn_part must hold ceil(positions / 128) rows
+ * (bn_part_rows); bn_rows is a HOST pointer. */
+int sf_conv_dgrad_bn(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
+                     const void* resid_bits, void* dx, const void* bn_y, int32_t bn_ldy, const float* bn_scale,
+                     const float* bn_shift, float* bn_part, int32_t bn_part_rows, int32_t* bn_rows, sf_stream_t stream);
 /* Thin layers -- at most 32 output columns and a contraction (taps x channels of the gathered operand) of at most 128, the
  * Fast pathway's 8-32 channel bottlenecks: a streaming kernel (independent waves, weights in registers) that reads positions
  * from the geometry's row table.  dgrad = 0: forward (plain input, optional bias, optional BatchNorm partial sums);

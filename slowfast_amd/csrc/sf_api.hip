@@ -220,6 +220,7 @@ static void igemm2_common(Igemm2Params& q, const IgemmParams& p) {
     q.y = p.y; q.ldy = p.ldy; q.bias = p.bias; q.resid = p.resid; q.ldr = p.ldr; q.stat_part = p.stat_part;
     q.act_mode = p.act_mode; q.act_aux = p.act_aux; q.ld_aux = p.ld_aux; q.resid_row0 = p.resid_row0; q.alpha = p.alpha;
     q.resid_bits = p.resid_bits;
+    q.bnb_y = p.bnb_y; q.bnb_ld = p.bnb_ld; q.bnb_scale = p.bnb_scale; q.bnb_shift = p.bnb_shift; q.bnb_part = p.bnb_part;
 }
 static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     // read on every call (three getenv per launch are noise): tests lower the thresholds for single cases
@@ -326,9 +327,13 @@ static bool try_igemm2_strided_dgrad(const IgemmParams& p, hipStream_t s) {
     return true;
 }
 
-static int run_igemm(IgemmParams& p, bool pw, hipStream_t s) {
+// bm_used: rows per M tile of the kernel that ran (= rows one bnb_part row covers); 0 for the residue-class launches
+static int run_igemm(IgemmParams& p, bool pw, hipStream_t s, int* bm_used = nullptr) {
+    if (bm_used) *bm_used = 256;
     if (try_igemm2(p, s)) return check_launch("igemm2");
+    if (bm_used) *bm_used = 0;
     if (try_igemm2_strided_dgrad(p, s)) return check_launch("igemm2 strided dgrad");
+    if (bm_used) *bm_used = 128;
     if (p.Nout > 64) { p.ntiles_n = cdiv(p.Nout, 128); launch_igemm<128, 64, 64>(p, pw, s); }
     else if (p.Nout > 32) { p.ntiles_n = 1; launch_igemm<64, 32, 64>(p, pw, s); }
     else if (p.Nout > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, pw, s); }
@@ -512,8 +517,9 @@ extern "C" int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const voi
     return run_igemm(p, is_pointwise(d), (hipStream_t)stream);
 }
 
-extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
-                             const void* resid_bits, void* dx, sf_stream_t stream) {
+static int conv_dgrad_impl(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
+                           const void* resid_bits, void* dx, const void* bn_y, int32_t bn_ldy, const float* bn_scale,
+                           const float* bn_shift, float* bn_part, int32_t* bn_rows, sf_stream_t stream) {
     if (check_desc(d)) return -1;
     REQUIRE(dy && wd && dx, "sf_conv_dgrad: null pointer");
     REQUIRE(!resid || (ldr >= d->Ci && ldr % 8 == 0), "sf_conv_dgrad: bad residual pitch");
@@ -529,7 +535,32 @@ extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* 
     p.resid = (const f16*)resid; p.ldr = ldr;
     REQUIRE(!resid_bits || resid, "sf_conv_dgrad: resid_bits without a residual");
     p.resid_bits = (const uint8_t*)resid_bits;
-    return run_igemm(p, is_pointwise(d), (hipStream_t)stream);
+    // the fused BatchNorm-backward reduction rides on dense stride-1 data gradients only (a strided one runs as one launch
+    // per residue class of input positions, or gathers with 3/4 of its taps masked): the caller then keeps sf_bn_bwd_reduce
+    const bool fuse = bn_part && d->sT == 1 && d->sH == 1 && d->sW == 1;
+    if (fuse) {
+        p.bnb_y = (const f16*)bn_y; p.bnb_ld = bn_ldy; p.bnb_scale = bn_scale; p.bnb_shift = bn_shift; p.bnb_part = bn_part;
+    }
+    int bm = 0;
+    const int rc = run_igemm(p, is_pointwise(d), (hipStream_t)stream, &bm);
+    if (bn_rows) *bn_rows = (fuse && bm > 0) ? cdiv(p.M, bm) : 0;
+    return rc;
+}
+
+extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
+                             const void* resid_bits, void* dx, sf_stream_t stream) {
+    return conv_dgrad_impl(d, dy, wd, resid, ldr, resid_bits, dx, nullptr, 0, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int sf_conv_dgrad_bn(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
+                                const void* resid_bits, void* dx, const void* bn_y, int32_t bn_ldy, const float* bn_scale,
+                                const float* bn_shift, float* bn_part, int32_t bn_part_rows, int32_t* bn_rows,
+                                sf_stream_t stream) {
+    REQUIRE(d && bn_y && bn_scale && bn_shift && bn_part && bn_rows, "sf_conv_dgrad_bn: null pointer");
+    REQUIRE(bn_ldy >= d->Ci && bn_ldy % 8 == 0 && ((uintptr_t)bn_y & 15) == 0, "sf_conv_dgrad_bn: bad bn_y pitch / alignment");
+    REQUIRE((int64_t)bn_part_rows * 128 >= (int64_t)d->N * d->Ti * d->Hi * d->Wi,
+            "sf_conv_dgrad_bn: bn_part needs ceil(rows / 128) rows of [2][Ci] floats");
+    return conv_dgrad_impl(d, dy, wd, resid, ldr, resid_bits, dx, bn_y, bn_ldy, bn_scale, bn_shift, bn_part, bn_rows, stream);
 }
 
 template <int BMW, int WM, int WN, int KS>

@@ -42,6 +42,10 @@ PACK_PLAN = os.environ.get("SF_PACK_PLAN", "1") != "0"
 # Intermediate activations of a block (relu(bn_a(ya)), relu(bn_b(yb))) are materialised in fp16 (default) or recomputed
 # in the consumer's operand loads (SF_MATERIALIZE=0, the round-1 schedule; kept for A/B runs).
 MATERIALIZE = os.environ.get("SF_MATERIALIZE", "1") != "0"
+# The reduction pass of an inner BatchNorm's backward (sums of g and g * y) is taken in the epilogue of the data gradient that
+# PRODUCES its input gradient (ops.conv_dgrad(..., bn=...)): one read of the y tile instead of a pass over dz and y, one launch
+# less per inner BatchNorm.  SF_BN_FUSE_REDUCE=0 keeps the separate sf_bn_bwd_reduce pass (A/B).
+BN_FUSE_REDUCE = os.environ.get("SF_BN_FUSE_REDUCE", "1") != "0"
 # Backward segmentation (slowfast_amd.step.TrainStep): models call cut() on the activations that cross a stage boundary.
 # Normally the identity.  While a _Segments recorder is installed the tensors are replaced by detached leaves, so that the
 # backward pass can be run -- and captured into HIP graphs -- stage by stage (head + res5 first), and the gradient all-reduce
@@ -390,8 +394,10 @@ class ConvUnit:
         y, part = ops.conv_fwd(x, wf, geom, in_affine=in_affine, bias=self.conv.bias, stats=use_batch_stats)
         return y, bn_statistics(bn, part, geom.out_rows, geom.Co, training)
 
-    def backward(self, x, in_affine, dy, need_dx, resid=None, resid_bits=None):
-        """Weight gradient into conv.weight.grad; returns dx (+ resid, masked by resid_bits when given) when need_dx."""
+    def backward(self, x, in_affine, dy, need_dx, resid=None, resid_bits=None, bn_fuse=None):
+        """Weight gradient into conv.weight.grad; returns dx (+ resid, masked by resid_bits when given) when need_dx.
+        ``bn_fuse = (y, BNState)`` of the BatchNorm-ReLU that produced x: returns (dx, part) with the reduction pass of that
+        BatchNorm's backward taken in the data gradient's epilogue (part None: not available for this geometry)."""
         geom = self.geom(x.shape)
         w = self.conv.weight
         if w.requires_grad:
@@ -406,10 +412,14 @@ class ConvUnit:
         if not need_dx:
             return None
         _, wd = self.weights(geom)
+        if bn_fuse is not None:
+            y, st = bn_fuse
+            return ops.conv_dgrad(dy, wd, geom, resid=resid, bn=(y, st.scale, st.shift))
         return ops.conv_dgrad(dy, wd, geom, resid=resid, resid_bits=resid_bits)
 
-    def bn_backward(self, dz, y, st, zmask=None, relu_self=False, want_g=False):
-        """BatchNorm3d backward (through ReLU) -> dy; writes bn.weight.grad / bn.bias.grad."""
+    def bn_backward(self, dz, y, st, zmask=None, relu_self=False, want_g=False, part=None):
+        """BatchNorm3d backward (through ReLU) -> dy; writes bn.weight.grad / bn.bias.grad.  ``part``: partial sums already
+        taken by the producer of dz (backward(..., bn_fuse=...))."""
         bn = self.bn
         if bn.weight.requires_grad:
             dgamma, zg = _grad_dest(bn.weight)
@@ -422,7 +432,7 @@ class ConvUnit:
             accumulate = False
         return ops.bn_bwd(dz, y, bn.weight, st.mean, st.rstd, dgamma, dbeta, zmask=zmask,
                           relu_affine=(st.scale, st.shift) if relu_self else None, inv_loss_scale=1.0,
-                          accumulate=accumulate, want_g=want_g, sync=_sync_of(bn))
+                          accumulate=accumulate, want_g=want_g, sync=_sync_of(bn), part=part)
 
     def params(self):
         p = [self.conv.weight]
@@ -679,11 +689,14 @@ class ResBlockFn(torch.autograd.Function):
         if P is not None:
             dy1 = P.bn_backward(dout, y1, s1, zmask=bits)
         for i in range(last, 0, -1):
-            if act[i - 1] is not None:
+            part = None
+            if act[i - 1] is not None and BN_FUSE_REDUCE and _sync_of(units[i - 1].bn) is None:
+                d_in, part = units[i].backward(act[i - 1], None, dy, need_dx=True, bn_fuse=(raw[i - 1], bn[i - 1]))
+            elif act[i - 1] is not None:
                 d_in = units[i].backward(act[i - 1], None, dy, need_dx=True)
             else:
                 d_in = units[i].backward(raw[i - 1], (bn[i - 1].scale, bn[i - 1].shift, True), dy, need_dx=True)
-            dy = units[i - 1].bn_backward(d_in, raw[i - 1], bn[i - 1], relu_self=True)
+            dy = units[i - 1].bn_backward(d_in, raw[i - 1], bn[i - 1], relu_self=True, part=part)
         if P is not None:
             dx1 = P.backward(x, None, dy1, need_dx=need_dx)
             dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=dx1)

@@ -229,9 +229,27 @@ def conv_fwd_fused(x, wf, geom, bias=None, resid=None, relu=False, out=None):
     return y
 
 
-def conv_dgrad(dy, wd, geom, resid=None, out=None, resid_bits=None):
+def conv_dgrad(dy, wd, geom, resid=None, out=None, resid_bits=None, bn=None):
     """dx = conv_transpose3d(dy, w) [+ resid].  ``resid_bits``: the bit mask bn_act(..., want_mask=True) wrote for the
-    tensor ``resid`` is the gradient of; only residual elements whose bit is set are added."""
+    tensor ``resid`` is the gradient of; only residual elements whose bit is set are added.
+
+    ``bn = (y, scale, shift)``: this convolution's input was relu(bn(y)); the kernel epilogue then also takes the reduction
+    pass of that BatchNorm's backward (sums of g and g * y over the positions, g = dx masked by the ReLU) from the tile it
+    stores.  Returns (dx, part) with part [rows, 2, Ci] fp32 for bn_bwd(..., part=part) -- or (dx, None) when the geometry
+    keeps the separate pass (strided data gradients)."""
+    if bn is not None:
+        y, sc, sh = bn
+        assert tuple(y.shape) == geom.in_shape and resid_bits is None
+        dx = cl_empty(geom.in_shape, dy.device) if out is None else out
+        M = rows(y)
+        cap = (M + 127) // 128
+        part = torch.empty((cap, 2, geom.Ci), dtype=torch.float32, device=dy.device)
+        nrows = c_int32(0)
+        get_lib().call("sf_conv_dgrad_bn", byref(geom.desc(cl_ld(dx), cl_ld(dy))), dy.data_ptr(), wd.data_ptr(), _ptr(resid),
+                       cl_ld(resid) if resid is not None else 0, None, dx.data_ptr(), y.data_ptr(), cl_ld(y), sc.data_ptr(),
+                       sh.data_ptr(), part.data_ptr(), cap, byref(nrows), _stream(dy),
+                       work=geom.work(reads_x=1 + int(resid is not None), reads_y=1, writes_x=1))
+        return dx, (part[:nrows.value] if nrows.value > 0 else None)
     assert tuple(dy.shape) == geom.out_shape
     ldy = cl_ld(dy)
     dx = cl_empty(geom.in_shape, dy.device) if out is None else out
@@ -377,17 +395,24 @@ def bn_act(y, scale=None, shift=None, relu=False, resid=None, rscale=None, rshif
 
 
 def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None, inv_loss_scale=1.0,
-           accumulate=False, want_g=False, out=None, sync=None):
+           accumulate=False, want_g=False, out=None, sync=None, part=None):
     """BatchNorm3d (training) backward through an optional ReLU.
 
     dz: gradient w.r.t. act(bn(y)); the ReLU mask is ``zmask > 0`` (block output) or recomputed from
-    ``relu_affine = (scale, shift)``; writes fp32 dgamma/dbeta and returns dy (and the masked g)."""
+    ``relu_affine = (scale, shift)``; writes fp32 dgamma/dbeta and returns dy (and the masked g).
+    ``part``: the [rows, 2, C] partial sums the producer of dz already took in its epilogue (conv_dgrad(..., bn=...)):
+    the reduction pass over dz and y is skipped."""
     lib = get_lib()
     N, C, T, H, W = y.shape
     M = rows(y)
     s = _stream(y)
-    nblk = lib.call("sf_bn_bwd_blocks", M, C)
-    part = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
+    fused_part = part
+    if fused_part is None:
+        nblk = lib.call("sf_bn_bwd_blocks", M, C)
+        part = torch.empty((nblk, 2, C), dtype=torch.float32, device=y.device)
+    else:
+        assert part.dtype == torch.float32 and part.is_contiguous() and tuple(part.shape[1:]) == (2, C)
+        nblk = part.shape[0]
     sc, sh = (relu_affine if relu_affine is not None else (None, None))
     relu_self = int(relu_affine is not None)
     bits = zmask is not None and zmask.dtype == torch.uint8     # the 1-bit mask of bn_act(..., want_mask=True)
@@ -395,8 +420,9 @@ def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None
         assert zmask.numel() == M * (C // 8) and zmask.is_contiguous()
     mcost = 0.0 if zmask is None else (1 / 16 if bits else 1.0)
     lddz, ldy, ldm = cl_ld(dz), cl_ld(y), (0 if bits or zmask is None else cl_ld(zmask))
-    lib.call("sf_bn_bwd_reduce", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
-             relu_self, part.data_ptr(), s, work=dict(bytes=2.0 * y.numel() * (2 + mcost)))
+    if fused_part is None:
+        lib.call("sf_bn_bwd_reduce", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
+                 relu_self, part.data_ptr(), s, work=dict(bytes=2.0 * y.numel() * (2 + mcost)))
     coef = torch.empty((3, C), dtype=torch.float32, device=y.device)
     if sync is None:
         lib.call("sf_bn_bwd_finalize", part.data_ptr(), nblk, C, gamma.numel(), float(M), gamma.data_ptr(), mean.data_ptr(),

@@ -129,6 +129,37 @@ def check_conv_dgrad(device, in_shape, Co, k, s, p, d=(1, 1, 1), resid=False, se
     return e
 
 
+def check_conv_dgrad_bn(device, in_shape, Co, k, p, d=(1, 1, 1), resid=False, seed=0):
+    """sf_conv_dgrad_bn: the data gradient is unchanged (bit for bit) and the fused epilogue's partial table sums to what
+    sf_bn_bwd_reduce computes from the STORED gradient in a separate pass: sum g and sum g * y per channel, g = dx masked by
+    (y * scale + shift > 0) -- compared against fp64 sums over the same fp16 tensors."""
+    s = (1, 1, 1)
+    x, w = make_conv_case(seed, in_shape, Co, k, s, p, d)
+    geom = ops.ConvGeom(in_shape, Co, k, s, p, d)
+    g = torch.Generator().manual_seed(seed + 2)
+    dy = torch.randn(geom.out_shape, generator=g).half().float()
+    r = torch.randn(in_shape, generator=g).half().float() if resid else None
+    ybn = torch.randn(in_shape, generator=g).half().float()                 # raw output of the producer convolution
+    sc = torch.rand(in_shape[1], generator=g) + 0.5
+    sh = torch.randn(in_shape[1], generator=g) * 0.3
+    _, wd = ops.prep_weights(w.to(device), geom)
+    dyc, rc = host_to_cl(dy, device), (host_to_cl(r, device) if resid else None)
+    base = ops.conv_dgrad(dyc, wd, geom, resid=rc)
+    dx, part = ops.conv_dgrad(dyc, wd, geom, resid=rc, bn=(host_to_cl(ybn, device), sc.to(device), sh.to(device)))
+    assert part is not None and part.shape[1:] == (2, in_shape[1])
+    assert torch.equal(cl_to_host(dx), cl_to_host(base)), "the fused epilogue must not change the stored gradient"
+    dxh = cl_to_host(dx).double()
+    mask = (ybn * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1) > 0).double()
+    gsum = (dxh * mask).sum((0, 2, 3, 4))
+    gysum = (dxh * mask * ybn.double()).sum((0, 2, 3, 4))
+    tot = part.double().sum(0).cpu()
+    scale_g = float((dxh * mask).abs().sum((0, 2, 3, 4)).max())
+    scale_gy = float((dxh * mask * ybn.double()).abs().sum((0, 2, 3, 4)).max())
+    assert float((tot[0] - gsum).abs().max()) <= 2e-6 * scale_g, (tot[0] - gsum).abs().max()
+    assert float((tot[1] - gysum).abs().max()) <= 2e-6 * scale_gy, (tot[1] - gysum).abs().max()
+    return part.shape[0]
+
+
 def check_conv_wgrad(device, in_shape, Co, k, s, p, d=(1, 1, 1), Cw=None, affine=False, out_scale=1.0, seed=0):
     x, w = make_conv_case(seed, in_shape, Co, k, s, p, d, Cw)
     geom = ops.ConvGeom(in_shape, Co, k, s, p, d, Cw=Cw)

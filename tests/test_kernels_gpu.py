@@ -235,3 +235,16 @@ def test_prep_weights_batch_equals_per_layer_gpu(gpu):
         (64, 64, 64, (1, 3, 3), True), (2048, 512, 512, (1, 1, 1), True), (8, 32, 32, (3, 1, 1), True),
         (54, 40, 40, (1, 1, 1), True), (64, 3, 8, (1, 7, 7), False), (16, 16, 16, (3, 3, 3), True),
         (512, 512, 512, (1, 3, 3), True), (8, 8, 8, (5, 11, 11), True)])
+
+
+@pytest.mark.gpu
+def test_conv_dgrad_fused_bn_reduce(gpu):
+    """sf_conv_dgrad_bn on the SlowFast-R50 inner-BatchNorm geometries: c -> b (pointwise, K = C) and b -> a (1x3x3 / 3x1x1)."""
+    assert kc.check_conv_dgrad_bn(gpu, (4, 64, 8, 56, 56), 256, (1, 1, 1), (0, 0, 0)) == 784       # res2 c: 128-row tiles
+    assert kc.check_conv_dgrad_bn(gpu, (4, 64, 8, 56, 56), 64, (1, 3, 3), (0, 1, 1)) == 392        # res2 b: igemm2, 256 rows
+    kc.check_conv_dgrad_bn(gpu, (4, 128, 8, 28, 28), 512, (1, 1, 1), (0, 0, 0))                     # res3 c: igemm2
+    kc.check_conv_dgrad_bn(gpu, (4, 256, 8, 14, 14), 256, (1, 3, 3), (0, 1, 1))
+    kc.check_conv_dgrad_bn(gpu, (4, 512, 8, 7, 7), 2048, (1, 1, 1), (0, 0, 0))
+    kc.check_conv_dgrad_bn(gpu, (4, 8, 32, 56, 56), 32, (1, 1, 1), (0, 0, 0))                       # Fast pathway c
+    kc.check_conv_dgrad_bn(gpu, (4, 8, 32, 56, 56), 8, (1, 3, 3), (0, 1, 1))
+    kc.check_conv_dgrad_bn(gpu, (4, 16, 32, 28, 28), 64, (1, 1, 1), (0, 0, 0), resid=True)

@@ -134,3 +134,17 @@ def test_prep_weights_batch_equals_per_layer(sim):
         (16, 16, 16, (3, 3, 3), True),        # 27 taps: 16-channel bricks
         (8, 8, 8, (5, 11, 11), True),         # 605 taps: does not fit a brick -> element-wise blocks
     ])
+
+
+def test_conv_dgrad_fused_bn_reduce(sim, monkeypatch):
+    """Data gradient + the reduction pass of the consumer BatchNorm's backward in one launch: both implicit-GEMM generations
+    (tile heights 128 / 256), every tile width of the first one, a 3x3 with padding, a residual, ragged last tiles."""
+    assert kc.check_conv_dgrad_bn(sim, (2, 64, 2, 9, 9), 256, (1, 1, 1), (0, 0, 0)) == 3           # 324 rows / 128
+    assert kc.check_conv_dgrad_bn(sim, (2, 16, 2, 8, 8), 24, (1, 3, 3), (0, 1, 1)) == 2            # BN = 16 tile
+    kc.check_conv_dgrad_bn(sim, (2, 32, 2, 8, 8), 64, (3, 1, 1), (1, 0, 0), resid=True)
+    kc.check_conv_dgrad_bn(sim, (1, 8, 4, 8, 8), 32, (1, 1, 1), (0, 0, 0))
+    kc.check_conv_dgrad_bn(sim, (2, 128, 2, 8, 8), 128, (1, 1, 1), (0, 0, 0))                       # two column tiles
+    monkeypatch.setenv("SF_IGEMM2_MINK", "64")
+    monkeypatch.setenv("SF_IGEMM2_MINROWS", "64")
+    assert kc.check_conv_dgrad_bn(sim, (2, 64, 2, 9, 9), 64, (1, 3, 3), (0, 1, 1)) == 2            # igemm2: 324 rows / 256
+    kc.check_conv_dgrad_bn(sim, (2, 64, 2, 8, 8), 128, (1, 1, 1), (0, 0, 0), resid=True)
