@@ -81,17 +81,23 @@ int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const void* wf, cons
  * materialising it. */
 int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
                   const void* resid_bits, void* dx, sf_stream_t stream);
-/* sf_conv_dgrad + the reduction pass of the BatchNorm backward that consumes dx (round 3).  When this convolution's INPUT
- * was relu(bn(bn_y)) (BottleneckTransform b / c reading relu(a_bn(a(x))) / relu(b_bn(b(..))), resnet_helper.py:377-392), the
- * gradient dx it stores is dz of that BatchNorm-ReLU, whose backward first needs the per-channel sums of g and g * bn_y,
- * g = dz masked by (bn_y * bn_scale + bn_shift > 0) (sf_bn_bwd_reduce).  The epilogue takes them from the stored fp16 tile:
- * bn_part[row][2][Ci] fp32, one row per M tile of the kernel that ran (deterministic order); *bn_rows = rows written, to be
- * passed to sf_bn_bwd_finalize as nblk -- or 0 when the geometry keeps the separate pass (strided data gradients), in which
- * case bn_part is untouched and the caller runs sf_bn_bwd_reduce.  bn_part must hold ceil(positions / 128) rows
- * (bn_part_rows); bn_rows is a HOST pointer. */
+/* sf_conv_dgrad + the reduction pass of the BatchNorm backward(s) that consume dx (round 3).  The gradient dx this call
+ * stores is dz of a BatchNorm-ReLU whose backward first needs the per-channel sums of g and g * y over the positions
+ * (sf_bn_bwd_reduce), g = dz under the ReLU mask.  The epilogue takes them from the fp16 tile it stores -- one read of the y
+ * tile instead of a pass over dz and y, one launch less:
+ *   - inner activations of a block (BottleneckTransform b / c reading relu(a_bn(a(x))) / relu(b_bn(b(.))),
+ *     resnet_helper.py:377-392): mask = (bn_y0 * mask_scale + mask_shift > 0), mask_bits NULL;
+ *   - a block INPUT that is the previous block's output relu(bn_c(yc) + shortcut) (resnet_helper.py:512-521): mask_bits = the
+ *     1-bit image sf_bn_act wrote for that output ([positions][Ci/8]); bn_y0 = yc, and bn_y1 = the raw output of the previous
+ *     block's projection shortcut when it has one (both BatchNorms share g).
+ * bn_partK[row][2][Ci] fp32, one row per M tile of the kernel that ran (fixed order: deterministic); *bn_rows = rows written,
+ * to be passed to sf_bn_bwd_finalize as nblk -- or 0 when the geometry keeps the separate pass (strided data gradients): the
+ * tables are then untouched and the caller runs sf_bn_bwd_reduce.  The tables hold ceil(positions / 128) rows (bn_part_rows);
+ * bn_rows is a HOST pointer. */
 int sf_conv_dgrad_bn(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
-                     const void* resid_bits, void* dx, const void* bn_y, int32_t bn_ldy, const float* bn_scale,
-                     const float* bn_shift, float* bn_part, int32_t bn_part_rows, int32_t* bn_rows, sf_stream_t stream);
+                     const void* resid_bits, void* dx, const float* mask_scale, const float* mask_shift,
+                     const void* mask_bits, const void* bn_y0, int32_t bn_ldy0, float* bn_part0, const void* bn_y1,
+                     int32_t bn_ldy1, float* bn_part1, int32_t bn_part_rows, int32_t* bn_rows, sf_stream_t stream);
 /* Thin layers -- at most 32 output columns and a contraction (taps x channels of the gathered operand) of at most 128, the
  * Fast pathway's 8-32 channel bottlenecks: a streaming kernel (independent waves, weights in registers) that reads positions
  * from the geometry's row table.  dgrad = 0: forward (plain input, optional bias, optional BatchNorm partial sums);

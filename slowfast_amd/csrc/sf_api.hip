@@ -221,6 +221,7 @@ static void igemm2_common(Igemm2Params& q, const IgemmParams& p) {
     q.act_mode = p.act_mode; q.act_aux = p.act_aux; q.ld_aux = p.ld_aux; q.resid_row0 = p.resid_row0; q.alpha = p.alpha;
     q.resid_bits = p.resid_bits;
     q.bnb_y = p.bnb_y; q.bnb_ld = p.bnb_ld; q.bnb_scale = p.bnb_scale; q.bnb_shift = p.bnb_shift; q.bnb_part = p.bnb_part;
+    q.bnb_bits = p.bnb_bits; q.bnb_y2 = p.bnb_y2; q.bnb_ld2 = p.bnb_ld2; q.bnb_part2 = p.bnb_part2;
 }
 static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     // read on every call (three getenv per launch are noise): tests lower the thresholds for single cases
@@ -517,9 +518,13 @@ extern "C" int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const voi
     return run_igemm(p, is_pointwise(d), (hipStream_t)stream);
 }
 
+struct BnFuse {     // the fused BatchNorm-backward reduction of sf_conv_dgrad_bn (all device pointers)
+    const float* scale; const float* shift; const void* bits;
+    const void* y0; int32_t ld0; float* part0;
+    const void* y1; int32_t ld1; float* part1;
+};
 static int conv_dgrad_impl(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
-                           const void* resid_bits, void* dx, const void* bn_y, int32_t bn_ldy, const float* bn_scale,
-                           const float* bn_shift, float* bn_part, int32_t* bn_rows, sf_stream_t stream) {
+                           const void* resid_bits, void* dx, const BnFuse* bn, int32_t* bn_rows, sf_stream_t stream) {
     if (check_desc(d)) return -1;
     REQUIRE(dy && wd && dx, "sf_conv_dgrad: null pointer");
     REQUIRE(!resid || (ldr >= d->Ci && ldr % 8 == 0), "sf_conv_dgrad: bad residual pitch");
@@ -537,9 +542,11 @@ static int conv_dgrad_impl(const sf_conv_desc* d, const void* dy, const void* wd
     p.resid_bits = (const uint8_t*)resid_bits;
     // the fused BatchNorm-backward reduction rides on dense stride-1 data gradients only (a strided one runs as one launch
     // per residue class of input positions, or gathers with 3/4 of its taps masked): the caller then keeps sf_bn_bwd_reduce
-    const bool fuse = bn_part && d->sT == 1 && d->sH == 1 && d->sW == 1;
+    const bool fuse = bn && d->sT == 1 && d->sH == 1 && d->sW == 1;
     if (fuse) {
-        p.bnb_y = (const f16*)bn_y; p.bnb_ld = bn_ldy; p.bnb_scale = bn_scale; p.bnb_shift = bn_shift; p.bnb_part = bn_part;
+        p.bnb_y = (const f16*)bn->y0; p.bnb_ld = bn->ld0; p.bnb_part = bn->part0;
+        p.bnb_scale = bn->scale; p.bnb_shift = bn->shift; p.bnb_bits = (const uint8_t*)bn->bits;
+        p.bnb_y2 = (const f16*)bn->y1; p.bnb_ld2 = bn->ld1; p.bnb_part2 = bn->part1;
     }
     int bm = 0;
     const int rc = run_igemm(p, is_pointwise(d), (hipStream_t)stream, &bm);
@@ -549,18 +556,23 @@ static int conv_dgrad_impl(const sf_conv_desc* d, const void* dy, const void* wd
 
 extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
                              const void* resid_bits, void* dx, sf_stream_t stream) {
-    return conv_dgrad_impl(d, dy, wd, resid, ldr, resid_bits, dx, nullptr, 0, nullptr, nullptr, nullptr, nullptr, stream);
+    return conv_dgrad_impl(d, dy, wd, resid, ldr, resid_bits, dx, nullptr, nullptr, stream);
 }
 
 extern "C" int sf_conv_dgrad_bn(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
-                                const void* resid_bits, void* dx, const void* bn_y, int32_t bn_ldy, const float* bn_scale,
-                                const float* bn_shift, float* bn_part, int32_t bn_part_rows, int32_t* bn_rows,
+                                const void* resid_bits, void* dx, const float* mask_scale, const float* mask_shift,
+                                const void* mask_bits, const void* bn_y0, int32_t bn_ldy0, float* bn_part0,
+                                const void* bn_y1, int32_t bn_ldy1, float* bn_part1, int32_t bn_part_rows, int32_t* bn_rows,
                                 sf_stream_t stream) {
-    REQUIRE(d && bn_y && bn_scale && bn_shift && bn_part && bn_rows, "sf_conv_dgrad_bn: null pointer");
-    REQUIRE(bn_ldy >= d->Ci && bn_ldy % 8 == 0 && ((uintptr_t)bn_y & 15) == 0, "sf_conv_dgrad_bn: bad bn_y pitch / alignment");
+    REQUIRE(d && bn_y0 && bn_part0 && bn_rows, "sf_conv_dgrad_bn: null pointer");
+    REQUIRE(mask_bits || (mask_scale && mask_shift), "sf_conv_dgrad_bn: a mask source is needed (mask_bits, or mask_scale + mask_shift)");
+    REQUIRE(bn_ldy0 >= d->Ci && bn_ldy0 % 8 == 0 && ((uintptr_t)bn_y0 & 15) == 0, "sf_conv_dgrad_bn: bad bn_y0 pitch / alignment");
+    REQUIRE((bn_y1 == nullptr) == (bn_part1 == nullptr), "sf_conv_dgrad_bn: bn_y1 and bn_part1 come together");
+    REQUIRE(!bn_y1 || (bn_ldy1 >= d->Ci && bn_ldy1 % 8 == 0 && ((uintptr_t)bn_y1 & 15) == 0), "sf_conv_dgrad_bn: bad bn_y1 pitch / alignment");
     REQUIRE((int64_t)bn_part_rows * 128 >= (int64_t)d->N * d->Ti * d->Hi * d->Wi,
-            "sf_conv_dgrad_bn: bn_part needs ceil(rows / 128) rows of [2][Ci] floats");
-    return conv_dgrad_impl(d, dy, wd, resid, ldr, resid_bits, dx, bn_y, bn_ldy, bn_scale, bn_shift, bn_part, bn_rows, stream);
+            "sf_conv_dgrad_bn: the partial tables need ceil(positions / 128) rows of [2][Ci] floats");
+    const BnFuse bn = {mask_scale, mask_shift, mask_bits, bn_y0, bn_ldy0, bn_part0, bn_y1, bn_ldy1, bn_part1};
+    return conv_dgrad_impl(d, dy, wd, resid, ldr, resid_bits, dx, &bn, bn_rows, stream);
 }
 
 template <int BMW, int WM, int WN, int KS>
@@ -621,7 +633,8 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     const int taps = d->kT * d->kH * d->kW;
     // workgroups to aim for: 2 per CU for pointwise layers, 4 per CU when the K axis spans several taps (measured per layer,
     // profiles/r2_v6_wgrad2_variants.md: the gathers of neighbouring taps overlap in L2, more splits in flight hide them)
-    const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : (taps > 1 ? 1024 : 512);
+    const bool deep = (e = getenv("SF_WGRAD2_NST")) && atoi(e) == 6;      // one workgroup per CU, six-stage ring
+    const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : deep ? 256 : (taps > 1 ? 1024 : 512);
     const int Ktot = taps * d->Ci;
     const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
     if (taps > SF_I2_MAXTAPS || M < minrows) return w;
@@ -889,8 +902,14 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
             else if (w2.BMW == 32 && w2.BKW == 128) hipLaunchKernelGGL((sf_wgrad2t_kernel<32, 128, 2>), grid, dim3(256), 0, s, q);
             else if (w2.BMW == 16) hipLaunchKernelGGL((sf_wgrad2t_kernel<16, 32, 3>), grid, dim3(256), 0, s, q);
             else hipLaunchKernelGGL((sf_wgrad2t_kernel<32, 32, 3>), grid, dim3(256), 0, s, q);
-        } else if (w2.BMW == 128) hipLaunchKernelGGL((sf_wgrad2_kernel<128>), grid, dim3(512), 0, s, q);
-        else hipLaunchKernelGGL((sf_wgrad2_kernel<64>), grid, dim3(512), 0, s, q);
+        } else {
+            const char* e6 = getenv("SF_WGRAD2_NST");
+            const bool deep = e6 && atoi(e6) == 6;
+            if (w2.BMW == 128 && deep) hipLaunchKernelGGL((sf_wgrad2_kernel<128, 6>), grid, dim3(512), 0, s, q);
+            else if (w2.BMW == 128) hipLaunchKernelGGL((sf_wgrad2_kernel<128, 3>), grid, dim3(512), 0, s, q);
+            else if (deep) hipLaunchKernelGGL((sf_wgrad2_kernel<64, 6>), grid, dim3(512), 0, s, q);
+            else hipLaunchKernelGGL((sf_wgrad2_kernel<64, 3>), grid, dim3(512), 0, s, q);
+        }
         splits = w2.splits; Co_pad = w2.Co_pad; Kpad = w2.Kpad;
     } else if (sp.ok && !in_scale) {
         REQUIRE(workspace_bytes >= (int64_t)sp.ws_bytes, "sf_conv_wgrad: workspace too small (%lld < %lld bytes)",

@@ -46,36 +46,56 @@ struct IgemmParams {
     const f16* bnb_y; int bnb_ld;
     const float* bnb_scale; const float* bnb_shift;
     float* bnb_part;
+    const uint8_t* bnb_bits;        // optional [rows][Nout/8] bit mask replacing the recomputed one (block-output ReLU)
+    const f16* bnb_y2; int bnb_ld2; float* bnb_part2;    // optional second BatchNorm sharing g (projection shortcut)
 };
 
-// g = dz masked by the producer's ReLU (same expression as masked_grad8 / sf_bn_bwd_apply use), accumulated per channel
+// g = dz masked by the producer's ReLU (same expression as masked_grad8 / sf_bn_bwd_apply use), accumulated per channel.
+// bits != nullptr: the mask is bit e of *bits (the 1-bit image of a block output, sf_bn_act) instead of the recomputed one.
 __device__ __forceinline__ void bnb_accumulate(const f16x8& dz, const f16x8& yv, const float (&sc)[8], const float (&sh)[8],
-                                               float (&sg)[8], float (&sgy)[8]) {
+                                               float (&sg)[8], float (&sgy)[8], const uint8_t* bits = nullptr,
+                                               const f16* y2 = nullptr, float* sgy2 = nullptr) {
+    float g[8];
+    if (bits) {
+        const uint32_t b = *bits;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((b >> e) & 1u) ? (float)dz[e] : 0.f;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((float)yv[e] * sc[e] + sh[e] > 0.f) ? (float)dz[e] : 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float g = ((float)yv[e] * sc[e] + sh[e] > 0.f) ? (float)dz[e] : 0.f;
-        sg[e] += g;
-        sgy[e] += g * (float)yv[e];
+        sg[e] += g[e];
+        sgy[e] += g[e] * (float)yv[e];
+    }
+    if (y2) {
+        const f16x8 v2 = ld16(y2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sgy2[e] += g[e] * (float)v2[e];
     }
 }
 
 // Workgroup reduction of the per-thread 8-channel sums of the store loop (thread t keeps column group t % CG): butterfly over
 // the lanes of a wave that share a group, waves through LDS in a fixed order, one partial-table row [2][Nout] per M tile.
 template <int NW, int CG>
-__device__ __forceinline__ void bnb_reduce_store(float (&sg)[8], float (&sgy)[8], float* red, float* prow, int n0, int Nout) {
+__device__ __forceinline__ void bnb_reduce_store(float (&sg)[8], float (&sgy)[8], float* red, float* prow, int n0, int Nout,
+                                                 float* sgy2 = nullptr, float* prow2 = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
         for (int mask = CG; mask < 64; mask <<= 1) {
             sg[e] += __shfl_xor(sg[e], mask);
             sgy[e] += __shfl_xor(sgy[e], mask);
+            if (prow2) sgy2[e] += __shfl_xor(sgy2[e], mask);
         }
     __syncthreads();                                   // every thread is done with the staging buffer `red` overlays
     if (lane < CG) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            red[(wave * CG + lane) * 16 + e] = sg[e];
-            red[(wave * CG + lane) * 16 + 8 + e] = sgy[e];
+            red[(wave * CG + lane) * 24 + e] = sg[e];
+            red[(wave * CG + lane) * 24 + 8 + e] = sgy[e];
+            if (prow2) red[(wave * CG + lane) * 24 + 16 + e] = sgy2[e];
         }
     }
     __syncthreads();
@@ -83,14 +103,16 @@ __device__ __forceinline__ void bnb_reduce_store(float (&sg)[8], float (&sgy)[8]
         const int cgi = tid >> 3, e = tid & 7;
         const int col = n0 + cgi * 8 + e;
         if (col < Nout) {
-            float s = 0.f, q = 0.f;
+            float s = 0.f, q = 0.f, q2 = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                s += red[(w * CG + cgi) * 16 + e];
-                q += red[(w * CG + cgi) * 16 + 8 + e];
+                s += red[(w * CG + cgi) * 24 + e];
+                q += red[(w * CG + cgi) * 24 + 8 + e];
+                if (prow2) q2 += red[(w * CG + cgi) * 24 + 16 + e];
             }
             prow[col] = s;
             prow[Nout + col] = q;
+            if (prow2) { prow2[col] = s; prow2[Nout + col] = q2; }
         }
     }
 }
@@ -408,10 +430,10 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
     constexpr int CG = BN / 8;
     static_assert(SF_THREADS % CG == 0 && 64 % CG == 0, "a thread keeps one column group over the whole store loop");
     const bool bnb = p.bnb_part != nullptr;
-    float bsg[8], bsgy[8], bsc[8], bsh[8];
+    float bsg[8], bsgy[8], bsgy2[8], bsc[8], bsh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
-    if (bnb && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
+    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsgy2[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
+    if (bnb && !p.bnb_bits && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
     for (int idx = tid; idx < BM * CG; idx += SF_THREADS) {
         const int row = idx / CG, cg = idx % CG;
         const int m = m0 + row, col = n0 + cg * 8;
@@ -443,10 +465,13 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
                 for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
                 st16(p.act_aux + (int64_t)m * p.ld_aux + col, a);
             }
-            if (bnb) bnb_accumulate(v, ld16(p.bnb_y + (int64_t)m * p.bnb_ld + col), bsc, bsh, bsg, bsgy);
+            if (bnb) bnb_accumulate(v, ld16(p.bnb_y + (int64_t)m * p.bnb_ld + col), bsc, bsh, bsg, bsgy,
+                                    p.bnb_bits ? p.bnb_bits + (int64_t)m * (p.Nout >> 3) + (col >> 3) : nullptr,
+                                    p.bnb_y2 ? p.bnb_y2 + (int64_t)m * p.bnb_ld2 + col : nullptr, bsgy2);
         }
     }
-    if (bnb) bnb_reduce_store<4, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);
+    if (bnb) bnb_reduce_store<4, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout,
+                                     bsgy2, p.bnb_y2 ? p.bnb_part2 + (int64_t)mt * 2 * p.Nout : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

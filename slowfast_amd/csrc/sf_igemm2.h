@@ -75,6 +75,8 @@ struct Igemm2Params {
     const f16* bnb_y; int bnb_ld;
     const float* bnb_scale; const float* bnb_shift;
     float* bnb_part;
+    const uint8_t* bnb_bits;        // optional [rows][Nout/8] bit mask replacing the recomputed one (block-output ReLU)
+    const f16* bnb_y2; int bnb_ld2; float* bnb_part2;    // optional second BatchNorm sharing g (projection shortcut)
 };
 
 // LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase
@@ -300,10 +302,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
     constexpr int CG = BN / 8;
     static_assert(NT % CG == 0 && 64 % CG == 0, "a thread keeps one column group over the whole store loop");
     const bool bnb = p.bnb_part != nullptr;
-    float bsg[8], bsgy[8], bsc[8], bsh[8];
+    float bsg[8], bsgy[8], bsgy2[8], bsc[8], bsh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
-    if (bnb && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
+    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsgy2[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
+    if (bnb && !p.bnb_bits && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
     for (int idx = tid; idx < BM * CG; idx += NT) {
         const int row = idx / CG, cg = idx % CG;
         const int mr = m0 + row, col = n0 + cg * 8;
@@ -336,8 +338,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
                 st16(p.act_aux + (int64_t)m * p.ld_aux + col, a);
             }
-            if (bnb) bnb_accumulate(v, ld16(p.bnb_y + (int64_t)m * p.bnb_ld + col), bsc, bsh, bsg, bsgy);
+            if (bnb) bnb_accumulate(v, ld16(p.bnb_y + (int64_t)m * p.bnb_ld + col), bsc, bsh, bsg, bsgy,
+                                    p.bnb_bits ? p.bnb_bits + (int64_t)m * (p.Nout >> 3) + (col >> 3) : nullptr,
+                                    p.bnb_y2 ? p.bnb_y2 + (int64_t)m * p.bnb_ld2 + col : nullptr, bsgy2);
         }
     }
-    if (bnb) bnb_reduce_store<NW, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);
+    if (bnb) bnb_reduce_store<NW, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout,
+                                      bsgy2, p.bnb_y2 ? p.bnb_part2 + (int64_t)mt * 2 * p.Nout : nullptr);
 }

@@ -397,7 +397,8 @@ class ConvUnit:
     def backward(self, x, in_affine, dy, need_dx, resid=None, resid_bits=None, bn_fuse=None):
         """Weight gradient into conv.weight.grad; returns dx (+ resid, masked by resid_bits when given) when need_dx.
         ``bn_fuse = (y, BNState)`` of the BatchNorm-ReLU that produced x: returns (dx, part) with the reduction pass of that
-        BatchNorm's backward taken in the data gradient's epilogue (part None: not available for this geometry)."""
+        BatchNorm's backward taken in the data gradient's epilogue (part None: not available for this geometry);
+        ``bn_fuse = {"bits", "y0", "y1"}`` (x is the previous block's output): returns (dx, part_c, part_1)."""
         geom = self.geom(x.shape)
         w = self.conv.weight
         if w.requires_grad:
@@ -413,8 +414,11 @@ class ConvUnit:
             return None
         _, wd = self.weights(geom)
         if bn_fuse is not None:
+            if isinstance(bn_fuse, dict):       # block input = the previous block's output: (dx, part_c, part_1)
+                return ops.conv_dgrad(dy, wd, geom, resid=resid, resid_bits=resid_bits, bn=bn_fuse)
             y, st = bn_fuse
-            return ops.conv_dgrad(dy, wd, geom, resid=resid, bn=(y, st.scale, st.shift))
+            dx, part, _ = ops.conv_dgrad(dy, wd, geom, resid=resid, bn=(y, st.scale, st.shift))
+            return dx, part
         return ops.conv_dgrad(dy, wd, geom, resid=resid, resid_bits=resid_bits)
 
     def bn_backward(self, dz, y, st, zmask=None, relu_self=False, want_g=False, part=None):
@@ -639,6 +643,9 @@ class ResBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, *params):
         ctx._sf_params = params
+        # when x is the previous block's output, that block left what ITS final BatchNorm backward will reduce over (see the
+        # end of this function): this block's last data gradient produces exactly that gradient and reduces it in its epilogue
+        ctx.prev_bn = getattr(x, "_sf_block_bn", None) if BN_FUSE_REDUCE else None
         x = as_cl(x)
         units, P = mod.branch2._chain, mod._proj
         tr = mod.training
@@ -673,6 +680,10 @@ class ResBlockFn(torch.autograd.Function):
         ctx.raw = (raw, y1, act, bits)
         ctx.bn = (bn, s1)
         ctx.save_for_backward(x)
+        if BN_FUSE_REDUCE and tr:
+            # a plain attribute of the output tensor: it reaches the next block only when that block receives THIS tensor
+            # (consecutive blocks of a stage); any op in between (fusion, pooling, a stage cut) drops it and nothing changes
+            out._sf_block_bn = {"bits": bits, "y0": yc, "y1": y1}
         return out
 
     @staticmethod
@@ -682,12 +693,17 @@ class ResBlockFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         raw, y1, act, bits = ctx.raw
         bn, s1 = ctx.bn
+        # partial sums the consumer block's data gradient already took over dout (tagged with the tensor they belong to)
+        tag = getattr(dout, "_sf_bn_part", None)
         dout = as_cl(dout)
         need_dx = ctx.needs_input_grad[0]
         last = len(units) - 1
-        dy = units[last].bn_backward(dout, raw[last], bn[last], zmask=bits)
+        part_c = part_1 = None
+        if tag is not None and tag[0] == raw[last].data_ptr() and tag[1] is not None:
+            part_c, part_1 = tag[1], tag[2]
+        dy = units[last].bn_backward(dout, raw[last], bn[last], zmask=bits, part=part_c)
         if P is not None:
-            dy1 = P.bn_backward(dout, y1, s1, zmask=bits)
+            dy1 = P.bn_backward(dout, y1, s1, zmask=bits, part=part_1)
         for i in range(last, 0, -1):
             part = None
             if act[i - 1] is not None and BN_FUSE_REDUCE and _sync_of(units[i - 1].bn) is None:
@@ -697,13 +713,20 @@ class ResBlockFn(torch.autograd.Function):
             else:
                 d_in = units[i].backward(raw[i - 1], (bn[i - 1].scale, bn[i - 1].shift, True), dy, need_dx=True)
             dy = units[i - 1].bn_backward(d_in, raw[i - 1], bn[i - 1], relu_self=True, part=part)
+        prev = ctx.prev_bn if need_dx else None
+        if prev is not None and (_sync_of(units[last].bn) is not None):
+            prev = None
         if P is not None:
             dx1 = P.backward(x, None, dy1, need_dx=need_dx)
-            dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=dx1)
+            dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=dx1, bn_fuse=prev)
         else:       # identity shortcut: dx = dgrad_a + dout * (out > 0), the mask applied to the residual in the epilogue
-            dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=dout, resid_bits=bits)
+            dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=dout, resid_bits=bits, bn_fuse=prev)
+        if prev is not None:
+            dx, pc, p1 = dx
+            if pc is not None:
+                dx._sf_bn_part = (prev["y0"].data_ptr(), pc, p1)
         _notify(mod._param_list)
-        ctx.raw = ctx.bn = None
+        ctx.raw = ctx.bn = ctx.prev_bn = None
         return (dx, None) + param_grads(ctx, 2)
 
 

@@ -179,6 +179,7 @@ class X3DBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, *params):
         ctx._sf_params = params
+        ctx.prev_bn = getattr(x, "_sf_block_bn", None) if engine.BN_FUSE_REDUCE else None      # see engine.ResBlockFn
         x = as_cl(x)
         t = mod.branch2
         tr = mod.training
@@ -208,6 +209,8 @@ class X3DBlockFn(torch.autograd.Function):
         ctx.mod = mod
         ctx.sv = dict(ya=ya, sa=sa, za=za, yb=yb, sb=sb, gate=gate, se=se, zb=zb, yc=yc, sc=sc, y1=y1, s1=s1, bits=bits)
         ctx.save_for_backward(x)
+        if engine.BN_FUSE_REDUCE and tr:
+            out._sf_block_bn = {"bits": bits, "y0": yc, "y1": y1}
         return out
 
     @staticmethod
@@ -216,12 +219,16 @@ class X3DBlockFn(torch.autograd.Function):
         t = mod.branch2
         A, C, P = t._a, t._c, mod._proj
         (x,) = ctx.saved_tensors
+        tag = getattr(dout, "_sf_bn_part", None)
         dout = as_cl(dout)
         need_dx = ctx.needs_input_grad[0]
         bits = sv["bits"]
-        dyc = C.bn_backward(dout, sv["yc"], sv["sc"], zmask=bits)
+        part_c = part_1 = None
+        if tag is not None and tag[0] == sv["yc"].data_ptr() and tag[1] is not None:
+            part_c, part_1 = tag[1], tag[2]
+        dyc = C.bn_backward(dout, sv["yc"], sv["sc"], zmask=bits, part=part_c)
         if P is not None:
-            dy1 = P.bn_backward(dout, sv["y1"], sv["s1"], zmask=bits)
+            dy1 = P.bn_backward(dout, sv["y1"], sv["s1"], zmask=bits, part=part_1)
         dzb = C.backward(sv["zb"], None, dyc, need_dx=True)
         yb, sb, gate = sv["yb"], sv["sb"], sv["gate"]
         dmean = None
@@ -232,13 +239,20 @@ class X3DBlockFn(torch.autograd.Function):
         dyb = t._b_bn.backward(du, yb, sb)
         dza = t._b.backward(sv["za"], dyb, need_dx=True)
         dya = A.bn_backward(dza, sv["ya"], sv["sa"], relu_self=True)
+        prev = ctx.prev_bn if need_dx else None
+        if prev is not None and _sync_of(C.bn) is not None:
+            prev = None
         if P is not None:
             dx1 = P.backward(x, None, dy1, need_dx=need_dx)
-            dx = A.backward(x, None, dya, need_dx=need_dx, resid=dx1)
+            dx = A.backward(x, None, dya, need_dx=need_dx, resid=dx1, bn_fuse=prev)
         else:       # identity shortcut: the masked block-output gradient is added in the dgrad epilogue
-            dx = A.backward(x, None, dya, need_dx=need_dx, resid=dout, resid_bits=bits)
+            dx = A.backward(x, None, dya, need_dx=need_dx, resid=dout, resid_bits=bits, bn_fuse=prev)
+        if prev is not None:
+            dx, pc, p1 = dx
+            if pc is not None:
+                dx._sf_bn_part = (prev["y0"].data_ptr(), pc, p1)
         _notify(mod._param_list)
-        ctx.sv = None
+        ctx.sv = ctx.prev_bn = None
         return (dx, None) + param_grads(ctx, 2)
 
 

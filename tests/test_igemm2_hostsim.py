@@ -96,6 +96,16 @@ def test_wgrad2(sim, force_w2, case):
     kc.check_conv_wgrad(sim, *case)
 
 
+@pytest.mark.parametrize("case", [WGRAD2_CASES[0], WGRAD2_CASES[-1]])
+def test_wgrad2_deep_ring(sim, force_w2, monkeypatch, case):
+    """SF_WGRAD2_NST=6: one workgroup per CU with a six-stage ring (more stages in flight than a short split has steps)."""
+    monkeypatch.setenv("SF_WGRAD2_NST", "6")
+    monkeypatch.setenv("SF_WGRAD2_BLOCKS", "2")
+    kc.check_conv_wgrad(sim, *case)
+    monkeypatch.setenv("SF_WGRAD2_BLOCKS", "64")      # splits shorter than the ring
+    kc.check_conv_wgrad(sim, *case)
+
+
 def test_wgrad2_accumulate_and_scale(sim, force_w2):
     kc.check_conv_wgrad(sim, (1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), out_scale=0.25)
 
