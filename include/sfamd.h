@@ -86,18 +86,18 @@ int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* wd, const v
  * (sf_bn_bwd_reduce), g = dz under the ReLU mask.  The epilogue takes them from the fp16 tile it stores -- one read of the y
  * tile instead of a pass over dz and y, one launch less:
  *   - inner activations of a block (BottleneckTransform b / c reading relu(a_bn(a(x))) / relu(b_bn(b(.))),
- *     resnet_helper.py:377-392): mask = (bn_y0 * mask_scale + mask_shift > 0), mask_bits NULL;
+ *     resnet_helper.py:377-392): mask = (bn_y * mask_scale + mask_shift > 0), mask_bits NULL;
  *   - a block INPUT that is the previous block's output relu(bn_c(yc) + shortcut) (resnet_helper.py:512-521): mask_bits = the
- *     1-bit image sf_bn_act wrote for that output ([positions][Ci/8]); bn_y0 = yc, and bn_y1 = the raw output of the previous
- *     block's projection shortcut when it has one (both BatchNorms share g).
- * bn_partK[row][2][Ci] fp32, one row per M tile of the kernel that ran (fixed order: deterministic); *bn_rows = rows written,
+ *     1-bit image sf_bn_act wrote for that output ([positions][Ci/8]), bn_y = yc (a projection shortcut's own BatchNorm keeps
+ *     its separate reduction pass).
+ * bn_part[row][2][Ci] fp32, one row per M tile of the kernel that ran (fixed order: deterministic); *bn_rows = rows written,
  * to be passed to sf_bn_bwd_finalize as nblk -- or 0 when the geometry keeps the separate pass (strided data gradients): the
- * tables are then untouched and the caller runs sf_bn_bwd_reduce.  The tables hold ceil(positions / 128) rows (bn_part_rows);
+ * table is then untouched and the caller runs sf_bn_bwd_reduce.  The table holds ceil(positions / 128) rows (bn_part_rows);
  * bn_rows is a HOST pointer. */
 int sf_conv_dgrad_bn(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
                      const void* resid_bits, void* dx, const float* mask_scale, const float* mask_shift,
-                     const void* mask_bits, const void* bn_y0, int32_t bn_ldy0, float* bn_part0, const void* bn_y1,
-                     int32_t bn_ldy1, float* bn_part1, int32_t bn_part_rows, int32_t* bn_rows, sf_stream_t stream);
+                     const void* mask_bits, const void* bn_y, int32_t bn_ldy, float* bn_part, int32_t bn_part_rows,
+                     int32_t* bn_rows, sf_stream_t stream);
 /* Thin layers -- at most 32 output columns and a contraction (taps x channels of the gathered operand) of at most 128, the
  * Fast pathway's 8-32 channel bottlenecks: a streaming kernel (independent waves, weights in registers) that reads positions
  * from the geometry's row table.  dgrad = 0: forward (plain input, optional bias, optional BatchNorm partial sums);

@@ -221,7 +221,7 @@ static void igemm2_common(Igemm2Params& q, const IgemmParams& p) {
     q.act_mode = p.act_mode; q.act_aux = p.act_aux; q.ld_aux = p.ld_aux; q.resid_row0 = p.resid_row0; q.alpha = p.alpha;
     q.resid_bits = p.resid_bits;
     q.bnb_y = p.bnb_y; q.bnb_ld = p.bnb_ld; q.bnb_scale = p.bnb_scale; q.bnb_shift = p.bnb_shift; q.bnb_part = p.bnb_part;
-    q.bnb_bits = p.bnb_bits; q.bnb_y2 = p.bnb_y2; q.bnb_ld2 = p.bnb_ld2; q.bnb_part2 = p.bnb_part2;
+    q.bnb_bits = p.bnb_bits;
 }
 static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     // read on every call (three getenv per launch are noise): tests lower the thresholds for single cases
@@ -521,7 +521,6 @@ extern "C" int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const voi
 struct BnFuse {     // the fused BatchNorm-backward reduction of sf_conv_dgrad_bn (all device pointers)
     const float* scale; const float* shift; const void* bits;
     const void* y0; int32_t ld0; float* part0;
-    const void* y1; int32_t ld1; float* part1;
 };
 static int conv_dgrad_impl(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
                            const void* resid_bits, void* dx, const BnFuse* bn, int32_t* bn_rows, sf_stream_t stream) {
@@ -546,7 +545,6 @@ static int conv_dgrad_impl(const sf_conv_desc* d, const void* dy, const void* wd
     if (fuse) {
         p.bnb_y = (const f16*)bn->y0; p.bnb_ld = bn->ld0; p.bnb_part = bn->part0;
         p.bnb_scale = bn->scale; p.bnb_shift = bn->shift; p.bnb_bits = (const uint8_t*)bn->bits;
-        p.bnb_y2 = (const f16*)bn->y1; p.bnb_ld2 = bn->ld1; p.bnb_part2 = bn->part1;
     }
     int bm = 0;
     const int rc = run_igemm(p, is_pointwise(d), (hipStream_t)stream, &bm);
@@ -561,17 +559,14 @@ extern "C" int sf_conv_dgrad(const sf_conv_desc* d, const void* dy, const void* 
 
 extern "C" int sf_conv_dgrad_bn(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
                                 const void* resid_bits, void* dx, const float* mask_scale, const float* mask_shift,
-                                const void* mask_bits, const void* bn_y0, int32_t bn_ldy0, float* bn_part0,
-                                const void* bn_y1, int32_t bn_ldy1, float* bn_part1, int32_t bn_part_rows, int32_t* bn_rows,
-                                sf_stream_t stream) {
-    REQUIRE(d && bn_y0 && bn_part0 && bn_rows, "sf_conv_dgrad_bn: null pointer");
+                                const void* mask_bits, const void* bn_y, int32_t bn_ldy, float* bn_part, int32_t bn_part_rows,
+                                int32_t* bn_rows, sf_stream_t stream) {
+    REQUIRE(d && bn_y && bn_part && bn_rows, "sf_conv_dgrad_bn: null pointer");
     REQUIRE(mask_bits || (mask_scale && mask_shift), "sf_conv_dgrad_bn: a mask source is needed (mask_bits, or mask_scale + mask_shift)");
-    REQUIRE(bn_ldy0 >= d->Ci && bn_ldy0 % 8 == 0 && ((uintptr_t)bn_y0 & 15) == 0, "sf_conv_dgrad_bn: bad bn_y0 pitch / alignment");
-    REQUIRE((bn_y1 == nullptr) == (bn_part1 == nullptr), "sf_conv_dgrad_bn: bn_y1 and bn_part1 come together");
-    REQUIRE(!bn_y1 || (bn_ldy1 >= d->Ci && bn_ldy1 % 8 == 0 && ((uintptr_t)bn_y1 & 15) == 0), "sf_conv_dgrad_bn: bad bn_y1 pitch / alignment");
+    REQUIRE(bn_ldy >= d->Ci && bn_ldy % 8 == 0 && ((uintptr_t)bn_y & 15) == 0, "sf_conv_dgrad_bn: bad bn_y pitch / alignment");
     REQUIRE((int64_t)bn_part_rows * 128 >= (int64_t)d->N * d->Ti * d->Hi * d->Wi,
-            "sf_conv_dgrad_bn: the partial tables need ceil(positions / 128) rows of [2][Ci] floats");
-    const BnFuse bn = {mask_scale, mask_shift, mask_bits, bn_y0, bn_ldy0, bn_part0, bn_y1, bn_ldy1, bn_part1};
+            "sf_conv_dgrad_bn: the partial table needs ceil(positions / 128) rows of [2][Ci] floats");
+    const BnFuse bn = {mask_scale, mask_shift, mask_bits, bn_y, bn_ldy, bn_part};
     return conv_dgrad_impl(d, dy, wd, resid, ldr, resid_bits, dx, &bn, bn_rows, stream);
 }
 
@@ -631,10 +626,13 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     const int mink = (e = getenv("SF_WGRAD2_MINK")) ? atoi(e) : 192;
     const int minrows = (e = getenv("SF_WGRAD2_MINROWS")) ? atoi(e) : 4096;
     const int taps = d->kT * d->kH * d->kW;
-    // workgroups to aim for: 2 per CU for pointwise layers, 4 per CU when the K axis spans several taps (measured per layer,
-    // profiles/r2_v6_wgrad2_variants.md: the gathers of neighbouring taps overlap in L2, more splits in flight hide them)
-    const bool deep = (e = getenv("SF_WGRAD2_NST")) && atoi(e) == 6;      // one workgroup per CU, six-stage ring
-    const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : deep ? 256 : (taps > 1 ? 1024 : 512);
+    // Workgroups to aim for: ONE resident round (2 per CU x 256 CUs).  The split count is rounded DOWN so that the grid never
+    // exceeds the target by a few workgroups: 18 tiles x 29 splits = 522 on 512 resident slots ran a second, almost empty round
+    // (s4.slow b: 120 us at 522 workgroups, 99 us at 396; profiles/r3_v2_wgrad_sweep.md -- which also shows the one-workgroup-
+    // per-CU six-stage ring, SF_WGRAD2_NST=6, losing everywhere).
+    const bool deep = (e = getenv("SF_WGRAD2_NST")) && atoi(e) == 6;
+    const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : deep ? 256 : 512;
+    (void)taps;
     const int Ktot = taps * d->Ci;
     const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
     if (taps > SF_I2_MAXTAPS || M < minrows) return w;
@@ -655,7 +653,7 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
         // one resident round of workgroups: LDS allows 2 per CU with 128-wide tiles (2 x 37-41 KB stages), 3 (BMW 32) or 4 (BMW 16)
         // with 32-wide ones; measured per layer, 512 / 768 / 1024 / 1536 / 2048: profiles/r2_v24_wgrad_thin.md
         const int target_t = (e = getenv("SF_WGRAD2T_BLOCKS")) ? atoi(e) : (w.BKW == 128 ? 512 : w.BMW == 32 ? 768 : 1024);
-        int splits = cdiv(target_t, w.tiles_k);
+        int splits = target_t / w.tiles_k;                  // rounded down: never a few workgroups beyond the resident round
         if (splits < 1) splits = 1;
         w.rows_per_split = roundup(cdiv(M, splits), 128);
         w.splits = cdiv(M, w.rows_per_split);
@@ -670,7 +668,7 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     w.tiles_c = cdiv(d->Co, w.BMW);
     w.Kpad = w.tiles_k * 256;
     w.Co_pad = w.tiles_c * w.BMW;
-    int splits = cdiv(target, (int64_t)w.tiles_k * w.tiles_c);
+    int splits = target / (w.tiles_k * w.tiles_c);
     const int64_t slab = (int64_t)w.Co_pad * w.Kpad * 4;
     const int64_t cap = (256ll << 20) / slab;
     if (splits > cap) splits = (int)(cap < 1 ? 1 : cap);

@@ -47,34 +47,29 @@ struct IgemmParams {
     const float* bnb_scale; const float* bnb_shift;
     float* bnb_part;
     const uint8_t* bnb_bits;        // optional [rows][Nout/8] bit mask replacing the recomputed one (block-output ReLU)
-    const f16* bnb_y2; int bnb_ld2; float* bnb_part2;    // optional second BatchNorm sharing g (projection shortcut)
 };
 
 // g = dz masked by the producer's ReLU (same expression as masked_grad8 / sf_bn_bwd_apply use), accumulated per channel.
-// bits != nullptr: the mask is bit e of *bits (the 1-bit image of a block output, sf_bn_act) instead of the recomputed one.
+// use_bits: the mask is bit e of `bits` (the 1-bit image of a block output, sf_bn_act) instead of the recomputed one.
 __device__ __forceinline__ void bnb_accumulate(const f16x8& dz, const f16x8& yv, const float (&sc)[8], const float (&sh)[8],
-                                               float (&sg)[8], float (&sgy)[8], const uint8_t* bits = nullptr,
-                                               const f16* y2 = nullptr, float* sgy2 = nullptr) {
-    float g[8];
-    if (bits) {
-        const uint32_t b = *bits;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = ((b >> e) & 1u) ? (float)dz[e] : 0.f;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = ((float)yv[e] * sc[e] + sh[e] > 0.f) ? (float)dz[e] : 0.f;
-    }
+                                               float (&sg)[8], float (&sgy)[8], bool use_bits, uint32_t bits) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        sg[e] += g[e];
-        sgy[e] += g[e] * (float)yv[e];
-    }
-    if (y2) {
-        const f16x8 v2 = ld16(y2);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sgy2[e] += g[e] * (float)v2[e];
+        const bool open = use_bits ? ((bits >> e) & 1u) != 0u : ((float)yv[e] * sc[e] + sh[e] > 0.f);
+        const float g = open ? (float)dz[e] : 0.f;
+        sg[e] += g;
+        sgy[e] += g * (float)yv[e];
     }
 }
+
+// Everything the store loop of the implicit-GEMM epilogues reads from global memory for ONE 8-column group of one row.  The
+// loop is run in chunks: all loads of a chunk are issued first (no store in between, so they are in flight together), then the
+// chunk is combined and stored -- the row-at-a-time form paid one full memory latency per row and operand
+// (round 3: the fused BatchNorm-backward reduction added a third operand and cost as much as the pass it replaced).
+struct EpiLoads {
+    f16x8 r, y;                 // residual, BatchNorm-backward operand (the rarer operands -- GELU input, second BatchNorm -- are
+    uint32_t rbits, bbits;      // read in the combine phase: 10 registers per row in flight, the budget the accumulators leave)
+};
 
 // Workgroup reduction of the per-thread 8-channel sums of the store loop (thread t keeps column group t % CG): butterfly over
 // the lanes of a wave that share a group, waves through LDS in a fixed order, one partial-table row [2][Nout] per M tile.
@@ -430,27 +425,51 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
     constexpr int CG = BN / 8;
     static_assert(SF_THREADS % CG == 0 && 64 % CG == 0, "a thread keeps one column group over the whole store loop");
     const bool bnb = p.bnb_part != nullptr;
-    float bsg[8], bsgy[8], bsgy2[8], bsc[8], bsh[8];
+    float bsg[8], bsgy[8], bsc[8], bsh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsgy2[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
     if (bnb && !p.bnb_bits && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
-    for (int idx = tid; idx < BM * CG; idx += SF_THREADS) {
-        const int row = idx / CG, cg = idx % CG;
-        const int m = m0 + row, col = n0 + cg * 8;
-        if (m < p.M && col < p.Nout) {
-            f16x8 v = ld16(stg + row * STG_LD + cg * 8);
-            if (resid && m >= p.resid_row0) {
-                f16x8 r = ld16(resid + (int64_t)m * p.ldr + col);
-                if (p.resid_bits) {
-                    const uint32_t b = p.resid_bits[(int64_t)m * (p.Nout >> 3) + (col >> 3)];
+    constexpr int ITER = BM * CG / SF_THREADS > 0 ? BM * CG / SF_THREADS : 1;
+    static_assert(BM * CG % SF_THREADS == 0 || BM * CG < SF_THREADS, "whole store iterations");
+    // rows in flight per thread: 2 where the register cap leaves room (the 128-VGPR variants hold their accumulators in VGPRs,
+    // dead by now); the others keep accumulators in AGPRs and have no spare VGPRs without losing a resident wave
+    constexpr int CH = (BN >= 128 && OCC4) ? 2 : 1;
+    static_assert(ITER % CH == 0, "whole chunks");
+    const int ecg = tid % CG, ecol = n0 + ecg * 8;
+    for (int it0 = 0; it0 < ITER; it0 += CH) {
+        EpiLoads L[CH];
+        bool ok[CH], rok[CH];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) r[e] = ((b >> e) & 1u) ? r[e] : (f16)0.f;
+        for (int u = 0; u < CH; ++u) {
+            const int idx = tid + (it0 + u) * SF_THREADS;
+            const int row = idx / CG, m = m0 + row;
+            ok[u] = idx < BM * CG && m < p.M && ecol < p.Nout;
+            rok[u] = ok[u] && resid && m >= p.resid_row0;
+            L[u].rbits = 0xffu; L[u].bbits = 0u;
+            if (rok[u]) {
+                L[u].r = ld16(resid + (int64_t)m * p.ldr + ecol);
+                if (p.resid_bits) L[u].rbits = p.resid_bits[(int64_t)m * (p.Nout >> 3) + (ecol >> 3)];
+            }
+            if (ok[u] && bnb) {
+                L[u].y = ld16(p.bnb_y + (int64_t)m * p.bnb_ld + ecol);
+                if (p.bnb_bits) L[u].bbits = p.bnb_bits[(int64_t)m * (p.Nout >> 3) + (ecol >> 3)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (!ok[u]) continue;
+            const int idx = tid + (it0 + u) * SF_THREADS;
+            const int row = idx / CG, m = m0 + row;
+            f16x8 v = ld16(stg + row * STG_LD + ecg * 8);
+            if (rok[u]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const f16 r = ((L[u].rbits >> e) & 1u) ? L[u].r[e] : (f16)0.f;
+                    v[e] = (f16)((float)v[e] + (float)r);
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)r[e]);
             }
             if (p.act_mode == 2) {
-                const f16x8 h = ld16(p.act_aux + (int64_t)m * p.ld_aux + col);
+                const f16x8 h = ld16(p.act_aux + (int64_t)m * p.ld_aux + ecol);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * gelu_df((float)h[e]));
             }
@@ -458,20 +477,17 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] > (f16)0.f ? v[e] : (f16)0.f;
             }
-            st16(yout + (int64_t)m * p.ldy + col, v);
+            st16(yout + (int64_t)m * p.ldy + ecol, v);
             if (p.act_mode == 1) {
                 f16x8 a;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
-                st16(p.act_aux + (int64_t)m * p.ld_aux + col, a);
+                st16(p.act_aux + (int64_t)m * p.ld_aux + ecol, a);
             }
-            if (bnb) bnb_accumulate(v, ld16(p.bnb_y + (int64_t)m * p.bnb_ld + col), bsc, bsh, bsg, bsgy,
-                                    p.bnb_bits ? p.bnb_bits + (int64_t)m * (p.Nout >> 3) + (col >> 3) : nullptr,
-                                    p.bnb_y2 ? p.bnb_y2 + (int64_t)m * p.bnb_ld2 + col : nullptr, bsgy2);
+            if (bnb) bnb_accumulate(v, L[u].y, bsc, bsh, bsg, bsgy, p.bnb_bits != nullptr, L[u].bbits);
         }
     }
-    if (bnb) bnb_reduce_store<4, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout,
-                                     bsgy2, p.bnb_y2 ? p.bnb_part2 + (int64_t)mt * 2 * p.Nout : nullptr);
+    if (bnb) bnb_reduce_store<4, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);
 }
 
 // ---------------------------------------------------------------------------------------------

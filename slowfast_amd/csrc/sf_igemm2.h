@@ -76,7 +76,6 @@ struct Igemm2Params {
     const float* bnb_scale; const float* bnb_shift;
     float* bnb_part;
     const uint8_t* bnb_bits;        // optional [rows][Nout/8] bit mask replacing the recomputed one (block-output ReLU)
-    const f16* bnb_y2; int bnb_ld2; float* bnb_part2;    // optional second BatchNorm sharing g (projection shortcut)
 };
 
 // LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase
@@ -302,28 +301,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
     constexpr int CG = BN / 8;
     static_assert(NT % CG == 0 && 64 % CG == 0, "a thread keeps one column group over the whole store loop");
     const bool bnb = p.bnb_part != nullptr;
-    float bsg[8], bsgy[8], bsgy2[8], bsc[8], bsh[8];
+    float bsg[8], bsgy[8], bsc[8], bsh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsgy2[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
     if (bnb && !p.bnb_bits && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
-    for (int idx = tid; idx < BM * CG; idx += NT) {
-        const int row = idx / CG, cg = idx % CG;
-        const int mr = m0 + row, col = n0 + cg * 8;
-        if (mr < p.M && col < p.Nout) {
-            const int m = p.omap ? s_orow[row] : mr;
-            f16x8 v = ld16(stg + row * STG_LD + cg * 8);
-            if (p.resid && m >= p.resid_row0) {
-                f16x8 r = ld16(p.resid + (int64_t)m * p.ldr + col);
-                if (p.resid_bits) {
-                    const uint32_t b = p.resid_bits[(int64_t)m * (p.Nout >> 3) + (col >> 3)];
+    constexpr int ITER = BM * CG / NT;
+    static_assert(BM * CG % NT == 0 && ITER >= 1, "whole store iterations");
+    constexpr int CH = ITER < 2 ? ITER : 2;
+    static_assert(ITER % CH == 0, "whole chunks");
+    const int ecg = tid % CG, ecol = n0 + ecg * 8;
+    for (int it0 = 0; it0 < ITER; it0 += CH) {
+        EpiLoads L[CH];
+        bool ok[CH], rok[CH];
+        int mo[CH];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) r[e] = ((b >> e) & 1u) ? r[e] : (f16)0.f;
+        for (int u = 0; u < CH; ++u) {
+            const int idx = tid + (it0 + u) * NT;
+            const int row = idx / CG, mr = m0 + row;
+            ok[u] = mr < p.M && ecol < p.Nout;
+            const int m = ok[u] ? (p.omap ? s_orow[row] : mr) : 0;
+            mo[u] = m;
+            rok[u] = ok[u] && p.resid && m >= p.resid_row0;
+            L[u].rbits = 0xffu; L[u].bbits = 0u;
+            if (rok[u]) {
+                L[u].r = ld16(p.resid + (int64_t)m * p.ldr + ecol);
+                if (p.resid_bits) L[u].rbits = p.resid_bits[(int64_t)m * (p.Nout >> 3) + (ecol >> 3)];
+            }
+            if (ok[u] && bnb) {
+                L[u].y = ld16(p.bnb_y + (int64_t)m * p.bnb_ld + ecol);
+                if (p.bnb_bits) L[u].bbits = p.bnb_bits[(int64_t)m * (p.Nout >> 3) + (ecol >> 3)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (!ok[u]) continue;
+            const int idx = tid + (it0 + u) * NT;
+            const int row = idx / CG, m = mo[u];
+            f16x8 v = ld16(stg + row * STG_LD + ecg * 8);
+            if (rok[u]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const f16 r = ((L[u].rbits >> e) & 1u) ? L[u].r[e] : (f16)0.f;
+                    v[e] = (f16)((float)v[e] + (float)r);
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)r[e]);
             }
             if (p.act_mode == 2) {
-                const f16x8 h = ld16(p.act_aux + (int64_t)m * p.ld_aux + col);
+                const f16x8 h = ld16(p.act_aux + (int64_t)m * p.ld_aux + ecol);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * gelu_df((float)h[e]));
             }
@@ -331,18 +354,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] > (f16)0.f ? v[e] : (f16)0.f;
             }
-            st16(p.y + (int64_t)m * p.ldy + col, v);
+            st16(p.y + (int64_t)m * p.ldy + ecol, v);
             if (p.act_mode == 1) {
                 f16x8 a;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
-                st16(p.act_aux + (int64_t)m * p.ld_aux + col, a);
+                st16(p.act_aux + (int64_t)m * p.ld_aux + ecol, a);
             }
-            if (bnb) bnb_accumulate(v, ld16(p.bnb_y + (int64_t)m * p.bnb_ld + col), bsc, bsh, bsg, bsgy,
-                                    p.bnb_bits ? p.bnb_bits + (int64_t)m * (p.Nout >> 3) + (col >> 3) : nullptr,
-                                    p.bnb_y2 ? p.bnb_y2 + (int64_t)m * p.bnb_ld2 + col : nullptr, bsgy2);
+            if (bnb) bnb_accumulate(v, L[u].y, bsc, bsh, bsg, bsgy, p.bnb_bits != nullptr, L[u].bbits);
         }
     }
-    if (bnb) bnb_reduce_store<NW, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout,
-                                      bsgy2, p.bnb_y2 ? p.bnb_part2 + (int64_t)mt * 2 * p.Nout : nullptr);
+    if (bnb) bnb_reduce_store<NW, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);
 }

@@ -398,7 +398,7 @@ class ConvUnit:
         """Weight gradient into conv.weight.grad; returns dx (+ resid, masked by resid_bits when given) when need_dx.
         ``bn_fuse = (y, BNState)`` of the BatchNorm-ReLU that produced x: returns (dx, part) with the reduction pass of that
         BatchNorm's backward taken in the data gradient's epilogue (part None: not available for this geometry);
-        ``bn_fuse = {"bits", "y0", "y1"}`` (x is the previous block's output): returns (dx, part_c, part_1)."""
+        ``bn_fuse = {"bits", "y0"}`` (x is the previous block's output): (dx, part) for that block's final BatchNorm."""
         geom = self.geom(x.shape)
         w = self.conv.weight
         if w.requires_grad:
@@ -414,11 +414,10 @@ class ConvUnit:
             return None
         _, wd = self.weights(geom)
         if bn_fuse is not None:
-            if isinstance(bn_fuse, dict):       # block input = the previous block's output: (dx, part_c, part_1)
+            if isinstance(bn_fuse, dict):       # block input = the previous block's output
                 return ops.conv_dgrad(dy, wd, geom, resid=resid, resid_bits=resid_bits, bn=bn_fuse)
             y, st = bn_fuse
-            dx, part, _ = ops.conv_dgrad(dy, wd, geom, resid=resid, bn=(y, st.scale, st.shift))
-            return dx, part
+            return ops.conv_dgrad(dy, wd, geom, resid=resid, bn=(y, st.scale, st.shift))
         return ops.conv_dgrad(dy, wd, geom, resid=resid, resid_bits=resid_bits)
 
     def bn_backward(self, dz, y, st, zmask=None, relu_self=False, want_g=False, part=None):
@@ -683,7 +682,7 @@ class ResBlockFn(torch.autograd.Function):
         if BN_FUSE_REDUCE and tr:
             # a plain attribute of the output tensor: it reaches the next block only when that block receives THIS tensor
             # (consecutive blocks of a stage); any op in between (fusion, pooling, a stage cut) drops it and nothing changes
-            out._sf_block_bn = {"bits": bits, "y0": yc, "y1": y1}
+            out._sf_block_bn = {"bits": bits, "y0": yc}
         return out
 
     @staticmethod
@@ -698,12 +697,12 @@ class ResBlockFn(torch.autograd.Function):
         dout = as_cl(dout)
         need_dx = ctx.needs_input_grad[0]
         last = len(units) - 1
-        part_c = part_1 = None
-        if tag is not None and tag[0] == raw[last].data_ptr() and tag[1] is not None:
-            part_c, part_1 = tag[1], tag[2]
+        part_c = None
+        if tag is not None and tag[0] == raw[last].data_ptr():
+            part_c = tag[1]
         dy = units[last].bn_backward(dout, raw[last], bn[last], zmask=bits, part=part_c)
         if P is not None:
-            dy1 = P.bn_backward(dout, y1, s1, zmask=bits, part=part_1)
+            dy1 = P.bn_backward(dout, y1, s1, zmask=bits)
         for i in range(last, 0, -1):
             part = None
             if act[i - 1] is not None and BN_FUSE_REDUCE and _sync_of(units[i - 1].bn) is None:
@@ -722,9 +721,9 @@ class ResBlockFn(torch.autograd.Function):
         else:       # identity shortcut: dx = dgrad_a + dout * (out > 0), the mask applied to the residual in the epilogue
             dx = units[0].backward(x, None, dy, need_dx=need_dx, resid=dout, resid_bits=bits, bn_fuse=prev)
         if prev is not None:
-            dx, pc, p1 = dx
+            dx, pc = dx
             if pc is not None:
-                dx._sf_bn_part = (prev["y0"].data_ptr(), pc, p1)
+                dx._sf_bn_part = (prev["y0"].data_ptr(), pc)
         _notify(mod._param_list)
         ctx.raw = ctx.bn = ctx.prev_bn = None
         return (dx, None) + param_grads(ctx, 2)

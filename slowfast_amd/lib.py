@@ -60,8 +60,8 @@ _SIGNATURES = {
     "sf_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _F, _F, c_int, _F, _P, _F, _P]),
     "sf_conv_fwd_fused": (c_int, [POINTER(ConvDesc), _P, _P, _F, _P, c_int32, c_int, _P, _P]),
     "sf_conv_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P, _P]),
-    "sf_conv_dgrad_bn": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, c_int32, _P,
-                                 c_int32, POINTER(c_int32), _P]),
+    "sf_conv_dgrad_bn": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32,
+                                 POINTER(c_int32), _P]),
     "sf_conv_wgrad_workspace": (c_int64, [POINTER(ConvDesc)]),
     "sf_conv_thin_rowtab_bytes": (c_int64, [POINTER(ConvDesc), c_int]),
     "sf_conv_thin_blocks": (c_int, [POINTER(ConvDesc), c_int]),

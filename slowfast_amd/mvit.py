@@ -399,7 +399,7 @@ class MViT(nn.Module):
         if self.enable_rev:                        # _forward_reversible, video_model_builder.py:1141-1164
             x = self.rev_backbone(x)               # fuse("concat") is the identity on the concatenated streams
         else:
-            ncut = max(len(self.blocks) // 3, 1)
+            ncut = 4 if len(self.blocks) >= 8 else max(len(self.blocks) // 3, 1)      # MViTv2-S: [0-3 | 4-7 | 8-11 | 12-15 + head]
             for i, blk in enumerate(self.blocks):
                 if i and i % ncut == 0:                # backward segments of step.TrainStep (identity otherwise)
                     x = engine.cut(x)

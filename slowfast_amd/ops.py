@@ -236,36 +236,31 @@ def conv_dgrad(dy, wd, geom, resid=None, out=None, resid_bits=None, bn=None):
     ``bn``: the kernel epilogue also takes the reduction pass of the BatchNorm backward(s) that consume dx (sums of g and
     g * y over the positions, g = dx under the ReLU mask) from the tile it stores.  Two forms:
       * ``(y, scale, shift)`` -- this convolution's input was the inner activation relu(bn(y)): mask recomputed;
-      * ``{"bits": mask, "y0": yc, "y1": y1 | None}`` -- its input was the previous block's output relu(bn_c(yc) + shortcut):
-        ``bits`` is that output's 1-bit image, ``y1`` the raw output of the previous block's projection shortcut (if any).
-    Returns (dx, part0, part1): partK [rows, 2, Ci] fp32 for bn_bwd(..., part=partK) -- Nones when the geometry keeps the
-    separate pass (strided data gradients)."""
+      * ``{"bits": mask, "y0": yc}`` -- its input was the previous block's output relu(bn_c(yc) + shortcut): ``bits`` is that
+        output's 1-bit image (the BatchNorm of a projection shortcut keeps its own reduction pass).
+    Returns (dx, part): part [rows, 2, Ci] fp32 for bn_bwd(..., part=part) -- None when the geometry keeps the separate pass
+    (strided data gradients)."""
     if bn is not None:
         if not isinstance(bn, dict):
             y0, sc, sh = bn                      # inner activation: mask recomputed from (y, scale, shift)
-            bits, y1 = None, None
+            bits = None
         else:
-            bits, y0, y1 = bn["bits"], bn["y0"], bn.get("y1")   # block input: the previous block's 1-bit output mask
+            bits, y0 = bn["bits"], bn["y0"]      # block input: the previous block's 1-bit output mask
             sc = sh = None
             assert bits.dtype == torch.uint8 and bits.numel() == rows(y0) * (geom.Ci // 8) and bits.is_contiguous()
-        assert tuple(y0.shape) == geom.in_shape and (y1 is None or tuple(y1.shape) == geom.in_shape)
+        assert tuple(y0.shape) == geom.in_shape
         dx = cl_empty(geom.in_shape, dy.device) if out is None else out
         M = rows(y0)
         cap = (M + 127) // 128
-        part0 = torch.empty((cap, 2, geom.Ci), dtype=torch.float32, device=dy.device)
-        part1 = torch.empty((cap, 2, geom.Ci), dtype=torch.float32, device=dy.device) if y1 is not None else None
+        part = torch.empty((cap, 2, geom.Ci), dtype=torch.float32, device=dy.device)
         nrows = c_int32(0)
         if resid_bits is not None:
             assert resid is not None and resid_bits.dtype == torch.uint8 and resid_bits.numel() == rows(resid) * (geom.Ci // 8)
         get_lib().call("sf_conv_dgrad_bn", byref(geom.desc(cl_ld(dx), cl_ld(dy))), dy.data_ptr(), wd.data_ptr(), _ptr(resid),
                        cl_ld(resid) if resid is not None else 0, _ptr(resid_bits), dx.data_ptr(), _ptr(sc), _ptr(sh), _ptr(bits),
-                       y0.data_ptr(), cl_ld(y0), part0.data_ptr(), _ptr(y1), cl_ld(y1) if y1 is not None else 0, _ptr(part1),
-                       cap, byref(nrows), _stream(dy),
-                       work=geom.work(reads_x=1 + int(resid is not None) + int(y1 is not None), reads_y=1, writes_x=1))
-        n = nrows.value
-        if n <= 0:
-            return dx, None, None
-        return dx, part0[:n], (part1[:n] if part1 is not None else None)
+                       y0.data_ptr(), cl_ld(y0), part.data_ptr(), cap, byref(nrows), _stream(dy),
+                       work=geom.work(reads_x=1 + int(resid is not None), reads_y=1, writes_x=1))
+        return dx, (part[:nrows.value] if nrows.value > 0 else None)
     assert tuple(dy.shape) == geom.out_shape
     ldy = cl_ld(dy)
     dx = cl_empty(geom.in_shape, dy.device) if out is None else out

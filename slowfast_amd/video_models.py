@@ -233,7 +233,7 @@ class SlowFast(_ResNetBase):
             if tuple(pool.kernel_size) != (1, 1, 1):
                 x[p] = _pathway_pool(pool, x[p])
         x = engine.cut(x)                # stage boundaries: backward segments of step.TrainStep (identity otherwise)
-        x = self.s3_fuse(self.s3(x))
+        x = engine.cut(self.s3_fuse(self.s3(x)))
         x = engine.cut(self.s4_fuse(self.s4(x)))
         x = self.s5(x)
         return self.head(x, bboxes) if self.enable_detection else self.head(x)
@@ -283,6 +283,6 @@ class ResNet(_ResNetBase):
         pool = self.pathway0_pool
         if tuple(pool.kernel_size) != (1, 1, 1):
             x[0] = _pathway_pool(pool, x[0])
-        x = self.s4(self.s3(engine.cut(x)))
+        x = self.s4(engine.cut(self.s3(engine.cut(x))))
         x = self.s5(engine.cut(x))
         return self.head(x, bboxes) if self.enable_detection else self.head(x)

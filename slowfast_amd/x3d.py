@@ -210,7 +210,7 @@ class X3DBlockFn(torch.autograd.Function):
         ctx.sv = dict(ya=ya, sa=sa, za=za, yb=yb, sb=sb, gate=gate, se=se, zb=zb, yc=yc, sc=sc, y1=y1, s1=s1, bits=bits)
         ctx.save_for_backward(x)
         if engine.BN_FUSE_REDUCE and tr:
-            out._sf_block_bn = {"bits": bits, "y0": yc, "y1": y1}
+            out._sf_block_bn = {"bits": bits, "y0": yc}
         return out
 
     @staticmethod
@@ -223,12 +223,10 @@ class X3DBlockFn(torch.autograd.Function):
         dout = as_cl(dout)
         need_dx = ctx.needs_input_grad[0]
         bits = sv["bits"]
-        part_c = part_1 = None
-        if tag is not None and tag[0] == sv["yc"].data_ptr() and tag[1] is not None:
-            part_c, part_1 = tag[1], tag[2]
+        part_c = tag[1] if (tag is not None and tag[0] == sv["yc"].data_ptr()) else None
         dyc = C.bn_backward(dout, sv["yc"], sv["sc"], zmask=bits, part=part_c)
         if P is not None:
-            dy1 = P.bn_backward(dout, sv["y1"], sv["s1"], zmask=bits, part=part_1)
+            dy1 = P.bn_backward(dout, sv["y1"], sv["s1"], zmask=bits)
         dzb = C.backward(sv["zb"], None, dyc, need_dx=True)
         yb, sb, gate = sv["yb"], sv["sb"], sv["gate"]
         dmean = None
@@ -248,9 +246,9 @@ class X3DBlockFn(torch.autograd.Function):
         else:       # identity shortcut: the masked block-output gradient is added in the dgrad epilogue
             dx = A.backward(x, None, dya, need_dx=need_dx, resid=dout, resid_bits=bits, bn_fuse=prev)
         if prev is not None:
-            dx, pc, p1 = dx
+            dx, pc = dx
             if pc is not None:
-                dx._sf_bn_part = (prev["y0"].data_ptr(), pc, p1)
+                dx._sf_bn_part = (prev["y0"].data_ptr(), pc)
         _notify(mod._param_list)
         ctx.sv = ctx.prev_bn = None
         return (dx, None) + param_grads(ctx, 2)
@@ -560,8 +558,10 @@ class X3D(nn.Module):
 
     def _backbone(self, x):
         x = self.s1(list(x))
-        for s in (self.s2, self.s3, self.s4, self.s5):
+        for i, s in enumerate((self.s2, self.s3, self.s4, self.s5)):
             x = s(x)
+            if i < 3:                        # stage boundaries: backward segments of step.TrainStep (identity otherwise)
+                x = engine.cut(x)
         return x
 
 

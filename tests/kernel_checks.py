@@ -145,38 +145,25 @@ def check_conv_dgrad_bn(device, in_shape, Co, k, p, d=(1, 1, 1), resid=False, se
     _, wd = ops.prep_weights(w.to(device), geom)
     dyc, rc = host_to_cl(dy, device), (host_to_cl(r, device) if resid else None)
     base = ops.conv_dgrad(dyc, wd, geom, resid=rc)
-    dx, part, _ = ops.conv_dgrad(dyc, wd, geom, resid=rc, bn=(host_to_cl(ybn, device), sc.to(device), sh.to(device)))
+    dx, part = ops.conv_dgrad(dyc, wd, geom, resid=rc, bn=(host_to_cl(ybn, device), sc.to(device), sh.to(device)))
     assert part is not None and part.shape[1:] == (2, in_shape[1])
     assert torch.equal(cl_to_host(dx), cl_to_host(base)), "the fused epilogue must not change the stored gradient"
     dxh = cl_to_host(dx).double()
     mask = (ybn * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1) > 0).double()
-    gsum = (dxh * mask).sum((0, 2, 3, 4))
-    gysum = (dxh * mask * ybn.double()).sum((0, 2, 3, 4))
-    tot = part.double().sum(0).cpu()
-    scale_g = float((dxh * mask).abs().sum((0, 2, 3, 4)).max())
-    scale_gy = float((dxh * mask * ybn.double()).abs().sum((0, 2, 3, 4)).max())
-    assert float((tot[0] - gsum).abs().max()) <= 2e-6 * scale_g, (tot[0] - gsum).abs().max()
-    assert float((tot[1] - gysum).abs().max()) <= 2e-6 * scale_gy, (tot[1] - gysum).abs().max()
-    # block-input form: the mask is a bit image, two BatchNorms (block-final + projection shortcut) share g
+
+    def close(tot, m):
+        ref_g, ref_gy = (dxh * m).sum((0, 2, 3, 4)), (dxh * m * ybn.double()).sum((0, 2, 3, 4))
+        assert float((tot[0] - ref_g).abs().max()) <= 2e-6 * float((dxh * m).abs().sum((0, 2, 3, 4)).max())
+        assert float((tot[1] - ref_gy).abs().max()) <= 2e-6 * float((dxh * m * ybn.double()).abs().sum((0, 2, 3, 4)).max())
+    close(part.double().sum(0).cpu(), mask)
+    # block-input form: the mask is a bit image (the previous block's output > 0)
     bmask = torch.rand(in_shape, generator=g) < 0.6
-    y1 = torch.randn(in_shape, generator=g).half().float()
     Mrows = in_shape[0] * in_shape[2] * in_shape[3] * in_shape[4]
     bl = bmask.permute(0, 2, 3, 4, 1).reshape(Mrows, in_shape[1] // 8, 8).to(torch.int32)
     bits = (bl << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8).contiguous().to(device)
-    for use_y1 in (False, True):
-        dx2, p0, p1 = ops.conv_dgrad(dyc, wd, geom, resid=rc, bn={"bits": bits, "y0": host_to_cl(ybn, device),
-                                                                   "y1": host_to_cl(y1, device) if use_y1 else None})
-        assert torch.equal(cl_to_host(dx2), cl_to_host(base)) and p0 is not None and (p1 is not None) == use_y1
-        m2 = bmask.double()
-        t0 = p0.double().sum(0).cpu()
-        assert float((t0[0] - (dxh * m2).sum((0, 2, 3, 4))).abs().max()) <= 2e-6 * float((dxh * m2).abs().sum((0, 2, 3, 4)).max())
-        ref_gy = (dxh * m2 * ybn.double()).sum((0, 2, 3, 4))
-        assert float((t0[1] - ref_gy).abs().max()) <= 2e-6 * float((dxh * m2 * ybn.double()).abs().sum((0, 2, 3, 4)).max())
-        if use_y1:
-            t1 = p1.double().sum(0).cpu()
-            assert torch.equal(p1[:, 0], p0[:, 0])
-            ref1 = (dxh * m2 * y1.double()).sum((0, 2, 3, 4))
-            assert float((t1[1] - ref1).abs().max()) <= 2e-6 * float((dxh * m2 * y1.double()).abs().sum((0, 2, 3, 4)).max())
+    dx2, p0 = ops.conv_dgrad(dyc, wd, geom, resid=rc, bn={"bits": bits, "y0": host_to_cl(ybn, device)})
+    assert torch.equal(cl_to_host(dx2), cl_to_host(base)) and p0 is not None
+    close(p0.double().sum(0).cpu(), bmask.double())
     return part.shape[0]
 
 

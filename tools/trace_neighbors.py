@@ -19,16 +19,38 @@ def main():
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            grid = "x".join(str(r.get(k, "?")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")) if "Grid_Size_X" in r \
+                else str(r.get("Grid_Size", "?"))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], grid))
     rows.sort()
     hist = collections.Counter()
     durs = collections.defaultdict(list)
-    for i, (st, en, name) in enumerate(rows):
+    for i, (st, en, name, _g) in enumerate(rows):
         if needle in name:
             prev = short(rows[i - 1][2]) if i else "-"
             nxt = short(rows[i + 1][2]) if i + 1 < len(rows) else "-"
             hist[(prev, nxt)] += 1
             durs[(prev, nxt)].append((en - st) / 1e3)
+    # the context of the longest run of matching dispatches: what precedes it, the sizes inside it, what follows
+    best, cur, start = (0, 0), 0, 0
+    for i, r in enumerate(rows):
+        if needle in r[2]:
+            if cur == 0:
+                start = i
+            cur += 1
+            if cur > best[0]:
+                best = (cur, start)
+        else:
+            cur = 0
+    n, st0 = best
+    if n:
+        print(f"longest run: {n} dispatches starting at dispatch {st0}")
+        for i in range(max(0, st0 - 6), st0):
+            print("   before:", short(rows[i][2]), "grid", rows[i][3], "dur us %.1f" % ((rows[i][1] - rows[i][0]) / 1e3))
+        sizes = collections.Counter(rows[i][3] for i in range(st0, st0 + n))
+        print("   grid sizes inside the run:", sizes.most_common(12))
+        for i in range(st0 + n, min(len(rows), st0 + n + 8)):
+            print("   after: ", short(rows[i][2]), "grid", rows[i][3], "dur us %.1f" % ((rows[i][1] - rows[i][0]) / 1e3))
     print(f"{sum(hist.values())} dispatches matching '{needle}' of {len(rows)}")
     for (prev, nxt), c in hist.most_common(40):
         d = durs[(prev, nxt)]

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--filter", default="slow")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    variants = [("3", b) for b in (256, 384, 512, 768, 1024, 1536)] + [("6", b) for b in (256, 512)]
+    variants = [("3", b) for b in (256, 384, 448, 512, 640, 768, 1024, 1536)]
     lines = ["| layer | x | " + " | ".join(f"nst{n} b{b}" for n, b in variants) + " | best |", "|---|---:|" + "---:|" * (len(variants) + 1)]
     tot = [0.0] * len(variants)
     best_tot = 0.0
