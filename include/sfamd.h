@@ -309,6 +309,13 @@ int sf_roi_align_max_bwd(int32_t R, int32_t B, int32_t H, int32_t W, int32_t C, 
  * A [M][K], W [N][K], Y / aux [M][N] fp16, row pitches in elements. */
 int sf_gemm_act(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias,
                 void* Y, int32_t ldy, int32_t mode, void* aux, int32_t ldaux, sf_stream_t stream);
+/* sf_gemm_act + the column sums of the tile it stores (round 3): colsum_part[row][2][N] fp32, slot 0 of every row = the sum of
+ * Y over the rows of one M tile (slot 1 unused), *colsum_rows (HOST pointer) = rows written.  With mode 2 (Y = d(loss)/d(fc1
+ * output)) the sums are the bias gradient of the Mlp's fc1 (common.py:25-34) once folded by sf_colsum_finalize -- the
+ * separate sf_colsum pass over the widest gradient tensor of every block goes away.  colsum_part holds ceil(M / 128) rows. */
+int sf_gemm_act_colsum(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
+                       const float* bias, void* Y, int32_t ldy, int32_t mode, void* aux, int32_t ldaux,
+                       float* colsum_part, int32_t colsum_part_rows, int32_t* colsum_rows, sf_stream_t stream);
 /* Input side -- replaces tensor_normalize (slowfast/datasets/utils.py:278-297), the THWC -> CTHW
  * permute (datasets/kinetics.py:375-408) and pack_pathway_output (datasets/utils.py:78-111) for one pathway:
  *   out[n][to][h][w][c] = ((frames[n][t_index[to]][h][w][s] / 255) - mean[s]) / std[s]   (s = c, or 2 - c when `reverse`),

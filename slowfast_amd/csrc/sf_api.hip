@@ -1225,9 +1225,9 @@ extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t 
     return check_launch("bgemm");
 }
 
-extern "C" int sf_gemm_act(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
-                           const float* bias, void* Y, int32_t ldy, int32_t mode, void* aux, int32_t ldaux,
-                           sf_stream_t stream) {
+static int gemm_act_impl(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
+                         const float* bias, void* Y, int32_t ldy, int32_t mode, void* aux, int32_t ldaux,
+                         float* colsum_part, int32_t* colsum_rows, sf_stream_t stream) {
     REQUIRE(A && W && Y && aux, "sf_gemm_act: null pointer");
     REQUIRE(M > 0 && M < (1ll << 31) && N > 0 && K > 0, "sf_gemm_act: bad shape");
     REQUIRE(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0 && ldaux % 8 == 0 && ldaux >= N,
@@ -1242,13 +1242,30 @@ extern "C" int sf_gemm_act(int64_t M, int32_t N, int32_t K, const void* A, int32
     p.y = (f16*)Y; p.ldy = ldy; p.bias = bias;
     p.bh = 1;
     p.act_mode = mode; p.act_aux = (f16*)aux; p.ld_aux = ldaux;
+    p.bnb_part = colsum_part;          // bnb_y == nullptr: plain column sums of the stored tile, one row per M tile
     hipStream_t s = (hipStream_t)stream;
+    if (colsum_rows) *colsum_rows = colsum_part ? cdiv(p.M, 256) : 0;
     if (try_igemm2(p, s, 1)) return check_launch("gemm_act2");
+    if (colsum_rows) *colsum_rows = colsum_part ? cdiv(p.M, 128) : 0;
     if (N > 64) { p.ntiles_n = cdiv(N, 128); launch_igemm<128, 64, 64>(p, true, s, 1); }
     else if (N > 32) { p.ntiles_n = 1; launch_igemm<64, 32, 64>(p, true, s, 1); }
     else if (N > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, true, s, 1); }
     else { p.ntiles_n = 1; launch_igemm<16, 32, 16>(p, true, s, 1); }
     return check_launch("gemm_act");
+}
+
+extern "C" int sf_gemm_act(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
+                           const float* bias, void* Y, int32_t ldy, int32_t mode, void* aux, int32_t ldaux,
+                           sf_stream_t stream) {
+    return gemm_act_impl(M, N, K, A, lda, W, ldw, bias, Y, ldy, mode, aux, ldaux, nullptr, nullptr, stream);
+}
+
+extern "C" int sf_gemm_act_colsum(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
+                                  const float* bias, void* Y, int32_t ldy, int32_t mode, void* aux, int32_t ldaux,
+                                  float* colsum_part, int32_t colsum_part_rows, int32_t* colsum_rows, sf_stream_t stream) {
+    REQUIRE(colsum_part && colsum_rows, "sf_gemm_act_colsum: null pointer");
+    REQUIRE((int64_t)colsum_part_rows * 128 >= M, "sf_gemm_act_colsum: colsum_part needs ceil(M / 128) rows of [2][N] floats");
+    return gemm_act_impl(M, N, K, A, lda, W, ldw, bias, Y, ldy, mode, aux, ldaux, colsum_part, colsum_rows, stream);
 }
 
 extern "C" int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int32_t ldp, const void* X, int32_t ldx,

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
     float bsg[8], bsgy[8], bsc[8], bsh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
-    if (bnb && !p.bnb_bits && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
+    if (bnb && p.bnb_y && !p.bnb_bits && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
     constexpr int ITER = BM * CG / SF_THREADS > 0 ? BM * CG / SF_THREADS : 1;
     static_assert(BM * CG % SF_THREADS == 0 || BM * CG < SF_THREADS, "whole store iterations");
     // rows in flight per thread: 2 where the register cap leaves room (the 128-VGPR variants hold their accumulators in VGPRs,
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
                 L[u].r = ld16(resid + (int64_t)m * p.ldr + ecol);
                 if (p.resid_bits) L[u].rbits = p.resid_bits[(int64_t)m * (p.Nout >> 3) + (ecol >> 3)];
             }
-            if (ok[u] && bnb) {
+            if (ok[u] && bnb && p.bnb_y) {
                 L[u].y = ld16(p.bnb_y + (int64_t)m * p.bnb_ld + ecol);
                 if (p.bnb_bits) L[u].bbits = p.bnb_bits[(int64_t)m * (p.Nout >> 3) + (ecol >> 3)];
             }
@@ -484,7 +484,11 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
                 for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
                 st16(p.act_aux + (int64_t)m * p.ld_aux + ecol, a);
             }
-            if (bnb) bnb_accumulate(v, L[u].y, bsc, bsh, bsg, bsgy, p.bnb_bits != nullptr, L[u].bbits);
+            if (bnb && p.bnb_y) bnb_accumulate(v, L[u].y, bsc, bsh, bsg, bsgy, p.bnb_bits != nullptr, L[u].bbits);
+            else if (bnb) {                 // plain column sums of the stored tile (bias gradient of the consumer Linear)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsg[e] += (float)v[e];
+            }
         }
     }
     if (bnb) bnb_reduce_store<4, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);

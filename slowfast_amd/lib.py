@@ -122,6 +122,7 @@ _SIGNATURES = {
     "sf_roi_align_max_bwd": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _F, _F,
                                      c_int32, c_int32, _P, _F, _P]),
     "sf_gemm_act": (c_int, [c_int64, c_int32, c_int32, _P, c_int32, _P, c_int32, _F, _P, c_int32, c_int32, _P, c_int32, _P]),
+    "sf_gemm_act_colsum": (c_int, [c_int64, c_int32, c_int32, _P, c_int32, _P, c_int32, _F, _P, c_int32, c_int32, _P, c_int32, _P, c_int32, POINTER(c_int32), _P]),
     "sf_pack_clip_u8": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_float, c_float, c_float, c_float,
                                 c_float, c_float, c_int32, _P, _P]),
     "sf_row_scale_add": (c_int, [_P, c_int32, _P, c_int64, _P, c_int32, _P, c_int32, c_int64, c_int32, _P]),

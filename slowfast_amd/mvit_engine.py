@@ -20,6 +20,9 @@ from . import engine as _engine
 from .engine import _grad_dest, _notify, param_grads
 
 _f16 = torch.float16
+# fc1's bias gradient from the epilogue of the GEMM that produces d(loss)/d(fc1 output) (tokens.gemm_gelu_grad(dbias=...))
+# instead of a separate column-sum pass over it; SF_FUSE_COLSUM=0 keeps the pass (A/B)
+FUSE_COLSUM = os.environ.get("SF_FUSE_COLSUM", "1") != "0"
 
 
 class LinearUnit:
@@ -66,8 +69,10 @@ class LinearUnit:
         w, _ = self._ops(fresh=True)
         return tokens.gemm_gelu(x, w, bias=self.lin.bias)
 
-    def backward_through_gelu(self, x, dy, h):
-        """Like backward(), but returns d(loss)/d(h) for x = gelu(h): the data gradient times gelu'(h) in one GEMM."""
+    def backward_through_gelu(self, x, dy, h, consumer_bias=None):
+        """Like backward(), but returns (d(loss)/d(h), bias_done) for x = gelu(h): the data gradient times gelu'(h) in one
+        GEMM.  ``consumer_bias``: the bias parameter of the Linear that produced h (fc1); bias_done = its gradient was taken in
+        this GEMM's epilogue."""
         lin = self.lin
         if lin.weight.requires_grad:
             dw, zero_first = _grad_dest(lin.weight)
@@ -76,15 +81,21 @@ class LinearUnit:
             db, zero_first = _grad_dest(lin.bias)
             tokens.bias_grad(dy, db, accumulate=not zero_first)
         _, wt = self._ops()
-        return tokens.gemm_gelu_grad(dy, wt, h)
+        if consumer_bias is not None and consumer_bias.requires_grad and FUSE_COLSUM:
+            # the result IS d(loss)/d(output of the Linear in front of the GELU): its bias gradient = the column sums of the tile
+            # the epilogue stores (one launch instead of a pass over the widest gradient tensor of the block)
+            dcb, zf = _grad_dest(consumer_bias)
+            return tokens.gemm_gelu_grad(dy, wt, h, dbias=dcb, accumulate=not zf), True
+        return tokens.gemm_gelu_grad(dy, wt, h), False
 
-    def backward(self, x, dy, need_dx=True, resid=None, out=None):
-        """weight/bias gradients into .grad; returns dx (+ resid)."""
+    def backward(self, x, dy, need_dx=True, resid=None, out=None, bias_done=False):
+        """weight/bias gradients into .grad; returns dx (+ resid).  ``bias_done``: the producer of dy already wrote the bias
+        gradient (backward_through_gelu(consumer_bias=...))."""
         lin = self.lin
         if lin.weight.requires_grad:
             dw, zero_first = _grad_dest(lin.weight)
             tokens.linear_wgrad(x, dy, dw, zero_first=zero_first)
-        if lin.bias is not None and lin.bias.requires_grad:
+        if lin.bias is not None and lin.bias.requires_grad and not bias_done:
             db, zero_first = _grad_dest(lin.bias)
             tokens.bias_grad(dy, db, accumulate=not zero_first)
         if not need_dx:
@@ -487,11 +498,11 @@ class MultiScaleBlockFn(torch.autograd.Function):
         # Mlp
         dbr = dout if drop is None else tokens.row_scale_add(dout, drop[1], dout.shape[1])
         if _FUSED_GELU:
-            dh = mod.mlp._fc2.backward_through_gelu(sv["a"], dbr, sv["h"])
+            dh, b1_done = mod.mlp._fc2.backward_through_gelu(sv["a"], dbr, sv["h"], consumer_bias=mod.mlp.fc1.bias)
         else:
             da = mod.mlp._fc2.backward(sv["a"], dbr)
-            dh = tokens.gelu_bwd(sv["h"], da)
-        dxn2 = mod.mlp._fc1.backward(sv["xn2"], dh)
+            dh, b1_done = tokens.gelu_bwd(sv["h"], da), False
+        dxn2 = mod.mlp._fc1.backward(sv["xn2"], dh, bias_done=b1_done)
         proj_first = mod._proj is not None and mod.dim_mul_in_att
         if mod._proj is not None and not proj_first:       # the skip path went through proj(norm2(x1))
             dxn2 = mod._proj.backward(sv["xn2"], dout, resid=dxn2)
@@ -559,10 +570,10 @@ def _mlp_sub_forward(sub, x):
 
 def _mlp_sub_backward(sub, sv, d_out, resid=None):
     if _FUSED_GELU:
-        dh = sub.mlp._fc2.backward_through_gelu(sv["a"], d_out, sv["h"])
+        dh, b1_done = sub.mlp._fc2.backward_through_gelu(sv["a"], d_out, sv["h"], consumer_bias=sub.mlp.fc1.bias)
     else:
-        dh = tokens.gelu_bwd(sv["h"], sub.mlp._fc2.backward(sv["a"], d_out))
-    dxn = sub.mlp._fc1.backward(sv["xn"], dh)
+        dh, b1_done = tokens.gelu_bwd(sv["h"], sub.mlp._fc2.backward(sv["a"], d_out)), False
+    dxn = sub.mlp._fc1.backward(sv["xn"], dh, bias_done=b1_done)
     return sub._norm.backward(dxn, sv["x"], *sv["st"], resid=resid)
 
 

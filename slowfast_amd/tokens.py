@@ -4,7 +4,7 @@ GELU, column sums, depthwise convolution, relative-position terms, softmax, tran
 Token tensors are fp16 with unit stride in the last (channel) dimension and a uniform row pitch: [B, N, C]
 contiguous, a channel slice of one, or a 2-D [M, C] view.  PyTorch is used for memory and streams only.
 """
-from ctypes import byref
+from ctypes import byref, c_int32
 
 import torch
 
@@ -70,14 +70,24 @@ def gemm_gelu(a, w16, bias=None):
     return h, act
 
 
-def gemm_gelu_grad(dy, wt16, h):
-    """Data gradient of fc2 times gelu'(h): d(loss)/d(fc1 output) in one GEMM."""
+def gemm_gelu_grad(dy, wt16, h, dbias=None, accumulate=False):
+    """Data gradient of fc2 times gelu'(h): d(loss)/d(fc1 output) in one GEMM.  ``dbias``: fc1's bias gradient (the column
+    sums of the result) is taken from the tiles the epilogue stores and folded into ``dbias`` -- no separate pass over dh."""
     M, K, lda = rows_pitch(dy)
     N = wt16.shape[0]
     assert rows_pitch(h)[:2] == (M, N)
     dh = torch.empty(h.shape, dtype=_f16, device=dy.device)
-    _lib_call("sf_gemm_act", M, N, K, dy.data_ptr(), lda, wt16.data_ptr(), wt16.stride(0), None, dh.data_ptr(), N, 2,
-              h.data_ptr(), rows_pitch(h)[2], _stream(dy), work=dict(flops=2.0 * M * N * K, bytes=2.0 * (M * K + 2 * M * N + N * K)))
+    work = dict(flops=2.0 * M * N * K, bytes=2.0 * (M * K + 2 * M * N + N * K))
+    if dbias is None:
+        _lib_call("sf_gemm_act", M, N, K, dy.data_ptr(), lda, wt16.data_ptr(), wt16.stride(0), None, dh.data_ptr(), N, 2,
+                  h.data_ptr(), rows_pitch(h)[2], _stream(dy), work=work)
+        return dh
+    cap = (M + 127) // 128
+    part = torch.empty((cap, 2, N), dtype=torch.float32, device=dy.device)
+    nrows = c_int32(0)
+    _lib_call("sf_gemm_act_colsum", M, N, K, dy.data_ptr(), lda, wt16.data_ptr(), wt16.stride(0), None, dh.data_ptr(), N, 2,
+              h.data_ptr(), rows_pitch(h)[2], part.data_ptr(), cap, byref(nrows), _stream(dy), work=work)
+    colsum_finalize(part[:nrows.value], N, N, dbias, None, 1.0, accumulate)
     return dh
 
 
