@@ -51,6 +51,12 @@ def main():
         print("   grid sizes inside the run:", sizes.most_common(12))
         for i in range(st0 + n, min(len(rows), st0 + n + 8)):
             print("   after: ", short(rows[i][2]), "grid", rows[i][3], "dur us %.1f" % ((rows[i][1] - rows[i][0]) / 1e3))
+    # per-step count: dispatches matching the needle between consecutive optimizer launches (sf_flat_sgd / sf_flat_adamw)
+    marks = [i for i, r in enumerate(rows) if "sf_flat_sgd" in r[2] or "sf_flat_adamw" in r[2]]
+    for a, b in zip(marks, marks[1:]):
+        n_in = sum(1 for i in range(a + 1, b) if needle in rows[i][2])
+        t_in = sum((rows[i][1] - rows[i][0]) / 1e3 for i in range(a + 1, b) if needle in rows[i][2])
+        print(f"step between optimizer launches at dispatch {a} and {b}: {b - a - 1} dispatches, {n_in} x {needle} ({t_in:.1f} us)")
     print(f"{sum(hist.values())} dispatches matching '{needle}' of {len(rows)}")
     for (prev, nxt), c in hist.most_common(40):
         d = durs[(prev, nxt)]
