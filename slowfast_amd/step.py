@@ -282,6 +282,14 @@ class TrainStep:
         self._finish()
         return self._loss.clone() if self._graph is not None else self._loss
 
+    def static_inputs(self):
+        """(inputs, labels) buffers the captured graph reads (None before the capture).  A loader that writes the next batch
+        straight into them -- e.g. data.pack_pathways_u8 with these tensors as its outputs -- saves the per-iteration
+        device-to-device copy __call__ otherwise makes from the tensors it is handed (0.28 ms for a 32-clip SlowFast batch)."""
+        if self._graph is None:
+            return None
+        return (list(self._static_in) if self._is_list else self._static_in), self._static_labels
+
     @property
     def logits(self):
         return self._logits.clone() if self._graph is not None and self._logits is not None else self._logits
