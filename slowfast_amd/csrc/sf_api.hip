@@ -186,6 +186,38 @@ static void launch_igemm2(Igemm2Params& q, hipStream_t s) {
     const dim3 grid((unsigned)(cdiv(q.M, 256) * q.ntiles_n));
     hipLaunchKernelGGL((sf_igemm2_kernel<256, BN, 4, 2, BK, 3>), grid, dim3(512), 0, s, q);
 }
+// STRIP variant (sf_igemm2.h): stride-1 convolutions over a row space that coincides with the source position space, at least
+// three taps, all tap displacements within 128 rows of each other (1x3x3 / pad 1 up to W = 63; 3x1x1 on 7x7 maps).  Fills the
+// strip fields of q and launches; false = not eligible.  SF_IGEMM2_STRIP=0 disables, =2 also replaces the 64-deep variant.
+static bool try_igemm2_strip(Igemm2Params& q, bool bk64, hipStream_t s) {
+    const char* e = getenv("SF_IGEMM2_STRIP");
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0 || (bk64 && mode < 2)) return false;
+    if (q.omap || q.ntaps < 3 || q.Nout <= 32 || q.C % 32 != 0) return false;
+    if (q.mulT != 1 || q.mulH != 1 || q.mulW != 1) return false;
+    if ((int)q.fdrT.d != q.sT || (int)q.fdrH.d != q.sH || (int)q.fdrW.d != q.sW) return false;
+    int dmin = 0, dmax = 0;
+    int32_t delta[SF_I2_MAXTAPS];
+    for (int t = 0; t < q.ntaps; ++t) {
+        delta[t] = ((q.offT + q.dt[t]) * q.sH + (q.offH + q.dh[t])) * q.sW + (q.offW + q.dw[t]);
+        if (t == 0 || delta[t] < dmin) dmin = delta[t];
+        if (t == 0 || delta[t] > dmax) dmax = delta[t];
+    }
+    if (dmax - dmin > 128) return false;
+    q.strip_e0 = -dmin;
+    q.strip_rows = roundup(256 + (dmax - dmin), 16);
+    for (int t = 0; t < q.ntaps; ++t) q.soff[t] = delta[t] - dmin;
+    const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;    // read per call: tests switch it on mid-process
+    if (trace) fprintf(stderr, "[sfamd] igemm2 strip: M=%d N=%d C=%d taps=%d rows=%d\n", q.M, q.Nout, q.C, q.ntaps, q.strip_rows);
+    if (q.Nout > 64) {
+        q.ntiles_n = cdiv(q.Nout, 128);
+        hipLaunchKernelGGL((sf_igemm2_kernel<256, 128, 4, 2, 32, 3, true>), dim3((unsigned)(cdiv(q.M, 256) * q.ntiles_n)), dim3(512), 0, s, q);
+    } else {
+        q.ntiles_n = 1;
+        hipLaunchKernelGGL((sf_igemm2_kernel<256, 64, 4, 2, 32, 3, true>), dim3((unsigned)cdiv(q.M, 256)), dim3(512), 0, s, q);
+    }
+    return true;
+}
 // K step: 64 deep (48 KB stages, ONE 8-wave workgroup per CU) when the grid is at most ~one tile per CU anyway -- the
 // res5-sized layers; otherwise 32 deep (24 KB stages, TWO workgroups per CU: one tile's epilogue and pipeline fill hide
 // behind the other's K loop).  Measured per layer in profiles/r2_v3_igemm2_variants.md.  SF_IGEMM2_BK=32|64 forces one.
@@ -195,6 +227,7 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     const int force_bk = (e = getenv("SF_IGEMM2_BK")) ? atoi(e) : 0;
     const bool bk64 = q.C % 64 == 0 && force_bk != 32 && (force_bk == 64 || tiles <= 320);
     static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+    if (try_igemm2_strip(q, bk64, s)) return;
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);
     if (q.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }
     else if (q.Nout > 32) { if (bk64) launch_igemm2<64, 64>(q, s); else launch_igemm2<64, 32>(q, s); }

@@ -49,6 +49,47 @@ def test_igemm2_channel_slice_input(sim, force_v2):
     kc.check_conv_fwd(sim, (1, 64, 1, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), ldx_extra=16)
 
 
+# ---- STRIP variant: one staged strip of source rows per channel chunk serves every tap (row offsets + fragment masks)
+STRIP_CASES = [
+    ((1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),       # BN 64 (upper waves carry no weight copy), 2 chunks, ragged tile
+    ((2, 64, 3, 12, 12), 136, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),    # 4 tiles (strips cross frame and sample borders), two N tiles
+    ((1, 128, 4, 6, 6), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),      # 3 temporal taps (delta +-36), 4 chunks: a strip issue at every third step
+    ((1, 96, 1, 8, 8), 96, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),       # dilation 2 (delta up to +-18), 3 chunks
+    ((1, 64, 3, 5, 5), 96, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),       # 27 taps, delta +-31
+    ((2, 32, 1, 40, 40), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),     # ONE chunk (no second strip), 13 tiles, wide rows (delta +-41)
+    ((1, 160, 2, 7, 7), 256, (1, 5, 5), (1, 1, 1), (0, 2, 2), (1, 1, 1)),     # 25 taps, 5 chunks, two full N tiles
+]
+
+
+@pytest.mark.parametrize("case", STRIP_CASES)
+def test_igemm2_strip_fwd_dgrad(sim, force_v2, case, monkeypatch, capfd):
+    monkeypatch.setenv("SF_IGEMM2_STRIP", "2")
+    monkeypatch.setenv("SF_TRACE", "1")
+    kc.check_conv_fwd(sim, *case)
+    kc.check_conv_dgrad(sim, *case)
+    err = capfd.readouterr().err
+    # the data gradient contracts over Co (needs Co % 32 == 0) and produces Ci columns (needs Ci > 32) to run this kernel family
+    want = 2 if (case[1] % 32 == 0 and case[0][1] > 32) else 1
+    assert err.count("igemm2 strip") >= want, "the strip variant must be taken: " + err[-400:]
+
+
+def test_igemm2_strip_epilogues(sim, force_v2, monkeypatch):
+    monkeypatch.setenv("SF_IGEMM2_STRIP", "2")
+    kc.check_conv_dgrad(sim, (1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), resid=True)
+    kc.check_conv_fwd_fused(sim, (1, 64, 2, 9, 9), 72, (1, 3, 3), (1, 1, 1), (0, 1, 1), resid=True, relu=True)
+    kc.check_conv_fwd(sim, (1, 64, 1, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), ldx_extra=16)
+    kc.check_conv_dgrad_bn(sim, (2, 64, 2, 9, 9), 64, (1, 3, 3), (0, 1, 1))
+
+
+def test_igemm2_strip_not_taken_when_ineligible(sim, force_v2, monkeypatch, capfd):
+    """Strided forward, two-tap and wide-displacement geometries keep the gather kernel."""
+    monkeypatch.setenv("SF_IGEMM2_STRIP", "2")
+    monkeypatch.setenv("SF_TRACE", "1")
+    kc.check_conv_fwd(sim, (1, 32, 2, 10, 10), 40, (1, 3, 3), (1, 2, 2), (0, 1, 1))            # stride 2
+    kc.check_conv_fwd(sim, (1, 64, 4, 12, 12), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0))            # delta +-144 rows
+    assert "igemm2 strip" not in capfd.readouterr().err
+
+
 # strided data gradients: one launch per stride-residue class (sf_api.hip: try_igemm2_strided_dgrad)
 STRIDED = [
     ((1, 64, 2, 10, 10), 64, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),     # 3x3 stride 2: classes with 1 / 2 / 2 / 4 taps
