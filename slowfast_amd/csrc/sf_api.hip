@@ -188,10 +188,11 @@ static void launch_igemm2(Igemm2Params& q, hipStream_t s) {
 }
 // STRIP variant (sf_igemm2.h): stride-1 convolutions over a row space that coincides with the source position space, at least
 // three taps, all tap displacements within 128 rows of each other (1x3x3 / pad 1 up to W = 63; 3x1x1 on 7x7 maps).  Fills the
-// strip fields of q and launches; false = not eligible.  SF_IGEMM2_STRIP=0 disables, =2 also replaces the 64-deep variant.
+// strip fields of q and launches; false = not eligible.  Off by default; SF_IGEMM2_STRIP=1 takes it wherever the 32-deep
+// gather variant would run, =2 also where the 64-deep one would.
 static bool try_igemm2_strip(Igemm2Params& q, bool bk64, hipStream_t s) {
     const char* e = getenv("SF_IGEMM2_STRIP");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = e ? atoi(e) : 0;   // opt-in: slower than the gather kernel on every eligible layer (profiles/r3_v5_strip_ab.txt)
     if (mode == 0 || (bk64 && mode < 2)) return false;
     if (q.omap || q.ntaps < 3 || q.Nout <= 32 || q.C % 32 != 0) return false;
     if (q.mulT != 1 || q.mulH != 1 || q.mulW != 1) return false;
@@ -227,6 +228,7 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     const int force_bk = (e = getenv("SF_IGEMM2_BK")) ? atoi(e) : 0;
     const bool bk64 = q.C % 64 == 0 && force_bk != 32 && (force_bk == 64 || tiles <= 320);
     static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+    q.ablate = (e = getenv("SF_IGEMM2_ABLATE")) ? atoi(e) : 0;     // diagnostic: parts of the kernel switched off (wrong results)
     if (try_igemm2_strip(q, bk64, s)) return;
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);
     if (q.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }

@@ -32,6 +32,11 @@
     } while (0)
 #endif
 
+// keeps a fragment register live without using it (diagnostic ablations only)
+#ifndef SF_KEEP_ALIVE
+#define SF_KEEP_ALIVE(x) asm volatile("" ::"v"(x))
+#endif
+
 // 16 bytes of zeros every padding tap reads (the module's own constant: the callee allocates nothing)
 __device__ __attribute__((aligned(64))) const uint32_t sf_zero_line[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -81,6 +86,9 @@ struct Igemm2Params {
     // (>= 0, <= 128), strip_e0 = -min(sdelta), strip_rows = 256 + max(soff) rounded up to 16 (<= 384).
     int strip_e0, strip_rows;
     int32_t soff[SF_I2_MAXTAPS];
+    // DIAGNOSTIC (SF_IGEMM2_ABLATE, tools/microbench.py only; results are garbage): bit 0 no copies inside the K loop, bit 1 no
+    // LDS reads / MFMAs, bit 2 LDS reads but no MFMAs, bit 3 return before the epilogue, bit 4 no barrier inside the K loop
+    int ablate;
 };
 
 // LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase
@@ -99,6 +107,10 @@ __device__ __forceinline__ int i2_lds_off(int row, int kslot) {
 // multiplied; a tap is a row offset into it, and rows whose tap leaves the source (padding) are zeroed in the FRAGMENT (per-lane
 // validity bits, 4 v_cndmask per fragment) because the strip is shared by taps with different padding.  Per tap step only the
 // 32 x BN weight slice is copied (one instruction per wave).  Same epilogue, same K order (chunk outer, tap inner).
+// MEASURED (profiles/r3_v5_strip_ab.txt): correct, and SLOWER than the gather kernel on every eligible SlowFast layer (s2.b
+// 145 -> 189 us, s3.b 105 -> 126, s4.b 86 -> 98; step 766 -> 758 clips/s): the loop carries 61 VALU instructions per step
+// against 21 (tap-dependent fragment addresses, validity masks), which costs more than the saved copies return.  Kept as an
+// opt-in (SF_IGEMM2_STRIP=1|2) with its tests; the launcher does not take it by default.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NST, bool STRIP = false>
 // register cap: the 32-deep variant must fit TWO workgroups per CU (4 waves per SIMD -> 128 VGPRs), the 64-deep one runs alone
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES_M * WAVES_N) / 4) void sf_igemm2_kernel(Igemm2Params p) {
@@ -261,6 +273,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
             for (int i = 0; i < TM; ++i) af[i] = ld16(As + i2_lds_off<BK>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = ld16(Bs + i2_lds_off<BK>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+            if (p.ablate & 4) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) SF_KEEP_ALIVE(af[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) SF_KEEP_ALIVE(bf[j]);
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -341,13 +360,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
             } else {
                 SF_WAIT_VMEM();
             }
-            SF_BARRIER_KEEP_VMEM();                                 // ... for every wave; stage ks - 1 is no longer read
-            if (issued < ksteps) { issue(tap_i, c_i, nxt); advance(); ++issued; }
-            compute(cur);
+            if (!(p.ablate & 16)) SF_BARRIER_KEEP_VMEM();           // ... for every wave; stage ks - 1 is no longer read
+            if (issued < ksteps) { if (!(p.ablate & 1)) issue(tap_i, c_i, nxt); advance(); ++issued; }
+            if (!(p.ablate & 2)) compute(cur);
             cur = cur == NST - 1 ? 0 : cur + 1;
             nxt = nxt == NST - 1 ? 0 : nxt + 1;
         }
         __syncthreads();                                            // the epilogue staging reuses the operand buffers
+        if (p.ablate & 8) return;
     }
 
     // ---------------- epilogue: scale, bias, BatchNorm partial statistics (fp32, from the accumulators)

@@ -326,6 +326,7 @@ inline void hipsim_global_load_lds16(const void* gptr, void* lds_base) {
 #define SF_WAVE_LDS_SYNC() hipsim::wave_sync()
 #define SF_WAIT_VMEM_N(N) hipsim::wave_sync()
 #define SF_BARRIER_KEEP_VMEM() __syncthreads()
+#define SF_KEEP_ALIVE(x) ((void)(x))
 #define SF_SCALAR_PTR(T, p) ((const T*)(p))
 
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }

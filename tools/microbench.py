@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--json", default="")
-    ap.add_argument("--filter", default="")
+    ap.add_argument("--filter", default="", help="substring of the layer name; several alternatives separated by |")
     ap.add_argument("--no-bn", action="store_true", help="skip the BatchNorm / activation kernels (GEMM variant sweeps)")
     ap.add_argument("--markers", action="store_true", help="launch a torch.arange kernel before the fwd / dgrad / wgrad phase of "
                     "every layer and after the last one: phase separators for tools/pmc_per_layer.py under rocprofv3 --pmc")
@@ -112,7 +112,7 @@ def main():
     rows = []
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0, "bn": 0.0}
     for name, Ci, T, H, W, Co, k, s, p, cnt in LAYERS:
-        if a.filter and a.filter not in name:
+        if a.filter and not any(f in name for f in a.filter.split("|")):
             continue
         Cw = Ci
         stem = "stem" in name
