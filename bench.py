@@ -212,6 +212,7 @@ def spawn_ranks(a):
 def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_profile, cpu_base):
     """Builds the model of `preset`, times `steps` training steps, returns the result object (rank 0) or None."""
     import slowfast_amd as sa
+    from slowfast_amd import lib as sflib
     from slowfast_amd.data_parallel import GradReducer
     from slowfast_amd.profiler import KernelProfiler
 
@@ -354,7 +355,7 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
                       f"per-GPU batch {batch}",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp16", "data": "DRY RUN on the CPU host simulator with a shrunken model -- not a measurement" if a.dry_run_cpu else "synthetic",
+            "dtype": sflib.ACT_MODE, "data": "DRY RUN on the CPU host simulator with a shrunken model -- not a measurement" if a.dry_run_cpu else "synthetic",
             "config": {"workload": f"{preset}: forward + {cfg.MODEL.LOSS_FUNC} loss + backward + {cfg.SOLVER.OPTIMIZING_METHOD} step, "
                                    f"inputs resident in HBM, "
                                    f"per-GPU batch {batch}", "global_batch": batch * world,
@@ -397,7 +398,8 @@ def main():
         return
     if a.dry_run_cpu and "SFAMD_LIBRARY" not in os.environ:
         from slowfast_amd import build_ext
-        os.environ["SFAMD_LIBRARY"] = build_ext.build_hostsim()      # inherited by the spawned ranks
+        from slowfast_amd import lib as sflib
+        os.environ["SFAMD_LIBRARY"] = build_ext.build_hostsim(act=sflib.ACT_MODE)      # inherited by the spawned ranks
         os.environ.setdefault("SF_SIM_THREADS", "2")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 18
+#define SF_ABI_VERSION 19
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -38,6 +38,14 @@ typedef struct sf_conv_desc {
 
 int sf_abi_version(void);
 const char* sf_backend(void);     /* "gfx950" (product) or "hostsim" (CPU test build of the same sources) */
+/* The 16-bit storage type this build of the library keeps activations / packed weights in and feeds the MFMAs with (every
+ * `void*` activation or packed-weight argument below points at elements of THAT type; "fp16" in the comments of this header
+ * means it).  The reference runs its mixed-precision path under torch.cuda.amp.autocast (tools/train_net.py:101-118), which
+ * admits float16 and bfloat16; libsfamd.so is the float16 build, libsfamd_bf16.so (same sources, -DSF_ACT_BF16) the bfloat16
+ * one.  Accumulation, statistics and parameter gradients are fp32 in both. */
+#define SF_ACT_FP16 0
+#define SF_ACT_BF16_ID 1
+int sf_act_dtype(void);
 const char* sf_last_error(void); /* host string, thread-local */
 
 /* ---- Conv3d -- replaces nn.Conv3d at resnet_helper.py:331-369 (BottleneckTransform a/b/c),

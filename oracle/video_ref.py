@@ -14,6 +14,9 @@ import torch
 import torch.nn.functional as F
 
 
+STORAGE_DTYPE = torch.float16     # the storage model's 16-bit type; a bf16 test process sets torch.bfloat16
+
+
 class _RoundFp16(torch.autograd.Function):
     """y = fp16(x) in forward AND fp16(dy) in backward: emulates an fp16 HBM round trip of an activation and of
     its gradient.  Used only by the "fp16 storage model" of the oracle (``video_forward(..., store=round_fp16)``),
@@ -21,11 +24,11 @@ class _RoundFp16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        return x.half().to(x.dtype)
+        return x.to(STORAGE_DTYPE).to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return g.half().to(g.dtype)
+        return g.to(STORAGE_DTYPE).to(g.dtype)
 
 
 def round_fp16(x):

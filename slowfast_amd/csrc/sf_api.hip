@@ -49,6 +49,7 @@ extern "C" const char* sf_backend(void) {
     return "gfx950";
 #endif
 }
+extern "C" int sf_act_dtype(void) { return SF_ACT_DTYPE_ID; }
 extern "C" const char* sf_last_error(void) { return g_err; }
 
 static int check_desc(const sf_conv_desc* d) {
@@ -229,6 +230,7 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     const bool bk64 = q.C % 64 == 0 && force_bk != 32 && (force_bk == 64 || tiles <= 320);
     static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
     q.ablate = (e = getenv("SF_IGEMM2_ABLATE")) ? atoi(e) : 0;     // diagnostic: parts of the kernel switched off (wrong results)
+    q.stagger = (e = getenv("SF_IGEMM2_STAGGER")) ? atoi(e) : 0;
     if (try_igemm2_strip(q, bk64, s)) return;
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);
     if (q.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }

@@ -178,21 +178,21 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
             for (int s = 0; s < KD; ++s) {
                 const f16x8 kf = ld16(Ks + (16 * t + pl) * KP + 32 * s + 8 * g);
 #pragma unroll
-                for (int u = 0; u < QT; ++u) st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][s], st[u], 0, 0, 0);
+                for (int u = 0; u < QT; ++u) st[u] = SF_MFMA16(kf, qf[u][s], st[u]);
             }
             if (bias) {
                 const f16x8 a0 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
 #pragma unroll
                 for (int u = 0; u < QT; ++u) {
-                    st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[u][0], st[u], 0, 0, 0);
-                    st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[u][0], st[u], 0, 0, 0);
+                    st[u] = SF_MFMA16(a0, rqh[u][0], st[u]);
+                    st[u] = SF_MFMA16(a0, rql[u][0], st[u]);
                 }
                 if (bias2) {
                     const f16x8 a1 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
 #pragma unroll
                     for (int u = 0; u < QT; ++u) {
-                        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[u][1], st[u], 0, 0, 0);
-                        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[u][1], st[u], 0, 0, 0);
+                        st[u] = SF_MFMA16(a1, rqh[u][1], st[u]);
+                        st[u] = SF_MFMA16(a1, rql[u][1], st[u]);
                     }
                 }
             }
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
         for (int dt = 0; dt < DT; ++dt) {
             const f16x8 vt = attn_tr_frag(Vs, KP, dt * 16, pl, g);
 #pragma unroll
-            for (int u = 0; u < QT; ++u) oacc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pf[u], oacc[u][dt], 0, 0, 0);
+            for (int u = 0; u < QT; ++u) oacc[u][dt] = SF_MFMA16(vt, pf[u], oacc[u][dt]);
         }
     }
 #pragma unroll
@@ -357,23 +357,23 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
                 const f16x8 vf = ld16(Vs + (16 * t + pl) * KP + 32 * s + 8 * g);
 #pragma unroll
                 for (int u = 0; u < QT; ++u) {
-                    st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][s], st[u], 0, 0, 0);
-                    dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof[u][s], dp[u], 0, 0, 0);
+                    st[u] = SF_MFMA16(kf, qf[u][s], st[u]);
+                    dp[u] = SF_MFMA16(vf, dof[u][s], dp[u]);
                 }
             }
             if (bias) {
                 const f16x8 a0 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
 #pragma unroll
                 for (int u = 0; u < QT; ++u) {
-                    st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rqh[u][0], st[u], 0, 0, 0);
-                    st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, rql[u][0], st[u], 0, 0, 0);
+                    st[u] = SF_MFMA16(a0, rqh[u][0], st[u]);
+                    st[u] = SF_MFMA16(a0, rql[u][0], st[u]);
                 }
                 if (bias2) {
                     const f16x8 a1 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
 #pragma unroll
                     for (int u = 0; u < QT; ++u) {
-                        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rqh[u][1], st[u], 0, 0, 0);
-                        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, rql[u][1], st[u], 0, 0, 0);
+                        st[u] = SF_MFMA16(a1, rqh[u][1], st[u]);
+                        st[u] = SF_MFMA16(a1, rql[u][1], st[u]);
                     }
                 }
             }
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
         for (int dt = 0; dt < DT; ++dt) {
             const f16x8 kt_ = attn_tr_frag(Ks, KP, dt * 16, pl, g);
 #pragma unroll
-            for (int u = 0; u < QT; ++u) dqacc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kt_, dsf[u], dqacc[u][dt], 0, 0, 0);
+            for (int u = 0; u < QT; ++u) dqacc[u][dt] = SF_MFMA16(kt_, dsf[u], dqacc[u][dt]);
         }
         if (bias) {
 #pragma unroll
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
                     const f16x8 oht = attn_tr_frag(OHs, SF_ATTN_OHP, jt * 16, pl, g);
 #pragma unroll
                     for (int u = 0; u < QT; ++u)
-                        drqacc[u][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oht, dsf[u], drqacc[u][jt], 0, 0, 0);
+                        drqacc[u][jt] = SF_MFMA16(oht, dsf[u], drqacc[u][jt]);
                 }
         }
     }
@@ -540,15 +540,15 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
-                st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Qs + (16 * t + pl) * KP + 32 * s + 8 * g), kf[s], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Os + (16 * t + pl) * KP + 32 * s + 8 * g), vf[s], dp, 0, 0, 0);
+                st = SF_MFMA16(ld16(Qs + (16 * t + pl) * KP + 32 * s + 8 * g), kf[s], st);
+                dp = SF_MFMA16(ld16(Os + (16 * t + pl) * KP + 32 * s + 8 * g), vf[s], dp);
             }
             if (bias) {
-                st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], st, 0, 0, 0);
+                st = SF_MFMA16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], st);
+                st = SF_MFMA16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], st);
                 if (bias2) {
-                    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], st, 0, 0, 0);
+                    st = SF_MFMA16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], st);
+                    st = SF_MFMA16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], st);
                 }
             }
 #pragma unroll
@@ -561,8 +561,8 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
         }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_tr_frag(Os, KP, dt * 16, pl, g), pf, dvacc[dt], 0, 0, 0);
-            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_tr_frag(Qs, KP, dt * 16, pl, g), dsf, dkacc[dt], 0, 0, 0);
+            dvacc[dt] = SF_MFMA16(attn_tr_frag(Os, KP, dt * 16, pl, g), pf, dvacc[dt]);
+            dkacc[dt] = SF_MFMA16(attn_tr_frag(Qs, KP, dt * 16, pl, g), dsf, dkacc[dt]);
         }
     }
     if (!kok) return;

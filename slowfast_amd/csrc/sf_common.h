@@ -2,13 +2,28 @@
 //
 // Data model: activations live in HBM as fp16, channels-last -- logical (N,C,T,H,W)
 // tensors whose memory order is N,T,H,W,C ("position rows" of C channels, row pitch `ld` elements so
-// channel-slice views work).  All contractions run on v_mfma_f32_16x16x32_f16 with fp32 accumulation;
+// channel-slice views work).  All contractions run on v_mfma_f32_16x16x32_{f16,bf16} with fp32 accumulation;
 // BatchNorm statistics, affine parameters and weight gradients are fp32.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// `f16` is THE 16-bit storage type of activations, packed weights and MFMA operands throughout the library: IEEE half in the
+// default build (libsfamd.so), bfloat16 when compiled with -DSF_ACT_BF16 (libsfamd_bf16.so, SF_ACT_DTYPE=bf16 on the Python
+// side; sf_act_dtype() tells which).  Everything else -- accumulators, statistics, parameter gradients -- is fp32 in both.
+#ifdef SF_ACT_BF16
+typedef __bf16 f16;
+#define SF_ACT_DTYPE_ID 1
+#ifndef SF_MFMA16
+#define SF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
+#else
 typedef _Float16 f16;
+#define SF_ACT_DTYPE_ID 0
+#ifndef SF_MFMA16
+#define SF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#endif
+#endif
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));

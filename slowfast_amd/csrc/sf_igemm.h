@@ -318,7 +318,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
     };
 
     if constexpr (GL && GL3) {
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
         }
     };
 

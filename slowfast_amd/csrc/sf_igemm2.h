@@ -89,6 +89,7 @@ struct Igemm2Params {
     // DIAGNOSTIC (SF_IGEMM2_ABLATE, tools/microbench.py only; results are garbage): bit 0 no copies inside the K loop, bit 1 no
     // LDS reads / MFMAs, bit 2 LDS reads but no MFMAs, bit 3 return before the epilogue, bit 4 no barrier inside the K loop
     int ablate;
+    int stagger;        // 1: waves NW/2.. issue the next stage's copies between the two MFMA halves of a stage (see compute())
 };
 
 // LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase
@@ -263,7 +264,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
+    // `mid` runs once per stage between two halves of its MFMAs (after all of the stage's LDS reads of that half are issued):
+    // the waves of the upper half of the workgroup issue their copies THERE instead of right after the barrier (p.stagger), so
+    // the two waves that share a SIMD do not sit in copy issue (back-pressured by the memory pipeline) at the same time
+    auto compute = [&](int buf, auto&& mid) {
         const f16* As = smem + buf * STAGE;
         const f16* Bs = As + A_ELEMS;
 #pragma unroll
@@ -280,11 +284,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 for (int j = 0; j < TN; ++j) SF_KEEP_ALIVE(bf[j]);
                 continue;
             }
+            if (BK == 64 && kk == 1) mid();
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                if (BK == 32 && i == TM / 2) mid();
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
+            }
         }
     };
 
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
     };
 
     if constexpr (STRIP) {
@@ -353,6 +360,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
         int issued = 0;
         for (; issued < NST - 1 && issued < ksteps; ++issued) { issue(tap_i, c_i, issued); advance(); }
         int cur = 0, nxt = NST - 1;
+        const bool late = p.stagger && wave >= NW / 2;              // wave-uniform
         for (int ks = 0; ks < ksteps; ++ks) {
             if constexpr (NST == 3) {
                 if (ks + 1 < ksteps) SF_WAIT_VMEM_N(COPIES);        // stage ks landed, stage ks + 1 may still be in flight
@@ -361,8 +369,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 SF_WAIT_VMEM();
             }
             if (!(p.ablate & 16)) SF_BARRIER_KEEP_VMEM();           // ... for every wave; stage ks - 1 is no longer read
-            if (issued < ksteps) { if (!(p.ablate & 1)) issue(tap_i, c_i, nxt); advance(); ++issued; }
-            if (!(p.ablate & 2)) compute(cur);
+            const bool doi = issued < ksteps && !(p.ablate & 1);
+            if (doi && !late) issue(tap_i, c_i, nxt);
+            if (!(p.ablate & 2)) compute(cur, [&]() { if (doi && late) issue(tap_i, c_i, nxt); });
+            else if (doi && late) issue(tap_i, c_i, nxt);
+            if (issued < ksteps) { advance(); ++issued; }
             cur = cur == NST - 1 ? 0 : cur + 1;
             nxt = nxt == NST - 1 ? 0 : nxt + 1;
         }

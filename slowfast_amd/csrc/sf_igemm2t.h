@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void sf_igemm2t_kernel(Igemm2tParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j][ks], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = SF_MFMA16(af[i], bf[j][ks], acc[i][j]);
         }
         const int m_base = slice_row0(s);
         // accumulator element r of tile (i, j): row i*16 + 4*(lane >> 4) + r, column j*16 + (lane & 15)

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_kernel(StemParams p) {
 #pragma unroll
         for (int i = 0; i < SF_STEM_TH; ++i) px[i] = ld16(base + i * row_step);
 #pragma unroll
-        for (int i = 0; i < SF_STEM_TH; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, px[i], acc[i], 0, 0, 0);
+        for (int i = 0; i < SF_STEM_TH; ++i) acc[i] = SF_MFMA16(a, px[i], acc[i]);
         wf = wnext;
         if (++kh == p.kH) { kh = 0; ++kt; }
     }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(SF_STEM_WG_THREADS, 4) void sf_stem_wgrad_kernel(St
                                 f16x4 tv = as_f16x4(SF_LDS_TR16(patch + xoff[h] + (koff[q] + 2 * jh) * 8));
                                 bf[4 * h + 0] = tv[0]; bf[4 * h + 1] = tv[1]; bf[4 * h + 2] = tv[2]; bf[4 * h + 3] = tv[3];
                             }
-                            acc[q][jh] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[q][jh], 0, 0, 0);
+                            acc[q][jh] = SF_MFMA16(af, bf, acc[q][jh]);
                         }
                     }
                 }

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512, NST > 3 ? 2 : 4) void sf_wgrad2_kernel(Wgrad2P
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
     };
 
     {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void sf_wgrad2t_kernel(Wgrad2Params p) {
         for (int i = 0; i < TMC; ++i)
 #pragma unroll
             for (int j = 0; j < TNK; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
     };
 
     {

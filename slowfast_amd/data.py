@@ -10,10 +10,12 @@ normalised fp16 N,T,H,W,4 buffer the stems read directly (``engine.StemConvUnit`
 produced here) -- a quarter of the bytes over PCIe and no fp32 clip in HBM."""
 import torch
 
+from . import lib as _sflib
+
 from . import ops
 from .lib import get_lib
 
-_f16 = torch.float16
+_f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
 
 
 def pathway_frame_indices(cfg, num_frames):

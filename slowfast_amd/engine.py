@@ -23,9 +23,11 @@ import os
 
 import torch
 
+from . import lib as _sflib
+
 from . import ops
 
-_f16 = torch.float16
+_f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
 _listeners = []
 # While a training step is being captured into a HIP graph (slowfast_amd.step.TrainStep) the fp32 -> fp16 weight
 # repack must be part of the captured work unconditionally: a replay runs after an optimizer update that the

@@ -11,8 +11,26 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
+# 16-bit storage type of activations / packed weights / MFMA operands, fixed per PROCESS: SF_ACT_DTYPE=fp16 (default) loads
+# libsfamd.so, =bf16 loads libsfamd_bf16.so -- the same sources compiled with -DSF_ACT_BF16 (bfloat16 storage,
+# v_mfma_f32_16x16x32_bf16); both are what torch.cuda.amp.autocast admits on the reference side (tools/train_net.py:101-118).
+ACT_MODE = os.environ.get("SF_ACT_DTYPE", "fp16").lower()
+if ACT_MODE not in ("fp16", "bf16"):
+    raise ValueError(f"SF_ACT_DTYPE={ACT_MODE!r}: expected fp16 or bf16")
+DEFAULT_LIBRARY = os.path.join(_HERE, "libsfamd.so" if ACT_MODE == "fp16" else "libsfamd_bf16.so")
+
+
+def act_dtype():
+    """torch dtype of every activation / packed-weight buffer handed to the library in this process."""
+    import torch
+    return torch.float16 if ACT_MODE == "fp16" else torch.bfloat16
+
+
+def act_eps():
+    """Unit round-off of the storage type (2^-11 fp16, 2^-8 bf16): test tolerances are stated for fp16 and scaled by
+    act_eps() / 2^-11 in a bf16 process."""
+    return 2.0 ** -11 if ACT_MODE == "fp16" else 2.0 ** -8
 
 
 class ConvDesc(Structure):
@@ -50,6 +68,7 @@ _F = c_void_p  # float* passed as raw address
 _SIGNATURES = {
     "sf_abi_version": (c_int, []),
     "sf_backend": (c_char_p, []),
+    "sf_act_dtype": (c_int, []),
     "sf_last_error": (c_char_p, []),
     "sf_conv_weight_ld": (c_int, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
     "sf_prep_weights": (c_int, [POINTER(ConvDesc), _F, _P, _P, _P]),
@@ -159,6 +178,9 @@ class SfLibrary:
         if ver != ABI_VERSION:
             raise SfError(f"{path}: ABI version {ver}, expected {ABI_VERSION}")
         self.backend = self.cdll.sf_backend().decode()
+        self.act_mode = ("fp16", "bf16")[self.cdll.sf_act_dtype()]
+        if self.act_mode != ACT_MODE:
+            raise SfError(f"{path} is the {self.act_mode} build of the library, this process runs with SF_ACT_DTYPE={ACT_MODE}")
 
     def call(self, name, *args, work=None):
         """Invoke an entry point; ``work`` = optional dict(bytes=, flops=) of algorithmic work (profiling only)."""

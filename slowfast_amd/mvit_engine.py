@@ -15,11 +15,13 @@ import os
 
 import torch
 
+from . import lib as _sflib
+
 from . import engine, tokens
 from . import engine as _engine
 from .engine import _grad_dest, _notify, param_grads
 
-_f16 = torch.float16
+_f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
 # fc1's bias gradient from the epilogue of the GEMM that produces d(loss)/d(fc1 output) (tokens.gemm_gelu_grad(dbias=...))
 # instead of a separate column-sum pass over it; SF_FUSE_COLSUM=0 keeps the pass (A/B)
 FUSE_COLSUM = os.environ.get("SF_FUSE_COLSUM", "1") != "0"

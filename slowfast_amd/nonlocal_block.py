@@ -6,12 +6,14 @@ Same constructor, children (conv_theta, conv_phi, conv_g, conv_out, bn, pool) an
 import torch
 import torch.nn as nn
 
+from . import lib as _sflib
+
 from . import engine, ops, tokens
 from .engine import ConvUnit, _grad_dest, _notify, as_cl, param_grads
 from .lib import get_lib
 from .x3d import cl5d, rows2d
 
-_f16 = torch.float16
+_f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
 
 
 def pool3d_fwd(x, k):

@@ -9,9 +9,11 @@ from ctypes import byref, c_int32
 
 import torch
 
+from . import lib as _sflib
+
 from .lib import ConvDesc, SfError, get_lib
 
-_f16 = torch.float16
+_f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
 
 
 def _triple(v):

@@ -13,6 +13,8 @@ from ctypes import byref
 import torch
 import torch.nn as nn
 
+from . import lib as _sflib
+
 from . import engine, ops, tokens
 from .engine import BNState, ConvUnit, StemConvUnit, _grad_dest, _notify, _sync_of, as_cl, bn_statistics, param_grads
 from .lib import get_lib
@@ -20,7 +22,7 @@ from .registry import MODEL_REGISTRY
 from .resblocks import ResStage, _TRANS
 from .video_models import get_norm, init_weights
 
-_f16 = torch.float16
+_f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
 
 
 def _pad8(c):

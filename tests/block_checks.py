@@ -6,9 +6,10 @@ from oracle import video_ref
 from slowfast_amd.resblocks import BottleneckTransform, ResBlock
 from slowfast_amd.stems import ResNetBasicStem
 from slowfast_amd.video_models import FuseFastToSlow
-from tests.kernel_checks import cl_to_host, host_to_cl
+from tests.kernel_checks import ACT, F16_EPS, cl_to_host, host_to_cl
 
-TOL = 2e-3   # relative L2, fp16 storage + fp32 accumulation -- asserted on EVERY compared quantity, no fallback
+EPS_SCALE = F16_EPS / 2.0 ** -10     # 1 in an fp16 process, 8 under SF_ACT_DTYPE=bf16: every bound below is stated for fp16
+TOL = 2e-3 * EPS_SCALE   # relative L2, 16-bit storage + fp32 accumulation -- asserted on EVERY compared quantity, no fallback
 
 # ReLU masks.  An element whose pre-activation lies within fp16 round-off of zero lands on either side of the ReLU in two
 # correct fp16 realisations, and although its forward effect is O(round-off) its backward effect is O(1) (its gradient is
@@ -18,7 +19,7 @@ TOL = 2e-3   # relative L2, fp16 storage + fp32 accumulation -- asserted on EVER
 # oracle.video_ref._ReluFixedMask): flipped elements are thereby excluded from the comparison and everything else -- all
 # the convolution / BatchNorm / residual arithmetic of the block, forward and backward -- must agree to TOL.  The number of
 # flipped elements is itself bounded (a wrong BatchNorm or a wrong tap flips a large fraction, not 0.1 %).
-MAX_FLIP_FRACTION = 3e-3
+MAX_FLIP_FRACTION = 3e-3 * EPS_SCALE
 
 
 def rel(a, b):
@@ -124,10 +125,10 @@ def check_resblock(device, dim_in, dim_out, temp_k, stride, inner, shape, dilati
     blk = ResBlock(dim_in, dim_out, temp_k, stride, BottleneckTransform, inner, dilation=dilation)
     sd = _load(blk, seed)
     blk = blk.to(device).train()
-    x = torch.randn(shape).half().float()
+    x = torch.randn(shape).to(ACT).float()
     with torch.no_grad():
         oshape = video_ref.res_block(x, sd_prefixed(sd, "blk."), "blk", stride, dilation, False, True, None).shape
-    dout = torch.randn(oshape).half().float()
+    dout = torch.randn(oshape).to(ACT).float()
 
     # the engine first: its masks (decided by the raw convolution outputs it stored and its BatchNorm scale / shift)
     xc = host_to_cl(x, device).requires_grad_(True)
@@ -179,8 +180,8 @@ def check_stem(device, dim_out, kernel, shape, seed=5):
     stem = stem.to(device).train()
     x = torch.randn(shape)
     with torch.no_grad():
-        o32 = video_ref.stem(x.half().float(), sd_prefixed(sd, "st."), "st", True, None)
-    dout = torch.randn(o32.shape).half().float()
+        o32 = video_ref.stem(x.to(ACT).float(), sd_prefixed(sd, "st."), "st", True, None)
+    dout = torch.randn(o32.shape).to(ACT).float()
     engine.CAPTURE = []
     try:
         out = stem(x.to(device))
@@ -201,7 +202,7 @@ def check_stem(device, dim_out, kernel, shape, seed=5):
     masks = {"relu": _pre_mask(raw, *cap["bn"][0]), "pool_index": pool_index}
 
     def body(p, st):
-        o = video_ref.stem(x.half().float(), p, "st", True, st, masks=masks)
+        o = video_ref.stem(x.to(ACT).float(), p, "st", True, st, masks=masks)
         o.backward(dout)
         return {"out": o.detach()}
 
@@ -219,10 +220,10 @@ def check_fuse(device, dim_in, ratio, kernel, alpha, shape_fast, seed=9):
     sd = _load(fz, seed)
     fz = fz.to(device).train()
     N, C, T, H, W = shape_fast
-    xf = torch.randn(shape_fast).half().float()
-    xs = torch.randn((N, dim_in * 4, T // alpha, H, W)).half().float()
-    dcat = torch.randn((N, dim_in * 4 + dim_in * ratio, T // alpha, H, W)).half().float()
-    dpass = torch.randn(shape_fast).half().float()      # gradient reaching x_f from the Fast pathway itself
+    xf = torch.randn(shape_fast).to(ACT).float()
+    xs = torch.randn((N, dim_in * 4, T // alpha, H, W)).to(ACT).float()
+    dcat = torch.randn((N, dim_in * 4 + dim_in * ratio, T // alpha, H, W)).to(ACT).float()
+    dpass = torch.randn(shape_fast).to(ACT).float()      # gradient reaching x_f from the Fast pathway itself
     xfc, xsc = host_to_cl(xf, device).requires_grad_(True), host_to_cl(xs, device).requires_grad_(True)
     cat, xf_out = fz([xsc, xfc])
     torch.autograd.backward([cat, xf_out], [host_to_cl(dcat, device), host_to_cl(dpass, device)])
@@ -233,7 +234,7 @@ def check_fuse(device, dim_in, ratio, kernel, alpha, shape_fast, seed=9):
         xfr, xsr = xf.clone().requires_grad_(True), xs.clone().requires_grad_(True)
         o = video_ref.fuse(xsr, xfr, p, "fz", alpha, True, st, masks=masks)
         (o * dcat).sum().backward()
-        return {"cat": o.detach(), "dx_s": xsr.grad, "dx_f": xfr.grad.half().float() + dpass}
+        return {"cat": o.detach(), "dx_s": xsr.grad, "dx_f": xfr.grad.to(ACT).float() + dpass}
 
     ref, rg, st = _oracle_run(_Case(sd, "fz.", body))
     return _compare(fz, "fz.", got, ref, rg, st)
@@ -246,8 +247,8 @@ def check_bottleneck_alone(device, shape, seed=11):
     t = BottleneckTransform(shape[1], 32, 3, 1, 8, 1)
     sd = _load(t, seed)
     t = t.to(device).train()
-    x = torch.randn(shape).half().float()
-    dout = torch.randn((shape[0], 32) + tuple(shape[2:])).half().float()
+    x = torch.randn(shape).to(ACT).float()
+    dout = torch.randn((shape[0], 32) + tuple(shape[2:])).to(ACT).float()
     xc = host_to_cl(x, device).requires_grad_(True)
     engine.CAPTURE = []
     try:
@@ -295,10 +296,10 @@ def check_x3d_block(device, dim_in, dim_out, stride, inner, shape, block_idx=0, 
     blk = ResBlock(dim_in, dim_out, 3, stride, X3DTransform, inner, num_groups=inner, block_idx=block_idx)
     sd = _load(blk, seed)
     blk = blk.to(device).train()
-    x = torch.randn(shape).half().float()
+    x = torch.randn(shape).to(ACT).float()
     with torch.no_grad():
         o32 = video_ref.x3d_block(x, sd_prefixed(sd, "blk."), "blk", stride, True, None)
-    dout = torch.randn(o32.shape).half().float()
+    dout = torch.randn(o32.shape).to(ACT).float()
     xc = host_to_cl(x, device).requires_grad_(True)
     out, caps = _capture_forward(lambda: blk(xc))
     dpad = torch.nn.functional.pad(dout, (0, 0, 0, 0, 0, 0, 0, out.shape[1] - dim_out))     # 54 -> 56: pad channels stay zero
@@ -335,8 +336,8 @@ def check_nonlocal(device, dim, dim_inner, pool_size, shape, instantiation="soft
     nl = Nonlocal(dim, dim_inner, pool_size, instantiation=instantiation)
     sd = _load(nl, seed)
     nl = nl.to(device).train()
-    x = torch.randn(shape).half().float()
-    dout = torch.randn(shape).half().float()
+    x = torch.randn(shape).to(ACT).float()
+    dout = torch.randn(shape).to(ACT).float()
     xc = host_to_cl(x, device).requires_grad_(True)
     out, caps = _capture_forward(lambda: nl(xc))
     out.backward(host_to_cl(dout, device))
@@ -378,12 +379,12 @@ def check_multiscale_block(device, dim, dim_out, heads, thw, stride_q, stride_kv
     blk.load_state_dict(sd)
     blk = blk.to(device).train()
     N = thw[0] * thw[1] * thw[2] + (1 if cls else 0)
-    x = torch.randn((B, N, dim)).half().float()
+    x = torch.randn((B, N, dim)).to(ACT).float()
     psd = sd_prefixed(sd, "blk.")
     with torch.no_grad():
         o32, thw_new = mvit_ref.block(x, psd, "blk", list(thw), heads, list(stride_q), list(stride_kv), cls, None, True, True)
-    dout = torch.randn(o32.shape).half().float()
-    xc = x.to(device).half().requires_grad_(True)
+    dout = torch.randn(o32.shape).to(ACT).float()
+    xc = x.to(device).to(ACT).requires_grad_(True)
     out, thw_e = blk(xc, list(thw))
     assert list(thw_e) == list(thw_new), (thw_e, thw_new)
     out.backward(dout.to(device).to(out.dtype))

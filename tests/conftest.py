@@ -41,8 +41,8 @@ def _use_library(path):
 
 @pytest.fixture(scope="session")
 def hostsim_path():
-    from slowfast_amd import build_ext
-    return build_ext.build_hostsim()
+    from slowfast_amd import build_ext, lib
+    return build_ext.build_hostsim(act=lib.ACT_MODE)      # a bf16 process (SF_ACT_DTYPE=bf16) gets the bf16 simulator build
 
 
 @pytest.fixture()

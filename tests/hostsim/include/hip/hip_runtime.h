@@ -257,8 +257,13 @@ inline int __any(int pred) {
 }
 #define SF_EXP2(x) exp2f(x)
 
-typedef _Float16 hipsim_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 hipsim_f16x4 __attribute__((ext_vector_type(4)));
+#ifdef SF_ACT_BF16
+typedef __bf16 hipsim_f16;      // the library's 16-bit storage type (see csrc/sf_common.h)
+#else
+typedef _Float16 hipsim_f16;
+#endif
+typedef hipsim_f16 hipsim_f16x8 __attribute__((ext_vector_type(8)));
+typedef hipsim_f16 hipsim_f16x4 __attribute__((ext_vector_type(4)));
 typedef float hipsim_f32x4 __attribute__((ext_vector_type(4)));
 
 // v_mfma_f32_16x16x32_f16: D(16x16) = A(16x32) * B(32x16) + C.
@@ -275,7 +280,7 @@ inline hipsim_f32x4 hipsim_mfma_16x16x32_f16(hipsim_f16x8 a, hipsim_f16x8 b, hip
         int row = 4 * (l >> 4) + r;
         float acc = 0.f;
         for (int k = 0; k < 32; ++k) {
-            _Float16 av, bv;
+            hipsim_f16 av, bv;
             memcpy(&av, &w.a[row + 16 * (k >> 3)][2 * (k & 7)], 2);
             memcpy(&bv, &w.b[col + 16 * (k >> 3)][2 * (k & 7)], 2);
             acc += (float)av * (float)bv;
@@ -285,7 +290,7 @@ inline hipsim_f32x4 hipsim_mfma_16x16x32_f16(hipsim_f16x8 a, hipsim_f16x8 b, hip
     hipsim::wave_sync();
     return c;
 }
-#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipsim_mfma_16x16x32_f16((a), (b), (c))
+#define SF_MFMA16(a, b, c) hipsim_mfma_16x16x32_f16((a), (b), (c))
 
 // ds_read_b64_tr_b16: per 16-lane group, lane p supplies the address of 4 contiguous b16
 // (row p/4, columns 4*(p%4)..+3 of a 4x16 block); lane q receives column q: element j comes from
@@ -298,7 +303,7 @@ inline hipsim_f16x4 hipsim_ds_read_tr16(const void* p) {
     int g = l & ~15, q = l & 15;
     hipsim_f16x4 out;
     for (int j = 0; j < 4; ++j) {
-        const _Float16* src = (const _Float16*)w.ptr[g + 4 * j + (q >> 2)];
+        const hipsim_f16* src = (const hipsim_f16*)w.ptr[g + 4 * j + (q >> 2)];
         out[j] = src[q & 3];
     }
     hipsim::wave_sync();

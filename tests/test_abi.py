@@ -71,4 +71,4 @@ def test_error_reporting_through_c_abi(sim):
     with pytest.raises(lib.SfError, match="multiples of 8"):
         ops.prep_weights(torch.zeros(16, 12, 1, 1, 1), geom)
     with pytest.raises(lib.SfError, match="not channels-last"):
-        ops.cl_ld(torch.zeros(1, 16, 1, 4, 4, dtype=torch.float16))
+        ops.cl_ld(torch.zeros(1, 16, 1, 4, 4, dtype=lib.act_dtype()))

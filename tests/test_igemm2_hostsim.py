@@ -49,6 +49,14 @@ def test_igemm2_channel_slice_input(sim, force_v2):
     kc.check_conv_fwd(sim, (1, 64, 1, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), ldx_extra=16)
 
 
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6]])
+def test_igemm2_staggered_copy_issue(sim, force_v2, case, monkeypatch):
+    """SF_IGEMM2_STAGGER=1: the upper four waves issue the next stage's copies between the two MFMA halves of a stage."""
+    monkeypatch.setenv("SF_IGEMM2_STAGGER", "1")
+    kc.check_conv_fwd(sim, *case)
+    kc.check_conv_dgrad(sim, *case)
+
+
 # ---- STRIP variant: one staged strip of source rows per channel chunk serves every tap (row offsets + fragment masks)
 STRIP_CASES = [
     ((1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),       # BN 64 (upper waves carry no weight copy), 2 chunks, ragged tile

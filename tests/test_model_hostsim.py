@@ -58,7 +58,7 @@ def test_precise_bn_protocol_on_drop_ins(sim):
         batch_stat = (new - 0.9 * sd[k]) / 0.1                  # what the oracle's update averaged in
         err = float((msd[k].float() - batch_stat).abs().max() / (batch_stat.abs().max() + 1e-6))
         worst = max(worst, err)
-    assert worst < 5e-2, worst                                  # tiny-model conditioning (see module docstring)
+    assert worst < 5e-2 * mc.EPS_SCALE, worst                                  # tiny-model conditioning (see module docstring)
     for bn in bns:                                              # fvcore then writes its averages back and restores momentum
         bn.running_mean.copy_(torch.zeros_like(bn.running_mean))
         bn.momentum = 0.1
@@ -227,15 +227,15 @@ def test_x3d_sub_batchnorm_backbone_with_full_batch_head(sim):
     loss = torch.nn.functional.cross_entropy(logits.float(), labels)
     (loss * 64.0).backward()
     grads = {k: p.grad.float() / 64.0 for k, p in model.named_parameters()}
-    assert float((logits.detach().float() - o_logits).abs().max()) < 2e-2 * float(o_logits.abs().max())
+    assert float((logits.detach().float() - o_logits).abs().max()) < 2e-2 * mc.EPS_SCALE * float(o_logits.abs().max())
     gn, ogn = float(video_ref.grad_norm(grads)), float(video_ref.grad_norm(o_grads))
-    assert abs(gn - ogn) < 5e-2 * ogn, (gn, ogn)
+    assert abs(gn - ogn) < 5e-2 * mc.EPS_SCALE * ogn, (gn, ogn)
     num = sum(float((grads[k].double() - g.double()).pow(2).sum()) for k, g in o_grads.items())
     den = sum(float(g.double().pow(2).sum()) for g in o_grads.values())
-    assert (num / den) ** 0.5 < 0.3, (num / den) ** 0.5          # tiny-model conditioning (2 samples per split)
+    assert (num / den) ** 0.5 < min(1.0, 0.3 * mc.EPS_SCALE), (num / den) ** 0.5          # tiny-model conditioning (2 samples per split)
     msd = model.state_dict()
     for k, v in o_stats.items():
-        assert float((msd[k].float() - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-4, k
+        assert float((msd[k].float() - v).abs().max()) <= 2e-2 * mc.EPS_SCALE * float(v.abs().max()) + 1e-4, k
 
 
 def test_well_conditioned_1e3_no_yardstick(sim):
