@@ -106,18 +106,6 @@ int sf_conv_dgrad_bn(const sf_conv_desc* d, const void* dy, const void* wd, cons
                      const void* resid_bits, void* dx, const float* mask_scale, const float* mask_shift,
                      const void* mask_bits, const void* bn_y, int32_t bn_ldy, float* bn_part, int32_t bn_part_rows,
                      int32_t* bn_rows, sf_stream_t stream);
-/* Thin layers -- at most 32 output columns and a contraction (taps x channels of the gathered operand) of at most 128, the
- * Fast pathway's 8-32 channel bottlenecks: a streaming kernel (independent waves, weights in registers) that reads positions
- * from the geometry's row table.  dgrad = 0: forward (plain input, optional bias, optional BatchNorm partial sums);
- * dgrad = 1: data gradient (stride 1, no residual).  sf_conv_thin_rowtab_bytes == 0: not a thin layer, use sf_conv_fwd /
- * sf_conv_dgrad.  The table is a function of the geometry and direction: build it once (32-byte aligned, caller-owned).
- * stat_part of sf_conv_fwd_thin has sf_conv_thin_blocks(d, 0) rows of [2][Co] (one per workgroup). */
-int64_t sf_conv_thin_rowtab_bytes(const sf_conv_desc* d, int dgrad);
-int sf_conv_thin_blocks(const sf_conv_desc* d, int dgrad);
-int sf_conv_thin_rowtab(const sf_conv_desc* d, int dgrad, void* tab, sf_stream_t stream);
-int sf_conv_fwd_thin(const sf_conv_desc* d, const void* x, const void* wf, const float* bias, void* y, float* stat_part,
-                     const void* rowtab, sf_stream_t stream);
-int sf_conv_dgrad_thin(const sf_conv_desc* d, const void* dy, const void* wd, void* dx, const void* rowtab, sf_stream_t stream);
 /* dw[Co][Cw][taps] = (zero_first ? 0 : dw) + out_scale * sum_m dy[m] (x) act(x)[m].  The reduction over positions
  * is split; `workspace` (>= sf_conv_wgrad_workspace(d) bytes, caller-owned) holds the per-split partials, which a
  * second kernel sums in a fixed order (no atomics: results are run-to-run reproducible). */

@@ -5,7 +5,6 @@
 #include "sf_igemm.h"
 #include "sf_igemm2.h"
 #include "sf_wgrad2.h"
-#include "sf_igemm2t.h"
 #include "sf_pool.h"
 #include "sf_dwconv.h"
 #include "sf_tokens.h"
@@ -187,39 +186,6 @@ static void launch_igemm2(Igemm2Params& q, hipStream_t s) {
     const dim3 grid((unsigned)(cdiv(q.M, 256) * q.ntiles_n));
     hipLaunchKernelGGL((sf_igemm2_kernel<256, BN, 4, 2, BK, 3>), grid, dim3(512), 0, s, q);
 }
-// STRIP variant (sf_igemm2.h): stride-1 convolutions over a row space that coincides with the source position space, at least
-// three taps, all tap displacements within 128 rows of each other (1x3x3 / pad 1 up to W = 63; 3x1x1 on 7x7 maps).  Fills the
-// strip fields of q and launches; false = not eligible.  Off by default; SF_IGEMM2_STRIP=1 takes it wherever the 32-deep
-// gather variant would run, =2 also where the 64-deep one would.
-static bool try_igemm2_strip(Igemm2Params& q, bool bk64, hipStream_t s) {
-    const char* e = getenv("SF_IGEMM2_STRIP");
-    const int mode = e ? atoi(e) : 0;   // opt-in: slower than the gather kernel on every eligible layer (profiles/r3_v5_strip_ab.txt)
-    if (mode == 0 || (bk64 && mode < 2)) return false;
-    if (q.omap || q.ntaps < 3 || q.Nout <= 32 || q.C % 32 != 0) return false;
-    if (q.mulT != 1 || q.mulH != 1 || q.mulW != 1) return false;
-    if ((int)q.fdrT.d != q.sT || (int)q.fdrH.d != q.sH || (int)q.fdrW.d != q.sW) return false;
-    int dmin = 0, dmax = 0;
-    int32_t delta[SF_I2_MAXTAPS];
-    for (int t = 0; t < q.ntaps; ++t) {
-        delta[t] = ((q.offT + q.dt[t]) * q.sH + (q.offH + q.dh[t])) * q.sW + (q.offW + q.dw[t]);
-        if (t == 0 || delta[t] < dmin) dmin = delta[t];
-        if (t == 0 || delta[t] > dmax) dmax = delta[t];
-    }
-    if (dmax - dmin > 128) return false;
-    q.strip_e0 = -dmin;
-    q.strip_rows = roundup(256 + (dmax - dmin), 16);
-    for (int t = 0; t < q.ntaps; ++t) q.soff[t] = delta[t] - dmin;
-    const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;    // read per call: tests switch it on mid-process
-    if (trace) fprintf(stderr, "[sfamd] igemm2 strip: M=%d N=%d C=%d taps=%d rows=%d\n", q.M, q.Nout, q.C, q.ntaps, q.strip_rows);
-    if (q.Nout > 64) {
-        q.ntiles_n = cdiv(q.Nout, 128);
-        hipLaunchKernelGGL((sf_igemm2_kernel<256, 128, 4, 2, 32, 3, true>), dim3((unsigned)(cdiv(q.M, 256) * q.ntiles_n)), dim3(512), 0, s, q);
-    } else {
-        q.ntiles_n = 1;
-        hipLaunchKernelGGL((sf_igemm2_kernel<256, 64, 4, 2, 32, 3, true>), dim3((unsigned)cdiv(q.M, 256)), dim3(512), 0, s, q);
-    }
-    return true;
-}
 // K step: 64 deep (48 KB stages, ONE 8-wave workgroup per CU) when the grid is at most ~one tile per CU anyway -- the
 // res5-sized layers; otherwise 32 deep (24 KB stages, TWO workgroups per CU: one tile's epilogue and pipeline fill hide
 // behind the other's K loop).  Measured per layer in profiles/r2_v3_igemm2_variants.md.  SF_IGEMM2_BK=32|64 forces one.
@@ -230,8 +196,6 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     const bool bk64 = q.C % 64 == 0 && force_bk != 32 && (force_bk == 64 || tiles <= 320);
     static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
     q.ablate = (e = getenv("SF_IGEMM2_ABLATE")) ? atoi(e) : 0;     // diagnostic: parts of the kernel switched off (wrong results)
-    q.stagger = (e = getenv("SF_IGEMM2_STAGGER")) ? atoi(e) : 0;
-    if (try_igemm2_strip(q, bk64, s)) return;
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);
     if (q.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }
     else if (q.Nout > 32) { if (bk64) launch_igemm2<64, 64>(q, s); else launch_igemm2<64, 32>(q, s); }
@@ -665,10 +629,9 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     const int taps = d->kT * d->kH * d->kW;
     // Workgroups to aim for: ONE resident round (2 per CU x 256 CUs).  The split count is rounded DOWN so that the grid never
     // exceeds the target by a few workgroups: 18 tiles x 29 splits = 522 on 512 resident slots ran a second, almost empty round
-    // (s4.slow b: 120 us at 522 workgroups, 99 us at 396; profiles/r3_v2_wgrad_sweep.md -- which also shows the one-workgroup-
-    // per-CU six-stage ring, SF_WGRAD2_NST=6, losing everywhere).
-    const bool deep = (e = getenv("SF_WGRAD2_NST")) && atoi(e) == 6;
-    const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : deep ? 256 : 512;
+    // (s4.slow b: 120 us at 522 workgroups, 99 us at 396; profiles/r3_v2_wgrad_sweep.md -- which also records a one-workgroup-
+    // per-CU six-stage ring with half the splits losing on every layer; that variant is gone again, commit 4267b0c has it).
+    const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : 512;
     (void)taps;
     const int Ktot = taps * d->Ci;
     const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
@@ -752,140 +715,6 @@ extern "C" int sf_conv_wgrad_rowtab(const sf_conv_desc* d, void* tab, sf_stream_
     return check_launch("wgrad_rowtab");
 }
 
-// ---- thin layers (sf_igemm2t.h): <= 32 output columns, contraction <= 128, streamed by independent waves -------------------
-// direction 0: forward (rows = output positions, operand x, columns Co); 1: data gradient (rows = input positions, operand dy,
-// columns Ci; stride 1 only).  SF_IGEMM2T=1 enables (see plan_thin), SF_IGEMM2T_MINROWS / SF_IGEMM2T_BLOCKS are A/B knobs.
-struct ThinPlan {
-    bool ok;
-    int BN, KP, blocks, nstages, Ktot;
-    int64_t M;
-    size_t tab_bytes;
-};
-static ThinPlan plan_thin(const sf_conv_desc* d, int dgrad) {
-    ThinPlan t;
-    memset(&t, 0, sizeof(t));
-    const char* e;
-    // OPT-IN (SF_IGEMM2T=1): parity-green on MI355X, but measured slower than sf_igemm_kernel's 128 x 16 tiles on the pointwise and
-    // temporal Fast-pathway layers (fwd 78 -> 102 us, dgrad 37 -> 63 us) and only 5-12 % faster on the 1x3x3 ones; -0.5 % on the
-    // SlowFast step (profiles/r2_v27_thin_fwd_ab.txt).  One wave per 32-position slice is too long an instruction stream per byte.
-    if (!((e = getenv("SF_IGEMM2T")) && atoi(e) != 0)) return t;
-    const int taps = d->kT * d->kH * d->kW;
-    const int N = dgrad ? d->Ci : d->Co, C = dgrad ? d->Co : d->Ci;
-    const int64_t M = dgrad ? (int64_t)d->N * d->Ti * d->Hi * d->Wi : (int64_t)d->N * d->To * d->Ho * d->Wo;
-    const int minrows = (e = getenv("SF_IGEMM2T_MINROWS")) ? atoi(e) : 16384;
-    if (N > 32 || N % 8 || C % 8 || taps * C > 128 || taps > SF_I2_MAXTAPS || M < minrows || M >= (1ll << 31) - 256) return t;
-    if ((d->kT - 1) * d->dT > 127 || (d->kH - 1) * d->dH > 127 || (d->kW - 1) * d->dW > 127) return t;
-    if (dgrad && (d->sT != 1 || d->sH != 1 || d->sW != 1)) return t;
-    if (!dgrad && plan_stem(d).ok) return t;
-    t.M = M;
-    t.Ktot = taps * C;
-    t.BN = N <= 16 ? 16 : 32;
-    t.KP = t.Ktot <= 32 ? 32 : 128;
-    t.nstages = (int)cdiv(M, 128);
-    // one resident round: 2 workgroups per CU with 128-wide slices (2 x 8 KB per wave), 4 with 32-wide ones
-    int target = (e = getenv("SF_IGEMM2T_BLOCKS")) ? atoi(e) : (t.KP == 128 ? 512 : 1024);
-    t.blocks = target < t.nstages ? target : t.nstages;
-    t.tab_bytes = ((size_t)M * 8 + 255) / 256 * 256 + 1280;
-    t.ok = true;
-    return t;
-}
-
-static void launch_rowtab_dgrad(const sf_conv_desc* d, void* tab, hipStream_t s) {
-    // the data gradient as a stride-1 convolution of dy: position i reads dy[i + pad - tap * dil]
-    RowtabParams t;
-    memset(&t, 0, sizeof(t));
-    t.tab = (i32x2*)tab;
-    t.M = d->N * d->Ti * d->Hi * d->Wi;
-    t.fdW = make_fastdiv(d->Wi); t.fdH = make_fastdiv(d->Hi); t.fdT = make_fastdiv(d->Ti);
-    t.sT = d->To; t.sH = d->Ho; t.sW = d->Wo;
-    t.strT = t.strH = t.strW = 1;
-    t.padT = (d->kT - 1) * d->dT - d->pT; t.padH = (d->kH - 1) * d->dH - d->pH; t.padW = (d->kW - 1) * d->dW - d->pW;
-    t.ntaps = d->kT * d->kH * d->kW;
-    int ti = 0;
-    for (int kt = 0; kt < d->kT; ++kt)
-        for (int kh = 0; kh < d->kH; ++kh)
-            for (int kw = 0; kw < d->kW; ++kw, ++ti) {
-                t.dt[ti] = (int8_t)((d->kT - 1 - kt) * d->dT); t.dh[ti] = (int8_t)((d->kH - 1 - kh) * d->dH);
-                t.dw[ti] = (int8_t)((d->kW - 1 - kw) * d->dW);
-            }
-    hipLaunchKernelGGL(sf_wgrad2_rowtab_kernel, dim3(cdiv(t.M, SF_THREADS)), dim3(SF_THREADS), 0, s, t);
-}
-
-extern "C" int64_t sf_conv_thin_rowtab_bytes(const sf_conv_desc* d, int dgrad) {
-    if (check_desc(d)) return -1;
-    const ThinPlan t = plan_thin(d, dgrad);
-    return t.ok ? (int64_t)t.tab_bytes : 0;
-}
-
-extern "C" int sf_conv_thin_blocks(const sf_conv_desc* d, int dgrad) {
-    if (check_desc(d)) return -1;
-    const ThinPlan t = plan_thin(d, dgrad);
-    return t.ok ? t.blocks : 0;
-}
-
-extern "C" int sf_conv_thin_rowtab(const sf_conv_desc* d, int dgrad, void* tab, sf_stream_t stream) {
-    if (check_desc(d)) return -1;
-    REQUIRE(tab && (uintptr_t)tab % 32 == 0, "sf_conv_thin_rowtab: tab must be a 32-byte aligned device pointer");
-    REQUIRE(plan_thin(d, dgrad).ok, "sf_conv_thin_rowtab: not a thin layer (sf_conv_thin_rowtab_bytes == 0)");
-    if (dgrad) launch_rowtab_dgrad(d, tab, (hipStream_t)stream);
-    else launch_rowtab(d, tab, (hipStream_t)stream);
-    return check_launch("thin_rowtab");
-}
-
-static int launch_thin(const ThinPlan& t, Igemm2tParams& q, hipStream_t s) {
-    const dim3 grid(t.blocks), block(256);
-    if (t.BN == 16 && t.KP == 128) hipLaunchKernelGGL((sf_igemm2t_kernel<16, 128, 2>), grid, block, 0, s, q);
-    else if (t.BN == 32 && t.KP == 128) hipLaunchKernelGGL((sf_igemm2t_kernel<32, 128, 2>), grid, block, 0, s, q);
-    else if (t.BN == 16) hipLaunchKernelGGL((sf_igemm2t_kernel<16, 32, 3>), grid, block, 0, s, q);
-    else hipLaunchKernelGGL((sf_igemm2t_kernel<32, 32, 3>), grid, block, 0, s, q);
-    return check_launch("igemm2t");
-}
-
-extern "C" int sf_conv_fwd_thin(const sf_conv_desc* d, const void* x, const void* wf, const float* bias, void* y,
-                                float* stat_part, const void* rowtab, sf_stream_t stream) {
-    if (check_desc(d)) return -1;
-    const ThinPlan t = plan_thin(d, 0);
-    REQUIRE(t.ok, "sf_conv_fwd_thin: not a thin layer");
-    REQUIRE(x && wf && y && rowtab, "sf_conv_fwd_thin: null pointer");
-    REQUIRE(((uintptr_t)x | (uintptr_t)wf | (uintptr_t)y) % 16 == 0 && (uintptr_t)rowtab % 32 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0,
-            "sf_conv_fwd_thin: operands must be 16-byte aligned (row table: 32)");
-    Igemm2tParams q;
-    memset(&q, 0, sizeof(q));
-    q.src = (const f16*)x; q.ld = d->ldx; q.C = d->Ci; q.M = (int)t.M; q.Ktot = t.Ktot; q.rowtab = (const i32x2*)rowtab;
-    int ti = 0;
-    for (int kt = 0; kt < d->kT; ++kt)
-        for (int kh = 0; kh < d->kH; ++kh)
-            for (int kw = 0; kw < d->kW; ++kw, ++ti) q.dlin[ti] = (kt * d->dT * d->Hi + kh * d->dH) * d->Wi + kw * d->dW;
-    int32_t ldf, ldd;
-    sf_conv_weight_ld(d, &ldf, &ldd);
-    q.wmat = (const f16*)wf; q.ldw = ldf; q.Nout = d->Co;
-    q.y = (f16*)y; q.ldy = d->ldy; q.bias = bias; q.stat_part = stat_part; q.nstages = t.nstages;
-    return launch_thin(t, q, (hipStream_t)stream);
-}
-
-extern "C" int sf_conv_dgrad_thin(const sf_conv_desc* d, const void* dy, const void* wd, void* dx, const void* rowtab,
-                                  sf_stream_t stream) {
-    if (check_desc(d)) return -1;
-    const ThinPlan t = plan_thin(d, 1);
-    REQUIRE(t.ok, "sf_conv_dgrad_thin: not a thin layer");
-    REQUIRE(dy && wd && dx && rowtab, "sf_conv_dgrad_thin: null pointer");
-    REQUIRE(((uintptr_t)dy | (uintptr_t)wd | (uintptr_t)dx) % 16 == 0 && (uintptr_t)rowtab % 32 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0,
-            "sf_conv_dgrad_thin: operands must be 16-byte aligned (row table: 32)");
-    Igemm2tParams q;
-    memset(&q, 0, sizeof(q));
-    q.src = (const f16*)dy; q.ld = d->ldy; q.C = d->Co; q.M = (int)t.M; q.Ktot = t.Ktot; q.rowtab = (const i32x2*)rowtab;
-    int ti = 0;
-    for (int kt = 0; kt < d->kT; ++kt)
-        for (int kh = 0; kh < d->kH; ++kh)
-            for (int kw = 0; kw < d->kW; ++kw, ++ti)
-                q.dlin[ti] = ((d->kT - 1 - kt) * d->dT * d->Ho + (d->kH - 1 - kh) * d->dH) * d->Wo + (d->kW - 1 - kw) * d->dW;
-    int32_t ldf, ldd;
-    sf_conv_weight_ld(d, &ldf, &ldd);
-    q.wmat = (const f16*)wd; q.ldw = ldd; q.Nout = d->Ci;
-    q.y = (f16*)dx; q.ldy = d->ldx; q.nstages = t.nstages;
-    return launch_thin(t, q, (hipStream_t)stream);
-}
-
 extern "C" int64_t sf_conv_wgrad_workspace(const sf_conv_desc* d) {
     if (check_desc(d)) return -1;
     int64_t generic = (int64_t)plan_wgrad(d).ws_bytes;
@@ -938,12 +767,8 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
             else if (w2.BMW == 16) hipLaunchKernelGGL((sf_wgrad2t_kernel<16, 32, 3>), grid, dim3(256), 0, s, q);
             else hipLaunchKernelGGL((sf_wgrad2t_kernel<32, 32, 3>), grid, dim3(256), 0, s, q);
         } else {
-            const char* e6 = getenv("SF_WGRAD2_NST");
-            const bool deep = e6 && atoi(e6) == 6;
-            if (w2.BMW == 128 && deep) hipLaunchKernelGGL((sf_wgrad2_kernel<128, 6>), grid, dim3(512), 0, s, q);
-            else if (w2.BMW == 128) hipLaunchKernelGGL((sf_wgrad2_kernel<128, 3>), grid, dim3(512), 0, s, q);
-            else if (deep) hipLaunchKernelGGL((sf_wgrad2_kernel<64, 6>), grid, dim3(512), 0, s, q);
-            else hipLaunchKernelGGL((sf_wgrad2_kernel<64, 3>), grid, dim3(512), 0, s, q);
+            if (w2.BMW == 128) hipLaunchKernelGGL((sf_wgrad2_kernel<128>), grid, dim3(512), 0, s, q);
+            else hipLaunchKernelGGL((sf_wgrad2_kernel<64>), grid, dim3(512), 0, s, q);
         }
         splits = w2.splits; Co_pad = w2.Co_pad; Kpad = w2.Kpad;
     } else if (sp.ok && !in_scale) {

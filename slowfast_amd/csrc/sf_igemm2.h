@@ -81,15 +81,9 @@ struct Igemm2Params {
     const float* bnb_scale; const float* bnb_shift;
     float* bnb_part;
     const uint8_t* bnb_bits;        // optional [rows][Nout/8] bit mask replacing the recomputed one (block-output ReLU)
-    // STRIP variant (sf_igemm2_kernel<..., true>): stride-1 convolutions whose row space IS the source position space (same
-    // extents, e.g. 1x3x3 / pad 1): tap t of row m reads source position m + sdelta[t].  soff[t] = sdelta[t] - min(sdelta)
-    // (>= 0, <= 128), strip_e0 = -min(sdelta), strip_rows = 256 + max(soff) rounded up to 16 (<= 384).
-    int strip_e0, strip_rows;
-    int32_t soff[SF_I2_MAXTAPS];
     // DIAGNOSTIC (SF_IGEMM2_ABLATE, tools/microbench.py only; results are garbage): bit 0 no copies inside the K loop, bit 1 no
     // LDS reads / MFMAs, bit 2 LDS reads but no MFMAs, bit 3 return before the epilogue, bit 4 no barrier inside the K loop
     int ablate;
-    int stagger;        // 1: waves NW/2.. issue the next stage's copies between the two MFMA halves of a stage (see compute())
 };
 
 // LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase
@@ -100,19 +94,14 @@ __device__ __forceinline__ int i2_lds_off(int row, int kslot) {
     else return lds_tile_off(row, kslot);
 }
 
-// STRIP (round 3): the A operand of ALL taps of a channel chunk comes from ONE staged strip of source rows.  The gather
-// formulation stages the tile's 256 rows once PER TAP -- nine shifted copies of (nearly) the same rows for a 3x3 kernel, 9x the
-// tile's bytes through L2 -> LDS and five to six copy instructions per wave and 32-deep step, which is what bounds the 64- and
-// 128-channel 1x3x3 layers (78 B/clk/CU asked of an L2 that delivers ~56).  Here the strip [m0 + min(delta), m0 + 255 +
-// max(delta)] (<= 384 rows of 32 channels, 24 KB) is copied ONCE per chunk into a two-deep ring while the previous chunk is
-// multiplied; a tap is a row offset into it, and rows whose tap leaves the source (padding) are zeroed in the FRAGMENT (per-lane
-// validity bits, 4 v_cndmask per fragment) because the strip is shared by taps with different padding.  Per tap step only the
-// 32 x BN weight slice is copied (one instruction per wave).  Same epilogue, same K order (chunk outer, tap inner).
-// MEASURED (profiles/r3_v5_strip_ab.txt): correct, and SLOWER than the gather kernel on every eligible SlowFast layer (s2.b
-// 145 -> 189 us, s3.b 105 -> 126, s4.b 86 -> 98; step 766 -> 758 clips/s): the loop carries 61 VALU instructions per step
-// against 21 (tap-dependent fragment addresses, validity masks), which costs more than the saved copies return.  Kept as an
-// opt-in (SF_IGEMM2_STRIP=1|2) with its tests; the launcher does not take it by default.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NST, bool STRIP = false>
+// Tried in round 3 and removed again (the code is in the history, commits c9ff12f / 6f38f0a; evidence under profiles/):
+//  * a STRIP variant -- ONE staged strip of source rows per channel chunk serves every tap, a tap is a row offset into it,
+//    padding is masked in the fragment: 6x fewer gathered bytes on 3x3 layers, and 15-30 % SLOWER on every eligible layer
+//    (61 VALU instructions per K step against 21; profiles/r3_v5_strip_ab.txt);
+//  * issuing the next stage's copies between the two MFMA halves of a stage in half of the waves: a wash
+//    (profiles/r3_v7_stagger_ab.txt).  profiles/r3_v6_igemm2_ablation.md shows what bounds the loop instead: the copy stream
+//    alone and the MFMA stream alone each take 75-80 % of the kernel's time and overlap only partly.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NST>
 // register cap: the 32-deep variant must fit TWO workgroups per CU (4 waves per SIMD -> 128 VGPRs), the 64-deep one runs alone
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES_M * WAVES_N) / 4) void sf_igemm2_kernel(Igemm2Params p) {
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
@@ -128,9 +117,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
     static_assert(BM % 128 == 0, "statistics are kept per 128 rows");
     constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
     constexpr int STG_LD = BN + 8;
-    constexpr int SR_MAX = 384, A_STRIP = SR_MAX * BK;          // STRIP: two strips of up to 384 rows + NST weight slices
-    static_assert(!STRIP || (BK == 32 && BM == 256 && NST == 3), "the strip variant is the 32-deep, two-workgroups-per-CU kernel");
-    constexpr int SMEM_MAIN = STRIP ? 2 * A_STRIP + NST * B_ELEMS : NST * STAGE, SMEM_STG = BM * STG_LD;
+    constexpr int SMEM_MAIN = NST * STAGE, SMEM_STG = BM * STG_LD;
     constexpr int SMEM = SMEM_MAIN > SMEM_STG ? SMEM_MAIN : SMEM_STG;
     constexpr int HALVES = BM / 128, WPH = WAVES_M / HALVES;    // 128-row statistic groups, wave rows per group
     static_assert(WAVES_M % HALVES == 0, "a wave row belongs to one 128-row group");
@@ -195,53 +182,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
     const int csteps = p.C / BK;                                    // K steps per tap
     const int ksteps = p.ntaps * csteps;
 
-    // ---- STRIP loader state: copy instruction j of the wave carries strip rows (wave + NW*j)*16 ..; strip row s is source
-    // position m0 - strip_e0 + s.  fmask[i]: validity bits of the taps for the row this lane reads in fragment i.
-    constexpr int NSJ = SR_MAX / 16 / NW;                           // 3 strip copies per wave and chunk
-    int64_t sbase[NSJ];
-    uint32_t fmask[TM];
-    if constexpr (STRIP) {
-#pragma unroll
-        for (int j = 0; j < NSJ; ++j) {
-            const int srow = (wave + NW * j) * 16 + lrow;
-            const int64_t pos = (int64_t)m0 - p.strip_e0 + srow;
-            sbase[j] = (srow < p.strip_rows && pos >= 0 && pos < (int64_t)p.M) ? pos * (int64_t)p.ld + kslot * 8 : -1;
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WM + i * 16 + (lane & 15);
-            uint32_t mk = 0;
-            if (m < p.M) {
-                uint32_t q, a, b, c, n;
-                fd_divmod((uint32_t)m, p.fdrW, q, c);
-                fd_divmod(q, p.fdrH, q, b);
-                fd_divmod(q, p.fdrT, n, a);
-                const int bt = (int)a * p.mulT + p.offT, bh = (int)b * p.mulH + p.offH, bw = (int)c * p.mulW + p.offW;
-                for (int t = 0; t < p.ntaps; ++t) {
-                    const int st = bt + p.dt[t], sh = bh + p.dh[t], sw = bw + p.dw[t];
-                    const bool ok = (unsigned)st < (unsigned)p.sT && (unsigned)sh < (unsigned)p.sH && (unsigned)sw < (unsigned)p.sW;
-                    mk |= (ok ? 1u : 0u) << t;
-                }
-            }
-            fmask[i] = mk;
-        }
-    }
-    auto issue_strip = [&](int c0, int abuf) {
-        f16* As = smem + abuf * A_STRIP;
-#pragma unroll
-        for (int j = 0; j < NSJ; ++j) {
-            const f16* g = sbase[j] >= 0 ? p.src + (sbase[j] + c0) : zline;
-            SF_GLOBAL_LOAD_LDS16_ASM(g, As + (wave + NW * j) * 512);
-        }
-    };
-    auto issue_bslice = [&](int tap, int c0, int slot) {
-        f16* Bs = smem + 2 * A_STRIP + slot * B_ELEMS;
-        const int wk = p.taps[tap].wcol + c0;
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            if (NBI % NW == 0 || wave + NW * j < NBI) SF_GLOBAL_LOAD_LDS16_ASM(bptr[j] + wk, Bs + (wave + NW * j) * 512);
-    };
-
     // stage (tap, channel chunk c0) -> LDS buffer `buf`
     auto issue = [&](int tap, int c0, int buf) {
         f16* As = smem + buf * STAGE;
@@ -264,10 +204,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // `mid` runs once per stage between two halves of its MFMAs (after all of the stage's LDS reads of that half are issued):
-    // the waves of the upper half of the workgroup issue their copies THERE instead of right after the barrier (p.stagger), so
-    // the two waves that share a SIMD do not sit in copy issue (back-pressured by the memory pipeline) at the same time
-    auto compute = [&](int buf, auto&& mid) {
+    auto compute = [&](int buf) {
         const f16* As = smem + buf * STAGE;
         const f16* Bs = As + A_ELEMS;
 #pragma unroll
@@ -284,69 +221,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 for (int j = 0; j < TN; ++j) SF_KEEP_ALIVE(bf[j]);
                 continue;
             }
-            if (BK == 64 && kk == 1) mid();
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (BK == 32 && i == TM / 2) mid();
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
-            }
         }
     };
 
-    auto compute_strip = [&](int abuf, int slot, int tap) {
-        const f16* As = smem + abuf * A_STRIP;
-        const f16* Bs = smem + 2 * A_STRIP + slot * B_ELEMS;
-        const int so = p.soff[tap];
-        f16x8 af[TM], bf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            af[i] = ld16(As + lds_tile_off(wm * WM + i * 16 + (lane & 15) + so, lane >> 4));
-            if (!((fmask[i] >> tap) & 1u)) af[i] = zero8();
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = ld16(Bs + i2_lds_off<BK>(wn * WN + j * 16 + (lane & 15), lane >> 4));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
-    };
-
-    if constexpr (STRIP) {
-        // step s = (chunk c, tap t), t inner.  Issue order per wave: prologue [strip(0), B(0), B(1)]; after the barrier of step s:
-        // B(s + 2), then -- at t == 0 -- strip(c + 1).  B(s) must have landed at step s; the copies issued after it are B(s + 1)
-        // (nbm = copies of one weight slice this wave carries: 1, or 0 for the upper waves of a 64-column tile) plus the NSJ strip
-        // copies of a chunk boundary that fell between them (t == 1: issued at step s - 1; t == 2: at step s - 2).
-        // The launcher guarantees ntaps >= 3 (with fewer taps a chunk boundary falls inside the two-step B look-ahead).
-        const int nbm = (NBI % NW == 0 || wave < NBI) ? NB : NB - 1;
-        const int ntaps = p.ntaps;
-        issue_strip(0, 0);
-        issue_bslice(0, 0, 0);
-        issue_bslice(1, 0, 1);
-        int tap = 0, c0 = 0, abuf = 0;                              // of the step being multiplied
-        int tap2 = 1, c2 = 0;                                       // of the last B slice issued
-        int slot = 0;
-        for (int ks = 0; ks < ksteps; ++ks) {
-            if (ks + 1 < ksteps) {
-                // strip(c + 1) was issued at tap 0 of THIS chunk (if there is a next chunk): at taps 1 and 2 it is younger than B(s)
-                const bool after_strip = (tap == 1 || tap == 2) && c0 + BK < p.C;
-                if (nbm) { if (after_strip) SF_WAIT_VMEM_N(NB + NSJ); else SF_WAIT_VMEM_N(NB); }
-                else { if (after_strip) SF_WAIT_VMEM_N(NSJ); else SF_WAIT_VMEM(); }
-            } else SF_WAIT_VMEM();
-            SF_BARRIER_KEEP_VMEM();
-            if (ks + 2 < ksteps) {                                  // B(s + 2) into the slot that step s - 1 read
-                if (++tap2 == ntaps) { tap2 = 0; c2 += BK; }
-                issue_bslice(tap2, c2, slot == 0 ? 2 : slot - 1);
-            }
-            if (tap == 0 && c0 + BK < p.C) issue_strip(c0 + BK, abuf ^ 1);      // next chunk's strip: 9 steps to land
-            compute_strip(abuf, slot, tap);
-            slot = slot == 2 ? 0 : slot + 1;
-            if (++tap == ntaps) { tap = 0; c0 += BK; abuf ^= 1; }
-        }
-        __syncthreads();
-    } else
     // ---- main loop: stages ks + 1 (and ks + 2 at NST == 3) are in flight while stage ks is multiplied
     {
         // copies one wave issues per stage: the count s_waitcnt vmcnt leaves outstanding (uniform over the waves whenever
@@ -360,7 +242,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
         int issued = 0;
         for (; issued < NST - 1 && issued < ksteps; ++issued) { issue(tap_i, c_i, issued); advance(); }
         int cur = 0, nxt = NST - 1;
-        const bool late = p.stagger && wave >= NW / 2;              // wave-uniform
         for (int ks = 0; ks < ksteps; ++ks) {
             if constexpr (NST == 3) {
                 if (ks + 1 < ksteps) SF_WAIT_VMEM_N(COPIES);        // stage ks landed, stage ks + 1 may still be in flight
@@ -369,11 +250,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 SF_WAIT_VMEM();
             }
             if (!(p.ablate & 16)) SF_BARRIER_KEEP_VMEM();           // ... for every wave; stage ks - 1 is no longer read
-            const bool doi = issued < ksteps && !(p.ablate & 1);
-            if (doi && !late) issue(tap_i, c_i, nxt);
-            if (!(p.ablate & 2)) compute(cur, [&]() { if (doi && late) issue(tap_i, c_i, nxt); });
-            else if (doi && late) issue(tap_i, c_i, nxt);
-            if (issued < ksteps) { advance(); ++issued; }
+            if (issued < ksteps) { if (!(p.ablate & 1)) issue(tap_i, c_i, nxt); advance(); ++issued; }
+            if (!(p.ablate & 2)) compute(cur);
             cur = cur == NST - 1 ? 0 : cur + 1;
             nxt = nxt == NST - 1 ? 0 : nxt + 1;
         }

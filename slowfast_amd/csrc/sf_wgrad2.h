@@ -73,12 +73,10 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad2_rowtab_kernel(RowtabPara
 __device__ __forceinline__ int w2_swz(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
 
 // BMW = 128: 8 waves as 2 (co) x 4 (k), wave tile 64 x 64.   BMW = 64: 8 waves as 1 x 8, wave tile 64 x 32.
-// NST = stages of the LDS ring: 3 (72 KB at BMW = 128: two workgroups per CU, the default) or 6 (144 KB: ONE workgroup per CU
-// with five 32-row stages in flight -- the "fewer, longer splits" schedule: half the split partials per launch, the latency
-// the second workgroup used to hide is covered by the deeper ring instead; SF_WGRAD2_NST=6)
-template <int BMW, int NST = 3>
-__global__ __launch_bounds__(512, NST > 3 ? 2 : 4) void sf_wgrad2_kernel(Wgrad2Params p) {
-    constexpr int BKW = 256, ROWS = 32, NW = 8;
+// Three-stage LDS ring (72 KB at BMW = 128): two workgroups per CU.
+template <int BMW>
+__global__ __launch_bounds__(512, 4) void sf_wgrad2_kernel(Wgrad2Params p) {
+    constexpr int BKW = 256, ROWS = 32, NW = 8, NST = 3;
     constexpr int WAVES_C = BMW / 64, WAVES_K = NW / WAVES_C;
     constexpr int WN = BKW / WAVES_K;                   // 64 or 32 columns of k per wave
     constexpr int TM = 4, TN = WN / 16;
@@ -213,9 +211,7 @@ __global__ __launch_bounds__(512, NST > 3 ? 2 : 4) void sf_wgrad2_kernel(Wgrad2P
         for (int ks = 0; ks < nsteps; ++ks) {
             // stages ks .. ks + NST - 2 are in flight (fewer at the tail): stage ks must have landed
             if (ks + NST - 2 < nsteps) {
-                if constexpr (NST == 3) SF_WAIT_VMEM_N(COPIES);         // (waves with a dY copy also wait for it: one early)
-                else if (ywave) SF_WAIT_VMEM_N((NST - 2) * (COPIES + 1));
-                else SF_WAIT_VMEM_N((NST - 2) * COPIES);
+                SF_WAIT_VMEM_N(COPIES);                                 // (waves with a dY copy also wait for it: one early)
             } else SF_WAIT_VMEM();
             SF_BARRIER_KEEP_VMEM();
             if (issued < nsteps) {

@@ -82,11 +82,6 @@ _SIGNATURES = {
     "sf_conv_dgrad_bn": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32,
                                  POINTER(c_int32), _P]),
     "sf_conv_wgrad_workspace": (c_int64, [POINTER(ConvDesc)]),
-    "sf_conv_thin_rowtab_bytes": (c_int64, [POINTER(ConvDesc), c_int]),
-    "sf_conv_thin_blocks": (c_int, [POINTER(ConvDesc), c_int]),
-    "sf_conv_thin_rowtab": (c_int, [POINTER(ConvDesc), c_int, _P, _P]),
-    "sf_conv_fwd_thin": (c_int, [POINTER(ConvDesc), _P, _P, _F, _P, _F, _P, _P]),
-    "sf_conv_dgrad_thin": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "sf_conv_wgrad_rowtab_bytes": (c_int64, [POINTER(ConvDesc)]),
     "sf_conv_wgrad_rowtab": (c_int, [POINTER(ConvDesc), _P, _P]),
     "sf_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _F, _F, c_int, _P, _F, c_float, c_int, _P, c_int64, _P, _P]),

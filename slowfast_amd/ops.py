@@ -196,14 +196,6 @@ def conv_fwd(x, wf, geom, in_affine=None, bias=None, stats=True, out=None):
     lib = get_lib()
     d = geom.desc(ldx, ldy)
     part = None
-    if in_affine is None:
-        tab = _thin_rowtab(geom, d, x.device, 0)
-        if tab is not None:             # thin layer (<= 32 output channels, K <= 128): the streaming kernel
-            if stats:
-                part = torch.empty((lib.call("sf_conv_thin_blocks", byref(d), 0), 2, geom.Co), dtype=torch.float32, device=x.device)
-            lib.call("sf_conv_fwd_thin", byref(d), x.data_ptr(), wf.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(part),
-                     tab.data_ptr(), _stream(x), work=geom.work(reads_x=1, reads_y=0, writes_y=1))
-            return y, part
     if stats:
         mt = lib.call("sf_conv_fwd_mtiles", byref(d))
         part = torch.empty((mt, 2, geom.Co), dtype=torch.float32, device=x.device)
@@ -272,13 +264,6 @@ def conv_dgrad(dy, wd, geom, resid=None, out=None, resid_bits=None, bn=None):
         assert tuple(resid.shape) == geom.in_shape
     if resid_bits is not None:
         assert resid is not None and resid_bits.dtype == torch.uint8 and resid_bits.numel() == rows(resid) * (geom.Ci // 8)
-    if resid is None:
-        d = geom.desc(ldx, ldy)
-        tab = _thin_rowtab(geom, d, dy.device, 1)
-        if tab is not None:
-            get_lib().call("sf_conv_dgrad_thin", byref(d), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), tab.data_ptr(), _stream(dy),
-                           work=geom.work(reads_y=1, writes_x=1))
-            return dx
     get_lib().call("sf_conv_dgrad", byref(geom.desc(ldx, ldy)), dy.data_ptr(), wd.data_ptr(), _ptr(resid), ldr,
                    _ptr(resid_bits), dx.data_ptr(), _stream(dy),
                    work=geom.work(reads_x=int(resid is not None), reads_y=1, writes_x=1))
@@ -336,27 +321,6 @@ def _capturing(device):
     return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
 
 
-def _thin_rowtab(geom, d, device, dgrad):
-    """Row table of the thin forward (dgrad=0) / data-gradient (dgrad=1) kernel for this geometry, or None when the layer takes
-    the general kernels.  The forward table is the one the weight gradient uses (same geometry, same content)."""
-    attr = "_thin_bytes_dgrad" if dgrad else "_thin_bytes_fwd"
-    nbytes = getattr(geom, attr, None)
-    if nbytes is None:
-        nbytes = get_lib().call("sf_conv_thin_rowtab_bytes", byref(d), dgrad)
-        setattr(geom, attr, nbytes)
-    if nbytes <= 0:
-        return None
-    key = (device, dgrad, geom.N, geom.Ti, geom.Hi, geom.Wi, geom.To, geom.Ho, geom.Wo, geom.k, geom.s, geom.p, geom.d)
-    if key not in _rowtabs:
-        tab = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        get_lib().call("sf_conv_thin_rowtab", byref(d), dgrad, tab.data_ptr(), _stream(tab))
-        if _capturing(device):
-            return tab                  # lives in the graph's pool, rebuilt by every replay: never shared through the cache
-        _rowtabs[key] = tab
-    return _rowtabs[key]
-
-
-
 def _wgrad_rowtab(geom, d, device):
     """The {first input position, tap mask} table of sf_conv_wgrad's large-K kernel is a function of the geometry alone:
     built once per (device, geometry) -- shared by every layer of that shape -- instead of once per call.  Built on first
@@ -372,7 +336,7 @@ def _wgrad_rowtab(geom, d, device):
         tab = torch.empty(nbytes, dtype=torch.uint8, device=device)
         get_lib().call("sf_conv_wgrad_rowtab", byref(d), tab.data_ptr(), _stream(tab))
         if _capturing(device):
-            return tab                  # see _thin_rowtab
+            return tab                  # lives in the graph's pool, rebuilt by every replay: never shared through the cache
         _rowtabs[key] = tab
     return _rowtabs[key]
 

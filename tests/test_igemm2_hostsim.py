@@ -49,73 +49,23 @@ def test_igemm2_channel_slice_input(sim, force_v2):
     kc.check_conv_fwd(sim, (1, 64, 1, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), ldx_extra=16)
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6]])
-def test_igemm2_staggered_copy_issue(sim, force_v2, case, monkeypatch):
-    """SF_IGEMM2_STAGGER=1: the upper four waves issue the next stage's copies between the two MFMA halves of a stage."""
-    monkeypatch.setenv("SF_IGEMM2_STAGGER", "1")
-    kc.check_conv_fwd(sim, *case)
-    kc.check_conv_dgrad(sim, *case)
-
-
-# ---- STRIP variant: one staged strip of source rows per channel chunk serves every tap (row offsets + fragment masks)
-STRIP_CASES = [
-    ((1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),       # BN 64 (upper waves carry no weight copy), 2 chunks, ragged tile
-    ((2, 64, 3, 12, 12), 136, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),    # 4 tiles (strips cross frame and sample borders), two N tiles
-    ((1, 128, 4, 6, 6), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),      # 3 temporal taps (delta +-36), 4 chunks: a strip issue at every third step
+# ---- stride-1 multi-tap shapes whose tiles cross frame / sample borders (written for the round-3 STRIP experiment, kept as
+# gather-kernel cases)
+BORDER_CASES = [
+    ((1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),       # BN 64, 2 chunks, ragged tile
+    ((2, 64, 3, 12, 12), 136, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),    # 4 tiles crossing frame and sample borders, two N tiles
+    ((1, 128, 4, 6, 6), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),      # 3 temporal taps (row delta +-36), 4 chunks
     ((1, 96, 1, 8, 8), 96, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),       # dilation 2 (delta up to +-18), 3 chunks
     ((1, 64, 3, 5, 5), 96, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),       # 27 taps, delta +-31
-    ((2, 32, 1, 40, 40), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),     # ONE chunk (no second strip), 13 tiles, wide rows (delta +-41)
+    ((2, 32, 1, 40, 40), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),     # ONE chunk, 13 tiles, wide rows (row delta +-41)
     ((1, 160, 2, 7, 7), 256, (1, 5, 5), (1, 1, 1), (0, 2, 2), (1, 1, 1)),     # 25 taps, 5 chunks, two full N tiles
 ]
 
 
-@pytest.mark.parametrize("case", STRIP_CASES)
-def test_igemm2_strip_fwd_dgrad(sim, force_v2, case, monkeypatch, capfd):
-    monkeypatch.setenv("SF_IGEMM2_STRIP", "2")
-    monkeypatch.setenv("SF_TRACE", "1")
+@pytest.mark.parametrize("case", BORDER_CASES)
+def test_igemm2_border_crossing_tiles(sim, force_v2, case):
     kc.check_conv_fwd(sim, *case)
     kc.check_conv_dgrad(sim, *case)
-    err = capfd.readouterr().err
-    # the data gradient contracts over Co (needs Co % 32 == 0) and produces Ci columns (needs Ci > 32) to run this kernel family
-    want = 2 if (case[1] % 32 == 0 and case[0][1] > 32) else 1
-    assert err.count("igemm2 strip") >= want, "the strip variant must be taken: " + err[-400:]
-
-
-def test_igemm2_strip_epilogues(sim, force_v2, monkeypatch):
-    monkeypatch.setenv("SF_IGEMM2_STRIP", "2")
-    kc.check_conv_dgrad(sim, (1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), resid=True)
-    kc.check_conv_fwd_fused(sim, (1, 64, 2, 9, 9), 72, (1, 3, 3), (1, 1, 1), (0, 1, 1), resid=True, relu=True)
-    kc.check_conv_fwd(sim, (1, 64, 1, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), ldx_extra=16)
-    kc.check_conv_dgrad_bn(sim, (2, 64, 2, 9, 9), 64, (1, 3, 3), (0, 1, 1))
-
-
-def test_igemm2_strip_not_taken_when_ineligible(sim, force_v2, monkeypatch, capfd):
-    """Strided forward, two-tap and wide-displacement geometries keep the gather kernel."""
-    monkeypatch.setenv("SF_IGEMM2_STRIP", "2")
-    monkeypatch.setenv("SF_TRACE", "1")
-    kc.check_conv_fwd(sim, (1, 32, 2, 10, 10), 40, (1, 3, 3), (1, 2, 2), (0, 1, 1))            # stride 2
-    kc.check_conv_fwd(sim, (1, 64, 4, 12, 12), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0))            # delta +-144 rows
-    assert "igemm2 strip" not in capfd.readouterr().err
-
-
-# strided data gradients: one launch per stride-residue class (sf_api.hip: try_igemm2_strided_dgrad)
-STRIDED = [
-    ((1, 64, 2, 10, 10), 64, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),     # 3x3 stride 2: classes with 1 / 2 / 2 / 4 taps
-    ((1, 32, 2, 9, 9), 64, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),       # 1x1 stride 2, odd extent: three tap-less classes
-    ((1, 32, 9, 4, 4), 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 1, 1)),       # lateral connection: temporal stride 4
-    ((1, 32, 1, 11, 11), 32, (1, 3, 3), (1, 2, 2), (0, 2, 2), (1, 2, 2)),     # stride 2 with dilation 2: one class owns all taps
-    ((2, 24, 3, 8, 8), 96, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),       # strides on all three axes, Ci = 24 (BN 32 tile)
-]
-
-
-@pytest.mark.parametrize("case", STRIDED)
-def test_igemm2_strided_dgrad(sim, force_v2, case):
-    kc.check_conv_dgrad(sim, *case)
-
-
-def test_igemm2_strided_dgrad_residual(sim, force_v2):
-    kc.check_conv_dgrad(sim, (1, 32, 9, 4, 4), 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), resid=True)
-    kc.check_conv_dgrad(sim, (1, 32, 2, 9, 9), 64, (1, 1, 1), (1, 2, 2), (0, 0, 0), resid=True)
 
 
 # ---- second-generation weight gradient (csrc/sf_wgrad2.h: row table, direct-to-LDS operands, transpose reads)
@@ -142,16 +92,6 @@ WGRAD2_CASES = [
 
 @pytest.mark.parametrize("case", WGRAD2_CASES)
 def test_wgrad2(sim, force_w2, case):
-    kc.check_conv_wgrad(sim, *case)
-
-
-@pytest.mark.parametrize("case", [WGRAD2_CASES[0], WGRAD2_CASES[-1]])
-def test_wgrad2_deep_ring(sim, force_w2, monkeypatch, case):
-    """SF_WGRAD2_NST=6: one workgroup per CU with a six-stage ring (more stages in flight than a short split has steps)."""
-    monkeypatch.setenv("SF_WGRAD2_NST", "6")
-    monkeypatch.setenv("SF_WGRAD2_BLOCKS", "2")
-    kc.check_conv_wgrad(sim, *case)
-    monkeypatch.setenv("SF_WGRAD2_BLOCKS", "64")      # splits shorter than the ring
     kc.check_conv_wgrad(sim, *case)
 
 
@@ -228,16 +168,8 @@ def test_wgrad2_thin_is_taken(sim, force_w2t):
     assert get_lib().call("sf_conv_wgrad_rowtab_bytes", byref(geom.desc(8, 8))) > 0
 
 
-# ---- thin forward / data gradient (sf_igemm2t.h: <= 32 output columns, K <= 128, independent waves, weights in registers)
-@pytest.fixture()
-def force_thin(monkeypatch):
-    monkeypatch.setenv("SF_IGEMM2T", "1")
-    monkeypatch.setenv("SF_IGEMM2T_MINROWS", "1")
-    monkeypatch.setenv("SF_IGEMM2T_BLOCKS", "3")      # several stages per workgroup even on tiny shapes
-
-
-# (in_shape, Co, kernel, stride, pad, dilation): forward is thin when Co <= 32 and taps*Ci <= 128, the data gradient when
-# Ci <= 32, taps*Co <= 128 and the stride is 1
+# ---- thin layers (<= 32 output columns, K <= 128: the Fast pathway's shapes) through the general kernels
+# (in_shape, Co, kernel, stride, pad, dilation)
 THIN_CASES = [
     ((2, 8, 3, 10, 10), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),      # Fast res2 b: BN 16, K 72 (128-wide slices), 600 rows
     ((1, 32, 6, 8, 8), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),       # Fast res2 a: fwd K 96 / dgrad K 24 (32-wide), BN 32
@@ -251,18 +183,7 @@ THIN_CASES = [
 
 
 @pytest.mark.parametrize("case", THIN_CASES)
-def test_igemm2_thin(sim, force_thin, case):
+def test_thin_layers(sim, case):
     kc.check_conv_fwd(sim, *case)
     kc.check_conv_dgrad(sim, *case)
 
-
-def test_igemm2_thin_is_taken(sim, force_thin):
-    from ctypes import byref
-    from slowfast_amd import ops
-    from slowfast_amd.lib import get_lib
-    geom = ops.ConvGeom((2, 8, 3, 10, 10), 8, (1, 3, 3), 1, (0, 1, 1))
-    d = geom.desc(8, 8)
-    assert get_lib().call("sf_conv_thin_rowtab_bytes", byref(d), 0) > 0 and get_lib().call("sf_conv_thin_rowtab_bytes", byref(d), 1) > 0
-    assert get_lib().call("sf_conv_thin_blocks", byref(d), 0) == 3
-    geom2 = ops.ConvGeom((1, 64, 2, 9, 9), 64, (1, 3, 3), 1, (0, 1, 1))
-    assert get_lib().call("sf_conv_thin_rowtab_bytes", byref(geom2.desc(64, 64)), 0) == 0

@@ -55,8 +55,7 @@ def test_wgrad2_thin(gpu, case):
     kc.check_conv_wgrad(gpu, *case)
 
 
-# thin forward / data gradient (sf_igemm2t.h: independent waves streaming 32-position slices, counted vmcnt over copies AND
-# stores): Fast-pathway sizes, i.e. dozens of slices per wave -- what a pipelining mistake needs to show
+# thin layers at Fast-pathway sizes (<= 32 output columns, K <= 128) through the general forward / data-gradient kernels
 THIN_GPU_CASES = [
     ((4, 8, 16, 56, 56), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),        # res2 b: both directions 128-wide, BN 16
     ((4, 32, 16, 56, 56), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),       # res2 a: fwd K 96 BN 16 / dgrad K 24 BN 32 (32-wide)
@@ -68,8 +67,7 @@ THIN_GPU_CASES = [
 
 
 @pytest.mark.parametrize("case", THIN_GPU_CASES)
-def test_igemm2_thin(gpu, case, monkeypatch):
-    monkeypatch.setenv("SF_IGEMM2T", "1")       # opt-in kernel (slower than the general one on most thin layers, see sf_api.hip)
+def test_thin_layers(gpu, case):
     kc.check_conv_fwd(gpu, *case)
     kc.check_conv_dgrad(gpu, *case)
 
@@ -98,8 +96,7 @@ def test_igemm2_small_shapes_forced(gpu):
             "kc.check_conv_dgrad(d,(1,64,2,9,9),64,(1,3,3),(1,1,1),(0,1,1),resid=True);"
             "kc.check_conv_fwd_fused(d,(1,64,2,9,9),72,(1,3,3),(1,1,1),(0,1,1),resid=True,relu=True); print('ok')")
     env = dict(os.environ, SF_IGEMM2_MINK="32", SF_IGEMM2_MINROWS="1", SF_WGRAD2_MINK="32", SF_WGRAD2_MINROWS="1",
-               SF_WGRAD2_BLOCKS="6", SF_WGRAD2T_MINROWS="1", SF_WGRAD2T_BLOCKS="5",
-               SF_IGEMM2T="1", SF_IGEMM2T_MINROWS="1", SF_IGEMM2T_BLOCKS="3")
+               SF_WGRAD2_BLOCKS="6", SF_WGRAD2T_MINROWS="1", SF_WGRAD2T_BLOCKS="5")
     env.pop("SFAMD_LIBRARY", None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)

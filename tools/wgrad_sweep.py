@@ -1,6 +1,6 @@
 """Weight-gradient schedule sweep on the SlowFast-8x8-R50 layer geometries (round 3): sf_conv_wgrad per layer under
-SF_WGRAD2_BLOCKS = target workgroup count (-> number of split partials) and SF_WGRAD2_NST = 3 (two workgroups per CU, three-stage
-ring) | 6 (one workgroup per CU, six-stage ring).  HIP events around `iters` back-to-back calls; the operands of a layer are
+SF_WGRAD2_BLOCKS = target workgroup count (-> number of split partials).  (The first sweep, profiles/r3_v2_wgrad_sweep.md, also
+had a six-stage one-workgroup-per-CU ring, SF_WGRAD2_NST=6; it lost everywhere and is gone.)  HIP events around `iters` back-to-back calls; the operands of a layer are
 re-created per layer (so small layers are cache-warm, as in tools/microbench.py).
     python tools/wgrad_sweep.py --md gpurun_out/x/wgrad_sweep.md"""
 import argparse
@@ -37,7 +37,6 @@ def main():
         dw = torch.empty((Co, Ci) + k, device=dev)
         ts = []
         for nst, blocks in variants:
-            os.environ["SF_WGRAD2_NST"] = nst
             os.environ["SF_WGRAD2_BLOCKS"] = str(blocks)
             geom.ws_bytes = None
             ts.append(timeit(lambda: ops.conv_wgrad(x, dy, geom, dw), a.iters) * 1e3)
