@@ -663,7 +663,7 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
         return w;
     }
     if (Ktot < mink) return w;
-    w.BMW = d->Co > 64 ? 128 : 64;
+    w.BMW = d->Co > 64 && !((e = getenv("SF_WGRAD2_BMW")) && atoi(e) == 64) ? 128 : 64;      // SF_WGRAD2_BMW=64: A/B knob (tools/wgrad_sweep.py)
     w.tiles_k = cdiv(Ktot, 256);
     w.tiles_c = cdiv(d->Co, w.BMW);
     w.Kpad = w.tiles_k * 256;

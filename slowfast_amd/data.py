@@ -28,18 +28,24 @@ def pathway_frame_indices(cfg, num_frames):
                               f"{cfg.MODEL.SINGLE_PATHWAY_ARCH + cfg.MODEL.MULTI_PATHWAY_ARCH}")
 
 
-def pack_pathways_u8(frames, cfg):
+def pack_pathways_u8(frames, cfg, out=None):
     """frames: uint8 (N, T, H, W, 3) device tensor (decoded, sampled, cropped).  Returns the model input list: one
-    channels-last fp16 tensor per pathway in the W-pair view (N, 8, T', H, W/2), tagged so that the stems use it as is."""
+    channels-last fp16 tensor per pathway in the W-pair view (N, 8, T', H, W/2), tagged so that the stems use it as is.
+    ``out``: tensors of a previous call (e.g. the static input buffers of a captured step.TrainStep) to write into."""
     assert frames.dtype == torch.uint8 and frames.dim() == 5 and frames.shape[-1] == 3 and frames.shape[3] % 2 == 0
     frames = frames.contiguous()
     N, T, H, W, _ = frames.shape
     mean, std = [float(v) for v in cfg.DATA.MEAN], [float(v) for v in cfg.DATA.STD]
-    out = []
-    for idx in pathway_frame_indices(cfg, T):
+    dst, out = out, []
+    for i, idx in enumerate(pathway_frame_indices(cfg, T)):
         Tout = T if idx is None else int(idx.numel())
         idx_dev = None if idx is None else idx.to(device=frames.device, dtype=torch.int32).contiguous()
-        base = torch.empty((N, Tout, H, W // 2, 8), dtype=_f16, device=frames.device)
+        if dst is None:
+            base = torch.empty((N, Tout, H, W // 2, 8), dtype=_f16, device=frames.device)
+        else:
+            base = dst[i].permute(0, 2, 3, 4, 1)
+            assert tuple(base.shape) == (N, Tout, H, W // 2, 8) and base.is_contiguous() and base.dtype == _f16, \
+                "out[i] must be a tensor a previous pack_pathways_u8 call returned for the same clip geometry"
         get_lib().call("sf_pack_clip_u8", frames.data_ptr(), N, T, H, W, ops._ptr(idx_dev), Tout, mean[0], mean[1], mean[2],
                        std[0], std[1], std[2], int(bool(cfg.DATA.REVERSE_INPUT_CHANNEL)), base.data_ptr(),
                        ops._stream(frames), work=dict(bytes=3.0 * N * Tout * H * W + 2.0 * base.numel()))

@@ -405,6 +405,12 @@ def check_pack_clip(device, arch="slowfast", reverse=False, seed=0):
         buf = x.permute(0, 2, 3, 4, 1).reshape(N, T, H, W2 * 2, 4).cpu()
         assert torch.equal(buf[..., :3].permute(0, 4, 1, 2, 3).contiguous(), r.to(ACT)), "normalised clip differs"
         assert float(buf[..., 3].abs().max()) == 0.0
+    # out=: the next batch written straight into the tensors of a previous call (a captured step's static input buffers)
+    frames2 = torch.randint(0, 256, (2, 8, 6, 10, 3), generator=g, dtype=torch.int64).to(torch.uint8)
+    ptrs = [x.data_ptr() for x in got]
+    again = sa.pack_pathways_u8(frames2.to(device), cfg, out=got)
+    fresh = sa.pack_pathways_u8(frames2.to(device), cfg)
+    assert [x.data_ptr() for x in again] == ptrs and all(torch.equal(a, f) for a, f in zip(again, fresh))
 
 
 def check_prep_weights_batch(device, cases, seed=0):

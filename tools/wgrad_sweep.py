@@ -22,8 +22,10 @@ def main():
     ap.add_argument("--filter", default="slow")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    variants = [("3", b) for b in (256, 384, 448, 512, 640, 768, 1024, 1536)]
-    lines = ["| layer | x | " + " | ".join(f"nst{n} b{b}" for n, b in variants) + " | best |", "|---|---:|" + "---:|" * (len(variants) + 1)]
+    # (co-tile rows of sf_wgrad2_kernel, workgroup target): 128 = default for Co > 64; 64 = SF_WGRAD2_BMW=64 (twice the tiles, half
+    # the split partials, the x operand read by twice as many workgroups)
+    variants = [(m, b) for m in ("128", "64") for b in (384, 512, 768, 1024)]
+    lines = ["| layer | x | " + " | ".join(f"bmw{n} b{b}" for n, b in variants) + " | best |", "|---|---:|" + "---:|" * (len(variants) + 1)]
     tot = [0.0] * len(variants)
     best_tot = 0.0
     for name, Ci, T, H, W, Co, k, s, p, cnt in LAYERS:
@@ -36,22 +38,23 @@ def main():
         dy.normal_()
         dw = torch.empty((Co, Ci) + k, device=dev)
         ts = []
-        for nst, blocks in variants:
+        for bmw, blocks in variants:
             os.environ["SF_WGRAD2_BLOCKS"] = str(blocks)
+            os.environ["SF_WGRAD2_BMW"] = bmw
             geom.ws_bytes = None
             ts.append(timeit(lambda: ops.conv_wgrad(x, dy, geom, dw), a.iters) * 1e3)
         for i, t in enumerate(ts):
             tot[i] += cnt * t
         best_tot += cnt * min(ts)
         b = min(range(len(ts)), key=lambda i: ts[i])
-        lines.append(f"| {name} | {cnt} | " + " | ".join(f"{t:.0f}" for t in ts) + f" | nst{variants[b][0]} b{variants[b][1]} |")
+        lines.append(f"| {name} | {cnt} | " + " | ".join(f"{t:.0f}" for t in ts) + f" | bmw{variants[b][0]} b{variants[b][1]} |")
         print(lines[-1], flush=True)
     lines.append("| **weighted total (us / step)** | | " + " | ".join(f"{t:.0f}" for t in tot) + f" | {best_tot:.0f} |")
     print(lines[-1])
     if a.md:
         os.makedirs(os.path.dirname(a.md) or ".", exist_ok=True)
         with open(a.md, "w") as f:
-            f.write("# sf_conv_wgrad per layer (us per call) vs split target and ring depth, SlowFast-8x8-R50 geometries, batch %d\n\n" % a.batch)
+            f.write("# sf_conv_wgrad per layer (us per call) vs split target and co-tile height, SlowFast-8x8-R50 geometries, batch %d\n\n" % a.batch)
             f.write("\n".join(lines) + "\n")
 
 
