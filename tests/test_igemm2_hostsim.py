@@ -68,6 +68,26 @@ def test_igemm2_border_crossing_tiles(sim, force_v2, case):
     kc.check_conv_dgrad(sim, *case)
 
 
+# strided data gradients: one launch per stride-residue class (sf_api.hip: try_igemm2_strided_dgrad)
+STRIDED = [
+    ((1, 64, 2, 10, 10), 64, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),     # 3x3 stride 2: classes with 1 / 2 / 2 / 4 taps
+    ((1, 32, 2, 9, 9), 64, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),       # 1x1 stride 2, odd extent: three tap-less classes
+    ((1, 32, 9, 4, 4), 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 1, 1)),       # lateral connection: temporal stride 4
+    ((1, 32, 1, 11, 11), 32, (1, 3, 3), (1, 2, 2), (0, 2, 2), (1, 2, 2)),     # stride 2 with dilation 2: one class owns all taps
+    ((2, 24, 3, 8, 8), 96, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),       # strides on all three axes, Ci = 24 (BN 32 tile)
+]
+
+
+@pytest.mark.parametrize("case", STRIDED)
+def test_igemm2_strided_dgrad(sim, force_v2, case):
+    kc.check_conv_dgrad(sim, *case)
+
+
+def test_igemm2_strided_dgrad_residual(sim, force_v2):
+    kc.check_conv_dgrad(sim, (1, 32, 9, 4, 4), 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), resid=True)
+    kc.check_conv_dgrad(sim, (1, 32, 2, 9, 9), 64, (1, 1, 1), (1, 2, 2), (0, 0, 0), resid=True)
+
+
 # ---- second-generation weight gradient (csrc/sf_wgrad2.h: row table, direct-to-LDS operands, transpose reads)
 @pytest.fixture()
 def force_w2(monkeypatch):
