@@ -140,40 +140,17 @@ static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s, int nbatc
     // SF_IGEMM_OCC4=0 restores the uncapped build for A/B runs
     static const bool occ4 = !(getenv("SF_IGEMM_OCC4") && atoi(getenv("SF_IGEMM_OCC4")) == 0);
     if (igemm_glds_ok(p, pw)) {
-        // SF_IGEMM_GL3=1: three LDS stages (two copy stages in flight) for the 128- and 64-wide tiles -- opt-in, unmeasured
-        static const bool gl3 = getenv("SF_IGEMM_GL3") && atoi(getenv("SF_IGEMM_GL3")) != 0;
-        if constexpr (BN >= 64) {
-            if (gl3 && p.ksteps >= 3) {
-                hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, BN == 128, false, true>), grid, dim3(SF_THREADS), 0, s, p);
-                return;
-            }
-        }
         hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, BN == 128>), grid, dim3(SF_THREADS), 0, s, p);
         return;
     }
-    // The incremental (LEAN) loader is an A/B option (SF_IGEMM_LEAN=1): measured 3 % SLOWER than the dividing gather on
-    // SlowFast (594 vs 614 clips/s, profiles/r1_visit19_ab.txt) -- hipcc already hoists / strength-reduces the divisions,
-    // and the iterator's carried state costs more scalar work and registers than it saves.
-    static const bool lean_on = getenv("SF_IGEMM_LEAN") && atoi(getenv("SF_IGEMM_LEAN")) != 0;
-    const bool lean = gather_is_lean(p.g) && lean_on;
     constexpr bool kCap = BN == 128;        // 128-VGPR cap only matters (and is only compiled) for the 128-wide tile
     const bool cap = kCap && occ4;
-    if (!lean) {
-        if (pw) {
-            if (cap) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, kCap, false>), grid, dim3(SF_THREADS), 0, s, p);
-            else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, false, false>), grid, dim3(SF_THREADS), 0, s, p);
-        } else {
-            if (cap) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, kCap, false>), grid, dim3(SF_THREADS), 0, s, p);
-            else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, false, false>), grid, dim3(SF_THREADS), 0, s, p);
-        }
-        return;
-    }
     if (pw) {
-        if (cap) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, kCap, true>), grid, dim3(SF_THREADS), 0, s, p);
-        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, false, true>), grid, dim3(SF_THREADS), 0, s, p);
+        if (cap) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, kCap>), grid, dim3(SF_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, false>), grid, dim3(SF_THREADS), 0, s, p);
     } else {
-        if (cap) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, kCap, true>), grid, dim3(SF_THREADS), 0, s, p);
-        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, false, true>), grid, dim3(SF_THREADS), 0, s, p);
+        if (cap) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, kCap>), grid, dim3(SF_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, false, false, false>), grid, dim3(SF_THREADS), 0, s, p);
     }
 }
 

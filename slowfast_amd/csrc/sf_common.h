@@ -103,6 +103,17 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
     } while (0)
 #endif
 
+// raw workgroup barrier that does NOT drain the direct-to-LDS copies in flight (__syncthreads() would: its fence waits
+// vmcnt(0)).  LDS reads of this wave are retired first (WAR: another wave may overwrite the stage after the barrier).
+#ifndef SF_BARRIER_KEEP_VMEM
+#define SF_BARRIER_KEEP_VMEM()                                          \
+    do {                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+        __builtin_amdgcn_s_barrier();                                   \
+        asm volatile("" ::: "memory");                                  \
+    } while (0)
+#endif
+
 // Read-only table read through the SCALAR cache: a wave-uniform index into constant-address-space memory becomes s_load
 // (lgkmcnt), which keeps it out of the vector-memory queue whose counted waits pace the direct-to-LDS copies (an ordinary
 // global_load beside them makes hipcc wait vmcnt(0) at its first use and drains the pipeline).  The table must have been
@@ -278,59 +289,6 @@ __device__ __forceinline__ bool gather_offset_pw(const GatherSide& g, const RowP
     if ((unsigned)t >= (unsigned)g.sT) return false;
     off = (((int64_t)r.n * g.sT + t) * (int64_t)g.fdHW.d + r.bh) * (int64_t)g.ld + c0;
     return true;
-}
-
-// Incremental tap decomposition of the K axis for the GEMM loaders: a loader thread visits k0, k0 + 32, k0 + 64, ...
-// (one 8-channel slot per K step), so (tap, channel) advance by carries instead of divisions, and a source position is
-// rowpos + dpos with one 32x32->64 multiply for the byte offset.  Valid for forward gathers (mode 0, any stride) and for
-// data-gradient gathers with unit strides (mode 1); strided data gradients need the divisions of gather_offset().
-struct TapIter {
-    int k0, c0, kt, kh, kw;
-    int dt, dh, dw, dpos;
-};
-__device__ __forceinline__ void tap_set_deltas(const GatherSide& g, TapIter& it) {
-    const int sgn = g.mode == 0 ? 1 : -1;
-    it.dt = sgn * it.kt * g.dilT;
-    it.dh = sgn * it.kh * g.dilH;
-    it.dw = sgn * it.kw * g.dilW;
-    it.dpos = (it.dt * g.sH + it.dh) * g.sW + it.dw;
-}
-__device__ __forceinline__ void tap_init(const GatherSide& g, TapIter& it, uint32_t k0) {
-    uint32_t tap, c0, q, kw, kt, kh;
-    fd_divmod(k0 < (uint32_t)g.Ktot ? k0 : 0u, g.fdC, tap, c0);
-    fd_divmod(tap, g.fdkW, q, kw);
-    fd_divmod(q, g.fdkH, kt, kh);
-    it.k0 = (int)k0; it.c0 = (int)c0; it.kt = (int)kt; it.kh = (int)kh; it.kw = (int)kw;
-    tap_set_deltas(g, it);
-}
-__device__ __forceinline__ void tap_next(const GatherSide& g, TapIter& it) {
-    it.k0 += 32;
-    it.c0 += 32;
-    if (it.c0 >= g.C) {
-        do {
-            it.c0 -= g.C;
-            if (++it.kw == g.kW) {
-                it.kw = 0;
-                if (++it.kh == g.kH) { it.kh = 0; ++it.kt; }
-            }
-        } while (it.c0 >= g.C);
-        tap_set_deltas(g, it);
-    }
-}
-// a loader row: linear source position of its base point and the base coordinates for the bounds checks
-struct RowLean {
-    int pos, bt, bh, bw;
-    bool valid;
-};
-__device__ __forceinline__ RowLean lean_row(const GatherSide& g, uint32_t row, bool valid) {
-    const RowPos r = decode_row(g, valid ? row : 0u, valid);
-    RowLean l;
-    l.bt = r.bt; l.bh = r.bh; l.bw = r.bw; l.valid = valid;
-    l.pos = ((r.n * g.sT + r.bt) * g.sH + r.bh) * g.sW + r.bw;
-    return l;
-}
-static inline bool gather_is_lean(const GatherSide& g) {
-    return g.mode == 0 || (g.strT == 1 && g.strH == 1 && g.strW == 1);
 }
 
 // y = max(lo, x*scale + shift) on 8 consecutive channels (lo = 0: ReLU, -inf: none), fp32 math, tables in LDS read as

@@ -120,17 +120,14 @@ __device__ __forceinline__ void bnb_reduce_store(float (&sg)[8], float (&sgy)[8]
 // to the last valid row (their results are never stored).
 // (A second register stage, "PF2", was measured and removed: +90 VGPRs, one resident workgroup, SlowFast 383 vs 507
 // clips/s -- profiles/r1_visit7_*_pf2.json.)
-// LEAN = the register-staged loader advances its tap decomposition incrementally (TapIter) instead of dividing in every K
-// step.  An experiment kept behind SF_IGEMM_LEAN=1: it measured 3 % slower end to end than the dividing gather.
-// GL3 (with GL) = THREE LDS stages: the copies of stage k+2 are issued while stage k+1 is still in flight and stage k is
-// being multiplied, so two 16 KiB stages per workgroup are always outstanding instead of one (an experiment aimed at the
-// memory-level parallelism of the K loop; 48 KiB of LDS -> 3 workgroups per CU).  Opt-in
-// (SF_IGEMM_GL3=1) until it has been timed on hardware.
-template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false, bool LEAN = false, bool GL3 = false>
-__global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm_kernel(IgemmParams p) {
+// Two loader experiments were measured and removed: an incremental tap iterator for the register-staged loader (3 % slower than
+// the dividing gather, profiles/r1/r1_visit19_ab.txt) and a three-stage ring for the direct-to-LDS path (inline-asm copies, raw
+// barrier, counted waits: no gain on any pointwise layer, -1 % on MViTv2-S at three workgroups per CU,
+// profiles/r3_v10_gl3_ab.txt -- these layers are not latency-bound).
+template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false>
+__global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(IgemmParams p) {
     constexpr int BM = 128, BK = 32;
-    static_assert(!GL3 || (GL && BN >= 64), "three stages: direct-to-LDS tiles whose waves all issue the same copy count");
-    constexpr int NST = GL3 ? 3 : 2;
+    constexpr int NST = 2;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int TM = WM / 16, TN = WN / 16;
@@ -181,26 +178,11 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
     // loader assignment: A rows (tid>>2) and (tid>>2)+64, 16-byte slot tid&3
     const int kq = tid & 3;
     RowPos rp[2];
-    RowLean rl[2];
-    TapIter it;
-    const f16* wptr[NB];
-    bool wok[NB];
     if constexpr (!GL) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int row = m0 + (tid >> 2) + 64 * j;
-            if constexpr (LEAN) rl[j] = lean_row(g, (uint32_t)row, row < p.M);
-            else rp[j] = PW ? decode_row_pw(g, (uint32_t)row, row < p.M) : decode_row(g, (uint32_t)row, row < p.M);
-        }
-        if constexpr (LEAN) {
-            tap_init(g, it, (uint32_t)(kq * 8));
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int idx = tid + SF_THREADS * j;
-                const int co = n0 + (idx >> 2);
-                wok[j] = (idx < BN * 4) && (co < p.Nout);
-                wptr[j] = wmat + (wok[j] ? (int64_t)co * p.ldw : 0) + kq * 8;
-            }
+            rp[j] = PW ? decode_row_pw(g, (uint32_t)row, row < p.M) : decode_row(g, (uint32_t)row, row < p.M);
         }
     }
     const float act_lo = g.relu ? 0.f : -INFINITY;
@@ -244,44 +226,25 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
     Stage st0;
 
     auto load_tile = [&](int ks, Stage& st) {
-        if constexpr (LEAN) {
-            // called for ks = 0, 1, 2, ... in order: `it` holds the (tap, channel) of this thread's slot at step ks
-            const bool kin = it.k0 < g.Ktot;
-            const int t0 = it.dt, h0 = it.dh, w0 = it.dw;
+        const uint32_t k0 = (uint32_t)(ks * BK + kq * 8);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bool ok = rl[j].valid && kin && (unsigned)(rl[j].bt + t0) < (unsigned)g.sT;
-                if constexpr (!PW)
-                    ok = ok && (unsigned)(rl[j].bh + h0) < (unsigned)g.sH && (unsigned)(rl[j].bw + w0) < (unsigned)g.sW;
-                const int64_t off = (int64_t)(rl[j].pos + it.dpos) * g.ld + it.c0;
-                // masked lanes issue no request (measured: an unconditional clamped load + select is 8-13 % SLOWER
-                // here, profiles/r1_visit9_*; the four loads of a stage are in flight together either way)
-                st.ra[j] = ok ? ld16(a_src + off) : zero8();
-                st.ok[j] = ok;
-            }
-            st.c0 = (uint32_t)it.c0;
+        for (int j = 0; j < 2; ++j) {
+            int64_t off;
+            uint32_t c0 = 0;
+            // masked lanes issue no request (measured: an unconditional clamped load + select is 8-13 % SLOWER here,
+            // profiles/r1/r1_visit9_*; the four loads of a stage are in flight together either way)
+            bool ok = PW ? gather_offset_pw(g, rp[j], k0, off, c0) : gather_offset(g, rp[j], k0, off, c0);
+            st.ra[j] = ok ? ld16(a_src + off) : zero8();
+            st.ok[j] = ok;
+            if (ok) st.c0 = c0;
+        }
 #pragma unroll
-            for (int j = 0; j < NB; ++j) st.rb[j] = (wok[j] && kin) ? ld16(wptr[j] + ks * BK) : zero8();
-            tap_next(g, it);
-        } else {
-            const uint32_t k0 = (uint32_t)(ks * BK + kq * 8);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                int64_t off;
-                uint32_t c0 = 0;
-                bool ok = PW ? gather_offset_pw(g, rp[j], k0, off, c0) : gather_offset(g, rp[j], k0, off, c0);
-                st.ra[j] = ok ? ld16(a_src + off) : zero8();
-                st.ok[j] = ok;
-                if (ok) st.c0 = c0;
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                int idx = tid + SF_THREADS * j;
-                int brow = idx >> 2;
-                int co = n0 + brow;
-                bool ok = (idx < BN * 4) && (co < p.Nout) && (k0 < (uint32_t)g.Ktot);
-                st.rb[j] = ok ? ld16(wmat + (int64_t)co * p.ldw + k0) : zero8();
-            }
+        for (int j = 0; j < NB; ++j) {
+            int idx = tid + SF_THREADS * j;
+            int brow = idx >> 2;
+            int co = n0 + brow;
+            bool ok = (idx < BN * 4) && (co < p.Nout) && (k0 < (uint32_t)g.Ktot);
+            st.rb[j] = ok ? ld16(wmat + (int64_t)co * p.ldw + k0) : zero8();
         }
     };
     auto store_tile = [&](int buf, const Stage& st) {
@@ -321,22 +284,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? (GL3 ? 3 : 4) : 1) void sf_igemm
                 acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
     };
 
-    if constexpr (GL && GL3) {
-        constexpr int COPIES = 2 + NBC;          // global_load_lds per wave and stage (uniform over the waves for BN >= 64)
-        issue_tile(0, 0);
-        if (p.ksteps > 1) issue_tile(1, 1);
-        int cur = 0, nxt = 2;                    // ring positions of stage ks and of stage ks + 2
-        for (int ks = 0; ks < p.ksteps; ++ks) {
-            if (ks + 1 < p.ksteps) SF_WAIT_VMEM_N(COPIES);   // stage ks landed, stage ks + 1 may still be in flight
-            else SF_WAIT_VMEM();
-            __syncthreads();                     // ... for every wave; also: all waves are done reading stage ks - 1
-            if (ks + 2 < p.ksteps) issue_tile(ks + 2, nxt);  // into the buffer stage ks - 1 occupied
-            compute(cur);
-            cur = cur == 2 ? 0 : cur + 1;
-            nxt = nxt == 2 ? 0 : nxt + 1;
-        }
-        __syncthreads();                         // the epilogue staging reuses the operand buffers
-    } else if constexpr (GL) {
+    if constexpr (GL) {
         issue_tile(0, 0);
         SF_WAIT_VMEM();
         __syncthreads();

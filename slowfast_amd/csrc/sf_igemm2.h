@@ -21,17 +21,6 @@
 
 #define SF_I2_MAXTAPS 32
 
-// raw workgroup barrier that does NOT drain the direct-to-LDS copies in flight (__syncthreads() would: its fence waits
-// vmcnt(0)).  LDS reads of this wave are retired first (WAR: another wave may overwrite the stage after the barrier).
-#ifndef SF_BARRIER_KEEP_VMEM
-#define SF_BARRIER_KEEP_VMEM()                                          \
-    do {                                                                \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
-        __builtin_amdgcn_s_barrier();                                   \
-        asm volatile("" ::: "memory");                                  \
-    } while (0)
-#endif
-
 // keeps a fragment register live without using it (diagnostic ablations only)
 #ifndef SF_KEEP_ALIVE
 #define SF_KEEP_ALIVE(x) asm volatile("" ::"v"(x))

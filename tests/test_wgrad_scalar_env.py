@@ -42,18 +42,16 @@ def test_x3d_model_on_version2_stencils(hostsim_path):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_igemm_three_stage_direct_to_lds(hostsim_path):
-    """SF_IGEMM_GL3=1: the direct-to-LDS implicit GEMM with three LDS stages (opt-in experiment) on
-    1x1x1 convolutions (forward, fused eval form, data gradient), a Linear layer and a batched attention-style GEMM,
-    128- and 64-wide tiles, K of 3 to 9 steps, ragged M."""
-    code = ("import torch; from tests import kernel_checks as kc, token_checks as tc; d=torch.device('cpu');"
-            "kc.check_conv_fwd(d,(1,96,2,7,9),128,(1,1,1),(1,1,1),(0,0,0));"
-            "kc.check_conv_fwd(d,(2,288,1,5,5),64,(1,1,1),(1,1,1),(0,0,0));"
-            "kc.check_conv_fwd_fused(d,(1,128,2,6,6),72,(1,1,1),(1,1,1),(0,0,0),resid=True);"
-            "kc.check_conv_dgrad(d,(1,64,2,6,6),160,(1,1,1),(1,1,1),(0,0,0));"
-            "tc.check_gemm(d,150,96,192); tc.check_gemm(d,77,256,64); tc.check_gemm_gelu(d,130,96,128);"
-            "tc.check_attention_core(d,1,1,96,(2,3,3),(2,3,3)); print('ok')")
-    env = dict(os.environ, SF_IGEMM_GL3="1", SFAMD_LIBRARY=hostsim_path)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+def test_igemm_direct_to_lds_shapes(sim):
+    """The direct-to-LDS (pointwise) path of sf_igemm_kernel on 1x1x1 convolutions (forward, fused eval form, data gradient), a
+    Linear layer and a batched attention-style GEMM, 128- and 64-wide tiles, K of 3 to 9 steps, ragged M."""
+    from tests import kernel_checks as kc, token_checks as tc
+    d = sim
+    kc.check_conv_fwd(d, (1, 96, 2, 7, 9), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    kc.check_conv_fwd(d, (2, 288, 1, 5, 5), 64, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    kc.check_conv_fwd_fused(d, (1, 128, 2, 6, 6), 72, (1, 1, 1), (1, 1, 1), (0, 0, 0), resid=True)
+    kc.check_conv_dgrad(d, (1, 64, 2, 6, 6), 160, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    tc.check_gemm(d, 150, 96, 192)
+    tc.check_gemm(d, 77, 256, 64)
+    tc.check_gemm_gelu(d, 130, 96, 128)
+    tc.check_attention_core(d, 1, 1, 96, (2, 3, 3), (2, 3, 3))
