@@ -1286,44 +1286,10 @@ static void dw_block_plan(DwParams& p, DwBlockIdx& bi, const sf_dw_desc* d, bool
     p.rt = make_rowtile(items, d->C, max_blocks, grid);
 }
 #define SF_DW_SMALL_W 3072
-#define SF_DW_DISPATCH(kind, KERNEL, grid, s, p, bi)                                                                    \
-    do {                                                                                                                  \
-        const bool small_w = (p).kT * (p).kH * (p).kW * (p).Cw <= SF_DW_SMALL_W;                                        \
-        if ((kind) == 1 && small_w) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-        else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_MAX_W>), grid, dim3(SF_THREADS), 0, s, p, bi);     \
-        else if ((kind) == 2 && small_w) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-        else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_MAX_W>), grid, dim3(SF_THREADS), 0, s, p, bi);     \
-        else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, s, p, bi);                    \
-    } while (0)
-// forward / data-gradient stencils: PF = one-plane software prefetch, an A/B option (SF_DW_PREFETCH=1): it costs ~90
-// VGPRs (2 instead of 3 waves per SIMD) and measured SLOWER than the plain loop (X3D-M 1092 vs 1137 clips/s,
-// profiles/r1_visit22_ab.txt)
-#define SF_DW_DISPATCH_PF(kind, KERNEL, grid, s, p, bi)                                                                 \
-    do {                                                                                                                  \
-        static const bool pf_ = getenv("SF_DW_PREFETCH") && atoi(getenv("SF_DW_PREFETCH")) != 0;                         \
-        const bool small_w = (p).kT * (p).kH * (p).kW * (p).Cw <= SF_DW_SMALL_W;                                        \
-        if (pf_) {                                                                                                        \
-            if ((kind) == 1 && small_w) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-            else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_MAX_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-            else if ((kind) == 2 && small_w) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_SMALL_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-            else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_MAX_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-            else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W, true>), grid, dim3(SF_THREADS), 0, s, p, bi);            \
-        } else {                                                                                                          \
-            if ((kind) == 1 && small_w) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-            else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_MAX_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-            else if ((kind) == 2 && small_w) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_SMALL_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-            else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_MAX_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-            else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W, false>), grid, dim3(SF_THREADS), 0, s, p, bi);           \
-        }                                                                                                                 \
-    } while (0)
-#define SF_DW_DISPATCH_B(kind, KERNEL, FLAG, grid, s, p, bi)                                                            \
-    do {                                                                                                                  \
-        if ((kind) == 1) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W, FLAG>), grid, dim3(SF_THREADS), 0, s, p, bi);   \
-        else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_SMALL_W, FLAG>), grid, dim3(SF_THREADS), 0, s, p, bi); \
-        else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W, FLAG>), grid, dim3(SF_THREADS), 0, s, p, bi);               \
-    } while (0)
-// version-2 stencils: fp32 LDS weights for the narrow layers, fp16 for the wide ones
-#define SF_DW_DISPATCH_V2(kind, KERNEL, grid, s, p, bi)                                                                 \
+// (A one-plane software prefetch in these stencils cost ~90 VGPRs -- 2 instead of 3 waves per SIMD -- and measured slower:
+// X3D-M 1092 vs 1137 clips/s, profiles/r1/r1_visit22_ab.txt; removed with the first-version stencils in round 3.)
+// forward / data-gradient stencils: fp32 LDS weights for the narrow layers, fp16 for the wide ones
+#define SF_DW_DISPATCH_WT(kind, KERNEL, grid, s, p, bi)                                                                 \
     do {                                                                                                                  \
         const bool small_w = (p).kT * (p).kH * (p).kW * (p).Cw <= SF_DW_SMALL_W;                                        \
         if ((kind) == 1 && small_w) hipLaunchKernelGGL((KERNEL<3, 1, SF_DW_SMALL_W, float>), grid, dim3(SF_THREADS), 0, s, p, bi); \
@@ -1353,12 +1319,7 @@ extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w,
     if (kind) {
         DwBlockIdx bi;
         dw_block_plan(p, bi, d, true, kDwFwdBlocks, grid);
-        // version 2 (uniform plane loop, address-selected zero taps, fp32 LDS weights: ~40 % fewer VALU instructions per
-        // plane in the gfx950 ISA, see sf_dwconv.h) is OPT-IN (SF_DW_FWD_V2=1) until it has been timed on an MI355X: it was
-        // written after the round's GPU budget was spent, and unmeasured code does not become the default
-        static const bool v2 = (getenv("SF_DW_FWD_V2") && atoi(getenv("SF_DW_FWD_V2")) != 0);
-        if (v2) SF_DW_DISPATCH_V2(kind, sf_dwconv_fwd_blocked2_kernel, grid, (hipStream_t)stream, p, bi);
-        else SF_DW_DISPATCH_PF(kind, sf_dwconv_fwd_blocked_kernel, grid, (hipStream_t)stream, p, bi);
+        SF_DW_DISPATCH_WT(kind, sf_dwconv_fwd_blocked_kernel, grid, (hipStream_t)stream, p, bi);
     } else {
         if (p.kT * p.kH * p.kW * p.Cw <= SF_DW_SMALL_W)
             hipLaunchKernelGGL(sf_dwconv_fwd_kernel<SF_DW_SMALL_W>, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
@@ -1377,9 +1338,7 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
     if (kind) {
         DwBlockIdx bi;
         dw_block_plan(p, bi, d, false, 8192, grid);
-        static const bool v2 = (getenv("SF_DW_DGRAD_V2") && atoi(getenv("SF_DW_DGRAD_V2")) != 0);   // opt-in: =1 -> version 2 (unmeasured)
-        if (v2) SF_DW_DISPATCH_V2(kind, sf_dwconv_dgrad_blocked2_kernel, grid, (hipStream_t)stream, p, bi);
-        else SF_DW_DISPATCH_PF(kind, sf_dwconv_dgrad_blocked_kernel, grid, (hipStream_t)stream, p, bi);
+        SF_DW_DISPATCH_WT(kind, sf_dwconv_dgrad_blocked_kernel, grid, (hipStream_t)stream, p, bi);
     } else {
         if (p.kT * p.kH * p.kW * p.Cw <= SF_DW_SMALL_W)
             hipLaunchKernelGGL(sf_dwconv_dgrad_kernel<SF_DW_SMALL_W>, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
@@ -1412,9 +1371,9 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
     REQUIRE(grid.y == 1, "sf_dwconv_wgrad: C > 2048 is not supported");
     p.x = (const f16*)x; p.ldx = d->ldx; p.dy = (const f16*)dy; p.lddy = d->ldy; p.wpart = (float*)workspace;
     grid.z = kind ? d->kT : d->kT * cdiv(d->kH * d->kW, 9);
-    static const bool v2 = (getenv("SF_DW_WGRAD_V2") && atoi(getenv("SF_DW_WGRAD_V2")) != 0);       // opt-in: =1 -> version 2 (unmeasured)
-    if (kind && v2) SF_DW_DISPATCH_B(kind, sf_dwconv_wgrad_blocked_kernel, true, grid, (hipStream_t)stream, p, bi);
-    else if (kind) SF_DW_DISPATCH_B(kind, sf_dwconv_wgrad_blocked_kernel, false, grid, (hipStream_t)stream, p, bi);
+    if (kind == 1) hipLaunchKernelGGL((sf_dwconv_wgrad_blocked_kernel<3, 1, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p, bi);
+    else if (kind == 2) hipLaunchKernelGGL((sf_dwconv_wgrad_blocked_kernel<3, 2, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p, bi);
+    else if (kind) hipLaunchKernelGGL((sf_dwconv_wgrad_blocked_kernel<1, 1, SF_DW_SMALL_W>), grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p, bi);
     else hipLaunchKernelGGL(sf_dwconv_wgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     if (check_launch("dwconv_wgrad")) return -1;
     DwFinalizeParams f;

@@ -281,133 +281,19 @@ __device__ __forceinline__ void cvt8(const f16x8& v, float (&o)[8]) {
     for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
 }
 
-template <int KW, int SW, int WSZ, bool PF>
-__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwParams p, DwBlockIdx bi) {
-    constexpr int NIN = (SF_DW_WB - 1) * SW + KW;
-    __shared__ __attribute__((aligned(16))) f16 s_w[WSZ];   // taps*Cw halfs: 6 KiB for Cw <= 112, else 24 KiB
-    __shared__ float s_red[SF_THREADS][17];
-    dw_stage_weights16(p, s_w);
-    __syncthreads();
-    int gcol, r0, r1, rstep;
-    const bool active = p.rt.init(gcol, r0, r1, rstep);
-    const int c = gcol * 8;
-    const int cw = c % p.Cw;
-    const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls, So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
-    float ssum[8], ssq[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
-    if (active) {
-        for (int m = r0; m < r1; m += rstep) {
-            uint32_t n;
-            int to, ho, wo0;
-            if (dwb_decode(bi, (uint32_t)m, n, to, ho, wo0)) {          // cls row: copy
-                f16x8 v = ld16(p.x + (int64_t)n * Si * p.ldx + c);
-                float f[8];
-                cvt8(v, f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { ssum[e] += f[e]; ssq[e] += f[e] * f[e]; }
-                st16(p.y + (int64_t)n * So * p.ldy + c, v);
-                continue;
-            }
-            const f16* xb = p.x + ((int64_t)n * Si + p.cls) * p.ldx + c;
-            float acc[SF_DW_WB][8];
-#pragma unroll
-            for (int i = 0; i < SF_DW_WB; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
-            const int wi0 = wo0 * SW - p.pW;
-            // The valid (kt, kh) planes are walked in order; PF adds a one-plane software prefetch (two register sets
-            // A / B).  Measured: the prefetch's extra registers cost a resident wave and it is slower (see sf_api.hip).
-            int kt_n = 0, kh_n = 0;
-            auto next_plane = [&](const f16*& line, int& tap) -> bool {
-                while (kt_n < p.kT) {
-                    const int kt = kt_n, kh = kh_n;
-                    if (++kh_n == p.kH) { kh_n = 0; ++kt_n; }
-                    const int t = to * p.sT - p.pT + kt, h = ho * p.sH - p.pH + kh;
-                    if ((unsigned)t < (unsigned)p.Ti && (unsigned)h < (unsigned)p.Hi) {
-                        line = xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx;
-                        tap = (kt * p.kH + kh) * KW;
-                        return true;
-                    }
-                }
-                return false;
-            };
-            auto load_plane = [&](f16x8 (&raw)[NIN], const f16* line) {
-#pragma unroll
-                for (int j = 0; j < NIN; ++j) raw[j] = ld16(line + (int64_t)clampi(wi0 + j, p.Wi - 1) * p.ldx);
-            };
-            auto fma_plane = [&](const f16x8 (&raw)[NIN], int tap) {
-                f16x8 wv[KW];
-#pragma unroll
-                for (int kw = 0; kw < KW; ++kw) wv[kw] = ld16(s_w + (tap + kw) * p.Cw + cw);
-#pragma unroll
-                for (int j = 0; j < NIN; ++j) {
-                    const f16x8 xin = keep8(raw[j], (unsigned)(wi0 + j) < (unsigned)p.Wi);
-#pragma unroll
-                    for (int i = 0; i < SF_DW_WB; ++i) {
-                        const int kw = j - i * SW;      // compile-time after unrolling
-                        if (kw >= 0 && kw < KW) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) acc[i][e] += (float)xin[e] * (float)wv[kw][e];
-                        }
-                    }
-                }
-            };
-            f16x8 rawA[NIN];
-            const f16* la = nullptr;
-            int ta = 0;
-            if constexpr (PF) {
-                f16x8 rawB[NIN];
-                const f16* lb = nullptr;
-                int tb = 0;
-                bool ha = next_plane(la, ta);
-                if (ha) load_plane(rawA, la);
-                while (ha) {
-                    const bool hb = next_plane(lb, tb);
-                    if (hb) load_plane(rawB, lb);
-                    fma_plane(rawA, ta);
-                    if (!hb) break;
-                    ha = next_plane(la, ta);
-                    if (ha) load_plane(rawA, la);
-                    fma_plane(rawB, tb);
-                }
-            } else {
-                while (next_plane(la, ta)) {
-                    load_plane(rawA, la);
-                    fma_plane(rawA, ta);
-                }
-            }
-            f16* yrow = p.y + ((int64_t)n * So + p.cls + ((int64_t)to * p.Ho + ho) * p.Wo + wo0) * p.ldy + c;
-#pragma unroll
-            for (int i = 0; i < SF_DW_WB; ++i) {
-                if (wo0 + i < p.Wo) {
-                    f16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        o[e] = (f16)acc[i][e];
-                        ssum[e] += acc[i][e];
-                        ssq[e] += acc[i][e] * acc[i][e];
-                    }
-                    st16(yrow + (int64_t)i * p.ldy, o);
-                }
-            }
-        }
-    }
-    if (p.stat_part)
-        rowtile_reduce_store(p.rt, active, c, ssum, ssq, p.stat_part + (int64_t)blockIdx.x * 2 * p.rt.C, s_red);
-}
-
-// ---- version 2 of the W-blocked forward stencil ------------------------------------------------------------------
-// The ISA of the kernel above (gfx950, hipcc 7.2) spends ~215 VALU instructions per (kt, kh) plane on 48 packed FMAs:
-// 72 fp16->fp32 converts (48 inputs + 24 weights), 24 v_cndmask zeroing out-of-range taps dword by dword, 32 v_mov
-// copying the accumulators around the divergent "next valid plane" search loop, and that loop's exec-mask bookkeeping.
-// Version 2 keeps the arithmetic (fp32 accumulate, same operand rounding) and removes the overhead:
+// ---- W-blocked forward stencil ----------------------------------------------------------------------------------------
+// The first version of this kernel (rounds 1-2; history) spent ~215 VALU instructions per (kt, kh) plane on 48 packed FMAs:
+// 72 fp16->fp32 converts (48 inputs + 24 weights), 24 v_cndmask zeroing out-of-range taps dword by dword, 32 v_mov copying
+// the accumulators around a divergent "next valid plane" search loop, and that loop's exec-mask bookkeeping.  This one keeps
+// the arithmetic (fp32 accumulate, same operand rounding) and removes the overhead:
 //   * every plane of the kT x kH window is visited (a uniform loop: accumulators stay in place, no divergence);
 //   * a tap outside the input is redirected to a 16-byte line of zeros in global memory by selecting the ADDRESS
 //     (one 64-bit select per plane, plus one per edge column) instead of zeroing the loaded DATA;
 //   * when the row length is a multiple of the 4-column block only column 0 of a group can fall outside (uniform test);
 //   * weights are staged as fp32 (no per-plane weight converts; the 141 VGPRs of this kernel cap residency at 3 waves
 //     per SIMD long before the larger LDS footprint does).
+// Measured with the same restructuring of the data- and weight-gradient stencils (profiles/r3_v11_dw_v2_ab.txt): X3D-M
+// 1183-1191 -> 1198-1203 clips/s, MViTv2-S 547-549 -> 551-553; the first version is gone.
 __device__ __attribute__((aligned(16))) f16 sf_dw_zero_line[8] = {};
 
 // 8 consecutive weights of one tap as fp32 from either LDS image (two ds_read_b128, or one + 8 converts)
@@ -423,7 +309,7 @@ __device__ __forceinline__ void dw_stage_weights_t(const DwParams& p, f16* s_w) 
 // WT = float for the narrow layers (taps*Cw <= 3072: 12 KiB of LDS), f16 for the wide ones (24 KiB instead of 48 KiB, so
 // that LDS does not cap residency below what the registers allow; costs 24 converts per plane)
 template <int KW, int SW, int WSZ, typename WT>
-__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked2_kernel(DwParams p, DwBlockIdx bi) {
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwParams p, DwBlockIdx bi) {
     constexpr int NIN = (SF_DW_WB - 1) * SW + KW;
     __shared__ __attribute__((aligned(16))) WT s_w[WSZ];        // taps*Cw weights, [tap][Cw]
     __shared__ float s_red[SF_THREADS][17];
@@ -516,116 +402,12 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked2_kernel(DwPa
 // data gradient, blocked over 4 consecutive INPUT columns w0..w0+3 (w0 % 4 == 0).  With pW = KW/2 the output
 // columns that can contribute are q0 + jj, q0 = (w0 + pW - (KW-1) + SW-1) / SW rounded as below, and the tap of
 // (input i, column jj) is kw = B0 + i - jj*SW with a compile-time B0.
-template <int KW, int SW, int WSZ, bool PF>
-__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked_kernel(DwParams p, DwBlockIdx bi) {
-    constexpr int PW = KW / 2;
-    // smallest q with w0 + PW - q*SW <= KW-1  (w0 % 4 == 0, SW in {1, 2}):  SW=1: q0 = w0 + PW - (KW-1);  SW=2: q0 = w0/2
-    constexpr int B0 = SW == 1 ? KW - 1 : PW;                 // kw of (i = 0, jj = 0)
-    constexpr int NQ = SW == 1 ? SF_DW_WB + KW - 1 : (SF_DW_WB - 1 + B0) / SW + 1;
-    __shared__ __attribute__((aligned(16))) f16 s_w[WSZ];
-    dw_stage_weights16(p, s_w);
-    __syncthreads();
-    int gcol, r0, r1, rstep;
-    if (!p.rt.init(gcol, r0, r1, rstep)) return;
-    const int c = gcol * 8;
-    const int cw = c % p.Cw;
-    const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls, So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
-    for (int m = r0; m < r1; m += rstep) {
-        uint32_t n;
-        int t, h, w0;
-        if (dwb_decode(bi, (uint32_t)m, n, t, h, w0)) {
-            st16(p.y + (int64_t)n * Si * p.ldy + c, ld16(p.dy + (int64_t)n * So * p.lddy + c));
-            continue;
-        }
-        const f16* db = p.dy + ((int64_t)n * So + p.cls) * p.lddy + c;
-        float acc[SF_DW_WB][8];
-#pragma unroll
-        for (int i = 0; i < SF_DW_WB; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
-        const int q0 = SW == 1 ? w0 + PW - (KW - 1) : w0 / 2;
-        // contributing (kt, kh) planes with a one-plane software prefetch, as in the forward kernel
-        int kt_n = 0, kh_n = 0;
-        auto next_plane = [&](const f16*& line, int& tap) -> bool {
-            while (kt_n < p.kT) {
-                const int kt = kt_n, kh = kh_n;
-                if (++kh_n == p.kH) { kh_n = 0; ++kt_n; }
-                const int ut = t + p.pT - kt, uh = h + p.pH - kh;
-                if (ut < 0 || uh < 0) continue;
-                uint32_t qt, rt, qh, rh;
-                fd_divmod((uint32_t)ut, p.fdsT, qt, rt);
-                fd_divmod((uint32_t)uh, p.fdsH, qh, rh);
-                if (rt || rh || qt >= (uint32_t)p.To || qh >= (uint32_t)p.Ho) continue;
-                line = db + (((int64_t)qt * p.Ho + qh) * p.Wo) * p.lddy;
-                tap = (kt * p.kH + kh) * KW;
-                return true;
-            }
-            return false;
-        };
-        auto load_plane = [&](f16x8 (&raw)[NQ], const f16* line) {
-#pragma unroll
-            for (int jj = 0; jj < NQ; ++jj) raw[jj] = ld16(line + (int64_t)clampi(q0 + jj, p.Wo - 1) * p.lddy);
-        };
-        auto fma_plane = [&](const f16x8 (&raw)[NQ], int tap) {
-            f16x8 wv[KW];
-#pragma unroll
-            for (int kw = 0; kw < KW; ++kw) wv[kw] = ld16(s_w + (tap + kw) * p.Cw + cw);
-#pragma unroll
-            for (int jj = 0; jj < NQ; ++jj) {
-                const f16x8 d = keep8(raw[jj], (unsigned)(q0 + jj) < (unsigned)p.Wo);
-#pragma unroll
-                for (int i = 0; i < SF_DW_WB; ++i) {
-                    const int kw = B0 + i - jj * SW;
-                    if (kw >= 0 && kw < KW) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[i][e] += (float)d[e] * (float)wv[kw][e];
-                    }
-                }
-            }
-        };
-        f16x8 rawA[NQ];
-        const f16* la = nullptr;
-        int ta = 0;
-        if constexpr (PF) {
-            f16x8 rawB[NQ];
-            const f16* lb = nullptr;
-            int tb = 0;
-            bool ha = next_plane(la, ta);
-            if (ha) load_plane(rawA, la);
-            while (ha) {
-                const bool hb = next_plane(lb, tb);
-                if (hb) load_plane(rawB, lb);
-                fma_plane(rawA, ta);
-                if (!hb) break;
-                ha = next_plane(la, ta);
-                if (ha) load_plane(rawA, la);
-                fma_plane(rawB, tb);
-            }
-        } else {
-            while (next_plane(la, ta)) {
-                load_plane(rawA, la);
-                fma_plane(rawA, ta);
-            }
-        }
-        f16* xrow = p.y + ((int64_t)n * Si + p.cls + ((int64_t)t * p.Hi + h) * p.Wi + w0) * p.ldy + c;
-#pragma unroll
-        for (int i = 0; i < SF_DW_WB; ++i) {
-            if (w0 + i < p.Wi) {
-                f16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)acc[i][e];
-                st16(xrow + (int64_t)i * p.ldy, o);
-            }
-        }
-    }
-}
-
-// ---- version 2 of the W-blocked data-gradient stencil (same restructuring as the forward, see above) ----------------
+// (uniform plane loop and address-selected zero taps as in the forward stencil above)
 // The planes that can contribute to input row (t, h) are kt = kt0 + a*sT, kh = kh0 + b*sH with kt0 = (t + pT) % sT,
 // kh0 = (h + pH) % sH: a uniform loop over (a, b) visits exactly those candidates (no divisibility test, no skipped
 // iterations for strided convolutions); a candidate outside the kernel or the output is read from the zero line.
 template <int KW, int SW, int WSZ, typename WT>
-__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked2_kernel(DwParams p, DwBlockIdx bi) {
+__global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked_kernel(DwParams p, DwBlockIdx bi) {
     constexpr int PW = KW / 2;
     constexpr int B0 = SW == 1 ? KW - 1 : PW;                 // kw of (i = 0, jj = 0)
     constexpr int NQ = SW == 1 ? SF_DW_WB + KW - 1 : (SF_DW_WB - 1 + B0) / SW + 1;
@@ -709,9 +491,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked2_kernel(Dw
 }
 
 // weight gradient, blocked over 4 consecutive OUTPUT columns; blockIdx.z = kt, kH*KW (<= 9) accumulators.
-// V2: out-of-range taps are redirected to the zero line by ADDRESS (see the version-2 forward kernel) instead of being
-// zeroed dword by dword after the load, and the (kh) planes are visited uniformly.
-template <int KW, int SW, int WSZ, bool V2 = false>
+// Out-of-range taps are redirected to the zero line by ADDRESS (see the forward kernel) and the (kh) planes are visited uniformly.
+template <int KW, int SW, int WSZ>
 __global__ __launch_bounds__(SF_THREADS, 3) void sf_dwconv_wgrad_blocked_kernel(DwParams p, DwBlockIdx bi) {
     constexpr int NIN = (SF_DW_WB - 1) * SW + KW;
     __shared__ float s_red[SF_THREADS][9];
@@ -739,13 +520,9 @@ __global__ __launch_bounds__(SF_THREADS, 3) void sf_dwconv_wgrad_blocked_kernel(
             f16x8 d[SF_DW_WB];
 #pragma unroll
             for (int i = 0; i < SF_DW_WB; ++i) {
-                if constexpr (V2) {
-                    const f16* a = drow + (int64_t)i * p.lddy;
-                    if (!edge_free) a = wo0 + i < p.Wo ? a : zline;
-                    d[i] = ld16(a);
-                } else {
-                    d[i] = keep8(ld16(drow + (int64_t)(wo0 + i < p.Wo ? i : 0) * p.lddy), wo0 + i < p.Wo);
-                }
+                const f16* a = drow + (int64_t)i * p.lddy;
+                if (!edge_free) a = wo0 + i < p.Wo ? a : zline;
+                d[i] = ld16(a);
             }
             const f16* xb = p.x + ((int64_t)n * Si + p.cls) * p.ldx + c;
             const int wi0 = wo0 * SW - p.pW;
@@ -753,7 +530,7 @@ __global__ __launch_bounds__(SF_THREADS, 3) void sf_dwconv_wgrad_blocked_kernel(
             for (int kh = 0; kh < 9 / KW; ++kh) {
                 if (kh < p.kH) {
                     const int h = ho * p.sH - p.pH + kh;
-                    if constexpr (V2) {
+                    {
                         const bool pv = (unsigned)h < (unsigned)p.Hi;
                         const f16* line = pv ? xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx : zline;
                         const int64_t cstride = pv ? (int64_t)p.ldx : 0;
@@ -769,24 +546,6 @@ __global__ __launch_bounds__(SF_THREADS, 3) void sf_dwconv_wgrad_blocked_kernel(
                         for (int j = 0; j < NIN; ++j) {
                             float xin[8];
                             cvt8(raw[j], xin);
-#pragma unroll
-                            for (int i = 0; i < SF_DW_WB; ++i) {
-                                const int kw = j - i * SW;
-                                if (kw >= 0 && kw < KW) {
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) acc[kh * KW + kw][e] += (float)d[i][e] * xin[e];
-                                }
-                            }
-                        }
-                    } else if ((unsigned)h < (unsigned)p.Hi) {
-                        const f16* line = xb + (((int64_t)t * p.Hi + h) * p.Wi) * p.ldx;
-                        f16x8 raw[NIN];
-#pragma unroll
-                        for (int j = 0; j < NIN; ++j) raw[j] = ld16(line + (int64_t)clampi(wi0 + j, p.Wi - 1) * p.ldx);
-#pragma unroll
-                        for (int j = 0; j < NIN; ++j) {
-                            float xin[8];
-                            cvt8(keep8(raw[j], (unsigned)(wi0 + j) < (unsigned)p.Wi), xin);
 #pragma unroll
                             for (int i = 0; i < SF_DW_WB; ++i) {
                                 const int kw = j - i * SW;

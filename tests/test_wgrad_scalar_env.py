@@ -1,4 +1,5 @@
-"""CPU: the SF_WGRAD_SCALAR=1 fragment path (read once per process) through the host simulator."""
+"""CPU: the SF_WGRAD_SCALAR=1 fragment path (read once per process) and shape sweeps of the depthwise / pointwise kernels
+through the host simulator."""
 import os
 import subprocess
 import sys
@@ -13,33 +14,19 @@ def test_wgrad_scalar_path(hostsim_path):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
-def test_depthwise_version2_kernels(hostsim_path):
-    """SF_DW_FWD_V2=1 / SF_DW_DGRAD_V2=1 / SF_DW_WGRAD_V2=1 select the second-generation W-blocked depthwise stencils
-    (opt-in until they have been timed on hardware; profiles/r1/r1_isa_dwconv_v2.md)."""
-    code = ("import torch; from tests import token_checks as tc; d=torch.device('cpu');"
-            "tc.check_dwconv(d,2,2,16,(2,6,6),(3,3,3),(1,2,2),cls=1);"
-            "tc.check_dwconv(d,1,1,32,(4,5,5),(3,3,3),(1,1,1),cls=1);"
-            "tc.check_dwconv(d,2,1,24,(6,4,4),(5,1,1),(1,1,1),cls=0);"
-            "tc.check_dwconv(d,1,2,8,(2,7,7),(3,3,3),(1,2,2),cls=0);"
-            "tc.check_dwconv(d,1,1,16,(3,5,8),(3,3,3),(1,1,1),cls=0);"
-            "tc.check_dwconv(d,1,1,8,(2,6,16),(3,3,3),(1,2,2),cls=1);"
-            "tc.check_dwconv(d,1,1,120,(2,4,8),(3,3,3),(1,1,1),cls=0);"
-            "tc.check_dwconv(d,1,1,16,(5,4,4),(5,1,1),(1,1,1),cls=0); print('ok')")
-    env = dict(os.environ, SF_DW_FWD_V2="1", SF_DW_DGRAD_V2="1", SF_DW_WGRAD_V2="1", SFAMD_LIBRARY=hostsim_path)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
-
-
-def test_x3d_model_on_version2_stencils(hostsim_path):
-    """The X3D miniature end to end (forward + backward vs the oracle) with the version-2 stencils switched on."""
-    code = ("import torch; from tests import model_checks as mc;"
-            "mc.check_engine('x3d_tiny', torch.device('cpu'), tol_logits=1e-2, tol_loss=2e-3, tol_gnorm=2e-2, tol_param=0.5,"
-            " tol_global=0.3, tol_stats=5e-3); print('ok')")
-    env = dict(os.environ, SF_DW_FWD_V2="1", SF_DW_DGRAD_V2="1", SF_DW_WGRAD_V2="1", SFAMD_LIBRARY=hostsim_path)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+def test_depthwise_blocked_stencil_shapes(sim):
+    """The W-blocked depthwise stencils (uniform plane loop, address-selected zero taps; the only version since round 3) on narrow
+    and wide layers, strides 1 / 2, whole and ragged 4-column groups, cls rows, (5,1,1) temporal kernels."""
+    from tests import token_checks as tc
+    d = sim
+    tc.check_dwconv(d, 2, 2, 16, (2, 6, 6), (3, 3, 3), (1, 2, 2), cls=1)
+    tc.check_dwconv(d, 1, 1, 32, (4, 5, 5), (3, 3, 3), (1, 1, 1), cls=1)
+    tc.check_dwconv(d, 2, 1, 24, (6, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)
+    tc.check_dwconv(d, 1, 2, 8, (2, 7, 7), (3, 3, 3), (1, 2, 2), cls=0)
+    tc.check_dwconv(d, 1, 1, 16, (3, 5, 8), (3, 3, 3), (1, 1, 1), cls=0)
+    tc.check_dwconv(d, 1, 1, 8, (2, 6, 16), (3, 3, 3), (1, 2, 2), cls=1)
+    tc.check_dwconv(d, 1, 1, 120, (2, 4, 8), (3, 3, 3), (1, 1, 1), cls=0)
+    tc.check_dwconv(d, 1, 1, 16, (5, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)
 
 
 def test_igemm_direct_to_lds_shapes(sim):

@@ -12,4 +12,3 @@ TAG=mvit_base;    run SF_DUMMY=1
 TAG=mvit_occ3;    run SF_IGEMM_OCC4=0
 P="--preset X3D_M --batch 64"
 TAG=x3d_base;     run SF_DUMMY=1
-TAG=x3d_dwv2;     run SF_DW_FWD_V2=1 SF_DW_DGRAD_V2=1 SF_DW_WGRAD_V2=1
