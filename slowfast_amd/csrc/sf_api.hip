@@ -549,11 +549,10 @@ extern "C" int sf_conv_dgrad_bn(const sf_conv_desc* d, const void* dy, const voi
 }
 
 template <int BMW, int WM, int WN, int KS>
-static void launch_wgrad(WgradParams& p, dim3 grid3, bool scalar, hipStream_t s) {
+static void launch_wgrad(WgradParams& p, dim3 grid3, hipStream_t s) {
     p.tiles_k = grid3.x; p.tiles_c = grid3.y;
     const dim3 grid(grid3.x * grid3.y * grid3.z);
-    if (scalar) hipLaunchKernelGGL((sf_wgrad_kernel<BMW, WM, WN, KS, false>), grid, dim3(SF_THREADS), 0, s, p);
-    else hipLaunchKernelGGL((sf_wgrad_kernel<BMW, WM, WN, KS, true>), grid, dim3(SF_THREADS), 0, s, p);
+    hipLaunchKernelGGL((sf_wgrad_kernel<BMW, WM, WN, KS>), grid, dim3(SF_THREADS), 0, s, p);
 }
 
 // Split-K plan of the weight gradient: the reduction over the M = N*To*Ho*Wo positions is cut into `splits`
@@ -640,7 +639,7 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
         return w;
     }
     if (Ktot < mink) return w;
-    w.BMW = d->Co > 64 && !((e = getenv("SF_WGRAD2_BMW")) && atoi(e) == 64) ? 128 : 64;      // SF_WGRAD2_BMW=64: A/B knob (tools/wgrad_sweep.py)
+    w.BMW = d->Co > 64 ? 128 : 64;       // 64-row co-tiles for wide layers lose 20-40 % on res3-res5 (profiles/r3_final_wgrad_sweep.md)
     w.tiles_k = cdiv(Ktot, 256);
     w.tiles_c = cdiv(d->Co, w.BMW);
     w.Kpad = w.tiles_k * 256;
@@ -708,7 +707,6 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
     REQUIRE(x && dy && dw && workspace, "sf_conv_wgrad: null pointer");
     REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sf_conv_wgrad: in_scale/in_shift must come together");
     REQUIRE(!in_scale || d->Ci <= 512, "sf_conv_wgrad: fused input BatchNorm supports Ci <= 512 (got %d)", d->Ci);
-    static const bool scalar = getenv("SF_WGRAD_SCALAR") && atoi(getenv("SF_WGRAD_SCALAR")) != 0;
     hipStream_t s = (hipStream_t)stream;
     int splits, Co_pad, Kpad;
     GatherSide gk = gather_fwd(d, x, in_scale, in_shift, in_relu);
@@ -772,10 +770,10 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
         p.nchunks = w.nchunks; p.chunks_per_split = w.chunks_per_split;
         dim3 grid(w.tiles_k, w.tiles_c, w.splits);
         switch (w.BMW) {
-            case 128: launch_wgrad<128, 64, 64, 1>(p, grid, scalar, s); break;
-            case 64: launch_wgrad<64, 32, 64, 1>(p, grid, scalar, s); break;
-            case 32: launch_wgrad<32, 32, 32, 4>(p, grid, scalar, s); break;
-            default: launch_wgrad<16, 16, 32, 4>(p, grid, scalar, s); break;
+            case 128: launch_wgrad<128, 64, 64, 1>(p, grid, s); break;
+            case 64: launch_wgrad<64, 32, 64, 1>(p, grid, s); break;
+            case 32: launch_wgrad<32, 32, 32, 4>(p, grid, s); break;
+            default: launch_wgrad<16, 16, 32, 4>(p, grid, s); break;
         }
         splits = w.splits; Co_pad = w.Co_pad; Kpad = w.Kpad;
     }
@@ -1115,7 +1113,6 @@ extern "C" int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int3
     REQUIRE(Kc % 8 == 0 && ldp % 8 == 0 && ldx % 8 == 0 && ldp >= R && ldx >= Kc && ldo >= Kc,
             "sf_bgemm_tn: Kc and the pitches must be multiples of 8");
     REQUIRE(nbatch >= 1 && bh >= 1 && nbatch % bh == 0 && nbatch <= 65535, "sf_bgemm_tn: bad batch");
-    static const bool scalar = getenv("SF_WGRAD_SCALAR") && atoi(getenv("SF_WGRAD_SCALAR")) != 0;
     WgradParams p;
     memset(&p, 0, sizeof(p));
     p.g = gather_matrix(X, M, Kc, ldx);
@@ -1125,10 +1122,10 @@ extern "C" int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int3
     p.out16 = (f16*)Out; p.ldo = ldo; p.out_scale = scale;
     hipStream_t s = (hipStream_t)stream;
     const int tiles_k = cdiv(Kc, 128);
-    if (R >= 128) { p.chunks_per_split = p.nchunks; launch_wgrad<128, 64, 64, 1>(p, dim3(tiles_k, cdiv(R, 128), nbatch), scalar, s); }
-    else if (R >= 64) { p.chunks_per_split = p.nchunks; launch_wgrad<64, 32, 64, 1>(p, dim3(tiles_k, cdiv(R, 64), nbatch), scalar, s); }
-    else if (R >= 32) { p.chunks_per_split = roundup(p.nchunks, 4); launch_wgrad<32, 32, 32, 4>(p, dim3(tiles_k, cdiv(R, 32), nbatch), scalar, s); }
-    else { p.chunks_per_split = roundup(p.nchunks, 4); launch_wgrad<16, 16, 32, 4>(p, dim3(tiles_k, cdiv(R, 16), nbatch), scalar, s); }
+    if (R >= 128) { p.chunks_per_split = p.nchunks; launch_wgrad<128, 64, 64, 1>(p, dim3(tiles_k, cdiv(R, 128), nbatch), s); }
+    else if (R >= 64) { p.chunks_per_split = p.nchunks; launch_wgrad<64, 32, 64, 1>(p, dim3(tiles_k, cdiv(R, 64), nbatch), s); }
+    else if (R >= 32) { p.chunks_per_split = roundup(p.nchunks, 4); launch_wgrad<32, 32, 32, 4>(p, dim3(tiles_k, cdiv(R, 32), nbatch), s); }
+    else { p.chunks_per_split = roundup(p.nchunks, 4); launch_wgrad<16, 16, 32, 4>(p, dim3(tiles_k, cdiv(R, 16), nbatch), s); }
     return check_launch("bgemm_tn");
 }
 

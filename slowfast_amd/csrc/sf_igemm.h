@@ -560,9 +560,8 @@ __device__ __forceinline__ bool gather_offset_tap(const GatherSide& g, const Row
 //   KS == 1: two LDS buffers, global loads of stage s+1 in flight under the MFMAs of stage s (MFMA-bound tiles);
 //   KS  > 1: small-Co tiles are HBM-bound and latency-limited -- a long stage (128 positions) amortises the
 //            barrier and the load latency, one LDS buffer + register staging keeps 3 workgroups per CU.
-// TR = true : MFMA fragments via ds_read_b64_tr_b16 (hardware transpose read)
-// TR = false: eight scalar LDS reads per fragment (reference path, selectable with SF_WGRAD_SCALAR=1)
-template <int BMW, int WM, int WN, int KS, bool TR>
+// MFMA fragments come from ds_read_b64_tr_b16 (hardware transpose read).
+template <int BMW, int WM, int WN, int KS>
 __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
     constexpr int BNW = 128, BKM = 32, ROWS = BKM * KS;
     constexpr int WAVES_N = BNW / WN, WAVES_M = BMW / WM;
@@ -665,7 +664,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
             const f16* Ys = smem + buf * BUF + ks * BKM * LDA;
             const f16* Xs = smem + buf * BUF + ROWS * LDA + ks * BKM * LDB;
             f16x8 af[TM], bf[TN];
-            if constexpr (TR) {
+            {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -684,15 +683,6 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_kernel(WgradParams p) {
                         bf[j][4 * h + 0] = t[0]; bf[j][4 * h + 1] = t[1]; bf[j][4 * h + 2] = t[2]; bf[j][4 * h + 3] = t[3];
                     }
                 }
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) af[i][e] = Ys[(8 * g4 + e) * LDA + wm * WM + i * 16 + pl];
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bf[j][e] = Xs[(8 * g4 + e) * LDB + wn * WN + j * 16 + pl];
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)

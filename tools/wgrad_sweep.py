@@ -22,9 +22,9 @@ def main():
     ap.add_argument("--filter", default="slow")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    # (co-tile rows of sf_wgrad2_kernel, workgroup target): 128 = default for Co > 64; 64 = SF_WGRAD2_BMW=64 (twice the tiles, half
-    # the split partials, the x operand read by twice as many workgroups)
-    variants = [(m, b) for m in ("128", "64") for b in (384, 512, 768, 1024)]
+    # (co-tile rows of sf_wgrad2_kernel, workgroup target).  profiles/r3_final_wgrad_sweep.md also has 64-row co-tiles for the wide
+    # layers (a knob that existed for that sweep: they lose 20-40 % on res3-res5 and the knob is gone)
+    variants = [("128", b) for b in (256, 384, 448, 512, 640, 768, 1024)]
     lines = ["| layer | x | " + " | ".join(f"bmw{n} b{b}" for n, b in variants) + " | best |", "|---|---:|" + "---:|" * (len(variants) + 1)]
     tot = [0.0] * len(variants)
     best_tot = 0.0
@@ -40,7 +40,6 @@ def main():
         ts = []
         for bmw, blocks in variants:
             os.environ["SF_WGRAD2_BLOCKS"] = str(blocks)
-            os.environ["SF_WGRAD2_BMW"] = bmw
             geom.ws_bytes = None
             ts.append(timeit(lambda: ops.conv_wgrad(x, dy, geom, dw), a.iters) * 1e3)
         for i, t in enumerate(ts):
