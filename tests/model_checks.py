@@ -144,7 +144,9 @@ def _worst_contributors(grads, ref, top=8):
 def _param_worst(grads, ref, ogn):
     worst, worst_k = 0.0, None
     for k, g in ref.items():
-        e = float((grads[k] - g).norm() / (g.norm() + 1e-3 * ogn / len(ref) ** 0.5))
+        # the floor stands for the round-off a 16-bit pipeline leaves on gradients that vanish identically in exact arithmetic
+        # (a LayerNorm bias in front of a softmax over the axis it is constant on, ...): it scales with the storage epsilon
+        e = float((grads[k] - g).norm() / (g.norm() + 1e-3 * EPS_SCALE * ogn / len(ref) ** 0.5))
         if e > worst:
             worst, worst_k = e, k
     return worst, worst_k
@@ -463,7 +465,10 @@ def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99,
         with torch.no_grad(), video_ref.fp16_storage_model():
             s_logits = fwd(sd, cfg, list(inputs), training=True, **kw)
         res["logits_l2_storage_model"] = float((s_logits - o_logits).norm() / o_logits.norm())
-        b_logits = max(tol, res["logits_l2_storage_model"])
+        # YARD: the storage model is ONE realisation of that rounding noise and the engine another (the model itself reads
+        # 1.19e-3 on the GPU box's host and 1.26e-3 in the build container -- thread count changes its summation order; the
+        # engine read 1.15e-3 with the first-generation pooling stencils and 1.19e-3 with the second)
+        b_logits = max(tol, YARD * res["logits_l2_storage_model"])
     for k in ("logits_l2", "loss", "grad_norm"):
         assert res[k] <= (b_logits if k == "logits_l2" else tol), (k, res)
     assert res["logits_max"] <= 2 * b_logits, res
