@@ -451,9 +451,6 @@ def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99,
         else (res["grad_global"], tol_global, None)
     res["masked_modules"] = len(table) if table else 0
     res["worst_params_unmasked"] = _worst_contributors(grads, o_grads)
-    _record(preset + "@full", device, dict(res, bounds=dict({k: tol for k in ("logits_l2", "loss", "grad_norm")},
-                                                            logits_max=2 * tol, grad_global_masked=gg_bound),
-                                           yardstick_kind="none (1e-3)"))
     b_logits = tol
     if res["logits_l2"] > tol:
         # above the north star's 1e-3: admissible only up to what the oracle's OWN fp16 storage model (the pinned reference
@@ -469,6 +466,9 @@ def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99,
         # 1.19e-3 on the GPU box's host and 1.26e-3 in the build container -- thread count changes its summation order; the
         # engine read 1.15e-3 with the first-generation pooling stencils and 1.19e-3 with the second)
         b_logits = max(tol, YARD * res["logits_l2_storage_model"])
+    _record(preset + "@full", device, dict(res, bounds=dict({"logits_l2": b_logits, "loss": tol, "grad_norm": tol},
+                                                            logits_max=2 * b_logits, grad_global_masked=gg_bound),
+                                           yardstick_kind="none (1e-3)" if b_logits == tol else "1.5 x storage model (logits only)"))
     for k in ("logits_l2", "loss", "grad_norm"):
         assert res[k] <= (b_logits if k == "logits_l2" else tol), (k, res)
     assert res["logits_max"] <= 2 * b_logits, res
