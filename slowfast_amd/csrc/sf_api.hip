@@ -323,7 +323,7 @@ static int run_igemm(IgemmParams& p, bool pw, hipStream_t s, int* bm_used = null
 // ------------------------------------------------------------------------------------------------
 // LDS-patch direct convolution for the thin W-pair-folded stems (sf_stem.h); SF_STEM_GENERIC=1 keeps the implicit GEMM.
 struct StemPlan {
-    bool ok;
+    bool ok, thin3;
     int tiles_w, tiles_h, tiles_t, ntiles, F, PR;
     int wg_blocks, tiles_per_block, Kpad;
     size_t ws_bytes;
@@ -333,8 +333,16 @@ static StemPlan plan_stem(const sf_conv_desc* d) {
     memset(&s, 0, sizeof(s));
     static const bool off = getenv("SF_STEM_GENERIC") && atoi(getenv("SF_STEM_GENERIC")) != 0;
     if (off) return s;
-    if (d->Ci != 8 || d->Cw != 8 || d->kW != 4 || d->sW != 1 || d->pW != 2 || d->dT != 1 || d->dH != 1 || d->dW != 1)
+    // thin3: an 8-channel (kT, kH, 3) stride-1 layer with one pixel of W padding (the Fast pathway's res2 1x3x3 bottleneck) is the
+    // same direct convolution with a zero fourth tap: forward, data gradient (conv_dgrad_impl) and weight gradient.  Measured on
+    // s2.fast b (profiles/r3_v13_thin3_ab.txt): fwd 105 -> 57-69 us, dgrad 110 -> 56, wgrad 95 -> 90; SlowFast step +0.6 %.
+    // SF_STEM_THIN3=0 keeps the implicit GEMM for A/B runs.
+    static const bool thin3_on = !(getenv("SF_STEM_THIN3") && atoi(getenv("SF_STEM_THIN3")) == 0);
+    const bool stemlike = d->kW == 4 && d->pW == 2;
+    const bool thin3 = thin3_on && d->kW == 3 && d->pW == 1 && d->sH == 1 && d->sT == 1;
+    if (d->Ci != 8 || d->Cw != 8 || !(stemlike || thin3) || d->sW != 1 || d->dT != 1 || d->dH != 1 || d->dW != 1)
         return s;
+    s.thin3 = thin3;
     if (d->Co > 16 || d->Co % 8 != 0 || (d->Cow && d->Cow != d->Co)) return s;
     if (d->kT * d->kH > SF_STEM_MAX_SLICES) return s;
     s.F = (SF_STEM_TT - 1) * d->sT + d->kT;
@@ -361,6 +369,9 @@ static StemParams stem_params(const sf_conv_desc* d, const StemPlan& s, const vo
     p.N = d->N; p.Ti = d->Ti; p.Hi = d->Hi; p.Wi = d->Wi;
     p.To = d->To; p.Ho = d->Ho; p.Wo = d->Wo; p.Co = d->Co;
     p.kT = d->kT; p.kH = d->kH; p.sT = d->sT; p.sH = d->sH; p.pT = d->pT; p.pH = d->pH;
+    p.pW = d->pW;
+    if (s.thin3) { p.wo0 = 0; p.wos = 24; p.wog = 8; p.kwc = 3; }
+    else { p.wo0 = 0; p.wos = 32; p.wog = 8; p.kwc = 4; }
     p.ldy = d->ldy;
     p.tiles_w = s.tiles_w; p.tiles_h = s.tiles_h; p.tiles_t = s.tiles_t; p.ntiles = s.ntiles;
     p.fd_tw = make_fastdiv(s.tiles_w); p.fd_th = make_fastdiv(s.tiles_h); p.fd_tt = make_fastdiv(s.tiles_t);
@@ -520,6 +531,29 @@ static int conv_dgrad_impl(const sf_conv_desc* d, const void* dy, const void* wd
     // the fused BatchNorm-backward reduction rides on dense stride-1 data gradients only (a strided one runs as one launch
     // per residue class of input positions, or gathers with 3/4 of its taps masked): the caller then keeps sf_bn_bwd_reduce
     const bool fuse = bn && d->sT == 1 && d->sH == 1 && d->sW == 1;
+    // thin3 (plan_stem): the data gradient of an 8-channel same-size (kT, kH, 3) layer is the LDS-patch direct convolution of dy
+    // with the flipped kernel, read from the packed data-gradient operand in reverse order
+    if (!resid && d->Co == 8 && d->To == d->Ti && d->Ho == d->Hi && d->Wo == d->Wi) {
+        sf_conv_desc dd = *d;
+        dd.Ci = d->Co; dd.Cw = d->Co; dd.Co = d->Ci; dd.Cow = 0;
+        dd.pT = d->kT - 1 - d->pT; dd.pH = d->kH - 1 - d->pH; dd.pW = d->kW - 1 - d->pW;
+        dd.ldx = d->ldy; dd.ldy = d->ldx;
+        const StemPlan sp = plan_stem(&dd);
+        if (sp.ok && sp.thin3 && (!fuse || sp.ntiles <= cdiv(p.M, 128))) {
+            StemParams q = stem_params(&dd, sp, dy);
+            const int S = d->kT * d->kH;
+            q.wmat = (const f16*)wd; q.ldw = ldd; q.y = (f16*)dx;
+            q.wo0 = ((S - 1) * 3 + 2) * 8; q.wos = -24; q.wog = -8; q.kwc = 3;
+            if (fuse) {
+                q.bnb_y = (const f16*)bn->y0; q.bnb_ld = bn->ld0; q.bnb_scale = bn->scale; q.bnb_shift = bn->shift;
+                q.bnb_bits = (const uint8_t*)bn->bits;
+                q.stat_part = bn->part0; q.stat_rows = 0;
+            }
+            hipLaunchKernelGGL(sf_stem_fwd_kernel, dim3(sp.ntiles), dim3(SF_THREADS), 0, (hipStream_t)stream, q);
+            if (bn_rows) *bn_rows = fuse ? sp.ntiles : 0;
+            return check_launch("stem_dgrad");
+        }
+    }
     if (fuse) {
         p.bnb_y = (const f16*)bn->y0; p.bnb_ld = bn->ld0; p.bnb_part = bn->part0;
         p.bnb_scale = bn->scale; p.bnb_shift = bn->shift; p.bnb_bits = (const uint8_t*)bn->bits;
@@ -781,6 +815,8 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
     WgradReduceParams r;
     r.ws = slabs; r.splits = splits; r.Co = d->Cow ? d->Cow : d->Co; r.Co_pad = Co_pad; r.Kpad = Kpad;
     r.Ktot = gk.Ktot; r.fdC = gk.fdC; r.dw = dw; r.Cw = d->Cw; r.taps = d->kT * d->kH * d->kW;
+    r.slice4 = 0;
+    if (sp.ok && sp.thin3 && !in_scale && !w2.ok) { r.slice4 = 1; r.Ktot = d->kT * d->kH * 32; }   // 4-chunk slices, the 4th is no tap
     r.out_scale = out_scale; r.accumulate = zero_first ? 0 : 1;
     int64_t total = (int64_t)r.Co * Kpad / 4;              // element quads
     int lanes = 1;

@@ -471,6 +471,7 @@ struct WgradReduceParams {
     float out_scale;
     int accumulate;
     int lanes;          // split lanes per output element (power of two, 1..32)
+    int slice4;         // 1: kcol = (slice*4 + chunk)*C + ci with three real taps per slice (sf_stem.h on 8-channel 3-wide kernels)
 };
 
 // 256 threads = E element quads x L split lanes (L = p.lanes, a power of two <= 32): lane z of a quad sums splits
@@ -512,6 +513,10 @@ __global__ __launch_bounds__(SF_THREADS) void sf_wgrad_reduce_kernel(WgradReduce
             if (kcol < p.Ktot) {
                 uint32_t tap, ci;
                 fd_divmod((uint32_t)kcol, p.fdC, tap, ci);
+                if (p.slice4) {
+                    if ((tap & 3u) == 3u) continue;
+                    tap = (tap >> 2) * 3u + (tap & 3u);
+                }
                 if (ci < (uint32_t)p.Cw) {
                     float* dst = p.dw + ((int64_t)co * p.Cw + ci) * p.taps + tap;
                     const float v = r[j] * p.out_scale;

@@ -1,7 +1,10 @@
-// Direct convolution for the thin RGB stems (forward + weight gradient), LDS-patch based.
+// Direct convolution for the thin RGB stems (forward + weight gradient), LDS-patch based -- and, since round 3, for 8-channel
+// (kT, kH, 3) stride-1 layers (the Fast pathway's res2 1x3x3 bottleneck: forward, data gradient with the fused BatchNorm-backward
+// sums of sf_conv_dgrad_bn, weight gradient), whose pixel IS one 16-byte chunk: three real taps and a zero fourth one per slice.
 //
 // Reference call sites: slowfast/models/stem_helper.py:182-189 (ResNetBasicStem.conv, the Fast pathway's
-// Conv3d(3, 8, [5,7,7], stride [1,2,2], padding [2,3,3])) and its autograd backward w.r.t. the weight.
+// Conv3d(3, 8, [5,7,7], stride [1,2,2], padding [2,3,3])), slowfast/models/resnet_helper.py:331-369 (BottleneckTransform.b of the
+// Fast pathway's res2 stage) and their autograd backward.
 //
 // The generic implicit GEMM (sf_igemm.h) gathers every im2col element with its own global load: for the Fast
 // stem that is M*K*2 B = 12.8M x 1120 x 2 = 28.7 GB through the vector L1 per pass, although the clip itself is
@@ -33,11 +36,19 @@ struct StemParams {
     const f16* x; int ldx;            // W-pair view rows (n, t, h, w2), 8 channels
     int N, Ti, Hi, Wi;                // Wi counts pairs
     int To, Ho, Wo, Co;
-    int kT, kH, sT, sH, pT, pH;       // kW = 4 pairs, sW = 1 pair, pW = 2 pairs
+    int kT, kH, sT, sH, pT, pH;       // kW = 4 chunks (the last may be a zero tap), sW = 1 chunk
+    int pW;                           // chunks of left padding: 2 pairs (stems), 1 pixel (8-channel 1x3x3 layers)
+    // weight of (slice s = kt*kH + kh, chunk g): wmat[co][wo0 + s*wos + g*wog .. +8]; chunks g >= kwc carry no weight.
+    // stems: (0, 32, 8, 4); 8-channel (kT,3,3) forward on the packed forward operand: (0, 24, 8, 3)
+    int wo0, wos, wog, kwc;
     const f16* wmat; int ldw;         // [Co][ldw], k = (kt*kH + kh)*32 + pair*8 + e
     f16* y; int ldy;
     float* stat_part; int stat_rows;  // [stat_rows][2][Co]; rows beyond the workgroup count are zeroed here
     const float* bias; int out_relu;  // inference-fused forward (sf_conv_fwd_fused): y = relu?(conv + bias[co])
+    // data-gradient use (thin3): the BatchNorm-backward partial sums of sf_conv_dgrad_bn instead of the forward statistics --
+    // stat_part rows become [2][Co] = {sum g, sum g * bnb_y}, g = stored output masked by (bnb_y * bnb_scale + bnb_shift > 0)
+    const f16* bnb_y; int bnb_ld; const float* bnb_scale; const float* bnb_shift;
+    const uint8_t* bnb_bits;          // optional [rows][Co/8] bit mask replacing the recomputed one (a block output's ReLU)
     int tiles_w, tiles_h, tiles_t, ntiles;
     FastDiv fd_tw, fd_th, fd_tt;
     int F, PR;                        // patch frames / rows
@@ -61,12 +72,12 @@ __device__ __forceinline__ StemTile stem_tile(const StemParams& p, uint32_t tile
     return t;
 }
 
-// stage the input patch of one tile: chunk (f, r, c) <- x[n][t0*sT - pT + f][h0*sH - pH + r][w0 - 2 + c], zeros outside
+// stage the input patch of one tile: chunk (f, r, c) <- x[n][t0*sT - pT + f][h0*sH - pH + r][w0 - pW + c], zeros outside
 template <int NTHREADS>
 __device__ __forceinline__ void stem_load_patch(const StemParams& p, f16* patch, const StemTile& t, int tid) {
     constexpr int U = 7;               // 16-byte loads in flight per thread (the Fast stem's patch is 12.5 / 6.2 per thread)
     const int nch = p.F * p.PR * SF_STEM_PC;
-    const int tin0 = t.t0 * p.sT - p.pT, hin0 = t.h0 * p.sH - p.pH, win0 = t.w0 - 2;
+    const int tin0 = t.t0 * p.sT - p.pT, hin0 = t.h0 * p.sH - p.pH, win0 = t.w0 - p.pW;
     for (int base = 0; base < nch; base += NTHREADS * U) {
         f16x8 v[U];
         bool ok[U];
@@ -105,8 +116,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_kernel(StemParams p) {
     f32x4 acc[SF_STEM_TH];
 #pragma unroll
     for (int i = 0; i < SF_STEM_TH; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool co_ok = pl < p.Co;
-    const f16* wrow = p.wmat + (co_ok ? (int64_t)pl * p.ldw : 0) + 8 * g4;
+    const bool co_ok = pl < p.Co && g4 < p.kwc;
+    const f16* wrow = p.wmat + (co_ok ? (int64_t)pl * p.ldw + p.wo0 + p.wog * g4 : 0);
     const int nsl = p.kT * p.kH;
     f16x8 wf = ld16(wrow);
     __syncthreads();
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_kernel(StemParams p) {
     const int row_step = p.sH * SF_STEM_PC * 8;
     for (int s = 0; s < nsl; ++s) {
         const int sn = s + 1 < nsl ? s + 1 : s;
-        const f16x8 wnext = ld16(wrow + sn * 32);
+        const f16x8 wnext = ld16(wrow + (co_ok ? sn * p.wos : 0));
         const f16x8 a = co_ok ? wf : zero8();
         const f16* base = patch + (((wave * p.sT + kt) * p.PR + kh) * SF_STEM_PC + pl + g4) * 8;
         f16x8 px[SF_STEM_TH];
@@ -135,19 +146,36 @@ __global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_kernel(StemParams p) {
         for (int r = 0; r < 4; ++r) b4[r] = p.bias[4 * g4 + r];
     }
     const float lo = p.out_relu ? 0.f : -INFINITY;
+    float msc[4] = {0.f, 0.f, 0.f, 0.f}, msh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bnb_y && !p.bnb_bits && 4 * g4 < p.Co) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { msc[r] = p.bnb_scale[4 * g4 + r]; msh[r] = p.bnb_shift[4 * g4 + r]; }
+    }
 #pragma unroll
     for (int i = 0; i < SF_STEM_TH; ++i) {
         const int ho = t.h0 + i;
         const bool ok = to < p.To && ho < p.Ho && wo < p.Wo;
         if (ok) {
+            const int64_t m = (((int64_t)t.n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+            f16x4 o = {(f16)fmaxf(acc[i][0] + b4[0], lo), (f16)fmaxf(acc[i][1] + b4[1], lo),
+                       (f16)fmaxf(acc[i][2] + b4[2], lo), (f16)fmaxf(acc[i][3] + b4[3], lo)};
+            if (p.bnb_y) {
+                if (4 * g4 < p.Co) {
+                    const f16x4 yv = *reinterpret_cast<const f16x4*>(p.bnb_y + m * p.bnb_ld + 4 * g4);
+                    const uint32_t mb = p.bnb_bits ? (uint32_t)p.bnb_bits[m * (p.Co >> 3) + (g4 >> 1)] >> (4 * (g4 & 1)) : 0u;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s4[r] += acc[i][r]; q4[r] += acc[i][r] * acc[i][r]; }
-            if (4 * g4 < p.Co) {
-                const int64_t m = (((int64_t)t.n * p.To + to) * p.Ho + ho) * p.Wo + wo;
-                f16x4 o = {(f16)fmaxf(acc[i][0] + b4[0], lo), (f16)fmaxf(acc[i][1] + b4[1], lo),
-                           (f16)fmaxf(acc[i][2] + b4[2], lo), (f16)fmaxf(acc[i][3] + b4[3], lo)};
-                *reinterpret_cast<f16x4*>(p.y + m * p.ldy + 4 * g4) = o;
+                    for (int r = 0; r < 4; ++r) {
+                        const bool open = p.bnb_bits ? ((mb >> r) & 1u) != 0u : ((float)yv[r] * msc[r] + msh[r] > 0.f);
+                        const float g = open ? (float)o[r] : 0.f;
+                        s4[r] += g;
+                        q4[r] += g * (float)yv[r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s4[r] += acc[i][r]; q4[r] += acc[i][r] * acc[i][r]; }
             }
+            if (4 * g4 < p.Co) *reinterpret_cast<f16x4*>(p.y + m * p.ldy + 4 * g4) = o;
         }
     }
     if (p.stat_part) {

@@ -163,14 +163,15 @@ def force_w2t(monkeypatch, force_w2):
 
 
 WGRAD2T_CASES = [
-    ((2, 8, 3, 10, 10), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),      # Fast res2 b: BMW 16, K 72 in one 128 tile, 600 rows
+    ((2, 16, 3, 10, 10), 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),    # Fast res3 b: BMW 16, K 144 (two 128-wide tiles), 600 rows
+                                                                             # (the 8-channel res2 b takes sf_stem.h since round 3)
     ((1, 32, 6, 8, 8), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),       # Fast res2 a: temporal taps, K 96
     ((2, 8, 2, 9, 9), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),       # Fast res2 c: BMW 32, K 8 -> 32-wide tile, 3 stages
     ((1, 16, 2, 12, 12), 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),    # BMW 16, K 16 -> 32-wide tile
     ((1, 64, 4, 6, 6), 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),      # K 192: two 128-wide k tiles
     ((1, 16, 2, 11, 11), 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),    # stride 2, Co 24 (BMW 32, ragged), K 144
     ((1, 24, 5, 7, 7), 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),      # 27 taps x 24 channels: taps straddle chunks and tiles
-    ((3, 8, 1, 7, 7), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),        # 147 rows: splits of one ragged stage
+    ((3, 8, 1, 7, 7), 8, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),        # 147 rows: splits of one ragged stage (dilation 2)
 ]
 
 
@@ -184,8 +185,8 @@ def test_wgrad2_thin_is_taken(sim, force_w2t):
     from ctypes import byref
     from slowfast_amd import ops
     from slowfast_amd.lib import get_lib
-    geom = ops.ConvGeom((2, 8, 3, 10, 10), 8, (1, 3, 3), 1, (0, 1, 1))
-    assert get_lib().call("sf_conv_wgrad_rowtab_bytes", byref(geom.desc(8, 8))) > 0
+    geom = ops.ConvGeom((2, 16, 3, 10, 10), 16, (1, 3, 3), 1, (0, 1, 1))
+    assert get_lib().call("sf_conv_wgrad_rowtab_bytes", byref(geom.desc(16, 16))) > 0
 
 
 # ---- thin layers (<= 32 output columns, K <= 128: the Fast pathway's shapes) through the general kernels

@@ -147,6 +147,19 @@ def test_stem_direct(gpu, case):
     kc.check_conv_wgrad(gpu, *case, Cw=8)
 
 
+def test_thin3_direct_convolution(gpu):
+    """8-channel (kT, kH, 3) stride-1 layers on the LDS-patch direct convolution of sf_stem.h (forward, data gradient with the fused
+    BatchNorm-backward sums, weight gradient) at Fast-pathway res2 size and two ragged shapes."""
+    for shp, co, k, p in (((4, 8, 16, 56, 56), 8, (1, 3, 3), (0, 1, 1)), ((2, 8, 5, 30, 30), 16, (1, 3, 3), (0, 1, 1)),
+                          ((2, 8, 6, 14, 14), 8, (3, 3, 3), (1, 1, 1))):
+        kc.check_conv_fwd(gpu, shp, co, k, (1, 1, 1), p)
+        kc.check_conv_wgrad(gpu, shp, co, k, (1, 1, 1), p)
+    for shp, co, k, p in (((4, 8, 16, 56, 56), 8, (1, 3, 3), (0, 1, 1)), ((2, 16, 5, 30, 30), 8, (1, 3, 3), (0, 1, 1)),
+                          ((2, 8, 6, 14, 14), 8, (3, 3, 3), (1, 1, 1))):
+        kc.check_conv_dgrad(gpu, shp, co, k, (1, 1, 1), p)
+        kc.check_conv_dgrad_bn(gpu, shp, co, k, p)
+
+
 def test_wgrad_round1_kernel_shapes(gpu):
     """Two shapes that take the round-1 weight-gradient kernel (K < 192 / few rows): transpose-read fragments vs torch."""
     kc.check_conv_wgrad(gpu, (2, 64, 4, 14, 14), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))
