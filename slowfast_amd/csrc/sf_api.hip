@@ -456,7 +456,7 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf,
             sf_conv_weight_ld(d, &ldf0, &ldd0);
             q.wmat = (const f16*)wf; q.ldw = ldf0; q.y = (f16*)y;
             q.stat_part = stat_part; q.stat_rows = sf_conv_fwd_mtiles(d);
-            static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+            const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;    // read per call: tests switch it on mid-process
             if (trace) fprintf(stderr, "[sfamd] stem_fwd: %d tiles, patch %dx%dx%d chunks\n", sp.ntiles, sp.F, sp.PR, SF_STEM_PC);
             hipLaunchKernelGGL(sf_stem_fwd_kernel, dim3(sp.ntiles), dim3(SF_THREADS), 0, (hipStream_t)stream, q);
             return check_launch("stem_fwd");
@@ -785,7 +785,7 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
                 (long long)workspace_bytes, (long long)sp.ws_bytes);
         StemParams q = stem_params(d, sp, x);
         q.dy = (const f16*)dy; q.ws = (float*)workspace;
-        static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+        const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;    // read per call: tests switch it on mid-process
         if (trace) fprintf(stderr, "[sfamd] stem_wgrad: %d workgroups x %d tiles\n", sp.wg_blocks, sp.tiles_per_block);
         if (d->Co <= 8) hipLaunchKernelGGL((sf_stem_wgrad_kernel<8>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
         else hipLaunchKernelGGL((sf_stem_wgrad_kernel<16>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
