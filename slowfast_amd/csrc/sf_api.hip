@@ -323,9 +323,9 @@ static int run_igemm(IgemmParams& p, bool pw, hipStream_t s, int* bm_used = null
 // ------------------------------------------------------------------------------------------------
 // LDS-patch direct convolution for the thin W-pair-folded stems (sf_stem.h); SF_STEM_GENERIC=1 keeps the implicit GEMM.
 struct StemPlan {
-    bool ok, thin3;
+    bool ok, thin3, small;      // small: the patch fits SF_STEM_CHUNKS_SMALL (12 KiB of LDS instead of 52)
     int tiles_w, tiles_h, tiles_t, ntiles, F, PR;
-    int wg_blocks, tiles_per_block, Kpad;
+    int wg_blocks, tiles_per_block, Kpad, wgroups;
     size_t ws_bytes;
 };
 static StemPlan plan_stem(const sf_conv_desc* d) {
@@ -348,20 +348,28 @@ static StemPlan plan_stem(const sf_conv_desc* d) {
     s.F = (SF_STEM_TT - 1) * d->sT + d->kT;
     s.PR = (SF_STEM_TH - 1) * d->sH + d->kH;
     if ((int64_t)s.F * s.PR * SF_STEM_PC > SF_STEM_CHUNKS) return s;
+    s.small = (int64_t)s.F * s.PR * SF_STEM_PC <= SF_STEM_CHUNKS_SMALL;
     s.tiles_w = cdiv(d->Wo, SF_STEM_TW);
     s.tiles_h = cdiv(d->Ho, SF_STEM_TH);
     s.tiles_t = cdiv(d->To, SF_STEM_TT);
     const int64_t nt = (int64_t)d->N * s.tiles_t * s.tiles_h * s.tiles_w;
     if (nt >= (1ll << 30)) return s;
     s.ntiles = (int)nt;
-    int g = s.ntiles < 512 ? s.ntiles : 512;             // 2 persistent 8-wave workgroups per CU
+    const int gmax = s.small ? 1024 : 512;               // persistent 8-wave workgroups: 2 per CU (52 KiB patches), 4 with small ones
+    int g = s.ntiles < gmax ? s.ntiles : gmax;
     s.tiles_per_block = cdiv(s.ntiles, g);
     s.wg_blocks = cdiv(s.ntiles, s.tiles_per_block);
     s.Kpad = roundup(d->kT * d->kH * 32, 128);
-    s.ws_bytes = (size_t)s.wg_blocks * 16 * s.Kpad * 4;
+    { const int nsl = d->kT * d->kH; s.wgroups = nsl <= 4 ? 8 / nsl : 1; }      // sf_stem_wgrad_kernel: wave groups share a tile's rows
+    s.ws_bytes = (size_t)s.wg_blocks * s.wgroups * 16 * s.Kpad * 4;
     s.ok = true;
     return s;
 }
+#define SF_STEM_FWD_LAUNCH(sp, q, stream)                                                                                          \
+    do {                                                                                                                          \
+        if ((sp).small) hipLaunchKernelGGL(sf_stem_fwd_kernel<SF_STEM_CHUNKS_SMALL>, dim3((sp).ntiles), dim3(SF_THREADS), 0, (hipStream_t)(stream), q); \
+        else hipLaunchKernelGGL(sf_stem_fwd_kernel<SF_STEM_CHUNKS>, dim3((sp).ntiles), dim3(SF_THREADS), 0, (hipStream_t)(stream), q); \
+    } while (0)
 static StemParams stem_params(const sf_conv_desc* d, const StemPlan& s, const void* x) {
     StemParams p;
     memset(&p, 0, sizeof(p));
@@ -377,7 +385,7 @@ static StemParams stem_params(const sf_conv_desc* d, const StemPlan& s, const vo
     p.fd_tw = make_fastdiv(s.tiles_w); p.fd_th = make_fastdiv(s.tiles_h); p.fd_tt = make_fastdiv(s.tiles_t);
     p.F = s.F; p.PR = s.PR;
     p.fd_pc = make_fastdiv(SF_STEM_PC); p.fd_prpc = make_fastdiv(s.PR * SF_STEM_PC);
-    p.Kpad = s.Kpad; p.tiles_per_block = s.tiles_per_block;
+    p.Kpad = s.Kpad; p.tiles_per_block = s.tiles_per_block; p.wgroups = s.wgroups;
     return p;
 }
 
@@ -458,7 +466,7 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf,
             q.stat_part = stat_part; q.stat_rows = sf_conv_fwd_mtiles(d);
             const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;    // read per call: tests switch it on mid-process
             if (trace) fprintf(stderr, "[sfamd] stem_fwd: %d tiles, patch %dx%dx%d chunks\n", sp.ntiles, sp.F, sp.PR, SF_STEM_PC);
-            hipLaunchKernelGGL(sf_stem_fwd_kernel, dim3(sp.ntiles), dim3(SF_THREADS), 0, (hipStream_t)stream, q);
+            SF_STEM_FWD_LAUNCH(sp, q, stream);
             return check_launch("stem_fwd");
         }
     }
@@ -489,7 +497,7 @@ extern "C" int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const voi
             sf_conv_weight_ld(d, &ldf0, &ldd0);
             q.wmat = (const f16*)wf; q.ldw = ldf0; q.y = (f16*)y;
             q.bias = bias; q.out_relu = out_relu;
-            hipLaunchKernelGGL(sf_stem_fwd_kernel, dim3(sp.ntiles), dim3(SF_THREADS), 0, (hipStream_t)stream, q);
+            SF_STEM_FWD_LAUNCH(sp, q, stream);
             return check_launch("stem_fwd_fused");
         }
     }
@@ -549,7 +557,7 @@ static int conv_dgrad_impl(const sf_conv_desc* d, const void* dy, const void* wd
                 q.bnb_bits = (const uint8_t*)bn->bits;
                 q.stat_part = bn->part0; q.stat_rows = 0;
             }
-            hipLaunchKernelGGL(sf_stem_fwd_kernel, dim3(sp.ntiles), dim3(SF_THREADS), 0, (hipStream_t)stream, q);
+            SF_STEM_FWD_LAUNCH(sp, q, stream);
             if (bn_rows) *bn_rows = fuse ? sp.ntiles : 0;
             return check_launch("stem_dgrad");
         }
@@ -787,9 +795,11 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
         q.dy = (const f16*)dy; q.ws = (float*)workspace;
         const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;    // read per call: tests switch it on mid-process
         if (trace) fprintf(stderr, "[sfamd] stem_wgrad: %d workgroups x %d tiles\n", sp.wg_blocks, sp.tiles_per_block);
-        if (d->Co <= 8) hipLaunchKernelGGL((sf_stem_wgrad_kernel<8>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
-        else hipLaunchKernelGGL((sf_stem_wgrad_kernel<16>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
-        splits = sp.wg_blocks; Co_pad = 16; Kpad = sp.Kpad;
+        if (d->Co <= 8 && sp.small) hipLaunchKernelGGL((sf_stem_wgrad_kernel<8, SF_STEM_CHUNKS_SMALL>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
+        else if (d->Co <= 8) hipLaunchKernelGGL((sf_stem_wgrad_kernel<8, SF_STEM_CHUNKS>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
+        else if (sp.small) hipLaunchKernelGGL((sf_stem_wgrad_kernel<16, SF_STEM_CHUNKS_SMALL>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
+        else hipLaunchKernelGGL((sf_stem_wgrad_kernel<16, SF_STEM_CHUNKS>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
+        splits = sp.wg_blocks * sp.wgroups; Co_pad = 16; Kpad = sp.Kpad;
     } else {
         const WgradPlan w = plan_wgrad(d);
         REQUIRE(workspace_bytes >= (int64_t)w.ws_bytes, "sf_conv_wgrad: workspace too small (%lld < %lld bytes)",

@@ -28,7 +28,9 @@
 #define SF_STEM_TH 8
 #define SF_STEM_TW 16
 #define SF_STEM_PC (SF_STEM_TW + 3)
-#define SF_STEM_CHUNKS 3328          // 16-byte chunks of LDS for the patch (52 KiB)
+#define SF_STEM_CHUNKS 3328          // 16-byte chunks of LDS for the patch (52 KiB): the stems
+#define SF_STEM_CHUNKS_SMALL 768     // 12 KiB: patches of the 8-channel (1, 3, 3) layers (4 x 10 x 19 chunks) -- the 52 KiB
+                                     // allocation held them at three workgroups per CU, and they are latency-bound
 #define SF_STEM_WG_THREADS 512
 #define SF_STEM_MAX_SLICES 40        // kT * kH
 
@@ -57,6 +59,7 @@ struct StemParams {
     const f16* dy;
     float* ws; int Kpad;              // per-workgroup slab [16][Kpad] fp32
     int tiles_per_block;
+    int wgroups;                      // > 1 (few slices): wave w works on slice w % nsl for the tile rows of group w / nsl; one slab per group
 };
 
 struct StemTile { int n, t0, h0, w0; };
@@ -73,9 +76,9 @@ __device__ __forceinline__ StemTile stem_tile(const StemParams& p, uint32_t tile
 }
 
 // stage the input patch of one tile: chunk (f, r, c) <- x[n][t0*sT - pT + f][h0*sH - pH + r][w0 - pW + c], zeros outside
-template <int NTHREADS>
+template <int NTHREADS, int U>      // U: 16-byte loads in flight per thread (the Fast stem's patch is 12.5 / 6.2 per thread -> 7; a
+                                     // 768-chunk patch is 3 / 1.5 per thread)
 __device__ __forceinline__ void stem_load_patch(const StemParams& p, f16* patch, const StemTile& t, int tid) {
-    constexpr int U = 7;               // 16-byte loads in flight per thread (the Fast stem's patch is 12.5 / 6.2 per thread)
     const int nch = p.F * p.PR * SF_STEM_PC;
     const int tin0 = t.t0 * p.sT - p.pT, hin0 = t.h0 * p.sH - p.pH, win0 = t.w0 - p.pW;
     for (int base = 0; base < nch; base += NTHREADS * U) {
@@ -104,14 +107,15 @@ __device__ __forceinline__ void stem_load_patch(const StemParams& p, f16* patch,
 
 // ---------------------------------------------------------------------------------------------
 // forward: wave w owns output frame t0 + w of the tile (8 rows x 16 pixels = 8 MFMA column tiles)
+template <int PCH>
 __global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_kernel(StemParams p) {
-    __shared__ __attribute__((aligned(16))) f16 patch[SF_STEM_CHUNKS * 8];
+    __shared__ __attribute__((aligned(16))) f16 patch[PCH * 8];
     __shared__ float s_red[4][2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g4 = lane >> 4;
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const StemTile t = stem_tile(p, bid);
-    stem_load_patch<SF_THREADS>(p, patch, t, tid);
+    stem_load_patch<SF_THREADS, (PCH <= SF_STEM_CHUNKS_SMALL ? 3 : 7)>(p, patch, t, tid);
 
     f32x4 acc[SF_STEM_TH];
 #pragma unroll
@@ -206,16 +210,20 @@ __global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_kernel(StemParams p) {
 // ---------------------------------------------------------------------------------------------
 // weight gradient: persistent workgroups (8 waves) over a contiguous range of tiles; wave w accumulates the
 // K-slices s = w, w+8, ... (s = kt*kH + kh, 32 weights each, two 16-column MFMA tiles) for all 16 channel rows.
-template <int COP>
+template <int COP, int PCH>
 __global__ __launch_bounds__(SF_STEM_WG_THREADS, 4) void sf_stem_wgrad_kernel(StemParams p) {
     constexpr int NW = SF_STEM_WG_THREADS / 64;
     constexpr int NQ = SF_STEM_MAX_SLICES / NW;
     constexpr int NPIX = SF_STEM_TT * SF_STEM_TH * SF_STEM_TW;
-    __shared__ __attribute__((aligned(16))) f16 patch[SF_STEM_CHUNKS * 8];
+    __shared__ __attribute__((aligned(16))) f16 patch[PCH * 8];
     __shared__ __attribute__((aligned(16))) f16 dyt[NPIX * COP + 8];     // + 8 zeros: the channel chunks beyond COP
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g4 = lane >> 4;
     const int nsl = p.kT * p.kH;
+    // few slices (the 8-channel 3x3 layers have 3): instead of idling five waves, `wgroups` groups of nsl waves share the rows
+    const int ng = p.wgroups > 1 ? p.wgroups : 1;
+    const int grp = ng > 1 ? wave / nsl : 0, sw = ng > 1 ? wave - grp * nsl : wave;
+    const bool wactive = grp < ng;
 
     f32x4 acc[NQ][2];
     int koff[NQ];
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(SF_STEM_WG_THREADS, 4) void sf_stem_wgrad_kernel(St
     for (int q = 0; q < NQ; ++q) {
         acc[q][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int s = wave + NW * q;
+        const int s = sw + NW * q;
         const int kt = s / p.kH, kh = s - kt * p.kH;
         koff[q] = (kt * p.PR + kh) * SF_STEM_PC;
     }
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(SF_STEM_WG_THREADS, 4) void sf_stem_wgrad_kernel(St
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const StemTile t = stem_tile(p, (uint32_t)tile);
         __syncthreads();
-        stem_load_patch<SF_STEM_WG_THREADS>(p, patch, t, tid);
+        stem_load_patch<SF_STEM_WG_THREADS, (PCH <= SF_STEM_CHUNKS_SMALL ? 2 : 7)>(p, patch, t, tid);
         for (int idx = tid; idx < NPIX * (COP / 8); idx += SF_STEM_WG_THREADS) {
             const int pix = idx / (COP / 8), cg = idx % (COP / 8);
             const int w = pix % SF_STEM_TW, hh = (pix / SF_STEM_TW) % SF_STEM_TH, tt = pix / (SF_STEM_TW * SF_STEM_TH);
@@ -258,8 +266,8 @@ __global__ __launch_bounds__(SF_STEM_WG_THREADS, 4) void sf_stem_wgrad_kernel(St
         }
         __syncthreads();
 #pragma unroll 1
-        for (int tc = 0; tc < SF_STEM_TT * (SF_STEM_TH / 2); ++tc) {
-            {
+        for (int tc = grp; tc < SF_STEM_TT * (SF_STEM_TH / 2); tc += ng) {
+            if (wactive) {
                 const int tt = tc / (SF_STEM_TH / 2), c = tc % (SF_STEM_TH / 2);
                 f16x8 af;
                 int xoff[2];
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(SF_STEM_WG_THREADS, 4) void sf_stem_wgrad_kernel(St
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    if (wave + NW * q < nsl) {
+                    if (sw + NW * q < nsl) {
 #pragma unroll
                         for (int jh = 0; jh < 2; ++jh) {
                             f16x8 bf;
@@ -291,11 +299,11 @@ __global__ __launch_bounds__(SF_STEM_WG_THREADS, 4) void sf_stem_wgrad_kernel(St
         }
     }
     // slab[co][k]: co = 4*g4 + r, k = s*32 + 16*jh + pl
-    float* slab = p.ws + (int64_t)blockIdx.x * 16 * p.Kpad;
+    float* slab = p.ws + ((int64_t)blockIdx.x * ng + grp) * 16 * p.Kpad;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int s = wave + NW * q;
-        if (s < nsl) {
+        const int s = sw + NW * q;
+        if (wactive && s < nsl) {
 #pragma unroll
             for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
