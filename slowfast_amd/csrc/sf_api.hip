@@ -365,10 +365,18 @@ static StemPlan plan_stem(const sf_conv_desc* d) {
     s.ok = true;
     return s;
 }
+// patch-row-major variants for the two shapes that matter (row stride / kernel height compile-time), generic loop otherwise;
+// SF_STEM_ROWMAJOR=0 keeps the generic loop for A/B runs
 #define SF_STEM_FWD_LAUNCH(sp, q, stream)                                                                                          \
     do {                                                                                                                          \
-        if ((sp).small) hipLaunchKernelGGL(sf_stem_fwd_kernel<SF_STEM_CHUNKS_SMALL>, dim3((sp).ntiles), dim3(SF_THREADS), 0, (hipStream_t)(stream), q); \
-        else hipLaunchKernelGGL(sf_stem_fwd_kernel<SF_STEM_CHUNKS>, dim3((sp).ntiles), dim3(SF_THREADS), 0, (hipStream_t)(stream), q); \
+        static const bool rm_ = !(getenv("SF_STEM_ROWMAJOR") && atoi(getenv("SF_STEM_ROWMAJOR")) == 0);                           \
+        const dim3 g_((sp).ntiles), b_(SF_THREADS);                                                                               \
+        if (rm_ && (q).sH == 2 && (q).kH == 7 && !(sp).small)                                                                     \
+            hipLaunchKernelGGL((sf_stem_fwd_kernel<SF_STEM_CHUNKS, 2, 7>), g_, b_, 0, (hipStream_t)(stream), q);                  \
+        else if (rm_ && (q).sH == 1 && (q).kH == 3 && (sp).small)                                                                 \
+            hipLaunchKernelGGL((sf_stem_fwd_kernel<SF_STEM_CHUNKS_SMALL, 1, 3>), g_, b_, 0, (hipStream_t)(stream), q);            \
+        else if ((sp).small) hipLaunchKernelGGL((sf_stem_fwd_kernel<SF_STEM_CHUNKS_SMALL>), g_, b_, 0, (hipStream_t)(stream), q); \
+        else hipLaunchKernelGGL((sf_stem_fwd_kernel<SF_STEM_CHUNKS>), g_, b_, 0, (hipStream_t)(stream), q);                       \
     } while (0)
 static StemParams stem_params(const sf_conv_desc* d, const StemPlan& s, const void* x) {
     StemParams p;
