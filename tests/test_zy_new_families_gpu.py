@@ -1,6 +1,6 @@
 """GPU (-m gpu): option families written after the round-1 GPU budget ended -- green on the host simulator against goldens
 pinned to the reference, not yet run on hardware.  The file sorts after every hardware-validated test file and before the
-opt-in kernels (tests/test_zz_optin_gpu.py), so that with ``pytest -x`` a failure here hides nothing that was green before."""
+shape sweeps (tests/test_zz_dwconv_shapes_gpu.py), so that with ``pytest -x`` a failure here hides nothing that was green before."""
 import pytest
 
 pytestmark = pytest.mark.gpu
