@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 19
+#define SF_ABI_VERSION 20
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -47,6 +47,10 @@ const char* sf_backend(void);     /* "gfx950" (product) or "hostsim" (CPU test b
 #define SF_ACT_BF16_ID 1
 int sf_act_dtype(void);
 const char* sf_last_error(void); /* host string, thread-local */
+/* Build provenance: the first 16 hex digits of the sha256 over the kernel sources and this header the binary was compiled
+ * from (slowfast_amd/build_ext.py:source_id passes it as -DSF_BUILD_ID).  The Python binding recomputes it from the sources
+ * beside the binary and refuses a library built from anything else. */
+const char* sf_build_id(void);
 
 /* ---- Conv3d -- replaces nn.Conv3d at resnet_helper.py:331-369 (BottleneckTransform a/b/c),
  * resnet_helper.py:485-493 (ResBlock.branch1), stem_helper.py:182-189 (ResNetBasicStem.conv),
@@ -193,6 +197,20 @@ int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const 
  * affinity (nonlocal_helper.py:130-132). */
 /* resid_row0: the residual is added to rows m >= resid_row0 only (residual pooling skips the cls row,
  * attention.py:381-385).  N need not be a multiple of 8 when ldy covers N rounded up to 8 (pad columns <- 0). */
+/* fp32 side rows of a token residual stream (round 4).  MultiScaleBlock adds two branch outputs per block to the stream
+ * (attention.py:500-510: x = x_res + drop_path(x_block); x = x + drop_path(x_mlp)); the reference keeps that stream in fp32
+ * (autocast leaves additions alone).  Rows m with m % period == 0 (period = tokens per sample: the class-token rows; period 1:
+ * every row) carry an fp32 copy at side row m / period, pitch ld floats.  `in`: residual operand rows (NULL: the 16-bit
+ * residual operand is used for them too), `out`: the sums.  The 16-bit output row is round(out row). */
+typedef struct sf_rows32 {
+    const float* in;
+    float* out;
+    int32_t ld, period;
+} sf_rows32;
+/* nn.Linear forward with the residual addition of the stream in its epilogue: Y = A W^T + bias + resid, side rows summed from
+ * the fp32 accumulators (attention.py:393 proj, common.py:31 fc2 followed by attention.py:502 / :510). */
+int sf_gemm_rows32(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias,
+                   const void* resid, int32_t ldr, void* Y, int32_t ldy, const sf_rows32* side, sf_stream_t stream);
 /* Batched "TN" GEMM  Out[z][r][c] = scale * sum_m P[z][m][r] * X[z][m][c]  (fp16 out): the attention gradients
  * dV = P^T dO and dK = dS^T q (autograd of attention.py:355,379). */
 int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int32_t ldp, const void* X, int32_t ldx, void* Out,
@@ -202,6 +220,9 @@ int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int32_t ldp, co
 /* nn.LayerNorm(C, eps) over the last dim (attention.py:240-268, 428, 456; video_model_builder.py:1032) */
 int sf_layernorm_fwd(int64_t M, int32_t C, const void* x, int32_t ldx, const float* gamma, const float* beta, float eps,
                      void* y, int32_t ldy, float* mean, float* rstd, sf_stream_t stream);
+/* same; rows that have an fp32 side copy (side->in) are normalised from it (norm1 / norm2 / the final norm reading the stream) */
+int sf_layernorm_fwd_rows32(int64_t M, int32_t C, const void* x, int32_t ldx, const float* gamma, const float* beta, float eps,
+                            void* y, int32_t ldy, float* mean, float* rstd, const sf_rows32* side, sf_stream_t stream);
 int sf_layernorm_bwd_blocks(int64_t M, int32_t C);   /* rows of `part` */
 /* dx = LN backward (+ resid); part[blk][0][c] = sum dy*xhat, part[blk][1][c] = sum dy -> sf_colsum_finalize */
 int sf_layernorm_bwd(int64_t M, int32_t C, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* gamma,
@@ -325,6 +346,9 @@ int sf_pack_clip_u8(const void* frames, int32_t N, int32_t Tin, int32_t H, int32
  * scale[b] = floor(keep_prob + u_b) / keep_prob sampled by the caller.  Rows are fp16 [M][C], C % 8 == 0. */
 int sf_row_scale_add(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,
                      int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C, sf_stream_t stream);
+/* same with fp32 side rows of the stream (sf_rows32 above): side rows read side->in (or resid), write side->out */
+int sf_row_scale_add_rows32(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,
+                            int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C, const sf_rows32* side, sf_stream_t stream);
 /* xt[b][head][c][k] = x[b][k][head*D + c], zero for k in [Nk, ldk): K-contiguous operand for P.V and dS.K */
 int sf_transpose_heads(const void* x, int32_t ldx, void* xt, int32_t ldk, int32_t B, int32_t Nk, int32_t heads, int32_t D,
                        sf_stream_t stream);

@@ -18,6 +18,30 @@ def _store(x):
     return _vr._STORE(x)
 
 
+# Storage-model policy of the RESIDUAL STREAM (tools/mvit_logits_bisect.py, tests/model_checks.py): None = the two residual
+# sums of every block are stored like any other tensor; otherwise a callable (x [B, N, C], block index, which in {0, 1}) ->
+# stored x, so a test can model an engine that keeps part of the stream (the class-token row, the last stage) in fp32.
+RESID_POLICY = None
+
+
+def _store_resid(x, prefix, which):
+    if RESID_POLICY is None or _vr._STORE is _vr._ident:
+        return _store(x)
+    return RESID_POLICY(x, int(prefix.split(".")[1]), which)
+
+
+def engine_resid_policy(cls_fp32=True, fp32_from_block=14):
+    """The residual-stream storage of slowfast_amd.mvit_engine (round 4): the class-token row of both residual sums of every
+    block stays fp32 (a [B, C] side buffer), and blocks >= ``fp32_from_block`` keep the whole stream in fp32."""
+    def policy(x, i, which):
+        if i >= fp32_from_block:
+            return x
+        if cls_fp32:
+            return torch.cat([x[:, :1], _store(x[:, 1:])], 1)
+        return _store(x)
+    return policy
+
+
 def _linear(x, sd, prefix):
     return _store(F.linear(x, _store(sd[prefix + ".weight"]), sd.get(prefix + ".bias")))
 
@@ -162,7 +186,7 @@ def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, drop=Non
         x_res = x
     if drop is not None:
         x_block = _store(x_block) * drop[0].view(-1, 1, 1)
-    x = _store(x_res + x_block)
+    x = _store_resid(x_res + x_block, prefix, 0)
     x_norm = _ln(x, sd, prefix + ".norm2")
     h = _linear(x_norm, sd, prefix + ".mlp.fc1")
     h = _store(F.gelu(h))
@@ -171,7 +195,7 @@ def block(x, sd, prefix, thw, heads, stride_q, stride_kv, has_cls=True, drop=Non
         x = _linear(x_norm, sd, prefix + ".proj")
     if drop is not None:
         x_mlp = _store(x_mlp) * drop[1].view(-1, 1, 1)
-    return _store(x + x_mlp), thw_new
+    return _store_resid(x + x_mlp, prefix, 1), thw_new
 
 
 def _mlp(x, sd, prefix):

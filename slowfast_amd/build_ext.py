@@ -18,16 +18,40 @@ SIM_LIB_BF16 = os.path.join(ROOT, "tests", "hostsim", "libsfamd_sim_bf16.so")
 
 
 def _sources():
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
     deps.append(os.path.join(ROOT, "include", "sfamd.h"))
     return deps
 
 
+def source_id():
+    """sha256 (first 16 hex digits) over the kernel sources, the C header and the host simulator's HIP shim, in name order:
+    compiled into every build as sf_build_id() and recomputed by lib.SfLibrary from the files shipped beside the binary."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_sources() + [os.path.join(ROOT, "tests", "hostsim", "include", "hip", "hip_runtime.h")]):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode() + b"\0")
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _built_id(target):
+    """Build id embedded in a binary ('' when it has none / cannot be read) without loading it into this process."""
+    try:
+        with open(target, "rb") as fh:
+            blob = fh.read()
+    except OSError:
+        return ""
+    tag = b"sfamd-build-id:"
+    i = blob.find(tag)
+    return blob[i + len(tag):i + len(tag) + 16].decode("ascii", "replace") if i >= 0 else ""
+
+
 def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    """A binary is current when it carries the hash of today's sources (mtimes are not trusted: a checkout or a copy to the
+    GPU box resets them)."""
+    return not os.path.exists(target) or _built_id(target) != source_id()
 
 
 def build_hip(force=False, verbose=False, act="fp16"):
@@ -37,7 +61,8 @@ def build_hip(force=False, verbose=False, act="fp16"):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
-           "-Wno-comment", "-I" + os.path.join(ROOT, "include")] + (["-DSF_ACT_BF16"] if act == "bf16" else []) + [SRC, "-o", out]
+           "-Wno-comment", "-I" + os.path.join(ROOT, "include"), '-DSF_BUILD_ID="%s"' % source_id()] + \
+          (["-DSF_ACT_BF16"] if act == "bf16" else []) + [SRC, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -51,7 +76,8 @@ def build_hostsim(force=False, verbose=False, act="fp16"):
         return out
     cxx = os.environ.get("SF_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
     cmd = [cxx, "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-shared", "-Wno-unknown-attributes", "-Wno-comment",
-           "-I" + os.path.join(ROOT, "tests", "hostsim", "include"), "-I" + os.path.join(ROOT, "include")] + \
+           "-I" + os.path.join(ROOT, "tests", "hostsim", "include"), "-I" + os.path.join(ROOT, "include"),
+           '-DSF_BUILD_ID="%s"' % source_id()] + \
           (["-DSF_ACT_BF16"] if act == "bf16" else []) + [SRC, "-o", out, "-lpthread"]
     if verbose:
         print(" ".join(cmd))

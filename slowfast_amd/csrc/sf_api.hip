@@ -50,6 +50,15 @@ extern "C" const char* sf_backend(void) {
 }
 extern "C" int sf_act_dtype(void) { return SF_ACT_DTYPE_ID; }
 extern "C" const char* sf_last_error(void) { return g_err; }
+// hash of the sources this binary was compiled from (slowfast_amd/build_ext.py passes it; lib.SfLibrary compares it with the
+// sources shipped beside the binary and refuses a stale one)
+#ifndef SF_BUILD_ID
+#define SF_BUILD_ID "unversioned"
+#endif
+extern "C" const char* sf_build_id(void) {
+    static const char tagged[] = "sfamd-build-id:" SF_BUILD_ID;
+    return tagged + 15;
+}
 
 static int check_desc(const sf_conv_desc* d) {
     REQUIRE(d != nullptr, "conv: null descriptor");
@@ -200,6 +209,7 @@ static void igemm2_common(Igemm2Params& q, const IgemmParams& p) {
     q.resid_bits = p.resid_bits;
     q.bnb_y = p.bnb_y; q.bnb_ld = p.bnb_ld; q.bnb_scale = p.bnb_scale; q.bnb_shift = p.bnb_shift; q.bnb_part = p.bnb_part;
     q.bnb_bits = p.bnb_bits;
+    q.f32 = p.f32;
 }
 static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     // read on every call (three getenv per launch are noise): tests lower the thresholds for single cases
@@ -1086,10 +1096,23 @@ static GatherSide gather_matrix(const void* a, int64_t M, int32_t K, int32_t lda
     return g;
 }
 
-extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
-                        const float* bias, const void* resid, int32_t ldr, void* Y, int32_t ldy, int32_t nbatch,
-                        int32_t bh, int64_t sa_b, int64_t sa_h, int64_t sw_b, int64_t sw_h, int64_t sy_b, int64_t sy_h,
-                        int64_t sr_b, int64_t sr_h, int32_t resid_row0, float alpha, sf_stream_t stream) {
+// sf_rows32 -> the kernels' F32Rows (need_out: the entry point writes side rows; otherwise it only reads them)
+static int rows32_arg(const char* who, const sf_rows32* side, int64_t M, int32_t C, bool need_out, F32Rows& f) {
+    memset(&f, 0, sizeof(f));
+    if (!side) return 0;
+    REQUIRE(side->period >= 1 && side->ld >= C && side->ld % 4 == 0, "%s: bad side rows (period %d, ld %d, C %d)", who,
+            side->period, side->ld, C);
+    REQUIRE(need_out ? side->out != nullptr : side->in != nullptr, "%s: side rows without a buffer", who);
+    REQUIRE(((uintptr_t)side->in | (uintptr_t)side->out) % 16 == 0, "%s: side rows need 16-byte bases", who);
+    f.in = side->in; f.out = side->out; f.ld = side->ld; f.fd = make_fastdiv((uint32_t)side->period);
+    (void)M;
+    return 0;
+}
+
+static int bgemm_impl(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
+                      const float* bias, const void* resid, int32_t ldr, void* Y, int32_t ldy, int32_t nbatch,
+                      int32_t bh, int64_t sa_b, int64_t sa_h, int64_t sw_b, int64_t sw_h, int64_t sy_b, int64_t sy_h,
+                      int64_t sr_b, int64_t sr_h, int32_t resid_row0, float alpha, const sf_rows32* side, sf_stream_t stream) {
     REQUIRE(A && W && Y, "sf_bgemm: null pointer");
     REQUIRE(M > 0 && M < (1ll << 31) && N > 0 && K > 0, "sf_bgemm: bad shape");
     // rows of Y are written in 16-byte groups: the pitch must cover N rounded up to 8 (the pad columns get zeros)
@@ -1107,6 +1130,10 @@ extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t 
     p.y = (f16*)Y; p.ldy = ldy; p.bias = bias; p.resid = (const f16*)resid; p.ldr = ldr;
     p.bh = bh; p.sa_b = sa_b; p.sa_h = sa_h; p.sw_b = sw_b; p.sw_h = sw_h; p.sy_b = sy_b; p.sy_h = sy_h;
     p.sr_b = sr_b; p.sr_h = sr_h; p.resid_row0 = resid_row0; p.alpha = alpha;
+    if (side) {
+        REQUIRE(nbatch == 1 && N % 8 == 0, "sf_gemm_rows32: one GEMM, N %% 8 == 0");
+        if (rows32_arg("sf_gemm_rows32", side, M, N, true, p.f32)) return -1;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (try_igemm2(p, s, nbatch)) return check_launch("bgemm2");
     if (N > 64) { p.ntiles_n = cdiv(N, 128); launch_igemm<128, 64, 64>(p, true, s, nbatch); }
@@ -1114,6 +1141,21 @@ extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t 
     else if (N > 16) { p.ntiles_n = 1; launch_igemm<32, 32, 32>(p, true, s, nbatch); }
     else { p.ntiles_n = 1; launch_igemm<16, 32, 16>(p, true, s, nbatch); }
     return check_launch("bgemm");
+}
+
+extern "C" int sf_bgemm(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
+                        const float* bias, const void* resid, int32_t ldr, void* Y, int32_t ldy, int32_t nbatch,
+                        int32_t bh, int64_t sa_b, int64_t sa_h, int64_t sw_b, int64_t sw_h, int64_t sy_b, int64_t sy_h,
+                        int64_t sr_b, int64_t sr_h, int32_t resid_row0, float alpha, sf_stream_t stream) {
+    return bgemm_impl(M, N, K, A, lda, W, ldw, bias, resid, ldr, Y, ldy, nbatch, bh, sa_b, sa_h, sw_b, sw_h, sy_b, sy_h, sr_b,
+                      sr_h, resid_row0, alpha, nullptr, stream);
+}
+
+extern "C" int sf_gemm_rows32(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
+                              const float* bias, const void* resid, int32_t ldr, void* Y, int32_t ldy,
+                              const sf_rows32* side, sf_stream_t stream) {
+    REQUIRE(side, "sf_gemm_rows32: null side rows");
+    return bgemm_impl(M, N, K, A, lda, W, ldw, bias, resid, ldr, Y, ldy, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.f, side, stream);
 }
 
 static int gemm_act_impl(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw,
@@ -1201,20 +1243,32 @@ static int check_ln(const char* who, int64_t M, int C) {
     REQUIRE(C > 0 && C % 8 == 0 && C <= 1024, "%s: C must be a multiple of 8, <= 1024 (got %d)", who, C);
     return 0;
 }
-extern "C" int sf_layernorm_fwd(int64_t M, int32_t C, const void* x, int32_t ldx, const float* gamma, const float* beta,
-                                float eps, void* y, int32_t ldy, float* mean, float* rstd, sf_stream_t stream) {
+static int layernorm_fwd_impl(int64_t M, int32_t C, const void* x, int32_t ldx, const float* gamma, const float* beta,
+                              float eps, void* y, int32_t ldy, float* mean, float* rstd, const sf_rows32* side,
+                              sf_stream_t stream) {
     if (check_ln("sf_layernorm_fwd", M, C)) return -1;
     REQUIRE(x && gamma && beta && y, "sf_layernorm_fwd: null pointer");
     LnParams p;
     memset(&p, 0, sizeof(p));
     p.M = (int)M; p.C = C; p.x = (const f16*)x; p.ldx = ldx; p.gamma = gamma; p.beta = beta; p.eps = eps;
     p.y = (f16*)y; p.ldy = ldy; p.mean = mean; p.rstd = rstd;
+    if (rows32_arg("sf_layernorm_fwd_rows32", side, M, C, false, p.f32)) return -1;
     hipStream_t s = (hipStream_t)stream;
     if (C <= 128) launch_ln_fwd<16, 1>(p, s);
     else if (C <= 256) launch_ln_fwd<32, 1>(p, s);
     else if (C <= 512) launch_ln_fwd<64, 1>(p, s);
     else launch_ln_fwd<64, 2>(p, s);
     return check_launch("layernorm_fwd");
+}
+extern "C" int sf_layernorm_fwd(int64_t M, int32_t C, const void* x, int32_t ldx, const float* gamma, const float* beta,
+                                float eps, void* y, int32_t ldy, float* mean, float* rstd, sf_stream_t stream) {
+    return layernorm_fwd_impl(M, C, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, nullptr, stream);
+}
+extern "C" int sf_layernorm_fwd_rows32(int64_t M, int32_t C, const void* x, int32_t ldx, const float* gamma,
+                                       const float* beta, float eps, void* y, int32_t ldy, float* mean, float* rstd,
+                                       const sf_rows32* side, sf_stream_t stream) {
+    REQUIRE(side, "sf_layernorm_fwd_rows32: null side rows");
+    return layernorm_fwd_impl(M, C, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, side, stream);
 }
 static int ln_bwd_plan(int64_t M, int C, int& rows_per_block) {
     const int rpb = SF_THREADS / ln_lanes(C);
@@ -1756,8 +1810,9 @@ extern "C" int sf_pack_clip_u8(const void* frames, int32_t N, int32_t Tin, int32
     return check_launch("pack_clip_u8");
 }
 
-extern "C" int sf_row_scale_add(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,
-                                int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C, sf_stream_t stream) {
+static int row_scale_add_impl(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,
+                              int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C, const sf_rows32* side,
+                              sf_stream_t stream) {
     REQUIRE(x && scale && y, "sf_row_scale_add: null pointer");
     if (check_rows("sf_row_scale_add", M, C)) return -1;
     REQUIRE(rows_per_sample > 0 && rows_per_sample < (1ll << 31), "sf_row_scale_add: bad rows_per_sample");
@@ -1765,11 +1820,22 @@ extern "C" int sf_row_scale_add(const void* x, int32_t ldx, const float* scale, 
     RowScaleParams p;
     p.x = (const f16*)x; p.ldx = ldx; p.scale = scale; p.resid = (const f16*)resid; p.ldr = ldr;
     p.y = (f16*)y; p.ldy = ldy;
+    if (rows32_arg("sf_row_scale_add_rows32", side, M, C, true, p.f32)) return -1;
     p.total = M * (C / 8);
     REQUIRE(p.total < (1ll << 31), "sf_row_scale_add: too many elements");
     p.fdG = make_fastdiv(C / 8); p.fdRows = make_fastdiv((uint32_t)rows_per_sample);
     hipLaunchKernelGGL(sf_row_scale_add_kernel, dim3(pool_grid(p.total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("row_scale_add");
+}
+extern "C" int sf_row_scale_add(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample, const void* resid,
+                                int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C, sf_stream_t stream) {
+    return row_scale_add_impl(x, ldx, scale, rows_per_sample, resid, ldr, y, ldy, M, C, nullptr, stream);
+}
+extern "C" int sf_row_scale_add_rows32(const void* x, int32_t ldx, const float* scale, int64_t rows_per_sample,
+                                       const void* resid, int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C,
+                                       const sf_rows32* side, sf_stream_t stream) {
+    REQUIRE(side, "sf_row_scale_add_rows32: null side rows");
+    return row_scale_add_impl(x, ldx, scale, rows_per_sample, resid, ldr, y, ldy, M, C, side, stream);
 }
 
 extern "C" int sf_transpose_heads(const void* x, int32_t ldx, void* xt, int32_t ldk, int32_t B, int32_t Nk, int32_t heads,

@@ -162,6 +162,52 @@ __device__ __forceinline__ void fd_divmod(uint32_t x, const FastDiv& f, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp32 side rows of a token residual stream (MultiScaleBlock's residual sums, attention.py:500-510):
+// rows m with m % period == 0 (period 1: every row) carry an fp32 copy at side row m / period, pitch ld floats.  The
+// class-token row of MViT is the only row the classifier reads, and 32 fp16 roundings of it (two residual sums per block) were
+// the largest single term of the logits' deviation from the fp32 reference (profiles/r3_mvit_logits_bisect.md).
+struct F32Rows {
+    const float* in;    // optional residual operand rows (nullptr: the kernel's 16-bit residual operand is used)
+    float* out;         // result rows; nullptr = feature off
+    int ld;
+    FastDiv fd;         // period
+};
+// (is row m a side row, its side-row index)
+__device__ __forceinline__ bool f32_row(const F32Rows& f, int m, uint32_t& s) {
+    uint32_t rem;
+    fd_divmod((uint32_t)m, f.fd, s, rem);
+    return rem == 0u;
+}
+
+// Side rows of a GEMM tile, taken from the fp32 accumulators BEFORE the 16-bit staging of the epilogue: out = acc (+ bias,
+// already applied) + residual (fp32 side rows when given, else the 16-bit residual operand); the accumulator is replaced by the
+// sum, so the 16-bit row the store loop writes is round(out) and the loop must not add the residual again on these rows.
+template <int TM, int TN>
+__device__ __forceinline__ void f32_rows_epilogue(f32x4 (&acc)[TM][TN], const F32Rows& f, int row0, int col0, int M, int Nout,
+                                                  const f16* resid, int ldr, int resid_row0) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = row0 + i * 16 + 4 * (lane >> 4) + r;
+            uint32_t s;
+            if (m >= M || !f32_row(f, m, s)) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = col0 + j * 16 + (lane & 15);
+                if (col >= Nout) continue;
+                float rr = 0.f;
+                if (f.in) rr = f.in[(int64_t)s * f.ld + col];
+                else if (resid && m >= resid_row0) rr = (float)resid[(int64_t)m * ldr + col];
+                const float o = acc[i][j][r] + rr;
+                f.out[(int64_t)s * f.ld + col] = o;
+                acc[i][j][r] = o;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // XCD-aware workgroup order.  Workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md); each XCD
 // has its own L2.  Remapping the linear id so that every XCD walks a CONTIGUOUS range of tiles keeps the tiles that
 // share an operand panel (same rows, neighbouring columns / same split) behind one L2 instead of eight.  Bijective for

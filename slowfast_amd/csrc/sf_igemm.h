@@ -47,6 +47,7 @@ struct IgemmParams {
     const float* bnb_scale; const float* bnb_shift;
     float* bnb_part;
     const uint8_t* bnb_bits;        // optional [rows][Nout/8] bit mask replacing the recomputed one (block-output ReLU)
+    F32Rows f32;                    // fp32 side rows of the output (token residual sums; sf_common.h), f32.out == nullptr: off
 };
 
 // g = dz masked by the producer's ReLU (same expression as masked_grad8 / sf_bn_bwd_apply use), accumulated per channel.
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha + b;
         }
     }
+    if (p.f32.out) f32_rows_epilogue<TM, TN>(acc, p.f32, m0 + wm * WM, n0 + wn * WN, p.M, p.Nout, resid, p.ldr, p.resid_row0);
     if (p.stat_part) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -393,6 +395,8 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
             const int row = idx / CG, m = m0 + row;
             ok[u] = idx < BM * CG && m < p.M && ecol < p.Nout;
             rok[u] = ok[u] && resid && m >= p.resid_row0;
+            uint32_t srow;
+            if (p.f32.out && f32_row(p.f32, m, srow)) rok[u] = false;      // residual already inside the staged value
             L[u].rbits = 0xffu; L[u].bbits = 0u;
             if (rok[u]) {
                 L[u].r = ld16(resid + (int64_t)m * p.ldr + ecol);

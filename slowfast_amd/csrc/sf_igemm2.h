@@ -73,6 +73,7 @@ struct Igemm2Params {
     // DIAGNOSTIC (SF_IGEMM2_ABLATE, tools/microbench.py only; results are garbage): bit 0 no copies inside the K loop, bit 1 no
     // LDS reads / MFMAs, bit 2 LDS reads but no MFMAs, bit 3 return before the epilogue, bit 4 no barrier inside the K loop
     int ablate;
+    F32Rows f32;        // fp32 side rows of the output (token residual sums; sf_common.h), f32.out == nullptr: off
 };
 
 // LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha + b;
         }
     }
+    if (p.f32.out) f32_rows_epilogue<TM, TN>(acc, p.f32, m0 + wm * WM, n0 + wn * WN, p.M, p.Nout, p.resid, p.ldr, p.resid_row0);
     if (p.stat_part) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -334,6 +336,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
             const int m = ok[u] ? (p.omap ? s_orow[row] : mr) : 0;
             mo[u] = m;
             rok[u] = ok[u] && p.resid && m >= p.resid_row0;
+            uint32_t srow;
+            if (p.f32.out && f32_row(p.f32, m, srow)) rok[u] = false;      // residual already inside the staged value
             L[u].rbits = 0xffu; L[u].bbits = 0u;
             if (rok[u]) {
                 L[u].r = ld16(p.resid + (int64_t)m * p.ldr + ecol);

@@ -25,6 +25,7 @@ struct LnParams {
     f16* dx; int lddx;
     float* part;                    // [gridDim.x][2][C]: sum dy*xhat, sum dy
     int rows_per_block;
+    F32Rows f32;                    // forward: rows with an fp32 side copy (f32.in) are normalised from it instead of from x
 };
 
 template <int L>
@@ -58,6 +59,13 @@ __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_fwd_kernel(LnParams p
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int c = (sub + s * L) * 8;
+            uint32_t srow;
+            if (p.f32.in && rowok && c < p.C && f32_row(p.f32, m, srow)) {
+                load8f(p.f32.in + (int64_t)srow * p.f32.ld + c, v[s]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s1 += v[s][e];
+                continue;
+            }
             f16x8 h = (rowok && c < p.C) ? ld16(p.x + (int64_t)m * p.ldx + c) : zero8();
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[s][e] = (float)h[e]; s1 += v[s][e]; }
@@ -548,6 +556,7 @@ struct RowScaleParams {
     f16* y; int ldy;
     int64_t total;                  // M * (C/8)
     FastDiv fdG, fdRows;            // C/8, rows per sample
+    F32Rows f32;                    // fp32 side rows: residual read from f32.in (when given), sum also written to f32.out
 };
 __global__ __launch_bounds__(SF_THREADS) void sf_row_scale_add_kernel(RowScaleParams p) {
     for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
@@ -558,6 +567,20 @@ __global__ __launch_bounds__(SF_THREADS) void sf_row_scale_add_kernel(RowScalePa
         const f16x8 v = ld16(p.x + (int64_t)m * p.ldx + g8 * 8);
         f16x8 r = zero8(), o;
         if (p.resid) r = ld16(p.resid + (int64_t)m * p.ldr + g8 * 8);
+        uint32_t srow;
+        if (p.f32.out && f32_row(p.f32, (int)m, srow)) {
+            float rf[8], of[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rf[e] = (float)r[e];
+            if (p.f32.in) load8f(p.f32.in + (int64_t)srow * p.f32.ld + g8 * 8, rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { of[e] = rf[e] + sc * (float)v[e]; o[e] = (f16)of[e]; }
+            float* dst = p.f32.out + (int64_t)srow * p.f32.ld + g8 * 8;
+            *reinterpret_cast<f32x4*>(dst) = (f32x4){of[0], of[1], of[2], of[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){of[4], of[5], of[6], of[7]};
+            st16(p.y + (int64_t)m * p.ldy + g8 * 8, o);
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (f16)((float)r[e] + sc * (float)v[e]);
         st16(p.y + (int64_t)m * p.ldy + g8 * 8, o);

@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 19
+ABI_VERSION = 20
 # 16-bit storage type of activations / packed weights / MFMA operands, fixed per PROCESS: SF_ACT_DTYPE=fp16 (default) loads
 # libsfamd.so, =bf16 loads libsfamd_bf16.so -- the same sources compiled with -DSF_ACT_BF16 (bfloat16 storage,
 # v_mfma_f32_16x16x32_bf16); both are what torch.cuda.amp.autocast admits on the reference side (tools/train_net.py:101-118).
@@ -56,6 +56,12 @@ class DwDesc(Structure):
         "pT", "pH", "pW", "ldx", "ldy", "Cwreal")]
 
 
+class Rows32(Structure):
+    """Mirror of ``sf_rows32``: fp32 side rows of a token residual stream."""
+
+    _fields_ = [("in_", c_void_p), ("out", c_void_p), ("ld", c_int32), ("period", c_int32)]
+
+
 class AttnDesc(Structure):
     """Mirror of ``sf_attn_desc``."""
 
@@ -70,6 +76,7 @@ _SIGNATURES = {
     "sf_backend": (c_char_p, []),
     "sf_act_dtype": (c_int, []),
     "sf_last_error": (c_char_p, []),
+    "sf_build_id": (c_char_p, []),
     "sf_conv_weight_ld": (c_int, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
     "sf_prep_weights": (c_int, [POINTER(ConvDesc), _F, _P, _P, _P]),
     "sf_prep_item_fill": (c_int, [POINTER(ConvDesc), _F, _P, _P, POINTER(PrepItem)]),
@@ -108,6 +115,10 @@ _SIGNATURES = {
     "sf_bgemm_tn": (c_int, [c_int64, c_int32, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_float, c_int32, c_int32]
                     + [c_int64] * 6 + [_P]),
     "sf_layernorm_fwd": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, c_float, _P, c_int32, _F, _F, _P]),
+    "sf_gemm_rows32": (c_int, [c_int64, c_int32, c_int32, _P, c_int32, _P, c_int32, _F, _P, c_int32, _P, c_int32,
+                               POINTER(Rows32), _P]),
+    "sf_layernorm_fwd_rows32": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, c_float, _P, c_int32, _F, _F,
+                                        POINTER(Rows32), _P]),
     "sf_layernorm_bwd_blocks": (c_int, [c_int64, c_int32]),
     "sf_layernorm_bwd": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _F, _F, _F, _P, c_int32, _P, c_int32, _F, _P]),
     "sf_colsum_blocks": (c_int, [c_int64, c_int32]),
@@ -140,6 +151,8 @@ _SIGNATURES = {
     "sf_pack_clip_u8": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_float, c_float, c_float, c_float,
                                 c_float, c_float, c_int32, _P, _P]),
     "sf_row_scale_add": (c_int, [_P, c_int32, _P, c_int64, _P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
+    "sf_row_scale_add_rows32": (c_int, [_P, c_int32, _P, c_int64, _P, c_int32, _P, c_int32, c_int64, c_int32,
+                                        POINTER(Rows32), _P]),
     "sf_transpose_heads": (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "sf_sample_chunks": (c_int, [c_int64, c_int32]),
     "sf_sample_mean": (c_int, [c_int32, c_int64, c_int32, _P, c_int32, _F, _F, c_int, _F, _F, _P]),
@@ -173,6 +186,14 @@ class SfLibrary:
         if ver != ABI_VERSION:
             raise SfError(f"{path}: ABI version {ver}, expected {ABI_VERSION}")
         self.backend = self.cdll.sf_backend().decode()
+        self.build_id = self.cdll.sf_build_id().decode()
+        # build provenance: the binary carries the hash of the sources it was compiled from (build_ext.source_id(), passed as
+        # -DSF_BUILD_ID); a binary that is older than the csrc/ + include/ shipped beside it must not produce results
+        from . import build_ext
+        want = build_ext.source_id()
+        if self.build_id != want and os.environ.get("SF_ALLOW_STALE_LIBRARY", "0") == "0":
+            raise SfError(f"{path} was built from other sources (build id {self.build_id}, sources {want}): rebuild with "
+                          "`python -m slowfast_amd.build_ext` (SF_ALLOW_STALE_LIBRARY=1 overrides)")
         self.act_mode = ("fp16", "bf16")[self.cdll.sf_act_dtype()]
         if self.act_mode != ACT_MODE:
             raise SfError(f"{path} is the {self.act_mode} build of the library, this process runs with SF_ACT_DTYPE={ACT_MODE}")

@@ -192,11 +192,13 @@ class MultiScaleBlock(nn.Module):
         s = torch.floor(keep + u) / keep
         return s[0].contiguous(), s[1].contiguous()
 
-    def forward(self, x, thw_shape=None):
+    def forward(self, x, thw_shape=None, side=None):
+        """``side`` (not in the reference's signature): the fp32 side rows of the residual stream travelling with x
+        (mvit_engine.ResidSide; MViT.forward passes it from block to block, None = 16-bit stream only)."""
         drop = None
         if self.training and self.drop_path_rate > 0.0:
             drop = self._drop_scales(x.shape[0], x.device)
-        out = MultiScaleBlockFn.apply(x, self, tuple(thw_shape), drop, *self._param_list)
+        out = MultiScaleBlockFn.apply(x, self, tuple(thw_shape), drop, side, *self._param_list)
         return out, list(self._plan(x.shape[0], thw_shape, x.device).q_thw)
 
 
@@ -315,6 +317,7 @@ class MViT(nn.Module):
             embed_dim = 2 * embed_dim              # the final norm and the head see the concatenated streams
         else:
             self.blocks = nn.ModuleList()
+        tokens_out = []                                # patch tokens a block hands on
         for i in range(0 if self.enable_rev else depth):
             num_heads = round_width(num_heads, head_mul[i])
             if m.DIM_MUL_IN_ATT:
@@ -330,7 +333,14 @@ class MViT(nn.Module):
                 residual_pooling=m.RESIDUAL_POOLING, dim_mul_in_att=m.DIM_MUL_IN_ATT, separate_qkv=m.SEPARATE_QKV))
             if len(stride_q[i]) > 0:
                 input_size = [size // stride for size, stride in zip(input_size, stride_q[i])]
+            tokens_out.append(math.prod(input_size))
             embed_dim = dim_out
+        if not self.enable_rev:
+            # blocks from the last q-pooling block on (MViTv2-S: 14-15, 393 tokens) keep every row of the residual stream in
+            # fp32 next to the 16-bit tensor (mvit_engine.ResidSide) when that stage is small; before that only the class-token row
+            last_pool = max([i for i in range(depth) if len(stride_q[i]) > 0 and math.prod(stride_q[i]) > 1], default=None)
+            for i, blk in enumerate(self.blocks):
+                blk._resid32_full = last_pool is not None and i >= last_pool and tokens_out[i] <= 1024
         self.norm = norm_layer(embed_dim)
         self._norm_unit = NormUnit(self.norm)
         if self.enable_detection:                  # video_model_builder.py:1034-1045
@@ -357,6 +367,17 @@ class MViT(nn.Module):
         self.apply(self._init_weights)
         self.head.projection.weight.data.mul_(m.HEAD_INIT_SCALE)
         self.head.projection.bias.data.mul_(m.HEAD_INIT_SCALE)
+
+    def _resid_side(self, x, pos):
+        """fp32 side rows of the residual stream at the first block (mvit_engine.ResidSide): the class-token rows
+        cls_token (+ its position embedding), exact.  None without a class token or with SF_MVIT_RESID32=0."""
+        from . import mvit_engine
+        if not (self.cls_embed_on and mvit_engine.RESID32):
+            return None
+        c = self.cls_token.detach().view(1, -1).float()
+        if pos is not None:
+            c = c + pos.detach()[0, :1].float()
+        return mvit_engine.ResidSide(cls32=c.expand(x.shape[0], -1).contiguous())
 
     def _init_weights(self, m):
         """video_model_builder.py:1085-1092."""
@@ -400,10 +421,11 @@ class MViT(nn.Module):
             x = self.rev_backbone(x)               # fuse("concat") is the identity on the concatenated streams
         else:
             ncut = 4 if len(self.blocks) >= 8 else max(len(self.blocks) // 3, 1)      # MViTv2-S: [0-3 | 4-7 | 8-11 | 12-15 + head]
+            side = self._resid_side(x, pos)
             for i, blk in enumerate(self.blocks):
                 if i and i % ncut == 0:                # backward segments of step.TrainStep (identity otherwise)
                     x = engine.cut(x)
-                x, thw = blk(x, thw)
+                x, thw = blk(x, thw, side)
         if self.enable_detection:                  # video_model_builder.py:1218-1226
             x = TokenNormFn.apply(x, self, self.cls_embed_on, self.norm.weight, self.norm.bias)
             B, _, C = x.shape
@@ -411,5 +433,6 @@ class MViT(nn.Module):
             return self.head([x], bboxes)
         # video_model_builder.py:1154-1161, 1226-1238: mean of the patch tokens then norm / norm of the cls rows / norm then mean
         mode = "mean_norm" if self.use_mean_pooling else ("cls" if self.cls_embed_on else "norm_mean")
-        x = ClsNormFn.apply(x, self, mode, self.cls_embed_on, self.norm.weight, self.norm.bias)
+        x = ClsNormFn.apply(x, self, mode, self.cls_embed_on, None if self.enable_rev else side, self.norm.weight,
+                            self.norm.bias)
         return self.head(x)

@@ -27,6 +27,41 @@ _f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.AC
 FUSE_COLSUM = os.environ.get("SF_FUSE_COLSUM", "1") != "0"
 
 
+# fp32 side copy of the residual stream (SF_MVIT_RESID32=0: everything in the 16-bit storage type, A/B runs): the reference adds
+# the two branch outputs of a MultiScaleBlock to an fp32 stream (attention.py:500-510; autocast does not touch additions).  Here
+# the stream is 16-bit storage with (a) the class-token row of every residual sum -- the only row the classifier reads -- and (b)
+# every row of the blocks of the last stage (393 tokens in MViTv2-S) ALSO kept in fp32: the GEMM epilogue that adds the residual
+# sums those rows from its fp32 accumulators (sf_gemm_rows32), the LayerNorms that read the stream normalise them from the fp32
+# copy.  The 16-bit rows are the rounded fp32 rows, so every other consumer (skip pooling, backward) is unchanged.
+RESID32 = os.environ.get("SF_MVIT_RESID32", "1") != "0"
+
+
+class ResidSide:
+    """The fp32 side rows that travel with the token tensor between MultiScaleBlocks: ``cls32`` [B, C] (the class-token rows)
+    or ``full32`` [B, N, C] (every row; last stage).  Forward-only data: gradients flow through the 16-bit tensor."""
+
+    def __init__(self, cls32=None, full32=None):
+        self.cls32, self.full32 = cls32, full32
+
+    def reader(self, N):
+        """``side`` argument of a kernel that READS the stream tensor [B, N, C]: (period, fp32 rows)."""
+        return (1, self.full32) if self.full32 is not None else (N, self.cls32)
+
+    def cls_rows(self):
+        return self.cls32 if self.full32 is None else self.full32[:, 0].contiguous()
+
+
+def _sum_side(src, B, N, C, full, device):
+    """``side`` argument of a kernel that WRITES a residual sum [B, N, C] of the stream: (period, fp32 residual rows or None,
+    fp32 result rows) and the ResidSide the sum travels on with.  src: the ResidSide of the residual operand (None: the operand
+    has no fp32 copy, e.g. it is a Linear output)."""
+    if full:
+        dst = torch.empty((B, N, C), dtype=torch.float32, device=device)
+        return (1, src.full32 if src is not None else None, dst), ResidSide(full32=dst)
+    dst = torch.empty((B, C), dtype=torch.float32, device=device)
+    return (N, src.cls_rows() if src is not None else None, dst), ResidSide(cls32=dst)
+
+
 class LinearUnit:
     """nn.Linear parameter container bound to the GEMM kernels: fp16 operand caches + gradient writes."""
 
@@ -62,9 +97,9 @@ class LinearUnit:
         self._w, self._wt, self._planned = wf, wd, True
         self._key = (w.data_ptr(), w._version, w.device, _engine.PARAM_EPOCH)
 
-    def forward(self, x, resid=None, out=None):
+    def forward(self, x, resid=None, out=None, side=None):
         w, _ = self._ops(fresh=True)
-        return tokens.gemm(x, w, bias=self.lin.bias, resid=resid, out=out)
+        return tokens.gemm(x, w, bias=self.lin.bias, resid=resid, out=out, side=side)
 
     def forward_gelu(self, x):
         """(pre-activation, gelu(pre-activation)) with the GELU in the GEMM epilogue."""
@@ -157,8 +192,8 @@ class NormUnit:
     def __init__(self, ln):
         self.ln = ln
 
-    def forward(self, x):
-        return tokens.layernorm_fwd(x, self.ln.weight, self.ln.bias, self.ln.eps)
+    def forward(self, x, side=None):
+        return tokens.layernorm_fwd(x, self.ln.weight, self.ln.bias, self.ln.eps, side=side)
 
     def backward(self, dy, x, mean, rstd, resid=None):
         ln = self.ln
@@ -443,12 +478,14 @@ class MultiScaleBlockFn(torch.autograd.Function):
     attention residual (DIM_MUL_IN_ATT, MViTv2) or after the Mlp (MViTv1)."""
 
     @staticmethod
-    def forward(ctx, x, mod, thw, drop, *params):
+    def forward(ctx, x, mod, thw, drop, side, *params):
+        """``side``: the ResidSide travelling with x (None: 16-bit stream only); it is UPDATED in place to the one of the
+        block output."""
         ctx._sf_params = params
         att = mod.attn
         B, N, dim = x.shape
         plan = mod._plan(B, thw, x.device)
-        xn, m1, r1 = mod._norm1.forward(x)
+        xn, m1, r1 = mod._norm1.forward(x, side=side.reader(N) if side is not None else None)
         if att.pool_first:
             qkv = None
             o, sv = attention_forward_pool_first(att, plan, xn)
@@ -457,8 +494,10 @@ class MultiScaleBlockFn(torch.autograd.Function):
             o, sv = attention_forward(att, plan, qkv)
         proj_first = mod._proj is not None and mod.dim_mul_in_att
         proj_last = mod._proj is not None and not mod.dim_mul_in_att
+        rside = side                                       # fp32 rows of the residual operand of the first sum
         if proj_first:
             xs = mod._proj.forward(xn)                     # dim change on the normed input (attention.py:494-495)
+            rside = None                                   # a Linear output: 16-bit only
         else:
             xs = x
         pool = None
@@ -466,13 +505,21 @@ class MultiScaleBlockFn(torch.autograd.Function):
             k, s, p = mod.pool_skip.kernel_size, mod.pool_skip.stride, mod.pool_skip.padding
             xres, arg, _ = tokens.token_pool_fwd(xs, B, thw, k, s, p, cls=mod.has_cls_embed)
             pool = (k, s, p, arg, xres)
+            if rside is not None:                          # the pooling passes the class-token row through: its fp32 copy stays valid
+                rside = ResidSide(cls32=rside.cls_rows())
         else:
             xres = xs
+        Nq, Ca = plan.Nq, xres.shape[-1]
+        full = bool(getattr(mod, "_resid32_full", False))
+        s1 = side1 = None
+        if side is not None:
+            s1, side1 = _sum_side(rside if (rside is None or not full or rside.full32 is not None) else None,
+                                  B, Nq, Ca, full, x.device)
         if drop is None:
-            x1 = att._proj.forward(o, resid=xres)          # x_res + attention output
+            x1 = att._proj.forward(o, resid=xres, side=s1)     # x_res + attention output
         else:                                              # x_res + drop_path(attention output), attention.py:500-502
-            x1 = tokens.row_scale_add(att._proj.forward(o), drop[0], xres.shape[1], resid=xres)
-        xn2, m2, r2 = mod._norm2.forward(x1)
+            x1 = tokens.row_scale_add(att._proj.forward(o), drop[0], xres.shape[1], resid=xres, side=s1)
+        xn2, m2, r2 = mod._norm2.forward(x1, side=side1.reader(Nq) if side1 is not None else None)
         if _FUSED_GELU:
             h, a = mod.mlp._fc1.forward_gelu(xn2)
         else:
@@ -480,10 +527,15 @@ class MultiScaleBlockFn(torch.autograd.Function):
             a = tokens.gelu_fwd(h)
         # MViTv1 (DIM_MUL_IN_ATT False): the dimension change acts on the normed Mlp input (attention.py:507-508)
         xb = mod._proj.forward(xn2) if proj_last else x1
+        s2 = side2 = None
+        if side is not None:
+            s2, side2 = _sum_side(None if proj_last else side1, B, Nq, xb.shape[-1], full, x.device)
         if drop is None:
-            out = mod.mlp._fc2.forward(a, resid=xb)
+            out = mod.mlp._fc2.forward(a, resid=xb, side=s2)
         else:                                              # x + drop_path(mlp), attention.py:508-510
-            out = tokens.row_scale_add(mod.mlp._fc2.forward(a), drop[1], xb.shape[1], resid=xb)
+            out = tokens.row_scale_add(mod.mlp._fc2.forward(a), drop[1], xb.shape[1], resid=xb, side=s2)
+        if side is not None:
+            side.cls32, side.full32 = side2.cls32, side2.full32
         ctx.drop = drop
         ctx.mod, ctx.plan, ctx.thw = mod, plan, tuple(thw)
         ctx.sv = dict(x=x, xn=xn, s1=(m1, r1), qkv=qkv, att=sv, o=o, pool=pool, x1=x1, xn2=xn2, s2=(m2, r2), h=h, a=a)
@@ -531,7 +583,7 @@ class MultiScaleBlockFn(torch.autograd.Function):
         dx = mod._norm1.backward(dxn, sv["x"], *sv["s1"], resid=dx_skip)
         _notify(mod._param_list)
         ctx.sv = None
-        return (dx, None, None, None) + param_grads(ctx, 4)
+        return (dx, None, None, None, None) + param_grads(ctx, 5)
 
 
 def _attention_sub_forward(sub, plan, x):
@@ -740,7 +792,7 @@ class ClsNormFn(torch.autograd.Function):
     "norm_mean" (no cls token, the reference's default there): norm of every token, then the mean over tokens."""
 
     @staticmethod
-    def forward(ctx, x, mod, mode, has_cls, *params):
+    def forward(ctx, x, mod, mode, has_cls, side, *params):
         ctx._sf_params = params
         unit = mod._norm_unit
         s = int(bool(has_cls))
@@ -751,12 +803,14 @@ class ClsNormFn(torch.autograd.Function):
             y = yt.view(B, N, C).float().mean(1).to(_f16)
         else:
             xc = x[:, s:].float().mean(1).to(_f16) if mode == "mean_norm" else x[:, 0].contiguous()
-            y, m, r = unit.forward(xc)
+            # the class-token rows of the stream in fp32 (ResidSide) when the blocks kept them, else the 16-bit rows
+            x32 = side.cls_rows() if (side is not None and mode == "cls") else xc.float()
+            y, m, r = unit.forward(xc, side=(1, x32) if (side is not None and mode == "cls") else None)
             # what the classifier consumes is a [B, C] tensor: hand it over in fp32 (the row statistics come from the
             # kernel, the affine map of 32 x 768 values is free) instead of rounding the normalised features to fp16 right
             # before a cancelling sum over C -- the dominant term of the logits' deviation from the fp32 reference
             ln = unit.ln
-            y = (xc.float() - m.view(-1, 1)) * r.view(-1, 1) * ln.weight.detach().float() + ln.bias.detach().float()
+            y = (x32 - m.view(-1, 1)) * r.view(-1, 1) * ln.weight.detach().float() + ln.bias.detach().float()
         ctx.unit, ctx.xc, ctx.st, ctx.shape, ctx.mode, ctx.s = unit, xc, (m, r), tuple(x.shape), mode, s
         return y
 
@@ -777,7 +831,7 @@ class ClsNormFn(torch.autograd.Function):
                 dx = torch.zeros(ctx.shape, dtype=_f16, device=dy.device)
                 dx[:, 0] = dxc
         _notify(ctx.unit.params())
-        return (dx, None, None, None) + param_grads(ctx, 4)
+        return (dx, None, None, None, None) + param_grads(ctx, 5)
 
 
 class TokenNormFn(torch.autograd.Function):

@@ -10,7 +10,7 @@ import torch
 
 from . import lib as _sflib
 
-from .lib import AttnDesc, DwDesc, SfError, get_lib
+from .lib import AttnDesc, DwDesc, Rows32, SfError, get_lib
 from .ops import _ptr, _stream, _workspace
 
 _f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
@@ -39,11 +39,24 @@ def _lib_call(name, *args, **kw):
 
 
 # ------------------------------------------------------------------------------------------------
+# fp32 side rows of a token residual stream (include/sfamd.h: sf_rows32)
+def _rows32(M, C, period, src=None, dst=None):
+    """ctypes descriptor: rows m % period == 0 of an [M, C] token tensor carry an fp32 copy at row m // period of
+    ``src`` (residual operand rows, optional) / ``dst`` (result rows), fp32 [M // period, C] each."""
+    for t in (src, dst):
+        if t is not None:
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[-1] == C and t.numel() * period == M * C, \
+                (tuple(t.shape), M, C, period)
+    return Rows32(_ptr(src), _ptr(dst), C, period)
+
+
+# ------------------------------------------------------------------------------------------------
 # GEMMs
-def gemm(a, w16, bias=None, resid=None, out=None, alpha=0.0):
+def gemm(a, w16, bias=None, resid=None, out=None, alpha=0.0, side=None):
     """out[m][n] = sum_k a[m][k] * w16[n][k] (+ bias[n]) (+ resid[m][n]).  a: token tensor (..., K); w16: fp16
     [N, K] (pitch = stride(0)); the nn.Linear forward with w16 = weight.half(), or its data gradient with
-    w16 = weight.t().half()."""
+    w16 = weight.t().half().  ``side = (period, src32 | None, dst32)``: rows m % period == 0 are also summed in fp32 from the
+    accumulators (+ src32 row, or the fp16 residual row when src32 is None) into dst32; their fp16 row is round(dst32 row)."""
     M, K, lda = rows_pitch(a)
     N = w16.shape[0]
     assert w16.dtype == _f16 and w16.shape[1] == K and w16.stride(1) == 1
@@ -55,6 +68,13 @@ def gemm(a, w16, bias=None, resid=None, out=None, alpha=0.0):
     if resid is not None:
         Mr, Nr, ldr = rows_pitch(resid)
         assert (Mr, Nr) == (M, N)
+    if side is not None:
+        assert alpha == 0.0
+        d = _rows32(M, N, side[0], side[1], side[2])
+        _lib_call("sf_gemm_rows32", M, N, K, a.data_ptr(), lda, w16.data_ptr(), w16.stride(0), _ptr(bias), _ptr(resid), ldr,
+                  out.data_ptr(), ldy, byref(d), _stream(a),
+                  work=dict(flops=2.0 * M * N * K, bytes=2.0 * (M * K + M * N + N * K)))
+        return out
     _lib_call("sf_bgemm", M, N, K, a.data_ptr(), lda, w16.data_ptr(), w16.stride(0), _ptr(bias), _ptr(resid), ldr,
               out.data_ptr(), ldy, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, float(alpha), _stream(a),
               work=dict(flops=2.0 * M * N * K, bytes=2.0 * (M * K + M * N + N * K)))
@@ -145,12 +165,18 @@ def _linear_geom(M, K, N):
 
 # ------------------------------------------------------------------------------------------------
 # LayerNorm / GELU / bias gradients
-def layernorm_fwd(x, gamma, beta, eps, out=None, save_stats=True):
+def layernorm_fwd(x, gamma, beta, eps, out=None, save_stats=True, side=None):
+    """``side = (period, src32)``: rows m % period == 0 are normalised from their fp32 copy src32[m // period]."""
     M, C, ldx = rows_pitch(x)
     y = torch.empty(x.shape, dtype=_f16, device=x.device) if out is None else out
     _, _, ldy = rows_pitch(y)
     mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    if side is not None:
+        d = _rows32(M, C, side[0], side[1], None)
+        _lib_call("sf_layernorm_fwd_rows32", M, C, x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), float(eps),
+                  y.data_ptr(), ldy, _ptr(mean), _ptr(rstd), byref(d), _stream(x), work=dict(bytes=4.0 * M * C))
+        return y, mean, rstd
     _lib_call("sf_layernorm_fwd", M, C, x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), float(eps), y.data_ptr(),
               ldy, _ptr(mean), _ptr(rstd), _stream(x), work=dict(bytes=4.0 * M * C))
     return y, mean, rstd
@@ -417,12 +443,18 @@ def attn_bwd(d, q, k, v, scale, rq, residual, o, do, lse, onehot=None, dq_out=No
     return dq, dk, dv, drq
 
 
-def row_scale_add(x, scale, rows_per_sample, resid=None):
-    """y = resid + scale[row // rows_per_sample] * x on token rows (stochastic depth, common.py:46-59)."""
+def row_scale_add(x, scale, rows_per_sample, resid=None, side=None):
+    """y = resid + scale[row // rows_per_sample] * x on token rows (stochastic depth, common.py:46-59).
+    ``side = (period, src32 | None, dst32)`` as in gemm()."""
     M, C, ldx = rows_pitch(x)
     y = torch.empty(x.shape, dtype=_f16, device=x.device)
     assert scale.dtype == torch.float32 and scale.numel() * rows_per_sample == M
     r_ptr, ldr = (resid.data_ptr(), rows_pitch(resid)[2]) if resid is not None else (None, 0)
+    if side is not None:
+        d = _rows32(M, C, side[0], side[1], side[2])
+        _lib_call("sf_row_scale_add_rows32", x.data_ptr(), ldx, scale.data_ptr(), rows_per_sample, r_ptr, ldr, y.data_ptr(),
+                  rows_pitch(y)[2], M, C, byref(d), _stream(x), work=dict(bytes=2.0 * x.numel() * (3 if resid is not None else 2)))
+        return y
     _lib_call("sf_row_scale_add", x.data_ptr(), ldx, scale.data_ptr(), rows_per_sample, r_ptr, ldr, y.data_ptr(),
               rows_pitch(y)[2], M, C, _stream(x), work=dict(bytes=2.0 * x.numel() * (3 if resid is not None else 2)))
     return y

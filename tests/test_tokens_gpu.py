@@ -13,6 +13,16 @@ def test_gemm_linear(gpu):
     tc.check_gemm(gpu, 77, 32, 24, bias=False, resid=False)
 
 
+def test_rows32_side_rows(gpu):
+    """fp32 side rows of the residual sums at MViTv2-S shapes: the attention projection of stage 3 (round-1 GEMM kernel), fc2 of
+    stage 3 (K = 1536: second-generation kernel), every row of the last stage."""
+    tc.check_rows32(gpu, 4, 1569, 384, 384)
+    tc.check_rows32(gpu, 4, 1569, 1536, 384)
+    tc.check_rows32(gpu, 3, 1569, 192, 192, bias=False, src32=False)
+    tc.check_rows32(gpu, 4, 393, 768, 768, period_full=True)
+    tc.check_rows32(gpu, 16, 393, 3072, 768, period_full=True)
+
+
 def test_layernorm(gpu):
     for M, C in ((5000, 96), (3001, 192), (777, 384), (400, 768), (37, 32)):
         tc.check_layernorm(gpu, M, C)

@@ -10,6 +10,14 @@ def test_gemm_linear(sim):
     tc.check_gemm(sim, 130, 192, 8, bias=True, resid=False)
 
 
+def test_rows32_side_rows(sim, monkeypatch):
+    tc.check_rows32(sim, 3, 50, 96, 192)                               # class-token rows, round-1 GEMM kernel
+    tc.check_rows32(sim, 2, 50, 64, 72, bias=False, src32=False)       # residual rows from the 16-bit operand, narrow N
+    tc.check_rows32(sim, 2, 9, 32, 96, period_full=True)               # every row (last stage)
+    tc.check_rows32(sim, 2, 150, 64, 160, igemm2=True, monkeypatch=monkeypatch)      # second-generation kernel (256-row tiles)
+    tc.check_rows32(sim, 2, 20, 64, 128, period_full=True, igemm2=True, monkeypatch=monkeypatch)
+
+
 def test_layernorm(sim):
     tc.check_layernorm(sim, 300, 96)
     tc.check_layernorm(sim, 37, 32)

@@ -242,3 +242,58 @@ def check_gemm_gelu(device, M, K, N, seed=0):
     (torch.nn.functional.gelu(hh) @ w2.t()).backward(dy)
     dh = tokens.gemm_gelu_grad(_h(dy, device), _h(w2.t().contiguous(), device), h)
     assert_close("d(fc1 output)", dh.float().cpu(), hh.grad, 3 * F16_EPS)
+
+
+def check_rows32(device, B, Ntok, K, N, period_full=False, bias=True, src32=True, seed=0, igemm2=False, monkeypatch=None):
+    """fp32 side rows of a residual sum (sf_gemm_rows32 / sf_layernorm_fwd_rows32 / sf_row_scale_add_rows32): the side rows are
+    the fp32 sum acc + bias + residual (fp32 residual rows when given) -- NOT rounded to the storage type anywhere -- the 16-bit
+    rows are their rounding, every other row is the plain kernel's."""
+    g = torch.Generator().manual_seed(seed)
+    M = B * Ntok
+    period = 1 if period_full else Ntok
+    a = torch.randn((M, K), generator=g).to(ACT).float()
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).to(ACT).float()
+    b = torch.randn(N, generator=g) if bias else None
+    r16 = (torch.randn((M, N), generator=g) * 3).to(ACT).float()
+    S = M // period
+    r32 = (r16[::period] + torch.randn((S, N), generator=g) * 1e-3) if src32 else None      # NOT 16-bit representable
+    lin = F.linear(a.double(), w.double(), b.double() if bias else None)
+    ref16 = (lin + r16.double()).float()
+    ref_side = (lin[::period] + (r32.double() if src32 else r16[::period].double())).float()
+    dst = torch.full((S, N), float("nan"), device=device)
+    if igemm2:
+        monkeypatch.setenv("SF_IGEMM2_MINK", "32")
+        monkeypatch.setenv("SF_IGEMM2_MINROWS", "1")
+    out = tokens.gemm(_h(a, device), _h(w, device), bias=b.to(device) if bias else None, resid=_h(r16, device),
+                      side=(period, r32.to(device) if src32 else None, dst))
+    # side rows: fp32 accumulate of 16-bit products, no 16-bit rounding -> 1e-5 of the row scale
+    assert_close("rows32 gemm side", dst.cpu(), ref_side, 2e-5)
+    o = out.float().cpu()
+    assert torch.equal(o[::period], dst.cpu().to(ACT).float()), "16-bit side rows must be the rounded fp32 rows"
+    if not period_full:
+        mask = torch.ones(M, dtype=torch.bool)
+        mask[::period] = False
+        assert_close("rows32 gemm other rows", o[mask], ref16[mask], 3 * F16_EPS)
+    # LayerNorm reading the side rows: statistics and output of those rows come from the fp32 copy
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    x16 = out                                                           # the stream tensor as the next kernel sees it
+    yk, mean, rstd = tokens.layernorm_fwd(x16, gamma.to(device), beta.to(device), 1e-6, side=(period, dst))
+    xmix = x16.float().cpu().clone()
+    xmix[::period] = dst.cpu()
+    yref = F.layer_norm(xmix, (N,), gamma, beta, 1e-6)
+    assert_close("rows32 ln", yk.float().cpu(), yref, 2 * F16_EPS)
+    assert_close("rows32 ln mean", mean.cpu(), xmix.mean(1), 1e-5)
+    # stochastic-depth form of the same sum
+    sc = torch.tensor([1.25, 0.0] * (B // 2) + [1.25] * (B % 2))
+    y16 = (torch.randn((M, N), generator=g)).to(ACT).float()
+    dst2 = torch.full((S, N), float("nan"), device=device)
+    o2 = tokens.row_scale_add(_h(y16, device), sc.to(device), Ntok, resid=_h(r16, device),
+                              side=(period, r32.to(device) if src32 else None, dst2))
+    scale_rows = sc.repeat_interleave(Ntok).view(-1, 1)
+    ref2 = r16 + scale_rows * y16
+    ref2_side = (r32 if src32 else r16[::period]) + scale_rows[::period] * y16[::period]
+    assert_close("rows32 row_scale_add side", dst2.cpu(), ref2_side, 1e-6)
+    o2c = o2.float().cpu()
+    assert torch.equal(o2c[::period], dst2.cpu().to(ACT).float())
+    if not period_full:
+        assert_close("rows32 row_scale_add rows", o2c[mask], ref2[mask], 2 * F16_EPS)
