@@ -684,7 +684,7 @@ class ResBlockFn(torch.autograd.Function):
         if BN_FUSE_REDUCE and tr:
             # a plain attribute of the output tensor: it reaches the next block only when that block receives THIS tensor
             # (consecutive blocks of a stage); any op in between (fusion, pooling, a stage cut) drops it and nothing changes
-            out._sf_block_bn = {"bits": bits, "y0": yc}
+            out._sf_block_bn = {"bits": bits, "y0": yc, "sync": _sync_of(units[-1].bn) is not None}
         return out
 
     @staticmethod
@@ -694,14 +694,11 @@ class ResBlockFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         raw, y1, act, bits = ctx.raw
         bn, s1 = ctx.bn
-        # partial sums the consumer block's data gradient already took over dout (tagged with the tensor they belong to)
-        tag = getattr(dout, "_sf_bn_part", None)
+        last = len(units) - 1
+        # partial sums the consumer block's data gradient already took over dout (tagged with the tensor state they describe)
+        part_c = tagged_bn_part(dout, raw[last])
         dout = as_cl(dout)
         need_dx = ctx.needs_input_grad[0]
-        last = len(units) - 1
-        part_c = None
-        if tag is not None and tag[0] == raw[last].data_ptr():
-            part_c = tag[1]
         dy = units[last].bn_backward(dout, raw[last], bn[last], zmask=bits, part=part_c)
         if P is not None:
             dy1 = P.bn_backward(dout, y1, s1, zmask=bits)
@@ -715,7 +712,7 @@ class ResBlockFn(torch.autograd.Function):
                 d_in = units[i].backward(raw[i - 1], (bn[i - 1].scale, bn[i - 1].shift, True), dy, need_dx=True)
             dy = units[i - 1].bn_backward(d_in, raw[i - 1], bn[i - 1], relu_self=True, part=part)
         prev = ctx.prev_bn if need_dx else None
-        if prev is not None and (_sync_of(units[last].bn) is not None):
+        if prev is not None and prev["sync"]:      # the PRODUCER's BatchNorm reduces its sums across ranks: not fused
             prev = None
         if P is not None:
             dx1 = P.backward(x, None, dy1, need_dx=need_dx)
@@ -725,10 +722,27 @@ class ResBlockFn(torch.autograd.Function):
         if prev is not None:
             dx, pc = dx
             if pc is not None:
-                dx._sf_bn_part = (prev["y0"].data_ptr(), pc)
+                tag_bn_part(dx, prev["y0"], pc)
         _notify(mod._param_list)
         ctx.raw = ctx.bn = ctx.prev_bn = None
         return (dx, None) + param_grads(ctx, 2)
+
+
+def tag_bn_part(dx, y0, part):
+    """Attach the BatchNorm-backward partial sums a data-gradient epilogue took over ``dx`` (the gradient w.r.t. the previous
+    block's output) to that tensor.  The tag names the tensor state it describes: the raw BatchNorm input it belongs to, the
+    gradient's storage and its version counter -- autograd may accumulate another consumer's gradient IN PLACE into the same
+    tensor object (feature taps, auxiliary heads, hooks), which keeps the Python attribute and changes the values."""
+    dx._sf_bn_part = (y0.data_ptr(), part, dx.data_ptr(), dx._version)
+
+
+def tagged_bn_part(dout, y0):
+    """The partial sums tagged onto ``dout`` if they still describe it (same BatchNorm input, same storage, not modified
+    since), else None -- the caller then runs the separate reduction pass."""
+    tag = getattr(dout, "_sf_bn_part", None)
+    if tag is None or tag[0] != y0.data_ptr() or tag[2] != dout.data_ptr() or tag[3] != dout._version:
+        return None
+    return tag[1]
 
 
 class ConvBNActFn(torch.autograd.Function):

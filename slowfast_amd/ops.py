@@ -234,6 +234,11 @@ def conv_dgrad(dy, wd, geom, resid=None, out=None, resid_bits=None, bn=None):
         output's 1-bit image (the BatchNorm of a projection shortcut keeps its own reduction pass).
     Returns (dx, part): part [rows, 2, Ci] fp32 for bn_bwd(..., part=part) -- None when the geometry keeps the separate pass
     (strided data gradients)."""
+    assert tuple(dy.shape) == geom.out_shape
+    if resid is not None:
+        assert tuple(resid.shape) == geom.in_shape
+    if out is not None:
+        assert tuple(out.shape) == geom.in_shape
     if bn is not None:
         if not isinstance(bn, dict):
             y0, sc, sh = bn                      # inner activation: mask recomputed from (y, scale, shift)
@@ -255,13 +260,10 @@ def conv_dgrad(dy, wd, geom, resid=None, out=None, resid_bits=None, bn=None):
                        y0.data_ptr(), cl_ld(y0), part.data_ptr(), cap, byref(nrows), _stream(dy),
                        work=geom.work(reads_x=1 + int(resid is not None), reads_y=1, writes_x=1))
         return dx, (part[:nrows.value] if nrows.value > 0 else None)
-    assert tuple(dy.shape) == geom.out_shape
     ldy = cl_ld(dy)
     dx = cl_empty(geom.in_shape, dy.device) if out is None else out
     ldx = cl_ld(dx)
     ldr = cl_ld(resid) if resid is not None else 0
-    if resid is not None:
-        assert tuple(resid.shape) == geom.in_shape
     if resid_bits is not None:
         assert resid is not None and resid_bits.dtype == torch.uint8 and resid_bits.numel() == rows(resid) * (geom.Ci // 8)
     get_lib().call("sf_conv_dgrad", byref(geom.desc(ldx, ldy)), dy.data_ptr(), wd.data_ptr(), _ptr(resid), ldr,

@@ -206,9 +206,19 @@ class TrainStep:
             handle.wait()
         return [float(v) for v in stats.cpu()]
 
+    @staticmethod
+    def _static_clone(x):
+        """The graph's own copy of an input: same strides (clone keeps a dense permuted layout), and the W-pair tag of a clip
+        packed by data.pack_pathways_u8 travels with it -- engine.StemConvUnit must read the copy exactly as it would read the
+        original, and a loader may later write packed clips straight into it (static_inputs())."""
+        c = x.clone()
+        if getattr(x, "_sf_wpairs", False):
+            c._sf_wpairs = True
+        return c
+
     def _capture(self, inputs, labels):
         self._is_list = isinstance(inputs, (list, tuple))
-        self._static_in = [x.clone() for x in inputs] if self._is_list else inputs.clone()
+        self._static_in = [self._static_clone(x) for x in inputs] if self._is_list else self._static_clone(inputs)
         self._static_labels = labels.clone()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -284,8 +294,11 @@ class TrainStep:
 
     def static_inputs(self):
         """(inputs, labels) buffers the captured graph reads (None before the capture).  A loader that writes the next batch
-        straight into them -- e.g. data.pack_pathways_u8 with these tensors as its outputs -- saves the per-iteration
-        device-to-device copy __call__ otherwise makes from the tensors it is handed (0.28 ms for a 32-clip SlowFast batch)."""
+        straight into them saves the per-iteration device-to-device copy __call__ otherwise makes from the tensors it is handed
+        (0.28 ms for a 32-clip SlowFast batch).  For a step captured on clips packed by data.pack_pathways_u8 these ARE packed
+        (tagged) buffers: ``pack_pathways_u8(frames, cfg, out=step.static_inputs()[0])`` then ``step(*step.static_inputs())``
+        (tests/test_step.py::test_packed_loader_writes_static_inputs).  A step captured on fp32 NCTHW clips has fp32 buffers,
+        which that loader rejects."""
         if self._graph is None:
             return None
         return (list(self._static_in) if self._is_list else self._static_in), self._static_labels

@@ -212,7 +212,7 @@ class X3DBlockFn(torch.autograd.Function):
         ctx.sv = dict(ya=ya, sa=sa, za=za, yb=yb, sb=sb, gate=gate, se=se, zb=zb, yc=yc, sc=sc, y1=y1, s1=s1, bits=bits)
         ctx.save_for_backward(x)
         if engine.BN_FUSE_REDUCE and tr:
-            out._sf_block_bn = {"bits": bits, "y0": yc}
+            out._sf_block_bn = {"bits": bits, "y0": yc, "sync": _sync_of(C.bn) is not None}
         return out
 
     @staticmethod
@@ -221,11 +221,10 @@ class X3DBlockFn(torch.autograd.Function):
         t = mod.branch2
         A, C, P = t._a, t._c, mod._proj
         (x,) = ctx.saved_tensors
-        tag = getattr(dout, "_sf_bn_part", None)
+        part_c = engine.tagged_bn_part(dout, sv["yc"])       # still describing dout? (engine.tag_bn_part)
         dout = as_cl(dout)
         need_dx = ctx.needs_input_grad[0]
         bits = sv["bits"]
-        part_c = tag[1] if (tag is not None and tag[0] == sv["yc"].data_ptr()) else None
         dyc = C.bn_backward(dout, sv["yc"], sv["sc"], zmask=bits, part=part_c)
         if P is not None:
             dy1 = P.bn_backward(dout, sv["y1"], sv["s1"], zmask=bits)
@@ -240,7 +239,7 @@ class X3DBlockFn(torch.autograd.Function):
         dza = t._b.backward(sv["za"], dyb, need_dx=True)
         dya = A.bn_backward(dza, sv["ya"], sv["sa"], relu_self=True)
         prev = ctx.prev_bn if need_dx else None
-        if prev is not None and _sync_of(C.bn) is not None:
+        if prev is not None and prev["sync"]:      # the PRODUCER's BatchNorm reduces its sums across ranks: not fused
             prev = None
         if P is not None:
             dx1 = P.backward(x, None, dy1, need_dx=need_dx)
@@ -250,7 +249,7 @@ class X3DBlockFn(torch.autograd.Function):
         if prev is not None:
             dx, pc = dx
             if pc is not None:
-                dx._sf_bn_part = (prev["y0"].data_ptr(), pc)
+                engine.tag_bn_part(dx, prev["y0"], pc)
         _notify(mod._param_list)
         ctx.sv = ctx.prev_bn = None
         return (dx, None) + param_grads(ctx, 2)

@@ -401,3 +401,48 @@ def check_multiscale_block(device, dim, dim_out, heads, thw, stride_q, stride_kv
     # norm_k.bias: the same vector added to every key leaves the softmax unchanged -- its gradient vanishes identically
     return _compare(blk, "blk.", got, ref, rg, st, tol=tol, zero_floor=0.1,
                     yard=_storage_yardstick(case, ref, rg, zero_floor=0.1))
+
+
+def check_bn_part_tag_second_consumer(device, seed=5):
+    """Two consecutive identity ResBlocks whose intermediate output has a SECOND autograd consumer (a feature tap): the fused
+    BatchNorm-backward partial sums the second block tags onto its input gradient describe only ITS contribution; autograd may
+    add the tap's gradient into the same tensor in place.  engine.tagged_bn_part must notice (storage + version counter) and the
+    first block must fall back to the separate reduction: identical gradients with the fusion on and off."""
+    from slowfast_amd import engine
+    assert engine.BN_FUSE_REDUCE
+    torch.manual_seed(seed)
+    b1 = ResBlock(32, 32, 1, 1, BottleneckTransform, 8)
+    b2 = ResBlock(32, 32, 1, 1, BottleneckTransform, 8)
+    _load(b1, seed), _load(b2, seed + 1)
+    b1, b2 = b1.to(device).train(), b2.to(device).train()
+    x = torch.randn((2, 32, 2, 8, 8)).to(ACT).float()
+    tapw = torch.randn((2, 32, 2, 8, 8)).to(ACT).float()
+    d2 = torch.randn((2, 32, 2, 8, 8)).to(ACT).float()
+    # unit level: a tag stops describing a tensor the moment the tensor is written to
+    t = torch.zeros(4)
+    y0 = torch.zeros(3)
+    engine.tag_bn_part(t, y0, "part")
+    assert engine.tagged_bn_part(t, y0) == "part" and engine.tagged_bn_part(t, torch.zeros(3)) is None
+    t.add_(1.0)
+    assert engine.tagged_bn_part(t, y0) is None
+
+    def run(fuse, tap_first):
+        engine.BN_FUSE_REDUCE = fuse
+        try:
+            for b in (b1, b2):
+                for p in b.parameters():
+                    p.grad = None
+            xc = host_to_cl(x, device).requires_grad_(True)
+            y1 = b1(xc)
+            tap = (y1.float() * host_to_cl(tapw, device).float()).sum()
+            y2 = b2(y1)
+            main = (y2.float() * host_to_cl(d2, device).float()).sum()
+            (tap + main if tap_first else main + tap).backward()
+            return [p.grad.detach().float().cpu().clone() for p in b1.parameters()] + [cl_to_host(xc.grad)]
+        finally:
+            engine.BN_FUSE_REDUCE = True
+
+    for tap_first in (False, True):
+        ref, got = run(False, tap_first), run(True, tap_first)
+        for a, b in zip(ref, got):
+            assert rel(b, a) < 1e-5, (tap_first, rel(b, a))

@@ -50,6 +50,33 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     lib.reset_lib()
 
 
+def test_stale_binary_is_refused(tmp_path, monkeypatch, hostsim_path):
+    """Build provenance: every binary carries the hash of the sources it was compiled from (sf_build_id); a binary whose id
+    differs from the csrc/ + include/ beside it is refused at load, and build_ext treats it as stale whatever its mtime."""
+    from slowfast_amd import build_ext, lib
+    want = build_ext.source_id()
+    for path in (build_ext.build_hip(), hostsim_path):
+        dll = ctypes.CDLL(path)
+        dll.sf_build_id.restype = ctypes.c_char_p
+        assert dll.sf_build_id().decode() == want == build_ext._built_id(path)
+        assert not build_ext._stale(path, None)
+    blob = open(hostsim_path, "rb").read()
+    tag = b"sfamd-build-id:" + want.encode()
+    assert blob.count(tag) == 1
+    old = tmp_path / "libsfamd_old.so"
+    old.write_bytes(blob.replace(tag, b"sfamd-build-id:" + b"0123456789abcdef"))
+    os.utime(old, (2e9, 2e9))                                   # newer than every source: mtimes do not vouch for a binary
+    assert build_ext._stale(str(old), None)
+    monkeypatch.setenv("SFAMD_LIBRARY", str(old))
+    lib.reset_lib()
+    with pytest.raises(lib.SfError, match="built from other sources"):
+        lib.get_lib()
+    monkeypatch.setenv("SF_ALLOW_STALE_LIBRARY", "1")
+    lib.reset_lib()
+    assert lib.get_lib().build_id == "0123456789abcdef"
+    lib.reset_lib()
+
+
 def test_cpu_tensor_with_gfx950_library_is_rejected(monkeypatch):
     """The product library never computes on host tensors."""
     import torch

@@ -14,6 +14,10 @@ def test_resblock_dilated(sim):
     bc.check_resblock(sim, 16, 32, 1, 1, 8, (2, 16, 1, 8, 8), dilation=2)
 
 
+def test_bn_part_tag_survives_only_unmodified_gradients(sim):
+    bc.check_bn_part_tag_second_consumer(sim)
+
+
 def test_stem_slow_and_fast(sim):
     bc.check_stem(sim, 16, [1, 7, 7], (1, 3, 2, 20, 20))
     bc.check_stem(sim, 8, [5, 7, 7], (1, 3, 4, 16, 16))

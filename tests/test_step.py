@@ -232,6 +232,63 @@ def test_segmented_graph_replay_matches_eager(gpu, name):
         assert torch.equal(a, b)
 
 
+def test_static_clone_keeps_wpair_tag_and_strides():
+    """TrainStep._static_clone: the captured graph's copy of a packed clip keeps the W-pair tag and the channels-last strides
+    (without the tag StemConvUnit would try to convert an 8-channel tensor and fail at capture)."""
+    from slowfast_amd.step import TrainStep
+    base = torch.zeros((2, 4, 6, 3, 8), dtype=torch.float16)
+    x = base.permute(0, 4, 1, 2, 3)
+    x._sf_wpairs = True
+    c = TrainStep._static_clone(x)
+    assert getattr(c, "_sf_wpairs", False) and c.stride() == x.stride() and c.data_ptr() != x.data_ptr()
+    assert c.permute(0, 2, 3, 4, 1).is_contiguous()
+    assert not hasattr(TrainStep._static_clone(torch.zeros(3)), "_sf_wpairs")
+
+
+@pytest.mark.gpu
+def test_packed_loader_writes_static_inputs(gpu):
+    """A TrainStep captured on clips packed by pack_pathways_u8; the next batches are packed STRAIGHT INTO the graph's static
+    input buffers (no device-to-device copy) and replayed: same losses and parameters as the eager step fed the same clips."""
+    import slowfast_amd as sa
+    from slowfast_amd.data_parallel import GradReducer
+    from slowfast_amd.optim import construct_optimizer
+    from slowfast_amd.step import TrainStep
+    from tests import model_checks as mc
+    gold = mc.load_golden("slowfast_tiny")
+    cfg = mc.cfg_for(gold)
+    S, T = cfg.DATA.TRAIN_CROP_SIZE, cfg.DATA.NUM_FRAMES
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.randint(0, 256, (2, T, S, S, 3), generator=g, dtype=torch.int64).to(torch.uint8).to(gpu),
+                torch.randint(0, cfg.MODEL.NUM_CLASSES, (2,), generator=g).to(gpu)) for _ in range(4)]
+
+    def run(use_graph):
+        torch.manual_seed(0)
+        model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg).to(gpu).train()
+        red = GradReducer(model, bucket_mb=0.05)
+        red.attach_torch_param_hooks(model.head.parameters())
+        opt = construct_optimizer(model, cfg, red, loss_scale=64.0, dynamic_loss_scale=False)
+        step = TrainStep(model, red, opt, F.cross_entropy, use_graph=use_graph, warmup=1)
+        losses = []
+        for frames, y in batches:
+            st = step.static_inputs()
+            if st is None:
+                losses.append(float(step(sa.pack_pathways_u8(frames, cfg), y)))
+            else:                                           # the loader writes into the graph's own buffers
+                xs = sa.pack_pathways_u8(frames, cfg, out=st[0])
+                assert all(a.data_ptr() == b.data_ptr() for a, b in zip(xs, st[0]))
+                st[1].copy_(y)
+                losses.append(float(step(xs, st[1])))
+        out = losses, [p.detach().float().cpu().clone() for p in model.parameters()]
+        red.close()
+        return out
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+
+
 def _count_calls(fn):
     """Runs fn() with a libsfamd call observer; returns (result, {entry point: calls})."""
     from slowfast_amd import lib
