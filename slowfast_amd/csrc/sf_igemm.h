@@ -125,7 +125,9 @@ __device__ __forceinline__ void bnb_reduce_store(float (&sg)[8], float (&sgy)[8]
 // the dividing gather, profiles/r1/r1_visit19_ab.txt) and a three-stage ring for the direct-to-LDS path (inline-asm copies, raw
 // barrier, counted waits: no gain on any pointwise layer, -1 % on MViTv2-S at three workgroups per CU,
 // profiles/r3_v10_gl3_ab.txt -- these layers are not latency-bound).
-template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false>
+// F32R: the fp32 side rows of the output (IgemmParams::f32) are compiled in -- a separate instantiation, because even the dead
+// branch costs the 128-VGPR variants 20 spilled registers (hipcc -Rpass-analysis=kernel-resource-usage, round 4).
+template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false, bool F32R = false>
 __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(IgemmParams p) {
     constexpr int BM = 128, BK = 32;
     constexpr int NST = 2;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha + b;
         }
     }
-    if (p.f32.out) f32_rows_epilogue<TM, TN>(acc, p.f32, m0 + wm * WM, n0 + wn * WN, p.M, p.Nout, resid, p.ldr, p.resid_row0);
+    if constexpr (F32R) f32_rows_epilogue<TM, TN>(acc, p.f32, m0 + wm * WM, n0 + wn * WN, p.M, p.Nout, resid, p.ldr, p.resid_row0);
     if (p.stat_part) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -395,8 +397,10 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
             const int row = idx / CG, m = m0 + row;
             ok[u] = idx < BM * CG && m < p.M && ecol < p.Nout;
             rok[u] = ok[u] && resid && m >= p.resid_row0;
-            uint32_t srow;
-            if (p.f32.out && f32_row(p.f32, m, srow)) rok[u] = false;      // residual already inside the staged value
+            if constexpr (F32R) {
+                uint32_t srow;
+                if (f32_row(p.f32, m, srow)) rok[u] = false;               // residual already inside the staged value
+            }
             L[u].rbits = 0xffu; L[u].bbits = 0u;
             if (rok[u]) {
                 L[u].r = ld16(resid + (int64_t)m * p.ldr + ecol);

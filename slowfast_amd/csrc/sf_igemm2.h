@@ -91,7 +91,7 @@ __device__ __forceinline__ int i2_lds_off(int row, int kslot) {
 //  * issuing the next stage's copies between the two MFMA halves of a stage in half of the waves: a wash
 //    (profiles/r3_v7_stagger_ab.txt).  profiles/r3_v6_igemm2_ablation.md shows what bounds the loop instead: the copy stream
 //    alone and the MFMA stream alone each take 75-80 % of the kernel's time and overlap only partly.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NST>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NST, bool F32R = false>   // F32R: see sf_igemm_kernel
 // register cap: the 32-deep variant must fit TWO workgroups per CU (4 waves per SIMD -> 128 VGPRs), the 64-deep one runs alone
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES_M * WAVES_N) / 4) void sf_igemm2_kernel(Igemm2Params p) {
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha + b;
         }
     }
-    if (p.f32.out) f32_rows_epilogue<TM, TN>(acc, p.f32, m0 + wm * WM, n0 + wn * WN, p.M, p.Nout, p.resid, p.ldr, p.resid_row0);
+    if constexpr (F32R) f32_rows_epilogue<TM, TN>(acc, p.f32, m0 + wm * WM, n0 + wn * WN, p.M, p.Nout, p.resid, p.ldr, p.resid_row0);
     if (p.stat_part) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -336,8 +336,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
             const int m = ok[u] ? (p.omap ? s_orow[row] : mr) : 0;
             mo[u] = m;
             rok[u] = ok[u] && p.resid && m >= p.resid_row0;
-            uint32_t srow;
-            if (p.f32.out && f32_row(p.f32, m, srow)) rok[u] = false;      // residual already inside the staged value
+            if constexpr (F32R) {
+                uint32_t srow;
+                if (f32_row(p.f32, m, srow)) rok[u] = false;               // residual already inside the staged value
+            }
             L[u].rbits = 0xffu; L[u].bbits = 0u;
             if (rok[u]) {
                 L[u].r = ld16(p.resid + (int64_t)m * p.ldr + ecol);
