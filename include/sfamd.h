@@ -208,7 +208,7 @@ typedef struct sf_rows32 {
     int32_t ld, period;
 } sf_rows32;
 /* nn.Linear forward with the residual addition of the stream in its epilogue: Y = A W^T + bias + resid, side rows summed from
- * the fp32 accumulators (attention.py:393 proj, common.py:31 fc2 followed by attention.py:502 / :510).  N > 64. */
+ * the fp32 accumulators (attention.py:393 proj, common.py:31 fc2 followed by attention.py:502 / :510). */
 int sf_gemm_rows32(int64_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias,
                    const void* resid, int32_t ldr, void* Y, int32_t ldy, const sf_rows32* side, sf_stream_t stream);
 /* Batched "TN" GEMM  Out[z][r][c] = scale * sum_m P[z][m][r] * X[z][m][c]  (fp16 out): the attention gradients

@@ -148,12 +148,10 @@ static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s, int nbatc
     // 128-VGPR cap (4 workgroups per CU) for the 128-wide tile: +0.2..1.2 % end to end (profiles/r1_visit9_*_occ4.json);
     // SF_IGEMM_OCC4=0 restores the uncapped build for A/B runs
     static const bool occ4 = !(getenv("SF_IGEMM_OCC4") && atoi(getenv("SF_IGEMM_OCC4")) == 0);
-    if constexpr (BN == 128) {
-        if (p.f32.out) {            // fp32 side rows of the output (sf_gemm_rows32: plain [M, K] operands, N > 64)
-            if (igemm_glds_ok(p, pw)) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, true, true>), grid, dim3(SF_THREADS), 0, s, p);
-            else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, true, true>), grid, dim3(SF_THREADS), 0, s, p);
-            return;
-        }
+    if (p.f32.out) {                // fp32 side rows of the output (sf_gemm_rows32: plain [M, K] operands)
+        if (igemm_glds_ok(p, pw)) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, BN == 128, true>), grid, dim3(SF_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, BN == 128, true>), grid, dim3(SF_THREADS), 0, s, p);
+        return;
     }
     if (igemm_glds_ok(p, pw)) {
         hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, BN == 128>), grid, dim3(SF_THREADS), 0, s, p);
@@ -177,7 +175,7 @@ template <int BN, int BK>
 static void launch_igemm2(Igemm2Params& q, hipStream_t s) {
     q.ntiles_n = cdiv(q.Nout, BN);
     const dim3 grid((unsigned)(cdiv(q.M, 256) * q.ntiles_n));
-    if constexpr (BN == 128) {
+    if constexpr (BN >= 64) {       // (N <= 32 never reaches this kernel: try_igemm2)
         if (q.f32.out) { hipLaunchKernelGGL((sf_igemm2_kernel<256, BN, 4, 2, BK, 3, true>), grid, dim3(512), 0, s, q); return; }
     }
     hipLaunchKernelGGL((sf_igemm2_kernel<256, BN, 4, 2, BK, 3>), grid, dim3(512), 0, s, q);
@@ -1141,7 +1139,7 @@ static int bgemm_impl(int64_t M, int32_t N, int32_t K, const void* A, int32_t ld
     p.bh = bh; p.sa_b = sa_b; p.sa_h = sa_h; p.sw_b = sw_b; p.sw_h = sw_h; p.sy_b = sy_b; p.sy_h = sy_h;
     p.sr_b = sr_b; p.sr_h = sr_h; p.resid_row0 = resid_row0; p.alpha = alpha;
     if (side) {
-        REQUIRE(nbatch == 1 && N % 8 == 0 && N > 64, "sf_gemm_rows32: one GEMM, N %% 8 == 0, N > 64 (N=%d)", N);
+        REQUIRE(nbatch == 1 && N % 8 == 0, "sf_gemm_rows32: one GEMM, N %% 8 == 0 (N=%d)", N);
         if (rows32_arg("sf_gemm_rows32", side, M, N, true, p.f32)) return -1;
     }
     hipStream_t s = (hipStream_t)stream;

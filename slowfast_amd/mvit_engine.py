@@ -34,6 +34,7 @@ FUSE_COLSUM = os.environ.get("SF_FUSE_COLSUM", "1") != "0"
 # sums those rows from its fp32 accumulators (sf_gemm_rows32), the LayerNorms that read the stream normalise them from the fp32
 # copy.  The 16-bit rows are the rounded fp32 rows, so every other consumer (skip pooling, backward) is unchanged.
 RESID32 = os.environ.get("SF_MVIT_RESID32", "1") != "0"
+RESID32_FULL = os.environ.get("SF_MVIT_RESID32", "1") != "cls"      # "cls": class-token rows only, also in the last stage (A/B)
 
 
 class ResidSide:
@@ -510,7 +511,7 @@ class MultiScaleBlockFn(torch.autograd.Function):
         else:
             xres = xs
         Nq, Ca = plan.Nq, xres.shape[-1]
-        full = bool(getattr(mod, "_resid32_full", False))
+        full = bool(getattr(mod, "_resid32_full", False)) and RESID32_FULL
         s1 = side1 = None
         if side is not None:
             s1, side1 = _sum_side(rside if (rside is None or not full or rside.full32 is not None) else None,

@@ -646,7 +646,7 @@ def check_mvit_resid_side(name, device, drop_path=False):
                         blk.drop_path_rate = 0.2
                     x, thw = blk(x, thw, side)
                     if mode:
-                        assert (side.full32 is not None) == bool(blk._resid32_full), i
+                        assert (side.full32 is not None) == (bool(blk._resid32_full) and mvit_engine.RESID32_FULL), i
                         rows = side.cls_rows()
                         assert torch.equal(rows.to(x.dtype), x[:, 0]), f"block {i}: class-token row != round(fp32 side row)"
                         if side.full32 is not None:
