@@ -30,9 +30,10 @@ def _store_resid(x, prefix, which):
     return RESID_POLICY(x, int(prefix.split(".")[1]), which)
 
 
-def engine_resid_policy(cls_fp32=True, fp32_from_block=14):
+def engine_resid_policy(cls_fp32=True, fp32_from_block=10 ** 6):
     """The residual-stream storage of slowfast_amd.mvit_engine (round 4): the class-token row of both residual sums of every
-    block stays fp32 (a [B, C] side buffer), and blocks >= ``fp32_from_block`` keep the whole stream in fp32."""
+    block stays fp32 (a [B, C] side buffer); blocks >= ``fp32_from_block`` keep the whole stream in fp32 (the engine's
+    SF_MVIT_RESID32=full option: MViTv2-S blocks 14-15)."""
     def policy(x, i, which):
         if i >= fp32_from_block:
             return x

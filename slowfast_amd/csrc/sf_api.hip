@@ -1608,6 +1608,14 @@ extern "C" int sf_softmax_bwd(const sf_attn_desc* d, void* dp, const void* prob,
 
 // ------------------------------------------------------------------------------------------------
 // fused attention (sf_attn.h)
+// key tiles per wave of the key-side backward kernel: 2 (each Q / dO fragment read from LDS feeds two MFMAs) whenever the head has
+// more than 64 keys and the accumulators of two tiles fit the register file (head dim <= 96); SF_ATTN_DKV_KT=1|2 forces one
+static int attn_dkv_kt(const sf_attn_desc* d) {
+    static const int kt_env = getenv("SF_ATTN_DKV_KT") ? atoi(getenv("SF_ATTN_DKV_KT")) : 0;
+    if (d->D > 96) return 1;
+    if (kt_env == 1 || kt_env == 2) return kt_env;
+    return d->Nk > 64 ? 2 : 1;
+}
 static int fill_attn(AttnParams& p, const sf_attn_desc* d, const char* who) {
     REQUIRE(d, "%s: null descriptor", who);
     REQUIRE(d->B > 0 && d->heads > 0 && d->Nq > 0 && d->Nk > 0, "%s: empty problem", who);
@@ -1616,7 +1624,7 @@ static int fill_attn(AttnParams& p, const sf_attn_desc* d, const char* who) {
     memset(&p, 0, sizeof(p));
     p.B = d->B; p.heads = d->heads; p.Nq = d->Nq; p.Nk = d->Nk; p.cls = d->cls;
     p.R = d->kH + d->kW + d->kT;
-    p.qtiles = cdiv(d->Nq, 64); p.ktiles = cdiv(d->Nk, 64);
+    p.qtiles = cdiv(d->Nq, 64); p.ktiles = cdiv(d->Nk, 64 * attn_dkv_kt(d));
     REQUIRE((int64_t)d->B * d->heads * (p.qtiles > p.ktiles ? p.qtiles : p.ktiles) < (1ll << 28), "%s: too many tiles", who);
     // dK/dV: split the queries so that ~1024 workgroups exist (Nk is small), at least 8 query chunks per split
     const int nchq = cdiv(d->Nq, 32);
@@ -1721,12 +1729,15 @@ extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
         static const int occ = getenv("SF_ATTN_DKV_OCC") ? atoi(getenv("SF_ATTN_DKV_OCC")) : 2;
         const int grid = d->B * d->heads * p.ktiles * p.qsplits;
         const int kd = d->D / 32;
+        const int kt = attn_dkv_kt(d);
 #define SF_DKV(KD_)                                                                                              \
     do {                                                                                                         \
-        if (occ == 2) hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
-        else hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 3>), dim3(grid), dim3(SF_THREADS), 0, st, p);      \
+        if (kt == 2) hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 2, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
+        else if (occ == 2) hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 2, 1>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
+        else hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 3, 1>), dim3(grid), dim3(SF_THREADS), 0, st, p);   \
     } while (0)
-        if (kd == 1) SF_DKV(1); else if (kd == 2) SF_DKV(2); else if (kd == 3) SF_DKV(3); else SF_DKV(4);
+        if (kd == 1) SF_DKV(1); else if (kd == 2) SF_DKV(2); else if (kd == 3) SF_DKV(3);
+        else hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<4, 2, 1>), dim3(grid), dim3(SF_THREADS), 0, st, p);
 #undef SF_DKV
     }
     if (check_launch("attn_bwd_dkv")) return -1;

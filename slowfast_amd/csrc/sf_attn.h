@@ -433,9 +433,11 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, key side: workgroup = 64 keys of one (batch, head) x one split of the queries; wave w owns keys
-// 16w .. 16w+15 and walks the split's queries in chunks of 32
-template <int KD, int OCC>
+// backward, key side: workgroup = 64 * KT keys of one (batch, head) x one split of the queries; wave w owns KT tiles of 16 keys
+// (keys (w*KT + u)*16 .. +15) and walks the split's queries in chunks of 32.  KT = 2 (round 4): every Q / dO / rq fragment read
+// from LDS feeds TWO MFMAs (one per key tile), as QT = 2 does in the query-side kernels -- at KT = 1 this kernel read ~1 KB of
+// LDS per MFMA and took 2.3x the time of the query-side kernel for 8/6 of its flops (profiles/r3_final_mvit_kernel_stats.md).
+template <int KD, int OCC, int KT>
 __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 8, DT = D / 16;
     __shared__ __attribute__((aligned(16))) f16 Qs[32 * KP];
@@ -450,22 +452,25 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
     const int rest = (int)(bid / (uint32_t)p.qsplits);
     const int bh = rest / p.ktiles, kt = rest % p.ktiles;
     const int b = bh / p.heads, head = bh % p.heads;
-    const int key = kt * 64 + wave * 16 + pl;
-    const bool kok = key < p.Nk;
-    const int kc_ = kok ? key : p.Nk - 1;
-    const f16* kptr = p.k + ((int64_t)b * p.Nk + kc_) * p.ldk + head * D;
-    const f16* vptr = p.v + ((int64_t)b * p.Nk + kc_) * p.ldk + head * D;
-    f16x8 kf[KD], vf[KD];
-#pragma unroll
-    for (int s = 0; s < KD; ++s) {
-        kf[s] = attn_scale8(ld16(kptr + 32 * s + 8 * g), p.scale2);      // only S = Q K^T uses the wave's own key rows
-        vf[s] = ld16(vptr + 32 * s + 8 * g);
-    }
     const bool bias = p.R > 0, bias2 = p.R > 32;
-    f16x8 ohb[2] = {zero8(), zero8()};
-    if (bias) {
-        ohb[0] = ld16(p.oh + (int64_t)kc_ * 64 + 8 * g);
-        ohb[1] = ld16(p.oh + (int64_t)kc_ * 64 + 32 + 8 * g);
+    int key[KT];
+    f16x8 kf[KT][KD], vf[KT][KD], ohb[KT][2];
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+        key[u] = kt * 64 * KT + (wave * KT + u) * 16 + pl;
+        const int kc_ = key[u] < p.Nk ? key[u] : p.Nk - 1;
+        const f16* kptr = p.k + ((int64_t)b * p.Nk + kc_) * p.ldk + head * D;
+        const f16* vptr = p.v + ((int64_t)b * p.Nk + kc_) * p.ldk + head * D;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            kf[u][s] = attn_scale8(ld16(kptr + 32 * s + 8 * g), p.scale2);   // only S = Q K^T uses the wave's own key rows
+            vf[u][s] = ld16(vptr + 32 * s + 8 * g);
+        }
+        ohb[u][0] = ohb[u][1] = zero8();
+        if (bias) {
+            ohb[u][0] = ld16(p.oh + (int64_t)kc_ * 64 + 8 * g);
+            ohb[u][1] = ld16(p.oh + (int64_t)kc_ * 64 + 32 + 8 * g);
+        }
     }
     const f16* qbase = p.q + (int64_t)b * p.Nq * p.ldq + head * D;
     const f16* dobase = p.dout + (int64_t)b * p.Nq * p.ldo + head * D;
@@ -474,12 +479,14 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
     int c1 = c0 + p.chunks_per_split;
     if (c1 > nch_all) c1 = nch_all;
 
-    f32x4 dkacc[DT], dvacc[DT];
+    f32x4 dkacc[KT][DT], dvacc[KT][DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        dkacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dvacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int u = 0; u < KT; ++u)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            dkacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dvacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     RowChunk<D, KP> qc, oc;
     // per-chunk side inputs, prefetched into registers like the Q / dO rows: 8 rq values per thread (row tid >> 3,
     // columns 8 * (tid & 7) ..), log-sum-exp and delta of row tid (tid < 32)
@@ -534,64 +541,97 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             oc.load(dobase, p.ldo, (c + 1) * 32, p.Nq, tid);
             side_load(c + 1);
         }
-        f16x8 pf, dsf;
+        f16x8 pf[KT], dsf[KT];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            f32x4 st[KT], dp[KT];
+#pragma unroll
+            for (int u = 0; u < KT; ++u) {
+                st[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dp[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
-                st = SF_MFMA16(ld16(Qs + (16 * t + pl) * KP + 32 * s + 8 * g), kf[s], st);
-                dp = SF_MFMA16(ld16(Os + (16 * t + pl) * KP + 32 * s + 8 * g), vf[s], dp);
+                const f16x8 qa = ld16(Qs + (16 * t + pl) * KP + 32 * s + 8 * g);
+                const f16x8 oa = ld16(Os + (16 * t + pl) * KP + 32 * s + 8 * g);
+#pragma unroll
+                for (int u = 0; u < KT; ++u) {
+                    st[u] = SF_MFMA16(qa, kf[u][s], st[u]);
+                    dp[u] = SF_MFMA16(oa, vf[u][s], dp[u]);
+                }
             }
             if (bias) {
-                st = SF_MFMA16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], st);
-                st = SF_MFMA16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 8 * g), ohb[0], st);
+                const f16x8 rh0 = ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
+                const f16x8 rl0 = ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
+#pragma unroll
+                for (int u = 0; u < KT; ++u) {
+                    st[u] = SF_MFMA16(rh0, ohb[u][0], st[u]);
+                    st[u] = SF_MFMA16(rl0, ohb[u][0], st[u]);
+                }
                 if (bias2) {
-                    st = SF_MFMA16(ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], st);
-                    st = SF_MFMA16(ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g), ohb[1], st);
+                    const f16x8 rh1 = ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
+                    const f16x8 rl1 = ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
+#pragma unroll
+                    for (int u = 0; u < KT; ++u) {
+                        st[u] = SF_MFMA16(rh1, ohb[u][1], st[u]);
+                        st[u] = SF_MFMA16(rl1, ohb[u][1], st[u]);
+                    }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = 16 * t + 4 * g + r;
-                const float pv = c * 32 + qi < p.Nq ? SF_EXP2(st[r] - s_lse[qi]) : 0.f;
-                pf[4 * t + r] = (f16)pv;
-                dsf[4 * t + r] = (f16)(pv * (dp[r] - s_delta[qi]));
+                const bool qin = c * 32 + qi < p.Nq;
+                const float ls = s_lse[qi], de = s_delta[qi];
+#pragma unroll
+                for (int u = 0; u < KT; ++u) {
+                    const float pv = qin ? SF_EXP2(st[u][r] - ls) : 0.f;
+                    pf[u][4 * t + r] = (f16)pv;
+                    dsf[u][4 * t + r] = (f16)(pv * (dp[u][r] - de));
+                }
             }
         }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            dvacc[dt] = SF_MFMA16(attn_tr_frag(Os, KP, dt * 16, pl, g), pf, dvacc[dt]);
-            dkacc[dt] = SF_MFMA16(attn_tr_frag(Qs, KP, dt * 16, pl, g), dsf, dkacc[dt]);
+            const f16x8 ot = attn_tr_frag(Os, KP, dt * 16, pl, g);
+            const f16x8 qt_ = attn_tr_frag(Qs, KP, dt * 16, pl, g);
+#pragma unroll
+            for (int u = 0; u < KT; ++u) {
+                dvacc[u][dt] = SF_MFMA16(ot, pf[u], dvacc[u][dt]);
+                dkacc[u][dt] = SF_MFMA16(qt_, dsf[u], dkacc[u][dt]);
+            }
         }
     }
-    if (!kok) return;
-    if (p.qsplits > 1) {
-        const int64_t C = (int64_t)p.heads * D;
-        const int64_t slab = (int64_t)p.B * p.Nk * C;
-        float* pk = p.part + ((int64_t)split * 2) * slab + ((int64_t)b * p.Nk + key) * C + head * D;
-        float* pv_ = pk + slab;
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+        if (key[u] >= p.Nk) continue;
+        if (p.qsplits > 1) {
+            const int64_t C = (int64_t)p.heads * D;
+            const int64_t slab = (int64_t)p.B * p.Nk * C;
+            float* pk = p.part + ((int64_t)split * 2) * slab + ((int64_t)b * p.Nk + key[u]) * C + head * D;
+            float* pv_ = pk + slab;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d0 = dt * 16 + 4 * g;
+                *reinterpret_cast<f32x4*>(pk + d0) = dkacc[u][dt];
+                *reinterpret_cast<f32x4*>(pv_ + d0) = dvacc[u][dt];
+            }
+            continue;
+        }
+        f16* dkrow = p.dk + ((int64_t)b * p.Nk + key[u]) * p.lddk + head * D;
+        f16* dvrow = p.dv + ((int64_t)b * p.Nk + key[u]) * p.lddk + head * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = dt * 16 + 4 * g;
-            *reinterpret_cast<f32x4*>(pk + d0) = dkacc[dt];
-            *reinterpret_cast<f32x4*>(pv_ + d0) = dvacc[dt];
-        }
-        return;
-    }
-    f16* dkrow = p.dk + ((int64_t)b * p.Nk + key) * p.lddk + head * D;
-    f16* dvrow = p.dv + ((int64_t)b * p.Nk + key) * p.lddk + head * D;
+            f16x4 a, c2;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const int d0 = dt * 16 + 4 * g;
-        f16x4 a, c2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            a[r] = (f16)(dkacc[dt][r] * p.scale);
-            c2[r] = (f16)dvacc[dt][r];
+            for (int r = 0; r < 4; ++r) {
+                a[r] = (f16)(dkacc[u][dt][r] * p.scale);
+                c2[r] = (f16)dvacc[u][dt][r];
+            }
+            *reinterpret_cast<f16x4*>(dkrow + d0) = a;
+            *reinterpret_cast<f16x4*>(dvrow + d0) = c2;
         }
-        *reinterpret_cast<f16x4*>(dkrow + d0) = a;
-        *reinterpret_cast<f16x4*>(dvrow + d0) = c2;
     }
 }
 

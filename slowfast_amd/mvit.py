@@ -336,8 +336,9 @@ class MViT(nn.Module):
             tokens_out.append(math.prod(input_size))
             embed_dim = dim_out
         if not self.enable_rev:
-            # blocks from the last q-pooling block on (MViTv2-S: 14-15, 393 tokens) keep every row of the residual stream in
-            # fp32 next to the 16-bit tensor (mvit_engine.ResidSide) when that stage is small; before that only the class-token row
+            # SF_MVIT_RESID32=full: blocks from the last q-pooling block on (MViTv2-S: 14-15, 393 tokens) keep every row of the
+            # residual stream in fp32 next to the 16-bit tensor (mvit_engine.ResidSide) when that stage is small; otherwise
+            # (and by default everywhere) only the class-token row
             last_pool = max([i for i in range(depth) if len(stride_q[i]) > 0 and math.prod(stride_q[i]) > 1], default=None)
             for i, blk in enumerate(self.blocks):
                 blk._resid32_full = last_pool is not None and i >= last_pool and tokens_out[i] <= 1024

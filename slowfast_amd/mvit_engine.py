@@ -27,14 +27,17 @@ _f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.AC
 FUSE_COLSUM = os.environ.get("SF_FUSE_COLSUM", "1") != "0"
 
 
-# fp32 side copy of the residual stream (SF_MVIT_RESID32=0: everything in the 16-bit storage type, A/B runs): the reference adds
-# the two branch outputs of a MultiScaleBlock to an fp32 stream (attention.py:500-510; autocast does not touch additions).  Here
-# the stream is 16-bit storage with (a) the class-token row of every residual sum -- the only row the classifier reads -- and (b)
-# every row of the blocks of the last stage (393 tokens in MViTv2-S) ALSO kept in fp32: the GEMM epilogue that adds the residual
-# sums those rows from its fp32 accumulators (sf_gemm_rows32), the LayerNorms that read the stream normalise them from the fp32
-# copy.  The 16-bit rows are the rounded fp32 rows, so every other consumer (skip pooling, backward) is unchanged.
+# fp32 side copy of the residual stream: the reference adds the two branch outputs of a MultiScaleBlock to an fp32 stream
+# (attention.py:500-510; autocast does not touch additions).  Here the stream is 16-bit storage with the class-token row of every
+# residual sum -- the only row the classifier reads -- ALSO kept in fp32: the GEMM epilogue that adds the residual sums those rows
+# from its fp32 accumulators (sf_gemm_rows32), the LayerNorms that read the stream normalise them from the fp32 copy.  The 16-bit
+# rows are the rounded fp32 rows, so every other consumer (skip pooling, backward) is unchanged.
+# Measured on MI355X (profiles/r4_v1_mvit_resid32_ab.txt), MViTv2-S 16x224^2 full-size logits against the fp32 oracle:
+#   SF_MVIT_RESID32=0     16-bit stream only              1.192e-3   549.0 clips/s
+#   (default)             class-token rows                9.05e-4    547.9
+#   SF_MVIT_RESID32=full  + every row of the last stage   9.09e-4    545-546   (no measurable gain for 77 MB of fp32 rows: opt-in)
 RESID32 = os.environ.get("SF_MVIT_RESID32", "1") != "0"
-RESID32_FULL = os.environ.get("SF_MVIT_RESID32", "1") != "cls"      # "cls": class-token rows only, also in the last stage (A/B)
+RESID32_FULL = os.environ.get("SF_MVIT_RESID32", "1") == "full"
 
 
 class ResidSide:

@@ -452,9 +452,9 @@ def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99,
     res["masked_modules"] = len(table) if table else 0
     res["worst_params_unmasked"] = _worst_contributors(grads, o_grads)
     # Flat bound, no yardstick (round 4): the north star's 1e-3 on the logits of every case.  MViTv2-S at full size read
-    # 1.15-1.19e-3 while the whole residual stream was 16-bit; the class-token rows of every residual sum and every row of the
-    # last stage are now also kept in fp32 (mvit_engine.ResidSide; profiles/r4_mvit_logits_bisect.md has the oracle-side
-    # ablation of the same storage policy, mvit_ref.engine_resid_policy).
+    # 1.15-1.19e-3 while the whole residual stream was 16-bit; the class-token rows of every residual sum are now also kept in
+    # fp32 (mvit_engine.ResidSide): 9.05e-4 measured on MI355X (profiles/r4_v1_mvit_resid32_ab.txt; profiles/r4_mvit_logits_bisect.md
+    # has the oracle-side ablation of the same storage policy, mvit_ref.engine_resid_policy).
     b_logits = tol
     _record(preset + "@full", device, dict(res, bounds=dict({"logits_l2": b_logits, "loss": tol, "grad_norm": tol},
                                                             logits_max=2 * b_logits, grad_global_masked=gg_bound),
@@ -619,7 +619,7 @@ def check_eval(name, device, fused=False, tol=2e-3, report=None):
     return res
 
 
-def check_mvit_resid_side(name, device, drop_path=False):
+def check_mvit_resid_side(name, device, drop_path=False, full=False):
     """The fp32 side rows of the residual stream (mvit_engine.ResidSide) through every block of a golden MViT case: after each
     block the 16-bit class-token row of the stream must be EXACTLY the rounding of its fp32 copy (any block that drops, skips or
     mis-indexes the side rows breaks the equality), the last-stage blocks must carry every row, and the stream with side rows
@@ -632,8 +632,9 @@ def check_mvit_resid_side(name, device, drop_path=False):
     model = model.to(device).train()
     assert model.cls_embed_on and mvit_engine.RESID32
     outs = {}
+    was_full = mvit_engine.RESID32_FULL
     for mode in (True, False):
-        mvit_engine.RESID32 = mode
+        mvit_engine.RESID32, mvit_engine.RESID32_FULL = mode, full
         try:
             with torch.no_grad():
                 x, bcthw = model.patch_embed(inputs[0].to(device), model.cls_token, None)
@@ -653,7 +654,7 @@ def check_mvit_resid_side(name, device, drop_path=False):
                             assert torch.equal(side.full32.to(x.dtype), x), f"block {i}: stream != round(fp32 side rows)"
                 outs[mode] = x.float().cpu()
         finally:
-            mvit_engine.RESID32 = True
+            mvit_engine.RESID32, mvit_engine.RESID32_FULL = True, was_full
     scale = float(outs[False].abs().max())
     assert float((outs[True] - outs[False]).abs().max()) <= 64 * F16_EPS * scale
     return True

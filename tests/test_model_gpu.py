@@ -157,11 +157,12 @@ def test_mvit_matches_reference(gpu, name):
         print(name, rep.get(name))
 
 
+@pytest.mark.parametrize("full", [False, True])
 @pytest.mark.parametrize("drop_path", [False, True])
-def test_mvit_resid_side_rows(gpu, drop_path):
+def test_mvit_resid_side_rows(gpu, drop_path, full):
     """fp32 side rows of the residual stream (mvit_engine.ResidSide): class-token rows through every block, every row in the last
     stage; the 16-bit stream is exactly their rounding."""
-    mc.check_mvit_resid_side("mvit_tiny", gpu, drop_path=drop_path)
+    mc.check_mvit_resid_side("mvit_tiny", gpu, drop_path=drop_path, full=full)
 
 
 def test_mvit_full_size_properties(gpu):

@@ -22,10 +22,11 @@ def test_mvit_engine_matches_oracle(sim):
     mc.check_engine("mvit_tiny", sim, tol_logits=1e-2, tol_loss=2e-3, tol_gnorm=3e-3, tol_param=0.2, tol_global=2e-2)
 
 
+@pytest.mark.parametrize("full", [False, True])
 @pytest.mark.parametrize("drop_path", [False, True])
-def test_mvit_resid_side_rows(sim, drop_path):
+def test_mvit_resid_side_rows(sim, drop_path, full):
     """fp32 side rows of the residual stream: class-token rows through every block, every row in the last stage."""
-    mc.check_mvit_resid_side("mvit_tiny", sim, drop_path=drop_path)
+    mc.check_mvit_resid_side("mvit_tiny", sim, drop_path=drop_path, full=full)
 
 
 def test_x3d_engine_matches_oracle(sim):

@@ -21,7 +21,7 @@ def analyse(src_root):
     for line in err.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
-            name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", m.group(1)], capture_output=True, text=True).stdout.strip()
+            name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
             out[name] = {}
         for k in KEYS:
             if name and k in line:
