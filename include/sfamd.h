@@ -235,6 +235,18 @@ int sf_colsum(int64_t M, int32_t C, const void* x, int32_t ldx, float* part, sf_
  * `part` is scratch (folded in place) */
 int sf_colsum_finalize(float* part, int32_t nblk, int32_t C, int32_t fold, float* out0, float* out1, float scale,
                        int accumulate, sf_stream_t stream);
+/* n finalizes in one launch (the backward of a MultiScaleBlock ends in ~9: LayerNorm affine gradients, bias gradients;
+ * attention.py:428-514).  `items` is a HOST array, passed to the kernel by value; two items must not share an output; tables of
+ * more than 2048 partial rows go through sf_colsum_finalize. */
+typedef struct sf_colfin_item {
+    float* part;
+    int32_t nblk, C, fold;
+    float* out0;
+    float* out1;
+    float scale;
+    int32_t accumulate;
+} sf_colfin_item;
+int sf_colsum_finalize_batch(const sf_colfin_item* items, int32_t n, sf_stream_t stream);
 /* out[i] (+)= scale * sum_b part[b*row_len + offset + i] */
 int sf_rows_sum(const float* part, int32_t nblk, int64_t row_len, int64_t offset, int32_t n, float* out, float scale,
                 int accumulate, sf_stream_t stream);

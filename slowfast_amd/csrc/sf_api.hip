@@ -1339,6 +1339,30 @@ extern "C" int sf_colsum_finalize(float* part, int32_t nblk, int32_t C, int32_t 
 }
 
 // ---- GELU
+extern "C" int sf_colsum_finalize_batch(const sf_colfin_item* items, int32_t n, sf_stream_t stream) {
+    REQUIRE(items && n > 0, "sf_colsum_finalize_batch: no items");
+    for (int i0 = 0; i0 < n; i0 += SF_COLFIN_BATCH) {
+        ColFinalizeBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n - i0 < SF_COLFIN_BATCH ? n - i0 : SF_COLFIN_BATCH;
+        int threads = SF_FIN_SEG * SF_FIN_CH;
+        for (int i = 0; i < b.n; ++i) {
+            const sf_colfin_item& it = items[i0 + i];
+            REQUIRE(it.part && it.nblk > 0 && it.C > 0 && it.fold > 0 && it.C % it.fold == 0 && (it.out0 || it.out1),
+                    "sf_colsum_finalize_batch: bad item %d", i0 + i);
+            REQUIRE(it.nblk <= kFoldAbove || it.nblk <= 256, "sf_colsum_finalize_batch: item %d has %d partial rows (use sf_colsum_finalize)",
+                    i0 + i, it.nblk);
+            ColFinalizeParams& p = b.item[i];
+            p.part = it.part; p.nblk = it.nblk; p.row_stride = 1; p.C = it.C; p.fold = it.fold; p.out0 = it.out0; p.out1 = it.out1;
+            p.scale = it.scale; p.accumulate = it.accumulate;
+            b.first[i + 1] = b.first[i] + cdiv(it.fold, SF_FIN_CH);
+            if (sf_fin_threads(it.nblk) > threads) threads = sf_fin_threads(it.nblk);
+        }
+        hipLaunchKernelGGL(sf_colsum_finalize_batch_kernel, dim3(b.first[b.n]), dim3(threads), 0, (hipStream_t)stream, b);
+    }
+    return check_launch("colsum_finalize_batch");
+}
+
 extern "C" int sf_gelu_fwd(int64_t n, const void* h, void* a, sf_stream_t stream) {
     REQUIRE(h && a && n > 0 && n % 8 == 0, "sf_gelu_fwd: bad arguments");
     hipLaunchKernelGGL(sf_gelu_fwd_kernel, dim3(pool_grid(n / 8)), dim3(SF_THREADS), 0, (hipStream_t)stream,

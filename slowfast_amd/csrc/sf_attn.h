@@ -440,8 +440,11 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
 template <int KD, int OCC, int KT>
 __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 8, DT = D / 16;
-    __shared__ __attribute__((aligned(16))) f16 Qs[32 * KP];
-    __shared__ __attribute__((aligned(16))) f16 Os[32 * KP];      // dO rows
+    // Q and dO chunks travel global -> LDS directly (global_load_lds_dwordx4, two buffers): no staging registers -- the two key
+    // tiles of a wave need them for accumulators -- and no ds_write pass.  The padded [32][KP] image is made of SPR 16-byte slots
+    // per row (the last one is the pad): slot i of a matrix is written by lane i & 63 of copy instruction i >> 6.
+    constexpr int SPR = KP / 8, NS = 32 * SPR, NI = (NS + 63) / 64, MSZ = NI * 512;       // MSZ: halfs per matrix buffer
+    __shared__ __attribute__((aligned(16))) f16 QO[2 * 2 * MSZ];  // [buffer][Q | dO]
     __shared__ __attribute__((aligned(16))) f16 Rh[32 * SF_ATTN_OHP];   // rq rows (times log2 e), fp16 hi / lo parts
     __shared__ __attribute__((aligned(16))) f16 Rl[32 * SF_ATTN_OHP];
     __shared__ float s_lse[32], s_delta[32];
@@ -487,9 +490,34 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             dkacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             dvacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    RowChunk<D, KP> qc, oc;
-    // per-chunk side inputs, prefetched into registers like the Q / dO rows: 8 rq values per thread (row tid >> 3,
-    // columns 8 * (tid & 7) ..), log-sum-exp and delta of row tid (tid < 32)
+    // copy instructions of this wave: j = wave, wave + 4, ... < 2 * NI; j < NI copies Q slots, the others dO slots.  Per lane:
+    // the slot's row inside the chunk and its element offset in the source row (-1: pad slot -> zeros)
+    constexpr int NCP = (2 * NI + 3) / 4;
+    int cp_row[NCP], cp_off[NCP];
+#pragma unroll
+    for (int jj = 0; jj < NCP; ++jj) {
+        const int j = wave + 4 * jj, i = j < NI ? j : j - NI;
+        const int slot = i * 64 + lane, row = slot / SPR, col = slot - row * SPR;
+        cp_row[jj] = row;
+        cp_off[jj] = (slot < NS && col < D / 8) ? col * 8 : -1;
+    }
+    const f16* const zline = reinterpret_cast<const f16*>(sf_zero_line);
+    auto issue_chunk = [&](int c, int buf) {
+        f16* Qb = QO + buf * 2 * MSZ;
+#pragma unroll
+        for (int jj = 0; jj < NCP; ++jj) {
+            const int j = wave + 4 * jj;
+            if (j >= 2 * NI) continue;
+            const bool isq = j < NI;
+            const int qr = c * 32 + cp_row[jj];
+            const f16* src = zline;
+            if (cp_off[jj] >= 0 && qr < p.Nq)
+                src = (isq ? qbase + (int64_t)qr * p.ldq : dobase + (int64_t)qr * p.ldo) + cp_off[jj];
+            SF_GLOBAL_LOAD_LDS16_ASM(src, Qb + (isq ? 0 : MSZ) + (isq ? j : j - NI) * 512);
+        }
+    };
+    // per-chunk side inputs, prefetched into registers: 8 rq values per thread (row tid >> 3, columns 8 * (tid & 7) ..),
+    // log-sum-exp and delta of row tid (tid < 32)
     float rqv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lsev = 0.f, deltav = 0.f;
     const int rr = tid >> 3, j0 = (tid & 7) * 8;
     auto side_load = [&](int c) {
@@ -511,14 +539,14 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
         }
     };
     if (c0 < c1) {
-        qc.load(qbase, p.ldq, c0 * 32, p.Nq, tid);
-        oc.load(dobase, p.ldo, c0 * 32, p.Nq, tid);
+        issue_chunk(c0, 0);
         side_load(c0);
     }
     for (int c = c0; c < c1; ++c) {
-        __syncthreads();
-        qc.store(Qs, tid);
-        oc.store(Os, tid);
+        const int buf = (c - c0) & 1;
+        const f16* const Qs = QO + buf * 2 * MSZ;
+        const f16* const Os = Qs + MSZ;
+        __syncthreads();            // every wave is done with chunk c - 1: Rh / Rl and the other Q / dO buffer are free
         if (tid < 32) {
             s_lse[tid] = lsev;
             s_delta[tid] = deltav;
@@ -535,10 +563,10 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             st16(Rh + rr * SF_ATTN_OHP + j0, hi);
             st16(Rl + rr * SF_ATTN_OHP + j0, lo);
         }
-        __syncthreads();
+        SF_WAIT_VMEM();             // this wave's copies of chunk c have landed ...
+        __syncthreads();            // ... and everybody else's
         if (c + 1 < c1) {
-            qc.load(qbase, p.ldq, (c + 1) * 32, p.Nq, tid);
-            oc.load(dobase, p.ldo, (c + 1) * 32, p.Nq, tid);
+            issue_chunk(c + 1, buf ^ 1);
             side_load(c + 1);
         }
         f16x8 pf[KT], dsf[KT];

@@ -161,6 +161,10 @@ __device__ __forceinline__ void fd_divmod(uint32_t x, const FastDiv& f, uint32_t
     r = x - q * f.d;
 }
 
+// 64 bytes of zeros: the source of every direct-to-LDS copy that stands for padding (the module's own constant: the callee
+// allocates nothing)
+__device__ __attribute__((aligned(64))) const uint32_t sf_zero_line[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
 // ---------------------------------------------------------------------------------------------
 // fp32 side rows of a token residual stream (MultiScaleBlock's residual sums, attention.py:500-510):
 // rows m with m % period == 0 (period 1: every row) carry an fp32 copy at side row m / period, pitch ld floats.  The

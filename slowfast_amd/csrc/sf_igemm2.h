@@ -26,8 +26,7 @@
 #define SF_KEEP_ALIVE(x) asm volatile("" ::"v"(x))
 #endif
 
-// 16 bytes of zeros every padding tap reads (the module's own constant: the callee allocates nothing)
-__device__ __attribute__((aligned(64))) const uint32_t sf_zero_line[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// padding taps read sf_zero_line (sf_common.h)
 
 struct Igemm2Tap {
     int32_t dlin;       // linear source-position offset of the tap: (dt*sH + dh)*sW + dw

@@ -248,6 +248,41 @@ __global__ __launch_bounds__(SF_FIN_THREADS_MAX) void sf_colsum_finalize_kernel(
     }
 }
 
+// Several finalizes in ONE launch (round 4: a MultiScaleBlock backward ends in ~9 of them -- two LayerNorms, the three head-dim
+// LayerNorms of the pooled q / k / v, four bias gradients -- each a 6-7 us launch for a few KB of work; 149 per MViTv2-S step).
+// The descriptors travel BY VALUE in the kernel arguments (no device-side table to keep alive or to upload); block b serves item
+// i with first[i] <= b < first[i + 1].
+#define SF_COLFIN_BATCH 16
+struct ColFinalizeBatch {
+    ColFinalizeParams item[SF_COLFIN_BATCH];
+    int first[SF_COLFIN_BATCH + 1];
+    int n;
+};
+__global__ __launch_bounds__(SF_FIN_THREADS_MAX) void sf_colsum_finalize_batch_kernel(ColFinalizeBatch b) {
+    __shared__ double s_s[SF_FIN_SEG_MAX][SF_FIN_CH];
+    __shared__ double s_q[SF_FIN_SEG_MAX][SF_FIN_CH];
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.first[i + 1]) ++i;
+    const ColFinalizeParams& p = b.item[i];
+    const int cx = threadIdx.x % SF_FIN_CH, seg = threadIdx.x / SF_FIN_CH;
+    const int co = ((int)blockIdx.x - b.first[i]) * SF_FIN_CH + cx;
+    double s = 0.0, q = 0.0;
+    if (co < p.fold) {
+        for (int c = co; c < p.C; c += p.fold) {
+            double a, bb;
+            strided_col_sums(p.part, p.nblk, p.row_stride, p.C, c, seg, a, bb);
+            s += a;
+            q += bb;
+        }
+    }
+    fin_fold(s_s, s_q, seg, cx, s, q);
+    if (seg == 0 && co < p.fold) {
+        const float v0 = (float)(s * p.scale), v1 = (float)(q * p.scale);
+        if (p.out0) p.out0[co] = p.accumulate ? p.out0[co] + v0 : v0;
+        if (p.out1) p.out1[co] = p.accumulate ? p.out1[co] + v1 : v1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // GELU (exact, erf) on contiguous fp16 arrays; n8 = number of 8-element groups.
 __global__ __launch_bounds__(SF_THREADS) void sf_gelu_fwd_kernel(const f16* h, f16* a, int64_t n8) {

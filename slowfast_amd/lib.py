@@ -62,6 +62,13 @@ class Rows32(Structure):
     _fields_ = [("in_", c_void_p), ("out", c_void_p), ("ld", c_int32), ("period", c_int32)]
 
 
+class ColFinItem(Structure):
+    """Mirror of ``sf_colfin_item`` (one finalize of a batched sf_colsum_finalize_batch launch)."""
+
+    _fields_ = [("part", c_void_p), ("nblk", c_int32), ("C", c_int32), ("fold", c_int32), ("out0", c_void_p),
+                ("out1", c_void_p), ("scale", c_float), ("accumulate", c_int32)]
+
+
 class AttnDesc(Structure):
     """Mirror of ``sf_attn_desc``."""
 
@@ -124,6 +131,7 @@ _SIGNATURES = {
     "sf_colsum_blocks": (c_int, [c_int64, c_int32]),
     "sf_colsum": (c_int, [c_int64, c_int32, _P, c_int32, _F, _P]),
     "sf_colsum_finalize": (c_int, [_F, c_int32, c_int32, c_int32, _F, _F, c_float, c_int, _P]),
+    "sf_colsum_finalize_batch": (c_int, [POINTER(ColFinItem), c_int32, _P]),
     "sf_rows_sum": (c_int, [_F, c_int32, c_int64, c_int64, c_int32, _F, c_float, c_int, _P]),
     "sf_gelu_fwd": (c_int, [c_int64, _P, _P, _P]),
     "sf_gelu_bwd": (c_int, [c_int64, _P, _P, _P, _P]),

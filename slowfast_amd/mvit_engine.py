@@ -548,6 +548,14 @@ class MultiScaleBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        # the ~9 column-sum finalizes of the block (LayerNorm affine and bias gradients) leave as one launch at the end
+        with tokens.deferred_finalizes():
+            dx = MultiScaleBlockFn._backward(ctx, dout)
+        _notify(ctx.mod._param_list)
+        return (dx, None, None, None, None) + param_grads(ctx, 5)
+
+    @staticmethod
+    def _backward(ctx, dout):
         mod, plan, sv = ctx.mod, ctx.plan, ctx.sv
         att = mod.attn
         B = plan.B
@@ -585,9 +593,8 @@ class MultiScaleBlockFn(torch.autograd.Function):
         else:
             dx_skip = dxs
         dx = mod._norm1.backward(dxn, sv["x"], *sv["s1"], resid=dx_skip)
-        _notify(mod._param_list)
         ctx.sv = None
-        return (dx, None, None, None, None) + param_grads(ctx, 5)
+        return dx
 
 
 def _attention_sub_forward(sub, plan, x):

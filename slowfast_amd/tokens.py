@@ -10,7 +10,7 @@ import torch
 
 from . import lib as _sflib
 
-from .lib import AttnDesc, DwDesc, Rows32, SfError, get_lib
+from .lib import AttnDesc, ColFinItem, DwDesc, Rows32, SfError, get_lib
 from .ops import _ptr, _stream, _workspace
 
 _f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
@@ -182,7 +182,57 @@ def layernorm_fwd(x, gamma, beta, eps, out=None, save_stats=True, side=None):
     return y, mean, rstd
 
 
+# Deferred finalizes (SF_FIN_BATCH=0: every finalize is its own launch, A/B runs).  Inside ``with deferred_finalizes():`` the
+# column-sum finalizes of bias / LayerNorm-affine gradients are collected and issued as ONE sf_colsum_finalize_batch launch when
+# the context exits (mvit_engine wraps the backward of a block in it: ~9 launches of 6-7 us become one).  The partial tables
+# and outputs are kept alive by the pending list; two finalizes into the same output are never batched together.
+import os as _os
+_FIN_BATCH = _os.environ.get("SF_FIN_BATCH", "1") != "0"
+_pending_fin = None         # list of (ColFinItem fields..., tensors kept alive) while a deferral context is open
+_FIN_MAX_ROWS = 2048        # tables up to this many rows are batched (longer ones keep their own launch with its fold stage)
+
+
+class deferred_finalizes:
+    def __enter__(self):
+        global _pending_fin
+        self._outer = _pending_fin
+        if _FIN_BATCH and _pending_fin is None:
+            _pending_fin = []
+        return self
+
+    def __exit__(self, *exc):
+        global _pending_fin
+        if self._outer is None and _pending_fin is not None:
+            try:
+                if exc[0] is None:
+                    flush_finalizes()
+            finally:
+                _pending_fin = None
+        return False
+
+
+def flush_finalizes():
+    """Issue the collected finalizes (one launch per 16)."""
+    global _pending_fin
+    items = _pending_fin
+    if not items:
+        return
+    _pending_fin = []
+    arr = (ColFinItem * len(items))()
+    for i, (part, C, fold, out0, out1, scale, accumulate) in enumerate(items):
+        arr[i] = ColFinItem(part.data_ptr(), part.shape[0], C, fold, _ptr(out0), _ptr(out1), float(scale), int(accumulate))
+    _lib_call("sf_colsum_finalize_batch", arr, len(items), _stream(items[0][0]))
+
+
 def colsum_finalize(part, C, fold, out0, out1, scale=1.0, accumulate=False):
+    if _pending_fin is not None and part.shape[0] <= _FIN_MAX_ROWS:
+        outs = [o.data_ptr() for o in (out0, out1) if o is not None]
+        for it in _pending_fin:                         # a second contribution to the same output waits for the first
+            if any(o is not None and o.data_ptr() in outs for o in (it[3], it[4])):
+                flush_finalizes()
+                break
+        _pending_fin.append((part, C, fold, out0, out1, scale, accumulate))
+        return
     _lib_call("sf_colsum_finalize", part.data_ptr(), part.shape[0], C, fold, _ptr(out0), _ptr(out1), float(scale),
               int(accumulate), _stream(part))
 
