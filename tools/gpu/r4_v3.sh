@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 4 visit 3: where do the attention kernels (and the depthwise stencils) spend their cycles?  tools/token_bench.py at
+# MViTv2-S shapes under rocprofv3 --pmc (one counter group per pass; kernel-trace only beside it).
+cd "$GRAFT_REPO_ROOT"; D=gpurun_out/v3; mkdir -p $D; export TMPDIR=/tmp PYTHONPATH=$PWD
+timeout 300 python tools/token_bench.py --iters 10 2>&1 | tee $D/token_bench.txt
+SF_ATTN_DKV_KT=1 timeout 300 python tools/token_bench.py --iters 10 --only attn 2>&1 | sed 's/^/kt1 /' | tee -a $D/token_bench.txt
+cd /tmp
+R=$GRAFT_REPO_ROOT
+i=0
+for G in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
+         "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_SMEM" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA" \
+         "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_INST_CYCLES_VALU SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_LEVEL_SMEM" \
+         "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" \
+         "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 240 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $R/$D/pmc$i -o p -- python $R/tools/token_bench.py --iters 2 --only stage3 > /dev/null 2>&1; echo "pmc$i rc=$?"
+  FM=$(find $R/$D/pmc$i -name "*counter_collection.csv" | head -1)
+  python $R/tools/pmc_metric.py $R/$D/pmc$i.md "round 4 visit 3, token_bench.py --iters 2 --only stage3 (MViTv2-S stage-3 attention and pooling shapes, batch 32), pass $i" "$FM" > /dev/null 2>&1
+  grep -E "attn|dwconv|kernel \||---" $R/$D/pmc$i.md | cut -c1-260
+done
+cd $R; find $D -name "*.csv" -size +1M -delete
+echo "exit 0"
