@@ -821,6 +821,8 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
         q.dy = (const f16*)dy; q.ws = (float*)workspace;
         const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;    // read per call: tests switch it on mid-process
         if (trace) fprintf(stderr, "[sfamd] stem_wgrad: %d workgroups x %d tiles\n", sp.wg_blocks, sp.tiles_per_block);
+        static const bool stem_plain = getenv("SF_STEM_XCD") && atoi(getenv("SF_STEM_XCD")) == 0;
+        q.plain_order = stem_plain ? 1 : 0;
         if (d->Co <= 8 && sp.small) hipLaunchKernelGGL((sf_stem_wgrad_kernel<8, SF_STEM_CHUNKS_SMALL>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
         else if (d->Co <= 8) hipLaunchKernelGGL((sf_stem_wgrad_kernel<8, SF_STEM_CHUNKS>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
         else if (sp.small) hipLaunchKernelGGL((sf_stem_wgrad_kernel<16, SF_STEM_CHUNKS_SMALL>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
@@ -1400,6 +1402,9 @@ static int fill_dw(DwParams& p, const sf_dw_desc* d, bool rows_are_outputs, int 
     p.fdW = make_fastdiv(rows_are_outputs ? d->Wo : d->Wi);
     p.fdH = make_fastdiv(rows_are_outputs ? d->Ho : d->Hi);
     p.fdsT = make_fastdiv(d->sT); p.fdsH = make_fastdiv(d->sH); p.fdsW = make_fastdiv(d->sW);
+    // row blocks handed out XCD-contiguously (sf_dwconv.h: dw_block_id); SF_DW_XCD=0 keeps the plain order (A/B runs)
+    static const bool xcd = !(getenv("SF_DW_XCD") && atoi(getenv("SF_DW_XCD")) == 0);
+    p.xcd_order = xcd ? 1 : 0;
     return 0;
 }
 static const int kDwFwdBlocks = 2048, kDwWgradBlocks = 256;

@@ -15,14 +15,15 @@
 struct RowTile {
     int M, C;
     int rows_per_block;
-    __device__ __forceinline__ bool init(int& gcol, int& r0, int& r1, int& rstep) const {
+    // bx: the row block this workgroup takes (default blockIdx.x; stencil kernels pass an XCD-aware permutation of it)
+    __device__ __forceinline__ bool init(int& gcol, int& r0, int& r1, int& rstep, int bx = (int)blockIdx.x) const {
         const int G = C >> 3;
         const int TG = G < SF_THREADS ? G : SF_THREADS;
         const int rpi = SF_THREADS / TG;
         const int tx = threadIdx.x % TG, ty = threadIdx.x / TG;
         gcol = blockIdx.y * SF_THREADS + tx;
-        r0 = blockIdx.x * rows_per_block + ty;
-        r1 = (blockIdx.x + 1) * rows_per_block;
+        r0 = bx * rows_per_block + ty;
+        r1 = (bx + 1) * rows_per_block;
         if (r1 > M) r1 = M;
         rstep = rpi;
         return ty < rpi && gcol < G;

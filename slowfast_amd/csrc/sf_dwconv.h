@@ -28,7 +28,25 @@ struct DwParams {
     float* wpart;                   // wgrad: [gridDim.x][taps][C] per-block partial weight gradients
     FastDiv fdRow, fdW, fdH;        // row -> (n, r); r - cls -> (t, h, w) of the iterated space
     FastDiv fdsT, fdsH, fdsW;
+    int xcd_order;                  // 1: row blocks are handed out XCD-contiguously (dw_block_id)
 };
+
+// Row block of this workgroup.  Workgroup b runs on XCD b % 8 (sf_common.h: xcd_remap): with the plain order the row blocks of
+// neighbouring lines and frames -- which share most of their 3x3x3 input window -- sit behind eight different L2s, and every
+// input line is fetched by several of them (measured on the stage-3 pooling of MViTv2-S, profiles/r4_v3_pmc_tokens.md: L2 hit
+// rate 25 %, FETCH_SIZE 3.4x the input).  The remap gives every XCD a contiguous range of row blocks (whole samples), so a
+// window is re-read from ONE L2.  A bijection of the block ids: partial-sum tables are still folded in index order.
+// The weight-gradient grids carry the kt plane (or tap chunk) in blockIdx.z: the planes of one row block go to the same XCD.
+__device__ __forceinline__ int dw_block_id(const DwParams& p, int* bz = nullptr) {
+    if (!p.xcd_order || gridDim.y != 1) {
+        if (bz) *bz = (int)blockIdx.z;
+        return (int)blockIdx.x;
+    }
+    const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.z;          // dispatch order: XCD = lin % 8
+    const uint32_t r = xcd_remap(lin, gridDim.x * gridDim.z);
+    if (bz) *bz = (int)(r % gridDim.z);
+    return (int)(r / gridDim.z);
+}
 
 __device__ __forceinline__ void dw_stage_weights(const DwParams& p, float* s_w) {
     // LDS layout [tap][Cw] so that a thread's 8 channels are contiguous
@@ -69,8 +87,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_kernel(DwParams p) {
     __shared__ float s_red[SF_THREADS][17];
     dw_stage_weights(p, s_w);
     __syncthreads();
+    const int bx = dw_block_id(p);
     int gcol, r0, r1, rstep;
-    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const bool active = p.rt.init(gcol, r0, r1, rstep, bx);
     const int c = gcol * 8;
     const int cw = c % p.Cw;
     const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls;
@@ -119,7 +138,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_kernel(DwParams p) {
         }
     }
     if (p.stat_part)
-        rowtile_reduce_store(p.rt, active, c, ssum, ssq, p.stat_part + (int64_t)blockIdx.x * 2 * p.rt.C, s_red);
+        rowtile_reduce_store(p.rt, active, c, ssum, ssq, p.stat_part + (int64_t)bx * 2 * p.rt.C, s_red);
 }
 
 // dx[n, t, h, w, c] = sum_taps w[c][tap] * dy[n, (t + pT - kt)/sT, (h + pH - kh)/sH, (w + pW - kw)/sW, c]
@@ -129,8 +148,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_kernel(DwParams p)
     __shared__ float s_w[WSZ];
     dw_stage_weights(p, s_w);
     __syncthreads();
+    const int bx = dw_block_id(p);
     int gcol, r0, r1, rstep;
-    if (!p.rt.init(gcol, r0, r1, rstep)) return;
+    if (!p.rt.init(gcol, r0, r1, rstep, bx)) return;
     const int c = gcol * 8;
     const int cw = c % p.Cw;
     const int64_t So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
@@ -189,13 +209,15 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_kernel(DwParams p)
 // configs/Kinetics/MVIT_B_32x3_CONV.yaml, take 3 and 9 chunks, each re-reading dy).
 __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_kernel(DwParams p) {
     __shared__ float s_red[SF_THREADS][9];
+    int bz;
+    const int bx = dw_block_id(p, &bz);
     int gcol, r0, r1, rstep;
-    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const bool active = p.rt.init(gcol, r0, r1, rstep, bx);
     const int c = gcol * 8;
     const int nsp_all = p.kH * p.kW;
     const int nchunk = (nsp_all + 8) / 9;
-    const int kt = blockIdx.z / nchunk;
-    const int i0 = (blockIdx.z % nchunk) * 9;
+    const int kt = bz / nchunk;
+    const int i0 = (bz % nchunk) * 9;
     const int nsp = nsp_all - i0 < 9 ? nsp_all - i0 : 9;
     const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls;
     float acc[9][8];
@@ -238,7 +260,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_kernel(DwParams p)
             for (int e = 0; e < 8; ++e) s_red[threadIdx.x][e] = acc[i][e];
             __syncthreads();
             if (active && (int)threadIdx.x < TG) {
-                float* o = p.wpart + ((int64_t)blockIdx.x * taps + kt * nsp_all + i0 + i) * p.rt.C + c;
+                float* o = p.wpart + ((int64_t)bx * taps + kt * nsp_all + i0 + i) * p.rt.C + c;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float a = 0.f;
@@ -315,8 +337,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwPar
     __shared__ float s_red[SF_THREADS][17];
     dw_stage_weights_t(p, s_w);
     __syncthreads();
+    const int bx = dw_block_id(p);
     int gcol, r0, r1, rstep;
-    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const bool active = p.rt.init(gcol, r0, r1, rstep, bx);
     const int c = gcol * 8;
     const int cw = c % p.Cw;
     const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls, So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
@@ -396,7 +419,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_fwd_blocked_kernel(DwPar
         }
     }
     if (p.stat_part)
-        rowtile_reduce_store(p.rt, active, c, ssum, ssq, p.stat_part + (int64_t)blockIdx.x * 2 * p.rt.C, s_red);
+        rowtile_reduce_store(p.rt, active, c, ssum, ssq, p.stat_part + (int64_t)bx * 2 * p.rt.C, s_red);
 }
 
 // data gradient, blocked over 4 consecutive INPUT columns w0..w0+3 (w0 % 4 == 0).  With pW = KW/2 the output
@@ -414,8 +437,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_dgrad_blocked_kernel(DwP
     __shared__ __attribute__((aligned(16))) WT s_w[WSZ];
     dw_stage_weights_t(p, s_w);
     __syncthreads();
+    const int bx = dw_block_id(p);
     int gcol, r0, r1, rstep;
-    if (!p.rt.init(gcol, r0, r1, rstep)) return;
+    if (!p.rt.init(gcol, r0, r1, rstep, bx)) return;
     const int c = gcol * 8;
     const int cw = c % p.Cw;
     const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls, So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
@@ -498,10 +522,12 @@ __global__ __launch_bounds__(SF_THREADS, 3) void sf_dwconv_wgrad_blocked_kernel(
     __shared__ float s_red[SF_THREADS][9];
     const bool edge_free = (p.Wo % SF_DW_WB) == 0 && (p.Wo - SF_DW_WB) * SW - p.pW + NIN - 1 < p.Wi;   // block-uniform
     const f16* const zline = sf_dw_zero_line;
+    int bz;
+    const int bx = dw_block_id(p, &bz);
     int gcol, r0, r1, rstep;
-    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    const bool active = p.rt.init(gcol, r0, r1, rstep, bx);
     const int c = gcol * 8;
-    const int kt = blockIdx.z;
+    const int kt = bz;
     const int nsp = p.kH * KW;
     const int64_t Si = (int64_t)p.Ti * p.Hi * p.Wi + p.cls, So = (int64_t)p.To * p.Ho * p.Wo + p.cls;
     float acc[9][8];
@@ -571,7 +597,7 @@ __global__ __launch_bounds__(SF_THREADS, 3) void sf_dwconv_wgrad_blocked_kernel(
             for (int e = 0; e < 8; ++e) s_red[threadIdx.x][e] = acc[i][e];
             __syncthreads();
             if (active && (int)threadIdx.x < TG) {
-                float* o = p.wpart + ((int64_t)blockIdx.x * taps + kt * nsp + i) * p.rt.C + c;
+                float* o = p.wpart + ((int64_t)bx * taps + kt * nsp + i) * p.rt.C + c;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float a = 0.f;

@@ -60,6 +60,7 @@ struct StemParams {
     float* ws; int Kpad;              // per-workgroup slab [16][Kpad] fp32
     int tiles_per_block;
     int wgroups;                      // > 1 (few slices): wave w works on slice w % nsl for the tile rows of group w / nsl; one slab per group
+    int plain_order;                  // weight gradient: 1 = workgroup b takes tile run b (SF_STEM_XCD=0, A/B); 0 = XCD-contiguous
 };
 
 struct StemTile { int n, t0, h0, w0; };
@@ -272,7 +273,10 @@ __global__ __launch_bounds__(SF_STEM_WG_THREADS, 4) void sf_stem_wgrad_kernel(St
     const int cchunk = 4 * (pl & 3);
     const int frame_step = p.sT * p.PR * SF_STEM_PC;
 
-    const int tile_begin = blockIdx.x * p.tiles_per_block;
+    // XCD-contiguous block order (sf_common.h: xcd_remap): a block takes a run of consecutive tiles, but the tile that shares a
+    // patch's 4-frame temporal halo is tiles_w * tiles_h tiles away -- with the plain order behind another XCD's L2
+    const int bxs = p.plain_order ? (int)blockIdx.x : (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_begin = bxs * p.tiles_per_block;
     int tile_end = tile_begin + p.tiles_per_block;
     if (tile_end > p.ntiles) tile_end = p.ntiles;
     for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(SF_STEM_WG_THREADS, 4) void sf_stem_wgrad_kernel(St
         }
     }
     // slab[co][k]: co = 4*g4 + r, k = s*32 + 16*jh + pl
-    float* slab = p.ws + ((int64_t)blockIdx.x * ng + grp) * 16 * p.Kpad;
+    float* slab = p.ws + ((int64_t)bxs * ng + grp) * 16 * p.Kpad;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int s = sw + NW * q;
