@@ -7,6 +7,7 @@
 #include "sf_wgrad2.h"
 #include "sf_pool.h"
 #include "sf_dwconv.h"
+#include "sf_dwtile.h"
 #include "sf_tokens.h"
 #include "sf_x3d.h"
 #include "sf_stem.h"
@@ -1440,6 +1441,65 @@ static void dw_block_plan(DwParams& p, DwBlockIdx& bi, const sf_dw_desc* d, bool
         else if ((kind) == 2) hipLaunchKernelGGL((KERNEL<3, 2, SF_DW_MAX_W, f16>), grid, dim3(SF_THREADS), 0, s, p, bi); \
         else hipLaunchKernelGGL((KERNEL<1, 1, SF_DW_SMALL_W, float>), grid, dim3(SF_THREADS), 0, s, p, bi);             \
     } while (0)
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled plane sweep (sf_dwtile.h) for the 3x3x3 / padding 1 / stride (1, s, s) depthwise convolutions of the MViT pooling
+// path, forward and data gradient.  Taken when the geometry fits (32-channel chunks inside one weight group, no BatchNorm
+// statistics epilogue); SF_DW_TILED=0 keeps the W-blocked stencils (A/B runs).  mode 0: forward, 1: data gradient.
+static bool dwtile_plan(const sf_dw_desc* d, int mode, DwTileParams& p, int& np) {
+    static const bool off = getenv("SF_DW_TILED") && atoi(getenv("SF_DW_TILED")) == 0;
+    if (off) return false;
+    if (d->kT != 3 || d->kH != 3 || d->kW != 3 || d->pT != 1 || d->pH != 1 || d->pW != 1) return false;
+    if (d->sT != 1 || d->sH != d->sW || (d->sH != 1 && d->sH != 2)) return false;
+    if (d->Cw % SF_DWT_CC != 0 || d->C % SF_DWT_CC != 0 || d->To != d->Ti) return false;
+    memset(&p, 0, sizeof(p));
+    p.N = d->N; p.C = d->C; p.Cw = d->Cw; p.Cwreal = d->Cwreal ? d->Cwreal : d->Cw; p.cls = d->cls ? 1 : 0; p.T = d->Ti;
+    if (mode == 0) {
+        p.Hs = d->Hi; p.Ws = d->Wi; p.Hd = d->Ho; p.Wd = d->Wo; p.Hg = d->Hi; p.Wg = d->Wi; p.s = d->sH;
+    } else {
+        p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->Hi; p.Wd = d->Wi; p.Hg = d->Hi; p.Wg = d->Wi; p.s = 1; p.flip = 1;
+        p.ups = d->sH == 2 ? 1 : 0;
+    }
+    p.CT = p.Wg + 2;
+    p.nchunks = d->C / SF_DWT_CC;
+    double best = 0.0;
+    int best_th = 0;
+    const char* e = getenv("SF_DWT_TH");            // tests force a row-tile height (read per call)
+    const int force_th = e ? atoi(e) : 0;
+    for (int th = p.Hd < 64 ? p.Hd : 64; th >= 1; --th) {
+        if (force_th > 0 && th != (force_th < p.Hd ? force_th : p.Hd)) continue;
+        const int rt = th * p.s + 2;
+        if ((int64_t)rt * p.CT * SF_DWT_CC > SF_DWT_PLANE || (int64_t)rt * p.CT * SF_DWT_G > SF_THREADS * SF_DWT_VPT) continue;
+        const int P = th * p.Wd, npk = cdiv(P, SF_DWT_PT);
+        if (npk > SF_DWT_NPMAX) continue;
+        const int tiles = cdiv(p.Hd, th);
+        const int npt = npk == 3 ? 4 : npk;                           // compiled for 1, 2, 4 positions per thread
+        const double eff = (double)p.Hd * p.Wd / ((double)tiles * npt * SF_DWT_PT);
+        const double halo = (double)(th * p.s) / rt;
+        const double blocks = (double)d->N * tiles * p.nchunks;
+        const double bal = blocks >= 768 ? 1.0 : blocks / 768.0;
+        const double score = eff * halo * bal;
+        if (score > best) { best = score; best_th = th; }
+    }
+    if (!best_th) return false;
+    p.TH = best_th; p.RT = best_th * p.s + 2;
+    p.tiles_h = cdiv(p.Hd, best_th);
+    np = cdiv(best_th * p.Wd, SF_DWT_PT);
+    if (np == 3) np = 4;
+    p.fdCT = make_fastdiv(p.CT); p.fdWd = make_fastdiv(p.Wd); p.fdG = make_fastdiv(SF_DWT_G);
+    const int64_t per_n_src = ((int64_t)p.T * p.Hs * p.Ws + p.cls), per_n_dst = ((int64_t)p.T * p.Hd * p.Wd + p.cls);
+    if (per_n_src * (mode == 0 ? d->ldx : d->ldy) >= (1ll << 31) || per_n_dst * (mode == 0 ? d->ldy : d->ldx) >= (1ll << 31)) return false;
+    return true;
+}
+static void dwtile_launch(DwTileParams& p, int np, hipStream_t s) {
+    const dim3 grid((unsigned)(p.N * p.tiles_h * p.nchunks));
+    static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+    if (trace) fprintf(stderr, "[sfamd] dwtile: N=%d C=%d T=%d %dx%d -> %dx%d s=%d ups=%d TH=%d tiles=%d NP=%d blocks=%u\n", p.N, p.C, p.T,
+                       p.Hs, p.Ws, p.Hd, p.Wd, p.s, p.ups, p.TH, p.tiles_h, np, grid.x);
+    if (np == 1) hipLaunchKernelGGL(sf_dwtile_kernel<1>, grid, dim3(SF_THREADS), 0, s, p);
+    else if (np == 2) hipLaunchKernelGGL(sf_dwtile_kernel<2>, grid, dim3(SF_THREADS), 0, s, p);
+    else hipLaunchKernelGGL(sf_dwtile_kernel<4>, grid, dim3(SF_THREADS), 0, s, p);
+}
+
 extern "C" int sf_dwconv_fwd_blocks(const sf_dw_desc* d) {
     DwParams p;
     dim3 grid;
@@ -1456,6 +1516,15 @@ extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w,
     dim3 grid;
     if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
     REQUIRE(x && w && y, "sf_dwconv_fwd: null pointer");
+    {
+        DwTileParams tp;
+        int np;
+        if (!stat_part && dwtile_plan(d, 0, tp, np)) {
+            tp.src = (const f16*)x; tp.ld_src = d->ldx; tp.dst = (f16*)y; tp.ld_dst = d->ldy; tp.w = w;
+            dwtile_launch(tp, np, (hipStream_t)stream);
+            return check_launch("dwconv_fwd (tiled)");
+        }
+    }
     p.x = (const f16*)x; p.ldx = d->ldx; p.w = w; p.y = (f16*)y; p.ldy = d->ldy; p.stat_part = stat_part;
     const int kind = dw_blocked_kind(d);
     if (kind) {
@@ -1475,6 +1544,15 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
     dim3 grid;
     if (fill_dw(p, d, false, 8192, grid)) return -1;
     REQUIRE(dy && w && dx, "sf_dwconv_dgrad: null pointer");
+    {
+        DwTileParams tp;
+        int np;
+        if (dwtile_plan(d, 1, tp, np)) {
+            tp.src = (const f16*)dy; tp.ld_src = d->ldy; tp.dst = (f16*)dx; tp.ld_dst = d->ldx; tp.w = w;
+            dwtile_launch(tp, np, (hipStream_t)stream);
+            return check_launch("dwconv_dgrad (tiled)");
+        }
+    }
     p.dy = (const f16*)dy; p.lddy = d->ldy; p.w = w; p.y = (f16*)dx; p.ldy = d->ldx;
     const int kind = dw_blocked_kind(d);
     if (kind) {

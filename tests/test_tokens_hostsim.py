@@ -46,6 +46,24 @@ def test_dwconv_tokens(sim):
     tc.check_dwconv(sim, 1, 1, 16, (2, 17, 17), (1, 9, 9), (1, 8, 8), cls=1)
 
 
+def test_dwconv_tiled_plane_sweep(sim, monkeypatch):
+    """LDS-tiled plane sweep (sf_dwtile.h): 32-channel chunks, strides 1 and 2 (forward, data gradient incl. the zero-upsampled
+    stride-2 form), partial last row tiles, odd extents, 1 / 2 / 4 positions per thread."""
+    import io, contextlib
+    monkeypatch.setenv("SF_TRACE", "1")
+    tc.check_dwconv(sim, 2, 2, 32, (3, 6, 6), (3, 3, 3), (1, 1, 1), cls=1)       # one tile, NP = 1
+    tc.check_dwconv(sim, 1, 1, 32, (2, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)     # MViT stage-3 plane, NP = 2 / 4
+    tc.check_dwconv(sim, 1, 1, 64, (3, 14, 14), (3, 3, 3), (1, 2, 2), cls=1)     # 14 -> 7, two chunks
+    tc.check_dwconv(sim, 1, 2, 32, (2, 7, 9), (3, 3, 3), (1, 2, 2), cls=0)       # odd extents: 7x9 -> 4x5, no cls
+    tc.check_dwconv(sim, 1, 1, 32, (1, 5, 30), (3, 3, 3), (1, 1, 1), cls=1)      # wide rows: several row tiles, T = 1
+    tc.check_dwconv(sim, 1, 1, 96, (4, 12, 12), (3, 3, 3), (1, 2, 2), cls=1)     # head width 96 (three chunks of one weight group)
+    monkeypatch.setenv("SF_DWT_TH", "7")                                         # 98 positions per tile: 2 per thread
+    tc.check_dwconv(sim, 1, 1, 32, (2, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
+    monkeypatch.setenv("SF_DWT_TH", "14")                                        # 196 positions: 4 per thread (3 rounds up)
+    tc.check_dwconv(sim, 1, 1, 32, (2, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
+    tc.check_dwconv(sim, 1, 1, 32, (2, 14, 14), (3, 3, 3), (1, 2, 2), cls=1)
+
+
 def test_token_pool(sim):
     tc.check_token_pool(sim, 2, 16, (2, 6, 6), (1, 2, 2))
     tc.check_token_pool(sim, 1, 8, (3, 5, 7), (1, 2, 2))
