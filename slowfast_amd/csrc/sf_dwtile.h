@@ -157,30 +157,35 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_kernel(DwTileParams p) {
         }
         __syncthreads();
         if (tin + 1 < p.T) prefetch(tin + 1);          // in flight under the sweep of plane tin
+        // One (kh, kw) tap per iteration of a ROLLED loop: the neighbour of every position (NP x 8 floats) and the three
+        // temporal weights of the tap (24 floats) are read from LDS, 3 x NP x 4 packed FMAs follow.  Unrolled, hipcc hoists all
+        // 27 x 8 weights and 9 x NP x 8 neighbours of a plane above the FMAs (256 VGPRs + 102 AGPRs at NP = 1: one wave per
+        // SIMD); the weights are also loop-invariant over the planes, so their address is laundered once per plane.
+        int wz = cg * 8;
+        SF_CONSUME_V(wz);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const int doffs = kh * rowf + kw * SF_DWT_CC;
+            float d[NP][8];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
+            for (int k = 0; k < NP; ++k) {
+                const float* src = s_plane + lbase[k] + doffs;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                float d[NP][8];
+                for (int e = 0; e < 4; ++e) { d[k][e] = a[e]; d[k][4 + e] = b[e]; }
+            }
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    const float* src = s_plane + lbase[k] + kh * rowf + kw * SF_DWT_CC;
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+            for (int kt = 0; kt < 3; ++kt) {
+                const float* wp = s_w + wz + (kt * 9 + tap) * SF_DWT_CC;
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(wp), wb = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { d[k][e] = a[e]; d[k][4 + e] = b[e]; }
-                }
+                for (int k = 0; k < NP; ++k)
 #pragma unroll
-                for (int kt = 0; kt < 3; ++kt) {
-                    const float* wp = s_w + (kt * 9 + kh * 3 + kw) * SF_DWT_CC + cg * 8;
-                    const f32x4 wa = *reinterpret_cast<const f32x4*>(wp), wb = *reinterpret_cast<const f32x4*>(wp + 4);
-#pragma unroll
-                    for (int k = 0; k < NP; ++k)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc[2 - kt][k][e] += d[k][e] * wa[e];
-                            acc[2 - kt][k][4 + e] += d[k][4 + e] * wb[e];
-                        }
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 - kt][k][e] += d[k][e] * wa[e];
+                        acc[2 - kt][k][4 + e] += d[k][4 + e] * wb[e];
+                    }
             }
         }
         if (tin >= 1) emit(tin - 1);
