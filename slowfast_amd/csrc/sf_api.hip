@@ -1446,8 +1446,11 @@ static void dw_block_plan(DwParams& p, DwBlockIdx& bi, const sf_dw_desc* d, bool
 // path, forward and data gradient.  Taken when the geometry fits (32-channel chunks inside one weight group, no BatchNorm
 // statistics epilogue); SF_DW_TILED=0 keeps the W-blocked stencils (A/B runs).  mode 0: forward, 1: data gradient.
 static bool dwtile_plan(const sf_dw_desc* d, int mode, DwTileParams& p, int& np) {
-    static const bool off = getenv("SF_DW_TILED") && atoi(getenv("SF_DW_TILED")) == 0;
-    if (off) return false;
+    // SF_DW_TILED: 0 = never, 1 (default) = stride-1 geometries (where it measured faster: profiles/r4_v5_dwtile_ab.txt), 2 = also
+    // the stride-2 forward and the zero-upsampled stride-2 data gradient
+    const char* lv = getenv("SF_DW_TILED");        // read per call (tests switch it mid-process)
+    const int lvl = lv ? atoi(lv) : 1;
+    if (lvl == 0 || (lvl == 1 && d->sH != 1)) return false;
     if (d->kT != 3 || d->kH != 3 || d->kW != 3 || d->pT != 1 || d->pH != 1 || d->pW != 1) return false;
     if (d->sT != 1 || d->sH != d->sW || (d->sH != 1 && d->sH != 2)) return false;
     if (d->Cw % SF_DWT_CC != 0 || d->C % SF_DWT_CC != 0 || d->To != d->Ti) return false;
@@ -1468,7 +1471,7 @@ static bool dwtile_plan(const sf_dw_desc* d, int mode, DwTileParams& p, int& np)
     for (int th = p.Hd < 64 ? p.Hd : 64; th >= 1; --th) {
         if (force_th > 0 && th != (force_th < p.Hd ? force_th : p.Hd)) continue;
         const int rt = th * p.s + 2;
-        if ((int64_t)rt * p.CT * SF_DWT_CC > SF_DWT_PLANE || (int64_t)rt * p.CT * SF_DWT_G > SF_THREADS * SF_DWT_VPT) continue;
+        if ((int64_t)rt * p.CT * SF_DWT_PP > SF_DWT_PLANE || (int64_t)rt * p.CT * SF_DWT_G > SF_THREADS * SF_DWT_VPT) continue;
         const int P = th * p.Wd, npk = cdiv(P, SF_DWT_PT);
         if (npk > SF_DWT_NPMAX) continue;
         const int tiles = cdiv(p.Hd, th);

@@ -23,6 +23,9 @@
 #define SF_DWT_CC 32                            // channels per workgroup
 #define SF_DWT_G (SF_DWT_CC / 8)                // 16-byte channel groups per position
 #define SF_DWT_PT (SF_THREADS / SF_DWT_G)       // position threads per workgroup
+#define SF_DWT_PP 48                            // floats per staged position: 32 channels as [half][channel group][4] + 16 of
+                                                // padding -- 192 B, so that the 16 lanes of every ds_read_b128 group (positions
+                                                // p, p+3, p+5, p+6 x 4 channel groups) hit 16 distinct 16-byte bank slots
 #define SF_DWT_PLANE 12288                      // floats of LDS for one plane tile (48 KiB)
 #define SF_DWT_VPT 6                            // 16-byte vectors a thread stages per plane (rows * cols * G <= 256 * VPT)
 #define SF_DWT_NPMAX 4                          // output positions per thread
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_kernel(DwTileParams p) {
             uint32_t pos, cgv, i, j;
             fd_divmod((uint32_t)v, p.fdG, pos, cgv);
             fd_divmod(pos, p.fdCT, i, j);
-            st_lds[u] = (int)pos * SF_DWT_CC + (int)cgv * 8;
+            st_lds[u] = (int)pos * SF_DWT_PP + (int)cgv * 4;
             const int gr = r0 * p.s - 1 + (int)i, gc = (int)j - 1;
             bool ok = (unsigned)gr < (unsigned)p.Hg && (unsigned)gc < (unsigned)p.Wg;
             int sr = gr, sc = gc;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_kernel(DwTileParams p) {
         fd_divmod((uint32_t)q, p.fdWd, r, wq);
         pok[k] = q < P && r0 + (int)r < p.Hd;
         if (!pok[k]) { r = 0; wq = 0; }
-        lbase[k] = ((int)r * p.s * p.CT + (int)wq * p.s) * SF_DWT_CC + cg * 8;
+        lbase[k] = ((int)r * p.s * p.CT + (int)wq * p.s) * SF_DWT_PP + cg * 4;
         doff[k] = ((r0 + (int)r) * p.Wd + (int)wq) * p.ld_dst + c0 + cg * 8;
     }
     f16* const dst_n = p.dst + ((int64_t)n * Sd + p.cls) * p.ld_dst;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_kernel(DwTileParams p) {
     };
 
     prefetch(0);
-    const int rowf = p.CT * SF_DWT_CC;      // floats per staged row
+    const int rowf = p.CT * SF_DWT_PP;      // floats per staged row
     for (int tin = 0; tin < p.T; ++tin) {
         __syncthreads();                    // every thread is done reading plane tin - 1 (and the weights are staged)
 #pragma unroll
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_kernel(DwTileParams p) {
                 float f[8];
                 dwt_cvt8(pre[u], f);
                 *reinterpret_cast<f32x4*>(s_plane + st_lds[u]) = (f32x4){f[0], f[1], f[2], f[3]};
-                *reinterpret_cast<f32x4*>(s_plane + st_lds[u] + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+                *reinterpret_cast<f32x4*>(s_plane + st_lds[u] + 16) = (f32x4){f[4], f[5], f[6], f[7]};
             }
         }
         __syncthreads();
@@ -166,12 +169,12 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_kernel(DwTileParams p) {
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int kh = tap / 3, kw = tap - 3 * kh;
-            const int doffs = kh * rowf + kw * SF_DWT_CC;
+            const int doffs = kh * rowf + kw * SF_DWT_PP;
             float d[NP][8];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const float* src = s_plane + lbase[k] + doffs;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 16);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { d[k][e] = a[e]; d[k][4 + e] = b[e]; }
             }

@@ -49,8 +49,8 @@ def test_dwconv_tokens(sim):
 def test_dwconv_tiled_plane_sweep(sim, monkeypatch):
     """LDS-tiled plane sweep (sf_dwtile.h): 32-channel chunks, strides 1 and 2 (forward, data gradient incl. the zero-upsampled
     stride-2 form), partial last row tiles, odd extents, 1 / 2 / 4 positions per thread."""
-    import io, contextlib
-    monkeypatch.setenv("SF_TRACE", "1")
+    monkeypatch.setenv("SF_DW_TILED", "2")      # also the stride-2 forms (the library's statics are read on first use: the
+    # fixture loads a fresh library handle per test, the env is read again)
     tc.check_dwconv(sim, 2, 2, 32, (3, 6, 6), (3, 3, 3), (1, 1, 1), cls=1)       # one tile, NP = 1
     tc.check_dwconv(sim, 1, 1, 32, (2, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)     # MViT stage-3 plane, NP = 2 / 4
     tc.check_dwconv(sim, 1, 1, 64, (3, 14, 14), (3, 3, 3), (1, 2, 2), cls=1)     # 14 -> 7, two chunks
