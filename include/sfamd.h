@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 20
+#define SF_ABI_VERSION 21
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -292,6 +292,13 @@ int sf_relpos_gather(const sf_attn_desc* d, const void* G, int32_t ldg, const in
                      const int32_t* idx_t, float* rq, sf_stream_t stream);
 int sf_relpos_scatter(const sf_attn_desc* d, const float* drq, const int32_t* idx_h, const int32_t* idx_w,
                       const int32_t* idx_t, void* E, int32_t lde, sf_stream_t stream);
+/* The concatenated table Tab = [rel_pos_h; rel_pos_w; rel_pos_t] (fp32 parameters, D columns) as 16-bit GEMM operands:
+ * t16 [TRp][D] (rows beyond the tables zero, TRp % 8 == 0) and t16t = t16^T [D][TRp]; and back: rows of dtab [TRp][D] fp32
+ * into the three parameter gradients (acc_*: accumulate instead of overwrite). */
+int sf_relpos_pack(const float* rel_h, const float* rel_w, const float* rel_t, int32_t rows_h, int32_t rows_w, int32_t rows_t,
+                   int32_t D, int32_t TRp, void* t16, void* t16t, sf_stream_t stream);
+int sf_relpos_unpack(const float* dtab, int32_t rows_h, int32_t rows_w, int32_t rows_t, int32_t D, float* grad_h, float* grad_w,
+                     float* grad_t, int32_t acc_h, int32_t acc_w, int32_t acc_t, sf_stream_t stream);
 /* in place: s <- softmax_k(scale*s + bias), bias from rq (NULL = none); pad columns [Nk, lds) <- 0 */
 int sf_softmax_fwd(const sf_attn_desc* d, void* s, int32_t lds, float scale, const float* rq, sf_stream_t stream);
 /* in place: dp <- scale * P*(dp - sum_k P*dp); drq (optional) <- per-(kh|kw|kt) sums of the unscaled dS */

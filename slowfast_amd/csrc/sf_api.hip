@@ -1635,9 +1635,35 @@ extern "C" int sf_relpos_gather(const sf_attn_desc* d, const void* G, int32_t ld
     REQUIRE(G && idx_h && idx_w && idx_t && rq, "sf_relpos_gather: null pointer");
     REQUIRE(ldg >= d->rows_h + d->rows_w + d->rows_t, "sf_relpos_gather: pitch smaller than the table row count");
     p.idx_h = idx_h; p.idx_w = idx_w; p.idx_t = idx_t; p.rq = rq;
-    hipLaunchKernelGGL(sf_relpos_gather_kernel, dim3(relpos_blocks(d)), dim3(SF_THREADS), 0, (hipStream_t)stream, p,
-                       (const f16*)G, ldg);
+    const int R = d->kH + d->kW + d->kT;
+    const int64_t total = (int64_t)d->B * d->Nq * d->heads * R;
+    REQUIRE(total < (1ll << 31), "sf_relpos_gather: too many elements");
+    hipLaunchKernelGGL(sf_relpos_gather_kernel, dim3(pool_grid(total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p,
+                       (const f16*)G, ldg, make_fastdiv((uint32_t)R), total);
     return check_launch("relpos_gather");
+}
+extern "C" int sf_relpos_pack(const float* rel_h, const float* rel_w, const float* rel_t, int32_t rows_h, int32_t rows_w,
+                              int32_t rows_t, int32_t D, int32_t TRp, void* t16, void* t16t, sf_stream_t stream) {
+    REQUIRE(rel_h && rel_w && rel_t && t16 && t16t, "sf_relpos_pack: null pointer");
+    REQUIRE(D > 0 && rows_h >= 0 && rows_w >= 0 && rows_t >= 0 && TRp >= rows_h + rows_w + rows_t && TRp % 8 == 0, "sf_relpos_pack: bad shape");
+    RelPosTabParams p;
+    memset(&p, 0, sizeof(p));
+    p.tab[0] = rel_h; p.tab[1] = rel_w; p.tab[2] = rel_t; p.rows[0] = rows_h; p.rows[1] = rows_w; p.rows[2] = rows_t;
+    p.D = D; p.TRp = TRp; p.t16 = (f16*)t16; p.t16t = (f16*)t16t;
+    hipLaunchKernelGGL(sf_relpos_pack_kernel, dim3(pool_grid((int64_t)TRp * D)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("relpos_pack");
+}
+extern "C" int sf_relpos_unpack(const float* dtab, int32_t rows_h, int32_t rows_w, int32_t rows_t, int32_t D, float* grad_h,
+                                float* grad_w, float* grad_t, int32_t acc_h, int32_t acc_w, int32_t acc_t, sf_stream_t stream) {
+    REQUIRE(dtab && grad_h && grad_w && grad_t, "sf_relpos_unpack: null pointer");
+    REQUIRE(D > 0 && rows_h >= 0 && rows_w >= 0 && rows_t >= 0 && rows_h + rows_w + rows_t > 0, "sf_relpos_unpack: bad shape");
+    RelPosTabParams p;
+    memset(&p, 0, sizeof(p));
+    p.grad[0] = grad_h; p.grad[1] = grad_w; p.grad[2] = grad_t; p.rows[0] = rows_h; p.rows[1] = rows_w; p.rows[2] = rows_t;
+    p.acc[0] = acc_h; p.acc[1] = acc_w; p.acc[2] = acc_t; p.D = D; p.dtab = dtab;
+    hipLaunchKernelGGL(sf_relpos_unpack_kernel, dim3(pool_grid((int64_t)(rows_h + rows_w + rows_t) * D)), dim3(SF_THREADS), 0,
+                       (hipStream_t)stream, p);
+    return check_launch("relpos_unpack");
 }
 extern "C" int sf_relpos_scatter(const sf_attn_desc* d, const float* drq, const int32_t* idx_h, const int32_t* idx_w,
                                  const int32_t* idx_t, void* E, int32_t lde, sf_stream_t stream) {
@@ -1646,8 +1672,12 @@ extern "C" int sf_relpos_scatter(const sf_attn_desc* d, const float* drq, const 
     REQUIRE(drq && idx_h && idx_w && idx_t && E, "sf_relpos_scatter: null pointer");
     REQUIRE(lde % 8 == 0 && lde >= d->rows_h + d->rows_w + d->rows_t, "sf_relpos_scatter: bad pitch");
     p.idx_h = idx_h; p.idx_w = idx_w; p.idx_t = idx_t; p.drq = drq;
-    hipLaunchKernelGGL(sf_relpos_scatter_kernel, dim3(relpos_blocks(d)), dim3(SF_THREADS), 0, (hipStream_t)stream, p,
-                       (f16*)E, lde);
+    const int R = d->kH + d->kW + d->kT;
+    const int64_t rows = (int64_t)d->B * d->Nq * d->heads, total = rows * R;
+    REQUIRE(total < (1ll << 31), "sf_relpos_scatter: too many elements");
+    REQUIRE(hipMemsetAsync(E, 0, (size_t)rows * lde * sizeof(f16), (hipStream_t)stream) == hipSuccess, "sf_relpos_scatter: memset failed");
+    hipLaunchKernelGGL(sf_relpos_scatter_kernel, dim3(pool_grid(total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p,
+                       (f16*)E, lde, make_fastdiv((uint32_t)R), total);
     return check_launch("relpos_scatter");
 }
 // out[i] (+)= scale * sum_b part[b*row_len + offset + i], i < n   (table gradients from per-block partials):

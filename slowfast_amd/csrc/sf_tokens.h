@@ -340,55 +340,68 @@ __device__ __forceinline__ void relpos_row_decode(const RelPosParams& p, uint32_
 // Tab = [rel_pos_h; rel_pos_w; rel_pos_t] (TR rows):  G = q Tab^T  (forward),  dq += E Tab,  dTab = E^T q  (backward),
 // where E[row][r] scatters drq[row][j] to column r = column of table row j.  These two kernels are the gather
 // (G -> rq) and the scatter (drq -> E) between the dense GEMM operands and the per-row (kH+kW+kT) vectors.
-// One wave per row; the cls row (token 0 when cls = 1) gets zeros.
-__global__ __launch_bounds__(SF_THREADS) void sf_relpos_gather_kernel(RelPosParams p, const f16* G, int ldg) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int R = p.KH + p.KW + p.KT;
-    const int total = p.B * p.Nq * p.heads;
-    for (int row = blockIdx.x * 4 + wave; row < total; row += gridDim.x * 4) {
-        if (lane >= R) continue;
-        uint32_t b, tok, head;
+// One thread per (row, j) element, consecutive threads on consecutive elements of rq / drq (round 4: the first version gave a
+// 64-lane wave to each row of kH + kW + kT = 22 values and moved 44 MB in 54 us); the cls row (token 0 when cls = 1) gets zeros.
+__device__ __forceinline__ int relpos_col(const RelPosParams& p, int j, int qt, int qh, int qw) {
+    if (j < p.KH) return p.idx_h[qh * p.KH + j];
+    if (j < p.KH + p.KW) return p.rows_h + p.idx_w[qw * p.KW + (j - p.KH)];
+    return p.rows_h + p.rows_w + p.idx_t[qt * p.KT + (j - p.KH - p.KW)];
+}
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_gather_kernel(RelPosParams p, const f16* G, int ldg, FastDiv fdR,
+                                                                       int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * SF_THREADS) {
+        uint32_t row, j, b, tok, head;
+        fd_divmod((uint32_t)i, fdR, row, j);
         int qt, qh, qw;
         bool is_cls;
-        relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
-        float v = 0.f;
-        if (!is_cls) {
-            int col;
-            if (lane < p.KH) col = p.idx_h[qh * p.KH + lane];
-            else if (lane < p.KH + p.KW) col = p.rows_h + p.idx_w[qw * p.KW + (lane - p.KH)];
-            else col = p.rows_h + p.rows_w + p.idx_t[qt * p.KT + (lane - p.KH - p.KW)];
-            v = (float)G[(int64_t)row * ldg + col];
-        }
-        p.rq[(int64_t)row * R + lane] = v;
+        relpos_row_decode(p, row, b, tok, head, qt, qh, qw, is_cls);
+        p.rq[i] = is_cls ? 0.f : (float)G[(int64_t)row * ldg + relpos_col(p, (int)j, qt, qh, qw)];
     }
 }
-__global__ __launch_bounds__(SF_THREADS) void sf_relpos_scatter_kernel(RelPosParams p, f16* E, int lde) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int R = p.KH + p.KW + p.KT;
-    const int total = p.B * p.Nq * p.heads;
-    // all waves of a block iterate together (the scatter follows the zero fill of the same row by the same wave;
-    // within a wave the two phases are ordered by the barrier)
-    for (int base = blockIdx.x * 4; base < total; base += gridDim.x * 4) {
-        const int row = base + wave;
-        const bool ok = row < total;
-        f16* erow = E + (int64_t)(ok ? row : 0) * lde;
-        if (ok)
-            for (int k8 = lane; k8 < lde / 8; k8 += 64) st16(erow + k8 * 8, zero8());
-        __syncthreads();
-        if (ok && lane < R) {
-            uint32_t b, tok, head;
-            int qt, qh, qw;
-            bool is_cls;
-            relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
-            if (!is_cls) {
-                int col;
-                if (lane < p.KH) col = p.idx_h[qh * p.KH + lane];
-                else if (lane < p.KH + p.KW) col = p.rows_h + p.idx_w[qw * p.KW + (lane - p.KH)];
-                else col = p.rows_h + p.rows_w + p.idx_t[qt * p.KT + (lane - p.KH - p.KW)];
-                erow[col] = (f16)p.drq[(int64_t)row * R + lane];
-            }
-        }
-        __syncthreads();
+// E is zero-filled by the caller of the kernel (sf_relpos_scatter: a memset node in front of it)
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_scatter_kernel(RelPosParams p, f16* E, int lde, FastDiv fdR,
+                                                                        int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * SF_THREADS) {
+        uint32_t row, j, b, tok, head;
+        fd_divmod((uint32_t)i, fdR, row, j);
+        int qt, qh, qw;
+        bool is_cls;
+        relpos_row_decode(p, row, b, tok, head, qt, qh, qw, is_cls);
+        if (!is_cls) E[(int64_t)row * lde + relpos_col(p, (int)j, qt, qh, qw)] = (f16)p.drq[i];
+    }
+}
+
+// The concatenated table Tab = [rel_pos_h; rel_pos_w; rel_pos_t] as 16-bit GEMM operands in ONE launch: t16 [TRp][D] (rows
+// beyond the tables are zero) and its transpose t16t [D][TRp] (round 4: torch.cat + zeros + copy + transpose-copy per block and
+// step before); and the way back, the rows of dTab [TRp][D] fp32 into the three parameter gradients (copy or accumulate).
+struct RelPosTabParams {
+    const float* tab[3]; float* grad[3];
+    int rows[3]; int acc[3];
+    int D, TRp;
+    f16* t16; f16* t16t;            // pack
+    const float* dtab;              // unpack
+};
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_pack_kernel(RelPosTabParams p) {
+    const int total = p.TRp * p.D;
+    for (int i = blockIdx.x * SF_THREADS + threadIdx.x; i < total; i += gridDim.x * SF_THREADS) {
+        const int r = i / p.D, c = i - r * p.D;
+        float v = 0.f;
+        if (r < p.rows[0]) v = p.tab[0][r * p.D + c];
+        else if (r < p.rows[0] + p.rows[1]) v = p.tab[1][(r - p.rows[0]) * p.D + c];
+        else if (r < p.rows[0] + p.rows[1] + p.rows[2]) v = p.tab[2][(r - p.rows[0] - p.rows[1]) * p.D + c];
+        p.t16[i] = (f16)v;
+        p.t16t[(int64_t)c * p.TRp + r] = (f16)v;
+    }
+}
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_unpack_kernel(RelPosTabParams p) {
+    const int total = (p.rows[0] + p.rows[1] + p.rows[2]) * p.D;
+    for (int i = blockIdx.x * SF_THREADS + threadIdx.x; i < total; i += gridDim.x * SF_THREADS) {
+        const int r = i / p.D, c = i - r * p.D;
+        const int k = r < p.rows[0] ? 0 : (r < p.rows[0] + p.rows[1] ? 1 : 2);
+        const int rr = r - (k > 0 ? p.rows[0] : 0) - (k > 1 ? p.rows[1] : 0);
+        float* dst = p.grad[k] + rr * p.D + c;
+        const float v = p.dtab[i];
+        *dst = p.acc[k] ? *dst + v : v;
     }
 }
 

@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 20
+ABI_VERSION = 21
 # 16-bit storage type of activations / packed weights / MFMA operands, fixed per PROCESS: SF_ACT_DTYPE=fp16 (default) loads
 # libsfamd.so, =bf16 loads libsfamd_bf16.so -- the same sources compiled with -DSF_ACT_BF16 (bfloat16 storage,
 # v_mfma_f32_16x16x32_bf16); both are what torch.cuda.amp.autocast admits on the reference side (tools/train_net.py:101-118).
@@ -142,6 +142,8 @@ _SIGNATURES = {
     "sf_dwconv_wgrad": (c_int, [POINTER(DwDesc), _P, _P, _F, c_float, c_int, _P, c_int64, _P]),
     "sf_relpos_gather": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, _P, _F, _P]),
     "sf_relpos_scatter": (c_int, [POINTER(AttnDesc), _F, _P, _P, _P, _P, c_int32, _P]),
+    "sf_relpos_pack": (c_int, [_F, _F, _F, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "sf_relpos_unpack": (c_int, [_F, c_int32, c_int32, c_int32, c_int32, _F, _F, _F, c_int32, c_int32, c_int32, _P]),
     "sf_softmax_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, c_float, _F, _P]),
     "sf_softmax_bwd": (c_int, [POINTER(AttnDesc), _P, _P, c_int32, c_float, _F, _P]),
     "sf_attn_fwd": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, c_int32, c_float, _F, _P, c_int32, _P, c_int32, _F, _P]),

@@ -381,12 +381,17 @@ def attn_desc(B, heads, D, cls, q_thw, k_thw, rows_h=0, rows_w=0, rows_t=0):
 def relpos_tables16(tables):
     """Concatenated table [rel_pos_h; rel_pos_w; rel_pos_t] as fp16 GEMM operands: (Tab [TRp, D], Tab^T [D, TRp]),
     TRp = row count rounded up to 8 (zero rows)."""
-    tab = torch.cat([t.detach() for t in tables], 0)
-    TR, D = tab.shape
-    TRp = (TR + 7) // 8 * 8
-    t16 = torch.zeros((TRp, D), dtype=_f16, device=tab.device)
-    t16[:TR] = tab
-    return t16, t16.t().contiguous()
+    D = tables[0].shape[1]
+    rows = [t.shape[0] for t in tables]
+    TRp = (sum(rows) + 7) // 8 * 8
+    tabs = [t.detach() for t in tables]
+    if not all(t.dtype == torch.float32 and t.is_contiguous() for t in tabs):       # resampled tables (plan.interp)
+        tabs = [t.float().contiguous() for t in tabs]
+    t16 = torch.empty((TRp, D), dtype=_f16, device=tabs[0].device)
+    t16t = torch.empty((D, TRp), dtype=_f16, device=tabs[0].device)
+    _lib_call("sf_relpos_pack", tabs[0].data_ptr(), tabs[1].data_ptr(), tabs[2].data_ptr(), rows[0], rows[1], rows[2], D, TRp,
+              t16.data_ptr(), t16t.data_ptr(), _stream(t16))
+    return t16, t16t
 
 
 def relpos_fwd(d, q, tables, idx, t16=None):
@@ -415,11 +420,10 @@ def relpos_bwd(d, q, tables, idx, drq, dq, dtables, accumulate, t16t=None):
     gemm(E, t16t, resid=dq2d, out=dq2d)                     # in place: each element is read then written by one thread
     dtab = torch.empty((TRp, d.D), dtype=torch.float32, device=q.device)
     linear_wgrad(q2d, E, dtab, zero_first=True)
-    off = 0
-    for t, g, acc in zip(tables, dtables, accumulate):
-        n = t.shape[0]
-        g.add_(dtab[off:off + n]) if acc else g.copy_(dtab[off:off + n])
-        off += n
+    rows = [t.shape[0] for t in tables]
+    assert all(g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == (n, d.D) for g, n in zip(dtables, rows))
+    _lib_call("sf_relpos_unpack", dtab.data_ptr(), rows[0], rows[1], rows[2], d.D, dtables[0].data_ptr(), dtables[1].data_ptr(),
+              dtables[2].data_ptr(), int(accumulate[0]), int(accumulate[1]), int(accumulate[2]), _stream(dtab))
 
 
 def softmax_fwd(d, s, scale, rq=None):
