@@ -192,11 +192,9 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
     q.ablate = (e = getenv("SF_IGEMM2_ABLATE")) ? atoi(e) : 0;     // diagnostic: parts of the kernel switched off (wrong results)
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);
-    // 256 x 256 tiles (round 4, opt-in: SF_IGEMM2_BN256=1): 128 flop per copied operand byte instead of 85 -- the copy stream is
-    // what profiles/r3_v6_igemm2_ablation.md found co-limiting -- at one workgroup per CU (144 KB of LDS, 128 accumulator VGPRs)
-    const bool bn256 = q.Nout >= 256 && !q.f32.out && (e = getenv("SF_IGEMM2_BN256")) && atoi(e) != 0 &&
-                       cdiv(q.M, 256) * cdiv(q.Nout, 256) >= (atoi(e) > 1 ? atoi(e) : 1);
-    if (bn256) { launch_igemm2<256, 32>(q, s); return; }
+    // (256 x 256 tiles -- 128 flop per copied operand byte instead of 85, one workgroup per CU -- were measured in round 4 and
+    // lost on both models: SlowFast 766.5 -> 741 clips/s on every eligible layer, 755 restricted to grids of >= 512 tiles,
+    // MViTv2-S 590.9 -> 584 / 588; profiles/r4_v6_knobs_ab.txt.  Removed.)
     if (q.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }
     else if (q.Nout > 32) { if (bk64) launch_igemm2<64, 64>(q, s); else launch_igemm2<64, 32>(q, s); }
     else launch_igemm2<32, 32>(q, s);

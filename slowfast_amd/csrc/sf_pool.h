@@ -39,13 +39,13 @@ __device__ __forceinline__ void bn_act8(const f16x8& v, const float (&sc)[8], co
     }
 }
 
-// Workgroups are numbered XCD-contiguously (sf_common.h: xcd_remap) in the four pooling kernels: neighbouring windows overlap,
-// and with the plain order every run of 32 positions sat behind a different XCD's L2.
+// (Round 4: an XCD-contiguous workgroup order -- what helped the depthwise stencils -- made the backward gather SLOWER here,
+// 136 -> 174 us on the MViT skip pooling, profiles/r4_v6_knobs_ab.txt; the plain order stays.)
 // One thread per (pooled position, 8 channels).  The FIRST maximum in scan order wins (the element torch's
 // max_pool3d records); its window-local index is kept for the backward pass.
 __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
     const int64_t ncls = p.cls ? (int64_t)p.N * (p.C >> 3) : 0;
-    for (int64_t idx = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * SF_THREADS + threadIdx.x; idx < p.total + ncls;
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total + ncls;
          idx += (int64_t)gridDim.x * SF_THREADS) {
         if (idx >= p.total) {     // cls rows: copy
             const int64_t j = idx - p.total;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
 // position and the pooled value is positive (the ReLU in front of the pool passed it).
 __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
     const int64_t ncls = p.cls ? (int64_t)p.N * (p.C >> 3) : 0;
-    for (int64_t idx = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * SF_THREADS + threadIdx.x; idx < p.total + ncls;
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total + ncls;
          idx += (int64_t)gridDim.x * SF_THREADS) {
         if (idx >= p.total) {     // cls rows: the gradient passes through
             const int64_t j = idx - p.total;
@@ -170,7 +170,7 @@ struct Pool3dParams {
     int64_t total;
 };
 __global__ __launch_bounds__(SF_THREADS) void sf_pool3d_fwd_kernel(Pool3dParams p) {
-    for (int64_t idx = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * SF_THREADS + threadIdx.x; idx < p.total;
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
          idx += (int64_t)gridDim.x * SF_THREADS) {
         uint32_t q, gcol, wo, ho, to, n;
         fd_divmod((uint32_t)idx, p.fdG, q, gcol);
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool3d_fwd_kernel(Pool3dParams 
     }
 }
 __global__ __launch_bounds__(SF_THREADS) void sf_pool3d_bwd_kernel(Pool3dParams p) {
-    for (int64_t idx = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * SF_THREADS + threadIdx.x; idx < p.total;
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total;
          idx += (int64_t)gridDim.x * SF_THREADS) {
         uint32_t q, gcol, w, h, t, n;
         fd_divmod((uint32_t)idx, p.fdG, q, gcol);
