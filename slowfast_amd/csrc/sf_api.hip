@@ -1873,6 +1873,7 @@ extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
         const int grid = d->B * d->heads * p.ktiles * p.qsplits;
         const int kd = d->D / 32;
         const int kt = attn_dkv_kt(d);
+        { const char* ea = getenv("SF_ATTN_ABLATE"); p.ablate = ea ? atoi(ea) : 0; }      // diagnostic (wrong results)
 #define SF_DKV(KD_)                                                                                              \
     do {                                                                                                         \
         if (kt == 2) hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 2, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p); \

@@ -56,6 +56,10 @@ struct AttnParams {
     int qtiles, ktiles;
     int qsplits, chunks_per_split;                            // dK/dV kernel: query chunks per split
     float* part;                                              // [qsplits][2][B][Nk][heads*D] fp32 (qsplits > 1)
+    // DIAGNOSTIC (SF_ATTN_ABLATE, tools/token_bench.py only; results are garbage) -- parts of the key-side backward kernel
+    // switched off: bit 0 no S / dP MFMAs, bit 1 no softmax arithmetic (exp, p, dS), bit 2 no dV / dK MFMAs (and their
+    // transposed LDS reads), bit 3 no workgroup barriers, bit 4 no Q / dO copies inside the loop, bit 5 no rq side loads / stores
+    int ablate;
 };
 
 // stage rows [r0, r0 + 32) of a [N][ld] matrix (columns [0, D)) into LDS rows of pitch KP; rows >= N are zero
@@ -554,12 +558,12 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
         const int buf = (c - c0) & 1;
         const f16* const Qs = QO + buf * 2 * MSZ;
         const f16* const Os = Qs + MSZ;
-        __syncthreads();            // every wave is done with chunk c - 1: Rh / Rl and the other Q / dO buffer are free
+        if (!(p.ablate & 8)) __syncthreads();   // every wave is done with chunk c - 1: Rh / Rl and the other Q / dO buffer are free
         if (tid < 32) {
             s_lse[tid] = lsev;
             s_delta[tid] = deltav;
         }
-        if (bias) {
+        if (bias && !(p.ablate & 32)) {
             f16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -572,10 +576,10 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             st16(Rl + rr * SF_ATTN_OHP + j0, lo);
         }
         SF_WAIT_VMEM();             // this wave's copies of chunk c have landed ...
-        __syncthreads();            // ... and everybody else's
+        if (!(p.ablate & 8)) __syncthreads();   // ... and everybody else's
         if (c + 1 < c1) {
-            issue_chunk(c + 1, buf ^ 1);
-            side_load(c + 1);
+            if (!(p.ablate & 16)) issue_chunk(c + 1, buf ^ 1);
+            if (!(p.ablate & 32)) side_load(c + 1);
         }
         f16x8 pf[KT], dsf[KT];
 #pragma unroll
@@ -586,6 +590,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
                 st[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 dp[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            if (!(p.ablate & 1)) {
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
                 const f16x8 qa = ld16(Qs + (16 * t + pl) * KP + 32 * s + 8 * g);
@@ -596,7 +601,8 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
                     dp[u] = SF_MFMA16(oa, vf[u][s], dp[u]);
                 }
             }
-            if (bias) {
+            }
+            if (bias && !(p.ablate & 1)) {
                 const f16x8 rh0 = ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
                 const f16x8 rl0 = ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
 #pragma unroll
@@ -621,12 +627,21 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
                 const float ls = s_lse[qi], de = s_delta[qi];
 #pragma unroll
                 for (int u = 0; u < KT; ++u) {
+                    if (p.ablate & 2) {             // diagnostic: keep the dependency, drop the arithmetic
+                        pf[u][4 * t + r] = (f16)st[u][r];
+                        dsf[u][4 * t + r] = (f16)dp[u][r];
+                        continue;
+                    }
                     const float pv = qin ? SF_EXP2(st[u][r] - ls) : 0.f;
                     pf[u][4 * t + r] = (f16)pv;
                     dsf[u][4 * t + r] = (f16)(pv * (dp[u][r] - de));
                 }
             }
         }
+        if (p.ablate & 4) {
+#pragma unroll
+            for (int u = 0; u < KT; ++u) { SF_KEEP_ALIVE(pf[u]); SF_KEEP_ALIVE(dsf[u]); }
+        } else {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const f16x8 ot = attn_tr_frag(Os, KP, dt * 16, pl, g);
@@ -636,6 +651,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
                 dvacc[u][dt] = SF_MFMA16(ot, pf[u], dvacc[u][dt]);
                 dkacc[u][dt] = SF_MFMA16(qt_, dsf[u], dkacc[u][dt]);
             }
+        }
         }
     }
 #pragma unroll

@@ -93,6 +93,10 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #ifndef SF_CONSUME_V
 #define SF_CONSUME_V(x) asm volatile("" : "+v"(x))
 #endif
+// keeps a fragment register live without using it (diagnostic ablations only)
+#ifndef SF_KEEP_ALIVE
+#define SF_KEEP_ALIVE(x) asm volatile("" ::"v"(x))
+#endif
 // wait until at most N (compile-time) of this wave's vector-memory operations are outstanding: retires everything but
 // the newest N, i.e. a whole copy stage while the next one stays in flight
 #ifndef SF_WAIT_VMEM_N

@@ -21,10 +21,6 @@
 
 #define SF_I2_MAXTAPS 32
 
-// keeps a fragment register live without using it (diagnostic ablations only)
-#ifndef SF_KEEP_ALIVE
-#define SF_KEEP_ALIVE(x) asm volatile("" ::"v"(x))
-#endif
 
 // padding taps read sf_zero_line (sf_common.h)
 

@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    if a.only in ("", "attn", "stage3"):
+    if a.only in ("", "attn", "stage3", "stage3attn"):
         attn_case(32, 4, 96, (8, 14, 14), (8, 7, 7), a.iters, dev)      # stage 3 (11 blocks)
     if a.only in ("", "attn"):
         attn_case(32, 1, 96, (8, 56, 56), (8, 7, 7), a.iters, dev)      # block 0
