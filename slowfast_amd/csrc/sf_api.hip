@@ -1771,15 +1771,23 @@ static int fill_attn(AttnParams& p, const sf_attn_desc* d, const char* who) {
     REQUIRE((int64_t)d->B * d->heads * (p.qtiles > p.ktiles ? p.qtiles : p.ktiles) < (1ll << 28), "%s: too many tiles", who);
     // dK/dV: split the queries so that ~1024 workgroups exist (Nk is small), at least 8 query chunks per split
     const int nchq = cdiv(d->Nq, 32);
-    int splits = cdiv(1024, (int64_t)d->B * d->heads * p.ktiles);
+    // SF_ATTN_DKV_WGS: workgroups the query split aims for (default 1024 = two rounds of the 512 resident ones; 512 = one round,
+    // no split for MViTv2-S: no fp32 partial tables, no reduce kernel)
+    static const int wgs_target = getenv("SF_ATTN_DKV_WGS") ? atoi(getenv("SF_ATTN_DKV_WGS")) : 1024;
+    int splits = cdiv(wgs_target > 0 ? wgs_target : 1024, (int64_t)d->B * d->heads * p.ktiles);
     if (splits > nchq / 8) splits = nchq / 8;
     if (splits < 1) splits = 1;
     p.chunks_per_split = cdiv(nchq, splits);
     p.qsplits = cdiv(nchq, p.chunks_per_split);
     return 0;
 }
-static int64_t attn_ws_bytes(const AttnParams& p, const sf_attn_desc* d) {
+// workspace of sf_attn_bwd: [fp32 split partials of dK / dV (qsplits > 1)] [rq hi / lo fp16 rows (relative positions)]
+static int64_t attn_part_bytes(const AttnParams& p, const sf_attn_desc* d) {
     return p.qsplits > 1 ? (int64_t)p.qsplits * 2 * d->B * d->Nk * d->heads * d->D * 4 : 0;
+}
+static int64_t attn_ws_bytes(const AttnParams& p, const sf_attn_desc* d) {
+    const bool rel = d->rows_h + d->rows_w + d->rows_t > 0;
+    return attn_part_bytes(p, d) + (rel ? (int64_t)d->B * d->Nq * d->heads * 128 * 2 : 0);
 }
 // two 16-query column tiles per wave (halves the LDS operand traffic per MFMA) once there are enough workgroups;
 // SF_ATTN_QT=1|2 forces either form
@@ -1825,6 +1833,7 @@ extern "C" int sf_attn_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     p.out = (f16*)o; p.ldout = ldo; p.rq = rq; p.oh = (const f16*)onehot; p.lse = lse;
     p.scale = scale; p.scale2 = scale * SF_LOG2E; p.residual = residual;
     if (!rq) p.R = 0;
+    { const char* ea = getenv("SF_ATTN_ABLATE"); p.ablate = ea ? atoi(ea) : 0; }      // diagnostic (wrong results)
     const bool qt2 = attn_two_tiles(d);
     if (qt2) p.qtiles = cdiv(d->Nq, 128);
     SF_ATTN_LAUNCH_Q(sf_attn_fwd_kernel, d->D, qt2, d->B * d->heads * p.qtiles, (hipStream_t)stream, p);
@@ -1858,6 +1867,10 @@ extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     p.rq = rq; p.drq = drq; p.oh = (const f16*)onehot; p.lse = const_cast<float*>(lse); p.delta = delta;
     p.scale = scale; p.scale2 = scale * SF_LOG2E; p.residual = residual; p.part = (float*)workspace;
     if (!rq) p.R = 0;
+    if (rq) {
+        REQUIRE(d->rows_h + d->rows_w + d->rows_t > 0, "sf_attn_bwd: rq given but the descriptor has no relative-position tables");
+        p.rqs = (f16*)((char*)workspace + attn_part_bytes(p, d));
+    }
     hipStream_t st = (hipStream_t)stream;
     {
         const bool qt2 = attn_two_tiles(d);

@@ -56,6 +56,8 @@ struct AttnParams {
     int qtiles, ktiles;
     int qsplits, chunks_per_split;                            // dK/dV kernel: query chunks per split
     float* part;                                              // [qsplits][2][B][Nk][heads*D] fp32 (qsplits > 1)
+    f16* rqs;   // [(b*Nq + q)*heads + head][2][64]: rq * log2(e) as fp16 hi / lo parts (zero beyond R and on cls rows), written by
+                // the query-side backward kernel, copied straight into LDS by the key-side one
     // DIAGNOSTIC (SF_ATTN_ABLATE, tools/token_bench.py only; results are garbage) -- parts of the key-side backward kernel
     // switched off: bit 0 no S / dP MFMAs, bit 1 no softmax arithmetic (exp, p, dS), bit 2 no dV / dK MFMAs (and their
     // transposed LDS reads), bit 3 no workgroup barriers, bit 4 no Q / dO copies inside the loop, bit 5 no rq side loads / stores
@@ -171,15 +173,18 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
     if (bias) ohr = ld16(p.oh + (int64_t)tid * 8);
     for (int c = 0; c < nch; ++c) {
         __syncthreads();
+        if (!(p.ablate & 64) || c == 0) {       // (diagnostic bit 64: the K / V / OH chunk is staged once and never refreshed)
         kc.store(Ks, tid);
         vc.store(Vs, tid);
         if (bias) st16(OHs + (tid >> 3) * SF_ATTN_OHP + (tid & 7) * 8, ohr);
+        }
         __syncthreads();
-        if (c + 1 < nch) {
+        if (c + 1 < nch && !(p.ablate & 64)) {
             kc.load(kbase, p.ldk, (c + 1) * 32, p.Nk, tid);
             vc.load(vbase, p.ldk, (c + 1) * 32, p.Nk, tid);
             if (bias) ohr = ld16(p.oh + ((int64_t)(c + 1) * 32 * 64) + (int64_t)tid * 8);
         }
+        if (p.ablate & 128) continue;           // (diagnostic bit 128: staging only, no arithmetic)
         float x[QT][8];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -324,6 +329,11 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
         for (int ks = 0; ks < 2; ++ks) {
             const int j0 = 32 * ks + 8 * g;
             attn_split8(on ? rqrow + (j0 < p.R ? j0 : 0) : nullptr, p.R - j0, on && j0 < p.R, rqh[u][ks], rql[u][ks]);
+            if (p.rqs && qok) {     // the split the key-side kernel needs for the same rows: made once here, not once per key tile
+                f16* dst = p.rqs + (((int64_t)b * p.Nq + qrow[u]) * p.heads + head) * 128 + j0;
+                st16(dst, rqh[u][ks]);
+                st16(dst + 64, rql[u][ks]);
+            }
         }
     }
     const f16* kbase = p.k + (int64_t)b * p.Nk * p.ldk + head * D;
@@ -456,10 +466,12 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
     // tiles of a wave need them for accumulators -- and no ds_write pass.  The padded [32][KP] image is made of SPR 16-byte slots
     // per row (the last one is the pad): slot i of a matrix is written by lane i & 63 of copy instruction i >> 6.
     constexpr int SPR = KP / 8, NS = 32 * SPR, NI = (NS + 63) / 64, MSZ = NI * 512;       // MSZ: halfs per matrix buffer
+    // rq rows (hi / lo fp16 parts, 64 columns each) travel the same way from the table the query-side kernel left (p.rqs):
+    // RS slots per row (8 data + 2 pad), one buffer [hi | lo] of 2 * RSZ halfs per chunk
+    constexpr int RS = SF_ATTN_OHP / 8, RNS = 32 * RS, RNI = (RNS + 63) / 64, RSZ = RNI * 512;
     __shared__ __attribute__((aligned(16))) f16 QO[2 * 2 * MSZ];  // [buffer][Q | dO]
-    __shared__ __attribute__((aligned(16))) f16 Rh[32 * SF_ATTN_OHP];   // rq rows (times log2 e), fp16 hi / lo parts
-    __shared__ __attribute__((aligned(16))) f16 Rl[32 * SF_ATTN_OHP];
-    __shared__ float s_lse[32], s_delta[32];
+    __shared__ __attribute__((aligned(16))) f16 RHL[2 * 2 * RSZ]; // [buffer][hi | lo]
+    __shared__ float s_lse[2][32], s_delta[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -502,48 +514,53 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             dkacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             dvacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    // copy instructions of this wave: j = wave, wave + 4, ... < 2 * NI; j < NI copies Q slots, the others dO slots.  Per lane:
-    // the slot's row inside the chunk and its element offset in the source row (-1: pad slot -> zeros)
-    constexpr int NCP = (2 * NI + 3) / 4;
+    // copy instructions of this wave: j = wave, wave + 4, ... over [Q | dO | rq hi | rq lo] instruction slots.  Per lane: the
+    // slot's row inside the chunk and its element offset in the source row (-1: pad slot -> zeros)
+    constexpr int NJ = 2 * NI + 2 * RNI;
+    constexpr int NCP = (NJ + 3) / 4;
     int cp_row[NCP], cp_off[NCP];
 #pragma unroll
     for (int jj = 0; jj < NCP; ++jj) {
-        const int j = wave + 4 * jj, i = j < NI ? j : j - NI;
-        const int slot = i * 64 + lane, row = slot / SPR, col = slot - row * SPR;
-        cp_row[jj] = row;
-        cp_off[jj] = (slot < NS && col < D / 8) ? col * 8 : -1;
+        const int j = wave + 4 * jj;
+        if (j < 2 * NI) {
+            const int i = j < NI ? j : j - NI;
+            const int slot = i * 64 + lane, row = slot / SPR, col = slot - row * SPR;
+            cp_row[jj] = row;
+            cp_off[jj] = (slot < NS && col < D / 8) ? col * 8 : -1;
+        } else {
+            const int i = j - 2 * NI < RNI ? j - 2 * NI : j - 2 * NI - RNI;
+            const int slot = i * 64 + lane, row = slot / RS, col = slot - row * RS;
+            cp_row[jj] = row;
+            cp_off[jj] = (slot < RNS && col < 8) ? col * 8 + (j - 2 * NI < RNI ? 0 : 64) : -1;
+        }
     }
     const f16* const zline = reinterpret_cast<const f16*>(sf_zero_line);
+    const f16* const rqs_b = p.rqs ? p.rqs + (((int64_t)b * p.Nq) * p.heads + head) * 128 : nullptr;
     auto issue_chunk = [&](int c, int buf) {
         f16* Qb = QO + buf * 2 * MSZ;
+        f16* Rb = RHL + buf * 2 * RSZ;
 #pragma unroll
         for (int jj = 0; jj < NCP; ++jj) {
             const int j = wave + 4 * jj;
-            if (j >= 2 * NI) continue;
-            const bool isq = j < NI;
+            if (j >= NJ) continue;
             const int qr = c * 32 + cp_row[jj];
             const f16* src = zline;
-            if (cp_off[jj] >= 0 && qr < p.Nq)
-                src = (isq ? qbase + (int64_t)qr * p.ldq : dobase + (int64_t)qr * p.ldo) + cp_off[jj];
-            SF_GLOBAL_LOAD_LDS16_ASM(src, Qb + (isq ? 0 : MSZ) + (isq ? j : j - NI) * 512);
+            if (j < 2 * NI) {
+                const bool isq = j < NI;
+                if (cp_off[jj] >= 0 && qr < p.Nq)
+                    src = (isq ? qbase + (int64_t)qr * p.ldq : dobase + (int64_t)qr * p.ldo) + cp_off[jj];
+                SF_GLOBAL_LOAD_LDS16_ASM(src, Qb + (isq ? 0 : MSZ) + (isq ? j : j - NI) * 512);
+            } else {
+                if (!bias || (p.ablate & 32)) continue;
+                const int jr = j - 2 * NI;
+                if (cp_off[jj] >= 0 && qr < p.Nq) src = rqs_b + (int64_t)qr * p.heads * 128 + cp_off[jj];
+                SF_GLOBAL_LOAD_LDS16_ASM(src, Rb + (jr < RNI ? jr : RSZ / 512 + (jr - RNI)) * 512);
+            }
         }
     };
-    // per-chunk side inputs, prefetched into registers: 8 rq values per thread (row tid >> 3, columns 8 * (tid & 7) ..),
-    // log-sum-exp and delta of row tid (tid < 32)
-    float rqv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lsev = 0.f, deltav = 0.f;
-    const int rr = tid >> 3, j0 = (tid & 7) * 8;
+    // log-sum-exp and delta of row tid (tid < 32), prefetched into registers
+    float lsev = 0.f, deltav = 0.f;
     auto side_load = [&](int c) {
-        const int qr = c * 32 + rr;
-        const bool on = bias && qr < p.Nq && qr >= p.cls;
-        if (bias) {
-            // unconditional loads from clamped (always valid) addresses, masked afterwards: eight loads in flight
-            const float* src = p.rq + (((int64_t)b * p.Nq + (on ? qr : 0)) * p.heads + head) * p.R;
-            float raw[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) raw[e] = src[j0 + e < p.R ? j0 + e : p.R - 1];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) rqv[e] = (on && j0 + e < p.R) ? raw[e] : 0.f;
-        }
         if (tid < 32) {
             const int q2 = c * 32 + tid;
             lsev = q2 < p.Nq ? p.lse[(int64_t)bh * p.Nq + q2] : 0.f;
@@ -554,32 +571,24 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
         issue_chunk(c0, 0);
         side_load(c0);
     }
+    // ONE barrier per chunk: every loop input is double-buffered (Q / dO / rq by direct-to-LDS copies, lse / delta through
+    // registers).  Chunk c + 1 is copied into the buffers chunk c - 1 was read from; every wave finished chunk c - 1 before it
+    // arrived at the barrier of chunk c.
     for (int c = c0; c < c1; ++c) {
         const int buf = (c - c0) & 1;
         const f16* const Qs = QO + buf * 2 * MSZ;
         const f16* const Os = Qs + MSZ;
-        if (!(p.ablate & 8)) __syncthreads();   // every wave is done with chunk c - 1: Rh / Rl and the other Q / dO buffer are free
+        const f16* const Rh = RHL + buf * 2 * RSZ;
+        const f16* const Rl = Rh + RSZ;
         if (tid < 32) {
-            s_lse[tid] = lsev;
-            s_delta[tid] = deltav;
-        }
-        if (bias && !(p.ablate & 32)) {
-            f16x8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = rqv[e] * SF_LOG2E;
-                const f16 h = (f16)v;
-                hi[e] = h;
-                lo[e] = (f16)(v - (float)h);
-            }
-            st16(Rh + rr * SF_ATTN_OHP + j0, hi);
-            st16(Rl + rr * SF_ATTN_OHP + j0, lo);
+            s_lse[buf][tid] = lsev;
+            s_delta[buf][tid] = deltav;
         }
         SF_WAIT_VMEM();             // this wave's copies of chunk c have landed ...
-        if (!(p.ablate & 8)) __syncthreads();   // ... and everybody else's
+        if (!(p.ablate & 8)) __syncthreads();   // ... and everybody else's; chunk c - 1 is no longer read by anyone
         if (c + 1 < c1) {
             if (!(p.ablate & 16)) issue_chunk(c + 1, buf ^ 1);
-            if (!(p.ablate & 32)) side_load(c + 1);
+            side_load(c + 1);
         }
         f16x8 pf[KT], dsf[KT];
 #pragma unroll
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             for (int r = 0; r < 4; ++r) {
                 const int qi = 16 * t + 4 * g + r;
                 const bool qin = c * 32 + qi < p.Nq;
-                const float ls = s_lse[qi], de = s_delta[qi];
+                const float ls = s_lse[buf][qi], de = s_delta[buf][qi];
 #pragma unroll
                 for (int u = 0; u < KT; ++u) {
                     if (p.ablate & 2) {             // diagnostic: keep the dependency, drop the arithmetic
