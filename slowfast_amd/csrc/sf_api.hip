@@ -1771,10 +1771,11 @@ static int fill_attn(AttnParams& p, const sf_attn_desc* d, const char* who) {
     REQUIRE((int64_t)d->B * d->heads * (p.qtiles > p.ktiles ? p.qtiles : p.ktiles) < (1ll << 28), "%s: too many tiles", who);
     // dK/dV: split the queries so that ~1024 workgroups exist (Nk is small), at least 8 query chunks per split
     const int nchq = cdiv(d->Nq, 32);
-    // SF_ATTN_DKV_WGS: workgroups the query split aims for (default 1024 = two rounds of the 512 resident ones; 512 = one round,
-    // no split for MViTv2-S: no fp32 partial tables, no reduce kernel)
-    static const int wgs_target = getenv("SF_ATTN_DKV_WGS") ? atoi(getenv("SF_ATTN_DKV_WGS")) : 1024;
-    int splits = cdiv(wgs_target > 0 ? wgs_target : 1024, (int64_t)d->B * d->heads * p.ktiles);
+    // SF_ATTN_DKV_WGS: workgroups the query split aims for.  512 = one round of resident workgroups: MViTv2-S needs no split
+    // then -- no fp32 partial tables (154 MB per call), no reduce kernel; measured against 1024 (two rounds, rounds 1-3) on
+    // the stage-3 shape: 314 vs 344 us for the whole backward call (profiles/r4_v8_attn_ab.txt)
+    static const int wgs_target = getenv("SF_ATTN_DKV_WGS") ? atoi(getenv("SF_ATTN_DKV_WGS")) : 512;
+    int splits = cdiv(wgs_target > 0 ? wgs_target : 512, (int64_t)d->B * d->heads * p.ktiles);
     if (splits > nchq / 8) splits = nchq / 8;
     if (splits < 1) splits = 1;
     p.chunks_per_split = cdiv(nchq, splits);

@@ -64,28 +64,6 @@ struct AttnParams {
     int ablate;
 };
 
-// stage rows [r0, r0 + 32) of a [N][ld] matrix (columns [0, D)) into LDS rows of pitch KP; rows >= N are zero
-template <int D, int KP>
-struct RowChunk {
-    f16x8 v[2];
-    __device__ __forceinline__ void load(const f16* base, int ld, int r0, int N, int tid) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int slot = tid + 256 * u;
-            const int row = slot / (D / 8), col = slot % (D / 8);
-            const bool ok = slot < 32 * (D / 8) && r0 + row < N;
-            v[u] = ok ? ld16(base + (int64_t)(r0 + row) * ld + col * 8) : zero8();
-        }
-    }
-    __device__ __forceinline__ void store(f16* s, int tid) const {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int slot = tid + 256 * u;
-            if (slot < 32 * (D / 8)) st16(s + (slot / (D / 8)) * KP + (slot % (D / 8)) * 8, v[u]);
-        }
-    }
-};
-
 // A operand (16 rows x 32 k) whose k-slots are LDS ROWS: slot (g, j) <-> row 4g + j (j < 4) / 16 + 4g + (j - 4),
 // rows of the operand = 16 consecutive columns starting at col0 (transposed read)
 __device__ __forceinline__ f16x8 attn_tr_frag(const f16* s, int KP, int col0, int pl, int g) {
@@ -120,15 +98,66 @@ __device__ __forceinline__ void attn_split8(const float* src, int n, bool on, f1
 }
 
 // ---------------------------------------------------------------------------------------------
+// Key-chunk staging of the query-side kernels (forward, dQ): 32 rows of K, V and of the one-hot bias matrix OH travel global ->
+// LDS directly (global_load_lds_dwordx4) into one of two buffers while the previous chunk is multiplied -- no staging
+// registers, no ds_write pass, ONE barrier per chunk (round 4; the register-staged version needed two and exposed the load
+// latency of cold operands: 164 us in the training step against 108 us cache-warm, profiles/r4_v8_attn_ab.txt).  A padded
+// [32][KP] image is SPR 16-byte slots per row (the last is the pad), slot i is written by lane i & 63 of copy instruction
+// i >> 6; the OH image [32][SF_ATTN_OHP] likewise with RS slots per row.
+template <int D>
+struct KeyChunkCopy {
+    static constexpr int KP = D + 16, SPR = KP / 8, NS = 32 * SPR, NI = (NS + 63) / 64, MSZ = NI * 512;
+    static constexpr int RS = SF_ATTN_OHP / 8, RNS = 32 * RS, RNI = (RNS + 63) / 64, RSZ = RNI * 512;
+    static constexpr int NJ = 2 * NI + RNI, NCP = (NJ + 3) / 4;
+    static constexpr int BUF = 2 * MSZ + RSZ;       // halfs per buffer: [K | V | OH]
+    int row[NCP], off[NCP];
+    __device__ __forceinline__ void init(int wave, int lane) {
+#pragma unroll
+        for (int jj = 0; jj < NCP; ++jj) {
+            const int j = wave + 4 * jj;
+            if (j < 2 * NI) {
+                const int i = j < NI ? j : j - NI;
+                const int slot = i * 64 + lane, r = slot / SPR, col = slot - r * SPR;
+                row[jj] = r;
+                off[jj] = (slot < NS && col < D / 8) ? col * 8 : -1;
+            } else {
+                const int slot = (j - 2 * NI) * 64 + lane, r = slot / RS, col = slot - r * RS;
+                row[jj] = r;
+                off[jj] = (slot < RNS && col < 8) ? col * 8 : -1;
+            }
+        }
+    }
+    // chunk c of (kbase, vbase: rows of pitch ldk, Nk valid rows; oh: [roundup(Nk, 32)][64]) -> buffer at `dst`
+    __device__ __forceinline__ void issue(int c, f16* dst, const f16* kbase, const f16* vbase, int ldk, int Nk, const f16* oh,
+                                          int wave) const {
+        const f16* const zline = reinterpret_cast<const f16*>(sf_zero_line);
+#pragma unroll
+        for (int jj = 0; jj < NCP; ++jj) {
+            const int j = wave + 4 * jj;
+            if (j >= NJ) continue;
+            const int kr = c * 32 + row[jj];
+            const f16* src = zline;
+            if (j < 2 * NI) {
+                if (off[jj] >= 0 && kr < Nk) src = (j < NI ? kbase : vbase) + (int64_t)kr * ldk + off[jj];
+                SF_GLOBAL_LOAD_LDS16_ASM(src, dst + (j < NI ? j : MSZ / 512 + (j - NI)) * 512);
+            } else {
+                if (!oh) continue;
+                if (off[jj] >= 0) src = oh + (int64_t)kr * 64 + off[jj];
+                SF_GLOBAL_LOAD_LDS16_ASM(src, dst + 2 * MSZ + (j - 2 * NI) * 512);
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // forward: workgroup = 64*QT queries of one (batch, head); wave w owns QT column tiles of 16 queries.  With QT = 2
 // every K / V / OH fragment read from LDS feeds two MFMAs (these kernels are LDS-bandwidth bound: 1 KB of operand per
 // 16x16x32 MFMA at QT = 1), and the K/V chunks are re-staged half as often.
 template <int KD, int QT>
 __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 16, DT = D / 16;
-    __shared__ __attribute__((aligned(16))) f16 Ks[32 * KP];
-    __shared__ __attribute__((aligned(16))) f16 Vs[32 * KP];
-    __shared__ __attribute__((aligned(16))) f16 OHs[32 * SF_ATTN_OHP];
+    typedef KeyChunkCopy<D> Copy;
+    __shared__ __attribute__((aligned(16))) f16 KVO[2 * Copy::BUF];      // two buffers of [K | V | OH]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -166,24 +195,18 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) oacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    RowChunk<D, KP> kc, vc;
-    f16x8 ohr = zero8();
-    kc.load(kbase, p.ldk, 0, p.Nk, tid);
-    vc.load(vbase, p.ldk, 0, p.Nk, tid);
-    if (bias) ohr = ld16(p.oh + (int64_t)tid * 8);
+    Copy cp;
+    cp.init(wave, lane);
+    cp.issue(0, KVO, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
     for (int c = 0; c < nch; ++c) {
-        __syncthreads();
-        if (!(p.ablate & 64) || c == 0) {       // (diagnostic bit 64: the K / V / OH chunk is staged once and never refreshed)
-        kc.store(Ks, tid);
-        vc.store(Vs, tid);
-        if (bias) st16(OHs + (tid >> 3) * SF_ATTN_OHP + (tid & 7) * 8, ohr);
-        }
-        __syncthreads();
-        if (c + 1 < nch && !(p.ablate & 64)) {
-            kc.load(kbase, p.ldk, (c + 1) * 32, p.Nk, tid);
-            vc.load(vbase, p.ldk, (c + 1) * 32, p.Nk, tid);
-            if (bias) ohr = ld16(p.oh + ((int64_t)(c + 1) * 32 * 64) + (int64_t)tid * 8);
-        }
+        const f16* const Ks = KVO + (c & 1) * Copy::BUF;
+        const f16* const Vs = Ks + Copy::MSZ;
+        const f16* const OHs = Ks + 2 * Copy::MSZ;
+        SF_WAIT_VMEM();             // this wave's copies of chunk c have landed ...
+        __syncthreads();            // ... and everybody else's; nobody reads chunk c - 1 any more
+        // (diagnostic bit 64: the chunks are not refreshed after the first two)
+        if (c + 1 < nch && !((p.ablate & 64) && c >= 1))
+            cp.issue(c + 1, KVO + ((c + 1) & 1) * Copy::BUF, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
         if (p.ablate & 128) continue;           // (diagnostic bit 128: staging only, no arithmetic)
         float x[QT][8];
 #pragma unroll
@@ -284,9 +307,8 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
 template <int KD, int QT>
 __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 16, DT = D / 16, JT = SF_ATTN_RMAX / 16;
-    __shared__ __attribute__((aligned(16))) f16 Ks[32 * KP];
-    __shared__ __attribute__((aligned(16))) f16 Vs[32 * KP];
-    __shared__ __attribute__((aligned(16))) f16 OHs[32 * SF_ATTN_OHP];
+    typedef KeyChunkCopy<D> Copy;
+    __shared__ __attribute__((aligned(16))) f16 KVO[2 * Copy::BUF];      // two buffers of [K | V | OH]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -348,22 +370,17 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) drqacc[u][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    RowChunk<D, KP> kc, vc;
-    f16x8 ohr = zero8();
-    kc.load(kbase, p.ldk, 0, p.Nk, tid);
-    vc.load(vbase, p.ldk, 0, p.Nk, tid);
-    if (bias) ohr = ld16(p.oh + (int64_t)tid * 8);
+    Copy cp;
+    cp.init(wave, lane);
+    cp.issue(0, KVO, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
     for (int c = 0; c < nch; ++c) {
-        __syncthreads();
-        kc.store(Ks, tid);
-        vc.store(Vs, tid);
-        if (bias) st16(OHs + (tid >> 3) * SF_ATTN_OHP + (tid & 7) * 8, ohr);
-        __syncthreads();
-        if (c + 1 < nch) {
-            kc.load(kbase, p.ldk, (c + 1) * 32, p.Nk, tid);
-            vc.load(vbase, p.ldk, (c + 1) * 32, p.Nk, tid);
-            if (bias) ohr = ld16(p.oh + ((int64_t)(c + 1) * 32 * 64) + (int64_t)tid * 8);
-        }
+        const f16* const Ks = KVO + (c & 1) * Copy::BUF;
+        const f16* const Vs = Ks + Copy::MSZ;
+        const f16* const OHs = Ks + 2 * Copy::MSZ;
+        SF_WAIT_VMEM();             // this wave's copies of chunk c have landed ...
+        __syncthreads();            // ... and everybody else's; nobody reads chunk c - 1 any more
+        if (c + 1 < nch)
+            cp.issue(c + 1, KVO + ((c + 1) & 1) * Copy::BUF, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
         f16x8 dsf[QT];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {

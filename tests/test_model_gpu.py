@@ -99,15 +99,7 @@ def test_well_conditioned_1e3_no_yardstick(gpu, name):
     print(name, mc.check_well_conditioned(name, gpu))
 
 
-FULL_SIZE = {
-    # BASELINE.json configs 2-5 at their full clip size, batch 2
-    "SLOWFAST_8x8_R50": dict(opts=[]),
-    "X3D_M": dict(opts=[]),
-    # MViT: logits, loss, gradient norm at 1e-3 and the gradient vector at 5e-3 as everywhere, no yardstick (round 4: fp32 side rows
-    # of the residual stream, mvit_engine.ResidSide)
-    "MVITv2_S_16x4": dict(opts=["MVIT.DROPPATH_RATE", 0.0, "MIXUP.ENABLE", False], gamma_scale=None, head_abs=False),
-    "SLOWFAST_32x2_R101_50_50": dict(opts=["DATA.TRAIN_CROP_SIZE", 256], boxes_per_clip=3, head_abs=False),
-}
+FULL_SIZE = mc.FULL_SIZE        # BASELINE.json configs 2-5 at their full clip size, batch 2 (MViT: no conditioning device)
 
 
 @pytest.mark.parametrize("preset", list(FULL_SIZE))
@@ -118,6 +110,13 @@ def test_full_size_batch2_against_oracle(gpu, preset):
     oracle's backward through the engine's own ReLU masks / max-pool routes (reference yamls: configs/Kinetics/{SLOWFAST_8x8_R50,X3D_M,
     MVITv2_S_16x4}.yaml, configs/AVA/c2/SLOWFAST_32x2_R101_50_50.yaml)."""
     print(preset, mc.check_full_size(preset, gpu, **FULL_SIZE[preset]))
+
+
+def test_full_size_batch32_against_oracle(gpu):
+    """BASELINE config 2 at the BENCHMARK's batch (32 clips, 32x224^2), no conditioning device, against the fp32 CPU oracle: logits,
+    loss, gradient norm and gradient vector within max(north star, 1.5 x the reference's own autocast(float16) deviation on the same
+    case, pinned in tests/golden/autocast_yardstick.json)."""
+    print(mc.check_batch32("SLOWFAST_8x8_R50", gpu))
 
 
 def test_full_size_batch32_properties(gpu):

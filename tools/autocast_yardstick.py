@@ -89,25 +89,52 @@ def run_eval_case(name, device, dtype):
             "storage_model": {"probs": float((sm - o_probs).abs().max() / pmax)}}
 
 
+def run_full_case(key, device, dtype, loss_scale):
+    """Full-size cases of tests/model_checks.py ("<preset>@full": BASELINE configs at batch 2; "<preset>@b32": the benchmark's batch
+    without any conditioning device): the SAME parameters and clips the GPU tests use, the oracle graph under autocast on the GPU
+    against its fp32 CPU run."""
+    preset, kind = key.split("@")
+    spec = mc.FULL_SIZE[preset] if kind == "full" else mc.BATCH32[preset]
+    cfg, model, fam, sd, inputs, labels, kw = mc.full_size_case(preset, **spec)
+    del model
+    o_logits, o_loss, o_grads, o_stats = fam.loss_and_grads(sd, cfg, list(inputs), labels, **kw)
+    kw = dict(kw, device=device, autocast_dtype=dtype, loss_scale=loss_scale)
+    while True:
+        logits, loss, grads, stats = fam.loss_and_grads(sd, cfg, list(inputs), labels, **kw)
+        if all(torch.isfinite(g).all() for g in grads.values()) or kw["loss_scale"] <= 1.0:
+            break
+        kw["loss_scale"] /= 2.0
+    rec = deviation(logits, loss, grads, stats, o_logits, o_loss, o_grads, o_stats)
+    rec["logits_l2"] = float((logits - o_logits).norm() / o_logits.norm())
+    rec["loss_scale_used"] = kw["loss_scale"]
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*")
+    ap.add_argument("--full", action="store_true", help="the named cases are full-size keys (PRESET@full | PRESET@b32); default: all")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "autocast_yardstick.json"))
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--dtype", default="float16")
     ap.add_argument("--loss-scale", type=float, default=1024.0)
     a = ap.parse_args()
-    names = a.cases or sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(mc.GOLDEN_DIR, "*.json"))
-                              if not os.path.basename(p).startswith("autocast_"))
+    if a.full:
+        names = a.cases or [k + "@full" for k in mc.FULL_SIZE] + [k + "@b32" for k in mc.BATCH32]
+    else:
+        names = a.cases or sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(mc.GOLDEN_DIR, "*.json"))
+                                  if not os.path.basename(p).startswith("autocast_"))
     out = {"_meta": {"torch": torch.__version__, "device": a.device, "dtype": a.dtype, "loss_scale": a.loss_scale,
                      "device_name": torch.cuda.get_device_name(0) if a.device.startswith("cuda") else "cpu",
                      "what": "deviation of the pinned oracle graph under torch.autocast from its fp32 CPU run"}}
-    if os.path.exists(a.out) and a.cases:
+    if os.path.exists(a.out) and (a.cases or a.full):       # a partial run keeps every other entry (and the first run's _meta)
         out.update(json.load(open(a.out)))
     for name in names:
         t = time.time()
         try:
-            if name.startswith("eval_"):
+            if "@" in name:
+                out[name] = run_full_case(name, a.device, getattr(torch, a.dtype), a.loss_scale)
+            elif name.startswith("eval_"):
                 out[name] = run_eval_case(name, a.device, getattr(torch, a.dtype))
             else:
                 out[name] = run_case(name, a.device, getattr(torch, a.dtype), a.loss_scale)
