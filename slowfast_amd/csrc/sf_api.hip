@@ -192,6 +192,16 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
     q.ablate = (e = getenv("SF_IGEMM2_ABLATE")) ? atoi(e) : 0;     // diagnostic: parts of the kernel switched off (wrong results)
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);
+    // 256 x 256 tiles on a SIXTEEN-wave workgroup (opt-in, SF_IGEMM2_FAT=<min tiles>): the wave tile stays 64 x 64 (64 accumulator
+    // registers, four waves per SIMD as with two 8-wave workgroups), the workgroup copies (256 + 256) x 32 operand elements per
+    // 256 x 256 x 32 MACs -- 128 flop per copied byte instead of 85
+    if (q.Nout >= 256 && !q.f32.out && !q.omap && (e = getenv("SF_IGEMM2_FAT")) && atoi(e) > 0 &&
+        cdiv(q.M, 256) * cdiv(q.Nout, 256) >= atoi(e)) {
+        q.ntiles_n = cdiv(q.Nout, 256);
+        const dim3 grid((unsigned)(cdiv(q.M, 256) * q.ntiles_n));
+        hipLaunchKernelGGL((sf_igemm2_kernel<256, 256, 4, 4, 32, 3>), grid, dim3(1024), 0, s, q);
+        return;
+    }
     // (256 x 256 tiles -- 128 flop per copied operand byte instead of 85, one workgroup per CU -- were measured in round 4 and
     // lost on both models: SlowFast 766.5 -> 741 clips/s on every eligible layer, 755 restricted to grids of >= 512 tiles,
     // MViTv2-S 590.9 -> 584 / 588; profiles/r4_v6_knobs_ab.txt.  Removed.)
