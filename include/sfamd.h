@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 21
+#define SF_ABI_VERSION 22
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -228,6 +228,12 @@ int sf_layernorm_bwd_blocks(int64_t M, int32_t C);   /* rows of `part` */
 int sf_layernorm_bwd(int64_t M, int32_t C, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* gamma,
                      const float* mean, const float* rstd, const void* resid, int32_t ldr, void* dx, int32_t lddx,
                      float* part, sf_stream_t stream);
+/* same, and part[blk][2][c] = sum of resid, part[blk][3][c] = sum of the stored dx (part is [blocks][4][C]): the bias gradients of
+ * the Linear layers on either side of the LayerNorm -- in MultiScaleBlock (attention.py:491-514) mlp.fc2.bias from
+ * resid = d(block output) and attn.proj.bias from dx -- without a column-sum pass of their own */
+int sf_layernorm_bwd_sums(int64_t M, int32_t C, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* gamma,
+                          const float* mean, const float* rstd, const void* resid, int32_t ldr, void* dx, int32_t lddx,
+                          float* part, sf_stream_t stream);
 /* column sums of an [M][C] tensor (bias gradients): part[blk][0][c] */
 int sf_colsum_blocks(int64_t M, int32_t C);
 int sf_colsum(int64_t M, int32_t C, const void* x, int32_t ldx, float* part, sf_stream_t stream);
@@ -245,6 +251,7 @@ typedef struct sf_colfin_item {
     float* out1;
     float scale;
     int32_t accumulate;
+    int32_t row_stride;   /* table rows of [2][C] floats between two partial rows (0 / 1: dense; 2: the pairs of a [blk][4][C] table) */
 } sf_colfin_item;
 int sf_colsum_finalize_batch(const sf_colfin_item* items, int32_t n, sf_stream_t stream);
 /* out[i] (+)= scale * sum_b part[b*row_len + offset + i] */

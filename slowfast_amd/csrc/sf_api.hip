@@ -192,19 +192,10 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
     q.ablate = (e = getenv("SF_IGEMM2_ABLATE")) ? atoi(e) : 0;     // diagnostic: parts of the kernel switched off (wrong results)
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);
-    // 256 x 256 tiles on a SIXTEEN-wave workgroup (opt-in, SF_IGEMM2_FAT=<min tiles>): the wave tile stays 64 x 64 (64 accumulator
-    // registers, four waves per SIMD as with two 8-wave workgroups), the workgroup copies (256 + 256) x 32 operand elements per
-    // 256 x 256 x 32 MACs -- 128 flop per copied byte instead of 85
-    if (q.Nout >= 256 && !q.f32.out && !q.omap && (e = getenv("SF_IGEMM2_FAT")) && atoi(e) > 0 &&
-        cdiv(q.M, 256) * cdiv(q.Nout, 256) >= atoi(e)) {
-        q.ntiles_n = cdiv(q.Nout, 256);
-        const dim3 grid((unsigned)(cdiv(q.M, 256) * q.ntiles_n));
-        hipLaunchKernelGGL((sf_igemm2_kernel<256, 256, 4, 4, 32, 3>), grid, dim3(1024), 0, s, q);
-        return;
-    }
     // (256 x 256 tiles -- 128 flop per copied operand byte instead of 85, one workgroup per CU -- were measured in round 4 and
     // lost on both models: SlowFast 766.5 -> 741 clips/s on every eligible layer, 755 restricted to grids of >= 512 tiles,
-    // MViTv2-S 590.9 -> 584 / 588; profiles/r4_v6_knobs_ab.txt.  Removed.)
+    // MViTv2-S 590.9 -> 584 / 588; profiles/r4_v6_knobs_ab.txt.  The same tile on a 16-wave workgroup (64 x 64 wave tiles, four
+    // waves per SIMD kept) moved no layer either: profiles/r4_v11_igemm2_fat_ab.txt.  Both removed.)
     if (q.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }
     else if (q.Nout > 32) { if (bk64) launch_igemm2<64, 64>(q, s); else launch_igemm2<64, 32>(q, s); }
     else launch_igemm2<32, 32>(q, s);
@@ -1252,10 +1243,14 @@ extern "C" int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int3
 // ---- LayerNorm
 template <int L, int NS>
 static void launch_ln_fwd(const LnParams& p, hipStream_t s) {
-    const int rpb = SF_THREADS / L;
+    // rows in flight per thread: 2 for the one-slot rows (SF_LN_RU=1 keeps one, A/B runs)
+    static const int ru_env = getenv("SF_LN_RU") ? atoi(getenv("SF_LN_RU")) : 2;
+    const int ru = (NS == 1 && ru_env != 1) ? 2 : 1;
+    const int rpb = SF_THREADS / L * ru;
     int blocks = cdiv(p.M, rpb);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((sf_layernorm_fwd_kernel<L, NS>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
+    if (ru == 2) hipLaunchKernelGGL((sf_layernorm_fwd_kernel<L, NS, NS == 1 ? 2 : 1>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((sf_layernorm_fwd_kernel<L, NS, 1>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
 }
 template <int L, int NS>
 static void launch_ln_bwd(const LnParams& p, int blocks, hipStream_t s) {
@@ -1306,13 +1301,14 @@ extern "C" int sf_layernorm_bwd_blocks(int64_t M, int32_t C) {
     int rpb;
     return ln_bwd_plan(M, C, rpb);
 }
-extern "C" int sf_layernorm_bwd(int64_t M, int32_t C, const void* dy, int32_t lddy, const void* x, int32_t ldx,
-                                const float* gamma, const float* mean, const float* rstd, const void* resid, int32_t ldr,
-                                void* dx, int32_t lddx, float* part, sf_stream_t stream) {
+static int layernorm_bwd_impl(int64_t M, int32_t C, const void* dy, int32_t lddy, const void* x, int32_t ldx,
+                              const float* gamma, const float* mean, const float* rstd, const void* resid, int32_t ldr,
+                              void* dx, int32_t lddx, float* part, int part_rows, sf_stream_t stream) {
     if (check_ln("sf_layernorm_bwd", M, C)) return -1;
     REQUIRE(dy && x && gamma && mean && rstd && dx && part, "sf_layernorm_bwd: null pointer");
     LnParams p;
     memset(&p, 0, sizeof(p));
+    p.part_rows = part_rows;
     p.M = (int)M; p.C = C; p.x = (const f16*)x; p.ldx = ldx; p.gamma = gamma; p.mean = (float*)mean; p.rstd = (float*)rstd;
     p.dy = (const f16*)dy; p.lddy = lddy; p.resid = (const f16*)resid; p.ldr = ldr; p.dx = (f16*)dx; p.lddx = lddx;
     p.part = part;
@@ -1323,6 +1319,16 @@ extern "C" int sf_layernorm_bwd(int64_t M, int32_t C, const void* dy, int32_t ld
     else if (C <= 512) launch_ln_bwd<64, 1>(p, blocks, s);
     else launch_ln_bwd<64, 2>(p, blocks, s);
     return check_launch("layernorm_bwd");
+}
+extern "C" int sf_layernorm_bwd(int64_t M, int32_t C, const void* dy, int32_t lddy, const void* x, int32_t ldx,
+                                const float* gamma, const float* mean, const float* rstd, const void* resid, int32_t ldr,
+                                void* dx, int32_t lddx, float* part, sf_stream_t stream) {
+    return layernorm_bwd_impl(M, C, dy, lddy, x, ldx, gamma, mean, rstd, resid, ldr, dx, lddx, part, 2, stream);
+}
+extern "C" int sf_layernorm_bwd_sums(int64_t M, int32_t C, const void* dy, int32_t lddy, const void* x, int32_t ldx,
+                                     const float* gamma, const float* mean, const float* rstd, const void* resid, int32_t ldr,
+                                     void* dx, int32_t lddx, float* part, sf_stream_t stream) {
+    return layernorm_bwd_impl(M, C, dy, lddy, x, ldx, gamma, mean, rstd, resid, ldr, dx, lddx, part, 4, stream);
 }
 
 // ---- column sums
@@ -1369,7 +1375,9 @@ extern "C" int sf_colsum_finalize_batch(const sf_colfin_item* items, int32_t n, 
             REQUIRE(it.nblk <= kFoldAbove || it.nblk <= 256, "sf_colsum_finalize_batch: item %d has %d partial rows (use sf_colsum_finalize)",
                     i0 + i, it.nblk);
             ColFinalizeParams& p = b.item[i];
-            p.part = it.part; p.nblk = it.nblk; p.row_stride = 1; p.C = it.C; p.fold = it.fold; p.out0 = it.out0; p.out1 = it.out1;
+            REQUIRE(it.row_stride >= 0 && it.row_stride <= 64, "sf_colsum_finalize_batch: bad row stride in item %d", i0 + i);
+            p.part = it.part; p.nblk = it.nblk; p.row_stride = it.row_stride > 0 ? it.row_stride : 1; p.C = it.C; p.fold = it.fold;
+            p.out0 = it.out0; p.out1 = it.out1;
             p.scale = it.scale; p.accumulate = it.accumulate;
             b.first[i + 1] = b.first[i] + cdiv(it.fold, SF_FIN_CH);
             if (sf_fin_threads(it.nblk) > threads) threads = sf_fin_threads(it.nblk);

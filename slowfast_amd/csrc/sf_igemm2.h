@@ -88,8 +88,7 @@ __device__ __forceinline__ int i2_lds_off(int row, int kslot) {
 //    alone and the MFMA stream alone each take 75-80 % of the kernel's time and overlap only partly.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NST, bool F32R = false>   // F32R: see sf_igemm_kernel
 // register cap: the 32-deep variant must fit TWO workgroups per CU (4 waves per SIMD -> 128 VGPRs), the 64-deep one runs alone
-// (16 waves -- the 256 x 256 "fat" workgroup, one per CU -- are capped at four waves per SIMD like two 8-wave workgroups)
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 16 ? 4 : (BK == 32 ? 2 : 1) * (WAVES_M * WAVES_N) / 4) void sf_igemm2_kernel(Igemm2Params p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES_M * WAVES_N) / 4) void sf_igemm2_kernel(Igemm2Params p) {
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 16, TN = WN / 16;

@@ -23,7 +23,10 @@ struct LnParams {
     const f16* dy; int lddy;
     const f16* resid; int ldr;      // optional: dx += resid (the skip path of a residual stream)
     f16* dx; int lddx;
-    float* part;                    // [gridDim.x][2][C]: sum dy*xhat, sum dy
+    float* part;                    // [gridDim.x][part_rows][C]: sum dy*xhat, sum dy [, sum resid, sum dx]
+    int part_rows;                  // 2, or 4: also the column sums of the residual operand and of the stored result -- the bias
+                                    // gradients of the Linear layers on either side of the LayerNorm (MultiScaleBlock: fc2.bias
+                                    // from resid = d(block output), attn.proj.bias from dx), without a pass of their own
     int rows_per_block;
     F32Rows f32;                    // forward: rows with an fp32 side copy (f32.in) are normalised from it instead of from x
 };
@@ -35,9 +38,12 @@ __device__ __forceinline__ float ln_group_sum(float v) {
     return v;
 }
 
-template <int L, int NS>
+// RU rows per thread and pass are in flight together (round 4: with one row the kernel sat at 2.5 TB/s -- one 16-byte load,
+// two shuffle reductions and a store per thread in strict sequence; the loads of the second row now overlap the first row's
+// reductions).  RU = 2 for the narrow rows (NS = 1), 1 for C > 512.
+template <int L, int NS, int RU>
 __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_fwd_kernel(LnParams p) {
-    constexpr int RPB = SF_THREADS / L;        // rows per block pass
+    constexpr int RPB = SF_THREADS / L;        // rows per block pass and unroll slot
     const int sub = threadIdx.x % L, rl = threadIdx.x / L;
     float ga[NS][8], be[NS][8];
 #pragma unroll
@@ -51,52 +57,63 @@ __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_fwd_kernel(LnParams p
     }
     const float invC = 1.f / (float)p.C;
     // all lanes of a wave stay in the loop together (shuffles): rows beyond M are computed on zeros, not stored
-    for (int base = blockIdx.x * RPB; base < p.M; base += gridDim.x * RPB) {
-        const int m = base + rl;
-        const bool rowok = m < p.M;
-        float v[NS][8];
-        float s1 = 0.f;
+    for (int base = blockIdx.x * RPB * RU; base < p.M; base += gridDim.x * RPB * RU) {
+        float v[RU][NS][8];
+        float s1[RU];
+        int m[RU];
+        bool rowok[RU];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int c = (sub + s * L) * 8;
-            uint32_t srow;
-            if (p.f32.in && rowok && c < p.C && f32_row(p.f32, m, srow)) {
-                load8f(p.f32.in + (int64_t)srow * p.f32.ld + c, v[s]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s1 += v[s][e];
-                continue;
-            }
-            f16x8 h = (rowok && c < p.C) ? ld16(p.x + (int64_t)m * p.ldx + c) : zero8();
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { v[s][e] = (float)h[e]; s1 += v[s][e]; }
-        }
-        const float mean = ln_group_sum<L>(s1) * invC;
-        float s2 = 0.f;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int c = (sub + s * L) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = c < p.C ? v[s][e] - mean : 0.f;
-                s2 += d * d;
-            }
-        }
-        const float var = ln_group_sum<L>(s2) * invC;
-        const float rstd = 1.0f / sqrtf(var + p.eps);
-        if (rowok) {
+        for (int u = 0; u < RU; ++u) {
+            m[u] = base + u * RPB + rl;
+            rowok[u] = m[u] < p.M;
+            s1[u] = 0.f;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int c = (sub + s * L) * 8;
-                if (c < p.C) {
-                    f16x8 o;
+                uint32_t srow;
+                if (p.f32.in && rowok[u] && c < p.C && f32_row(p.f32, m[u], srow)) {
+                    load8f(p.f32.in + (int64_t)srow * p.f32.ld + c, v[u][s]);
+                } else {
+                    const f16x8 h = (rowok[u] && c < p.C) ? ld16(p.x + (int64_t)m[u] * p.ldx + c) : zero8();
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (f16)((v[s][e] - mean) * rstd * ga[s][e] + be[s][e]);
-                    st16(p.y + (int64_t)m * p.ldy + c, o);
+                    for (int e = 0; e < 8; ++e) v[u][s][e] = (float)h[e];
                 }
             }
-            if (sub == 0) {
-                if (p.mean) p.mean[m] = mean;
-                if (p.rstd) p.rstd[m] = rstd;
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s1[u] += v[u][s][e];
+            const float mean = ln_group_sum<L>(s1[u]) * invC;
+            float s2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int c = (sub + s * L) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = c < p.C ? v[u][s][e] - mean : 0.f;
+                    s2 += d * d;
+                }
+            }
+            const float var = ln_group_sum<L>(s2) * invC;
+            const float rstd = 1.0f / sqrtf(var + p.eps);
+            if (rowok[u]) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int c = (sub + s * L) * 8;
+                    if (c < p.C) {
+                        f16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (f16)((v[u][s][e] - mean) * rstd * ga[s][e] + be[s][e]);
+                        st16(p.y + (int64_t)m[u] * p.ldy + c, o);
+                    }
+                }
+                if (sub == 0) {
+                    if (p.mean) p.mean[m[u]] = mean;
+                    if (p.rstd) p.rstd[m[u]] = rstd;
+                }
             }
         }
     }
@@ -109,7 +126,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_bwd_kernel(LnParams p
     constexpr int RPB = SF_THREADS / L;
     __shared__ float s_acc[SF_THREADS][NS * 16 + 1];
     const int sub = threadIdx.x % L, rl = threadIdx.x / L;
-    float ga[NS][8], ag[NS][8], ab[NS][8];
+    const bool sums = p.part_rows == 4;
+    float ga[NS][8], ag[NS][8], ab[NS][8], ar[NS][8], ax[NS][8];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int c = (sub + s * L) * 8;
@@ -118,6 +136,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_bwd_kernel(LnParams p
             ga[s][e] = c < p.C ? p.gamma[c + e] : 0.f;
             ag[s][e] = 0.f;
             ab[s][e] = 0.f;
+            ar[s][e] = 0.f;
+            ax[s][e] = 0.f;
         }
     }
     const float invC = 1.f / (float)p.C;
@@ -159,34 +179,41 @@ __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_bwd_kernel(LnParams p
                     for (int e = 0; e < 8; ++e)
                         o[e] = (f16)(rstd * (g[s][e] - c1 - xh[s][e] * c2) + (float)r[e]);
                     st16(p.dx + (int64_t)m * p.lddx + c, o);
+                    if (sums) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { ar[s][e] += (float)r[e]; ax[s][e] += (float)o[e]; }
+                    }
                 }
             }
         }
     }
-    // fold the RPB row-lanes of the block (fixed order), write one partial row
+    // fold the RPB row-lanes of the block (fixed order), write one partial row (two passes when the extra sums are wanted)
+    for (int pass = 0; pass < (sums ? 2 : 1); ++pass) {
+        if (pass) __syncthreads();
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            s_acc[threadIdx.x][s * 16 + e] = ag[s][e];
-            s_acc[threadIdx.x][s * 16 + 8 + e] = ab[s][e];
-        }
-    __syncthreads();
-    if (rl == 0) {
-        float* o = p.part + (int64_t)blockIdx.x * 2 * p.C;
+            for (int e = 0; e < 8; ++e) {
+                s_acc[threadIdx.x][s * 16 + e] = pass ? ar[s][e] : ag[s][e];
+                s_acc[threadIdx.x][s * 16 + 8 + e] = pass ? ax[s][e] : ab[s][e];
+            }
+        __syncthreads();
+        if (rl == 0) {
+            float* o = p.part + ((int64_t)blockIdx.x * p.part_rows + 2 * pass) * p.C;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int c = (sub + s * L) * 8;
-            if (c < p.C) {
+            for (int s = 0; s < NS; ++s) {
+                const int c = (sub + s * L) * 8;
+                if (c < p.C) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float a = 0.f, b = 0.f;
-                    for (int k = 0; k < RPB; ++k) {
-                        a += s_acc[sub + k * L][s * 16 + e];
-                        b += s_acc[sub + k * L][s * 16 + 8 + e];
+                    for (int e = 0; e < 8; ++e) {
+                        float a = 0.f, b = 0.f;
+                        for (int k = 0; k < RPB; ++k) {
+                            a += s_acc[sub + k * L][s * 16 + e];
+                            b += s_acc[sub + k * L][s * 16 + 8 + e];
+                        }
+                        o[c + e] = a;
+                        o[p.C + c + e] = b;
                     }
-                    o[c + e] = a;
-                    o[p.C + c + e] = b;
                 }
             }
         }

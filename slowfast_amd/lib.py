@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 21
+ABI_VERSION = 22
 # 16-bit storage type of activations / packed weights / MFMA operands, fixed per PROCESS: SF_ACT_DTYPE=fp16 (default) loads
 # libsfamd.so, =bf16 loads libsfamd_bf16.so -- the same sources compiled with -DSF_ACT_BF16 (bfloat16 storage,
 # v_mfma_f32_16x16x32_bf16); both are what torch.cuda.amp.autocast admits on the reference side (tools/train_net.py:101-118).
@@ -66,7 +66,7 @@ class ColFinItem(Structure):
     """Mirror of ``sf_colfin_item`` (one finalize of a batched sf_colsum_finalize_batch launch)."""
 
     _fields_ = [("part", c_void_p), ("nblk", c_int32), ("C", c_int32), ("fold", c_int32), ("out0", c_void_p),
-                ("out1", c_void_p), ("scale", c_float), ("accumulate", c_int32)]
+                ("out1", c_void_p), ("scale", c_float), ("accumulate", c_int32), ("row_stride", c_int32)]
 
 
 class AttnDesc(Structure):
@@ -128,6 +128,7 @@ _SIGNATURES = {
                                         POINTER(Rows32), _P]),
     "sf_layernorm_bwd_blocks": (c_int, [c_int64, c_int32]),
     "sf_layernorm_bwd": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _F, _F, _F, _P, c_int32, _P, c_int32, _F, _P]),
+    "sf_layernorm_bwd_sums": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _F, _F, _F, _P, c_int32, _P, c_int32, _F, _P]),
     "sf_colsum_blocks": (c_int, [c_int64, c_int32]),
     "sf_colsum": (c_int, [c_int64, c_int32, _P, c_int32, _F, _P]),
     "sf_colsum_finalize": (c_int, [_F, c_int32, c_int32, c_int32, _F, _F, c_float, c_int, _P]),

@@ -110,15 +110,15 @@ class LinearUnit:
         w, _ = self._ops(fresh=True)
         return tokens.gemm_gelu(x, w, bias=self.lin.bias)
 
-    def backward_through_gelu(self, x, dy, h, consumer_bias=None):
+    def backward_through_gelu(self, x, dy, h, consumer_bias=None, bias_done=False):
         """Like backward(), but returns (d(loss)/d(h), bias_done) for x = gelu(h): the data gradient times gelu'(h) in one
-        GEMM.  ``consumer_bias``: the bias parameter of the Linear that produced h (fc1); bias_done = its gradient was taken in
-        this GEMM's epilogue."""
+        GEMM.  ``consumer_bias``: the bias parameter of the Linear that produced h (fc1); the returned flag = its gradient was
+        taken in this GEMM's epilogue.  ``bias_done``: this layer's own bias gradient comes from elsewhere (bias_sum_dest)."""
         lin = self.lin
         if lin.weight.requires_grad:
             dw, zero_first = _grad_dest(lin.weight)
             tokens.linear_wgrad(x, dy, dw, zero_first=zero_first)
-        if lin.bias is not None and lin.bias.requires_grad:
+        if lin.bias is not None and lin.bias.requires_grad and not bias_done:
             db, zero_first = _grad_dest(lin.bias)
             tokens.bias_grad(dy, db, accumulate=not zero_first)
         _, wt = self._ops()
@@ -143,6 +143,15 @@ class LinearUnit:
             return None
         _, wt = self._ops()
         return tokens.gemm(dy, wt, resid=resid, out=out)
+
+    def bias_sum_dest(self):
+        """(fp32 [N] destination, accumulate) for a kernel that produces the column sums of this layer's output gradient as a
+        by-product (tokens.layernorm_bwd(sums=...)), or None when the bias takes no gradient."""
+        b = self.lin.bias
+        if b is None or not b.requires_grad:
+            return None
+        dest, zero_first = _grad_dest(b)
+        return dest, not zero_first
 
     def params(self):
         return [p for p in (self.lin.weight, self.lin.bias) if p is not None]
@@ -199,12 +208,12 @@ class NormUnit:
     def forward(self, x, side=None):
         return tokens.layernorm_fwd(x, self.ln.weight, self.ln.bias, self.ln.eps, side=side)
 
-    def backward(self, dy, x, mean, rstd, resid=None):
+    def backward(self, dy, x, mean, rstd, resid=None, sums=None):
         ln = self.ln
         dg, zg = _grad_dest(ln.weight)
         db, zb = _grad_dest(ln.bias)
         assert zg == zb
-        return tokens.layernorm_bwd(dy, x, ln.weight, mean, rstd, dg, db, resid=resid, accumulate=not zg)
+        return tokens.layernorm_bwd(dy, x, ln.weight, mean, rstd, dg, db, resid=resid, accumulate=not zg, sums=sums)
 
     def params(self):
         return [self.ln.weight, self.ln.bias]
@@ -285,6 +294,8 @@ class AttentionPlan:
 _FUSED_DEFAULT = "1"
 # GELU in the fc1 GEMM epilogue / gelu' in the fc2 data-gradient epilogue (SF_GELU_FUSED=0: separate elementwise passes)
 _FUSED_GELU = os.environ.get("SF_GELU_FUSED", "1") != "0"
+# bias gradients of mlp.fc2 / attn.proj from the column sums norm2's backward takes in passing (SF_LN_BIAS_SUMS=0: separate passes)
+_LN_BIAS_SUMS = os.environ.get("SF_LN_BIAS_SUMS", "1") != "0"
 
 
 def _fused_attention(plan):
@@ -563,20 +574,29 @@ class MultiScaleBlockFn(torch.autograd.Function):
         drop = ctx.drop
         # Mlp
         dbr = dout if drop is None else tokens.row_scale_add(dout, drop[1], dout.shape[1])
+        proj_first = mod._proj is not None and mod.dim_mul_in_att
+        proj_last = mod._proj is not None and not proj_first
+        # Without stochastic depth, norm2's backward reads d(block output) as its residual operand and writes d(x1): their column
+        # sums ARE the bias gradients of mlp.fc2 and attn.proj -- taken from that pass instead of two column-sum passes (round 4)
+        ln_sums = drop is None and not proj_last and _LN_BIAS_SUMS
         if _FUSED_GELU:
-            dh, b1_done = mod.mlp._fc2.backward_through_gelu(sv["a"], dbr, sv["h"], consumer_bias=mod.mlp.fc1.bias)
+            dh, b1_done = mod.mlp._fc2.backward_through_gelu(sv["a"], dbr, sv["h"], consumer_bias=mod.mlp.fc1.bias,
+                                                            bias_done=ln_sums)
         else:
-            da = mod.mlp._fc2.backward(sv["a"], dbr)
+            da = mod.mlp._fc2.backward(sv["a"], dbr, bias_done=ln_sums)
             dh, b1_done = tokens.gelu_bwd(sv["h"], da), False
         dxn2 = mod.mlp._fc1.backward(sv["xn2"], dh, bias_done=b1_done)
-        proj_first = mod._proj is not None and mod.dim_mul_in_att
-        if mod._proj is not None and not proj_first:       # the skip path went through proj(norm2(x1))
+        if proj_last:                                      # the skip path went through proj(norm2(x1))
             dxn2 = mod._proj.backward(sv["xn2"], dout, resid=dxn2)
             dx1 = mod._norm2.backward(dxn2, sv["x1"], *sv["s2"])
+        elif ln_sums:
+            dx1 = mod._norm2.backward(dxn2, sv["x1"], *sv["s2"], resid=dout,
+                                      sums=(mod.mlp._fc2.bias_sum_dest(), att._proj.bias_sum_dest()))
         else:
             dx1 = mod._norm2.backward(dxn2, sv["x1"], *sv["s2"], resid=dout)
         # attention output projection, attention core, qkv projection
-        do = att._proj.backward(sv["o"], dx1 if drop is None else tokens.row_scale_add(dx1, drop[0], dx1.shape[1]))
+        do = att._proj.backward(sv["o"], dx1 if drop is None else tokens.row_scale_add(dx1, drop[0], dx1.shape[1]),
+                                bias_done=ln_sums)
         if att.pool_first:
             dxn = attention_backward_pool_first(att, plan, sv["xn"], sv["att"], do)
         else:

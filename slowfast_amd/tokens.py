@@ -218,27 +218,39 @@ def flush_finalizes():
     if not items:
         return
     _pending_fin = []
+    _finalize_batch(items)
+
+
+def _finalize_batch(items):
     arr = (ColFinItem * len(items))()
-    for i, (part, C, fold, out0, out1, scale, accumulate) in enumerate(items):
-        arr[i] = ColFinItem(part.data_ptr(), part.shape[0], C, fold, _ptr(out0), _ptr(out1), float(scale), int(accumulate))
+    for i, (part, C, fold, out0, out1, scale, accumulate, stride) in enumerate(items):
+        arr[i] = ColFinItem(part.data_ptr(), part.shape[0], C, fold, _ptr(out0), _ptr(out1), float(scale), int(accumulate),
+                            int(stride))
     _lib_call("sf_colsum_finalize_batch", arr, len(items), _stream(items[0][0]))
 
 
-def colsum_finalize(part, C, fold, out0, out1, scale=1.0, accumulate=False):
+def colsum_finalize(part, C, fold, out0, out1, scale=1.0, accumulate=False, row_stride=1):
+    """``part``: [rows, 2, C] view of the table (``row_stride`` > 1: the pairs of a wider [rows, 2 * row_stride, C] table, the view
+    starting at the first pair wanted)."""
     if _pending_fin is not None and part.shape[0] <= _FIN_MAX_ROWS:
         outs = [o.data_ptr() for o in (out0, out1) if o is not None]
         for it in _pending_fin:                         # a second contribution to the same output waits for the first
             if any(o is not None and o.data_ptr() in outs for o in (it[3], it[4])):
                 flush_finalizes()
                 break
-        _pending_fin.append((part, C, fold, out0, out1, scale, accumulate))
+        _pending_fin.append((part, C, fold, out0, out1, scale, accumulate, row_stride))
+        return
+    if row_stride != 1:
+        _finalize_batch([(part, C, fold, out0, out1, scale, accumulate, row_stride)])
         return
     _lib_call("sf_colsum_finalize", part.data_ptr(), part.shape[0], C, fold, _ptr(out0), _ptr(out1), float(scale),
               int(accumulate), _stream(part))
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, resid=None, accumulate=False, out=None):
-    """dx (+ resid); dgamma / dbeta written (or accumulated) in fp32."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, resid=None, accumulate=False, out=None, sums=None):
+    """dx (+ resid); dgamma / dbeta written (or accumulated) in fp32.  ``sums = ((dest_resid, accumulate) | None,
+    (dest_dx, accumulate) | None)``: the column sums of ``resid`` and of the stored result land in those fp32 [C] vectors -- the
+    bias gradients of the Linear layers whose output gradient they are -- from the same pass."""
     M, C, ldx = rows_pitch(x)
     _, _, lddy = rows_pitch(dy)
     dx = torch.empty(x.shape, dtype=_f16, device=x.device) if out is None else out
@@ -246,6 +258,22 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, resid=None, accumulat
     ldr = rows_pitch(resid)[2] if resid is not None else 0
     lib = get_lib()
     nblk = lib.call("sf_layernorm_bwd_blocks", M, C)
+    if sums is not None and (sums[0] is not None or sums[1] is not None):
+        assert sums[0] is None or resid is not None
+        part = torch.empty((nblk, 4, C), dtype=torch.float32, device=x.device)
+        lib.call("sf_layernorm_bwd_sums", M, C, dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), mean.data_ptr(),
+                 rstd.data_ptr(), _ptr(resid), ldr, dx.data_ptr(), lddx, part.data_ptr(), _stream(x),
+                 work=dict(bytes=2.0 * M * C * (3 + int(resid is not None))))
+        colsum_finalize(part[:, 0:2], C, C, dgamma, dbeta, 1.0, accumulate, row_stride=2)
+        (d0, a0), (d1, a1) = (sums[0] or (None, False)), (sums[1] or (None, False))
+        if d0 is not None and d1 is not None and a0 == a1:
+            colsum_finalize(part[:, 2:4], C, C, d0, d1, 1.0, a0, row_stride=2)
+        else:
+            if d0 is not None:
+                colsum_finalize(part[:, 2:4], C, C, d0, None, 1.0, a0, row_stride=2)
+            if d1 is not None:
+                colsum_finalize(part[:, 2:4], C, C, None, d1, 1.0, a1, row_stride=2)
+        return dx
     part = torch.empty((nblk, 2, C), dtype=torch.float32, device=x.device)
     lib.call("sf_layernorm_bwd", M, C, dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), mean.data_ptr(),
              rstd.data_ptr(), _ptr(resid), ldr, dx.data_ptr(), lddx, part.data_ptr(), _stream(x),

@@ -27,14 +27,6 @@ CASES = [
 ]
 
 
-def test_igemm2_fat_workgroup(sim, force_v2, monkeypatch):
-    """Opt-in 256 x 256 tiles on a 16-wave workgroup (SF_IGEMM2_FAT): forward with BatchNorm statistics, data gradient."""
-    monkeypatch.setenv("SF_IGEMM2_FAT", "1")
-    kc.check_conv_fwd(sim, (2, 64, 1, 20, 20), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1))
-    kc.check_conv_fwd(sim, (1, 64, 2, 9, 9), 320, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1))      # ragged second N tile
-    kc.check_conv_dgrad(sim, (1, 256, 2, 6, 6), 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1))    # dgrad: N = Ci = 256
-
-
 @pytest.mark.parametrize("case", CASES)
 def test_igemm2_fwd(sim, force_v2, case):
     kc.check_conv_fwd(sim, *case)

@@ -48,6 +48,15 @@ def check_layernorm(device, M, C, seed=0):
     assert_close("ln dx", dx.float().cpu(), xr.grad + res, 3 * F16_EPS)
     assert_close("ln dgamma", dg.cpu(), gr.grad, 1e-3 * EPS_SCALE)
     assert_close("ln dbeta", db.cpu(), br.grad, 1e-3 * EPS_SCALE)
+    # the same pass with the column sums of the residual operand and of the stored result (bias gradients of the neighbouring
+    # Linear layers): same dx bit for bit, sums of exactly the 16-bit values that were read / written
+    dg2, db2 = torch.empty(C, device=device), torch.empty(C, device=device)
+    sr, sx = torch.full((C,), 7.0, device=device), torch.full((C,), 3.0, device=device)
+    dx2 = tokens.layernorm_bwd(_h(dy, device), _h(x, device), gamma.to(device), mean, rstd, dg2, db2, resid=_h(res, device),
+                               sums=((sr, False), (sx, True)))
+    assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
+    assert_close("ln sum resid", sr.cpu(), res.sum(0), 1e-4 * EPS_SCALE)
+    assert_close("ln sum dx (accumulated onto 3)", sx.cpu(), dx.float().cpu().sum(0) + 3.0, 1e-4 * EPS_SCALE)
 
 
 def check_gelu(device, n, seed=0):
