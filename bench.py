@@ -282,7 +282,8 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
             reducer.finish(loss_scale=a.loss_scale)
         else:
             (loss * opt.loss_scale).backward()
-            reducer.finish(loss_scale=None)
+            opt.finish_and_step()
+            return loss
         opt.step()
         return loss
 

@@ -415,7 +415,8 @@ int sf_gate_act_bwd(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy,
  *   [0] loss scale  [1] growth tracker  [2] found_inf of this step  [3] global gradient norm (unscaled, mean over ranks)
  *   [4] multiplier applied to the raw gradients = clip_coef / (world * scale)  [5] clean optimizer steps  [6] skipped steps. */
 int sf_flat_blocks(int64_t n);                                  /* rows of `part` ([rows][2] fp32) for sf_flat_sumsq */
-int sf_flat_sumsq(const float* g, int64_t n, float* part, sf_stream_t stream);
+int sf_flat_sumsq(const float* g, int64_t n, float* part, sf_stream_t stream);     /* g: any 4-byte aligned range of the buffer (a
+                                                                 * bucket at a time: the partial rows simply add up) */
 /* one workgroup: norm / found_inf / clip coefficient into ctl; GradScaler.update() when `dynamic` */
 int sf_step_control(const float* part, int32_t nblk, float* ctl, float world, float clip_norm, int dynamic, float growth,
                     float backoff, int32_t growth_interval, sf_stream_t stream);

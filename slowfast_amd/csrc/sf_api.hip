@@ -2166,7 +2166,7 @@ extern "C" int sf_flat_blocks(int64_t n) {
 }
 extern "C" int sf_flat_sumsq(const float* g, int64_t n, float* part, sf_stream_t stream) {
     REQUIRE(g && part && n > 0, "sf_flat_sumsq: bad arguments");
-    REQUIRE((uintptr_t)g % 16 == 0, "sf_flat_sumsq: the buffer must be 16-byte aligned");
+    REQUIRE((uintptr_t)g % 4 == 0, "sf_flat_sumsq: the buffer must be 4-byte aligned");
     FlatSumsqParams p;
     p.g = g; p.n = n; p.part = part;
     hipLaunchKernelGGL(sf_flat_sumsq_kernel, dim3(sf_flat_blocks(n)), dim3(SF_THREADS), 0, (hipStream_t)stream, p);

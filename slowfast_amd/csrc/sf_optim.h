@@ -29,11 +29,17 @@ struct FlatSumsqParams {
 __global__ __launch_bounds__(SF_THREADS) void sf_flat_sumsq_kernel(FlatSumsqParams p) {
     __shared__ double s_s[SF_THREADS];
     __shared__ float s_b[SF_THREADS];
-    const int64_t n4 = p.n >> 2;
+    // a bucket of the gradient buffer may start at any element (slowfast_amd.optim: per-bucket partial sums while later buckets
+    // are still being exchanged): up to three leading elements are peeled so that the body reads aligned 16-byte vectors
+    int64_t head = (4 - (int64_t)((reinterpret_cast<uintptr_t>(p.g) >> 2) & 3)) & 3;
+    if (head > p.n) head = p.n;
+    const float* const g = p.g + head;
+    const int64_t nb = p.n - head;
+    const int64_t n4 = nb >> 2;
     double acc = 0.0;
     float bad = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * SF_THREADS) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p.g + 4 * i);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + 4 * i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x = v[e];
@@ -41,12 +47,18 @@ __global__ __launch_bounds__(SF_THREADS) void sf_flat_sumsq_kernel(FlatSumsqPara
             else acc += (double)x * (double)x;
         }
     }
-    if (blockIdx.x == 0)
-        for (int64_t i = 4 * n4 + threadIdx.x; i < p.n; i += SF_THREADS) {
-            const float x = p.g[i];
+    if (blockIdx.x == 0) {
+        for (int64_t i = 4 * n4 + threadIdx.x; i < nb; i += SF_THREADS) {
+            const float x = g[i];
             if (!(fabsf(x) <= 3.0e38f)) bad += 1.f;
             else acc += (double)x * (double)x;
         }
+        if ((int64_t)threadIdx.x < head) {
+            const float x = p.g[threadIdx.x];
+            if (!(fabsf(x) <= 3.0e38f)) bad += 1.f;
+            else acc += (double)x * (double)x;
+        }
+    }
     s_s[threadIdx.x] = acc;
     s_b[threadIdx.x] = bad;
     __syncthreads();

@@ -111,26 +111,37 @@ class GradReducer:
             # under torch's hook; FlatOptimizer's inf check then skips the step and backs the scale off.
             low = (view * self._prescale).to(self.comm_dtype)
             h = dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._handles.append((h, view, low))
+            self._handles.append((h, view, low, bi))
             self._prescaled.add(bi)
         else:
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._handles.append((h, None, None))
+            self._handles.append((h, None, None, bi))
 
-    def finish(self, loss_scale=1.0):
+    def finish(self, loss_scale=1.0, on_bucket=None):
         """Wait for outstanding collectives; gradients become mean over ranks of the unscaled gradients.
         ``loss_scale=None``: only wait -- the buffer keeps the loss-scaled SUM over ranks, which is what
-        slowfast_amd.optim.FlatOptimizer.step() expects (it folds 1 / (world * scale) into its single update pass)."""
+        slowfast_amd.optim.FlatOptimizer.step() expects (it folds 1 / (world * scale) into its single update pass).
+        ``on_bucket(bi)``: called right after bucket bi's collective has been waited for (a stream-level wait under RCCL), in
+        launch order -- FlatOptimizer takes the bucket's share of the gradient norm / overflow check there, so that pass runs
+        under the exchange of the buckets still in flight instead of after all of them."""
+        done = set()
         if self.collectives:
             for bi, n in enumerate(self._pending):
                 if n > 0:                         # parameters that got no gradient this iteration
                     self._pending[bi] = 0
                     self._launch(bi)
-            for h, view, low in self._handles:
+            for h, view, low, bi in self._handles:
                 h.wait()
                 if low is not None:
                     view.copy_(low)
+                if on_bucket is not None:
+                    on_bucket(bi)
+                    done.add(bi)
             self._handles = []
+        if on_bucket is not None:                 # buckets without a collective (world 1, capture replay of a single rank)
+            for bi in range(len(self.buckets)):
+                if bi not in done:
+                    on_bucket(bi)
         if loss_scale is None:
             for bi in self._prescaled:      # compressed buckets were averaged before the cast: back to a sum
                 s, e, _ = self.buckets[bi]

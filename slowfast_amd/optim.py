@@ -77,7 +77,16 @@ class FlatOptimizer:
         self.ctl = torch.zeros(8, dtype=torch.float32, device=dev)
         self.ctl[CTL_SCALE] = float(loss_scale)
         self.init_loss_scale = float(loss_scale)
-        self._part = torch.empty((get_lib().call("sf_flat_blocks", flat_g.numel()), 2), dtype=torch.float32, device=dev)
+        # partial rows of the norm / overflow pass: one range per gradient bucket (finish_and_step), rows simply add up
+        lib = get_lib()
+        self._bucket_rows = []
+        r = 0
+        for s0, e0, _ in reducer.buckets:
+            nb = lib.call("sf_flat_blocks", e0 - s0)
+            self._bucket_rows.append((r, nb))
+            r += nb
+        self._part = torch.empty((max(r, lib.call("sf_flat_blocks", flat_g.numel())), 2), dtype=torch.float32, device=dev)
+        self._rows_bucketed = r
 
     # -- what the training loop touches ---------------------------------------------------------------------------
     @property
@@ -95,13 +104,32 @@ class FlatOptimizer:
     def found_inf(self):
         return self.ctl[CTL_FOUND_INF]
 
-    def step(self):
+    def _sumsq_bucket(self, bi):
+        """Bucket bi's share of the norm / overflow pass (its own rows of the partial table)."""
+        s0, e0, _ = self.reducer.buckets[bi]
+        r0, _ = self._bucket_rows[bi]
+        g = self.reducer.flat
+        get_lib().call("sf_flat_sumsq", g.data_ptr() + 4 * s0, e0 - s0, self._part.data_ptr() + 8 * r0, _stream(g),
+                       work=dict(bytes=4.0 * (e0 - s0)))
+
+    def finish_and_step(self):
+        """GradReducer.finish(loss_scale=None) + step(), with the norm / overflow pass taken bucket by bucket as the collectives
+        complete: the pass over the early buckets runs under the exchange of the late ones, and the update waits only for the
+        control launch (only the ~30 us pass moves -- the update itself needs the global norm)."""
+        self.reducer.finish(loss_scale=None, on_bucket=self._sumsq_bucket)
+        self.step(_sumsq_rows=self._rows_bucketed)
+
+    def step(self, _sumsq_rows=None):
         """Call after the gradient all-reduce finished (GradReducer.finish(loss_scale=None)): norm + overflow check,
-        GradScaler update, clipped / unscaled parameter update -- skipped as a whole on overflow."""
+        GradScaler update, clipped / unscaled parameter update -- skipped as a whole on overflow.  ``_sumsq_rows``: the partial
+        table already holds that many rows (finish_and_step)."""
         lib, g = get_lib(), self.reducer.flat
         s = _stream(g)
-        lib.call("sf_flat_sumsq", g.data_ptr(), g.numel(), self._part.data_ptr(), s, work=dict(bytes=4.0 * g.numel()))
-        lib.call("sf_step_control", self._part.data_ptr(), self._part.shape[0], self.ctl.data_ptr(), float(self.reducer.world),
+        nrows = _sumsq_rows
+        if nrows is None:
+            nrows = lib.call("sf_flat_blocks", g.numel())
+            lib.call("sf_flat_sumsq", g.data_ptr(), g.numel(), self._part.data_ptr(), s, work=dict(bytes=4.0 * g.numel()))
+        lib.call("sf_step_control", self._part.data_ptr(), nrows, self.ctl.data_ptr(), float(self.reducer.world),
                  self.clip_norm, int(self.dynamic), self.growth, self.backoff, self.growth_interval, s)
         ng = len(self.param_groups)
         lr = (c_float * ng)(*[float(gp["lr"]) for gp in self.param_groups])

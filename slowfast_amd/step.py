@@ -153,8 +153,7 @@ class TrainStep:
         if self._flat:
             # one norm pass + one control launch + one fused update over the flat buffers (csrc/sf_optim.h): unscale, inf /
             # NaN check with skip-step, GradScaler update, clipping and the optimizer arithmetic -- no host sync
-            self.reducer.finish(loss_scale=None)
-            self.optimizer.step()
+            self.optimizer.finish_and_step()       # the norm pass runs bucket by bucket under the remaining collectives
             self.grad_norm = self.optimizer.grad_norm
             self._queue_stats()
             return

@@ -119,9 +119,9 @@ def check_train_step_vs_torch(device, case, solver_opts, steps=5, overflow_at=2,
     snaps = []
     orig_step = opt.step
 
-    def snap_step():
+    def snap_step(**kw):
         snaps.append(red.flat.detach().float().cpu().clone())      # loss-scaled gradients, right before the fused update
-        orig_step()
+        orig_step(**kw)
     opt.step = snap_step
 
     # (A) torch.optim + GradScaler on the engine's own gradients; (B) the same sequence on the oracle's

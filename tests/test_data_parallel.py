@@ -397,7 +397,9 @@ def _overlap_worker(rank, world, port, simlib, q):
         offs[p] = o
         o += p.numel()
     ref = torch.cat([mean[offs[p]:offs[p] + p.numel()] for p in red.params])
-    q.put((rank, float((got - ref).norm() / ref.norm()), step.overlap_log[-1], len(step._seg_params), len(red.buckets)))
+    # the norm pass ran bucket by bucket under the later collectives (FlatOptimizer.finish_and_step)
+    nerr = abs(float(opt.grad_norm) - float(ref.double().norm())) / float(ref.double().norm())
+    q.put((rank, max(float((got - ref).norm() / ref.norm()), nerr), step.overlap_log[-1], len(step._seg_params), len(red.buckets)))
     red.close()
     dist.destroy_process_group()
 

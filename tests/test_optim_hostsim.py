@@ -84,6 +84,46 @@ def test_flat_adamw_clipping_and_world(sim):
     red.close()
 
 
+def test_bucketwise_norm_pass_matches_whole_buffer(sim):
+    """finish_and_step(): the norm / overflow pass taken bucket by bucket (as each bucket's all-reduce completes) leaves the
+    same control block and parameters as the one-pass step(); tiny buckets make every bucket start unaligned."""
+    for poison in (False, True):
+        outs = []
+        for bucketed in (False, True):
+            net, ref = _pair()
+            for m in (net, ref):                         # 7 elements ahead of everything else in the flat buffer
+                m.d = torch.nn.Parameter(torch.linspace(-1, 1, 7))
+            red = GradReducer(net, bucket_mb=4e-5 if bucketed else 48)            # 10 elements: a bucket per parameter
+            assert (len(red.buckets) > 3) == bucketed
+            if bucketed:
+                assert any(s0 % 4 for s0, _, _ in red.buckets)
+            groups = _groups(net, 0.1)
+            groups[1]["params"].append(net.d)
+            opt = FlatOptimizer(groups, red, method="sgd", momentum=0.9, nesterov=True, loss_scale=32.0,
+                                clip_grad_l2norm=0.5, dynamic_loss_scale=True)
+            seen = []
+            for it in range(2):
+                _set_grads(net, ref, red, 50 + it, 32.0, poison=poison and it == 1)
+                if bucketed:
+                    sumsq = opt._sumsq_bucket
+                    opt._sumsq_bucket = lambda bi, f=sumsq: (seen.append(bi), f(bi))[1]
+                    opt.finish_and_step()
+                    opt._sumsq_bucket = sumsq
+                else:
+                    red.finish(loss_scale=None)
+                    opt.step()
+            if bucketed:
+                assert sorted(seen) == sorted(2 * list(range(len(red.buckets))))
+            outs.append(([p.data.clone() for p in net.parameters()], opt.ctl.clone()))
+            red.close()
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+        ca, cb = outs[0][1], outs[1][1]
+        fin = torch.isfinite(ca)
+        assert torch.equal(fin, torch.isfinite(cb)) and torch.allclose(ca[fin], cb[fin], rtol=1e-6)
+        assert float(cb[2]) == float(poison)
+
+
 def test_flat_sgd_clip_value(sim):
     net, ref = _pair()
     red = GradReducer(net)
