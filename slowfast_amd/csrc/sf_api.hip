@@ -1696,9 +1696,10 @@ extern "C" int sf_relpos_scatter(const sf_attn_desc* d, const float* drq, const 
     const int R = d->kH + d->kW + d->kT;
     const int64_t rows = (int64_t)d->B * d->Nq * d->heads, total = rows * R;
     REQUIRE(total < (1ll << 31), "sf_relpos_scatter: too many elements");
-    REQUIRE(hipMemsetAsync(E, 0, (size_t)rows * lde * sizeof(f16), (hipStream_t)stream) == hipSuccess, "sf_relpos_scatter: memset failed");
-    hipLaunchKernelGGL(sf_relpos_scatter_kernel, dim3(pool_grid(total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p,
-                       (f16*)E, lde, make_fastdiv((uint32_t)R), total);
+    REQUIRE((uintptr_t)E % 16 == 0, "sf_relpos_scatter: E must be 16-byte aligned");
+    const int64_t chunks = (rows + SF_RELPOS_SC_ROWS - 1) / SF_RELPOS_SC_ROWS;
+    hipLaunchKernelGGL(sf_relpos_scatter_kernel, dim3((unsigned)(chunks < 8192 ? chunks : 8192)), dim3(SF_THREADS), 0,
+                       (hipStream_t)stream, p, (f16*)E, lde, make_fastdiv((uint32_t)R), R, rows);
     return check_launch("relpos_scatter");
 }
 // out[i] (+)= scale * sum_b part[b*row_len + offset + i], i < n   (table gradients from per-block partials):

@@ -385,16 +385,29 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_gather_kernel(RelPosPara
         p.rq[i] = is_cls ? 0.f : (float)G[(int64_t)row * ldg + relpos_col(p, (int)j, qt, qh, qw)];
     }
 }
-// E is zero-filled by the caller of the kernel (sf_relpos_scatter: a memset node in front of it)
-__global__ __launch_bounds__(SF_THREADS) void sf_relpos_scatter_kernel(RelPosParams p, f16* E, int lde, FastDiv fdR,
-                                                                        int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * SF_THREADS) {
-        uint32_t row, j, b, tok, head;
-        fd_divmod((uint32_t)i, fdR, row, j);
-        int qt, qh, qw;
-        bool is_cls;
-        relpos_row_decode(p, row, b, tok, head, qt, qh, qw, is_cls);
-        if (!is_cls) E[(int64_t)row * lde + relpos_col(p, (int)j, qt, qh, qw)] = (f16)p.drq[i];
+// Each workgroup owns chunks of SF_RELPOS_SC_ROWS whole rows of E: it zero-fills them with 16-byte stores and then, behind a
+// barrier, drops the rows' R gradient entries into place.  (A hipMemsetAsync in front of a flat scatter did the same in eager
+// launches, but as a memset node of a captured graph the fill did not take effect before the readers of E on ROCm 7.2: from
+// the second replay on E kept what the block's previous owner had left -- profiles/r4_v13_graph_memset.md.  libsfamd issues
+// no memset / memcpy stream operations any more: everything a captured step does is a kernel node.)
+#define SF_RELPOS_SC_ROWS 32
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_scatter_kernel(RelPosParams p, f16* E, int lde, FastDiv fdR, int R,
+                                                                        int64_t rows) {
+    const int l8 = lde >> 3;
+    for (int64_t r0 = (int64_t)blockIdx.x * SF_RELPOS_SC_ROWS; r0 < rows; r0 += (int64_t)gridDim.x * SF_RELPOS_SC_ROWS) {
+        const int nr = rows - r0 < SF_RELPOS_SC_ROWS ? (int)(rows - r0) : SF_RELPOS_SC_ROWS;
+        f32x4* const dst = reinterpret_cast<f32x4*>(E + r0 * lde);
+        for (int i = threadIdx.x; i < nr * l8; i += SF_THREADS) dst[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * R; i += SF_THREADS) {
+            uint32_t lr, j, b, tok, head;
+            fd_divmod((uint32_t)i, fdR, lr, j);
+            const int64_t row = r0 + lr;
+            int qt, qh, qw;
+            bool is_cls;
+            relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
+            if (!is_cls) E[row * lde + relpos_col(p, (int)j, qt, qh, qw)] = (f16)p.drq[row * R + j];
+        }
     }
 }
 

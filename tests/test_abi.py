@@ -99,3 +99,15 @@ def test_error_reporting_through_c_abi(sim):
         ops.prep_weights(torch.zeros(16, 12, 1, 1, 1), geom)
     with pytest.raises(lib.SfError, match="not channels-last"):
         ops.cl_ld(torch.zeros(1, 16, 1, 4, 4, dtype=lib.act_dtype()))
+
+
+def test_captured_step_is_kernel_nodes_only():
+    """libsfamd issues kernel launches only: a hipMemsetAsync in front of the rel-pos scatter became a memset node under stream
+    capture whose fill did not take effect before its readers from the second replay on (profiles/r4_v13_graph_memset.md)."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "slowfast_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*"))):
+        with open(path) as f:
+            code = re.sub(r"//[^\n]*", "", f.read())
+        assert not re.search(r"\bhipMem(set|cpy)\w*\s*\(", code), path
