@@ -1252,9 +1252,15 @@ static void launch_ln_fwd(const LnParams& p, hipStream_t s) {
     if (ru == 2) hipLaunchKernelGGL((sf_layernorm_fwd_kernel<L, NS, NS == 1 ? 2 : 1>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
     else hipLaunchKernelGGL((sf_layernorm_fwd_kernel<L, NS, 1>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
 }
+static int ln_bwd_ru() {
+    static const int ru = getenv("SF_LN_BWD_RU") ? atoi(getenv("SF_LN_BWD_RU")) : 2;
+    return ru;
+}
 template <int L, int NS>
 static void launch_ln_bwd(const LnParams& p, int blocks, hipStream_t s) {
-    hipLaunchKernelGGL((sf_layernorm_bwd_kernel<L, NS>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
+    // rows in flight per thread: 2 for the one-slot rows (SF_LN_BWD_RU=1 keeps one, A/B runs)
+    if (NS == 1 && ln_bwd_ru() != 1) hipLaunchKernelGGL((sf_layernorm_bwd_kernel<L, NS, NS == 1 ? 2 : 1>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((sf_layernorm_bwd_kernel<L, NS, 1>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
 }
 static int ln_lanes(int C) { return C <= 128 ? 16 : C <= 256 ? 32 : 64; }
 static int check_ln(const char* who, int64_t M, int C) {
@@ -1291,8 +1297,11 @@ extern "C" int sf_layernorm_fwd_rows32(int64_t M, int32_t C, const void* x, int3
 }
 static int ln_bwd_plan(int64_t M, int C, int& rows_per_block) {
     const int rpb = SF_THREADS / ln_lanes(C);
+    // every workgroup resident at once: 256 CUs x 4 (one row in flight, 4 waves per SIMD) or x 3 (two rows, 154 VGPRs)
+    static const int env_blocks = getenv("SF_LN_BWD_BLOCKS") ? atoi(getenv("SF_LN_BWD_BLOCKS")) : 0;
+    const int max_blocks = env_blocks > 0 ? env_blocks : (C <= 512 && ln_bwd_ru() != 1) ? 768 : 1024;
     int blocks = cdiv(M, rpb);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > max_blocks) blocks = max_blocks;
     rows_per_block = roundup(cdiv(M, blocks), rpb);
     return cdiv(M, rows_per_block);
 }

@@ -121,7 +121,11 @@ __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_fwd_kernel(LnParams p
 
 // dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * gamma;  per-block partial sums of
 // dy*xhat (dgamma) and dy (dbeta) for the column reduction.
-template <int L, int NS>
+// RU rows per thread are in flight together and the residual operand is fetched with x and dy at the top of the iteration
+// (round 4: with one row per pass and the residual load issued only behind the two shuffle reductions, a thread had two, then
+// one, 16-byte loads outstanding -- at the launch's four waves per SIMD that bounded the kernel at ~2.5 TB/s).  RU = 2 takes 154
+// VGPRs = three waves per SIMD: the launch is sized to 768 workgroups then, all resident at once (sf_api.hip: ln_bwd_plan).
+template <int L, int NS, int RU>
 __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_bwd_kernel(LnParams p) {
     constexpr int RPB = SF_THREADS / L;
     __shared__ float s_acc[SF_THREADS][NS * 16 + 1];
@@ -144,79 +148,103 @@ __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_bwd_kernel(LnParams p
     const int r0 = blockIdx.x * p.rows_per_block;
     int r1 = r0 + p.rows_per_block;
     if (r1 > p.M) r1 = p.M;
-    for (int base = r0; base < r1; base += RPB) {
-        const int m = base + rl;
-        const bool rowok = m < r1;
-        const float mean = rowok ? p.mean[m] : 0.f, rstd = rowok ? p.rstd[m] : 0.f;
-        float xh[NS][8], g[NS][8];
-        float s1 = 0.f, s2 = 0.f;
+    for (int base = r0; base < r1; base += RPB * RU) {
+        f16x8 hx[RU][NS], hd[RU][NS], hr[RU][NS];
+        float mean[RU], rstd[RU];
+        int m[RU];
+        bool rowok[RU];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int c = (sub + s * L) * 8;
-            const bool ok = rowok && c < p.C;
-            f16x8 hx = ok ? ld16(p.x + (int64_t)m * p.ldx + c) : zero8();
-            f16x8 hd = ok ? ld16(p.dy + (int64_t)m * p.lddy + c) : zero8();
+        for (int u = 0; u < RU; ++u) {
+            m[u] = base + u * RPB + rl;
+            rowok[u] = m[u] < r1;
+            mean[u] = rowok[u] ? p.mean[m[u]] : 0.f;
+            rstd[u] = rowok[u] ? p.rstd[m[u]] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = (float)hd[e];
-                xh[s][e] = ok ? ((float)hx[e] - mean) * rstd : 0.f;
-                g[s][e] = d * ga[s][e];
-                s1 += g[s][e];
-                s2 += g[s][e] * xh[s][e];
-                ag[s][e] += d * xh[s][e];
-                ab[s][e] += d;
+            for (int s = 0; s < NS; ++s) {
+                const int c = (sub + s * L) * 8;
+                const bool ok = rowok[u] && c < p.C;
+                hx[u][s] = ok ? ld16(p.x + (int64_t)m[u] * p.ldx + c) : zero8();
+                hd[u][s] = ok ? ld16(p.dy + (int64_t)m[u] * p.lddy + c) : zero8();
+                hr[u][s] = (ok && p.resid) ? ld16(p.resid + (int64_t)m[u] * p.ldr + c) : zero8();
             }
         }
-        const float c1 = ln_group_sum<L>(s1) * invC, c2 = ln_group_sum<L>(s2) * invC;
-        if (rowok) {
+        float s1[RU], s2[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            s1[u] = 0.f;
+            s2[u] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const bool ok = rowok[u] && (sub + s * L) * 8 < p.C;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (float)hd[u][s][e];
+                    const float xh = ok ? ((float)hx[u][s][e] - mean[u]) * rstd[u] : 0.f;
+                    const float g = d * ga[s][e];
+                    s1[u] += g;
+                    s2[u] += g * xh;
+                    ag[s][e] += d * xh;
+                    ab[s][e] += d;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            s1[u] = ln_group_sum<L>(s1[u]) * invC;
+            s2[u] = ln_group_sum<L>(s2[u]) * invC;
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            if (!rowok[u]) continue;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int c = (sub + s * L) * 8;
                 if (c < p.C) {
-                    f16x8 r = p.resid ? ld16(p.resid + (int64_t)m * p.ldr + c) : zero8();
                     f16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        o[e] = (f16)(rstd * (g[s][e] - c1 - xh[s][e] * c2) + (float)r[e]);
-                    st16(p.dx + (int64_t)m * p.lddx + c, o);
+                    for (int e = 0; e < 8; ++e) {
+                        // xhat and g are recomputed from the 16-bit operands (the same expressions as above): keeping them
+                        // for RU rows costs 16 registers per row
+                        const float xh = ((float)hx[u][s][e] - mean[u]) * rstd[u];
+                        const float g = (float)hd[u][s][e] * ga[s][e];
+                        o[e] = (f16)(rstd[u] * (g - s1[u] - xh * s2[u]) + (float)hr[u][s][e]);
+                    }
+                    st16(p.dx + (int64_t)m[u] * p.lddx + c, o);
                     if (sums) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { ar[s][e] += (float)r[e]; ax[s][e] += (float)o[e]; }
+                        for (int e = 0; e < 8; ++e) { ar[s][e] += (float)hr[u][s][e]; ax[s][e] += (float)o[e]; }
                     }
                 }
             }
         }
     }
-    // fold the RPB row-lanes of the block (fixed order), write one partial row (two passes when the extra sums are wanted)
-    for (int pass = 0; pass < (sums ? 2 : 1); ++pass) {
-        if (pass) __syncthreads();
+    // fold the RPB row-lanes of the block (fixed order): every thread folds L * NS * 16 / SF_THREADS of the block's
+    // L * NS * 16 column sums (a second pass when the extra sums are wanted).  The two passes are spelled out: selecting the
+    // accumulator set by a loop variable put all four sets into scratch memory.
+    auto fold = [&](const float (&A)[NS][8], const float (&B)[NS][8], int pass) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                s_acc[threadIdx.x][s * 16 + e] = pass ? ar[s][e] : ag[s][e];
-                s_acc[threadIdx.x][s * 16 + 8 + e] = pass ? ax[s][e] : ab[s][e];
+                s_acc[threadIdx.x][s * 16 + e] = A[s][e];
+                s_acc[threadIdx.x][s * 16 + 8 + e] = B[s][e];
             }
         __syncthreads();
-        if (rl == 0) {
-            float* o = p.part + ((int64_t)blockIdx.x * p.part_rows + 2 * pass) * p.C;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int c = (sub + s * L) * 8;
-                if (c < p.C) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float a = 0.f, b = 0.f;
-                        for (int k = 0; k < RPB; ++k) {
-                            a += s_acc[sub + k * L][s * 16 + e];
-                            b += s_acc[sub + k * L][s * 16 + 8 + e];
-                        }
-                        o[c + e] = a;
-                        o[p.C + c + e] = b;
-                    }
-                }
+        float* const o = p.part + ((int64_t)blockIdx.x * p.part_rows + 2 * pass) * p.C;
+        for (int idx = threadIdx.x; idx < L * NS * 16; idx += SF_THREADS) {
+            const int so = idx / (NS * 16), j = idx - so * (NS * 16), s = j >> 4, jj = j & 15;
+            const int c = (so + s * L) * 8 + (jj & 7);
+            if (c < p.C) {
+                float a = 0.f;
+                for (int k = 0; k < RPB; ++k) a += s_acc[so + k * L][j];
+                o[(jj >> 3) * p.C + c] = a;
             }
         }
+    };
+    fold(ag, ab, 0);
+    if (sums) {
+        __syncthreads();
+        fold(ar, ax, 1);
     }
 }
 

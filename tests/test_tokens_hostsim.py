@@ -24,6 +24,7 @@ def test_layernorm(sim):
     tc.check_layernorm(sim, 50, 192)
     tc.check_layernorm(sim, 21, 384)
     tc.check_layernorm(sim, 19, 768)
+    tc.check_layernorm(sim, 25000 + 5, 96)        # several passes per workgroup, ragged last one (768 workgroups x 16 rows x 2)
 
 
 def test_gelu(sim):

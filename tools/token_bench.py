@@ -1,6 +1,6 @@
 """Microbenchmark of the MViT token-space kernels at MViTv2-S shapes (batch 32): fused attention forward / backward and the
 depthwise pooling convolutions, HIP-event timed; also the thing `rocprofv3 --pmc` is pointed at (tools/gpu/r4_v3.sh).
-`python tools/token_bench.py [--iters N] [--only attn|dw|stage3]`"""
+`python tools/token_bench.py [--iters N] [--only attn|dw|ln|stage3]`"""
 import argparse
 import os
 import sys
@@ -62,6 +62,38 @@ def dw_case(B, heads, Cw, thw, stride, iters, dev):
           f"{by / t_d * 1e-3:5.0f} GB/s | wgrad {t_w:6.1f} us {(by + 2.0 * C * geom.rows_out) / t_w * 1e-3:5.0f} GB/s")
 
 
+def ln_case(M, C, iters, dev):
+    """LayerNorm forward / backward (with the residual operand and the two extra column sums, as MultiScaleBlock runs it); the
+    operands are cycled over enough copies to come from HBM, not from the 256 MB Infinity Cache."""
+    f16 = lib.act_dtype()
+    ncopy = max(1, int(1.2e9 // (2.0 * M * C * 4)))
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn((M, C), generator=g).to(f16).to(dev) for _ in range(ncopy)]
+    dys = [torch.randn((M, C), generator=g).to(f16).to(dev) for _ in range(ncopy)]
+    rs = [torch.randn((M, C), generator=g).to(f16).to(dev) for _ in range(ncopy)]
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    dg, db, s0, s1 = (torch.empty(C, device=dev) for _ in range(4))
+    y, mean, rstd = tokens.layernorm_fwd(xs[0], gamma, beta, 1e-6)
+    out, dx = torch.empty_like(xs[0]), torch.empty_like(xs[0])
+    it = [0]
+
+    def fwd():
+        it[0] += 1
+        tokens.layernorm_fwd(xs[it[0] % ncopy], gamma, beta, 1e-6, out=out)
+
+    def bwd(sums):
+        it[0] += 1
+        i = it[0] % ncopy
+        tokens.layernorm_bwd(dys[i], xs[i], gamma, mean, rstd, dg, db, resid=rs[i], out=dx,
+                             sums=((s0, False), (s1, False)) if sums else None)
+    t_f = timed(fwd, iters)
+    t_b = timed(lambda: bwd(False), iters)
+    t_s = timed(lambda: bwd(True), iters)
+    by = 2.0 * M * C
+    print(f"layernorm M{M} C{C}: fwd {t_f:7.1f} us {2 * by / t_f * 1e-3:6.0f} GB/s | bwd+resid {t_b:7.1f} us {4 * by / t_b * 1e-3:6.0f} GB/s"
+          f" | bwd+resid+sums {t_s:7.1f} us {4 * by / t_s * 1e-3:6.0f} GB/s (incl. the finalize launches)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
@@ -73,6 +105,11 @@ def main():
     if a.only in ("", "attn"):
         attn_case(32, 1, 96, (8, 56, 56), (8, 7, 7), a.iters, dev)      # block 0
         attn_case(32, 8, 96, (8, 7, 7), (8, 7, 7), a.iters, dev)        # stage 4
+    if a.only in ("", "ln"):
+        ln_case(32 * 25089, 96, a.iters, dev)                            # block 0
+        ln_case(32 * 6273, 192, a.iters, dev)                            # stage 2
+        ln_case(32 * 1569, 384, a.iters, dev)                            # stage 3 (11 blocks)
+        ln_case(32 * 393, 768, a.iters, dev)                             # stage 4
     if a.only in ("", "dw", "stage3"):
         dw_case(32, 4, 96, (8, 14, 14), (1, 1, 1), a.iters, dev)        # stage 3 q pool
         dw_case(32, 4, 96, (8, 14, 14), (1, 2, 2), a.iters, dev)        # stage 3 k / v pool
