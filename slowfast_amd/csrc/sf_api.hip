@@ -1243,13 +1243,15 @@ extern "C" int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int3
 // ---- LayerNorm
 template <int L, int NS>
 static void launch_ln_fwd(const LnParams& p, hipStream_t s) {
-    // rows in flight per thread: 2 for the one-slot rows (SF_LN_RU=1 keeps one, A/B runs)
+    // rows in flight per thread: 2 for the one- and three-slot rows (SF_LN_RU=1 keeps one, A/B runs)
     static const int ru_env = getenv("SF_LN_RU") ? atoi(getenv("SF_LN_RU")) : 2;
-    const int ru = (NS == 1 && ru_env != 1) ? 2 : 1;
+    constexpr int RU2 = NS != 2 ? 2 : 1;
+    const int ru = ru_env != 1 ? RU2 : 1;
+    static const int max_blocks = getenv("SF_LN_FWD_BLOCKS") ? atoi(getenv("SF_LN_FWD_BLOCKS")) : 4096;
     const int rpb = SF_THREADS / L * ru;
     int blocks = cdiv(p.M, rpb);
-    if (blocks > 4096) blocks = 4096;
-    if (ru == 2) hipLaunchKernelGGL((sf_layernorm_fwd_kernel<L, NS, NS == 1 ? 2 : 1>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (ru == 2) hipLaunchKernelGGL((sf_layernorm_fwd_kernel<L, NS, RU2>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
     else hipLaunchKernelGGL((sf_layernorm_fwd_kernel<L, NS, 1>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
 }
 static int ln_bwd_ru() {
@@ -1279,7 +1281,12 @@ static int layernorm_fwd_impl(int64_t M, int32_t C, const void* x, int32_t ldx, 
     p.y = (f16*)y; p.ldy = ldy; p.mean = mean; p.rstd = rstd;
     if (rows32_arg("sf_layernorm_fwd_rows32", side, M, C, false, p.f32)) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (C <= 128) launch_ln_fwd<16, 1>(p, s);
+    // C = 768: three 8-channel slots on 32 lanes (no idle lanes, 8 rows per workgroup pass) instead of two slots on 64 lanes
+    // with a quarter of them idle: 41.6 -> 30.8 us at M = 12576.  The same idea at C = 96 / 192 / 384 (4 / 8 / 16 lanes x three
+    // slots) is SLOWER than the power-of-two lane counts with idle lanes (72 -> 81, 44 -> 52, 34 -> 49 us): a wave's 16-byte
+    // loads then cover 64 / 128 / 256-byte pieces at the row pitch instead of whole rows (profiles/r4_v16_ln_bench.txt).
+    if (C == 768) launch_ln_fwd<32, 3>(p, s);
+    else if (C <= 128) launch_ln_fwd<16, 1>(p, s);
     else if (C <= 256) launch_ln_fwd<32, 1>(p, s);
     else if (C <= 512) launch_ln_fwd<64, 1>(p, s);
     else launch_ln_fwd<64, 2>(p, s);
