@@ -1247,7 +1247,9 @@ static void launch_ln_fwd(const LnParams& p, hipStream_t s) {
     static const int ru_env = getenv("SF_LN_RU") ? atoi(getenv("SF_LN_RU")) : 2;
     constexpr int RU2 = NS != 2 ? 2 : 1;
     const int ru = ru_env != 1 ? RU2 : 1;
-    static const int max_blocks = getenv("SF_LN_FWD_BLOCKS") ? atoi(getenv("SF_LN_FWD_BLOCKS")) : 4096;
+    // 2048 workgroups (= the chip's 8 waves per SIMD once over) walking the rows: 68 / 39 / 27.5 us at the MViTv2-S block-0 /
+    // stage-2 / stage-3 shapes against 73 / 44 / 36 us with 4096 and 81 / 58 / 45 us with 8192 (profiles/r4_v17_ln_fwd_blocks.txt)
+    static const int max_blocks = getenv("SF_LN_FWD_BLOCKS") ? atoi(getenv("SF_LN_FWD_BLOCKS")) : 2048;
     const int rpb = SF_THREADS / L * ru;
     int blocks = cdiv(p.M, rpb);
     if (blocks > max_blocks) blocks = max_blocks;

@@ -50,6 +50,16 @@ __global__ __launch_bounds__(SF_THREADS) void sf_part_fold_kernel(float* part, i
     float* base = part + (int64_t)r0 * cols + col;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int r = r0;
+    // eight rows in flight (round 4: 6.3 -> 5.3 us per launch; same order of additions as the four-row form below).  The same
+    // change in the finalize kernels' row walk, together with a shuffle fold instead of the LDS tree, made THEM slower (7.5 ->
+    // 7.9 us, profiles/r4_v17_finalize_ab.txt): they are not bound by their load chain.
+    for (; r + 8 <= r1; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = base[(int64_t)(r - r0 + i) * cols];
+        a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+        a0 += (double)v[4]; a1 += (double)v[5]; a2 += (double)v[6]; a3 += (double)v[7];
+    }
     for (; r + 4 <= r1; r += 4) {
         const float v0 = base[(int64_t)(r - r0) * cols], v1 = base[(int64_t)(r - r0 + 1) * cols];
         const float v2 = base[(int64_t)(r - r0 + 2) * cols], v3 = base[(int64_t)(r - r0 + 3) * cols];
