@@ -1609,6 +1609,69 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
     }
     return check_launch("dwconv_dgrad");
 }
+// LDS-tiled weight gradient (sf_dwtile.h: sf_dwtile_wgrad_kernel).  SF_DW_WGRAD_TILED=0 keeps the stencils (A/B runs).
+static bool dwtile_wgrad_shape_ok(const sf_dw_desc* d) {
+    if (d->kT != 3 || d->kH != 3 || d->kW != 3 || d->pT != 1 || d->pH != 1 || d->pW != 1) return false;
+    if (d->sT != 1 || d->sH != d->sW || (d->sH != 1 && d->sH != 2) || d->To != d->Ti) return false;
+    return d->C % SF_DWT_CC == 0 && d->Wi <= 16;        // wider planes: the stencil is as fast (sf_dwtile.h)
+}
+static bool dwtile_wgrad_plan(const sf_dw_desc* d, DwTileWgradParams& p, int& cls_lds) {
+    const char* lv = getenv("SF_DW_WGRAD_TILED");   // read per call (tests switch it mid-process)
+    if (lv && atoi(lv) == 0) return false;
+    if (!dwtile_wgrad_shape_ok(d)) return false;
+    memset(&p, 0, sizeof(p));
+    p.N = d->N; p.C = d->C; p.cls = d->cls ? 1 : 0; p.T = d->Ti;
+    p.Hi = d->Hi; p.Wi = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo; p.s = d->sH;
+    p.CT = p.Wi + 2;
+    p.rowf = p.CT * SF_DWW_PP + 16;
+    p.nchunks = d->C / SF_DWT_CC;
+    double best = 0.0;
+    int best_th = 0;
+    int best_cls = 0;
+    const char* e = getenv("SF_DWT_TH");            // tests force a row-tile height (read per call)
+    const int force_th = e ? atoi(e) : 0;
+    for (int th = p.Ho < 64 ? p.Ho : 64; th >= 1; --th) {
+        if (force_th > 0 && th != (force_th < p.Ho ? force_th : p.Ho)) continue;
+        const int rt = (th - 1) * p.s + 3;
+        const int64_t xf = (int64_t)rt * p.rowf, dp = (int64_t)th * p.Wo * SF_DWT_CC + 32;
+        if ((int64_t)rt * p.CT * SF_DWT_G > SF_THREADS * SF_DWT_VPT || (int64_t)th * p.Wo * SF_DWT_G > SF_THREADS * SF_DWW_VPT) continue;
+        // LDS class: 0 = 47 KiB (three workgroups per CU), 1 = large x tile + small dy slots, 67 KiB (two), 2 = 85 KiB (one)
+        if (xf > SF_DWW_XF_L || dp > SF_DWW_DP_L) continue;
+        const int lc = xf <= SF_DWW_XF_S && dp <= SF_DWW_DP_S ? 0 : dp <= SF_DWW_DP_S ? 1 : 2;
+        const bool small = lc == 0;
+        const double resid = lc == 0 ? 1.0 : lc == 1 ? 0.75 : 0.5;
+        const int tiles = cdiv(p.Ho, th);
+        // rows are cut into nseg pieces of >= 4 positions: the cut that loads the seven subsets most evenly (fewest pieces on a tie)
+        int nseg = 0;
+        double balance = 0.0;
+        for (int ns = cdiv(p.Wo, 16); ns <= (p.Wo >= 4 ? p.Wo / 4 : 1); ++ns) {
+            const int items = th * ns, nsub = items < SF_DWW_SUBMAX ? items : SF_DWW_SUBMAX;
+            const double b = (double)items / ((double)cdiv(items, nsub) * SF_DWW_SUBMAX);     // busy share of the 7 subsets
+            if (b > balance + 1e-9) { balance = b; nseg = ns; }
+        }
+        if (!nseg) { nseg = 1; balance = (double)(th < SF_DWW_SUBMAX ? th : SF_DWW_SUBMAX) / SF_DWW_SUBMAX; }
+        const double rows = (double)p.Ho / ((double)tiles * th);                                 // useful rows of the tiles
+        const double halo = (double)(th * p.s) / rt;
+        const double blocks = (double)d->N * tiles * p.nchunks;
+        const double want = small ? 768.0 : lc == 1 ? 512.0 : 256.0;
+        const double fill = blocks >= want ? 1.0 : blocks / want;
+        const double quality = balance * rows * halo * resid;
+        if (quality < 0.3 && force_th <= 0) continue;       // badly filled tiles: the stencil is the better kernel
+        const double score = quality * fill;
+        if (score > best) { best = score; best_th = th; best_cls = lc; p.nseg = nseg; }
+    }
+    if (!best_th) return false;
+    p.TH = best_th; p.RT = (best_th - 1) * p.s + 3;
+    p.tiles_h = cdiv(p.Ho, best_th);
+    p.SL = cdiv(p.Wo, p.nseg);
+    p.nitems = best_th * p.nseg;
+    p.nsub = p.nitems < SF_DWW_SUBMAX ? p.nitems : SF_DWW_SUBMAX;
+    p.fdCT = make_fastdiv(p.CT); p.fdG = make_fastdiv(SF_DWT_G); p.fdWo = make_fastdiv(p.Wo); p.fdSeg = make_fastdiv(p.nseg);
+    cls_lds = best_cls;
+    const int64_t per_n_x = (int64_t)p.T * p.Hi * p.Wi + p.cls, per_n_dy = (int64_t)p.T * p.Ho * p.Wo + p.cls;
+    if (per_n_x * d->ldx >= (1ll << 31) || per_n_dy * d->ldy >= (1ll << 31)) return false;
+    return true;
+}
 extern "C" int64_t sf_dwconv_wgrad_workspace(const sf_dw_desc* d) {
     DwParams p;
     dim3 grid;
@@ -1617,7 +1680,11 @@ extern "C" int64_t sf_dwconv_wgrad_workspace(const sf_dw_desc* d) {
         DwBlockIdx bi;
         dw_block_plan(p, bi, d, true, kDwWgradBlocks, grid);
     }
-    return (int64_t)grid.x * d->kT * d->kH * d->kW * d->C * 4;
+    // the tiled kernel writes one row per (sample, row tile): at most N * Ho of them whatever tile height a later call plans
+    // (the size is cached by the callers; SF_DW_WGRAD_TILED / SF_DWT_TH are read per call)
+    int64_t rows = grid.x;
+    if (dwtile_wgrad_shape_ok(d) && (int64_t)d->N * d->Ho > rows) rows = (int64_t)d->N * d->Ho;
+    return rows * d->kT * d->kH * d->kW * d->C * 4;
 }
 extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* dy, float* dw, float out_scale,
                                int zero_first, void* workspace, int64_t workspace_bytes, sf_stream_t stream) {
@@ -1626,6 +1693,38 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
     if (fill_dw(p, d, true, kDwWgradBlocks, grid)) return -1;
     REQUIRE(x && dy && dw && workspace, "sf_dwconv_wgrad: null pointer");
     const int taps = d->kT * d->kH * d->kW;
+    {
+        DwTileWgradParams tp;
+        int lc;
+        if (dwtile_wgrad_plan(d, tp, lc)) {
+            const int nblk = tp.N * tp.tiles_h;
+            REQUIRE(workspace_bytes >= (int64_t)nblk * taps * d->C * 4, "sf_dwconv_wgrad: workspace too small");
+            tp.x = (const f16*)x; tp.ldx = d->ldx; tp.dy = (const f16*)dy; tp.lddy = d->ldy; tp.wpart = (float*)workspace;
+            const dim3 tgrid((unsigned)(nblk * tp.nchunks));
+            hipStream_t s = (hipStream_t)stream;
+            static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+            if (trace) fprintf(stderr, "[sfamd] dwtile wgrad: N=%d C=%d T=%d %dx%d -> %dx%d s=%d TH=%d tiles=%d nsub=%d items=%d lds class %d blocks=%u\n", tp.N,
+                               tp.C, tp.T, tp.Hi, tp.Wi, tp.Ho, tp.Wo, tp.s, tp.TH, tp.tiles_h, tp.nsub, tp.nitems, lc, tgrid.x);
+#define SF_DWW_LAUNCH(S, XF, DP) hipLaunchKernelGGL((sf_dwtile_wgrad_kernel<S, XF, DP>), tgrid, dim3(SF_THREADS), 0, s, tp)
+            if (tp.s == 1) {
+                if (lc == 0) SF_DWW_LAUNCH(1, SF_DWW_XF_S, SF_DWW_DP_S);
+                else if (lc == 1) SF_DWW_LAUNCH(1, SF_DWW_XF_L, SF_DWW_DP_S);
+                else SF_DWW_LAUNCH(1, SF_DWW_XF_L, SF_DWW_DP_L);
+            } else {
+                if (lc == 0) SF_DWW_LAUNCH(2, SF_DWW_XF_S, SF_DWW_DP_S);
+                else if (lc == 1) SF_DWW_LAUNCH(2, SF_DWW_XF_L, SF_DWW_DP_S);
+                else SF_DWW_LAUNCH(2, SF_DWW_XF_L, SF_DWW_DP_L);
+            }
+#undef SF_DWW_LAUNCH
+            if (check_launch("dwconv_wgrad (tiled)")) return -1;
+            DwFinalizeParams f;
+            f.wpart = (const float*)workspace; f.nblk = nblk; f.taps = taps; f.C = d->C; f.Cw = d->Cw;
+            f.Cwreal = d->Cwreal ? d->Cwreal : d->Cw;
+            f.dw = dw; f.scale = out_scale; f.accumulate = zero_first ? 0 : 1;
+            hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, 32)), dim3(SF_THREADS), 0, s, f);
+            return check_launch("dwconv_wgrad_finalize");
+        }
+    }
     const int kind = dw_blocked_kind(d);
     DwBlockIdx bi;
     if (kind) dw_block_plan(p, bi, d, true, kDwWgradBlocks, grid);

@@ -203,3 +203,202 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_kernel(DwTileParams p) {
     }
     emit(p.T - 1);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolutions on the same staging (round 4): dw[c][kt][kh][kw] = sum over (n, t, h, w) of
+// dy[n][t][h][w][c] * x[n][t + kt - 1][h*s + kh - 1][w*s + kw - 1][c].
+//
+// The W-blocked stencil (sf_dwconv_wgrad_blocked_kernel) runs one grid slice per kt, reads every dy element three times and
+// every x element 13.5 times through the vector-memory path with an address select per load, and at the 14-wide planes of
+// MViT stage 3 its 4-column blocks do not divide the row (edge selects on every load, one eighth of the lanes idle).
+// Here a workgroup sweeps the T frames of one (sample, row tile, 32-channel chunk) like the forward kernel above:
+//   * the input plane tile is staged once as fp32 (halo zero-filled), the output-gradient planes t - 1, t, t + 1 it pairs with
+//     sit in LDS as fp16 (three rotating slots, 64 B apart modulo the bank span);
+//   * thread = (row-segment subset, (kt, kh) role, 8-channel group): 3 x 8 accumulators (the three kw taps), walking its row
+//     segments (the tile's rows cut into equal pieces so that the seven subsets are evenly loaded) with a sliding window over
+//     the staged row -- per position one new 32-byte x read (two at stride 2), one
+//     16-byte dy read, 24 FMAs; lanes that differ only in kt read the same x address, lanes that differ only in kh the same
+//     dy address (LDS broadcast), the rest of a 16-lane group falls on distinct bank slots;
+//   * no range checks or address selects in the loop: out-of-image taps are zeros in the staged tile, output rows beyond the
+//     image are zeros in the staged dy.
+// The workgroup folds its subsets in a fixed order and writes ONE partial row [27][32 channels of C]; the existing
+// sf_dwconv_wgrad_finalize_kernel sums the rows (and the head copies of a shared weight).
+// The staged x tile keeps the forward kernel's 48-float position pitch (conflict-free staging stores) and every staged row
+// carries 64 B of padding, which puts the three kh rows of a column on different bank slots.
+// Three LDS size classes (static arrays; XF floats of x tile, DP halves per dy plane slot incl. 64 B of bank offset between the
+// slots): <7168, 3168> = 47 KiB, three workgroups per CU (a 9 x 16 staged x tile: seven 14-wide output rows at stride 1);
+// <12288, 3168> = 67 KiB, two per CU (a whole 14 x 14 input plane with its 7 x 7 stride-2 output); <12288, 6304> = 85 KiB, one
+// per CU.  Planes wider than 16 stay on the stencil: with a 32-float pitch (2-way conflicts in the staging stores) and rows cut
+// into short segments they fit three workgroups per CU but measured no faster than the stencil (28 x 28 stride 2: 67 against
+// 61 us, 56 x 56: 220 = 220 us) and slowed the 14-wide ones (52 -> 56, 30 -> 38 us; profiles/r4_v19_dw_bench.txt).
+#define SF_DWW_PP SF_DWT_PP
+#define SF_DWW_XF_S 7168
+#define SF_DWW_DP_S (98 * SF_DWT_CC + 32)
+#define SF_DWW_XF_L SF_DWT_PLANE
+#define SF_DWW_DP_L (196 * SF_DWT_CC + 32)
+#define SF_DWW_VPT 4                            // 16-byte dy vectors a thread stages per plane
+#define SF_DWW_SUBMAX 7                         // 7 subsets x 9 roles x 4 channel groups = 252 threads
+
+struct DwTileWgradParams {
+    const f16* x; int ldx;
+    const f16* dy; int lddy;
+    float* wpart;                       // [N * tiles_h][27][C]
+    int N, C, cls, T;
+    int Hi, Wi, Ho, Wo, s;
+    int TH, RT, CT, rowf;               // output rows per tile; staged x rows = (TH - 1) * s + 3, columns = Wi + 2; floats per staged row
+    int tiles_h, nchunks, nsub, nseg, SL, nitems;
+    FastDiv fdCT, fdG, fdWo, fdSeg;
+};
+
+template <int S, int XF, int DP>
+__global__ __launch_bounds__(SF_THREADS) void sf_dwtile_wgrad_kernel(DwTileWgradParams p) {
+    __shared__ __attribute__((aligned(16))) float s_x[XF];
+    __shared__ __attribute__((aligned(16))) f16 s_dy[3 * DP];
+    const int tid = threadIdx.x;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = (int)(bid % (uint32_t)p.nchunks);
+    const int tile = (int)((bid / (uint32_t)p.nchunks) % (uint32_t)p.tiles_h);
+    const int n = (int)(bid / (uint32_t)(p.nchunks * p.tiles_h));
+    const int c0 = chunk * SF_DWT_CC;
+    const int r0 = tile * p.TH;                                 // first output row of the tile
+    const int64_t Si = (int64_t)p.T * p.Hi * p.Wi + p.cls, So = (int64_t)p.T * p.Ho * p.Wo + p.cls;
+
+    // ---- staging maps (as in the forward kernel; the x rows carry 64 B of padding so that the kh rows of a column sit on
+    // different bank slots)
+    const int VX = p.RT * p.CT * SF_DWT_G;
+    int x_off[SF_DWT_VPT], x_lds[SF_DWT_VPT];
+#pragma unroll
+    for (int u = 0; u < SF_DWT_VPT; ++u) {
+        const int v = tid + SF_THREADS * u;
+        x_off[u] = -1;
+        x_lds[u] = -1;
+        if (v < VX) {
+            uint32_t pos, cgv, i, j;
+            fd_divmod((uint32_t)v, p.fdG, pos, cgv);
+            fd_divmod(pos, p.fdCT, i, j);
+            x_lds[u] = (int)i * p.rowf + (int)j * SF_DWW_PP + (int)cgv * 4;
+            const int gr = r0 * p.s - 1 + (int)i, gc = (int)j - 1;
+            if ((unsigned)gr < (unsigned)p.Hi && (unsigned)gc < (unsigned)p.Wi) x_off[u] = (gr * p.Wi + gc) * p.ldx + c0 + (int)cgv * 8;
+        }
+    }
+    const int VD = p.TH * p.Wo * SF_DWT_G;
+    int d_off[SF_DWW_VPT], d_lds[SF_DWW_VPT];
+#pragma unroll
+    for (int u = 0; u < SF_DWW_VPT; ++u) {
+        const int v = tid + SF_THREADS * u;
+        d_off[u] = -1;
+        d_lds[u] = -1;
+        if (v < VD) {
+            uint32_t pos, cgv, r, w;
+            fd_divmod((uint32_t)v, p.fdG, pos, cgv);
+            fd_divmod(pos, p.fdWo, r, w);
+            d_lds[u] = (int)pos * SF_DWT_CC + (int)cgv * 8;
+            if (r0 + (int)r < p.Ho) d_off[u] = ((r0 + (int)r) * p.Wo + (int)w) * p.lddy + c0 + (int)cgv * 8;
+        }
+    }
+    const f16* const x_n = p.x + ((int64_t)n * Si + p.cls) * p.ldx;
+    const f16* const dy_n = p.dy + ((int64_t)n * So + p.cls) * p.lddy;
+    const int64_t plane_x = (int64_t)p.Hi * p.Wi * p.ldx, plane_dy = (int64_t)p.Ho * p.Wo * p.lddy;
+    f16x8 prex[SF_DWT_VPT], pred[SF_DWW_VPT];
+    auto prefetch_x = [&](int t) {
+        const f16* base = x_n + (int64_t)t * plane_x;
+#pragma unroll
+        for (int u = 0; u < SF_DWT_VPT; ++u) prex[u] = x_off[u] >= 0 ? ld16(base + x_off[u]) : zero8();
+    };
+    auto prefetch_dy = [&](int t) {
+        const f16* base = dy_n + (int64_t)t * plane_dy;
+#pragma unroll
+        for (int u = 0; u < SF_DWW_VPT; ++u) pred[u] = d_off[u] >= 0 ? ld16(base + d_off[u]) : zero8();
+    };
+    auto store_dy = [&](int t) {
+        f16* slot = s_dy + (t % 3) * DP;
+#pragma unroll
+        for (int u = 0; u < SF_DWW_VPT; ++u)
+            if (d_lds[u] >= 0) st16(slot + d_lds[u], pred[u]);
+    };
+
+    // ---- compute map
+    const int cg = tid % SF_DWT_G, role = (tid / SF_DWT_G) % 9, sub = tid / (SF_DWT_G * 9);
+    const int kt = role / 3, kh = role - 3 * kt;
+    const bool worker = sub < p.nsub;
+    float acc[3][8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    auto X = [&](const float* row, int j, float (&o)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(row + j * SF_DWW_PP), b = *reinterpret_cast<const f32x4*>(row + j * SF_DWW_PP + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+    };
+
+    prefetch_dy(0);
+    store_dy(0);
+    prefetch_x(0);
+    if (p.T > 1) prefetch_dy(1);
+    for (int tin = 0; tin < p.T; ++tin) {
+        __syncthreads();                    // every thread is done with x plane tin - 1 and dy plane tin - 2
+#pragma unroll
+        for (int u = 0; u < SF_DWT_VPT; ++u) {
+            if (x_lds[u] >= 0) {
+                float f[8];
+                dwt_cvt8(prex[u], f);
+                *reinterpret_cast<f32x4*>(s_x + x_lds[u]) = (f32x4){f[0], f[1], f[2], f[3]};
+                *reinterpret_cast<f32x4*>(s_x + x_lds[u] + 16) = (f32x4){f[4], f[5], f[6], f[7]};
+            }
+        }
+        if (tin + 1 < p.T) store_dy(tin + 1);
+        __syncthreads();
+        if (tin + 1 < p.T) prefetch_x(tin + 1);        // in flight under the sweep of plane tin
+        if (tin + 2 < p.T) prefetch_dy(tin + 2);
+        const int t = tin - kt + 1;                     // the output plane this role pairs with input plane tin
+        if (worker && (unsigned)t < (unsigned)p.T) {
+            const f16* const dyp = s_dy + (t % 3) * DP + cg * 8;
+            for (int it = sub; it < p.nitems; it += p.nsub) {
+                uint32_t r, g;
+                fd_divmod((uint32_t)it, p.fdSeg, r, g);
+                const int w0 = (int)g * p.SL;
+                int w1 = w0 + p.SL;
+                if (w1 > p.Wo) w1 = p.Wo;
+                const float* const xrow = s_x + ((int)r * S + kh) * p.rowf + cg * 4;
+                const f16* const dyr = dyp + (int)r * p.Wo * SF_DWT_CC;
+                float x0[8], x1[8], x2[8];
+                X(xrow, w0 * S, x0);
+                if (S == 1) X(xrow, w0 + 1, x1);
+                for (int w = w0; w < w1; ++w) {
+                    if (S == 2) X(xrow, 2 * w + 1, x1);
+                    X(xrow, w * S + 2, x2);
+                    float d[8];
+                    dwt_cvt8(ld16(dyr + w * SF_DWT_CC), d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        acc[0][e] += d[e] * x0[e];
+                        acc[1][e] += d[e] * x1[e];
+                        acc[2][e] += d[e] * x2[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (S == 1) { x0[e] = x1[e]; x1[e] = x2[e]; }
+                        else x0[e] = x2[e];
+                    }
+                }
+            }
+        }
+    }
+    // ---- fold the subsets (fixed order) and write the workgroup's partial row
+    __syncthreads();
+    if (worker) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_x[((sub * 27) + role * 3 + k) * SF_DWT_CC + cg * 8 + e] = acc[k][e];
+    }
+    __syncthreads();
+    float* const out = p.wpart + ((int64_t)(n * p.tiles_h + tile) * 27) * p.C + c0;
+    for (int idx = tid; idx < 27 * SF_DWT_CC; idx += SF_THREADS) {
+        const int tap = idx / SF_DWT_CC, c = idx - tap * SF_DWT_CC;
+        float a = 0.f;
+        for (int k = 0; k < p.nsub; ++k) a += s_x[(k * 27 + tap) * SF_DWT_CC + c];
+        out[(int64_t)tap * p.C + c] = a;
+    }
+}

@@ -49,7 +49,7 @@ def test_dwconv_tokens(sim):
 
 def test_dwconv_tiled_plane_sweep(sim, monkeypatch):
     """LDS-tiled plane sweep (sf_dwtile.h): 32-channel chunks, strides 1 and 2 (forward, data gradient incl. the zero-upsampled
-    stride-2 form), partial last row tiles, odd extents, 1 / 2 / 4 positions per thread."""
+    stride-2 form, weight gradient in its three LDS classes), partial last row tiles, odd extents, 1 / 2 / 4 positions per thread."""
     monkeypatch.setenv("SF_DW_TILED", "2")      # also the stride-2 forms (the library's statics are read on first use: the
     # fixture loads a fresh library handle per test, the env is read again)
     tc.check_dwconv(sim, 2, 2, 32, (3, 6, 6), (3, 3, 3), (1, 1, 1), cls=1)       # one tile, NP = 1
@@ -58,6 +58,12 @@ def test_dwconv_tiled_plane_sweep(sim, monkeypatch):
     tc.check_dwconv(sim, 1, 2, 32, (2, 7, 9), (3, 3, 3), (1, 2, 2), cls=0)       # odd extents: 7x9 -> 4x5, no cls
     tc.check_dwconv(sim, 1, 1, 32, (1, 5, 30), (3, 3, 3), (1, 1, 1), cls=1)      # wide rows: several row tiles, T = 1
     tc.check_dwconv(sim, 1, 1, 96, (4, 12, 12), (3, 3, 3), (1, 2, 2), cls=1)     # head width 96 (three chunks of one weight group)
+    monkeypatch.setenv("SF_DWT_TH", "13")                                        # weight gradient: the 85 KiB class (182 positions
+    tc.check_dwconv(sim, 1, 1, 32, (2, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)     # per dy slot), partial second tile
+    monkeypatch.delenv("SF_DWT_TH")
+    monkeypatch.setenv("SF_DW_WGRAD_TILED", "0")                                 # ... and the stencil it replaces, same case
+    tc.check_dwconv(sim, 1, 1, 32, (2, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
+    monkeypatch.delenv("SF_DW_WGRAD_TILED")
     monkeypatch.setenv("SF_DWT_TH", "7")                                         # 98 positions per tile: 2 per thread
     tc.check_dwconv(sim, 1, 1, 32, (2, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
     monkeypatch.setenv("SF_DWT_TH", "14")                                        # 196 positions: 4 per thread (3 rounds up)
