@@ -1,6 +1,6 @@
 """Microbenchmark of the MViT token-space kernels at MViTv2-S shapes (batch 32): fused attention forward / backward and the
 depthwise pooling convolutions, HIP-event timed; also the thing `rocprofv3 --pmc` is pointed at (tools/gpu/r4_v3.sh).
-`python tools/token_bench.py [--iters N] [--only attn|dw|ln|stage3]`"""
+`python tools/token_bench.py [--iters N] [--only attn|dw|ln|colsum|stage3]`"""
 import argparse
 import os
 import sys
@@ -94,6 +94,23 @@ def ln_case(M, C, iters, dev):
           f" | bwd+resid+sums {t_s:7.1f} us {4 * by / t_s * 1e-3:6.0f} GB/s (incl. the finalize launches)")
 
 
+def colsum_case(M, C, iters, dev):
+    """Bias gradient of a Linear layer: column sums of its output gradient (sf_colsum + finalize), operands from HBM."""
+    f16 = lib.act_dtype()
+    ncopy = max(1, int(1.2e9 // (2.0 * M * C)))
+    g = torch.Generator().manual_seed(0)
+    base = torch.randn((M, C), generator=g).to(f16).to(dev)
+    xs = [base] + [base.clone() for _ in range(ncopy - 1)]
+    db = torch.empty(C, device=dev)
+    it = [0]
+
+    def run():
+        it[0] += 1
+        tokens.bias_grad(xs[it[0] % ncopy], db)
+    t = timed(run, iters)
+    print(f"colsum M{M} C{C}: {t:7.1f} us {2.0 * M * C / t * 1e-3:6.0f} GB/s (incl. the finalize launch)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
@@ -105,6 +122,9 @@ def main():
     if a.only in ("", "attn"):
         attn_case(32, 1, 96, (8, 56, 56), (8, 7, 7), a.iters, dev)      # block 0
         attn_case(32, 8, 96, (8, 7, 7), (8, 7, 7), a.iters, dev)        # stage 4
+    if a.only in ("", "colsum"):
+        colsum_case(32 * 25089, 288, a.iters, dev)                       # block 0 d(qkv)
+        colsum_case(32 * 1569, 1152, a.iters, dev)                       # stage 3 d(qkv)
     if a.only in ("", "ln"):
         ln_case(32 * 25089, 96, a.iters, dev)                            # block 0
         ln_case(32 * 6273, 192, a.iters, dev)                            # stage 2
