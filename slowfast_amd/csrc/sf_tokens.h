@@ -264,7 +264,19 @@ __global__ __launch_bounds__(SF_THREADS) void sf_colsum_kernel(ColSumParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; }
     if (active) {
-        for (int m = r0; m < r1; m += rstep) {
+        // four rows in flight per thread (round 4: one load per iteration kept 4 MB in flight chip-wide -- 2.4 TB/s); the
+        // additions keep the order of the one-row loop
+        int m = r0;
+        for (; m + 3 * rstep < r1; m += 4 * rstep) {
+            f16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ld16(p.x + (int64_t)(m + u * rstep) * p.ldx + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += (float)v[u][e];
+        }
+        for (; m < r1; m += rstep) {
             f16x8 v = ld16(p.x + (int64_t)m * p.ldx + c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
