@@ -61,6 +61,10 @@ class _Segments:
 
     def cut(self, tensors):
         leaves = [t.detach().requires_grad_(True) if t.requires_grad else t for t in tensors]
+        for l, t in zip(leaves, tensors):       # what a block hands its successor through the tensor object travels across the cut
+            tag = getattr(t, "_sf_block_bn", None)
+            if l is not t and tag is not None:
+                l._sf_block_bn = tag
         if any(l is not t for l, t in zip(leaves, tensors)):
             self.cuts.append((list(tensors), leaves))
         return leaves
@@ -728,12 +732,29 @@ class ResBlockFn(torch.autograd.Function):
         return (dx, None) + param_grads(ctx, 2)
 
 
+CUT_BACKWARD = False     # True while step.TrainStep runs one segment of a cut backward pass
+_cut_bn_tags = {}        # gradient storage -> tag recorded during such a segment (see retag_cut_grad)
+
+
+def retag_cut_grad(g):
+    """A gradient that crosses a stage cut arrives as ``leaf.grad``: autograd's accumulation detaches it into a new tensor
+    object (same storage, same version counter) and the Python attribute tag_bn_part() put on it is gone -- the producer block
+    would fall back to the separate reduction pass and the segmented backward would round differently from the unsegmented one
+    (X3D / ResNet stages end in a block, SlowFast's in a fusion layer).  step.TrainStep calls this on every leaf gradient before
+    it starts the next segment: the tag recorded for that storage is put back if it still describes the tensor."""
+    tag = _cut_bn_tags.pop(g.data_ptr(), None)
+    if tag is not None and getattr(g, "_sf_bn_part", None) is None and tag[2] == g.data_ptr() and tag[3] == g._version:
+        g._sf_bn_part = tag
+
+
 def tag_bn_part(dx, y0, part):
     """Attach the BatchNorm-backward partial sums a data-gradient epilogue took over ``dx`` (the gradient w.r.t. the previous
     block's output) to that tensor.  The tag names the tensor state it describes: the raw BatchNorm input it belongs to, the
     gradient's storage and its version counter -- autograd may accumulate another consumer's gradient IN PLACE into the same
     tensor object (feature taps, auxiliary heads, hooks), which keeps the Python attribute and changes the values."""
     dx._sf_bn_part = (y0.data_ptr(), part, dx.data_ptr(), dx._version)
+    if CUT_BACKWARD:
+        _cut_bn_tags[dx.data_ptr()] = dx._sf_bn_part
 
 
 def tagged_bn_part(dout, y0):

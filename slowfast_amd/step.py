@@ -122,13 +122,21 @@ class TrainStep:
     @staticmethod
     def _backward_segment(k, nseg, scaled_loss, cuts):
         """Segment k of the backward pass, k = nseg-1 (head side) ... 0 (input side)."""
-        if k == nseg - 1:
-            torch.autograd.backward([scaled_loss])
-        else:
-            origs, leaves = cuts[k]
-            pairs = [(o, l.grad) for o, l in zip(origs, leaves) if l is not o and l.grad is not None]
-            if pairs:
-                torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+        engine.CUT_BACKWARD = True
+        try:
+            if k == nseg - 1:
+                engine._cut_bn_tags.clear()
+                torch.autograd.backward([scaled_loss])
+            else:
+                origs, leaves = cuts[k]
+                pairs = [(o, l.grad) for o, l in zip(origs, leaves) if l is not o and l.grad is not None]
+                for _, g in pairs:
+                    engine.retag_cut_grad(g)
+                engine._cut_bn_tags.clear()     # tags of gradients that did not end at a cut describe nothing any more
+                if pairs:
+                    torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+        finally:
+            engine.CUT_BACKWARD = False
         engine.join_side_streams()      # a backward segment (and its graph) ends with every forked stream joined
 
     def _iteration_segmented_eager(self, inputs, labels, record=False):

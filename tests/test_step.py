@@ -2,6 +2,8 @@
 sequence zero_grad -> forward -> loss -> backward -> finish -> optimizer.step (tools/train_net.py:104-172)."""
 import copy
 
+import contextlib
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -209,9 +211,11 @@ def _run_model(device, name, segmented, use_graph, steps=2):
     return out
 
 
-@pytest.mark.parametrize("name", [pytest.param("slowfast_tiny", marks=pytest.mark.slow), "mvit_tiny"])
+@pytest.mark.parametrize("name", [pytest.param("slowfast_tiny", marks=pytest.mark.slow), "mvit_tiny", "x3d_tiny", "c2d_tiny"])
 def test_segmented_backward_equals_unsegmented(sim, name):
-    """Backward run stage by stage across engine.cut() boundaries == one backward pass: same losses, same parameters."""
+    """Backward run stage by stage across engine.cut() boundaries == one backward pass: same losses, same parameters.
+    (x3d / c2d: their stages end in a residual block, whose fused BatchNorm-backward partial sums ride on the gradient tensor
+    object -- engine.retag_cut_grad carries them across the cut.)"""
     l0, p0, n0, _ = _run_model(sim, name, segmented=False, use_graph=False)
     l1, p1, n1, _ = _run_model(sim, name, segmented=True, use_graph=False)
     assert n1 >= 3, "the model must expose at least two stage boundaries"
@@ -221,7 +225,7 @@ def test_segmented_backward_equals_unsegmented(sim, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["slowfast_tiny", "mvit_tiny"])
+@pytest.mark.parametrize("name", ["slowfast_tiny", "mvit_tiny", "x3d_tiny"])
 def test_segmented_graph_replay_matches_eager(gpu, name):
     """Forward graph + one graph per backward segment (shared memory pool) replayed in order == the eager iteration."""
     l0, p0, _, _ = _run_model(gpu, name, segmented=False, use_graph=False, steps=4)
@@ -230,6 +234,55 @@ def test_segmented_graph_replay_matches_eager(gpu, name):
     assert l0 == l1, (l0, l1)
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)
+
+
+@contextlib.contextmanager
+def _poisoned_allocations():
+    """Every torch.empty / empty_like / new_empty comes back filled with NaN (floating point) or 0xA5 (uint8 masks): a kernel
+    that reads memory nobody wrote -- or relies on a fill that does not happen, as the memset node of round 4 did under graph
+    replay (profiles/r4_v13_graph_memset.md) -- shows up as a different result, in eager launches and in captured graphs alike
+    (the fills are launches like any other and are captured with the step)."""
+    orig = (torch.empty, torch.empty_like, torch.Tensor.new_empty)
+
+    def poison(t):
+        if t.numel():
+            if t.is_floating_point():
+                t.fill_(float("nan"))
+            elif t.dtype == torch.uint8:
+                t.fill_(0xA5)
+        return t
+    torch.empty = lambda *a, **k: poison(orig[0](*a, **k))
+    torch.empty_like = lambda *a, **k: poison(orig[1](*a, **k))
+    torch.Tensor.new_empty = lambda self, *a, **k: poison(orig[2](self, *a, **k))
+    try:
+        yield
+    finally:
+        torch.empty, torch.empty_like, torch.Tensor.new_empty = orig
+
+
+@pytest.mark.parametrize("name", [pytest.param("slowfast_tiny", marks=pytest.mark.slow), "mvit_tiny", "x3d_tiny"])
+def test_poisoned_allocations_do_not_change_the_step(sim, name):
+    """Host simulator, eager: the training step reads nothing it (or a kernel before it) has not written."""
+    l0, p0, _, _ = _run_model(sim, name, segmented=False, use_graph=False)
+    with _poisoned_allocations():
+        l1, p1, _, _ = _run_model(sim, name, segmented=False, use_graph=False)
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["slowfast_tiny", "mvit_tiny", "x3d_tiny"])
+def test_graph_replay_with_poisoned_allocations(gpu, name):
+    """Captured step (forward graph + backward segment graphs), four iterations, every allocation poisoned before use == the
+    clean eager iterations bit for bit: nothing inside the graph depends on what a buffer held before the replay."""
+    l0, p0, _, _ = _run_model(gpu, name, segmented=False, use_graph=False, steps=4)
+    with _poisoned_allocations():
+        l1, p1, _, _ = _run_model(gpu, name, segmented=True, use_graph=True, steps=4)
+        l2, p2, _, _ = _run_model(gpu, name, segmented=False, use_graph=True, steps=4)
+    assert l0 == l1 == l2, (l0, l1, l2)
+    for a, b, c in zip(p0, p1, p2):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 def test_static_clone_keeps_wpair_tag_and_strides():
