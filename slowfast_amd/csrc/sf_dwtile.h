@@ -154,8 +154,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_kernel(DwTileParams p) {
             if (st_lds[u] >= 0) {
                 float f[8];
                 dwt_cvt8(pre[u], f);
-                *reinterpret_cast<f32x4*>(s_plane + st_lds[u]) = (f32x4){f[0], f[1], f[2], f[3]};
-                *reinterpret_cast<f32x4*>(s_plane + st_lds[u] + 16) = (f32x4){f[4], f[5], f[6], f[7]};
+                f32x4* const q = reinterpret_cast<f32x4*>(s_plane) + (st_lds[u] >> 2);     // indexed as vectors: the compiler cannot
+                q[0] = (f32x4){f[0], f[1], f[2], f[3]};                                     // see that a float offset is a multiple of
+                q[4] = (f32x4){f[4], f[5], f[6], f[7]};                                     // 4 and splits the store into ds_write2_b32
             }
         }
         __syncthreads();
@@ -251,7 +252,8 @@ struct DwTileWgradParams {
 };
 
 template <int S, int XF, int DP>
-__global__ __launch_bounds__(SF_THREADS) void sf_dwtile_wgrad_kernel(DwTileWgradParams p) {
+__global__ __launch_bounds__(SF_THREADS, 3) void sf_dwtile_wgrad_kernel(DwTileWgradParams p) {
+    // (launch bounds: at most 168 registers, so that the 47 KiB class keeps its third workgroup per CU)
     __shared__ __attribute__((aligned(16))) float s_x[XF];
     __shared__ __attribute__((aligned(16))) f16 s_dy[3 * DP];
     const int tid = threadIdx.x;
@@ -343,8 +345,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_wgrad_kernel(DwTileWgrad
             if (x_lds[u] >= 0) {
                 float f[8];
                 dwt_cvt8(prex[u], f);
-                *reinterpret_cast<f32x4*>(s_x + x_lds[u]) = (f32x4){f[0], f[1], f[2], f[3]};
-                *reinterpret_cast<f32x4*>(s_x + x_lds[u] + 16) = (f32x4){f[4], f[5], f[6], f[7]};
+                f32x4* const q = reinterpret_cast<f32x4*>(s_x) + (x_lds[u] >> 2);
+                q[0] = (f32x4){f[0], f[1], f[2], f[3]};
+                q[4] = (f32x4){f[4], f[5], f[6], f[7]};
             }
         }
         if (tin + 1 < p.T) store_dy(tin + 1);
@@ -362,24 +365,54 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_wgrad_kernel(DwTileWgrad
                 if (w1 > p.Wo) w1 = p.Wo;
                 const float* const xrow = s_x + ((int)r * S + kh) * p.rowf + cg * 4;
                 const f16* const dyr = dyp + (int)r * p.Wo * SF_DWT_CC;
-                float x0[8], x1[8], x2[8];
-                X(xrow, w0 * S, x0);
-                if (S == 1) X(xrow, w0 + 1, x1);
-                for (int w = w0; w < w1; ++w) {
-                    if (S == 2) X(xrow, 2 * w + 1, x1);
-                    X(xrow, w * S + 2, x2);
+                // sliding window over the staged row, unrolled over its rotation (3 positions at stride 1, 2 at stride 2): the
+                // window registers change roles instead of being copied (16 v_mov per position in the rolled form, of ~40
+                // VALU instructions per position on a kernel that is ~60 % VALU-bound; profiles/r4_v23_pmc2_dw_insts.md)
+                float xa[8], xb[8], xc[8];
+                auto fma3 = [&](const float (&a)[8], const float (&b)[8], const float (&c)[8], int w) {
                     float d[8];
                     dwt_cvt8(ld16(dyr + w * SF_DWT_CC), d);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        acc[0][e] += d[e] * x0[e];
-                        acc[1][e] += d[e] * x1[e];
-                        acc[2][e] += d[e] * x2[e];
+                        acc[0][e] += d[e] * a[e];
+                        acc[1][e] += d[e] * b[e];
+                        acc[2][e] += d[e] * c[e];
                     }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        if (S == 1) { x0[e] = x1[e]; x1[e] = x2[e]; }
-                        else x0[e] = x2[e];
+                };
+                int w = w0;
+                if (S == 1) {
+                    X(xrow, w0, xa);
+                    X(xrow, w0 + 1, xb);
+                    for (; w + 2 < w1; w += 3) {
+                        X(xrow, w + 2, xc);
+                        fma3(xa, xb, xc, w);
+                        X(xrow, w + 3, xa);
+                        fma3(xb, xc, xa, w + 1);
+                        X(xrow, w + 4, xb);
+                        fma3(xc, xa, xb, w + 2);
+                    }
+                    if (w < w1) {
+                        X(xrow, w + 2, xc);
+                        fma3(xa, xb, xc, w);
+                        if (w + 1 < w1) {
+                            X(xrow, w + 3, xa);
+                            fma3(xb, xc, xa, w + 1);
+                        }
+                    }
+                } else {
+                    X(xrow, 2 * w0, xa);
+                    for (; w + 1 < w1; w += 2) {
+                        X(xrow, 2 * w + 1, xb);
+                        X(xrow, 2 * w + 2, xc);
+                        fma3(xa, xb, xc, w);
+                        X(xrow, 2 * w + 3, xb);
+                        X(xrow, 2 * w + 4, xa);
+                        fma3(xc, xb, xa, w + 1);
+                    }
+                    if (w < w1) {
+                        X(xrow, 2 * w + 1, xb);
+                        X(xrow, 2 * w + 2, xc);
+                        fma3(xa, xb, xc, w);
                     }
                 }
             }
