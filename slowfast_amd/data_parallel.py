@@ -204,9 +204,10 @@ def wrap_ddp(model, device=None, find_unused_parameters=False, fp16_allreduce=Fa
     """torch.nn.parallel.DistributedDataParallel around the drop-in model, as slowfast/models/build.py:64-80 wraps the
     reference model.  Switches the engine to autograd-delivered parameter gradients (engine.GRADS_VIA_AUTOGRAD): DDP's
     reducer hooks the parameters' AccumulateGrad nodes, so gradients written straight into ``param.grad`` would never be
-    all-reduced.  The switch is process-global but FOLLOWS THE MODEL whose iteration is running: the wrapper's forward
-    pre-hook turns it on, GradReducer.zero_grad() (first call of every in-place iteration) turns it off, so a DDP-wrapped
-    model and a GradReducer-driven one can alternate in one process."""
+    all-reduced.  The switch says which mode the model that is running its FORWARD is in: the wrapper's forward pre-hook turns
+    it on, GradReducer.zero_grad() (first call of every in-place iteration) turns it off, and every engine Function records
+    the value it saw at forward time and runs its backward under that (engine.record_params / delivers_grads) -- a DDP-wrapped
+    model and a GradReducer-driven one can interleave their forward and backward passes in one process."""
     engine.GRADS_VIA_AUTOGRAD = True
 
     def _via_autograd(module, args):

@@ -19,6 +19,7 @@ Parameter gradients are written straight into ``param.grad`` (fp32; accumulated 
 exists, which is how GradReducer's flat bucket views receive them) and ``grad_ready`` listeners are
 told which parameters are final, so the gradient all-reduce can overlap the rest of backward.
 """
+import functools
 import os
 
 import torch
@@ -296,6 +297,30 @@ def as_cl(t):
 # applies, slowfast/models/build.py:64-80) hooks its bucketed all-reduce and any register_comm_hook() hook.
 GRADS_VIA_AUTOGRAD = False
 _pending_grads = {}
+
+
+def record_params(ctx, params):
+    """Function.forward: remember the ``*params`` it received and the gradient-delivery mode of THIS iteration of THIS model.
+    The global above says which mode the model that is running its forward is in (GradReducer.zero_grad() / the DDP forward
+    pre-hook set it right before); the backward may run after another model's forward has changed it, so it goes by what the
+    forward recorded (delivers_grads)."""
+    ctx._sf_params = params
+    ctx._sf_via_autograd = GRADS_VIA_AUTOGRAD
+
+
+def delivers_grads(backward):
+    """Decorator of a Function.backward that writes parameter gradients (_grad_dest / _notify / param_grads): runs it under the
+    delivery mode its forward recorded."""
+    @functools.wraps(backward)
+    def wrapped(ctx, *grads):
+        global GRADS_VIA_AUTOGRAD
+        prev = GRADS_VIA_AUTOGRAD
+        GRADS_VIA_AUTOGRAD = getattr(ctx, "_sf_via_autograd", prev)
+        try:
+            return backward(ctx, *grads)
+        finally:
+            GRADS_VIA_AUTOGRAD = prev
+    return wrapped
 
 
 def _grad_dest(param):
@@ -577,7 +602,7 @@ class StemFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
-        ctx._sf_params = params
+        record_params(ctx, params)
         unit = mod._unit
         xcl = unit.prepare_input(x) if isinstance(unit, StemConvUnit) else ops.to_cl(x)
         y, st = unit.forward(xcl, None, mod.training)
@@ -592,6 +617,7 @@ class StemFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @delivers_grads
     def backward(ctx, dout):
         unit = ctx.mod._unit
         st = ctx.st
@@ -610,7 +636,7 @@ class FuseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_s, x_f, mod, *params):
-        ctx._sf_params = params
+        record_params(ctx, params)
         unit = mod._unit
         x_s, x_f = as_cl(x_s), as_cl(x_f)
         yf, st = unit.forward(x_f, None, mod.training)
@@ -627,6 +653,7 @@ class FuseFn(torch.autograd.Function):
         return cat, x_f.view_as(x_f)
 
     @staticmethod
+    @delivers_grads
     def backward(ctx, dcat, dxf):
         unit = ctx.mod._unit
         (x_f,) = ctx.saved_tensors
@@ -647,7 +674,7 @@ class ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
-        ctx._sf_params = params
+        record_params(ctx, params)
         # when x is the previous block's output, that block left what ITS final BatchNorm backward will reduce over (see the
         # end of this function): this block's last data gradient produces exactly that gradient and reduces it in its epilogue
         ctx.prev_bn = getattr(x, "_sf_block_bn", None) if BN_FUSE_REDUCE else None
@@ -692,6 +719,7 @@ class ResBlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @delivers_grads
     def backward(ctx, dout):
         mod = ctx.mod
         units, P = mod.branch2._chain, mod._proj
@@ -771,7 +799,7 @@ class ConvBNActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, unit, relu, training, *params):
-        ctx._sf_params = params
+        record_params(ctx, params)
         x = as_cl(x)
         y, st = unit.forward(x, None, training)
         out = ops.bn_act(y, st.scale, st.shift, relu=relu)
@@ -782,6 +810,7 @@ class ConvBNActFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @delivers_grads
     def backward(ctx, dout):
         unit = ctx.unit
         (x,) = ctx.saved_tensors

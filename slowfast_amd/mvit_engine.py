@@ -496,7 +496,7 @@ class MultiScaleBlockFn(torch.autograd.Function):
     def forward(ctx, x, mod, thw, drop, side, *params):
         """``side``: the ResidSide travelling with x (None: 16-bit stream only); it is UPDATED in place to the one of the
         block output."""
-        ctx._sf_params = params
+        engine.record_params(ctx, params)
         att = mod.attn
         B, N, dim = x.shape
         plan = mod._plan(B, thw, x.device)
@@ -558,6 +558,7 @@ class MultiScaleBlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @engine.delivers_grads
     def backward(ctx, dout):
         # the ~9 column-sum finalizes of the block (LayerNorm affine and bias gradients) leave as one launch at the end
         with tokens.deferred_finalizes():
@@ -674,7 +675,7 @@ class RevBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, mod, thw, drop, *params):
-        ctx._sf_params = params
+        engine.record_params(ctx, params)
         B, N, _ = x2.shape
         plan = mod._plan(B, thw, x2.device)
         att = mod.F.attn
@@ -692,6 +693,7 @@ class RevBlockFn(torch.autograd.Function):
         return y1, y2
 
     @staticmethod
+    @engine.delivers_grads
     def backward(ctx, dy1, dy2):
         mod, plan, drop = ctx.mod, ctx.plan, ctx.drop
         dy1, dy2 = _f16c(dy1), _f16c(dy2)
@@ -712,7 +714,7 @@ class StageTransitionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, mod, thw, drop, *params):
-        ctx._sf_params = params
+        engine.record_params(ctx, params)
         B, N, C = x1.shape
         plan = mod._plan(B, thw, x1.device)
         att = mod.F.attn
@@ -735,6 +737,7 @@ class StageTransitionFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @engine.delivers_grads
     def backward(ctx, dout):
         mod, plan, drop, res = ctx.mod, ctx.plan, ctx.drop, ctx.res
         att = mod.F.attn
@@ -769,7 +772,7 @@ class PatchEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, cls_token, pos, *params):
-        ctx._sf_params = params
+        engine.record_params(ctx, params)
         unit = mod._unit
         xcl = unit.prepare_input(x)
         y, _ = unit.forward(xcl, None, mod.training)            # (B, C, T, H, W) channels-last == (B, THW, C) rows
@@ -791,6 +794,7 @@ class PatchEmbedFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @engine.delivers_grads
     def backward(ctx, dout):
         mod, cls_token = ctx.mod, ctx.cls
         unit = mod._unit
@@ -824,7 +828,7 @@ class ClsNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, mode, has_cls, side, *params):
-        ctx._sf_params = params
+        engine.record_params(ctx, params)
         unit = mod._norm_unit
         s = int(bool(has_cls))
         if mode == "norm_mean":
@@ -846,6 +850,7 @@ class ClsNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @engine.delivers_grads
     def backward(ctx, dy):
         B, N, C = ctx.shape
         s = ctx.s
@@ -871,7 +876,7 @@ class TokenNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, has_cls, *params):
-        ctx._sf_params = params
+        engine.record_params(ctx, params)
         unit = mod._norm_unit
         s = int(bool(has_cls))
         B, N, C = x.shape
@@ -881,6 +886,7 @@ class TokenNormFn(torch.autograd.Function):
         return y.view(B, N - s, C)
 
     @staticmethod
+    @engine.delivers_grads
     def backward(ctx, dy):
         B, N, C = ctx.shape
         s = ctx.s

@@ -71,7 +71,7 @@ def _affinity(mod, theta, phi, g, N, S, T, H, W, device):
 class NonlocalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, *params):
-        ctx._sf_params = params
+        engine.record_params(ctx, params)
         x = as_cl(x)
         N, C, T, H, W = x.shape
         tr = mod.training
@@ -96,6 +96,7 @@ class NonlocalFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @engine.delivers_grads
     def backward(ctx, dout):
         mod, sv = ctx.mod, ctx.sv
         (x,) = ctx.saved_tensors

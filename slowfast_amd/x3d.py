@@ -151,7 +151,7 @@ class X3DStemFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
-        ctx._sf_params = params
+        engine.record_params(ctx, params)
         xy, dw, bn = mod._xy, mod._dw, mod._bn
         xcl = xy.prepare_input(x)
         y1, _ = xy.forward(xcl, None, mod.training)
@@ -164,6 +164,7 @@ class X3DStemFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @engine.delivers_grads
     def backward(ctx, dout):
         mod = ctx.mod
         xcl, y1, y2, st = ctx.sv
@@ -180,7 +181,7 @@ class X3DBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
-        ctx._sf_params = params
+        engine.record_params(ctx, params)
         ctx.prev_bn = getattr(x, "_sf_block_bn", None) if engine.BN_FUSE_REDUCE else None      # see engine.ResBlockFn
         x = as_cl(x)
         t = mod.branch2
@@ -216,6 +217,7 @@ class X3DBlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @engine.delivers_grads
     def backward(ctx, dout):
         mod, sv = ctx.mod, ctx.sv
         t = mod.branch2
@@ -261,7 +263,7 @@ class X3DHeadPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, *params):
-        ctx._sf_params = params
+        engine.record_params(ctx, params)
         x = as_cl(x)
         unit = mod._conv5
         y, st = unit.forward(x, None, mod.training)
@@ -273,6 +275,7 @@ class X3DHeadPoolFn(torch.autograd.Function):
         return m[:, :unit.conv.out_channels].contiguous()
 
     @staticmethod
+    @engine.delivers_grads
     def backward(ctx, dm):
         mod, y, st = ctx.mod, ctx.y, ctx.st
         unit = mod._conv5

@@ -302,6 +302,41 @@ def test_param_grads_through_autograd_equal_in_place(sim, name):
         assert float((got[k] - r).norm()) <= 1e-5 * float(r.norm()) + 1e-9, k
 
 
+def test_delivery_mode_follows_the_forward_not_the_global(sim):
+    """The delivery mode is recorded by every Function at forward time (engine.record_params / delivers_grads): a model that
+    ran its forward in autograd-delivery mode (DDP) still returns its gradients through autograd when another model's
+    GradReducer.zero_grad() has flipped the process-global switch before the backward -- and the other way round."""
+    from slowfast_amd import engine
+    from tests import model_checks as mc
+    gold = mc.load_golden("mvit_tiny")
+    cfg = mc.cfg_for(gold)
+    model, sd, inputs, labels, *_ = mc.oracle_run(gold, cfg)
+    model.load_state_dict(sd)
+    model.train()
+
+    def run(mode_fwd, mode_bwd):
+        for p in model.parameters():
+            p.grad = None
+        engine.GRADS_VIA_AUTOGRAD = mode_fwd
+        try:
+            loss = torch.nn.functional.cross_entropy(model([x.clone() for x in inputs]).float(), labels)
+            engine.GRADS_VIA_AUTOGRAD = mode_bwd            # what another model's iteration would leave behind
+            loss.backward()
+            assert engine.GRADS_VIA_AUTOGRAD == mode_bwd, "the backward must restore the switch it found"
+            assert not engine._pending_grads
+        finally:
+            engine.GRADS_VIA_AUTOGRAD = False
+            engine._pending_grads.clear()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    ref = run(False, False)
+    for fwd, bwd in ((True, False), (False, True), (True, True)):
+        got = run(fwd, bwd)
+        assert set(got) == set(ref), (fwd, bwd)
+        for k, r in ref.items():
+            assert float((got[k] - r).norm()) <= 1e-5 * float(r.norm()) + 1e-9, (fwd, bwd, k)
+
+
 def _ddp_worker(rank, world, port, simlib, q, fp16):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SFAMD_LIBRARY=simlib, SF_SIM_THREADS="2")
     sys.path.insert(0, ROOT)
