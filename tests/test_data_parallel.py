@@ -330,7 +330,7 @@ def test_delivery_mode_follows_the_forward_not_the_global(sim):
         return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
 
     ref = run(False, False)
-    for fwd, bwd in ((True, False), (False, True), (True, True)):
+    for fwd, bwd in ((True, False), (False, True)):        # (True, True): test_param_grads_through_autograd_equal_in_place
         got = run(fwd, bwd)
         assert set(got) == set(ref), (fwd, bwd)
         for k, r in ref.items():
