@@ -23,16 +23,26 @@ def _sources():
     return deps
 
 
-def source_id():
-    """sha256 (first 16 hex digits) over the kernel sources, the C header and the host simulator's HIP shim, in name order:
-    compiled into every build as sf_build_id() and recomputed by lib.SfLibrary from the files shipped beside the binary."""
+SIM_SHIM = os.path.join(ROOT, "tests", "hostsim", "include", "hip", "hip_runtime.h")
+
+
+def sources_present():
+    """False in a deployment that ships the binaries without csrc/ (nothing to compare a build id against)."""
+    return os.path.isfile(SRC) and os.path.isfile(os.path.join(ROOT, "include", "sfamd.h"))
+
+
+def source_id(sim=False):
+    """sha256 (first 16 hex digits) over the sources of ONE target, in name order: the kernel sources + the C header for the
+    gfx950 libraries; the host simulator's HIP shim on top of them for the simulator builds only (``sim=True``) -- an edit of
+    the test shim must not make the GPU library unloadable.  Compiled into every build as sf_build_id() and recomputed by
+    lib.SfLibrary from the files shipped beside the binary.  A listed file that is missing raises (a silent skip would hash a
+    different set of files into the same id)."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(_sources() + [os.path.join(ROOT, "tests", "hostsim", "include", "hip", "hip_runtime.h")]):
-        if os.path.isfile(f):
-            h.update(os.path.basename(f).encode() + b"\0")
-            with open(f, "rb") as fh:
-                h.update(fh.read())
+    for f in sorted(_sources() + ([SIM_SHIM] if sim else [])):
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
     return h.hexdigest()[:16]
 
 
@@ -48,16 +58,16 @@ def _built_id(target):
     return blob[i + len(tag):i + len(tag) + 16].decode("ascii", "replace") if i >= 0 else ""
 
 
-def _stale(target, deps):
-    """A binary is current when it carries the hash of today's sources (mtimes are not trusted: a checkout or a copy to the
-    GPU box resets them)."""
-    return not os.path.exists(target) or _built_id(target) != source_id()
+def _stale(target, sim=False):
+    """A binary is current when it carries the hash of today's sources of its target (mtimes are not trusted: a checkout or a
+    copy to the GPU box resets them)."""
+    return not os.path.exists(target) or _built_id(target) != source_id(sim)
 
 
 def build_hip(force=False, verbose=False, act="fp16"):
     """act = "fp16" -> libsfamd.so, "bf16" -> libsfamd_bf16.so (the 16-bit storage type, lib.ACT_MODE)."""
     out = LIB if act == "fp16" else LIB_BF16
-    if not force and not _stale(out, _sources()):
+    if not force and not _stale(out):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
@@ -71,13 +81,12 @@ def build_hip(force=False, verbose=False, act="fp16"):
 
 def build_hostsim(force=False, verbose=False, act="fp16"):
     out = SIM_LIB if act == "fp16" else SIM_LIB_BF16
-    deps = _sources() + [os.path.join(ROOT, "tests", "hostsim", "include", "hip", "hip_runtime.h")]
-    if not force and not _stale(out, deps):
+    if not force and not _stale(out, sim=True):
         return out
     cxx = os.environ.get("SF_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
     cmd = [cxx, "-x", "c++", "-std=c++20", "-O2", "-fPIC", "-shared", "-Wno-unknown-attributes", "-Wno-comment",
            "-I" + os.path.join(ROOT, "tests", "hostsim", "include"), "-I" + os.path.join(ROOT, "include"),
-           '-DSF_BUILD_ID="%s"' % source_id()] + \
+           '-DSF_BUILD_ID="%s"' % source_id(sim=True)] + \
           (["-DSF_ACT_BF16"] if act == "bf16" else []) + [SRC, "-o", out, "-lpthread"]
     if verbose:
         print(" ".join(cmd))

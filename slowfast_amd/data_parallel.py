@@ -134,6 +134,11 @@ class GradReducer:
                 h.wait()
                 if low is not None:
                     view.copy_(low)
+                    if loss_scale is None and bi in self._prescaled:
+                        # the caller (FlatOptimizer.finish_and_step) reads the bucket inside on_bucket and expects the
+                        # loss-scaled SUM over ranks: undo the 1/world of the compressed exchange BEFORE handing it over
+                        view.mul_(float(self.world))
+                        self._prescaled.discard(bi)
                 if on_bucket is not None:
                     on_bucket(bi)
                     done.add(bi)

@@ -198,13 +198,18 @@ class SfLibrary:
             raise SfError(f"{path}: ABI version {ver}, expected {ABI_VERSION}")
         self.backend = self.cdll.sf_backend().decode()
         self.build_id = self.cdll.sf_build_id().decode()
-        # build provenance: the binary carries the hash of the sources it was compiled from (build_ext.source_id(), passed as
-        # -DSF_BUILD_ID); a binary that is older than the csrc/ + include/ shipped beside it must not produce results
+        # build provenance: the binary carries the hash of the sources it was compiled from (build_ext.source_id() of its
+        # target, passed as -DSF_BUILD_ID); a binary that is older than the csrc/ + include/ shipped beside it must not produce
+        # results.  A deployment without the source tree has nothing to compare against: the check is skipped with a warning.
         from . import build_ext
-        want = build_ext.source_id()
-        if self.build_id != want and os.environ.get("SF_ALLOW_STALE_LIBRARY", "0") == "0":
-            raise SfError(f"{path} was built from other sources (build id {self.build_id}, sources {want}): rebuild with "
-                          "`python -m slowfast_amd.build_ext` (SF_ALLOW_STALE_LIBRARY=1 overrides)")
+        if build_ext.sources_present():
+            want = build_ext.source_id(sim=self.backend == "hostsim")
+            if self.build_id != want and os.environ.get("SF_ALLOW_STALE_LIBRARY", "0") == "0":
+                raise SfError(f"{path} was built from other sources (build id {self.build_id}, sources {want}): rebuild with "
+                              "`python -m slowfast_amd.build_ext` (SF_ALLOW_STALE_LIBRARY=1 overrides)")
+        else:
+            import warnings
+            warnings.warn(f"{path}: kernel sources not found beside the package, build id {self.build_id} not verified")
         self.act_mode = ("fp16", "bf16")[self.cdll.sf_act_dtype()]
         if self.act_mode != ACT_MODE:
             raise SfError(f"{path} is the {self.act_mode} build of the library, this process runs with SF_ACT_DTYPE={ACT_MODE}")

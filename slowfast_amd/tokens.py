@@ -193,6 +193,11 @@ _FIN_MAX_ROWS = 2048        # tables up to this many rows are batched (longer on
 
 
 class deferred_finalizes:
+    """Collect the column-sum finalizes issued inside the ``with`` block and launch them in batches at its end.  Assumes ONE
+    thread and ONE stream per block backward (the autograd worker that runs the Function): the pending list is process-global,
+    not thread-safe, and a flush launches on the current stream of its first item.  Any OTHER kernel that writes one of the
+    pending outputs inside the block must call flush_finalizes() first (colsum_finalize does so for its own immediate path)."""
+
     def __enter__(self):
         global _pending_fin
         self._outer = _pending_fin
@@ -240,6 +245,12 @@ def colsum_finalize(part, C, fold, out0, out1, scale=1.0, accumulate=False, row_
                 break
         _pending_fin.append((part, C, fold, out0, out1, scale, accumulate, row_stride))
         return
+    if _pending_fin:
+        # an immediate finalize (table too long to defer) into an output a deferred one also writes: launch order must stay
+        # program order (overwrite-then-accumulate), so the pending items go first
+        outs = [o.data_ptr() for o in (out0, out1) if o is not None]
+        if any(o is not None and o.data_ptr() in outs for it in _pending_fin for o in (it[3], it[4])):
+            flush_finalizes()
     if row_stride != 1:
         _finalize_batch([(part, C, fold, out0, out1, scale, accumulate, row_stride)])
         return

@@ -54,19 +54,20 @@ def test_stale_binary_is_refused(tmp_path, monkeypatch, hostsim_path):
     """Build provenance: every binary carries the hash of the sources it was compiled from (sf_build_id); a binary whose id
     differs from the csrc/ + include/ beside it is refused at load, and build_ext treats it as stale whatever its mtime."""
     from slowfast_amd import build_ext, lib
-    want = build_ext.source_id()
-    for path in (build_ext.build_hip(), hostsim_path):
+    for path, sim in ((build_ext.build_hip(), False), (hostsim_path, True)):
+        want = build_ext.source_id(sim)
         dll = ctypes.CDLL(path)
         dll.sf_build_id.restype = ctypes.c_char_p
         assert dll.sf_build_id().decode() == want == build_ext._built_id(path)
-        assert not build_ext._stale(path, None)
+        assert not build_ext._stale(path, sim)
+    assert build_ext.source_id(False) != build_ext.source_id(True), "the test shim is hashed into the simulator builds only"
     blob = open(hostsim_path, "rb").read()
     tag = b"sfamd-build-id:" + want.encode()
     assert blob.count(tag) == 1
     old = tmp_path / "libsfamd_old.so"
     old.write_bytes(blob.replace(tag, b"sfamd-build-id:" + b"0123456789abcdef"))
     os.utime(old, (2e9, 2e9))                                   # newer than every source: mtimes do not vouch for a binary
-    assert build_ext._stale(str(old), None)
+    assert build_ext._stale(str(old), True)
     monkeypatch.setenv("SFAMD_LIBRARY", str(old))
     lib.reset_lib()
     with pytest.raises(lib.SfError, match="built from other sources"):

@@ -459,6 +459,74 @@ def test_allreduce_overlaps_backward_segments(hostsim_path):
         assert inflight >= 1, "no collective was in flight when the last backward segment started"
 
 
+def _compressed_norm_worker(rank, world, port, simlib, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SFAMD_LIBRARY=simlib, SF_SIM_THREADS="2")
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from slowfast_amd.data_parallel import GradReducer
+    from slowfast_amd.optim import FlatOptimizer
+
+    def run(bucketed):
+        model = _build()
+        red = GradReducer(model, bucket_mb=0.004, comm_dtype=torch.float16)
+        assert len(red.buckets) >= 3
+        opt = FlatOptimizer([{"params": list(model.parameters()), "lr": 0.0}], red, loss_scale=4.0)
+        torch.manual_seed(7 + rank)
+        x = torch.randn(2, 16, 4, 8, 8)
+        red.zero_grad()
+        (model(x).square().mean() * opt.loss_scale).backward()
+        seen = []
+        if bucketed:
+            # what on_bucket sees must already be the loss-scaled SUM over ranks (it was the mean)
+            orig = opt._sumsq_bucket
+            def spy(bi):
+                s0, e0, _ = red.buckets[bi]
+                seen.append((bi, red.flat[s0:e0].clone()))
+                orig(bi)
+            opt._sumsq_bucket = spy
+            opt.finish_and_step()
+        else:
+            red.finish(loss_scale=None)
+            opt.step()
+        out = (float(opt.grad_norm), red.flat.clone(), seen)
+        red.close()
+        return out
+
+    n_ref, flat_ref, _ = run(False)
+    n_got, flat_got, seen = run(True)
+    err = abs(n_got - n_ref) / n_ref
+    ferr = float((flat_got - flat_ref).abs().max())
+    berr = 0.0
+    # bucket contents handed to on_bucket == the final buffer (no later rescale may touch them)
+    model = _build()
+    red = GradReducer(model, bucket_mb=0.004, comm_dtype=torch.float16)
+    for bi, t in seen:
+        s0, e0, _ = red.buckets[bi]
+        berr = max(berr, float((t - flat_ref[s0:e0]).abs().max()))
+    red.close()
+    q.put((rank, err, ferr, berr, n_ref, len(seen)))
+    dist.destroy_process_group()
+
+
+def test_compressed_exchange_bucketwise_norm_two_ranks(hostsim_path):
+    """MODEL.FP16_ALLREDUCE-style compression (comm_dtype=float16) at world size 2: FlatOptimizer.finish_and_step (norm pass
+    bucket by bucket inside GradReducer.finish's on_bucket) must see the loss-scaled SUM over ranks in every bucket -- gradient
+    norm and buffer identical to finish(loss_scale=None) + step()."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_compressed_norm_worker, args=(r, 2, port, hostsim_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(2)]
+    for rank, err, ferr, berr, n_ref, nseen in res:
+        assert n_ref > 0 and nseen >= 3, res
+        assert err < 1e-6 and ferr == 0.0 and berr == 0.0, res
+
+
 # ---- the reference's own boundary on the GPU: build_model -> DistributedDataParallel + register_comm_hook over RCCL -----------
 _DDP_RCCL_SCRIPT = """
 import os, sys, torch, torch.distributed as dist
