@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 23
+#define SF_ABI_VERSION 22
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -154,53 +154,6 @@ int sf_bn_bwd_finalize(float* part, int32_t nblk, int32_t C, int32_t Creal, floa
 int sf_bn_bwd_apply(int64_t M, int32_t C, const void* dz, int32_t lddz, const void* zmask, int32_t ldm, const void* y,
                     int32_t ldy, const float* scale, const float* shift, int relu_self, const float* coef, void* dy,
                     int32_t lddy, void* gout, int32_t ldg, sf_stream_t stream);
-
-/* ---- BatchNorm finalize INSIDE the producing convolution (round 5; csrc/sf_tailfold.h).  The workgroup that completes a
- * group of M tiles folds the group's partial rows, the one that completes a column tile finalizes its channels: no
- * sf_bn_finalize / sf_bn_bwd_finalize launch (220 per SlowFast step), same outputs.  Reference op: F.batch_norm(training=True)
- * behind every nn.Conv3d of resnet_helper.py:331-372 and its backward.
- *   counters : SF_BN_FOLD_COUNTERS int32, zeroed ONCE by the caller; every launch leaves them zero (one buffer per stream)
- *   scratch  : sf_bn_fold_scratch_bytes(C) bytes (fp64 group rows), contents irrelevant
- *   mode 1 (sf_conv_fwd_bn): gamma, beta, running_mean / running_var (optional), momentum, eps, count -> scale, shift,
- *            save_mean, save_rstd (exactly sf_bn_finalize's arguments)
- *   mode 2 (sf_conv_dgrad_bn_fin): gamma, mean, rstd, inv_loss_scale, count -> dgamma, dbeta (+= when accumulate), coef[3][C]
- *            (exactly sf_bn_bwd_finalize's arguments)
- * Both entry points return 1 when the launch finalized in place, 0 when this geometry keeps the separate pass (thin stems,
- * strided data gradients: the partial table is filled as before and the caller runs sf_bn_finalize / sf_bn_bwd_finalize),
- * negative on error. */
-#define SF_BN_FOLD_COUNTERS 132096     /* (128 + 1) groups x 16 column tiles, one 256-byte line each */
-typedef struct sf_bn_fold {
-    int32_t* counters;
-    void* scratch;
-    int64_t scratch_bytes;
-    int32_t Creal;
-    float count;
-    const float* gamma;
-    const float* beta;
-    float* running_mean;
-    float* running_var;
-    float momentum, eps;
-    float* scale;
-    float* shift;
-    float* save_mean;
-    float* save_rstd;
-    const float* mean;
-    const float* rstd;
-    float inv_loss_scale;
-    float* dgamma;
-    float* dbeta;
-    int32_t accumulate;
-    float* coef;
-} sf_bn_fold;
-int64_t sf_bn_fold_scratch_bytes(int32_t C);
-/* sf_conv_fwd + in-launch statistics finalize; stat_part as for sf_conv_fwd (required) */
-int sf_conv_fwd_bn(const sf_conv_desc* d, const void* x, const void* wf, const float* in_scale, const float* in_shift,
-                   int in_relu, const float* bias, void* y, float* stat_part, const sf_bn_fold* fold, sf_stream_t stream);
-/* sf_conv_dgrad_bn + in-launch finalize of the reduced BatchNorm's backward sums */
-int sf_conv_dgrad_bn_fin(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
-                         const void* resid_bits, void* dx, const float* mask_scale, const float* mask_shift,
-                         const void* mask_bits, const void* bn_y, int32_t bn_ldy, float* bn_part, int32_t bn_part_rows,
-                         int32_t* bn_rows, const sf_bn_fold* fold, sf_stream_t stream);
 
 /* ---- nn.MaxPool3d([1,kH,kW],[1,sH,sW],[0,pH,pW]) fused with the producer's BN(+ReLU) --
  * stem_helper.py:190-201 (bn -> relu -> pool_layer). */

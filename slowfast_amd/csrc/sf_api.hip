@@ -130,40 +130,6 @@ static GatherSide gather_dgrad(const sf_conv_desc* d, const void* dy) {
     return g;
 }
 
-// ------------------------------------------------------------------------------------------------
-// In-launch BatchNorm finalize (sf_tailfold.h): the caller's sf_bn_fold request travels in IgemmParams::tail with only the
-// pointers / finalize operands set; the launcher that knows the tile shape completes it (or switches it off) and reports
-// through g_fold_applied whether the kernel it launched finalizes in place.
-#define SF_FOLD_MAX_GROUPS 128
-static thread_local int g_fold_applied = 0;
-extern "C" int64_t sf_bn_fold_scratch_bytes(int32_t C) { return (int64_t)SF_FOLD_MAX_GROUPS * 2 * (C > 0 ? C : 0) * 8; }
-static void fold_request(TailFold& t, const sf_bn_fold* f, int mode) {
-    memset(&t, 0, sizeof(t));
-    if (!f || !f->counters || !f->scratch) return;
-    t.cnt = f->counters; t.lvl1 = (double*)f->scratch;
-    t.nrows = (int)(f->scratch_bytes / 16);           // until fold_complete(): capacity of the scratch in fp64 PAIRS
-    t.mode = mode; t.Creal = f->Creal; t.count = f->count;
-    t.gamma = f->gamma; t.beta = f->beta; t.running_mean = f->running_mean; t.running_var = f->running_var;
-    t.momentum = f->momentum; t.eps = f->eps;
-    t.scale = f->scale; t.shift = f->shift; t.save_mean = f->save_mean; t.save_rstd = f->save_rstd;
-    t.mean = f->mean; t.rstd = f->rstd; t.inv_loss_scale = f->inv_loss_scale;
-    t.dgamma = f->dgamma; t.dbeta = f->dbeta; t.accumulate = f->accumulate; t.coef = f->coef;
-}
-// group size ~ sqrt(M tiles): both levels then read about the same number of rows; at most SF_FOLD_MAX_GROUPS groups
-static void fold_complete(TailFold& t, int C, int mtiles, int ntiles_n, int rows_per_tile, int nrows) {
-    g_fold_applied = 0;
-    if (!t.cnt) return;
-    int group = 1;
-    while (group * group < mtiles) ++group;
-    const int lo = cdiv(mtiles, SF_FOLD_MAX_GROUPS);
-    if (group < lo) group = lo;
-    const int ngroups = cdiv(mtiles, group);
-    const int64_t cap_pairs = t.nrows;
-    if ((int64_t)(ngroups + 1) * ntiles_n * SF_FOLD_CNT_STRIDE > SF_BN_FOLD_COUNTERS || (int64_t)ngroups * C > cap_pairs) { t.cnt = nullptr; return; }
-    t.group = group; t.ngroups = ngroups; t.rows_per_tile = rows_per_tile; t.nrows = nrows;
-    g_fold_applied = 1;
-}
-
 // direct global -> LDS operand copies (GL): plain row-major GEMM operands only -- one tap, no fused input BatchNorm,
 // K a multiple of the 32-wide K step, 16-byte aligned rows.  SF_IGEMM_GLDS=0 keeps the register-staged loads.
 static bool igemm_glds_ok(const IgemmParams& p, bool pw) {
@@ -177,11 +143,8 @@ static bool igemm_glds_ok(const IgemmParams& p, bool pw) {
 }
 
 template <int BN, int WM, int WN>
-static void launch_igemm(const IgemmParams& p_in, bool pw, hipStream_t s, int nbatch = 1) {
-    int mt = cdiv(p_in.M, 128);
-    IgemmParams p = p_in;
-    if (nbatch != 1) p.tail.cnt = nullptr;
-    fold_complete(p.tail, p.Nout, mt, p.ntiles_n, 1, mt);
+static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s, int nbatch = 1) {
+    int mt = cdiv(p.M, 128);
     dim3 grid((unsigned)(mt * p.ntiles_n), (unsigned)nbatch);
     // 128-VGPR cap (4 workgroups per CU) for the 128-wide tile: +0.2..1.2 % end to end (profiles/r1_visit9_*_occ4.json);
     // SF_IGEMM_OCC4=0 restores the uncapped build for A/B runs
@@ -212,9 +175,6 @@ static void launch_igemm(const IgemmParams& p_in, bool pw, hipStream_t s, int nb
 template <int BN, int BK>
 static void launch_igemm2(Igemm2Params& q, hipStream_t s) {
     q.ntiles_n = cdiv(q.Nout, BN);
-    // forward statistics are kept per 128 rows (two table rows per 256-row tile), the backward sums per tile
-    fold_complete(q.tail, q.Nout, cdiv(q.M, 256), q.ntiles_n, q.tail.mode == 1 ? 2 : 1,
-                  q.tail.mode == 1 ? cdiv(q.M, 128) : cdiv(q.M, 256));
     const dim3 grid((unsigned)(cdiv(q.M, 256) * q.ntiles_n));
     if constexpr (BN >= 64) {       // (N <= 32 never reaches this kernel: try_igemm2)
         if (q.f32.out) { hipLaunchKernelGGL((sf_igemm2_kernel<256, BN, 4, 2, BK, 3, true>), grid, dim3(512), 0, s, q); return; }
@@ -263,7 +223,6 @@ static void igemm2_common(Igemm2Params& q, const IgemmParams& p) {
     q.bnb_y = p.bnb_y; q.bnb_ld = p.bnb_ld; q.bnb_scale = p.bnb_scale; q.bnb_shift = p.bnb_shift; q.bnb_part = p.bnb_part;
     q.bnb_bits = p.bnb_bits;
     q.f32 = p.f32;
-    q.tail = p.tail;
 }
 static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     // read on every call (three getenv per launch are noise): tests lower the thresholds for single cases
@@ -338,7 +297,6 @@ static bool try_igemm2_strided_dgrad(const IgemmParams& p, hipStream_t s) {
                 if (empty) continue;
                 Igemm2Params q;
                 igemm2_common(q, p);
-                q.tail.cnt = nullptr;           // one launch per residue class: no in-launch fold
                 q.fdrT = make_fastdiv(cnt[0]); q.fdrH = make_fastdiv(cnt[1]); q.fdrW = make_fastdiv(cnt[2]);
                 q.mulT = q.mulH = q.mulW = 1;
                 q.offT = q0[0]; q.offH = q0[1]; q.offW = q0[2];
@@ -522,11 +480,10 @@ extern "C" int sf_conv_fwd_mtiles(const sf_conv_desc* d) {
     return cdiv((int64_t)d->N * d->To * d->Ho * d->Wo, 128);
 }
 
-static int conv_fwd_impl(const sf_conv_desc* d, const void* x, const void* wf, const float* in_scale,
-                         const float* in_shift, int in_relu, const float* bias, void* y, float* stat_part,
-                         const sf_bn_fold* fold, sf_stream_t stream) {
+extern "C" int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf, const float* in_scale,
+                           const float* in_shift, int in_relu, const float* bias, void* y, float* stat_part,
+                           sf_stream_t stream) {
     if (check_desc(d)) return -1;
-    g_fold_applied = 0;
     REQUIRE(x && wf && y, "sf_conv_fwd: null pointer");
     REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sf_conv_fwd: in_scale/in_shift must come together");
     REQUIRE(!in_scale || d->Ci <= 512, "sf_conv_fwd: fused input BatchNorm supports Ci <= 512 (got %d)", d->Ci);
@@ -555,31 +512,7 @@ static int conv_fwd_impl(const sf_conv_desc* d, const void* x, const void* wf, c
     p.y = (f16*)y; p.ldy = d->ldy;
     p.bias = bias; p.resid = nullptr; p.ldr = 0;
     p.stat_part = stat_part;
-    if (fold && stat_part) fold_request(p.tail, fold, 1);
     return run_igemm(p, is_pointwise(d), (hipStream_t)stream);
-}
-extern "C" int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf, const float* in_scale,
-                           const float* in_shift, int in_relu, const float* bias, void* y, float* stat_part,
-                           sf_stream_t stream) {
-    return conv_fwd_impl(d, x, wf, in_scale, in_shift, in_relu, bias, y, stat_part, nullptr, stream);
-}
-static int check_fold(const sf_bn_fold* f, int mode, int C) {
-    REQUIRE(f && f->counters && f->scratch, "sf_bn_fold: counters and scratch are required");
-    REQUIRE(((uintptr_t)f->scratch & 7) == 0 && f->scratch_bytes >= 0, "sf_bn_fold: scratch must be 8-byte aligned");
-    REQUIRE(f->Creal > 0 && f->Creal <= C && f->count > 0.f && f->gamma, "sf_bn_fold: bad Creal / count / gamma");
-    if (mode == 1) REQUIRE(f->beta && f->scale && f->shift && (!f->running_mean == !f->running_var),
-                           "sf_bn_fold (forward): beta, scale, shift are required; running statistics come together");
-    else REQUIRE(f->mean && f->rstd && f->dgamma && f->dbeta && f->coef,
-                 "sf_bn_fold (backward): mean, rstd, dgamma, dbeta, coef are required");
-    return 0;
-}
-extern "C" int sf_conv_fwd_bn(const sf_conv_desc* d, const void* x, const void* wf, const float* in_scale,
-                              const float* in_shift, int in_relu, const float* bias, void* y, float* stat_part,
-                              const sf_bn_fold* fold, sf_stream_t stream) {
-    REQUIRE(d && stat_part, "sf_conv_fwd_bn: the partial table is required");
-    if (check_fold(fold, 1, d->Co)) return -1;
-    const int rc = conv_fwd_impl(d, x, wf, in_scale, in_shift, in_relu, bias, y, stat_part, fold, stream);
-    return rc < 0 ? rc : g_fold_applied;
 }
 
 extern "C" int sf_conv_fwd_fused(const sf_conv_desc* d, const void* x, const void* wf, const float* bias,
@@ -618,10 +551,8 @@ struct BnFuse {     // the fused BatchNorm-backward reduction of sf_conv_dgrad_b
     const void* y0; int32_t ld0; float* part0;
 };
 static int conv_dgrad_impl(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
-                           const void* resid_bits, void* dx, const BnFuse* bn, int32_t* bn_rows, sf_stream_t stream,
-                           const sf_bn_fold* fold = nullptr) {
+                           const void* resid_bits, void* dx, const BnFuse* bn, int32_t* bn_rows, sf_stream_t stream) {
     if (check_desc(d)) return -1;
-    g_fold_applied = 0;
     REQUIRE(dy && wd && dx, "sf_conv_dgrad: null pointer");
     REQUIRE(!resid || (ldr >= d->Ci && ldr % 8 == 0), "sf_conv_dgrad: bad residual pitch");
     IgemmParams p;
@@ -665,7 +596,6 @@ static int conv_dgrad_impl(const sf_conv_desc* d, const void* dy, const void* wd
     if (fuse) {
         p.bnb_y = (const f16*)bn->y0; p.bnb_ld = bn->ld0; p.bnb_part = bn->part0;
         p.bnb_scale = bn->scale; p.bnb_shift = bn->shift; p.bnb_bits = (const uint8_t*)bn->bits;
-        if (fold) fold_request(p.tail, fold, 2);
     }
     int bm = 0;
     const int rc = run_igemm(p, is_pointwise(d), (hipStream_t)stream, &bm);
@@ -689,20 +619,6 @@ extern "C" int sf_conv_dgrad_bn(const sf_conv_desc* d, const void* dy, const voi
             "sf_conv_dgrad_bn: the partial table needs ceil(positions / 128) rows of [2][Ci] floats");
     const BnFuse bn = {mask_scale, mask_shift, mask_bits, bn_y, bn_ldy, bn_part};
     return conv_dgrad_impl(d, dy, wd, resid, ldr, resid_bits, dx, &bn, bn_rows, stream);
-}
-extern "C" int sf_conv_dgrad_bn_fin(const sf_conv_desc* d, const void* dy, const void* wd, const void* resid, int32_t ldr,
-                                    const void* resid_bits, void* dx, const float* mask_scale, const float* mask_shift,
-                                    const void* mask_bits, const void* bn_y, int32_t bn_ldy, float* bn_part,
-                                    int32_t bn_part_rows, int32_t* bn_rows, const sf_bn_fold* fold, sf_stream_t stream) {
-    REQUIRE(d && bn_y && bn_part && bn_rows, "sf_conv_dgrad_bn_fin: null pointer");
-    REQUIRE(mask_bits || (mask_scale && mask_shift), "sf_conv_dgrad_bn_fin: a mask source is needed (mask_bits, or mask_scale + mask_shift)");
-    REQUIRE(bn_ldy >= d->Ci && bn_ldy % 8 == 0 && ((uintptr_t)bn_y & 15) == 0, "sf_conv_dgrad_bn_fin: bad bn_y pitch / alignment");
-    REQUIRE((int64_t)bn_part_rows * 128 >= (int64_t)d->N * d->Ti * d->Hi * d->Wi,
-            "sf_conv_dgrad_bn_fin: the partial table needs ceil(positions / 128) rows of [2][Ci] floats");
-    if (check_fold(fold, 2, d->Ci)) return -1;
-    const BnFuse bn = {mask_scale, mask_shift, mask_bits, bn_y, bn_ldy, bn_part};
-    const int rc = conv_dgrad_impl(d, dy, wd, resid, ldr, resid_bits, dx, &bn, bn_rows, stream, fold);
-    return rc < 0 ? rc : (*bn_rows > 0 ? g_fold_applied : 0);
 }
 
 template <int BMW, int WM, int WN, int KS>

@@ -11,7 +11,6 @@
 // buffered LDS (global loads of step s+1 are in flight under the MFMAs of step s).
 #pragma once
 #include "sf_common.h"
-#include "sf_tailfold.h"
 
 struct IgemmParams {
     GatherSide g;
@@ -49,7 +48,6 @@ struct IgemmParams {
     float* bnb_part;
     const uint8_t* bnb_bits;        // optional [rows][Nout/8] bit mask replacing the recomputed one (block-output ReLU)
     F32Rows f32;                    // fp32 side rows of the output (token residual sums; sf_common.h), f32.out == nullptr: off
-    TailFold tail;                  // in-launch finalize of stat_part (mode 1) or bnb_part (mode 2), sf_tailfold.h; cnt == nullptr: off
 };
 
 // g = dz masked by the producer's ReLU (same expression as masked_grad8 / sf_bn_bwd_apply use), accumulated per channel.
@@ -108,8 +106,8 @@ __device__ __forceinline__ void bnb_reduce_store(float (&sg)[8], float (&sgy)[8]
                 q += red[(w * CG + cgi) * 24 + 8 + e];
                 if (prow2) q2 += red[(w * CG + cgi) * 24 + 16 + e];
             }
-            SF_AGENT_STORE(prow + col, s);              // write-through: a tail fold in another workgroup may read the row
-            SF_AGENT_STORE(prow + Nout + col, q);
+            prow[col] = s;
+            prow[Nout + col] = q;
             if (prow2) { prow2[col] = s; prow2[Nout + col] = q2; }
         }
     }
@@ -145,8 +143,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
     // ONE LDS object (hipcc serialises direct-to-LDS copies against ds_reads of any OTHER __shared__ object):
     // [operand stages | epilogue staging] [BatchNorm scale/shift tables (register-staged variant only)] [stat partials]
     constexpr int TF_BYTES = GL ? 0 : 2 * 512 * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SMEM * 2 + TF_BYTES + WAVES_M * 2 * BN * 4 + 16];
-    volatile int* const s_fold_flag = reinterpret_cast<volatile int*>(lds_raw + SMEM * 2 + TF_BYTES + WAVES_M * 2 * BN * 4);
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SMEM * 2 + TF_BYTES + WAVES_M * 2 * BN * 4];
     f16* const smem = reinterpret_cast<f16*>(lds_raw);
     float* const s_scale = reinterpret_cast<float*>(lds_raw + SMEM * 2);
     float* const s_shift = s_scale + 512;
@@ -158,7 +155,6 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
     const int tile = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int nt = tile % p.ntiles_n, mt = tile / p.ntiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
-    if (tid == 0) *s_fold_flag = 0;                                 // (ordered by the barriers of the K loop)
     const GatherSide& g = p.g;
     const bool has_tf = g.scale != nullptr;
     const f16* a_src = g.src;
@@ -374,13 +370,10 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
                 s += s_red[w][0][tid];
                 q += s_red[w][1][tid];
             }
-            SF_AGENT_STORE(p.stat_part + ((int64_t)mt * 2 + 0) * p.Nout + col, s);
-            SF_AGENT_STORE(p.stat_part + ((int64_t)mt * 2 + 1) * p.Nout + col, q);
+            p.stat_part[((int64_t)mt * 2 + 0) * p.Nout + col] = s;
+            p.stat_part[((int64_t)mt * 2 + 1) * p.Nout + col] = q;
         }
     }
-    constexpr int STAT_WAVES = (BN + 63) / 64;                      // the waves that just stored statistics rows
-    if (p.tail.cnt && p.tail.mode == 1 && wave < STAT_WAVES)
-        tail_group_ticket_wave(p.tail, mt, (int)gridDim.x / p.ntiles_n, nt, p.ntiles_n, STAT_WAVES, s_fold_flag);
     constexpr int CG = BN / 8;
     static_assert(SF_THREADS % CG == 0 && 64 % CG == 0, "a thread keeps one column group over the whole store loop");
     const bool bnb = p.bnb_part != nullptr;
@@ -455,14 +448,6 @@ __global__ __launch_bounds__(SF_THREADS, OCC4 ? 4 : 1) void sf_igemm_kernel(Igem
         }
     }
     if (bnb) bnb_reduce_store<4, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);
-    if (p.tail.cnt) {
-        static_assert(SMEM * 2 >= SF_THREADS * 8 && 2 * BN <= SF_THREADS, "tail fold scratch overlays the operand stages");
-        // tile coordinates recomputed here (scalar arithmetic) instead of kept live across the K loop
-        const int tile_t = (int)xcd_remap(blockIdx.x, gridDim.x);
-        const int nt_t = tile_t % p.ntiles_n, mt_t = tile_t / p.ntiles_n;
-        tail_fold<SF_THREADS>(p.tail, p.tail.mode == 1 ? p.stat_part : p.bnb_part, p.Nout, mt_t, (int)gridDim.x / p.ntiles_n, nt_t,
-                              p.ntiles_n, nt_t * BN, BN, reinterpret_cast<double*>(lds_raw), s_fold_flag, p.tail.mode == 1);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------

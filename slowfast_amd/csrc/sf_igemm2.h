@@ -18,7 +18,6 @@
 // The producer's BatchNorm + ReLU is NOT applied here: engine.ResBlockFn materialises relu(bn(y)) once (engine.MATERIALIZE).
 #pragma once
 #include "sf_common.h"
-#include "sf_tailfold.h"
 
 #define SF_I2_MAXTAPS 32
 
@@ -70,7 +69,6 @@ struct Igemm2Params {
     // LDS reads / MFMAs, bit 2 LDS reads but no MFMAs, bit 3 return before the epilogue, bit 4 no barrier inside the K loop
     int ablate;
     F32Rows f32;        // fp32 side rows of the output (token residual sums; sf_common.h), f32.out == nullptr: off
-    TailFold tail;      // in-launch finalize of stat_part (mode 1) or bnb_part (mode 2), sf_tailfold.h; cnt == nullptr: off
 };
 
 // LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase
@@ -110,8 +108,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
     static_assert(WAVES_M % HALVES == 0, "a wave row belongs to one 128-row group");
 
     // ONE LDS object (hipcc serialises direct-to-LDS copies against ds_reads of any other __shared__ object)
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SMEM * 2 + WAVES_M * 2 * BN * 4 + BM * 4 + 16];
-    volatile int* const s_fold_flag = reinterpret_cast<volatile int*>(lds_raw + SMEM * 2 + WAVES_M * 2 * BN * 4 + BM * 4);
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SMEM * 2 + WAVES_M * 2 * BN * 4 + BM * 4];
     f16* const smem = reinterpret_cast<f16*>(lds_raw);
     float (*const s_red)[2][BN] = reinterpret_cast<float (*)[2][BN]>(lds_raw + SMEM * 2);
     int* const s_orow = reinterpret_cast<int*>(lds_raw + SMEM * 2 + WAVES_M * 2 * BN * 4);   // output row of a tile row
@@ -122,7 +119,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
     const int tile = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int nt = tile % p.ntiles_n, mt = tile / p.ntiles_n;
     const int m0 = mt * BM, n0 = nt * BN;
-    if (tid == 0) *s_fold_flag = 0;                                 // (ordered by the barriers of the K loop)
 
     // ---- loader state: the rows this lane copies in every stage (instruction j of the wave -> rows (wave + NW*j)*RPI ..)
     const int lrow = lane / KSL;                                    // row inside a copy instruction
@@ -210,15 +206,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 for (int j = 0; j < TN; ++j) SF_KEEP_ALIVE(bf[j]);
                 continue;
             }
+            if (p.ablate & 64) __builtin_amdgcn_s_setprio(1);      // experiment: priority around the MFMA cluster (guide T5)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
+            if (p.ablate & 64) __builtin_amdgcn_s_setprio(0);
         }
     };
 
     // ---- main loop: stages ks + 1 (and ks + 2 at NST == 3) are in flight while stage ks is multiplied
+    if ((p.ablate & 32) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);     // experiment: static priority for the younger half (T5 static form)
     {
         // copies one wave issues per stage: the count s_waitcnt vmcnt leaves outstanding (uniform over the waves whenever
         // NBI % NW == 0; a partial last round only makes some waves wait for one copy more than necessary)
@@ -307,13 +306,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 s += s_red[half * WPH + w][0][c];
                 q += s_red[half * WPH + w][1][c];
             }
-            SF_AGENT_STORE(p.stat_part + ((int64_t)prow * 2 + 0) * p.Nout + col, s);       // write-through (sf_tailfold.h)
-            SF_AGENT_STORE(p.stat_part + ((int64_t)prow * 2 + 1) * p.Nout + col, q);
+            p.stat_part[((int64_t)prow * 2 + 0) * p.Nout + col] = s;
+            p.stat_part[((int64_t)prow * 2 + 1) * p.Nout + col] = q;
         }
     }
-    constexpr int STAT_WAVES = (HALVES * BN + 63) / 64;             // the waves that just stored statistics rows
-    if (p.tail.cnt && p.tail.mode == 1 && wave < STAT_WAVES)
-        tail_group_ticket_wave(p.tail, mt, (int)gridDim.x / p.ntiles_n, nt, p.ntiles_n, STAT_WAVES, s_fold_flag);
     constexpr int CG = BN / 8;
     static_assert(NT % CG == 0 && 64 % CG == 0, "a thread keeps one column group over the whole store loop");
     const bool bnb = p.bnb_part != nullptr;
@@ -389,12 +385,4 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
         }
     }
     if (bnb) bnb_reduce_store<NW, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);
-    if (p.tail.cnt) {
-        static_assert(SMEM * 2 >= NT * 8 && 2 * BN <= NT, "tail fold scratch overlays the operand stages");
-        // tile coordinates recomputed here (scalar arithmetic) instead of kept live across the K loop
-        const int tile_t = (int)xcd_remap(blockIdx.x, gridDim.x);
-        const int nt_t = tile_t % p.ntiles_n, mt_t = tile_t / p.ntiles_n;
-        tail_fold<NT>(p.tail, p.tail.mode == 1 ? p.stat_part : p.bnb_part, p.Nout, mt_t, (int)gridDim.x / p.ntiles_n, nt_t,
-                      p.ntiles_n, nt_t * BN, BN, reinterpret_cast<double*>(lds_raw), s_fold_flag, p.tail.mode == 1);
-    }
 }

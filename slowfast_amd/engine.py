@@ -283,17 +283,6 @@ def bn_statistics(bn, part, count, C, training):
     return BNState(*st)
 
 
-def bn_fold_request(bn, count, training):
-    """Operands of the in-launch statistics finalize (ops.conv_fwd(..., bn_fold=...)) for a BatchNorm that runs on batch
-    statistics, or None when the separate pass is needed: synchronised BatchNorm all-reduces the [2, C] sums between the
-    statistics epilogue and the finalize."""
-    if _sync_of(bn) is not None or bn.weight is None or bn.bias is None:
-        return None
-    track = bn.track_running_stats and training and bn.running_mean is not None
-    return dict(gamma=bn.weight, beta=bn.bias, running_mean=bn.running_mean if track else None,
-                running_var=bn.running_var if track else None, momentum=bn.momentum, eps=bn.eps, count=count)
-
-
 def as_cl(t):
     """Gradients/activations entering a block from torch code may be fp32 or NCTHW-contiguous."""
     if t.dtype == _f16 and ops.is_cl(t):
@@ -433,12 +422,6 @@ class ConvUnit:
             y, _ = ops.conv_fwd(x, wf, geom, in_affine=in_affine, bias=self.conv.bias, stats=False)
             return y, None
         use_batch_stats = training or bn.running_mean is None
-        fold = bn_fold_request(bn, geom.out_rows, training) if use_batch_stats else None
-        if fold is not None:        # statistics finalized by the convolution's own launch (csrc/sf_tailfold.h)
-            y, part, st = ops.conv_fwd(x, wf, geom, in_affine=in_affine, bias=self.conv.bias, stats=True, bn_fold=fold)
-            if st is not None:
-                return y, BNState(*st)
-            return y, bn_statistics(bn, part, geom.out_rows, geom.Co, training)
         y, part = ops.conv_fwd(x, wf, geom, in_affine=in_affine, bias=self.conv.bias, stats=use_batch_stats)
         return y, bn_statistics(bn, part, geom.out_rows, geom.Co, training)
 

@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 23
+ABI_VERSION = 22
 # 16-bit storage type of activations / packed weights / MFMA operands, fixed per PROCESS: SF_ACT_DTYPE=fp16 (default) loads
 # libsfamd.so, =bf16 loads libsfamd_bf16.so -- the same sources compiled with -DSF_ACT_BF16 (bfloat16 storage,
 # v_mfma_f32_16x16x32_bf16); both are what torch.cuda.amp.autocast admits on the reference side (tools/train_net.py:101-118).
@@ -69,20 +69,6 @@ class ColFinItem(Structure):
                 ("out1", c_void_p), ("scale", c_float), ("accumulate", c_int32), ("row_stride", c_int32)]
 
 
-class BnFold(Structure):
-    """Mirror of ``sf_bn_fold``: the BatchNorm finalize taken inside the producing convolution (csrc/sf_tailfold.h)."""
-
-    _fields_ = [("counters", c_void_p), ("scratch", c_void_p), ("scratch_bytes", c_int64), ("Creal", c_int32),
-                ("count", c_float), ("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p),
-                ("running_var", c_void_p), ("momentum", c_float), ("eps", c_float), ("scale", c_void_p), ("shift", c_void_p),
-                ("save_mean", c_void_p), ("save_rstd", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
-                ("inv_loss_scale", c_float), ("dgamma", c_void_p), ("dbeta", c_void_p), ("accumulate", c_int32),
-                ("coef", c_void_p)]
-
-
-BN_FOLD_COUNTERS = 132096   # SF_BN_FOLD_COUNTERS
-
-
 class AttnDesc(Structure):
     """Mirror of ``sf_attn_desc``."""
 
@@ -105,14 +91,10 @@ _SIGNATURES = {
     "sf_prep_weights_batch": (c_int, [_P, _P, _P, c_int32, _P]),
     "sf_conv_fwd_mtiles": (c_int, [POINTER(ConvDesc)]),
     "sf_conv_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _F, _F, c_int, _F, _P, _F, _P]),
-    "sf_bn_fold_scratch_bytes": (c_int64, [c_int32]),
-    "sf_conv_fwd_bn": (c_int, [POINTER(ConvDesc), _P, _P, _F, _F, c_int, _F, _P, _F, POINTER(BnFold), _P]),
     "sf_conv_fwd_fused": (c_int, [POINTER(ConvDesc), _P, _P, _F, _P, c_int32, c_int, _P, _P]),
     "sf_conv_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P, _P]),
     "sf_conv_dgrad_bn": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32,
                                  POINTER(c_int32), _P]),
-    "sf_conv_dgrad_bn_fin": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32,
-                                 POINTER(c_int32), POINTER(BnFold), _P]),
     "sf_conv_wgrad_workspace": (c_int64, [POINTER(ConvDesc)]),
     "sf_conv_wgrad_rowtab_bytes": (c_int64, [POINTER(ConvDesc)]),
     "sf_conv_wgrad_rowtab": (c_int, [POINTER(ConvDesc), _P, _P]),

@@ -5,14 +5,13 @@ shape (N, C, T, H, W) -- the reference's NCTHW convention (slowfast/models/video
 -- whose MEMORY order is N,T,H,W,C with a row pitch ``ld`` (``torch.channels_last_3d`` strides, or a
 channel slice of such a tensor).  Nothing in this file computes on the CPU or through ATen kernels.
 """
-import os
 from ctypes import byref, c_int32
 
 import torch
 
 from . import lib as _sflib
 
-from .lib import BN_FOLD_COUNTERS, BnFold, ConvDesc, SfError, get_lib
+from .lib import ConvDesc, SfError, get_lib
 
 _f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
 
@@ -188,35 +187,8 @@ def _affine(in_affine):
     return scale, shift, int(bool(relu))
 
 
-# In-launch BatchNorm finalize (csrc/sf_tailfold.h): the convolution that produces a BatchNorm's partial sums also folds and
-# finalizes them -- no sf_bn_finalize / sf_bn_bwd_finalize launch.  SF_BN_FOLD=0 keeps the separate launches (A/B runs).
-BN_FOLD = os.environ.get("SF_BN_FOLD", "1") != "0"
-_fold_counters = {}
-
-
-def _fold_resources(device, C):
-    """(ticket counters, fp64 group-row scratch) of sf_conv_fwd_bn / sf_conv_dgrad_bn_fin, or None.  The counters are zeroed
-    ONCE (every launch leaves them zero); one buffer per device because every user is enqueued on the same stream.  They must
-    exist before a graph capture starts (the eager warm-up iteration of step.TrainStep allocates them): a first use during a
-    capture would put the zero-fill into the graph, so that call keeps the separate finalize launch instead."""
-    cnt = _fold_counters.get(device)
-    if cnt is None:
-        if _capturing(device):
-            return None
-        cnt = _fold_counters[device] = torch.zeros(BN_FOLD_COUNTERS, dtype=torch.int32, device=device)
-    nbytes = get_lib().call("sf_bn_fold_scratch_bytes", C)
-    ws = _workspaces.get((device, "bnfold"))
-    if (ws is None or ws.numel() < nbytes) and _capturing(device):
-        return None
-    return cnt, _workspace(device, nbytes, "bnfold")
-
-
-def conv_fwd(x, wf, geom, in_affine=None, bias=None, stats=True, out=None, bn_fold=None):
-    """y = conv3d(act(x)); returns (y, stat_part or None).  act = producer BN(+ReLU) applied on the fly.
-
-    ``bn_fold = dict(gamma, beta, running_mean, running_var, momentum, eps, count)`` (training-mode BatchNorm behind this
-    convolution): the launch also finalizes the statistics; returns (y, stat_part, state) with state = (scale, shift, mean,
-    rstd), or None when this geometry keeps the separate pass (the caller then runs bn_finalize on stat_part)."""
+def conv_fwd(x, wf, geom, in_affine=None, bias=None, stats=True, out=None):
+    """y = conv3d(act(x)); returns (y, stat_part or None).  act = producer BN(+ReLU) applied on the fly."""
     assert tuple(x.shape) == geom.in_shape, (x.shape, geom.in_shape)
     ldx = cl_ld(x)
     y = cl_empty(geom.out_shape, x.device) if out is None else out
@@ -228,29 +200,9 @@ def conv_fwd(x, wf, geom, in_affine=None, bias=None, stats=True, out=None, bn_fo
         mt = lib.call("sf_conv_fwd_mtiles", byref(d))
         part = torch.empty((mt, 2, geom.Co), dtype=torch.float32, device=x.device)
     sc, sh, relu = _affine(in_affine)
-    if bn_fold is not None:
-        assert stats
-        res = _fold_resources(x.device, geom.Co) if BN_FOLD else None
-        state = None
-        if res is not None:
-            cnt, ws = res
-            C = geom.Co
-            st = tuple(torch.empty(C, dtype=torch.float32, device=x.device) for _ in range(4))
-            f = BnFold(counters=cnt.data_ptr(), scratch=ws.data_ptr(), scratch_bytes=ws.numel(),
-                       Creal=bn_fold["gamma"].numel(), count=float(bn_fold["count"]), gamma=bn_fold["gamma"].data_ptr(),
-                       beta=bn_fold["beta"].data_ptr(), running_mean=_ptr(bn_fold.get("running_mean")),
-                       running_var=_ptr(bn_fold.get("running_var")), momentum=float(bn_fold["momentum"]),
-                       eps=float(bn_fold["eps"]), scale=st[0].data_ptr(), shift=st[1].data_ptr(), save_mean=st[2].data_ptr(),
-                       save_rstd=st[3].data_ptr())
-            rc = lib.call("sf_conv_fwd_bn", byref(d), x.data_ptr(), wf.data_ptr(), _ptr(sc), _ptr(sh), relu, _ptr(bias),
-                          y.data_ptr(), part.data_ptr(), byref(f), _stream(x),
-                          work=geom.work(reads_x=1, reads_y=0, writes_y=1))
-            if rc == 1:
-                state = st
-            return y, part, state
     lib.call("sf_conv_fwd", byref(d), x.data_ptr(), wf.data_ptr(), _ptr(sc), _ptr(sh), relu, _ptr(bias),
              y.data_ptr(), _ptr(part), _stream(x), work=geom.work(reads_x=1, reads_y=0, writes_y=1))
-    return (y, part, None) if bn_fold is not None else (y, part)
+    return y, part
 
 
 def conv_fwd_fused(x, wf, geom, bias=None, resid=None, relu=False, out=None):

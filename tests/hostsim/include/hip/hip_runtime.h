@@ -333,13 +333,6 @@ inline void hipsim_global_load_lds16(const void* gptr, void* lds_base) {
 #define SF_BARRIER_KEEP_VMEM() __syncthreads()
 #define SF_KEEP_ALIVE(x) ((void)(x))
 #define SF_SCALAR_PTR(T, p) ((const T*)(p))
-// agent-scope accessors of sf_tailfold.h: blocks run on several host threads, so these are real atomics
-template <typename T> inline T hipsim_agent_load(const T* p) { T v; __atomic_load(const_cast<T*>(p), &v, __ATOMIC_ACQUIRE); return v; }
-template <typename T, typename U> inline void hipsim_agent_store(T* p, U v) { T t = (T)v; __atomic_store(p, &t, __ATOMIC_RELEASE); }
-#define SF_AGENT_LOAD(p) hipsim_agent_load(p)
-#define SF_AGENT_STORE(p, v) hipsim_agent_store((p), (v))
-#define SF_AGENT_FETCH_ADD(p, v) __atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL)
-#define SF_DRAIN_VMEM() ((void)0)
 
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

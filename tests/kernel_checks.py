@@ -172,53 +172,6 @@ def check_conv_dgrad_bn(device, in_shape, Co, k, p, d=(1, 1, 1), resid=False, se
     return part.shape[0]
 
 
-def check_conv_fwd_bn_fold(device, in_shape, Co, k, s, p, d=(1, 1, 1), Creal=None, track=True, seed=0, expect=True):
-    """In-launch statistics finalize (ops.conv_fwd(..., bn_fold=...), csrc/sf_tailfold.h) against the separate pass it
-    replaces (sf_conv_fwd + sf_bn_finalize on the same partial table): scale / shift / mean / rstd and the running
-    statistics agree to fp32 round-off of the two summation orders, the ticket counters are back to zero, and a second launch
-    on the same counters gives the same bits (deterministic whoever arrives last)."""
-    x, w = make_conv_case(seed, in_shape, Co, k, s, p, d)
-    geom = ops.ConvGeom(in_shape, Co, k, s, p, d)
-    wf, _ = ops.prep_weights(w.to(device), geom)
-    xd = host_to_cl(x, device)
-    g = torch.Generator().manual_seed(seed + 1)
-    Cr = Creal or geom.Co
-    gamma = (torch.rand(Cr, generator=g) + 0.5).to(device)
-    beta = torch.randn(Cr, generator=g).to(device)
-    rm0, rv0 = torch.randn(Cr, generator=g).to(device), (torch.rand(Cr, generator=g) + 0.5).to(device)
-    count = geom.out_rows
-
-    def fold_run():
-        rm, rv = rm0.clone(), rv0.clone()
-        y, part, st = ops.conv_fwd(xd, wf, geom, stats=True, bn_fold=dict(
-            gamma=gamma, beta=beta, running_mean=rm if track else None, running_var=rv if track else None, momentum=0.1,
-            eps=1e-5, count=count))
-        return y, part, st, rm, rv
-
-    y1, part1, st1, rm1, rv1 = fold_run()
-    assert (st1 is not None) == expect, "in-launch fold %s for this geometry" % ("expected" if expect else "not expected")
-    if st1 is None:
-        return None
-    rm2, rv2 = rm0.clone(), rv0.clone()
-    y2, part2 = ops.conv_fwd(xd, wf, geom, stats=True)
-    assert torch.equal(y1, y2) and torch.equal(part1, part2)
-    st2 = ops.bn_finalize(part2, count, gamma, beta, rm2 if track else None, rv2 if track else None, 0.1, 1e-5,
-                          training=True, C=geom.Co)
-    worst = 0.0
-    for name, a, b in zip(("scale", "shift", "mean", "rstd"), st1, st2):
-        worst = max(worst, assert_close("fold " + name, a.cpu(), b.cpu(), 2e-6))
-    if track:
-        worst = max(worst, assert_close("fold running_mean", rm1.cpu(), rm2.cpu(), 2e-6))
-        worst = max(worst, assert_close("fold running_var", rv1.cpu(), rv2.cpu(), 2e-6))
-    cnt = ops._fold_counters[xd.device]
-    assert int(cnt.abs().sum()) == 0, "ticket counters must be re-armed by the launch"
-    _, _, st3, rm3, _ = fold_run()
-    for a, b in zip(st1, st3):
-        assert torch.equal(a, b), "the in-launch fold must be deterministic"
-    assert int(cnt.abs().sum()) == 0
-    return worst
-
-
 def check_conv_wgrad(device, in_shape, Co, k, s, p, d=(1, 1, 1), Cw=None, affine=False, out_scale=1.0, seed=0):
     x, w = make_conv_case(seed, in_shape, Co, k, s, p, d, Cw)
     geom = ops.ConvGeom(in_shape, Co, k, s, p, d, Cw=Cw)

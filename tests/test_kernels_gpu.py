@@ -252,19 +252,3 @@ def test_conv_dgrad_fused_bn_reduce(gpu):
     kc.check_conv_dgrad_bn(gpu, (4, 8, 32, 56, 56), 32, (1, 1, 1), (0, 0, 0))                       # Fast pathway c
     kc.check_conv_dgrad_bn(gpu, (4, 8, 32, 56, 56), 8, (1, 3, 3), (0, 1, 1))
     kc.check_conv_dgrad_bn(gpu, (4, 16, 32, 28, 28), 64, (1, 1, 1), (0, 0, 0), resid=True)
-
-
-@pytest.mark.gpu
-def test_conv_fwd_bn_fold_in_launch(gpu):
-    """BatchNorm statistics finalized inside the producing convolution (csrc/sf_tailfold.h; agent-scope tickets + write-through
-    partial rows across XCDs) == sf_conv_fwd + sf_bn_finalize on SlowFast-R50 geometries, batch 4: pointwise layers (round-1
-    kernel, 784 / 196 M tiles), igemm2 layers (two table rows per 256-row tile), 16 column tiles, the Fast pathway's widths."""
-    kc.check_conv_fwd_bn_fold(gpu, (4, 64, 8, 56, 56), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0))         # res2 c: 784 tiles, 28 groups
-    kc.check_conv_fwd_bn_fold(gpu, (4, 64, 8, 56, 56), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))          # res2 b: igemm2
-    kc.check_conv_fwd_bn_fold(gpu, (4, 1024, 8, 14, 14), 256, (3, 1, 1), (1, 1, 1), (1, 0, 0))       # res4 a: igemm2, 2 column tiles
-    kc.check_conv_fwd_bn_fold(gpu, (4, 512, 8, 7, 7), 2048, (1, 1, 1), (1, 1, 1), (0, 0, 0))         # res5 c: 16 column tiles
-    kc.check_conv_fwd_bn_fold(gpu, (4, 8, 32, 56, 56), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0))          # Fast pathway c
-    kc.check_conv_fwd_bn_fold(gpu, (4, 32, 32, 56, 56), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0))          # Fast pathway a
-    kc.check_conv_fwd_bn_fold(gpu, (32, 320, 8, 56, 56), 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), seed=3)   # res3 a at batch 32: 6272 tiles
-    for seed in range(4):        # uneven arrival orders: repeated launches must agree bit for bit (checked inside)
-        kc.check_conv_fwd_bn_fold(gpu, (8, 256, 8, 14, 14), 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), seed=seed)

@@ -148,20 +148,3 @@ def test_conv_dgrad_fused_bn_reduce(sim, monkeypatch):
     monkeypatch.setenv("SF_IGEMM2_MINROWS", "64")
     assert kc.check_conv_dgrad_bn(sim, (2, 64, 2, 9, 9), 64, (1, 3, 3), (0, 1, 1)) == 2            # igemm2: 324 rows / 256
     kc.check_conv_dgrad_bn(sim, (2, 64, 2, 8, 8), 128, (1, 1, 1), (0, 0, 0), resid=True)
-
-
-def test_conv_fwd_bn_fold_in_launch(sim, monkeypatch):
-    """BatchNorm statistics finalized inside the producing convolution (csrc/sf_tailfold.h) == sf_conv_fwd + sf_bn_finalize:
-    both implicit-GEMM generations, one and several groups of M tiles, several column tiles, ragged last tiles, channel padding,
-    with the simulator's workgroups running on several host threads (the tickets are real atomics there)."""
-    monkeypatch.setenv("SF_SIM_THREADS", "4")
-    kc.check_conv_fwd_bn_fold(sim, (2, 16, 2, 5, 5), 32, (1, 1, 1), (1, 1, 1), (0, 0, 0))            # one M tile, one group
-    kc.check_conv_fwd_bn_fold(sim, (2, 32, 4, 12, 12), 64, (1, 1, 1), (1, 1, 1), (0, 0, 0))          # 9 tiles -> 3 groups of 3
-    kc.check_conv_fwd_bn_fold(sim, (3, 16, 3, 11, 13), 136, (1, 3, 3), (1, 1, 1), (0, 1, 1))         # 11 tiles (ragged), 2 column tiles
-    kc.check_conv_fwd_bn_fold(sim, (2, 16, 2, 9, 9), 24, (1, 1, 1), (1, 1, 1), (0, 0, 0), Creal=20)  # zero-padded channels
-    kc.check_conv_fwd_bn_fold(sim, (2, 16, 2, 9, 9), 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), track=False)
-    kc.check_conv_fwd_bn_fold(sim, (1, 8, 2, 18, 16), 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), expect=False)   # thin3 direct conv: separate pass
-    monkeypatch.setenv("SF_IGEMM2_MINK", "64")
-    monkeypatch.setenv("SF_IGEMM2_MINROWS", "64")
-    kc.check_conv_fwd_bn_fold(sim, (2, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))             # igemm2: 2 tiles, 3 table rows
-    kc.check_conv_fwd_bn_fold(sim, (3, 64, 4, 12, 12), 192, (1, 1, 1), (1, 1, 1), (0, 0, 0))          # igemm2: 7 tiles, 3 groups, 2 column tiles
