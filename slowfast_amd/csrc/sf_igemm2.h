@@ -206,18 +206,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
                 for (int j = 0; j < TN; ++j) SF_KEEP_ALIVE(bf[j]);
                 continue;
             }
-            if (p.ablate & 64) __builtin_amdgcn_s_setprio(1);      // experiment: priority around the MFMA cluster (guide T5)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = SF_MFMA16(af[i], bf[j], acc[i][j]);
-            if (p.ablate & 64) __builtin_amdgcn_s_setprio(0);
         }
     };
 
     // ---- main loop: stages ks + 1 (and ks + 2 at NST == 3) are in flight while stage ks is multiplied
-    if ((p.ablate & 32) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);     // experiment: static priority for the younger half (T5 static form)
     {
         // copies one wave issues per stage: the count s_waitcnt vmcnt leaves outstanding (uniform over the waves whenever
         // NBI % NW == 0; a partial last round only makes some waves wait for one copy more than necessary)
