@@ -4,6 +4,7 @@
 #include "sf_common.h"
 #include "sf_igemm.h"
 #include "sf_igemm2.h"
+#include "sf_igemm3.h"
 #include "sf_wgrad2.h"
 #include "sf_pool.h"
 #include "sf_dwconv.h"
@@ -196,6 +197,19 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     // lost on both models: SlowFast 766.5 -> 741 clips/s on every eligible layer, 755 restricted to grids of >= 512 tiles,
     // MViTv2-S 590.9 -> 584 / 588; profiles/r4_v6_knobs_ab.txt.  The same tile on a 16-wave workgroup (64 x 64 wave tiles, four
     // waves per SIMD kept) moved no layer either: profiles/r4_v11_igemm2_fat_ab.txt.  Both removed.)
+    // third generation (sf_igemm3.h, 256 x 256 x 64 eight-phase ping-pong): EXPERIMENT, SF_IGEMM3=<min tiles> switches it on
+    {
+        const int i3_min = (e = getenv("SF_IGEMM3")) ? atoi(e) : 0;
+        const int i3_minn = (e = getenv("SF_IGEMM3_MINN")) ? atoi(e) : 192;
+        const int t3 = cdiv(q.M, 256) * cdiv(q.Nout, 256);
+        if (i3_min > 0 && q.C % 64 == 0 && q.Nout >= i3_minn && t3 >= i3_min) {
+            q.ntiles_n = cdiv(q.Nout, 256);
+            if (trace) fprintf(stderr, "[sfamd] igemm3: %d tiles\n", t3);
+            if (q.f32.out) hipLaunchKernelGGL((sf_igemm3_kernel<true>), dim3((unsigned)t3), dim3(512), 0, s, q);
+            else hipLaunchKernelGGL((sf_igemm3_kernel<false>), dim3((unsigned)t3), dim3(512), 0, s, q);
+            return;
+        }
+    }
     if (q.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }
     else if (q.Nout > 32) { if (bk64) launch_igemm2<64, 64>(q, s); else launch_igemm2<64, 32>(q, s); }
     else launch_igemm2<32, 32>(q, s);

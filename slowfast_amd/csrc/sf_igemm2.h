@@ -79,6 +79,163 @@ __device__ __forceinline__ int i2_lds_off(int row, int kslot) {
     else return lds_tile_off(row, kslot);
 }
 
+// Epilogue shared by the second-generation kernels (sf_igemm2_kernel, sf_igemm3_kernel): alpha / bias, fp32 side rows, BatchNorm
+// partial statistics from the accumulators, the tile staged through LDS (the operand stages are dead by now; the caller has
+// passed the workgroup barrier that ends its K loop) and stored in 16-byte row-contiguous pieces with residual (+ bit mask), GELU
+// epilogues, the fused BatchNorm-backward reduction.  acc[i][j] = rows wm * WM + i * 16 .., columns wn * WN + j * 16 .. of the tile.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool F32R>
+__device__ __forceinline__ void i2_epilogue(const Igemm2Params& p, f32x4 (&acc)[BM / WAVES_M / 16][BN / WAVES_N / 16], f16* smem,
+                                            float (*s_red)[2][BN], int* s_orow, int mt, int nt) {
+    constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int STG_LD = BN + 8;
+    constexpr int HALVES = BM / 128, WPH = WAVES_M / HALVES;
+    static_assert(WAVES_M % HALVES == 0, "a wave row belongs to one 128-row group");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = mt * BM, n0 = nt * BN;
+    // ---------------- epilogue: scale, bias, BatchNorm partial statistics (fp32, from the accumulators)
+    {
+        const float alpha = p.alpha != 0.f ? p.alpha : 1.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int colj = n0 + wn * WN + j * 16 + (lane & 15);
+            const float b = (p.bias && colj < p.Nout) ? p.bias[colj] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha + b;
+        }
+    }
+    if constexpr (F32R) f32_rows_epilogue<TM, TN>(acc, p.f32, m0 + wm * WM, n0 + wn * WN, p.M, p.Nout, p.resid, p.ldr, p.resid_row0);
+    if (p.stat_part) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool rowok = m0 + wm * WM + i * 16 + 4 * (lane >> 4) + r < p.M;
+                    const float v = rowok ? acc[i][j][r] : 0.f;
+                    s += v;
+                    q += v * v;
+                }
+            s = wave_sum_over_row_groups(s);
+            q = wave_sum_over_row_groups(q);
+            if (lane < 16) {
+                s_red[wm][0][wn * WN + j * 16 + lane] = s;
+                s_red[wm][1][wn * WN + j * 16 + lane] = q;
+            }
+        }
+    }
+    f16* stg = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * WN + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * WM + i * 16 + 4 * (lane >> 4) + r;
+                stg[row * STG_LD + col] = (f16)acc[i][j][r];
+            }
+        }
+    __syncthreads();
+    if (p.stat_part && tid < HALVES * BN) {
+        const int half = tid / BN, c = tid % BN;
+        const int col = n0 + c;
+        const int prow = mt * HALVES + half;                        // statistics rows are 128 positions each
+        if (col < p.Nout && (int64_t)prow * 128 < p.M) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPH; ++w) {
+                s += s_red[half * WPH + w][0][c];
+                q += s_red[half * WPH + w][1][c];
+            }
+            p.stat_part[((int64_t)prow * 2 + 0) * p.Nout + col] = s;
+            p.stat_part[((int64_t)prow * 2 + 1) * p.Nout + col] = q;
+        }
+    }
+    constexpr int CG = BN / 8;
+    static_assert(NT % CG == 0 && 64 % CG == 0, "a thread keeps one column group over the whole store loop");
+    const bool bnb = p.bnb_part != nullptr;
+    float bsg[8], bsgy[8], bsc[8], bsh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
+    if (bnb && p.bnb_y && !p.bnb_bits && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
+    constexpr int ITER = BM * CG / NT;
+    static_assert(BM * CG % NT == 0 && ITER >= 1, "whole store iterations");
+    constexpr int CH = ITER < 2 ? ITER : 2;
+    static_assert(ITER % CH == 0, "whole chunks");
+    const int ecg = tid % CG, ecol = n0 + ecg * 8;
+    for (int it0 = 0; it0 < ITER; it0 += CH) {
+        EpiLoads L[CH];
+        bool ok[CH], rok[CH];
+        int mo[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int idx = tid + (it0 + u) * NT;
+            const int row = idx / CG, mr = m0 + row;
+            ok[u] = mr < p.M && ecol < p.Nout;
+            const int m = ok[u] ? (p.omap ? s_orow[row] : mr) : 0;
+            mo[u] = m;
+            rok[u] = ok[u] && p.resid && m >= p.resid_row0;
+            if constexpr (F32R) {
+                uint32_t srow;
+                if (f32_row(p.f32, m, srow)) rok[u] = false;               // residual already inside the staged value
+            }
+            L[u].rbits = 0xffu; L[u].bbits = 0u;
+            if (rok[u]) {
+                L[u].r = ld16(p.resid + (int64_t)m * p.ldr + ecol);
+                if (p.resid_bits) L[u].rbits = p.resid_bits[(int64_t)m * (p.Nout >> 3) + (ecol >> 3)];
+            }
+            if (ok[u] && bnb && p.bnb_y) {
+                L[u].y = ld16(p.bnb_y + (int64_t)m * p.bnb_ld + ecol);
+                if (p.bnb_bits) L[u].bbits = p.bnb_bits[(int64_t)m * (p.Nout >> 3) + (ecol >> 3)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (!ok[u]) continue;
+            const int idx = tid + (it0 + u) * NT;
+            const int row = idx / CG, m = mo[u];
+            f16x8 v = ld16(stg + row * STG_LD + ecg * 8);
+            if (rok[u]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const f16 r = ((L[u].rbits >> e) & 1u) ? L[u].r[e] : (f16)0.f;
+                    v[e] = (f16)((float)v[e] + (float)r);
+                }
+            }
+            if (p.act_mode == 2) {
+                const f16x8 h = ld16(p.act_aux + (int64_t)m * p.ld_aux + ecol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * gelu_df((float)h[e]));
+            }
+            if (p.act_mode == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > (f16)0.f ? v[e] : (f16)0.f;
+            }
+            st16(p.y + (int64_t)m * p.ldy + ecol, v);
+            if (p.act_mode == 1) {
+                f16x8 a;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
+                st16(p.act_aux + (int64_t)m * p.ld_aux + ecol, a);
+            }
+            if (bnb && p.bnb_y) bnb_accumulate(v, L[u].y, bsc, bsh, bsg, bsgy, p.bnb_bits != nullptr, L[u].bbits);
+            else if (bnb) {                 // plain column sums of the stored tile (bias gradient of the consumer Linear)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsg[e] += (float)v[e];
+            }
+        }
+    }
+    if (bnb) bnb_reduce_store<NW, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);
+}
+
 // Tried in round 3 and removed again (the code is in the history, commits c9ff12f / 6f38f0a; evidence under profiles/):
 //  * a STRIP variant -- ONE staged strip of source rows per channel chunk serves every tap, a tap is a row offset into it,
 //    padding is masked in the fragment: 6x fewer gathered bytes on 3x3 layers, and 15-30 % SLOWER on every eligible layer
@@ -244,142 +401,5 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
         if (p.ablate & 8) return;
     }
 
-    // ---------------- epilogue: scale, bias, BatchNorm partial statistics (fp32, from the accumulators)
-    {
-        const float alpha = p.alpha != 0.f ? p.alpha : 1.f;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int colj = n0 + wn * WN + j * 16 + (lane & 15);
-            const float b = (p.bias && colj < p.Nout) ? p.bias[colj] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha + b;
-        }
-    }
-    if constexpr (F32R) f32_rows_epilogue<TM, TN>(acc, p.f32, m0 + wm * WM, n0 + wn * WN, p.M, p.Nout, p.resid, p.ldr, p.resid_row0);
-    if (p.stat_part) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool rowok = m0 + wm * WM + i * 16 + 4 * (lane >> 4) + r < p.M;
-                    const float v = rowok ? acc[i][j][r] : 0.f;
-                    s += v;
-                    q += v * v;
-                }
-            s = wave_sum_over_row_groups(s);
-            q = wave_sum_over_row_groups(q);
-            if (lane < 16) {
-                s_red[wm][0][wn * WN + j * 16 + lane] = s;
-                s_red[wm][1][wn * WN + j * 16 + lane] = q;
-            }
-        }
-    }
-    f16* stg = smem;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = wn * WN + j * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * WM + i * 16 + 4 * (lane >> 4) + r;
-                stg[row * STG_LD + col] = (f16)acc[i][j][r];
-            }
-        }
-    __syncthreads();
-    if (p.stat_part && tid < HALVES * BN) {
-        const int half = tid / BN, c = tid % BN;
-        const int col = n0 + c;
-        const int prow = mt * HALVES + half;                        // statistics rows are 128 positions each
-        if (col < p.Nout && (int64_t)prow * 128 < p.M) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WPH; ++w) {
-                s += s_red[half * WPH + w][0][c];
-                q += s_red[half * WPH + w][1][c];
-            }
-            p.stat_part[((int64_t)prow * 2 + 0) * p.Nout + col] = s;
-            p.stat_part[((int64_t)prow * 2 + 1) * p.Nout + col] = q;
-        }
-    }
-    constexpr int CG = BN / 8;
-    static_assert(NT % CG == 0 && 64 % CG == 0, "a thread keeps one column group over the whole store loop");
-    const bool bnb = p.bnb_part != nullptr;
-    float bsg[8], bsgy[8], bsc[8], bsh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { bsg[e] = 0.f; bsgy[e] = 0.f; bsc[e] = 1.f; bsh[e] = 0.f; }
-    if (bnb && p.bnb_y && !p.bnb_bits && n0 + (tid % CG) * 8 < p.Nout) { load8f(p.bnb_scale + n0 + (tid % CG) * 8, bsc); load8f(p.bnb_shift + n0 + (tid % CG) * 8, bsh); }
-    constexpr int ITER = BM * CG / NT;
-    static_assert(BM * CG % NT == 0 && ITER >= 1, "whole store iterations");
-    constexpr int CH = ITER < 2 ? ITER : 2;
-    static_assert(ITER % CH == 0, "whole chunks");
-    const int ecg = tid % CG, ecol = n0 + ecg * 8;
-    for (int it0 = 0; it0 < ITER; it0 += CH) {
-        EpiLoads L[CH];
-        bool ok[CH], rok[CH];
-        int mo[CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int idx = tid + (it0 + u) * NT;
-            const int row = idx / CG, mr = m0 + row;
-            ok[u] = mr < p.M && ecol < p.Nout;
-            const int m = ok[u] ? (p.omap ? s_orow[row] : mr) : 0;
-            mo[u] = m;
-            rok[u] = ok[u] && p.resid && m >= p.resid_row0;
-            if constexpr (F32R) {
-                uint32_t srow;
-                if (f32_row(p.f32, m, srow)) rok[u] = false;               // residual already inside the staged value
-            }
-            L[u].rbits = 0xffu; L[u].bbits = 0u;
-            if (rok[u]) {
-                L[u].r = ld16(p.resid + (int64_t)m * p.ldr + ecol);
-                if (p.resid_bits) L[u].rbits = p.resid_bits[(int64_t)m * (p.Nout >> 3) + (ecol >> 3)];
-            }
-            if (ok[u] && bnb && p.bnb_y) {
-                L[u].y = ld16(p.bnb_y + (int64_t)m * p.bnb_ld + ecol);
-                if (p.bnb_bits) L[u].bbits = p.bnb_bits[(int64_t)m * (p.Nout >> 3) + (ecol >> 3)];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            if (!ok[u]) continue;
-            const int idx = tid + (it0 + u) * NT;
-            const int row = idx / CG, m = mo[u];
-            f16x8 v = ld16(stg + row * STG_LD + ecg * 8);
-            if (rok[u]) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const f16 r = ((L[u].rbits >> e) & 1u) ? L[u].r[e] : (f16)0.f;
-                    v[e] = (f16)((float)v[e] + (float)r);
-                }
-            }
-            if (p.act_mode == 2) {
-                const f16x8 h = ld16(p.act_aux + (int64_t)m * p.ld_aux + ecol);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * gelu_df((float)h[e]));
-            }
-            if (p.act_mode == 3) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > (f16)0.f ? v[e] : (f16)0.f;
-            }
-            st16(p.y + (int64_t)m * p.ldy + ecol, v);
-            if (p.act_mode == 1) {
-                f16x8 a;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = (f16)gelu_f((float)v[e]);
-                st16(p.act_aux + (int64_t)m * p.ld_aux + ecol, a);
-            }
-            if (bnb && p.bnb_y) bnb_accumulate(v, L[u].y, bsc, bsh, bsg, bsgy, p.bnb_bits != nullptr, L[u].bbits);
-            else if (bnb) {                 // plain column sums of the stored tile (bias gradient of the consumer Linear)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bsg[e] += (float)v[e];
-            }
-        }
-    }
-    if (bnb) bnb_reduce_store<NW, CG>(bsg, bsgy, reinterpret_cast<float*>(smem), p.bnb_part + (int64_t)mt * 2 * p.Nout, n0, p.Nout);
+    i2_epilogue<BM, BN, WAVES_M, WAVES_N, F32R>(p, acc, smem, s_red, s_orow, mt, nt);
 }

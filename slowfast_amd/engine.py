@@ -184,6 +184,66 @@ def join_side_streams():
         torch.cuda.current_stream(device).wait_stream(_side_streams[device])
     _side_pending.clear()
     _side_keep.clear()
+    for device in {d for d, _ in _pathway_streams}:
+        _join_pathways(device)
+
+
+# Independent PATHWAYS on their own HIP streams (round 5).  Between two lateral connections the Slow and the Fast pathway of a
+# SlowFast stage do not depend on each other (slowfast/models/video_model_builder.py:423-441: s_i runs every pathway, s_i_fuse
+# joins them), in forward and in backward.  Issued on ONE stream their kernels run back to back: the Slow pathway's MFMA-bound
+# convolutions leave a quarter of the CUs idle (196 / 392 tiles on 256 CUs at batch 32) and every kernel pays its own fill and
+# drain, the Fast pathway's kernels are thin HBM streams.  Forked onto a second stream the two interleave on the chip -- as
+# graph BRANCHES under a captured step -- and fill each other's holes: SlowFast-8x8-R50 41.4 -> 38.7 ms per step
+# (profiles/r5_v4_pathway_streams.txt; the per-pair probe of round 2 had predicted 7 %).  run_pathways() forks before and joins
+# after a stage; autograd runs every backward node on the stream of its forward, so the backward forks and joins by itself.
+# Rules that keep it exact: scratch memory is per stream (ops._workspace), parameter-gradient consumers join every stream first
+# (join_side_streams), tensors that cross a fork / join stay referenced by autograd until their consumers are enqueued.
+# SF_PATHWAY_STREAMS=0: one stream (A/B runs).
+PATHWAY_STREAMS = os.environ.get("SF_PATHWAY_STREAMS", "1") != "0"
+_pathway_streams = {}    # (device, pathway) -> stream
+_pathway_main = {}       # device -> the stream the last fork left from
+
+
+def _pathway_stream(device, p):
+    s = _pathway_streams.get((device, p))
+    if s is None:
+        s = _pathway_streams[(device, p)] = torch.cuda.Stream(device=device)
+    return s
+
+
+def run_pathways(n, fn, like):
+    """[fn(p) for p in range(n)] -- pathway 0 on the current stream, pathways 1 .. n-1 each on its own side stream, forked after
+    everything already enqueued on the current stream and joined before this returns.  ``like``: a tensor that tells the device
+    (CPU tensors / one pathway / SF_PATHWAY_STREAMS=0: a plain loop)."""
+    if not (PATHWAY_STREAMS and n > 1 and like.is_cuda):
+        return [fn(p) for p in range(n)]
+    dev = like.device
+    main = torch.cuda.current_stream(dev)
+    _pathway_main[dev] = main
+    outs = [None] * n
+    sides = []
+    for p in range(1, n):
+        side = _pathway_stream(dev, p)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            outs[p] = fn(p)
+        sides.append(side)
+    outs[0] = fn(0)
+    for side in sides:
+        main.wait_stream(side)
+    return outs
+
+
+def _join_pathways(device):
+    """The CURRENT stream of ``device`` waits for every pathway stream and for the stream they were forked from: whatever it
+    enqueues next (a gradient all-reduce, an optimizer pass) sees the gradients of all pathways."""
+    cur = torch.cuda.current_stream(device)
+    for (d, _), s in _pathway_streams.items():
+        if d == device and s != cur:
+            cur.wait_stream(s)
+    main = _pathway_main.get(device)
+    if main is not None and main != cur:
+        cur.wait_stream(main)
 
 
 # Test hook: when a list, every Function with a ReLU or a max-pool appends the tensors that decide its backward routing (raw conv
@@ -227,7 +287,7 @@ def _always():
 def _notify(params):
     if GRADS_VIA_AUTOGRAD:          # the consumer of the gradients (DDP's reducer) hooks autograd itself
         return
-    if _side_pending and any(getattr(fn, "needs_join", _always)() for fn in _listeners):
+    if (_side_pending or _pathway_streams) and any(getattr(fn, "needs_join", _always)() for fn in _listeners):
         join_side_streams()         # a listener is about to start the all-reduce of these gradients: they must be complete
     if _sub_passes > 1:
         final = []

@@ -285,7 +285,10 @@ def _workspace(device, nbytes, key=None):
     allocator): a graph captured earlier keeps writing its split-K partials into memory that is still reserved for
     exactly that, instead of into whatever tensor the allocator would have placed there.  Growth happens a handful of
     times per process (the largest layer geometry wins), so the retained memory is bounded by ~2x the final size."""
-    k = (device, key)           # launches on different streams (engine.WGRAD_STREAM) must not share scratch memory
+    # launches on different streams (engine.run_pathways, engine.WGRAD_STREAM) must not share scratch memory: one buffer per
+    # (device, stream) -- a captured graph bakes the stream's buffer into its branch
+    sid = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    k = (device, key, sid)
     ws = _workspaces.get(k)
     if ws is None or ws.numel() < nbytes:
         if ws is not None:
@@ -339,6 +342,8 @@ def _wgrad_rowtab(geom, d, device):
         get_lib().call("sf_conv_wgrad_rowtab", byref(d), tab.data_ptr(), _stream(tab))
         if _capturing(device):
             return tab                  # lives in the graph's pool, rebuilt by every replay: never shared through the cache
+        if device.type == "cuda":       # the cached table is read from OTHER streams too (engine.run_pathways): complete it first
+            torch.cuda.current_stream(device).synchronize()     # (once per geometry, during the eager warm-up iteration)
         _rowtabs[key] = tab
     return _rowtabs[key]
 

@@ -4,7 +4,7 @@ the fully fused schedule of engine.ResBlockFn; ``BottleneckTransform`` on its ow
 three conv+BN units materialised."""
 import torch.nn as nn
 
-from .engine import ConvBNActFn, ConvUnit, ResBlockFn, as_cl
+from .engine import ConvBNActFn, ConvUnit, ResBlockFn, as_cl, run_pathways
 
 
 class BottleneckTransform(nn.Module):
@@ -181,21 +181,21 @@ class ResStage(nn.Module):
                                              norm_module=norm_module))
 
     def forward(self, inputs):
-        out = []
-        for p in range(self.num_pathways):
-            x = inputs[p]
-            for i in range(self.num_blocks[p]):
-                x = getattr(self, f"pathway{p}_res{i}")(x)
-                nln = getattr(self, f"pathway{p}_nonlocal{i}", None)
-                if nln is not None:
-                    g = self.nonlocal_group[p]
-                    if g > 1:
-                        # fold T into the batch around the block (resnet_helper.py:706-723); channels-last memory is
-                        # N,T,H,W,C, so both folds are views of the same rows
-                        b, c, t, h, w = x.shape
-                        x = _fold_time(x, b * g, t // g)
-                        x = _fold_time(nln(x), b, t)
-                    else:
-                        x = nln(x)
-            out.append(x)
-        return out
+        # the pathways of a stage are independent: each on its own stream (engine.run_pathways)
+        return run_pathways(self.num_pathways, lambda p: self._pathway(p, inputs[p]), inputs[0])
+
+    def _pathway(self, p, x):
+        for i in range(self.num_blocks[p]):
+            x = getattr(self, f"pathway{p}_res{i}")(x)
+            nln = getattr(self, f"pathway{p}_nonlocal{i}", None)
+            if nln is not None:
+                g = self.nonlocal_group[p]
+                if g > 1:
+                    # fold T into the batch around the block (resnet_helper.py:706-723); channels-last memory is
+                    # N,T,H,W,C, so both folds are views of the same rows
+                    b, c, t, h, w = x.shape
+                    x = _fold_time(x, b * g, t // g)
+                    x = _fold_time(nln(x), b, t)
+                else:
+                    x = nln(x)
+        return x

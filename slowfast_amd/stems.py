@@ -4,7 +4,7 @@ conv -> [BN statistics in the conv epilogue] -> BN+ReLU+MaxPool in one pass (eng
 import torch.nn as nn
 
 from . import ops
-from .engine import ConvUnit, StemConvUnit, StemFn
+from .engine import ConvUnit, StemConvUnit, StemFn, run_pathways
 
 
 class ResNetBasicStem(nn.Module):
@@ -66,4 +66,4 @@ class VideoModelStem(nn.Module):
 
     def forward(self, x):
         assert len(x) == self.num_pathways, f"Input tensor does not contain {self.num_pathways} pathway"
-        return [getattr(self, f"pathway{i}_stem")(x[i]) for i in range(self.num_pathways)]
+        return run_pathways(self.num_pathways, lambda i: getattr(self, f"pathway{i}_stem")(x[i]), x[0])

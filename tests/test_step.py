@@ -285,6 +285,25 @@ def test_graph_replay_with_poisoned_allocations(gpu, name):
         assert torch.equal(a, b) and torch.equal(a, c)
 
 
+@pytest.mark.gpu
+def test_pathway_streams_do_not_change_the_step(gpu, monkeypatch):
+    """engine.run_pathways (Slow / Fast pathway of every stage on two HIP streams, graph branches under capture): four training
+    steps give the same losses and the same parameters BIT FOR BIT as the single-stream run -- eagerly, as one captured graph and
+    as segmented backward graphs, repeatedly (a race between the streams -- shared scratch memory, a join that is missing --
+    shows as a run that differs)."""
+    from slowfast_amd import engine
+    monkeypatch.setattr(engine, "PATHWAY_STREAMS", False)
+    l0, p0, _, _ = _run_model(gpu, "slowfast_tiny", segmented=False, use_graph=False, steps=4)
+    monkeypatch.setattr(engine, "PATHWAY_STREAMS", True)
+    for rep in range(3):
+        for segmented, use_graph in ((False, False), (True, True), (False, True)):
+            l1, p1, _, _ = _run_model(gpu, "slowfast_tiny", segmented=segmented, use_graph=use_graph, steps=4)
+            assert l1 == l0, (rep, segmented, use_graph, l0, l1)
+            for a, b in zip(p0, p1):
+                assert torch.equal(a, b), (rep, segmented, use_graph)
+    assert engine._pathway_streams, "the Fast pathway must have run on its own stream"
+
+
 def test_static_clone_keeps_wpair_tag_and_strides():
     """TrainStep._static_clone: the captured graph's copy of a packed clip keeps the W-pair tag and the channels-last strides
     (without the tag StemConvUnit would try to convert an 8-channel tensor and fail at capture)."""
