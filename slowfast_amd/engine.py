@@ -200,6 +200,7 @@ def join_side_streams():
 # (join_side_streams), tensors that cross a fork / join stay referenced by autograd until their consumers are enqueued.
 # SF_PATHWAY_STREAMS=0: one stream (A/B runs).
 PATHWAY_STREAMS = os.environ.get("SF_PATHWAY_STREAMS", "1") != "0"
+CAT_IN_PLACE = os.environ.get("SF_CAT_IN_PLACE", "1") != "0"       # ResBlockFn writes into FuseFn's buffer (A/B switch)
 _pathway_streams = {}    # (device, pathway) -> stream
 _pathway_main = {}       # device -> the stream the last fork left from
 
@@ -703,8 +704,12 @@ class FuseFn(torch.autograd.Function):
         N, Cs, T, H, W = x_s.shape
         Cf = yf.shape[1]
         assert tuple(yf.shape) == (N, Cf, T, H, W), "lateral connection does not match the Slow pathway shape"
-        cat = ops.cl_empty((N, Cs + Cf, T, H, W), x_s.device)
-        ops.bn_act(x_s, out=cat[:, :Cs])
+        cat = getattr(x_s, "_sf_cat", None)
+        if cat is not None and tuple(cat.shape) == (N, Cs + Cf, T, H, W) and cat.data_ptr() == x_s.data_ptr():
+            pass                                        # the Slow block already wrote its slice (ResBlockFn, _cat_extra)
+        else:
+            cat = ops.cl_empty((N, Cs + Cf, T, H, W), x_s.device)
+            ops.bn_act(x_s, out=cat[:, :Cs])
         ops.bn_act(yf, st.scale, st.shift, relu=True, out=cat[:, Cs:])
         if CAPTURE is not None:
             CAPTURE.append({"kind": "fuse", "mod": mod, "raw": [yf], "bn": [(st.scale, st.shift)]})
@@ -759,13 +764,24 @@ class ResBlockFn(torch.autograd.Function):
         yc, sc = raw[-1], bn[-1]
         # the backward pass needs only the SIGN of the block output (ReLU mask): one bit per element, written here, stands
         # in for two full reads of `out` in BatchNorm backward (and for the masked gradient tensor of the identity shortcut)
+        # The last Slow block of a stage that a lateral connection follows (video_models.SlowFast marks it: _cat_extra = channels
+        # of the lateral branch) writes its output straight into the channel slice of the concatenated buffer FuseFn would
+        # otherwise copy it into (one read + one write of the widest tensor of the stage less per lateral connection).
+        out_view, cat = None, None
+        extra = getattr(mod, "_cat_extra", 0)
+        if extra and CAT_IN_PLACE:
+            N_, C_, T_, H_, W_ = yc.shape
+            cat = ops.cl_empty((N_, C_ + extra, T_, H_, W_), x.device)
+            out_view = cat[:, :C_]
         if P is not None:
             y1, s1 = P.forward(x, None, tr)
             out, bits = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=y1, rscale=s1.scale, rshift=s1.shift,
-                                   want_mask=True)
+                                   want_mask=True, out=out_view)
         else:
             y1, s1 = None, None
-            out, bits = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x, want_mask=True)
+            out, bits = ops.bn_act(yc, sc.scale, sc.shift, relu=True, resid=x, want_mask=True, out=out_view)
+        if cat is not None:
+            out._sf_cat = cat
         if CAPTURE is not None:
             CAPTURE.append({"kind": "resblock", "mod": mod, "raw": list(raw), "bn": [(b.scale, b.shift) for b in bn], "out": out})
         ctx.mod = mod

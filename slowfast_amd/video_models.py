@@ -205,7 +205,13 @@ class SlowFast(_ResNetBase):
                                 dim_inner=[inner * 2 ** i, inner * 2 ** i // beta_inv], depth=depth)
             setattr(self, f"s{i + 2}", stage)
             if i < 3:
-                setattr(self, f"s{i + 2}_fuse", fuse(width_out))
+                f2s = fuse(width_out)
+                setattr(self, f"s{i + 2}_fuse", f2s)
+                # the stage's last Slow block writes its output into the lateral connection's concatenated buffer
+                # (engine.ResBlockFn / FuseFn) -- unless a Nonlocal block sits between them
+                last = depth - 1
+                if not hasattr(stage, f"pathway0_nonlocal{last}"):
+                    getattr(stage, f"pathway0_res{last}")._cat_extra = f2s.conv_f2s.out_channels
             if i == 0:
                 for p in range(2):
                     ps = _POOL1[arch][p]

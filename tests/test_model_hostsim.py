@@ -249,3 +249,34 @@ def test_well_conditioned_1e3_no_yardstick(sim):
     """The north-star bar asserted directly (no yardstick) on a well-conditioned C2D-R50 (tests/golden/c2d_wc.json); the
     GPU suite runs the SlowFast / X3D / R101+Nonlocal cases as well."""
     mc.check_well_conditioned("c2d_wc", sim)
+
+
+def test_lateral_concat_written_in_place(sim, monkeypatch):
+    """The last Slow block of a stage writes its output into the lateral connection's concatenated buffer (engine.ResBlockFn
+    `_cat_extra` / FuseFn): three full-tensor copies less per SlowFast forward, logits and every parameter gradient bit for bit
+    what the copying schedule gives."""
+    import torch
+    import slowfast_amd as sa
+    from slowfast_amd import engine, lib
+    gold = mc.load_golden("slowfast_tiny")
+    cfg = mc.cfg_for(gold)
+    T, S = cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE
+    g = torch.Generator().manual_seed(1)
+    fast = torch.randn((2, 3, T, S, S), generator=g)
+    slow = torch.index_select(fast, 2, torch.linspace(0, T - 1, T // cfg.SLOWFAST.ALPHA).long())
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(engine, "CAT_IN_PLACE", flag)
+        torch.manual_seed(0)
+        model = sa.MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg).train()
+        calls = []
+        lib.set_call_observer(lambda name, thunk, work: (calls.append(name), thunk())[1])
+        try:
+            out = model([slow, fast])
+            out.float().sum().backward()
+        finally:
+            lib.set_call_observer(None)
+        res[flag] = (out.detach().clone(), [p.grad.clone() for p in model.parameters()], calls.count("sf_bn_act"))
+    assert res[False][2] - res[True][2] == 3, "one copy per lateral connection after res2 / res3 / res4"
+    assert torch.equal(res[True][0], res[False][0])
+    assert all(torch.equal(a, b) for a, b in zip(res[True][1], res[False][1]))

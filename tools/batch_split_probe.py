@@ -52,9 +52,38 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e3
 
+    def run_graph(nsplit, steps):
+        """the same work captured ONCE into a HIP graph (the halves are branches) and replayed: the eager loop enqueues the
+        second half only after the first one's ~1100 launches, by which time the GPU has nearly finished it"""
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nsplit)]
+        xs, ys = x.chunk(nsplit), y.chunk(nsplit)
+        cap = torch.cuda.Stream(device=dev)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(g, stream=cap):
+                for s in streams:
+                    s.wait_stream(cap)
+                for h, s in enumerate(streams):
+                    with torch.cuda.stream(s):
+                        loss = F.cross_entropy(model([xs[h]]).float(), ys[h])
+                        (loss * 1024.0).backward()
+                for s in streams:
+                    cap.wait_stream(s)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
     for nsplit in (1, a.splits, 1, a.splits):
         run(nsplit, 2)
         print(f"{a.preset} batch {a.batch}: {nsplit} stream(s) x batch {a.batch // nsplit}: {run(nsplit, a.steps):.2f} ms per fwd+bwd", flush=True)
+    for nsplit in (1, a.splits, 1, a.splits):
+        print(f"{a.preset} batch {a.batch}: GRAPH {nsplit} branch(es) x batch {a.batch // nsplit}: {run_graph(nsplit, a.steps):.2f} ms per fwd+bwd", flush=True)
 
 
 if __name__ == "__main__":
