@@ -64,15 +64,20 @@ def _stale(target, sim=False):
     return not os.path.exists(target) or _built_id(target) != source_id(sim)
 
 
-def build_hip(force=False, verbose=False, act="fp16"):
-    """act = "fp16" -> libsfamd.so, "bf16" -> libsfamd_bf16.so (the 16-bit storage type, lib.ACT_MODE)."""
-    out = LIB if act == "fp16" else LIB_BF16
+LIB_DIAG = os.path.join(ROOT, "slowfast_amd", "libsfamd_diag.so")    # -DSF_DIAG: tuning knobs / ablation bits read the environment
+
+
+def build_hip(force=False, verbose=False, act="fp16", diag=False):
+    """act = "fp16" -> libsfamd.so, "bf16" -> libsfamd_bf16.so (the 16-bit storage type, lib.ACT_MODE).  ``diag``: the fp16
+    library compiled with -DSF_DIAG (libsfamd_diag.so; point SFAMD_LIBRARY at it): A/B knobs and the kernels' ablation
+    switches are live there, compile-time constants everywhere else (csrc/sf_api.hip: tune_knob)."""
+    out = LIB_DIAG if diag else (LIB if act == "fp16" else LIB_BF16)
     if not force and not _stale(out):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
            "-Wno-comment", "-I" + os.path.join(ROOT, "include"), '-DSF_BUILD_ID="%s"' % source_id()] + \
-          (["-DSF_ACT_BF16"] if act == "bf16" else []) + [SRC, "-o", out]
+          (["-DSF_ACT_BF16"] if act == "bf16" and not diag else []) + (["-DSF_DIAG"] if diag else []) + [SRC, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -96,6 +101,9 @@ def build_hostsim(force=False, verbose=False, act="fp16"):
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
+    if "--diag" in sys.argv:
+        print(build_hip(force=force, verbose=True, diag=True))
+        sys.exit(0)
     for act in ("fp16", "bf16"):
         print(build_hip(force=force, verbose=True, act=act))
         if "--hostsim" in sys.argv:

@@ -41,6 +41,19 @@ static int check_launch(const char* what) {
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
 
+// Environment switches, two classes (47 getenv sites, many per launch, each an untested product configuration):
+//   test_hook(name, default)  dispatch thresholds the TEST SUITE lowers so that small shapes reach a kernel (SF_IGEMM2_MINK ...),
+//                             kernel selectors its parity cases flip (SF_DW_TILED ...) and SF_TRACE: read in every build;
+//   tune_knob(name, default)  A/B knobs whose optimum was measured (block targets, occupancy caps, variant selectors; the
+//                             evidence is under profiles/): COMPILE-TIME constants in the product build, overridable only in
+//                             -DSF_DIAG builds (libsfamd_diag.so, tools/ sweeps).
+static inline int test_hook(const char* name, int def) { const char* e = getenv(name); return e ? atoi(e) : def; }
+#ifdef SF_DIAG
+static inline int tune_knob(const char* name, int def) { const char* e = getenv(name); return e ? atoi(e) : def; }
+#else
+#define tune_knob(name, def) (def)
+#endif
+
 extern "C" int sf_abi_version(void) { return SF_ABI_VERSION; }
 // "gfx950" for the hipcc build; the host functional simulator used by the CPU tests reports itself.
 extern "C" const char* sf_backend(void) {
@@ -134,7 +147,7 @@ static GatherSide gather_dgrad(const sf_conv_desc* d, const void* dy) {
 // direct global -> LDS operand copies (GL): plain row-major GEMM operands only -- one tap, no fused input BatchNorm,
 // K a multiple of the 32-wide K step, 16-byte aligned rows.  SF_IGEMM_GLDS=0 keeps the register-staged loads.
 static bool igemm_glds_ok(const IgemmParams& p, bool pw) {
-    static const bool off = getenv("SF_IGEMM_GLDS") && atoi(getenv("SF_IGEMM_GLDS")) == 0;
+    static const bool off = tune_knob("SF_IGEMM_GLDS", 1) == 0;
     if (off || !pw || p.g.scale) return false;
     if (p.g.Ktot != p.g.C || p.g.Ktot % 32 != 0 || p.g.ld % 8 != 0 || p.ldw % 8 != 0) return false;
     if (p.g.padT != 0) return false;
@@ -149,7 +162,7 @@ static void launch_igemm(const IgemmParams& p, bool pw, hipStream_t s, int nbatc
     dim3 grid((unsigned)(mt * p.ntiles_n), (unsigned)nbatch);
     // 128-VGPR cap (4 workgroups per CU) for the 128-wide tile: +0.2..1.2 % end to end (profiles/r1_visit9_*_occ4.json);
     // SF_IGEMM_OCC4=0 restores the uncapped build for A/B runs
-    static const bool occ4 = !(getenv("SF_IGEMM_OCC4") && atoi(getenv("SF_IGEMM_OCC4")) == 0);
+    static const bool occ4 = tune_knob("SF_IGEMM_OCC4", 1) != 0;
     if (p.f32.out) {                // fp32 side rows of the output (sf_gemm_rows32: plain [M, K] operands)
         if (igemm_glds_ok(p, pw)) hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, true, BN == 128, true>), grid, dim3(SF_THREADS), 0, s, p);
         else hipLaunchKernelGGL((sf_igemm_kernel<BN, WM, WN, true, false, BN == 128, true>), grid, dim3(SF_THREADS), 0, s, p);
@@ -184,23 +197,23 @@ static void launch_igemm2(Igemm2Params& q, hipStream_t s) {
 }
 // K step: 64 deep (48 KB stages, ONE 8-wave workgroup per CU) when the grid is at most ~one tile per CU anyway -- the
 // res5-sized layers; otherwise 32 deep (24 KB stages, TWO workgroups per CU: one tile's epilogue and pipeline fill hide
-// behind the other's K loop).  Measured per layer in profiles/r2_v3_igemm2_variants.md.  SF_IGEMM2_BK=32|64 forces one.
+// behind the other's K loop).  Measured per layer in profiles/r2/r2_v3_igemm2_variants.md.  SF_IGEMM2_BK=32|64 forces one.
 static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     const char* e;
     const int tiles = cdiv(q.M, 256) * cdiv(q.Nout, q.Nout > 64 ? 128 : 64);
-    const int force_bk = (e = getenv("SF_IGEMM2_BK")) ? atoi(e) : 0;
+    const int force_bk = tune_knob("SF_IGEMM2_BK", 0);
     const bool bk64 = q.C % 64 == 0 && force_bk != 32 && (force_bk == 64 || tiles <= 320);
-    static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
-    q.ablate = (e = getenv("SF_IGEMM2_ABLATE")) ? atoi(e) : 0;     // diagnostic: parts of the kernel switched off (wrong results)
+    static const bool trace = test_hook("SF_TRACE", 0) != 0;
+    q.ablate = tune_knob("SF_IGEMM2_ABLATE", 0);        // diagnostic builds only: parts of the kernel switched off (wrong results)
     if (trace) fprintf(stderr, "[sfamd] igemm2: M=%d N=%d C=%d taps=%d BK=%d omap=%d\n", q.M, q.Nout, q.C, q.ntaps, bk64 ? 64 : 32, q.omap);
     // (256 x 256 tiles -- 128 flop per copied operand byte instead of 85, one workgroup per CU -- were measured in round 4 and
     // lost on both models: SlowFast 766.5 -> 741 clips/s on every eligible layer, 755 restricted to grids of >= 512 tiles,
-    // MViTv2-S 590.9 -> 584 / 588; profiles/r4_v6_knobs_ab.txt.  The same tile on a 16-wave workgroup (64 x 64 wave tiles, four
-    // waves per SIMD kept) moved no layer either: profiles/r4_v11_igemm2_fat_ab.txt.  Both removed.)
+    // MViTv2-S 590.9 -> 584 / 588; profiles/r4/r4_v6_knobs_ab.txt.  The same tile on a 16-wave workgroup (64 x 64 wave tiles, four
+    // waves per SIMD kept) moved no layer either: profiles/r4/r4_v11_igemm2_fat_ab.txt.  Both removed.)
     // third generation (sf_igemm3.h, 256 x 256 x 64 eight-phase ping-pong): EXPERIMENT, SF_IGEMM3=<min tiles> switches it on
     {
-        const int i3_min = (e = getenv("SF_IGEMM3")) ? atoi(e) : 0;
-        const int i3_minn = (e = getenv("SF_IGEMM3_MINN")) ? atoi(e) : 192;
+        const int i3_min = test_hook("SF_IGEMM3", 0);
+        const int i3_minn = test_hook("SF_IGEMM3_MINN", 192);
         const int t3 = cdiv(q.M, 256) * cdiv(q.Nout, 256);
         if (i3_min > 0 && q.C % 64 == 0 && q.Nout >= i3_minn && t3 >= i3_min) {
             q.ntiles_n = cdiv(q.Nout, 256);
@@ -241,9 +254,9 @@ static void igemm2_common(Igemm2Params& q, const IgemmParams& p) {
 static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     // read on every call (three getenv per launch are noise): tests lower the thresholds for single cases
     const char* e;
-    const bool off = (e = getenv("SF_IGEMM2")) && atoi(e) == 0;
-    const int mink = (e = getenv("SF_IGEMM2_MINK")) ? atoi(e) : 512;
-    const int minrows = (e = getenv("SF_IGEMM2_MINROWS")) ? atoi(e) : 4096;
+    const bool off = test_hook("SF_IGEMM2", 1) == 0;
+    const int mink = test_hook("SF_IGEMM2_MINK", 512);
+    const int minrows = test_hook("SF_IGEMM2_MINROWS", 4096);
     const GatherSide& g = p.g;
     if (off || !igemm2_operands_ok(p, nbatch)) return false;
     if (g.Ktot < mink || p.Nout <= 32 || p.M < minrows) return false;
@@ -285,8 +298,8 @@ static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
 // (1x1 kernels) just store the residual / zeros.
 static bool try_igemm2_strided_dgrad(const IgemmParams& p, hipStream_t s) {
     const char* e;
-    const bool off = ((e = getenv("SF_IGEMM2")) && atoi(e) == 0) || ((e = getenv("SF_IGEMM2_STRIDED")) && atoi(e) == 0);
-    const int minrows = (e = getenv("SF_IGEMM2_MINROWS")) ? atoi(e) : 4096;
+    const bool off = test_hook("SF_IGEMM2", 1) == 0 || tune_knob("SF_IGEMM2_STRIDED", 1) == 0;
+    const int minrows = test_hook("SF_IGEMM2_MINROWS", 4096);
     const GatherSide& g = p.g;
     if (off || g.mode != 1 || (g.strT == 1 && g.strH == 1 && g.strW == 1)) return false;
     if (!igemm2_operands_ok(p, 1) || p.Nout <= 16 || p.M < minrows || p.stat_part || p.act_mode) return false;
@@ -368,13 +381,13 @@ struct StemPlan {
 static StemPlan plan_stem(const sf_conv_desc* d) {
     StemPlan s;
     memset(&s, 0, sizeof(s));
-    static const bool off = getenv("SF_STEM_GENERIC") && atoi(getenv("SF_STEM_GENERIC")) != 0;
+    static const bool off = tune_knob("SF_STEM_GENERIC", 0) != 0;
     if (off) return s;
     // thin3: an 8-channel (kT, kH, 3) stride-1 layer with one pixel of W padding (the Fast pathway's res2 1x3x3 bottleneck) is the
     // same direct convolution with a zero fourth tap: forward, data gradient (conv_dgrad_impl) and weight gradient.  Measured on
-    // s2.fast b (profiles/r3_v13_thin3_ab.txt): fwd 105 -> 57-69 us, dgrad 110 -> 56, wgrad 95 -> 90; SlowFast step +0.6 %.
+    // s2.fast b (profiles/r3/r3_v13_thin3_ab.txt): fwd 105 -> 57-69 us, dgrad 110 -> 56, wgrad 95 -> 90; SlowFast step +0.6 %.
     // SF_STEM_THIN3=0 keeps the implicit GEMM for A/B runs.
-    static const bool thin3_on = !(getenv("SF_STEM_THIN3") && atoi(getenv("SF_STEM_THIN3")) == 0);
+    static const bool thin3_on = tune_knob("SF_STEM_THIN3", 1) != 0;
     const bool stemlike = d->kW == 4 && d->pW == 2;
     const bool thin3 = thin3_on && d->kW == 3 && d->pW == 1 && d->sH == 1 && d->sT == 1;
     if (d->Ci != 8 || d->Cw != 8 || !(stemlike || thin3) || d->sW != 1 || d->dT != 1 || d->dH != 1 || d->dW != 1)
@@ -406,7 +419,7 @@ static StemPlan plan_stem(const sf_conv_desc* d) {
 // SF_STEM_ROWMAJOR=0 keeps the generic loop for A/B runs
 #define SF_STEM_FWD_LAUNCH(sp, q, stream)                                                                                          \
     do {                                                                                                                          \
-        static const bool rm_ = !(getenv("SF_STEM_ROWMAJOR") && atoi(getenv("SF_STEM_ROWMAJOR")) == 0);                           \
+        static const bool rm_ = tune_knob("SF_STEM_ROWMAJOR", 1) != 0;                           \
         const dim3 g_((sp).ntiles), b_(SF_THREADS);                                                                               \
         if (rm_ && (q).sH == 2 && (q).kH == 7 && !(sp).small)                                                                     \
             hipLaunchKernelGGL((sf_stem_fwd_kernel<SF_STEM_CHUNKS, 2, 7>), g_, b_, 0, (hipStream_t)(stream), q);                  \
@@ -509,7 +522,7 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const void* x, const void* wf,
             sf_conv_weight_ld(d, &ldf0, &ldd0);
             q.wmat = (const f16*)wf; q.ldw = ldf0; q.y = (f16*)y;
             q.stat_part = stat_part; q.stat_rows = sf_conv_fwd_mtiles(d);
-            const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;    // read per call: tests switch it on mid-process
+            const bool trace = test_hook("SF_TRACE", 0) != 0;          // read per call: tests switch it on mid-process
             if (trace) fprintf(stderr, "[sfamd] stem_fwd: %d tiles, patch %dx%dx%d chunks\n", sp.ntiles, sp.F, sp.PR, SF_STEM_PC);
             SF_STEM_FWD_LAUNCH(sp, q, stream);
             return check_launch("stem_fwd");
@@ -662,7 +675,7 @@ static WgradPlan plan_wgrad(const sf_conv_desc* d) {
     w.Co_pad = w.tiles_c * w.BMW;
     w.nchunks = cdiv(M, 32);
     const int64_t slab = (int64_t)w.Co_pad * w.Kpad * 4;
-    static const int target = getenv("SF_WGRAD_BLOCKS") ? atoi(getenv("SF_WGRAD_BLOCKS")) : 1024;   // A/B knob
+    static const int target = tune_knob("SF_WGRAD_BLOCKS", 1024);
     int splits = cdiv(target, (int64_t)w.tiles_k * w.tiles_c);
     const int64_t cap = (256ll << 20) / slab;            // keep the workspace <= 256 MiB
     if (splits > cap) splits = (int)(cap < 1 ? 1 : cap);
@@ -686,15 +699,15 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     Wgrad2Plan w;
     memset(&w, 0, sizeof(w));
     const char* e;
-    if ((e = getenv("SF_WGRAD2")) && atoi(e) == 0) return w;
-    const int mink = (e = getenv("SF_WGRAD2_MINK")) ? atoi(e) : 192;
-    const int minrows = (e = getenv("SF_WGRAD2_MINROWS")) ? atoi(e) : 4096;
+    if (test_hook("SF_WGRAD2", 1) == 0) return w;
+    const int mink = test_hook("SF_WGRAD2_MINK", 192);
+    const int minrows = test_hook("SF_WGRAD2_MINROWS", 4096);
     const int taps = d->kT * d->kH * d->kW;
     // Workgroups to aim for: ONE resident round (2 per CU x 256 CUs).  The split count is rounded DOWN so that the grid never
     // exceeds the target by a few workgroups: 18 tiles x 29 splits = 522 on 512 resident slots ran a second, almost empty round
-    // (s4.slow b: 120 us at 522 workgroups, 99 us at 396; profiles/r3_v2_wgrad_sweep.md -- which also records a one-workgroup-
+    // (s4.slow b: 120 us at 522 workgroups, 99 us at 396; profiles/r3/r3_v2_wgrad_sweep.md -- which also records a one-workgroup-
     // per-CU six-stage ring with half the splits losing on every layer; that variant is gone again, commit 4267b0c has it).
-    const int target = (e = getenv("SF_WGRAD2_BLOCKS")) ? atoi(e) : 512;
+    const int target = test_hook("SF_WGRAD2_BLOCKS", 512);
     (void)taps;
     const int Ktot = taps * d->Ci;
     const int64_t M = (int64_t)d->N * d->To * d->Ho * d->Wo;
@@ -703,8 +716,8 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     if (plan_stem(d).ok) return w;
     if (d->Co <= 32) {
         // thin layers (sf_wgrad2t_kernel): one workgroup tile holds every output channel; SF_WGRAD2T=0 keeps the first kernel
-        if ((e = getenv("SF_WGRAD2T")) && atoi(e) == 0) return w;
-        const int minrows_t = (e = getenv("SF_WGRAD2T_MINROWS")) ? atoi(e) : 16384;
+        if (test_hook("SF_WGRAD2T", 1) == 0) return w;
+        const int minrows_t = test_hook("SF_WGRAD2T_MINROWS", 16384);
         if (M < minrows_t) return w;
         w.thin = true;
         w.BMW = d->Co <= 16 ? 16 : 32;
@@ -714,8 +727,8 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
         w.Kpad = w.tiles_k * w.BKW;
         w.Co_pad = w.BMW;
         // one resident round of workgroups: LDS allows 2 per CU with 128-wide tiles (2 x 37-41 KB stages), 3 (BMW 32) or 4 (BMW 16)
-        // with 32-wide ones; measured per layer, 512 / 768 / 1024 / 1536 / 2048: profiles/r2_v24_wgrad_thin.md
-        const int target_t = (e = getenv("SF_WGRAD2T_BLOCKS")) ? atoi(e) : (w.BKW == 128 ? 512 : w.BMW == 32 ? 768 : 1024);
+        // with 32-wide ones; measured per layer, 512 / 768 / 1024 / 1536 / 2048: profiles/r2/r2_v24_wgrad_thin.md
+        const int target_t = test_hook("SF_WGRAD2T_BLOCKS", w.BKW == 128 ? 512 : w.BMW == 32 ? 768 : 1024);
         int splits = target_t / w.tiles_k;                  // rounded down: never a few workgroups beyond the resident round
         if (splits < 1) splits = 1;
         w.rows_per_split = roundup(cdiv(M, splits), 128);
@@ -726,7 +739,7 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
         return w;
     }
     if (Ktot < mink) return w;
-    w.BMW = d->Co > 64 ? 128 : 64;       // 64-row co-tiles for wide layers lose 20-40 % on res3-res5 (profiles/r3_final_wgrad_sweep.md)
+    w.BMW = d->Co > 64 ? 128 : 64;       // 64-row co-tiles for wide layers lose 20-40 % on res3-res5 (profiles/r3/r3_final_wgrad_sweep.md)
     w.tiles_k = cdiv(Ktot, 256);
     w.tiles_c = cdiv(d->Co, w.BMW);
     w.Kpad = w.tiles_k * 256;
@@ -819,9 +832,9 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
         slabs = (float*)((char*)workspace + w2.tab_bytes);
         q.ws = slabs; q.Co_pad = w2.Co_pad; q.Kpad = w2.Kpad;
         q.tiles_k = w2.tiles_k; q.tiles_c = w2.tiles_c; q.rows_per_split = w2.rows_per_split;
-        { const char* e = getenv("SF_WGRAD2T_RR"); q.stage_stride = (w2.thin && !(e && atoi(e) == 0)) ? w2.splits : 0; }
+        q.stage_stride = (w2.thin && tune_knob("SF_WGRAD2T_RR", 1) != 0) ? w2.splits : 0;
         const dim3 grid((unsigned)(w2.tiles_k * w2.tiles_c * w2.splits));
-        static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+        static const bool trace = test_hook("SF_TRACE", 0) != 0;
         if (trace) fprintf(stderr, "[sfamd] wgrad2: M=%d Co=%d K=%d tiles %dx%d splits %d\n", q.M, q.Co, q.Ktot, w2.tiles_c, w2.tiles_k, w2.splits);
         if (w2.thin) {
             if (w2.BMW == 16 && w2.BKW == 128) hipLaunchKernelGGL((sf_wgrad2t_kernel<16, 128, 2>), grid, dim3(256), 0, s, q);
@@ -838,9 +851,9 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
                 (long long)workspace_bytes, (long long)sp.ws_bytes);
         StemParams q = stem_params(d, sp, x);
         q.dy = (const f16*)dy; q.ws = (float*)workspace;
-        const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;    // read per call: tests switch it on mid-process
+        const bool trace = test_hook("SF_TRACE", 0) != 0;          // read per call: tests switch it on mid-process
         if (trace) fprintf(stderr, "[sfamd] stem_wgrad: %d workgroups x %d tiles\n", sp.wg_blocks, sp.tiles_per_block);
-        static const bool stem_plain = getenv("SF_STEM_XCD") && atoi(getenv("SF_STEM_XCD")) == 0;
+        static const bool stem_plain = tune_knob("SF_STEM_XCD", 1) == 0;
         q.plain_order = stem_plain ? 1 : 0;
         if (d->Co <= 8 && sp.small) hipLaunchKernelGGL((sf_stem_wgrad_kernel<8, SF_STEM_CHUNKS_SMALL>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
         else if (d->Co <= 8) hipLaunchKernelGGL((sf_stem_wgrad_kernel<8, SF_STEM_CHUNKS>), dim3(sp.wg_blocks), dim3(SF_STEM_WG_THREADS), 0, s, q);
@@ -908,7 +921,7 @@ static int check_rows(const char* who, int64_t M, int C) {
 // Tables up to kFoldAbove rows are finalized directly by a 1024-thread block per 8 channels (<= 16 rows per thread:
 // 7.5 us for the 1024-row tables of the backward pass against 5 + 5 us for fold + finalize); longer tables (the per-tile
 // partials of a forward convolution over 800k positions) measured no faster that way and keep the fold stage.
-static const int kFoldAbove = getenv("SF_FOLD_ABOVE") ? atoi(getenv("SF_FOLD_ABOVE")) : 2048;
+static const int kFoldAbove = tune_knob("SF_FOLD_ABOVE", 2048);
 static int fold_partials(float* part, int& nblk, int C, hipStream_t s) {
     if (nblk <= kFoldAbove || nblk <= 256) return 1;
     const int group = nblk <= 2048 ? 16 : nblk <= 8192 ? 32 : 64;
@@ -950,7 +963,7 @@ extern "C" int sf_bn_act(int64_t M, int32_t C, const void* y, int32_t ldy, const
 }
 
 // row blocks of the BatchNorm-backward reduce (= rows of its partial table); SF_BN_BWD_BLOCKS is an A/B knob
-static const int kBwdBlocks = getenv("SF_BN_BWD_BLOCKS") ? atoi(getenv("SF_BN_BWD_BLOCKS")) : 1024;
+static const int kBwdBlocks = tune_knob("SF_BN_BWD_BLOCKS", 1024);
 extern "C" int sf_bn_bwd_blocks(int64_t M, int32_t C) {
     if (check_rows("sf_bn_bwd_blocks", M, C)) return -1;
     dim3 grid;
@@ -1258,12 +1271,12 @@ extern "C" int sf_bgemm_tn(int64_t M, int32_t R, int32_t Kc, const void* P, int3
 template <int L, int NS>
 static void launch_ln_fwd(const LnParams& p, hipStream_t s) {
     // rows in flight per thread: 2 for the one- and three-slot rows (SF_LN_RU=1 keeps one, A/B runs)
-    static const int ru_env = getenv("SF_LN_RU") ? atoi(getenv("SF_LN_RU")) : 2;
+    static const int ru_env = tune_knob("SF_LN_RU", 2);
     constexpr int RU2 = NS != 2 ? 2 : 1;
     const int ru = ru_env != 1 ? RU2 : 1;
     // 2048 workgroups (= the chip's 8 waves per SIMD once over) walking the rows: 68 / 39 / 27.5 us at the MViTv2-S block-0 /
-    // stage-2 / stage-3 shapes against 73 / 44 / 36 us with 4096 and 81 / 58 / 45 us with 8192 (profiles/r4_v17_ln_fwd_blocks.txt)
-    static const int max_blocks = getenv("SF_LN_FWD_BLOCKS") ? atoi(getenv("SF_LN_FWD_BLOCKS")) : 2048;
+    // stage-2 / stage-3 shapes against 73 / 44 / 36 us with 4096 and 81 / 58 / 45 us with 8192 (profiles/r4/r4_v17_ln_fwd_blocks.txt)
+    static const int max_blocks = tune_knob("SF_LN_FWD_BLOCKS", 2048);
     const int rpb = SF_THREADS / L * ru;
     int blocks = cdiv(p.M, rpb);
     if (blocks > max_blocks) blocks = max_blocks;
@@ -1271,7 +1284,7 @@ static void launch_ln_fwd(const LnParams& p, hipStream_t s) {
     else hipLaunchKernelGGL((sf_layernorm_fwd_kernel<L, NS, 1>), dim3(blocks), dim3(SF_THREADS), 0, s, p);
 }
 static int ln_bwd_ru() {
-    static const int ru = getenv("SF_LN_BWD_RU") ? atoi(getenv("SF_LN_BWD_RU")) : 2;
+    static const int ru = tune_knob("SF_LN_BWD_RU", 2);
     return ru;
 }
 template <int L, int NS>
@@ -1300,7 +1313,7 @@ static int layernorm_fwd_impl(int64_t M, int32_t C, const void* x, int32_t ldx, 
     // C = 768: three 8-channel slots on 32 lanes (no idle lanes, 8 rows per workgroup pass) instead of two slots on 64 lanes
     // with a quarter of them idle: 41.6 -> 30.8 us at M = 12576.  The same idea at C = 96 / 192 / 384 (4 / 8 / 16 lanes x three
     // slots) is SLOWER than the power-of-two lane counts with idle lanes (72 -> 81, 44 -> 52, 34 -> 49 us): a wave's 16-byte
-    // loads then cover 64 / 128 / 256-byte pieces at the row pitch instead of whole rows (profiles/r4_v16_ln_bench.txt).
+    // loads then cover 64 / 128 / 256-byte pieces at the row pitch instead of whole rows (profiles/r4/r4_v16_ln_bench.txt).
     if (C == 768) launch_ln_fwd<32, 3>(p, s);
     else if (C <= 128) launch_ln_fwd<16, 1>(p, s);
     else if (C <= 256) launch_ln_fwd<32, 1>(p, s);
@@ -1321,7 +1334,7 @@ extern "C" int sf_layernorm_fwd_rows32(int64_t M, int32_t C, const void* x, int3
 static int ln_bwd_plan(int64_t M, int C, int& rows_per_block) {
     const int rpb = SF_THREADS / ln_lanes(C);
     // every workgroup resident at once: 256 CUs x 4 (one row in flight, 4 waves per SIMD) or x 3 (two rows, 154 VGPRs)
-    static const int env_blocks = getenv("SF_LN_BWD_BLOCKS") ? atoi(getenv("SF_LN_BWD_BLOCKS")) : 0;
+    static const int env_blocks = tune_knob("SF_LN_BWD_BLOCKS", 0);
     const int max_blocks = env_blocks > 0 ? env_blocks : (C <= 512 && ln_bwd_ru() != 1) ? 768 : 1024;
     int blocks = cdiv(M, rpb);
     if (blocks > max_blocks) blocks = max_blocks;
@@ -1457,7 +1470,7 @@ static int fill_dw(DwParams& p, const sf_dw_desc* d, bool rows_are_outputs, int 
     p.fdH = make_fastdiv(rows_are_outputs ? d->Ho : d->Hi);
     p.fdsT = make_fastdiv(d->sT); p.fdsH = make_fastdiv(d->sH); p.fdsW = make_fastdiv(d->sW);
     // row blocks handed out XCD-contiguously (sf_dwconv.h: dw_block_id); SF_DW_XCD=0 keeps the plain order (A/B runs)
-    static const bool xcd = !(getenv("SF_DW_XCD") && atoi(getenv("SF_DW_XCD")) == 0);
+    static const bool xcd = tune_knob("SF_DW_XCD", 1) != 0;
     p.xcd_order = xcd ? 1 : 0;
     return 0;
 }
@@ -1465,7 +1478,7 @@ static const int kDwFwdBlocks = 2048, kDwWgradBlocks = 256;
 
 // W-blocked kernels: (kW, sW) in {(3,1), (3,2), (1,1)} with pW = kW/2; returns 0 when the geometry is not covered
 static int dw_blocked_kind(const sf_dw_desc* d) {
-    if (getenv("SF_DW_GENERIC") && atoi(getenv("SF_DW_GENERIC")) != 0) return 0;
+    if (tune_knob("SF_DW_GENERIC", 0) != 0) return 0;
     if (d->pW != d->kW / 2 || d->kH * d->kW > 9) return 0;      // the blocked weight gradient keeps <= 9 taps per plane
     if (d->kW == 3 && d->sW == 1) return 1;
     if (d->kW == 3 && d->sW == 2) return 2;
@@ -1499,7 +1512,7 @@ static void dw_block_plan(DwParams& p, DwBlockIdx& bi, const sf_dw_desc* d, bool
 // path, forward and data gradient.  Taken when the geometry fits (32-channel chunks inside one weight group, no BatchNorm
 // statistics epilogue); SF_DW_TILED=0 keeps the W-blocked stencils (A/B runs).  mode 0: forward, 1: data gradient.
 static bool dwtile_plan(const sf_dw_desc* d, int mode, DwTileParams& p, int& np) {
-    // SF_DW_TILED: 0 = never, 1 (default) = stride-1 geometries (where it measured faster: profiles/r4_v5_dwtile_ab.txt), 2 = also
+    // SF_DW_TILED: 0 = never, 1 (default) = stride-1 geometries (where it measured faster: profiles/r4/r4_v5_dwtile_ab.txt), 2 = also
     // the stride-2 forward and the zero-upsampled stride-2 data gradient
     const char* lv = getenv("SF_DW_TILED");        // read per call (tests switch it mid-process)
     const int lvl = lv ? atoi(lv) : 1;
@@ -1548,7 +1561,7 @@ static bool dwtile_plan(const sf_dw_desc* d, int mode, DwTileParams& p, int& np)
 }
 static void dwtile_launch(DwTileParams& p, int np, hipStream_t s) {
     const dim3 grid((unsigned)(p.N * p.tiles_h * p.nchunks));
-    static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+    static const bool trace = test_hook("SF_TRACE", 0) != 0;
     if (trace) fprintf(stderr, "[sfamd] dwtile: N=%d C=%d T=%d %dx%d -> %dx%d s=%d ups=%d TH=%d tiles=%d NP=%d blocks=%u\n", p.N, p.C, p.T,
                        p.Hs, p.Ws, p.Hd, p.Wd, p.s, p.ups, p.TH, p.tiles_h, np, grid.x);
     if (np == 1) hipLaunchKernelGGL(sf_dwtile_kernel<1>, grid, dim3(SF_THREADS), 0, s, p);
@@ -1716,7 +1729,7 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
             tp.x = (const f16*)x; tp.ldx = d->ldx; tp.dy = (const f16*)dy; tp.lddy = d->ldy; tp.wpart = (float*)workspace;
             const dim3 tgrid((unsigned)(nblk * tp.nchunks));
             hipStream_t s = (hipStream_t)stream;
-            static const bool trace = getenv("SF_TRACE") && atoi(getenv("SF_TRACE")) != 0;
+            static const bool trace = test_hook("SF_TRACE", 0) != 0;
             if (trace) fprintf(stderr, "[sfamd] dwtile wgrad: N=%d C=%d T=%d %dx%d -> %dx%d s=%d TH=%d tiles=%d nsub=%d items=%d lds class %d blocks=%u\n", tp.N,
                                tp.C, tp.T, tp.Hi, tp.Wi, tp.Ho, tp.Wo, tp.s, tp.TH, tp.tiles_h, tp.nsub, tp.nitems, lc, tgrid.x);
 #define SF_DWW_LAUNCH(S, XF, DP) hipLaunchKernelGGL((sf_dwtile_wgrad_kernel<S, XF, DP>), tgrid, dim3(SF_THREADS), 0, s, tp)
@@ -1904,7 +1917,7 @@ extern "C" int sf_softmax_bwd(const sf_attn_desc* d, void* dp, const void* prob,
 // key tiles per wave of the key-side backward kernel: 2 (each Q / dO fragment read from LDS feeds two MFMAs) whenever the head has
 // more than 64 keys and the accumulators of two tiles fit the register file (head dim <= 96); SF_ATTN_DKV_KT=1|2 forces one
 static int attn_dkv_kt(const sf_attn_desc* d) {
-    static const int kt_env = getenv("SF_ATTN_DKV_KT") ? atoi(getenv("SF_ATTN_DKV_KT")) : 0;
+    static const int kt_env = tune_knob("SF_ATTN_DKV_KT", 0);
     if (d->D > 96) return 1;
     if (kt_env == 1 || kt_env == 2) return kt_env;
     return d->Nk > 64 ? 2 : 1;
@@ -1923,8 +1936,8 @@ static int fill_attn(AttnParams& p, const sf_attn_desc* d, const char* who) {
     const int nchq = cdiv(d->Nq, 32);
     // SF_ATTN_DKV_WGS: workgroups the query split aims for.  512 = one round of resident workgroups: MViTv2-S needs no split
     // then -- no fp32 partial tables (154 MB per call), no reduce kernel; measured against 1024 (two rounds, rounds 1-3) on
-    // the stage-3 shape: 314 vs 344 us for the whole backward call (profiles/r4_v8_attn_ab.txt)
-    static const int wgs_target = getenv("SF_ATTN_DKV_WGS") ? atoi(getenv("SF_ATTN_DKV_WGS")) : 512;
+    // the stage-3 shape: 314 vs 344 us for the whole backward call (profiles/r4/r4_v8_attn_ab.txt)
+    static const int wgs_target = tune_knob("SF_ATTN_DKV_WGS", 512);
     int splits = cdiv(wgs_target > 0 ? wgs_target : 512, (int64_t)d->B * d->heads * p.ktiles);
     if (splits > nchq / 8) splits = nchq / 8;
     if (splits < 1) splits = 1;
@@ -1943,7 +1956,7 @@ static int64_t attn_ws_bytes(const AttnParams& p, const sf_attn_desc* d) {
 // two 16-query column tiles per wave (halves the LDS operand traffic per MFMA) once there are enough workgroups;
 // SF_ATTN_QT=1|2 forces either form
 static bool attn_two_tiles(const sf_attn_desc* d) {
-    static const int qt_env = getenv("SF_ATTN_QT") ? atoi(getenv("SF_ATTN_QT")) : 0;
+    static const int qt_env = tune_knob("SF_ATTN_QT", 0);
     return qt_env ? qt_env == 2 : (int64_t)d->B * d->heads * cdiv(d->Nq, 128) >= 1024;
 }
 #define SF_ATTN_LAUNCH_Q(KERNEL, D_, two, grid, st, p)                                                     \
@@ -1984,7 +1997,7 @@ extern "C" int sf_attn_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     p.out = (f16*)o; p.ldout = ldo; p.rq = rq; p.oh = (const f16*)onehot; p.lse = lse;
     p.scale = scale; p.scale2 = scale * SF_LOG2E; p.residual = residual;
     if (!rq) p.R = 0;
-    { const char* ea = getenv("SF_ATTN_ABLATE"); p.ablate = ea ? atoi(ea) : 0; }      // diagnostic (wrong results)
+    p.ablate = tune_knob("SF_ATTN_ABLATE", 0);        // diagnostic builds only (wrong results)
     const bool qt2 = attn_two_tiles(d);
     if (qt2) p.qtiles = cdiv(d->Nq, 128);
     SF_ATTN_LAUNCH_Q(sf_attn_fwd_kernel, d->D, qt2, d->B * d->heads * p.qtiles, (hipStream_t)stream, p);
@@ -2033,11 +2046,11 @@ extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     if (check_launch("attn_bwd_dq")) return -1;
     {
         // waves per SIMD the key-side kernel is compiled for: 2 (no spills; 508 vs 505 clips/s, profiles/r1_visit14_*) or 3
-        static const int occ = getenv("SF_ATTN_DKV_OCC") ? atoi(getenv("SF_ATTN_DKV_OCC")) : 2;
+        static const int occ = tune_knob("SF_ATTN_DKV_OCC", 2);
         const int grid = d->B * d->heads * p.ktiles * p.qsplits;
         const int kd = d->D / 32;
         const int kt = attn_dkv_kt(d);
-        { const char* ea = getenv("SF_ATTN_ABLATE"); p.ablate = ea ? atoi(ea) : 0; }      // diagnostic (wrong results)
+        p.ablate = tune_knob("SF_ATTN_ABLATE", 0);        // diagnostic builds only (wrong results)
 #define SF_DKV(KD_)                                                                                              \
     do {                                                                                                         \
         if (kt == 2) hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 2, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p); \

@@ -37,7 +37,7 @@
 //   * ds_read_b64_tr_b16 reads (8 rows x 32 bytes per 32-lane group): row * pitch/4 = odd multiples of 8 banks, eight distinct
 //     8-bank windows.
 // The former pitch D + 8 (an odd number of 16-byte slots) put 5 of 16 lanes of every b128 group on a busy slot: 38-43 % of the
-// LDS cycles of these kernels were bank-conflict cycles (profiles/r4_v3_pmc_tokens.md).
+// LDS cycles of these kernels were bank-conflict cycles (profiles/r4/r4_v3_pmc_tokens.md).
 #define SF_ATTN_OHP 80             // LDS pitch of an OH / rq row
 #define SF_LOG2E 1.4426950408889634f
 #define SF_LN2 0.6931471805599453f
@@ -101,7 +101,7 @@ __device__ __forceinline__ void attn_split8(const float* src, int n, bool on, f1
 // Key-chunk staging of the query-side kernels (forward, dQ): 32 rows of K, V and of the one-hot bias matrix OH travel global ->
 // LDS directly (global_load_lds_dwordx4) into one of two buffers while the previous chunk is multiplied -- no staging
 // registers, no ds_write pass, ONE barrier per chunk (round 4; the register-staged version needed two and exposed the load
-// latency of cold operands: 164 us in the training step against 108 us cache-warm, profiles/r4_v8_attn_ab.txt).  A padded
+// latency of cold operands: 164 us in the training step against 108 us cache-warm, profiles/r4/r4_v8_attn_ab.txt).  A padded
 // [32][KP] image is SPR 16-byte slots per row (the last is the pad), slot i is written by lane i & 63 of copy instruction
 // i >> 6; the OH image [32][SF_ATTN_OHP] likewise with RS slots per row.
 template <int D>
@@ -205,9 +205,9 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
         SF_WAIT_VMEM();             // this wave's copies of chunk c have landed ...
         __syncthreads();            // ... and everybody else's; nobody reads chunk c - 1 any more
         // (diagnostic bit 64: the chunks are not refreshed after the first two)
-        if (c + 1 < nch && !((p.ablate & 64) && c >= 1))
+        if (c + 1 < nch && !((SF_ABLATE(p) & 64) && c >= 1))
             cp.issue(c + 1, KVO + ((c + 1) & 1) * Copy::BUF, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
-        if (p.ablate & 128) continue;           // (diagnostic bit 128: staging only, no arithmetic)
+        if (SF_ABLATE(p) & 128) continue;           // (diagnostic bit 128: staging only, no arithmetic)
         float x[QT][8];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
 // backward, key side: workgroup = 64 * KT keys of one (batch, head) x one split of the queries; wave w owns KT tiles of 16 keys
 // (keys (w*KT + u)*16 .. +15) and walks the split's queries in chunks of 32.  KT = 2 (round 4): every Q / dO / rq fragment read
 // from LDS feeds TWO MFMAs (one per key tile), as QT = 2 does in the query-side kernels -- at KT = 1 this kernel read ~1 KB of
-// LDS per MFMA and took 2.3x the time of the query-side kernel for 8/6 of its flops (profiles/r3_final_mvit_kernel_stats.md).
+// LDS per MFMA and took 2.3x the time of the query-side kernel for 8/6 of its flops (profiles/r3/r3_final_mvit_kernel_stats.md).
 template <int KD, int OCC, int KT>
 __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnParams p) {
     constexpr int D = 32 * KD, KP = D + 16, DT = D / 16;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
                     src = (isq ? qbase + (int64_t)qr * p.ldq : dobase + (int64_t)qr * p.ldo) + cp_off[jj];
                 SF_GLOBAL_LOAD_LDS16_ASM(src, Qb + (isq ? 0 : MSZ) + (isq ? j : j - NI) * 512);
             } else {
-                if (!bias || (p.ablate & 32)) continue;
+                if (!bias || (SF_ABLATE(p) & 32)) continue;
                 const int jr = j - 2 * NI;
                 if (cp_off[jj] >= 0 && qr < p.Nq) src = rqs_b + (int64_t)qr * p.heads * 128 + cp_off[jj];
                 SF_GLOBAL_LOAD_LDS16_ASM(src, Rb + (jr < RNI ? jr : RSZ / 512 + (jr - RNI)) * 512);
@@ -602,9 +602,9 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             s_delta[buf][tid] = deltav;
         }
         SF_WAIT_VMEM();             // this wave's copies of chunk c have landed ...
-        if (!(p.ablate & 8)) __syncthreads();   // ... and everybody else's; chunk c - 1 is no longer read by anyone
+        if (!(SF_ABLATE(p) & 8)) __syncthreads();   // ... and everybody else's; chunk c - 1 is no longer read by anyone
         if (c + 1 < c1) {
-            if (!(p.ablate & 16)) issue_chunk(c + 1, buf ^ 1);
+            if (!(SF_ABLATE(p) & 16)) issue_chunk(c + 1, buf ^ 1);
             side_load(c + 1);
         }
         f16x8 pf[KT], dsf[KT];
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
                 st[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 dp[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            if (!(p.ablate & 1)) {
+            if (!(SF_ABLATE(p) & 1)) {
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
                 const f16x8 qa = ld16(Qs + (16 * t + pl) * KP + 32 * s + 8 * g);
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
                 }
             }
             }
-            if (bias && !(p.ablate & 1)) {
+            if (bias && !(SF_ABLATE(p) & 1)) {
                 const f16x8 rh0 = ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
                 const f16x8 rl0 = ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 8 * g);
 #pragma unroll
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
                 const float ls = s_lse[buf][qi], de = s_delta[buf][qi];
 #pragma unroll
                 for (int u = 0; u < KT; ++u) {
-                    if (p.ablate & 2) {             // diagnostic: keep the dependency, drop the arithmetic
+                    if (SF_ABLATE(p) & 2) {             // diagnostic: keep the dependency, drop the arithmetic
                         pf[u][4 * t + r] = (f16)st[u][r];
                         dsf[u][4 * t + r] = (f16)dp[u][r];
                         continue;
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
                 }
             }
         }
-        if (p.ablate & 4) {
+        if (SF_ABLATE(p) & 4) {
 #pragma unroll
             for (int u = 0; u < KT; ++u) { SF_KEEP_ALIVE(pf[u]); SF_KEEP_ALIVE(dsf[u]); }
         } else {

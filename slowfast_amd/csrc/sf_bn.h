@@ -52,7 +52,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_part_fold_kernel(float* part, i
     int r = r0;
     // eight rows in flight (round 4: 6.3 -> 5.3 us per launch; same order of additions as the four-row form below).  The same
     // change in the finalize kernels' row walk, together with a shuffle fold instead of the LDS tree, made THEM slower (7.5 ->
-    // 7.9 us, profiles/r4_v17_finalize_ab.txt): they are not bound by their load chain.
+    // 7.9 us, profiles/r4/r4_v17_finalize_ab.txt): they are not bound by their load chain.
     for (; r + 8 <= r1; r += 8) {
         float v[8];
 #pragma unroll

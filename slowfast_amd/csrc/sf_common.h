@@ -118,6 +118,16 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
     } while (0)
 #endif
 
+// Diagnostic ablation switches of the hot kernels (Igemm2Params::ablate, AttnParams::ablate: parts of a kernel switched off,
+// results are garbage) exist only in -DSF_DIAG builds (`python -m slowfast_amd.build_ext --diag` -> libsfamd_diag.so, used by
+// the tools/ sweeps through SFAMD_LIBRARY).  In the product build the tests fold to constants: no branch, no register, and a stray
+// environment variable cannot corrupt a training run.
+#ifdef SF_DIAG
+#define SF_ABLATE(p) ((p).ablate)
+#else
+#define SF_ABLATE(p) 0
+#endif
+
 // Read-only table read through the SCALAR cache: a wave-uniform index into constant-address-space memory becomes s_load
 // (lgkmcnt), which keeps it out of the vector-memory queue whose counted waits pace the direct-to-LDS copies (an ordinary
 // global_load beside them makes hipcc wait vmcnt(0) at its first use and drains the pipeline).  The table must have been
@@ -173,7 +183,7 @@ __device__ __attribute__((aligned(64))) const uint32_t sf_zero_line[16] = {0, 0,
 // fp32 side rows of a token residual stream (MultiScaleBlock's residual sums, attention.py:500-510):
 // rows m with m % period == 0 (period 1: every row) carry an fp32 copy at side row m / period, pitch ld floats.  The
 // class-token row of MViT is the only row the classifier reads, and 32 fp16 roundings of it (two residual sums per block) were
-// the largest single term of the logits' deviation from the fp32 reference (profiles/r3_mvit_logits_bisect.md).
+// the largest single term of the logits' deviation from the fp32 reference (profiles/r3/r3_mvit_logits_bisect.md).
 struct F32Rows {
     const float* in;    // optional residual operand rows (nullptr: the kernel's 16-bit residual operand is used)
     float* out;         // result rows; nullptr = feature off

@@ -33,7 +33,7 @@ struct DwParams {
 
 // Row block of this workgroup.  Workgroup b runs on XCD b % 8 (sf_common.h: xcd_remap): with the plain order the row blocks of
 // neighbouring lines and frames -- which share most of their 3x3x3 input window -- sit behind eight different L2s, and every
-// input line is fetched by several of them (measured on the stage-3 pooling of MViTv2-S, profiles/r4_v3_pmc_tokens.md: L2 hit
+// input line is fetched by several of them (measured on the stage-3 pooling of MViTv2-S, profiles/r4/r4_v3_pmc_tokens.md: L2 hit
 // rate 25 %, FETCH_SIZE 3.4x the input).  The remap gives every XCD a contiguous range of row blocks (whole samples), so a
 // window is re-read from ONE L2.  A bijection of the block ids: partial-sum tables are still folded in index order.
 // The weight-gradient grids carry the kt plane (or tap chunk) in blockIdx.z: the planes of one row block go to the same XCD.
@@ -314,7 +314,7 @@ __device__ __forceinline__ void cvt8(const f16x8& v, float (&o)[8]) {
 //   * when the row length is a multiple of the 4-column block only column 0 of a group can fall outside (uniform test);
 //   * weights are staged as fp32 (no per-plane weight converts; the 141 VGPRs of this kernel cap residency at 3 waves
 //     per SIMD long before the larger LDS footprint does).
-// Measured with the same restructuring of the data- and weight-gradient stencils (profiles/r3_v11_dw_v2_ab.txt): X3D-M
+// Measured with the same restructuring of the data- and weight-gradient stencils (profiles/r3/r3_v11_dw_v2_ab.txt): X3D-M
 // 1183-1191 -> 1198-1203 clips/s, MViTv2-S 547-549 -> 551-553; the first version is gone.
 __device__ __attribute__((aligned(16))) f16 sf_dw_zero_line[8] = {};
 

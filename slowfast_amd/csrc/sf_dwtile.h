@@ -6,7 +6,7 @@
 //
 // Why: the W-blocked stencils of sf_dwconv.h read every input element 13.5 times through the vector-memory path and convert it
 // from fp16 each time -- 60 VALU lane-operations per output element, 129 VALU instructions per (kt, kh) plane for 48 packed
-// FMAs (profiles/r4_v3_pmc_tokens.md, r4_v4: 57 us for a 15 us stream even with the window re-reads served by one L2).
+// FMAs (profiles/r4/r4_v3_pmc_tokens.md, r4_v4: 57 us for a 15 us stream even with the window re-reads served by one L2).
 // Here a workgroup sweeps the T frames of one (sample, row tile, 32-channel chunk):
 //   * every input plane tile (with its halo, zero-filled outside the image) is fetched ONCE, converted to fp32 ONCE and kept
 //     in LDS; the 9 (kh, kw) neighbours of an output position are ds_read_b128 pairs at compile-time-constant offsets -- no
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwtile_kernel(DwTileParams p) {
 // <12288, 3168> = 67 KiB, two per CU (a whole 14 x 14 input plane with its 7 x 7 stride-2 output); <12288, 6304> = 85 KiB, one
 // per CU.  Planes wider than 16 stay on the stencil: with a 32-float pitch (2-way conflicts in the staging stores) and rows cut
 // into short segments they fit three workgroups per CU but measured no faster than the stencil (28 x 28 stride 2: 67 against
-// 61 us, 56 x 56: 220 = 220 us) and slowed the 14-wide ones (52 -> 56, 30 -> 38 us; profiles/r4_v19_dw_bench.txt).
+// 61 us, 56 x 56: 220 = 220 us) and slowed the 14-wide ones (52 -> 56, 30 -> 38 us; profiles/r4/r4_v19_dw_bench.txt).
 #define SF_DWW_PP SF_DWT_PP
 #define SF_DWW_XF_S 7168
 #define SF_DWW_DP_S (98 * SF_DWT_CC + 32)
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(SF_THREADS, 3) void sf_dwtile_wgrad_kernel(DwTileWg
                 const f16* const dyr = dyp + (int)r * p.Wo * SF_DWT_CC;
                 // sliding window over the staged row, unrolled over its rotation (3 positions at stride 1, 2 at stride 2): the
                 // window registers change roles instead of being copied (16 v_mov per position in the rolled form, of ~40
-                // VALU instructions per position on a kernel that is ~60 % VALU-bound; profiles/r4_v23_pmc2_dw_insts.md)
+                // VALU instructions per position on a kernel that is ~60 % VALU-bound; profiles/r4/r4_v23_pmc2_dw_insts.md)
                 float xa[8], xb[8], xc[8];
                 auto fma3 = [&](const float (&a)[8], const float (&b)[8], const float (&c)[8], int w) {
                     float d[8];

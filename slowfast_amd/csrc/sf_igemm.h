@@ -124,7 +124,7 @@ __device__ __forceinline__ void bnb_reduce_store(float (&sg)[8], float (&sgy)[8]
 // Two loader experiments were measured and removed: an incremental tap iterator for the register-staged loader (3 % slower than
 // the dividing gather, profiles/r1/r1_visit19_ab.txt) and a three-stage ring for the direct-to-LDS path (inline-asm copies, raw
 // barrier, counted waits: no gain on any pointwise layer, -1 % on MViTv2-S at three workgroups per CU,
-// profiles/r3_v10_gl3_ab.txt -- these layers are not latency-bound).
+// profiles/r3/r3_v10_gl3_ab.txt -- these layers are not latency-bound).
 // F32R: the fp32 side rows of the output (IgemmParams::f32) are compiled in -- a separate instantiation, because even the dead
 // branch costs the 128-VGPR variants 20 spilled registers (hipcc -Rpass-analysis=kernel-resource-usage, round 4).
 template <int BN, int WM, int WN, bool PW, bool GL = false, bool OCC4 = false, bool F32R = false>

@@ -3,7 +3,7 @@
 // Same contraction as sf_igemm.h (reference call sites: slowfast/models/resnet_helper.py:331-369 BottleneckTransform a/b/c,
 // :485-493 ResBlock.branch1, video_model_builder.py:147-154 FuseFastToSlow.conv_f2s; nn.Linear of attention.py / common.py):
 //   Y[m, n] = sum_{tap, c} SRC[pos(m) + delta(tap)][c] * W[n][wcol(tap) + c]
-// What changed against the first kernel (profiles/r2_*: its loaders were VALU-bound -- three magic-number divisions, bounds
+// What changed against the first kernel (profiles/r2/r2_*: its loaders were VALU-bound -- three magic-number divisions, bounds
 // checks and a BatchNorm transform per 16-byte operand group and K step -- and every 32-deep K step ended in vmcnt(0) + barrier):
 //   * a K step never straddles a tap (C % BK == 0), so the tap of a step is WAVE-UNIFORM: one scalar table lookup per step,
 //     no per-lane tap decomposition.  A lane keeps, for the rows it copies, the element offset of the row's base position and
@@ -239,9 +239,9 @@ __device__ __forceinline__ void i2_epilogue(const Igemm2Params& p, f32x4 (&acc)[
 // Tried in round 3 and removed again (the code is in the history, commits c9ff12f / 6f38f0a; evidence under profiles/):
 //  * a STRIP variant -- ONE staged strip of source rows per channel chunk serves every tap, a tap is a row offset into it,
 //    padding is masked in the fragment: 6x fewer gathered bytes on 3x3 layers, and 15-30 % SLOWER on every eligible layer
-//    (61 VALU instructions per K step against 21; profiles/r3_v5_strip_ab.txt);
+//    (61 VALU instructions per K step against 21; profiles/r3/r3_v5_strip_ab.txt);
 //  * issuing the next stage's copies between the two MFMA halves of a stage in half of the waves: a wash
-//    (profiles/r3_v7_stagger_ab.txt).  profiles/r3_v6_igemm2_ablation.md shows what bounds the loop instead: the copy stream
+//    (profiles/r3/r3_v7_stagger_ab.txt).  profiles/r3/r3_v6_igemm2_ablation.md shows what bounds the loop instead: the copy stream
 //    alone and the MFMA stream alone each take 75-80 % of the kernel's time and overlap only partly.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NST, bool F32R = false>   // F32R: see sf_igemm_kernel
 // register cap: the 32-deep variant must fit TWO workgroups per CU (4 waves per SIMD -> 128 VGPRs), the 64-deep one runs alone
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
             for (int i = 0; i < TM; ++i) af[i] = ld16(As + i2_lds_off<BK>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = ld16(Bs + i2_lds_off<BK>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
-            if (p.ablate & 4) {
+            if (SF_ABLATE(p) & 4) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) SF_KEEP_ALIVE(af[i]);
 #pragma unroll
@@ -391,14 +391,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BK == 32 ? 2 : 1) * (WAVES
             } else {
                 SF_WAIT_VMEM();
             }
-            if (!(p.ablate & 16)) SF_BARRIER_KEEP_VMEM();           // ... for every wave; stage ks - 1 is no longer read
-            if (issued < ksteps) { if (!(p.ablate & 1)) issue(tap_i, c_i, nxt); advance(); ++issued; }
-            if (!(p.ablate & 2)) compute(cur);
+            if (!(SF_ABLATE(p) & 16)) SF_BARRIER_KEEP_VMEM();           // ... for every wave; stage ks - 1 is no longer read
+            if (issued < ksteps) { if (!(SF_ABLATE(p) & 1)) issue(tap_i, c_i, nxt); advance(); ++issued; }
+            if (!(SF_ABLATE(p) & 2)) compute(cur);
             cur = cur == NST - 1 ? 0 : cur + 1;
             nxt = nxt == NST - 1 ? 0 : nxt + 1;
         }
         __syncthreads();                                            // the epilogue staging reuses the operand buffers
-        if (p.ablate & 8) return;
+        if (SF_ABLATE(p) & 8) return;
     }
 
     i2_epilogue<BM, BN, WAVES_M, WAVES_N, F32R>(p, acc, smem, s_red, s_orow, mt, nt);

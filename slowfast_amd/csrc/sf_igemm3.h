@@ -10,7 +10,7 @@
 //   * the two wave rows run ONE BARRIER APART: while waves 0-3 (one per SIMD) multiply, waves 4-7 (their SIMD partners) read
 //     fragments and issue copies, and vice versa -- the matrix pipe of a SIMD always has one wave in its MFMA cluster
 //     (s_setprio 1 around it) instead of all eight waves standing in copy issue together (sf_igemm2's measured loss,
-//     profiles/r3_v6_igemm2_ablation.md: copy stream and MFMA stream each 75-80 % of the kernel, imperfectly overlapped);
+//     profiles/r3/r3_v6_igemm2_ablation.md: copy stream and MFMA stream each 75-80 % of the kernel, imperfectly overlapped);
 //   * copies run up to six phases ahead of their use: two tile buffers of four half-tiles (A rows 0-127 / 128-255, B rows
 //     0-127 / 128-255; 16 KB each, 128 KB in all), a half-tile slot is re-filled in the phase after its last fragment read;
 //     ONE counted s_waitcnt vmcnt per K tile, never zero inside the loop.

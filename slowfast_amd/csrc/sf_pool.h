@@ -40,7 +40,7 @@ __device__ __forceinline__ void bn_act8(const f16x8& v, const float (&sc)[8], co
 }
 
 // (Round 4: an XCD-contiguous workgroup order -- what helped the depthwise stencils -- made the backward gather SLOWER here,
-// 136 -> 174 us on the MViT skip pooling, profiles/r4_v6_knobs_ab.txt; the plain order stays.)
+// 136 -> 174 us on the MViT skip pooling, profiles/r4/r4_v6_knobs_ab.txt; the plain order stays.)
 // One thread per (pooled position, 8 channels).  The FIRST maximum in scan order wins (the element torch's
 // max_pool3d records); its window-local index is kept for the backward pass.
 __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_gather_kernel(RelPosPara
 // Each workgroup owns chunks of SF_RELPOS_SC_ROWS whole rows of E: it zero-fills them with 16-byte stores and then, behind a
 // barrier, drops the rows' R gradient entries into place.  (A hipMemsetAsync in front of a flat scatter did the same in eager
 // launches, but as a memset node of a captured graph the fill did not take effect before the readers of E on ROCm 7.2: from
-// the second replay on E kept what the block's previous owner had left -- profiles/r4_v13_graph_memset.md.  libsfamd issues
+// the second replay on E kept what the block's previous owner had left -- profiles/r4/r4_v13_graph_memset.md.  libsfamd issues
 // no memset / memcpy stream operations any more: everything a captured step does is a kernel node.)
 #define SF_RELPOS_SC_ROWS 32
 __global__ __launch_bounds__(SF_THREADS) void sf_relpos_scatter_kernel(RelPosParams p, f16* E, int lde, FastDiv fdR, int R,

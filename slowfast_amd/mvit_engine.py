@@ -32,7 +32,7 @@ FUSE_COLSUM = os.environ.get("SF_FUSE_COLSUM", "1") != "0"
 # residual sum -- the only row the classifier reads -- ALSO kept in fp32: the GEMM epilogue that adds the residual sums those rows
 # from its fp32 accumulators (sf_gemm_rows32), the LayerNorms that read the stream normalise them from the fp32 copy.  The 16-bit
 # rows are the rounded fp32 rows, so every other consumer (skip pooling, backward) is unchanged.
-# Measured on MI355X (profiles/r4_v1_mvit_resid32_ab.txt), MViTv2-S 16x224^2 full-size logits against the fp32 oracle:
+# Measured on MI355X (profiles/r4/r4_v1_mvit_resid32_ab.txt), MViTv2-S 16x224^2 full-size logits against the fp32 oracle:
 #   SF_MVIT_RESID32=0     16-bit stream only              1.192e-3   549.0 clips/s
 #   (default)             class-token rows                9.05e-4    547.9
 #   SF_MVIT_RESID32=full  + every row of the last stage   9.09e-4    545-546   (no measurable gain for 77 MB of fp32 rows: opt-in)

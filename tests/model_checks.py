@@ -482,7 +482,7 @@ def check_full_size(preset, device, opts=(), batch=2, boxes_per_clip=0, seed=99,
     res["worst_params_unmasked"] = _worst_contributors(grads, o_grads)
     # Flat bound, no yardstick (round 4): the north star's 1e-3 on the logits of every case.  MViTv2-S at full size read
     # 1.15-1.19e-3 while the whole residual stream was 16-bit; the class-token rows of every residual sum are now also kept in
-    # fp32 (mvit_engine.ResidSide): 9.05e-4 measured on MI355X (profiles/r4_v1_mvit_resid32_ab.txt; profiles/r4_mvit_logits_bisect.md
+    # fp32 (mvit_engine.ResidSide): 9.05e-4 measured on MI355X (profiles/r4/r4_v1_mvit_resid32_ab.txt; profiles/r4/r4_mvit_logits_bisect.md
     # has the oracle-side ablation of the same storage policy, mvit_ref.engine_resid_policy).
     b_logits = tol
     # the reference's own mixed-precision path on this very case, recorded beside every bound (informational for the quantities

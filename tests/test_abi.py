@@ -104,7 +104,7 @@ def test_error_reporting_through_c_abi(sim):
 
 def test_captured_step_is_kernel_nodes_only():
     """libsfamd issues kernel launches only: a hipMemsetAsync in front of the rel-pos scatter became a memset node under stream
-    capture whose fill did not take effect before its readers from the second replay on (profiles/r4_v13_graph_memset.md)."""
+    capture whose fill did not take effect before its readers from the second replay on (profiles/r4/r4_v13_graph_memset.md)."""
     import glob
     import re
     csrc = os.path.join(ROOT, "slowfast_amd", "csrc")

@@ -240,7 +240,7 @@ def test_segmented_graph_replay_matches_eager(gpu, name):
 def _poisoned_allocations():
     """Every torch.empty / empty_like / new_empty comes back filled with NaN (floating point) or 0xA5 (uint8 masks): a kernel
     that reads memory nobody wrote -- or relies on a fill that does not happen, as the memset node of round 4 did under graph
-    replay (profiles/r4_v13_graph_memset.md) -- shows up as a different result, in eager launches and in captured graphs alike
+    replay (profiles/r4/r4_v13_graph_memset.md) -- shows up as a different result, in eager launches and in captured graphs alike
     (the fills are launches like any other and are captured with the step)."""
     orig = (torch.empty, torch.empty_like, torch.Tensor.new_empty)
 

@@ -1,7 +1,7 @@
 """Who launches the small device-to-device copies?  Reads a rocprofv3 --kernel-trace CSV (kernel_trace.csv), orders the
 dispatches by start time and prints, for every dispatch whose kernel name contains `needle` (default copyBuffer), the kernels
 right before and after it -- as a histogram of (previous, next) pairs.
-    python tools/trace_neighbors.py <kernel_trace.csv> [needle] > profiles/r3_copybuffer_neighbors.txt"""
+    python tools/trace_neighbors.py <kernel_trace.csv> [needle] > profiles/r3/r3_copybuffer_neighbors.txt"""
 import collections
 import csv
 import sys

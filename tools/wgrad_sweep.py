@@ -1,5 +1,5 @@
 """Weight-gradient schedule sweep on the SlowFast-8x8-R50 layer geometries (round 3): sf_conv_wgrad per layer under
-SF_WGRAD2_BLOCKS = target workgroup count (-> number of split partials).  (The first sweep, profiles/r3_v2_wgrad_sweep.md, also
+SF_WGRAD2_BLOCKS = target workgroup count (-> number of split partials).  (The first sweep, profiles/r3/r3_v2_wgrad_sweep.md, also
 had a six-stage one-workgroup-per-CU ring, SF_WGRAD2_NST=6; it lost everywhere and is gone.)  HIP events around `iters` back-to-back calls; the operands of a layer are
 re-created per layer (so small layers are cache-warm, as in tools/microbench.py).
     python tools/wgrad_sweep.py --md gpurun_out/x/wgrad_sweep.md"""
@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--filter", default="slow")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    # (co-tile rows of sf_wgrad2_kernel, workgroup target).  profiles/r3_final_wgrad_sweep.md also has 64-row co-tiles for the wide
+    # (co-tile rows of sf_wgrad2_kernel, workgroup target).  profiles/r3/r3_final_wgrad_sweep.md also has 64-row co-tiles for the wide
     # layers (a knob that existed for that sweep: they lose 20-40 % on res3-res5 and the knob is gone)
     variants = [("128", b) for b in (256, 384, 448, 512, 640, 768, 1024)]
     lines = ["| layer | x | " + " | ".join(f"bmw{n} b{b}" for n, b in variants) + " | best |", "|---|---:|" + "---:|" * (len(variants) + 1)]
