@@ -235,6 +235,33 @@ def run_pathways(n, fn, like):
     return outs
 
 
+# Independent BRANCHES inside a block (the q and the k / v pooling chains of MultiScaleAttention, attention.py:13-45, 320-351:
+# three depthwise convolutions + LayerNorms on disjoint channel slices of qkv) on two streams: each of these launches covers a few
+# hundred workgroups on a 256-CU chip -- side by side they fill it.  Same fork / join discipline as run_pathways.
+BRANCH_STREAMS = os.environ.get("SF_BRANCH_STREAMS", "1") != "0"
+
+
+def run_branches(fns, like):
+    """[fn() for fn in fns] -- fns[0] on the current stream, the others each on a side stream, forked after everything already
+    enqueued and joined before this returns."""
+    if not (BRANCH_STREAMS and len(fns) > 1 and like.is_cuda):
+        return [fn() for fn in fns]
+    dev = like.device
+    main = torch.cuda.current_stream(dev)
+    outs = [None] * len(fns)
+    sides = []
+    for i in range(1, len(fns)):
+        side = _pathway_stream(dev, ("branch", i))
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            outs[i] = fns[i]()
+        sides.append(side)
+    outs[0] = fns[0]()
+    for side in sides:
+        main.wait_stream(side)
+    return outs
+
+
 def _join_pathways(device):
     """The CURRENT stream of ``device`` waits for every pathway stream and for the stream they were forked from: whatever it
     enqueues next (a gradient all-reduce, an optimizer pass) sees the gradients of all pathways."""

@@ -307,16 +307,23 @@ def _fused_attention(plan):
     return plan.D % 32 == 0 and plan.D <= 128 and (not plan.rel or kt + kh + kw <= 48)
 
 
-def _core_forward(att, plan, qn, kn, vn):
+def _relpos_forward(att, plan, qn):
+    """The q . rel_pos_{h,w,t} contractions (attention.py:48-147): a function of q alone -> (rq, packed tables for the backward);
+    (None, None) without relative positions.  attention_forward runs it inside the q branch (engine.run_branches)."""
+    if not plan.rel:
+        return None, None
+    tables = plan.tables(att)
+    t16, t16t = tokens.relpos_tables16(tables)
+    return tokens.relpos_fwd(plan.desc, qn, tables, plan.idx, t16=t16), t16t
+
+
+def _core_forward(att, plan, qn, kn, vn, rel=None):
     """softmax(q*scale k^T + rel-pos bias) v (+ q on the non-cls rows: residual pooling), attention.py:355-385.
-    qn / kn / vn: [B, N*, att] token tensors of any row pitch -> (o [B, Nq, att], saved tensors of the core)."""
+    qn / kn / vn: [B, N*, att] token tensors of any row pitch -> (o [B, Nq, att], saved tensors of the core).
+    ``rel``: what _relpos_forward(att, plan, qn) returned, when the caller already ran it."""
     B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
     Nq, Nk, lds = plan.Nq, plan.Nk, plan.lds
-    tables = plan.tables(att) if plan.rel else None
-    t16 = t16t = None
-    if plan.rel:
-        t16, t16t = tokens.relpos_tables16(tables)
-    rq = tokens.relpos_fwd(plan.desc, qn, tables, plan.idx, t16=t16) if plan.rel else None
+    rq, t16t = rel if rel is not None else _relpos_forward(att, plan, qn)
     if _fused_attention(plan):
         if plan.rel and plan.onehot is None:
             plan.onehot = tokens.attn_onehot(plan.desc, qn.device)
@@ -340,9 +347,11 @@ def rows_not_dense(x):
     return x.stride(-2) != x.shape[-1]
 
 
-def _core_backward(att, plan, core, do, dq_out=None, dkv_out=None):
+def _core_backward(att, plan, core, do, dq_out=None, dkv_out=None, defer_rel=False):
     """d(o) -> (dq, dk, dv) of the attention core, each [B, N*, att]; writes the gradients of rel_pos_{h,w,t} and adds
-    their term to dq.  dq_out / dkv_out: destinations the fused kernels may write in place (slices of d(qkv))."""
+    their term to dq.  dq_out / dkv_out: destinations the fused kernels may write in place (slices of d(qkv)).
+    ``defer_rel``: returns (dq, dk, dv, drq) WITHOUT the rel-pos part; the caller runs _relpos_backward(att, plan, core, drq, dq)
+    before it uses dq (attention_backward does so inside its q branch)."""
     B, heads, D, C = plan.B, plan.heads, plan.D, plan.att
     Nq, Nk, lds = plan.Nq, plan.Nk, plan.lds
     qn, kn, vn = core["qn"], core["kn"], core["vn"]
@@ -369,11 +378,20 @@ def _core_backward(att, plan, core, do, dq_out=None, dkv_out=None):
         dkn = torch.empty((B, Nk, C), dtype=_f16, device=dev)
         tokens.bgemm_tn_heads(dS, (heads * Nq * lds, Nq * lds), lds, qn, (Nq * C, D), C, Nq, Nk, D, dkn, (Nk * C, D), C,
                               B, heads)
+    if defer_rel:
+        return dqn, dkn, dvn, drq
+    _relpos_backward(att, plan, core, drq, dqn)
+    return dqn, dkn, dvn
+
+
+def _relpos_backward(att, plan, core, drq, dqn):
+    """Gradient of the q . rel_pos_{h,w,t} contractions: the tables' gradients, and their term added to dq in place."""
+    qn = core["qn"]
     if plan.rel:
         params = (att.rel_pos_h, att.rel_pos_w, att.rel_pos_t)
         dests = [_grad_dest(t) for t in params]
         # a resampled table receives its gradient through the transposed interpolation map
-        tmp = [None if w is None else torch.empty((w.shape[0], plan.D), dtype=torch.float32, device=do.device)
+        tmp = [None if w is None else torch.empty((w.shape[0], plan.D), dtype=torch.float32, device=dqn.device)
                for w in plan.interp]
         tokens.relpos_bwd(plan.desc, qn, [d[0] if t is None else t for d, t in zip(dests, tmp)], plan.idx, drq, dqn,
                           [d[0] if t is None else t for d, t in zip(dests, tmp)],
@@ -381,7 +399,6 @@ def _core_backward(att, plan, core, do, dq_out=None, dkv_out=None):
         for (g, zero_first), t, w in zip(dests, tmp, plan.interp):
             if w is not None:
                 g.copy_(w.t() @ t) if zero_first else g.add_(w.t() @ t)
-    return dqn, dkn, dvn
 
 
 def _pool_norm(x_in, pool, norm_unit, geom, B, N, C, D):
@@ -397,16 +414,35 @@ def attention_forward(att, plan, qkv):
     Nq, Nk = plan.Nq, plan.Nk
     q_in, k_in, v_in = qkv[..., 0:C], qkv[..., C:2 * C], qkv[..., 2 * C:3 * C]
     qp = kp = vp = sq = sk = sv_ = None
-    if plan.gq is not None:
-        qp, qn, sq = _pool_norm(q_in, att.pool_q, att._norm_q, plan.gq, B, Nq, C, D)
+
+    rel = None
+
+    def q_chain():
+        qp_, qn_, sq_ = _pool_norm(q_in, att.pool_q, att._norm_q, plan.gq, B, Nq, C, D)
+        return qp_, qn_, sq_, _relpos_forward(att, plan, qn_)      # the rel-pos contractions need q only: same branch
+
+    def k_chain():
+        return _pool_norm(k_in, att.pool_k, att._norm_k, plan.gk, B, Nk, C, D)
+
+    def v_chain():
+        return _pool_norm(v_in, att.pool_v, att._norm_v, plan.gk, B, Nk, C, D)
+
+    def kv_chain():
+        return k_chain(), v_chain()
+
+    if plan.gq is not None and plan.gk is not None:
+        # the q chain and the k / v chains read disjoint channel slices of qkv: two streams (engine.run_branches)
+        (qp, qn, sq, rel), ((kp, kn, sk), (vp, vn, sv_)) = engine.run_branches([q_chain, kv_chain], qkv)
     else:
-        qn = q_in                                   # channel slice of qkv (row pitch 3C): used in place
-    if plan.gk is not None:
-        kp, kn, sk = _pool_norm(k_in, att.pool_k, att._norm_k, plan.gk, B, Nk, C, D)
-        vp, vn, sv_ = _pool_norm(v_in, att.pool_v, att._norm_v, plan.gk, B, Nk, C, D)
-    else:
-        kn, vn = k_in, v_in
-    o, core = _core_forward(att, plan, qn, kn, vn)
+        if plan.gq is not None:
+            qp, qn, sq, rel = q_chain()
+        else:
+            qn = q_in                               # channel slice of qkv (row pitch 3C): used in place
+        if plan.gk is not None:
+            (kp, kn, sk), (vp, vn, sv_) = kv_chain()
+        else:
+            kn, vn = k_in, v_in
+    o, core = _core_forward(att, plan, qn, kn, vn, rel=rel)
     return o, dict(qp=qp, kp=kp, vp=vp, sq=sq, sk=sk, sv=sv_, core=core)
 
 
@@ -421,28 +457,46 @@ def attention_backward(att, plan, qkv, sv, do):
         # gradients of un-pooled q / k / v ARE slices of d(qkv): the kernels write them in place (row pitch 3C)
         dq_out = dqkv[..., 0:C] if plan.gq is None and not plan.rel else None
         dkv_out = (dqkv[..., C:2 * C], dqkv[..., 2 * C:3 * C]) if plan.gk is None else None
-    dqn, dkn, dvn = _core_backward(att, plan, core, do, dq_out=dq_out, dkv_out=dkv_out)
+    dqn, dkn, dvn, drq = _core_backward(att, plan, core, do, dq_out=dq_out, dkv_out=dkv_out, defer_rel=True)
     # LayerNorm(head_dim) and depthwise pooling backward.  Tensors that were not pooled skip both: their gradient is
     # (or is copied into) the matching slice of d(qkv).
-    work = []
-    if plan.gq is not None:                                  # LayerNorm(head_dim) backward, then the pooling conv
-        dqp = att._norm_q.backward(dqn.view(-1, D), sv["qp"].view(-1, D), *sv["sq"]).view(B, Nq, C)
-        work.append((0, dqp, att.pool_q, plan.gq))
-    elif dqn.data_ptr() != dqkv.data_ptr():
-        dqkv[..., 0:C].copy_(dqn)
-    if plan.gk is not None:
-        dkp = att._norm_k.backward(dkn.view(-1, D), sv["kp"].view(-1, D), *sv["sk"]).view(B, Nk, C)
-        dvp = att._norm_v.backward(dvn.view(-1, D), sv["vp"].view(-1, D), *sv["sv"]).view(B, Nk, C)
-        work += [(1, dkp, att.pool_k, plan.gk), (2, dvp, att.pool_v, plan.gk)]
-    elif dkn.data_ptr() != dqkv[..., C:2 * C].data_ptr():
-        dqkv[..., C:2 * C].copy_(dkn)
-        dqkv[..., 2 * C:3 * C].copy_(dvn)
-    # depthwise pooling backward into the slices of d(qkv)
-    for i, dy, pool, geom in work:
+    def pool_back(i, dy, pool, geom):                        # depthwise pooling backward into slice i of d(qkv)
         x_in = qkv[..., i * C:(i + 1) * C]
         tokens.dwconv_dgrad(dy.view(-1, C), pool.weight, geom, out=dqkv[..., i * C:(i + 1) * C])
         dw, zero_first = _grad_dest(pool.weight)
         tokens.dwconv_wgrad(x_in, dy.view(-1, C), geom, dw, zero_first=zero_first)
+
+    def q_chain():                                           # rel-pos, LayerNorm(head_dim) backward, then the pooling conv
+        _relpos_backward(att, plan, core, drq, dqn)
+        dqp = att._norm_q.backward(dqn.view(-1, D), sv["qp"].view(-1, D), *sv["sq"]).view(B, Nq, C)
+        pool_back(0, dqp, att.pool_q, plan.gq)
+
+    def k_chain():
+        dkp = att._norm_k.backward(dkn.view(-1, D), sv["kp"].view(-1, D), *sv["sk"]).view(B, Nk, C)
+        pool_back(1, dkp, att.pool_k, plan.gk)
+
+    def v_chain():
+        dvp = att._norm_v.backward(dvn.view(-1, D), sv["vp"].view(-1, D), *sv["sv"]).view(B, Nk, C)
+        pool_back(2, dvp, att.pool_v, plan.gk)
+
+    def kv_chain():
+        k_chain()
+        v_chain()
+
+    if plan.gq is not None and plan.gk is not None and not engine.GRADS_VIA_AUTOGRAD:
+        engine.run_branches([q_chain, kv_chain], do)         # disjoint slices of d(qkv), disjoint parameters: two streams
+    else:
+        if plan.gq is not None:
+            q_chain()
+        else:
+            _relpos_backward(att, plan, core, drq, dqn)
+            if dqn.data_ptr() != dqkv.data_ptr():
+                dqkv[..., 0:C].copy_(dqn)
+        if plan.gk is not None:
+            kv_chain()
+        elif dkn.data_ptr() != dqkv[..., C:2 * C].data_ptr():
+            dqkv[..., C:2 * C].copy_(dkn)
+            dqkv[..., 2 * C:3 * C].copy_(dvn)
     return dqkv
 
 

@@ -304,6 +304,22 @@ def test_pathway_streams_do_not_change_the_step(gpu, monkeypatch):
     assert engine._pathway_streams, "the Fast pathway must have run on its own stream"
 
 
+@pytest.mark.gpu
+def test_branch_streams_do_not_change_the_step(gpu, monkeypatch):
+    """engine.run_branches (the q and the k / v pooling chains of MultiScaleAttention on two HIP streams, forward and backward):
+    four MViT training steps bit for bit what the single-stream run gives -- eager, one captured graph, segmented graphs."""
+    from slowfast_amd import engine
+    monkeypatch.setattr(engine, "BRANCH_STREAMS", False)
+    l0, p0, _, _ = _run_model(gpu, "mvit_tiny", segmented=False, use_graph=False, steps=4)
+    monkeypatch.setattr(engine, "BRANCH_STREAMS", True)
+    for rep in range(3):
+        for segmented, use_graph in ((False, False), (True, True), (False, True)):
+            l1, p1, _, _ = _run_model(gpu, "mvit_tiny", segmented=segmented, use_graph=use_graph, steps=4)
+            assert l1 == l0, (rep, segmented, use_graph, l0, l1)
+            for a, b in zip(p0, p1):
+                assert torch.equal(a, b), (rep, segmented, use_graph)
+
+
 def test_static_clone_keeps_wpair_tag_and_strides():
     """TrainStep._static_clone: the captured graph's copy of a packed clip keeps the W-pair tag and the channels-last strides
     (without the tag StemConvUnit would try to convert an 8-channel tensor and fail at capture)."""

@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5 visit 19: rel-pos contractions inside the q branch (forward and backward)
+cd "$GRAFT_REPO_ROOT"; D=gpurun_out/v19; mkdir -p $D; export TMPDIR=/tmp PYTHONPATH=$PWD
+timeout 900 python -m pytest -q -m gpu -x --tb=short tests/test_step.py -k "branch_streams or mvit" > $D/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $D/pytest.log | cut -c1-300
+ROUNDS=3 bash tools/gpu/ab.sh $D --preset MVITv2_S_16x4 -- "mvit branches=1:SF_BRANCH_STREAMS=1" "mvit branches=0:SF_BRANCH_STREAMS=0"
+timeout 900 python -m pytest -q -m gpu -x --tb=short tests/test_model_gpu.py -k "MVIT or mvit" > $D/pytest_model.log 2>&1; echo "pytest mvit model rc=$?"; tail -3 $D/pytest_model.log | cut -c1-300
+echo "exit 0"
