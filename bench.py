@@ -325,6 +325,19 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
         with KernelProfiler() as prof:
             eager_step()
         summ = prof.summary()
+        # the same step on ONE stream (engine.run_pathways / run_branches off): what the dominant kernel does when nothing runs
+        # beside it -- reported next to the figure of the step as it is timed (`roofline.serial`), never instead of it
+        from slowfast_amd import engine as _eng
+        serial = None
+        if dev.type == "cuda" and (_eng.PATHWAY_STREAMS or _eng.BRANCH_STREAMS):
+            keep = (_eng.PATHWAY_STREAMS, _eng.BRANCH_STREAMS)
+            _eng.PATHWAY_STREAMS = _eng.BRANCH_STREAMS = False
+            try:
+                with KernelProfiler() as prof1:
+                    eager_step()
+                serial = prof1.summary()
+            finally:
+                _eng.PATHWAY_STREAMS, _eng.BRANCH_STREAMS = keep
         tot = sum(v["ms"] for v in summ.values())
         for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]:
             kernels[k] = {"calls": v["calls"], "ms": round(v["ms"], 3), "avg_ms": round(v["avg_ms"], 4),
@@ -347,9 +360,16 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
         roof["launches_per_step"] = v["calls"]
         roof["kernel_ms_per_step"] = round(tot, 2)
         roof["timing_note"] = ("entry points timed with HIP events on the launch stream in ONE extra EAGER step after the timed "
-                               "region: includes event / launch overhead (the per-kernel sum exceeds the graph-replayed "
-                               "ms_per_step by a few per cent); the rocprofv3 --kernel-trace table of the same command is under "
-                               "profiles/")
+                               "region: includes event / launch overhead; independent pathways / branches run on two streams "
+                               "(engine.run_pathways / run_branches), so kernels overlap -- the per-kernel sum exceeds "
+                               "ms_per_step and a kernel's duration includes what its neighbour on the other stream costs it; "
+                               "the rocprofv3 --kernel-trace table of the same command is under profiles/")
+        if serial is not None and name in serial:
+            sv = serial[name]
+            key, peak = ("tflops", MFMA_PEAK_TFLOPS) if roof["bound"] == "mfma" else ("gbs", HBM_PEAK_GBS)
+            roof["serial"] = {"achieved": round(sv[key], 1), "frac": round(sv[key] / peak, 4), "avg_launch_ms": round(sv["avg_ms"], 4),
+                              "kernel_ms_per_step": round(sum(x["ms"] for x in serial.values()), 2),
+                              "note": "the same eager step on ONE stream: the kernel without a neighbour"}
 
     out = None
     if rank == 0:

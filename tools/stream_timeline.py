@@ -20,8 +20,15 @@ def main():
             q = r.get("Queue_Id") or r.get("Stream_Id") or "0"
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), q, r["Kernel_Name"]))
     rows.sort()
+    # the timed steps are the LAST dense cluster of dispatches: cut at the last idle gap longer than 2 ms (model build, graph
+    # capture and the warm-up iterations sit before it); --last-frac keeps at most that share of the trace
     t_lo, t_hi = rows[0][0], max(r[1] for r in rows)
-    cut = t_hi - (t_hi - t_lo) * frac                    # the steady-state tail of the trace (timed steps)
+    cut = t_hi - (t_hi - t_lo) * frac
+    end = rows[0][1]
+    for s_, e_, _, _ in rows:
+        if s_ - end > 2_000_000 and s_ > cut:
+            cut = s_
+        end = max(end, e_)
     rows = [r for r in rows if r[0] >= cut]
     t_lo, t_hi = rows[0][0], max(r[1] for r in rows)
     ev = []
@@ -53,7 +60,7 @@ def main():
     for s, e, q, n in rows:
         per_queue[q] += e - s
         cnt[q] += 1
-    out = [f"# queue timeline of {src} (last {frac:.0%} of the trace: {wall / 1e6:.2f} ms, {len(rows)} dispatches)", ""]
+    out = [f"# queue timeline of {src} (last dense cluster of the trace: {wall / 1e6:.2f} ms, {len(rows)} dispatches)", ""]
     out.append("| queues busy | ms | share |")
     out.append("|---:|---:|---:|")
     for k in sorted(busy_by_count):
