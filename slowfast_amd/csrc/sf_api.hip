@@ -5,7 +5,6 @@
 #include "sf_igemm.h"
 #include "sf_igemm2.h"
 #include "sf_igemm3.h"
-#include "sf_igemm2p.h"
 #include "sf_wgrad2.h"
 #include "sf_pool.h"
 #include "sf_dwconv.h"
@@ -199,12 +198,6 @@ static void launch_igemm2(Igemm2Params& q, hipStream_t s) {
 // K step: 64 deep (48 KB stages, ONE 8-wave workgroup per CU) when the grid is at most ~one tile per CU anyway -- the
 // res5-sized layers; otherwise 32 deep (24 KB stages, TWO workgroups per CU: one tile's epilogue and pipeline fill hide
 // behind the other's K loop).  Measured per layer in profiles/r2/r2_v3_igemm2_variants.md.  SF_IGEMM2_BK=32|64 forces one.
-// sf_igemm2p.h covers: bias / alpha, residual (no bit mask), fp32 side rows, BatchNorm statistics, GELU / GELU' / ReLU epilogues,
-// plain column sums of the stored tile; NOT the fused BatchNorm-backward reduction, residual bit masks, mapped output rows
-static const int kIgemm2pMinTiles = 1 << 30;        // default: off (SF_IGEMM2P=<min tiles> switches it on)
-static bool igemm2p_ok(const Igemm2Params& q) {
-    return !q.omap && !q.resid_bits && !q.bnb_y && !q.bnb_bits && q.C % 32 == 0 && q.Nout > 32;
-}
 static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     const char* e;
     const int tiles = cdiv(q.M, 256) * cdiv(q.Nout, q.Nout > 64 ? 128 : 64);
@@ -217,25 +210,6 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     // lost on both models: SlowFast 766.5 -> 741 clips/s on every eligible layer, 755 restricted to grids of >= 512 tiles,
     // MViTv2-S 590.9 -> 584 / 588; profiles/r4/r4_v6_knobs_ab.txt.  The same tile on a 16-wave workgroup (64 x 64 wave tiles, four
     // waves per SIMD kept) moved no layer either: profiles/r4/r4_v11_igemm2_fat_ab.txt.  Both removed.)
-    // persistent form with drain waves (sf_igemm2p.h): many tiles per CU and an epilogue this kernel's drain waves cover
-    {
-        const int BNp = q.Nout > 64 ? 128 : 64;
-        const int tp = cdiv(q.M, 256) * cdiv(q.Nout, BNp);
-        if (igemm2p_ok(q) && tp >= test_hook("SF_IGEMM2P", kIgemm2pMinTiles)) {
-            q.ntiles_n = cdiv(q.Nout, BNp);
-            const int gmax = test_hook("SF_IGEMM2P_GRID", 256);        // (tests: few workgroups, many tiles each)
-            const int grid = tp < gmax ? tp : gmax;
-            if (trace) fprintf(stderr, "[sfamd] igemm2p: %d tiles on %d workgroups\n", tp, grid);
-            if (BNp == 128) {
-                if (q.f32.out) hipLaunchKernelGGL((sf_igemm2p_kernel<128, true>), dim3(grid), dim3(1024), 0, s, q, tp);
-                else hipLaunchKernelGGL((sf_igemm2p_kernel<128, false>), dim3(grid), dim3(1024), 0, s, q, tp);
-            } else {
-                if (q.f32.out) hipLaunchKernelGGL((sf_igemm2p_kernel<64, true>), dim3(grid), dim3(1024), 0, s, q, tp);
-                else hipLaunchKernelGGL((sf_igemm2p_kernel<64, false>), dim3(grid), dim3(1024), 0, s, q, tp);
-            }
-            return;
-        }
-    }
     // third generation (sf_igemm3.h, 256 x 256 x 64 eight-phase ping-pong): EXPERIMENT, SF_IGEMM3=<min tiles> switches it on
     {
         const int i3_min = test_hook("SF_IGEMM3", 0);
@@ -285,10 +259,7 @@ static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     const int minrows = test_hook("SF_IGEMM2_MINROWS", 4096);
     const GatherSide& g = p.g;
     if (off || !igemm2_operands_ok(p, nbatch)) return false;
-    const bool shallow_ok = test_hook("SF_IGEMM2P", kIgemm2pMinTiles) < (1 << 30) && g.Ktot >= test_hook("SF_IGEMM2P_MINK", 96) &&
-                            !p.resid_bits && !p.bnb_y && !p.bnb_bits &&
-                            cdiv(p.M, 256) * cdiv(p.Nout, p.Nout > 64 ? 128 : 64) >= test_hook("SF_IGEMM2P", kIgemm2pMinTiles);
-    if ((g.Ktot < mink && !shallow_ok) || p.Nout <= 32 || p.M < minrows) return false;
+    if (g.Ktot < mink || p.Nout <= 32 || p.M < minrows) return false;
     if (g.mode == 1 && !(g.strT == 1 && g.strH == 1 && g.strW == 1)) return false;
     const int taps = g.kT * g.kH * g.kW;
     Igemm2Params q;
