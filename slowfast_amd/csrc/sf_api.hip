@@ -2000,7 +2000,26 @@ extern "C" int sf_attn_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     p.ablate = tune_knob("SF_ATTN_ABLATE", 0);        // diagnostic builds only (wrong results)
     const bool qt2 = attn_two_tiles(d);
     if (qt2) p.qtiles = cdiv(d->Nq, 128);
-    SF_ATTN_LAUNCH_Q(sf_attn_fwd_kernel, d->D, qt2, d->B * d->heads * p.qtiles, (hipStream_t)stream, p);
+    {
+        const int grid = d->B * d->heads * p.qtiles;
+        hipStream_t st = (hipStream_t)stream;
+#define SF_FWD(KD_, QT_)                                                                                                 \
+    do {                                                                                                                 \
+        if (p.R > 32) hipLaunchKernelGGL((sf_attn_fwd_kernel<KD_, QT_, true>), dim3(grid), dim3(SF_THREADS), 0, st, p);  \
+        else hipLaunchKernelGGL((sf_attn_fwd_kernel<KD_, QT_, false>), dim3(grid), dim3(SF_THREADS), 0, st, p);          \
+    } while (0)
+        switch (d->D / 32 * 2 + (qt2 ? 1 : 0)) {
+            case 2: SF_FWD(1, 1); break;
+            case 3: SF_FWD(1, 2); break;
+            case 4: SF_FWD(2, 1); break;
+            case 5: SF_FWD(2, 2); break;
+            case 6: SF_FWD(3, 1); break;
+            case 7: SF_FWD(3, 2); break;
+            case 8: SF_FWD(4, 1); break;
+            default: SF_FWD(4, 2); break;
+        }
+#undef SF_FWD
+    }
     return check_launch("attn_fwd");
 }
 

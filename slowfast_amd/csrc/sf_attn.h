@@ -86,15 +86,44 @@ __device__ __forceinline__ f16x8 attn_scale8(f16x8 v, float s) {
     return o;
 }
 
-// 8 consecutive fp32 (times log2 e) -> fp16 hi / lo parts; elements with index >= n are zero
-__device__ __forceinline__ void attn_split8(const float* src, int n, bool on, f16x8& hi, f16x8& lo) {
+// columns j0 .. j0 + 7 of an rq row of R floats (times log2 e) -> fp16 hi / lo parts; columns >= R (and everything when !on) are
+// zero.  The eight loads are UNCONDITIONAL (column index clamped into the row) so that they -- and those of the other rows of
+// the wave -- are in flight together: the predicated form (`on && e < n ? src[e] : 0`) compiled to one exec-masked block with its
+// own `s_waitcnt vmcnt(0)` per element, 32 serial round trips in the prologue of the query-side kernels (round 5).
+__device__ __forceinline__ void attn_rq_load8(const float* row, int j0, int R, float* raw) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) raw[e] = row[j0 + e < R ? j0 + e : R - 1];
+}
+__device__ __forceinline__ void attn_rq_split8(const float* raw, int j0, int R, bool on, f16x8& hi, f16x8& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float v = (on && e < n) ? src[e] * SF_LOG2E : 0.f;
+        const float v = (on && j0 + e < R) ? raw[e] * SF_LOG2E : 0.f;
         const f16 h = (f16)v;
         hi[e] = h;
         lo[e] = (f16)(v - (float)h);
     }
+}
+// the rq rows of the wave's QT query tiles -> hi / lo parts of columns 0 .. 63: per 32-column half, the loads of every tile, then
+// the conversions (one wait per half; the second half only exists for key grids with kH + kW + kT > 32)
+template <int QT, int NKS = 2>
+__device__ __forceinline__ void attn_rq_rows(const float* const* rqrow, const bool* on, int R, int g, f16x8 (*rqh)[NKS], f16x8 (*rql)[NKS]) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int u = 0; u < QT; ++u) rqh[u][ks] = rql[u][ks] = zero8();
+        if (32 * ks < R) {
+            float raw[QT][8];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) attn_rq_load8(rqrow[u], 32 * ks + 8 * g, R, raw[u]);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) attn_rq_split8(raw[u], 32 * ks + 8 * g, R, on[u], rqh[u][ks], rql[u][ks]);
+        }
+    }
+}
+
+// lane-local maximum of eight scores in four instructions (v_max3_f32; fmaxf costs a canonicalising v_max x, x per operand)
+__device__ __forceinline__ float attn_max8(const float* x) {
+    return fmaxf(SF_MAX3(x[0], x[1], x[2]), SF_MAX3(x[3], x[4], SF_MAX3(x[5], x[6], x[7])));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -153,9 +182,13 @@ struct KeyChunkCopy {
 // forward: workgroup = 64*QT queries of one (batch, head); wave w owns QT column tiles of 16 queries.  With QT = 2
 // every K / V / OH fragment read from LDS feeds two MFMAs (these kernels are LDS-bandwidth bound: 1 KB of operand per
 // 16x16x32 MFMA at QT = 1), and the K/V chunks are re-staged half as often.
-template <int KD, int QT>
-__global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kernel(AttnParams p) {
-    constexpr int D = 32 * KD, KP = D + 16, DT = D / 16;
+// B2: the key grid has more than 32 relative-position columns (kH + kW + kT > 32).  Without them (every MViTv2-S stage: 7 + 7 + 8)
+// the second hi / lo halves of the rq rows do not exist, and the 96-wide two-tile kernel fits 168 registers: THREE workgroups
+// per CU instead of two.  The kernel is a chain of latency phases (rows in, 13 key chunks, rows out) that only overlap ACROSS
+// workgroups (profiles/r5_v27_attn_fwd_ablation.txt: the phases add up linearly at two per CU).
+template <int KD, int QT, bool B2>
+__global__ __launch_bounds__(SF_THREADS, QT == 2 ? ((!B2 && KD <= 3) ? 3 : 2) : 1) void sf_attn_fwd_kernel(AttnParams p) {
+    constexpr int D = 32 * KD, KP = D + 16, DT = D / 16, NKS = B2 ? 2 : 1;
     typedef KeyChunkCopy<D> Copy;
     __shared__ __attribute__((aligned(16))) f16 KVO[2 * Copy::BUF];      // two buffers of [K | V | OH]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,28 +196,36 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = (int)(bid / (uint32_t)p.qtiles), qt = (int)(bid % (uint32_t)p.qtiles);
     const int b = bh / p.heads, head = bh % p.heads;
-    const bool bias = p.R > 0, bias2 = p.R > 32;
+    const bool bias = p.R > 0;
+    constexpr bool bias2 = B2;
+    if (SF_ABLATE(p) & 2048) return;                // (diagnostic: dispatch cost alone)
+    const f16* kbase = p.k + (int64_t)b * p.Nk * p.ldk + head * D;
+    const f16* vbase = p.v + (int64_t)b * p.Nk * p.ldk + head * D;
+    const int nch = (p.Nk + 31) / 32;
+    // the first key chunk is on its way before the wave's own rows are asked for: the two round trips overlap
+    Copy cp;
+    cp.init(wave, lane);
+    cp.issue(0, KVO, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
     int qrow[QT];
     const f16* qptr[QT];
-    f16x8 qf[QT][KD], rqh[QT][2], rql[QT][2];
+    const float* rqrow[QT];
+    bool rq_on[QT];
+    f16x8 qf[QT][KD], rqh[QT][NKS], rql[QT][NKS];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         qrow[u] = qt * 64 * QT + (wave * QT + u) * 16 + pl;
         const int qc = qrow[u] < p.Nq ? qrow[u] : p.Nq - 1;
         qptr[u] = p.q + ((int64_t)b * p.Nq + qc) * p.ldq + head * D;
 #pragma unroll
-        for (int s = 0; s < KD; ++s) qf[u][s] = attn_scale8(ld16(qptr[u] + 32 * s + 8 * g), p.scale2);
-        const bool on = bias && qc >= p.cls;
-        const float* rqrow = p.rq + (((int64_t)b * p.Nq + qc) * p.heads + head) * p.R;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int j0 = 32 * ks + 8 * g;
-            attn_split8(on ? rqrow + (j0 < p.R ? j0 : 0) : nullptr, p.R - j0, on && j0 < p.R, rqh[u][ks], rql[u][ks]);
-        }
+        for (int s = 0; s < KD; ++s) qf[u][s] = (SF_ABLATE(p) & 512) ? zero8() : ld16(qptr[u] + 32 * s + 8 * g);
+        rq_on[u] = bias && qc >= p.cls;
+        rqrow[u] = p.rq + (((int64_t)b * p.Nq + qc) * p.heads + head) * p.R;
     }
-    const f16* kbase = p.k + (int64_t)b * p.Nk * p.ldk + head * D;
-    const f16* vbase = p.v + (int64_t)b * p.Nk * p.ldk + head * D;
-    const int nch = (p.Nk + 31) / 32;
+    attn_rq_rows<QT, NKS>(rqrow, rq_on, (SF_ABLATE(p) & 512) ? 0 : p.R, g, rqh, rql);
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int s = 0; s < KD; ++s) qf[u][s] = attn_scale8(qf[u][s], p.scale2);
 
     float m[QT], l[QT];
     f32x4 oacc[QT][DT];
@@ -195,9 +236,6 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) oacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    Copy cp;
-    cp.init(wave, lane);
-    cp.issue(0, KVO, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
     for (int c = 0; c < nch; ++c) {
         const f16* const Ks = KVO + (c & 1) * Copy::BUF;
         const f16* const Vs = Ks + Copy::MSZ;
@@ -227,12 +265,12 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
                     st[u] = SF_MFMA16(a0, rqh[u][0], st[u]);
                     st[u] = SF_MFMA16(a0, rql[u][0], st[u]);
                 }
-                if (bias2) {
+                if constexpr (bias2) {
                     const f16x8 a1 = ld16(OHs + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
 #pragma unroll
                     for (int u = 0; u < QT; ++u) {
-                        st[u] = SF_MFMA16(a1, rqh[u][1], st[u]);
-                        st[u] = SF_MFMA16(a1, rql[u][1], st[u]);
+                        st[u] = SF_MFMA16(a1, rqh[u][NKS - 1], st[u]);
+                        st[u] = SF_MFMA16(a1, rql[u][NKS - 1], st[u]);
                     }
                 }
             }
@@ -249,21 +287,36 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
                     for (int u = 0; u < QT; ++u) x[u][i] = -INFINITY;
                 }
         }
+        // The running maximum of a query (shared by the four lanes of its column) moves only when the chunk's maximum exceeds
+        // it by 2^8.  Whether ANY column of the wave does is decided from the lane-local maxima alone -- a column's maximum
+        // exceeds m + 8 iff one of its lanes' does -- so the two cross-lane exchanges per tile (ds_bpermute round trips in the
+        // middle of the S -> P -> PV dependency chain) run only in the rare chunks that rescale (always the first).
+        float lm[QT];
+        bool any_grow = false;
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            lm[u] = attn_max8(x[u]);
+            any_grow = any_grow || lm[u] > m[u] + 8.f;
+        }
+        if (__any(any_grow)) {
+#pragma unroll
+            for (int u = 0; u < QT; ++u) {
+                float cmax = lm[u];
+                cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+                cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+                const bool grow = cmax > m[u] + 8.f;          // also true on the first chunk (m = -inf)
+                if (__any(grow)) {
+                    const float alpha = grow ? SF_EXP2(m[u] - cmax) : 1.f;
+                    if (grow) m[u] = cmax;
+                    l[u] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) oacc[u][dt] *= alpha;
+                }
+            }
+        }
         f16x8 pf[QT];
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
-            float cmax = fmaxf(fmaxf(fmaxf(x[u][0], x[u][1]), fmaxf(x[u][2], x[u][3])),
-                               fmaxf(fmaxf(x[u][4], x[u][5]), fmaxf(x[u][6], x[u][7])));
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-            const bool grow = cmax > m[u] + 8.f;          // also true on the first chunk (m = -inf)
-            if (__any(grow)) {
-                const float alpha = grow ? SF_EXP2(m[u] - cmax) : 1.f;
-                if (grow) m[u] = cmax;
-                l[u] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) oacc[u][dt] *= alpha;
-            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float pv = SF_EXP2(x[u][i] - m[u]);
@@ -278,26 +331,40 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 1) void sf_attn_fwd_kerne
             for (int u = 0; u < QT; ++u) oacc[u][dt] = SF_MFMA16(vt, pf[u], oacc[u][dt]);
         }
     }
+    // epilogue: the residual rows (q again) of BOTH tiles are requested before anything is stored -- on gfx950 stores count in
+    // vmcnt, so a load issued after a store waits for that store's acknowledgement; the per-tile form (load, wait, store, six
+    // times per tile) was a chain of twelve memory round trips per wave
+    float inv[QT], lt_[QT];
+    f16x4 rv[QT][DT];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         float lt = l[u];
         lt += __shfl_xor(lt, 16);
         lt += __shfl_xor(lt, 32);
-        const float inv = 1.f / lt;
-        if (qrow[u] < p.Nq) {
+        lt_[u] = lt;
+        inv[u] = 1.f / lt;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            rv[u][dt] = (f16x4){(f16)0, (f16)0, (f16)0, (f16)0};
+            if (p.residual && !(SF_ABLATE(p) & 1024))
+                rv[u][dt] = *reinterpret_cast<const f16x4*>(qptr[u] + dt * 16 + 4 * g);   // clamped row: always valid
+        }
+    }
+    // (diagnostic bits 256 / 512 / 1024: no output stores / no q and rq loads / no residual loads)
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        if (qrow[u] < p.Nq && !(SF_ABLATE(p) & 256)) {
             const bool res = p.residual && qrow[u] >= p.cls;
             f16* orow = p.out + ((int64_t)b * p.Nq + qrow[u]) * p.ldout + head * D;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int d0 = dt * 16 + 4 * g;
-                f16x4 rv = {(f16)0, (f16)0, (f16)0, (f16)0};
-                if (res) rv = *reinterpret_cast<const f16x4*>(qptr[u] + d0);
                 f16x4 ov;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (f16)(oacc[u][dt][r] * inv + (float)rv[r]);
+                for (int r = 0; r < 4; ++r) ov[r] = (f16)(oacc[u][dt][r] * inv[u] + (res ? (float)rv[u][dt][r] : 0.f));
                 *reinterpret_cast<f16x4*>(orow + d0) = ov;
             }
-            if (g == 0) p.lse[(int64_t)bh * p.Nq + qrow[u]] = m[u] + log2f(lt);
+            if (g == 0) p.lse[(int64_t)bh * p.Nq + qrow[u]] = m[u] + log2f(lt_[u]);
         }
     }
 }
@@ -315,52 +382,68 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
     const int bh = (int)(bid / (uint32_t)p.qtiles), qt = (int)(bid % (uint32_t)p.qtiles);
     const int b = bh / p.heads, head = bh % p.heads;
     const bool bias = p.R > 0, bias2 = p.R > 32;
+    const f16* kbase = p.k + (int64_t)b * p.Nk * p.ldk + head * D;
+    const f16* vbase = p.v + (int64_t)b * p.Nk * p.ldk + head * D;
+    const int nch = (p.Nk + 31) / 32;
+    Copy cp;                                        // first key chunk under way before the wave's own rows (as in the forward kernel)
+    cp.init(wave, lane);
+    cp.issue(0, KVO, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
     int qrow[QT];
     const f16* doptr[QT];
     bool res[QT];
     f16x8 qf[QT][KD], dof[QT][KD], rqh[QT][2], rql[QT][2];
     float dl[QT], lse[QT];
+    // every global load of the prologue first (both tiles: q, dO, O, lse, the rq rows), the stores (delta, the rq split for the
+    // key-side kernel) after all of them: a load issued behind a store waits for that store (one vmcnt counter)
+    {
+        f16x8 of[QT][KD];
+        const float* rqrow[QT];
+        bool rq_on[QT];
 #pragma unroll
-    for (int u = 0; u < QT; ++u) {
-        qrow[u] = qt * 64 * QT + (wave * QT + u) * 16 + pl;
-        const bool qok = qrow[u] < p.Nq;
-        const int qc = qok ? qrow[u] : p.Nq - 1;
-        res[u] = p.residual && qc >= p.cls;
-        const f16* qptr = p.q + ((int64_t)b * p.Nq + qc) * p.ldq + head * D;
-        doptr[u] = p.dout + ((int64_t)b * p.Nq + qc) * p.ldo + head * D;
-        const f16* optr = p.o + ((int64_t)b * p.Nq + qc) * p.ldo + head * D;
-        float d = 0.f;
+        for (int u = 0; u < QT; ++u) {
+            qrow[u] = qt * 64 * QT + (wave * QT + u) * 16 + pl;
+            const int qc = qrow[u] < p.Nq ? qrow[u] : p.Nq - 1;
+            res[u] = p.residual && qc >= p.cls;
+            const f16* qptr = p.q + ((int64_t)b * p.Nq + qc) * p.ldq + head * D;
+            doptr[u] = p.dout + ((int64_t)b * p.Nq + qc) * p.ldo + head * D;
+            const f16* optr = p.o + ((int64_t)b * p.Nq + qc) * p.ldo + head * D;
 #pragma unroll
-        for (int s = 0; s < KD; ++s) {
-            qf[u][s] = ld16(qptr + 32 * s + 8 * g);
-            dof[u][s] = ld16(doptr[u] + 32 * s + 8 * g);
-            const f16x8 ov = ld16(optr + 32 * s + 8 * g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d += (float)dof[u][s][e] * ((float)ov[e] - (res[u] ? (float)qf[u][s][e] : 0.f));
+            for (int s = 0; s < KD; ++s) {
+                qf[u][s] = ld16(qptr + 32 * s + 8 * g);
+                dof[u][s] = ld16(doptr[u] + 32 * s + 8 * g);
+                of[u][s] = ld16(optr + 32 * s + 8 * g);
+            }
+            lse[u] = p.lse[(int64_t)bh * p.Nq + qc];
+            rq_on[u] = bias && qc >= p.cls;
+            rqrow[u] = p.rq + (((int64_t)b * p.Nq + qc) * p.heads + head) * p.R;
         }
-        d += __shfl_xor(d, 16);
-        d += __shfl_xor(d, 32);
-        dl[u] = d;
+        attn_rq_rows<QT>(rqrow, rq_on, p.R, g, rqh, rql);
 #pragma unroll
-        for (int s = 0; s < KD; ++s) qf[u][s] = attn_scale8(qf[u][s], p.scale2);      // from here on only S^T uses q
-        lse[u] = p.lse[(int64_t)bh * p.Nq + qc];
-        if (qok && g == 0) p.delta[(int64_t)bh * p.Nq + qrow[u]] = d;
-        const bool on = bias && qc >= p.cls;
-        const float* rqrow = p.rq + (((int64_t)b * p.Nq + qc) * p.heads + head) * p.R;
+        for (int u = 0; u < QT; ++u) {
+            const bool qok = qrow[u] < p.Nq;
+            float d = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int j0 = 32 * ks + 8 * g;
-            attn_split8(on ? rqrow + (j0 < p.R ? j0 : 0) : nullptr, p.R - j0, on && j0 < p.R, rqh[u][ks], rql[u][ks]);
+            for (int s = 0; s < KD; ++s) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    d += (float)dof[u][s][e] * ((float)of[u][s][e] - (res[u] ? (float)qf[u][s][e] : 0.f));
+            }
+            d += __shfl_xor(d, 16);
+            d += __shfl_xor(d, 32);
+            dl[u] = d;
+#pragma unroll
+            for (int s = 0; s < KD; ++s) qf[u][s] = attn_scale8(qf[u][s], p.scale2);      // from here on only S^T uses q
+            if (qok && g == 0) p.delta[(int64_t)bh * p.Nq + qrow[u]] = d;
             if (p.rqs && qok) {     // the split the key-side kernel needs for the same rows: made once here, not once per key tile
-                f16* dst = p.rqs + (((int64_t)b * p.Nq + qrow[u]) * p.heads + head) * 128 + j0;
-                st16(dst, rqh[u][ks]);
-                st16(dst + 64, rql[u][ks]);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    f16* dst = p.rqs + (((int64_t)b * p.Nq + qrow[u]) * p.heads + head) * 128 + 32 * ks + 8 * g;
+                    st16(dst, rqh[u][ks]);
+                    st16(dst + 64, rql[u][ks]);
+                }
             }
         }
     }
-    const f16* kbase = p.k + (int64_t)b * p.Nk * p.ldk + head * D;
-    const f16* vbase = p.v + (int64_t)b * p.Nk * p.ldk + head * D;
-    const int nch = (p.Nk + 31) / 32;
 
     f32x4 dqacc[QT][DT], drqacc[QT][JT];
 #pragma unroll
@@ -370,9 +453,6 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) drqacc[u][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    Copy cp;
-    cp.init(wave, lane);
-    cp.issue(0, KVO, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
     for (int c = 0; c < nch; ++c) {
         const f16* const Ks = KVO + (c & 1) * Copy::BUF;
         const f16* const Vs = Ks + Copy::MSZ;
@@ -444,6 +524,15 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
                 }
         }
     }
+    // the residual rows (dO again) of both tiles are requested before anything is stored (see the forward kernel's epilogue)
+    f16x4 rv[QT][DT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            rv[u][dt] = (f16x4){(f16)0, (f16)0, (f16)0, (f16)0};
+            if (p.residual) rv[u][dt] = *reinterpret_cast<const f16x4*>(doptr[u] + dt * 16 + 4 * g);   // clamped row: always valid
+        }
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         if (qrow[u] >= p.Nq) continue;
@@ -451,11 +540,9 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = dt * 16 + 4 * g;
-            f16x4 rv = {(f16)0, (f16)0, (f16)0, (f16)0};
-            if (res[u]) rv = *reinterpret_cast<const f16x4*>(doptr[u] + d0);
             f16x4 ov;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (f16)(dqacc[u][dt][r] * p.scale + (float)rv[r]);
+            for (int r = 0; r < 4; ++r) ov[r] = (f16)(dqacc[u][dt][r] * p.scale + (res[u] ? (float)rv[u][dt][r] : 0.f));
             *reinterpret_cast<f16x4*>(dqrow + d0) = ov;
         }
         if (bias) {

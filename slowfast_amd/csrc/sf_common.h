@@ -137,6 +137,16 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #endif
 
 // 2^x on the transcendental unit (v_exp_f32: -inf -> 0, no range fix-ups)
+// max of three floats as ONE v_max3_f32: fmaxf(fmaxf(a, b), c) compiles (IEEE mode) to a canonicalising v_max_f32 x, x per operand
+// in front of the two maxima.  NaN operands are ignored exactly like fmaxf does.  (Host simulator: plain fmaxf.)
+#ifndef SF_MAX3
+__device__ __forceinline__ float sf_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#define SF_MAX3(a, b, c) sf_max3(a, b, c)
+#endif
 #ifndef SF_EXP2
 #define SF_EXP2(x) __builtin_amdgcn_exp2f(x)
 #endif

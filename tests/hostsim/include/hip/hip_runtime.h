@@ -256,6 +256,7 @@ inline int __any(int pred) {
     return r;
 }
 #define SF_EXP2(x) exp2f(x)
+#define SF_MAX3(a, b, c) fmaxf(fmaxf((a), (b)), (c))
 
 #ifdef SF_ACT_BF16
 typedef __bf16 hipsim_f16;      // the library's 16-bit storage type (see csrc/sf_common.h)
