@@ -1991,6 +1991,7 @@ extern "C" int sf_attn_fwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     if (fill_attn(p, d, "sf_attn_fwd")) return -1;
     REQUIRE(q && k && v && o && lse, "sf_attn_fwd: null pointer");
     REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "sf_attn_fwd: row pitches must be multiples of 8");
+    REQUIRE(ldk < (1 << 20), "sf_attn_fwd: ldk too large for the 27-bit chunk offsets");
     REQUIRE((rq == nullptr) == (onehot == nullptr), "sf_attn_fwd: rq and onehot come together");
     REQUIRE(!rq || p.R <= SF_ATTN_RMAX, "sf_attn_fwd: kH + kW + kT = %d exceeds %d", p.R, SF_ATTN_RMAX);
     p.q = (const f16*)q; p.k = (const f16*)k; p.v = (const f16*)v; p.ldq = ldq; p.ldk = ldk;
@@ -2040,6 +2041,7 @@ extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     REQUIRE((rq == nullptr) == (drq == nullptr) && (rq == nullptr) == (onehot == nullptr),
             "sf_attn_bwd: rq, onehot and drq come together");
     REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0, "sf_attn_bwd: bad row pitch");
+    REQUIRE(ldq < (1 << 20) && ldk < (1 << 20) && ldo < (1 << 20) && d->heads < 8192, "sf_attn_bwd: row pitch too large for the 27-bit chunk offsets");
     REQUIRE(!rq || p.R <= SF_ATTN_RMAX, "sf_attn_bwd: kH + kW + kT = %d exceeds %d", p.R, SF_ATTN_RMAX);
     const int64_t need = attn_ws_bytes(p, d);
     REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "sf_attn_bwd: workspace too small (%lld < %lld bytes)",
@@ -2072,7 +2074,8 @@ extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
         p.ablate = tune_knob("SF_ATTN_ABLATE", 0);        // diagnostic builds only (wrong results)
 #define SF_DKV(KD_)                                                                                              \
     do {                                                                                                         \
-        if (kt == 2) hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 2, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
+        if (kt == 2 && p.R <= 32) hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 2, 2, false>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
+        else if (kt == 2) hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 2, 2>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
         else if (occ == 2) hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 2, 1>), dim3(grid), dim3(SF_THREADS), 0, st, p); \
         else hipLaunchKernelGGL((sf_attn_bwd_dkv_kernel<KD_, 3, 1>), dim3(grid), dim3(SF_THREADS), 0, st, p);   \
     } while (0)

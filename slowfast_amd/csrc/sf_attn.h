@@ -139,40 +139,47 @@ struct KeyChunkCopy {
     static constexpr int RS = SF_ATTN_OHP / 8, RNS = 32 * RS, RNI = (RNS + 63) / 64, RSZ = RNI * 512;
     static constexpr int NJ = 2 * NI + RNI, NCP = (NJ + 3) / 4;
     static constexpr int BUF = 2 * MSZ + RSZ;       // halfs per buffer: [K | V | OH]
-    int row[NCP], off[NCP];
-    __device__ __forceinline__ void init(int wave, int lane) {
+    // Per copy instruction of this wave ONE register: (row inside the chunk) << 27 | byte offset of the lane's 16 bytes from the
+    // chunk's first row (K / V: row * ldk * 2 + col * 16, OH: row * 128 + col * 16).  The chunk's first row is a wave-uniform
+    // base (scalar arithmetic per chunk), the copy takes base + offset (SF_GLOBAL_LOAD_LDS16_SADDR).  Pad slots -- never read --
+    // copy their row's first 16 bytes; rows past Nk (last chunk only) copy row Nk - 1: whatever such a key column holds is
+    // multiplied by an exactly-zero probability downstream (the kernels mask keys >= Nk themselves).
+    uint32_t desc[NCP];
+    __device__ __forceinline__ void init(int wave, int lane, int ldk) {
 #pragma unroll
         for (int jj = 0; jj < NCP; ++jj) {
             const int j = wave + 4 * jj;
             if (j < 2 * NI) {
                 const int i = j < NI ? j : j - NI;
-                const int slot = i * 64 + lane, r = slot / SPR, col = slot - r * SPR;
-                row[jj] = r;
-                off[jj] = (slot < NS && col < D / 8) ? col * 8 : -1;
+                const int slot = i * 64 + lane, r = slot < NS ? slot / SPR : 0, col = slot < NS ? slot - r * SPR : 0;
+                desc[jj] = ((uint32_t)r << 27) | (uint32_t)(r * ldk * 2 + (col < D / 8 ? col : 0) * 16);
             } else {
-                const int slot = (j - 2 * NI) * 64 + lane, r = slot / RS, col = slot - r * RS;
-                row[jj] = r;
-                off[jj] = (slot < RNS && col < 8) ? col * 8 : -1;
+                const int slot = (j - 2 * NI) * 64 + lane, r = slot < RNS ? slot / RS : 0, col = slot < RNS ? slot - r * RS : 0;
+                desc[jj] = ((uint32_t)r << 27) | (uint32_t)(r * 128 + (col < 8 ? col : 0) * 16);
             }
         }
     }
     // chunk c of (kbase, vbase: rows of pitch ldk, Nk valid rows; oh: [roundup(Nk, 32)][64]) -> buffer at `dst`
     __device__ __forceinline__ void issue(int c, f16* dst, const f16* kbase, const f16* vbase, int ldk, int Nk, const f16* oh,
                                           int wave) const {
-        const f16* const zline = reinterpret_cast<const f16*>(sf_zero_line);
+        const f16* const kb = kbase + (int64_t)c * 32 * ldk;
+        const f16* const vb = vbase + (int64_t)c * 32 * ldk;
+        const f16* const ob = oh + (int64_t)c * 32 * 64;
+        const int last = Nk - 1 - c * 32;              // last valid row of this chunk (>= 31: every row valid)
 #pragma unroll
         for (int jj = 0; jj < NCP; ++jj) {
             const int j = wave + 4 * jj;
             if (j >= NJ) continue;
-            const int kr = c * 32 + row[jj];
-            const f16* src = zline;
+            uint32_t off = desc[jj] & 0x7ffffffu;
             if (j < 2 * NI) {
-                if (off[jj] >= 0 && kr < Nk) src = (j < NI ? kbase : vbase) + (int64_t)kr * ldk + off[jj];
-                SF_GLOBAL_LOAD_LDS16_ASM(src, dst + (j < NI ? j : MSZ / 512 + (j - NI)) * 512);
+                if (last < 31) {                        // wave-uniform: the partial chunk
+                    const int r = (int)(desc[jj] >> 27);
+                    if (r > last) off -= (uint32_t)((r - last) * ldk * 2);
+                }
+                SF_GLOBAL_LOAD_LDS16_SADDR(j < NI ? kb : vb, off, dst + (j < NI ? j : MSZ / 512 + (j - NI)) * 512);
             } else {
                 if (!oh) continue;
-                if (off[jj] >= 0) src = oh + (int64_t)kr * 64 + off[jj];
-                SF_GLOBAL_LOAD_LDS16_ASM(src, dst + 2 * MSZ + (j - 2 * NI) * 512);
+                SF_GLOBAL_LOAD_LDS16_SADDR(ob, off, dst + 2 * MSZ + (j - 2 * NI) * 512);
             }
         }
     }
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? ((!B2 && KD <= 3) ? 3 : 2) : 
     const int nch = (p.Nk + 31) / 32;
     // the first key chunk is on its way before the wave's own rows are asked for: the two round trips overlap
     Copy cp;
-    cp.init(wave, lane);
+    cp.init(wave, lane, p.ldk);
     cp.issue(0, KVO, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
     int qrow[QT];
     const f16* qptr[QT];
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
     const f16* vbase = p.v + (int64_t)b * p.Nk * p.ldk + head * D;
     const int nch = (p.Nk + 31) / 32;
     Copy cp;                                        // first key chunk under way before the wave's own rows (as in the forward kernel)
-    cp.init(wave, lane);
+    cp.init(wave, lane, p.ldk);
     cp.issue(0, KVO, kbase, vbase, p.ldk, p.Nk, bias ? p.oh : nullptr, wave);
     int qrow[QT];
     const f16* doptr[QT];
@@ -431,6 +438,8 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
             d += __shfl_xor(d, 16);
             d += __shfl_xor(d, 32);
             dl[u] = d;
+            SF_CONSUME_V(lse[u]);           // first read inside the key loop otherwise: hipcc's wait for it lands THERE, a vmcnt(0)
+                                            // per chunk that also drains the next chunk's copies
 #pragma unroll
             for (int s = 0; s < KD; ++s) qf[u][s] = attn_scale8(qf[u][s], p.scale2);      // from here on only S^T uses q
             if (qok && g == 0) p.delta[(int64_t)bh * p.Nq + qrow[u]] = d;
@@ -563,9 +572,13 @@ __global__ __launch_bounds__(SF_THREADS, QT == 2 ? 2 : 3) void sf_attn_bwd_dq_ke
 // (keys (w*KT + u)*16 .. +15) and walks the split's queries in chunks of 32.  KT = 2 (round 4): every Q / dO / rq fragment read
 // from LDS feeds TWO MFMAs (one per key tile), as QT = 2 does in the query-side kernels -- at KT = 1 this kernel read ~1 KB of
 // LDS per MFMA and took 2.3x the time of the query-side kernel for 8/6 of its flops (profiles/r3/r3_final_mvit_kernel_stats.md).
-template <int KD, int OCC, int KT>
+// B2: more than 32 relative-position columns (see the forward kernel).  Without the second one-hot halves -- and with the copy
+// descriptors packed into one register each -- the 96-wide two-tile kernel no longer spills: its 12 spilled registers were
+// reloaded inside the query loop, and hipcc puts `s_waitcnt vmcnt(0)` behind every scratch load, which drained the NEXT chunk's
+// direct-to-LDS copies six times per chunk (round 5; the loop ran load -> wait -> compute).
+template <int KD, int OCC, int KT, bool B2 = true>
 __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnParams p) {
-    constexpr int D = 32 * KD, KP = D + 16, DT = D / 16;
+    constexpr int D = 32 * KD, KP = D + 16, DT = D / 16, NKS = B2 ? 2 : 1;
     // Q and dO chunks travel global -> LDS directly (global_load_lds_dwordx4, two buffers): no staging registers -- the two key
     // tiles of a wave need them for accumulators -- and no ds_write pass.  The padded [32][KP] image is made of SPR 16-byte slots
     // per row (the last one is the pad): slot i of a matrix is written by lane i & 63 of copy instruction i >> 6.
@@ -583,9 +596,10 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
     const int rest = (int)(bid / (uint32_t)p.qsplits);
     const int bh = rest / p.ktiles, kt = rest % p.ktiles;
     const int b = bh / p.heads, head = bh % p.heads;
-    const bool bias = p.R > 0, bias2 = p.R > 32;
+    const bool bias = p.R > 0;
+    constexpr bool bias2 = B2;
     int key[KT];
-    f16x8 kf[KT][KD], vf[KT][KD], ohb[KT][2];
+    f16x8 kf[KT][KD], vf[KT][KD], ohb[KT][NKS];
 #pragma unroll
     for (int u = 0; u < KT; ++u) {
         key[u] = kt * 64 * KT + (wave * KT + u) * 16 + pl;
@@ -597,11 +611,17 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             kf[u][s] = attn_scale8(ld16(kptr + 32 * s + 8 * g), p.scale2);   // only S = Q K^T uses the wave's own key rows
             vf[u][s] = ld16(vptr + 32 * s + 8 * g);
         }
-        ohb[u][0] = ohb[u][1] = zero8();
-        if (bias) {
-            ohb[u][0] = ld16(p.oh + (int64_t)kc_ * 64 + 8 * g);
-            ohb[u][1] = ld16(p.oh + (int64_t)kc_ * 64 + 32 + 8 * g);
-        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) ohb[u][ks] = bias ? ld16(p.oh + (int64_t)kc_ * 64 + 32 * ks + 8 * g) : zero8();
+    }
+    // the raw operands (v, the one-hot rows) are first READ inside the query loop: without this hipcc's wait for their loads lands
+    // there -- `s_waitcnt vmcnt(0)` in every iteration, draining the next chunk's copies (sf_common.h: SF_CONSUME_V)
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+#pragma unroll
+        for (int s = 0; s < KD; ++s) SF_CONSUME_V(vf[u][s]);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) SF_CONSUME_V(ohb[u][ks]);
     }
     const f16* qbase = p.q + (int64_t)b * p.Nq * p.ldq + head * D;
     const f16* dobase = p.dout + (int64_t)b * p.Nq * p.ldo + head * D;
@@ -618,58 +638,63 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             dkacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             dvacc[u][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    // copy instructions of this wave: j = wave, wave + 4, ... over [Q | dO | rq hi | rq lo] instruction slots.  Per lane: the
-    // slot's row inside the chunk and its element offset in the source row (-1: pad slot -> zeros)
+    // copy instructions of this wave: j = wave, wave + 4, ... over [Q | dO | rq hi | rq lo] instruction slots.  Per instruction
+    // ONE register: (row inside the chunk) << 27 | byte offset of the lane's 16 bytes from the chunk's first row (as in
+    // KeyChunkCopy: wave-uniform chunk base + 32-bit offset; pad slots copy their row's first bytes, rows past Nq copy row
+    // Nq - 1 -- their probabilities are forced to zero below, `qin`)
     constexpr int NJ = 2 * NI + 2 * RNI;
     constexpr int NCP = (NJ + 3) / 4;
-    int cp_row[NCP], cp_off[NCP];
+    uint32_t cp_desc[NCP];
 #pragma unroll
     for (int jj = 0; jj < NCP; ++jj) {
         const int j = wave + 4 * jj;
         if (j < 2 * NI) {
             const int i = j < NI ? j : j - NI;
-            const int slot = i * 64 + lane, row = slot / SPR, col = slot - row * SPR;
-            cp_row[jj] = row;
-            cp_off[jj] = (slot < NS && col < D / 8) ? col * 8 : -1;
+            const int slot = i * 64 + lane, row = slot < NS ? slot / SPR : 0, col = slot < NS ? slot - row * SPR : 0;
+            cp_desc[jj] = ((uint32_t)row << 27) | (uint32_t)(row * (j < NI ? p.ldq : p.ldo) * 2 + (col < D / 8 ? col : 0) * 16);
         } else {
             const int i = j - 2 * NI < RNI ? j - 2 * NI : j - 2 * NI - RNI;
-            const int slot = i * 64 + lane, row = slot / RS, col = slot - row * RS;
-            cp_row[jj] = row;
-            cp_off[jj] = (slot < RNS && col < 8) ? col * 8 + (j - 2 * NI < RNI ? 0 : 64) : -1;
+            const int slot = i * 64 + lane, row = slot < RNS ? slot / RS : 0, col = slot < RNS ? slot - row * RS : 0;
+            cp_desc[jj] = ((uint32_t)row << 27) |
+                          (uint32_t)(row * p.heads * 256 + (col < 8 ? col : 0) * 16 + (j - 2 * NI < RNI ? 0 : 128));
         }
     }
-    const f16* const zline = reinterpret_cast<const f16*>(sf_zero_line);
     const f16* const rqs_b = p.rqs ? p.rqs + (((int64_t)b * p.Nq) * p.heads + head) * 128 : nullptr;
     auto issue_chunk = [&](int c, int buf) {
         f16* Qb = QO + buf * 2 * MSZ;
         f16* Rb = RHL + buf * 2 * RSZ;
+        const f16* const qb = qbase + (int64_t)c * 32 * p.ldq;
+        const f16* const ob = dobase + (int64_t)c * 32 * p.ldo;
+        const f16* const rb = rqs_b + (int64_t)c * 32 * p.heads * 128;
+        const int last = p.Nq - 1 - c * 32;             // last valid row of this chunk (>= 31: every row valid)
 #pragma unroll
         for (int jj = 0; jj < NCP; ++jj) {
             const int j = wave + 4 * jj;
             if (j >= NJ) continue;
-            const int qr = c * 32 + cp_row[jj];
-            const f16* src = zline;
+            uint32_t off = cp_desc[jj] & 0x7ffffffu;
+            const int over = (int)(cp_desc[jj] >> 27) - last;       // rows past the end (partial chunk only)
             if (j < 2 * NI) {
                 const bool isq = j < NI;
-                if (cp_off[jj] >= 0 && qr < p.Nq)
-                    src = (isq ? qbase + (int64_t)qr * p.ldq : dobase + (int64_t)qr * p.ldo) + cp_off[jj];
-                SF_GLOBAL_LOAD_LDS16_ASM(src, Qb + (isq ? 0 : MSZ) + (isq ? j : j - NI) * 512);
+                if (last < 31 && over > 0) off -= (uint32_t)(over * (isq ? p.ldq : p.ldo) * 2);
+                SF_GLOBAL_LOAD_LDS16_SADDR(isq ? qb : ob, off, Qb + (isq ? 0 : MSZ) + (isq ? j : j - NI) * 512);
             } else {
                 if (!bias || (SF_ABLATE(p) & 32)) continue;
                 const int jr = j - 2 * NI;
-                if (cp_off[jj] >= 0 && qr < p.Nq) src = rqs_b + (int64_t)qr * p.heads * 128 + cp_off[jj];
-                SF_GLOBAL_LOAD_LDS16_ASM(src, Rb + (jr < RNI ? jr : RSZ / 512 + (jr - RNI)) * 512);
+                if (last < 31 && over > 0) off -= (uint32_t)(over * p.heads * 256);
+                SF_GLOBAL_LOAD_LDS16_SADDR(rb, off, Rb + (jr < RNI ? jr : RSZ / 512 + (jr - RNI)) * 512);
             }
         }
     };
     // log-sum-exp and delta of row tid (tid < 32), prefetched into registers
     float lsev = 0.f, deltav = 0.f;
+    // (unconditional, row index clamped: the predicated form `tid < 32 && q2 < Nq ? load : 0` put an exec-masked block with its own
+    // `s_waitcnt vmcnt(0)` right behind the chunk copies -- the copies of chunk c + 1 were drained before chunk c was computed.
+    // Rows past Nq get row Nq - 1's statistics; their probabilities are forced to zero below, `qin`.)
     auto side_load = [&](int c) {
-        if (tid < 32) {
-            const int q2 = c * 32 + tid;
-            lsev = q2 < p.Nq ? p.lse[(int64_t)bh * p.Nq + q2] : 0.f;
-            deltav = q2 < p.Nq ? p.delta[(int64_t)bh * p.Nq + q2] : 0.f;
-        }
+        const int q2 = c * 32 + (tid & 31);
+        const int64_t at = (int64_t)bh * p.Nq + (q2 < p.Nq ? q2 : p.Nq - 1);
+        lsev = p.lse[at];
+        deltav = p.delta[at];
     };
     if (c0 < c1) {
         issue_chunk(c0, 0);
@@ -723,13 +748,13 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
                     st[u] = SF_MFMA16(rh0, ohb[u][0], st[u]);
                     st[u] = SF_MFMA16(rl0, ohb[u][0], st[u]);
                 }
-                if (bias2) {
+                if constexpr (bias2) {
                     const f16x8 rh1 = ld16(Rh + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
                     const f16x8 rl1 = ld16(Rl + (16 * t + pl) * SF_ATTN_OHP + 32 + 8 * g);
 #pragma unroll
                     for (int u = 0; u < KT; ++u) {
-                        st[u] = SF_MFMA16(rh1, ohb[u][1], st[u]);
-                        st[u] = SF_MFMA16(rl1, ohb[u][1], st[u]);
+                        st[u] = SF_MFMA16(rh1, ohb[u][NKS - 1], st[u]);
+                        st[u] = SF_MFMA16(rl1, ohb[u][NKS - 1], st[u]);
                     }
                 }
             }

@@ -83,6 +83,24 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
     } while (0)
 #endif
 #endif
+// The same copy with the source given as a WAVE-UNIFORM base (scalar register pair) plus a 32-bit per-lane byte offset
+// (`global_load_lds_dwordx4 voff, s[base]`): one VGPR per copy slot instead of a 64-bit per-lane pointer, and the per-stage
+// address update is scalar arithmetic on the base.  (Round 5: the loop-invariant 64-bit lane pointers hipcc hoisted out of the
+// attention kernels' chunk loops were what it spilled; their reloads drained the copy pipeline, see sf_attn.h.)
+#ifndef SF_GLOBAL_LOAD_LDS16_SADDR
+#define SF_GLOBAL_LOAD_LDS16_SADDR(base, voff, l)                                                                    \
+    do {                                                                                                                \
+        const unsigned sf_lds_addr_ = (unsigned)__builtin_amdgcn_readfirstlane(                                         \
+            (int)(uintptr_t)(__attribute__((address_space(3))) void*)(l));                                              \
+        const uint64_t sf_b_ = (uint64_t)(base);                                                                        \
+        const uint64_t sf_bu_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(sf_b_ >> 32)) << 32) |       \
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sf_b_);                         \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                  \
+                     :                                                                                                  \
+                     : "v"((uint32_t)(voff)), "s"(sf_bu_), "s"(sf_lds_addr_)                                            \
+                     : "memory");                                                                                       \
+    } while (0)
+#endif
 // LDS hand-over between the lanes of ONE wave (ds_write by some lanes, ds_read of the same bytes by others): the hardware runs
 // a wave's LDS instructions in order, so only the compiler must be kept from reordering them; the host simulator, whose lanes
 // are fibers, needs a real rendezvous here
@@ -214,6 +232,14 @@ template <int TM, int TN>
 __device__ __forceinline__ void f32_rows_epilogue(f32x4 (&acc)[TM][TN], const F32Rows& f, int row0, int col0, int M, int Nout,
                                                   const f16* resid, int ldr, int resid_row0) {
     const int lane = threadIdx.x & 63;
+    {   // Wave-uniform early-out: no side row among the 16 * TM rows of this wave's tile (with one class token per ~1600 rows, true
+        // for 5 tiles in 6).  Without it every wave walked TM * 4 * TN exec-masked blocks -- a compare, a saveexec and a branch
+        // each, ~300 instructions per tile -- to find all of them empty.
+        uint32_t q, rem;
+        fd_divmod((uint32_t)__builtin_amdgcn_readfirstlane(row0), f.fd, q, rem);
+        const uint32_t first = (uint32_t)row0 + (rem ? f.fd.d - rem : 0u);        // first side row >= row0
+        if (first >= (uint32_t)(row0 + 16 * TM) || first >= (uint32_t)M) return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll

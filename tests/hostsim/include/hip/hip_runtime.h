@@ -325,6 +325,7 @@ inline void hipsim_global_load_lds16(const void* gptr, void* lds_base) {
 }
 #define SF_GLOBAL_LOAD_LDS16(g, l) hipsim_global_load_lds16((const void*)(g), (void*)(l))
 #define SF_GLOBAL_LOAD_LDS16_ASM(g, l) hipsim_global_load_lds16((const void*)(g), (void*)(l))
+#define SF_GLOBAL_LOAD_LDS16_SADDR(base, voff, l) hipsim_global_load_lds16((const void*)((const char*)(base) + (uint32_t)(voff)), (void*)(l))
 // a wave's own vmcnt wait makes its LDS-DMA data visible to all of ITS lanes (no workgroup barrier needed for a wave that reads
 // only what it copied itself): the emulated copies above finish with a per-lane memcpy, so the wait is a wave rendezvous here
 #define SF_WAIT_VMEM() hipsim::wave_sync()
