@@ -173,7 +173,8 @@ struct KeyChunkCopy {
             uint32_t off = desc[jj] & 0x7ffffffu;
             if (j < 2 * NI) {
                 if (last < 31) {                        // wave-uniform: the partial chunk
-                    const int r = (int)(desc[jj] >> 27);
+                    int r = (int)(desc[jj] >> 27);
+                    SF_CONSUME_V(r);                    // keeps hipcc from hoisting this arithmetic out of the chunk loop (registers)
                     if (r > last) off -= (uint32_t)((r - last) * ldk * 2);
                 }
                 SF_GLOBAL_LOAD_LDS16_SADDR(j < NI ? kb : vb, off, dst + (j < NI ? j : MSZ / 512 + (j - NI)) * 512);
@@ -672,15 +673,20 @@ __global__ __launch_bounds__(SF_THREADS, OCC) void sf_attn_bwd_dkv_kernel(AttnPa
             const int j = wave + 4 * jj;
             if (j >= NJ) continue;
             uint32_t off = cp_desc[jj] & 0x7ffffffu;
-            const int over = (int)(cp_desc[jj] >> 27) - last;       // rows past the end (partial chunk only)
+            int over = 0;                                   // rows past the end (partial chunk only)
+            if (last < 31) {
+                int r = (int)(cp_desc[jj] >> 27);
+                SF_CONSUME_V(r);                            // keeps hipcc from hoisting this arithmetic out of the chunk loop (registers)
+                over = r > last ? r - last : 0;
+            }
             if (j < 2 * NI) {
                 const bool isq = j < NI;
-                if (last < 31 && over > 0) off -= (uint32_t)(over * (isq ? p.ldq : p.ldo) * 2);
+                off -= (uint32_t)(over * (isq ? p.ldq : p.ldo) * 2);
                 SF_GLOBAL_LOAD_LDS16_SADDR(isq ? qb : ob, off, Qb + (isq ? 0 : MSZ) + (isq ? j : j - NI) * 512);
             } else {
                 if (!bias || (SF_ABLATE(p) & 32)) continue;
                 const int jr = j - 2 * NI;
-                if (last < 31 && over > 0) off -= (uint32_t)(over * p.heads * 256);
+                off -= (uint32_t)(over * p.heads * 256);
                 SF_GLOBAL_LOAD_LDS16_SADDR(rb, off, Rb + (jr < RNI ? jr : RSZ / 512 + (jr - RNI)) * 512);
             }
         }
