@@ -223,6 +223,19 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
             return;
         }
     }
+    // 128 x 128 tiles on four waves, THREE workgroups per CU (52 KB of LDS each), for the plain matrix products (`linear`) without a statistics / column-sum
+    // epilogue whose grid is several rounds deep anyway (the MViT Linears with K >= 512: fc2, the fc1 / qkv data gradients): a third
+    // resident workgroup hides more of the store epilogue than the bigger tile saves in operand traffic -- fc2 forward 103.7 ->
+    // 99.2 us HBM-cold, MViTv2-S 707 -> 712 clips/s (profiles/r5_v35_*).  Not below K = 512 (there the round-1 kernel at four
+    // workgroups per CU stays ahead: 114 vs 128 us for fc1).  SF_IGEMM2_T128=0 switches it off.
+    const int t128 = test_hook("SF_IGEMM2_T128", 1);      // 2: also on grids of at most one round (tests)
+    if (t128 && q.linear && q.Nout > 64 && !q.stat_part && !q.bnb_part && (!bk64 || t128 == 2)) {
+        q.ntiles_n = cdiv(q.Nout, 128);
+        const dim3 grid((unsigned)(cdiv(q.M, 128) * q.ntiles_n));
+        if (q.f32.out) hipLaunchKernelGGL((sf_igemm2_kernel<128, 128, 2, 2, 32, 3, true>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((sf_igemm2_kernel<128, 128, 2, 2, 32, 3>), grid, dim3(256), 0, s, q);
+        return;
+    }
     if (q.Nout > 64) { if (bk64) launch_igemm2<128, 64>(q, s); else launch_igemm2<128, 32>(q, s); }
     else if (q.Nout > 32) { if (bk64) launch_igemm2<64, 64>(q, s); else launch_igemm2<64, 32>(q, s); }
     else launch_igemm2<32, 32>(q, s);
@@ -250,6 +263,7 @@ static void igemm2_common(Igemm2Params& q, const IgemmParams& p) {
     q.bnb_y = p.bnb_y; q.bnb_ld = p.bnb_ld; q.bnb_scale = p.bnb_scale; q.bnb_shift = p.bnb_shift; q.bnb_part = p.bnb_part;
     q.bnb_bits = p.bnb_bits;
     q.f32 = p.f32;
+    q.linear = p.linear;
 }
 static bool try_igemm2(const IgemmParams& p, hipStream_t s, int nbatch = 1) {
     // read on every call (three getenv per launch are noise): tests lower the thresholds for single cases
@@ -1171,6 +1185,7 @@ static int bgemm_impl(int64_t M, int32_t N, int32_t K, const void* A, int32_t ld
     p.ksteps = cdiv(K, 32);
     p.y = (f16*)Y; p.ldy = ldy; p.bias = bias; p.resid = (const f16*)resid; p.ldr = ldr;
     p.bh = bh; p.sa_b = sa_b; p.sa_h = sa_h; p.sw_b = sw_b; p.sw_h = sw_h; p.sy_b = sy_b; p.sy_h = sy_h;
+    p.linear = 1;
     p.sr_b = sr_b; p.sr_h = sr_h; p.resid_row0 = resid_row0; p.alpha = alpha;
     if (side) {
         REQUIRE(nbatch == 1 && N % 8 == 0, "sf_gemm_rows32: one GEMM, N %% 8 == 0 (N=%d)", N);
@@ -1217,6 +1232,7 @@ static int gemm_act_impl(int64_t M, int32_t N, int32_t K, const void* A, int32_t
     p.y = (f16*)Y; p.ldy = ldy; p.bias = bias;
     p.bh = 1;
     p.act_mode = mode; p.act_aux = (f16*)aux; p.ld_aux = ldaux;
+    p.linear = 1;
     p.bnb_part = colsum_part;          // bnb_y == nullptr: plain column sums of the stored tile, one row per M tile
     hipStream_t s = (hipStream_t)stream;
     if (colsum_rows) *colsum_rows = colsum_part ? cdiv(p.M, 256) : 0;

@@ -48,6 +48,7 @@ struct IgemmParams {
     float* bnb_part;
     const uint8_t* bnb_bits;        // optional [rows][Nout/8] bit mask replacing the recomputed one (block-output ReLU)
     F32Rows f32;                    // fp32 side rows of the output (token residual sums; sf_common.h), f32.out == nullptr: off
+    int linear;                     // host-side hint: a plain matrix product (nn.Linear / attention GEMM), not a convolution
 };
 
 // g = dz masked by the producer's ReLU (same expression as masked_grad8 / sf_bn_bwd_apply use), accumulated per channel.

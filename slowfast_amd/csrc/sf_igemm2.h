@@ -69,6 +69,7 @@ struct Igemm2Params {
     // LDS reads / MFMAs, bit 2 LDS reads but no MFMAs, bit 3 return before the epilogue, bit 4 no barrier inside the K loop
     int ablate;
     F32Rows f32;        // fp32 side rows of the output (token residual sums; sf_common.h), f32.out == nullptr: off
+    int linear;         // host-side hint: a plain matrix product (tile choice, sf_api.hip)
 };
 
 // LDS operand tile [rows][BK] fp16; the 16-byte K slot of a row is XOR-swizzled so that the 16 lanes one ds_read_b128 phase

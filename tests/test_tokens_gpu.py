@@ -11,6 +11,7 @@ def test_gemm_linear(gpu):
     tc.check_gemm(gpu, 1000, 96, 288)
     tc.check_gemm(gpu, 394, 768, 3072, resid=False)
     tc.check_gemm(gpu, 77, 32, 24, bias=False, resid=False)
+    tc.check_gemm(gpu, 100001, 512, 264)                 # sf_igemm2 with 128 x 128 tiles (plain matrix product, K >= 512, > 320 tiles)
 
 
 def test_rows32_side_rows(gpu):

@@ -16,6 +16,9 @@ def test_rows32_side_rows(sim, monkeypatch):
     tc.check_rows32(sim, 2, 9, 32, 96, period_full=True)               # every row (last stage)
     tc.check_rows32(sim, 2, 150, 64, 160, igemm2=True, monkeypatch=monkeypatch)      # second-generation kernel (256-row tiles)
     tc.check_rows32(sim, 2, 20, 64, 128, period_full=True, igemm2=True, monkeypatch=monkeypatch)
+    monkeypatch.setenv("SF_IGEMM2_T128", "2")                          # the 128 x 128 tile of the same kernel (plain matrix products)
+    tc.check_rows32(sim, 2, 150, 64, 160, igemm2=True, monkeypatch=monkeypatch)
+    tc.check_rows32(sim, 3, 47, 96, 136, src32=False, igemm2=True, monkeypatch=monkeypatch)
 
 
 def test_layernorm(sim):
