@@ -1081,8 +1081,13 @@ extern "C" int sf_pool_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C
     p.fdW = make_fastdiv(W); p.fdH = make_fastdiv(H);
     p.total = (int64_t)N * T * H * W * (C / 8);
     REQUIRE(p.total < (1ll << 31), "sf_pool_bwd: too many elements");
-    hipLaunchKernelGGL(sf_pool_bwd_kernel, dim3(pool_grid(p.total + (int64_t)N * (C / 8))), dim3(SF_THREADS), 0,
-                       (hipStream_t)stream, p);
+    p.fdsH = make_fastdiv(sH); p.fdsW = make_fastdiv(sW);
+    if (kH <= 2 * sH && kW <= 2 * sW && test_hook("SF_POOL_BWD4", 1))      // at most 2 x 2 windows cover a position (sf_pool.h)
+        hipLaunchKernelGGL(sf_pool_bwd4_kernel, dim3(pool_grid(p.total + (int64_t)N * (C / 8))), dim3(SF_THREADS), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(sf_pool_bwd_kernel, dim3(pool_grid(p.total + (int64_t)N * (C / 8))), dim3(SF_THREADS), 0,
+                           (hipStream_t)stream, p);
     return check_launch("pool_bwd");
 }
 

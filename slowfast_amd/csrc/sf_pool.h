@@ -20,6 +20,7 @@ struct PoolParams {
     int64_t total;
     int cls;                        // token tensors: every sample's T*H*W rows are preceded by one cls row, which
     FastDiv fdT;                    // passes through the pool (attention.py:24-36); row += nt / T + 1
+    FastDiv fdsH, fdsW;             // bwd: the strides (window index of a position)
 };
 
 // row of (nt = n*T + t, h, w) in a tensor whose spatial dims are (Hx, Wx)
@@ -150,6 +151,77 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
                 }
             }
         }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)g[e];
+        st16(p.out + pool_row(p, nt, p.H, p.W, (int)h, (int)w) * p.ldo + c, o);
+    }
+}
+
+// The same gather when at most TWO windows per dimension cover a position (kH <= 2 sH and kW <= 2 sW: every pooling layer of the
+// model zoo -- 3x3 / stride 2 stems and skip paths).  The four candidate windows' operands (argmax bytes, gradient, pooled value)
+// are requested TOGETHER, with clamped coordinates and validity as predicates: 12 loads in flight per thread.  The nested loops
+// above have runtime bounds, so every window was its own load -> wait -> combine trip, behind two runtime divisions (the stem
+// pool of SlowFast: 434 us for ~670 MB, round 5).  Same summation order (ho, then wo, ascending): bit-identical.
+__global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd4_kernel(PoolParams p) {
+    const int64_t ncls = p.cls ? (int64_t)p.N * (p.C >> 3) : 0;
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total + ncls;
+         idx += (int64_t)gridDim.x * SF_THREADS) {
+        if (idx >= p.total) {     // cls rows: the gradient passes through
+            const int64_t j = idx - p.total;
+            const int G = p.C >> 3;
+            const int64_t n = j / G;
+            const int c = (int)(j % G) * 8;
+            st16(p.out + n * ((int64_t)p.T * p.H * p.W + 1) * p.ldo + c,
+                 ld16(p.dout + n * ((int64_t)p.T * p.Ho * p.Wo + 1) * p.lddo + c));
+            continue;
+        }
+        uint32_t q, gcol, w, h, nt;
+        fd_divmod((uint32_t)idx, p.fdG, q, gcol);
+        fd_divmod(q, p.fdW, q, w);
+        fd_divmod(q, p.fdH, nt, h);
+        const int c = gcol * 8;
+        // candidate windows per dimension: the last one that starts at or before the position, and the one before it
+        const int hh = (int)fd_div(h + (uint32_t)p.pH, p.fdsH), wh = (int)fd_div(w + (uint32_t)p.pW, p.fdsW);
+        int hoc[2], woc[2], khs[2], kws[2];
+        bool hv[2], wv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ho = hh - 1 + a, wo = wh - 1 + a;
+            khs[a] = (int)h - (ho * p.sH - p.pH);
+            kws[a] = (int)w - (wo * p.sW - p.pW);
+            hv[a] = ho >= 0 && ho < p.Ho && khs[a] < p.kH;
+            wv[a] = wo >= 0 && wo < p.Wo && kws[a] < p.kW;
+            hoc[a] = ho < 0 ? 0 : (ho > p.Ho - 1 ? p.Ho - 1 : ho);
+            woc[a] = wo < 0 ? 0 : (wo > p.Wo - 1 ? p.Wo - 1 : wo);
+        }
+        u32x2 pk[2][2];
+        f16x8 d[2][2], pv[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int64_t orow = pool_row(p, nt, p.Ho, p.Wo, hoc[a], woc[b]);
+                pk[a][b] = *reinterpret_cast<const u32x2*>(p.argmax + orow * p.C + c);
+                d[a][b] = ld16(p.dout + orow * p.lddo + c);
+                pv[a][b] = ld16(p.pooled + orow * p.ldp + c);
+            }
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const bool on = hv[a] && wv[b];
+                const uint32_t me = (uint32_t)(khs[a] * p.kW + kws[b]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t am = ((e < 4 ? pk[a][b].x : pk[a][b].y) >> (8 * (e & 3))) & 0xffu;
+                    const bool take = on && (am == me) && (!p.relu || (float)pv[a][b][e] > 0.f);
+                    g[e] += take ? (float)d[a][b][e] : 0.f;
+                }
+            }
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (f16)g[e];
