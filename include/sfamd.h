@@ -122,15 +122,6 @@ int sf_conv_wgrad_rowtab(const sf_conv_desc* d, void* tab, sf_stream_t stream);
 int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, int in_relu,
                   const void* dy, float* dw, float out_scale, int zero_first, void* workspace, int64_t workspace_bytes,
                   const void* rowtab, sf_stream_t stream);
-/* The same with the second kernel NOT launched: `pending` (host memory, sf_wgrad_pending_bytes() bytes) receives the record of
- * the outstanding reduction, `workspace` must stay untouched until sf_wgrad_reduce_batch has run it.  A training step queues
- * the ~100 reductions of a backward segment and runs them in a few launches (the autograd engine of the reference has no
- * counterpart: torch's conv backward returns a finished gradient per layer).  Records of one batch must name distinct `dw`. */
-int64_t sf_wgrad_pending_bytes(void);
-int sf_conv_wgrad_split(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, int in_relu,
-                        const void* dy, float* dw, float out_scale, int zero_first, void* workspace, int64_t workspace_bytes,
-                        const void* rowtab, void* pending, sf_stream_t stream);
-int sf_wgrad_reduce_batch(const void* pending, int32_t n, sf_stream_t stream);
 
 /* ---- BatchNorm3d -- replaces nn.BatchNorm3d built by batchnorm_helper.py:16-37 (get_norm) at every
  * *_bn call site of resnet_helper.py / stem_helper.py / video_model_builder.py:155-159, plus the

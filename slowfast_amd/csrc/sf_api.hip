@@ -814,14 +814,9 @@ extern "C" int64_t sf_conv_wgrad_workspace(const sf_conv_desc* d) {
     return sp.ok && (int64_t)sp.ws_bytes > generic ? (int64_t)sp.ws_bytes : generic;
 }
 
-// a split reduction that was not launched: what sf_wgrad_reduce_batch needs to run it later
-struct WgradPending {
-    WgradReduceParams r;
-    int blocks;
-};
-static int conv_wgrad_impl(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
-                           int in_relu, const void* dy, float* dw, float out_scale, int zero_first,
-                           void* workspace, int64_t workspace_bytes, const void* rowtab, sf_stream_t stream, WgradPending* defer) {
+extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
+                             int in_relu, const void* dy, float* dw, float out_scale, int zero_first,
+                             void* workspace, int64_t workspace_bytes, const void* rowtab, sf_stream_t stream) {
     if (check_desc(d)) return -1;
     REQUIRE(x && dy && dw && workspace, "sf_conv_wgrad: null pointer");
     REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "sf_conv_wgrad: in_scale/in_shift must come together");
@@ -901,7 +896,6 @@ static int conv_wgrad_impl(const sf_conv_desc* d, const void* x, const float* in
         splits = w.splits; Co_pad = w.Co_pad; Kpad = w.Kpad;
     }
     if (check_launch("wgrad")) return -1;
-    if (tune_knob("SF_WGRAD_SKIP_REDUCE", 0)) return 0;      // DIAGNOSTIC (timing only, gradients are garbage): what the reduce launches cost (r5_v41)
     WgradReduceParams r;
     r.ws = slabs; r.splits = splits; r.Co = d->Cow ? d->Cow : d->Co; r.Co_pad = Co_pad; r.Kpad = Kpad;
     r.Ktot = gk.Ktot; r.fdC = gk.fdC; r.dw = dw; r.Cw = d->Cw; r.taps = d->kT * d->kH * d->kW;
@@ -913,48 +907,8 @@ static int conv_wgrad_impl(const sf_conv_desc* d, const void* x, const float* in
     while (lanes < 32 && lanes * 4 <= splits) lanes *= 2;   // ~>= 4 splits per lane, 8..256 elements per block
     r.lanes = lanes;
     const int per_block = SF_THREADS / lanes;
-    if (defer) {                    // the caller keeps `workspace` alive and runs the reduction with others (sf_wgrad_reduce_batch)
-        defer->r = r;
-        defer->blocks = cdiv(total, per_block);
-        return 0;
-    }
     hipLaunchKernelGGL(sf_wgrad_reduce_kernel, dim3(cdiv(total, per_block)), dim3(SF_THREADS), 0, s, r);
     return check_launch("wgrad_reduce");
-}
-extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
-                             int in_relu, const void* dy, float* dw, float out_scale, int zero_first,
-                             void* workspace, int64_t workspace_bytes, const void* rowtab, sf_stream_t stream) {
-    return conv_wgrad_impl(d, x, in_scale, in_shift, in_relu, dy, dw, out_scale, zero_first, workspace, workspace_bytes, rowtab,
-                           stream, nullptr);
-}
-extern "C" int64_t sf_wgrad_pending_bytes(void) { return (int64_t)sizeof(WgradPending); }
-extern "C" int sf_conv_wgrad_split(const sf_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
-                                   int in_relu, const void* dy, float* dw, float out_scale, int zero_first,
-                                   void* workspace, int64_t workspace_bytes, const void* rowtab, void* pending,
-                                   sf_stream_t stream) {
-    REQUIRE(pending, "sf_conv_wgrad_split: null pending record");
-    return conv_wgrad_impl(d, x, in_scale, in_shift, in_relu, dy, dw, out_scale, zero_first, workspace, workspace_bytes, rowtab,
-                           stream, (WgradPending*)pending);
-}
-extern "C" int sf_wgrad_reduce_batch(const void* pending, int32_t n, sf_stream_t stream) {
-    REQUIRE(n >= 0 && (pending || n == 0), "sf_wgrad_reduce_batch: bad arguments");
-    const WgradPending* it = (const WgradPending*)pending;
-    for (int i0 = 0; i0 < n; i0 += SF_WGRAD_BATCH) {
-        WgradReduceBatch b;
-        memset(&b, 0, sizeof(b));
-        b.n = n - i0 < SF_WGRAD_BATCH ? n - i0 : SF_WGRAD_BATCH;
-        int64_t blocks = 0;
-        for (int i = 0; i < b.n; ++i) {
-            b.first[i] = (int)blocks;
-            b.item[i] = it[i0 + i].r;
-            blocks += it[i0 + i].blocks;
-        }
-        b.first[b.n] = (int)blocks;
-        REQUIRE(blocks > 0 && blocks < (1ll << 31), "sf_wgrad_reduce_batch: bad block count");
-        hipLaunchKernelGGL(sf_wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(SF_THREADS), 0, (hipStream_t)stream, b);
-        if (check_launch("wgrad_reduce_batch")) return -1;
-    }
-    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

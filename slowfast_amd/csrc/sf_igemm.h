@@ -487,12 +487,13 @@ struct WgradReduceParams {
 // z, z+L, ... of four consecutive kcol (one 16-byte load per slab, four loads in flight), an LDS tree folds the L lanes
 // (fixed order: the result does not depend on scheduling).  Consecutive quads are contiguous in every slab, so the
 // E threads of one lane read E*16 contiguous bytes (a full 128-byte line for E >= 8).
-__device__ __forceinline__ void wgrad_reduce_block(const WgradReduceParams& p, int64_t block, f32x4* s_acc) {
+__global__ __launch_bounds__(SF_THREADS) void sf_wgrad_reduce_kernel(WgradReduceParams p) {
+    __shared__ f32x4 s_acc[SF_THREADS];
     const int L = p.lanes, E = SF_THREADS / L;
     const int e = threadIdx.x % E, z0 = threadIdx.x / E;
     const int64_t total = (int64_t)p.Co * p.Kpad;           // Kpad is a multiple of 128
     const int64_t slab = (int64_t)p.Co_pad * p.Kpad;
-    const int64_t idx = (block * E + e) * 4;
+    const int64_t idx = ((int64_t)blockIdx.x * E + e) * 4;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     if (idx < total) {
         const float* src = p.ws + idx;          // element (co, kcol) sits at co*Kpad + kcol = idx in every slab
@@ -533,29 +534,6 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradReduceParams& p, i
             }
         }
     }
-}
-__global__ __launch_bounds__(SF_THREADS) void sf_wgrad_reduce_kernel(WgradReduceParams p) {
-    __shared__ f32x4 s_acc[SF_THREADS];
-    wgrad_reduce_block(p, blockIdx.x, s_acc);
-}
-
-// Several split reductions in ONE launch (round 5): the reduce of a layer's partials is 10-20 us of launch latency and pipeline
-// tail around a few MB of traffic, 110 times per SlowFast step (1.35 ms of a 37.8 ms step by ablation, profiles/r5_v41_*).  The
-// weight gradients are not needed before the backward segment ends, so the engine keeps the partial slabs and hands a batch of
-// reductions to this kernel (sf_wgrad_reduce_batch): workgroup b belongs to item i with first[i] <= b < first[i + 1] and runs
-// the same code on that item's parameters.  Items of one batch write disjoint gradients (the caller flushes before it queues a
-// second reduction into the same tensor).
-#define SF_WGRAD_BATCH 32
-struct WgradReduceBatch {
-    int n;
-    int first[SF_WGRAD_BATCH + 1];
-    WgradReduceParams item[SF_WGRAD_BATCH];
-};
-__global__ __launch_bounds__(SF_THREADS) void sf_wgrad_reduce_batch_kernel(WgradReduceBatch b) {
-    __shared__ f32x4 s_acc[SF_THREADS];
-    int i = 0;
-    while (i + 1 < b.n && (int)blockIdx.x >= b.first[i + 1]) ++i;
-    wgrad_reduce_block(b.item[i], (int64_t)blockIdx.x - b.first[i], s_acc);
 }
 
 template <class V>

@@ -180,7 +180,6 @@ def join_side_streams():
     segment, and before parameters are announced final to a gradient reducer."""
     global _join_queued
     _join_queued = False
-    ops.flush_wgrads()              # queued split reductions of the weight gradients: each on the stream it was queued on
     for device in list(_side_pending):
         torch.cuda.current_stream(device).wait_stream(_side_streams[device])
     _side_pending.clear()
@@ -316,7 +315,7 @@ def _always():
 def _notify(params):
     if GRADS_VIA_AUTOGRAD:          # the consumer of the gradients (DDP's reducer) hooks autograd itself
         return
-    if (_side_pending or _pathway_streams or ops.wgrads_pending()) and any(getattr(fn, "needs_join", _always)() for fn in _listeners):
+    if (_side_pending or _pathway_streams) and any(getattr(fn, "needs_join", _always)() for fn in _listeners):
         join_side_streams()         # a listener is about to start the all-reduce of these gradients: they must be complete
     if _sub_passes > 1:
         final = []
@@ -529,8 +528,7 @@ class ConvUnit:
                 with torch.cuda.stream(side):
                     ops.conv_wgrad(x, dy, geom, dw, in_affine=in_affine, out_scale=1.0, zero_first=zero_first, side=True)
             else:
-                ops.conv_wgrad(x, dy, geom, dw, in_affine=in_affine, out_scale=1.0, zero_first=zero_first,
-                               defer=not GRADS_VIA_AUTOGRAD)
+                ops.conv_wgrad(x, dy, geom, dw, in_affine=in_affine, out_scale=1.0, zero_first=zero_first)
         if not need_dx:
             return None
         _, wd = self.weights(geom)

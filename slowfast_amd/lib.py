@@ -99,9 +99,6 @@ _SIGNATURES = {
     "sf_conv_wgrad_rowtab_bytes": (c_int64, [POINTER(ConvDesc)]),
     "sf_conv_wgrad_rowtab": (c_int, [POINTER(ConvDesc), _P, _P]),
     "sf_conv_wgrad": (c_int, [POINTER(ConvDesc), _P, _F, _F, c_int, _P, _F, c_float, c_int, _P, c_int64, _P, _P]),
-    "sf_wgrad_pending_bytes": (c_int64, []),
-    "sf_conv_wgrad_split": (c_int, [POINTER(ConvDesc), _P, _F, _F, c_int, _P, _F, c_float, c_int, _P, c_int64, _P, _P, _P]),
-    "sf_wgrad_reduce_batch": (c_int, [_P, c_int32, _P]),
     "sf_bn_finalize": (c_int, [_F, c_int32, c_int32, c_int32, c_float, _F, _F, _F, _F, c_float, c_float, _F, _F, _F, _F, _P]),
     "sf_bn_act": (c_int, [c_int64, c_int32, _P, c_int32, _F, _F, _P, c_int32, _F, _F, c_int, _P, c_int32, _P, _P]),
     "sf_bn_bwd_blocks": (c_int, [c_int64, c_int32]),

@@ -117,7 +117,7 @@ class LinearUnit:
         lin = self.lin
         if lin.weight.requires_grad:
             dw, zero_first = _grad_dest(lin.weight)
-            tokens.linear_wgrad(x, dy, dw, zero_first=zero_first, defer=not engine.GRADS_VIA_AUTOGRAD)
+            tokens.linear_wgrad(x, dy, dw, zero_first=zero_first)
         if lin.bias is not None and lin.bias.requires_grad and not bias_done:
             db, zero_first = _grad_dest(lin.bias)
             tokens.bias_grad(dy, db, accumulate=not zero_first)
@@ -135,7 +135,7 @@ class LinearUnit:
         lin = self.lin
         if lin.weight.requires_grad:
             dw, zero_first = _grad_dest(lin.weight)
-            tokens.linear_wgrad(x, dy, dw, zero_first=zero_first, defer=not engine.GRADS_VIA_AUTOGRAD)
+            tokens.linear_wgrad(x, dy, dw, zero_first=zero_first)
         if lin.bias is not None and lin.bias.requires_grad and not bias_done:
             db, zero_first = _grad_dest(lin.bias)
             tokens.bias_grad(dy, db, accumulate=not zero_first)
@@ -188,7 +188,7 @@ class QKVUnit:
             dy = dqkv[..., i * C:(i + 1) * C]
             if lin.weight.requires_grad:
                 dw, zero_first = _grad_dest(lin.weight)
-                tokens.linear_wgrad(x, dy, dw, zero_first=zero_first, defer=not engine.GRADS_VIA_AUTOGRAD)
+                tokens.linear_wgrad(x, dy, dw, zero_first=zero_first)
             if lin.bias is not None and lin.bias.requires_grad:
                 db, zero_first = _grad_dest(lin.bias)
                 tokens.bias_grad(dy, db, accumulate=not zero_first)

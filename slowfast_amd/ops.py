@@ -7,8 +7,6 @@ channel slice of such a tensor).  Nothing in this file computes on the CPU or th
 """
 from ctypes import byref, c_int32
 
-import os
-
 import torch
 
 from . import lib as _sflib
@@ -300,98 +298,8 @@ def _workspace(device, nbytes, key=None):
     return ws
 
 
-# ------------------------------------------------------------------------------------------------
-# Deferred split reductions of the weight gradients (round 5).  sf_conv_wgrad = a split-K kernel + a reduction of its partial
-# slabs; the reduction is 10-20 us of launch latency and pipeline tail around a few MB, ~110 times per SlowFast step (1.35 ms of
-# 37.8 by ablation, profiles/r5_v41_*).  Nobody reads a weight gradient before the backward segment ends, so inside
-# ``with deferred_wgrads():`` (step.TrainStep around a backward pass / segment) the calls that ask for it (``defer=True``: the
-# destination is the parameter's gradient itself) run sf_conv_wgrad_split -- every call on a slab of its own -- and the
-# reductions are launched together, <= 32 per launch, by flush_wgrads(): at the end of the block, before any stream join
-# (engine.join_side_streams) and before a second reduction into the same tensor is queued.  Each stream keeps its own list and
-# its flush is enqueued on that stream.  SF_DEFER_WGRAD=0: every call reduces at once (A/B runs).
-DEFER_WGRAD = os.environ.get("SF_DEFER_WGRAD", "1") != "0"
-# a list is also flushed once its slabs exceed this: the reduction should find them in the 256 MB Infinity Cache, not in HBM
-DEFER_WGRAD_BYTES = int(float(os.environ.get("SF_DEFER_WGRAD_MB", "96")) * (1 << 20))
-_defer_depth = 0
-_pending_wgrads = {}        # stream id -> _PendingWgrads
-
-
-class _PendingWgrads:
-    CAP = 96
-
-    def __init__(self, device, stream):
-        import ctypes
-        self.device, self.stream = device, stream
-        self.rec_bytes = int(get_lib().call("sf_wgrad_pending_bytes"))
-        self.buf = ctypes.create_string_buffer(self.rec_bytes * self.CAP)
-        self.base = ctypes.addressof(self.buf)
-        self.n, self.keep, self.dsts, self.nbytes = 0, [], set(), 0
-
-
-class deferred_wgrads:
-    def __enter__(self):
-        global _defer_depth
-        _defer_depth += 1
-        return self
-
-    def __exit__(self, *exc):
-        global _defer_depth
-        _defer_depth -= 1
-        if _defer_depth == 0:
-            flush_wgrads()
-        return False
-
-
-def wgrads_pending():
-    return any(p.n for p in _pending_wgrads.values())
-
-
-def flush_wgrads(only_current=False):
-    """Launch the queued reductions, each list on the stream it was queued on."""
-    for sid, p in list(_pending_wgrads.items()):
-        if not p.n:
-            continue
-        if only_current and sid != (torch.cuda.current_stream(p.device).cuda_stream if p.device.type == "cuda" else 0):
-            continue
-        n, p.n = p.n, 0
-        keep, p.keep, p.dsts, p.nbytes = p.keep, [], set(), 0
-        if p.device.type == "cuda":
-            with torch.cuda.stream(p.stream):
-                get_lib().call("sf_wgrad_reduce_batch", p.base, n, p.stream.cuda_stream)
-        else:
-            get_lib().call("sf_wgrad_reduce_batch", p.base, n, None)
-        del keep            # the slabs go back to the allocator behind the reduction (same stream: ordered)
-
-
-def wgrad_call(d, x_ptr, sc, sh, relu, dy_ptr, dw, out_scale, zero_first, ws_bytes, rowtab, device, stream, work, ws_key=None,
-               defer=False):
-    """sf_conv_wgrad, or -- inside deferred_wgrads() when the caller allows it -- sf_conv_wgrad_split with the reduction queued."""
-    lib = get_lib()
-    if defer and DEFER_WGRAD and _defer_depth > 0:
-        cur = torch.cuda.current_stream(device) if device.type == "cuda" else None
-        sid = cur.cuda_stream if cur is not None else 0
-        p = _pending_wgrads.get(sid)
-        if p is None:
-            p = _pending_wgrads[sid] = _PendingWgrads(device, cur)
-        if p.n == p.CAP or dw.data_ptr() in p.dsts or p.nbytes + int(ws_bytes) > DEFER_WGRAD_BYTES:
-            # full / a second reduction into the same gradient / the slabs would leave the cache: run the queued ones now
-            flush_wgrads(only_current=True)
-        slab = torch.empty(int(ws_bytes), dtype=torch.uint8, device=device)
-        lib.call("sf_conv_wgrad_split", d, x_ptr, sc, sh, relu, dy_ptr, dw.data_ptr(), float(out_scale), int(zero_first),
-                 slab.data_ptr(), slab.numel(), rowtab, p.base + p.n * p.rec_bytes, stream, work=work)
-        p.n += 1
-        p.nbytes += int(ws_bytes)
-        p.keep.append(slab)
-        p.dsts.add(dw.data_ptr())
-        return
-    ws = _workspace(device, ws_bytes, ws_key)
-    lib.call("sf_conv_wgrad", d, x_ptr, sc, sh, relu, dy_ptr, dw.data_ptr(), float(out_scale), int(zero_first),
-             ws.data_ptr(), ws.numel(), rowtab, stream, work=work)
-
-
-def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True, side=False, defer=False):
-    """dw (+)= out_scale * d(loss)/d(weight); dw is an fp32 tensor shaped like the Conv3d weight.  ``defer``: the caller does not
-    read dw before the enclosing deferred_wgrads() block ends (see above)."""
+def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True, side=False):
+    """dw (+)= out_scale * d(loss)/d(weight); dw is an fp32 tensor shaped like the Conv3d weight."""
     assert tuple(x.shape) == geom.in_shape and tuple(dy.shape) == geom.out_shape
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == geom.Cow * geom.Cw * geom.taps
     sc, sh, relu = _affine(in_affine)
@@ -399,9 +307,11 @@ def conv_wgrad(x, dy, geom, dw, in_affine=None, out_scale=1.0, zero_first=True, 
     d = geom.desc(cl_ld(x), cl_ld(dy))
     if geom.ws_bytes is None:
         geom.ws_bytes = lib.call("sf_conv_wgrad_workspace", byref(d))
-    wgrad_call(byref(d), x.data_ptr(), _ptr(sc), _ptr(sh), relu, dy.data_ptr(), dw, out_scale, zero_first, geom.ws_bytes,
-               _ptr(_wgrad_rowtab(geom, d, x.device)) if sc is None else None, x.device, _stream(x),
-               geom.work(reads_x=1, reads_y=1), ws_key="wgrad-side" if side else None, defer=defer and not side)
+    ws = _workspace(x.device, geom.ws_bytes, "wgrad-side" if side else None)
+    lib.call("sf_conv_wgrad", byref(d), x.data_ptr(), _ptr(sc), _ptr(sh), relu,
+                   dy.data_ptr(), dw.data_ptr(), float(out_scale), int(zero_first), ws.data_ptr(), ws.numel(),
+                   _ptr(_wgrad_rowtab(geom, d, x.device)) if sc is None else None, _stream(x),
+                   work=geom.work(reads_x=1, reads_y=1))
     return dw
 
 

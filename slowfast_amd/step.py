@@ -21,7 +21,7 @@ Without a GPU (host-simulator tests) or with ``use_graph=False`` the same sequen
 """
 import torch
 
-from . import engine, ops
+from . import engine
 
 
 class TrainStep:
@@ -99,9 +99,8 @@ class TrainStep:
         loss = self.loss_fn(logits.float(), labels)
         # FlatOptimizer: the (dynamic) loss scale is a device scalar -- a captured graph reads its current value at replay
         scale = self.optimizer.loss_scale if self._flat else self.loss_scale
-        with ops.deferred_wgrads():     # split reductions of the weight gradients queued, run together (ops.deferred_wgrads)
-            (loss * scale).backward()
-            engine.join_side_streams()  # queued reductions flushed on their streams, every forked stream joined
+        (loss * scale).backward()
+        engine.join_side_streams()      # weight gradients forked to the side stream (engine.WGRAD_STREAM)
         return logits, loss
 
     # ---- segmented iteration --------------------------------------------------------------------------------------
@@ -124,8 +123,6 @@ class TrainStep:
     def _backward_segment(k, nseg, scaled_loss, cuts):
         """Segment k of the backward pass, k = nseg-1 (head side) ... 0 (input side)."""
         engine.CUT_BACKWARD = True
-        defer = ops.deferred_wgrads()
-        defer.__enter__()
         try:
             if k == nseg - 1:
                 engine._cut_bn_tags.clear()
@@ -140,8 +137,7 @@ class TrainStep:
                     torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
         finally:
             engine.CUT_BACKWARD = False
-            engine.join_side_streams()  # queued weight-gradient reductions flushed, every forked stream joined: a backward
-            defer.__exit__(None, None, None)    # segment (and its graph) ends complete
+        engine.join_side_streams()      # a backward segment (and its graph) ends with every forked stream joined
 
     def _iteration_segmented_eager(self, inputs, labels, record=False):
         logits, loss, scaled, cuts = self._forward_segmented(inputs, labels)

@@ -132,9 +132,9 @@ def bgemm_tn_heads(p, p_strides, ldp, x, x_strides, ldx, M, R, Kc, out, o_stride
     return out
 
 
-def linear_wgrad(x, dy, dw, zero_first=True, defer=False):
+def linear_wgrad(x, dy, dw, zero_first=True):
     """dw[n][k] (+)= sum_m dy[m][n] * x[m][k] -- the nn.Linear weight gradient, through the conv weight-gradient
-    kernels on a 1x1x1 geometry (fp32, deterministic split reduction).  ``defer``: see ops.deferred_wgrads."""
+    kernels on a 1x1x1 geometry (fp32, deterministic split reduction)."""
     from . import ops
     M, K, ldx = rows_pitch(x)
     Md, N, ldy = rows_pitch(dy)
@@ -144,9 +144,10 @@ def linear_wgrad(x, dy, dw, zero_first=True, defer=False):
     d = geom.desc(ldx, ldy)
     if geom.ws_bytes is None:
         geom.ws_bytes = lib.call("sf_conv_wgrad_workspace", byref(d))
-    ops.wgrad_call(byref(d), x.data_ptr(), None, None, 0, dy.data_ptr(), dw, 1.0, zero_first, geom.ws_bytes,
-                   _ptr(ops._wgrad_rowtab(geom, d, x.device)), x.device, _stream(x),
-                   dict(flops=2.0 * M * N * K, bytes=2.0 * M * (N + K)), defer=defer)
+    ws = _workspace(x.device, geom.ws_bytes)
+    lib.call("sf_conv_wgrad", byref(d), x.data_ptr(), None, None, 0, dy.data_ptr(), dw.data_ptr(), 1.0, int(zero_first),
+             ws.data_ptr(), ws.numel(), _ptr(ops._wgrad_rowtab(geom, d, x.device)), _stream(x),
+             work=dict(flops=2.0 * M * N * K, bytes=2.0 * M * (N + K)))
     return dw
 
 

@@ -193,43 +193,6 @@ def check_conv_wgrad(device, in_shape, Co, k, s, p, d=(1, 1, 1), Cw=None, affine
     return assert_close("conv_wgrad", dw.cpu(), ref, 1e-4)
 
 
-def check_deferred_wgrads(device, seed=0):
-    """ops.deferred_wgrads: the split reductions queued and run in batches give the gradients of the immediate form, bit for bit --
-    several geometries (different split-K kernels), accumulation into a preset gradient, a second reduction into the SAME tensor
-    (flushes the first), more items than one batch launch holds."""
-    cases = [((2, 16, 2, 6, 6), 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)), ((1, 32, 2, 5, 5), 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
-             ((2, 8, 4, 8, 8), 8, (3, 1, 1), (1, 1, 1), (1, 0, 0)), ((1, 64, 1, 4, 4), 128, (1, 1, 1), (1, 2, 2), (0, 0, 0))]
-    items = []
-    for i, (in_shape, Co, k, s, p) in enumerate(cases * 10):          # 40 items: two batch launches
-        x, w = make_conv_case(seed + i, in_shape, Co, k, s, p, (1, 1, 1), None)
-        geom = ops.ConvGeom(in_shape, Co, k, s, p, (1, 1, 1))
-        g = torch.Generator().manual_seed(seed + 100 + i)
-        dy = torch.randn(geom.out_shape, generator=g).to(ACT).float()
-        items.append((host_to_cl(x, device), host_to_cl(dy, device), geom, tuple(w.shape), torch.randn(w.shape, generator=g)))
-
-    def run(defer):
-        outs = []
-        for x, dy, geom, wshape, init in items:
-            dw = init.clone().to(device)
-            ops.conv_wgrad(x, dy, geom, dw, zero_first=False, defer=defer)
-            outs.append(dw)
-        x, dy, geom, _, _ = items[0]
-        ops.conv_wgrad(x, dy, geom, outs[0], zero_first=False, defer=defer)      # a second contribution to the first gradient
-        return outs
-
-    ref = run(False)
-    with ops.deferred_wgrads():
-        got = run(True)
-        assert ops.wgrads_pending(), "the reductions must have been queued"
-    assert not ops.wgrads_pending()
-    for a, b in zip(ref, got):
-        assert torch.equal(a.cpu(), b.cpu())
-    # outside the block `defer` is ignored
-    dw = items[1][4].clone().to(device)
-    ops.conv_wgrad(items[1][0], items[1][1], items[1][2], dw, zero_first=False, defer=True)
-    assert not ops.wgrads_pending() and torch.equal(dw.cpu(), ref[1].cpu())
-
-
 def check_bn_chain(device, shape, relu=True, residual=None, seed=0):
     """conv-stat partials -> finalize -> bn_act, and the backward (reduce/finalize/apply)."""
     g = torch.Generator().manual_seed(seed)

@@ -178,10 +178,6 @@ def test_bn_chain(gpu, shape, relu, residual):
     kc.check_bn_chain(gpu, shape, relu=relu, residual=residual)
 
 
-def test_deferred_wgrad_reductions(gpu):
-    kc.check_deferred_wgrads(gpu)
-
-
 def test_pool(gpu):
     kc.check_pool(gpu, (1, 8, 2, 9, 9))
     kc.check_pool(gpu, (2, 64, 2, 56, 56))

@@ -110,10 +110,6 @@ def test_wgrad_many_splits(sim):
     kc.check_conv_wgrad(sim, (1, 8, 4, 32, 32), 32, (3, 1, 1), (1, 1, 1), (1, 0, 0))
 
 
-def test_deferred_wgrad_reductions(sim):
-    kc.check_deferred_wgrads(sim)
-
-
 def test_roi_align_published_vectors(sim):
     kc.check_roi_known_answer(sim)
 
