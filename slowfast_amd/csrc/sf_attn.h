@@ -60,7 +60,9 @@ struct AttnParams {
                 // the query-side backward kernel, copied straight into LDS by the key-side one
     // DIAGNOSTIC (SF_ATTN_ABLATE, tools/token_bench.py only; results are garbage) -- parts of the key-side backward kernel
     // switched off: bit 0 no S / dP MFMAs, bit 1 no softmax arithmetic (exp, p, dS), bit 2 no dV / dK MFMAs (and their
-    // transposed LDS reads), bit 3 no workgroup barriers, bit 4 no Q / dO copies inside the loop, bit 5 no rq side loads / stores
+    // transposed LDS reads), bit 3 no workgroup barriers, bit 4 no Q / dO copies inside the loop, bit 5 no rq side loads / stores;
+    // forward kernel: 64 key chunks not refreshed after the first two, 128 staging only (no arithmetic), 256 no output stores, 512 no
+    // q / rq loads, 1024 no residual loads, 2048 return at once (profiles/r5_v27_attn_fwd_ablation.txt)
     int ablate;
 };
 
