@@ -1863,8 +1863,12 @@ extern "C" int sf_relpos_scatter(const sf_attn_desc* d, const float* drq, const 
     REQUIRE(total < (1ll << 31), "sf_relpos_scatter: too many elements");
     REQUIRE((uintptr_t)E % 16 == 0, "sf_relpos_scatter: E must be 16-byte aligned");
     const int64_t chunks = (rows + SF_RELPOS_SC_ROWS - 1) / SF_RELPOS_SC_ROWS;
-    hipLaunchKernelGGL(sf_relpos_scatter_kernel, dim3((unsigned)(chunks < 8192 ? chunks : 8192)), dim3(SF_THREADS), 0,
-                       (hipStream_t)stream, p, (f16*)E, lde, make_fastdiv((uint32_t)R), R, rows);
+    if (lde <= SF_RELPOS_SC_LDE && test_hook("SF_RELPOS_SC_LDS", 1))
+        hipLaunchKernelGGL(sf_relpos_scatter_lds_kernel, dim3((unsigned)(chunks < 8192 ? chunks : 8192)), dim3(SF_THREADS), 0,
+                           (hipStream_t)stream, p, (f16*)E, lde, make_fastdiv((uint32_t)R), R, rows);
+    else
+        hipLaunchKernelGGL(sf_relpos_scatter_kernel, dim3((unsigned)(chunks < 8192 ? chunks : 8192)), dim3(SF_THREADS), 0,
+                           (hipStream_t)stream, p, (f16*)E, lde, make_fastdiv((uint32_t)R), R, rows);
     return check_launch("relpos_scatter");
 }
 // out[i] (+)= scale * sum_b part[b*row_len + offset + i], i < n   (table gradients from per-block partials):

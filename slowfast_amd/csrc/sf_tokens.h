@@ -451,6 +451,36 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_scatter_kernel(RelPosPar
     }
 }
 
+// The same through an LDS image of the chunk (round 5): the chunk's 32 rows are contiguous in E, so the image -- zero-filled, the
+// rows' R entries dropped in with 2-byte LDS writes -- leaves as plain 16-byte stores.  The global form above writes every row
+// twice, the second time as isolated 2-byte stores (read-modify-write of 32-byte sectors at the L2): 56 us for 47 MB at the
+// MViTv2-S stage-3 shape.  Needs lde <= SF_RELPOS_SC_LDE halfs (16 KB image); bit-identical.
+#define SF_RELPOS_SC_LDE 256
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_scatter_lds_kernel(RelPosParams p, f16* E, int lde, FastDiv fdR, int R,
+                                                                            int64_t rows) {
+    __shared__ __attribute__((aligned(16))) f16 img[SF_RELPOS_SC_ROWS * SF_RELPOS_SC_LDE];
+    const int l8 = lde >> 3;
+    for (int64_t r0 = (int64_t)blockIdx.x * SF_RELPOS_SC_ROWS; r0 < rows; r0 += (int64_t)gridDim.x * SF_RELPOS_SC_ROWS) {
+        const int nr = rows - r0 < SF_RELPOS_SC_ROWS ? (int)(rows - r0) : SF_RELPOS_SC_ROWS;
+        f32x4* const li = reinterpret_cast<f32x4*>(img);
+        for (int i = threadIdx.x; i < nr * l8; i += SF_THREADS) li[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * R; i += SF_THREADS) {
+            uint32_t lr, j, b, tok, head;
+            fd_divmod((uint32_t)i, fdR, lr, j);
+            const int64_t row = r0 + lr;
+            int qt, qh, qw;
+            bool is_cls;
+            relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
+            if (!is_cls) img[(int)lr * lde + relpos_col(p, (int)j, qt, qh, qw)] = (f16)p.drq[row * R + j];
+        }
+        __syncthreads();
+        f32x4* const dst = reinterpret_cast<f32x4*>(E + r0 * lde);
+        for (int i = threadIdx.x; i < nr * l8; i += SF_THREADS) dst[i] = li[i];
+        __syncthreads();            // the image is rewritten by the next chunk
+    }
+}
+
 // The concatenated table Tab = [rel_pos_h; rel_pos_w; rel_pos_t] as 16-bit GEMM operands in ONE launch: t16 [TRp][D] (rows
 // beyond the tables are zero) and its transpose t16t [D][TRp] (round 4: torch.cat + zeros + copy + transpose-copy per block and
 // step before); and the way back, the rows of dTab [TRp][D] fp32 into the three parameter gradients (copy or accumulate).
