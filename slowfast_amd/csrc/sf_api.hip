@@ -1824,6 +1824,12 @@ extern "C" int sf_relpos_gather(const sf_attn_desc* d, const void* G, int32_t ld
     const int R = d->kH + d->kW + d->kT;
     const int64_t total = (int64_t)d->B * d->Nq * d->heads * R;
     REQUIRE(total < (1ll << 31), "sf_relpos_gather: too many elements");
+    if (ldg % 8 == 0 && ldg <= 256 && (uintptr_t)G % 16 == 0 && test_hook("SF_RELPOS_GA_LDS", 1)) {
+        const int64_t rows = (int64_t)d->B * d->Nq * d->heads, chunks = (rows + 31) / 32;
+        hipLaunchKernelGGL(sf_relpos_gather_lds_kernel, dim3((unsigned)(chunks < 8192 ? chunks : 8192)), dim3(SF_THREADS), 0,
+                           (hipStream_t)stream, p, (const f16*)G, ldg, make_fastdiv((uint32_t)R), R, rows);
+        return check_launch("relpos_gather");
+    }
     hipLaunchKernelGGL(sf_relpos_gather_kernel, dim3(pool_grid(total)), dim3(SF_THREADS), 0, (hipStream_t)stream, p,
                        (const f16*)G, ldg, make_fastdiv((uint32_t)R), total);
     return check_launch("relpos_gather");

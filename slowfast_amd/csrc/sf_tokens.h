@@ -425,6 +425,32 @@ __global__ __launch_bounds__(SF_THREADS) void sf_relpos_gather_kernel(RelPosPara
         p.rq[i] = is_cls ? 0.f : (float)G[(int64_t)row * ldg + relpos_col(p, (int)j, qt, qh, qw)];
     }
 }
+// The gather through an LDS image of 32 whole rows of G (round 5, as the scatter below): the rows arrive with plain 16-byte loads
+// (the element-wise form touched every 128-byte line of G anyway, two bytes at a time behind a dependent index load), the R picks
+// per row come out of LDS and rq is written in order.  ldg % 8 == 0, ldg <= SF_RELPOS_SC_LDE,
+// G 16-byte aligned; bit-identical.
+__global__ __launch_bounds__(SF_THREADS) void sf_relpos_gather_lds_kernel(RelPosParams p, const f16* G, int ldg, FastDiv fdR, int R,
+                                                                           int64_t rows) {
+    __shared__ __attribute__((aligned(16))) f16 img[32 * 256];
+    const int l8 = ldg >> 3;
+    for (int64_t r0 = (int64_t)blockIdx.x * 32; r0 < rows; r0 += (int64_t)gridDim.x * 32) {
+        const int nr = rows - r0 < 32 ? (int)(rows - r0) : 32;
+        const f32x4* const src = reinterpret_cast<const f32x4*>(G + r0 * ldg);
+        f32x4* const li = reinterpret_cast<f32x4*>(img);
+        for (int i = threadIdx.x; i < nr * l8; i += SF_THREADS) li[i] = src[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * R; i += SF_THREADS) {
+            uint32_t lr, j, b, tok, head;
+            fd_divmod((uint32_t)i, fdR, lr, j);
+            const int64_t row = r0 + lr;
+            int qt, qh, qw;
+            bool is_cls;
+            relpos_row_decode(p, (uint32_t)row, b, tok, head, qt, qh, qw, is_cls);
+            p.rq[row * R + j] = is_cls ? 0.f : (float)img[(int)lr * ldg + relpos_col(p, (int)j, qt, qh, qw)];
+        }
+        __syncthreads();            // the image is rewritten by the next chunk
+    }
+}
 // Each workgroup owns chunks of SF_RELPOS_SC_ROWS whole rows of E: it zero-fills them with 16-byte stores and then, behind a
 // barrier, drops the rows' R gradient entries into place.  (A hipMemsetAsync in front of a flat scatter did the same in eager
 // launches, but as a memset node of a captured graph the fill did not take effect before the readers of E on ROCm 7.2: from
