@@ -62,6 +62,10 @@ __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_fwd_kernel(LnParams p
         float s1[RU];
         int m[RU];
         bool rowok[RU];
+        // every 16-bit row piece of the pass is requested first, UNCONDITIONALLY (offset 0 stands in for rows / columns past the end,
+        // the value is replaced by zero afterwards): with the load inside `ok ? ld16(..) : zero8()` / the side-row branch, hipcc
+        // waited for row u before it asked for row u + 1 -- the "RU rows in flight" above were one (round 5)
+        f16x8 h[RU][NS];
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             m[u] = base + u * RPB + rl;
@@ -70,15 +74,26 @@ __global__ __launch_bounds__(SF_THREADS) void sf_layernorm_fwd_kernel(LnParams p
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int c = (sub + s * L) * 8;
-                uint32_t srow;
-                if (p.f32.in && rowok[u] && c < p.C && f32_row(p.f32, m[u], srow)) {
-                    load8f(p.f32.in + (int64_t)srow * p.f32.ld + c, v[u][s]);
-                } else {
-                    const f16x8 h = (rowok[u] && c < p.C) ? ld16(p.x + (int64_t)m[u] * p.ldx + c) : zero8();
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[u][s][e] = (float)h[e];
-                }
+                h[u][s] = ld16(p.x + ((rowok[u] && c < p.C) ? (int64_t)m[u] * p.ldx + c : 0));
             }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const bool ok = rowok[u] && (sub + s * L) * 8 < p.C;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][s][e] = ok ? (float)h[u][s][e] : 0.f;
+            }
+        if (p.f32.in) {             // rows with an fp32 side copy (class tokens) are normalised from it
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int c = (sub + s * L) * 8;
+                    uint32_t srow;
+                    if (rowok[u] && c < p.C && f32_row(p.f32, m[u], srow)) load8f(p.f32.in + (int64_t)srow * p.f32.ld + c, v[u][s]);
+                }
         }
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
