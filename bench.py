@@ -73,7 +73,9 @@ def pmc_traffic(entry, preset, launches_per_step):
     if entry not in ENTRY_KERNELS or not os.path.exists(path):
         return None
     with open(path) as f:
-        kern = json.load(f)["kernels"]
+        doc = json.load(f)
+    kern = doc["kernels"]
+    pmc_traffic.build_id = doc.get("sf_build_id")       # the library build the PMC passes were taken on
     tot, steps = 0.0, None
     for name, v in kern.items():
         if any(name.replace("void ", "").startswith(k) for k in ENTRY_KERNELS[entry]):
@@ -110,6 +112,9 @@ def parse():
                          "slowfast_amd.optim.FlatOptimizer (one norm pass + one fused update, device-side dynamic loss scale)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the second model of BASELINE.json's metric (MViTv2-S) that the default run appends as `secondary`")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the remaining GPU configurations of BASELINE.json (X3D-M batch 64, SlowFast-R101 + Nonlocal AVA batch 16) "
+                         "that the default run appends as `others` (--no-secondary skips them too)")
     ap.add_argument("--master-port", type=int, default=0, help="(self-spawned multi-GPU runs) rendezvous port, 0 = pick a free one")
     return ap.parse_args()
 
@@ -320,6 +325,37 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
         dt = float(t.item())
     final_loss = float(loss.detach())
 
+    # N > 1: what a scaling efficiency below 0.9 would have to be attributed to.  `overlap_log` = collectives
+    # still in flight when the LAST backward segment starts (per timed iteration); `one_stream` = the same binary with the
+    # pathway / branch streams off (engine.run_pathways / run_branches), i.e. without RCCL's kernels sharing the chip with a
+    # two-queue backward.
+    multi = None
+    if world > 1 and not a.dry_run_cpu:
+        from slowfast_amd import engine as _eng
+        multi = {"overlap_log": list(train_step.overlap_log)[-steps:], "segments": len(getattr(train_step, "_seg_params", []) or []),
+                 "buckets": len(reducer.buckets)}
+        keep = (_eng.PATHWAY_STREAMS, _eng.BRANCH_STREAMS)
+        _eng.PATHWAY_STREAMS = _eng.BRANCH_STREAMS = False
+        try:
+            ts1 = TrainStep(step_model, reducer, opt, loss_fn, loss_scale=a.loss_scale, use_graph=not a.no_graph, warmup=1,
+                            clip_grad_l2norm=cfg.SOLVER.CLIP_GRAD_L2NORM, clip_grad_val=cfg.SOLVER.CLIP_GRAD_VAL)
+            for _ in range(3):
+                ts1(inputs, labels)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                ts1(inputs, labels)
+            fence()
+            d1 = time.perf_counter() - t1
+            tt = torch.tensor([d1], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            multi["one_stream"] = {"ms_per_step": round(float(tt.item()) / steps * 1e3, 3),
+                                   "overlap_log": list(ts1.overlap_log)[-steps:],
+                                   "note": "SF_PATHWAY_STREAMS=0 SF_BRANCH_STREAMS=0 equivalent, same process, after the timed region"}
+            del ts1
+        finally:
+            _eng.PATHWAY_STREAMS, _eng.BRANCH_STREAMS = keep
+
     kernels, roof = {}, None
     if kernel_profile:
         with KernelProfiler() as prof:
@@ -356,6 +392,8 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
             roof["traffic_note"] = ("HBM bytes per launch from the COMMITTED rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                     f"(profiles/pmc_traffic_{preset}.json, not this run); algorithmic bytes per launch = "
                                     f"{v['bytes'] / max(v['calls'], 1):.0f}")
+            roof["traffic_sf_build_id"] = getattr(pmc_traffic, "build_id", None)
+            roof["sf_build_id"] = sflib.get_lib().build_id
         roof["avg_launch_ms"] = round(v["avg_ms"], 4)
         roof["launches_per_step"] = v["calls"]
         roof["kernel_ms_per_step"] = round(tot, 2)
@@ -398,6 +436,8 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
                 "unit": "GB/s", "frac": round(per_gpu * BYTE_FLOOR_GB_PER_CLIP[preset] / HBM_PEAK_GBS, 4),
                 "note": "whole step vs the fused-ideal byte floor 5*E*2B per clip (SURVEY.md 8d)",
                 "mfma_tflops": round(per_gpu * TRAIN_GFLOP_PER_CLIP[preset] / 1e3, 1)}
+        if multi is not None:
+            out["multi_gpu"] = multi
         if roof is not None:
             out["roofline"] = roof
             out["kernels"] = kernels
@@ -460,6 +500,21 @@ def main():
                                                     "model_roofline", "roofline", "kernels", "final_loss", "cpu_baseline")
                                 if k in sec}
             out["secondary"]["preset"] = "MVITv2_S_16x4"
+        # ... and the other two GPU configurations BASELINE.json names (configs[2]: X3D-M batch 64, configs[4]: SlowFast-R101 +
+        # Nonlocal on AVA-shaped clips), so that the driver's record covers every one of them; CPU samples bounded harder still
+        if not a.no_others:
+            others = []
+            for preset, batch in (("X3D_M", 64), ("SLOWFAST_32x2_R101_50_50", 16)):
+                a.cpu_baseline_timeout = min(a.cpu_baseline_timeout, 90.0)
+                r = run_preset(a, preset, batch, min(a.steps, 10), min(a.warmup, 3), rank, local, world, dev,
+                               kernel_profile=not a.no_kernel_profile, cpu_base=not a.no_cpu_baseline)
+                if r is not None:
+                    o = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "model_roofline",
+                                           "roofline", "final_loss", "cpu_baseline") if k in r}
+                    o["preset"] = preset
+                    others.append(o)
+            if out is not None:
+                out["others"] = others
     if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -9,6 +9,7 @@
 #include "sf_pool.h"
 #include "sf_dwconv.h"
 #include "sf_dwtile.h"
+#include "sf_dwsweep.h"
 #include "sf_tokens.h"
 #include "sf_x3d.h"
 #include "sf_stem.h"
@@ -1590,10 +1591,219 @@ static void dwtile_launch(DwTileParams& p, int np, hipStream_t s) {
     else hipLaunchKernelGGL(sf_dwtile_kernel<4>, grid, dim3(SF_THREADS), 0, s, p);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ring-buffered plane sweep with the channels on the lanes (sf_dwsweep.h, round 6): every 3x3x3 / padding 1 / stride (1, s, s),
+// s = 1 | 2 depthwise convolution (MViT pooling, X3D channelwise), forward / data gradient / weight gradient.  SF_DW_SWEEP=0 keeps
+// the older kernels (A/B runs, read per call).  dir: 0 forward, 1 data gradient, 2 weight gradient.
+static bool dwsweep_shape_ok(const sf_dw_desc* d) {
+    if (d->kT != 3 || d->kH != 3 || d->kW != 3 || d->pT != 1 || d->pH != 1 || d->pW != 1) return false;
+    if (d->sT != 1 || d->sH != d->sW || (d->sH != 1 && d->sH != 2) || d->To != d->Ti) return false;
+    return d->C % 8 == 0 && d->Cw % 8 == 0;
+}
+static int64_t dwsweep_max_rows(const sf_dw_desc* d) { return (int64_t)d->N * d->Ho * 4; }
+static bool dwsweep_plan(const sf_dw_desc* d, int dir, DwSweepParams& p, int& kmode, int& ks) {
+    const char* lv = getenv("SF_DW_SWEEP");
+    if (lv && atoi(lv) == 0) return false;
+    if (!dwsweep_shape_ok(d)) return false;
+    memset(&p, 0, sizeof(p));
+    p.N = d->N; p.C = d->C; p.Cw = d->Cw; p.Cwreal = d->Cwreal ? d->Cwreal : d->Cw; p.cls = d->cls ? 1 : 0; p.T = d->Ti;
+    p.nchunks = cdiv(d->C, 32);
+    const int s = d->sH;
+    int LS;                                             // rows of the staged tile between the rows of neighbouring lanes
+    if (dir == 0) { kmode = 0; ks = s; p.Ha = d->Hi; p.Wa = d->Wi; p.Hd = d->Ho; p.Wd = d->Wo; p.Hit = d->Ho; p.Wit = d->Wo; LS = s; }
+    else if (dir == 1 && s == 1) { kmode = 0; ks = 1; p.flip = 1; p.Ha = d->Ho; p.Wa = d->Wo; p.Hd = d->Hi; p.Wd = d->Wi; p.Hit = d->Hi; p.Wit = d->Wi; LS = 1; }
+    else if (dir == 1) { kmode = 1; ks = 2; p.Ha = d->Ho; p.Wa = d->Wo; p.Hd = d->Hi; p.Wd = d->Wi; p.Hit = d->Ho; p.Wit = d->Wo; LS = 1; }
+    else { kmode = 2; ks = s; p.Ha = d->Hi; p.Wa = d->Wi; p.Hb = d->Ho; p.Wb = d->Wo; p.Hit = d->Ho; p.Wit = d->Wo; LS = s; }
+    const int es = kmode == 1 ? 1 : ks;                 // staged positions per iterated position and axis
+    const int halo = kmode == 1 ? 1 : 2;
+    auto env_int = [](const char* n) { const char* e = getenv(n); return e ? atoi(e) : 0; };
+    const int f_th = env_int("SF_DWS_TH"), f_tw = env_int("SF_DWS_TW"), f_seg = env_int("SF_DWS_NSEG");     // tests / tuning
+    double best = 0.0;
+    for (int kw = 1; kw <= 16; ++kw) {
+        const int tw = cdiv(p.Wit, kw);
+        if (kw > 1 && tw == cdiv(p.Wit, kw - 1)) continue;
+        if (f_tw > 0 && tw != (f_tw < p.Wit ? f_tw : p.Wit)) continue;
+        const int ca = (tw - 1) * es + 1 + halo;
+        int rp = ca * 64;
+        if (LS == 1) { if (rp % 128 == 0) rp += 64; } else rp += 32;
+        for (int th = p.Hit < 32 ? p.Hit : 32; th >= 1; --th) {
+            if (f_th > 0 && th != (f_th < p.Hit ? f_th : p.Hit)) continue;
+            const int ra = (th - 1) * es + 1 + halo;
+            const int slotb = roundup(ra * rp, 1024);
+            if (slotb > SF_DWS_MAXVPT * 4096) continue;
+            int lds = SF_DWS_NR * slotb, rpb = 0, slotbB = 0;
+            if (kmode == 2) {
+                rpb = tw * 64;
+                if (rpb % 128 == 0) rpb += 64;
+                slotbB = roundup(th * rpb, 1024);
+                if (slotbB > SF_DWS_MAXVPTB * 4096) continue;
+                lds += SF_DWS_NRB * slotbB;
+            }
+            if (lds > SF_DWS_LDS) continue;
+            const int tiles_h = cdiv(p.Hit, th), tiles_w = cdiv(p.Wit, tw);
+            if ((int64_t)p.N * tiles_h * tiles_w > dwsweep_max_rows(d)) continue;
+            const int ngrp = cdiv(th, 8);
+            for (int nseg = 1; nseg <= 8 && nseg <= tw; ++nseg) {
+                if (f_seg > 0 && nseg != (f_seg < tw ? f_seg : tw)) continue;
+                const int sl = cdiv(tw, nseg);
+                if (cdiv(tw, sl) != nseg) continue;
+                const int ntask = ngrp * nseg;
+                // VALU time of the busiest wave per plane (columns + the window fill of every segment) against the useful columns
+                const double wave_cols = (double)cdiv(ntask, 4) * (sl + 0.5);
+                const double useful = (double)p.Hit * p.Wit / ((double)tiles_h * tiles_w);        // outputs of an average tile
+                const double valu_eff = useful / (wave_cols * 4.0 * 8.0);
+                const double stage_eff = (double)(th * es) * (tw * es) / ((double)ra * ca);        // halo re-reads (L2 -> LDS)
+                const double sweep = (double)p.T * wave_cols;
+                const double startup = sweep / (sweep + 10.0);                                      // weights + ring fill per workgroup
+                const double blocks = (double)p.N * tiles_h * tiles_w * p.nchunks;
+                const double fill = blocks >= 512.0 ? blocks / (cdiv((int64_t)blocks, 512) * 512.0) : blocks / 512.0;
+                const double score = valu_eff * (0.5 + 0.5 * stage_eff) * startup * (0.5 + 0.5 * fill);
+                if (score > best) {
+                    best = score;
+                    p.TH = th; p.TW = tw; p.tiles_h = tiles_h; p.tiles_w = tiles_w;
+                    p.RA = ra; p.CA = ca; p.RP = rp; p.slotb = slotb; p.vpt = cdiv(slotb, 4096);
+                    p.RB = th; p.CBt = tw; p.RPB = rpb; p.slotbB = slotbB; p.vptB = slotbB ? cdiv(slotbB, 4096) : 0;
+                    p.ngrp = ngrp; p.nseg = nseg; p.SL = sl;
+                }
+            }
+        }
+    }
+    if (best <= 0.0) return false;
+    p.fdRP = make_fastdiv(p.RP); p.fdRPB = make_fastdiv(p.RPB ? p.RPB : 1); p.fdSeg = make_fastdiv(p.nseg);
+    const int64_t per_n_a = (int64_t)p.T * p.Ha * p.Wa + p.cls;
+    const int lda = dir == 1 ? d->ldy : d->ldx;
+    if ((int64_t)p.Ha * p.Wa * lda >= (1ll << 31) || per_n_a * lda >= (1ll << 40)) return false;
+    if (kmode == 2 && (int64_t)p.Hb * p.Wb * d->ldy >= (1ll << 31)) return false;
+    return true;
+}
+// Rotating-accumulator form of the sweep (sf_dwsweep.h: sf_dwrot_kernel): forward, stride-1 data gradient, weight gradient.
+// A tile is ngrp groups of 4 rows x nseg runs of SL columns, one (group, run) per wave.  SF_DW_ROT=0 keeps sf_dwsweep_kernel.
+// strides >= 3 (windows do not overlap): forward and weight gradient on sf_dwrot_kernel<., 3, ...> (packed staging), data
+// gradient on sf_dwgap_dgrad_kernel
+static bool dwgap_shape_ok(const sf_dw_desc* d) {
+    if (d->kT != 3 || d->kH != 3 || d->kW != 3 || d->pT != 1 || d->pH != 1 || d->pW != 1) return false;
+    if (d->sT != 1 || d->sH != d->sW || d->sH < 3 || d->To != d->Ti) return false;
+    return d->C % 8 == 0 && d->Cw % 8 == 0;
+}
+static bool dwrot_plan(const sf_dw_desc* d, int dir, DwSweepParams& p, int& kmode, int& ks, int& ksl) {
+    const char* lv = getenv("SF_DW_ROT");
+    if (lv && atoi(lv) == 0) return false;
+    lv = getenv("SF_DW_SWEEP");
+    if (lv && atoi(lv) == 0) return false;
+    const bool gap = dwgap_shape_ok(d);
+    if (!dwsweep_shape_ok(d) && !gap) return false;
+    if (dir == 1 && d->sH != 1) return false;           // stride 2: sf_dwsweep_kernel<1, 2>; strides >= 3: sf_dwgap_dgrad_kernel
+    memset(&p, 0, sizeof(p));
+    p.N = d->N; p.C = d->C; p.Cw = d->Cw; p.Cwreal = d->Cwreal ? d->Cwreal : d->Cw; p.cls = d->cls ? 1 : 0; p.T = d->Ti;
+    p.nchunks = cdiv(d->C, 32);
+    const int s = gap ? 3 : d->sH;                      // kernel template stride (3 = packed staging of a stride p.gs >= 3)
+    p.gs = d->sH;
+    if (dir == 0) { kmode = 0; ks = s; p.Ha = d->Hi; p.Wa = d->Wi; p.Hd = d->Ho; p.Wd = d->Wo; p.Hit = d->Ho; p.Wit = d->Wo; }
+    else if (dir == 1) { kmode = 0; ks = 1; p.flip = 1; p.Ha = d->Ho; p.Wa = d->Wo; p.Hd = d->Hi; p.Wd = d->Wi; p.Hit = d->Hi; p.Wit = d->Wi; }
+    else { kmode = 2; ks = s; p.Ha = d->Hi; p.Wa = d->Wi; p.Hb = d->Ho; p.Wb = d->Wo; p.Hit = d->Ho; p.Wit = d->Wo; }
+    const int lds_cap = ks == 1 ? DwrLds<0, 1>::bytes : DwrLds<0, 2>::bytes;
+    const int64_t max_rows = gap ? (int64_t)d->N * d->Ho * d->Wo : dwsweep_max_rows(d);
+    auto env_int = [](const char* n) { const char* e = getenv(n); return e ? atoi(e) : 0; };
+    const int f_sl = env_int("SF_DWR_SL"), f_grp = env_int("SF_DWR_NGRP"), f_seg = env_int("SF_DWR_NSEG");         // tests / tuning
+    const int f_nr = env_int("SF_DWR_NR");
+    double best = 0.0;
+    static const int kSL[2] = {7, 4};
+    for (int si = 0; si < 2; ++si) {
+        const int sl = kSL[si];
+        if (f_sl > 0 && sl != f_sl) continue;
+        for (int ngrp = 1; ngrp <= 4; ++ngrp)
+            for (int nseg = 1; ngrp * nseg <= 4; ++nseg) {
+                if ((f_grp > 0 && ngrp != f_grp) || (f_seg > 0 && nseg != f_seg)) continue;
+                const int th = 4 * ngrp, tw = sl * nseg;
+                const int ca = (tw - 1) * ks + 3, ra = (th - 1) * ks + 3;
+                int rp = ca * 64;
+                if (ks != 2) { if (rp % 128 == 0) rp += 64; } else rp += 32;      // (stride * pitch) % 128 == 64: the rows of a read group
+                const int slotb = roundup(ra * rp, 1024);
+                if (slotb > SF_DWS_MAXVPT * 4096) continue;
+                int rpb = 0, slotbB = 0;
+                if (kmode == 2) {
+                    rpb = tw * 64;
+                    if (rpb % 128 == 0) rpb += 64;
+                    slotbB = roundup(th * rpb, 1024);
+                    if (slotbB > SF_DWS_MAXVPTB * 4096) continue;
+                }
+                // ring depth: up to three planes in flight when the LDS class holds them (measured: 3 / 4 / 5 slots within 3 % of each
+                // other at the MViT stage-3 planes, profiles/r6_v10_ring_depth.txt -- the sweep is not bound by the copies' latency)
+                int nr = f_nr > 0 ? f_nr : 4;
+                while (nr >= 3 && nr * slotb + (nr - 1) * slotbB > lds_cap) --nr;
+                if (nr < 3 || nr > SF_DWR_MAXNR) continue;
+                if (nr > p.T + 1) nr = p.T + 1 > 3 ? p.T + 1 : 3;
+                const int tiles_h = cdiv(p.Hit, th), tiles_w = cdiv(p.Wit, tw);
+                if ((int64_t)p.N * tiles_h * tiles_w > max_rows) continue;
+                const int ntask = ngrp * nseg;
+                const double valu_eff = (double)p.Hit * p.Wit / ((double)tiles_h * tiles_w * ntask * 4.0 * sl);
+                const double stage_eff = gap ? 1.0 : (double)(th * ks) * (tw * ks) / ((double)ra * ca);
+                const double occ = ntask == 4 ? 1.0 : ntask == 3 ? 0.85 : ntask == 2 ? 0.7 : 0.5;     // idle waves hold registers and LDS
+                const double run = (sl + 2.0 / ks) / (sl + 2.0);                                    // window words per output
+                const double score = valu_eff * occ * (0.6 + 0.4 * stage_eff) * (0.9 + 0.1 * run);
+                if (score > best) {
+                    best = score;
+                    ksl = sl;
+                    p.nr = nr;
+                    p.TH = th; p.TW = tw; p.tiles_h = tiles_h; p.tiles_w = tiles_w;
+                    p.RA = ra; p.CA = ca; p.RP = rp; p.slotb = slotb; p.vpt = cdiv(slotb, 4096);
+                    p.RB = th; p.CBt = tw; p.RPB = rpb; p.slotbB = slotbB; p.vptB = slotbB ? cdiv(slotbB, 4096) : 0;
+                    p.ngrp = ngrp; p.nseg = nseg; p.SL = sl;
+                }
+            }
+    }
+    if (best <= 0.0) return false;
+    p.fdRP = make_fastdiv(p.RP); p.fdRPB = make_fastdiv(p.RPB ? p.RPB : 1); p.fdSeg = make_fastdiv(p.nseg);
+    const int64_t per_n_a = (int64_t)p.T * p.Ha * p.Wa + p.cls;
+    const int lda = dir == 1 ? d->ldy : d->ldx;
+    if ((int64_t)p.Ha * p.Wa * lda >= (1ll << 31) || per_n_a * lda >= (1ll << 40)) return false;
+    if (kmode == 2 && (int64_t)p.Hb * p.Wb * d->ldy >= (1ll << 31)) return false;
+    return true;
+}
+static void dwrot_launch(DwSweepParams& p, int kmode, int ks, int sl, bool stats, hipStream_t s) {
+    const dim3 grid((unsigned)(p.N * p.tiles_h * p.tiles_w * p.nchunks));
+    static const bool trace = test_hook("SF_TRACE", 0) != 0;
+    if (trace) fprintf(stderr, "[sfamd] dwrot: mode %d s=%d SL=%d N=%d C=%d T=%d a %dx%d it %dx%d TH=%d TW=%d tiles %dx%d RA=%d CA=%d RP=%d slot %d "
+                       "(b %d) ring %d grp=%d seg=%d blocks=%u\n", kmode, ks, sl, p.N, p.C, p.T, p.Ha, p.Wa, p.Hit, p.Wit, p.TH, p.TW, p.tiles_h, p.tiles_w,
+                       p.RA, p.CA, p.RP, p.slotb, p.slotbB, p.nr, p.ngrp, p.nseg, grid.x);
+#define SF_DWR_LAUNCH(M, S, L, ST) hipLaunchKernelGGL((sf_dwrot_kernel<M, S, L, ST>), grid, dim3(SF_THREADS), 0, s, p)
+#define SF_DWR_SL(M, S, ST) do { if (sl == 7) SF_DWR_LAUNCH(M, S, 7, ST); else SF_DWR_LAUNCH(M, S, 4, ST); } while (0)
+    if (kmode == 0) {
+        if (ks == 1) { if (stats) SF_DWR_SL(0, 1, true); else SF_DWR_SL(0, 1, false); }
+        else if (ks == 2) { if (stats) SF_DWR_SL(0, 2, true); else SF_DWR_SL(0, 2, false); }
+        else { if (stats) SF_DWR_SL(0, 3, true); else SF_DWR_SL(0, 3, false); }
+    } else if (ks == 1) SF_DWR_SL(2, 1, false);
+    else if (ks == 2) SF_DWR_SL(2, 2, false);
+    else SF_DWR_SL(2, 3, false);
+#undef SF_DWR_SL
+#undef SF_DWR_LAUNCH
+}
+static void dwsweep_launch(DwSweepParams& p, int kmode, int ks, bool stats, hipStream_t s) {
+    const dim3 grid((unsigned)(p.N * p.tiles_h * p.tiles_w * p.nchunks));
+    static const bool trace = test_hook("SF_TRACE", 0) != 0;
+    if (trace) fprintf(stderr, "[sfamd] dwsweep: mode %d s=%d N=%d C=%d T=%d a %dx%d it %dx%d TH=%d TW=%d tiles %dx%d RA=%d CA=%d RP=%d slot %d "
+                       "(b %d) grp=%d seg=%d SL=%d blocks=%u\n", kmode, ks, p.N, p.C, p.T, p.Ha, p.Wa, p.Hit, p.Wit, p.TH, p.TW, p.tiles_h, p.tiles_w,
+                       p.RA, p.CA, p.RP, p.slotb, p.slotbB, p.ngrp, p.nseg, p.SL, grid.x);
+#define SF_DWS_LAUNCH(M, S, ST) hipLaunchKernelGGL((sf_dwsweep_kernel<M, S, ST>), grid, dim3(SF_THREADS), 0, s, p)
+    if (kmode == 0) {
+        if (ks == 1) { if (stats) SF_DWS_LAUNCH(0, 1, true); else SF_DWS_LAUNCH(0, 1, false); }
+        else { if (stats) SF_DWS_LAUNCH(0, 2, true); else SF_DWS_LAUNCH(0, 2, false); }
+    } else if (kmode == 1) SF_DWS_LAUNCH(1, 2, false);
+    else if (ks == 1) SF_DWS_LAUNCH(2, 1, false);
+    else SF_DWS_LAUNCH(2, 2, false);
+#undef SF_DWS_LAUNCH
+}
+
 extern "C" int sf_dwconv_fwd_blocks(const sf_dw_desc* d) {
     DwParams p;
     dim3 grid;
     if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
+    if (!d->cls) {      // the sweep carries the BatchNorm partial sums: one row per (sample, tile)
+        DwSweepParams sp;
+        int km, ks, sl;
+        if (dwrot_plan(d, 0, sp, km, ks, sl)) return sp.N * sp.tiles_h * sp.tiles_w;
+        if (dwsweep_plan(d, 0, sp, km, ks)) return sp.N * sp.tiles_h * sp.tiles_w;
+    }
     if (dw_blocked_kind(d)) {
         DwBlockIdx bi;
         dw_block_plan(p, bi, d, true, kDwFwdBlocks, grid);
@@ -1606,6 +1816,20 @@ extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w,
     dim3 grid;
     if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
     REQUIRE(x && w && y, "sf_dwconv_fwd: null pointer");
+    if (!(stat_part && d->cls)) {
+        DwSweepParams sp;
+        int km, ks, sl;
+        if (dwrot_plan(d, 0, sp, km, ks, sl)) {
+            sp.a = (const f16*)x; sp.lda = d->ldx; sp.dst = (f16*)y; sp.ldd = d->ldy; sp.w = w; sp.part = stat_part;
+            dwrot_launch(sp, km, ks, sl, stat_part != nullptr, (hipStream_t)stream);
+            return check_launch("dwconv_fwd (rot)");
+        }
+        if (dwsweep_plan(d, 0, sp, km, ks)) {
+            sp.a = (const f16*)x; sp.lda = d->ldx; sp.dst = (f16*)y; sp.ldd = d->ldy; sp.w = w; sp.part = stat_part;
+            dwsweep_launch(sp, km, ks, stat_part != nullptr, (hipStream_t)stream);
+            return check_launch("dwconv_fwd (sweep)");
+        }
+    }
     {
         DwTileParams tp;
         int np;
@@ -1634,6 +1858,39 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
     dim3 grid;
     if (fill_dw(p, d, false, 8192, grid)) return -1;
     REQUIRE(dy && w && dx, "sf_dwconv_dgrad: null pointer");
+    {
+        DwSweepParams sp;
+        int km, ks, sl;
+        if (dwrot_plan(d, 1, sp, km, ks, sl)) {
+            sp.a = (const f16*)dy; sp.lda = d->ldy; sp.dst = (f16*)dx; sp.ldd = d->ldx; sp.w = w;
+            dwrot_launch(sp, km, ks, sl, false, (hipStream_t)stream);
+            return check_launch("dwconv_dgrad (rot)");
+        }
+        if (dwsweep_plan(d, 1, sp, km, ks)) {
+            sp.a = (const f16*)dy; sp.lda = d->ldy; sp.dst = (f16*)dx; sp.ldd = d->ldx; sp.w = w;
+            dwsweep_launch(sp, km, ks, false, (hipStream_t)stream);
+            return check_launch("dwconv_dgrad (sweep)");
+        }
+        const char* lv = getenv("SF_DW_SWEEP");
+        if (dwgap_shape_ok(d) && !(lv && atoi(lv) == 0) && 27 * d->Cw <= SF_DW_GAP_W) {
+            DwGapParams gp;
+            memset(&gp, 0, sizeof(gp));
+            gp.dy = (const f16*)dy; gp.lddy = d->ldy; gp.dx = (f16*)dx; gp.lddx = d->ldx; gp.w = w;
+            gp.N = d->N; gp.C = d->C; gp.Cw = d->Cw; gp.Cwreal = d->Cwreal ? d->Cwreal : d->Cw; gp.cls = d->cls ? 1 : 0;
+            gp.T = d->Ti; gp.Hi = d->Hi; gp.Wi = d->Wi; gp.Ho = d->Ho; gp.Wo = d->Wo; gp.s = d->sH;
+            const int64_t Si = (int64_t)d->Ti * d->Hi * d->Wi + gp.cls;
+            gp.rows = (int64_t)d->N * Si;
+            if (gp.rows * (d->C / 8) < (1ll << 32)) {
+                gp.fdRow = make_fastdiv((uint32_t)Si); gp.fdW = make_fastdiv(d->Wi); gp.fdH = make_fastdiv(d->Hi);
+                gp.fdS = make_fastdiv(d->sH); gp.fdG = make_fastdiv(d->C / 8);
+                const int64_t items = gp.rows * (d->C / 8);
+                int blocks = cdiv(items, SF_THREADS * 4);
+                if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL(sf_dwgap_dgrad_kernel, dim3(blocks), dim3(SF_THREADS), 0, (hipStream_t)stream, gp);
+                return check_launch("dwconv_dgrad (gap)");
+            }
+        }
+    }
     {
         DwTileParams tp;
         int np;
@@ -1732,6 +1989,8 @@ extern "C" int64_t sf_dwconv_wgrad_workspace(const sf_dw_desc* d) {
     // (the size is cached by the callers; SF_DW_WGRAD_TILED / SF_DWT_TH are read per call)
     int64_t rows = grid.x;
     if (dwtile_wgrad_shape_ok(d) && (int64_t)d->N * d->Ho > rows) rows = (int64_t)d->N * d->Ho;
+    if (dwsweep_shape_ok(d) && dwsweep_max_rows(d) > rows) rows = dwsweep_max_rows(d);
+    if (dwgap_shape_ok(d) && (int64_t)d->N * d->Ho * d->Wo > rows) rows = (int64_t)d->N * d->Ho * d->Wo;
     return rows * d->kT * d->kH * d->kW * d->C * 4;
 }
 extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* dy, float* dw, float out_scale,
@@ -1741,6 +2000,26 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
     if (fill_dw(p, d, true, kDwWgradBlocks, grid)) return -1;
     REQUIRE(x && dy && dw && workspace, "sf_dwconv_wgrad: null pointer");
     const int taps = d->kT * d->kH * d->kW;
+    {
+        DwSweepParams sp;
+        int km, ks, sl = 0;
+        const bool rot = dwrot_plan(d, 2, sp, km, ks, sl);
+        if (rot || dwsweep_plan(d, 2, sp, km, ks)) {
+            const int nblk = sp.N * sp.tiles_h * sp.tiles_w;
+            REQUIRE(workspace_bytes >= (int64_t)nblk * taps * d->C * 4, "sf_dwconv_wgrad: workspace too small");
+            sp.a = (const f16*)x; sp.lda = d->ldx; sp.b = (const f16*)dy; sp.ldb = d->ldy; sp.part = (float*)workspace;
+            hipStream_t s = (hipStream_t)stream;
+            if (rot) dwrot_launch(sp, km, ks, sl, false, s);
+            else dwsweep_launch(sp, km, ks, false, s);
+            if (check_launch("dwconv_wgrad (sweep)")) return -1;
+            DwFinalizeParams f;
+            f.wpart = (const float*)workspace; f.nblk = nblk; f.taps = taps; f.C = d->C; f.Cw = d->Cw;
+            f.Cwreal = d->Cwreal ? d->Cwreal : d->Cw;
+            f.dw = dw; f.scale = out_scale; f.accumulate = zero_first ? 0 : 1;
+            hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, 32)), dim3(SF_THREADS), 0, s, f);
+            return check_launch("dwconv_wgrad_finalize");
+        }
+    }
     {
         DwTileWgradParams tp;
         int lc;

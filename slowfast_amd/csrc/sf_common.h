@@ -101,6 +101,13 @@ typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
                      : "memory");                                                                                       \
     } while (0)
 #endif
+// ... and with lanes masked off: their 16 bytes of LDS keep what they held (a pre-zeroed halo); `on` may diverge inside the wave
+#ifndef SF_GLOBAL_LOAD_LDS16_SADDR_IF
+#define SF_GLOBAL_LOAD_LDS16_SADDR_IF(on, base, voff, l)                \
+    do {                                                                \
+        if (on) SF_GLOBAL_LOAD_LDS16_SADDR(base, voff, l);              \
+    } while (0)
+#endif
 // LDS hand-over between the lanes of ONE wave (ds_write by some lanes, ds_read of the same bytes by others): the hardware runs
 // a wave's LDS instructions in order, so only the compiler must be kept from reordering them; the host simulator, whose lanes
 // are fibers, needs a real rendezvous here

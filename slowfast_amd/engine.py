@@ -194,7 +194,7 @@ def join_side_streams():
 # convolutions leave a quarter of the CUs idle (196 / 392 tiles on 256 CUs at batch 32) and every kernel pays its own fill and
 # drain, the Fast pathway's kernels are thin HBM streams.  Forked onto a second stream the two interleave on the chip -- as
 # graph BRANCHES under a captured step -- and fill each other's holes: SlowFast-8x8-R50 41.4 -> 38.7 ms per step
-# (profiles/r5_v4_pathway_streams.txt; the per-pair probe of round 2 had predicted 7 %).  run_pathways() forks before and joins
+# (profiles/r5_v4_pathway_streams_probe.txt, r5_v5_pathway_streams_ab.txt; the per-pair probe of round 2 had predicted 7 %).  run_pathways() forks before and joins
 # after a stage; autograd runs every backward node on the stream of its forward, so the backward forks and joins by itself.
 # Rules that keep it exact: scratch memory is per stream (ops._workspace), parameter-gradient consumers join every stream first
 # (join_side_streams), tensors that cross a fork / join stay referenced by autograd until their consumers are enqueued.
@@ -312,7 +312,24 @@ def _always():
     return True
 
 
+def _queue_join_at_end_of_backward():
+    """Backward nodes of the Fast pathway / of the k-v branch write param.grad in place on THEIR streams.  TrainStep and the
+    reducer join explicitly; a plain ``loss.backward(); optimizer.step()`` caller does not, so the join rides on the backward
+    pass itself (the same end-of-pass callback the side-stream weight gradients use): whatever the caller enqueues after
+    ``backward()`` returns sees every pathway's gradients.  (before this it held only because autograd's leaf-stream
+    synchronisation happened to cover the AccumulateGrad nodes created under the side stream.)"""
+    global _join_queued
+    if _join_queued or not _pathway_streams:
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        _join_queued = True
+    except RuntimeError:
+        pass            # not inside a backward pass (a segment driven by TrainStep, which joins itself)
+
+
 def _notify(params):
+    _queue_join_at_end_of_backward()
     if GRADS_VIA_AUTOGRAD:          # the consumer of the gradients (DDP's reducer) hooks autograd itself
         return
     if (_side_pending or _pathway_streams) and any(getattr(fn, "needs_join", _always)() for fn in _listeners):

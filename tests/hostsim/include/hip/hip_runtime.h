@@ -323,6 +323,18 @@ inline void hipsim_global_load_lds16(const void* gptr, void* lds_base) {
     hipsim::wave_sync();
     memcpy(base + 16 * l, gptr, 16);
 }
+// the same with some lanes masked off (EXEC): they take part in the rendezvous, their 16 bytes of LDS stay as they are
+inline void hipsim_global_load_lds16_if(bool on, const void* gptr, void* lds_base) {
+    hipsim::WaveScratch& w = hipsim::wave();
+    int l = hipsim::lane_id();
+    w.ptr[l] = lds_base;
+    hipsim::wave_sync();
+    unsigned char* base = (unsigned char*)w.ptr[0];
+    hipsim::wave_sync();
+    if (on) memcpy(base + 16 * l, gptr, 16);
+}
+#define SF_GLOBAL_LOAD_LDS16_SADDR_IF(on, base, voff, l) \
+    hipsim_global_load_lds16_if((on), (const void*)((const char*)(base) + ((on) ? (uint32_t)(voff) : 0u)), (void*)(l))
 #define SF_GLOBAL_LOAD_LDS16(g, l) hipsim_global_load_lds16((const void*)(g), (void*)(l))
 #define SF_GLOBAL_LOAD_LDS16_ASM(g, l) hipsim_global_load_lds16((const void*)(g), (void*)(l))
 #define SF_GLOBAL_LOAD_LDS16_SADDR(base, voff, l) hipsim_global_load_lds16((const void*)((const char*)(base) + (uint32_t)(voff)), (void*)(l))

@@ -320,6 +320,45 @@ def test_branch_streams_do_not_change_the_step(gpu, monkeypatch):
                 assert torch.equal(a, b), (rep, segmented, use_graph)
 
 
+def _run_plain_loop(device, name, steps=3):
+    """``loss.backward(); optimizer.step()`` with torch.optim.SGD and NO TrainStep / GradReducer: the caller never joins a side
+    stream itself."""
+    from tests import model_checks as mc
+    gold = mc.load_golden(name)
+    cfg = mc.cfg_for(gold)
+    model, sd, inputs, labels, *_ = mc.oracle_run(gold, cfg)
+    model.load_state_dict(sd)
+    model = model.to(device).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    xs, ys = [x.to(device) for x in inputs], labels.to(device)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=False)
+        loss = F.cross_entropy(model(xs).float(), ys)
+        (loss * 64.0).backward()
+        opt.step()                  # reads every param.grad on the current stream right behind backward()
+        losses.append(float(loss))
+    return losses, [p.detach().float().cpu().clone() for p in model.parameters()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,flag", [("slowfast_tiny", "PATHWAY_STREAMS"), ("mvit_tiny", "BRANCH_STREAMS")])
+def test_plain_backward_joins_side_streams(gpu, monkeypatch, name, flag):
+    """a user loop without TrainStep.  The Fast pathway's / the k-v branch's backward nodes write param.grad
+    on side streams; engine._notify queues join_side_streams as an end-of-backward callback, so optimizer.step() behind a plain
+    backward() reads finished gradients: three steps bit for bit what the single-stream run gives, repeatedly."""
+    from slowfast_amd import engine
+    monkeypatch.setattr(engine, flag, False)
+    l0, p0 = _run_plain_loop(gpu, name)
+    monkeypatch.setattr(engine, flag, True)
+    for rep in range(3):
+        l1, p1 = _run_plain_loop(gpu, name)
+        assert l1 == l0, (rep, l0, l1)
+        for a, b in zip(p0, p1):
+            assert torch.equal(a, b), rep
+    assert engine._pathway_streams and not engine._join_queued
+
+
 def test_static_clone_keeps_wpair_tag_and_strides():
     """TrainStep._static_clone: the captured graph's copy of a packed clip keeps the W-pair tag and the channels-last strides
     (without the tag StemConvUnit would try to convert an 8-channel tensor and fail at capture)."""

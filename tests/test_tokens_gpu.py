@@ -51,6 +51,56 @@ def test_dwconv_tokens(gpu):
     tc.check_dwconv(gpu, 1, 8, 96, (2, 7, 7), (3, 3, 3), (1, 1, 1), cls=1)
 
 
+def test_dwconv_ring_sweep(gpu, monkeypatch):
+    """sf_dwsweep.h at the production planes of MViTv2-S (56- / 28- / 14- / 7-wide, every stride, heads sharing the weight, cls
+    rows, slices of a wider tensor) and X3D-M (54 -> 56, 108 -> 112, 216, 432 channels: tail chunks; BatchNorm partial sums), plus
+    forced ragged tilings."""
+    tc.check_dwconv(gpu, 2, 1, 96, (4, 56, 56), (3, 3, 3), (1, 1, 1), cls=1)     # block 0 q
+    tc.check_dwconv(gpu, 2, 2, 96, (4, 56, 56), (3, 3, 3), (1, 2, 2), cls=1)     # block 1 q
+    tc.check_dwconv(gpu, 2, 2, 96, (4, 28, 28), (3, 3, 3), (1, 1, 1), cls=1)     # block 2 q
+    tc.check_dwconv(gpu, 2, 4, 96, (4, 28, 28), (3, 3, 3), (1, 2, 2), cls=1)     # block 3 q / k / v
+    tc.check_dwconv(gpu, 1, 8, 96, (4, 14, 14), (3, 3, 3), (1, 2, 2), cls=1)     # block 14 q
+    tc.check_dwconv(gpu, 2, 1, 56, (4, 112, 112), (3, 3, 3), (1, 2, 2), cls=0)   # X3D s2 first block
+    tc.check_dwconv(gpu, 2, 1, 56, (4, 56, 56), (3, 3, 3), (1, 1, 1), cls=0)
+    tc.check_dwconv(gpu, 2, 1, 112, (4, 56, 56), (3, 3, 3), (1, 2, 2), cls=0)
+    tc.check_dwconv(gpu, 2, 1, 112, (4, 28, 28), (3, 3, 3), (1, 1, 1), cls=0)
+    tc.check_dwconv(gpu, 2, 1, 216, (4, 28, 28), (3, 3, 3), (1, 2, 2), cls=0)
+    tc.check_dwconv(gpu, 2, 1, 216, (4, 14, 14), (3, 3, 3), (1, 1, 1), cls=0)
+    tc.check_dwconv(gpu, 2, 1, 432, (4, 14, 14), (3, 3, 3), (1, 2, 2), cls=0)
+    tc.check_dwconv(gpu, 2, 1, 432, (4, 7, 7), (3, 3, 3), (1, 1, 1), cls=0)
+    # strides 4 and 8 (k / v pooling of blocks 0 - 2): packed staging, one-tap data gradient
+    tc.check_dwconv(gpu, 2, 1, 96, (4, 56, 56), (3, 3, 3), (1, 8, 8), cls=1)
+    tc.check_dwconv(gpu, 2, 2, 96, (4, 56, 56), (3, 3, 3), (1, 4, 4), cls=1)
+    tc.check_dwconv(gpu, 2, 2, 96, (4, 28, 28), (3, 3, 3), (1, 4, 4), cls=1)
+    for sl, grp, seg in ((7, 2, 2), (7, 4, 1), (4, 2, 2), (4, 1, 3)):
+        monkeypatch.setenv("SF_DWR_SL", str(sl))
+        monkeypatch.setenv("SF_DWR_NGRP", str(grp))
+        monkeypatch.setenv("SF_DWR_NSEG", str(seg))
+        tc.check_dwconv(gpu, 2, 4, 96, (5, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
+        tc.check_dwconv(gpu, 1, 1, 40, (3, 13, 21), (3, 3, 3), (1, 2, 2), cls=0)
+    for k in ("SF_DWR_SL", "SF_DWR_NGRP", "SF_DWR_NSEG"):
+        monkeypatch.delenv(k)
+    monkeypatch.setenv("SF_DW_ROT", "0")                                         # the four-channel v_fma_mix body, forced tilings
+    monkeypatch.setenv("SF_DWS_TH", "5")
+    monkeypatch.setenv("SF_DWS_TW", "6")
+    tc.check_dwconv(gpu, 2, 4, 96, (3, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
+    tc.check_dwconv(gpu, 2, 4, 96, (3, 14, 14), (3, 3, 3), (1, 2, 2), cls=1)
+    monkeypatch.setenv("SF_DWS_TH", "11")
+    monkeypatch.setenv("SF_DWS_TW", "20")
+    monkeypatch.setenv("SF_DWS_NSEG", "3")
+    tc.check_dwconv(gpu, 1, 1, 40, (2, 12, 20), (3, 3, 3), (1, 1, 1), cls=1)
+    tc.check_dwconv(gpu, 1, 1, 40, (1, 13, 21), (3, 3, 3), (1, 2, 2), cls=0)
+
+
+def test_dwconv_tokens_stencils(gpu, monkeypatch):
+    """The stencils and the round-4 LDS plane sweep the ring sweep replaced (still the fallback for other geometries)."""
+    monkeypatch.setenv("SF_DW_SWEEP", "0")
+    tc.check_dwconv(gpu, 2, 2, 96, (4, 14, 14), (3, 3, 3), (1, 2, 2), cls=1)
+    tc.check_dwconv(gpu, 2, 4, 96, (4, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
+    tc.check_dwconv(gpu, 2, 1, 56, (4, 28, 28), (3, 3, 3), (1, 1, 1), cls=0)
+    tc.check_dwconv(gpu, 2, 1, 216, (4, 14, 14), (3, 3, 3), (1, 2, 2), cls=0)
+
+
 def test_token_pool(gpu):
     tc.check_token_pool(gpu, 2, 192, (4, 28, 28), (1, 2, 2))
     tc.check_token_pool(gpu, 1, 96, (3, 13, 15), (1, 2, 2))

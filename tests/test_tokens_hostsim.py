@@ -35,6 +35,16 @@ def test_gelu(sim):
 
 
 def test_dwconv_tokens(sim):
+    _dwconv_tokens(sim)
+
+
+def test_dwconv_tokens_stencils(sim, monkeypatch):
+    """The same geometries on the W-blocked / generic stencils the ring sweep (sf_dwsweep.h) replaced for 3x3x3, stride <= 2."""
+    monkeypatch.setenv("SF_DW_SWEEP", "0")
+    _dwconv_tokens(sim)
+
+
+def _dwconv_tokens(sim):
     tc.check_dwconv(sim, 2, 2, 16, (2, 6, 6), (3, 3, 3), (1, 2, 2), cls=1)
     tc.check_dwconv(sim, 1, 1, 32, (4, 5, 5), (3, 3, 3), (1, 1, 1), cls=1)
     tc.check_dwconv(sim, 2, 1, 24, (6, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)
@@ -50,9 +60,57 @@ def test_dwconv_tokens(sim):
     tc.check_dwconv(sim, 1, 1, 16, (2, 17, 17), (1, 9, 9), (1, 8, 8), cls=1)
 
 
+def test_dwconv_ring_sweep(sim, monkeypatch):
+    """Ring-buffered plane sweep with the channels on the lanes (sf_dwsweep.h, round 6): forward (stride 1 | 2, with and without the
+    BatchNorm partial sums), both data gradients, the weight gradient; whole and ragged tiles in H and W, several row groups and
+    column segments per wave, 8- / 16- / 24-channel tail chunks, heads sharing a weight, T = 1, odd extents.  (SF_DW_ROT=0: the
+    four-channel v_fma_mix body; by default only its stride-2 data gradient is dispatched.)"""
+    monkeypatch.setenv("SF_DW_ROT", "0")
+    tc.check_dwconv(sim, 1, 1, 32, (2, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)     # MViT stage-3 plane: two row groups x two segments
+    tc.check_dwconv(sim, 1, 1, 64, (3, 14, 14), (3, 3, 3), (1, 2, 2), cls=1)     # 14 -> 7, two chunks
+    tc.check_dwconv(sim, 1, 2, 32, (2, 7, 9), (3, 3, 3), (1, 2, 2), cls=0)       # odd extents: 7x9 -> 4x5, no cls (partial sums ride)
+    tc.check_dwconv(sim, 1, 1, 56, (2, 9, 10), (3, 3, 3), (1, 1, 1), cls=0)      # X3D width 54 -> 56: a 32- and a 24-channel chunk
+    tc.check_dwconv(sim, 1, 1, 40, (1, 6, 11), (3, 3, 3), (1, 2, 2), cls=0)      # 8-channel tail chunk, T = 1
+    monkeypatch.setenv("SF_DWS_TH", "5")                                         # ragged row tiles (14 = 5 + 5 + 4), ...
+    monkeypatch.setenv("SF_DWS_TW", "6")                                         # ... ragged column tiles (14 = 6 + 6 + 2)
+    tc.check_dwconv(sim, 1, 1, 32, (3, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
+    tc.check_dwconv(sim, 1, 1, 32, (2, 14, 14), (3, 3, 3), (1, 2, 2), cls=0)
+    monkeypatch.setenv("SF_DWS_TH", "11")                                        # two row groups, the second one partial
+    monkeypatch.setenv("SF_DWS_TW", "20")
+    monkeypatch.setenv("SF_DWS_NSEG", "3")                                       # segments of 7, 7, 6 columns (window rotation tails)
+    tc.check_dwconv(sim, 1, 1, 16, (2, 12, 20), (3, 3, 3), (1, 1, 1), cls=1)
+    monkeypatch.setenv("SF_DWS_NSEG", "1")                                       # one segment: tasks < waves
+    tc.check_dwconv(sim, 1, 1, 16, (2, 12, 20), (3, 3, 3), (1, 2, 2), cls=1)
+
+
+def test_dwconv_rotating_sweep(sim, monkeypatch):
+    """Rotating-accumulator form (sf_dwrot_kernel): runs of 7 and 4 columns, every (row groups x segments) split of the four waves,
+    ragged tiles, T = 1 / 2 / 3 / 4 / 5 (the plane loop is unrolled by three), tail chunks, heads sharing a weight, both strides,
+    forward with and without partial sums, stride-1 data gradient, weight gradient."""
+    for sl, grp, seg in ((7, 2, 2), (7, 4, 1), (7, 1, 4), (4, 2, 2), (4, 1, 3), (7, 1, 1), (4, 3, 1)):
+        monkeypatch.setenv("SF_DWR_SL", str(sl))
+        monkeypatch.setenv("SF_DWR_NGRP", str(grp))
+        monkeypatch.setenv("SF_DWR_NSEG", str(seg))
+        tc.check_dwconv(sim, 1, 1, 32, (3, 14, 14), (3, 3, 3), (1, 1, 1), cls=1)
+        tc.check_dwconv(sim, 1, 1, 40, (2, 9, 10), (3, 3, 3), (1, 2, 2), cls=0)
+    for k in ("SF_DWR_SL", "SF_DWR_NGRP", "SF_DWR_NSEG"):
+        monkeypatch.delenv(k)
+    for T in (1, 2, 3, 4, 5):
+        tc.check_dwconv(sim, 1, 2, 16, (T, 6, 9), (3, 3, 3), (1, 1, 1), cls=T % 2)
+        tc.check_dwconv(sim, 1, 1, 24, (T, 7, 7), (3, 3, 3), (1, 2, 2), cls=0)
+    tc.check_dwconv(sim, 2, 1, 56, (2, 9, 10), (3, 3, 3), (1, 1, 1), cls=0)      # X3D width 54 -> 56: a 32- and a 24-channel chunk
+    # strides >= 3 (MViT k / v pooling of the early stages): packed staging + the one-tap data gradient
+    tc.check_dwconv(sim, 1, 1, 32, (3, 17, 17), (3, 3, 3), (1, 4, 4), cls=1)
+    tc.check_dwconv(sim, 2, 2, 16, (2, 16, 24), (3, 3, 3), (1, 8, 8), cls=1)
+    tc.check_dwconv(sim, 1, 1, 24, (4, 10, 13), (3, 3, 3), (1, 3, 3), cls=0)
+    monkeypatch.setenv("SF_DWR_SL", "7")
+    tc.check_dwconv(sim, 1, 1, 32, (2, 30, 30), (3, 3, 3), (1, 4, 4), cls=1)
+
+
 def test_dwconv_tiled_plane_sweep(sim, monkeypatch):
     """LDS-tiled plane sweep (sf_dwtile.h): 32-channel chunks, strides 1 and 2 (forward, data gradient incl. the zero-upsampled
     stride-2 form, weight gradient in its three LDS classes), partial last row tiles, odd extents, 1 / 2 / 4 positions per thread."""
+    monkeypatch.setenv("SF_DW_SWEEP", "0")      # the round-6 ring sweep would take every one of these geometries
     monkeypatch.setenv("SF_DW_TILED", "2")      # also the stride-2 forms (the library's statics are read on first use: the
     # fixture loads a fresh library handle per test, the env is read again)
     tc.check_dwconv(sim, 2, 2, 32, (3, 6, 6), (3, 3, 3), (1, 1, 1), cls=1)       # one tile, NP = 1

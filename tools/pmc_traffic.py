@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc counter CSVs (one pass per counter) into per-kernel HBM traffic per launch.
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json [sf_build_id]
 
 FETCH_SIZE / WRITE_SIZE are in KiB (TCC_EA0_RDREQ/WRREQ derived).  Per MI355X_MICROARCH.md (HBM section): on gfx950
 FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced streaming read -> the read side is doubled
@@ -35,8 +35,8 @@ def main():
         res[k] = {"launches": n, "fetch_KiB_per_launch_raw": vf / max(nf, 1), "write_KiB_per_launch_raw": vw / max(nw, 1),
                   "hbm_bytes_per_launch_corrected": (2.0 * vf / max(nf, 1) + vw / max(nw, 1)) * 1024.0}
     with open(out, "w") as fo:
-        json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; WRITE_SIZE as reported", "kernels": res},
-                  fo, indent=1)
+        json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; WRITE_SIZE as reported",
+                   "sf_build_id": sys.argv[4] if len(sys.argv) > 4 else None, "kernels": res}, fo, indent=1)
     for k, v in list(res.items())[:12]:
         print(f"{v['hbm_bytes_per_launch_corrected']/1e6:10.1f} MB/launch  x{v['launches']:5d}  {k[:90]}")
 
