@@ -706,8 +706,9 @@ static WgradPlan plan_wgrad(const sf_conv_desc* d) {
 // Second-generation weight gradient (sf_wgrad2.h): plain (already activated) input, at least 33 output channels, a K axis
 // that fills most of a 256-wide tile.  SF_WGRAD2=0 keeps the first kernel.
 struct Wgrad2Plan {
-    bool ok, thin;
+    bool ok, thin, dual;
     int BMW, BKW, tiles_k, tiles_c, Co_pad, Kpad, rows_per_split, splits;
+    int slabs;          // fp32 partial tiles sets written (= splits, or split PAIRS of the dual kernel)
     size_t tab_bytes, ws_bytes;
 };
 static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
@@ -750,6 +751,7 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
         w.splits = cdiv(M, w.rows_per_split);
         w.tab_bytes = ((size_t)M * 8 + 255) / 256 * 256 + 1280;  // pad: the thin kernel reads whole 32-byte groups up to one 128-position stage past M
         w.ws_bytes = w.tab_bytes + (size_t)w.Co_pad * w.Kpad * 4 * w.splits;
+        w.slabs = w.splits;
         w.ok = true;
         return w;
     }
@@ -764,8 +766,28 @@ static Wgrad2Plan plan_wgrad2(const sf_conv_desc* d) {
     const int64_t cap = (256ll << 20) / slab;
     if (splits > cap) splits = (int)(cap < 1 ? 1 : cap);
     if (splits < 1) splits = 1;
+    // two splits per 1024-thread workgroup, summed through LDS before anything is stored (sf_wgrad2_kernel<., true>): the same
+    // waves, rings and position ranges per CU, half the partial tiles.  The resident round is then target / 2 workgroups of
+    // PAIRS: the pair count is rounded down against it (24 tiles x 11 pairs = 264 workgroups on 256 CUs ran a second round:
+    // 110 -> 191 us, profiles/r6_v15_wgrad_sweep_dual.md).  SF_WGRAD2_DUAL=0 keeps one split per workgroup.
+    // Taken where it pays (per layer, profiles/r6_v16_wgrad_sweep_dual.md): short position loops (many splits of few steps: the
+    // stores and the reduction are a large share -- s4 c 256 -> 1024 57 -> 49 us, s3 a 512 -> 128 87 -> 56 us), not the long
+    // loops of the 3x1x1 layers (the shared barrier costs them ~3 %), and only when the pairs fill the chip as well as the
+    // single splits did (96 tiles: 2 pairs = 192 workgroups against 5 splits = 480 halves: 117 -> 133 us).
+    w.dual = false;
+    if (splits >= 2 && test_hook("SF_WGRAD2_DUAL", 1) != 0) {
+        const int tiles = w.tiles_k * w.tiles_c;
+        const int pairs = (target / 2) / tiles;
+        const int64_t steps = cdiv(cdiv(M, splits), 32);
+        if (pairs >= 1 && 2 * pairs * 10 >= (2 * pairs < splits ? splits : 2 * pairs) * 9 && steps <= test_hook("SF_WGRAD2_DUAL_STEPS", 80)) {
+            w.dual = true;
+            if (2 * pairs < splits) splits = 2 * pairs;
+        }
+    }
     w.rows_per_split = roundup(cdiv(M, splits), 32);
     w.splits = cdiv(M, w.rows_per_split);
+    if (w.splits < 2) w.dual = false;
+    w.slabs = w.dual ? cdiv(w.splits, 2) : w.splits;
     w.tab_bytes = ((size_t)M * 8 + 255) / 256 * 256 + 1280;  // pad: the thin kernel reads whole 32-byte groups up to one 128-position stage past M
     w.ws_bytes = w.tab_bytes + (size_t)slab * w.splits;
     w.ok = true;
@@ -848,19 +870,23 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const void* x, const float* 
         q.ws = slabs; q.Co_pad = w2.Co_pad; q.Kpad = w2.Kpad;
         q.tiles_k = w2.tiles_k; q.tiles_c = w2.tiles_c; q.rows_per_split = w2.rows_per_split;
         q.stage_stride = (w2.thin && tune_knob("SF_WGRAD2T_RR", 1) != 0) ? w2.splits : 0;
-        const dim3 grid((unsigned)(w2.tiles_k * w2.tiles_c * w2.splits));
+        const dim3 grid((unsigned)(w2.tiles_k * w2.tiles_c * w2.slabs));
         static const bool trace = test_hook("SF_TRACE", 0) != 0;
-        if (trace) fprintf(stderr, "[sfamd] wgrad2: M=%d Co=%d K=%d tiles %dx%d splits %d\n", q.M, q.Co, q.Ktot, w2.tiles_c, w2.tiles_k, w2.splits);
+        if (trace) fprintf(stderr, "[sfamd] wgrad2: M=%d Co=%d K=%d tiles %dx%d splits %d%s\n", q.M, q.Co, q.Ktot, w2.tiles_c, w2.tiles_k, w2.splits,
+                           w2.dual ? " (two per workgroup)" : "");
         if (w2.thin) {
             if (w2.BMW == 16 && w2.BKW == 128) hipLaunchKernelGGL((sf_wgrad2t_kernel<16, 128, 2>), grid, dim3(256), 0, s, q);
             else if (w2.BMW == 32 && w2.BKW == 128) hipLaunchKernelGGL((sf_wgrad2t_kernel<32, 128, 2>), grid, dim3(256), 0, s, q);
             else if (w2.BMW == 16) hipLaunchKernelGGL((sf_wgrad2t_kernel<16, 32, 3>), grid, dim3(256), 0, s, q);
             else hipLaunchKernelGGL((sf_wgrad2t_kernel<32, 32, 3>), grid, dim3(256), 0, s, q);
+        } else if (w2.dual) {
+            if (w2.BMW == 128) hipLaunchKernelGGL((sf_wgrad2_kernel<128, true>), grid, dim3(1024), 0, s, q);
+            else hipLaunchKernelGGL((sf_wgrad2_kernel<64, true>), grid, dim3(1024), 0, s, q);
         } else {
             if (w2.BMW == 128) hipLaunchKernelGGL((sf_wgrad2_kernel<128>), grid, dim3(512), 0, s, q);
             else hipLaunchKernelGGL((sf_wgrad2_kernel<64>), grid, dim3(512), 0, s, q);
         }
-        splits = w2.splits; Co_pad = w2.Co_pad; Kpad = w2.Kpad;
+        splits = w2.slabs; Co_pad = w2.Co_pad; Kpad = w2.Kpad;
     } else if (sp.ok && !in_scale) {
         REQUIRE(workspace_bytes >= (int64_t)sp.ws_bytes, "sf_conv_wgrad: workspace too small (%lld < %lld bytes)",
                 (long long)workspace_bytes, (long long)sp.ws_bytes);

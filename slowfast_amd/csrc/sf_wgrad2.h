@@ -74,8 +74,14 @@ __device__ __forceinline__ int w2_swz(int m) { return (m & 3) | (((m >> 3) & 1) 
 
 // BMW = 128: 8 waves as 2 (co) x 4 (k), wave tile 64 x 64.   BMW = 64: 8 waves as 1 x 8, wave tile 64 x 32.
 // Three-stage LDS ring (72 KB at BMW = 128): two workgroups per CU.
-template <int BMW>
-__global__ __launch_bounds__(512, 4) void sf_wgrad2_kernel(Wgrad2Params p) {
+// DUAL (round 6): ONE 1024-thread workgroup carries two splits of the same tile -- waves 0-7 and 8-15 are two copies of the
+// kernel above (own ring, own position range 2*bz and 2*bz + 1, the workgroup barrier shared) and at the end the halves exchange
+// half of their accumulators through LDS (the rings are dead by then: 128 KB), add and store ONE partial tile.  Occupancy and
+// the loop are what they were (16 waves and 144 KB per CU either way); the fp32 split partials written here and re-read by
+// sf_wgrad_reduce_kernel are halved -- they were 1.5x the algorithmic bytes of the layer for three rounds
+// (profiles/pmc_traffic_SLOWFAST_8x8_R50.json).  own + other is commutative: both halves of the tile see the same sum order.
+template <int BMW, bool DUAL = false>
+__global__ __launch_bounds__(DUAL ? 1024 : 512, 4) void sf_wgrad2_kernel(Wgrad2Params p) {
     constexpr int BKW = 256, ROWS = 32, NW = 8, NST = 3;
     constexpr int WAVES_C = BMW / 64, WAVES_K = NW / WAVES_C;
     constexpr int WN = BKW / WAVES_K;                   // 64 or 32 columns of k per wave
@@ -84,20 +90,30 @@ __global__ __launch_bounds__(512, 4) void sf_wgrad2_kernel(Wgrad2Params p) {
     constexpr int YI = Y_ELEMS / 512;                   // dY copy instructions per stage (8 or 4), 512 halfs = 1 KB each
     constexpr int YRPI = 512 / BMW;                     // dY rows per instruction (4 or 8)
     constexpr int YCH = BMW / 8;                        // 16-byte chunks per dY row (16 or 8)
-    __shared__ __attribute__((aligned(16))) f16 smem[NST * STAGE];
+    __shared__ __attribute__((aligned(16))) f16 smem_all[(DUAL ? 2 : 1) * NST * STAGE];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = DUAL ? wave_all >> 3 : 0, wave = wave_all & 7;
+    f16* const smem = smem_all + half * (NST * STAGE);
     const int wc = wave / WAVES_K, wk = wave % WAVES_K;
     const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = (int)(wg % (uint32_t)p.tiles_k);
     const int by = (int)((wg / (uint32_t)p.tiles_k) % (uint32_t)p.tiles_c);
     const int bz = (int)(wg / ((uint32_t)p.tiles_k * (uint32_t)p.tiles_c));
     const int k0 = bx * BKW, c0 = by * BMW;
-    const int r0 = bz * p.rows_per_split;
+    const int r0 = (DUAL ? 2 * bz + half : bz) * p.rows_per_split;
     int r1 = r0 + p.rows_per_split;
     if (r1 > p.M) r1 = p.M;
     const int nsteps = r1 > r0 ? (r1 - r0 + ROWS - 1) / ROWS : 0;
+    // DUAL: both halves pass the same barriers -- as many as the first half (never the shorter one) has steps
+    int nsteps_wg = nsteps;
+    if constexpr (DUAL) {
+        const int ra = 2 * bz * p.rows_per_split;
+        int rb = ra + p.rows_per_split;
+        if (rb > p.M) rb = p.M;
+        nsteps_wg = rb > ra ? (rb - ra + ROWS - 1) / ROWS : 0;
+    }
     const f16* const zline = reinterpret_cast<const f16*>(sf_zero_line);
 
     // ---- X loader: instruction j of the wave (2 per stage) copies stage rows 2*(wave + 8j) + {0, 1}; lane -> row bit
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(512, 4) void sf_wgrad2_kernel(Wgrad2Params p) {
         for (; issued < NST - 1 && issued < nsteps; ++issued) { tab_rows(issued, e); issue(issued, issued, e); }
         if (issued < nsteps) tab_rows(issued, e);                       // entries of the next step to issue
         int cur = 0, nxt = NST - 1;
-        for (int ks = 0; ks < nsteps; ++ks) {
+        for (int ks = 0; ks < nsteps_wg; ++ks) {
             // stages ks .. ks + NST - 2 are in flight (fewer at the tail): stage ks must have landed
             if (ks + NST - 2 < nsteps) {
                 SF_WAIT_VMEM_N(COPIES);                                 // (waves with a dY copy also wait for it: one early)
@@ -219,23 +235,61 @@ __global__ __launch_bounds__(512, 4) void sf_wgrad2_kernel(Wgrad2Params p) {
                 ++issued;
                 if (issued < nsteps) tab_rows(issued, e);               // scalar loads, consumed one step later
             }
-            compute(cur);
+            if (!DUAL || ks < nsteps) compute(cur);
             cur = cur == NST - 1 ? 0 : cur + 1;
             nxt = nxt == NST - 1 ? 0 : nxt + 1;
         }
     }
 
-    // every split owns its slab: plain stores, also when it had no rows to reduce (zeros)
+    // DUAL: half h keeps the fragment rows i in [h * TM / 2, (h + 1) * TM / 2) of the tile and hands the others over
+    constexpr int I0 = 0, IH = DUAL ? TM / 2 : TM;
+    if constexpr (DUAL) {
+        static_assert(TM % 2 == 0, "the halves split the fragment rows");
+        static_assert(2 * NST * STAGE * 2 >= 2 * IH * TN * 4 * 512 * 4, "the exchange reuses both rings");
+        __syncthreads();                                                // every ring is dead
+        float* xch = reinterpret_cast<float*>(smem_all);
+        const int t512 = tid & 511;
+        float* mine = xch + half * (IH * TN * 4 * 512);                 // what this half SENDS
+        const float* theirs = xch + (1 - half) * (IH * TN * 4 * 512);
+#pragma unroll
+        for (int ii = 0; ii < IH; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4& a0 = acc[ii][j];                       // half 1 sends rows [0, IH)
+                    const f32x4& a1 = acc[IH + ii][j];                  // half 0 sends rows [IH, TM)
+                    mine[((ii * TN + j) * 4 + r) * 512 + t512] = half ? a0[r] : a1[r];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < IH; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float o = theirs[((ii * TN + j) * 4 + r) * 512 + t512];
+                    if (half) acc[IH + ii][j][r] += o; else acc[ii][j][r] += o;
+                }
+    }
+
+    // every split (pair) owns its slab: plain stores, also when it had no rows to reduce (zeros)
     float* slab = p.ws + (int64_t)bz * p.Co_pad * p.Kpad;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int kcol = k0 + wk * WN + j * 16 + pl;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int ii = I0; ii < IH; ++ii)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = c0 + wc * 64 + i * 16 + 4 * g4 + r;
-                slab[(int64_t)co * p.Kpad + kcol] = acc[i][j][r];
+                if constexpr (DUAL) {
+                    const int co0 = c0 + wc * 64 + ii * 16 + 4 * g4 + r;
+                    const float v0 = acc[ii][j][r], v1 = acc[IH + ii][j][r];
+                    slab[(int64_t)(co0 + (half ? IH * 16 : 0)) * p.Kpad + kcol] = half ? v1 : v0;
+                } else {
+                    const int co = c0 + wc * 64 + ii * 16 + 4 * g4 + r;
+                    slab[(int64_t)co * p.Kpad + kcol] = acc[ii][j][r];
+                }
             }
     }
 }

@@ -115,6 +115,24 @@ def test_wgrad2(sim, force_w2, case):
     kc.check_conv_wgrad(sim, *case)
 
 
+# two splits per 1024-thread workgroup (sf_wgrad2_kernel<., true>): both co-tile heights, even and odd split counts (the last
+# pair's second half has no rows), a second half shorter than the first
+WGRAD2_DUAL_CASES = [
+    (((2, 64, 3, 12, 12), 136, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)), 24),      # BMW 128, 6 tiles x 4 splits of 224 rows (864)
+    (((2, 64, 3, 12, 12), 136, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)), 30),      # 5 splits: three pairs, the last one half empty
+    (((2, 320, 1, 20, 20), 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)), 12),     # plain GEMM, 4 tiles x 3 splits (288 / 288 / 224)
+    (((1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)), 15),         # BMW 64, 5 splits of 64 rows (162: last one 34)
+]
+
+
+@pytest.mark.parametrize("case,blocks", WGRAD2_DUAL_CASES)
+def test_wgrad2_two_splits_per_workgroup(sim, force_w2, monkeypatch, case, blocks):
+    monkeypatch.setenv("SF_WGRAD2_BLOCKS", str(blocks))
+    kc.check_conv_wgrad(sim, *case)
+    monkeypatch.setenv("SF_WGRAD2_DUAL", "0")           # the one-split-per-workgroup kernel on the same plan
+    kc.check_conv_wgrad(sim, *case)
+
+
 def test_wgrad2_accumulate_and_scale(sim, force_w2):
     kc.check_conv_wgrad(sim, (1, 64, 2, 9, 9), 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), out_scale=0.25)
 

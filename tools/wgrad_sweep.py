@@ -20,12 +20,14 @@ def main():
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--md", default="")
     ap.add_argument("--filter", default="slow")
+    ap.add_argument("--dual", action="store_true", help="compare one / two splits per workgroup (SF_WGRAD2_DUAL) instead of split targets only")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     # (co-tile rows of sf_wgrad2_kernel, workgroup target).  profiles/r3/r3_final_wgrad_sweep.md also has 64-row co-tiles for the wide
     # layers (a knob that existed for that sweep: they lose 20-40 % on res3-res5 and the knob is gone)
-    variants = [("128", b) for b in (256, 384, 448, 512, 640, 768, 1024)]
-    lines = ["| layer | x | " + " | ".join(f"bmw{n} b{b}" for n, b in variants) + " | best |", "|---|---:|" + "---:|" * (len(variants) + 1)]
+    # round 6: (splits per workgroup, workgroup-half target): "1" = sf_wgrad2_kernel<., false>, "2" = the dual kernel (SF_WGRAD2_DUAL)
+    variants = [("1", 512), ("2", 384), ("2", 448), ("2", 512), ("2", 640)] if a.dual else [("1", b) for b in (256, 384, 448, 512, 640, 768, 1024)]
+    lines = ["| layer | x | " + " | ".join(f"spw{n} b{b}" for n, b in variants) + " | best |", "|---|---:|" + "---:|" * (len(variants) + 1)]
     tot = [0.0] * len(variants)
     best_tot = 0.0
     for name, Ci, T, H, W, Co, k, s, p, cnt in LAYERS:
@@ -40,13 +42,14 @@ def main():
         ts = []
         for bmw, blocks in variants:
             os.environ["SF_WGRAD2_BLOCKS"] = str(blocks)
+            os.environ["SF_WGRAD2_DUAL"] = "1" if bmw == "2" else "0"
             geom.ws_bytes = None
             ts.append(timeit(lambda: ops.conv_wgrad(x, dy, geom, dw), a.iters) * 1e3)
         for i, t in enumerate(ts):
             tot[i] += cnt * t
         best_tot += cnt * min(ts)
         b = min(range(len(ts)), key=lambda i: ts[i])
-        lines.append(f"| {name} | {cnt} | " + " | ".join(f"{t:.0f}" for t in ts) + f" | bmw{variants[b][0]} b{variants[b][1]} |")
+        lines.append(f"| {name} | {cnt} | " + " | ".join(f"{t:.0f}" for t in ts) + f" | spw{variants[b][0]} b{variants[b][1]} |")
         print(lines[-1], flush=True)
     lines.append("| **weighted total (us / step)** | | " + " | ".join(f"{t:.0f}" for t in tot) + f" | {best_tot:.0f} |")
     print(lines[-1])
