@@ -40,6 +40,10 @@ def _ident(x):
 
 
 _STORE = _ident   # identity = the reference's fp32 graph; round_fp16 = fp16 storage model
+# Storage-model policy of the dot-product Nonlocal affinity theta^T phi / P and of its gradient: True = one 16-bit tensor (what
+# slowfast_amd.nonlocal_block stores), False = kept exact (a 16-bit hi + lo pair; tools/nl_storage_probe.py measures what that buys)
+NL_AFFINITY_16BIT = True
+NL_EXACT = frozenset()      # probe only: names among theta / phi / g / y / out (conv_out's result) kept exact by the storage model
 
 
 class fp16_storage_model:
@@ -55,6 +59,10 @@ class fp16_storage_model:
     def __exit__(self, *exc):
         global _STORE
         _STORE = self._old
+
+
+class _Recorder(dict):
+    """Per-module mask table being FILLED by a pass (recording_masks): the ReLU masks / max-pool routes the pass itself used."""
 
 
 class _ReluFixedMask(torch.autograd.Function):
@@ -75,6 +83,9 @@ class _ReluFixedMask(torch.autograd.Function):
 
 
 def _relu(x, masks=None, key=None):
+    if isinstance(masks, _Recorder):
+        masks[key] = (x > 0).detach()
+        return F.relu(x)
     if masks is not None and masks.get(key) is not None:
         return _ReluFixedMask.apply(x, masks[key])
     return F.relu(x)
@@ -120,6 +131,10 @@ class _AmaxRouted(torch.autograd.Function):
 
 
 def _max_pool(x, kernel, stride, padding, masks=None, key="pool_route"):
+    if isinstance(masks, _Recorder):
+        y, idx = F.max_pool3d(x, tuple(kernel), tuple(stride), tuple(padding), return_indices=True)
+        masks[key] = idx.detach()
+        return y
     if masks is not None and masks.get(key) is not None:
         return _MaxPoolRouted.apply(x, tuple(kernel), tuple(stride), tuple(padding), masks[key])
     return F.max_pool3d(x, tuple(kernel), tuple(stride), tuple(padding))
@@ -144,6 +159,30 @@ class handed_masks:
     def __exit__(self, *exc):
         global _HANDED
         _HANDED = self._old
+
+
+class recording_masks:
+    """Context manager: the pass inside records the ReLU masks / max-pool routes IT uses into ``self.table`` ({module prefix:
+    {key: mask / route}}, the shape handed_masks takes) -- two oracle passes (fp32 / a storage model) can then be compared
+    under identical masks without an engine run (tools/nl_storage_probe.py)."""
+
+    def __enter__(self):
+        global _HANDED
+        self.table = _RecorderTable()
+        self._old, _HANDED = _HANDED, self.table
+        return self
+
+    def __exit__(self, *exc):
+        global _HANDED
+        _HANDED = self._old
+        self.table = {k: dict(v) for k, v in self.table.items()}
+
+
+class _RecorderTable(dict):
+    def get(self, prefix, default=None):
+        if prefix not in self:
+            self[prefix] = _Recorder()
+        return self[prefix]
 
 
 def _handed(prefix, masks):
@@ -247,22 +286,29 @@ def nonlocal_block(x, sd, prefix, pool_size, instantiation, training, stats_out)
     """Nonlocal.forward (nonlocal_helper.py:103-144): theta/phi/g 1x1x1 convs (+bias), phi and g on the max-pooled
     input, affinity theta^T phi normalised by softmax(./sqrt(C)) or by 1/N ("dot_product"), out conv + BN, residual."""
     N, C, T, H, W = x.shape
-    theta = _conv(x, sd[prefix + ".conv_theta.weight"], sd[prefix + ".conv_theta.bias"])
+
+    def st(name):       # storage-model probe: tensors named in NL_EXACT stay exact (tools/nl_storage_probe.py)
+        return _ident if name in NL_EXACT else _STORE
+
+    def conv(name, inp):
+        return st(name)(F.conv3d(inp, _STORE(sd[prefix + ".conv_" + name + ".weight"]), sd[prefix + ".conv_" + name + ".bias"]))
+    theta = conv("theta", x)
     xp = _max_pool(x, pool_size, pool_size, (0, 0, 0), _handed(prefix, None)) if any(s > 1 for s in pool_size) else x
-    phi = _conv(xp, sd[prefix + ".conv_phi.weight"], sd[prefix + ".conv_phi.bias"])
-    g = _conv(xp, sd[prefix + ".conv_g.weight"], sd[prefix + ".conv_g.bias"])
+    phi = conv("phi", xp)
+    g = conv("g", xp)
     ci = theta.shape[1]
     theta, phi, g = theta.view(N, ci, -1), phi.view(N, ci, -1), g.view(N, ci, -1)
-    a = _STORE(torch.einsum("nct,ncp->ntp", theta, phi))
+    store_a = _STORE if (NL_AFFINITY_16BIT or instantiation != "dot_product") else _ident
+    a = store_a(torch.einsum("nct,ncp->ntp", theta, phi))
     if instantiation == "softmax":
         a = F.softmax(a * (ci ** -0.5), dim=2)
     elif instantiation == "dot_product":
         a = a / a.shape[2]
     else:
         raise NotImplementedError(instantiation)
-    a = _STORE(a)
-    y = _STORE(torch.einsum("ntg,ncg->nct", a, g)).view(N, ci, T, H, W)
-    p = _conv(y, sd[prefix + ".conv_out.weight"], sd[prefix + ".conv_out.bias"])
+    a = store_a(a)
+    y = st("y")(torch.einsum("ntg,ncg->nct", a, g)).view(N, ci, T, H, W)
+    p = conv("out", y)
     p = _bn(p, sd, prefix + ".bn", training, stats_out)
     return _STORE(x + p)
 

@@ -228,7 +228,7 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     // epilogue whose grid is several rounds deep anyway (the MViT Linears with K >= 512: fc2, the fc1 / qkv data gradients): a third
     // resident workgroup hides more of the store epilogue than the bigger tile saves in operand traffic -- fc2 forward 103.7 ->
     // 99.2 us HBM-cold, MViTv2-S 707 -> 712 clips/s (profiles/r5_v35_*).  Not below K = 512 (there the round-1 kernel at four
-    // workgroups per CU stays ahead: 114 vs 128 us for fc1).  SF_IGEMM2_T128=0 switches it off.
+    // workgroups per CU stays ahead: 114 vs 128 us for fc1).
     const int t128 = test_hook("SF_IGEMM2_T128", 1);      // 2: also on grids of at most one round (tests)
     if (t128 && q.linear && q.Nout > 64 && !q.stat_part && !q.bnb_part && (!bk64 || t128 == 2)) {
         q.ntiles_n = cdiv(q.Nout, 128);
@@ -1109,7 +1109,7 @@ extern "C" int sf_pool_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C
     p.total = (int64_t)N * T * H * W * (C / 8);
     REQUIRE(p.total < (1ll << 31), "sf_pool_bwd: too many elements");
     p.fdsH = make_fastdiv(sH); p.fdsW = make_fastdiv(sW);
-    if (kH <= 2 * sH && kW <= 2 * sW && test_hook("SF_POOL_BWD4", 1))      // at most 2 x 2 windows cover a position (sf_pool.h)
+    if (kH <= 2 * sH && kW <= 2 * sW)      // at most 2 x 2 windows cover a position (sf_pool.h)
         hipLaunchKernelGGL(sf_pool_bwd4_kernel, dim3(pool_grid(p.total + (int64_t)N * (C / 8))), dim3(SF_THREADS), 0,
                            (hipStream_t)stream, p);
     else
@@ -2129,7 +2129,7 @@ extern "C" int sf_relpos_gather(const sf_attn_desc* d, const void* G, int32_t ld
     const int R = d->kH + d->kW + d->kT;
     const int64_t total = (int64_t)d->B * d->Nq * d->heads * R;
     REQUIRE(total < (1ll << 31), "sf_relpos_gather: too many elements");
-    if (ldg % 8 == 0 && ldg <= 256 && (uintptr_t)G % 16 == 0 && test_hook("SF_RELPOS_GA_LDS", 1)) {
+    if (ldg % 8 == 0 && ldg <= 256 && (uintptr_t)G % 16 == 0) {
         const int64_t rows = (int64_t)d->B * d->Nq * d->heads, chunks = (rows + 31) / 32;
         hipLaunchKernelGGL(sf_relpos_gather_lds_kernel, dim3((unsigned)(chunks < 8192 ? chunks : 8192)), dim3(SF_THREADS), 0,
                            (hipStream_t)stream, p, (const f16*)G, ldg, make_fastdiv((uint32_t)R), R, rows);
@@ -2174,7 +2174,7 @@ extern "C" int sf_relpos_scatter(const sf_attn_desc* d, const float* drq, const 
     REQUIRE(total < (1ll << 31), "sf_relpos_scatter: too many elements");
     REQUIRE((uintptr_t)E % 16 == 0, "sf_relpos_scatter: E must be 16-byte aligned");
     const int64_t chunks = (rows + SF_RELPOS_SC_ROWS - 1) / SF_RELPOS_SC_ROWS;
-    if (lde <= SF_RELPOS_SC_LDE && test_hook("SF_RELPOS_SC_LDS", 1))
+    if (lde <= SF_RELPOS_SC_LDE)
         hipLaunchKernelGGL(sf_relpos_scatter_lds_kernel, dim3((unsigned)(chunks < 8192 ? chunks : 8192)), dim3(SF_THREADS), 0,
                            (hipStream_t)stream, p, (f16*)E, lde, make_fastdiv((uint32_t)R), R, rows);
     else
