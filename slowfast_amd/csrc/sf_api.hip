@@ -4,7 +4,6 @@
 #include "sf_common.h"
 #include "sf_igemm.h"
 #include "sf_igemm2.h"
-#include "sf_igemm3.h"
 #include "sf_wgrad2.h"
 #include "sf_pool.h"
 #include "sf_dwconv.h"
@@ -211,19 +210,10 @@ static void launch_igemm2_auto(Igemm2Params& q, hipStream_t s) {
     // lost on both models: SlowFast 766.5 -> 741 clips/s on every eligible layer, 755 restricted to grids of >= 512 tiles,
     // MViTv2-S 590.9 -> 584 / 588; profiles/r4/r4_v6_knobs_ab.txt.  The same tile on a 16-wave workgroup (64 x 64 wave tiles, four
     // waves per SIMD kept) moved no layer either: profiles/r4/r4_v11_igemm2_fat_ab.txt.  Both removed.)
-    // third generation (sf_igemm3.h, 256 x 256 x 64 eight-phase ping-pong): EXPERIMENT, SF_IGEMM3=<min tiles> switches it on
-    {
-        const int i3_min = test_hook("SF_IGEMM3", 0);
-        const int i3_minn = test_hook("SF_IGEMM3_MINN", 192);
-        const int t3 = cdiv(q.M, 256) * cdiv(q.Nout, 256);
-        if (i3_min > 0 && q.C % 64 == 0 && q.Nout >= i3_minn && t3 >= i3_min) {
-            q.ntiles_n = cdiv(q.Nout, 256);
-            if (trace) fprintf(stderr, "[sfamd] igemm3: %d tiles\n", t3);
-            if (q.f32.out) hipLaunchKernelGGL((sf_igemm3_kernel<true>), dim3((unsigned)t3), dim3(512), 0, s, q);
-            else hipLaunchKernelGGL((sf_igemm3_kernel<false>), dim3((unsigned)t3), dim3(512), 0, s, q);
-            return;
-        }
-    }
+    // (A third-generation kernel -- sf_igemm3.h, 256 x 256 x 64 tiles on the eight-phase ping-pong schedule, 958-1013 TFLOP/s on
+    // res5 a -- lived here as an opt-in through round 5.  Re-measured in the step with every threshold in round 6 it loses on both
+    // models (SlowFast 855.7 vs 846.7 / 852.2 at >= 400 / 1500 tiles, MViTv2-S 739.4 vs 727.5 / 737.1: profiles/r6_v19_igemm3_instep_ab.txt):
+    // one workgroup per CU leaves its HBM-bound epilogue uncovered.  Removed; commit 488e9e9 has the file and its tests.)
     // 128 x 128 tiles on four waves, THREE workgroups per CU (52 KB of LDS each), for the plain matrix products (`linear`) without a statistics / column-sum
     // epilogue whose grid is several rounds deep anyway (the MViT Linears with K >= 512: fc2, the fc1 / qkv data gradients): a third
     // resident workgroup hides more of the store epilogue than the bigger tile saves in operand traffic -- fc2 forward 103.7 ->

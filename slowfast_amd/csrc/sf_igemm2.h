@@ -80,7 +80,7 @@ __device__ __forceinline__ int i2_lds_off(int row, int kslot) {
     else return lds_tile_off(row, kslot);
 }
 
-// Epilogue shared by the second-generation kernels (sf_igemm2_kernel, sf_igemm3_kernel): alpha / bias, fp32 side rows, BatchNorm
+// Epilogue of the second-generation kernel (sf_igemm2_kernel; a function of its own since the round-5 sf_igemm3 experiment shared it): alpha / bias, fp32 side rows, BatchNorm
 // partial statistics from the accumulators, the tile staged through LDS (the operand stages are dead by now; the caller has
 // passed the workgroup barrier that ends its K loop) and stored in 16-byte row-contiguous pieces with residual (+ bit mask), GELU
 // epilogues, the fused BatchNorm-backward reduction.  acc[i][j] = rows wm * WM + i * 16 .., columns wn * WN + j * 16 .. of the tile.
