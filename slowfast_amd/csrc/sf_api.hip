@@ -9,6 +9,7 @@
 #include "sf_dwconv.h"
 #include "sf_dwtile.h"
 #include "sf_dwsweep.h"
+#include "sf_dwtemporal.h"
 #include "sf_tokens.h"
 #include "sf_x3d.h"
 #include "sf_stem.h"
@@ -1810,10 +1811,51 @@ static void dwsweep_launch(DwSweepParams& p, int kmode, int ks, bool stats, hipS
 #undef SF_DWS_LAUNCH
 }
 
+// Temporal depthwise convolution (kT, 1, 1) / stride 1 / padding kT / 2 (X3D stem): one register-window pass (sf_dwtemporal.h).
+// SF_DW_TEMPORAL=0 keeps the W-blocked stencils (A/B runs, read per call).  dir: 0 forward, 1 data gradient, 2 weight gradient.
+static bool dwtemp_plan(const sf_dw_desc* d, int dir, DwTempParams& p) {
+    const char* lv = getenv("SF_DW_TEMPORAL");
+    if (lv && atoi(lv) == 0) return false;
+    if (d->kH != 1 || d->kW != 1 || (d->kT != 3 && d->kT != 5 && d->kT != 7) || d->pT != d->kT / 2 || d->pH != 0 || d->pW != 0) return false;
+    if (d->sT != 1 || d->sH != 1 || d->sW != 1 || d->To != d->Ti || d->Ho != d->Hi || d->Wo != d->Wi || d->cls) return false;
+    if (d->C % 8 != 0 || d->C / 8 > SF_THREADS) return false;
+    const int64_t cols = (int64_t)d->N * d->Hi * d->Wi;
+    if (cols >= (1ll << 31) || (int64_t)d->Hi * d->Wi * (d->ldx > d->ldy ? d->ldx : d->ldy) >= (1ll << 31)) return false;
+    memset(&p, 0, sizeof(p));
+    p.N = d->N; p.C = d->C; p.Cw = d->Cw; p.Cwreal = d->Cwreal ? d->Cwreal : d->Cw; p.T = d->Ti; p.HW = d->Hi * d->Wi;
+    p.G = d->C / 8; p.PP = SF_THREADS / p.G; p.cols = (int)cols; p.flip = dir == 1 ? 1 : 0;
+    const int64_t passes = cdiv(cols, (int64_t)p.PP);
+    // workgroups = rows of the partial tables: at most 2048 (forward statistics, finalized without a fold stage) / 1024 (weight gradient)
+    const int forced = test_hook("SF_DWTP_BLOCKS", 0);       // tests: several passes per workgroup on small shapes
+    const int64_t max_blocks = forced > 0 ? forced : dir == 2 ? 1024 : 2048;
+    p.iters = (int)cdiv(passes, max_blocks);
+    p.fdHW = make_fastdiv(p.HW); p.fdG = make_fastdiv(p.G);
+    return true;
+}
+static int dwtemp_blocks(const DwTempParams& p) { return (int)cdiv(cdiv((int64_t)p.cols, (int64_t)p.PP), (int64_t)p.iters); }
+static void dwtemp_launch(DwTempParams& p, int kT, int dir, bool stats, hipStream_t s) {
+    const dim3 grid((unsigned)dwtemp_blocks(p));
+    static const bool trace = test_hook("SF_TRACE", 0) != 0;
+    if (trace) fprintf(stderr, "[sfamd] dwtemporal: dir %d kT=%d N=%d C=%d T=%d HW=%d PP=%d iters=%d blocks=%u\n", dir, kT, p.N, p.C, p.T, p.HW, p.PP, p.iters, grid.x);
+#define SF_DWTP_LAUNCH(K) do {                                                                                                   \
+        if (dir == 2) hipLaunchKernelGGL((sf_dwtemporal_kernel<K, 2, false>), grid, dim3(SF_THREADS), 0, s, p);                    \
+        else if (stats) hipLaunchKernelGGL((sf_dwtemporal_kernel<K, 0, true>), grid, dim3(SF_THREADS), 0, s, p);                   \
+        else hipLaunchKernelGGL((sf_dwtemporal_kernel<K, 0, false>), grid, dim3(SF_THREADS), 0, s, p);                             \
+    } while (0)
+    if (kT == 3) SF_DWTP_LAUNCH(3);
+    else if (kT == 5) SF_DWTP_LAUNCH(5);
+    else SF_DWTP_LAUNCH(7);
+#undef SF_DWTP_LAUNCH
+}
+
 extern "C" int sf_dwconv_fwd_blocks(const sf_dw_desc* d) {
     DwParams p;
     dim3 grid;
     if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
+    {
+        DwTempParams tp;
+        if (dwtemp_plan(d, 0, tp)) return dwtemp_blocks(tp);
+    }
     if (!d->cls) {      // the sweep carries the BatchNorm partial sums: one row per (sample, tile)
         DwSweepParams sp;
         int km, ks, sl;
@@ -1832,6 +1874,14 @@ extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w,
     dim3 grid;
     if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
     REQUIRE(x && w && y, "sf_dwconv_fwd: null pointer");
+    {
+        DwTempParams tp;
+        if (dwtemp_plan(d, 0, tp)) {
+            tp.a = (const f16*)x; tp.lda = d->ldx; tp.dst = (f16*)y; tp.ldd = d->ldy; tp.w = w; tp.part = stat_part;
+            dwtemp_launch(tp, d->kT, 0, stat_part != nullptr, (hipStream_t)stream);
+            return check_launch("dwconv_fwd (temporal)");
+        }
+    }
     if (!(stat_part && d->cls)) {
         DwSweepParams sp;
         int km, ks, sl;
@@ -1874,6 +1924,14 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
     dim3 grid;
     if (fill_dw(p, d, false, 8192, grid)) return -1;
     REQUIRE(dy && w && dx, "sf_dwconv_dgrad: null pointer");
+    {
+        DwTempParams tp;
+        if (dwtemp_plan(d, 1, tp)) {
+            tp.a = (const f16*)dy; tp.lda = d->ldy; tp.dst = (f16*)dx; tp.ldd = d->ldx; tp.w = w;
+            dwtemp_launch(tp, d->kT, 1, false, (hipStream_t)stream);
+            return check_launch("dwconv_dgrad (temporal)");
+        }
+    }
     {
         DwSweepParams sp;
         int km, ks, sl;
@@ -2007,6 +2065,7 @@ extern "C" int64_t sf_dwconv_wgrad_workspace(const sf_dw_desc* d) {
     if (dwtile_wgrad_shape_ok(d) && (int64_t)d->N * d->Ho > rows) rows = (int64_t)d->N * d->Ho;
     if (dwsweep_shape_ok(d) && dwsweep_max_rows(d) > rows) rows = dwsweep_max_rows(d);
     if (dwgap_shape_ok(d) && (int64_t)d->N * d->Ho * d->Wo > rows) rows = (int64_t)d->N * d->Ho * d->Wo;
+    if (rows < 1024) rows = 1024;       // sf_dwtemporal_kernel: at most 1024 partial rows
     return rows * d->kT * d->kH * d->kW * d->C * 4;
 }
 extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* dy, float* dw, float out_scale,
@@ -2016,6 +2075,23 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
     if (fill_dw(p, d, true, kDwWgradBlocks, grid)) return -1;
     REQUIRE(x && dy && dw && workspace, "sf_dwconv_wgrad: null pointer");
     const int taps = d->kT * d->kH * d->kW;
+    {
+        DwTempParams tp;
+        if (dwtemp_plan(d, 2, tp)) {
+            const int nblk = dwtemp_blocks(tp);
+            REQUIRE(workspace_bytes >= (int64_t)nblk * taps * d->C * 4, "sf_dwconv_wgrad: workspace too small");
+            tp.a = (const f16*)x; tp.lda = d->ldx; tp.b = (const f16*)dy; tp.ldb = d->ldy; tp.part = (float*)workspace;
+            hipStream_t s = (hipStream_t)stream;
+            dwtemp_launch(tp, d->kT, 2, false, s);
+            if (check_launch("dwconv_wgrad (temporal)")) return -1;
+            DwFinalizeParams f;
+            f.wpart = (const float*)workspace; f.nblk = nblk; f.taps = taps; f.C = d->C; f.Cw = d->Cw;
+            f.Cwreal = d->Cwreal ? d->Cwreal : d->Cw;
+            f.dw = dw; f.scale = out_scale; f.accumulate = zero_first ? 0 : 1;
+            hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, 32)), dim3(SF_THREADS), 0, s, f);
+            return check_launch("dwconv_wgrad_finalize");
+        }
+    }
     {
         DwSweepParams sp;
         int km, ks, sl = 0;

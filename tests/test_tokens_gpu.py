@@ -51,6 +51,19 @@ def test_dwconv_tokens(gpu):
     tc.check_dwconv(gpu, 1, 8, 96, (2, 7, 7), (3, 3, 3), (1, 1, 1), cls=1)
 
 
+def test_dwconv_temporal(gpu, monkeypatch):
+    """sf_dwtemporal.h at the X3D-M stem's production plane (24 channels, 16 frames, 112 x 112; batch 3 here: several passes per
+    workgroup), other window lengths, and the stencils it replaces."""
+    tc.check_dwconv(gpu, 3, 1, 24, (16, 112, 112), (5, 1, 1), (1, 1, 1), cls=0)
+    tc.check_dwconv(gpu, 2, 2, 8, (5, 20, 20), (3, 1, 1), (1, 1, 1), cls=0)
+    tc.check_dwconv(gpu, 1, 1, 40, (2, 9, 9), (7, 1, 1), (1, 1, 1), cls=0)
+    monkeypatch.setenv("SF_DWTP_BLOCKS", "7")
+    tc.check_dwconv(gpu, 2, 1, 24, (8, 12, 12), (5, 1, 1), (1, 1, 1), cls=0)
+    monkeypatch.delenv("SF_DWTP_BLOCKS")
+    monkeypatch.setenv("SF_DW_TEMPORAL", "0")
+    tc.check_dwconv(gpu, 2, 1, 24, (8, 12, 12), (5, 1, 1), (1, 1, 1), cls=0)
+
+
 def test_dwconv_ring_sweep(gpu, monkeypatch):
     """sf_dwsweep.h at the production planes of MViTv2-S (56- / 28- / 14- / 7-wide, every stride, heads sharing the weight, cls
     rows, slices of a wider tensor) and X3D-M (54 -> 56, 108 -> 112, 216, 432 channels: tail chunks; BatchNorm partial sums), plus

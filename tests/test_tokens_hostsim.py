@@ -44,6 +44,21 @@ def test_dwconv_tokens_stencils(sim, monkeypatch):
     _dwconv_tokens(sim)
 
 
+def test_dwconv_temporal(sim, monkeypatch):
+    """(kT, 1, 1) stride-1 depthwise convolutions on the register-window walk (sf_dwtemporal.h; X3D stem conv_t): kT = 3 / 5 / 7,
+    clips shorter than the window and its look-ahead, heads sharing the weights, a channel count that leaves idle lanes (24 = 3
+    groups: 85 positions per pass), several passes per workgroup, and the stencils it replaces on the same cases."""
+    cases = [(2, 1, 24, (6, 4, 4), (5, 1, 1)), (1, 1, 16, (1, 3, 3), (5, 1, 1)), (1, 1, 16, (2, 3, 3), (7, 1, 1)),
+             (1, 2, 8, (3, 5, 5), (3, 1, 1)), (2, 1, 24, (9, 12, 12), (5, 1, 1)), (1, 1, 40, (4, 6, 6), (7, 1, 1))]
+    for B, heads, Cw, thw, k in cases:
+        tc.check_dwconv(sim, B, heads, Cw, thw, k, (1, 1, 1), cls=0)
+    monkeypatch.setenv("SF_DWTP_BLOCKS", "2")                   # 288 positions / 85 per pass = 4 passes on 2 workgroups
+    tc.check_dwconv(sim, 2, 1, 24, (9, 12, 12), (5, 1, 1), (1, 1, 1), cls=0)
+    monkeypatch.delenv("SF_DWTP_BLOCKS")
+    monkeypatch.setenv("SF_DW_TEMPORAL", "0")
+    tc.check_dwconv(sim, 2, 1, 24, (6, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)
+
+
 def _dwconv_tokens(sim):
     tc.check_dwconv(sim, 2, 2, 16, (2, 6, 6), (3, 3, 3), (1, 2, 2), cls=1)
     tc.check_dwconv(sim, 1, 1, 32, (4, 5, 5), (3, 3, 3), (1, 1, 1), cls=1)
