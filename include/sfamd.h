@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 22
+#define SF_ABI_VERSION 23
 typedef void* sf_stream_t;
 
 /* Geometry of one nn.Conv3d (groups == 1).  Ci is the channel count of the activation buffer
@@ -407,6 +407,13 @@ int sf_outer_sum(const float* a, int32_t lda, const float* b, int32_t ldb, int32
 int sf_gate_act_bwd(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift,
                     const float* gate, int swish, const void* dz, int32_t lddz, const float* dmean, void* du, int32_t lddu,
                     sf_stream_t stream);
+/* the same pass, also leaving the per-workgroup column sums of du and du * y in bn_part[sf_gate_act_bwd_bn_rows()][2][C]: the
+ * reduction half of the backward of the BatchNorm in front of the gate (X3DTransform.b_bn, resnet_helper.py:226-250), which
+ * sf_bn_bwd_finalize takes in place of sf_bn_bwd_reduce's table (ABI 23) */
+int sf_gate_act_bwd_bn_rows(int32_t N, int64_t S, int32_t C);
+int sf_gate_act_bwd_bn(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift,
+                       const float* gate, int swish, const void* dz, int32_t lddz, const float* dmean, void* du, int32_t lddu,
+                       float* bn_part, sf_stream_t stream);
 
 /* ---- training-step glue on the flat gradient memory -- replaces tools/train_net.py:150-172 (GradScaler.unscale_ / step /
  * update, clip_grad_norm_ / clip_grad_value_, optimizer.get_grad_norm_, misc.check_nan_losses) and optimizer.step()

@@ -2693,11 +2693,11 @@ extern "C" int sf_outer_sum(const float* a, int32_t lda, const float* b, int32_t
     return check_launch("outer_sum");
 }
 static int fill_gate_act(GateActParams& p, int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale,
-                         const float* shift, const float* gate, int swish, dim3& grid) {
+                         const float* shift, const float* gate, int swish, dim3& grid, int max_blocks = 8192) {
     if (check_rows("gate_act", (int64_t)N * S, C)) return -1;
     REQUIRE(y && scale && shift, "gate_act: null pointer");
     memset(&p, 0, sizeof(p));
-    p.rt = make_rowtile((int64_t)N * S, C, 8192, grid);
+    p.rt = make_rowtile((int64_t)N * S, C, max_blocks, grid);
     p.S = S; p.y = (const f16*)y; p.ldy = ldy; p.scale = scale; p.shift = shift; p.gate = gate; p.swish = swish;
     p.fdS = make_fastdiv((uint32_t)S);
     return 0;
@@ -2720,8 +2720,30 @@ extern "C" int sf_gate_act_bwd(int32_t N, int64_t S, int32_t C, const void* y, i
     if (fill_gate_act(p, N, S, C, y, ldy, scale, shift, gate, swish, grid)) return -1;
     REQUIRE(dz && du, "sf_gate_act_bwd: null pointer");
     p.dz = (const f16*)dz; p.lddz = lddz; p.dmean = dmean; p.inv_S = 1.0f / (float)S; p.z = (f16*)du; p.ldz = lddu;
-    hipLaunchKernelGGL(sf_gate_act_bwd_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(sf_gate_act_bwd_kernel<false>, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("gate_act_bwd");
+}
+// ... with the reduction of the BatchNorm backward that follows fused in: bn_part[sf_gate_act_bwd_bn_rows()][2][C] gets the column
+// sums of du and du * y (X3DTransform: the BatchNorm between the channelwise 3x3x3 convolution and SE / Swish,
+// resnet_helper.py:226-250); 2048 workgroups at most, so that sf_bn_bwd_finalize needs no fold stage
+static const int kGateBnBlocks = 2048;
+extern "C" int sf_gate_act_bwd_bn_rows(int32_t N, int64_t S, int32_t C) {
+    if (check_rows("gate_act", (int64_t)N * S, C)) return -1;
+    dim3 grid;
+    make_rowtile((int64_t)N * S, C, kGateBnBlocks, grid);
+    return (int)grid.x;
+}
+extern "C" int sf_gate_act_bwd_bn(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale,
+                                  const float* shift, const float* gate, int swish, const void* dz, int32_t lddz,
+                                  const float* dmean, void* du, int32_t lddu, float* bn_part, sf_stream_t stream) {
+    GateActParams p;
+    dim3 grid;
+    if (fill_gate_act(p, N, S, C, y, ldy, scale, shift, gate, swish, grid, kGateBnBlocks)) return -1;
+    REQUIRE(dz && du && bn_part, "sf_gate_act_bwd_bn: null pointer");
+    p.dz = (const f16*)dz; p.lddz = lddz; p.dmean = dmean; p.inv_S = 1.0f / (float)S; p.z = (f16*)du; p.ldz = lddu;
+    p.bn_part = bn_part;
+    hipLaunchKernelGGL(sf_gate_act_bwd_kernel<true>, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("gate_act_bwd_bn");
 }
 
 

@@ -180,6 +180,8 @@ struct GateActParams {
     const f16* dz; int lddz;        // bwd in
     const float* dmean; float inv_S;
     FastDiv fdS;
+    float* bn_part;                 // bwd, optional: [gridDim.x][2][C] column sums of du and du * y over the workgroup's rows --
+                                    // what sf_bn_bwd_reduce would take in a pass of its own over du and y (round 6)
 };
 __global__ __launch_bounds__(SF_THREADS) void sf_gate_act_fwd_kernel(GateActParams p) {
     int gcol, r0, r1, rstep;
@@ -199,26 +201,37 @@ __global__ __launch_bounds__(SF_THREADS) void sf_gate_act_fwd_kernel(GateActPara
         st16(p.z + (int64_t)m * p.ldz + c, o);
     }
 }
+// BNP: the BatchNorm-backward reduction of the BatchNorm in front of the gate rides on this pass (sums of the STORED, 16-bit du
+// and of du * y, one partial row per workgroup, fixed order -- the quantities and the rounding of sf_bn_bwd_reduce_kernel)
+template <bool BNP>
 __global__ __launch_bounds__(SF_THREADS) void sf_gate_act_bwd_kernel(GateActParams p) {
+    __shared__ float s_red[BNP ? SF_THREADS : 1][17];
     int gcol, r0, r1, rstep;
-    if (!p.rt.init(gcol, r0, r1, rstep)) return;
+    const bool active = p.rt.init(gcol, r0, r1, rstep);
+    if (!BNP && !active) return;
     const int c = gcol * 8;
-    float sc[8], sh[8];
-    load8f(p.scale + c, sc);
-    load8f(p.shift + c, sh);
-    for (int m = r0; m < r1; m += rstep) {
-        const int64_t n = fd_div((uint32_t)m, p.fdS);
-        float gt[8], dm[8];
+    float sc[8], sh[8], sg[8], sgy[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { gt[e] = 1.f; dm[e] = 0.f; }
-        if (p.gate) load8f(p.gate + n * p.rt.C + c, gt);
-        if (p.dmean) load8f(p.dmean + n * p.rt.C + c, dm);
-        f16x8 v = ld16(p.y + (int64_t)m * p.ldy + c), d = ld16(p.dz + (int64_t)m * p.lddz + c), o;
+    for (int e = 0; e < 8; ++e) { sc[e] = 0.f; sh[e] = 0.f; sg[e] = 0.f; sgy[e] = 0.f; }
+    if (active) {
+        load8f(p.scale + c, sc);
+        load8f(p.shift + c, sh);
+        for (int m = r0; m < r1; m += rstep) {
+            const int64_t n = fd_div((uint32_t)m, p.fdS);
+            float gt[8], dm[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float u = (float)v[e] * sc[e] + sh[e];
-            o[e] = (f16)((float)d[e] * act_grad(gt[e] * u, p.swish) * gt[e] + dm[e] * p.inv_S);
+            for (int e = 0; e < 8; ++e) { gt[e] = 1.f; dm[e] = 0.f; }
+            if (p.gate) load8f(p.gate + n * p.rt.C + c, gt);
+            if (p.dmean) load8f(p.dmean + n * p.rt.C + c, dm);
+            f16x8 v = ld16(p.y + (int64_t)m * p.ldy + c), d = ld16(p.dz + (int64_t)m * p.lddz + c), o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float u = (float)v[e] * sc[e] + sh[e];
+                o[e] = (f16)((float)d[e] * act_grad(gt[e] * u, p.swish) * gt[e] + dm[e] * p.inv_S);
+                if constexpr (BNP) { sg[e] += (float)o[e]; sgy[e] += (float)o[e] * (float)v[e]; }
+            }
+            st16(p.z + (int64_t)m * p.ldz + c, o);
         }
-        st16(p.z + (int64_t)m * p.ldz + c, o);
     }
+    if constexpr (BNP) rowtile_reduce_store(p.rt, active, c, sg, sgy, p.bn_part + (int64_t)blockIdx.x * 2 * p.rt.C, s_red);
 }

@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 22
+ABI_VERSION = 23
 # 16-bit storage type of activations / packed weights / MFMA operands, fixed per PROCESS: SF_ACT_DTYPE=fp16 (default) loads
 # libsfamd.so, =bf16 loads libsfamd_bf16.so -- the same sources compiled with -DSF_ACT_BF16 (bfloat16 storage,
 # v_mfma_f32_16x16x32_bf16); both are what torch.cuda.amp.autocast admits on the reference side (tools/train_net.py:101-118).
@@ -173,6 +173,8 @@ _SIGNATURES = {
     "sf_se_gate_bwd": (c_int, [c_int32, c_int32, c_int32, c_int32, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "sf_outer_sum": (c_int, [_F, c_int32, _F, c_int32, c_int32, c_int32, c_int32, _F, c_float, c_int, _P]),
     "sf_gate_act_bwd": (c_int, [c_int32, c_int64, c_int32, _P, c_int32, _F, _F, _F, c_int, _P, c_int32, _F, _P, c_int32, _P]),
+    "sf_gate_act_bwd_bn_rows": (c_int, [c_int32, c_int64, c_int32]),
+    "sf_gate_act_bwd_bn": (c_int, [c_int32, c_int64, c_int32, _P, c_int32, _F, _F, _F, c_int, _P, c_int32, _F, _P, c_int32, _F, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

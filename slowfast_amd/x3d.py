@@ -8,6 +8,7 @@ X3D-M widths 54 and 108 are not multiples of 8: activation buffers are padded to
 lanes are exact zeros end to end (zero weight rows, zero BN scale/shift); parameters keep the reference shapes.
 """
 import math
+import os
 from ctypes import byref
 
 import torch
@@ -23,6 +24,9 @@ from .resblocks import ResStage, _TRANS
 from .video_models import get_norm, init_weights
 
 _f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
+
+# SF_GATE_BN_FUSE=0: the separate sf_bn_bwd_reduce pass behind sf_gate_act_bwd (A/B runs; profiles/r6_v22_gate_bn_fuse_ab.txt)
+GATE_BN_FUSE = os.environ.get("SF_GATE_BN_FUSE", "1") != "0"
 
 
 def _pad8(c):
@@ -79,13 +83,22 @@ def gate_act_fwd(y, scale, shift, gate, swish):
     return z
 
 
-def gate_act_bwd(y, scale, shift, gate, swish, dz, dmean):
+def gate_act_bwd(y, scale, shift, gate, swish, dz, dmean, bn_part=False):
+    """``bn_part``: also return the [rows, 2, C] column sums of du and du * y -- the reduction of the BatchNorm backward that
+    follows, taken in this pass instead of one of its own (ops.bn_bwd(..., part=...))."""
     N, C = y.shape[:2]
     S = ops.rows(y) // N
     du = ops.cl_empty(y.shape, y.device)
-    get_lib().call("sf_gate_act_bwd", N, S, C, y.data_ptr(), ops.cl_ld(y), scale.data_ptr(), shift.data_ptr(),
-                   ops._ptr(gate), int(bool(swish)), dz.data_ptr(), ops.cl_ld(dz), ops._ptr(dmean), du.data_ptr(),
-                   ops.cl_ld(du), ops._stream(y), work=dict(bytes=6.0 * y.numel()))
+    lib = get_lib()
+    if bn_part:
+        part = torch.empty((lib.call("sf_gate_act_bwd_bn_rows", N, S, C), 2, C), dtype=torch.float32, device=y.device)
+        lib.call("sf_gate_act_bwd_bn", N, S, C, y.data_ptr(), ops.cl_ld(y), scale.data_ptr(), shift.data_ptr(),
+                 ops._ptr(gate), int(bool(swish)), dz.data_ptr(), ops.cl_ld(dz), ops._ptr(dmean), du.data_ptr(),
+                 ops.cl_ld(du), part.data_ptr(), ops._stream(y), work=dict(bytes=6.0 * y.numel()))
+        return du, part
+    lib.call("sf_gate_act_bwd", N, S, C, y.data_ptr(), ops.cl_ld(y), scale.data_ptr(), shift.data_ptr(),
+             ops._ptr(gate), int(bool(swish)), dz.data_ptr(), ops.cl_ld(dz), ops._ptr(dmean), du.data_ptr(),
+             ops.cl_ld(du), ops._stream(y), work=dict(bytes=6.0 * y.numel()))
     return du
 
 
@@ -99,13 +112,14 @@ class BNUnit:
     def finalize(self, part, count, C, training):
         return bn_statistics(self.bn, part, count, C, training)
 
-    def backward(self, dz, y, st, relu_self=False):
+    def backward(self, dz, y, st, relu_self=False, part=None):
         bn = self.bn
         dgamma, zg = _grad_dest(bn.weight)
         dbeta, zb = _grad_dest(bn.bias)
         assert zg == zb
         return ops.bn_bwd(dz, y, bn.weight, st.mean, st.rstd, dgamma, dbeta,
-                          relu_affine=(st.scale, st.shift) if relu_self else None, accumulate=not zg, sync=_sync_of(bn))
+                          relu_affine=(st.scale, st.shift) if relu_self else None, accumulate=not zg, sync=_sync_of(bn),
+                          part=part)
 
 
 class DwUnit:
@@ -236,8 +250,11 @@ class X3DBlockFn(torch.autograd.Function):
         if t._se is not None:
             dgate = gate_grad(yb, sb.scale, sb.shift, dzb, gate, t._swish_inner)
             dmean = t._se.gate_bwd(sv["se"][0], sv["se"][1], gate, dgate)
-        du = gate_act_bwd(yb, sb.scale, sb.shift, gate, t._swish_inner, dzb, dmean)
-        dyb = t._b_bn.backward(du, yb, sb)
+        if engine.BN_FUSE_REDUCE and GATE_BN_FUSE:      # the reduction of b_bn's backward rides on the gate / Swish backward pass
+            du, part_b = gate_act_bwd(yb, sb.scale, sb.shift, gate, t._swish_inner, dzb, dmean, bn_part=True)
+        else:
+            du, part_b = gate_act_bwd(yb, sb.scale, sb.shift, gate, t._swish_inner, dzb, dmean), None
+        dyb = t._b_bn.backward(du, yb, sb, part=part_b)
         dza = t._b.backward(sv["za"], dyb, need_dx=True)
         dya = A.bn_backward(dza, sv["ya"], sv["sa"], relu_self=True)
         prev = ctx.prev_bn if need_dx else None
