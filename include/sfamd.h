@@ -275,6 +275,9 @@ typedef struct sf_dw_desc {
     int32_t Cwreal;   /* rows of the fp32 weight (0 = Cw); channels [Cwreal, Cw) are zero padding (X3D widths 54, 108) */
 } sf_dw_desc;
 int sf_dwconv_fwd_blocks(const sf_dw_desc* d);       /* rows of stat_part */
+/* rows of the statistics table of sf_dwconv_fwd that belong to one sample when the table is sample-major (rows [n * r, (n + 1) * r)
+ * = sample n), else 0: per-sample channel sums (SE squeeze, operators.py:38-45) can then be read from the table (ABI 23) */
+int sf_dwconv_fwd_sample_rows(const sf_dw_desc* d);
 /* stat_part (optional): [blocks][2][C] per-block sum / sum of squares of the outputs (BatchNorm statistics) */
 int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w, void* y, float* stat_part, sf_stream_t stream);
 int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float* w, void* dx, sf_stream_t stream);

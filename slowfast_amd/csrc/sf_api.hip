@@ -1868,6 +1868,24 @@ extern "C" int sf_dwconv_fwd_blocks(const sf_dw_desc* d) {
     }
     return (int)grid.x;
 }
+// Rows of sf_dwconv_fwd's statistics table that belong to ONE sample when the table is sample-major (the plane sweeps write one
+// row per (sample, tile): rows [n * r, (n + 1) * r) are sample n's), 0 when the kernel this geometry takes cuts its rows without
+// regard to samples.  Lets a caller take per-sample channel sums (the SE squeeze, operators.py:38-45) from the table instead of
+// from a pass over y.
+extern "C" int sf_dwconv_fwd_sample_rows(const sf_dw_desc* d) {
+    DwParams p;
+    dim3 grid;
+    if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
+    DwTempParams tp;
+    if (dwtemp_plan(d, 0, tp)) return 0;
+    if (!d->cls) {
+        DwSweepParams sp;
+        int km, ks, sl;
+        if (dwrot_plan(d, 0, sp, km, ks, sl)) return sp.tiles_h * sp.tiles_w;
+        if (dwsweep_plan(d, 0, sp, km, ks)) return sp.tiles_h * sp.tiles_w;
+    }
+    return 0;
+}
 extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w, void* y, float* stat_part,
                              sf_stream_t stream) {
     DwParams p;

@@ -352,6 +352,8 @@ def dwconv_fwd(x, w, geom, out=None, stats=False):
     part = None
     if stats:
         part = torch.empty((lib.call("sf_dwconv_fwd_blocks", byref(d)), 2, C), dtype=torch.float32, device=x.device)
+        # rows of the table per sample when it is sample-major (0: not), for callers that want per-sample sums (x3d SE squeeze)
+        geom.stat_sample_rows = lib.call("sf_dwconv_fwd_sample_rows", byref(d))
     lib.call("sf_dwconv_fwd", byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), _ptr(part), _stream(x),
              work=dict(bytes=2.0 * C * (geom.rows_in + geom.rows_out), flops=2.0 * geom.rows_out * C * geom.taps))
     return (y, part) if stats else y

@@ -27,6 +27,9 @@ _f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.AC
 
 # SF_GATE_BN_FUSE=0: the separate sf_bn_bwd_reduce pass behind sf_gate_act_bwd (A/B runs; profiles/r6_v22_gate_bn_fuse_ab.txt)
 GATE_BN_FUSE = os.environ.get("SF_GATE_BN_FUSE", "1") != "0"
+# SF_SE_FROM_STATS=0: the SE squeeze as a pass of its own over the activation (sf_sample_mean) instead of from the depthwise
+# convolution's statistics table (A/B runs; profiles/r6_v24_se_from_stats_ab.txt)
+SE_FROM_STATS = os.environ.get("SF_SE_FROM_STATS", "1") != "0"
 
 
 def _pad8(c):
@@ -204,10 +207,18 @@ class X3DBlockFn(torch.autograd.Function):
         ya, sa = A.forward(x, None, tr)
         za = ops.bn_act(ya, sa.scale, sa.shift, relu=True)
         yb, part, g = t._b.forward(za, stats=True)
+        # SE squeeze (operators.py:38-45) = per-sample mean of bn(y) = an affine map of the per-sample channel sums, which the
+        # plane sweep's statistics table already holds (one row per (sample, tile)): no pass over yb.  Taken BEFORE the
+        # finalize (which may fold the table in place).
+        nrow = getattr(g, "stat_sample_rows", 0) if (t._se is not None and SE_FROM_STATS) else 0
+        ysum = part.view(yb.shape[0], nrow, 2, -1)[:, :, 0].sum(1) if nrow > 0 else None
         sb = t._b_bn.finalize(part, g.rows_out, yb.shape[1], tr)
         gate = se = None
         if t._se is not None:
-            m = sample_mean(yb, sb.scale, sb.shift, relu=False)
+            if ysum is not None:
+                m = torch.addcmul(sb.shift, ysum, sb.scale, value=float(yb.shape[0]) / float(g.rows_out))
+            else:
+                m = sample_mean(yb, sb.scale, sb.shift, relu=False)
             h, gate = t._se.gate_fwd(m)
             se = (m, h)
         zb = gate_act_fwd(yb, sb.scale, sb.shift, gate, t._swish_inner)

@@ -31,6 +31,21 @@ def test_bottleneck_transform_standalone(sim):
     bc.check_bottleneck_alone(sim, (2, 16, 2, 8, 8))
 
 
+def test_x3d_se_squeeze_from_statistics_table(sim, monkeypatch):
+    """The SE squeeze of an X3D block is read from the depthwise convolution's per-(sample, tile) statistics table (round 6:
+    x3d.SE_FROM_STATS, sf_dwconv_fwd_sample_rows): no sf_sample_mean pass over the activation, and the block still matches the
+    oracle; with the switch off the pass is back."""
+    from slowfast_amd import x3d
+    calls = []
+    real = x3d.sample_mean
+    monkeypatch.setattr(x3d, "sample_mean", lambda y, sc, sh, relu: (calls.append(relu), real(y, sc, sh, relu))[1])
+    bc.check_x3d_block(sim, 24, 48, 2, 108, (4, 24, 4, 16, 16))              # SE block, stride 2, 108 -> 112 channels
+    assert calls == []
+    monkeypatch.setattr(x3d, "SE_FROM_STATS", False)
+    bc.check_x3d_block(sim, 24, 48, 2, 108, (4, 24, 4, 16, 16))
+    assert calls == [False]
+
+
 def test_x3d_block_masks_handed(sim):
     bc.check_x3d_block(sim, 24, 48, 2, 108, (4, 24, 4, 16, 16))              # projection shortcut, stride 2, SE block
     bc.check_x3d_block(sim, 48, 48, 1, 108, (4, 48, 4, 8, 8), block_idx=1)   # identity shortcut, no SE
