@@ -2478,7 +2478,8 @@ extern "C" int sf_attn_bwd(const sf_attn_desc* d, const void* q, int32_t ldq, co
     }
     hipStream_t st = (hipStream_t)stream;
     {
-        const bool qt2 = attn_two_tiles(d);
+        static const int dq_qt = tune_knob("SF_ATTN_DQ_QT", 0);       // 1 | 2 forces the query-side backward alone (A/B)
+        const bool qt2 = dq_qt ? dq_qt == 2 : attn_two_tiles(d);
         const int qtiles = qt2 ? cdiv(d->Nq, 128) : p.qtiles;
         AttnParams pq = p;
         pq.qtiles = qtiles;
