@@ -413,6 +413,14 @@ int sf_gate_act_bwd(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy,
 /* the same pass, also leaving the per-workgroup column sums of du and du * y in bn_part[sf_gate_act_bwd_bn_rows()][2][C]: the
  * reduction half of the backward of the BatchNorm in front of the gate (X3DTransform.b_bn, resnet_helper.py:226-250), which
  * sf_bn_bwd_finalize takes in place of sf_bn_bwd_reduce's table (ABI 23) */
+/* one pass for the backward of SE-gated Swish: du0 = dz * act'(gate * u) * gate stored, sums[N][3][C] = per-sample sums of
+ * dz * act'(gate * u) * u (the gate's gradient), du0 and du0 * y; part: [N * sf_sample_chunks(S, C)][4][C] scratch (ABI 23) */
+int sf_gate_bwd_sums(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift,
+                     const void* dz, int32_t lddz, const float* gate, int swish, void* du0, int32_t lddu, float* part,
+                     float* sums, sf_stream_t stream);
+/* sf_bn_bwd_apply for a gradient that lacks a per-sample constant: dy = k1 * (dz + sample_add[row / S][c]) + k2 + k3 * y (ABI 23) */
+int sf_bn_bwd_apply_sample(int64_t M, int32_t C, const void* dz, int32_t lddz, const void* y, int32_t ldy, const float* coef,
+                           const float* sample_add, int64_t S, void* dy, int32_t lddy, sf_stream_t stream);
 int sf_gate_act_bwd_bn_rows(int32_t N, int64_t S, int32_t C);
 int sf_gate_act_bwd_bn(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale, const float* shift,
                        const float* gate, int swish, const void* dz, int32_t lddz, const float* dmean, void* du, int32_t lddu,

@@ -1044,8 +1044,27 @@ extern "C" int sf_bn_bwd_apply(int64_t M, int32_t C, const void* dz, int32_t ldd
     p.dz = (const f16*)dz; p.lddz = lddz; p.zmask = (const f16*)zmask; p.ldm = ldm;
     p.y = (const f16*)y; p.ldy = ldy; p.scale = scale; p.shift = shift; p.relu_self = relu_self;
     p.coef = coef; p.dy = (f16*)dy; p.lddy = lddy; p.gout = (f16*)gout; p.ldg = ldg;
+    p.sample_add = nullptr; p.fdS = make_fastdiv(1);
     hipLaunchKernelGGL(sf_bn_bwd_apply_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     return check_launch("bn_bwd_apply");
+}
+// ... for a gradient dz that lacks a per-sample constant: dy = k1 * (dz + sample_add[row / S][c]) + k2 + k3 * y (the sums behind
+// coef must be those of the COMPLETE gradient).  X3DTransform: the SE squeeze's contribution dmean[n][c] / S (operators.py:38-45)
+extern "C" int sf_bn_bwd_apply_sample(int64_t M, int32_t C, const void* dz, int32_t lddz, const void* y, int32_t ldy,
+                                      const float* coef, const float* sample_add, int64_t S, void* dy, int32_t lddy,
+                                      sf_stream_t stream) {
+    if (check_rows("sf_bn_bwd_apply_sample", M, C)) return -1;
+    REQUIRE(dz && y && coef && dy && sample_add, "sf_bn_bwd_apply_sample: null pointer");
+    REQUIRE(S > 0 && S < (1ll << 31) && M % S == 0, "sf_bn_bwd_apply_sample: rows must be whole samples of S positions");
+    BnBwdApplyParams p;
+    dim3 grid;
+    p.rt = make_rowtile(M, C, 8192, grid);
+    p.dz = (const f16*)dz; p.lddz = lddz; p.zmask = nullptr; p.ldm = 0;
+    p.y = (const f16*)y; p.ldy = ldy; p.scale = nullptr; p.shift = nullptr; p.relu_self = 0;
+    p.coef = coef; p.dy = (f16*)dy; p.lddy = lddy; p.gout = nullptr; p.ldg = 0;
+    p.sample_add = sample_add; p.fdS = make_fastdiv((uint32_t)S);
+    hipLaunchKernelGGL(sf_bn_bwd_apply_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
+    return check_launch("bn_bwd_apply_sample");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2676,6 +2695,28 @@ extern "C" int sf_gate_grad(int32_t N, int64_t S, int32_t C, const void* y, int3
                             float* dgate, sf_stream_t stream) {
     REQUIRE(dz && scale, "sf_gate_grad: null pointer");
     return sample_sum(1, N, S, C, y, ldy, scale, shift, 0, dz, lddz, gate, swish, part, dgate, 1.0f, (hipStream_t)stream);
+}
+// One pass over y and dz for the backward of SE-gated Swish (X3DTransform, resnet_helper.py:226-250): du0 = dz * act'(gate * u) * gate
+// is stored, sums[n][0] = the gate's gradient sum_pos dz * act'(gate * u) * u, sums[n][1] = sum_pos du0, sums[n][2] = sum_pos du0 * y
+// (stored 16-bit du0: what sf_bn_bwd_reduce would sum).  part: [N * sf_sample_chunks(S, C)][4][C] scratch.
+extern "C" int sf_gate_bwd_sums(int32_t N, int64_t S, int32_t C, const void* y, int32_t ldy, const float* scale,
+                                const float* shift, const void* dz, int32_t lddz, const float* gate, int swish, void* du0,
+                                int32_t lddu, float* part, float* sums, sf_stream_t stream) {
+    if (check_rows("sf_gate_bwd_sums", S, C)) return -1;
+    REQUIRE(N > 0 && N <= 65535 && y && dz && scale && shift && du0 && part && sums, "sf_gate_bwd_sums: bad arguments");
+    SampleSumParams p;
+    memset(&p, 0, sizeof(p));
+    dim3 grid;
+    const int chunks = sample_plan(S, C, p.rt, grid);
+    REQUIRE(grid.y == 1, "sf_gate_bwd_sums: C > 2048 is not supported");
+    grid.z = N;
+    p.S = S; p.y = (const f16*)y; p.ldy = ldy; p.scale = scale; p.shift = shift; p.mode = 2;
+    p.dz = (const f16*)dz; p.lddz = lddz; p.gate = gate; p.swish = swish; p.part = part; p.z = (f16*)du0; p.ldz = lddu;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sf_sample_sum_kernel, grid, dim3(SF_THREADS), 0, s, p);
+    if (check_launch("gate_bwd_sums")) return -1;
+    hipLaunchKernelGGL(sf_sample_fold3_kernel, dim3(cdiv(C, SF_THREADS), N, 3), dim3(SF_THREADS), 0, s, (const float*)part, chunks, C, sums);
+    return check_launch("gate_bwd_sums_fold");
 }
 static int fill_se(SeGateParams& p, int32_t C, int32_t Cp, int32_t F, const float* w1, const float* b1, const float* w2,
                    const float* b2) {

@@ -377,6 +377,8 @@ struct BnBwdApplyParams {
     const float* coef;       // [3][C]
     f16* dy; int lddy;
     f16* gout; int ldg;      // optional: the masked gradient itself (identity-shortcut path)
+    const float* sample_add; // optional [N][C]: a per-sample constant of the gradient that was NOT stored into dz (round 6, X3D: the SE
+    FastDiv fdS;             // squeeze term dmean[n][c] / S): dy = k1 * (g + sample_add[row / S]) + k2 + k3 * y
 };
 
 __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_apply_kernel(BnBwdApplyParams p) {
@@ -398,6 +400,12 @@ __global__ __launch_bounds__(SF_THREADS) void sf_bn_bwd_apply_kernel(BnBwdApplyP
         masked_grad8(dz, yv, (p.zmask && !bitm) ? p.zmask + (int64_t)m * p.ldm + c : nullptr, p.relu_self, sc, sh, g,
                      bitm ? reinterpret_cast<const uint8_t*>(p.zmask) + (int64_t)m * (C >> 3) + gcol : nullptr);
         f16x8 o;
+        if (p.sample_add) {
+            float ad[8];
+            load8f(p.sample_add + (int64_t)fd_div((uint32_t)m, p.fdS) * C + c, ad);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += ad[e];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (f16)(k1[e] * g[e] + k2[e] + k3[e] * (float)yv[e]);
         st16(p.dy + (int64_t)m * p.lddy + c, o);

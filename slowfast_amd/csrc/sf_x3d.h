@@ -22,7 +22,8 @@ struct SampleSumParams {
     const f16* dz; int lddz;
     const float* gate;              // [N][C] or null (gate = 1)
     int swish;                      // mode 1: activation is swish (1) or relu (0)
-    float* part;                    // [N*gridDim.x][2][C]
+    float* part;                    // [N*gridDim.x][2][C] (mode 2: [N*gridDim.x][4][C])
+    f16* z; int ldz;                // mode 2: du0 = dz * act'(gate * u) * gate, the gate / Swish backward WITHOUT the squeeze term
 };
 
 __device__ __forceinline__ float act_grad(float s, int swish) {
@@ -43,9 +44,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_sample_sum_kernel(SampleSumPara
     const bool active = p.rt.init(gcol, r0, r1, rstep);
     const int c = gcol * 8;
     const int n = blockIdx.z;
-    float a[8], b[8], sc[8], sh[8], gt[8];
+    float a[8], b[8], a2[8], b2[8], sc[8], sh[8], gt[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; gt[e] = 1.f; }
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; a2[e] = 0.f; b2[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; gt[e] = 1.f; }
     if (active) {
         if (p.scale) { load8f(p.scale + c, sc); load8f(p.shift + c, sh); }
         if (p.gate) load8f(p.gate + (int64_t)n * p.rt.C + c, gt);
@@ -59,17 +60,51 @@ __global__ __launch_bounds__(SF_THREADS) void sf_sample_sum_kernel(SampleSumPara
                     if (p.relu) u = u > 0.f ? u : 0.f;
                     a[e] += u;
                 }
-            } else {
+            } else if (p.mode == 1) {
                 f16x8 d = ld16(p.dz + row * p.lddz + c);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float u = (float)v[e] * sc[e] + sh[e];
                     a[e] += (float)d[e] * act_grad(gt[e] * u, p.swish) * u;
                 }
+            } else {
+                // mode 2 (round 6): ONE pass for what sf_gate_grad + sf_gate_act_bwd + sf_bn_bwd_reduce read y and dz three times
+                // for -- the gate's gradient sum (a), du0 stored, and the per-sample sums of the stored du0 (b) and du0 * y (a2)
+                f16x8 d = ld16(p.dz + row * p.lddz + c), o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float u = (float)v[e] * sc[e] + sh[e];
+                    const float t = (float)d[e] * act_grad(gt[e] * u, p.swish);
+                    a[e] += t * u;
+                    o[e] = (f16)(t * gt[e]);
+                    b[e] += (float)o[e];
+                    a2[e] += (float)o[e] * (float)v[e];
+                }
+                st16(p.z + row * p.ldz + c, o);
             }
         }
     }
+    if (p.mode == 2) {
+        float* o = p.part + ((int64_t)n * gridDim.x + blockIdx.x) * 4 * p.rt.C;
+        rowtile_reduce_store(p.rt, active, c, a, b, o, s_red);
+        __syncthreads();
+        rowtile_reduce_store(p.rt, active, c, a2, b2, o + 2 * p.rt.C, s_red);
+        return;
+    }
     rowtile_reduce_store(p.rt, active, c, a, b, p.part + ((int64_t)n * gridDim.x + blockIdx.x) * 2 * p.rt.C, s_red);
+}
+
+// sums[n][j][c] = sum_chunks part[(n*chunks + k)][j][c], j < 3 of the 4 slots of mode 2
+__global__ __launch_bounds__(SF_THREADS) void sf_sample_fold3_kernel(const float* part, int chunks, int C, float* out) {
+    const int n = blockIdx.y, j = blockIdx.z;
+    const int c = blockIdx.x * SF_THREADS + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    const float* src = part + ((int64_t)n * chunks * 4 + j) * C + c;
+    int k = 0;
+    for (; k + 2 <= chunks; k += 2) { s0 += src[(int64_t)k * 4 * C]; s1 += src[(int64_t)(k + 1) * 4 * C]; }
+    if (k < chunks) s0 += src[(int64_t)k * 4 * C];
+    out[((int64_t)n * 3 + j) * C + c] = s0 + s1;
 }
 
 // mean[n][c] = inv_count * sum_chunks part[(n*chunks + k)][0][c]

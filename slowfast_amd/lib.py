@@ -174,6 +174,8 @@ _SIGNATURES = {
     "sf_se_gate_bwd": (c_int, [c_int32, c_int32, c_int32, c_int32, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "sf_outer_sum": (c_int, [_F, c_int32, _F, c_int32, c_int32, c_int32, c_int32, _F, c_float, c_int, _P]),
     "sf_gate_act_bwd": (c_int, [c_int32, c_int64, c_int32, _P, c_int32, _F, _F, _F, c_int, _P, c_int32, _F, _P, c_int32, _P]),
+    "sf_gate_bwd_sums": (c_int, [c_int32, c_int64, c_int32, _P, c_int32, _F, _F, _P, c_int32, _F, c_int, _P, c_int32, _F, _F, _P]),
+    "sf_bn_bwd_apply_sample": (c_int, [c_int64, c_int32, _P, c_int32, _P, c_int32, _F, _F, c_int64, _P, c_int32, _P]),
     "sf_gate_act_bwd_bn_rows": (c_int, [c_int32, c_int64, c_int32]),
     "sf_gate_act_bwd_bn": (c_int, [c_int32, c_int64, c_int32, _P, c_int32, _F, _F, _F, c_int, _P, c_int32, _F, _P, c_int32, _F, _P]),
 }

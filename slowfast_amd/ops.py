@@ -379,13 +379,14 @@ def bn_act(y, scale=None, shift=None, relu=False, resid=None, rscale=None, rshif
 
 
 def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None, inv_loss_scale=1.0,
-           accumulate=False, want_g=False, out=None, sync=None, part=None):
+           accumulate=False, want_g=False, out=None, sync=None, part=None, sample_add=None):
     """BatchNorm3d (training) backward through an optional ReLU.
 
     dz: gradient w.r.t. act(bn(y)); the ReLU mask is ``zmask > 0`` (block output) or recomputed from
     ``relu_affine = (scale, shift)``; writes fp32 dgamma/dbeta and returns dy (and the masked g).
     ``part``: the [rows, 2, C] partial sums the producer of dz already took in its epilogue (conv_dgrad(..., bn=...)):
-    the reduction pass over dz and y is skipped."""
+    the reduction pass over dz and y is skipped.  ``sample_add`` [N, C] fp32: dz lacks this per-sample constant (``part`` must hold
+    the sums of the complete gradient); the apply pass adds it back (sf_bn_bwd_apply_sample)."""
     lib = get_lib()
     N, C, T, H, W = y.shape
     M = rows(y)
@@ -429,6 +430,12 @@ def bn_bwd(dz, y, gamma, mean, rstd, dgamma, dbeta, zmask=None, relu_affine=None
                  mean.data_ptr(), rstd.data_ptr(), float(inv_loss_scale), scratch[0].data_ptr(), scratch[1].data_ptr(), 0,
                  coef.data_ptr(), s)
     dy = cl_empty(y.shape, y.device) if out is None else out
+    if sample_add is not None:
+        assert fused_part is not None and zmask is None and relu_affine is None and not want_g
+        assert sample_add.dtype == torch.float32 and sample_add.is_contiguous() and tuple(sample_add.shape) == (N, C)
+        lib.call("sf_bn_bwd_apply_sample", M, C, dz.data_ptr(), lddz, y.data_ptr(), ldy, coef.data_ptr(), sample_add.data_ptr(),
+                 M // N, dy.data_ptr(), cl_ld(dy), s, work=dict(bytes=2.0 * y.numel() * 3))
+        return dy
     g = cl_empty(y.shape, y.device) if want_g else None
     lib.call("sf_bn_bwd_apply", M, C, dz.data_ptr(), lddz, _ptr(zmask), ldm, y.data_ptr(), ldy, _ptr(sc), _ptr(sh),
              relu_self, coef.data_ptr(), dy.data_ptr(), cl_ld(dy), _ptr(g), cl_ld(g) if g is not None else 0, s,

@@ -30,6 +30,8 @@ GATE_BN_FUSE = os.environ.get("SF_GATE_BN_FUSE", "1") != "0"
 # SF_SE_FROM_STATS=0: the SE squeeze as a pass of its own over the activation (sf_sample_mean) instead of from the depthwise
 # convolution's statistics table (A/B runs; profiles/r6_v24_se_from_stats_ab.txt)
 SE_FROM_STATS = os.environ.get("SF_SE_FROM_STATS", "1") != "0"
+# SF_GATE_ONE_PASS=0: SE blocks run sf_gate_grad + sf_gate_act_bwd (two passes over y and dz) instead of sf_gate_bwd_sums (A/B runs)
+GATE_ONE_PASS = os.environ.get("SF_GATE_ONE_PASS", "1") != "0"
 
 
 def _pad8(c):
@@ -105,6 +107,22 @@ def gate_act_bwd(y, scale, shift, gate, swish, dz, dmean, bn_part=False):
     return du
 
 
+def gate_bwd_sums(y, scale, shift, gate, swish, dz):
+    """ONE pass over y and dz (round 6): returns du0 = dz * act'(gate * u) * gate (the gate / Swish backward without the SE squeeze
+    term) and sums [N, 3, C] = per-sample sums of dz * act'(gate * u) * u (the gate's gradient), du0, du0 * y."""
+    N, C = y.shape[:2]
+    S = ops.rows(y) // N
+    lib = get_lib()
+    chunks = lib.call("sf_sample_chunks", S, C)
+    part = torch.empty((N * chunks, 4, C), dtype=torch.float32, device=y.device)
+    sums = torch.empty((N, 3, C), dtype=torch.float32, device=y.device)
+    du0 = ops.cl_empty(y.shape, y.device)
+    lib.call("sf_gate_bwd_sums", N, S, C, y.data_ptr(), ops.cl_ld(y), scale.data_ptr(), shift.data_ptr(), dz.data_ptr(),
+             ops.cl_ld(dz), ops._ptr(gate), int(bool(swish)), du0.data_ptr(), ops.cl_ld(du0), part.data_ptr(), sums.data_ptr(),
+             ops._stream(y), work=dict(bytes=6.0 * y.numel()))
+    return du0, sums
+
+
 class BNUnit:
     """Stand-alone nn.BatchNorm3d container fed by per-block partial sums (dwconv epilogue)."""
 
@@ -115,14 +133,14 @@ class BNUnit:
     def finalize(self, part, count, C, training):
         return bn_statistics(self.bn, part, count, C, training)
 
-    def backward(self, dz, y, st, relu_self=False, part=None):
+    def backward(self, dz, y, st, relu_self=False, part=None, sample_add=None):
         bn = self.bn
         dgamma, zg = _grad_dest(bn.weight)
         dbeta, zb = _grad_dest(bn.bias)
         assert zg == zb
         return ops.bn_bwd(dz, y, bn.weight, st.mean, st.rstd, dgamma, dbeta,
                           relu_affine=(st.scale, st.shift) if relu_self else None, accumulate=not zg, sync=_sync_of(bn),
-                          part=part)
+                          part=part, sample_add=sample_add)
 
 
 class DwUnit:
@@ -235,7 +253,8 @@ class X3DBlockFn(torch.autograd.Function):
             engine.CAPTURE.append({"kind": "x3d_block", "mod": mod, "raw": [ya], "bn": [(sa.scale, sa.shift)], "out": out,
                                    "se_h": None if se is None else se[1]})
         ctx.mod = mod
-        ctx.sv = dict(ya=ya, sa=sa, za=za, yb=yb, sb=sb, gate=gate, se=se, zb=zb, yc=yc, sc=sc, y1=y1, s1=s1, bits=bits)
+        ctx.sv = dict(ya=ya, sa=sa, za=za, yb=yb, sb=sb, gate=gate, se=se, zb=zb, yc=yc, sc=sc, y1=y1, s1=s1, bits=bits,
+                      ysum=ysum)
         ctx.save_for_backward(x)
         if engine.BN_FUSE_REDUCE and tr:
             out._sf_block_bn = {"bits": bits, "y0": yc, "sync": _sync_of(C.bn) is not None}
@@ -258,14 +277,26 @@ class X3DBlockFn(torch.autograd.Function):
         dzb = C.backward(sv["zb"], None, dyc, need_dx=True)
         yb, sb, gate = sv["yb"], sv["sb"], sv["gate"]
         dmean = None
-        if t._se is not None:
-            dgate = gate_grad(yb, sb.scale, sb.shift, dzb, gate, t._swish_inner)
-            dmean = t._se.gate_bwd(sv["se"][0], sv["se"][1], gate, dgate)
-        if engine.BN_FUSE_REDUCE and GATE_BN_FUSE:      # the reduction of b_bn's backward rides on the gate / Swish backward pass
-            du, part_b = gate_act_bwd(yb, sb.scale, sb.shift, gate, t._swish_inner, dzb, dmean, bn_part=True)
+        if t._se is not None and sv["ysum"] is not None and engine.BN_FUSE_REDUCE and GATE_ONE_PASS:
+            # SE block, ONE pass over (yb, dzb) instead of three (sf_gate_grad, sf_gate_act_bwd, sf_bn_bwd_reduce): the squeeze
+            # term dmean[n][c] / S of du is a per-sample constant, so it is never stored -- the pass leaves du0 and the
+            # per-sample sums; b_bn's reduction follows from them and from the per-sample sums of yb the forward kept
+            # (sum du = sum_n (sum du0_n + dmean_n), sum du * y = sum_n (sum (du0 y)_n + dmean_n / S * sum y_n)), and the apply
+            # pass adds the constant back: dyb = k1 * (du0 + dmean_n / S) + k2 + k3 * yb.
+            du, sums = gate_bwd_sums(yb, sb.scale, sb.shift, gate, t._swish_inner, dzb)
+            dmean = t._se.gate_bwd(sv["se"][0], sv["se"][1], gate, sums[:, 0].contiguous())
+            add = dmean * (float(yb.shape[0]) / float(ops.rows(yb)))                    # dmean / S, [N, C]
+            part_b = torch.stack(((sums[:, 1] + dmean).sum(0), (sums[:, 2] + add * sv["ysum"]).sum(0))).unsqueeze(0).contiguous()
+            dyb = t._b_bn.backward(du, yb, sb, part=part_b, sample_add=add.contiguous())
         else:
-            du, part_b = gate_act_bwd(yb, sb.scale, sb.shift, gate, t._swish_inner, dzb, dmean), None
-        dyb = t._b_bn.backward(du, yb, sb, part=part_b)
+            if t._se is not None:
+                dgate = gate_grad(yb, sb.scale, sb.shift, dzb, gate, t._swish_inner)
+                dmean = t._se.gate_bwd(sv["se"][0], sv["se"][1], gate, dgate)
+            if engine.BN_FUSE_REDUCE and GATE_BN_FUSE:  # the reduction of b_bn's backward rides on the gate / Swish backward pass
+                du, part_b = gate_act_bwd(yb, sb.scale, sb.shift, gate, t._swish_inner, dzb, dmean, bn_part=True)
+            else:
+                du, part_b = gate_act_bwd(yb, sb.scale, sb.shift, gate, t._swish_inner, dzb, dmean), None
+            dyb = t._b_bn.backward(du, yb, sb, part=part_b)
         dza = t._b.backward(sv["za"], dyb, need_dx=True)
         dya = A.bn_backward(dza, sv["ya"], sv["sa"], relu_self=True)
         prev = ctx.prev_bn if need_dx else None

@@ -46,6 +46,24 @@ def test_x3d_se_squeeze_from_statistics_table(sim, monkeypatch):
     assert calls == [False]
 
 
+def test_x3d_se_backward_in_one_pass(sim, monkeypatch):
+    """SE blocks: sf_gate_bwd_sums (one pass over y and dz: du0 + per-sample sums) + sf_bn_bwd_apply_sample (the squeeze term added
+    back as a per-sample constant) against the oracle, and the three-pass form (sf_gate_grad, sf_gate_act_bwd[_bn]) behind
+    x3d.GATE_ONE_PASS = False; which entry points run is checked through the call observer."""
+    from slowfast_amd import lib, x3d
+    seen = []
+    lib.set_call_observer(lambda name, thunk, work: (seen.append(name), thunk())[1])
+    try:
+        bc.check_x3d_block(sim, 24, 48, 2, 108, (4, 24, 4, 16, 16))
+        assert "sf_gate_bwd_sums" in seen and "sf_bn_bwd_apply_sample" in seen and "sf_gate_grad" not in seen
+        del seen[:]
+        monkeypatch.setattr(x3d, "GATE_ONE_PASS", False)
+        bc.check_x3d_block(sim, 24, 48, 2, 108, (4, 24, 4, 16, 16))
+        assert "sf_gate_grad" in seen and "sf_gate_act_bwd_bn" in seen and "sf_gate_bwd_sums" not in seen
+    finally:
+        lib.set_call_observer(None)
+
+
 def test_x3d_block_masks_handed(sim):
     bc.check_x3d_block(sim, 24, 48, 2, 108, (4, 24, 4, 16, 16))              # projection shortcut, stride 2, SE block
     bc.check_x3d_block(sim, 48, 48, 1, 108, (4, 48, 4, 8, 8), block_idx=1)   # identity shortcut, no SE
