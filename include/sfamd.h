@@ -284,6 +284,18 @@ int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float* w, void* d
 int64_t sf_dwconv_wgrad_workspace(const sf_dw_desc* d);
 int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* dy, float* dw, float out_scale, int zero_first,
                     void* workspace, int64_t workspace_bytes, sf_stream_t stream);
+/* PAIR forms (ABI 23): two depthwise convolutions of the SAME geometry d on two tensors (x, x2) with separate weights in one launch
+ * per direction -- MViT pool_k / pool_v of a block (attention.py:227-266).  sf_dwconv_pair_ok(d) == 1 when the geometry is taken
+ * (3x3x3 / padding 1 plane sweeps in all three directions, C % 32 == 0); results equal two single calls bit for bit.
+ * sf_dwconv_wgrad_pair needs 2 x sf_dwconv_wgrad_workspace(d) bytes. */
+int sf_dwconv_pair_ok(const sf_dw_desc* d);
+int sf_dwconv_fwd_pair(const sf_dw_desc* d, const void* x, const void* x2, const float* w, const float* w2, void* y, void* y2,
+                       sf_stream_t stream);
+int sf_dwconv_dgrad_pair(const sf_dw_desc* d, const void* dy, const void* dy2, const float* w, const float* w2, void* dx, void* dx2,
+                         sf_stream_t stream);
+int sf_dwconv_wgrad_pair(const sf_dw_desc* d, const void* x, const void* x2, const void* dy, const void* dy2, float* dw, float* dw2,
+                         float out_scale, int zero_first, int zero_first2, void* workspace, int64_t workspace_bytes,
+                         sf_stream_t stream);
 
 /* Pooled attention (attention.py:354-385).  Tokens are [B][N][heads*D]; scores [B][heads][Nq][lds]. */
 typedef struct sf_attn_desc {

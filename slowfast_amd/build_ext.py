@@ -71,6 +71,8 @@ def build_hip(force=False, verbose=False, act="fp16", diag=False):
     """act = "fp16" -> libsfamd.so, "bf16" -> libsfamd_bf16.so (the 16-bit storage type, lib.ACT_MODE).  ``diag``: the fp16
     library compiled with -DSF_DIAG (libsfamd_diag.so; point SFAMD_LIBRARY at it): A/B knobs and the kernels' ablation
     switches are live there, compile-time constants everywhere else (csrc/sf_api.hip: tune_knob)."""
+    if diag and act != "fp16":
+        raise ValueError("build_hip: the diagnostic build exists for float16 storage only (diag=True with act=%r)" % (act,))
     out = LIB_DIAG if diag else (LIB if act == "fp16" else LIB_BF16)
     if not force and not _stale(out):
         return out

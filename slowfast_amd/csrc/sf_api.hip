@@ -2025,6 +2025,96 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
     }
     return check_launch("dwconv_dgrad");
 }
+// ------------------------------------------------------------------------------------------------
+// PAIR entry points (round 6): two depthwise convolutions of ONE geometry on two tensors in ONE launch per direction -- MViT's
+// pool_k and pool_v of a block (attention.py:227-266: same kernel / stride / padding, adjacent channel slices of qkv, separate
+// weights).  At the stage-3 / 4 planes (14 -> 7, 7 x 7) a launch is 25-35 us of start-up and ramp around 8 planes of work; both
+// tensors behind one start-up cost 1.45x one (tools/dw_bench.py: C = 768 against C = 384 at the same plane).  The descriptor
+// describes ONE tensor; the plane sweeps (sf_dwsweep.h, PAIR mode) must take the geometry in all three directions and C must be a
+// multiple of 32: sf_dwconv_pair_ok.  Same arithmetic as two single calls, bit for bit.
+static bool dw_sweep_plan_any(const sf_dw_desc* d, int dir, DwSweepParams& sp, int& km, int& ks, int& sl, bool& rot) {
+    sl = 0;
+    rot = dwrot_plan(d, dir, sp, km, ks, sl);
+    return rot || dwsweep_plan(d, dir, sp, km, ks);
+}
+static void dw_pair_setup(DwSweepParams& sp, const sf_dw_desc* d) {
+    sp.csplit = d->C; sp.Cpart = 2 * d->C; sp.nchunks *= 2;
+}
+extern "C" int sf_dwconv_pair_ok(const sf_dw_desc* d) {
+    DwParams p;
+    dim3 grid;
+    if (fill_dw(p, d, true, kDwFwdBlocks, grid)) return -1;
+    const char* lv = getenv("SF_DW_PAIR");
+    if (lv && atoi(lv) == 0) return 0;
+    if (d->C % 32 != 0) return 0;
+    DwTempParams tp;
+    if (dwtemp_plan(d, 0, tp)) return 0;
+    DwSweepParams sp;
+    int km, ks, sl;
+    bool rot;
+    for (int dir = 0; dir < 3; ++dir)
+        if (!dw_sweep_plan_any(d, dir, sp, km, ks, sl, rot)) return 0;
+    return 1;
+}
+extern "C" int sf_dwconv_fwd_pair(const sf_dw_desc* d, const void* x, const void* x2, const float* w, const float* w2, void* y,
+                                  void* y2, sf_stream_t stream) {
+    REQUIRE(sf_dwconv_pair_ok(d) == 1, "sf_dwconv_fwd_pair: geometry not taken (sf_dwconv_pair_ok)");
+    REQUIRE(x && x2 && w && w2 && y && y2, "sf_dwconv_fwd_pair: null pointer");
+    DwSweepParams sp;
+    int km, ks, sl;
+    bool rot;
+    dw_sweep_plan_any(d, 0, sp, km, ks, sl, rot);
+    dw_pair_setup(sp, d);
+    sp.a = (const f16*)x; sp.a2 = (const f16*)x2; sp.lda = d->ldx; sp.dst = (f16*)y; sp.dst2 = (f16*)y2; sp.ldd = d->ldy;
+    sp.w = w; sp.w2 = w2;
+    if (rot) dwrot_launch(sp, km, ks, sl, false, (hipStream_t)stream);
+    else dwsweep_launch(sp, km, ks, false, (hipStream_t)stream);
+    return check_launch("dwconv_fwd_pair");
+}
+extern "C" int sf_dwconv_dgrad_pair(const sf_dw_desc* d, const void* dy, const void* dy2, const float* w, const float* w2,
+                                    void* dx, void* dx2, sf_stream_t stream) {
+    REQUIRE(sf_dwconv_pair_ok(d) == 1, "sf_dwconv_dgrad_pair: geometry not taken (sf_dwconv_pair_ok)");
+    REQUIRE(dy && dy2 && w && w2 && dx && dx2, "sf_dwconv_dgrad_pair: null pointer");
+    DwSweepParams sp;
+    int km, ks, sl;
+    bool rot;
+    dw_sweep_plan_any(d, 1, sp, km, ks, sl, rot);
+    dw_pair_setup(sp, d);
+    sp.a = (const f16*)dy; sp.a2 = (const f16*)dy2; sp.lda = d->ldy; sp.dst = (f16*)dx; sp.dst2 = (f16*)dx2; sp.ldd = d->ldx;
+    sp.w = w; sp.w2 = w2;
+    if (rot) dwrot_launch(sp, km, ks, sl, false, (hipStream_t)stream);
+    else dwsweep_launch(sp, km, ks, false, (hipStream_t)stream);
+    return check_launch("dwconv_dgrad_pair");
+}
+// workspace: 2 x sf_dwconv_wgrad_workspace(d) bytes
+extern "C" int sf_dwconv_wgrad_pair(const sf_dw_desc* d, const void* x, const void* x2, const void* dy, const void* dy2,
+                                    float* dw, float* dw2, float out_scale, int zero_first, int zero_first2, void* workspace,
+                                    int64_t workspace_bytes, sf_stream_t stream) {
+    REQUIRE(sf_dwconv_pair_ok(d) == 1, "sf_dwconv_wgrad_pair: geometry not taken (sf_dwconv_pair_ok)");
+    REQUIRE(x && x2 && dy && dy2 && dw && dw2 && workspace, "sf_dwconv_wgrad_pair: null pointer");
+    DwSweepParams sp;
+    int km, ks, sl;
+    bool rot;
+    dw_sweep_plan_any(d, 2, sp, km, ks, sl, rot);
+    dw_pair_setup(sp, d);
+    const int taps = 27, nblk = sp.N * sp.tiles_h * sp.tiles_w;
+    REQUIRE(workspace_bytes >= (int64_t)nblk * taps * 2 * d->C * 4, "sf_dwconv_wgrad_pair: workspace too small");
+    sp.a = (const f16*)x; sp.a2 = (const f16*)x2; sp.lda = d->ldx; sp.b = (const f16*)dy; sp.b2 = (const f16*)dy2; sp.ldb = d->ldy;
+    sp.part = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    if (rot) dwrot_launch(sp, km, ks, sl, false, s);
+    else dwsweep_launch(sp, km, ks, false, s);
+    if (check_launch("dwconv_wgrad_pair")) return -1;
+    for (int h = 0; h < 2; ++h) {
+        DwFinalizeParams f;
+        f.wpart = (const float*)workspace + (h ? d->C : 0); f.nblk = nblk; f.taps = taps; f.C = d->C; f.Cw = d->Cw; f.ldc = 2 * d->C;
+        f.Cwreal = d->Cwreal ? d->Cwreal : d->Cw;
+        f.dw = h ? dw2 : dw; f.scale = out_scale; f.accumulate = (h ? zero_first2 : zero_first) ? 0 : 1;
+        hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, 32)), dim3(SF_THREADS), 0, s, f);
+    }
+    return check_launch("dwconv_wgrad_pair_finalize");
+}
+
 // LDS-tiled weight gradient (sf_dwtile.h: sf_dwtile_wgrad_kernel).  SF_DW_WGRAD_TILED=0 keeps the stencils (A/B runs).
 static bool dwtile_wgrad_shape_ok(const sf_dw_desc* d) {
     if (d->kT != 3 || d->kH != 3 || d->kW != 3 || d->pT != 1 || d->pH != 1 || d->pW != 1) return false;
@@ -2122,7 +2212,7 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
             dwtemp_launch(tp, d->kT, 2, false, s);
             if (check_launch("dwconv_wgrad (temporal)")) return -1;
             DwFinalizeParams f;
-            f.wpart = (const float*)workspace; f.nblk = nblk; f.taps = taps; f.C = d->C; f.Cw = d->Cw;
+            f.wpart = (const float*)workspace; f.nblk = nblk; f.taps = taps; f.C = d->C; f.Cw = d->Cw; f.ldc = 0;
             f.Cwreal = d->Cwreal ? d->Cwreal : d->Cw;
             f.dw = dw; f.scale = out_scale; f.accumulate = zero_first ? 0 : 1;
             hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, 32)), dim3(SF_THREADS), 0, s, f);
@@ -2142,7 +2232,7 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
             else dwsweep_launch(sp, km, ks, false, s);
             if (check_launch("dwconv_wgrad (sweep)")) return -1;
             DwFinalizeParams f;
-            f.wpart = (const float*)workspace; f.nblk = nblk; f.taps = taps; f.C = d->C; f.Cw = d->Cw;
+            f.wpart = (const float*)workspace; f.nblk = nblk; f.taps = taps; f.C = d->C; f.Cw = d->Cw; f.ldc = 0;
             f.Cwreal = d->Cwreal ? d->Cwreal : d->Cw;
             f.dw = dw; f.scale = out_scale; f.accumulate = zero_first ? 0 : 1;
             hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, 32)), dim3(SF_THREADS), 0, s, f);
@@ -2174,7 +2264,7 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
 #undef SF_DWW_LAUNCH
             if (check_launch("dwconv_wgrad (tiled)")) return -1;
             DwFinalizeParams f;
-            f.wpart = (const float*)workspace; f.nblk = nblk; f.taps = taps; f.C = d->C; f.Cw = d->Cw;
+            f.wpart = (const float*)workspace; f.nblk = nblk; f.taps = taps; f.C = d->C; f.Cw = d->Cw; f.ldc = 0;
             f.Cwreal = d->Cwreal ? d->Cwreal : d->Cw;
             f.dw = dw; f.scale = out_scale; f.accumulate = zero_first ? 0 : 1;
             hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, 32)), dim3(SF_THREADS), 0, s, f);
@@ -2194,7 +2284,7 @@ extern "C" int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* d
     else hipLaunchKernelGGL(sf_dwconv_wgrad_kernel, grid, dim3(SF_THREADS), 0, (hipStream_t)stream, p);
     if (check_launch("dwconv_wgrad")) return -1;
     DwFinalizeParams f;
-    f.wpart = (const float*)workspace; f.nblk = grid.x; f.taps = taps; f.C = d->C; f.Cw = d->Cw;
+    f.wpart = (const float*)workspace; f.nblk = grid.x; f.taps = taps; f.C = d->C; f.Cw = d->Cw; f.ldc = 0;
     f.Cwreal = d->Cwreal ? d->Cwreal : d->Cw;
     f.dw = dw; f.scale = out_scale; f.accumulate = zero_first ? 0 : 1;
     hipLaunchKernelGGL(sf_dwconv_wgrad_finalize_kernel, dim3(cdiv(taps * d->Cw, 32)), dim3(SF_THREADS), 0,

@@ -614,6 +614,7 @@ __global__ __launch_bounds__(SF_THREADS, 3) void sf_dwconv_wgrad_blocked_kernel(
 struct DwFinalizeParams {
     const float* wpart; int nblk, taps, C, Cw, Cwreal;
     float* dw; float scale; int accumulate;
+    int ldc;            // row width of the table's tap rows (0: C); > C when the table holds two tensors' partials side by side
 };
 __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_finalize_kernel(DwFinalizeParams p) {
     // 32 outputs (tap, cw) per block x 8 segments of the (block, channel-copy) sum; fixed-order LDS fold
@@ -625,8 +626,9 @@ __global__ __launch_bounds__(SF_THREADS) void sf_dwconv_wgrad_finalize_kernel(Dw
     double s = 0.0;
     if (ok && cw < p.Cwreal) {
         const int copies = p.C / p.Cw;
-        const int64_t bs = (int64_t)p.taps * p.C;
-        const float* src = p.wpart + (int64_t)tap * p.C + cw;
+        const int ldc = p.ldc > 0 ? p.ldc : p.C;
+        const int64_t bs = (int64_t)p.taps * ldc;
+        const float* src = p.wpart + (int64_t)tap * ldc + cw;
         // four independent partial sums (loads of four table rows in flight), folded in a fixed order
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int b = seg;

@@ -51,6 +51,11 @@ struct DwSweepParams {
     int ngrp, nseg, SL;                 // 8-row groups of the tile, column segments per group, columns per segment
     int nr;                             // sf_dwrot_kernel: ring slots of the staged operand (dy: nr - 1)
     int gs;                             // sf_dwrot_kernel<., 3, ...>: the convolution's stride (>= 3, windows do not overlap)
+    // PAIR mode (csplit > 0; round 6): ONE launch for two convolutions of the same geometry on two tensors of csplit channels each
+    // (MViT pool_k / pool_v of a block: attention.py:227-266) -- channel chunks >= csplit take the second operand set, with
+    // channel offsets counted from csplit; the partial tables are [rows][.][2 * csplit] (Cpart), first tensor first
+    const f16* a2; const f16* b2; f16* dst2; const float* w2;
+    int csplit, Cpart;
     FastDiv fdRP, fdRPB, fdSeg;
 };
 
@@ -126,7 +131,12 @@ __global__ __launch_bounds__(SF_THREADS, 2) void sf_dwsweep_kernel(DwSweepParams
     bid /= (uint32_t)p.tiles_w;
     const int th = (int)(bid % (uint32_t)p.tiles_h);
     const int n = (int)(bid / (uint32_t)p.tiles_h);
-    const int c0 = chunk * 32;
+    int c0 = chunk * 32;                                        // channel offset inside the operand tensors ...
+    const int cpart = c0, cpw = p.csplit > 0 ? p.Cpart : p.C;   // ... and inside the partial tables (row width cpw)
+    if (p.csplit > 0 && c0 >= p.csplit) {                       // PAIR mode, second tensor (workgroup-uniform)
+        c0 -= p.csplit;
+        p.a = p.a2; p.b = p.b2; p.dst = p.dst2; p.w = p.w2;
+    }
     const int cq = (p.C - c0) >= 32 ? 8 : (p.C - c0) >> 2;      // channel quads of this chunk
     const bool qok = q < cq;
     const int r0 = th * p.TH, q0 = tw * p.TW;                   // tile origin in the iterated space
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void sf_dwsweep_kernel(DwSweepParams
                 acc += st ? v * v : v;
             }
             const int64_t prow = ((int64_t)n * p.tiles_h + th) * p.tiles_w + tw;
-            if ((ch >> 2) < cq) p.part[(prow * 2 + st) * p.C + c0 + ch] = acc;
+            if ((ch >> 2) < cq) p.part[(prow * 2 + st) * cpw + cpart + ch] = acc;
         }
     }
     if constexpr (MODE == 2) {
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void sf_dwsweep_kernel(DwSweepParams
                 float acc = 0.f;
                 for (int wv = 0; wv < 4; ++wv)
                     for (int r = 0; r < 8; ++r) acc += red[(wv * 64 + r * 8 + (ch >> 2)) * 36 + i * 4 + (ch & 3)];
-                if ((ch >> 2) < cq) p.part[(prow * 27 + kt * 9 + i) * p.C + c0 + ch] = acc;
+                if ((ch >> 2) < cq) p.part[(prow * 27 + kt * 9 + i) * cpw + cpart + ch] = acc;
             }
         }
     }
@@ -557,7 +567,12 @@ __global__ __launch_bounds__(SF_THREADS, MODE == 2 || S == 2 || SL > 4 ? 3 : 4) 
     bid /= (uint32_t)p.tiles_w;
     const int th = (int)(bid % (uint32_t)p.tiles_h);
     const int n = (int)(bid / (uint32_t)p.tiles_h);
-    const int c0 = chunk * 32;
+    int c0 = chunk * 32;                                        // channel offset inside the operand tensors ...
+    const int cpart = c0, cpw = p.csplit > 0 ? p.Cpart : p.C;   // ... and inside the partial tables (row width cpw)
+    if (p.csplit > 0 && c0 >= p.csplit) {                       // PAIR mode, second tensor (workgroup-uniform)
+        c0 -= p.csplit;
+        p.a = p.a2; p.b = p.b2; p.dst = p.dst2; p.w = p.w2;
+    }
     const int cq = (p.C - c0) >= 32 ? 8 : (p.C - c0) >> 2;      // channel quads of this chunk (pairs: 2 * cq)
     const bool pok = pr < 2 * cq;
     const int r0 = th * p.TH, q0 = tw * p.TW;
@@ -840,7 +855,7 @@ __global__ __launch_bounds__(SF_THREADS, MODE == 2 || S == 2 || SL > 4 ? 3 : 4) 
                 acc += st ? v * v : v;
             }
             const int64_t prow = ((int64_t)n * p.tiles_h + th) * p.tiles_w + tw;
-            if ((ch >> 2) < cq) p.part[(prow * 2 + st) * p.C + c0 + ch] = acc;
+            if ((ch >> 2) < cq) p.part[(prow * 2 + st) * cpw + cpart + ch] = acc;
         }
     }
     if constexpr (MODE == 2) {
@@ -860,7 +875,7 @@ __global__ __launch_bounds__(SF_THREADS, MODE == 2 || S == 2 || SL > 4 ? 3 : 4) 
                 float acc = 0.f;
                 for (int wv = 0; wv < 4; ++wv)
                     for (int rr = 0; rr < 4; ++rr) acc += red[(wv * 64 + rr * 16 + (ch >> 1)) * 18 + i * 2 + (ch & 1)];
-                if ((ch >> 2) < cq) p.part[(prow * 27 + kt * 9 + i) * p.C + c0 + ch] = acc;
+                if ((ch >> 2) < cq) p.part[(prow * 27 + kt * 9 + i) * cpw + cpart + ch] = acc;
             }
         }
     }

@@ -52,9 +52,11 @@ class GradReducer:
         self._prescale, self._prescaled = 1.0 / self.world, set()   # compressed buckets are averaged before the cast
         def listener(params):
             self._on_ready(params)
-        # weight gradients may still be running on the engine's side stream when a block announces its parameters: only a
-        # reducer that is about to launch a collective on them needs them joined (not world size 1, not while capturing)
-        listener.needs_join = lambda: self.collectives and not self.capturing
+        # weight gradients / the other pathway's gradients may still be running on a side stream when a block announces its
+        # parameters.  The join (engine.join_side_streams) is made where a collective is actually launched (_launch: a bucket
+        # is complete), not on every announcement -- joining per block serialised the Slow and Fast pathways' backward in the
+        # eager multi-GPU path
+        listener.needs_join = lambda: False
         self._listener = engine.add_grad_ready_listener(listener)
         # parameters owned by plain torch modules (the head) announce themselves through autograd hooks
         self._hooked = set()
@@ -102,6 +104,7 @@ class GradReducer:
     def _launch(self, bi):
         if not self.collectives or self.capturing:
             return
+        engine.join_side_streams()              # every stream that wrote a gradient of this bucket, before RCCL reads it
         s, e, _ = self.buckets[bi]
         view = self.flat[s:e]
         if self.comm_dtype is not None:

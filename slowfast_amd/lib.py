@@ -138,6 +138,10 @@ _SIGNATURES = {
     "sf_gelu_bwd": (c_int, [c_int64, _P, _P, _P, _P]),
     "sf_dwconv_fwd_blocks": (c_int, [POINTER(DwDesc)]),
     "sf_dwconv_fwd_sample_rows": (c_int, [POINTER(DwDesc)]),
+    "sf_dwconv_pair_ok": (c_int, [POINTER(DwDesc)]),
+    "sf_dwconv_fwd_pair": (c_int, [POINTER(DwDesc), _P, _P, _F, _F, _P, _P, _P]),
+    "sf_dwconv_dgrad_pair": (c_int, [POINTER(DwDesc), _P, _P, _F, _F, _P, _P, _P]),
+    "sf_dwconv_wgrad_pair": (c_int, [POINTER(DwDesc), _P, _P, _P, _P, _F, _F, c_float, c_int, c_int, _P, c_int64, _P]),
     "sf_dwconv_fwd": (c_int, [POINTER(DwDesc), _P, _F, _P, _F, _P]),
     "sf_dwconv_dgrad": (c_int, [POINTER(DwDesc), _P, _F, _P, _P]),
     "sf_dwconv_wgrad_workspace": (c_int64, [POINTER(DwDesc)]),

@@ -22,6 +22,17 @@ from . import engine as _engine
 from .engine import _grad_dest, _notify, param_grads
 
 _f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.ACT_MODE)
+
+# pool_k and pool_v of a block in ONE launch per direction (tokens.dwconv_*_pair).  Measured in the step
+# (profiles/r6_v27_pair_kv_ab.txt): +1.2 % on MViT-B-16x4, whose blocks mostly pool k / v only -- the two chains then run back to
+# back on one stream -- and -0.5 % on MViTv2-S, where every block also pools q: the k / v chains already hide behind the longer q
+# chain on a second stream (engine.run_branches) and one 768-workgroup launch disturbs it more than two of 384.  So: "auto" =
+# paired only in blocks without a q pooling branch; SF_PAIR_KV=1 always, 0 never (A/B runs).
+PAIR_KV = os.environ.get("SF_PAIR_KV", "auto")
+
+
+def _pair_kv(plan):
+    return PAIR_KV == "1" or (PAIR_KV not in ("0", "1") and plan.gq is None)
 # fc1's bias gradient from the epilogue of the GEMM that produces d(loss)/d(fc1 output) (tokens.gemm_gelu_grad(dbias=...))
 # instead of a separate column-sum pass over it; SF_FUSE_COLSUM=0 keeps the pass (A/B)
 FUSE_COLSUM = os.environ.get("SF_FUSE_COLSUM", "1") != "0"
@@ -428,6 +439,12 @@ def attention_forward(att, plan, qkv):
         return _pool_norm(v_in, att.pool_v, att._norm_v, plan.gk, B, Nk, C, D)
 
     def kv_chain():
+        if _pair_kv(plan) and tokens.dwconv_pair_ok(plan.gk, tokens.rows_pitch(k_in)[2], C):
+            # pool_k and pool_v: one geometry, adjacent channel slices of qkv -> ONE launch (tokens.dwconv_fwd_pair)
+            kp_, vp_ = tokens.dwconv_fwd_pair(k_in, v_in, att.pool_k.weight, att.pool_v.weight, plan.gk)
+            kn_, mk, rk = att._norm_k.forward(kp_.view(-1, D))
+            vn_, mv, rv = att._norm_v.forward(vp_.view(-1, D))
+            return (kp_.view(B, Nk, C), kn_.view(B, Nk, C), (mk, rk)), (vp_.view(B, Nk, C), vn_.view(B, Nk, C), (mv, rv))
         return k_chain(), v_chain()
 
     if plan.gq is not None and plan.gk is not None:
@@ -480,6 +497,15 @@ def attention_backward(att, plan, qkv, sv, do):
         pool_back(2, dvp, att.pool_v, plan.gk)
 
     def kv_chain():
+        k_in, v_in = qkv[..., C:2 * C], qkv[..., 2 * C:3 * C]
+        if _pair_kv(plan) and tokens.dwconv_pair_ok(plan.gk, tokens.rows_pitch(k_in)[2], C):
+            dkp = att._norm_k.backward(dkn.view(-1, D), sv["kp"].view(-1, D), *sv["sk"]).view(-1, C)
+            dvp = att._norm_v.backward(dvn.view(-1, D), sv["vp"].view(-1, D), *sv["sv"]).view(-1, C)
+            tokens.dwconv_dgrad_pair(dkp, dvp, att.pool_k.weight, att.pool_v.weight, plan.gk,
+                                     out=dqkv[..., C:2 * C], out2=dqkv[..., 2 * C:3 * C])
+            (dwk, zk), (dwv, zv) = _grad_dest(att.pool_k.weight), _grad_dest(att.pool_v.weight)
+            tokens.dwconv_wgrad_pair(k_in, v_in, dkp, dvp, plan.gk, dwk, dwv, zero_first=zk, zero_first2=zv)
+            return
         k_chain()
         v_chain()
 

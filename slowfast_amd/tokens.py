@@ -194,8 +194,9 @@ _FIN_MAX_ROWS = 2048        # tables up to this many rows are batched (longer on
 
 class deferred_finalizes:
     """Collect the column-sum finalizes issued inside the ``with`` block and launch them in batches at its end.  Assumes ONE
-    thread and ONE stream per block backward (the autograd worker that runs the Function): the pending list is process-global,
-    not thread-safe, and a flush launches on the current stream of its first item.  Any OTHER kernel that writes one of the
+    thread per block backward (the autograd worker that runs the Function): the pending list is process-global, not
+    thread-safe.  A flush launches on the CURRENT stream; items collected on another stream (engine.run_branches) make it wait
+    for that stream first.  Any OTHER kernel that writes one of the
     pending outputs inside the block must call flush_finalizes() first (colsum_finalize does so for its own immediate path)."""
 
     def __enter__(self):
@@ -228,10 +229,16 @@ def flush_finalizes():
 
 def _finalize_batch(items):
     arr = (ColFinItem * len(items))()
-    for i, (part, C, fold, out0, out1, scale, accumulate, stride) in enumerate(items):
+    part0 = items[0][0]
+    cur = torch.cuda.current_stream(part0.device) if part0.is_cuda else None
+    for i, (part, C, fold, out0, out1, scale, accumulate, stride, st) in enumerate(items):
         arr[i] = ColFinItem(part.data_ptr(), part.shape[0], C, fold, _ptr(out0), _ptr(out1), float(scale), int(accumulate),
                             int(stride))
-    _lib_call("sf_colsum_finalize_batch", arr, len(items), _stream(items[0][0]))
+        # an item collected on ANOTHER stream (a branch of engine.run_branches) whose table may still be in production there:
+        # the launching stream waits for it (a no-op once the branch has been joined) -- ADVICE r5
+        if st is not None and cur is not None and st != cur:
+            cur.wait_stream(st)
+    _lib_call("sf_colsum_finalize_batch", arr, len(items), _stream(part0))
 
 
 def colsum_finalize(part, C, fold, out0, out1, scale=1.0, accumulate=False, row_stride=1):
@@ -243,7 +250,8 @@ def colsum_finalize(part, C, fold, out0, out1, scale=1.0, accumulate=False, row_
             if any(o is not None and o.data_ptr() in outs for o in (it[3], it[4])):
                 flush_finalizes()
                 break
-        _pending_fin.append((part, C, fold, out0, out1, scale, accumulate, row_stride))
+        _pending_fin.append((part, C, fold, out0, out1, scale, accumulate, row_stride,
+                             torch.cuda.current_stream(part.device) if part.is_cuda else None))
         return
     if _pending_fin:
         # an immediate finalize (table too long to defer) into an output a deferred one also writes: launch order must stay
@@ -252,7 +260,7 @@ def colsum_finalize(part, C, fold, out0, out1, scale=1.0, accumulate=False, row_
         if any(o is not None and o.data_ptr() in outs for it in _pending_fin for o in (it[3], it[4])):
             flush_finalizes()
     if row_stride != 1:
-        _finalize_batch([(part, C, fold, out0, out1, scale, accumulate, row_stride)])
+        _finalize_batch([(part, C, fold, out0, out1, scale, accumulate, row_stride, None)])
         return
     _lib_call("sf_colsum_finalize", part.data_ptr(), part.shape[0], C, fold, _ptr(out0), _ptr(out1), float(scale),
               int(accumulate), _stream(part))
@@ -382,6 +390,59 @@ def dwconv_wgrad(x, dy, geom, dw, zero_first=True, out_scale=1.0):
              ws.data_ptr(), ws.numel(), _stream(x),
              work=dict(bytes=2.0 * geom.C * (3 * geom.rows_out + geom.rows_in), flops=2.0 * geom.rows_out * geom.C * geom.taps))
     return dw
+
+
+# PAIR forms (round 6): two depthwise convolutions of one geometry on two tensors in ONE launch per direction (MViT pool_k / pool_v of
+# a block).  Same arithmetic as two single calls; dwconv_pair_ok says whether the native library takes the geometry.
+def dwconv_pair_ok(geom, ldx, ldy):
+    key = ("pair_ok", ldx, ldy)
+    cache = geom.__dict__.setdefault("_pair_cache", {})
+    if key not in cache:
+        cache[key] = get_lib().call("sf_dwconv_pair_ok", byref(geom.desc(ldx, ldy))) == 1
+    return cache[key]
+
+
+def _pair_pitches(a, b):
+    Ma, Ca, lda = rows_pitch(a)
+    Mb, Cb, ldb = rows_pitch(b)
+    assert (Ma, Ca, lda) == (Mb, Cb, ldb), "the two tensors of a pair share rows, channels and pitch"
+    return Ma, Ca, lda
+
+
+def dwconv_fwd_pair(x, x2, w, w2, geom):
+    M, C, ldx = _pair_pitches(x, x2)
+    assert M == geom.rows_in and C == geom.C and w.dtype == w2.dtype == torch.float32 and w.is_contiguous() and w2.is_contiguous()
+    y = torch.empty((geom.rows_out, C), dtype=_f16, device=x.device)
+    y2 = torch.empty((geom.rows_out, C), dtype=_f16, device=x.device)
+    get_lib().call("sf_dwconv_fwd_pair", byref(geom.desc(ldx, C)), x.data_ptr(), x2.data_ptr(), w.data_ptr(), w2.data_ptr(),
+                   y.data_ptr(), y2.data_ptr(), _stream(x),
+                   work=dict(bytes=4.0 * C * (geom.rows_in + geom.rows_out), flops=4.0 * geom.rows_out * C * geom.taps))
+    return y, y2
+
+
+def dwconv_dgrad_pair(dy, dy2, w, w2, geom, out, out2):
+    M, C, lddy = _pair_pitches(dy, dy2)
+    Mi, Ci, lddx = _pair_pitches(out, out2)
+    assert M == geom.rows_out and C == geom.C and Mi == geom.rows_in and Ci == C
+    get_lib().call("sf_dwconv_dgrad_pair", byref(geom.desc(lddx, lddy)), dy.data_ptr(), dy2.data_ptr(), w.data_ptr(), w2.data_ptr(),
+                   out.data_ptr(), out2.data_ptr(), _stream(dy),
+                   work=dict(bytes=4.0 * C * (geom.rows_in + geom.rows_out), flops=4.0 * geom.rows_out * C * geom.taps))
+    return out, out2
+
+
+def dwconv_wgrad_pair(x, x2, dy, dy2, geom, dw, dw2, zero_first=True, zero_first2=True, out_scale=1.0):
+    _, C, ldx = _pair_pitches(x, x2)
+    _, _, lddy = _pair_pitches(dy, dy2)
+    for g in (dw, dw2):
+        assert g.dtype == torch.float32 and g.is_contiguous() and g.numel() == geom.Cw_real * geom.taps
+    lib = get_lib()
+    d = geom.desc(ldx, lddy)
+    if geom.ws_bytes is None:
+        geom.ws_bytes = lib.call("sf_dwconv_wgrad_workspace", byref(d))
+    ws = _workspace(x.device, 2 * geom.ws_bytes)
+    lib.call("sf_dwconv_wgrad_pair", byref(d), x.data_ptr(), x2.data_ptr(), dy.data_ptr(), dy2.data_ptr(), dw.data_ptr(),
+             dw2.data_ptr(), float(out_scale), int(zero_first), int(zero_first2), ws.data_ptr(), ws.numel(), _stream(x),
+             work=dict(bytes=4.0 * geom.C * (3 * geom.rows_out + geom.rows_in), flops=4.0 * geom.rows_out * geom.C * geom.taps))
 
 
 # ------------------------------------------------------------------------------------------------

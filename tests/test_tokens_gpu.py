@@ -64,6 +64,15 @@ def test_dwconv_temporal(gpu, monkeypatch):
     tc.check_dwconv(gpu, 2, 1, 24, (8, 12, 12), (5, 1, 1), (1, 1, 1), cls=0)
 
 
+def test_dwconv_pair(gpu):
+    """pool_k / pool_v in ONE launch per direction at the MViTv2-S production planes (stage 3: 14 -> 7 stride 2, C = 384; stage 4:
+    7 x 7 stride 1, C = 768; block 3: 28 -> 14 stride 2): bit-equal to two single launches."""
+    tc.check_dwconv_pair(gpu, 2, 4, 96, (8, 14, 14), (1, 2, 2), cls=1)
+    tc.check_dwconv_pair(gpu, 2, 8, 96, (8, 7, 7), (1, 1, 1), cls=1)
+    tc.check_dwconv_pair(gpu, 2, 4, 96, (4, 28, 28), (1, 2, 2), cls=1)
+    tc.check_dwconv_pair(gpu, 1, 2, 96, (4, 56, 56), (1, 1, 1), cls=1)
+
+
 def test_dwconv_ring_sweep(gpu, monkeypatch):
     """sf_dwsweep.h at the production planes of MViTv2-S (56- / 28- / 14- / 7-wide, every stride, heads sharing the weight, cls
     rows, slices of a wider tensor) and X3D-M (54 -> 56, 108 -> 112, 216, 432 channels: tail chunks; BatchNorm partial sums), plus

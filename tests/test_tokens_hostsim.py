@@ -59,6 +59,17 @@ def test_dwconv_temporal(sim, monkeypatch):
     tc.check_dwconv(sim, 2, 1, 24, (6, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)
 
 
+def test_dwconv_pair(sim, monkeypatch):
+    """pool_k / pool_v in one launch per direction (sf_dwconv_*_pair; PAIR mode of the plane sweeps): strides 1 / 2 (the rotating-
+    accumulator body and the stride-2 data-gradient body), two heads sharing each weight, cls rows, a forced ragged tiling."""
+    tc.check_dwconv_pair(sim, 2, 1, 32, (3, 6, 6), (1, 2, 2), cls=1)
+    tc.check_dwconv_pair(sim, 1, 2, 32, (2, 5, 5), (1, 1, 1), cls=1)
+    tc.check_dwconv_pair(sim, 1, 1, 96, (2, 7, 7), (1, 2, 2), cls=0)
+    monkeypatch.setenv("SF_DWR_SL", "4")
+    monkeypatch.setenv("SF_DWR_NGRP", "1")
+    tc.check_dwconv_pair(sim, 1, 1, 64, (2, 9, 9), (1, 1, 1), cls=1)
+
+
 def _dwconv_tokens(sim):
     tc.check_dwconv(sim, 2, 2, 16, (2, 6, 6), (3, 3, 3), (1, 2, 2), cls=1)
     tc.check_dwconv(sim, 1, 1, 32, (4, 5, 5), (3, 3, 3), (1, 1, 1), cls=1)

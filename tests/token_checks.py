@@ -110,6 +110,40 @@ def check_dwconv(device, B, heads, Cw, thw, kernel, stride, cls, seed=0):
     assert_close("dwconv stats sumsq", tot[1], (yf * yf).sum(0), 2e-3 * EPS_SCALE)
 
 
+def check_dwconv_pair(device, B, heads, Cw, thw, stride, cls, seed=0):
+    """PAIR forms (tokens.dwconv_*_pair: the k and v slices of a [B, N, 3C] tensor in one launch per direction) against two single
+    calls: the same arithmetic, so every result must be EQUAL bit for bit (outputs, the two input-gradient slices, both weight
+    gradients with and without accumulation)."""
+    g = torch.Generator().manual_seed(seed)
+    T, H, W = thw
+    C = heads * Cw
+    N = cls + T * H * W
+    kernel, pad = (3, 3, 3), (1, 1, 1)
+    geom = tokens.DwGeom(B, C, Cw, thw, kernel, stride, pad, cls)
+    big = _h(torch.randn((B, N, 3 * C), generator=g).to(ACT).float(), device)
+    k_in, v_in = big[..., C:2 * C], big[..., 2 * C:3 * C]
+    wk = (torch.randn((Cw, 1) + kernel, generator=g) * 0.3).to(device)
+    wv = (torch.randn((Cw, 1) + kernel, generator=g) * 0.3).to(device)
+    assert tokens.dwconv_pair_ok(geom, 3 * C, C)
+    yk, yv = tokens.dwconv_fwd_pair(k_in, v_in, wk, wv, geom)
+    assert torch.equal(yk, tokens.dwconv_fwd(k_in, wk, geom)) and torch.equal(yv, tokens.dwconv_fwd(v_in, wv, geom))
+    dk = _h(torch.randn((geom.rows_out, C), generator=g).to(ACT).float(), device)
+    dv = _h(torch.randn((geom.rows_out, C), generator=g).to(ACT).float(), device)
+    d1 = torch.zeros((B, N, 3 * C), dtype=ACT, device=device)
+    d2 = torch.zeros((B, N, 3 * C), dtype=ACT, device=device)
+    tokens.dwconv_dgrad_pair(dk, dv, wk, wv, geom, out=d1[..., C:2 * C], out2=d1[..., 2 * C:3 * C])
+    tokens.dwconv_dgrad(dk, wk, geom, out=d2[..., C:2 * C])
+    tokens.dwconv_dgrad(dv, wv, geom, out=d2[..., 2 * C:3 * C])
+    assert torch.equal(d1, d2)
+    for zero_first in (True, False):
+        gk1, gv1 = torch.full(wk.shape, 2.0, device=device), torch.full(wv.shape, -3.0, device=device)
+        gk2, gv2 = gk1.clone(), gv1.clone()
+        tokens.dwconv_wgrad_pair(k_in, v_in, dk, dv, geom, gk1, gv1, zero_first=zero_first, zero_first2=not zero_first)
+        tokens.dwconv_wgrad(k_in, dk, geom, gk2, zero_first=zero_first)
+        tokens.dwconv_wgrad(v_in, dv, geom, gv2, zero_first=not zero_first)
+        assert torch.equal(gk1, gk2) and torch.equal(gv1, gv2)
+
+
 def check_token_pool(device, B, C, thw, stride, seed=0):
     g = torch.Generator().manual_seed(seed)
     T, H, W = thw
