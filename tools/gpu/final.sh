@@ -1,7 +1,7 @@
 #!/bin/bash
 # evidence visit: full GPU suite, smoke, default bench line, kernel stats + queue timeline + HBM-traffic PMC passes of the
-# bench command for both headline models, all presets.  Usage: ROUND=6 bash tools/gpu/final.sh [tag] [noprof]
-cd "$GRAFT_REPO_ROOT"; TAG=${1:-final}; D=gpurun_out/$TAG; mkdir -p $D; export TMPDIR=/tmp PYTHONPATH=$PWD
+# bench command for both headline models, all presets.  Usage: ROUND=6 bash tools/gpu/final.sh [tag] [noprof]  ->  gpurun_out/r6_<tag>/ (files r6_<tag>_*)
+cd "$GRAFT_REPO_ROOT"; TAG=${1:-final}; D=gpurun_out/r${ROUND:-6}_$TAG; mkdir -p $D; export TMPDIR=/tmp PYTHONPATH=$PWD
 R=$GRAFT_REPO_ROOT
 rm -f $D/parity_report.jsonl
 SF_PARITY_REPORT=$R/$D/parity_report.jsonl timeout 2400 python -m pytest tests -q -m gpu --tb=short > $D/pytest_gpu.log 2>&1; echo "pytest gpu rc=$?"; grep -E "passed|failed|FAILED|Error" $D/pytest_gpu.log | tail -6 | cut -c1-300
