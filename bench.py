@@ -330,7 +330,8 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
     # pathway / branch streams off (engine.run_pathways / run_branches), i.e. without RCCL's kernels sharing the chip with a
     # two-queue backward.
     multi = None
-    if world > 1 and not a.dry_run_cpu:
+    # (SF_BENCH_ATTRIB=1 runs the same block on one GPU: the only way to exercise it on a one-GPU box)
+    if (world > 1 or os.environ.get("SF_BENCH_ATTRIB") == "1") and not a.dry_run_cpu:
         from slowfast_amd import engine as _eng
         multi = {"overlap_log": list(train_step.overlap_log)[-steps:], "segments": len(getattr(train_step, "_seg_params", []) or []),
                  "buckets": len(reducer.buckets)}
@@ -348,11 +349,14 @@ def run_preset(a, preset, batch, steps, warmup, rank, local, world, dev, kernel_
             fence()
             d1 = time.perf_counter() - t1
             tt = torch.tensor([d1], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             multi["one_stream"] = {"ms_per_step": round(float(tt.item()) / steps * 1e3, 3),
                                    "overlap_log": list(ts1.overlap_log)[-steps:],
                                    "note": "SF_PATHWAY_STREAMS=0 SF_BRANCH_STREAMS=0 equivalent, same process, after the timed region"}
             del ts1
+        except Exception as e:      # an attribution aid must never take the measurement down with it (same code on every rank)
+            multi["one_stream"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         finally:
             _eng.PATHWAY_STREAMS, _eng.BRANCH_STREAMS = keep
 

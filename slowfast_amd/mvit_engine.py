@@ -148,6 +148,8 @@ class LinearUnit:
             dw, zero_first = _grad_dest(lin.weight)
             tokens.linear_wgrad(x, dy, dw, zero_first=zero_first)
         if lin.bias is not None and lin.bias.requires_grad and not bias_done:
+            # (the stand-alone bias pass -- the qkv Linear's: d(qkv) is written by three pooling kernels -- on a second stream beside
+            # these GEMMs costs more in fork / join than the 40 us it hides: 729.9 -> 725.3 clips/s, profiles/r6_v30_bias_side_ab.txt)
             db, zero_first = _grad_dest(lin.bias)
             tokens.bias_grad(dy, db, accumulate=not zero_first)
         if not need_dx:
