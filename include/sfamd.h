@@ -281,6 +281,11 @@ int sf_dwconv_fwd_sample_rows(const sf_dw_desc* d);
 /* stat_part (optional): [blocks][2][C] per-block sum / sum of squares of the outputs (BatchNorm statistics) */
 int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w, void* y, float* stat_part, sf_stream_t stream);
 int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float* w, void* dx, sf_stream_t stream);
+/* ... that also leaves the per-workgroup column sums of dx (cls row included) in slot 0 of sum_part[sf_dwconv_dgrad_sum_rows(d)][2][C]
+ * (slot 1 unspecified); rows == 0: the kernel this geometry takes cannot.  MViT's qkv bias gradient = the column sums of d(qkv),
+ * which the three pooling data gradients write (attention.py:318-330) (ABI 23) */
+int sf_dwconv_dgrad_sum_rows(const sf_dw_desc* d);
+int sf_dwconv_dgrad_sums(const sf_dw_desc* d, const void* dy, const float* w, void* dx, float* sum_part, sf_stream_t stream);
 int64_t sf_dwconv_wgrad_workspace(const sf_dw_desc* d);
 int sf_dwconv_wgrad(const sf_dw_desc* d, const void* x, const void* dy, float* dw, float out_scale, int zero_first,
                     void* workspace, int64_t workspace_bytes, sf_stream_t stream);

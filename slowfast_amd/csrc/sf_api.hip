@@ -1824,7 +1824,7 @@ static void dwsweep_launch(DwSweepParams& p, int kmode, int ks, bool stats, hipS
     if (kmode == 0) {
         if (ks == 1) { if (stats) SF_DWS_LAUNCH(0, 1, true); else SF_DWS_LAUNCH(0, 1, false); }
         else { if (stats) SF_DWS_LAUNCH(0, 2, true); else SF_DWS_LAUNCH(0, 2, false); }
-    } else if (kmode == 1) SF_DWS_LAUNCH(1, 2, false);
+    } else if (kmode == 1) { if (stats) SF_DWS_LAUNCH(1, 2, true); else SF_DWS_LAUNCH(1, 2, false); }
     else if (ks == 1) SF_DWS_LAUNCH(2, 1, false);
     else SF_DWS_LAUNCH(2, 2, false);
 #undef SF_DWS_LAUNCH
@@ -1956,7 +1956,38 @@ extern "C" int sf_dwconv_fwd(const sf_dw_desc* d, const void* x, const float* w,
     }
     return check_launch("dwconv_fwd");
 }
+// rows of the optional column-sum table of sf_dwconv_dgrad_sums ([rows][2][C]: slot 0 = per-workgroup column sums of dx, the
+// cls row included; slot 1 unspecified), 0 when the kernel this geometry takes cannot leave them
+static int dw_dgrad_sum_rows(const sf_dw_desc* d) {
+    DwTempParams tp;
+    if (dwtemp_plan(d, 1, tp)) return 0;
+    DwSweepParams sp;
+    int km, ks, sl;
+    if (dwrot_plan(d, 1, sp, km, ks, sl) || dwsweep_plan(d, 1, sp, km, ks)) return sp.N * sp.tiles_h * sp.tiles_w;
+    return 0;
+}
+extern "C" int sf_dwconv_dgrad_sum_rows(const sf_dw_desc* d) {
+    DwParams p;
+    dim3 grid;
+    if (fill_dw(p, d, false, 8192, grid)) return -1;
+    return dw_dgrad_sum_rows(d);
+}
+static int dwconv_dgrad_impl(const sf_dw_desc* d, const void* dy, const float* w, void* dx, float* sum_part, sf_stream_t stream);
 extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float* w, void* dx, sf_stream_t stream) {
+    return dwconv_dgrad_impl(d, dy, w, dx, nullptr, stream);
+}
+// sf_dwconv_dgrad that also leaves the column sums of dx: MViT's qkv Linear takes its bias gradient (the column sums of d(qkv),
+// attention.py:318-330) from the three pooling data gradients that write d(qkv) instead of from a pass over it
+extern "C" int sf_dwconv_dgrad_sums(const sf_dw_desc* d, const void* dy, const float* w, void* dx, float* sum_part,
+                                    sf_stream_t stream) {
+    REQUIRE(sum_part, "sf_dwconv_dgrad_sums: null table");
+    DwParams p;
+    dim3 grid;
+    if (fill_dw(p, d, false, 8192, grid)) return -1;
+    REQUIRE(dw_dgrad_sum_rows(d) > 0, "sf_dwconv_dgrad_sums: this geometry leaves no column sums (sf_dwconv_dgrad_sum_rows == 0)");
+    return dwconv_dgrad_impl(d, dy, w, dx, sum_part, stream);
+}
+static int dwconv_dgrad_impl(const sf_dw_desc* d, const void* dy, const float* w, void* dx, float* sum_part, sf_stream_t stream) {
     DwParams p;
     dim3 grid;
     if (fill_dw(p, d, false, 8192, grid)) return -1;
@@ -1973,13 +2004,13 @@ extern "C" int sf_dwconv_dgrad(const sf_dw_desc* d, const void* dy, const float*
         DwSweepParams sp;
         int km, ks, sl;
         if (dwrot_plan(d, 1, sp, km, ks, sl)) {
-            sp.a = (const f16*)dy; sp.lda = d->ldy; sp.dst = (f16*)dx; sp.ldd = d->ldx; sp.w = w;
-            dwrot_launch(sp, km, ks, sl, false, (hipStream_t)stream);
+            sp.a = (const f16*)dy; sp.lda = d->ldy; sp.dst = (f16*)dx; sp.ldd = d->ldx; sp.w = w; sp.part = sum_part;
+            dwrot_launch(sp, km, ks, sl, sum_part != nullptr, (hipStream_t)stream);
             return check_launch("dwconv_dgrad (rot)");
         }
         if (dwsweep_plan(d, 1, sp, km, ks)) {
-            sp.a = (const f16*)dy; sp.lda = d->ldy; sp.dst = (f16*)dx; sp.ldd = d->ldx; sp.w = w;
-            dwsweep_launch(sp, km, ks, false, (hipStream_t)stream);
+            sp.a = (const f16*)dy; sp.lda = d->ldy; sp.dst = (f16*)dx; sp.ldd = d->ldx; sp.w = w; sp.part = sum_part;
+            dwsweep_launch(sp, km, ks, sum_part != nullptr, (hipStream_t)stream);
             return check_launch("dwconv_dgrad (sweep)");
         }
         const char* lv = getenv("SF_DW_SWEEP");

@@ -423,6 +423,15 @@ __global__ __launch_bounds__(SF_THREADS, 2) void sf_dwsweep_kernel(DwSweepParams
                             *reinterpret_cast<dws_x4*>(d1) = v10;
                             if (col1) *reinterpret_cast<dws_x4*>(d1 + p.ldd) = v11;
                         }
+                        if constexpr (STATS) {          // column sums of dx (the bias gradient of the Linear that produced x)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float a = o00[e];
+                                if (col1) a += o01[e];
+                                if (row1) { a += o10[e]; if (col1) a += o11[e]; }
+                                ssum[e] += a;
+                            }
+                        }
                     }
                 };
                 load2(D0, cs);
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void sf_dwsweep_kernel(DwSweepParams
     }
 
     // ---- epilogues: fold the 32 lanes (8 row slots x 4 waves) that share a channel quad, fixed order
-    if constexpr (MODE == 0 && STATS) {
+    if constexpr (MODE != 2 && STATS) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);
 #pragma unroll

@@ -144,6 +144,8 @@ _SIGNATURES = {
     "sf_dwconv_wgrad_pair": (c_int, [POINTER(DwDesc), _P, _P, _P, _P, _F, _F, c_float, c_int, c_int, _P, c_int64, _P]),
     "sf_dwconv_fwd": (c_int, [POINTER(DwDesc), _P, _F, _P, _F, _P]),
     "sf_dwconv_dgrad": (c_int, [POINTER(DwDesc), _P, _F, _P, _P]),
+    "sf_dwconv_dgrad_sum_rows": (c_int, [POINTER(DwDesc)]),
+    "sf_dwconv_dgrad_sums": (c_int, [POINTER(DwDesc), _P, _F, _P, _F, _P]),
     "sf_dwconv_wgrad_workspace": (c_int64, [POINTER(DwDesc)]),
     "sf_dwconv_wgrad": (c_int, [POINTER(DwDesc), _P, _P, _F, c_float, c_int, _P, c_int64, _P]),
     "sf_relpos_gather": (c_int, [POINTER(AttnDesc), _P, c_int32, _P, _P, _P, _F, _P]),

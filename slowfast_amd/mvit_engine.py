@@ -29,6 +29,9 @@ _f16 = _sflib.act_dtype()        # fp16, or bf16 under SF_ACT_DTYPE=bf16 (lib.AC
 # chain on a second stream (engine.run_branches) and one 768-workgroup launch disturbs it more than two of 384.  So: "auto" =
 # paired only in blocks without a q pooling branch; SF_PAIR_KV=1 always, 0 never (A/B runs).
 PAIR_KV = os.environ.get("SF_PAIR_KV", "auto")
+# SF_BIAS_FROM_POOL=0: the qkv bias gradient from a pass over d(qkv) (sf_colsum) instead of from the column sums the pooling data
+# gradients leave (A/B runs; profiles/r6_v31_bias_from_pool_ab.txt)
+BIAS_FROM_POOL = os.environ.get("SF_BIAS_FROM_POOL", "1") != "0"
 
 
 def _pair_kv(plan):
@@ -75,6 +78,21 @@ def _sum_side(src, B, N, C, full, device):
         return (1, src.full32 if src is not None else None, dst), ResidSide(full32=dst)
     dst = torch.empty((B, C), dtype=torch.float32, device=device)
     return (N, src.cls_rows() if src is not None else None, dst), ResidSide(cls32=dst)
+
+
+def _bias_from_parts(dy, db, accumulate, parts):
+    """db (+)= column sums of dy [.., n * C]: slice i from ``parts[i]`` ([rows, 2, C] tables whose slot 0 holds partial column sums,
+    tokens.dwconv_dgrad(sums=True)) where given, from a pass over that slice (sf_colsum) otherwise."""
+    if not parts or all(p is None for p in parts):
+        tokens.bias_grad(dy, db, accumulate=accumulate)
+        return
+    C = dy.shape[-1] // len(parts)
+    for i, part in enumerate(parts):
+        dst = db[i * C:(i + 1) * C]
+        if part is None:
+            tokens.bias_grad(dy[..., i * C:(i + 1) * C], dst, accumulate=accumulate)
+        else:
+            tokens.colsum_finalize(part, C, C, dst, None, 1.0, accumulate)
 
 
 class LinearUnit:
@@ -151,7 +169,7 @@ class LinearUnit:
             # (the stand-alone bias pass -- the qkv Linear's: d(qkv) is written by three pooling kernels -- on a second stream beside
             # these GEMMs costs more in fork / join than the 40 us it hides: 729.9 -> 725.3 clips/s, profiles/r6_v30_bias_side_ab.txt)
             db, zero_first = _grad_dest(lin.bias)
-            tokens.bias_grad(dy, db, accumulate=not zero_first)
+            _bias_from_parts(dy, db, not zero_first, getattr(dy, "_sf_bias_parts", None))
         if not need_dx:
             return None
         _, wt = self._ops()
@@ -204,7 +222,8 @@ class QKVUnit:
                 tokens.linear_wgrad(x, dy, dw, zero_first=zero_first)
             if lin.bias is not None and lin.bias.requires_grad:
                 db, zero_first = _grad_dest(lin.bias)
-                tokens.bias_grad(dy, db, accumulate=not zero_first)
+                parts = getattr(dqkv, "_sf_bias_parts", None)
+                _bias_from_parts(dy, db, not zero_first, None if parts is None else [parts[i]])
         _, wt = self._ops()
         return tokens.gemm(dqkv, wt)
 
@@ -479,9 +498,15 @@ def attention_backward(att, plan, qkv, sv, do):
     dqn, dkn, dvn, drq = _core_backward(att, plan, core, do, dq_out=dq_out, dkv_out=dkv_out, defer_rel=True)
     # LayerNorm(head_dim) and depthwise pooling backward.  Tensors that were not pooled skip both: their gradient is
     # (or is copied into) the matching slice of d(qkv).
+    # column sums of the slices of d(qkv) (= the qkv bias gradient) that the pooling data gradients leave as a by-product: taken by
+    # the qkv Linear's backward instead of a pass over d(qkv) (LinearUnit / QKVUnit.backward: dy._sf_bias_parts)
+    bias_parts = [None, None, None]
+
     def pool_back(i, dy, pool, geom):                        # depthwise pooling backward into slice i of d(qkv)
         x_in = qkv[..., i * C:(i + 1) * C]
-        tokens.dwconv_dgrad(dy.view(-1, C), pool.weight, geom, out=dqkv[..., i * C:(i + 1) * C])
+        res = tokens.dwconv_dgrad(dy.view(-1, C), pool.weight, geom, out=dqkv[..., i * C:(i + 1) * C], sums=BIAS_FROM_POOL)
+        if BIAS_FROM_POOL:
+            bias_parts[i] = res[1]
         dw, zero_first = _grad_dest(pool.weight)
         tokens.dwconv_wgrad(x_in, dy.view(-1, C), geom, dw, zero_first=zero_first)
 
@@ -525,6 +550,8 @@ def attention_backward(att, plan, qkv, sv, do):
         elif dkn.data_ptr() != dqkv[..., C:2 * C].data_ptr():
             dqkv[..., C:2 * C].copy_(dkn)
             dqkv[..., 2 * C:3 * C].copy_(dvn)
+    if any(bp is not None for bp in bias_parts):
+        dqkv._sf_bias_parts = bias_parts
     return dqkv
 
 

@@ -367,14 +367,25 @@ def dwconv_fwd(x, w, geom, out=None, stats=False):
     return (y, part) if stats else y
 
 
-def dwconv_dgrad(dy, w, geom, out=None):
+def dwconv_dgrad(dy, w, geom, out=None, sums=False):
+    """``sums``: returns (dx, part) -- part [rows, 2, C] fp32 whose slot 0 holds per-workgroup column sums of dx (cls row included;
+    take them with colsum_finalize), or None when the kernel this geometry runs on cannot leave them."""
     M, C, lddy = rows_pitch(dy)
     assert M == geom.rows_out and C == geom.C
     dx = torch.empty((geom.rows_in, C), dtype=_f16, device=dy.device) if out is None else out
     _, _, lddx = rows_pitch(dx)
-    _lib_call("sf_dwconv_dgrad", byref(geom.desc(lddx, lddy)), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), _stream(dy),
-              work=dict(bytes=2.0 * C * (geom.rows_in + geom.rows_out), flops=2.0 * geom.rows_out * C * geom.taps))
-    return dx
+    d = geom.desc(lddx, lddy)
+    work = dict(bytes=2.0 * C * (geom.rows_in + geom.rows_out), flops=2.0 * geom.rows_out * C * geom.taps)
+    if sums:
+        lib = get_lib()
+        rows = lib.call("sf_dwconv_dgrad_sum_rows", byref(d))
+        if rows > 0:
+            part = torch.empty((rows, 2, C), dtype=torch.float32, device=dy.device)
+            lib.call("sf_dwconv_dgrad_sums", byref(d), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), part.data_ptr(), _stream(dy),
+                     work=work)
+            return dx, part
+    _lib_call("sf_dwconv_dgrad", byref(d), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), _stream(dy), work=work)
+    return (dx, None) if sums else dx
 
 
 def dwconv_wgrad(x, dy, geom, dw, zero_first=True, out_scale=1.0):

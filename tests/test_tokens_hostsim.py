@@ -59,6 +59,21 @@ def test_dwconv_temporal(sim, monkeypatch):
     tc.check_dwconv(sim, 2, 1, 24, (6, 4, 4), (5, 1, 1), (1, 1, 1), cls=0)
 
 
+def test_dwconv_dgrad_leaves_column_sums(sim):
+    """sf_dwconv_dgrad_sums: the plane sweeps (stride 1: rotating body, stride 2: 2 x 2 block body) leave the column sums of dx, cls
+    row included -- what MViT's qkv bias gradient is taken from; strides >= 3 and other windows report no table (the caller falls
+    back to a pass).  The values are checked inside tc.check_dwconv for every geometry that has a table."""
+    import torch
+    from ctypes import byref
+    from slowfast_amd import lib, tokens
+    for stride, want in (((1, 1, 1), True), ((1, 2, 2), True), ((1, 4, 4), False)):
+        geom = tokens.DwGeom(2, 64, 32, (2, 8, 8), (3, 3, 3), stride, (1, 1, 1), 1)
+        rows = lib.get_lib().call("sf_dwconv_dgrad_sum_rows", byref(geom.desc(192, 64)))
+        assert (rows > 0) == want, (stride, rows)
+    tc.check_dwconv(sim, 2, 2, 32, (2, 8, 8), (3, 3, 3), (1, 2, 2), cls=1)
+    tc.check_dwconv(sim, 1, 2, 32, (3, 7, 7), (3, 3, 3), (1, 1, 1), cls=1)
+
+
 def test_dwconv_pair(sim, monkeypatch):
     """pool_k / pool_v in one launch per direction (sf_dwconv_*_pair; PAIR mode of the plane sweeps): strides 1 / 2 (the rotating-
     accumulator body and the stride-2 data-gradient body), two heads sharing each weight, cls rows, a forced ragged tiling."""

@@ -99,6 +99,12 @@ def check_dwconv(device, B, heads, Cw, thw, kernel, stride, cls, seed=0):
     tokens.dwconv_dgrad(_h(dy, device).view(-1, C), w.to(device), geom, out=dbig[..., C:2 * C])
     assert_close("dwconv dgrad", dbig[..., C:2 * C].float().cpu(), xr.grad, 2 * F16_EPS)
     assert float(dbig[..., :C].abs().max()) == 0.0 and float(dbig[..., 2 * C:].abs().max()) == 0.0
+    # ... and the column sums of dx the plane sweeps leave as a by-product (the qkv bias gradient of MViT), cls row included
+    dbig2 = torch.zeros((B, N, 3 * C), dtype=ACT, device=device)
+    _, spart = tokens.dwconv_dgrad(_h(dy, device).view(-1, C), w.to(device), geom, out=dbig2[..., C:2 * C], sums=True)
+    assert torch.equal(dbig2, dbig)
+    if spart is not None:
+        assert_close("dwconv dgrad column sums", spart[:, 0].sum(0).cpu(), xr.grad.reshape(-1, C).sum(0), 2e-3 * EPS_SCALE)
     dw = torch.full(w.shape, 5.0, device=device)
     tokens.dwconv_wgrad(xd, _h(dy, device).view(-1, C), geom, dw, zero_first=True)
     assert_close("dwconv wgrad", dw.cpu(), wr.grad, 1e-3 * EPS_SCALE)
