@@ -421,13 +421,26 @@ static StemPlan plan_stem(const sf_conv_desc* d) {
     s.ok = true;
     return s;
 }
+// SF_STEM_SLIDE (test hook, read per call): groups of 4 output frames a workgroup of the sliding Fast-stem forward walks; 0 = the
+// tile kernel.  profiles/r6_v34_stem_slide_ab.txt
+#define SF_STEM_SLIDE_GROUPS 4
 // patch-row-major variants for the two shapes that matter (row stride / kernel height compile-time), generic loop otherwise;
 // SF_STEM_ROWMAJOR=0 keeps the generic loop for A/B runs
 #define SF_STEM_FWD_LAUNCH(sp, q, stream)                                                                                          \
     do {                                                                                                                          \
         static const bool rm_ = tune_knob("SF_STEM_ROWMAJOR", 1) != 0;                           \
         const dim3 g_((sp).ntiles), b_(SF_THREADS);                                                                               \
-        if (rm_ && (q).sH == 2 && (q).kH == 7 && !(sp).small)                                                                     \
+        const int sg_ = test_hook("SF_STEM_SLIDE", SF_STEM_SLIDE_GROUPS);                                                         \
+        if (rm_ && sg_ > 0 && (q).sH == 2 && (q).kH == 7 && !(sp).small && (q).sT == 1 && (q).kT > 1 && (q).kT <= 5 &&            \
+            (q).Co <= 8 && !(q).bnb_y) {                                                                                                         \
+            StemParams qs_ = (q);                   /* a workgroup walks sg_ groups of 4 output frames (sf_stem_fwd_slide_kernel) */ \
+            qs_.seg_groups = sg_ < (sp).tiles_t ? sg_ : (sp).tiles_t;                                                             \
+            qs_.tiles_t = cdiv((sp).tiles_t, qs_.seg_groups);                                                                     \
+            qs_.fd_tt = make_fastdiv(qs_.tiles_t);                                                                                \
+            const dim3 gs_((unsigned)((int64_t)(q).N * qs_.tiles_t * (sp).tiles_h * (sp).tiles_w));                                \
+            if (test_hook("SF_TRACE", 0)) fprintf(stderr, "[sfamd] stem_fwd_slide: %u runs of %d groups\n", gs_.x, qs_.seg_groups); \
+            hipLaunchKernelGGL((sf_stem_fwd_slide_kernel<2, 7>), gs_, b_, 0, (hipStream_t)(stream), qs_);                         \
+        } else if (rm_ && (q).sH == 2 && (q).kH == 7 && !(sp).small)                                                              \
             hipLaunchKernelGGL((sf_stem_fwd_kernel<SF_STEM_CHUNKS, 2, 7>), g_, b_, 0, (hipStream_t)(stream), q);                  \
         else if (rm_ && (q).sH == 1 && (q).kH == 3 && (sp).small)                                                                 \
             hipLaunchKernelGGL((sf_stem_fwd_kernel<SF_STEM_CHUNKS_SMALL, 1, 3>), g_, b_, 0, (hipStream_t)(stream), q);            \

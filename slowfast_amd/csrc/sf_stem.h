@@ -61,6 +61,7 @@ struct StemParams {
     int tiles_per_block;
     int wgroups;                      // > 1 (few slices): wave w works on slice w % nsl for the tile rows of group w / nsl; one slab per group
     int plain_order;                  // weight gradient: 1 = workgroup b takes tile run b (SF_STEM_XCD=0, A/B); 0 = XCD-contiguous
+    int seg_groups;                   // sliding forward: groups of SF_STEM_TT output frames a workgroup walks (tiles_t counts the runs)
 };
 
 struct StemTile { int n, t0, h0, w0; };
@@ -228,6 +229,177 @@ __global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_kernel(StemParams p) {
             // the table has one row per 128 output positions: rows no workgroup owns must read as zero
             for (int64_t row = (int64_t)bid + gridDim.x; row < p.stat_rows; row += gridDim.x)
                 p.stat_part[(row * 2 + which) * p.Co + co] = 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, SLIDING over T with TWO output frames per MFMA (round 6; sT == 1, 1 < kT <= 5, Co <= 8: the Fast pathway's stem).
+// The tile kernel above stages (TT - 1) sT + kT = 8 input frames for 4 output frames: every input frame goes through LDS twice (1.28 GB
+// of patch loads per launch at batch 32 for a 0.31 GB clip), each 16-byte chunk with its own div / mod addressing, and its MFMAs use 8
+// of their 16 rows.  Here
+//   * a workgroup owns an (8 rows x 16 pixels) column of the output and WALKS a run of `seg_groups` groups of 4 output frames: the 8
+//     frame slots are a ring (input frame j of the run lives in slot j & 7), a step stages only its 4 new frames -- requested BEFORE
+//     the step's MFMAs, written into the slots the step retires after them -- and a thread's two chunk offsets inside a frame are
+//     computed once per run;
+//   * wave w owns output frames A = 2 (w & 1), A + 1 of the step and rows 4 (w >> 1) .. + 3 of the tile: MFMA rows 0-7 carry the
+//     weights of tap kt = jj for frame A, rows 8-15 those of tap kt = jj - 1 for frame A + 1, both against input frame A + jj:
+//     kT + 1 = 6 frame passes per 2 output frames instead of 2 kT = 10 (168 MFMAs and 78 ds_read_b128 per wave and step, 280 / 105
+//     before);
+//   * the weight slices of the next pass are requested before the MFMAs of the current one.
+template <int SH, int KH>
+__global__ __launch_bounds__(SF_THREADS) void sf_stem_fwd_slide_kernel(StemParams p) {
+    constexpr int PRC = (SF_STEM_TH - 1) * SH + KH;                // patch rows of a frame
+    constexpr int FCH = PRC * SF_STEM_PC;                          // chunks of a frame
+    constexpr int LPF = (FCH + SF_THREADS - 1) / SF_THREADS;       // chunks of a frame per thread
+    constexpr int NEWF = SF_STEM_TT;                               // frames a step adds
+    constexpr int RH = SF_STEM_TH / 2;                             // output rows of a wave
+    constexpr int WR = (RH - 1) * SH + KH;                         // patch rows of a wave's window
+    static_assert(8 * FCH <= SF_STEM_CHUNKS, "the ring is the tile kernel's patch");
+    static_assert(SF_STEM_TT == 4 && SF_THREADS == 256, "4 waves = 2 frame pairs x 2 row halves");
+    __shared__ __attribute__((aligned(16))) f16 ring[8 * FCH * 8];
+    __shared__ float s_red[8][2][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g4 = lane >> 4;
+    const int fp = wave & 1, rh = wave >> 1;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const StemTile t = stem_tile(p, bid);                          // t.t0 / TT = the run
+    const int t_begin = (t.t0 / SF_STEM_TT) * p.seg_groups * SF_STEM_TT;
+    const int t_end = t_begin + p.seg_groups * SF_STEM_TT < p.To ? t_begin + p.seg_groups * SF_STEM_TT : p.To;
+    const int G = (t_end - t_begin + SF_STEM_TT - 1) / SF_STEM_TT;
+
+    int coff[LPF];
+    bool cok[LPF];
+    {
+        const int hin0 = t.h0 * SH - p.pH, win0 = t.w0 - p.pW;
+#pragma unroll
+        for (int u = 0; u < LPF; ++u) {
+            const int c = tid + SF_THREADS * u;
+            const int r = c / SF_STEM_PC, col = c - r * SF_STEM_PC;
+            const int hin = hin0 + r, win = win0 + col;
+            cok[u] = c < FCH && (unsigned)hin < (unsigned)p.Hi && (unsigned)win < (unsigned)p.Wi;
+            coff[u] = cok[u] ? (hin * p.Wi + win) * p.ldx : 0;
+        }
+    }
+    const int64_t fstride = (int64_t)p.Hi * p.Wi * p.ldx;
+    const f16* xn = p.x + (int64_t)t.n * p.Ti * fstride;
+    const int tin0 = t_begin - p.pT;                               // input frame of ring index 0 (sT == 1)
+    f16x8 nv[NEWF][LPF];
+    // request ring frames j0 .. j0 + NEWF - 1 / write them to their slots
+    auto request = [&](int j0) {
+#pragma unroll
+        for (int f = 0; f < NEWF; ++f) {
+            const int tin = tin0 + j0 + f;
+            const f16* xf = xn + ((unsigned)tin < (unsigned)p.Ti ? tin * fstride : 0);
+#pragma unroll
+            for (int u = 0; u < LPF; ++u) nv[f][u] = ld16(xf + coff[u]);
+        }
+    };
+    auto deposit = [&](int j0) {
+#pragma unroll
+        for (int f = 0; f < NEWF; ++f) {
+            const bool tok = (unsigned)(tin0 + j0 + f) < (unsigned)p.Ti;
+            f16* slot = ring + ((j0 + f) & 7) * (FCH * 8);
+#pragma unroll
+            for (int u = 0; u < LPF; ++u) {
+                const int c = tid + SF_THREADS * u;
+                if (c < FCH) st16(slot + c * 8, tok && cok[u] ? nv[f][u] : zero8());
+            }
+        }
+    };
+    request(0);
+    deposit(0);
+    request(NEWF);
+    deposit(NEWF);
+
+    // A operand of lane (pl, g4): MFMA row pl = (frame pl >> 3 of the pair, channel pl & 7), k chunk g4; pass jj -> tap jj - (pl >> 3)
+    const int which = pl >> 3, co = pl & 7;
+    const bool co_ok = co < p.Co && g4 < p.kwc;
+    const f16* wrow = p.wmat + (co_ok ? (int64_t)co * p.ldw + p.wo0 + p.wog * g4 : 0);
+    f16x8 wc[KH], wn[KH];
+    auto load_w = [&](int jj, f16x8* w) {
+        const int kt = jj - which;
+        const bool ok = co_ok && kt >= 0 && kt < p.kT;
+        const f16* wp = wrow + (ok ? kt * KH * p.wos : 0);
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            const f16x8 v = ld16(wp + kh * p.wos);
+            w[kh] = ok ? v : zero8();
+        }
+    };
+    load_w(0, wc);
+    // D of lane (pl, g4): rows 4 g4 .. + 3 = frame g4 >> 1 of the pair, channels 4 (g4 & 1) .. + 3, pixel w0 + pl
+    const int wo = t.w0 + pl, c4 = 4 * (g4 & 1);
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && c4 < p.Co) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4[r] = p.bias[c4 + r];
+    }
+    const float lo = p.out_relu ? 0.f : -INFINITY;
+
+    for (int g = 0; g < G; ++g) {
+        const bool more = g + 1 < G;
+        if (more) request(NEWF * (g + 2));
+        __syncthreads();                                           // the slots of this step are written
+        f32x4 acc[RH];
+#pragma unroll
+        for (int i = 0; i < RH; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int jj = 0; jj <= p.kT; ++jj) {
+            load_w(jj < p.kT ? jj + 1 : 0, wn);
+            const f16* base = ring + ((((NEWF * g + 2 * fp + jj) & 7) * PRC + RH * SH * rh) * SF_STEM_PC + pl + g4) * 8;
+#pragma unroll
+            for (int r = 0; r < WR; ++r) {
+                const f16x8 px = ld16(base + r * (SF_STEM_PC * 8));
+#pragma unroll
+                for (int kh = r % SH; kh < KH; kh += SH) {
+                    const int i = (r - kh) / SH;                        // compile-time after unrolling
+                    if (r >= kh && i < RH) acc[i] = SF_MFMA16(wc[kh], px, acc[i]);
+                }
+            }
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) wc[kh] = wn[kh];
+        }
+        const int to = t_begin + SF_STEM_TT * g + 2 * fp + (g4 >> 1);
+#pragma unroll
+        for (int i = 0; i < RH; ++i) {
+            const int ho = t.h0 + RH * rh + i;
+            if (to < t_end && ho < p.Ho && wo < p.Wo && c4 < p.Co) {
+                const int64_t m = (((int64_t)t.n * p.To + to) * p.Ho + ho) * p.Wo + wo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s4[r] += acc[i][r]; q4[r] += acc[i][r] * acc[i][r]; }
+                *reinterpret_cast<f16x4*>(p.y + m * p.ldy + c4) =
+                    (f16x4){(f16)fmaxf(acc[i][0] + b4[0], lo), (f16)fmaxf(acc[i][1] + b4[1], lo),
+                            (f16)fmaxf(acc[i][2] + b4[2], lo), (f16)fmaxf(acc[i][3] + b4[3], lo)};
+            }
+        }
+        if (more) {
+            __syncthreads();                                       // every wave is done with the slots this step retires
+            deposit(NEWF * (g + 2));
+        }
+    }
+    if (p.stat_part) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int mask = 1; mask < 16; mask <<= 1) {
+                s4[r] += __shfl_xor(s4[r], mask);
+                q4[r] += __shfl_xor(q4[r], mask);
+            }
+            if (pl == 0) {
+                s_red[2 * wave + (g4 >> 1)][0][c4 + r] = s4[r];
+                s_red[2 * wave + (g4 >> 1)][1][c4 + r] = q4[r];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * p.Co) {
+            const int wh = tid / p.Co, ch = tid % p.Co;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += s_red[k][wh][ch];
+            p.stat_part[((int64_t)bid * 2 + wh) * p.Co + ch] = v;
+            for (int64_t row = (int64_t)bid + gridDim.x; row < p.stat_rows; row += gridDim.x)
+                p.stat_part[(row * 2 + wh) * p.Co + ch] = 0.f;
         }
     }
 }

@@ -48,6 +48,20 @@ def test_stem_direct_fwd(sim, case):
     kc.check_conv_fwd(sim, *case, Cw=8)
 
 
+@pytest.mark.parametrize("groups", [8, 3, 2, 1, 0])
+def test_stem_fwd_sliding_ring(sim, monkeypatch, capfd, groups):
+    """Fast-stem forward on the sliding kernel (sf_stem_fwd_slide_kernel): 14 frames = 3.5 groups of 4, so the 8-slot frame ring wraps
+    and the last group is ragged; a workgroup walks the whole clip (8), runs of 3 + 1 groups, single groups, or the tile kernel (0).
+    Output and the BatchNorm statistics table against F.conv3d in every split."""
+    monkeypatch.setenv("SF_STEM_SLIDE", str(groups))
+    monkeypatch.setenv("SF_TRACE", "1")
+    kc.check_conv_fwd(sim, (2, 8, 14, 36, 22), 8, (5, 7, 4), (1, 2, 1), (2, 3, 2), Cw=8)
+    if groups == 2:        # bias + ReLU epilogue (the eval-mode stem)
+        kc.check_conv_fwd_fused(sim, (1, 8, 9, 20, 20), 8, (5, 7, 4), (1, 2, 1), (2, 3, 2))
+    err = capfd.readouterr().err
+    assert ("stem_fwd_slide" in err) == (groups > 0), err
+
+
 @pytest.mark.parametrize("case", STEM_CASES)
 def test_stem_direct_wgrad(sim, case):
     kc.check_conv_wgrad(sim, *case, Cw=8)
