@@ -160,9 +160,10 @@ int sf_bn_bwd_apply(int64_t M, int32_t C, const void* dz, int32_t lddz, const vo
 int sf_pool_fwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kH, int32_t kW, int32_t sH, int32_t sW,
                 int32_t pH, int32_t pW, const void* y, int32_t ldy, const float* scale, const float* shift, int relu,
                 void* out, int32_t ldo, void* argmax, int32_t cls, sf_stream_t stream);
-/* g[N,T,H,W,C] = gradient w.r.t. the BatchNorm output (pool + ReLU backward) from the forward's pooled output
- * (ReLU mask: pooled > 0) and its byte argmax table [N,T,Ho,Wo][C] (window-local index kh*kW+kw of the first
- * maximum, as recorded by torch's max_pool3d) */
+/* g[N,T,H,W,C] = gradient w.r.t. the BatchNorm output (pool + ReLU backward) from the forward's byte argmax table
+ * [N,T,Ho,Wo][C] (window-local index kh*kW+kw of the first maximum, as recorded by torch's max_pool3d; with relu, 0xFF for a
+ * window whose maximum is not positive -- the ReLU mask `pooled > 0` -- written by sf_pool_fwd(relu = 1), kH*kW <= 255).
+ * `pooled` / `ldp` are kept in the signature and not read (round 6); `relu` must be the forward's. */
 int sf_pool_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kH, int32_t kW, int32_t sH, int32_t sW,
                 int32_t pH, int32_t pW, const void* pooled, int32_t ldp, const void* argmax, int relu,
                 const void* dout, int32_t lddo, void* g, int32_t ldg, int32_t cls, sf_stream_t stream);

@@ -97,6 +97,12 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
         const int64_t orow = pool_row(p, nt, p.Ho, p.Wo, (int)ho, (int)wo);
         st16(p.out + orow * p.ldo + c, o);
         if (p.argmax) {
+            // ReLU in front of the pool: a window whose maximum is not positive passes no gradient -- recorded HERE as code 0xFF
+            // (no tap has it), so that the backward gathers read argmax + gradient only, not the pooled tensor (round 6)
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) arg[e] = best[e] > 0.f ? arg[e] : 0xFFu;
+            }
             u32x2 pk;
             pk.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
             pk.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_fwd_kernel(PoolParams p) {
 
 // Gather form of the max-pool(+ReLU) backward: one thread per (input position, 8 channels) visits the (at most
 // ceil(kH/sH)*ceil(kW/sW)) windows that cover it and takes a window's gradient iff the recorded argmax is this
-// position and the pooled value is positive (the ReLU in front of the pool passed it).
+// position (a window the ReLU in front of the pool did not pass carries code 0xFF: sf_pool_fwd_kernel).
 __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
     const int64_t ncls = p.cls ? (int64_t)p.N * (p.C >> 3) : 0;
     for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < p.total + ncls;
@@ -142,12 +148,10 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
                 const int64_t orow = pool_row(p, nt, p.Ho, p.Wo, ho, wo);
                 const u32x2 pk = *reinterpret_cast<const u32x2*>(p.argmax + orow * p.C + c);
                 const f16x8 d = ld16(p.dout + orow * p.lddo + c);
-                const f16x8 pv = ld16(p.pooled + orow * p.ldp + c);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const uint32_t a = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
-                    const bool take = (a == me) && (!p.relu || (float)pv[e] > 0.f);
-                    g[e] += take ? (float)d[e] : 0.f;
+                    g[e] += a == me ? (float)d[e] : 0.f;
                 }
             }
         }
@@ -160,7 +164,8 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd_kernel(PoolParams p) {
 
 // The same gather when at most TWO windows per dimension cover a position (kH <= 2 sH and kW <= 2 sW: every pooling layer of the
 // model zoo -- 3x3 / stride 2 stems and skip paths).  The four candidate windows' operands (argmax bytes, gradient, pooled value)
-// are requested TOGETHER, with clamped coordinates and validity as predicates: 12 loads in flight per thread.  The nested loops
+// are requested TOGETHER, with clamped coordinates and validity as predicates: 8 loads in flight per thread (round 6: the pooled
+// value is no longer read -- 40 % of the bytes a thread requested; the ReLU test lives in the argmax code).  The nested loops
 // above have runtime bounds, so every window was its own load -> wait -> combine trip, behind two runtime divisions (the stem
 // pool of SlowFast: 434 us for ~670 MB, round 5).  Same summation order (ho, then wo, ascending): bit-identical.
 __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd4_kernel(PoolParams p) {
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd4_kernel(PoolParams p) 
             woc[a] = wo < 0 ? 0 : (wo > p.Wo - 1 ? p.Wo - 1 : wo);
         }
         u32x2 pk[2][2];
-        f16x8 d[2][2], pv[2][2];
+        f16x8 d[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -204,7 +209,6 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd4_kernel(PoolParams p) 
                 const int64_t orow = pool_row(p, nt, p.Ho, p.Wo, hoc[a], woc[b]);
                 pk[a][b] = *reinterpret_cast<const u32x2*>(p.argmax + orow * p.C + c);
                 d[a][b] = ld16(p.dout + orow * p.lddo + c);
-                pv[a][b] = ld16(p.pooled + orow * p.ldp + c);
             }
         float g[8];
 #pragma unroll
@@ -218,8 +222,7 @@ __global__ __launch_bounds__(SF_THREADS) void sf_pool_bwd4_kernel(PoolParams p) 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const uint32_t am = ((e < 4 ? pk[a][b].x : pk[a][b].y) >> (8 * (e & 3))) & 0xffu;
-                    const bool take = on && (am == me) && (!p.relu || (float)pv[a][b][e] > 0.f);
-                    g[e] += take ? (float)d[a][b][e] : 0.f;
+                    g[e] += on && am == me ? (float)d[a][b][e] : 0.f;
                 }
             }
         f16x8 o;

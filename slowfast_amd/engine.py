@@ -715,7 +715,10 @@ class StemFn(torch.autograd.Function):
         assert k[0] == 1 and s[0] == 1 and p[0] == 0, "stem pooling is spatial-only in every reference config"
         out, arg = ops.pool_fwd(y, k[1:], s[1:], p[1:], affine=(st.scale, st.shift, True))
         if CAPTURE is not None:
-            CAPTURE.append({"kind": "stem", "mod": mod, "raw": [y], "bn": [(st.scale, st.shift)], "out": out, "argmax": arg})
+            # code 0xFF = a window the ReLU did not pass (every entry is 0 after it; sf_pool_fwd): any route is the true maximum and
+            # carries no gradient -> the checks are handed tap 0
+            CAPTURE.append({"kind": "stem", "mod": mod, "raw": [y], "bn": [(st.scale, st.shift)], "out": out,
+                            "argmax": torch.where(arg == 255, torch.zeros_like(arg), arg)})
         ctx.mod, ctx.xcl, ctx.y, ctx.st = mod, xcl, y, st
         ctx.pool = (tuple(k[1:]), tuple(s[1:]), tuple(p[1:]))
         ctx.pooled, ctx.arg = out, arg

@@ -452,7 +452,8 @@ def _pool_args(y, kernel, stride, padding):
 
 def pool_fwd(y, kernel, stride, padding, affine=None, want_argmax=True):
     """MaxPool over (H,W) of act(y), act = producer BN(+ReLU) from ``affine = (scale, shift, relu)``.
-    Returns (pooled, argmax): argmax = uint8 window-local index of the first maximum (for pool_bwd)."""
+    Returns (pooled, argmax): argmax = uint8 window-local index of the first maximum (for pool_bwd); with a ReLU in ``affine``,
+    0xFF marks a window whose maximum is not positive (it passes no gradient)."""
     args, (Ho, Wo) = _pool_args(y, kernel, stride, padding)
     N, C, T, H, W = y.shape
     out = cl_empty((N, C, T, Ho, Wo), y.device)
@@ -464,7 +465,8 @@ def pool_fwd(y, kernel, stride, padding, affine=None, want_argmax=True):
 
 
 def pool_bwd(in_shape, pooled, argmax, dout, kernel, stride, padding, relu=True):
-    """Gradient w.r.t. the BatchNorm output feeding relu -> max-pool (argmax gather + ReLU mask pooled > 0)."""
+    """Gradient w.r.t. the BatchNorm output feeding relu -> max-pool (argmax gather; the ReLU mask pooled > 0 is
+    the code 0xFF of the forward's table -- ``pooled`` itself is not read)."""
     N, C, T, H, W = in_shape
     (kH, kW), (sH, sW), (pH, pW) = kernel, stride, padding
     assert tuple(dout.shape) == tuple(pooled.shape)
