@@ -1177,6 +1177,13 @@ extern "C" int sf_pool3d_bwd(int32_t N, int32_t T, int32_t H, int32_t W, int32_t
 extern "C" int sf_ncthw_to_cl(const float* x, int32_t N, int32_t C, int64_t S, int32_t Cp, void* out,
                               sf_stream_t stream) {
     REQUIRE(x && out && (Cp % 8 == 0 || Cp == 4) && Cp >= C, "sf_ncthw_to_cl: bad arguments");
+    static const bool quad = test_hook("SF_LAYOUT_QUAD", 1) != 0;
+    if (quad && C <= 4 && Cp <= 8 && S % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {   // RGB clips: four positions per lane
+        const int grid = pool_grid((int64_t)N * (S / 4));
+        if (Cp == 4) hipLaunchKernelGGL(sf_ncthw_to_cl_quad_kernel<4>, dim3(grid), dim3(SF_THREADS), 0, (hipStream_t)stream, x, (f16*)out, N, C, S / 4);
+        else hipLaunchKernelGGL(sf_ncthw_to_cl_quad_kernel<8>, dim3(grid), dim3(SF_THREADS), 0, (hipStream_t)stream, x, (f16*)out, N, C, S / 4);
+        return check_launch("ncthw_to_cl");
+    }
     hipLaunchKernelGGL(sf_ncthw_to_cl_kernel, dim3(pool_grid((int64_t)N * S)), dim3(SF_THREADS), 0,
                        (hipStream_t)stream, x, (f16*)out, N, C, S, Cp);
     return check_launch("ncthw_to_cl");

@@ -335,6 +335,40 @@ __global__ __launch_bounds__(SF_THREADS) void sf_ncthw_to_cl_kernel(const float*
     }
 }
 
+// The same conversion for clips of at most 4 channels (every RGB input) when S is a multiple of 4: a lane owns FOUR consecutive
+// positions -- one 16-byte load per channel plane (a wave reads 1 KB of a plane per instruction instead of 256 B) and 32 (CP = 4)
+// or 64 (CP = 8) contiguous bytes of output.  Bit-identical to the kernel above (one fp32 -> 16-bit rounding per element).
+template <int CP>
+__global__ __launch_bounds__(SF_THREADS) void sf_ncthw_to_cl_quad_kernel(const float* x, f16* out, int N, int C, int64_t S4) {
+    const int64_t total = (int64_t)N * S4;
+    for (int64_t idx = (int64_t)blockIdx.x * SF_THREADS + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * SF_THREADS) {
+        const int64_t n = idx / S4, q = idx - n * S4;
+        const f32x4* src = reinterpret_cast<const f32x4*>(x) + (n * C) * S4 + q;
+        f32x4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = e < C ? src[e * S4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f16* dst = out + idx * (4 * CP);
+        if (CP == 4) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (f16)v[e][2 * h]; o[4 + e] = (f16)v[e][2 * h + 1]; }
+                st16(dst + 8 * h, o);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f16x8 o = zero8();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (f16)v[e][j];
+                st16(dst + 8 * j, o);
+            }
+        }
+    }
+}
+
 // channels-last fp16 (row pitch ld) -> NCTHW fp32
 __global__ __launch_bounds__(SF_THREADS) void sf_cl_to_ncthw_kernel(const f16* x, int ld, float* out, int N, int C,
                                                                     int64_t S) {

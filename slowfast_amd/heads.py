@@ -7,7 +7,43 @@ import torch
 import torch.nn as nn
 
 from . import engine, ops
+import os
+
 from .lib import get_lib
+
+# the training-crop average pool of ResNetBasicHead on sf_tmean_* (SF_HEAD_FUSED_MEAN=0: torch fp32 ops, the round 1-5 path)
+FUSED_MEAN = os.environ.get("SF_HEAD_FUSED_MEAN", "0") != "0"
+
+
+class _GlobalMeanFn(torch.autograd.Function):
+    """Mean over the whole (T, H, W) extent of a channels-last 16-bit activation -> (N, C, 1, 1, 1) fp32, on the temporal-mean
+    kernels of the RoI head (sf_tmean_fwd / sf_tmean_bwd) instead of `x.float().mean()`: the fp32 copy of the res5 output (and its
+    mirror image in backward: an fp32 broadcast that is then cast back) is never written.  The rows of a clip are read as
+    [k][rows / k] so that every thread sums k = 8 rows; the [N, rows / k, C] fp32 partial means are averaged by torch."""
+    K = 8
+
+    @staticmethod
+    def eligible(x):
+        return x.dim() == 5 and ops.is_cl(x) and x.shape[1] % 8 == 0 and (x.shape[2] * x.shape[3] * x.shape[4]) % _GlobalMeanFn.K == 0
+
+    @staticmethod
+    def forward(ctx, x):
+        N, C, T, H, W = x.shape
+        k, rows = _GlobalMeanFn.K, T * H * W
+        part = torch.empty((N * (rows // k), C), dtype=torch.float32, device=x.device)
+        get_lib().call("sf_tmean_fwd", N, k, rows // k, C, x.data_ptr(), ops.cl_ld(x), part.data_ptr(), ops._stream(x),
+                       work=dict(bytes=2.0 * x.numel()))
+        ctx.geom = (N, C, T, H, W)
+        return part.view(N, rows // k, C).mean(1).view(N, C, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, C, T, H, W = ctx.geom
+        dout = dout.reshape(N, C).float().contiguous()
+        dx = ops.cl_empty((N, C, T, H, W), dout.device)
+        get_lib().call("sf_tmean_bwd", N, T * H * W, 1, C, dout.data_ptr(), dx.data_ptr(), ops.cl_ld(dx), ops._stream(dout),
+                       work=dict(bytes=2.0 * dx.numel()))
+        return dx
 
 
 class ResNetBasicHead(nn.Module):
@@ -41,7 +77,9 @@ class ResNetBasicHead(nn.Module):
         for i, x in enumerate(inputs):
             pool = getattr(self, f"pathway{i}_avgpool")
             full = isinstance(pool, nn.AdaptiveAvgPool3d) or tuple(pool.kernel_size) == tuple(x.shape[2:])
-            if full and x.dim() == 5 and x.stride(1) == 1:
+            if full and _GlobalMeanFn.eligible(x) and FUSED_MEAN:
+                pooled.append(_GlobalMeanFn.apply(x))
+            elif full and x.dim() == 5 and x.stride(1) == 1:
                 # the pool window is the whole (T,H,W) extent (training crop): mean over the channels-last rows
                 N, C = x.shape[:2]
                 rows = x.permute(0, 2, 3, 4, 1).reshape(N, -1, C)

@@ -277,6 +277,26 @@ def check_pool(device, shape, seed=0):
     assert_close("pool_bwd", cl_to_host(gm), gref, 2 * F16_EPS)
 
 
+def check_head_mean(device, shape, seed=0):
+    """heads._GlobalMeanFn (sf_tmean_fwd as [8][rows / 8] partial means + sf_tmean_bwd as a broadcast) against the AvgPool3d over
+    the whole extent of the reference head (head_helper.py:293-300) on the same 16-bit operand: fp32 sums in another order."""
+    from slowfast_amd import heads
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g).to(ACT).float()
+    dout = torch.randn((shape[0], shape[1], 1, 1, 1), generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.avg_pool3d(xr, shape[2:], stride=1)
+    ref.backward(dout)
+    xc = host_to_cl(x, device).requires_grad_(True)
+    assert heads._GlobalMeanFn.eligible(xc)
+    out = heads._GlobalMeanFn.apply(xc)
+    assert out.dtype == torch.float32 and tuple(out.shape) == tuple(ref.shape)
+    out.backward(dout.to(device))
+    assert_close("head mean", out.detach().cpu(), ref.detach(), 1e-6)
+    assert ops.is_cl(xc.grad)
+    assert_close("head mean dx", cl_to_host(xc.grad), xr.grad.to(ACT).float(), F16_EPS)  # dout * (1 / rows) against dout / rows, rounded once
+
+
 def check_layout(device, shape, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(shape, generator=g)
@@ -286,6 +306,14 @@ def check_layout(device, shape, seed=0):
     assert float(cl_to_host(xc)[:, shape[1]:].abs().max()) == 0.0 if xc.shape[1] > shape[1] else True
     back = ops.cl_to_ncthw(xc)
     assert_close("cl_to_ncthw", back.cpu()[:, : shape[1]], x.to(ACT).float(), 1e-6)
+    if shape[1] <= 4 and shape[4] % 2 == 0:
+        # the W-pair-folded stem operand (Cp = 4): logical channel (w & 1) * 4 + c of column w / 2, bit-exact against the rounding
+        xw = cl_to_host(ops.ncthw_to_cl_wpairs(x.to(device)))                        # [N, 8, T, H, W / 2]
+        N, C, T, H, W = shape
+        ref = torch.zeros(N, 8, T, H, W // 2)
+        for par in range(2):
+            ref[:, par * 4: par * 4 + C] = x.to(ACT).float()[..., par::2]
+        assert torch.equal(xw, ref), "ncthw_to_cl_wpairs"
 
 
 def check_bn_finalize_long(device, nblk, C, seed=0):

@@ -183,9 +183,17 @@ def test_pool(gpu):
     kc.check_pool(gpu, (2, 64, 2, 56, 56))
 
 
+def test_head_mean(gpu):
+    kc.check_head_mean(gpu, (4, 2048, 8, 7, 7))
+    kc.check_head_mean(gpu, (4, 256, 32, 7, 7))
+    kc.check_head_mean(gpu, (2, 16, 2, 3, 4))
+
+
 def test_layout(gpu):
     kc.check_layout(gpu, (2, 3, 4, 32, 32))
     kc.check_layout(gpu, (1, 16, 1, 4, 4))
+    kc.check_layout(gpu, (3, 3, 2, 6, 10))       # S % 4 == 0, fewer positions than one workgroup
+    kc.check_layout(gpu, (2, 3, 3, 5, 5))        # S % 4 != 0: the one-position kernel
 
 
 def test_bn_finalize_long_tables(gpu):

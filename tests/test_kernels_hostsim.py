@@ -105,9 +105,16 @@ def test_pool(sim):
     kc.check_pool(sim, (2, 16, 1, 8, 8))
 
 
+def test_head_mean(sim):
+    kc.check_head_mean(sim, (2, 16, 2, 3, 4))
+    kc.check_head_mean(sim, (1, 8, 4, 2, 2))
+
+
 def test_layout(sim):
     kc.check_layout(sim, (2, 3, 2, 5, 5))
     kc.check_layout(sim, (1, 16, 1, 4, 4))
+    kc.check_layout(sim, (2, 3, 2, 4, 6))        # S % 4 == 0: four positions per lane (sf_ncthw_to_cl_quad_kernel)
+    kc.check_layout(sim, (1, 4, 1, 2, 2))
 
 
 def test_bn_finalize_long_tables(sim):
