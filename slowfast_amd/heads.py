@@ -12,7 +12,7 @@ import os
 from .lib import get_lib
 
 # the training-crop average pool of ResNetBasicHead on sf_tmean_* (SF_HEAD_FUSED_MEAN=0: torch fp32 ops, the round 1-5 path)
-FUSED_MEAN = os.environ.get("SF_HEAD_FUSED_MEAN", "0") != "0"
+FUSED_MEAN = os.environ.get("SF_HEAD_FUSED_MEAN", "1") != "0"
 
 
 class _GlobalMeanFn(torch.autograd.Function):
