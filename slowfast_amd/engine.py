@@ -151,6 +151,7 @@ def cut(x):
 # actually overlaps.  Works under graph capture too (the fork / join become graph edges).  OPT-IN (SF_WGRAD_STREAM=1): on
 # ROCm 7.2 a replayed hipGraph runs the two branches back to back -- measured 734 vs 735 clips/s on SlowFast, 523 vs 524
 # on MViTv2-S, 1166 vs 1175 on X3D-M (profiles/r2/r2_v15_wgrad_stream_ab.txt) -- so the default keeps the single stream.
+# Re-measured at the end of round 6 (profiles/r6_v43_wgrad_stream_ab.txt): X3D-M 1493 vs 1502, MViTv2-S 757 vs 758, SlowFast 825 vs 870.
 WGRAD_STREAM = os.environ.get("SF_WGRAD_STREAM", "0") != "0"
 _side_streams = {}
 _side_keep = []          # tensors the side stream still reads: kept alive until the join (no allocator stream bookkeeping)
